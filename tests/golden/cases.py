@@ -1,0 +1,104 @@
+"""Golden-case table shared by make_golden.py (runs the UNMODIFIED reference) and the tests.
+
+fixture: name -> generator parameters (genomics_general_amd.synth).  case: tool, argv (reference CLI
+syntax, with {geno} / {dir} placeholders), output file name."""
+
+FIXTURES = {
+    # BASELINE.json configs[0]: 10k sites (2 scaffolds x 5000), 8 diploids
+    "c1": dict(seed=20260925, n_dip=8, n_pops=2, scaf_len=[5000, 5000], density=1.0, var_thr=6554, miss_thr=3277, fmt="phased", sep="/"),
+    # sparse positions -> empty windows, gaps; 12 diploids / 3 pops; '|' separator
+    "sparse": dict(seed=20260926, n_dip=12, n_pops=3, scaf_len=[6000, 3000, 2500], density=0.25, var_thr=30000, miss_thr=6000, fmt="phased", sep="|", gap=(2000, 3700)),
+    # heavy missingness -> pairs below minSites, all-nan blocks
+    "holes": dict(seed=20260927, n_dip=6, n_pops=2, scaf_len=[3000], density=0.5, var_thr=40000, miss_thr=36000, fmt="phased", sep="/"),
+    # four populations for ABBA-BABA
+    "abba": dict(seed=20260928, n_dip=16, n_pops=4, scaf_len=[8000, 4000], density=0.6, var_thr=45000, miss_thr=5000, fmt="phased", sep="/"),
+    # same data as 'abba' rendered in the other genotype formats
+    "abba_pairs": dict(seed=20260928, n_dip=16, n_pops=4, scaf_len=[8000, 4000], density=0.6, var_thr=45000, miss_thr=5000, fmt="pairs", sep=""),
+    "abba_diplo": dict(seed=20260928, n_dip=16, n_pops=4, scaf_len=[8000, 4000], density=0.6, var_thr=45000, miss_thr=5000, fmt="diplo", sep=""),
+    # haploid cells
+    "haplo": dict(seed=20260929, n_dip=5, n_pops=2, scaf_len=[4000], density=0.5, var_thr=30000, miss_thr=4000, fmt="haplo", sep=""),
+}
+
+
+def pops_args(n_dip, n_pops, flag="-p"):
+    per = n_dip // n_pops
+    out = []
+    for k in range(n_pops):
+        out += [flag, "pop%d" % k, ",".join("s%d" % d for d in range(k * per, (k + 1) * per))]
+    return out
+
+
+def abba_args(n_dip):
+    per = n_dip // 4
+    out = []
+    for flag, k in (("-P1", 0), ("-P2", 1), ("-P3", 2), ("-O", 3)):
+        out += [flag, "pop%d" % k, ",".join("s%d" % d for d in range(k * per, (k + 1) * per))]
+    return out
+
+
+CASES = [
+    # ---- popgenWindows.py ----
+    dict(name="c1_popgen", tool="popgenWindows.py", fixture="c1",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "100"] + pops_args(8, 2)),
+    dict(name="c1_popgen_T2_round12", tool="popgenWindows.py", fixture="c1",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "100", "--roundTo", "12", "-T", "2"] + pops_args(8, 2)),
+    dict(name="c1_popgen_allpop", tool="popgenWindows.py", fixture="c1",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "2500", "-m", "50"]),
+    dict(name="sparse_overlap_failed_id", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "500", "-s", "250", "-m", "10", "--writeFailedWindows",
+               "--addWindowID", "--roundTo", "6"] + pops_args(12, 3)),
+    dict(name="sparse_stepgap", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "300", "-s", "700", "-m", "5", "--writeFailedWindows"] + pops_args(12, 3)),
+    dict(name="sparse_popfreq_indpair", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--analysis", "popFreq", "popDist", "popPairDist",
+               "indPairDist", "--roundTo", "8"] + pops_args(12, 3)),
+    dict(name="sparse_indpair_only", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1500", "-m", "20", "--analysis", "indPairDist", "--roundTo", "8",
+               "--samples", "s0,s1,s5,s9"]),
+    dict(name="sparse_sites_windows", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "200", "-O", "50", "-m", "100", "--roundTo", "8"] + pops_args(12, 3)),
+    dict(name="sparse_sites_maxdist", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "100", "-D", "300", "-m", "40", "--roundTo", "8"] + pops_args(12, 3)),
+    dict(name="sparse_predefined", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "predefined", "--windCoords", "{dir}/sparse_coords.txt", "-m", "5",
+               "--writeFailedWindows", "--addWindowID", "--roundTo", "8"] + pops_args(12, 3)),
+    dict(name="sparse_exclude", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "10", "--exclude", "{dir}/sparse_exclude.txt"] + pops_args(12, 3)),
+    dict(name="sparse_include", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "10", "--include", "{dir}/sparse_include.txt"] + pops_args(12, 3)),
+    dict(name="holes_minsites_nan", tool="popgenWindows.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "400", "-m", "60", "--minData", "0.5", "--roundTo", "8", "--writeFailedWindows"] + pops_args(6, 2)),
+    dict(name="holes_sites_m0", tool="popgenWindows.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "150", "-m", "0", "--roundTo", "8"] + pops_args(6, 2)),
+    dict(name="abba_pairs_popgen", tool="popgenWindows.py", fixture="abba_pairs",
+         argv=["-g", "{geno}", "-f", "pairs", "-w", "2000", "-m", "50", "--roundTo", "8"] + pops_args(16, 4)),
+    dict(name="abba_diplo_popgen", tool="popgenWindows.py", fixture="abba_diplo",
+         argv=["-g", "{geno}", "-f", "diplo", "-w", "2000", "-m", "50", "--roundTo", "8"] + pops_args(16, 4)),
+    dict(name="abba_phased_popgen", tool="popgenWindows.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "2000", "-m", "50", "--roundTo", "8"] + pops_args(16, 4)),
+    dict(name="haplo_popgen", tool="popgenWindows.py", fixture="haplo",
+         argv=["-g", "{geno}", "-f", "haplo", "-w", "1000", "-m", "20", "--roundTo", "8", "-p", "a", "s0_A,s0_B,s1_A,s1_B,s2_A",
+               "-p", "b", "s2_B,s3_A,s3_B,s4_A,s4_B"]),
+    # ---- ABBABABAwindows.py ----
+    dict(name="abba_windows", tool="ABBABABAwindows.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--minData", "0.5"] + abba_args(16)),
+    dict(name="abba_windows_failed_id", tool="ABBABABAwindows.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "500", "-s", "250", "-m", "60", "--minData", "0.9", "--writeFailedWindows", "--addWindowID"] + abba_args(16)),
+    dict(name="abba_windows_sites", tool="ABBABABAwindows.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "400", "--overlap", "100", "-m", "50"] + abba_args(16)),
+    dict(name="abba_windows_diplo", tool="ABBABABAwindows.py", fixture="abba_diplo",
+         argv=["-g", "{geno}", "-f", "diplo", "-w", "1000", "-m", "20", "--minData", "0.5"] + abba_args(16)),
+    # ---- distMat.py ----
+    dict(name="holes_distmat_phylip", tool="distMat.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "10", "--windowDataOutFile", "{out}.windows"]),
+    dict(name="holes_distmat_raw_same", tool="distMat.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1500", "-m", "10", "--outFormat", "raw", "--includeSameWithSame", "--roundTo", "6"]),
+    dict(name="holes_distmat_cat_nexus", tool="distMat.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "cat", "--outFormat", "nexus", "--roundTo", "8"]),
+]
+
+AUX_FILES = {
+    "sparse_coords.txt": "chr1 100 900 first\nchr1 500 1500 second\nchr1 4000 4100 third\nchr3 1 1000 onThree\nchr3 2000 2600 lastOne\n",
+    "sparse_exclude.txt": "chr2\n",
+    "sparse_include.txt": "chr1\nchr2\n",
+}
