@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: popgenWindows pi / dxy / Fst over 50 kb coordinate windows (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|northstar|c3]
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the launcher).  A step is one pass of the whole per-window
+statistics path over the rank's resident synthetic data set: pack -> pairwise D/C -> population sums on the GPU,
+D2H of the result table, float64 finalisation (pi, dxy, Fst) on the host, and (N>1) the RCCL all-gather of the
+per-window table.  Inputs are generated on the device before the timed region (counter-based generator,
+genomics_general_amd/synth.py) and stay resident in HBM.  Weak scaling: every rank owns a full-size data set
+(different sites), `value` = windows of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_pairwise), timed with HIP events on the
+stream it runs on; `cpu_baseline` is the CPU oracle's faithful pair-loop port timed on a bounded sample
+(N=1, rank 0 only).  No torch anywhere: barriers and the gather go through RCCL in libpopgen_hip.so.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from genomics_general_amd import _lib, dist, synth, windows  # noqa: E402
+from genomics_general_amd.engine import Engine  # noqa: E402
+from genomics_general_amd.samples import HapLayout, SampleData  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: 10^7 sites x 100 diploids, 4 pops, 50 kb windows
+    "c2": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
+               desc="popgenWindows pi/Fst/Dxy: 1e7 sites x 100 diploids (200 haplotypes), 4 pops, 50 kb windows"),
+    # north-star single-GPU shape: first 10^8 sites of config 5 (200 diploids)
+    "northstar": dict(n_sites=100_000_000, n_scaf=4, n_dip=200, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
+                      desc="popgenWindows pi/Fst/Dxy: 1e8 sites x 200 diploids (400 haplotypes), 4 pops, 50 kb windows"),
+    # BASELINE.json configs[2]: ABBA-BABA
+    "c3": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=50_000, min_sites=100, tool="abba",
+               desc="ABBABABAwindows D/fd: 1e7 sites, P1/P2/P3/O x 25 diploids, 50 kb windows"),
+    # small variant for quick checks
+    "tiny": dict(n_sites=400_000, n_scaf=2, n_dip=20, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
+                 desc="tiny smoke workload"),
+}
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PAIRSITES_PEAK = 3.6e14   # 7 lane-ops per 32 pair-sites at 7.9e13 lane-ops/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=2, help="windows of the workload timed on the CPU port")
+    args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    world = dist.world_from_env()
+    assert world.size == args.gpus, "WORLD_SIZE (%d) must equal --gpus (%d)" % (world.size, args.gpus)
+
+    # ---- setup (untimed) ---------------------------------------------------------------------------
+    n_dip, n_pops = wl["n_dip"], wl["n_pops"]
+    names = ["s%d" % d for d in range(n_dip)]
+    per = n_dip // n_pops
+    sd = SampleData(popNames=["pop%d" % k for k in range(n_pops)],
+                    popInds=[names[k * per:(k + 1) * per] for k in range(n_pops)])
+    lay = HapLayout(sd, names, "phased")
+    slot_gen = np.array([2 * names.index(nm) + k for nm in lay.ind_order for k in range(2)], dtype=np.int32)
+    eng = Engine(world.local_rank)
+    eng.set_layout(lay)
+    comm = dist.RcclComm(eng, world) if world.size > 1 else dist.SoloComm()
+    n_sites = wl["n_sites"]
+    scaf_len = n_sites // wl["n_scaf"]
+    eng.reserve(n_sites)
+    # rank r owns global sites [r*n_sites, (r+1)*n_sites): distinct scaffolds, same shape
+    eng.synth_fill(0, n_sites, world.rank * n_sites, synth.SEED_DEFAULT, scaf_len, n_dip, n_pops, slot_gen,
+                   synth.VAR_THR, synth.MISS_THR)
+    run_starts = np.arange(wl["n_scaf"], dtype=np.int64) * scaf_len
+    run_names = ["chr%d" % (world.rank * wl["n_scaf"] + k + 1) for k in range(wl["n_scaf"])]
+    positions = np.tile(np.arange(1, scaf_len + 1, dtype=np.int32), wl["n_scaf"])
+    T = windows.coord_windows(run_starts, run_names, positions, wl["wind"], wl["wind"])
+    del positions
+    good = T.sites >= wl["min_sites"]
+    lo, hi = T.lo[good], T.hi[good]
+    n_win = int(len(lo))
+    sites_per_step = int((hi - lo).sum())
+
+    def step():
+        wb = eng.batch(lo, hi)
+        if wl["tool"] == "popgen":
+            st = wb.groupDistStats(doPairs=True, minSites=wl["min_sites"], minData=0.01)
+        else:
+            st = wb.ABBABABA("pop0", "pop1", "pop2", "pop3", 0.01)
+        keys = sorted(k for k in st if k != "sitesUsed")
+        table = np.stack([st[k] for k in keys], axis=1)
+        if world.size > 1:
+            table = dist.gather_table(comm, table, n_win * world.size) if False else comm.allgather(table.ravel())
+        return st, table
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    eng.kernel_time_reset()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st, _tab = step()
+    eng.sync()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = float(np.max(comm.allgather(np.array([elapsed])))) if world.size > 1 else elapsed
+
+    # ---- per-kernel timing of the timed region (HIP events on the engine's stream) ---------------------
+    kt = {name: eng.kernel_time(kid) for kid, name in _lib.KERNEL_NAMES.items()}
+    dom_id = _lib.K_PAIRWISE if wl["tool"] == "popgen" else _lib.K_SITESTATS
+    dom_ms, dom_n = eng.kernel_time(dom_id)
+    n_hap = lay.n_hap
+    roofline = None
+    extra = {}
+    if dom_n > 0:
+        per_launch_s = dom_ms / dom_n / 1e3
+        launches_per_step = dom_n / args.steps
+        alg_bytes_launch = n_hap * sites_per_step / launches_per_step       # 1 byte per haplotype allele call
+        achieved = alg_bytes_launch / per_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get(args.workload, {}).get(_lib.KERNEL_NAMES[dom_id])
+            except Exception:
+                traffic = None
+        roofline = {"kernel": _lib.KERNEL_NAMES[dom_id], "bound": "hbm", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": traffic, "avg_launch_ms": round(dom_ms / dom_n, 4), "launches": int(dom_n),
+                    "algorithmic_bytes_per_launch": int(alg_bytes_launch)}
+        if wl["tool"] == "popgen":
+            pair_sites = n_hap * (n_hap - 1) / 2 * sites_per_step / launches_per_step
+            extra["valu"] = {"pair_sites_per_s": pair_sites / per_launch_s, "peak": VALU_PAIRSITES_PEAK,
+                             "frac": round(pair_sites / per_launch_s / VALU_PAIRSITES_PEAK, 4),
+                             "note": "k_pairwise is VALU-integer bound (SURVEY.md 8d); HBM frac is reported as asked"}
+    extra["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in kt.items() if v[1] > 0}
+
+    # ---- CPU baseline: the oracle's faithful port of the reference algorithm, bounded sample -------------
+    cpu = None
+    if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:
+        from oracle import popgen_oracle as orc
+        nw = max(1, min(args.cpu_windows, n_win))
+        t_cpu = 0.0
+        ok = True
+        for w in range(nw):
+            codes = eng.download(int(lo[w]), int(hi[w] - lo[w]))
+            aln, _ = orc.aln_from_codes(codes, lay.hap_names, lay.hap_sample_name, lay.hap_group)
+            c0 = time.perf_counter()
+            if wl["tool"] == "popgen":
+                D, C = orc.pair_counts_loop(aln)                     # genomics.py:903-916 + 1042-1047, pair by pair
+                so, _ = orc.group_dist_stats(aln, D, C, True, wl["min_sites"], 0.01)
+            else:
+                so = orc.abbababa(aln, "pop0", "pop1", "pop2", "pop3", 0.01)
+            t_cpu += time.perf_counter() - c0
+            for k, v in so.items():
+                if k == "sitesUsed":
+                    ok = ok and int(st[k][w]) == int(v)
+                    continue
+                g = st[k][w]
+                ok = ok and (abs(g - v) <= 1e-6 * max(1.0, abs(v)) or (g != g and v != v))
+        cpu = {"value": round(nw / t_cpu, 5), "unit": "windows/s", "cores": 1, "kind": "port",
+               "sample": "first %d windows (%d sites x %d haplotypes each) of the workload, numeric core only "
+                         "(no text parsing / alignment build, which dominate the real reference)" % (nw, wl["wind"], n_hap),
+               "seconds": round(t_cpu, 2), "gpu_matches_oracle_on_sample": bool(ok)}
+
+    if world.rank == 0:
+        total_windows = n_win * world.size * args.steps
+        total_sites = sites_per_step * world.size * args.steps
+        line = {
+            "metric": "windows_per_sec", "value": round(total_windows / elapsed, 3), "unit": "windows/s",
+            "sites_per_sec": round(total_sites / elapsed, 1),
+            "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 bit-planes / int32 counts / f64 statistics", "data": "synthetic",
+            "config": {"workload": wl["desc"], "name": args.workload, "windows_per_gpu": n_win,
+                       "sites_per_gpu": sites_per_step, "haplotypes": n_hap, "parallelism": "windows sharded, dp%d" % world.size},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line))
+    comm.barrier()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""ctypes binding of libpopgen_hip.so (include/popgen_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or (for anything but the host tokenizer)
+no MI355X is visible, the call fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpopgen_hip.so")
+
+
+class PopgenError(RuntimeError):
+    """A libpopgen_hip.so call returned a negative pg_status."""
+
+    def __init__(self, code, msg):
+        super().__init__("libpopgen_hip: [%d] %s" % (code, msg))
+        self.code = code
+
+
+PG_ERR_ARG, PG_ERR_HIP, PG_ERR_NODEV, PG_ERR_PARSE, PG_ERR_RCCL, PG_ERR_STATE = -1, -2, -3, -4, -5, -6
+FMT = {"phased": 0, "pairs": 1, "haplo": 2, "diplo": 3}
+K_PACK, K_PAIRWISE, K_POPDIST_FIN, K_SITESTATS, K_SYNTH = 0, 1, 2, 3, 4
+KERNEL_NAMES = {K_PACK: "k_pack", K_PAIRWISE: "k_pairwise", K_POPDIST_FIN: "k_popdist_fin",
+                K_SITESTATS: "k_sitestats", K_SYNTH: "k_synth"}
+
+_lib = None
+
+_P = C.c_void_p
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+# name -> (restype, argtypes); every name here must be declared in include/popgen_hip.h
+SIGNATURES = {
+    "pg_abi_version": (C.c_int, []),
+    "pg_last_error": (C.c_char_p, []),
+    "pg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pg_ctx_create": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "pg_ctx_destroy": (C.c_int, [_P]),
+    "pg_sync": (C.c_int, [_P]),
+    "pg_set_samples": (C.c_int, [_P, C.c_int, _i32p, _i32p, C.c_int]),
+    "pg_reserve_sites": (C.c_int, [_P, C.c_int64]),
+    "pg_upload_sites": (C.c_int, [_P, C.c_int64, _i8p, C.c_int64]),
+    "pg_download_sites": (C.c_int, [_P, C.c_int64, _i8p, C.c_int64]),
+    "pg_synth_fill": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32,
+                                _i32p, C.c_int32, C.c_int32]),
+    "pg_encode_text": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i8p, _i32p,
+                                 _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
+    "pg_scaffold_runs": (C.c_int, [C.c_char_p, _i64p, _i32p, C.c_int64, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
+    "pg_count_lines": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]),
+    "pg_pairwise": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i32p, _i32p]),
+    "pg_popdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
+    "pg_indpairdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
+    "pg_abbababa": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _f64p, _i64p]),
+    "pg_popfreq": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p, _i64p, _i64p]),
+    "pg_hap_called": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p]),
+    "pg_site_counts": (C.c_int, [_P, C.c_int64, C.c_int64, _i32p]),
+    "pg_kernel_time": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pg_kernel_time_reset": (C.c_int, [_P]),
+    "pg_set_scratch_limit": (C.c_int, [_P, C.c_int64]),
+    "pg_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "pg_comm_init": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p]),
+    "pg_comm_allgather_f64": (C.c_int, [_P, _f64p, _f64p, C.c_int64]),
+    "pg_comm_barrier": (C.c_int, [_P]),
+    "pg_comm_destroy": (C.c_int, [_P]),
+}
+
+
+def lib():
+    """Load (once) and return the shared library; raise ImportError with a build hint if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C genomics_general_amd/csrc` (needs hipcc, --offload-arch=gfx950). "
+                              "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.pg_abi_version() != 1:
+            raise ImportError("libpopgen_hip.so ABI version %d != 1" % L.pg_abi_version())
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise PopgenError(rc, lib().pg_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def device_count():
+    """Number of visible GPUs (0 when none; never raises for 'no device')."""
+    n = C.c_int(0)
+    rc = lib().pg_device_count(C.byref(n))
+    if rc == PG_ERR_NODEV:
+        return 0
+    check(rc)
+    return n.value

@@ -1,0 +1,490 @@
+"""Drop-in command lines: popgenWindows.py, ABBABABAwindows.py and distMat.py of the reference, same flags, same
+`.geno` input, same CSV / matrix output, with the per-window numeric work done by
+libpopgen_hip.so on an MI355X.  There is no CPU engine: without the library or a GPU these exit with an error.
+
+Reference flag tables: popgenWindows.py:172-210, ABBABABAwindows.py:111-145, distMat.py:118-156.
+Additive flags: --device N (GPU index; default LOCAL_RANK or 0).  Under a one-process-per-GPU launcher
+(RANK/WORLD_SIZE set) windows are sharded across ranks and rank 0 writes the output.
+"""
+import argparse
+import gzip
+import itertools
+import sys
+
+import numpy as np
+
+from . import dist, genoio, windows
+from .engine import Engine
+from .samples import HapLayout, SampleData
+
+WINDOW_FLAGS = [
+    (("--windType",), dict(choices=None, default="coordinate", help="Type of windows to make")),
+    (("-w", "--windSize"), dict(type=int, metavar="sites", help="Window size in bases (or sites)")),
+    (("-s", "--stepSize"), dict(type=int, metavar="sites", help="Step size for sliding window")),
+    (("-m", "--minSites"), dict(type=int, metavar="sites", default=1, help="Minimum good sites per window")),
+    (("-D", "--maxDist"), dict(type=int, help="Maximum span distance for sites window")),
+    (("--windCoords",), dict(help="Window coordinates file (scaffold start end)")),
+]
+IO_FLAGS = [
+    (("-g", "--genoFile"), dict(help="Input genotypes file (.gz by suffix; stdin if absent)")),
+    (("-o", "--outFile"), dict(help="Results file (.gz by suffix; stdout if absent)")),
+    (("--exclude",), dict(help="File of scaffolds to exclude")),
+    (("--include",), dict(help="File of scaffolds to analyse")),
+    (("-f", "--genoFormat"), dict(choices=("phased", "pairs", "haplo", "diplo"), required=True,
+                                  help="Format of genotypes in genotypes file")),
+    (("--verbose",), dict(action="store_true", help="Verbose output")),
+    (("--addWindowID",), dict(action="store_true", help="Add window name or number as first column")),
+    (("--writeFailedWindows",), dict(action="store_true", help="Write output even for windows with too few sites.")),
+    (("--device",), dict(type=int, default=None, help="GPU index (MI355X engine)")),
+]
+PLOIDY_FLAGS = [
+    (("--ploidy",), dict(type=int, nargs="+", help="Ploidy for each sample")),
+    (("--ploidyFile",), dict(help="File with samples names and ploidy as columns")),
+    (("--inferPloidy",), dict(action="store_true", help="(not supported by the GPU engine)")),
+]
+
+
+def _add(parser, table, **override):
+    for names, kw in table:
+        kw = dict(kw)
+        if names[0] in override:
+            kw.update(override[names[0]])
+        parser.add_argument(*names, **kw)
+
+
+def _lines(path):
+    with open(path, "rt") as f:
+        return [ln.rstrip() for ln in f.readlines()]
+
+
+def _open_out(path):
+    if not path:
+        return sys.stdout
+    return gzip.open(path, "wt") if path.endswith(".gz") else open(path, "wt")
+
+
+def _window_setup(args, overlap):
+    """The window-parameter asserts shared by the three drivers (popgenWindows.py:216-244)."""
+    wt = args.windType
+    p = dict(windType=wt, windSize=args.windSize, stepSize=None, overlap=0, maxDist=np.inf, windCoords=None)
+    if wt == "coordinate":
+        assert args.windSize, "Window size must be provided."
+        p["stepSize"] = args.stepSize if args.stepSize else args.windSize
+        assert not overlap, "Overlap does not apply to coordinate windows. Use --stepSize instead."
+        assert not args.maxDist, "Maximum distance only applies to sites windows."
+    elif wt == "sites":
+        assert args.windSize, "Window size (number of sites) must be provided."
+        p["overlap"] = overlap if overlap else 0
+        p["maxDist"] = args.maxDist if args.maxDist else np.inf
+        assert not args.stepSize, "Step size only applies to coordinate windows. Use --overlap instead."
+    elif wt == "predefined":
+        assert args.windCoords, "Please provide a file of window coordinates."
+        p["windCoords"] = args.windCoords
+        assert not overlap, "Overlap does not apply for predefined windows."
+        assert not args.maxDist, "Maximum does not apply for predefined windows."
+        assert not args.stepSize, "Step size does not apply for predefined windows."
+        assert not args.include, "You cannot only include specific scaffolds if using predefined windows."
+        assert not args.exclude, "You cannot exclude specific scaffolds if using predefined windows."
+    return p
+
+
+def _ploidy_dict(args, inds, haploid_list):
+    """popgenWindows.py:293-305."""
+    if args.ploidy is not None:
+        pl = args.ploidy if len(args.ploidy) != 1 else args.ploidy * len(inds)
+        assert len(pl) == len(inds), "Incorrect number of ploidy values supplied."
+        return dict(zip(inds, pl))
+    if args.ploidyFile is not None:
+        with open(args.ploidyFile, "rt") as pf:
+            return dict([[s[0], int(s[1])] for s in [ln.split() for ln in pf]])
+    if args.inferPloidy:
+        raise SystemExit("--inferPloidy is not supported by the MI355X engine (the reference itself marks it NOT RECOMMENDED)")
+    d = dict(zip(inds, [1 if args.genoFormat == "haplo" else 2] * len(inds)))
+    for s in haploid_list or []:
+        d[s] = 1
+    return d
+
+
+def _make_windows(p, data, minSites, coords_keep=4):
+    inc = _lines(p["include"]) if p.get("include") else None
+    exc = _lines(p["exclude"]) if p.get("exclude") else None
+    if p["windType"] == "coordinate":
+        return windows.coord_windows(data.run_starts, data.run_names, data.pos, p["windSize"], p["stepSize"], inc, exc)
+    if p["windType"] == "sites":
+        return windows.sites_windows(data.run_starts, data.run_names, data.pos, p["windSize"], p["overlap"],
+                                     p["maxDist"], minSites, inc, exc)
+    with open(p["windCoords"], "rt") as wc:
+        coords = []
+        for line in wc:
+            f = line.split()[:coords_keep]
+            if len(f) >= 3:
+                coords.append(tuple([f[0], int(f[1]), int(f[2])] + f[3:4]))
+    return windows.predefined_windows(data.run_starts, data.run_names, data.pos, coords)
+
+
+class Run:
+    """Shared plumbing: input -> layout -> windows -> engine (+ multi-GPU shard of the window list)."""
+
+    def __init__(self, args, sampleData, wparams, minSites, header_line=None, coords_keep=4, windows_fn=None):
+        self.world = dist.world_from_env()
+        raw = genoio.read_all(args.genoFile)
+        names, body = genoio.split_header(raw, header_line)
+        self.layout = HapLayout(sampleData, names, args.genoFormat)
+        self.data = genoio.encode(body, self.layout)
+        wparams = dict(wparams, include=args.include, exclude=args.exclude)
+        self.T = windows_fn(self.data) if windows_fn else _make_windows(wparams, self.data, minSites, coords_keep)
+        dev = args.device if args.device is not None else self.world.local_rank
+        self.engine = Engine(dev)
+        self.engine.set_layout(self.layout)
+        self.comm = dist.RcclComm(self.engine, self.world) if self.world.size > 1 else dist.SoloComm()
+        # this rank's windows (contiguous range) and only the sites they cover
+        self.w0, self.w1 = dist.shard_range(self.T.n, self.world.size, self.world.rank)
+        lo, hi = self.T.lo[self.w0:self.w1], self.T.hi[self.w0:self.w1]
+        nz = hi > lo
+        if np.any(nz):
+            s0, s1 = int(lo[nz].min()), int(hi[nz].max())
+        else:
+            s0 = s1 = 0
+        self.engine.load_sites(self.data.gt[s0:s1])
+        self.site0 = s0
+        self.lo, self.hi = lo - s0, hi - s0
+        self.lo[~nz] = 0
+        self.hi[~nz] = 0
+
+    def batch(self, mask):
+        """WindowBatch over this rank's windows selected by boolean `mask`."""
+        return self.engine.batch(self.lo[mask], self.hi[mask])
+
+    def gather(self, table):
+        return dist.gather_table(self.comm, table, self.T.n)
+
+
+def _fmt_cell(v):
+    return str(v)
+
+
+# ==========================================================================================================
+# popgenWindows.py
+# ==========================================================================================================
+def popgen_main(argv=None):
+    ap = argparse.ArgumentParser(prog="popgenWindows.py")
+    _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined"))})
+    ap.add_argument("-O", "--overlap", type=int, metavar="sites", help="Overlap for sites sliding window")
+    ap.add_argument("--minData", type=float, metavar="prop", default=0.01,
+                    help="Minimum proportion of individuals (or pairs) with >=minSites data")
+    ap.add_argument("-p", "--population", action="append", nargs="+", metavar=("popName", "[samples]"),
+                    help="Pop name and optionally sample names (separated by commas)")
+    ap.add_argument("--popsFile", help="Optional file of sample names and populations")
+    ap.add_argument("--samples", metavar="sample names", help="Samples to include for individual analysis")
+    _add(ap, PLOIDY_FLAGS)
+    ap.add_argument("--haploid", metavar="sample names", help="Samples that are haploid (comma separated)")
+    ap.add_argument("--analysis", nargs="+", default=("popDist", "popPairDist"),
+                    choices=("popFreq", "popDist", "popPairDist", "indPairDist", "indHet", "hapStats"),
+                    help="Type of statistics to get")
+    ap.add_argument("--hapDist", type=float, default=0)
+    ap.add_argument("--roundTo", type=int, default=4, help="Round stats to X decimal places")
+    ap.add_argument("--header", help="Header text if no header in input")
+    ap.add_argument("-T", "--threads", type=int, default=1, metavar="threads",
+                    help="accepted for compatibility; the GPU engine does not use worker processes")
+    _add(ap, IO_FLAGS)
+    args = ap.parse_args(argv)
+
+    wp = _window_setup(args, args.overlap)
+    minSites = args.minSites
+    if not minSites:
+        minSites = args.windSize
+    for a in args.analysis:
+        if a in ("indHet", "hapStats"):
+            raise SystemExit("--analysis %s is not implemented by the MI355X engine yet (SURVEY.md 8f, 'next' rows)" % a)
+
+    # samples and populations (popgenWindows.py:259-291)
+    popNames, popInds, allInds = [], [], []
+    if args.population is not None:
+        for p in args.population:
+            popNames.append(p[0])
+            popInds.append(p[1].split(",") if len(p) > 1 else [])
+        if args.popsFile:
+            with open(args.popsFile, "rt") as pf:
+                for ind, pop in (ln.split()[:2] for ln in pf if ln.strip()):
+                    if pop in popNames:
+                        popInds[popNames.index(pop)].append(ind)
+        for p in popInds:
+            assert len(p) >= 1, "All populations must be represented by at least one sample."
+        for p in popInds:
+            for i in p:
+                if i not in allInds:
+                    allInds.append(i)
+    if args.samples is not None:
+        for i in args.samples.split(","):
+            if i not in allInds:
+                allInds.append(i)
+    if len(allInds) == 0:
+        assert args.genoFile, "sample names are read from the file header: give -g, or -p/--samples when piping"
+        allInds = genoio.read_header_names(args.genoFile)
+    pop_analysis = any(a in args.analysis for a in ("popFreq", "popDist", "popPairDist", "hapStats"))
+    if len(popNames) == 0 and pop_analysis:
+        popNames.append("all")
+        popInds.append(list(allInds))
+    ploidyDict = _ploidy_dict(args, allInds, args.haploid.split(",") if args.haploid else None)
+    sampleData = SampleData(indNames=list(allInds), popNames=popNames, popInds=popInds, ploidyDict=ploidyDict)
+    if pop_analysis:
+        nopop = [i for i in sampleData.indNames if sampleData.getPop(i) is None]
+        assert not nopop, "samples without a population cannot be mixed with population statistics: " + ",".join(nopop[:5])
+
+    # statistics, in output order (popgenWindows.py:326-354)
+    stats = []
+    if "popFreq" in args.analysis:
+        for pre in ("l_", "S_", "thetaPi_", "thetaW_", "TajD_"):
+            stats += [pre + n for n in popNames]
+    if "popDist" in args.analysis:
+        stats += ["pi_" + n for n in popNames]
+    if "popPairDist" in args.analysis:
+        stats += ["dxy_" + x + "_" + y for x, y in itertools.combinations(popNames, 2)]
+        stats += ["Fst_" + x + "_" + y for x, y in itertools.combinations(popNames, 2)]
+    if "indPairDist" in args.analysis:
+        stats += ["_".join(["d", i, j]) for i, j in itertools.combinations_with_replacement(sorted(allInds), 2)]
+    int_stat = [s.startswith("l_") or s.startswith("S_") for s in stats]
+
+    run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=3)
+    T = run.T
+    sites_local = T.sites[run.w0:run.w1]
+    good = sites_local >= minSites
+    table = np.full((run.w1 - run.w0, len(stats)), np.nan)
+    if np.any(good) and stats:
+        wb = run.batch(good)
+        sd = {}
+        if "popFreq" in args.analysis:
+            sd.update(wb.groupFreqStats())
+        if "popDist" in args.analysis or "popPairDist" in args.analysis:
+            sd.update(wb.groupDistStats(doPairs="popPairDist" in args.analysis, minSites=minSites, minData=args.minData))
+        if "indPairDist" in args.analysis:
+            pdd = wb.indPairDists()
+            for i, j in itertools.combinations_with_replacement(sorted(pdd.keys()), 2):
+                sd["_".join(["d", i, j])] = pdd[i][j]
+        for c, s in enumerate(stats):
+            table[good, c] = sd[s]
+    full = run.gather(table)
+
+    if run.world.rank == 0:
+        out = _open_out(args.outFile)
+        out.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites," + ",".join(stats) + "\n")
+        written = 0
+        for k in range(T.n):
+            ok = T.sites[k] >= minSites
+            if not (ok or args.writeFailedWindows):
+                continue
+            vals = []
+            for c in range(len(stats)):
+                v = full[k, c]
+                if int_stat[c] and v == v:
+                    vals.append(int(v))
+                else:
+                    vals.append(round(np.float64(v), args.roundTo))
+            row = ([T.ID[k]] if args.addWindowID else []) + [T.scaffold[k], T.start[k], T.end[k], T.mid[k], int(T.sites[k])] + vals
+            out.write(",".join(_fmt_cell(x) for x in row) + "\n")
+            written += 1
+        if out is not sys.stdout:
+            out.close()
+        sys.stderr.write(str(T.n) + " windows were tested.\n")
+        sys.stderr.write(str(written) + " results were written.\n")
+        sys.stderr.write("\nDone.\n")
+    run.comm.barrier()
+    return 0
+
+
+# ==========================================================================================================
+# ABBABABAwindows.py
+# ==========================================================================================================
+def abbababa_main(argv=None):
+    ap = argparse.ArgumentParser(prog="ABBABABAwindows.py")
+    _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined"))})
+    ap.add_argument("--overlap", type=int, metavar="sites", help="Overlap for sites sliding window")
+    ap.add_argument("--minData", type=float, metavar="proportion", default=0.01,
+                    help="Min proportion of samples genotyped per site")
+    for flag, dest, what in (("-P1", "pop1", "P1"), ("-P2", "pop2", "P2"), ("-P3", "pop3", "P3"), ("-O", "outgroup", "outgroup")):
+        ap.add_argument(flag, "--" + dest, dest=dest, nargs="+", required=True, metavar=("popName", "[samples]"),
+                        help="Pop name and optionally sample names for " + what)
+    ap.add_argument("--popsFile", help="Optional file of sample names and populations")
+    _add(ap, PLOIDY_FLAGS)
+    ap.add_argument("--haploid", metavar="sample names", help="Samples that are haploid (comma separated)")
+    ap.add_argument("--header", help="Header text if no header in input")
+    ap.add_argument("-T", "--Threads", type=int, default=1, help="accepted for compatibility")
+    _add(ap, IO_FLAGS)
+    args = ap.parse_args(argv)
+
+    wp = _window_setup(args, args.overlap)
+    minSites = args.minSites
+    if not minSites:
+        minSites = args.windSize
+    minData = args.minData
+    assert 0 <= minData <= 1, "minimum data per site must be between 0 and 1."
+
+    popNames, popInds = [], []
+    for p in (args.pop1, args.pop2, args.pop3, args.outgroup):
+        popNames.append(p[0])
+        popInds.append(p[1].split(",") if len(p) > 1 else [])
+    if args.popsFile:
+        with open(args.popsFile, "rt") as pf:
+            for ind, pop in (ln.split()[:2] for ln in pf if ln.strip()):
+                if pop in popNames:
+                    popInds[popNames.index(pop)].append(ind)
+    for p in popInds:
+        assert len(p) >= 1, "All populations must be represented by at least one sample."
+    allInds = []
+    for p in popInds:
+        for i in p:
+            if i not in allInds:
+                allInds.append(i)
+    ploidyDict = _ploidy_dict(args, allInds, args.haploid.split(",") if args.haploid else None)
+    sampleData = SampleData(popNames=popNames, popInds=popInds, ploidyDict=ploidyDict)
+
+    run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=4)
+    T = run.T
+    stats = ["ABBA", "BABA", "D", "fd", "fdM"]
+    sites_local = T.sites[run.w0:run.w1]
+    good = sites_local >= minSites
+    table = np.full((run.w1 - run.w0, 1 + len(stats)), np.nan)           # sitesUsed + 5 statistics
+    if np.any(good):
+        sd = run.batch(good).ABBABABA(popNames[0], popNames[1], popNames[2], popNames[3], minData)
+        table[good, 0] = sd["sitesUsed"]
+        for c, s in enumerate(stats):
+            table[good, 1 + c] = sd[s]
+    full = run.gather(table)
+
+    if run.world.rank == 0:
+        out = _open_out(args.outFile)
+        out.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites,sitesUsed,ABBA,BABA,D,fd,fdM\n")
+        written = 0
+        for k in range(T.n):
+            used = full[k, 0]
+            ok = T.sites[k] >= minSites and used >= minSites           # ABBABABAwindows.py:35-46
+            if not (ok or args.writeFailedWindows):
+                continue
+            vals = [round(np.float64(v), 4) for v in full[k, 1:]] if ok else [np.nan] * len(stats)
+            used_cell = int(used) if used == used else np.nan
+            row = ([T.ID[k]] if args.addWindowID else []) + [T.scaffold[k], T.start[k], T.end[k], T.mid[k], int(T.sites[k]), used_cell] + vals
+            out.write(",".join(_fmt_cell(x) for x in row) + "\n")
+            written += 1
+        if out is not sys.stdout:
+            out.close()
+        sys.stderr.write("%d windows were tested\n%d results were written\n\nDone.\n" % (T.n, written))
+    run.comm.barrier()
+    return 0
+
+
+# ==========================================================================================================
+# distMat.py
+# ==========================================================================================================
+def _matrix_text(M, names, fmt, roundTo):
+    """genomics.py:2288-2306 makeDistMatString / PhylipString / NexusString."""
+    txt = M.round(roundTo).astype(str)
+    n = len(names)
+    if fmt == "raw":
+        return "\n".join(" ".join(r) for r in txt) + "\n"
+    if fmt == "phylip":
+        return str(M.shape[0]) + "\n" + "".join(str(names[i]) + "  " + " ".join(txt[i]) + "\n" for i in range(n))
+    s = "\nBEGIN Taxa;\nDIMENSIONS ntax={};\nTAXLABELS\n".format(n)
+    s += "".join("[{}] '{}'\n".format(i + 1, names[i]) for i in range(n))
+    s += ";\nEND; [Taxa]\n"
+    s += "\nBEGIN Distances;\nDIMENSIONS ntax={};\nFORMAT labels=left diagonal triangle=both;\nMATRIX\n".format(n)
+    s += "".join("[{}] '{}'    ".format(i + 1, names[i]) + " ".join(txt[i]) + "\n" for i in range(n))
+    return s + ";\nEND; [Distances]\n"
+
+
+def distmat_main(argv=None):
+    ap = argparse.ArgumentParser(prog="distMat.py")
+    _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined", "cat")),
+                              "-m": dict(default=None)})
+    ap.add_argument("--overlap", type=int, metavar="sites", help="Overlap for sites sliding window")
+    ap.add_argument("-Mi", "--minPerInd", type=int, metavar="sites", help="Minimum sites per individual")
+    ap.add_argument("--includeSameWithSame", action="store_true", help="Include comparisons of each haplotype to itself")
+    ap.add_argument("--outFormat", choices=("raw", "phylip", "nexus"), default="phylip")
+    ap.add_argument("--roundTo", type=int, default=4)
+    ap.add_argument("--headers", nargs="+", help="Header fields if the input has no header line")
+    ap.add_argument("--windowDataOutFile", help="Optional file for window coordinates")
+    ap.add_argument("--samples", nargs="+", help="Samples to include")
+    _add(ap, PLOIDY_FLAGS)
+    ap.add_argument("--haploid", nargs="+", metavar="sample", help="Samples that are haploid")
+    ap.add_argument("-T", "--threads", type=int, default=1, help="accepted for compatibility")
+    _add(ap, IO_FLAGS)
+    args = ap.parse_args(argv)
+
+    minSites = args.minSites
+    if args.windType == "cat":
+        wp = dict(windType="cat", windSize=None, stepSize=None, overlap=0, maxDist=np.inf, windCoords=None)
+        minSites = 1
+    else:
+        wp = _window_setup(args, args.overlap)
+    if not minSites:
+        minSites = args.windSize
+
+    if args.samples:
+        samples = list(args.samples)
+    elif args.headers:
+        samples = list(args.headers[2:])
+    else:
+        assert args.genoFile, "If piping from stdin, you need to specify either --samples or --headers"
+        samples = genoio.read_header_names(args.genoFile)
+    ploidyDict = _ploidy_dict(args, samples, args.haploid)
+    sampleData = SampleData(indNames=list(samples), ploidyDict=ploidyDict)
+    header_line = "\t".join(args.headers) if args.headers else None
+
+    def cat_window(data):
+        # parseGenoFile (genomics.py:1949-1967): every site of the file, positions ignored
+        T = windows.WindowTable()
+        T.add(None, None, None, 0, data.n_sites, None)
+        T.finish(data.pos)
+        T.mid = [float("nan")]
+        return T
+
+    run = Run(args, sampleData, wp, minSites, header_line=header_line, coords_keep=3,
+              windows_fn=cat_window if args.windType == "cat" else None)
+    T = run.T
+    lay = run.layout
+    n = len(samples)
+    npairs = n * (n + 1) // 2
+    sites_local = T.sites[run.w0:run.w1]
+    good = sites_local >= minSites
+    table = np.full((run.w1 - run.w0, npairs + 1), np.nan)               # pair means + minPerInd verdict
+    table[:, npairs] = 1.0
+    if np.any(good):
+        wb = run.batch(good)
+        if args.minPerInd:
+            called = wb.hapCalled()
+            table[good, npairs] = (called.min(axis=1) >= args.minPerInd).astype(np.float64)
+        pdd = wb.indPairDists(includeSameWithSame=args.includeSameWithSame)
+        col = 0
+        for i in range(n):
+            for j in range(i, n):
+                table[good, col] = pdd[samples[i]][samples[j]]
+                col += 1
+    full = run.gather(table)
+
+    if run.world.rank == 0:
+        out = _open_out(args.outFile)
+        wout = None
+        if args.windowDataOutFile:
+            wout = _open_out(args.windowDataOutFile)
+            # the reference writes this header without a newline and tab-separated rows after it (distMat.py:238-239, 58)
+            wout.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites,")
+        written = 0
+        iu = np.triu_indices(n)
+        for k in range(T.n):
+            ok = T.sites[k] >= minSites and full[k, npairs] > 0
+            if not (ok or args.writeFailedWindows):
+                continue
+            M = np.full((n, n), np.nan)
+            if ok:
+                M[iu] = full[k, :npairs]
+                M[(iu[1], iu[0])] = full[k, :npairs]
+            out.write(_matrix_text(M, samples, args.outFormat, args.roundTo))
+            if wout is not None:
+                wd = ([T.ID[k]] if args.addWindowID else []) + [T.scaffold[k], T.start[k], T.end[k], T.mid[k], int(T.sites[k])]
+                wout.write("\t".join(str(x) for x in wd) + "\n")
+            written += 1
+        for f in (out, wout):
+            if f is not None and f is not sys.stdout:
+                f.close()
+        sys.stderr.write("{} windows were tested.\n{} results were written.\n\n### Done. ###\n".format(T.n, written))
+    run.comm.barrier()
+    return 0

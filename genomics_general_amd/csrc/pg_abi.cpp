@@ -1,0 +1,569 @@
+// C-ABI host layer of libpopgen_hip.so: context, resident site buffer, window batching, kernel timing.
+// See include/popgen_hip.h for the contract of every entry point.
+#include "pg_ctx.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+static thread_local char g_err[1024] = "";
+
+int pg_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *pg_last_error(void) { return g_err; }
+extern "C" int pg_abi_version(void) { return PG_ABI_VERSION; }
+
+extern "C" int pg_device_count(int *n_out) {
+    if (!n_out) return pg_fail(PG_ERR_ARG, "pg_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *n_out = 0;
+        (void)hipGetLastError();
+        return pg_fail(PG_ERR_NODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *n_out = n;
+    return PG_OK;
+}
+
+extern "C" int pg_ctx_create(pg_ctx **out, int device) {
+    if (!out) return pg_fail(PG_ERR_ARG, "pg_ctx_create: null output");
+    *out = nullptr;
+    int n = 0;
+    int rc = pg_device_count(&n);
+    if (rc != PG_OK) return rc;
+    if (n <= 0) return pg_fail(PG_ERR_NODEV, "no HIP device visible: the popgen engine needs an AMD GPU (gfx950)");
+    if (device < 0 || device >= n) return pg_fail(PG_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    pg_ctx *c = new pg_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return pg_fail(PG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return PG_OK;
+}
+
+static void drop_events(pg_ctx *c) {
+    for (int k = 0; k < PG_K_COUNT_; ++k) {
+        for (auto &pr : c->events[k]) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        c->events[k].clear();
+        c->acc_ms[k] = 0.0;
+        c->acc_launches[k] = 0;
+    }
+}
+
+extern "C" int pg_ctx_destroy(pg_ctx *c) {
+    if (!c) return PG_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    pg_comm_destroy(c);
+    drop_events(c);
+    c->gt.release();
+    c->hap_pop.release();
+    c->pop_start.release();
+    c->samp_start.release();
+    c->tasks.release();
+    c->planes.release();
+    c->Cmat.release();
+    c->Dmat.release();
+    c->win.release();
+    c->res_f64.release();
+    c->res_i64.release();
+    c->part_f64.release();
+    c->part_i64.release();
+    c->slot_gen.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PG_OK;
+}
+
+extern "C" int pg_sync(pg_ctx *c) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+extern "C" int pg_set_scratch_limit(pg_ctx *c, int64_t bytes) {
+    if (!c || bytes < (64ll << 20)) return pg_fail(PG_ERR_ARG, "scratch limit must be >= 64 MiB");
+    c->scratch_limit = bytes;
+    return PG_OK;
+}
+
+// ---- samples ----------------------------------------------------------------------------------------
+extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, const int32_t *hap_sample, int n_pops) {
+    if (!c || !hap_pop || !hap_sample) return pg_fail(PG_ERR_ARG, "pg_set_samples: null argument");
+    if (n_hap < 1 || n_hap > PG_MAX_HAP) return pg_fail(PG_ERR_ARG, "n_hap %d out of range [1,%d]", n_hap, PG_MAX_HAP);
+    if (n_pops < 0) return pg_fail(PG_ERR_ARG, "n_pops < 0");
+    HIPCHK(hipSetDevice(c->device));
+    // populations: contiguous, increasing, -1 last
+    std::vector<int32_t> pstart(n_pops + 1, 0);
+    int prev = (n_pops > 0 ? 0 : -1), h = 0;
+    {
+        std::vector<int32_t> count(n_pops, 0);
+        int last = -2;
+        bool seen_none = false;
+        for (h = 0; h < n_hap; ++h) {
+            int p = hap_pop[h];
+            if (p < -1 || p >= n_pops) return pg_fail(PG_ERR_ARG, "hap_pop[%d]=%d out of range", h, p);
+            if (p == -1) { seen_none = true; continue; }
+            if (seen_none) return pg_fail(PG_ERR_ARG, "haplotype slots without a population must come last (slot %d)", h);
+            if (last != -2 && p < last) return pg_fail(PG_ERR_ARG, "populations must be contiguous and increasing in slot order (slot %d)", h);
+            last = p;
+            count[p]++;
+        }
+        int acc = 0;
+        for (int p = 0; p < n_pops; ++p) { pstart[p] = acc; acc += count[p]; }
+        pstart[n_pops] = acc;
+        (void)prev;
+    }
+    // individuals: contiguous runs
+    std::vector<int32_t> sstart;
+    {
+        int last = -1;
+        std::vector<char> used;
+        for (h = 0; h < n_hap; ++h) {
+            int s = hap_sample[h];
+            if (s < 0) return pg_fail(PG_ERR_ARG, "hap_sample[%d] < 0", h);
+            if (s != last) {
+                if ((size_t)s >= used.size()) used.resize(s + 1, 0);
+                if (used[s]) return pg_fail(PG_ERR_ARG, "haplotype slots of individual %d are not contiguous", s);
+                if (s != (int)sstart.size()) return pg_fail(PG_ERR_ARG, "individuals must be numbered 0.. in slot order (slot %d has %d)", h, s);
+                used[s] = 1;
+                sstart.push_back(h);
+                last = s;
+            }
+        }
+        sstart.push_back(n_hap);
+    }
+    c->n_hap = n_hap;
+    c->n_pops = n_pops;
+    c->n_samp = (int)sstart.size() - 1;
+    c->S = (n_hap + 15) / 16 * 16;
+    c->NP = (n_hap + 63) / 64 * 64;
+    c->h_pop_start = pstart;
+    c->h_samp_start = sstart;
+    // pair-kernel task table: column chunk of 64 x row sub-tiles of 8 strictly above the chunk's last column
+    std::vector<PgPairTask> tasks;
+    for (int col0 = 0; col0 < n_hap; col0 += 64) {
+        int jmax = std::min(col0 + 63, n_hap - 1);
+        int nsub_total = (jmax + 7) / 8;                 // rows 0 .. jmax-1
+        for (int s = 0; s < nsub_total; s += 4) {
+            PgPairTask t;
+            t.row0 = 8 * s;
+            t.nsub = std::min(4, nsub_total - s);
+            t.col0 = col0;
+            t.pad = 0;
+            tasks.push_back(t);
+        }
+    }
+    c->n_tasks = (int)tasks.size();
+    int rc;
+    if ((rc = c->hap_pop.upload(hap_pop, n_hap, c->stream)) != PG_OK) return rc;
+    if ((rc = c->pop_start.upload(pstart.data(), pstart.size(), c->stream)) != PG_OK) return rc;
+    if ((rc = c->samp_start.upload(sstart.data(), sstart.size(), c->stream)) != PG_OK) return rc;
+    if (!tasks.empty() && (rc = c->tasks.upload(tasks.data(), tasks.size(), c->stream)) != PG_OK) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // the resident buffer layout depends on S: drop it
+    c->gt.release();
+    c->cap_sites = 0;
+    return PG_OK;
+}
+
+// ---- resident site buffer ---------------------------------------------------------------------------
+extern "C" int pg_reserve_sites(pg_ctx *c, int64_t n_sites) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    if (n_sites < 0) return pg_fail(PG_ERR_ARG, "n_sites < 0");
+    HIPCHK(hipSetDevice(c->device));
+    if (n_sites <= c->cap_sites) return PG_OK;
+    c->gt.release();
+    int rc = c->gt.alloc((size_t)(n_sites + 32) * c->S);     // +32 rows so a word tile never reads past the end
+    if (rc != PG_OK) return rc;
+    HIPCHK(hipMemsetAsync(c->gt.p, 0, (size_t)(n_sites + 32) * c->S, c->stream));
+    c->cap_sites = n_sites;
+    return PG_OK;
+}
+
+extern "C" int pg_upload_sites(pg_ctx *c, int64_t off, const int8_t *gt, int64_t n) {
+    if (!c || (!gt && n > 0)) return pg_fail(PG_ERR_ARG, "pg_upload_sites: null argument");
+    if (off < 0 || n < 0 || off + n > c->cap_sites) return pg_fail(PG_ERR_ARG, "sites [%lld,%lld) exceed reserved %lld", (long long)off, (long long)(off + n), (long long)c->cap_sites);
+    if (n == 0) return PG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy2DAsync(c->gt.p + off * c->S, c->S, gt, c->n_hap, c->n_hap, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+extern "C" int pg_download_sites(pg_ctx *c, int64_t off, int8_t *gt_out, int64_t n) {
+    if (!c || (!gt_out && n > 0)) return pg_fail(PG_ERR_ARG, "pg_download_sites: null argument");
+    if (off < 0 || n < 0 || off + n > c->cap_sites) return pg_fail(PG_ERR_ARG, "sites out of range");
+    if (n == 0) return PG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy2DAsync(gt_out, c->n_hap, c->gt.p + off * c->S, c->S, c->n_hap, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+// ---- kernel timing ----------------------------------------------------------------------------------
+int pg_time_begin(pg_ctx *c, int k, hipEvent_t *e0, hipEvent_t *e1) {
+    HIPCHK(hipEventCreate(e0));
+    HIPCHK(hipEventCreate(e1));
+    HIPCHK(hipEventRecord(*e0, c->stream));
+    (void)k;
+    return PG_OK;
+}
+
+int pg_time_end(pg_ctx *c, int k, hipEvent_t e0, hipEvent_t e1, int launches) {
+    HIPCHK(hipEventRecord(e1, c->stream));
+    c->events[k].push_back(std::make_pair(e0, e1));
+    c->acc_launches[k] += launches;
+    return PG_OK;
+}
+
+static int fold_events(pg_ctx *c) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < PG_K_COUNT_; ++k) {
+        for (auto &pr : c->events[k]) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+            c->acc_ms[k] += ms;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        c->events[k].clear();
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_kernel_time(pg_ctx *c, int kernel_id, double *ms_out, int64_t *launches_out) {
+    if (!c || kernel_id < 0 || kernel_id >= PG_K_COUNT_) return pg_fail(PG_ERR_ARG, "bad kernel id");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = fold_events(c);
+    if (rc != PG_OK) return rc;
+    if (ms_out) *ms_out = c->acc_ms[kernel_id];
+    if (launches_out) *launches_out = c->acc_launches[kernel_id];
+    return PG_OK;
+}
+
+extern "C" int pg_kernel_time_reset(pg_ctx *c) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = fold_events(c);
+    if (rc != PG_OK) return rc;
+    for (int k = 0; k < PG_K_COUNT_; ++k) { c->acc_ms[k] = 0.0; c->acc_launches[k] = 0; }
+    return PG_OK;
+}
+
+// ---- synthetic fill ---------------------------------------------------------------------------------
+extern "C" int pg_synth_fill(pg_ctx *c, int64_t off, int64_t n, int64_t first_site_index, uint64_t seed,
+                             int64_t scaf_len, int32_t n_dip, int32_t n_pops_gen, const int32_t *slot_gen_hap,
+                             int32_t var_thr, int32_t miss_thr) {
+    if (!c || !slot_gen_hap) return pg_fail(PG_ERR_ARG, "pg_synth_fill: null argument");
+    if (off < 0 || n < 0 || off + n > c->cap_sites) return pg_fail(PG_ERR_ARG, "sites out of reserved range");
+    if (scaf_len < 1 || n_dip < 1 || n_pops_gen < 1) return pg_fail(PG_ERR_ARG, "bad generator parameters");
+    for (int h = 0; h < c->n_hap; ++h)
+        if (slot_gen_hap[h] < 0 || slot_gen_hap[h] >= 2 * n_dip) return pg_fail(PG_ERR_ARG, "slot_gen_hap[%d] out of range", h);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = c->slot_gen.upload(slot_gen_hap, c->n_hap, c->stream);
+    if (rc != PG_OK) return rc;
+    PgSynthParams p;
+    p.seed = seed; p.first_site_index = first_site_index; p.scaf_len = scaf_len;
+    p.n_dip = n_dip; p.n_pops = n_pops_gen; p.var_thr = var_thr; p.miss_thr = miss_thr;
+    hipEvent_t e0, e1;
+    if ((rc = pg_time_begin(c, PG_K_SYNTH, &e0, &e1)) != PG_OK) return rc;
+    pg_launch_synth(c->stream, c->gt.p, c->S, c->n_hap, off, n, c->slot_gen.p, p);
+    if ((rc = pg_time_end(c, PG_K_SYNTH, e0, e1, 1)) != PG_OK) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+// ---- window validation + batching -------------------------------------------------------------------
+static int check_windows(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    if (n_win < 0 || (n_win > 0 && (!lo || !hi))) return pg_fail(PG_ERR_ARG, "bad window arrays");
+    for (int w = 0; w < n_win; ++w) {
+        if (lo[w] < 0 || hi[w] < lo[w] || hi[w] > c->cap_sites)
+            return pg_fail(PG_ERR_ARG, "window %d = [%lld,%lld) outside resident sites [0,%lld)", w, (long long)lo[w], (long long)hi[w], (long long)c->cap_sites);
+        if (hi[w] - lo[w] > 0x7FFFFFFFll) return pg_fail(PG_ERR_ARG, "window %d longer than 2^31-1 sites", w);
+    }
+    return PG_OK;
+}
+
+// Upload lo/hi (+ word offsets) of windows [w0,w1) into ctx->win = [lo | hi | woff(n+1)].
+static int stage_windows(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w0, int w1, int64_t *total_words,
+                         int *max_words, int64_t *max_len) {
+    int n = w1 - w0;
+    std::vector<int64_t> h(3 * (size_t)n + 1);
+    int64_t acc = 0;
+    int mw = 0;
+    int64_t ml = 0;
+    for (int k = 0; k < n; ++k) {
+        h[k] = lo[w0 + k];
+        h[n + k] = hi[w0 + k];
+        h[2 * (size_t)n + k] = acc;
+        int64_t len = hi[w0 + k] - lo[w0 + k];
+        int words = (int)((len + 31) / 32);
+        acc += words;
+        mw = std::max(mw, words);
+        ml = std::max(ml, len);
+    }
+    h[3 * (size_t)n] = acc;
+    if (total_words) *total_words = acc;
+    if (max_words) *max_words = mw;
+    if (max_len) *max_len = ml;
+    int rc = c->win.upload(h.data(), h.size(), c->stream);
+    if (rc != PG_OK) return rc;
+    // the host vector dies at return: the copy must have completed
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+// Run pack + pairwise over windows in batches that fit the scratch budget; `consume(batch_w0, batch_n)` is called
+// with C/D of the batch resident in ctx->Cmat / ctx->Dmat (upper triangle valid).
+template <class F>
+static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, F consume) {
+    const int N = c->n_hap, NP = c->NP;
+    const int64_t mat_bytes = 2ll * N * N * 4;
+    int w0 = 0;
+    while (w0 < n_win) {
+        int64_t words = 0, bytes = 0;
+        int w1 = w0;
+        while (w1 < n_win) {
+            int64_t wlen = (hi[w1] - lo[w1] + 31) / 32;
+            int64_t nb = (words + wlen) * 5ll * NP * 4 + (int64_t)(w1 - w0 + 1) * mat_bytes;
+            if (w1 > w0 && nb > c->scratch_limit) break;
+            words += wlen;
+            bytes = nb;
+            ++w1;
+            if (w1 - w0 >= 65535) break;                      // gridDim.y limit
+        }
+        (void)bytes;
+        const int nb = w1 - w0;
+        int64_t total_words = 0, max_len = 0;
+        int max_words = 0;
+        int rc = stage_windows(c, lo, hi, w0, w1, &total_words, &max_words, &max_len);
+        if (rc != PG_OK) return rc;
+        const int64_t *d_lo = c->win.p, *d_hi = c->win.p + nb, *d_woff = c->win.p + 2 * (size_t)nb;
+        if ((rc = c->planes.ensure((size_t)std::max<int64_t>(total_words, 1) * 5 * NP)) != PG_OK) return rc;
+        if ((rc = c->Cmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
+        if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
+        hipEvent_t e0, e1;
+        if ((rc = pg_time_begin(c, PG_K_PACK, &e0, &e1)) != PG_OK) return rc;
+        pg_launch_pack(c->stream, c->gt.p, c->S, d_lo, d_hi, d_woff, nb, max_words, c->planes.p, NP);
+        if ((rc = pg_time_end(c, PG_K_PACK, e0, e1, 1)) != PG_OK) return rc;
+        if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
+        pg_launch_pairwise(c->stream, c->planes.p, d_woff, nb, c->tasks.p, c->n_tasks, NP, N, c->Cmat.p, c->Dmat.p);
+        if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
+        HIPCHK(hipGetLastError());
+        if ((rc = consume(w0, nb)) != PG_OK) return rc;
+        w0 = w1;
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_pairwise(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int32_t *D_out, int32_t *C_out) {
+    int rc = check_windows(c, lo, hi, n_win);
+    if (rc != PG_OK) return rc;
+    if (n_win > 0 && (!D_out || !C_out)) return pg_fail(PG_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t NN = (size_t)c->n_hap * c->n_hap;
+    rc = pairwise_batches(c, lo, hi, n_win, [&](int w0, int nb) -> int {
+        pg_launch_mirror(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, nb);
+        HIPCHK(hipMemcpyAsync(C_out + (size_t)w0 * NN, c->Cmat.p, nb * NN * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(D_out + (size_t)w0 * NN, c->Dmat.p, nb * NN * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return PG_OK;
+    });
+    return rc;
+}
+
+extern "C" int pg_popdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites,
+                          double *sum_out, int64_t *cnt_out) {
+    int rc = check_windows(c, lo, hi, n_win);
+    if (rc != PG_OK) return rc;
+    if (c->n_pops < 1) return pg_fail(PG_ERR_STATE, "pg_popdist needs at least one population");
+    if (n_win > 0 && (!sum_out || !cnt_out)) return pg_fail(PG_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(c->device));
+    const int npairs = c->n_pops * (c->n_pops + 1) / 2;
+    if ((rc = c->res_f64.ensure((size_t)std::max(n_win, 1) * npairs)) != PG_OK) return rc;
+    if ((rc = c->res_i64.ensure((size_t)std::max(n_win, 1) * npairs)) != PG_OK) return rc;
+    rc = pairwise_batches(c, lo, hi, n_win, [&](int w0, int nb) -> int {
+        hipEvent_t e0, e1;
+        int r = pg_time_begin(c, PG_K_POPDIST_FIN, &e0, &e1);
+        if (r != PG_OK) return r;
+        pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, nb, c->pop_start.p, c->n_pops, min_pair_sites,
+                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs);
+        if ((r = pg_time_end(c, PG_K_POPDIST_FIN, e0, e1, 1)) != PG_OK) return r;
+        HIPCHK(hipGetLastError());
+        return PG_OK;
+    });
+    if (rc != PG_OK) return rc;
+    if (n_win > 0) {
+        HIPCHK(hipMemcpyAsync(sum_out, c->res_f64.p, (size_t)n_win * npairs * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(cnt_out, c->res_i64.p, (size_t)n_win * npairs * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+extern "C" int pg_indpairdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites,
+                              double *sum_out, int64_t *cnt_out) {
+    int rc = check_windows(c, lo, hi, n_win);
+    if (rc != PG_OK) return rc;
+    if (n_win > 0 && (!sum_out || !cnt_out)) return pg_fail(PG_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t npairs = (size_t)c->n_samp * (c->n_samp + 1) / 2;
+    // results are copied back per batch (they can be large for distMat-sized inputs)
+    rc = pairwise_batches(c, lo, hi, n_win, [&](int w0, int nb) -> int {
+        int r;
+        if ((r = c->res_f64.ensure((size_t)nb * npairs)) != PG_OK) return r;
+        if ((r = c->res_i64.ensure((size_t)nb * npairs)) != PG_OK) return r;
+        pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, nb, c->samp_start.p, c->n_samp, min_pair_sites,
+                              c->res_f64.p, c->res_i64.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(sum_out + (size_t)w0 * npairs, c->res_f64.p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(cnt_out + (size_t)w0 * npairs, c->res_i64.p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return PG_OK;
+    });
+    return rc;
+}
+
+// ---- site statistics --------------------------------------------------------------------------------
+extern "C" int pg_abbababa(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int p1, int p2, int p3, int p4,
+                           double min_data, double *sums_out, int64_t *used_out) {
+    int rc = check_windows(c, lo, hi, n_win);
+    if (rc != PG_OK) return rc;
+    const int ps[4] = {p1, p2, p3, p4};
+    for (int k = 0; k < 4; ++k)
+        if (ps[k] < 0 || ps[k] >= c->n_pops) return pg_fail(PG_ERR_ARG, "population id %d out of range [0,%d)", ps[k], c->n_pops);
+    if (n_win == 0) return PG_OK;
+    if (!sums_out || !used_out) return pg_fail(PG_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(c->device));
+    int w0 = 0;
+    while (w0 < n_win) {
+        int w1 = std::min(n_win, w0 + 65535);
+        int nb = w1 - w0;
+        int64_t max_len = 0;
+        if ((rc = stage_windows(c, lo, hi, w0, w1, nullptr, nullptr, &max_len)) != PG_OK) return rc;
+        int max_chunks = (int)((max_len + PG_SITES_PER_BLOCK - 1) / PG_SITES_PER_BLOCK);
+        if ((rc = c->part_f64.ensure((size_t)nb * std::max(max_chunks, 1) * PG_ABBA_NSUM)) != PG_OK) return rc;
+        if ((rc = c->part_i64.ensure((size_t)nb * std::max(max_chunks, 1))) != PG_OK) return rc;
+        if ((rc = c->res_f64.ensure((size_t)nb * PG_ABBA_NSUM)) != PG_OK) return rc;
+        if ((rc = c->res_i64.ensure((size_t)nb)) != PG_OK) return rc;
+        hipEvent_t e0, e1;
+        if ((rc = pg_time_begin(c, PG_K_SITESTATS, &e0, &e1)) != PG_OK) return rc;
+        pg_launch_abba(c->stream, c->gt.p, c->S, c->win.p, c->win.p + nb, nb, max_chunks, c->pop_start.p, p1, p2, p3, p4,
+                       min_data, c->part_f64.p, c->part_i64.p, c->res_f64.p, c->res_i64.p);
+        if ((rc = pg_time_end(c, PG_K_SITESTATS, e0, e1, 1)) != PG_OK) return rc;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(sums_out + (size_t)w0 * PG_ABBA_NSUM, c->res_f64.p, (size_t)nb * PG_ABBA_NSUM * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(used_out + w0, c->res_i64.p, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        w0 = w1;
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_popfreq(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int64_t *l_out, int64_t *S_out,
+                          int64_t *pairsum_out) {
+    int rc = check_windows(c, lo, hi, n_win);
+    if (rc != PG_OK) return rc;
+    if (c->n_pops < 1 || c->n_pops > PG_MAX_POPS) return pg_fail(PG_ERR_ARG, "pg_popfreq supports 1..%d populations (got %d)", PG_MAX_POPS, c->n_pops);
+    if (n_win == 0) return PG_OK;
+    if (!l_out || !S_out || !pairsum_out) return pg_fail(PG_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(c->device));
+    const int P = c->n_pops;
+    int w0 = 0;
+    while (w0 < n_win) {
+        int w1 = std::min(n_win, w0 + 65535);
+        int nb = w1 - w0;
+        int64_t max_len = 0;
+        if ((rc = stage_windows(c, lo, hi, w0, w1, nullptr, nullptr, &max_len)) != PG_OK) return rc;
+        int max_chunks = (int)((max_len + PG_SITES_PER_BLOCK - 1) / PG_SITES_PER_BLOCK);
+        size_t nres = (size_t)nb * (1 + 2 * P);
+        if ((rc = c->res_i64.ensure(nres)) != PG_OK) return rc;
+        HIPCHK(hipMemsetAsync(c->res_i64.p, 0, nres * 8, c->stream));
+        unsigned long long *dl = reinterpret_cast<unsigned long long *>(c->res_i64.p);
+        unsigned long long *dS = dl + nb, *dP = dS + (size_t)nb * P;
+        hipEvent_t e0, e1;
+        if ((rc = pg_time_begin(c, PG_K_SITESTATS, &e0, &e1)) != PG_OK) return rc;
+        pg_launch_popfreq(c->stream, c->gt.p, c->S, c->n_hap, c->win.p, c->win.p + nb, nb, max_chunks, c->pop_start.p, P, dl, dS, dP);
+        if ((rc = pg_time_end(c, PG_K_SITESTATS, e0, e1, 1)) != PG_OK) return rc;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(l_out + w0, dl, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(S_out + (size_t)w0 * P, dS, (size_t)nb * P * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(pairsum_out + (size_t)w0 * P, dP, (size_t)nb * P * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        w0 = w1;
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_site_counts(pg_ctx *c, int64_t site_lo, int64_t site_hi, int32_t *cnt_out) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    if (site_lo < 0 || site_hi < site_lo || site_hi > c->cap_sites) return pg_fail(PG_ERR_ARG, "site range out of bounds");
+    if (c->n_pops < 1) return pg_fail(PG_ERR_STATE, "no populations set");
+    int64_t n = site_hi - site_lo;
+    if (n == 0) return PG_OK;
+    if (!cnt_out) return pg_fail(PG_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t chunk = 1 << 22;
+    DevBuf<int32_t> tmp;
+    int rc = tmp.alloc((size_t)std::min(n, chunk) * c->n_pops * 4);
+    if (rc != PG_OK) return rc;
+    for (int64_t s = site_lo; s < site_hi; s += chunk) {
+        int64_t e = std::min(site_hi, s + chunk);
+        pg_launch_site_counts(c->stream, c->gt.p, c->S, s, e, c->pop_start.p, c->n_pops, tmp.p);
+        hipError_t err = hipGetLastError();
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(cnt_out + (size_t)(s - site_lo) * c->n_pops * 4, tmp.p, (size_t)(e - s) * c->n_pops * 16, hipMemcpyDeviceToHost, c->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+        if (err != hipSuccess) { tmp.release(); return pg_fail(PG_ERR_HIP, "pg_site_counts: %s", hipGetErrorString(err)); }
+    }
+    tmp.release();
+    return PG_OK;
+}
+
+extern "C" int pg_hap_called(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int64_t *called_out) {
+    int rc = check_windows(c, lo, hi, n_win);
+    if (rc != PG_OK) return rc;
+    if (n_win == 0) return PG_OK;
+    if (!called_out) return pg_fail(PG_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(c->device));
+    int w0 = 0;
+    while (w0 < n_win) {
+        int w1 = std::min(n_win, w0 + 65535);
+        int nb = w1 - w0;
+        int64_t max_len = 0;
+        if ((rc = stage_windows(c, lo, hi, w0, w1, nullptr, nullptr, &max_len)) != PG_OK) return rc;
+        int max_chunks = (int)((max_len + PG_SITES_PER_BLOCK - 1) / PG_SITES_PER_BLOCK);
+        size_t nres = (size_t)nb * c->n_hap;
+        if ((rc = c->res_i64.ensure(nres)) != PG_OK) return rc;
+        HIPCHK(hipMemsetAsync(c->res_i64.p, 0, nres * 8, c->stream));
+        pg_launch_hap_called(c->stream, c->gt.p, c->S, c->n_hap, c->win.p, c->win.p + nb, nb, max_chunks,
+                             reinterpret_cast<unsigned long long *>(c->res_i64.p));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(called_out + (size_t)w0 * c->n_hap, c->res_i64.p, nres * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        w0 = w1;
+    }
+    return PG_OK;
+}

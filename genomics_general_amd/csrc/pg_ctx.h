@@ -1,0 +1,81 @@
+// Context object and small device-buffer helper of the C-ABI host layer.
+#pragma once
+#include "../../include/popgen_hip.h"
+#include "pg_internal.h"
+
+#include <utility>
+#include <vector>
+
+#define PG_MAX_HAP 32768
+
+int pg_fail(int code, const char *fmt, ...);
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return pg_fail(PG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return pg_fail(PG_ERR_HIP, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+        }
+        cap = n;
+        return PG_OK;
+    }
+    int ensure(size_t n) { return n <= cap ? PG_OK : alloc(n); }
+    int upload(const T *h, size_t n, hipStream_t st) {
+        int rc = ensure(n);
+        if (rc != PG_OK) return rc;
+        hipError_t e = hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return pg_fail(PG_ERR_HIP, "hipMemcpyAsync H2D: %s", hipGetErrorString(e));
+        return PG_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct pg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // samples
+    int n_hap = 0, n_pops = 0, n_samp = 0;
+    int S = 0;    // bytes per site row of the resident buffer (multiple of 16, pad = 0)
+    int NP = 0;   // haplotype stride of the bit-planes (multiple of 64, pad = 0)
+    int n_tasks = 0;
+    std::vector<int32_t> h_pop_start, h_samp_start;
+    DevBuf<int32_t> hap_pop, pop_start, samp_start, slot_gen;
+    DevBuf<PgPairTask> tasks;
+    // resident sites
+    DevBuf<int8_t> gt;
+    int64_t cap_sites = 0;
+    // scratch
+    int64_t scratch_limit = 16ll << 30;
+    DevBuf<uint32_t> planes;
+    DevBuf<int32_t> Cmat, Dmat;
+    DevBuf<int64_t> win;        // [lo | hi | woff]
+    DevBuf<double> res_f64, part_f64;
+    DevBuf<int64_t> res_i64, part_i64;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events[PG_K_COUNT_];
+    double acc_ms[PG_K_COUNT_] = {0, 0, 0, 0, 0};
+    int64_t acc_launches[PG_K_COUNT_] = {0, 0, 0, 0, 0};
+    // RCCL (opaque here)
+    void *comm = nullptr;
+    int comm_ranks = 0, comm_rank = 0;
+    DevBuf<double> comm_send, comm_recv;
+};
+
+int pg_time_begin(pg_ctx *c, int k, hipEvent_t *e0, hipEvent_t *e1);
+int pg_time_end(pg_ctx *c, int k, hipEvent_t e0, hipEvent_t e1, int launches);

@@ -1,0 +1,205 @@
+// K0: native multi-threaded `.geno` tokenizer (host only; no GPU call).
+// Replaces the reference's per-line Python parsing and per-window string->array conversion:
+//   GenoFileReader.nextSite / parseGenoLine  genomics.py:1940-1945, 1884-1904
+//   splitSeq / forceHomo / seqArrayToNumArray genomics.py:390-396, 407-408, 74-77
+// Output is the engine's one-hot int8 code (A=1 C=2 G=4 T=8, everything else 0 = missing) written straight
+// into device-slot order, plus int32 positions and the location of each row's scaffold token.
+#include "pg_ctx.h"
+
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+namespace {
+
+struct CodeTables {
+    uint8_t base[256];        // allele char -> one-hot
+    uint8_t dip[256][2];      // IUPAC diploid char -> two one-hot codes (genomics.py:14-15)
+    CodeTables() {
+        memset(base, 0, sizeof(base));
+        base[(int)'A'] = 1; base[(int)'C'] = 2; base[(int)'G'] = 4; base[(int)'T'] = 8;
+        memset(dip, 0, sizeof(dip));
+        const char *d = "ACGKMNSRTWY";
+        const char *pr[] = {"AA", "CC", "GG", "GT", "AC", "NN", "CG", "AG", "TT", "AT", "CT"};
+        for (int k = 0; d[k]; ++k) {
+            dip[(int)d[k]][0] = base[(int)pr[k][0]];
+            dip[(int)d[k]][1] = base[(int)pr[k][1]];
+        }
+    }
+};
+const CodeTables T;
+
+inline bool is_ws(char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f'; }
+
+struct Shared {
+    const char *buf;
+    size_t len;
+    int fmt, n_cols, max_ploidy, n_hap;
+    const int32_t *col_slot, *col_ploidy;
+    int8_t *gt;
+    int32_t *pos;
+    int64_t *scaf_off;
+    int32_t *scaf_len;
+    int64_t cap;
+    std::atomic<int> err;
+    char msg[256];
+};
+
+// Is the line [b,e) a data row?  ('#' comment lines and whitespace-only lines are not.)
+inline bool data_line(const char *b, const char *e) {
+    if (b >= e || *b == '#') return false;
+    for (const char *p = b; p < e; ++p)
+        if (!is_ws(*p)) return true;
+    return false;
+}
+
+int64_t count_rows(const char *b, const char *e) {
+    int64_t n = 0;
+    while (b < e) {
+        const char *nl = static_cast<const char *>(memchr(b, '\n', e - b));
+        const char *le = nl ? nl : e;
+        if (data_line(b, le)) ++n;
+        b = le + 1;
+    }
+    return n;
+}
+
+void set_err(Shared &sh, const char *what, int64_t row, int col) {
+    int expected = 0;
+    if (sh.err.compare_exchange_strong(expected, 1))
+        snprintf(sh.msg, sizeof(sh.msg), "%s (data row %lld, genotype column %d)", what, (long long)row, col);
+}
+
+void parse_range(Shared &sh, const char *b, const char *e, int64_t row) {
+    const int H = sh.n_hap;
+    while (b < e && !sh.err.load(std::memory_order_relaxed)) {
+        const char *nl = static_cast<const char *>(memchr(b, '\n', e - b));
+        const char *le = nl ? nl : e;
+        if (data_line(b, le)) {
+            if (row >= sh.cap) { set_err(sh, "more rows than output capacity", row, -1); return; }
+            const char *p = b;
+            while (p < le && is_ws(*p)) ++p;
+            const char *s0 = p;
+            while (p < le && !is_ws(*p)) ++p;
+            sh.scaf_off[row] = s0 - sh.buf;
+            sh.scaf_len[row] = (int32_t)(p - s0);
+            while (p < le && is_ws(*p)) ++p;
+            // position: optional sign + digits (Python int())
+            bool neg = false;
+            if (p < le && (*p == '+' || *p == '-')) { neg = (*p == '-'); ++p; }
+            if (p >= le || *p < '0' || *p > '9') { set_err(sh, "position is not an integer", row, -1); return; }
+            int64_t v = 0;
+            while (p < le && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); if (v > 0x7FFFFFFFll) break; ++p; }
+            if (v > 0x7FFFFFFFll || (p < le && !is_ws(*p))) { set_err(sh, "position is not a 32-bit integer", row, -1); return; }
+            sh.pos[row] = (int32_t)(neg ? -v : v);
+            int8_t *out = sh.gt + (size_t)row * H;
+            memset(out, 0, H);
+            for (int c = 0; c < sh.n_cols; ++c) {
+                while (p < le && is_ws(*p)) ++p;
+                const char *c0 = p;
+                while (p < le && !is_ws(*p)) ++p;
+                const int w = (int)(p - c0);
+                if (w == 0) { set_err(sh, "row has fewer genotype columns than the header", row, c); return; }
+                const int pl = sh.col_ploidy[c];
+                if (pl <= 0) continue;
+                const int32_t *slots = sh.col_slot + (size_t)c * sh.max_ploidy;
+                switch (sh.fmt) {
+                    case PG_FMT_PHASED:
+                        if (w != 2 * pl - 1) { set_err(sh, "Sample ploidy doesn't match number of sequences (cell width)", row, c); return; }
+                        for (int k = 0; k < pl; ++k) out[slots[k]] = (int8_t)T.base[(uint8_t)c0[2 * k]];
+                        break;
+                    case PG_FMT_PAIRS:
+                    case PG_FMT_HAPLO:
+                        if (w != pl) { set_err(sh, "Sample ploidy doesn't match number of sequences (cell width)", row, c); return; }
+                        for (int k = 0; k < pl; ++k) out[slots[k]] = (int8_t)T.base[(uint8_t)c0[k]];
+                        break;
+                    default:  // PG_FMT_DIPLO
+                        if (w != 1 || pl != 2) { set_err(sh, "Sample ploidy doesn't match number of sequences (diplo cell)", row, c); return; }
+                        out[slots[0]] = (int8_t)T.dip[(uint8_t)c0[0]][0];
+                        out[slots[1]] = (int8_t)T.dip[(uint8_t)c0[0]][1];
+                        break;
+                }
+            }
+            ++row;
+        }
+        b = le + 1;
+    }
+}
+
+}  // namespace
+
+extern "C" int pg_count_lines(const char *buf, size_t len, int64_t *n_rows_out) {
+    if ((!buf && len) || !n_rows_out) return pg_fail(PG_ERR_ARG, "pg_count_lines: null argument");
+    *n_rows_out = count_rows(buf, buf + len);
+    return PG_OK;
+}
+
+extern "C" int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
+                              const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int32_t *pos_out, int64_t *scaf_off,
+                              int32_t *scaf_len, int64_t cap_sites, int64_t *n_sites_out, int n_threads) {
+    if ((!buf && len) || !col_slot || !col_ploidy || !n_sites_out) return pg_fail(PG_ERR_ARG, "pg_encode_text: null argument");
+    if (cap_sites > 0 && (!gt_out || !pos_out || !scaf_off || !scaf_len)) return pg_fail(PG_ERR_ARG, "pg_encode_text: null output");
+    if (fmt < PG_FMT_PHASED || fmt > PG_FMT_DIPLO) return pg_fail(PG_ERR_ARG, "unknown genotype format %d", fmt);
+    if (n_cols < 0 || max_ploidy < 1 || n_hap < 1) return pg_fail(PG_ERR_ARG, "bad column description");
+    for (int c = 0; c < n_cols; ++c) {
+        if (col_ploidy[c] < 0 || col_ploidy[c] > max_ploidy) return pg_fail(PG_ERR_ARG, "col_ploidy[%d] out of range", c);
+        for (int k = 0; k < col_ploidy[c]; ++k) {
+            int s = col_slot[(size_t)c * max_ploidy + k];
+            if (s < 0 || s >= n_hap) return pg_fail(PG_ERR_ARG, "col_slot[%d][%d]=%d out of range", c, k, s);
+        }
+        if (fmt == PG_FMT_DIPLO && col_ploidy[c] != 0 && col_ploidy[c] != 2)
+            return pg_fail(PG_ERR_PARSE, "Sample ploidy (%d) doesn't match number of sequences (2): diplo format is diploid", col_ploidy[c]);
+    }
+    *n_sites_out = 0;
+    if (len == 0) return PG_OK;
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if ((size_t)nt > len / (1 << 16) + 1) nt = (int)(len / (1 << 16) + 1);
+    // chunk boundaries at line starts
+    std::vector<size_t> cut(nt + 1, len);
+    cut[0] = 0;
+    for (int t = 1; t < nt; ++t) {
+        size_t guess = len / nt * t;
+        if (guess < cut[t - 1]) guess = cut[t - 1];
+        const char *nl = static_cast<const char *>(memchr(buf + guess, '\n', len - guess));
+        cut[t] = nl ? (size_t)(nl - buf) + 1 : len;
+    }
+    std::vector<int64_t> cnt(nt, 0);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() { cnt[t] = count_rows(buf + cut[t], buf + cut[t + 1]); });
+        for (auto &x : th) x.join();
+    }
+    std::vector<int64_t> base(nt + 1, 0);
+    for (int t = 0; t < nt; ++t) base[t + 1] = base[t] + cnt[t];
+    if (base[nt] > cap_sites) return pg_fail(PG_ERR_ARG, "text holds %lld rows but output capacity is %lld", (long long)base[nt], (long long)cap_sites);
+    Shared sh;
+    sh.buf = buf; sh.len = len; sh.fmt = fmt; sh.n_cols = n_cols; sh.max_ploidy = max_ploidy; sh.n_hap = n_hap;
+    sh.col_slot = col_slot; sh.col_ploidy = col_ploidy; sh.gt = gt_out; sh.pos = pos_out; sh.scaf_off = scaf_off;
+    sh.scaf_len = scaf_len; sh.cap = cap_sites; sh.err = 0; sh.msg[0] = 0;
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() { parse_range(sh, buf + cut[t], buf + cut[t + 1], base[t]); });
+        for (auto &x : th) x.join();
+    }
+    if (sh.err.load()) return pg_fail(PG_ERR_PARSE, "%s", sh.msg);
+    *n_sites_out = base[nt];
+    return PG_OK;
+}
+
+extern "C" int pg_scaffold_runs(const char *buf, const int64_t *scaf_off, const int32_t *scaf_len, int64_t n_sites,
+                                int64_t *run_start_out, int64_t max_runs, int64_t *n_runs_out) {
+    if (!n_runs_out || (n_sites > 0 && (!buf || !scaf_off || !scaf_len))) return pg_fail(PG_ERR_ARG, "pg_scaffold_runs: null argument");
+    int64_t n = 0;
+    for (int64_t i = 0; i < n_sites; ++i) {
+        bool same = i > 0 && scaf_len[i] == scaf_len[i - 1] &&
+                    memcmp(buf + scaf_off[i], buf + scaf_off[i - 1], (size_t)scaf_len[i]) == 0;
+        if (!same) {
+            if (n < max_runs && run_start_out) run_start_out[n] = i;
+            ++n;
+        }
+    }
+    *n_runs_out = n;
+    if (n > max_runs) return pg_fail(PG_ERR_ARG, "%lld scaffold runs exceed capacity %lld", (long long)n, (long long)max_runs);
+    return PG_OK;
+}

@@ -1,0 +1,52 @@
+// Internal declarations shared by the HIP kernels (pg_kernels.hip) and the C-ABI host layer (pg_abi.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PG_MAX_POPS 16          // populations handled by the site-statistics kernels (K3/K6 take any number)
+#define PG_SITES_PER_BLOCK 1024 // sites reduced by one block of the site-statistics kernels
+#define PG_ABBA_NSUM 6
+
+struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,row0+8*nsub) x cols [col0,col0+64)
+    int32_t row0, nsub, col0, pad;
+};
+
+struct PgSynthParams {
+    uint64_t seed;
+    int64_t first_site_index, scaf_len;
+    int32_t n_dip, n_pops, var_thr, miss_thr;
+};
+
+// ---- launchers (all asynchronous on `st`) -----------------------------------------------------------
+void pg_launch_synth(hipStream_t st, int8_t *gt, int S, int n_hap, int64_t site0, int64_t n_sites,
+                     const int32_t *slot_gen_hap, PgSynthParams p);
+
+void pg_launch_pack(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
+                    const int64_t *woff, int n_win, int max_words, uint32_t *planes, int NP);
+
+void pg_launch_pairwise(hipStream_t st, const uint32_t *planes, const int64_t *woff, int n_win,
+                        const PgPairTask *tasks, int n_tasks, int NP, int N, int32_t *Cmat, int32_t *Dmat);
+
+void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int n_win,
+                           const int32_t *pop_start, int n_pops, int min_pair_sites, double *sum_out,
+                           int64_t *cnt_out);
+
+void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int n_win,
+                           const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,
+                           int64_t *cnt_out);
+
+void pg_launch_mirror(hipStream_t st, int32_t *Cmat, int32_t *Dmat, int N, int n_win);
+
+void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
+                    int n_win, int max_chunks, const int32_t *pop_start, int p1, int p2, int p3, int p4,
+                    double min_data, double *part_sums, int64_t *part_used, double *sums_out, int64_t *used_out);
+
+void pg_launch_popfreq(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
+                       const int64_t *win_hi, int n_win, int max_chunks, const int32_t *pop_start, int n_pops,
+                       unsigned long long *l_out, unsigned long long *S_out, unsigned long long *pairsum_out);
+
+void pg_launch_site_counts(hipStream_t st, const int8_t *gt, int S, int64_t site_lo, int64_t site_hi,
+                           const int32_t *pop_start, int n_pops, int32_t *cnt_out);
+
+void pg_launch_hap_called(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
+                          const int64_t *win_hi, int n_win, int max_chunks, unsigned long long *out);

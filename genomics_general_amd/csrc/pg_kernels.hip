@@ -1,0 +1,654 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the per-window statistics path.
+//
+//   K_pack      site-major one-hot int8 rows  ->  per-window bit-planes [word][plane A,C,G,T,V][hap]
+//   K_pairwise  bit-planes -> C[i][j] (#sites both called) and D[i][j] (#both called & differ)
+//               (replaces genomics.py:903-916, 1042-1047, 1219-1221)
+//   K_popdist   D,C -> per population-pair float64 sums of D/C + valid-pair counts (genomics.py:956-995)
+//   K_indpair   D,C -> per individual-pair sums/counts (genomics.py:934-954)
+//   K_abba      per-site population base counts -> ABBA/BABA/f4 window sums (genomics.py:1647-1695)
+//   K_popfreq   per-site population base counts -> l, S, sum of allele-pair products (genomics.py:1002-1028)
+//   K_counts    raw per-site per-population base counts (genomics.py:1049-1052)
+//   K_synth     counter-based synthetic genotype generator (spec: genomics_general_amd/synth.py)
+//
+// Integer work is exact; float64 work is compiled with -ffp-contract=off so the per-site products are the
+// same IEEE operations, in the same order, as the NumPy expressions of the reference.
+#include "pg_internal.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------------
+// K_synth
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_synth(int8_t *__restrict__ gt, int S, int n_hap, int64_t site0,
+                                               int64_t n_sites, const int32_t *__restrict__ slot_gen_hap,
+                                               PgSynthParams p) {
+    const int groups = S >> 2;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t site = idx / groups;
+    int g = (int)(idx - site * groups);
+    if (site >= n_sites) return;
+    int64_t gi = p.first_site_index + site;
+    uint64_t scaf = (uint64_t)(gi / p.scaf_len);
+    uint64_t pos = (uint64_t)(gi % p.scaf_len) + 1ull;
+    uint64_t ks = mix64(mix64(p.seed ^ (scaf * 0xD6E8FEB86659FD93ull)) ^ pos);
+    int ref = (int)(ks & 3ull);
+    bool variable = (int)((ks >> 2) & 0xFFFFull) < p.var_thr;
+    int altoff = (int)((ks >> 18) & 0xFFull) % 3;
+    int alt = (ref + 1 + altoff) & 3;
+    bool has3 = (int)((ks >> 26) & 0xFFFFull) < 655;
+    int third = (ref + 1 + (altoff + 1) % 3) & 3;
+    int64_t p16 = (int64_t)((ks >> 42) & 0xFFFFull);
+    uint32_t word = 0;
+    for (int k = 0; k < 4; ++k) {
+        int h = 4 * g + k;
+        if (h >= n_hap) break;
+        int gh = slot_gen_hap[h];
+        int dip = gh >> 1;
+        int pop = (int)(((int64_t)dip * p.n_pops) / p.n_dip);
+        uint64_t kp = mix64(ks ^ (0xA24BAED4963EE407ull * (uint64_t)(pop + 1)));
+        int64_t z = (int64_t)(kp & 0xFFFFull) + (int64_t)((kp >> 16) & 0xFFFFull) +
+                    (int64_t)((kp >> 32) & 0xFFFFull) + (int64_t)((kp >> 48) & 0xFFFFull) - 131070;
+        int64_t v = p16 + ((z * 17027) >> 16);
+        v = v < 0 ? 0 : (v > 65535 ? 65535 : v);
+        if (pop == p.n_pops - 1 && p.n_pops > 1) {
+            if ((int)(mix64(kp) & 0xFFFFull) < 52429) v = 0;
+        }
+        uint64_t kh = mix64(ks ^ (0x9FB21C651E98DF25ull * (uint64_t)(gh + 1)));
+        bool derived = (int64_t)(kh & 0xFFFFull) < v;
+        bool use3 = has3 && ((int)((kh >> 16) & 0xFFull) < 26);
+        uint64_t kd = mix64(ks ^ (0xC2B2AE3D27D4EB4Full * (uint64_t)(dip + 1)));
+        bool missing = (int)((kd >> 8) & 0xFFFFull) < p.miss_thr;
+        int allele = ref;
+        if (variable && derived) allele = use3 ? third : alt;
+        uint32_t code = missing ? 0u : (1u << allele);
+        word |= code << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(gt + (site0 + site) * (int64_t)S + 4 * g) = word;
+}
+
+void pg_launch_synth(hipStream_t st, int8_t *gt, int S, int n_hap, int64_t site0, int64_t n_sites,
+                     const int32_t *slot_gen_hap, PgSynthParams p) {
+    int64_t total = n_sites * (S >> 2);
+    if (total <= 0) return;
+    int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, st, gt, S, n_hap, site0, n_sites, slot_gen_hap, p);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_pack: 32 sites x 4 haplotypes per thread, SWAR bit gathering.
+//   gt row = S bytes (S % 16 == 0, pad bytes zero).  A thread owns haplotypes 4g..4g+3 and builds, for each
+//   of the four allele planes, the 32-site word of each of its haplotypes.  Bit order inside a word is
+//   arbitrary but identical for every haplotype, which is all popcount needs.  Tail sites of a window are
+//   zero bits (not called) so they contribute to neither C nor D.
+//   planes[(woff[b]+w)*5*NP + p*NP + h], p = 0..3 allele planes, 4 = valid (called) plane.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t byte_gather(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, int k) {
+    return ((a0 >> (8 * k)) & 0xFFu) | (((a1 >> (8 * k)) & 0xFFu) << 8) | (((a2 >> (8 * k)) & 0xFFu) << 16) |
+           (((a3 >> (8 * k)) & 0xFFu) << 24);
+}
+
+template <int TPW>
+__global__ __launch_bounds__(256) void k_pack(const int8_t *__restrict__ gt, int S,
+                                              const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
+                                              const int64_t *__restrict__ woff, uint32_t *__restrict__ planes, int NP) {
+    constexpr int WPB = 256 / TPW;                       // words per block
+    const int b = blockIdx.y;
+    const int64_t lo = win_lo[b], hi = win_hi[b];
+    const int nwords = (int)(woff[b + 1] - woff[b]);
+    const int w = blockIdx.x * WPB + threadIdx.x / TPW;
+    if (w >= nwords) return;
+    const int t = threadIdx.x % TPW;
+    const int64_t s0 = lo + 32ll * w;
+    const int ns = (int)((hi - s0) < 32 ? (hi - s0) : 32);
+    uint32_t *outw = planes + (size_t)(woff[b] + w) * 5u * (size_t)NP;
+    const int ngroups = NP >> 2;
+    for (int g = t; g < ngroups; g += TPW) {
+        uint32_t acc[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[p][q] = 0u;
+        if (4 * g < S) {
+            const int8_t *src = gt + s0 * (int64_t)S + 4 * g;
+            if (ns == 32) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t d[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s)
+                        d[s] = *reinterpret_cast<const uint32_t *>(src + (int64_t)(q * 8 + s) * S);
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[p][q] = (acc[p][q] << 1) | ((d[s] >> p) & 0x01010101u);
+                    }
+                }
+            } else {
+                for (int si = 0; si < ns; ++si) {
+                    uint32_t d = *reinterpret_cast<const uint32_t *>(src + (int64_t)si * S);
+                    int q = si >> 3;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        uint32_t bit = (d >> p) & 0x01010101u;
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq)
+                            if (qq == q) acc[p][qq] = (acc[p][qq] << 1) | bit;
+                    }
+                }
+            }
+        }
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint4 o;
+            o.x = byte_gather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], 0);
+            o.y = byte_gather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], 1);
+            o.z = byte_gather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], 2);
+            o.w = byte_gather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], 3);
+            v.x |= o.x; v.y |= o.y; v.z |= o.z; v.w |= o.w;
+            *reinterpret_cast<uint4 *>(outw + (size_t)p * NP + 4 * g) = o;
+        }
+        *reinterpret_cast<uint4 *>(outw + (size_t)4 * NP + 4 * g) = v;
+    }
+}
+
+void pg_launch_pack(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
+                    const int64_t *woff, int n_win, int max_words, uint32_t *planes, int NP) {
+    if (n_win <= 0 || max_words <= 0) return;
+    int groups = NP >> 2;
+    if (groups <= 64) {
+        hipLaunchKernelGGL(k_pack<64>, dim3((max_words + 3) / 4, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi, woff, planes, NP);
+    } else if (groups <= 128) {
+        hipLaunchKernelGGL(k_pack<128>, dim3((max_words + 1) / 2, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi, woff, planes, NP);
+    } else {
+        hipLaunchKernelGGL(k_pack<256>, dim3(max_words, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi, woff, planes, NP);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_pairwise.  One wave = rows [row0, row0+8*NSUB) x 64 columns of one window.
+//   Column (j) operands: one VGPR per plane per lane, coalesced 256-byte loads (hap-minor layout).
+//   Row (i) operands: wave-uniform -> scalar loads into SGPRs, used directly as VALU source operands, so the
+//   row side costs no vector memory traffic, no LDS and no VGPRs.
+//   Per (row, word): v_and + v_bcnt (C) ; v_and + 3 x v_and_or + v_bcnt (same-allele) = 7 VALU for 32 sites
+//   of 64 pairs.  D = C - same.  Accumulators: 2 x 8*NSUB VGPRs.
+//   Grid is 1-D and XCD-aware: hardware places block b on XCD b % 8; all waves of one window are given to
+//   the same XCD so the window's planes are fetched from HBM once into that XCD's L2 and re-read from there.
+// ------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(4))) const uint32_t CU32;
+
+template <int NSUB>
+__device__ __forceinline__ void pair_body(const uint32_t *__restrict__ base, int nwords, int NP, int row0, int j,
+                                          int lane_valid, int N, int col_j, int32_t *__restrict__ Cw,
+                                          int32_t *__restrict__ Dw) {
+    constexpr int R = 8 * NSUB;
+    uint32_t accC[R], accS[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { accC[r] = 0u; accS[r] = 0u; }
+    const size_t wstride = (size_t)5 * NP;
+    for (int w = 0; w < nwords; ++w) {
+        const uint32_t *pw = base + (size_t)w * wstride;
+        const uint32_t ja = pw[j], jc = pw[NP + j], jg = pw[2 * NP + j], jt = pw[3 * NP + j], jv = pw[4 * NP + j];
+        // wave-uniform address in the constant address space -> s_load_dwordx8 into SGPRs
+        const CU32 *pr = (const CU32 *)(pw + row0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t ia = pr[r], ic = pr[NP + r], ig = pr[2 * NP + r], it = pr[3 * NP + r], iv = pr[4 * NP + r];
+            accC[r] += __popc(iv & jv);
+            accS[r] += __popc((ia & ja) | (ic & jc) | (ig & jg) | (it & jt));
+        }
+    }
+    if (lane_valid) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = row0 + r;
+            if (i < col_j && i < N) {
+                Cw[(size_t)i * N + col_j] = (int32_t)accC[r];
+                Dw[(size_t)i * N + col_j] = (int32_t)(accC[r] - accS[r]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pairwise(const uint32_t *__restrict__ planes, const int64_t *__restrict__ woff,
+                                                  int n_win, const PgPairTask *__restrict__ tasks, int n_tasks,
+                                                  int tasks_wg, int NP, int N, int32_t *__restrict__ Cmat,
+                                                  int32_t *__restrict__ Dmat) {
+    const int xcd = blockIdx.x & 7;
+    const int v = blockIdx.x >> 3;
+    const int win = (v / tasks_wg) * 8 + xcd;
+    if (win >= n_win) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int t = (v % tasks_wg) * 4 + wave;
+    if (t >= n_tasks) return;
+    const PgPairTask tk = tasks[t];
+    const int row0 = __builtin_amdgcn_readfirstlane(tk.row0);
+    const int nsub = __builtin_amdgcn_readfirstlane(tk.nsub);
+    const int col0 = __builtin_amdgcn_readfirstlane(tk.col0);
+    const int64_t w0 = woff[win];
+    const int nwords = (int)(woff[win + 1] - w0);
+    const uint32_t *base = planes + (size_t)w0 * 5u * (size_t)NP;
+    const int j = col0 + lane;
+    const int lane_valid = j < N;
+    int32_t *Cw = Cmat + (size_t)win * N * N;
+    int32_t *Dw = Dmat + (size_t)win * N * N;
+    switch (nsub) {
+        case 1: pair_body<1>(base, nwords, NP, row0, j, lane_valid, N, j, Cw, Dw); break;
+        case 2: pair_body<2>(base, nwords, NP, row0, j, lane_valid, N, j, Cw, Dw); break;
+        case 3: pair_body<3>(base, nwords, NP, row0, j, lane_valid, N, j, Cw, Dw); break;
+        default: pair_body<4>(base, nwords, NP, row0, j, lane_valid, N, j, Cw, Dw); break;
+    }
+}
+
+void pg_launch_pairwise(hipStream_t st, const uint32_t *planes, const int64_t *woff, int n_win,
+                        const PgPairTask *tasks, int n_tasks, int NP, int N, int32_t *Cmat, int32_t *Dmat) {
+    if (n_win <= 0 || n_tasks <= 0) return;
+    int tasks_wg = (n_tasks + 3) / 4;
+    int64_t blocks = (int64_t)((n_win + 7) / 8) * tasks_wg * 8;
+    hipLaunchKernelGGL(k_pairwise, dim3((unsigned)blocks), dim3(256), 0, st, planes, woff, n_win, tasks, n_tasks,
+                       tasks_wg, NP, N, Cmat, Dmat);
+}
+
+// Fill the lower triangle and the diagonal (pg_pairwise returns full symmetric matrices to the host).
+__global__ __launch_bounds__(256) void k_mirror(int32_t *__restrict__ Cmat, int32_t *__restrict__ Dmat, int N) {
+    int32_t *Cw = Cmat + (size_t)blockIdx.y * N * N;
+    int32_t *Dw = Dmat + (size_t)blockIdx.y * N * N;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N * N; idx += gridDim.x * blockDim.x) {
+        int i = idx / N, j = idx - i * N;
+        if (i == j) { Cw[idx] = 0; Dw[idx] = 0; }
+        else if (i > j) { Cw[idx] = Cw[(size_t)j * N + i]; Dw[idx] = Dw[(size_t)j * N + i]; }
+    }
+}
+
+void pg_launch_mirror(hipStream_t st, int32_t *Cmat, int32_t *Dmat, int N, int n_win) {
+    if (n_win <= 0) return;
+    int bx = (N * N + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_mirror, dim3(bx, n_win), dim3(256), 0, st, Cmat, Dmat, N);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Deterministic block reductions (fixed thread partition + fixed tree).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_f64(double v, double *sh) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (t < s) sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (t < s) sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    unsigned long long r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_popdist: one block per (population pair, window).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat,
+                                                     int N, const int32_t *__restrict__ pop_start, int n_pops,
+                                                     int min_pair_sites, double *__restrict__ sum_out,
+                                                     int64_t *__restrict__ cnt_out) {
+    __shared__ double shd[256];
+    __shared__ unsigned long long shu[256];
+    // decode pair index -> (x<=y)
+    int pidx = blockIdx.x, x = 0;
+    int rem = pidx;
+    while (rem >= n_pops - x) { rem -= n_pops - x; ++x; }
+    const int y = x + rem;
+    const int win = blockIdx.y;
+    const int32_t *Cw = Cmat + (size_t)win * N * N;
+    const int32_t *Dw = Dmat + (size_t)win * N * N;
+    const int xs = pop_start[x], xe = pop_start[x + 1], ys = pop_start[y], ye = pop_start[y + 1];
+    const int nx = xe - xs, ny = ye - ys;
+    const int thr = min_pair_sites > 1 ? min_pair_sites : 1;
+    double sum = 0.0;
+    unsigned long long cnt = 0;
+    const long long total = (long long)nx * ny;
+    for (long long idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int i = xs + (int)(idx / ny), j = ys + (int)(idx % ny);
+        if (x == y && i >= j) continue;
+        const int c = Cw[(size_t)i * N + j];
+        if (c >= thr) {
+            sum += (double)Dw[(size_t)i * N + j] / (double)c;
+            ++cnt;
+        }
+    }
+    sum = block_sum_f64(sum, shd);
+    cnt = block_sum_u64(cnt, shu);
+    if (threadIdx.x == 0) {
+        const int npairs = n_pops * (n_pops + 1) / 2;
+        sum_out[(size_t)win * npairs + pidx] = sum;
+        cnt_out[(size_t)win * npairs + pidx] = (int64_t)cnt;
+    }
+}
+
+void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int n_win,
+                           const int32_t *pop_start, int n_pops, int min_pair_sites, double *sum_out,
+                           int64_t *cnt_out) {
+    if (n_win <= 0 || n_pops <= 0) return;
+    int npairs = n_pops * (n_pops + 1) / 2;
+    hipLaunchKernelGGL(k_popdist_fin, dim3(npairs, n_win), dim3(256), 0, st, Cmat, Dmat, N, pop_start, n_pops,
+                       min_pair_sites, sum_out, cnt_out);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_indpair: one thread per unordered individual pair (s<=t); haplotype slots of an individual are contiguous.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat,
+                                                     int N, const int32_t *__restrict__ samp_start, int n_samp,
+                                                     int min_pair_sites, double *__restrict__ sum_out,
+                                                     int64_t *__restrict__ cnt_out) {
+    const int win = blockIdx.y;
+    const long long npairs = (long long)n_samp * (n_samp + 1) / 2;
+    const int32_t *Cw = Cmat + (size_t)win * N * N;
+    const int32_t *Dw = Dmat + (size_t)win * N * N;
+    const int thr = min_pair_sites > 1 ? min_pair_sites : 1;
+    for (long long pidx = (long long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs;
+         pidx += (long long)gridDim.x * blockDim.x) {
+        // row s of the upper triangle starts at s*n - s(s-1)/2
+        long long lo = 0, hi = n_samp - 1;
+        while (lo < hi) {
+            long long mid = (lo + hi + 1) >> 1;
+            long long start = mid * n_samp - mid * (mid - 1) / 2;
+            if (start <= pidx) lo = mid; else hi = mid - 1;
+        }
+        const int s = (int)lo;
+        const int t = s + (int)(pidx - ((long long)s * n_samp - (long long)s * (s - 1) / 2));
+        double sum = 0.0;
+        long long cnt = 0;
+        for (int a = samp_start[s]; a < samp_start[s + 1]; ++a)
+            for (int b = samp_start[t]; b < samp_start[t + 1]; ++b) {
+                if (s == t && a >= b) continue;
+                const int c = Cw[(size_t)a * N + b];
+                if (c >= thr) { sum += (double)Dw[(size_t)a * N + b] / (double)c; ++cnt; }
+            }
+        sum_out[(size_t)win * npairs + pidx] = sum;
+        cnt_out[(size_t)win * npairs + pidx] = cnt;
+    }
+}
+
+void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int n_win,
+                           const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,
+                           int64_t *cnt_out) {
+    if (n_win <= 0 || n_samp <= 0) return;
+    long long npairs = (long long)n_samp * (n_samp + 1) / 2;
+    int bx = (int)((npairs + 255) / 256);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(k_indpair_fin, dim3(bx, n_win), dim3(256), 0, st, Cmat, Dmat, N, samp_start, n_samp,
+                       min_pair_sites, sum_out, cnt_out);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Per-site population base counts (SWAR on one-hot bytes): cnt[b] = #haplotypes of [s,e) with allele b.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void range_counts(const int8_t *__restrict__ row, int s, int e, uint32_t cnt[4]) {
+    cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0u;
+    if (e <= s) return;
+    const int d0 = s >> 2, d1 = (e - 1) >> 2;
+    for (int d = d0; d <= d1; ++d) {
+        uint32_t v = *reinterpret_cast<const uint32_t *>(row + 4 * d);
+        const int lo = (s > 4 * d ? s - 4 * d : 0), hi = (e < 4 * d + 4 ? e - 4 * d : 4);
+        uint32_t m = (hi == 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
+        v &= m;
+        cnt[0] += __popc(v & 0x01010101u);
+        cnt[1] += __popc(v & 0x02020202u);
+        cnt[2] += __popc(v & 0x04040404u);
+        cnt[3] += __popc(v & 0x08080808u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_abba: grid (chunk, window); 256 threads x 4 sites.  Per-site terms follow genomics.py:1409-1475 and
+// 1565-1569 operation for operation; per-block partial sums are combined by k_abba_reduce in chunk order.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double f4_term(double a, double b, double c, double d) {
+    return (1 - a) * b * c * (1 - d) - a * (1 - b) * c * (1 - d);
+}
+
+__global__ __launch_bounds__(256) void k_abba(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
+                                              const int64_t *__restrict__ win_hi, int max_chunks,
+                                              const int32_t *__restrict__ pop_start, int q1, int q2, int q3, int q4,
+                                              double min_data, double *__restrict__ part_sums,
+                                              int64_t *__restrict__ part_used) {
+    __shared__ double shd[256];
+    __shared__ unsigned long long shu[256];
+    const int win = blockIdx.y, chunk = blockIdx.x;
+    const int64_t lo = win_lo[win], hi = win_hi[win];
+    const int64_t c0 = lo + (int64_t)chunk * PG_SITES_PER_BLOCK;
+    double acc[PG_ABBA_NSUM];
+#pragma unroll
+    for (int k = 0; k < PG_ABBA_NSUM; ++k) acc[k] = 0.0;
+    unsigned long long used = 0;
+    const int ps[4] = {pop_start[q1], pop_start[q2], pop_start[q3], pop_start[q4]};
+    const int pe[4] = {pop_start[q1 + 1], pop_start[q2 + 1], pop_start[q3 + 1], pop_start[q4 + 1]};
+    if (c0 < hi) {
+        for (int k = 0; k < PG_SITES_PER_BLOCK / 256; ++k) {
+            const int64_t site = c0 + k * 256 + threadIdx.x;
+            if (site >= hi) break;
+            const int8_t *row = gt + site * (int64_t)S;
+            uint32_t cnt[4][4];
+            uint32_t n[4], tot[4] = {0u, 0u, 0u, 0u};
+            bool enough = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                range_counts(row, ps[q], pe[q], cnt[q]);
+                n[q] = cnt[q][0] + cnt[q][1] + cnt[q][2] + cnt[q][3];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) tot[b] += cnt[q][b];
+                enough = enough && ((double)n[q] * 1. / (double)(pe[q] - ps[q]) >= min_data);   // genomics.py:1657-1660
+            }
+            const int nall = (tot[0] > 0) + (tot[1] > 0) + (tot[2] > 0) + (tot[3] > 0);
+            if (nall != 2 || !enough) continue;                                                    // :1655, :1662
+            const uint32_t ntot = n[0] + n[1] + n[2] + n[3];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                // alleleIndex = where((all4freqs > 0) & (P4freqs == 0)), genomics.py:1672; freqs are count/n
+                const double allf = (double)tot[b] / (double)ntot;
+                const double f4q = (double)cnt[3][b] / (double)n[3];
+                if (!(allf > 0.0) || !(f4q == 0.0)) continue;
+                const double p1 = (double)cnt[0][b] / (double)n[0];
+                const double p2 = (double)cnt[1][b] / (double)n[1];
+                const double p3 = (double)cnt[2][b] / (double)n[2];
+                const double p4 = f4q;
+                const double abba = (1 - p1) * p2 * p3 * (1 - p4);
+                const double baba = p1 * (1 - p2) * p3 * (1 - p4);
+                acc[0] += f4_term(p1, p2, p3, p4);
+                acc[1] += abba + baba;
+                const double pd = p2 * (double)(p2 > p3) + p3 * (double)(p3 >= p2);              // :1446
+                acc[2] += f4_term(p1, pd, pd, p4);
+                const bool a = p3 > p1, bb = p3 > p2, x = p1 > p2, y = !x;                       // :1460-1468
+                const double xa = (double)(x && a), nxa = (double)(!(x && a));
+                const double yb = (double)(y && bb), nyb = (double)(!(y && bb));
+                const double pdm1 = p3 * xa + p1 * nxa;
+                const double pdm2 = p3 * yb + p2 * nyb;
+                const double pdm3 = -p3 * xa + p3 * yb - p1 * (double)(x && !a) + p2 * (double)(y && !bb);
+                acc[3] += f4_term(pdm1, pdm2, pdm3, p4);
+                acc[4] += abba;
+                acc[5] += baba;
+                ++used;
+            }
+        }
+    }
+    const size_t o = (size_t)win * max_chunks + chunk;
+#pragma unroll
+    for (int k = 0; k < PG_ABBA_NSUM; ++k) {
+        const double r = block_sum_f64(acc[k], shd);
+        if (threadIdx.x == 0) part_sums[o * PG_ABBA_NSUM + k] = r;
+    }
+    const unsigned long long u = block_sum_u64(used, shu);
+    if (threadIdx.x == 0) part_used[o] = (int64_t)u;
+}
+
+__global__ void k_abba_reduce(const double *__restrict__ part_sums, const int64_t *__restrict__ part_used, int n_win,
+                              int max_chunks, const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
+                              double *__restrict__ sums_out, int64_t *__restrict__ used_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int win = idx / (PG_ABBA_NSUM + 1), k = idx % (PG_ABBA_NSUM + 1);
+    if (win >= n_win) return;
+    const int64_t len = win_hi[win] - win_lo[win];
+    const int nch = (int)((len + PG_SITES_PER_BLOCK - 1) / PG_SITES_PER_BLOCK);
+    if (k < PG_ABBA_NSUM) {
+        double s = 0.0;
+        for (int c = 0; c < nch; ++c) s += part_sums[((size_t)win * max_chunks + c) * PG_ABBA_NSUM + k];
+        sums_out[(size_t)win * PG_ABBA_NSUM + k] = s;
+    } else {
+        int64_t u = 0;
+        for (int c = 0; c < nch; ++c) u += part_used[(size_t)win * max_chunks + c];
+        used_out[win] = u;
+    }
+}
+
+void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
+                    int n_win, int max_chunks, const int32_t *pop_start, int p1, int p2, int p3, int p4,
+                    double min_data, double *part_sums, int64_t *part_used, double *sums_out, int64_t *used_out) {
+    if (n_win <= 0) return;
+    if (max_chunks > 0)
+        hipLaunchKernelGGL(k_abba, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi, max_chunks,
+                           pop_start, p1, p2, p3, p4, min_data, part_sums, part_used);
+    int total = n_win * (PG_ABBA_NSUM + 1);
+    hipLaunchKernelGGL(k_abba_reduce, dim3((total + 255) / 256), dim3(256), 0, st, part_sums, part_used, n_win,
+                       max_chunks, win_lo, win_hi, sums_out, used_out);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_popfreq: exact integers, so the cross-block combination uses integer atomics (order independent).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_popfreq(const int8_t *__restrict__ gt, int S, int n_hap,
+                                                 const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
+                                                 const int32_t *__restrict__ pop_start, int n_pops,
+                                                 unsigned long long *__restrict__ l_out,
+                                                 unsigned long long *__restrict__ S_out,
+                                                 unsigned long long *__restrict__ pairsum_out) {
+    __shared__ unsigned long long shu[256];
+    const int win = blockIdx.y, chunk = blockIdx.x;
+    const int64_t lo = win_lo[win], hi = win_hi[win];
+    const int64_t c0 = lo + (int64_t)chunk * PG_SITES_PER_BLOCK;
+    if (c0 >= hi) return;
+    unsigned long long l = 0, Sx[PG_MAX_POPS], Px[PG_MAX_POPS];
+#pragma unroll
+    for (int q = 0; q < PG_MAX_POPS; ++q) { Sx[q] = 0; Px[q] = 0; }
+    for (int k = 0; k < PG_SITES_PER_BLOCK / 256; ++k) {
+        const int64_t site = c0 + k * 256 + threadIdx.x;
+        if (site >= hi) break;
+        const int8_t *row = gt + site * (int64_t)S;
+        uint32_t call[4];
+        range_counts(row, 0, n_hap, call);
+        if ((int)(call[0] + call[1] + call[2] + call[3]) != n_hap) continue;       // genomics.py:1010
+        ++l;
+#pragma unroll
+        for (int q = 0; q < PG_MAX_POPS; ++q) {
+            if (q < n_pops) {
+                uint32_t c[4];
+                range_counts(row, pop_start[q], pop_start[q + 1], c);
+                const unsigned long long pr = (unsigned long long)c[0] * c[1] + (unsigned long long)c[0] * c[2] +
+                                              (unsigned long long)c[0] * c[3] + (unsigned long long)c[1] * c[2] +
+                                              (unsigned long long)c[1] * c[3] + (unsigned long long)c[2] * c[3];
+                Px[q] += pr;
+                Sx[q] += (pr != 0ull);
+            }
+        }
+    }
+    unsigned long long r = block_sum_u64(l, shu);
+    if (threadIdx.x == 0 && r) atomicAdd(&l_out[win], r);
+    for (int q = 0; q < n_pops; ++q) {
+        r = block_sum_u64(Sx[q], shu);
+        if (threadIdx.x == 0 && r) atomicAdd(&S_out[(size_t)win * n_pops + q], r);
+        r = block_sum_u64(Px[q], shu);
+        if (threadIdx.x == 0 && r) atomicAdd(&pairsum_out[(size_t)win * n_pops + q], r);
+    }
+}
+
+void pg_launch_popfreq(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
+                       const int64_t *win_hi, int n_win, int max_chunks, const int32_t *pop_start, int n_pops,
+                       unsigned long long *l_out, unsigned long long *S_out, unsigned long long *pairsum_out) {
+    if (n_win <= 0 || max_chunks <= 0) return;
+    hipLaunchKernelGGL(k_popfreq, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, n_hap, win_lo, win_hi, pop_start,
+                       n_pops, l_out, S_out, pairsum_out);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_counts: cnt[site][pop][4]
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_site_counts(const int8_t *__restrict__ gt, int S, int64_t site_lo,
+                                                     int64_t site_hi, const int32_t *__restrict__ pop_start, int n_pops,
+                                                     int32_t *__restrict__ cnt_out) {
+    const int64_t site = site_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (site >= site_hi) return;
+    const int8_t *row = gt + site * (int64_t)S;
+    for (int q = 0; q < n_pops; ++q) {
+        uint32_t c[4];
+        range_counts(row, pop_start[q], pop_start[q + 1], c);
+        int4 o = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);
+        *reinterpret_cast<int4 *>(cnt_out + ((size_t)(site - site_lo) * n_pops + q) * 4) = o;
+    }
+}
+
+void pg_launch_site_counts(hipStream_t st, const int8_t *gt, int S, int64_t site_lo, int64_t site_hi,
+                           const int32_t *pop_start, int n_pops, int32_t *cnt_out) {
+    int64_t n = site_hi - site_lo;
+    if (n <= 0 || n_pops <= 0) return;
+    hipLaunchKernelGGL(k_site_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gt, S, site_lo, site_hi,
+                       pop_start, n_pops, cnt_out);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_called: per-window, per-haplotype number of called sites (Alignment.seqNonNan, genomics.py:1038-1040).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hap_called(const int8_t *__restrict__ gt, int S, int n_hap,
+                                                    const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
+                                                    unsigned long long *__restrict__ out) {
+    const int win = blockIdx.y;
+    const int64_t lo = win_lo[win], hi = win_hi[win];
+    const int64_t c0 = lo + (int64_t)blockIdx.x * PG_SITES_PER_BLOCK;
+    if (c0 >= hi) return;
+    const int64_t c1 = (c0 + PG_SITES_PER_BLOCK < hi) ? c0 + PG_SITES_PER_BLOCK : hi;
+    for (int g = threadIdx.x; 4 * g < n_hap; g += blockDim.x) {
+        uint32_t tot[4] = {0u, 0u, 0u, 0u};
+        uint32_t acc = 0u;
+        int pending = 0;
+        for (int64_t s = c0; s < c1; ++s) {
+            const uint32_t d = *reinterpret_cast<const uint32_t *>(gt + s * (int64_t)S + 4 * g);
+            acc += (d | (d >> 1) | (d >> 2) | (d >> 3)) & 0x01010101u;
+            if (++pending == 255) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tot[k] += (acc >> (8 * k)) & 0xFFu;
+                acc = 0u;
+                pending = 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tot[k] += (acc >> (8 * k)) & 0xFFu;
+            if (4 * g + k < n_hap && tot[k]) atomicAdd(&out[(size_t)win * n_hap + 4 * g + k], (unsigned long long)tot[k]);
+        }
+    }
+}
+
+void pg_launch_hap_called(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
+                          const int64_t *win_hi, int n_win, int max_chunks, unsigned long long *out) {
+    if (n_win <= 0 || max_chunks <= 0) return;
+    hipLaunchKernelGGL(k_hap_called, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, n_hap, win_lo, win_hi, out);
+}

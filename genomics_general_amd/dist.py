@@ -1,0 +1,149 @@
+"""Multi-GPU sharding of windows: one process per GPU, windows split into contiguous ranges, one RCCL all-gather
+of the per-window result table (C1 in SURVEY.md section 2.2; replaces the sorter/writer re-ordering of
+popgenWindows.py:108-157).  Windows are independent, so there is no other data-path communication.
+
+Launch contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment (what
+`python -m torch.distributed.run` sets).  The product path does not import torch: the 128-byte RCCL unique id is
+handed from rank 0 to the other ranks of the node through an atomically renamed file in /tmp, everything else goes
+through RCCL in libpopgen_hip.so.  `GlooComm` (torch.distributed, backend gloo) exists for the CPU tests of the
+sharding / gather logic.
+"""
+import os
+import time
+
+import numpy as np
+
+
+class World:
+    def __init__(self, rank=0, size=1, local_rank=0):
+        self.rank, self.size, self.local_rank = rank, size, local_rank
+
+
+def world_from_env(env=None):
+    env = os.environ if env is None else env
+    size = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    return World(rank, size, int(env.get("LOCAL_RANK", str(rank))))
+
+
+def shard_range(n_items, size, rank):
+    """Contiguous balanced split: ranks [0, n%size) get one extra item."""
+    base, extra = divmod(n_items, size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_counts(n_items, size):
+    return [shard_range(n_items, size, r)[1] - shard_range(n_items, size, r)[0] for r in range(size)]
+
+
+# ---- rendezvous of the RCCL unique id ------------------------------------------------------------------
+def _rdzv_path():
+    if os.environ.get("PG_RDZV_FILE"):
+        return os.environ["PG_RDZV_FILE"]
+    key = "%s_%s_%s_%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"),
+                           os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+    return os.path.join("/tmp", "pg_rdzv_" + key.replace("/", "_"))
+
+
+def exchange_unique_id(world, make_id, timeout_s=180.0):
+    """rank 0 creates the id and publishes it; the others wait for the file.  Single node only."""
+    path = _rdzv_path()
+    if world.rank == 0:
+        uid = make_id()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid, path
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid, path
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError("rank %d: no RCCL unique id at %s after %.0f s" % (world.rank, path, timeout_s))
+        time.sleep(0.01)
+
+
+# ---- communicators (same small interface) ------------------------------------------------------------------
+class SoloComm:
+    size, rank = 1, 0
+
+    def allgather(self, arr):
+        return np.asarray(arr, dtype=np.float64).reshape(1, -1)
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class RcclComm:
+    """RCCL communicator owned by an Engine's ctx (pg_comm_* of the C-ABI)."""
+
+    def __init__(self, engine, world):
+        from .engine import Engine
+        self.e, self.size, self.rank = engine, world.size, world.rank
+        uid, path = exchange_unique_id(world, Engine.comm_unique_id)
+        engine.comm_setup(world.size, world.rank, uid)
+        engine.comm_barrier()
+        if world.rank == 0:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+    def allgather(self, arr):
+        return self.e.comm_allgather(arr)
+
+    def barrier(self):
+        self.e.comm_barrier()
+
+    def close(self):
+        pass
+
+
+class GlooComm:
+    """CPU stand-in with the same interface (tests only): torch.distributed, backend gloo."""
+
+    def __init__(self, world):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=world.rank, world_size=world.size)
+        self.size, self.rank = world.size, world.rank
+
+    def allgather(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64).ravel().copy())
+        outs = [self.torch.zeros_like(t) for _ in range(self.size)]
+        self.dist.all_gather(outs, t)
+        return np.stack([o.numpy() for o in outs])
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        if self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def gather_table(comm, local_rows, n_total):
+    """All ranks hold rows of their contiguous window shard ([n_local][k] float64); returns the full
+    [n_total][k] table in window order on every rank.  One all-gather of equal-size (padded) blocks."""
+    local_rows = np.asarray(local_rows, dtype=np.float64)
+    k = local_rows.shape[1] if local_rows.ndim == 2 else 1
+    local_rows = local_rows.reshape(-1, k)
+    counts = shard_counts(n_total, comm.size)
+    assert local_rows.shape[0] == counts[comm.rank], "shard size mismatch"
+    width = max(counts) if counts else 0
+    pad = np.zeros((width, k), dtype=np.float64)
+    pad[:local_rows.shape[0]] = local_rows
+    allr = comm.allgather(pad.ravel()).reshape(comm.size, width, k)
+    return np.concatenate([allr[r, :counts[r]] for r in range(comm.size)], axis=0) if n_total else np.zeros((0, k))

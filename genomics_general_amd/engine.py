@@ -1,0 +1,307 @@
+"""Host side of the MI355X engine: a ctypes-driven context plus `WindowBatch`, which plays the role the
+list of per-window `genomics.Alignment` objects plays in the reference's worker loop
+(popgenWindows.py:44-52, ABBABABAwindows.py:37-38, distMat.py:39-42).
+
+`WindowBatch` keeps the reference's method names, argument meaning and result keys:
+    groupDistStats(doPairs, minSites, minData)  -> genomics.py:956-995
+    groupFreqStats()                            -> genomics.py:1002-1028
+    indPairDists(includeSameWithSame, minSites) -> genomics.py:934-954
+    ABBABABA(P1, P2, P3, P4, minData)           -> genomics.py:1647-1695
+    pairCounts()                                -> the integers behind distMatrix()/pairNonNan()
+All per-site / per-pair work happens in HIP kernels; what is left here is the O(populations^2) float64
+finalisation per window, written with the same NumPy expressions as the reference.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+def encode_text(buf, layout, n_threads=0):
+    """K0 host tokenizer.  buf: bytes of complete `.geno` data lines (no header).
+    Returns (gt int8 [L][n_hap] in slot order, pos int32 [L], scaf_off int64 [L], scaf_len int32 [L])."""
+    L = _lib.lib()
+    n = C.c_int64(0)
+    check(L.pg_count_lines(buf, len(buf), C.byref(n)))
+    cap = max(int(n.value), 1)
+    gt = np.zeros((cap, layout.n_hap), dtype=np.int8)
+    pos = np.zeros(cap, dtype=np.int32)
+    soff = np.zeros(cap, dtype=np.int64)
+    slen = np.zeros(cap, dtype=np.int32)
+    got = C.c_int64(0)
+    check(L.pg_encode_text(buf, len(buf), _lib.FMT[layout.genoFormat], len(layout.col_ploidy), layout.max_ploidy,
+                           np.ascontiguousarray(layout.col_slot), layout.col_ploidy, layout.n_hap, gt, pos, soff, slen,
+                           cap, C.byref(got), n_threads))
+    k = int(got.value)
+    return gt[:k], pos[:k], soff[:k], slen[:k]
+
+
+class Engine:
+    """One device context (pg_ctx).  Not thread-safe; one per GPU."""
+
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        check(self._L.pg_ctx_create(C.byref(h), device))
+        self._h = h
+        self.device = device
+        self.layout = None
+        self.n_sites = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- configuration / data ---------------------------------------------------------------
+    def set_layout(self, layout):
+        check(self._L.pg_set_samples(self._h, layout.n_hap, layout.hap_pop, layout.hap_sample, layout.n_pops))
+        self.layout = layout
+        self.n_sites = 0
+
+    def reserve(self, n_sites):
+        check(self._L.pg_reserve_sites(self._h, int(n_sites)))
+        self.n_sites = max(self.n_sites, int(n_sites))
+
+    def upload(self, gt, offset=0):
+        gt = np.ascontiguousarray(gt, dtype=np.int8)
+        assert gt.ndim == 2 and gt.shape[1] == self.layout.n_hap
+        check(self._L.pg_upload_sites(self._h, int(offset), gt, gt.shape[0]))
+
+    def load_sites(self, gt):
+        self.reserve(len(gt))
+        self.upload(gt, 0)
+
+    def download(self, offset, n):
+        out = np.zeros((n, self.layout.n_hap), dtype=np.int8)
+        check(self._L.pg_download_sites(self._h, int(offset), out, n))
+        return out
+
+    def synth_fill(self, offset, n_sites, first_site_index, seed, scaf_len, n_dip, n_pops_gen, slot_gen_hap,
+                   var_thr, miss_thr):
+        check(self._L.pg_synth_fill(self._h, int(offset), int(n_sites), int(first_site_index), int(seed), int(scaf_len),
+                                    int(n_dip), int(n_pops_gen), np.ascontiguousarray(slot_gen_hap, dtype=np.int32),
+                                    int(var_thr), int(miss_thr)))
+
+    def sync(self):
+        check(self._L.pg_sync(self._h))
+
+    def set_scratch_limit(self, nbytes):
+        check(self._L.pg_set_scratch_limit(self._h, int(nbytes)))
+
+    def kernel_time(self, kernel_id):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(self._L.pg_kernel_time(self._h, kernel_id, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def kernel_time_reset(self):
+        check(self._L.pg_kernel_time_reset(self._h))
+
+    def batch(self, win_lo, win_hi):
+        return WindowBatch(self, win_lo, win_hi)
+
+    # ---- multi-GPU ---------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        check(_lib.lib().pg_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, n_ranks, rank, uid):
+        check(self._L.pg_comm_init(self._h, n_ranks, rank, uid))
+
+    def comm_allgather(self, send):
+        send = np.ascontiguousarray(send, dtype=np.float64).ravel()
+        recv = np.zeros(send.size * self._comm_ranks(), dtype=np.float64)
+        check(self._L.pg_comm_allgather_f64(self._h, send, recv, send.size))
+        return recv.reshape(self._comm_ranks(), -1)
+
+    def _comm_ranks(self):
+        return self._n_ranks
+
+    def comm_setup(self, n_ranks, rank, uid):
+        self.comm_init(n_ranks, rank, uid)
+        self._n_ranks = n_ranks
+
+    def comm_barrier(self):
+        check(self._L.pg_comm_barrier(self._h))
+
+
+def _nanmean_min(total, n_valid, size, minimum):
+    """nanmean_min (genomics.py:88-90) of a block holding `size` cells of which `n_valid` are not nan and sum to
+    `total` (arrays over windows)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        frac_ok = 1 - (1. * (size - n_valid) / size) >= minimum if size else np.zeros_like(n_valid, dtype=bool)
+        mean = total / n_valid
+    return np.where(frac_ok & (n_valid > 0), mean, np.nan)
+
+
+class WindowBatch:
+    """Statistics of a set of windows [lo,hi) of the engine's resident sites."""
+
+    def __init__(self, engine, win_lo, win_hi):
+        self.e = engine
+        self.lay = engine.layout
+        self.lo = np.ascontiguousarray(win_lo, dtype=np.int64)
+        self.hi = np.ascontiguousarray(win_hi, dtype=np.int64)
+        self.n = len(self.lo)
+        self._popdist_min_sites = None     # set once groupDistStats has "masked the cached matrix"
+
+    # -- integers ---------------------------------------------------------------------------------
+    def pairCounts(self, reference_order=True):
+        """D[w][i][j], C[w][i][j] (int32).  reference_order: rows/cols permuted to the reference's
+        sorted-haplotype-name order (genomics.py:1122); otherwise device slot order."""
+        N = self.lay.n_hap
+        D = np.zeros((self.n, N, N), dtype=np.int32)
+        Cc = np.zeros((self.n, N, N), dtype=np.int32)
+        check(self.e._L.pg_pairwise(self.e._h, self.lo, self.hi, self.n, D, Cc))
+        if reference_order:
+            o = self.lay.ref_order
+            D = D[:, o][:, :, o]
+            Cc = Cc[:, o][:, :, o]
+        return D, Cc
+
+    def hapCalled(self):
+        """seqNonNan per window: int64 [n_win][n_hap] in device slot order (genomics.py:1038-1040)."""
+        out = np.zeros((self.n, self.lay.n_hap), dtype=np.int64)
+        check(self.e._L.pg_hap_called(self.e._h, self.lo, self.hi, self.n, out))
+        return out
+
+    def siteCounts(self, site_lo, site_hi):
+        out = np.zeros((site_hi - site_lo, self.lay.n_pops, 4), dtype=np.int32)
+        check(self.e._L.pg_site_counts(self.e._h, int(site_lo), int(site_hi), out))
+        return out
+
+    # -- popDist / popPairDist ----------------------------------------------------------------------
+    def groupDistStats(self, doPairs=True, minSites=None, minData=0.01):
+        lay = self.lay
+        P = lay.n_pops
+        npairs = P * (P + 1) // 2
+        sums = np.zeros((self.n, npairs), dtype=np.float64)
+        cnts = np.zeros((self.n, npairs), dtype=np.int64)
+        ms = int(minSites) if minSites else 0
+        check(self.e._L.pg_popdist(self.e._h, self.lo, self.hi, self.n, ms, sums, cnts))
+        self._popdist_min_sites = ms
+        names = lay.sampleData.popNames
+        size = lay.pop_sizes
+        out = {}
+        pi = []
+        for x in range(P):
+            k = lay.pop_pair_index(x, x)
+            # block(x,x) holds every unordered pair twice plus a nan diagonal (genomics.py:963, 976)
+            v = _nanmean_min(2 * sums[:, k], 2 * cnts[:, k], size[x] * size[x], minData)
+            pi.append(v)
+            out["pi_" + names[x]] = v
+        if P > 1 and doPairs:
+            for x in range(P - 1):
+                for y in range(x + 1, P):
+                    k = lay.pop_pair_index(x, y)
+                    dxy = _nanmean_min(sums[:, k], cnts[:, k], size[x] * size[y], minData)
+                    out["dxy_%s_%s" % (names[x], names[y])] = out["dxy_%s_%s" % (names[y], names[x])] = dxy
+                    kx, ky = lay.pop_pair_index(x, x), lay.pop_pair_index(y, y)
+                    nx, ny = size[x], size[y]
+                    w = 1. * nx / (nx + ny)                                      # genomics.py:988-991
+                    pi_s = w * pi[x] + (1 - w) * pi[y]
+                    tot = 2 * sums[:, kx] + 2 * sums[:, ky] + 2 * sums[:, k]
+                    cnt = 2 * cnts[:, kx] + 2 * cnts[:, ky] + 2 * cnts[:, k]
+                    pi_t = _nanmean_min(tot, cnt, (nx + ny) * (nx + ny), minData)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        fst = 1 - pi_s / pi_t
+                    out["Fst_%s_%s" % (names[x], names[y])] = out["Fst_%s_%s" % (names[y], names[x])] = fst
+        return out
+
+    # -- popFreq --------------------------------------------------------------------------------------
+    def groupFreqStats(self):
+        lay = self.lay
+        P = lay.n_pops
+        l = np.zeros(self.n, dtype=np.int64)
+        S = np.zeros((self.n, P), dtype=np.int64)
+        prs = np.zeros((self.n, P), dtype=np.int64)
+        check(self.e._L.pg_popfreq(self.e._h, self.lo, self.hi, self.n, l, S, prs))
+        out = {}
+        has = l >= 1
+        for x, name in enumerate(lay.sampleData.popNames):
+            N = lay.pop_sizes[x]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                denom = .5 * N * (N - 1)
+                theta_pi = np.where(has, prs[:, x] / np.float64(denom), np.nan)
+                a = np.sum(1. / np.arange(1, N))
+                theta_w = np.where(has, S[:, x] / a, np.nan)
+                taj = np.where(has, _tajima_d(N, S[:, x].astype(np.float64), theta_pi), np.nan)
+            out["l_" + name] = l
+            out["S_" + name] = np.where(has, S[:, x].astype(np.float64), np.nan)
+            out["S_int_" + name] = S[:, x]
+            out["thetaPi_" + name] = theta_pi
+            out["thetaW_" + name] = theta_w
+            out["TajD_" + name] = taj
+        return out
+
+    # -- indPairDist -------------------------------------------------------------------------------------
+    def indPairDists(self, includeSameWithSame=False, minSites=None):
+        """{name: {name: array over windows}} like Alignment.indPairDists(asDict=True).  As in the reference
+        (which mutates its cached distance matrix), a preceding groupDistStats leaves its minSites mask and nan
+        diagonal in force."""
+        lay = self.lay
+        n = lay.n_samp
+        npairs = n * (n + 1) // 2
+        sums = np.zeros((self.n, npairs), dtype=np.float64)
+        cnts = np.zeros((self.n, npairs), dtype=np.int64)
+        ms = int(minSites) if minSites else 0
+        diag_nan = not includeSameWithSame
+        if self._popdist_min_sites is not None:
+            ms = max(ms, self._popdist_min_sites)
+            diag_nan = True
+        check(self.e._L.pg_indpairdist(self.e._h, self.lo, self.hi, self.n, ms, sums, cnts))
+        out = {a: {} for a in lay.ind_order}
+        for s in range(n):
+            pl = len(lay.ind_slots[lay.ind_order[s]])
+            for t in range(s, n):
+                k = lay.sample_pair_index(s, t)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    if s != t:
+                        v = np.where(cnts[:, k] > 0, sums[:, k] / cnts[:, k], np.nan)
+                    elif diag_nan:
+                        v = np.where(cnts[:, k] > 0, (2 * sums[:, k]) / (2 * cnts[:, k]), np.nan)
+                    else:       # the zero diagonal of distMatrix() counts as data (genomics.py:940)
+                        v = (2 * sums[:, k]) / (2 * cnts[:, k] + pl)
+                out[lay.ind_order[s]][lay.ind_order[t]] = v
+                out[lay.ind_order[t]][lay.ind_order[s]] = v
+        return out
+
+    # -- ABBA-BABA ----------------------------------------------------------------------------------------
+    def ABBABABA(self, P1, P2, P3, P4, minData):
+        names = self.lay.sampleData.popNames
+        ids = [names.index(p) for p in (P1, P2, P3, P4)]
+        sums = np.zeros((self.n, 6), dtype=np.float64)
+        used = np.zeros(self.n, dtype=np.int64)
+        check(self.e._L.pg_abbababa(self.e._h, self.lo, self.hi, self.n, ids[0], ids[1], ids[2], ids[3], float(minData),
+                                    sums, used))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out = {"D": sums[:, 0] * 1. / sums[:, 1], "fd": sums[:, 0] * 1. / sums[:, 2], "fdM": sums[:, 0] * 1. / sums[:, 3],
+                   "ABBA": sums[:, 4], "BABA": sums[:, 5], "sitesUsed": used}
+        return out
+
+
+def _tajima_d(n, S, theta_pi):
+    """genomics.py:619-632 on arrays (n scalar)."""
+    if n < 2:
+        return np.full_like(theta_pi, np.nan)
+    a = sum(1. / i for i in range(1, n))
+    theta_w = 1. * S / a
+    a2 = sum(1. / (i ** 2) for i in range(1, n))
+    b1 = (n + 1.) / (3 * (n - 1))
+    b2 = (2. * (n ** 2 + n + 3)) / (9 * n * (n - 1))
+    c1 = b1 - (1. / a)
+    c2 = b2 - ((n + 2) / (a * n)) + a2 / (a ** 2)
+    e1 = c1 / a
+    e2 = c2 / (a ** 2 + a2)
+    d = theta_pi - theta_w
+    return d / np.sqrt(e1 * S + e2 * S * (S - 1))

@@ -1,0 +1,70 @@
+"""`.geno` input for the drop-in drivers: header handling + bulk tokenisation through the C-ABI (K0).
+
+Replaces the line-at-a-time GenoFileReader (genomics.py:1914-1945).  The file format is unchanged:
+whitespace separated, first line `#CHROM POS name...` (or `--header` text), `.gz` by suffix, stdin if no file.
+"""
+import ctypes as C
+import gzip
+import sys
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .engine import encode_text
+
+
+def read_all(path):
+    """Whole input as bytes (gunzipped when the name ends in .gz; stdin when path is None)."""
+    if path is None:
+        return sys.stdin.buffer.read()
+    if str(path).endswith(".gz"):
+        with gzip.open(path, "rb") as f:
+            return f.read()
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def read_header_names(path):
+    """Sample names of the file's first line (popgenWindows.py:284-286, distMat.py:205-206)."""
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "rt") as f:
+        return f.readline().split()[2:]
+
+
+def split_header(data, header_line=None):
+    """(sample names, data bytes after the header).  With --header the file has no header line
+    (GenoFileReader.__init__, genomics.py:1917-1919)."""
+    if header_line:
+        return header_line.split()[2:], data
+    nl = data.find(b"\n")
+    first = data if nl < 0 else data[:nl]
+    rest = b"" if nl < 0 else data[nl + 1:]
+    return first.decode("utf-8", "replace").split()[2:], rest
+
+
+class GenoData:
+    """Encoded input: one-hot int8 genotypes in device slot order, positions and scaffold runs."""
+
+    def __init__(self, gt, pos, run_starts, run_names):
+        self.gt, self.pos, self.run_starts, self.run_names = gt, pos, run_starts, run_names
+        self.n_sites = len(pos)
+
+
+def encode(data, layout, n_threads=0):
+    gt, pos, soff, slen = encode_text(data, layout, n_threads)
+    n = len(pos)
+    L = _lib.lib()
+    cap = 1024
+    while True:
+        starts = np.zeros(cap, dtype=np.int64)
+        nr = C.c_int64(0)
+        rc = L.pg_scaffold_runs(data, soff, slen, n, starts, cap, C.byref(nr))
+        if nr.value > cap:
+            cap = int(nr.value)
+            continue
+        check(rc)
+        break
+    starts = starts[:nr.value]
+    names = [data[int(soff[i]):int(soff[i]) + int(slen[i])].decode("utf-8", "replace") for i in starts]
+    return GenoData(gt, pos, starts, names)

@@ -1,0 +1,209 @@
+"""Window index computation: which sites land in which window, and which (possibly empty) windows exist.
+
+The reference does this one text line at a time inside Python generators (genomics.py:1971-2223).  Here the
+positions of the whole input are already an int32 array (K0), so windows are computed as index ranges
+[lo,hi) into it with searchsorted, reproducing the generators' observable behaviour:
+
+  slidingCoordWindows   genomics.py:1971-2027  -> coord_windows
+  slidingSitesWindows   genomics.py:2032-2108  -> sites_windows
+  predefinedCoordWindows genomics.py:2112-2171 -> predefined_windows
+
+including their quirks: the first window of every scaffold run is [1,windSize]; empty windows are emitted;
+windows stop at the first one whose end reaches the run's last site; the window that precedes a skipped
+(--exclude / not --include) scaffold is emitted a second time when more wanted data follows.  Positions must be
+non-decreasing inside a scaffold run (the reference silently drops out-of-order sites; we raise).
+Not reproduced: the reference's infinite loop at EOF under --include.
+"""
+import numpy as np
+
+
+class WindowTable:
+    """Columns of the emitted windows, in emission order."""
+
+    def __init__(self):
+        self.scaffold, self.start, self.end, self.lo, self.hi, self.ID = [], [], [], [], [], []
+
+    def add(self, scaffold, start, end, lo, hi, ID):
+        self.scaffold.append(scaffold)
+        self.start.append(start)
+        self.end.append(end)
+        self.lo.append(lo)
+        self.hi.append(hi)
+        self.ID.append(ID)
+
+    def finish(self, positions):
+        self.lo = np.asarray(self.lo, dtype=np.int64)
+        self.hi = np.asarray(self.hi, dtype=np.int64)
+        self.n = len(self.lo)
+        self.sites = self.hi - self.lo
+        # GenoWindow.midPos (genomics.py:1795-1797): int(round(sum/len)), nan when empty
+        csum = np.concatenate([[0], np.cumsum(np.asarray(positions, dtype=np.int64))])
+        tot = csum[self.hi] - csum[self.lo]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mean = tot / self.sites
+        self.mid = [int(np.rint(m)) if s > 0 else float("nan") for m, s in zip(mean, self.sites)]
+        return self
+
+
+def _wanted(scaf, include, exclude):                 # genomics.py:2016
+    if not include and not exclude:
+        return True
+    if include:
+        return scaf in include
+    return scaf not in exclude
+
+
+def _check_sorted(positions, a, b, scaf):
+    p = positions[a:b]
+    if len(p) > 1 and np.any(p[1:] < p[:-1]):
+        raise ValueError("positions of scaffold %s are not sorted; sliding windows need sorted input" % scaf)
+
+
+def _runs(run_starts, n_sites):
+    ends = list(run_starts[1:]) + [n_sites]
+    return list(zip([int(x) for x in run_starts], [int(x) for x in ends]))
+
+
+def coord_windows(run_starts, run_names, positions, windSize, stepSize, include=None, exclude=None):
+    """All windows slidingCoordWindows would yield.  run_starts[r] = first row of scaffold run r."""
+    positions = np.asarray(positions)
+    T = WindowTable()
+    done = 0
+    pending = None                       # last emitted window, re-emitted if a skipped run is followed by a wanted one
+    runs = _runs(run_starts, len(positions))
+    skipped_since = False
+    for r, (a, b) in enumerate(runs):
+        scaf = run_names[r]
+        if not _wanted(scaf, include, exclude):
+            skipped_since = True
+            continue
+        if skipped_since and pending is not None:
+            done += 1
+            T.add(*pending)              # same ID as its first emission (genomics.py:2001-2005 keeps window.ID)
+        skipped_since = False
+        _check_sorted(positions, a, b, scaf)
+        p = positions[a:b].astype(np.int64)
+        last = int(p[-1])
+        k_last = 0 if last <= windSize else -((windSize - last) // stepSize)      # ceil((last-w)/step)
+        k = np.arange(k_last + 1, dtype=np.int64)
+        starts = 1 + k * stepSize
+        ends = windSize + k * stepSize
+        lo = a + np.searchsorted(p, starts, side="left")
+        hi = a + np.searchsorted(p, ends, side="right")
+        for i in range(len(k)):
+            T.add(scaf, int(starts[i]), int(ends[i]), int(lo[i]), int(hi[i]), done + 1)
+            done += 1
+        pending = (scaf, int(starts[-1]), int(ends[-1]), int(lo[-1]), int(hi[-1]), done)
+    return T.finish(positions)
+
+
+def sites_windows(run_starts, run_names, positions, windSites, overlap, maxDist=np.inf, minSites=None,
+                  include=None, exclude=None):
+    """All windows slidingSitesWindows would yield; start/end are firstPos()/lastPos() (popgenWindows.py:39)."""
+    positions = np.asarray(positions)
+    if not minSites:
+        minSites = windSites
+    if overlap >= windSites:
+        raise ValueError("overlap must be smaller than the window size (the reference would loop forever)")
+    T = WindowTable()
+    done = 0
+    pending = None
+    skipped_since = False
+    finite = not np.isinf(maxDist)
+    for r, (a, b) in enumerate(_runs(run_starts, len(positions))):
+        scaf = run_names[r]
+        if not _wanted(scaf, include, exclude):
+            skipped_since = True
+            continue
+        if skipped_since and pending is not None:
+            done += 1
+            T.add(*pending)               # the generator re-yields its unchanged last window after a skipped scaffold
+        skipped_since = False
+        pending = None
+        _check_sorted(positions, a, b, scaf)
+        p = positions[a:b].astype(np.int64)
+        n = b - a
+        lo = hi = 0                       # current window = rows [lo,hi) of this run
+        wid = done + 1
+        while True:
+            if hi < n:                    # grow (genomics.py:2052)
+                cap = min(n, lo + windSites)
+                if finite:
+                    cap = min(cap, int(np.searchsorted(p, p[lo] + maxDist, side="right")))
+                hi = max(hi, cap)
+            emitted = (hi - lo) >= minSites
+            if emitted:
+                done += 1
+                pending = (scaf, int(p[lo]), int(p[hi - 1]), a + lo, a + hi, wid)
+                T.add(*pending)
+            if hi >= n:                   # next line is another scaffold or EOF: the window object is left as it is
+                if not emitted:
+                    pending = None
+                break
+            if emitted:                   # GenoWindow.trim(leave=overlap) == rows[len-overlap:], genomics.py:1779-1788
+                remove = (hi - lo) - overlap
+                if remove <= 0:
+                    raise ValueError("sites window of %d rows cannot advance with overlap %d under maxDist "
+                                     "(the reference yields this window forever)" % (hi - lo, overlap))
+                lo = min(lo + remove, hi)
+                wid = done + 1
+            elif hi > lo:
+                lo += 1                   # trim(remove=1)
+    return T.finish(positions)
+
+
+def predefined_windows(run_starts, run_names, positions, windCoords):
+    """All windows predefinedCoordWindows would yield.  windCoords: [(scaffold, start, end[, ID])].
+    Faithful quirk: on consecutive windows of one scaffold the generator only trims the LEFT of the previous
+    window's rows (GenoWindow.slide(newLimits)), so rows beyond the new end that were already read stay in."""
+    positions = np.asarray(positions)
+    all_scafs = [w[0] for w in windCoords]
+    scafs = sorted(set(all_scafs), key=all_scafs.index)
+    runs = _runs(run_starts, len(positions))
+    n = len(positions)
+    run_of_row = np.zeros(n, dtype=np.int64)
+    for r, (a, b) in enumerate(runs):
+        run_of_row[a:b] = r
+    T = WindowTable()
+    cur = 0                               # the "line in hand"
+    prev = None                           # (scaffold, lo, hi) of the previous window's rows
+    for w in windCoords:
+        scaf, start, end = w[0], int(w[1]), int(w[2])
+        ID = w[3] if len(w) > 3 else "NA"
+        widx = scafs.index(scaf)
+        kept = None
+        if prev is not None and prev[0] == scaf and prev[2] > prev[1]:
+            k_lo = prev[1] + int(np.searchsorted(positions[prev[1]:prev[2]], start, side="left"))
+            if prev[2] > k_lo:
+                kept = (k_lo, prev[2])
+        while cur < n:                    # genomics.py:2142-2145
+            name = run_names[run_of_row[cur]]
+            if name not in scafs or scafs.index(name) < widx:
+                cur = runs[run_of_row[cur]][1]
+            else:
+                break
+        new = None
+        if cur < n and run_names[run_of_row[cur]] == scaf:
+            a, b = runs[run_of_row[cur]]
+            _check_sorted(positions, a, b, scaf)
+            p = positions[cur:b]
+            x = cur + int(np.searchsorted(p, start, side="left"))
+            y = cur + int(np.searchsorted(p, end, side="right"))
+            if y > x:
+                new = (x, y)
+                cur = y
+            else:
+                cur = x
+        if kept and new:
+            rows = (kept[0], new[1])
+        elif kept:
+            rows = kept
+        elif new:
+            rows = new
+        else:
+            rows = (cur, cur) if cur <= n else (n, n)
+        T.add(scaf, start, end, rows[0], rows[1], ID)
+        prev = (scaf, rows[0], rows[1])
+        if cur >= n:
+            break
+    return T.finish(positions)

@@ -1,0 +1,168 @@
+/* popgen_hip.h -- C ABI of libpopgen_hip.so, the MI355X (gfx950) engine behind the per-window
+ * statistics path of simonhmartin/genomics_general.
+ *
+ * The reference has no FFI: its CLI drivers call genomics.py functions directly.  Each entry point
+ * below names the reference call site(s) it replaces (paths relative to the reference root); the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md and lives in
+ * genomics_general_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions across the boundary;
+ *   - every function returns 0 on success, a negative pg_status on failure; the message for the last
+ *     failure on the calling thread is pg_last_error();
+ *   - the caller owns every host array passed in or out; the library owns all device memory of a ctx
+ *     and frees it in pg_ctx_destroy;
+ *   - a ctx is bound to one device and is not thread-safe; distinct ctxs may be used from distinct threads;
+ *   - allele codes are one-hot int8: A=1 C=2 G=4 T=8, 0 = missing (anything that is not ACGT);
+ *   - genotype blocks are site-major: gt[site][hap], haplotypes in *device slot order*, which the host
+ *     chooses (populations contiguous, haplotypes of one individual adjacent);
+ *   - a window is a half-open range [lo, hi) of site indices in the ctx's resident site buffer.
+ */
+#ifndef POPGEN_HIP_H
+#define POPGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+
+typedef struct pg_ctx pg_ctx;
+
+enum pg_status {
+    PG_OK = 0,
+    PG_ERR_ARG = -1,       /* bad argument / precondition */
+    PG_ERR_HIP = -2,       /* HIP runtime error (message carries hipGetErrorString) */
+    PG_ERR_NODEV = -3,     /* no usable GPU */
+    PG_ERR_PARSE = -4,     /* malformed .geno text */
+    PG_ERR_RCCL = -5,      /* RCCL error */
+    PG_ERR_STATE = -6      /* call made in the wrong state (e.g. no samples set) */
+};
+
+/* genotype text formats, reference `-f/--genoFormat` (popgenWindows.py:205, genomics.py:390-396) */
+enum pg_geno_format { PG_FMT_PHASED = 0, PG_FMT_PAIRS = 1, PG_FMT_HAPLO = 2, PG_FMT_DIPLO = 3 };
+
+/* kernels whose HIP-event timings pg_kernel_time reports */
+enum pg_kernel_id { PG_K_PACK = 0, PG_K_PAIRWISE = 1, PG_K_POPDIST_FIN = 2, PG_K_SITESTATS = 3, PG_K_SYNTH = 4, PG_K_COUNT_ = 5 };
+
+int pg_abi_version(void);
+const char *pg_last_error(void);
+
+/* ---- device / context -------------------------------------------------------------------------- */
+int pg_device_count(int *n_out);
+int pg_ctx_create(pg_ctx **out, int device);
+int pg_ctx_destroy(pg_ctx *ctx);
+int pg_sync(pg_ctx *ctx);
+
+/* Haplotype -> population / individual maps in device slot order.
+ * Replaces the groups/sampleNames arrays of the Alignment built by genomics.genoToAlignment
+ * (genomics.py:1101-1127) and SampleData.getPop (genomics.py:1282-1286).
+ * hap_pop[h] in [0,n_pops) or -1 (no population); slots of one population must be contiguous and
+ * populations must appear in increasing id order, -1 slots last.  hap_sample[h] = individual index in
+ * [0,n_samples); slots of one individual must be contiguous. */
+int pg_set_samples(pg_ctx *ctx, int n_hap, const int32_t *hap_pop, const int32_t *hap_sample, int n_pops);
+
+/* ---- resident site buffer ------------------------------------------------------------------------ */
+int pg_reserve_sites(pg_ctx *ctx, int64_t n_sites);
+/* Copy gt[n_sites][n_hap] (tightly packed rows) to sites [site_offset, site_offset+n_sites). */
+int pg_upload_sites(pg_ctx *ctx, int64_t site_offset, const int8_t *gt, int64_t n_sites);
+int pg_download_sites(pg_ctx *ctx, int64_t site_offset, int8_t *gt_out, int64_t n_sites);
+/* Fill sites on device with the counter-based synthetic generator (genomics_general_amd/synth.py is
+ * the specification).  Dense layout: site i is scaffold i / scaf_len, position i % scaf_len + 1.
+ * slot_gen_hap[h] = generator haplotype index held by device slot h. */
+int pg_synth_fill(pg_ctx *ctx, int64_t site_offset, int64_t n_sites, int64_t first_site_index, uint64_t seed,
+                  int64_t scaf_len, int32_t n_dip, int32_t n_pops_gen, const int32_t *slot_gen_hap,
+                  int32_t var_thr, int32_t miss_thr);
+
+/* ---- K0: host tokenizer (no GPU needed) -------------------------------------------------------- */
+/* Replaces GenoFileReader.nextSite / parseGenoLine (genomics.py:1940-1945, 1884-1904) + splitSeq /
+ * forceHomo / seqArrayToNumArray (genomics.py:390-396, 407-408, 74-77) for a buffer of complete lines.
+ *   buf,len      text (no header line); lines starting with '#' are skipped, an empty line ends input
+ *   n_cols       number of genotype columns in the file
+ *   col_slot     [n_cols][max_ploidy] device slot of each allele of each column, -1 = column/allele unused
+ *   col_ploidy   [n_cols] expected ploidy of the column's cells (0 = column not wanted)
+ *   gt_out       [cap_sites][n_hap] one-hot codes (rows are fully written, unused slots = 0)
+ *   pos_out      [cap_sites]
+ *   scaf_off/len [cap_sites] byte offset/length of the scaffold token of each row inside buf
+ *   n_sites_out  rows produced.  n_threads <= 0 -> hardware concurrency.
+ * Error PG_ERR_PARSE when a wanted cell does not have the width its ploidy/format implies (the
+ * reference asserts "Sample ploidy doesn't match number of sequences", genomics.py:1111). */
+int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
+                   const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int32_t *pos_out, int64_t *scaf_off,
+                   int32_t *scaf_len, int64_t cap_sites, int64_t *n_sites_out, int n_threads);
+/* Row indices at which the scaffold token changes (contiguous scaffold runs, the unit slidingCoordWindows
+ * restarts its window on, genomics.py:2013-2017).  n_runs_out is always the true count. */
+int pg_scaffold_runs(const char *buf, const int64_t *scaf_off, const int32_t *scaf_len, int64_t n_sites,
+                     int64_t *run_start_out, int64_t max_runs, int64_t *n_runs_out);
+/* Count data rows (non-'#', non-empty) in a text buffer so the caller can size the outputs. */
+int pg_count_lines(const char *buf, size_t len, int64_t *n_rows_out);
+
+/* ---- K2: pairwise matrices ----------------------------------------------------------------------- */
+/* Replaces Alignment.distMatrix / pairDist / numHamming (genomics.py:907-916, 903-905, 1219-1221) and
+ * Alignment.pairNonNan (genomics.py:1042-1047).  For each window: D[i][j] = #sites where i and j are
+ * both called and differ, C[i][j] = #sites both called; full symmetric [n_hap][n_hap] int32 matrices with
+ * zero diagonal, in device slot order.  distMat[i][j] of the reference == D/C (nan when C == 0). */
+int pg_pairwise(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int32_t *D_out, int32_t *C_out);
+
+/* ---- K2+K3: population distance sums -------------------------------------------------------------- */
+/* Replaces Alignment.groupDistStats (genomics.py:956-995).  For every window and every unordered
+ * population pair (x<=y), in the order (0,0),(0,1),..,(0,P-1),(1,1),.. : the float64 sum of D/C over
+ * haplotype pairs {i in x, j in y, i<j when x==y} with C >= max(min_pair_sites,1), and the number of such
+ * pairs.  nanmean / minData / pi_s / pi_t / Fst are formed from these on the host (engine.py). */
+int pg_popdist(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites,
+               double *sum_out, int64_t *cnt_out);
+
+/* ---- K2+K6: individual-pair distance sums -------------------------------------------------------- */
+/* Replaces Alignment.indPairDists (genomics.py:934-954).  For every window and unordered individual pair
+ * (s<=t), (0,0),(0,1).. : sum of D/C over haplotype pairs {a in s, b in t, a<b when s==t} with
+ * C >= max(min_pair_sites,1), and their number. */
+int pg_indpairdist(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites,
+                   double *sum_out, int64_t *cnt_out);
+
+/* ---- K1+K4: ABBA-BABA window sums ------------------------------------------------------------------ */
+/* Replaces genomics.ABBABABA(polarize=True) (genomics.py:1647-1695) with f4/D/fd/fdm/ABBA/BABA
+ * (genomics.py:1409-1475, 1565-1569).  sums_out[n_win][6] = { sum f4(p1,p2,p3,p4), sum (ABBA+BABA),
+ * sum f4(p1,pd,pd,p4), sum f4(pdm1,pdm2,pdm3,p4), sum ABBA, sum BABA }; sites_used_out[n_win]. */
+int pg_abbababa(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int p1, int p2, int p3,
+                int p4, double min_data, double *sums_out, int64_t *sites_used_out);
+
+/* ---- K1+K5: site-frequency window sums -------------------------------------------------------------- */
+/* Replaces Alignment.groupFreqStats (genomics.py:1002-1028) + baseCountPi (609-616).  Sites used are those
+ * with no missing call in ANY haplotype slot.  l_out[n_win]; S_out[n_win][n_pops] = #sites with >1 allele
+ * in the population; pairsum_out[n_win][n_pops] = sum over sites of sum_{a<b} c_a c_b (exact integers). */
+int pg_popfreq(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int64_t *l_out,
+               int64_t *S_out, int64_t *pairsum_out);
+
+/* ---- K1 raw: per-site per-population base counts ------------------------------------------------- */
+/* Replaces Alignment.siteFreqs(asCounts=True) / binBaseFreqs (genomics.py:1049-1052, 592-599) for every
+ * population at once: cnt_out[n_sites][n_pops][4] (A,C,G,T) for sites [site_lo, site_hi). */
+int pg_site_counts(pg_ctx *ctx, int64_t site_lo, int64_t site_hi, int32_t *cnt_out);
+
+/* ---- per-haplotype called-site counts ------------------------------------------------------------ */
+/* Replaces Alignment.seqNonNan (genomics.py:1038-1040) as used by distMat.py:40 (--minPerInd):
+ * called_out[n_win][n_hap] = number of sites of the window at which the haplotype slot is called. */
+int pg_hap_called(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int64_t *called_out);
+
+/* ---- measurement ------------------------------------------------------------------------------------ */
+/* Accumulated HIP-event time (ms) and launch count of a kernel family since the last reset. */
+int pg_kernel_time(pg_ctx *ctx, int kernel_id, double *ms_out, int64_t *launches_out);
+int pg_kernel_time_reset(pg_ctx *ctx);
+/* scratch budget (bytes) for per-batch bit-planes + matrices; default 16 GiB */
+int pg_set_scratch_limit(pg_ctx *ctx, int64_t bytes);
+
+/* ---- C1: multi-GPU result gather (RCCL over xGMI), one process per GPU ----------------------------- */
+/* Replaces the sorter/writer threads' re-ordering role (popgenWindows.py:108-157).  uid is 128 bytes. */
+int pg_comm_unique_id(void *uid128_out);
+int pg_comm_init(pg_ctx *ctx, int n_ranks, int rank, const void *uid128);
+/* Gather count doubles from every rank into recv[n_ranks*count] on every rank (ncclAllGather). */
+int pg_comm_allgather_f64(pg_ctx *ctx, const double *send, double *recv, int64_t count);
+int pg_comm_barrier(pg_ctx *ctx);
+int pg_comm_destroy(pg_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POPGEN_HIP_H */

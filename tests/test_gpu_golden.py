@@ -1,0 +1,65 @@
+"""-m gpu: the drop-in command lines, end to end (.geno text -> K0 -> HIP kernels -> CSV), against the committed
+outputs of the unmodified reference (tests/golden/, made by tests/golden/make_golden.py).
+
+Cells must be textually identical except floating-point cells, which may differ by at most half a unit of the
+rounding digit plus 1e-6 (a 1-ulp difference can flip a rounding tie; SURVEY.md section 7 'float formatting parity')."""
+import os
+
+import pytest
+
+from cases import CASES
+from genomics_general_amd import cli
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MAINS = {"popgenWindows.py": cli.popgen_main, "ABBABABAwindows.py": cli.abbababa_main, "distMat.py": cli.distmat_main}
+
+
+def round_digits(case):
+    if case["tool"] == "ABBABABAwindows.py":
+        return 4
+    if "--roundTo" in case["argv"]:
+        return int(case["argv"][case["argv"].index("--roundTo") + 1])
+    return 4
+
+
+def cells(text):
+    return [ln.replace(",", " ").split() for ln in text.splitlines()]
+
+
+def compare_text(got, want, digits):
+    g, w = cells(got), cells(want)
+    assert len(g) == len(w), "row count %d != %d" % (len(g), len(w))
+    tol = 0.5 * 10.0 ** (-digits) + 1e-6
+    n_inexact = 0
+    for r, (gr, wr) in enumerate(zip(g, w)):
+        assert len(gr) == len(wr), "row %d: %r vs %r" % (r, gr, wr)
+        for gc, wc in zip(gr, wr):
+            if gc == wc:
+                continue
+            try:
+                gv, wv = float(gc), float(wc)
+            except ValueError:
+                raise AssertionError("row %d: %r != %r" % (r, gc, wc))
+            assert abs(gv - wv) <= tol, "row %d: %r vs %r" % (r, gc, wc)
+            n_inexact += 1
+    return n_inexact
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_cli_reproduces_reference_output(case, tmp_path):
+    geno = os.path.join(GOLD, case["fixture"] + ".geno.gz")
+    out = str(tmp_path / (case["name"] + ".out"))
+    argv = [a.format(geno=geno, dir=GOLD, out=out) for a in case["argv"]] + ["-o", out]
+    MAINS[case["tool"]](argv)
+    with open(out) as f:
+        got = f.read()
+    with open(os.path.join(GOLD, case["name"] + ".out")) as f:
+        want = f.read()
+    n_inexact = compare_text(got, want, round_digits(case))
+    # ties at the rounding digit are rare: the bulk must be textually identical
+    assert n_inexact <= max(2, len(want.split()) // 50), "%d cells differ in the last digit" % n_inexact
+    side = os.path.join(GOLD, case["name"] + ".out.windows")
+    if os.path.exists(side):
+        with open(out + ".windows") as f, open(side) as g:
+            assert f.read() == g.read()

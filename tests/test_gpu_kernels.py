@@ -1,0 +1,158 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+Integer outputs must be bit-exact; float64 outputs within 1e-9 relative (north_star tolerance is 1e-6)."""
+import numpy as np
+import pytest
+
+from genomics_general_amd import synth
+from oracle import popgen_oracle as orc
+
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_aln(lay, codes, lo, hi):
+    aln, _ = orc.aln_from_codes(codes[lo:hi], lay.hap_names, lay.hap_sample_name,
+                                [g if g is not None else "~none" for g in lay.hap_group])
+    return aln
+
+
+@pytest.mark.parametrize("n_dip,n_pops,L,wins", [
+    (8, 2, 3000, [(0, 1000), (1000, 2000), (2000, 3000)]),
+    (25, 4, 4096, [(0, 4096), (5, 37), (100, 100), (7, 8), (4000, 4096)]),      # whole, tiny, empty, single-site, tail
+    (37, 3, 2500, [(0, 1250), (600, 1900), (1250, 2500)]),                       # odd haplotype count, overlapping windows
+    (150, 4, 1500, [(0, 700), (700, 1500)]),                                     # several 64-column chunks
+])
+def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins):
+    e, lay, codes, _ = G.make_engine(n_dip, n_pops, L, seed=11 + n_dip)
+    lo = np.array([w[0] for w in wins]); hi = np.array([w[1] for w in wins])
+    D, C = e.batch(lo, hi).pairCounts(reference_order=True)
+    for k, (a, b) in enumerate(wins):
+        Do, Co = orc.pair_counts_gemm(oracle_aln(lay, codes, a, b))
+        assert np.array_equal(C[k], Co), "C differs in window %d" % k
+        assert np.array_equal(D[k], Do), "D differs in window %d" % k
+    e.close()
+
+
+def test_pairwise_matches_reference_pair_loop_small():
+    """the faithful pair-by-pair loop of the reference (not the GEMM shortcut) on a small case"""
+    e, lay, codes, _ = G.make_engine(6, 2, 700, seed=5, miss_thr=20000)
+    D, C = e.batch([0], [700]).pairCounts(reference_order=True)
+    Do, Co = orc.pair_counts_loop(oracle_aln(lay, codes, 0, 700))
+    assert np.array_equal(D[0], Do) and np.array_equal(C[0], Co)
+    e.close()
+
+
+@pytest.mark.parametrize("min_sites,min_data,miss", [(1, 0.01, 5000), (40, 0.5, 30000), (300, 0.01, 20000)])
+def test_group_dist_stats(min_sites, min_data, miss):
+    e, lay, codes, _ = G.make_engine(20, 4, 2400, seed=21, miss_thr=miss)
+    wins = [(0, 800), (800, 1100), (1100, 2400)]
+    wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
+    st = wb.groupDistStats(doPairs=True, minSites=min_sites, minData=min_data)
+    for k, (a, b) in enumerate(wins):
+        aln = oracle_aln(lay, codes, a, b)
+        Do, Co = orc.pair_counts_gemm(aln)
+        so, _ = orc.group_dist_stats(aln, Do, Co, True, min_sites, min_data)
+        for key, v in so.items():
+            assert G.close(st[key][k], v), (key, k, st[key][k], v)
+    e.close()
+
+
+def test_ind_pair_dists_with_and_without_popdist_mask():
+    e, lay, codes, names = G.make_engine(9, 3, 1500, seed=33, miss_thr=25000)
+    wins = [(0, 700), (700, 1500)]
+    for after_popdist in (False, True):
+        for same in (False, True):
+            wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
+            if after_popdist:
+                wb.groupDistStats(True, 120, 0.01)
+            got = wb.indPairDists(includeSameWithSame=same)
+            for k, (a, b) in enumerate(wins):
+                aln = oracle_aln(lay, codes, a, b)
+                Do, Co = orc.pair_counts_gemm(aln)
+                if after_popdist:
+                    _, dm = orc.group_dist_stats(aln, Do, Co, True, 120, 0.01)
+                else:
+                    dm = orc.dist_from_counts(Do, Co)
+                want, _ = orc.ind_pair_dists(aln, dm, include_same=same)
+                for i in names:
+                    for j in names:
+                        assert G.close(got[i][j][k], want[i][j]), (after_popdist, same, i, j, k)
+    e.close()
+
+
+@pytest.mark.parametrize("min_data,miss", [(0.01, 5000), (0.5, 20000), (0.9, 9000), (0.0, 50000)])
+def test_abbababa_sums(min_data, miss):
+    e, lay, codes, _ = G.make_engine(16, 4, 6000, seed=44, var_thr=45000, miss_thr=miss)
+    wins = [(0, 3000), (3000, 3010), (3010, 6000), (10, 10)]
+    wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
+    got = wb.ABBABABA("p0", "p1", "p2", "p3", min_data)
+    for k, (a, b) in enumerate(wins):
+        if b == a:
+            assert got["sitesUsed"][k] == 0
+            continue
+        want = orc.abbababa(oracle_aln(lay, codes, a, b), "p0", "p1", "p2", "p3", min_data)
+        assert got["sitesUsed"][k] == want["sitesUsed"]
+        if want["sitesUsed"] > 0:
+            for key in ("D", "fd", "fdM", "ABBA", "BABA"):
+                assert G.close(got[key][k], want[key]), (key, k, got[key][k], want[key])
+    e.close()
+
+
+def test_group_freq_stats_exact_integers():
+    e, lay, codes, _ = G.make_engine(10, 2, 5000, seed=55, miss_thr=400)
+    wins = [(0, 2500), (2500, 5000), (17, 18)]
+    got = e.batch([w[0] for w in wins], [w[1] for w in wins]).groupFreqStats()
+    for k, (a, b) in enumerate(wins):
+        want = orc.group_freq_stats(oracle_aln(lay, codes, a, b))
+        for key, v in want.items():
+            if key.startswith("l_") or key.startswith("S_"):
+                g = got[key][k]
+                assert (g == v) or (g != g and v != v), (key, k, g, v)
+            else:
+                assert G.close(got[key][k], v), (key, k, got[key][k], v)
+    e.close()
+
+
+def test_site_counts_and_hap_called_exact():
+    e, lay, codes, _ = G.make_engine(13, 3, 3000, seed=66, miss_thr=15000, extra_nopop=1)
+    cnt = e.batch([0], [1]).siteCounts(100, 2900)
+    lut = {1: 0, 2: 1, 4: 2, 8: 3}
+    ps = [0] + list(np.cumsum(lay.pop_sizes))
+    want = np.zeros_like(cnt)
+    sub = codes[100:2900]
+    for q in range(lay.n_pops):
+        for code, b in lut.items():
+            want[:, q, b] = (sub[:, ps[q]:ps[q + 1]] == code).sum(axis=1)
+    assert np.array_equal(cnt, want)
+    wins = [(0, 3000), (5, 1500), (2999, 3000), (40, 40)]
+    called = e.batch([w[0] for w in wins], [w[1] for w in wins]).hapCalled()
+    for k, (a, b) in enumerate(wins):
+        assert np.array_equal(called[k], (codes[a:b] != 0).sum(axis=0))
+    e.close()
+
+
+def test_device_generator_matches_numpy_spec():
+    names, lay = G.make_layout(30, 4)
+    from genomics_general_amd.engine import Engine
+    e = Engine(0)
+    e.set_layout(lay)
+    L, scaf_len = 20000, 7000
+    e.reserve(L)
+    sg = G.slot_gen_hap(names, lay)
+    e.synth_fill(0, L, 123456, 20260925, scaf_len, 30, 4, sg, synth.VAR_THR, synth.MISS_THR)
+    got = e.download(0, L)
+    gi = 123456 + np.arange(L)
+    want = synth.gen_codes(20260925, gi // scaf_len, gi % scaf_len + 1, 30, 4, hap_index=sg)
+    assert np.array_equal(got, want)
+    e.close()
+
+
+def test_errors_are_loud_not_fatal():
+    from genomics_general_amd._lib import PopgenError
+    e, lay, codes, _ = G.make_engine(4, 2, 100, seed=1)
+    with pytest.raises(PopgenError):
+        e.batch([0], [101]).pairCounts()
+    with pytest.raises(PopgenError):
+        e.batch([50], [40]).hapCalled()
+    e.close()
