@@ -1,0 +1,68 @@
+"""Multi-GPU sharding / gather logic on CPU: world_size 2 with the gloo stand-in communicator, plus shard arithmetic."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from genomics_general_amd import dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from genomics_general_amd import dist
+world = dist.world_from_env()
+comm = dist.GlooComm(world)
+n_total, k = 11, 3
+lo, hi = dist.shard_range(n_total, world.size, world.rank)
+full = (np.arange(n_total * k, dtype=np.float64).reshape(n_total, k) * 1.5) - 7
+full[4, 1] = np.nan
+got = dist.gather_table(comm, full[lo:hi], n_total)
+assert got.shape == full.shape
+assert np.array_equal(np.isnan(got), np.isnan(full)) and np.allclose(np.nan_to_num(got), np.nan_to_num(full))
+t = comm.allgather(np.array([float(world.rank + 1)]))
+assert t.ravel().tolist() == [1.0, 2.0]
+# empty shard on one rank
+lo1, hi1 = dist.shard_range(1, world.size, world.rank)
+one = dist.gather_table(comm, np.full((hi1 - lo1, 2), 5.0), 1)
+assert one.tolist() == [[5.0, 5.0]]
+comm.barrier(); comm.close()
+print("rank", world.rank, "ok")
+''' % ROOT
+
+
+def test_shard_arithmetic():
+    for n in (0, 1, 7, 200, 60001):
+        for size in (1, 2, 3, 8):
+            rng = [dist.shard_range(n, size, r) for r in range(size)]
+            assert rng[0][0] == 0 and rng[-1][1] == n
+            assert all(rng[r][1] == rng[r + 1][0] for r in range(size - 1))
+            counts = dist.shard_counts(n, size)
+            assert sum(counts) == n and max(counts) - min(counts) <= 1
+
+
+def test_gather_table_world_size_2_gloo(tmp_path):
+    port = 29000 + os.getpid() % 2000
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        outs.append(o.decode())
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
+    monkeypatch.setenv("PG_RDZV_FILE", str(tmp_path / "rdzv"))
+    uid0, path = dist.exchange_unique_id(dist.World(0, 2, 0), lambda: bytes(range(128)))
+    uid1, _ = dist.exchange_unique_id(dist.World(1, 2, 1), lambda: b"", timeout_s=5)
+    assert uid0 == uid1 == bytes(range(128)) and os.path.exists(path)

@@ -1,0 +1,197 @@
+"""CPU-only tests (-m "not gpu"): the C-ABI library loads and exports every declared symbol, the native tokenizer
+(K0, host code inside the .so) agrees with the oracle's parser, sample layout, host finalisers, error behaviour."""
+import gzip
+import os
+import re
+
+import numpy as np
+import pytest
+
+from genomics_general_amd import _lib, genoio
+from genomics_general_amd.engine import WindowBatch, encode_text
+from genomics_general_amd.samples import HapLayout, SampleData
+from oracle import popgen_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "popgen_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = header_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "libpopgen_hip.so does not export " + n
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert L.pg_abi_version() == 1
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from genomics_general_amd.engine import Engine
+    with pytest.raises(_lib.PopgenError) as ei:
+        Engine(0)
+    assert ei.value.code == _lib.PG_ERR_NODEV
+
+
+FIX = [("c1", "phased", 8), ("sparse", "phased", 12), ("abba_pairs", "pairs", 16), ("abba_diplo", "diplo", 16), ("haplo", "haplo", 10)]
+
+
+@pytest.mark.parametrize("name,fmt,n", FIX)
+def test_tokenizer_matches_oracle_parser(name, fmt, n):
+    path = os.path.join(GOLD, name + ".geno.gz")
+    raw = genoio.read_all(path)
+    names, body = genoio.split_header(raw)
+    assert len(names) == n
+    pl = 1 if fmt == "haplo" else 2
+    sd = SampleData(indNames=list(names), ploidyDict={nm: pl for nm in names})
+    lay = HapLayout(sd, names, fmt)
+    data = genoio.encode(body, lay)
+    with gzip.open(path, "rt") as fh:
+        onames, sites = orc.read_sites(fh)
+    assert onames == names and data.n_sites == len(sites)
+    assert np.array_equal(data.pos, [s[1] for s in sites])
+    # scaffold runs
+    runs = [0] + [i for i in range(1, len(sites)) if sites[i][0] != sites[i - 1][0]]
+    assert list(data.run_starts) == runs and data.run_names == [sites[i][0] for i in runs]
+    # codes: slot order == file order here (no populations)
+    lut = {"A": 1, "C": 2, "G": 4, "T": 8}
+    for row in (0, 1, len(sites) // 2, len(sites) - 1):
+        want = []
+        for cell in sites[row][2]:
+            want += [lut.get(a, 0) for a in orc.split_cell(cell, fmt, pl)]
+        assert list(data.gt[row]) == want
+
+
+def test_tokenizer_thread_count_does_not_change_output():
+    raw = genoio.read_all(os.path.join(GOLD, "abba.geno.gz"))
+    names, body = genoio.split_header(raw)
+    lay = HapLayout(SampleData(indNames=list(names)), names, "phased")
+    a = encode_text(body, lay, n_threads=1)
+    b = encode_text(body, lay, n_threads=7)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_tokenizer_column_selection_and_slot_order():
+    text = b"chr1 5 A/C G/T N/N T/T\n#comment\nchr1 9 C|C a/T G/G A/N\n\nchr2 2 T/T T/G C/A G/C\n"
+    names = ["w", "x", "y", "z"]
+    sd = SampleData(popNames=["P", "Q"], popInds=[["z"], ["x", "w"]])          # slot order: z | x w ; y unused
+    lay = HapLayout(sd, names, "phased")
+    assert lay.ind_order == ["z", "x", "w"] and lay.hap_names == ["z_A", "z_B", "x_A", "x_B", "w_A", "w_B"]
+    assert list(lay.hap_pop) == [0, 0, 1, 1, 1, 1]
+    gt, pos, soff, slen = encode_text(text, lay)
+    assert list(pos) == [5, 9, 2]
+    assert gt.tolist() == [[8, 8, 4, 8, 1, 2], [1, 0, 0, 8, 2, 2], [4, 2, 8, 4, 8, 8]]   # lower case 'a' = missing
+    assert [text[o:o + n] for o, n in zip(soff, slen)] == [b"chr1", b"chr1", b"chr2"]
+    assert list(np.array(lay.hap_names)[lay.ref_order]) == sorted(lay.hap_names)
+
+
+@pytest.mark.parametrize("text,fmt,msg", [
+    (b"chr1 5 A/C G\n", "phased", "ploidy"),
+    (b"chr1 5 A/C\n", "phased", "fewer genotype columns"),
+    (b"chr1 x A/C G/T\n", "phased", "position"),
+    (b"chr1 5 AC GTT\n", "pairs", "ploidy"),
+])
+def test_tokenizer_errors(text, fmt, msg):
+    lay = HapLayout(SampleData(indNames=["a", "b"]), ["a", "b"], fmt)
+    with pytest.raises(_lib.PopgenError) as ei:
+        encode_text(text, lay)
+    assert ei.value.code == _lib.PG_ERR_PARSE and msg in str(ei.value)
+
+
+def test_sampledata_mirror():
+    sd = SampleData(indNames=["q"], popNames=["A", "B"], popInds=[["x", "y"], ["y", "z"]], ploidyDict={"q": 1, "x": 2, "y": 2, "z": 2})
+    assert sd.indNames == ["q", "x", "y", "z"]
+    assert sd.getPop("x") == "A" and sd.getPop("y") == ("A", "B") and sd.getPop("q") is None
+    assert sd.popInds[0] == ["x", "y"] and sd.ploidy["q"] == 1
+    with pytest.raises(ValueError):
+        HapLayout(sd, ["q", "x", "y", "z"], "phased")            # y in two populations
+    with pytest.raises(KeyError):
+        HapLayout(SampleData(indNames=["nope"]), ["a"], "phased")
+
+
+class FakeLib:
+    """Stands in for libpopgen_hip.so in the finaliser test: fills the C-ABI outputs from oracle integer counts."""
+
+    def __init__(self, codes, lay):
+        self.codes, self.lay = codes, lay
+
+    def _counts(self, a, b):
+        aln, _ = orc.aln_from_codes(self.codes[a:b], [str(i).zfill(4) for i in range(self.lay.n_hap)],
+                                    self.lay.hap_sample_name, self.lay.hap_group)
+        return orc.pair_counts_gemm(aln)
+
+    def pg_popdist(self, h, lo, hi, n, ms, sums, cnts):
+        ps = [0] + list(np.cumsum(self.lay.pop_sizes))
+        thr = max(ms, 1)
+        for w in range(n):
+            D, C = self._counts(lo[w], hi[w])
+            k = 0
+            for x in range(self.lay.n_pops):
+                for y in range(x, self.lay.n_pops):
+                    s, c = 0.0, 0
+                    for i in range(ps[x], ps[x + 1]):
+                        for j in range(ps[y], ps[y + 1]):
+                            if (x == y and i >= j) or C[i, j] < thr:
+                                continue
+                            s += D[i, j] / C[i, j]
+                            c += 1
+                    sums[w, k], cnts[w, k] = s, c
+                    k += 1
+        return 0
+
+
+class FakeEngine:
+    def __init__(self, lib, lay):
+        self._L, self._h, self.layout = lib, None, lay
+
+
+@pytest.mark.parametrize("min_sites,min_data", [(1, 0.01), (30, 0.6), (400, 0.01)])
+def test_host_finalisers_match_reference_formulas(min_sites, min_data):
+    from genomics_general_amd import synth
+    n_dip, n_pops, L = 9, 3, 600
+    names = ["s%d" % d for d in range(n_dip)]
+    sd = SampleData(popNames=["a", "b", "c"], popInds=[names[0:2], names[2:6], names[6:9]])
+    lay = HapLayout(sd, names, "phased")
+    sid, pos = synth.dense_sites(L, 1)
+    codes = synth.gen_codes(3, sid, pos, n_dip, n_pops, var_thr=40000, miss_thr=25000)
+    wb = WindowBatch(FakeEngine(FakeLib(codes, lay), lay), [0, 300], [300, 600])
+    got = wb.groupDistStats(True, min_sites, min_data)
+    for w, (a, b) in enumerate([(0, 300), (300, 600)]):
+        aln, _ = orc.aln_from_codes(codes[a:b], lay.hap_names, lay.hap_sample_name, lay.hap_group)
+        D, C = orc.pair_counts_gemm(aln)
+        want, _ = orc.group_dist_stats(aln, D, C, True, min_sites, min_data)
+        assert set(want) == set(got)
+        for k, v in want.items():
+            g = got[k][w]
+            assert (abs(g - v) < 1e-12) or (g != g and v != v), (k, g, v)
+
+
+def test_cli_asserts_like_the_reference():
+    from genomics_general_amd import cli
+    with pytest.raises(AssertionError, match="Window size must be provided"):
+        cli.popgen_main(["-f", "phased", "-g", "x.geno"])
+    with pytest.raises(AssertionError, match="Overlap does not apply to coordinate windows"):
+        cli.popgen_main(["-f", "phased", "-g", "x.geno", "-w", "100", "-O", "5"])
+    with pytest.raises(AssertionError, match="between 0 and 1"):
+        cli.abbababa_main(["-f", "phased", "-g", "x.geno", "-w", "100", "--minData", "2", "-P1", "a", "s1", "-P2", "b", "s2",
+                           "-P3", "c", "s3", "-O", "d", "s4"])
+
+
+def test_oracle_gemm_counts_equal_reference_pair_loop():
+    from genomics_general_amd import synth
+    sid, pos = synth.dense_sites(400, 1)
+    codes = synth.gen_codes(9, sid, pos, 7, 2, var_thr=40000, miss_thr=20000)
+    names = ["h%02d" % i for i in range(14)]
+    aln, _ = orc.aln_from_codes(codes, names, names, ["g"] * 14)
+    D1, C1 = orc.pair_counts_loop(aln)
+    D2, C2 = orc.pair_counts_gemm(aln)
+    assert np.array_equal(D1, D2) and np.array_equal(C1, C2)
