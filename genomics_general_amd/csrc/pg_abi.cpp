@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 static thread_local char g_err[1024] = "";
 
@@ -76,6 +77,10 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->pop_start.release();
     c->samp_start.release();
     c->tasks.release();
+    c->tasks2.release();
+    c->Vp.release();
+    c->XY.release();
+    c->nw.release();
     c->planes.release();
     c->Cmat.release();
     c->Dmat.release();
@@ -101,6 +106,29 @@ extern "C" int pg_set_scratch_limit(pg_ctx *c, int64_t bytes) {
     if (!c || bytes < (64ll << 20)) return pg_fail(PG_ERR_ARG, "scratch limit must be >= 64 MiB");
     c->scratch_limit = bytes;
     return PG_OK;
+}
+
+// ---- v2 pair-kernel task table -------------------------------------------------------------------------
+// Units [0,n).  Full 64-column chunks cover columns [0, 64*floor(n/64)) with the rows above them (i<j); the remaining
+// R = n mod 64 units are handled as ROWS against every column chunk (pairs j<i, written at (j,i)), so no wave runs with
+// only R of its 64 lanes useful.  Rows come in sub-tiles of 8, up to max_nsub sub-tiles per wave.
+std::vector<PgTask2> pg_make_tasks2(int n, int max_nsub, int diag) {
+    std::vector<PgTask2> out;
+    const int full = (n / 64) * 64;
+    auto push_rows = [&](int row_begin, int row_end, int col0, int lower) {       // rows [row_begin,row_end), 8-aligned begin
+        for (int r = row_begin; r < row_end; r += 8 * max_nsub) {
+            PgTask2 t;
+            t.row0 = r;
+            t.nsub = std::min(max_nsub, (row_end - r + 7) / 8);
+            t.col0 = col0;
+            t.lower = lower;
+            out.push_back(t);
+        }
+    };
+    for (int c0 = 0; c0 < full; c0 += 64) push_rows(0, c0 + 63 + (diag ? 1 : 0), c0, 0);   // rows i < c0+63 (<= with diag)
+    if (n > full)
+        for (int c0 = 0; c0 < n; c0 += 64) push_rows(full, n, c0, 1);
+    return out;
 }
 
 // ---- samples ----------------------------------------------------------------------------------------
@@ -171,11 +199,14 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
         }
     }
     c->n_tasks = (int)tasks.size();
+    std::vector<PgTask2> tasks2 = pg_make_tasks2(n_hap, 2, 0);
+    c->n_tasks2 = (int)tasks2.size();
     int rc;
     if ((rc = c->hap_pop.upload(hap_pop, n_hap, c->stream)) != PG_OK) return rc;
     if ((rc = c->pop_start.upload(pstart.data(), pstart.size(), c->stream)) != PG_OK) return rc;
     if ((rc = c->samp_start.upload(sstart.data(), sstart.size(), c->stream)) != PG_OK) return rc;
     if (!tasks.empty() && (rc = c->tasks.upload(tasks.data(), tasks.size(), c->stream)) != PG_OK) return rc;
+    if (!tasks2.empty() && (rc = c->tasks2.upload(tasks2.data(), tasks2.size(), c->stream)) != PG_OK) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     // the resident buffer layout depends on S: drop it
     c->gt.release();
@@ -334,42 +365,94 @@ static int stage_windows(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w0
     return PG_OK;
 }
 
+// Upload [lo | hi | goff(n+1) | vgoff(n+1)] of windows [w0,w1) for the v2 pipeline.
+static int stage_windows2(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w0, int w1, int64_t *total_groups,
+                          int64_t *total_vg, int *max_groups) {
+    const int n = w1 - w0;
+    std::vector<int64_t> h(4 * (size_t)n + 2);
+    int64_t ga = 0, va = 0;
+    int mg = 0;
+    for (int k = 0; k < n; ++k) {
+        h[k] = lo[w0 + k];
+        h[n + k] = hi[w0 + k];
+        const int64_t words = (hi[w0 + k] - lo[w0 + k] + 31) / 32;
+        h[2 * (size_t)n + k] = ga;
+        h[3 * (size_t)n + 1 + k] = va;
+        const int64_t groups = (words + PG_GROUP - 1) / PG_GROUP;
+        ga += groups;
+        va += (words + 3) / 4;
+        mg = std::max<int64_t>(mg, groups);
+    }
+    h[3 * (size_t)n] = ga;
+    h[4 * (size_t)n + 1] = va;
+    *total_groups = ga;
+    *total_vg = va;
+    *max_groups = mg;
+    int rc = c->win.upload(h.data(), h.size(), c->stream);
+    if (rc != PG_OK) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+static bool use_v2(const pg_ctx *c) { return c->NP <= 1024 && getenv("PG_PAIR_V1") == nullptr; }
+
 // Run pack + pairwise over windows in batches that fit the scratch budget; `consume(batch_w0, batch_n)` is called
 // with C/D of the batch resident in ctx->Cmat / ctx->Dmat (upper triangle valid).
 template <class F>
 static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, F consume) {
     const int N = c->n_hap, NP = c->NP;
     const int64_t mat_bytes = 2ll * N * N * 4;
+    const bool v2 = use_v2(c);
+    // scratch bytes per 32-site input word: v1 = 5 planes; v2 = called plane + worst-case (all polymorphic) 8 planes
+    const int64_t word_bytes = v2 ? (int64_t)NP * 4 * 9 : (int64_t)NP * 4 * 5;
     int w0 = 0;
     while (w0 < n_win) {
-        int64_t words = 0, bytes = 0;
+        int64_t words = 0;
         int w1 = w0;
         while (w1 < n_win) {
-            int64_t wlen = (hi[w1] - lo[w1] + 31) / 32;
-            int64_t nb = (words + wlen) * 5ll * NP * 4 + (int64_t)(w1 - w0 + 1) * mat_bytes;
+            int64_t wlen = ((hi[w1] - lo[w1] + 31) / 32 + PG_GROUP - 1) / PG_GROUP * PG_GROUP;
+            int64_t nb = (words + wlen) * word_bytes + (int64_t)(w1 - w0 + 1) * mat_bytes;
             if (w1 > w0 && nb > c->scratch_limit) break;
             words += wlen;
-            bytes = nb;
             ++w1;
             if (w1 - w0 >= 65535) break;                      // gridDim.y limit
         }
-        (void)bytes;
         const int nb = w1 - w0;
-        int64_t total_words = 0, max_len = 0;
-        int max_words = 0;
-        int rc = stage_windows(c, lo, hi, w0, w1, &total_words, &max_words, &max_len);
-        if (rc != PG_OK) return rc;
-        const int64_t *d_lo = c->win.p, *d_hi = c->win.p + nb, *d_woff = c->win.p + 2 * (size_t)nb;
-        if ((rc = c->planes.ensure((size_t)std::max<int64_t>(total_words, 1) * 5 * NP)) != PG_OK) return rc;
+        int rc;
         if ((rc = c->Cmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
         hipEvent_t e0, e1;
-        if ((rc = pg_time_begin(c, PG_K_PACK, &e0, &e1)) != PG_OK) return rc;
-        pg_launch_pack(c->stream, c->gt.p, c->S, d_lo, d_hi, d_woff, nb, max_words, c->planes.p, NP);
-        if ((rc = pg_time_end(c, PG_K_PACK, e0, e1, 1)) != PG_OK) return rc;
-        if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
-        pg_launch_pairwise(c->stream, c->planes.p, d_woff, nb, c->tasks.p, c->n_tasks, NP, N, c->Cmat.p, c->Dmat.p);
-        if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
+        if (!v2) {
+            int64_t total_words = 0, max_len = 0;
+            int max_words = 0;
+            if ((rc = stage_windows(c, lo, hi, w0, w1, &total_words, &max_words, &max_len)) != PG_OK) return rc;
+            const int64_t *d_lo = c->win.p, *d_hi = c->win.p + nb, *d_woff = c->win.p + 2 * (size_t)nb;
+            if ((rc = c->planes.ensure((size_t)std::max<int64_t>(total_words, 1) * 5 * NP)) != PG_OK) return rc;
+            if ((rc = pg_time_begin(c, PG_K_PACK, &e0, &e1)) != PG_OK) return rc;
+            pg_launch_pack(c->stream, c->gt.p, c->S, d_lo, d_hi, d_woff, nb, max_words, c->planes.p, NP);
+            if ((rc = pg_time_end(c, PG_K_PACK, e0, e1, 1)) != PG_OK) return rc;
+            if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
+            pg_launch_pairwise(c->stream, c->planes.p, d_woff, nb, c->tasks.p, c->n_tasks, NP, N, c->Cmat.p, c->Dmat.p);
+            if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
+        } else {
+            int64_t total_groups = 0, total_vg = 0;
+            int max_groups = 0;
+            if ((rc = stage_windows2(c, lo, hi, w0, w1, &total_groups, &total_vg, &max_groups)) != PG_OK) return rc;
+            const int64_t *d_lo = c->win.p, *d_hi = c->win.p + nb, *d_goff = c->win.p + 2 * (size_t)nb,
+                          *d_vgoff = c->win.p + 3 * (size_t)nb + 1;
+            if ((rc = c->Vp.ensure((size_t)std::max<int64_t>(total_vg, 1) * NP * 4)) != PG_OK) return rc;
+            if ((rc = c->XY.ensure((size_t)std::max<int64_t>(total_groups, 1) * PG_GROUP * 8 * NP)) != PG_OK) return rc;
+            if ((rc = c->nw.ensure((size_t)std::max<int64_t>(total_groups, 1))) != PG_OK) return rc;
+            if ((rc = pg_time_begin(c, PG_K_PACK, &e0, &e1)) != PG_OK) return rc;
+            pg_launch_pack2(c->stream, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, c->Vp.p, NP, c->XY.p, NP, c->nw.p);
+            if ((rc = pg_time_end(c, PG_K_PACK, e0, e1, 1)) != PG_OK) return rc;
+            if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
+            pg_launch_pairC(c->stream, c->Vp.p, d_vgoff, nb, c->tasks2.p, c->n_tasks2, NP, N, 0, c->Cmat.p);
+            if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
+            if ((rc = pg_time_begin(c, PG_K_PAIRD, &e0, &e1)) != PG_OK) return rc;
+            pg_launch_pairD(c->stream, c->XY.p, c->nw.p, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, c->Dmat.p);
+            if ((rc = pg_time_end(c, PG_K_PAIRD, e0, e1, 1)) != PG_OK) return rc;
+        }
         HIPCHK(hipGetLastError());
         if ((rc = consume(w0, nb)) != PG_OK) return rc;
         w0 = w1;

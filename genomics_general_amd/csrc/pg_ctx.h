@@ -57,6 +57,10 @@ struct pg_ctx {
     std::vector<int32_t> h_pop_start, h_samp_start;
     DevBuf<int32_t> hap_pop, pop_start, samp_start, slot_gen;
     DevBuf<PgPairTask> tasks;
+    DevBuf<PgTask2> tasks2;      // v2 pair kernels (haplotype units)
+    int n_tasks2 = 0;
+    DevBuf<uint32_t> Vp, XY;     // v2 planes
+    DevBuf<int32_t> nw;          // v2: compacted words per group
     // resident sites
     DevBuf<int8_t> gt;
     int64_t cap_sites = 0;
@@ -69,13 +73,14 @@ struct pg_ctx {
     DevBuf<int64_t> res_i64, part_i64;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[PG_K_COUNT_];
-    double acc_ms[PG_K_COUNT_] = {0, 0, 0, 0, 0};
-    int64_t acc_launches[PG_K_COUNT_] = {0, 0, 0, 0, 0};
+    double acc_ms[PG_K_COUNT_] = {0, 0, 0, 0, 0, 0};
+    int64_t acc_launches[PG_K_COUNT_] = {0, 0, 0, 0, 0, 0};
     // RCCL (opaque here)
     void *comm = nullptr;
     int comm_ranks = 0, comm_rank = 0;
     DevBuf<double> comm_send, comm_recv;
 };
 
+std::vector<PgTask2> pg_make_tasks2(int n, int max_nsub, int diag);
 int pg_time_begin(pg_ctx *c, int k, hipEvent_t *e0, hipEvent_t *e1);
 int pg_time_end(pg_ctx *c, int k, hipEvent_t e0, hipEvent_t e1, int launches);

@@ -11,6 +11,12 @@ struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,r
     int32_t row0, nsub, col0, pad;
 };
 
+#define PG_GROUP 64             // input words (of 32 sites) per compaction group of k_pack2
+
+struct PgTask2 {                // one wave of k_pairC / k_pairD: rows [row0,row0+8*nsub) x cols [col0,col0+64)
+    int32_t row0, nsub, col0, lower;   // lower = 1: remainder rows, the valid pairs are those with col < row
+};
+
 struct PgSynthParams {
     uint64_t seed;
     int64_t first_site_index, scaf_len;
@@ -50,3 +56,12 @@ void pg_launch_site_counts(hipStream_t st, const int8_t *gt, int S, int64_t site
 
 void pg_launch_hap_called(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
                           const int64_t *win_hi, int n_win, int max_chunks, unsigned long long *out);
+
+// ---- v2 pairwise pipeline (pg_pair2.hip) ---------------------------------------------------------------
+void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
+                     const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, uint32_t *Vp, int NPv,
+                     uint32_t *XY, int NP, int32_t *nw);
+void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, const PgTask2 *tasks, int n_tasks,
+                     int NPv, int n_units, int diag, int32_t *Cmat);
+void pg_launch_pairD(hipStream_t st, const uint32_t *XY, const int32_t *nw, const int64_t *goff, int n_win,
+                     const PgTask2 *tasks, int n_tasks, int NP, int N, int32_t *Dmat);

@@ -1,0 +1,343 @@
+// v2 pairwise pipeline: the pairwise matrices split into the two terms that need different amounts of work.
+//
+//   C[i][j] = sum over ALL sites of v_i & v_j                      -> k_pairC on the "called" plane only (2 VALU / 32 pair-sites)
+//   D[i][j] = sum over POLYMORPHIC sites of differ(i,j) & v_i & v_j -> k_pairD on compacted allele planes (5 VALU / 32 pair-sites)
+//
+// A site whose called haplotypes all carry the same allele adds the same amount to C and to "same allele", i.e. nothing to D
+// (genomics.py:903-905, 1219-1221: numHamming counts differences among jointly called sites).  k_pack2 therefore detects
+// polymorphic sites (>= 2 alleles present among the called haplotypes of the window's slots) while it transposes, and
+// bit-compacts only those into the allele planes.  Data-dependent, exact, and the algorithmic pair-sites stay the denominator
+// of every reported rate.
+//
+// Layouts (uint32 words, 32 sites per word):
+//   Vp[(vgoff[b] + wq) * NPv + unit][4]        called plane, 4 consecutive words of one unit contiguous (one 16-byte load per
+//                                               lane per 128 sites; 16 rows x 4 words = 4 x s_load_dwordx16)
+//   XY[((goff[b] + g) * PG_GROUP + k) * 8 + p][NP]  compacted planes of group g (64 input words): p = 0..3 X_a (allele a called),
+//                                               p = 4..7 Y_a = called & not allele a;  nw[goff[b]+g] = words used (0..64)
+// differ & both called  ==  OR_a (X_a,i & Y_a,j): row operands X in SGPRs, column operands Y in VGPRs.
+#include "pg_internal.h"
+
+typedef __attribute__((address_space(4))) const uint32_t CU32;
+
+// ------------------------------------------------------------------------------------------------------
+// k_pack2
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bgather(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, int k) {
+    return ((a0 >> (8 * k)) & 0xFFu) | (((a1 >> (8 * k)) & 0xFFu) << 8) | (((a2 >> (8 * k)) & 0xFFu) << 16) |
+           (((a3 >> (8 * k)) & 0xFFu) << 24);
+}
+
+// 32 sites x 4 haplotypes -> x[a][k] (allele plane a of haplotype k) ; ns = valid sites (tail -> zero bits)
+__device__ __forceinline__ void load_word(const int8_t *__restrict__ src, int S, int ns, uint32_t x[4][4]) {
+    uint32_t acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = 0u;
+    if (ns == 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t d[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) d[s] = *reinterpret_cast<const uint32_t *>(src + (int64_t)(q * 8 + s) * S);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p][q] = (acc[p][q] << 1) | ((d[s] >> p) & 0x01010101u);
+        }
+    } else {
+        for (int si = 0; si < ns; ++si) {
+            const uint32_t d = *reinterpret_cast<const uint32_t *>(src + (int64_t)si * S);
+            const int q = si >> 3;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t bit = (d >> p) & 0x01010101u;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    if (qq == q) acc[p][qq] = (acc[p][qq] << 1) | bit;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[p][k] = bgather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], k);
+}
+
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
+                                               const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
+                                               const int64_t *__restrict__ vgoff, uint32_t *__restrict__ Vp, int NPv,
+                                               uint32_t *__restrict__ XY, int NP, int32_t *__restrict__ nw) {
+    constexpr int NWAVE = TPB / 64;
+    __shared__ uint32_t sh_pres[2][NWAVE][4];
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int64_t lo = win_lo[b], hi = win_hi[b];
+    const int W = (int)((hi - lo + 31) >> 5);
+    const int w_begin = g * PG_GROUP;
+    if (w_begin >= W) return;
+    const int w_end = (w_begin + PG_GROUP < W) ? w_begin + PG_GROUP : W;
+    const int t = threadIdx.x;
+    const int h0 = 4 * t;
+    const bool has_data = h0 < S;            // pad threads (h0 >= S) still write zero planes up to NP
+    const bool in_np = h0 < NP;
+    const bool in_npv = h0 < NPv;
+    uint32_t out[8][4];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[p][k] = 0u;
+    int cnt = 0, nflush = 0, parity = 0;
+    uint32_t *xy_base = XY + (size_t)(goff[b] + g) * PG_GROUP * 8u * (size_t)NP;
+    const int64_t vg_base = vgoff[b] + (int64_t)(w_begin >> 2);
+    for (int wq = 0; 4 * wq + w_begin < w_end; ++wq) {
+        uint32_t vhold[4][4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int w = w_begin + 4 * wq + k4;
+            uint32_t x[4][4], v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = 0u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[p][k] = 0u;
+            const bool live = w < w_end;            // block-uniform
+            if (live && has_data) {
+                const int64_t s0 = lo + 32ll * w;
+                const int ns = (int)((hi - s0) < 32 ? (hi - s0) : 32);
+                load_word(gt + s0 * (int64_t)S + h0, S, ns, x);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = x[0][k] | x[1][k] | x[2][k] | x[3][k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vhold[k][k4] = v[k];
+            if (live) {
+                // alleles present among called haplotypes, per site, across the whole block
+                uint32_t pr[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) pr[p] = wave_or(x[p][0] | x[p][1] | x[p][2] | x[p][3]);
+                if (NWAVE > 1) {
+                    if ((t & 63) == 0) {
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) sh_pres[parity][t >> 6][p] = pr[p];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        uint32_t a = 0u;
+#pragma unroll
+                        for (int wv = 0; wv < NWAVE; ++wv) a |= sh_pres[parity][wv][p];
+                        pr[p] = a;
+                    }
+                    parity ^= 1;
+                }
+                uint32_t m = (pr[0] & pr[1]) | (pr[0] & pr[2]) | (pr[0] & pr[3]) | (pr[1] & pr[2]) | (pr[1] & pr[3]) | (pr[2] & pr[3]);
+                m = __builtin_amdgcn_readfirstlane(m);
+                while (m) {
+                    const int bit = __builtin_ctz(m);
+                    m &= m - 1u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t vb = (v[k] >> bit) & 1u;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const uint32_t xb = (x[p][k] >> bit) & 1u;
+                            out[p][k] = (out[p][k] << 1) | xb;
+                            out[4 + p][k] = (out[4 + p][k] << 1) | (vb ^ xb);
+                        }
+                    }
+                    if (++cnt == 32) {
+                        if (in_np) {
+                            uint32_t *o = xy_base + (size_t)nflush * 8u * (size_t)NP + h0;
+#pragma unroll
+                            for (int p = 0; p < 8; ++p)
+                                *reinterpret_cast<uint4 *>(o + (size_t)p * NP) = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
+                        }
+#pragma unroll
+                        for (int p = 0; p < 8; ++p)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) out[p][k] = 0u;
+                        cnt = 0;
+                        ++nflush;
+                    }
+                }
+            }
+        }
+        if (in_npv) {
+            uint32_t *o = Vp + ((size_t)(vg_base + wq) * NPv + h0) * 4u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<uint4 *>(o + 4 * k) = make_uint4(vhold[k][0], vhold[k][1], vhold[k][2], vhold[k][3]);
+        }
+    }
+    if (cnt) {
+        if (in_np) {
+            uint32_t *o = xy_base + (size_t)nflush * 8u * (size_t)NP + h0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                *reinterpret_cast<uint4 *>(o + (size_t)p * NP) = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
+        }
+        ++nflush;
+    }
+    if (t == 0) nw[goff[b] + g] = nflush;
+}
+
+void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
+                     const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, uint32_t *Vp, int NPv,
+                     uint32_t *XY, int NP, int32_t *nw) {
+    if (n_win <= 0 || max_groups <= 0) return;
+    const int threads = (NP > NPv ? NP : NPv) / 4;
+    dim3 grid(max_groups, n_win);
+    if (threads <= 64)
+        hipLaunchKernelGGL(k_pack2<64>, grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XY, NP, nw);
+    else if (threads <= 128)
+        hipLaunchKernelGGL(k_pack2<128>, grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XY, NP, nw);
+    else
+        hipLaunchKernelGGL(k_pack2<256>, grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XY, NP, nw);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Task decoding shared by k_pairC / k_pairD.  1-D XCD-aware grid: block b runs on XCD b % 8; all waves of a window go
+// to one XCD so its planes are served by that XCD's L2.
+// ------------------------------------------------------------------------------------------------------
+struct PairCtx {
+    int win, row0, nsub, col0, lower, lane;
+};
+
+__device__ __forceinline__ bool pair_decode(const PgTask2 *__restrict__ tasks, int n_tasks, int tasks_wg, int n_win, PairCtx &c) {
+    const int xcd = blockIdx.x & 7;
+    const int v = blockIdx.x >> 3;
+    c.win = (v / tasks_wg) * 8 + xcd;
+    if (c.win >= n_win) return false;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.lane = threadIdx.x & 63;
+    const int t = (v % tasks_wg) * 4 + wave;
+    if (t >= n_tasks) return false;
+    const PgTask2 tk = tasks[t];
+    c.row0 = __builtin_amdgcn_readfirstlane(tk.row0);
+    c.nsub = __builtin_amdgcn_readfirstlane(tk.nsub);
+    c.col0 = __builtin_amdgcn_readfirstlane(tk.col0);
+    c.lower = __builtin_amdgcn_readfirstlane(tk.lower);
+    return true;
+}
+
+// store acc[r] for pair (row0+r, j): upper tasks keep i<j (i<=j with diag), lower tasks keep j<i (j<=i) and write (j,i)
+template <int R>
+__device__ __forceinline__ void pair_store(const uint32_t (&acc)[R], int row0, int j, int n, int lower, int diag,
+                                           int32_t *__restrict__ M) {
+    if (j >= n) return;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = row0 + r;
+        if (i >= n) continue;
+        if (!lower) {
+            if (i < j || (diag && i == j)) M[(size_t)i * n + j] = (int32_t)acc[r];
+        } else {
+            if (j < i || (diag && i == j)) M[(size_t)j * n + i] = (int32_t)acc[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_pairC: units x units "both called" counts.  Wave = 8*NSUB rows (SGPR operands) x 64 columns, 4 words per iteration.
+// ------------------------------------------------------------------------------------------------------
+template <int NSUB>
+__device__ __forceinline__ void pairC_body(const uint32_t *__restrict__ Vp, int64_t vg0, int nwq, int NPv, const PairCtx &c,
+                                           int n_units, int diag, int32_t *__restrict__ Cw) {
+    constexpr int R = 8 * NSUB;
+    uint32_t acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0u;
+    const int j = c.col0 + c.lane;
+    const uint32_t *base = Vp + (size_t)vg0 * NPv * 4u;
+    for (int wq = 0; wq < nwq; ++wq) {
+        const uint32_t *pw = base + (size_t)wq * NPv * 4u;
+        const uint4 jv = *reinterpret_cast<const uint4 *>(pw + (size_t)j * 4u);
+        const CU32 *pr = (const CU32 *)(pw + (size_t)c.row0 * 4u);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r] += __popc(pr[4 * r + 0] & jv.x);
+            acc[r] += __popc(pr[4 * r + 1] & jv.y);
+            acc[r] += __popc(pr[4 * r + 2] & jv.z);
+            acc[r] += __popc(pr[4 * r + 3] & jv.w);
+        }
+    }
+    pair_store<R>(acc, c.row0, j, n_units, c.lower, diag, Cw);
+}
+
+__global__ __launch_bounds__(256) void k_pairC(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vgoff, int n_win,
+                                               const PgTask2 *__restrict__ tasks, int n_tasks, int tasks_wg, int NPv,
+                                               int n_units, int diag, int32_t *__restrict__ Cmat) {
+    PairCtx c;
+    if (!pair_decode(tasks, n_tasks, tasks_wg, n_win, c)) return;
+    const int64_t vg0 = vgoff[c.win];
+    const int nwq = (int)(vgoff[c.win + 1] - vg0);
+    int32_t *Cw = Cmat + (size_t)c.win * n_units * n_units;
+    if (c.nsub == 1) pairC_body<1>(Vp, vg0, nwq, NPv, c, n_units, diag, Cw);
+    else pairC_body<2>(Vp, vg0, nwq, NPv, c, n_units, diag, Cw);
+}
+
+void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, const PgTask2 *tasks, int n_tasks,
+                     int NPv, int n_units, int diag, int32_t *Cmat) {
+    if (n_win <= 0 || n_tasks <= 0) return;
+    const int tasks_wg = (n_tasks + 3) / 4;
+    const int64_t blocks = (int64_t)((n_win + 7) / 8) * tasks_wg * 8;
+    hipLaunchKernelGGL(k_pairC, dim3((unsigned)blocks), dim3(256), 0, st, Vp, vgoff, n_win, tasks, n_tasks, tasks_wg, NPv,
+                       n_units, diag, Cmat);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_pairD: haplotype x haplotype difference counts over the compacted polymorphic words of a window.
+// ------------------------------------------------------------------------------------------------------
+template <int NSUB>
+__device__ __forceinline__ void pairD_body(const uint32_t *__restrict__ XY, const int32_t *__restrict__ nw, int64_t g0, int ng,
+                                           int NP, const PairCtx &c, int N, int32_t *__restrict__ Dw) {
+    constexpr int R = 8 * NSUB;
+    uint32_t acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0u;
+    const int j = c.col0 + c.lane;
+    const size_t wstride = (size_t)8 * NP;
+    for (int g = 0; g < ng; ++g) {
+        const int n = __builtin_amdgcn_readfirstlane(nw[g0 + g]);
+        const uint32_t *gb = XY + (size_t)(g0 + g) * PG_GROUP * wstride;
+        for (int w = 0; w < n; ++w) {
+            const uint32_t *pw = gb + (size_t)w * wstride;
+            const uint32_t y0 = pw[(size_t)4 * NP + j], y1 = pw[(size_t)5 * NP + j], y2 = pw[(size_t)6 * NP + j],
+                           y3 = pw[(size_t)7 * NP + j];
+            const CU32 *pr = (const CU32 *)(pw + c.row0);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                acc[r] += __popc((pr[r] & y0) | (pr[NP + r] & y1) | (pr[2 * NP + r] & y2) | (pr[3 * NP + r] & y3));
+        }
+    }
+    pair_store<R>(acc, c.row0, j, N, c.lower, 0, Dw);
+}
+
+__global__ __launch_bounds__(256) void k_pairD(const uint32_t *__restrict__ XY, const int32_t *__restrict__ nw,
+                                               const int64_t *__restrict__ goff, int n_win, const PgTask2 *__restrict__ tasks,
+                                               int n_tasks, int tasks_wg, int NP, int N, int32_t *__restrict__ Dmat) {
+    PairCtx c;
+    if (!pair_decode(tasks, n_tasks, tasks_wg, n_win, c)) return;
+    const int64_t g0 = goff[c.win];
+    const int ng = (int)(goff[c.win + 1] - g0);
+    int32_t *Dw = Dmat + (size_t)c.win * N * N;
+    if (c.nsub == 1) pairD_body<1>(XY, nw, g0, ng, NP, c, N, Dw);
+    else pairD_body<2>(XY, nw, g0, ng, NP, c, N, Dw);
+}
+
+void pg_launch_pairD(hipStream_t st, const uint32_t *XY, const int32_t *nw, const int64_t *goff, int n_win,
+                     const PgTask2 *tasks, int n_tasks, int NP, int N, int32_t *Dmat) {
+    if (n_win <= 0 || n_tasks <= 0) return;
+    const int tasks_wg = (n_tasks + 3) / 4;
+    const int64_t blocks = (int64_t)((n_win + 7) / 8) * tasks_wg * 8;
+    hipLaunchKernelGGL(k_pairD, dim3((unsigned)blocks), dim3(256), 0, st, XY, nw, goff, n_win, tasks, n_tasks, tasks_wg, NP, N,
+                       Dmat);
+}
