@@ -78,6 +78,10 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->samp_start.release();
     c->tasks.release();
     c->tasks2.release();
+    c->tasksC.release();
+    c->flag.release();
+    c->Cfull.release();
+    c->Dfull.release();
     c->Vp.release();
     c->XY.release();
     c->nw.release();
@@ -201,12 +205,19 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
     c->n_tasks = (int)tasks.size();
     std::vector<PgTask2> tasks2 = pg_make_tasks2(n_hap, 2, 0);
     c->n_tasks2 = (int)tasks2.size();
+    c->all_diploid = (n_hap % 2 == 0);
+    for (size_t k = 0; k + 1 < sstart.size() && c->all_diploid; ++k)
+        if (sstart[k + 1] - sstart[k] != 2) c->all_diploid = false;
+    std::vector<PgTask2> tasksC;
+    if (c->all_diploid) tasksC = pg_make_tasks2(n_hap / 2, 2, 1);
+    c->n_tasksC = (int)tasksC.size();
     int rc;
     if ((rc = c->hap_pop.upload(hap_pop, n_hap, c->stream)) != PG_OK) return rc;
     if ((rc = c->pop_start.upload(pstart.data(), pstart.size(), c->stream)) != PG_OK) return rc;
     if ((rc = c->samp_start.upload(sstart.data(), sstart.size(), c->stream)) != PG_OK) return rc;
     if (!tasks.empty() && (rc = c->tasks.upload(tasks.data(), tasks.size(), c->stream)) != PG_OK) return rc;
     if (!tasks2.empty() && (rc = c->tasks2.upload(tasks2.data(), tasks2.size(), c->stream)) != PG_OK) return rc;
+    if (!tasksC.empty() && (rc = c->tasksC.upload(tasksC.data(), tasksC.size(), c->stream)) != PG_OK) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     // the resident buffer layout depends on S: drop it
     c->gt.release();
@@ -396,15 +407,20 @@ static int stage_windows2(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w
 
 static bool use_v2(const pg_ctx *c) { return c->NP <= 1024 && getenv("PG_PAIR_V1") == nullptr; }
 
-// Run pack + pairwise over windows in batches that fit the scratch budget; `consume(batch_w0, batch_n)` is called
-// with C/D of the batch resident in ctx->Cmat / ctx->Dmat (upper triangle valid).
+// Run pack + pairwise over windows in batches that fit the scratch budget; `consume(batch_w0, batch_n)` is called with the
+// batch's matrices resident: D in ctx->Dmat ([N][N] per window, upper triangle) and the called counts in ctx->Cmat
+// ([cN][cN] per window, upper triangle, entry of haplotypes (i,j) at (i>>cshift, j>>cshift)).
 template <class F>
-static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, F consume) {
+static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, bool dip, F consume) {
     const int N = c->n_hap, NP = c->NP;
-    const int64_t mat_bytes = 2ll * N * N * 4;
     const bool v2 = use_v2(c);
-    // scratch bytes per 32-site input word: v1 = 5 planes; v2 = called plane + worst-case (all polymorphic) 8 planes
-    const int64_t word_bytes = v2 ? (int64_t)NP * 4 * 9 : (int64_t)NP * 4 * 5;
+    const int n_units = dip ? N / 2 : N;
+    const int NPv = dip ? (n_units + 63) / 64 * 64 : NP;
+    c->cN = n_units;
+    c->cshift = dip ? 1 : 0;
+    const int64_t mat_bytes = 4ll * N * N + 4ll * n_units * n_units;
+    // scratch bytes per 32-site input word: v1 = 5 planes; v2 = called plane + worst-case (all polymorphic) 5 planes
+    const int64_t word_bytes = v2 ? (int64_t)NP * 4 * 5 + (int64_t)NPv * 4 : (int64_t)NP * 4 * 5;
     int w0 = 0;
     while (w0 < n_win) {
         int64_t words = 0;
@@ -419,7 +435,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         }
         const int nb = w1 - w0;
         int rc;
-        if ((rc = c->Cmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
+        if ((rc = c->Cmat.ensure((size_t)nb * n_units * n_units)) != PG_OK) return rc;
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
         hipEvent_t e0, e1;
         if (!v2) {
@@ -440,17 +456,19 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
             if ((rc = stage_windows2(c, lo, hi, w0, w1, &total_groups, &total_vg, &max_groups)) != PG_OK) return rc;
             const int64_t *d_lo = c->win.p, *d_hi = c->win.p + nb, *d_goff = c->win.p + 2 * (size_t)nb,
                           *d_vgoff = c->win.p + 3 * (size_t)nb + 1;
-            if ((rc = c->Vp.ensure((size_t)std::max<int64_t>(total_vg, 1) * NP * 4)) != PG_OK) return rc;
-            if ((rc = c->XY.ensure((size_t)std::max<int64_t>(total_groups, 1) * PG_GROUP * 8 * NP)) != PG_OK) return rc;
+            if ((rc = c->Vp.ensure((size_t)std::max<int64_t>(total_vg, 1) * NPv * 4)) != PG_OK) return rc;
+            if ((rc = c->XY.ensure((size_t)std::max<int64_t>(total_groups, 1) * PG_GROUP * 5 * NP)) != PG_OK) return rc;
             if ((rc = c->nw.ensure((size_t)std::max<int64_t>(total_groups, 1))) != PG_OK) return rc;
             if ((rc = pg_time_begin(c, PG_K_PACK, &e0, &e1)) != PG_OK) return rc;
-            pg_launch_pack2(c->stream, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, c->Vp.p, NP, c->XY.p, NP, c->nw.p);
+            pg_launch_pack2(c->stream, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, c->Vp.p, NPv, c->XY.p, NP,
+                            c->nw.p, dip ? 1 : 0, c->flag.p);
             if ((rc = pg_time_end(c, PG_K_PACK, e0, e1, 1)) != PG_OK) return rc;
             if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
-            pg_launch_pairC(c->stream, c->Vp.p, d_vgoff, nb, c->tasks2.p, c->n_tasks2, NP, N, 0, c->Cmat.p);
+            if (dip) pg_launch_pairC(c->stream, c->Vp.p, d_vgoff, nb, c->tasksC.p, c->n_tasksC, NPv, n_units, 1, total_vg / nb, c->Cmat.p);
+            else pg_launch_pairC(c->stream, c->Vp.p, d_vgoff, nb, c->tasks2.p, c->n_tasks2, NPv, n_units, 0, total_vg / nb, c->Cmat.p);
             if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
             if ((rc = pg_time_begin(c, PG_K_PAIRD, &e0, &e1)) != PG_OK) return rc;
-            pg_launch_pairD(c->stream, c->XY.p, c->nw.p, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, c->Dmat.p);
+            pg_launch_pairD(c->stream, c->XY.p, c->nw.p, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, total_groups / nb, c->Dmat.p);
             if ((rc = pg_time_end(c, PG_K_PAIRD, e0, e1, 1)) != PG_OK) return rc;
         }
         HIPCHK(hipGetLastError());
@@ -460,16 +478,38 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     return PG_OK;
 }
 
+// Diploid fast path first (called counts per individual); if any window turns out to hold an individual whose two
+// haplotypes differ in calledness (e.g. phased `A|N`), everything is recomputed with per-haplotype called counts.
+template <class F>
+static int pairwise_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, F consume) {
+    const bool dip = use_v2(c) && c->all_diploid && getenv("PG_NO_DIP") == nullptr;
+    int rc;
+    if ((rc = c->flag.ensure(1)) != PG_OK) return rc;
+    if (dip) {
+        HIPCHK(hipMemsetAsync(c->flag.p, 0, 4, c->stream));
+        if ((rc = pairwise_batches(c, lo, hi, n_win, true, consume)) != PG_OK) return rc;
+        int32_t flag = 0;
+        HIPCHK(hipMemcpyAsync(&flag, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!flag) return PG_OK;
+    }
+    return pairwise_batches(c, lo, hi, n_win, false, consume);
+}
+
 extern "C" int pg_pairwise(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int32_t *D_out, int32_t *C_out) {
     int rc = check_windows(c, lo, hi, n_win);
     if (rc != PG_OK) return rc;
     if (n_win > 0 && (!D_out || !C_out)) return pg_fail(PG_ERR_ARG, "null output");
     HIPCHK(hipSetDevice(c->device));
     const size_t NN = (size_t)c->n_hap * c->n_hap;
-    rc = pairwise_batches(c, lo, hi, n_win, [&](int w0, int nb) -> int {
-        pg_launch_mirror(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, nb);
-        HIPCHK(hipMemcpyAsync(C_out + (size_t)w0 * NN, c->Cmat.p, nb * NN * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(D_out + (size_t)w0 * NN, c->Dmat.p, nb * NN * 4, hipMemcpyDeviceToHost, c->stream));
+    rc = pairwise_run(c, lo, hi, n_win, [&](int w0, int nb) -> int {
+        int r;
+        if ((r = c->Cfull.ensure((size_t)nb * NN)) != PG_OK) return r;
+        if ((r = c->Dfull.ensure((size_t)nb * NN)) != PG_OK) return r;
+        pg_launch_expand(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->Cfull.p, c->Dfull.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(C_out + (size_t)w0 * NN, c->Cfull.p, nb * NN * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(D_out + (size_t)w0 * NN, c->Dfull.p, nb * NN * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         return PG_OK;
     });
@@ -486,11 +526,11 @@ extern "C" int pg_popdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n
     const int npairs = c->n_pops * (c->n_pops + 1) / 2;
     if ((rc = c->res_f64.ensure((size_t)std::max(n_win, 1) * npairs)) != PG_OK) return rc;
     if ((rc = c->res_i64.ensure((size_t)std::max(n_win, 1) * npairs)) != PG_OK) return rc;
-    rc = pairwise_batches(c, lo, hi, n_win, [&](int w0, int nb) -> int {
+    rc = pairwise_run(c, lo, hi, n_win, [&](int w0, int nb) -> int {
         hipEvent_t e0, e1;
         int r = pg_time_begin(c, PG_K_POPDIST_FIN, &e0, &e1);
         if (r != PG_OK) return r;
-        pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, nb, c->pop_start.p, c->n_pops, min_pair_sites,
+        pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, c->n_pops, min_pair_sites,
                               c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs);
         if ((r = pg_time_end(c, PG_K_POPDIST_FIN, e0, e1, 1)) != PG_OK) return r;
         HIPCHK(hipGetLastError());
@@ -513,11 +553,11 @@ extern "C" int pg_indpairdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, i
     HIPCHK(hipSetDevice(c->device));
     const size_t npairs = (size_t)c->n_samp * (c->n_samp + 1) / 2;
     // results are copied back per batch (they can be large for distMat-sized inputs)
-    rc = pairwise_batches(c, lo, hi, n_win, [&](int w0, int nb) -> int {
+    rc = pairwise_run(c, lo, hi, n_win, [&](int w0, int nb) -> int {
         int r;
         if ((r = c->res_f64.ensure((size_t)nb * npairs)) != PG_OK) return r;
         if ((r = c->res_i64.ensure((size_t)nb * npairs)) != PG_OK) return r;
-        pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, nb, c->samp_start.p, c->n_samp, min_pair_sites,
+        pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->samp_start.p, c->n_samp, min_pair_sites,
                               c->res_f64.p, c->res_i64.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sum_out + (size_t)w0 * npairs, c->res_f64.p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->stream));

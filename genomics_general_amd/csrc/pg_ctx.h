@@ -59,8 +59,15 @@ struct pg_ctx {
     DevBuf<PgPairTask> tasks;
     DevBuf<PgTask2> tasks2;      // v2 pair kernels (haplotype units)
     int n_tasks2 = 0;
+    DevBuf<PgTask2> tasksC;      // v2 k_pairC when its units are diploid individuals (diagonal included)
+    int n_tasksC = 0;
+    bool all_diploid = false;    // every individual owns exactly slots (2k, 2k+1)
     DevBuf<uint32_t> Vp, XY;     // v2 planes
     DevBuf<int32_t> nw;          // v2: compacted words per group
+    DevBuf<int32_t> flag;        // v2: [0] = some window had haplotypes of one individual with different calledness
+    DevBuf<int32_t> Cfull, Dfull;  // pg_pairwise staging
+    // how the matrices of the last batch are laid out (set by pairwise_batches)
+    int cN = 0, cshift = 0;
     // resident sites
     DevBuf<int8_t> gt;
     int64_t cap_sites = 0;

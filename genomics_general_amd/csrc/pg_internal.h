@@ -33,11 +33,11 @@ void pg_launch_pack(hipStream_t st, const int8_t *gt, int S, const int64_t *win_
 void pg_launch_pairwise(hipStream_t st, const uint32_t *planes, const int64_t *woff, int n_win,
                         const PgPairTask *tasks, int n_tasks, int NP, int N, int32_t *Cmat, int32_t *Dmat);
 
-void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int n_win,
+void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *pop_start, int n_pops, int min_pair_sites, double *sum_out,
                            int64_t *cnt_out);
 
-void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int n_win,
+void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,
                            int64_t *cnt_out);
 
@@ -60,8 +60,10 @@ void pg_launch_hap_called(hipStream_t st, const int8_t *gt, int S, int n_hap, co
 // ---- v2 pairwise pipeline (pg_pair2.hip) ---------------------------------------------------------------
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                      const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, uint32_t *Vp, int NPv,
-                     uint32_t *XY, int NP, int32_t *nw);
+                     uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch);
+void pg_launch_expand(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
+                      int32_t *Cfull, int32_t *Dfull);
 void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, const PgTask2 *tasks, int n_tasks,
-                     int NPv, int n_units, int diag, int32_t *Cmat);
+                     int NPv, int n_units, int diag, int64_t avg_wq, int32_t *Cmat);
 void pg_launch_pairD(hipStream_t st, const uint32_t *XY, const int32_t *nw, const int64_t *goff, int n_win,
-                     const PgTask2 *tasks, int n_tasks, int NP, int N, int32_t *Dmat);
+                     const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat);

@@ -308,7 +308,7 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 // K_popdist: one block per (population pair, window).
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat,
-                                                     int N, const int32_t *__restrict__ pop_start, int n_pops,
+                                                     int N, int cN, int cshift, const int32_t *__restrict__ pop_start, int n_pops,
                                                      int min_pair_sites, double *__restrict__ sum_out,
                                                      int64_t *__restrict__ cnt_out) {
     __shared__ double shd[256];
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__
     while (rem >= n_pops - x) { rem -= n_pops - x; ++x; }
     const int y = x + rem;
     const int win = blockIdx.y;
-    const int32_t *Cw = Cmat + (size_t)win * N * N;
+    const int32_t *Cw = Cmat + (size_t)win * cN * cN;      // unit-level called counts (units = haplotypes or diploid individuals)
     const int32_t *Dw = Dmat + (size_t)win * N * N;
     const int xs = pop_start[x], xe = pop_start[x + 1], ys = pop_start[y], ye = pop_start[y + 1];
     const int nx = xe - xs, ny = ye - ys;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__
     for (long long idx = threadIdx.x; idx < total; idx += blockDim.x) {
         const int i = xs + (int)(idx / ny), j = ys + (int)(idx % ny);
         if (x == y && i >= j) continue;
-        const int c = Cw[(size_t)i * N + j];
+        const int c = Cw[(size_t)(i >> cshift) * cN + (j >> cshift)];
         if (c >= thr) {
             sum += (double)Dw[(size_t)i * N + j] / (double)c;
             ++cnt;
@@ -345,12 +345,12 @@ __global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__
     }
 }
 
-void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int n_win,
+void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *pop_start, int n_pops, int min_pair_sites, double *sum_out,
                            int64_t *cnt_out) {
     if (n_win <= 0 || n_pops <= 0) return;
     int npairs = n_pops * (n_pops + 1) / 2;
-    hipLaunchKernelGGL(k_popdist_fin, dim3(npairs, n_win), dim3(256), 0, st, Cmat, Dmat, N, pop_start, n_pops,
+    hipLaunchKernelGGL(k_popdist_fin, dim3(npairs, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops,
                        min_pair_sites, sum_out, cnt_out);
 }
 
@@ -358,12 +358,12 @@ void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *D
 // K_indpair: one thread per unordered individual pair (s<=t); haplotype slots of an individual are contiguous.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat,
-                                                     int N, const int32_t *__restrict__ samp_start, int n_samp,
+                                                     int N, int cN, int cshift, const int32_t *__restrict__ samp_start, int n_samp,
                                                      int min_pair_sites, double *__restrict__ sum_out,
                                                      int64_t *__restrict__ cnt_out) {
     const int win = blockIdx.y;
     const long long npairs = (long long)n_samp * (n_samp + 1) / 2;
-    const int32_t *Cw = Cmat + (size_t)win * N * N;
+    const int32_t *Cw = Cmat + (size_t)win * cN * cN;
     const int32_t *Dw = Dmat + (size_t)win * N * N;
     const int thr = min_pair_sites > 1 ? min_pair_sites : 1;
     for (long long pidx = (long long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__
         for (int a = samp_start[s]; a < samp_start[s + 1]; ++a)
             for (int b = samp_start[t]; b < samp_start[t + 1]; ++b) {
                 if (s == t && a >= b) continue;
-                const int c = Cw[(size_t)a * N + b];
+                const int c = Cw[(size_t)(a >> cshift) * cN + (b >> cshift)];
                 if (c >= thr) { sum += (double)Dw[(size_t)a * N + b] / (double)c; ++cnt; }
             }
         sum_out[(size_t)win * npairs + pidx] = sum;
@@ -390,14 +390,14 @@ __global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__
     }
 }
 
-void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int n_win,
+void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,
                            int64_t *cnt_out) {
     if (n_win <= 0 || n_samp <= 0) return;
     long long npairs = (long long)n_samp * (n_samp + 1) / 2;
     int bx = (int)((npairs + 255) / 256);
     if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(k_indpair_fin, dim3(bx, n_win), dim3(256), 0, st, Cmat, Dmat, N, samp_start, n_samp,
+    hipLaunchKernelGGL(k_indpair_fin, dim3(bx, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, samp_start, n_samp,
                        min_pair_sites, sum_out, cnt_out);
 }
 

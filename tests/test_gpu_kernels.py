@@ -156,3 +156,54 @@ def test_errors_are_loud_not_fatal():
     with pytest.raises(PopgenError):
         e.batch([50], [40]).hapCalled()
     e.close()
+
+
+@pytest.mark.parametrize("mode", ["default", "PG_NO_DIP", "PG_PAIR_V1"])
+def test_every_pairwise_code_path_gives_the_same_integers(mode, monkeypatch):
+    """diploid fast path (called counts per individual), per-haplotype v2 path, and the v1 kernel"""
+    if mode != "default":
+        monkeypatch.setenv(mode, "1")
+    e, lay, codes, _ = G.make_engine(70, 4, 5000, seed=77, var_thr=9000, miss_thr=4000)
+    wins = [(0, 2100), (2100, 4167), (4167, 5000), (13, 14)]
+    D, C = e.batch([w[0] for w in wins], [w[1] for w in wins]).pairCounts(reference_order=True)
+    for k, (a, b) in enumerate(wins):
+        Do, Co = orc.pair_counts_gemm(oracle_aln(lay, codes, a, b))
+        assert np.array_equal(C[k], Co) and np.array_equal(D[k], Do), (mode, k)
+    e.close()
+
+
+def test_half_missing_genotypes_fall_back_to_haplotype_level_called_counts():
+    """phased data such as `A|N`: the two haplotypes of an individual differ in calledness, so the per-individual
+    called-count shortcut must be abandoned (and the result still be exact)"""
+    from genomics_general_amd.engine import Engine
+    names, lay = G.make_layout(21, 3)
+    sid, pos = synth.dense_sites(3000, 1)
+    codes = synth.gen_codes(5, sid, pos, 21, 3, hap_index=G.slot_gen_hap(names, lay), var_thr=30000, miss_thr=3000).copy()
+    rng = np.random.default_rng(0)
+    knock = rng.random(codes.shape) < 0.02
+    codes[knock] = 0
+    e = Engine(0)
+    e.set_layout(lay)
+    e.load_sites(codes)
+    wins = [(0, 1500), (1500, 3000)]
+    wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
+    D, C = wb.pairCounts(reference_order=True)
+    st = wb.groupDistStats(True, 5, 0.01)
+    for k, (a, b) in enumerate(wins):
+        aln = oracle_aln(lay, codes, a, b)
+        Do, Co = orc.pair_counts_gemm(aln)
+        assert np.array_equal(C[k], Co) and np.array_equal(D[k], Do)
+        so, _ = orc.group_dist_stats(aln, Do, Co, True, 5, 0.01)
+        for key, v in so.items():
+            assert G.close(st[key][k], v), (key, k)
+    e.close()
+
+
+def test_dense_polymorphism_and_multiallelic_sites():
+    """every site variable, many third alleles: the compaction emits whole words"""
+    e, lay, codes, _ = G.make_engine(12, 2, 2500, seed=88, var_thr=65536, miss_thr=9000)
+    D, C = e.batch([0, 700], [700, 2500]).pairCounts(reference_order=True)
+    for k, (a, b) in enumerate([(0, 700), (700, 2500)]):
+        Do, Co = orc.pair_counts_gemm(oracle_aln(lay, codes, a, b))
+        assert np.array_equal(C[k], Co) and np.array_equal(D[k], Do)
+    e.close()
