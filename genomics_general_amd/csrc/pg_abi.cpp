@@ -50,6 +50,12 @@ extern "C" int pg_ctx_create(pg_ctx **out, int device) {
         delete c;
         return pg_fail(PG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return pg_fail(PG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
     *out = c;
     return PG_OK;
 }
@@ -70,7 +76,17 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     if (!c) return PG_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream2);
     pg_comm_destroy(c);
+    for (int k = 0; k < 2; ++k) {
+        c->slot[k].Vp.release();
+        c->slot[k].XV.release();
+        c->slot[k].nw.release();
+        c->slot[k].win.release();
+        if (c->slot[k].packed) (void)hipEventDestroy(c->slot[k].packed);
+        if (c->slot[k].consumed) (void)hipEventDestroy(c->slot[k].consumed);
+    }
+    (void)hipStreamDestroy(c->stream2);
     drop_events(c);
     c->gt.release();
     c->hap_pop.release();
@@ -278,6 +294,7 @@ int pg_time_end(pg_ctx *c, int k, hipEvent_t e0, hipEvent_t e1, int launches) {
 
 static int fold_events(pg_ctx *c) {
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream2));
     for (int k = 0; k < PG_K_COUNT_; ++k) {
         for (auto &pr : c->events[k]) {
             float ms = 0.f;
@@ -407,74 +424,154 @@ static int stage_windows2(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w
 
 static bool use_v2(const pg_ctx *c) { return c->NP <= 1024 && getenv("PG_PAIR_V1") == nullptr; }
 
-// Run pack + pairwise over windows in batches that fit the scratch budget; `consume(batch_w0, batch_n)` is called with the
-// batch's matrices resident: D in ctx->Dmat ([N][N] per window, upper triangle) and the called counts in ctx->Cmat
-// ([cN][cN] per window, upper triangle, entry of haplotypes (i,j) at (i>>cshift, j>>cshift)).
+// v1 path (more than 1024 haplotype slots): pack + k_pairwise, one batch after the other on ctx->stream.
 template <class F>
-static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, bool dip, F consume) {
+static int pairwise_batches_v1(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, F consume) {
     const int N = c->n_hap, NP = c->NP;
-    const bool v2 = use_v2(c);
-    const int n_units = dip ? N / 2 : N;
-    const int NPv = dip ? (n_units + 63) / 64 * 64 : NP;
-    c->cN = n_units;
-    c->cshift = dip ? 1 : 0;
-    const int64_t mat_bytes = 4ll * N * N + 4ll * n_units * n_units;
-    // scratch bytes per 32-site input word: v1 = 5 planes; v2 = called plane + worst-case (all polymorphic) 5 planes
-    const int64_t word_bytes = v2 ? (int64_t)NP * 4 * 5 + (int64_t)NPv * 4 : (int64_t)NP * 4 * 5;
+    c->cN = N;
+    c->cshift = 0;
+    const int64_t mat_bytes = 8ll * N * N;
+    const int64_t word_bytes = (int64_t)NP * 4 * 5;
     int w0 = 0;
     while (w0 < n_win) {
         int64_t words = 0;
         int w1 = w0;
         while (w1 < n_win) {
-            int64_t wlen = ((hi[w1] - lo[w1] + 31) / 32 + PG_GROUP - 1) / PG_GROUP * PG_GROUP;
+            int64_t wlen = (hi[w1] - lo[w1] + 31) / 32;
             int64_t nb = (words + wlen) * word_bytes + (int64_t)(w1 - w0 + 1) * mat_bytes;
             if (w1 > w0 && nb > c->scratch_limit) break;
+            words += wlen;
+            ++w1;
+            if (w1 - w0 >= 65535) break;
+        }
+        const int nb = w1 - w0;
+        int rc;
+        if ((rc = c->Cmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
+        if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
+        hipEvent_t e0, e1;
+        int64_t total_words = 0, max_len = 0;
+        int max_words = 0;
+        if ((rc = stage_windows(c, lo, hi, w0, w1, &total_words, &max_words, &max_len)) != PG_OK) return rc;
+        const int64_t *d_lo = c->win.p, *d_hi = c->win.p + nb, *d_woff = c->win.p + 2 * (size_t)nb;
+        if ((rc = c->planes.ensure((size_t)std::max<int64_t>(total_words, 1) * 5 * NP)) != PG_OK) return rc;
+        if ((rc = pg_time_begin(c, PG_K_PACK, &e0, &e1)) != PG_OK) return rc;
+        pg_launch_pack(c->stream, c->gt.p, c->S, d_lo, d_hi, d_woff, nb, max_words, c->planes.p, NP);
+        if ((rc = pg_time_end(c, PG_K_PACK, e0, e1, 1)) != PG_OK) return rc;
+        if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
+        pg_launch_pairwise(c->stream, c->planes.p, d_woff, nb, c->tasks.p, c->n_tasks, NP, N, c->Cmat.p, c->Dmat.p);
+        if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
+        HIPCHK(hipGetLastError());
+        if ((rc = consume(w0, nb)) != PG_OK) return rc;
+        w0 = w1;
+    }
+    return PG_OK;
+}
+
+// v2 path.  Windows are cut into sub-batches; k_pack2 of sub-batch k+1 runs on ctx->stream2 while k_pairC / k_pairD and
+// `consume` of sub-batch k run on ctx->stream (two slots of planes).  `consume(batch_w0, batch_n)` is called with the
+// batch's matrices queued on ctx->stream: D in ctx->Dmat ([N][N] per window, upper triangle) and the called counts in
+// ctx->Cmat ([cN][cN] per window, upper triangle, entry of haplotypes (i,j) at (i>>cshift, j>>cshift)).
+template <class F>
+static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, bool dip, F consume) {
+    if (!use_v2(c)) return pairwise_batches_v1(c, lo, hi, n_win, consume);
+    const int N = c->n_hap, NP = c->NP;
+    const int n_units = dip ? N / 2 : N;
+    const int NPv = dip ? (n_units + 63) / 64 * 64 : NP;
+    c->cN = n_units;
+    c->cshift = dip ? 1 : 0;
+    const int64_t mat_bytes = 4ll * N * N + 4ll * n_units * n_units;
+    // scratch bytes per 32-site input word of one slot: called plane + worst-case (all polymorphic) 5 planes
+    const int64_t word_bytes = (int64_t)NP * 4 * 5 + (int64_t)NPv * 4;
+    // sub-batch size: at most half the scratch budget per slot, and at least ~8 sub-batches per call so the two
+    // streams have something to overlap (but not so small that a sub-batch cannot fill the GPU)
+    int64_t total_words_all = 0;
+    for (int w = 0; w < n_win; ++w) total_words_all += ((hi[w] - lo[w] + 31) / 32 + PG_GROUP - 1) / PG_GROUP * PG_GROUP;
+    // measured on MI355X (profiles/): k_pack2 is itself ~75 % VALU-issue bound, so running it beside the pair kernels
+    // gains nothing yet; sub-batching stays opt-in until the pack kernel is HBM-bound
+    const bool overlap = getenv("PG_OVERLAP") != nullptr;
+    int64_t target_words = overlap ? std::max<int64_t>(total_words_all / 8, 32768) : total_words_all;
+    for (int k = 0; k < 2; ++k) {
+        if (!c->slot[k].packed) HIPCHK(hipEventCreateWithFlags(&c->slot[k].packed, hipEventDisableTiming));
+        if (!c->slot[k].consumed) HIPCHK(hipEventCreateWithFlags(&c->slot[k].consumed, hipEventDisableTiming));
+        c->slot[k].used = false;
+    }
+    int w0 = 0, bi = 0;
+    while (w0 < n_win) {
+        int64_t words = 0;
+        int w1 = w0;
+        while (w1 < n_win) {
+            int64_t wlen = ((hi[w1] - lo[w1] + 31) / 32 + PG_GROUP - 1) / PG_GROUP * PG_GROUP;
+            int64_t nbytes = (words + wlen) * word_bytes + (int64_t)(w1 - w0 + 1) * mat_bytes;
+            if (w1 > w0 && (nbytes > c->scratch_limit / 2 || words + wlen > target_words)) break;
             words += wlen;
             ++w1;
             if (w1 - w0 >= 65535) break;                      // gridDim.y limit
         }
         const int nb = w1 - w0;
+        pg_ctx::Slot &sl = c->slot[bi & 1];
         int rc;
+        // the slot's previous occupant (sub-batch bi-2) must be fully consumed before its planes are overwritten, and
+        // its staging vector must have been copied before it is rebuilt
+        if (sl.used) {
+            HIPCHK(hipStreamWaitEvent(c->stream2, sl.consumed, 0));
+            HIPCHK(hipEventSynchronize(sl.packed));
+        }
+        // stage [lo | hi | goff(n+1) | vgoff(n+1)]
+        std::vector<int64_t> &h = sl.host;
+        h.assign(4 * (size_t)nb + 2, 0);
+        int64_t ga = 0, va = 0;
+        int max_groups = 0;
+        for (int k = 0; k < nb; ++k) {
+            h[k] = lo[w0 + k];
+            h[nb + k] = hi[w0 + k];
+            const int64_t wds = (hi[w0 + k] - lo[w0 + k] + 31) / 32;
+            h[2 * (size_t)nb + k] = ga;
+            h[3 * (size_t)nb + 1 + k] = va;
+            const int64_t groups = (wds + PG_GROUP - 1) / PG_GROUP;
+            ga += groups;
+            va += (wds + 3) / 4;
+            max_groups = (int)std::max<int64_t>(max_groups, groups);
+        }
+        h[3 * (size_t)nb] = ga;
+        h[4 * (size_t)nb + 1] = va;
+        if ((rc = sl.win.upload(h.data(), h.size(), c->stream2)) != PG_OK) return rc;
+        const int64_t *d_lo = sl.win.p, *d_hi = sl.win.p + nb, *d_goff = sl.win.p + 2 * (size_t)nb,
+                      *d_vgoff = sl.win.p + 3 * (size_t)nb + 1;
+        if ((rc = sl.Vp.ensure((size_t)std::max<int64_t>(va, 1) * NPv * 4)) != PG_OK) return rc;
+        if ((rc = sl.XV.ensure((size_t)std::max<int64_t>(ga, 1) * PG_GROUP * 5 * NP)) != PG_OK) return rc;
+        if ((rc = sl.nw.ensure((size_t)std::max<int64_t>(ga, 1))) != PG_OK) return rc;
         if ((rc = c->Cmat.ensure((size_t)nb * n_units * n_units)) != PG_OK) return rc;
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
         hipEvent_t e0, e1;
-        if (!v2) {
-            int64_t total_words = 0, max_len = 0;
-            int max_words = 0;
-            if ((rc = stage_windows(c, lo, hi, w0, w1, &total_words, &max_words, &max_len)) != PG_OK) return rc;
-            const int64_t *d_lo = c->win.p, *d_hi = c->win.p + nb, *d_woff = c->win.p + 2 * (size_t)nb;
-            if ((rc = c->planes.ensure((size_t)std::max<int64_t>(total_words, 1) * 5 * NP)) != PG_OK) return rc;
-            if ((rc = pg_time_begin(c, PG_K_PACK, &e0, &e1)) != PG_OK) return rc;
-            pg_launch_pack(c->stream, c->gt.p, c->S, d_lo, d_hi, d_woff, nb, max_words, c->planes.p, NP);
-            if ((rc = pg_time_end(c, PG_K_PACK, e0, e1, 1)) != PG_OK) return rc;
-            if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
-            pg_launch_pairwise(c->stream, c->planes.p, d_woff, nb, c->tasks.p, c->n_tasks, NP, N, c->Cmat.p, c->Dmat.p);
-            if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
-        } else {
-            int64_t total_groups = 0, total_vg = 0;
-            int max_groups = 0;
-            if ((rc = stage_windows2(c, lo, hi, w0, w1, &total_groups, &total_vg, &max_groups)) != PG_OK) return rc;
-            const int64_t *d_lo = c->win.p, *d_hi = c->win.p + nb, *d_goff = c->win.p + 2 * (size_t)nb,
-                          *d_vgoff = c->win.p + 3 * (size_t)nb + 1;
-            if ((rc = c->Vp.ensure((size_t)std::max<int64_t>(total_vg, 1) * NPv * 4)) != PG_OK) return rc;
-            if ((rc = c->XY.ensure((size_t)std::max<int64_t>(total_groups, 1) * PG_GROUP * 5 * NP)) != PG_OK) return rc;
-            if ((rc = c->nw.ensure((size_t)std::max<int64_t>(total_groups, 1))) != PG_OK) return rc;
-            if ((rc = pg_time_begin(c, PG_K_PACK, &e0, &e1)) != PG_OK) return rc;
-            pg_launch_pack2(c->stream, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, c->Vp.p, NPv, c->XY.p, NP,
-                            c->nw.p, dip ? 1 : 0, c->flag.p);
-            if ((rc = pg_time_end(c, PG_K_PACK, e0, e1, 1)) != PG_OK) return rc;
-            if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
-            if (dip) pg_launch_pairC(c->stream, c->Vp.p, d_vgoff, nb, c->tasksC.p, c->n_tasksC, NPv, n_units, 1, total_vg / nb, c->Cmat.p);
-            else pg_launch_pairC(c->stream, c->Vp.p, d_vgoff, nb, c->tasks2.p, c->n_tasks2, NPv, n_units, 0, total_vg / nb, c->Cmat.p);
-            if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
-            if ((rc = pg_time_begin(c, PG_K_PAIRD, &e0, &e1)) != PG_OK) return rc;
-            pg_launch_pairD(c->stream, c->XY.p, c->nw.p, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, total_groups / nb, c->Dmat.p);
-            if ((rc = pg_time_end(c, PG_K_PAIRD, e0, e1, 1)) != PG_OK) return rc;
-        }
+        // ---- stream2: pack ----
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, c->stream2));
+        pg_launch_pack2(c->stream2, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, sl.Vp.p, NPv, sl.XV.p, NP,
+                        sl.nw.p, dip ? 1 : 0, c->flag.p);
+        HIPCHK(hipEventRecord(e1, c->stream2));
+        c->events[PG_K_PACK].push_back(std::make_pair(e0, e1));
+        c->acc_launches[PG_K_PACK] += 1;
+        HIPCHK(hipEventRecord(sl.packed, c->stream2));
+        // ---- stream: pair kernels + consume ----
+        HIPCHK(hipStreamWaitEvent(c->stream, sl.packed, 0));
+        if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
+        if (dip) pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasksC.p, c->n_tasksC, NPv, n_units, 1, va / nb, c->Cmat.p);
+        else pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasks2.p, c->n_tasks2, NPv, n_units, 0, va / nb, c->Cmat.p);
+        if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
+        if ((rc = pg_time_begin(c, PG_K_PAIRD, &e0, &e1)) != PG_OK) return rc;
+        pg_launch_pairD(c->stream, sl.XV.p, sl.nw.p, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, ga / nb, c->Dmat.p);
+        if ((rc = pg_time_end(c, PG_K_PAIRD, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
         if ((rc = consume(w0, nb)) != PG_OK) return rc;
+        HIPCHK(hipEventRecord(sl.consumed, c->stream));
+        sl.used = true;
         w0 = w1;
+        ++bi;
     }
+    // leave both streams quiescent with respect to each other: later work on ctx->stream must see stream2's writes done
+    for (int k = 0; k < 2; ++k)
+        if (c->slot[k].used) HIPCHK(hipEventSynchronize(c->slot[k].packed));
     return PG_OK;
 }
 
@@ -486,7 +583,7 @@ static int pairwise_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_w
     int rc;
     if ((rc = c->flag.ensure(1)) != PG_OK) return rc;
     if (dip) {
-        HIPCHK(hipMemsetAsync(c->flag.p, 0, 4, c->stream));
+        HIPCHK(hipMemsetAsync(c->flag.p, 0, 4, c->stream2));      // k_pack2 (stream2) raises it
         if ((rc = pairwise_batches(c, lo, hi, n_win, true, consume)) != PG_OK) return rc;
         int32_t flag = 0;
         HIPCHK(hipMemcpyAsync(&flag, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream));

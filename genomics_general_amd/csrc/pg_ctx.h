@@ -62,8 +62,19 @@ struct pg_ctx {
     DevBuf<PgTask2> tasksC;      // v2 k_pairC when its units are diploid individuals (diagonal included)
     int n_tasksC = 0;
     bool all_diploid = false;    // every individual owns exactly slots (2k, 2k+1)
-    DevBuf<uint32_t> Vp, XY;     // v2 planes
+    DevBuf<uint32_t> Vp, XY;     // v2 planes (slot 0; also used by nothing else)
     DevBuf<int32_t> nw;          // v2: compacted words per group
+    // v2 software pipeline: k_pack2 of sub-batch k+1 (HBM-bound, stream2) overlaps the pair kernels of sub-batch k
+    // (VALU-bound, stream).  Two slots of planes / window tables.
+    hipStream_t stream2 = nullptr;
+    struct Slot {
+        DevBuf<uint32_t> Vp, XV;
+        DevBuf<int32_t> nw;
+        DevBuf<int64_t> win;
+        std::vector<int64_t> host;        // staging of [lo | hi | goff | vgoff], alive until its H2D copy completed
+        hipEvent_t packed = nullptr, consumed = nullptr;
+        bool used = false;
+    } slot[2];
     DevBuf<int32_t> flag;        // v2: [0] = some window had haplotypes of one individual with different calledness
     DevBuf<int32_t> Cfull, Dfull;  // pg_pairwise staging
     // how the matrices of the last batch are laid out (set by pairwise_batches)
