@@ -403,102 +403,364 @@ void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *D
 
 // ------------------------------------------------------------------------------------------------------
 // Per-site population base counts (SWAR on one-hot bytes): cnt[b] = #haplotypes of [s,e) with allele b.
+// `row` = the site's S/4 dwords (global memory or an LDS tile row); only the first and last dword of a range need a mask.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void range_counts(const int8_t *__restrict__ row, int s, int e, uint32_t cnt[4]) {
+__device__ __forceinline__ void count_dword(uint32_t v, uint32_t cnt[4]) {
+    cnt[0] += __popc(v & 0x01010101u);
+    cnt[1] += __popc(v & 0x02020202u);
+    cnt[2] += __popc(v & 0x04040404u);
+    cnt[3] += __popc(v & 0x08080808u);
+}
+
+__device__ __forceinline__ void range_counts(const uint32_t *__restrict__ row, int s, int e, uint32_t cnt[4]) {
     cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0u;
     if (e <= s) return;
     const int d0 = s >> 2, d1 = (e - 1) >> 2;
-    for (int d = d0; d <= d1; ++d) {
-        uint32_t v = *reinterpret_cast<const uint32_t *>(row + 4 * d);
-        const int lo = (s > 4 * d ? s - 4 * d : 0), hi = (e < 4 * d + 4 ? e - 4 * d : 4);
-        uint32_t m = (hi == 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
-        v &= m;
-        cnt[0] += __popc(v & 0x01010101u);
-        cnt[1] += __popc(v & 0x02020202u);
-        cnt[2] += __popc(v & 0x04040404u);
-        cnt[3] += __popc(v & 0x08080808u);
+    const uint32_t m_first = ~((1u << (8 * (s & 3))) - 1u);
+    const int hi = ((e - 1) & 3) + 1;
+    const uint32_t m_last = hi == 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
+    if (d0 == d1) {
+        count_dword(row[d0] & m_first & m_last, cnt);
+        return;
     }
+    count_dword(row[d0] & m_first, cnt);
+    for (int d = d0 + 1; d < d1; ++d) count_dword(row[d], cnt);
+    count_dword(row[d1] & m_last, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K_abba: grid (chunk, window); 256 threads x 4 sites.  Per-site terms follow genomics.py:1409-1475 and
-// 1565-1569 operation for operation; per-block partial sums are combined by k_abba_reduce in chunk order.
+// LDS tile staging for the site-statistics kernels: a block copies TS consecutive site rows (one contiguous TS*S byte
+// region of the site-major buffer) into LDS with fully coalesced 16-byte loads, then each thread owns one site row.
+// (A thread reading its own row straight from global memory touches 64 different cache lines per wave instruction:
+// measured 0.45 TB/s; the staged version is bandwidth-bound.)
+// ------------------------------------------------------------------------------------------------------
+// Double-buffered LDS-DMA tile stream.  A tile = TS = blockDim.x consecutive site rows = one contiguous TS*S byte region,
+// copied with `global_load_lds_dwordx4` (no VGPR staging, 1 KiB per wave instruction, LDS image linear).  Wave w issues
+// K = S/16 instructions per tile, instruction j covering 16-byte chunks [(j*nw+w)*64, +64).  Loop shape per tile:
+//     s_waitcnt vmcnt(0)  ->  s_barrier  ->  issue tile t+1 into the other buffer  ->  compute tile t
+// so the next tile's loads are in flight during the whole compute phase, and the single barrier also guarantees that
+// every wave has finished reading the buffer about to be overwritten.  hipcc does not count asm loads (guide 5.7): the
+// waits are ours.
+#define PG_TILE_LDS_BUDGET (52 * 1024)      // both buffers; keeps 3 blocks per CU
+
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void tile_issue(const int8_t *__restrict__ gt, int S, int64_t site0, int ns, uint32_t lds_byte) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6, lane = threadIdx.x & 63;
+    const int K = S >> 4;
+    const int last = ns * K - 1;                         // rows beyond ns are filled with a copy of the last chunk
+    const int8_t *base = gt + site0 * (int64_t)S;
+    for (int j = 0; j < K; ++j) {
+        const int blk = j * nw + wave;
+        int c = blk * 64 + lane;
+        c = c < last ? c : last;
+        glds16(base + (size_t)c * 16u, lds_byte + (uint32_t)blk * 1024u);
+    }
+}
+
+__device__ __forceinline__ void tile_wait_and_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+static int tile_sites(int S) {              // sites per tile = threads per block (multiple of 64), 0 = row too long for LDS
+    if (S > 1008) return 0;                 // K = S/16 LDS-DMA instructions per wave must stay below the vmcnt range
+    int ts = PG_TILE_LDS_BUDGET / (2 * S);
+    ts = (ts / 64) * 64;
+    if (ts < 64) ts = 64;
+    return ts > 256 ? 256 : ts;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_abba: grid (chunk, window).  Per-site terms follow genomics.py:1409-1475 and 1565-1569 operation for operation;
+// per-block partial sums are combined by k_abba_reduce in chunk order (deterministic).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double f4_term(double a, double b, double c, double d) {
     return (1 - a) * b * c * (1 - d) - a * (1 - b) * c * (1 - d);
 }
 
+struct AbbaAcc {
+    double acc[PG_ABBA_NSUM];
+    unsigned long long used;
+};
+
+// Integer phase: per-population base counts of one site.  Returns true when the site is usable (biallelic among the called
+// alleles of the four populations, every population has >= nmin[q] called haplotypes, and exactly one allele is present
+// overall but absent from the outgroup) and then fills e = {c1, c2, c3 (derived-allele counts), n1..n4}.
+// nmin[q] = smallest n with (double)n * 1. / (double)N_q >= min_data (the reference's test, genomics.py:1657-1660, is
+// monotone in n, so comparing integers is the same predicate).
+__device__ __forceinline__ bool abba_counts(const uint32_t *__restrict__ row, const int ps[4], const int pe[4],
+                                            const int nmin[4], uint32_t e[7]) {
+    uint32_t cnt[4][4];
+    uint32_t n[4], tot[4] = {0u, 0u, 0u, 0u};
+    bool enough = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        range_counts(row, ps[q], pe[q], cnt[q]);
+        n[q] = cnt[q][0] + cnt[q][1] + cnt[q][2] + cnt[q][3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) tot[b] += cnt[q][b];
+        enough = enough && ((int)n[q] >= nmin[q]);
+    }
+    const int nall = (tot[0] > 0) + (tot[1] > 0) + (tot[2] > 0) + (tot[3] > 0);
+    if (nall != 2 || !enough) return false;                                                // :1655, :1662
+    // alleleIndex = where((all4freqs > 0) & (P4freqs == 0)), genomics.py:1672: tot[b] > 0 and cnt_O[b]/n_O == 0.0, which
+    // needs n_O > 0 (0/0 is nan).  At a biallelic site with n_O > 0 at most one allele qualifies.
+    if (n[3] == 0) return false;
+    int b = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (tot[k] > 0 && cnt[3][k] == 0) b = k;
+    if (b < 0) return false;
+    e[0] = cnt[0][b]; e[1] = cnt[1][b]; e[2] = cnt[2][b];
+    e[3] = n[0]; e[4] = n[1]; e[5] = n[2]; e[6] = n[3];
+    return true;
+}
+
+// Float64 phase for one usable site (operation order of genomics.py:1409-1475, 1565-1569).
+__device__ __forceinline__ void abba_terms(const uint32_t e[7], AbbaAcc &A) {
+    const double p1 = (double)e[0] / (double)e[3];
+    const double p2 = (double)e[1] / (double)e[4];
+    const double p3 = (double)e[2] / (double)e[5];
+    const double p4 = (double)0u / (double)e[6];
+    const double abba = (1 - p1) * p2 * p3 * (1 - p4);
+    const double baba = p1 * (1 - p2) * p3 * (1 - p4);
+    A.acc[0] += f4_term(p1, p2, p3, p4);
+    A.acc[1] += abba + baba;
+    const double pd = p2 * (double)(p2 > p3) + p3 * (double)(p3 >= p2);              // :1446
+    A.acc[2] += f4_term(p1, pd, pd, p4);
+    const bool a = p3 > p1, bb = p3 > p2, x = p1 > p2, y = !x;                       // :1460-1468
+    const double xa = (double)(x && a), nxa = (double)(!(x && a));
+    const double yb = (double)(y && bb), nyb = (double)(!(y && bb));
+    const double pdm1 = p3 * xa + p1 * nxa;
+    const double pdm2 = p3 * yb + p2 * nyb;
+    const double pdm3 = -p3 * xa + p3 * yb - p1 * (double)(x && !a) + p2 * (double)(y && !bb);
+    A.acc[3] += f4_term(pdm1, pdm2, pdm3, p4);
+    A.acc[4] += abba;
+    A.acc[5] += baba;
+    ++A.used;
+}
+
+// TILED = 1: blockDim.x sites per LDS tile; TILED = 0: rows read straight from global memory (rows too long for LDS).
+// Usable sites (~10 % of the sites of real data) are compacted, in site order, into an LDS list before the float64 phase, so
+// the divisions are issued by ceil(usable/64) waves instead of by every wave.
+template <int TILED>
 __global__ __launch_bounds__(256) void k_abba(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
                                               const int64_t *__restrict__ win_hi, int max_chunks,
                                               const int32_t *__restrict__ pop_start, int q1, int q2, int q3, int q4,
                                               double min_data, double *__restrict__ part_sums,
                                               int64_t *__restrict__ part_used) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
     __shared__ double shd[256];
     __shared__ unsigned long long shu[256];
+    __shared__ uint32_t list[256][8];
+    __shared__ int wave_cnt[4];
     const int win = blockIdx.y, chunk = blockIdx.x;
     const int64_t lo = win_lo[win], hi = win_hi[win];
     const int64_t c0 = lo + (int64_t)chunk * PG_SITES_PER_BLOCK;
-    double acc[PG_ABBA_NSUM];
+    AbbaAcc A;
 #pragma unroll
-    for (int k = 0; k < PG_ABBA_NSUM; ++k) acc[k] = 0.0;
-    unsigned long long used = 0;
+    for (int k = 0; k < PG_ABBA_NSUM; ++k) A.acc[k] = 0.0;
+    A.used = 0;
     const int ps[4] = {pop_start[q1], pop_start[q2], pop_start[q3], pop_start[q4]};
     const int pe[4] = {pop_start[q1 + 1], pop_start[q2 + 1], pop_start[q3 + 1], pop_start[q4 + 1]};
+    int nmin[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int Nq = pe[q] - ps[q];
+        int n = 0;
+        while (n <= Nq && !((double)n * 1. / (double)Nq >= min_data)) ++n;       // n = Nq+1 when no count passes
+        nmin[q] = n;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     if (c0 < hi) {
-        for (int k = 0; k < PG_SITES_PER_BLOCK / 256; ++k) {
-            const int64_t site = c0 + k * 256 + threadIdx.x;
-            if (site >= hi) break;
-            const int8_t *row = gt + site * (int64_t)S;
-            uint32_t cnt[4][4];
-            uint32_t n[4], tot[4] = {0u, 0u, 0u, 0u};
-            bool enough = true;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                range_counts(row, ps[q], pe[q], cnt[q]);
-                n[q] = cnt[q][0] + cnt[q][1] + cnt[q][2] + cnt[q][3];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) tot[b] += cnt[q][b];
-                enough = enough && ((double)n[q] * 1. / (double)(pe[q] - ps[q]) >= min_data);   // genomics.py:1657-1660
+        const int64_t c1 = (c0 + PG_SITES_PER_BLOCK < hi) ? c0 + PG_SITES_PER_BLOCK : hi;
+        const int TS = blockDim.x;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)tile;
+        const uint32_t buf_bytes = (uint32_t)TS * (uint32_t)S;
+        int it = 0;
+        if (TILED) {
+            const int ns0 = (int)((c1 - c0) < (int64_t)TS ? (c1 - c0) : (int64_t)TS);
+            tile_issue(gt, S, c0, ns0, lds0);
+        }
+        for (int64_t t0 = c0; t0 < c1; t0 += TS, ++it) {
+            const int ns = (int)((c1 - t0) < (int64_t)TS ? (c1 - t0) : (int64_t)TS);
+            uint32_t e[7];
+            bool good = false;
+            if (TILED) {
+                tile_wait_and_sync();                       // tile `it` landed; buffer (it+1)&1 and the list are free
+                if (t0 + TS < c1) {
+                    const int nsn = (int)((c1 - t0 - TS) < (int64_t)TS ? (c1 - t0 - TS) : (int64_t)TS);
+                    tile_issue(gt, S, t0 + TS, nsn, lds0 + ((it + 1) & 1) * buf_bytes);
+                }
+                const uint32_t *rows = tile + (size_t)(it & 1) * (buf_bytes >> 2);
+                if ((int)threadIdx.x < ns) good = abba_counts(rows + (size_t)threadIdx.x * (S >> 2), ps, pe, nmin, e);
+            } else {
+                __syncthreads();
+                if ((int)threadIdx.x < ns)
+                    good = abba_counts(reinterpret_cast<const uint32_t *>(gt + (t0 + threadIdx.x) * (int64_t)S), ps, pe, nmin, e);
             }
-            const int nall = (tot[0] > 0) + (tot[1] > 0) + (tot[2] > 0) + (tot[3] > 0);
-            if (nall != 2 || !enough) continue;                                                    // :1655, :1662
-            const uint32_t ntot = n[0] + n[1] + n[2] + n[3];
+            // rank of this usable site in site order
+            const unsigned long long bal = __ballot(good);
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[wave] = __popcll(bal);
+            __syncthreads();
+            int base = 0, total = 0;
+            for (int w = 0; w < nwave; ++w) {
+                if (w < wave) base += wave_cnt[w];
+                total += wave_cnt[w];
+            }
+            if (good) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) list[base + before][k] = e[k];
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < total) {
+                uint32_t f[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) f[k] = list[threadIdx.x][k];
+                abba_terms(f, A);
+            }
+        }
+    }
+    __syncthreads();
+    const size_t o = (size_t)win * max_chunks + chunk;
+#pragma unroll
+    for (int k = 0; k < PG_ABBA_NSUM; ++k) {
+        const double r = block_sum_f64(A.acc[k], shd);
+        if (threadIdx.x == 0) part_sums[o * PG_ABBA_NSUM + k] = r;
+    }
+    const unsigned long long u = block_sum_u64(A.used, shu);
+    if (threadIdx.x == 0) part_used[o] = (int64_t)u;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_abba_q: four lanes per site, one per population (P1,P2,P3,O).  A wave covers 16 consecutive site rows, i.e. a contiguous
+// 16*S byte span that stays in L1 while the lanes walk their own population's byte range with 16-byte loads; no LDS row
+// staging, so occupancy is not LDS-limited.  The four lanes of a site exchange counts with quad shuffles; usable sites are
+// appended, in site order, to an LDS list and the float64 phase runs on full waves of list entries.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void range_counts_x4(const int8_t *__restrict__ rowb, int s, int e, uint32_t cnt[4]) {
+    cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0u;
+    if (e <= s) return;
+    // bytes [s,e): 16-byte loads from the dword holding s (rows are 16-byte padded and the buffer has slack rows, so reading
+    // a little past e is safe); only the first and the last dword of the range need a byte mask
+    const int b0 = s & ~3;
+    const int last = (e - 1) & ~3;                                         // byte offset of the last dword
+    const uint32_t m_first = ~((1u << (8 * (s & 3))) - 1u);
+    const int hi = ((e - 1) & 3) + 1;
+    const uint32_t m_last = hi == 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
+    for (int b = b0; b <= last; b += 16) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(rowb + b);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (b == b0) w[0] &= m_first;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int off = b + 4 * k;
+            if (off == last) w[k] &= m_last;
+            if (off > last) w[k] = 0u;
+            count_dword(w[k], cnt);
+        }
+    }
+}
+
+#define PG_ABBA_RING 128          // per-wave ring of usable sites waiting for the float64 phase
+
+__global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
+                                                const int64_t *__restrict__ win_hi, int max_chunks,
+                                                const int32_t *__restrict__ pop_start, int q1, int q2, int q3, int q4,
+                                                double min_data, double *__restrict__ part_sums,
+                                                int64_t *__restrict__ part_used) {
+    __shared__ double shd[256];
+    __shared__ unsigned long long shu[256];
+    __shared__ uint32_t ring[4][PG_ABBA_RING][8];
+    const int win = blockIdx.y, chunk = blockIdx.x;
+    const int64_t lo = win_lo[win], hi = win_hi[win];
+    const int64_t c0 = lo + (int64_t)chunk * PG_SITES_PER_BLOCK;
+    AbbaAcc A;
+#pragma unroll
+    for (int k = 0; k < PG_ABBA_NSUM; ++k) A.acc[k] = 0.0;
+    A.used = 0;
+    const int qs[4] = {q1, q2, q3, q4};
+    const int q = threadIdx.x & 3;
+    const int my_s = pop_start[qs[q]], my_e = pop_start[qs[q] + 1];
+    int my_nmin = 0;
+    {
+        const int Nq = my_e - my_s;
+        while (my_nmin <= Nq && !((double)my_nmin * 1. / (double)Nq >= min_data)) ++my_nmin;   // genomics.py:1657-1660, as integers
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qbase = lane & ~3;
+    uint32_t(*my_ring)[8] = ring[wave];
+    int head = 0, tail = 0;                             // wave-uniform ring cursors (entries [head,tail) are pending)
+    if (c0 < hi) {
+        const int64_t c1 = (c0 + PG_SITES_PER_BLOCK < hi) ? c0 + PG_SITES_PER_BLOCK : hi;
+        // a wave owns 16 consecutive sites per step; the whole loop is wave-synchronous (no block barrier)
+        for (int64_t t0 = c0 + 16 * wave; t0 < c1; t0 += 64) {
+            const int64_t site = t0 + (lane >> 2);
+            uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+            if (site < c1) range_counts_x4(gt + site * (int64_t)S, my_s, my_e, cnt);
+            const uint32_t n = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+            int ok = (site < c1) && ((int)n >= my_nmin);
+            ok &= __shfl_xor(ok, 1, 64);
+            ok &= __shfl_xor(ok, 2, 64);
+            uint32_t tot[4], c3[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                // alleleIndex = where((all4freqs > 0) & (P4freqs == 0)), genomics.py:1672; freqs are count/n
-                const double allf = (double)tot[b] / (double)ntot;
-                const double f4q = (double)cnt[3][b] / (double)n[3];
-                if (!(allf > 0.0) || !(f4q == 0.0)) continue;
-                const double p1 = (double)cnt[0][b] / (double)n[0];
-                const double p2 = (double)cnt[1][b] / (double)n[1];
-                const double p3 = (double)cnt[2][b] / (double)n[2];
-                const double p4 = f4q;
-                const double abba = (1 - p1) * p2 * p3 * (1 - p4);
-                const double baba = p1 * (1 - p2) * p3 * (1 - p4);
-                acc[0] += f4_term(p1, p2, p3, p4);
-                acc[1] += abba + baba;
-                const double pd = p2 * (double)(p2 > p3) + p3 * (double)(p3 >= p2);              // :1446
-                acc[2] += f4_term(p1, pd, pd, p4);
-                const bool a = p3 > p1, bb = p3 > p2, x = p1 > p2, y = !x;                       // :1460-1468
-                const double xa = (double)(x && a), nxa = (double)(!(x && a));
-                const double yb = (double)(y && bb), nyb = (double)(!(y && bb));
-                const double pdm1 = p3 * xa + p1 * nxa;
-                const double pdm2 = p3 * yb + p2 * nyb;
-                const double pdm3 = -p3 * xa + p3 * yb - p1 * (double)(x && !a) + p2 * (double)(y && !bb);
-                acc[3] += f4_term(pdm1, pdm2, pdm3, p4);
-                acc[4] += abba;
-                acc[5] += baba;
-                ++used;
+                uint32_t t = cnt[b] + (uint32_t)__shfl_xor((int)cnt[b], 1, 64);
+                tot[b] = t + (uint32_t)__shfl_xor((int)t, 2, 64);
+                c3[b] = (uint32_t)__shfl((int)cnt[b], qbase + 3, 64);
             }
+            const uint32_t n_o = (uint32_t)__shfl((int)n, qbase + 3, 64);
+            const int nall = (tot[0] > 0) + (tot[1] > 0) + (tot[2] > 0) + (tot[3] > 0);
+            int der = -1;                                // allele present overall, absent from the outgroup (genomics.py:1672)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (tot[b] > 0 && c3[b] == 0) der = b;
+            const bool good = ok && nall == 2 && n_o > 0 && der >= 0;
+            uint32_t cder = 0u;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (b == der) cder = cnt[b];
+            // gather the quad's derived-allele counts and called counts into its lane 0
+            const uint32_t c_p2 = (uint32_t)__shfl((int)cder, qbase + 1, 64), c_p3 = (uint32_t)__shfl((int)cder, qbase + 2, 64);
+            const uint32_t n_p2 = (uint32_t)__shfl((int)n, qbase + 1, 64), n_p3 = (uint32_t)__shfl((int)n, qbase + 2, 64);
+            const bool writer = good && q == 0;
+            const unsigned long long bal = __ballot(writer);
+            if (writer) {
+                const int before = __popcll(bal & ((1ull << lane) - 1ull));
+                uint32_t *e = my_ring[(tail + before) & (PG_ABBA_RING - 1)];
+                e[0] = cder; e[1] = c_p2; e[2] = c_p3; e[3] = n; e[4] = n_p2; e[5] = n_p3; e[6] = n_o;
+            }
+            tail += (int)__popcll(bal);
+            if (tail - head >= 64) {                     // a full wave of usable sites: float64 phase
+                uint32_t f[7];
+                const uint32_t *e = my_ring[(head + lane) & (PG_ABBA_RING - 1)];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) f[k] = e[k];
+                abba_terms(f, A);
+                head += 64;
+            }
+        }
+        if (lane < tail - head) {
+            uint32_t f[7];
+            const uint32_t *e = my_ring[(head + lane) & (PG_ABBA_RING - 1)];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) f[k] = e[k];
+            abba_terms(f, A);
         }
     }
     const size_t o = (size_t)win * max_chunks + chunk;
 #pragma unroll
     for (int k = 0; k < PG_ABBA_NSUM; ++k) {
-        const double r = block_sum_f64(acc[k], shd);
+        const double r = block_sum_f64(A.acc[k], shd);
         if (threadIdx.x == 0) part_sums[o * PG_ABBA_NSUM + k] = r;
     }
-    const unsigned long long u = block_sum_u64(used, shu);
+    const unsigned long long u = block_sum_u64(A.used, shu);
     if (threadIdx.x == 0) part_used[o] = (int64_t)u;
 }
 
@@ -525,9 +787,10 @@ void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_
                     int n_win, int max_chunks, const int32_t *pop_start, int p1, int p2, int p3, int p4,
                     double min_data, double *part_sums, int64_t *part_used, double *sums_out, int64_t *used_out) {
     if (n_win <= 0) return;
-    if (max_chunks > 0)
-        hipLaunchKernelGGL(k_abba, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi, max_chunks,
+    if (max_chunks > 0) {
+        hipLaunchKernelGGL(k_abba_q, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi, max_chunks,
                            pop_start, p1, p2, p3, p4, min_data, part_sums, part_used);
+    }
     int total = n_win * (PG_ABBA_NSUM + 1);
     hipLaunchKernelGGL(k_abba_reduce, dim3((total + 255) / 256), dim3(256), 0, st, part_sums, part_used, n_win,
                        max_chunks, win_lo, win_hi, sums_out, used_out);
@@ -536,47 +799,78 @@ void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_
 // ------------------------------------------------------------------------------------------------------
 // K_popfreq: exact integers, so the cross-block combination uses integer atomics (order independent).
 // ------------------------------------------------------------------------------------------------------
+struct FreqAcc {
+    unsigned long long l, Sx[PG_MAX_POPS], Px[PG_MAX_POPS];
+};
+
+__device__ __forceinline__ void popfreq_site(const uint32_t *__restrict__ row, int n_hap, const int32_t *__restrict__ pop_start,
+                                             int n_pops, FreqAcc &F) {
+    uint32_t call[4];
+    range_counts(row, 0, n_hap, call);
+    if ((int)(call[0] + call[1] + call[2] + call[3]) != n_hap) return;       // genomics.py:1010
+    ++F.l;
+#pragma unroll
+    for (int q = 0; q < PG_MAX_POPS; ++q) {
+        if (q < n_pops) {
+            uint32_t c[4];
+            range_counts(row, pop_start[q], pop_start[q + 1], c);
+            const unsigned long long pr = (unsigned long long)c[0] * c[1] + (unsigned long long)c[0] * c[2] +
+                                          (unsigned long long)c[0] * c[3] + (unsigned long long)c[1] * c[2] +
+                                          (unsigned long long)c[1] * c[3] + (unsigned long long)c[2] * c[3];
+            F.Px[q] += pr;
+            F.Sx[q] += (pr != 0ull);
+        }
+    }
+}
+
+template <int TILED>
 __global__ __launch_bounds__(256) void k_popfreq(const int8_t *__restrict__ gt, int S, int n_hap,
                                                  const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
                                                  const int32_t *__restrict__ pop_start, int n_pops,
                                                  unsigned long long *__restrict__ l_out,
                                                  unsigned long long *__restrict__ S_out,
                                                  unsigned long long *__restrict__ pairsum_out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
     __shared__ unsigned long long shu[256];
     const int win = blockIdx.y, chunk = blockIdx.x;
     const int64_t lo = win_lo[win], hi = win_hi[win];
     const int64_t c0 = lo + (int64_t)chunk * PG_SITES_PER_BLOCK;
     if (c0 >= hi) return;
-    unsigned long long l = 0, Sx[PG_MAX_POPS], Px[PG_MAX_POPS];
+    FreqAcc F;
+    F.l = 0;
 #pragma unroll
-    for (int q = 0; q < PG_MAX_POPS; ++q) { Sx[q] = 0; Px[q] = 0; }
-    for (int k = 0; k < PG_SITES_PER_BLOCK / 256; ++k) {
-        const int64_t site = c0 + k * 256 + threadIdx.x;
-        if (site >= hi) break;
-        const int8_t *row = gt + site * (int64_t)S;
-        uint32_t call[4];
-        range_counts(row, 0, n_hap, call);
-        if ((int)(call[0] + call[1] + call[2] + call[3]) != n_hap) continue;       // genomics.py:1010
-        ++l;
-#pragma unroll
-        for (int q = 0; q < PG_MAX_POPS; ++q) {
-            if (q < n_pops) {
-                uint32_t c[4];
-                range_counts(row, pop_start[q], pop_start[q + 1], c);
-                const unsigned long long pr = (unsigned long long)c[0] * c[1] + (unsigned long long)c[0] * c[2] +
-                                              (unsigned long long)c[0] * c[3] + (unsigned long long)c[1] * c[2] +
-                                              (unsigned long long)c[1] * c[3] + (unsigned long long)c[2] * c[3];
-                Px[q] += pr;
-                Sx[q] += (pr != 0ull);
+    for (int q = 0; q < PG_MAX_POPS; ++q) { F.Sx[q] = 0; F.Px[q] = 0; }
+    const int64_t c1 = (c0 + PG_SITES_PER_BLOCK < hi) ? c0 + PG_SITES_PER_BLOCK : hi;
+    const int TS = blockDim.x;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)tile;
+    const uint32_t buf_bytes = (uint32_t)TS * (uint32_t)S;
+    int it = 0;
+    if (TILED) {
+        const int ns0 = (int)((c1 - c0) < (int64_t)TS ? (c1 - c0) : (int64_t)TS);
+        tile_issue(gt, S, c0, ns0, lds0);
+    }
+    for (int64_t t0 = c0; t0 < c1; t0 += TS, ++it) {
+        const int ns = (int)((c1 - t0) < (int64_t)TS ? (c1 - t0) : (int64_t)TS);
+        if (TILED) {
+            tile_wait_and_sync();
+            if (t0 + TS < c1) {
+                const int nsn = (int)((c1 - t0 - TS) < (int64_t)TS ? (c1 - t0 - TS) : (int64_t)TS);
+                tile_issue(gt, S, t0 + TS, nsn, lds0 + ((it + 1) & 1) * buf_bytes);
             }
+            const uint32_t *rows = tile + (size_t)(it & 1) * (buf_bytes >> 2);
+            if ((int)threadIdx.x < ns) popfreq_site(rows + (size_t)threadIdx.x * (S >> 2), n_hap, pop_start, n_pops, F);
+        } else {
+            if ((int)threadIdx.x < ns)
+                popfreq_site(reinterpret_cast<const uint32_t *>(gt + (t0 + threadIdx.x) * (int64_t)S), n_hap, pop_start, n_pops, F);
         }
     }
-    unsigned long long r = block_sum_u64(l, shu);
+    __syncthreads();
+    unsigned long long r = block_sum_u64(F.l, shu);
     if (threadIdx.x == 0 && r) atomicAdd(&l_out[win], r);
     for (int q = 0; q < n_pops; ++q) {
-        r = block_sum_u64(Sx[q], shu);
+        r = block_sum_u64(F.Sx[q], shu);
         if (threadIdx.x == 0 && r) atomicAdd(&S_out[(size_t)win * n_pops + q], r);
-        r = block_sum_u64(Px[q], shu);
+        r = block_sum_u64(F.Px[q], shu);
         if (threadIdx.x == 0 && r) atomicAdd(&pairsum_out[(size_t)win * n_pops + q], r);
     }
 }
@@ -585,8 +879,13 @@ void pg_launch_popfreq(hipStream_t st, const int8_t *gt, int S, int n_hap, const
                        const int64_t *win_hi, int n_win, int max_chunks, const int32_t *pop_start, int n_pops,
                        unsigned long long *l_out, unsigned long long *S_out, unsigned long long *pairsum_out) {
     if (n_win <= 0 || max_chunks <= 0) return;
-    hipLaunchKernelGGL(k_popfreq, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, n_hap, win_lo, win_hi, pop_start,
-                       n_pops, l_out, S_out, pairsum_out);
+    const int ts = tile_sites(S);
+    if (ts >= 64)
+        hipLaunchKernelGGL(k_popfreq<1>, dim3(max_chunks, n_win), dim3(ts), (size_t)2 * ts * S, st, gt, S, n_hap, win_lo, win_hi,
+                           pop_start, n_pops, l_out, S_out, pairsum_out);
+    else
+        hipLaunchKernelGGL(k_popfreq<0>, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, n_hap, win_lo, win_hi, pop_start,
+                           n_pops, l_out, S_out, pairsum_out);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -597,7 +896,7 @@ __global__ __launch_bounds__(256) void k_site_counts(const int8_t *__restrict__ 
                                                      int32_t *__restrict__ cnt_out) {
     const int64_t site = site_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (site >= site_hi) return;
-    const int8_t *row = gt + site * (int64_t)S;
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(gt + site * (int64_t)S);
     for (int q = 0; q < n_pops; ++q) {
         uint32_t c[4];
         range_counts(row, pop_start[q], pop_start[q + 1], c);
