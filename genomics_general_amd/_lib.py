@@ -54,6 +54,7 @@ SIGNATURES = {
     "pg_count_lines": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "pg_pairwise": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i32p, _i32p]),
     "pg_popdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
+    "pg_popdist_stats": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_double, C.c_int, _f64p]),
     "pg_indpairdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
     "pg_abbababa": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _f64p, _i64p]),
     "pg_popfreq": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p, _i64p, _i64p]),

@@ -61,6 +61,8 @@ extern "C" int pg_ctx_create(pg_ctx **out, int device) {
 }
 
 static void drop_events(pg_ctx *c) {
+    for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
+    c->event_pool.clear();
     for (int k = 0; k < PG_K_COUNT_; ++k) {
         for (auto &pr : c->events[k]) {
             (void)hipEventDestroy(pr.first);
@@ -106,6 +108,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->Dmat.release();
     c->win.release();
     c->res_f64.release();
+    c->stats.release();
     c->res_i64.release();
     c->part_f64.release();
     c->part_i64.release();
@@ -277,9 +280,21 @@ extern "C" int pg_download_sites(pg_ctx *c, int64_t off, int8_t *gt_out, int64_t
 }
 
 // ---- kernel timing ----------------------------------------------------------------------------------
+// timing events are pooled: creating a pair per launch costs more host time than a small kernel
+static int event_get(pg_ctx *c, hipEvent_t *e) {
+    if (!c->event_pool.empty()) {
+        *e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return PG_OK;
+    }
+    HIPCHK(hipEventCreate(e));
+    return PG_OK;
+}
+
 int pg_time_begin(pg_ctx *c, int k, hipEvent_t *e0, hipEvent_t *e1) {
-    HIPCHK(hipEventCreate(e0));
-    HIPCHK(hipEventCreate(e1));
+    int rc;
+    if ((rc = event_get(c, e0)) != PG_OK) return rc;
+    if ((rc = event_get(c, e1)) != PG_OK) return rc;
     HIPCHK(hipEventRecord(*e0, c->stream));
     (void)k;
     return PG_OK;
@@ -292,6 +307,8 @@ int pg_time_end(pg_ctx *c, int k, hipEvent_t e0, hipEvent_t e1, int launches) {
     return PG_OK;
 }
 
+static int fold_events(pg_ctx *c);
+
 static int fold_events(pg_ctx *c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->stream2));
@@ -300,8 +317,8 @@ static int fold_events(pg_ctx *c) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
             c->acc_ms[k] += ms;
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
         }
         c->events[k].clear();
     }
@@ -544,8 +561,8 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
         hipEvent_t e0, e1;
         // ---- stream2: pack ----
-        HIPCHK(hipEventCreate(&e0));
-        HIPCHK(hipEventCreate(&e1));
+        if ((rc = event_get(c, &e0)) != PG_OK) return rc;
+        if ((rc = event_get(c, &e1)) != PG_OK) return rc;
         HIPCHK(hipEventRecord(e0, c->stream2));
         pg_launch_pack2(c->stream2, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, sl.Vp.p, NPv, sl.XV.p, NP,
                         sl.nw.p, dip ? 1 : 0, c->flag.p);
@@ -638,6 +655,49 @@ extern "C" int pg_popdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n
         HIPCHK(hipMemcpyAsync(sum_out, c->res_f64.p, (size_t)n_win * npairs * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(cnt_out, c->res_i64.p, (size_t)n_win * npairs * 8, hipMemcpyDeviceToHost, c->stream));
     }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites, double min_data,
+                                int do_pairs, double *stats_out) {
+    int rc = check_windows(c, lo, hi, n_win);
+    if (rc != PG_OK) return rc;
+    if (c->n_pops < 1) return pg_fail(PG_ERR_STATE, "pg_popdist_stats needs at least one population");
+    if (n_win == 0) return PG_OK;
+    if (!stats_out) return pg_fail(PG_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(c->device));
+    const int P = c->n_pops, npairs = P * (P + 1) / 2, ncols = P + (do_pairs ? P * (P - 1) : 0);
+    if ((rc = c->res_f64.ensure((size_t)n_win * npairs)) != PG_OK) return rc;
+    if ((rc = c->res_i64.ensure((size_t)n_win * npairs)) != PG_OK) return rc;
+    if ((rc = c->stats.ensure((size_t)n_win * ncols)) != PG_OK) return rc;
+    if ((rc = c->flag.ensure(1)) != PG_OK) return rc;
+    if (c->events[PG_K_PACK].size() > 4096 && (rc = fold_events(c)) != PG_OK) return rc;
+    auto consume = [&](int w0, int nb) -> int {
+        hipEvent_t e0, e1;
+        int r = pg_time_begin(c, PG_K_POPDIST_FIN, &e0, &e1);
+        if (r != PG_OK) return r;
+        pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, P, min_pair_sites,
+                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs);
+        pg_launch_popstats(c->stream, c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, nb, c->pop_start.p, P,
+                           min_data, do_pairs, c->stats.p + (size_t)w0 * ncols);
+        if ((r = pg_time_end(c, PG_K_POPDIST_FIN, e0, e1, 1)) != PG_OK) return r;
+        HIPCHK(hipGetLastError());
+        return PG_OK;
+    };
+    const bool dip = use_v2(c) && c->all_diploid && getenv("PG_NO_DIP") == nullptr;
+    int32_t flag = 0;
+    if (dip) {
+        HIPCHK(hipMemsetAsync(c->flag.p, 0, 4, c->stream2));
+        if ((rc = pairwise_batches(c, lo, hi, n_win, true, consume)) != PG_OK) return rc;
+        // one synchronisation for both the result table and the diploid-shortcut verdict
+        HIPCHK(hipMemcpyAsync(stats_out, c->stats.p, (size_t)n_win * ncols * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&flag, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!flag) return PG_OK;
+    }
+    if ((rc = pairwise_batches(c, lo, hi, n_win, false, consume)) != PG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(stats_out, c->stats.p, (size_t)n_win * ncols * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return PG_OK;
 }

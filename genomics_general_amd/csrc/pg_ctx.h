@@ -87,7 +87,8 @@ struct pg_ctx {
     DevBuf<uint32_t> planes;
     DevBuf<int32_t> Cmat, Dmat;
     DevBuf<int64_t> win;        // [lo | hi | woff]
-    DevBuf<double> res_f64, part_f64;
+    DevBuf<double> res_f64, part_f64, stats;
+    std::vector<hipEvent_t> event_pool;
     DevBuf<int64_t> res_i64, part_i64;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[PG_K_COUNT_];

@@ -67,3 +67,6 @@ void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, i
                      int NPv, int n_units, int diag, int64_t avg_wq, int32_t *Cmat);
 void pg_launch_pairD(hipStream_t st, const uint32_t *XY, const int32_t *nw, const int64_t *goff, int n_win,
                      const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat);
+
+void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts, int n_win, const int32_t *pop_start,
+                        int n_pops, double min_data, int do_pairs, double *out);

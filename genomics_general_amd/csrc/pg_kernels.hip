@@ -355,6 +355,65 @@ void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *D
 }
 
 // ------------------------------------------------------------------------------------------------------
+// K_popstats: pi / dxy / Fst from the per-pair sums and counts, one thread per (window, population pair x<=y), with the
+// float64 operations of genomics.py:88-90 (nanmean_min) and 976-993 in the reference's order (-ffp-contract=off):
+//   nanmean_min(block) = nan if 1 - (1.*n_nan/size) < minData (or nothing valid) else sum/count
+//   pi_x   : block (x,x) holds every unordered pair twice plus a nan diagonal      -> (2*sum)/(2*cnt), size n_x^2
+//   dxy    : block (x,y)                                                              -> sum/cnt, size n_x*n_y
+//   Fst    : w = 1.*n_x/(n_x+n_y); pi_s = w*pi_x + (1-w)*pi_y; pi_t over block (x+y, x+y); Fst = 1 - pi_s/pi_t
+// out[w][0..P) = pi, out[w][P + k] = dxy of the k-th pair (x<y, x-major), out[w][P + npo + k] = Fst.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double nanmean_min_dev(double total, long long n_valid, long long size, double min_data) {
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    if (size == 0) return nan;
+    const bool frac_ok = (1 - (1. * (double)(size - n_valid) / (double)size)) >= min_data;
+    if (!frac_ok || n_valid <= 0) return nan;
+    return total / (double)n_valid;
+}
+
+__global__ __launch_bounds__(256) void k_popstats(const double *__restrict__ sums, const int64_t *__restrict__ cnts, int n_win,
+                                                  const int32_t *__restrict__ pop_start, int n_pops, double min_data, int do_pairs,
+                                                  double *__restrict__ out) {
+    const int npairs = n_pops * (n_pops + 1) / 2;
+    const int npo = n_pops * (n_pops - 1) / 2;
+    const int ncols = n_pops + (do_pairs ? 2 * npo : 0);
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n_win * npairs) return;
+    const int win = (int)(idx / npairs), pidx = (int)(idx % npairs);
+    int x = 0, rem = pidx;
+    while (rem >= n_pops - x) { rem -= n_pops - x; ++x; }
+    const int y = x + rem;
+    const double *S = sums + (size_t)win * npairs;
+    const int64_t *Cn = cnts + (size_t)win * npairs;
+    const long long nx = pop_start[x + 1] - pop_start[x], ny = pop_start[y + 1] - pop_start[y];
+    auto kdiag = [&](int p) { return p * n_pops - p * (p - 1) / 2; };
+    auto pi_of = [&](int p, long long np_) { return nanmean_min_dev(2 * S[kdiag(p)], 2 * Cn[kdiag(p)], np_ * np_, min_data); };
+    double *O = out + (size_t)win * ncols;
+    if (x == y) {
+        O[x] = pi_of(x, nx);
+        return;
+    }
+    if (!do_pairs) return;
+    // index of (x,y) among the x<y pairs, x-major
+    const int k = x * n_pops - x * (x + 1) / 2 + (y - x - 1);
+    O[n_pops + k] = nanmean_min_dev(S[pidx], Cn[pidx], nx * ny, min_data);
+    const double w = 1. * (double)nx / (double)(nx + ny);
+    const double pi_s = w * pi_of(x, nx) + (1 - w) * pi_of(y, ny);
+    const double tot = 2 * S[kdiag(x)] + 2 * S[kdiag(y)] + 2 * S[pidx];
+    const long long cnt = 2 * Cn[kdiag(x)] + 2 * Cn[kdiag(y)] + 2 * Cn[pidx];
+    const double pi_t = nanmean_min_dev(tot, cnt, (nx + ny) * (nx + ny), min_data);
+    O[n_pops + npo + k] = 1 - pi_s / pi_t;
+}
+
+void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts, int n_win, const int32_t *pop_start,
+                        int n_pops, double min_data, int do_pairs, double *out) {
+    if (n_win <= 0 || n_pops <= 0) return;
+    const long long total = (long long)n_win * (n_pops * (n_pops + 1) / 2);
+    hipLaunchKernelGGL(k_popstats, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sums, cnts, n_win, pop_start, n_pops,
+                       min_data, do_pairs, out);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K_indpair: one thread per unordered individual pair (s<=t); haplotype slots of an individual are contiguous.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat,

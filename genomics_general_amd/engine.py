@@ -8,8 +8,8 @@ list of per-window `genomics.Alignment` objects plays in the reference's worker 
     indPairDists(includeSameWithSame, minSites) -> genomics.py:934-954
     ABBABABA(P1, P2, P3, P4, minData)           -> genomics.py:1647-1695
     pairCounts()                                -> the integers behind distMatrix()/pairNonNan()
-All per-site / per-pair work happens in HIP kernels; what is left here is the O(populations^2) float64
-finalisation per window, written with the same NumPy expressions as the reference.
+All per-site / per-pair work AND the float64 finalisation of pi / dxy / Fst happen in HIP kernels; what is left here is
+naming the columns (and, for popFreq / indPairDist / ABBA-BABA, a few O(1)-per-window NumPy expressions).
 """
 import ctypes as C
 
@@ -135,15 +135,6 @@ class Engine:
         check(self._L.pg_comm_barrier(self._h))
 
 
-def _nanmean_min(total, n_valid, size, minimum):
-    """nanmean_min (genomics.py:88-90) of a block holding `size` cells of which `n_valid` are not nan and sum to
-    `total` (arrays over windows)."""
-    with np.errstate(divide="ignore", invalid="ignore"):
-        frac_ok = 1 - (1. * (size - n_valid) / size) >= minimum if size else np.zeros_like(n_valid, dtype=bool)
-        mean = total / n_valid
-    return np.where(frac_ok & (n_valid > 0), mean, np.nan)
-
-
 class WindowBatch:
     """Statistics of a set of windows [lo,hi) of the engine's resident sites."""
 
@@ -182,41 +173,36 @@ class WindowBatch:
 
     # -- popDist / popPairDist ----------------------------------------------------------------------
     def groupDistStats(self, doPairs=True, minSites=None, minData=0.01):
+        """pi / dxy / Fst of every window, finished on the device (k_popstats: the float64 operations of genomics.py:976-993
+        in the reference's order).  Returns {stat name: array over windows}, both key orders for the pair statistics."""
         lay = self.lay
         P = lay.n_pops
+        ms = int(minSites) if minSites else 0
+        pairs = bool(P > 1 and doPairs)
+        ncols = P + (P * (P - 1) if pairs else 0)
+        tab = np.zeros((self.n, ncols), dtype=np.float64)
+        check(self.e._L.pg_popdist_stats(self.e._h, self.lo, self.hi, self.n, ms, float(minData), 1 if pairs else 0, tab))
+        self._popdist_min_sites = ms
+        names = lay.sampleData.popNames
+        out = {"pi_" + names[x]: tab[:, x] for x in range(P)}
+        if pairs:
+            npo = P * (P - 1) // 2
+            k = 0
+            for x in range(P - 1):
+                for y in range(x + 1, P):
+                    out["dxy_%s_%s" % (names[x], names[y])] = out["dxy_%s_%s" % (names[y], names[x])] = tab[:, P + k]
+                    out["Fst_%s_%s" % (names[x], names[y])] = out["Fst_%s_%s" % (names[y], names[x])] = tab[:, P + npo + k]
+                    k += 1
+        return out
+
+    def groupDistSums(self, minSites=None):
+        """The raw K3 output: float64 sums of D/C and valid-pair counts per unordered population pair (pg_popdist)."""
+        P = self.lay.n_pops
         npairs = P * (P + 1) // 2
         sums = np.zeros((self.n, npairs), dtype=np.float64)
         cnts = np.zeros((self.n, npairs), dtype=np.int64)
-        ms = int(minSites) if minSites else 0
-        check(self.e._L.pg_popdist(self.e._h, self.lo, self.hi, self.n, ms, sums, cnts))
-        self._popdist_min_sites = ms
-        names = lay.sampleData.popNames
-        size = lay.pop_sizes
-        out = {}
-        pi = []
-        for x in range(P):
-            k = lay.pop_pair_index(x, x)
-            # block(x,x) holds every unordered pair twice plus a nan diagonal (genomics.py:963, 976)
-            v = _nanmean_min(2 * sums[:, k], 2 * cnts[:, k], size[x] * size[x], minData)
-            pi.append(v)
-            out["pi_" + names[x]] = v
-        if P > 1 and doPairs:
-            for x in range(P - 1):
-                for y in range(x + 1, P):
-                    k = lay.pop_pair_index(x, y)
-                    dxy = _nanmean_min(sums[:, k], cnts[:, k], size[x] * size[y], minData)
-                    out["dxy_%s_%s" % (names[x], names[y])] = out["dxy_%s_%s" % (names[y], names[x])] = dxy
-                    kx, ky = lay.pop_pair_index(x, x), lay.pop_pair_index(y, y)
-                    nx, ny = size[x], size[y]
-                    w = 1. * nx / (nx + ny)                                      # genomics.py:988-991
-                    pi_s = w * pi[x] + (1 - w) * pi[y]
-                    tot = 2 * sums[:, kx] + 2 * sums[:, ky] + 2 * sums[:, k]
-                    cnt = 2 * cnts[:, kx] + 2 * cnts[:, ky] + 2 * cnts[:, k]
-                    pi_t = _nanmean_min(tot, cnt, (nx + ny) * (nx + ny), minData)
-                    with np.errstate(divide="ignore", invalid="ignore"):
-                        fst = 1 - pi_s / pi_t
-                    out["Fst_%s_%s" % (names[x], names[y])] = out["Fst_%s_%s" % (names[y], names[x])] = fst
-        return out
+        check(self.e._L.pg_popdist(self.e._h, self.lo, self.hi, self.n, int(minSites) if minSites else 0, sums, cnts))
+        return sums, cnts
 
     # -- popFreq --------------------------------------------------------------------------------------
     def groupFreqStats(self):

@@ -116,6 +116,13 @@ int pg_pairwise(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n
 int pg_popdist(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites,
                double *sum_out, int64_t *cnt_out);
 
+/* ---- K2+K3 with the statistics finished on the device -------------------------------------------- */
+/* Replaces Alignment.groupDistStats (genomics.py:956-995) end to end: stats_out[n_win][P + (do_pairs ? P*(P-1) : 0)] =
+ * pi of every population (CLI order), then (do_pairs) dxy of every pair x<y (x-major), then Fst of every pair; nan exactly
+ * where the reference's nanmean_min / Fst give nan.  Same float64 operations, in the same order, as the reference. */
+int pg_popdist_stats(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites,
+                     double min_data, int do_pairs, double *stats_out);
+
 /* ---- K2+K6: individual-pair distance sums -------------------------------------------------------- */
 /* Replaces Alignment.indPairDists (genomics.py:934-954).  For every window and unordered individual pair
  * (s<=t), (0,0),(0,1).. : sum of D/C over haplotype pairs {a in s, b in t, a<b when s==t} with

@@ -149,6 +149,40 @@ class FakeLib:
         return 0
 
 
+    def pg_popdist_stats(self, h, lo, hi, n, ms, min_data, do_pairs, tab):
+        """CPU emulation of k_popstats (same expression order) on top of the oracle-derived sums."""
+        P = self.lay.n_pops
+        npairs = P * (P + 1) // 2
+        sums = np.zeros((n, npairs)); cnts = np.zeros((n, npairs), dtype=np.int64)
+        self.pg_popdist(h, lo, hi, n, ms, sums, cnts)
+        size = self.lay.pop_sizes
+        kd = lambda p: p * P - p * (p - 1) // 2
+
+        def nmm(total, nv, sz):
+            if sz == 0 or not (1 - (1. * (sz - nv) / sz) >= min_data) or nv <= 0:
+                return np.nan
+            return total / float(nv)
+        npo = P * (P - 1) // 2
+        for w in range(n):
+            pi = [nmm(2 * sums[w, kd(x)], 2 * cnts[w, kd(x)], size[x] * size[x]) for x in range(P)]
+            tab[w, :P] = pi
+            k = 0
+            for x in range(P - 1):
+                for y in range(x + 1, P):
+                    if do_pairs:
+                        kxy = kd(x) + (y - x)
+                        tab[w, P + k] = nmm(sums[w, kxy], cnts[w, kxy], size[x] * size[y])
+                        wt = 1. * size[x] / (size[x] + size[y])
+                        pi_s = wt * pi[x] + (1 - wt) * pi[y]
+                        tot = 2 * sums[w, kd(x)] + 2 * sums[w, kd(y)] + 2 * sums[w, kxy]
+                        cnt = 2 * cnts[w, kd(x)] + 2 * cnts[w, kd(y)] + 2 * cnts[w, kxy]
+                        pi_t = nmm(tot, cnt, (size[x] + size[y]) ** 2)
+                        with np.errstate(divide="ignore", invalid="ignore"):
+                            tab[w, P + npo + k] = 1 - np.float64(pi_s) / np.float64(pi_t)
+                    k += 1
+        return 0
+
+
 class FakeEngine:
     def __init__(self, lib, lay):
         self._L, self._h, self.layout = lib, None, lay
