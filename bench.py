@@ -39,6 +39,9 @@ WORKLOADS = {
     # BASELINE.json configs[2]: ABBA-BABA
     "c3": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=50_000, min_sites=100, tool="abba",
                desc="ABBABABAwindows D/fd: 1e7 sites, P1/P2/P3/O x 25 diploids, 50 kb windows"),
+    # BASELINE.json configs[3]: distMat pairwise-kernel stress
+    "c4": dict(n_sites=1_000_000, n_scaf=1, n_dip=1000, n_pops=1, wind=100_000, min_sites=1, tool="distmat",
+               desc="distMat full pairwise distance: 1e6 sites x 1000 diploids (2000 haplotypes), 100 kb windows"),
     # small variant for quick checks
     "tiny": dict(n_sites=400_000, n_scaf=2, n_dip=20, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
                  desc="tiny smoke workload"),
@@ -91,6 +94,10 @@ def main():
         wb = eng.batch(lo, hi)
         if wl["tool"] == "popgen":
             st = wb.groupDistStats(doPairs=True, minSites=wl["min_sites"], minData=0.01)
+        elif wl["tool"] == "distmat":
+            sums, cnts = wb.indPairSums()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                return {"d": sums / cnts}, sums
         else:
             st = wb.ABBABABA("pop0", "pop1", "pop2", "pop3", 0.01)
         keys = sorted(k for k in st if k != "sitesUsed")
@@ -115,7 +122,7 @@ def main():
     # ---- per-kernel timing of the timed region (HIP events on the engine's stream) ---------------------
     kt = {name: eng.kernel_time(kid) for kid, name in _lib.KERNEL_NAMES.items()}
     # dominant kernel = the kernel family with the most GPU time in the timed region
-    cand = [_lib.K_PACK, _lib.K_PAIRWISE, _lib.K_PAIRD] if wl["tool"] == "popgen" else [_lib.K_SITESTATS]
+    cand = [_lib.K_PACK, _lib.K_PAIRWISE, _lib.K_PAIRD] if wl["tool"] in ("popgen", "distmat") else [_lib.K_SITESTATS]
     dom_id = max(cand, key=lambda k: eng.kernel_time(k)[0])
     dom_ms, dom_n = eng.kernel_time(dom_id)
     n_hap = lay.n_hap
@@ -165,6 +172,9 @@ def main():
             if wl["tool"] == "popgen":
                 D, C = orc.pair_counts_loop(aln)                     # genomics.py:903-916 + 1042-1047, pair by pair
                 so, _ = orc.group_dist_stats(aln, D, C, True, wl["min_sites"], 0.01)
+            elif wl["tool"] == "distmat":
+                D, C = orc.pair_counts_loop(aln)
+                so = {}
             else:
                 so = orc.abbababa(aln, "pop0", "pop1", "pop2", "pop3", 0.01)
             t_cpu += time.perf_counter() - c0

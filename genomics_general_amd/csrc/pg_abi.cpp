@@ -83,6 +83,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     for (int k = 0; k < 2; ++k) {
         c->slot[k].Vp.release();
         c->slot[k].XV.release();
+        c->slot[k].pres.release();
         c->slot[k].nw.release();
         c->slot[k].win.release();
         if (c->slot[k].packed) (void)hipEventDestroy(c->slot[k].packed);
@@ -439,7 +440,7 @@ static int stage_windows2(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w
     return PG_OK;
 }
 
-static bool use_v2(const pg_ctx *c) { return c->NP <= 1024 && getenv("PG_PAIR_V1") == nullptr; }
+static bool use_v2(const pg_ctx *c) { (void)c; return getenv("PG_PAIR_V1") == nullptr; }
 
 // v1 path (more than 1024 haplotype slots): pack + k_pairwise, one batch after the other on ctx->stream.
 template <class F>
@@ -564,8 +565,9 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         if ((rc = event_get(c, &e0)) != PG_OK) return rc;
         if ((rc = event_get(c, &e1)) != PG_OK) return rc;
         HIPCHK(hipEventRecord(e0, c->stream2));
-        pg_launch_pack2(c->stream2, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, sl.Vp.p, NPv, sl.XV.p, NP,
-                        sl.nw.p, dip ? 1 : 0, c->flag.p);
+        if (NP > 1024 && (rc = sl.pres.ensure((size_t)std::max<int64_t>(ga, 1) * PG_GROUP * 4)) != PG_OK) return rc;
+        pg_launch_pack2(c->stream2, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, ga, sl.Vp.p, NPv, sl.XV.p, NP,
+                        sl.nw.p, dip ? 1 : 0, c->flag.p, sl.pres.p);
         HIPCHK(hipEventRecord(e1, c->stream2));
         c->events[PG_K_PACK].push_back(std::make_pair(e0, e1));
         c->acc_launches[PG_K_PACK] += 1;

@@ -68,7 +68,7 @@ struct pg_ctx {
     // (VALU-bound, stream).  Two slots of planes / window tables.
     hipStream_t stream2 = nullptr;
     struct Slot {
-        DevBuf<uint32_t> Vp, XV;
+        DevBuf<uint32_t> Vp, XV, pres;
         DevBuf<int32_t> nw;
         DevBuf<int64_t> win;
         std::vector<int64_t> host;        // staging of [lo | hi | goff | vgoff], alive until its H2D copy completed

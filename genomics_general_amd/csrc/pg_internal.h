@@ -59,8 +59,8 @@ void pg_launch_hap_called(hipStream_t st, const int8_t *gt, int S, int n_hap, co
 
 // ---- v2 pairwise pipeline (pg_pair2.hip) ---------------------------------------------------------------
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
-                     const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, uint32_t *Vp, int NPv,
-                     uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch);
+                     const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, int64_t total_groups, uint32_t *Vp,
+                     int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres);
 void pg_launch_expand(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                       int32_t *Cfull, int32_t *Dfull);
 void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, const PgTask2 *tasks, int n_tasks,

@@ -547,39 +547,6 @@ struct AbbaAcc {
     unsigned long long used;
 };
 
-// Integer phase: per-population base counts of one site.  Returns true when the site is usable (biallelic among the called
-// alleles of the four populations, every population has >= nmin[q] called haplotypes, and exactly one allele is present
-// overall but absent from the outgroup) and then fills e = {c1, c2, c3 (derived-allele counts), n1..n4}.
-// nmin[q] = smallest n with (double)n * 1. / (double)N_q >= min_data (the reference's test, genomics.py:1657-1660, is
-// monotone in n, so comparing integers is the same predicate).
-__device__ __forceinline__ bool abba_counts(const uint32_t *__restrict__ row, const int ps[4], const int pe[4],
-                                            const int nmin[4], uint32_t e[7]) {
-    uint32_t cnt[4][4];
-    uint32_t n[4], tot[4] = {0u, 0u, 0u, 0u};
-    bool enough = true;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        range_counts(row, ps[q], pe[q], cnt[q]);
-        n[q] = cnt[q][0] + cnt[q][1] + cnt[q][2] + cnt[q][3];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) tot[b] += cnt[q][b];
-        enough = enough && ((int)n[q] >= nmin[q]);
-    }
-    const int nall = (tot[0] > 0) + (tot[1] > 0) + (tot[2] > 0) + (tot[3] > 0);
-    if (nall != 2 || !enough) return false;                                                // :1655, :1662
-    // alleleIndex = where((all4freqs > 0) & (P4freqs == 0)), genomics.py:1672: tot[b] > 0 and cnt_O[b]/n_O == 0.0, which
-    // needs n_O > 0 (0/0 is nan).  At a biallelic site with n_O > 0 at most one allele qualifies.
-    if (n[3] == 0) return false;
-    int b = -1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (tot[k] > 0 && cnt[3][k] == 0) b = k;
-    if (b < 0) return false;
-    e[0] = cnt[0][b]; e[1] = cnt[1][b]; e[2] = cnt[2][b];
-    e[3] = n[0]; e[4] = n[1]; e[5] = n[2]; e[6] = n[3];
-    return true;
-}
-
 // Float64 phase for one usable site (operation order of genomics.py:1409-1475, 1565-1569).
 __device__ __forceinline__ void abba_terms(const uint32_t e[7], AbbaAcc &A) {
     const double p1 = (double)e[0] / (double)e[3];
@@ -602,99 +569,6 @@ __device__ __forceinline__ void abba_terms(const uint32_t e[7], AbbaAcc &A) {
     A.acc[4] += abba;
     A.acc[5] += baba;
     ++A.used;
-}
-
-// TILED = 1: blockDim.x sites per LDS tile; TILED = 0: rows read straight from global memory (rows too long for LDS).
-// Usable sites (~10 % of the sites of real data) are compacted, in site order, into an LDS list before the float64 phase, so
-// the divisions are issued by ceil(usable/64) waves instead of by every wave.
-template <int TILED>
-__global__ __launch_bounds__(256) void k_abba(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
-                                              const int64_t *__restrict__ win_hi, int max_chunks,
-                                              const int32_t *__restrict__ pop_start, int q1, int q2, int q3, int q4,
-                                              double min_data, double *__restrict__ part_sums,
-                                              int64_t *__restrict__ part_used) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
-    __shared__ double shd[256];
-    __shared__ unsigned long long shu[256];
-    __shared__ uint32_t list[256][8];
-    __shared__ int wave_cnt[4];
-    const int win = blockIdx.y, chunk = blockIdx.x;
-    const int64_t lo = win_lo[win], hi = win_hi[win];
-    const int64_t c0 = lo + (int64_t)chunk * PG_SITES_PER_BLOCK;
-    AbbaAcc A;
-#pragma unroll
-    for (int k = 0; k < PG_ABBA_NSUM; ++k) A.acc[k] = 0.0;
-    A.used = 0;
-    const int ps[4] = {pop_start[q1], pop_start[q2], pop_start[q3], pop_start[q4]};
-    const int pe[4] = {pop_start[q1 + 1], pop_start[q2 + 1], pop_start[q3 + 1], pop_start[q4 + 1]};
-    int nmin[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int Nq = pe[q] - ps[q];
-        int n = 0;
-        while (n <= Nq && !((double)n * 1. / (double)Nq >= min_data)) ++n;       // n = Nq+1 when no count passes
-        nmin[q] = n;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    if (c0 < hi) {
-        const int64_t c1 = (c0 + PG_SITES_PER_BLOCK < hi) ? c0 + PG_SITES_PER_BLOCK : hi;
-        const int TS = blockDim.x;
-        const uint32_t lds0 = (uint32_t)(uintptr_t)tile;
-        const uint32_t buf_bytes = (uint32_t)TS * (uint32_t)S;
-        int it = 0;
-        if (TILED) {
-            const int ns0 = (int)((c1 - c0) < (int64_t)TS ? (c1 - c0) : (int64_t)TS);
-            tile_issue(gt, S, c0, ns0, lds0);
-        }
-        for (int64_t t0 = c0; t0 < c1; t0 += TS, ++it) {
-            const int ns = (int)((c1 - t0) < (int64_t)TS ? (c1 - t0) : (int64_t)TS);
-            uint32_t e[7];
-            bool good = false;
-            if (TILED) {
-                tile_wait_and_sync();                       // tile `it` landed; buffer (it+1)&1 and the list are free
-                if (t0 + TS < c1) {
-                    const int nsn = (int)((c1 - t0 - TS) < (int64_t)TS ? (c1 - t0 - TS) : (int64_t)TS);
-                    tile_issue(gt, S, t0 + TS, nsn, lds0 + ((it + 1) & 1) * buf_bytes);
-                }
-                const uint32_t *rows = tile + (size_t)(it & 1) * (buf_bytes >> 2);
-                if ((int)threadIdx.x < ns) good = abba_counts(rows + (size_t)threadIdx.x * (S >> 2), ps, pe, nmin, e);
-            } else {
-                __syncthreads();
-                if ((int)threadIdx.x < ns)
-                    good = abba_counts(reinterpret_cast<const uint32_t *>(gt + (t0 + threadIdx.x) * (int64_t)S), ps, pe, nmin, e);
-            }
-            // rank of this usable site in site order
-            const unsigned long long bal = __ballot(good);
-            const int before = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) wave_cnt[wave] = __popcll(bal);
-            __syncthreads();
-            int base = 0, total = 0;
-            for (int w = 0; w < nwave; ++w) {
-                if (w < wave) base += wave_cnt[w];
-                total += wave_cnt[w];
-            }
-            if (good) {
-#pragma unroll
-                for (int k = 0; k < 7; ++k) list[base + before][k] = e[k];
-            }
-            __syncthreads();
-            if ((int)threadIdx.x < total) {
-                uint32_t f[7];
-#pragma unroll
-                for (int k = 0; k < 7; ++k) f[k] = list[threadIdx.x][k];
-                abba_terms(f, A);
-            }
-        }
-    }
-    __syncthreads();
-    const size_t o = (size_t)win * max_chunks + chunk;
-#pragma unroll
-    for (int k = 0; k < PG_ABBA_NSUM; ++k) {
-        const double r = block_sum_f64(A.acc[k], shd);
-        if (threadIdx.x == 0) part_sums[o * PG_ABBA_NSUM + k] = r;
-    }
-    const unsigned long long u = block_sum_u64(A.used, shu);
-    if (threadIdx.x == 0) part_used[o] = (int64_t)u;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -69,12 +69,44 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 
 #define PG_DENSE_BITS 14      // a word with at least this many polymorphic sites is emitted whole instead of bit by bit
 
-template <int TPB, int DIP>
+// More than 1024 haplotype slots do not fit one block: k_presence (same loads and transposition, grid.z = blocks of 1024 slots)
+// first ORs the per-site allele-presence words of all slot blocks into pres[word][4]; k_pack2<.,.,PRES=1> then reads them.
+__global__ __launch_bounds__(256) void k_presence(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
+                                                  const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
+                                                  uint32_t *__restrict__ pres) {
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int64_t lo = win_lo[b], hi = win_hi[b];
+    const int W = (int)((hi - lo + 31) >> 5);
+    const int w_begin = g * PG_GROUP;
+    if (w_begin >= W) return;
+    const int w_end = (w_begin + PG_GROUP < W) ? w_begin + PG_GROUP : W;
+    const int h0 = 4 * (blockIdx.z * 256 + threadIdx.x);
+    uint32_t *dst = pres + (size_t)(goff[b] + g) * PG_GROUP * 4u;
+    for (int w = w_begin; w < w_end; ++w) {
+        uint32_t x[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[p][k] = 0u;
+        if (h0 < S) {
+            const int64_t s0 = lo + 32ll * w;
+            const int ns = (int)((hi - s0) < 32 ? (hi - s0) : 32);
+            load_word(gt + s0 * (int64_t)S + h0, S, ns, x);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t pr = wave_or(x[p][0] | x[p][1] | x[p][2] | x[p][3]);
+            if ((threadIdx.x & 63) == 0 && pr) atomicOr(&dst[(size_t)(w - w_begin) * 4u + p], pr);
+        }
+    }
+}
+
+template <int TPB, int DIP, int PRES>
 __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
                                                const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
                                                const int64_t *__restrict__ vgoff, uint32_t *__restrict__ Vp, int NPv,
                                                uint32_t *__restrict__ XV, int NP, int32_t *__restrict__ nw,
-                                               int32_t *__restrict__ mismatch) {
+                                               int32_t *__restrict__ mismatch, const uint32_t *__restrict__ pres) {
     constexpr int NWAVE = TPB / 64;
     __shared__ uint32_t sh_pres[2][NWAVE][4];
     const int b = blockIdx.y, g = blockIdx.x;
@@ -83,7 +115,7 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
     const int w_begin = g * PG_GROUP;
     if (w_begin >= W) return;
     const int w_end = (w_begin + PG_GROUP < W) ? w_begin + PG_GROUP : W;
-    const int t = threadIdx.x;
+    const int t = blockIdx.z * TPB + threadIdx.x;
     const int h0 = 4 * t;
     const bool has_data = h0 < S;            // pad threads (h0 >= S) still write zero planes up to NP
     const bool in_np = h0 < NP;
@@ -124,9 +156,15 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
             if (live) {
                 // alleles present among called haplotypes, per site, across the whole block
                 uint32_t pr[4];
+                if (PRES) {
+                    const uint32_t *src = pres + ((size_t)(goff[b] + g) * PG_GROUP + (size_t)(w - w_begin)) * 4u;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) pr[p] = wave_or(x[p][0] | x[p][1] | x[p][2] | x[p][3]);
-                if (NWAVE > 1) {
+                    for (int p = 0; p < 4; ++p) pr[p] = src[p];
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) pr[p] = wave_or(x[p][0] | x[p][1] | x[p][2] | x[p][3]);
+                }
+                if (!PRES && NWAVE > 1) {
                     if ((t & 63) == 0) {
 #pragma unroll
                         for (int p = 0; p < 4; ++p) sh_pres[parity][t >> 6][p] = pr[p];
@@ -225,23 +263,30 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
 template <int DIP>
 static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *gt, int S, const int64_t *win_lo,
                          const int64_t *win_hi, const int64_t *goff, const int64_t *vgoff, uint32_t *Vp, int NPv, uint32_t *XV,
-                         int NP, int32_t *nw, int32_t *mismatch) {
+                         int NP, int32_t *nw, int32_t *mismatch, uint32_t *pres) {
     if (threads <= 64)
-        hipLaunchKernelGGL((k_pack2<64, DIP>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch);
+        hipLaunchKernelGGL((k_pack2<64, DIP, 0>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
     else if (threads <= 128)
-        hipLaunchKernelGGL((k_pack2<128, DIP>), grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch);
-    else
-        hipLaunchKernelGGL((k_pack2<256, DIP>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch);
+        hipLaunchKernelGGL((k_pack2<128, DIP, 0>), grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
+    else if (threads <= 256)
+        hipLaunchKernelGGL((k_pack2<256, DIP, 0>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
+    else {
+        grid.z = (threads + 255) / 256;
+        hipLaunchKernelGGL(k_presence, grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, pres);
+        hipLaunchKernelGGL((k_pack2<256, DIP, 1>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
+    }
 }
 
+// pres: scratch of total_groups * PG_GROUP * 4 words, only used (and zeroed here) when there are more than 1024 slots
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
-                     const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, uint32_t *Vp, int NPv,
-                     uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch) {
+                     const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, int64_t total_groups, uint32_t *Vp,
+                     int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres) {
     if (n_win <= 0 || max_groups <= 0) return;
     const int threads = NP / 4;
+    if (threads > 256) (void)hipMemsetAsync(pres, 0, (size_t)total_groups * PG_GROUP * 16u, st);
     dim3 grid(max_groups, n_win);
-    if (dip) launch_pack2<1>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch);
-    else launch_pack2<0>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch);
+    if (dip) launch_pack2<1>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
+    else launch_pack2<0>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
 }
 
 // ------------------------------------------------------------------------------------------------------

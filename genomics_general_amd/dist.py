@@ -90,9 +90,19 @@ class RcclComm:
     def __init__(self, engine, world):
         from .engine import Engine
         self.e, self.size, self.rank = engine, world.size, world.rank
-        uid, path = exchange_unique_id(world, Engine.comm_unique_id)
-        engine.comm_setup(world.size, world.rank, uid)
-        engine.comm_barrier()
+        # RCCL prints a version banner on file descriptor 1 while it initialises; the drivers' stdout carries data (CSV, the
+        # benchmark's JSON line), so fd 1 is pointed at stderr for the duration of the initialisation
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            uid, path = exchange_unique_id(world, Engine.comm_unique_id)
+            engine.comm_setup(world.size, world.rank, uid)
+            engine.comm_barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         if world.rank == 0:
             try:
                 os.remove(path)

@@ -230,6 +230,15 @@ class WindowBatch:
             out["TajD_" + name] = taj
         return out
 
+    def indPairSums(self, minSites=None):
+        """Raw K6 output (pg_indpairdist): sums of D/C and valid-pair counts per unordered individual pair."""
+        n = self.lay.n_samp
+        npairs = n * (n + 1) // 2
+        sums = np.zeros((self.n, npairs), dtype=np.float64)
+        cnts = np.zeros((self.n, npairs), dtype=np.int64)
+        check(self.e._L.pg_indpairdist(self.e._h, self.lo, self.hi, self.n, int(minSites) if minSites else 0, sums, cnts))
+        return sums, cnts
+
     # -- indPairDist -------------------------------------------------------------------------------------
     def indPairDists(self, includeSameWithSame=False, minSites=None):
         """{name: {name: array over windows}} like Alignment.indPairDists(asDict=True).  As in the reference

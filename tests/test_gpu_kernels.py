@@ -22,6 +22,7 @@ def oracle_aln(lay, codes, lo, hi):
     (25, 4, 4096, [(0, 4096), (5, 37), (100, 100), (7, 8), (4000, 4096)]),      # whole, tiny, empty, single-site, tail
     (37, 3, 2500, [(0, 1250), (600, 1900), (1250, 2500)]),                       # odd haplotype count, overlapping windows
     (150, 4, 1500, [(0, 700), (700, 1500)]),                                     # several 64-column chunks
+    (530, 3, 2200, [(0, 2200), (100, 421), (2150, 2200)]),                        # > 1024 haplotype slots: presence pre-pass
 ])
 def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins):
     e, lay, codes, _ = G.make_engine(n_dip, n_pops, L, seed=11 + n_dip)
@@ -206,4 +207,23 @@ def test_dense_polymorphism_and_multiallelic_sites():
     for k, (a, b) in enumerate([(0, 700), (700, 2500)]):
         Do, Co = orc.pair_counts_gemm(oracle_aln(lay, codes, a, b))
         assert np.array_equal(C[k], Co) and np.array_equal(D[k], Do)
+    e.close()
+
+
+def test_rccl_communicator_single_rank_roundtrip(tmp_path, monkeypatch):
+    """the RCCL path of the C-ABI (lazy dlopen, unique id, comm init, all-gather, barrier) with one rank on one GPU"""
+    from genomics_general_amd import dist
+    from genomics_general_amd.engine import Engine
+    monkeypatch.setenv("PG_RDZV_FILE", str(tmp_path / "rdzv"))
+    names, lay = G.make_layout(4, 2)
+    e = Engine(0)
+    e.set_layout(lay)
+    comm = dist.RcclComm(e, dist.World(0, 1, 0))
+    x = np.arange(12, dtype=np.float64) * 0.5 - 1
+    x[3] = np.nan
+    got = comm.allgather(x)
+    assert got.shape == (1, 12) and np.array_equal(np.isnan(got[0]), np.isnan(x)) and np.allclose(np.nan_to_num(got[0]), np.nan_to_num(x))
+    comm.barrier()
+    tab = dist.gather_table(comm, x.reshape(4, 3), 4)
+    assert tab.shape == (4, 3)
     e.close()

@@ -229,3 +229,25 @@ def test_oracle_gemm_counts_equal_reference_pair_loop():
     D1, C1 = orc.pair_counts_loop(aln)
     D2, C2 = orc.pair_counts_gemm(aln)
     assert np.array_equal(D1, D2) and np.array_equal(C1, C2)
+
+
+def test_tokenizer_throughput_report(capsys):
+    """Tier T2 evidence: native tokenizer rate on this host (printed; only a loose floor is asserted)."""
+    import time
+    n_dip, n_lines = 100, 60000
+    names = ["s%d" % d for d in range(n_dip)]
+    rng = np.random.default_rng(1)
+    cells = np.array(["A/A", "A/C", "C/C", "G/T", "N/N", "T/T"])
+    rows = cells[rng.integers(0, len(cells), size=(512, n_dip))]
+    block = ["\t".join(r) for r in rows]
+    text = "".join("chr1\t%d\t%s\n" % (i + 1, block[i % 512]) for i in range(n_lines)).encode()
+    lay = HapLayout(SampleData(indNames=list(names)), names, "phased")
+    encode_text(text[:100000].rsplit(b"\n", 1)[0] + b"\n", lay)          # warm up
+    t0 = time.perf_counter()
+    gt, pos, _, _ = encode_text(text, lay)
+    dt = time.perf_counter() - t0
+    assert len(pos) == n_lines and gt.shape == (n_lines, 2 * n_dip)
+    rate = len(text) / dt / 1e6
+    with capsys.disabled():
+        print("\n[tokenizer] %.0f MB/s, %.2f M sites/s (%d diploids, %d host threads)" % (rate, n_lines / dt / 1e6, n_dip, os.cpu_count()))
+    assert rate > 20
