@@ -33,17 +33,19 @@ __device__ __forceinline__ uint32_t bgather(uint32_t a0, uint32_t a1, uint32_t a
            (((a3 >> (8 * k)) & 0xFFu) << 24);
 }
 
-// 32 sites x 4 haplotypes -> x[a][k] (allele plane a of haplotype k); sites >= ns are zero bits
-__device__ __forceinline__ void load_word(const int8_t *__restrict__ src, int S, int ns, uint32_t x[4][4]) {
+// 32 sites x 4 haplotypes -> x[a][k] (allele plane a of haplotype k); sites >= ns are zero bits.
+// The 32 loads are raw buffer loads: descriptor base = the word's first site row (wave-uniform, SGPRs), scalar offset =
+// row * S, lane offset = h0 -> no VALU address arithmetic at all (a flat load needs a 64-bit add per load).  The descriptor's
+// size is ns rows, so rows past the end of a window read as zero without a select.
+__device__ __forceinline__ void load_word(const int8_t *__restrict__ rows, int h0, int S, int ns, uint32_t x[4][4]) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(rows), 0, ns * S, 0x00020000);
     uint32_t acc[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         uint32_t d[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(src + (int64_t)(q * 8 + s) * S);
-            d[s] = (q * 8 + s < ns) ? v : 0u;
-        }
+        for (int s = 0; s < 8; ++s) d[s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, h0, (q * 8 + s) * S, 0);
         uint32_t a0 = 0u, a1 = 0u, a2 = 0u, a3 = 0u;
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
@@ -61,10 +63,17 @@ __device__ __forceinline__ void load_word(const int8_t *__restrict__ src, int S,
         for (int k = 0; k < 4; ++k) x[p][k] = bgather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], k);
 }
 
+// OR over the 64 lanes of a wave with DPP row shifts / broadcasts (six VALU ops, no LDS traffic); the total ends in lane 63.
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
-    return v;
+#define PG_DPP_OR(ctrl, rmask) v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false)
+    PG_DPP_OR(0x111, 0xf);      // row_shr:1
+    PG_DPP_OR(0x112, 0xf);      // row_shr:2
+    PG_DPP_OR(0x114, 0xf);      // row_shr:4
+    PG_DPP_OR(0x118, 0xf);      // row_shr:8   -> lane 15 of each row holds the row total
+    PG_DPP_OR(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    PG_DPP_OR(0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+#undef PG_DPP_OR
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 #define PG_DENSE_BITS 14      // a word with at least this many polymorphic sites is emitted whole instead of bit by bit
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void k_presence(const int8_t *__restrict__ gt,
         if (h0 < S) {
             const int64_t s0 = lo + 32ll * w;
             const int ns = (int)((hi - s0) < 32 ? (hi - s0) : 32);
-            load_word(gt + s0 * (int64_t)S + h0, S, ns, x);
+            load_word(gt + s0 * (int64_t)S, h0, S, ns, x);
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
             if (live && has_data) {
                 const int64_t s0 = lo + 32ll * w;
                 const int ns = (int)((hi - s0) < 32 ? (hi - s0) : 32);
-                load_word(gt + s0 * (int64_t)S + h0, S, ns, x);
+                load_word(gt + s0 * (int64_t)S, h0, S, ns, x);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = x[0][k] | x[1][k] | x[2][k] | x[3][k];
             }
