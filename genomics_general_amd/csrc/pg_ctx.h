@@ -66,8 +66,7 @@ struct pg_ctx {
     DevBuf<int32_t> nw;          // v2: compacted words per group
     // v2 software pipeline: k_pack2 of sub-batch k+1 (HBM-bound, stream2) overlaps the pair kernels of sub-batch k
     // (VALU-bound, stream).  Two slots of planes / window tables.
-    hipStream_t stream2 = nullptr, stream3 = nullptr;
-    hipEvent_t d_done = nullptr, d_free = nullptr;
+    hipStream_t stream2 = nullptr;
     struct Slot {
         DevBuf<uint32_t> Vp, XV, pres;
         DevBuf<int32_t> nw;
