@@ -488,3 +488,139 @@ def distmat_main(argv=None):
         sys.stderr.write("{} windows were tested.\n{} results were written.\n\n### Done. ###\n".format(T.n, written))
     run.comm.barrier()
     return 0
+
+
+# ==========================================================================================================
+# freq.py  (SURVEY.md 8f "next" row 1: the raw output of the per-site population count kernel as a TSV)
+# ==========================================================================================================
+def freq_main(argv=None):
+    """Drop-in for the reference's freq.py (freq.py:30-113, 192-300): per-site per-population base counts, or the
+    frequency / count of a target allele (`--target derived|minor`).  Counts come from k_site_counts (pg_site_counts).
+    Divergence: for `--target minor` the reference breaks count ties with np.random.choice (genomics.py:664-669); here the
+    tied allele with the lower base index is taken."""
+    ap = argparse.ArgumentParser(prog="freq.py")
+    ap.add_argument("-g", "--genoFile", help="Input geno file")
+    ap.add_argument("-o", "--outFile", help="Output file")
+    ap.add_argument("-f", "--genoFormat", choices=("phased", "diplo", "alleles"), default="phased")
+    ap.add_argument("-p", "--population", action="append", nargs="+", metavar=("popName", "[samples]"))
+    ap.add_argument("--popsFile")
+    ap.add_argument("--indFreqs", action="store_true", help="treat every individual as its own population")
+    ap.add_argument("--target", choices=("minor", "derived"), default=None)
+    ap.add_argument("--asCounts", action="store_true")
+    ap.add_argument("--ploidy", type=int, nargs="+")
+    ap.add_argument("--ploidyFile")
+    ap.add_argument("--haploid", nargs="+")
+    ap.add_argument("--minData", type=float, default=0, metavar="proportion")
+    ap.add_argument("--threshold", type=float, metavar="proportion")
+    ap.add_argument("--keepNanLines", action="store_true")
+    ap.add_argument("-t", "--threads", type=int, default=1, help="accepted for compatibility")
+    ap.add_argument("--sliceSize", type=int, default=1000000, help="accepted for compatibility")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--test", action="store_true", help="accepted for compatibility")
+    ap.add_argument("--device", type=int, default=None, help="GPU index (MI355X engine)")
+    args = ap.parse_args(argv)
+
+    raw = genoio.read_all(args.genoFile)
+    headerInds, body = genoio.split_header(raw)
+    if not args.indFreqs and not args.population:
+        if args.target == "derived":
+            popNames, popInds = ["ingroup", "outgroup"], [headerInds[:-1], [headerInds[-1]]]
+        else:
+            popNames, popInds = ["all"], [list(headerInds)]
+    elif args.indFreqs:
+        popNames, popInds = list(headerInds), [[i] for i in headerInds]
+    else:
+        popNames, popInds = [], []
+        for p in args.population:
+            popNames.append(p[0])
+            popInds.append(p[1].split(",") if len(p) > 1 else [])
+        if args.popsFile:
+            with open(args.popsFile, "rt") as pf:
+                for ind, pop in (ln.split()[:2] for ln in pf if ln.strip()):
+                    if pop in popNames:
+                        popInds[popNames.index(pop)].append(ind)
+        for p in popInds:
+            assert len(p) >= 1, "All populations must be represented by at least one sample."
+    allInds = []
+    for p in popInds:
+        for i in p:
+            if i not in allInds:
+                allInds.append(i)
+    if args.ploidy is not None:
+        pl = args.ploidy if len(args.ploidy) != 1 else args.ploidy * len(allInds)
+        assert len(pl) == len(allInds), "Incorrect number of ploidy values supplied."
+        ploidyDict = dict(zip(allInds, pl))
+    elif args.ploidyFile is not None:
+        with open(args.ploidyFile, "rt") as pf:
+            ploidyDict = dict([[s[0], int(s[1])] for s in [ln.split() for ln in pf]])
+    else:
+        ploidyDict = dict(zip(allInds, [2] * len(allInds)))
+    for ind in args.haploid or []:
+        ploidyDict[ind] = 1
+    sampleData = SampleData(popNames=popNames, popInds=popInds, ploidyDict=ploidyDict)
+    fmt = "pairs" if args.genoFormat == "alleles" else args.genoFormat
+    layout = HapLayout(sampleData, headerInds, fmt)
+    data = genoio.encode(body, layout)
+    asCounts = args.asCounts if args.target else True                      # freq.py:222-224
+    keepNan = args.keepNanLines if args.target else True
+    minData = args.minData if args.target else 0
+
+    eng = Engine(args.device if args.device is not None else 0)
+    eng.set_layout(layout)
+    out = _open_out(args.outFile)
+    out.write("scaffold\tposition\t" + "\t".join(popNames) + "\n")
+    run_of_row = np.repeat(np.arange(len(data.run_starts)), np.diff(np.append(data.run_starts, data.n_sites)))
+    P = len(popNames)
+    CH = 1 << 20
+    for a in range(0, data.n_sites, CH):
+        b = min(data.n_sites, a + CH)
+        eng.load_sites(data.gt[a:b])
+        cnt = eng.batch([0], [0]).siteCounts(0, b - a).astype(np.int64)        # [n][P][4]
+        n = cnt.sum(axis=2)
+        if not args.target:
+            cols = [[",".join(r) for r in cnt[:, q, :].astype(str)] for q in range(P)]
+            keep = np.arange(b - a)
+            cells = list(zip(*cols))
+        else:
+            if args.target == "derived":                                        # derivedAllele, genomics.py:636-662
+                outc = cnt[:, P - 1, :] > 0
+                inc = cnt[:, :P - 1, :].sum(axis=1) > 0
+                ok = (outc.sum(axis=1) == 1) & (inc.sum(axis=1) == 2) & np.any(outc & inc, axis=1)
+                base = np.argmax(inc & ~outc, axis=1)
+            else:                                                               # minorAllele, genomics.py:664-669
+                tot = cnt.sum(axis=1)
+                ok = (tot > 0).sum(axis=1) == 2
+                masked = np.where(tot > 0, tot, np.iinfo(np.int64).max)
+                base = np.argmin(masked, axis=1)
+            cols = []
+            for q in range(P):
+                good = ok & (n[:, q] >= minData)                                # freq.py:80: the COUNT is compared
+                tf = np.zeros(b - a, dtype=int) if asCounts else np.full(b - a, np.nan)
+                idx = np.where(good)[0]
+                if len(idx):
+                    c = cnt[idx, q, base[idx]]
+                    if asCounts:
+                        tf[idx] = c
+                    else:
+                        with np.errstate(divide="ignore", invalid="ignore"):
+                            tf[idx] = 1. * c / n[idx, q]
+                cols.append(np.around(tf, 4))
+            allf = np.column_stack(cols)
+            if args.threshold and not asCounts:
+                hi_, lo_ = allf >= args.threshold, allf < args.threshold
+                allf[hi_] = 1
+                allf[lo_] = 0
+            if keepNan:
+                keep = np.arange(b - a)
+            elif not asCounts:
+                keep = np.where(~np.all(np.isnan(allf), axis=1))[0]
+            else:
+                keep = np.where(~np.all(allf == 0, axis=1))[0]
+            cells = allf.astype(str)
+        names = data.run_names
+        for i in keep:
+            out.write(names[run_of_row[a + i]] + "\t" + str(int(data.pos[a + i])) + "\t" + "\t".join(cells[i]) + "\n")
+    if out is not sys.stdout:
+        out.close()
+    sys.stderr.write("\nDone\n")
+    return 0

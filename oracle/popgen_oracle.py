@@ -622,3 +622,80 @@ def aln_from_codes(codes_sites_by_hap, hap_names, sample_names, groups):
     order = np.argsort(hap_names)
     return Aln(np.ascontiguousarray(num[order]), [hap_names[o] for o in order],
                [sample_names[o] for o in order], [groups[o] for o in order]), order
+
+
+# ----------------------------------------------------------------------------------------------
+# freq.py (SURVEY.md 8f "next" row 1): per-site per-population base counts / target-allele frequencies
+# ----------------------------------------------------------------------------------------------
+def freq_tsv(geno_path, fmt, pops, target=None, as_counts=False, min_data=0, threshold=None, keep_nan=False,
+             ploidy=None):
+    """freq.py:30-113 (freqs_wrapper) + 222-224 (asCounts / keepNanLines / minData are overridden without --target) +
+    297-298 (header).  pops: [(name, [samples])] in CLI order; `minor` target is not restated (the reference breaks ties with
+    np.random.choice, freq.py/genomics.py:664-669)."""
+    with open_text(geno_path) as fh:
+        file_names, sites = read_sites(fh)
+    if not target:
+        as_counts, keep_nan, min_data = True, True, 0
+    ind_names = []
+    for _, members in pops:
+        for m in members:
+            if m not in ind_names:
+                ind_names.append(m)
+    pop_of = {nm: [p for p, mem in pops if nm in mem][0] for nm in ind_names}
+    ploidy_of = {nm: 2 for nm in ind_names}
+    if ploidy:
+        ploidy_of.update(ploidy)
+    win = Win(None, None, None, [s[2] for s in sites], [s[1] for s in sites], None)
+    aln = window_to_aln(win, file_names, ind_names, pop_of, ploidy_of, "pairs" if fmt == "alleles" else fmt)
+    g = np.array(aln.groups, dtype=object)
+    pop_names = [p[0] for p in pops]
+    counts = {}
+    for p in pop_names:
+        counts[p] = site_pop_counts(aln, np.where(g == p)[0])
+    L = aln.L
+    lines = ["scaffold\tposition\t" + "\t".join(pop_names)]
+    if not target:
+        cols = [[",".join(r) for r in counts[p][0].astype(str)] for p in pop_names]
+        for i in range(L):
+            lines.append("\t".join([sites[i][0], str(sites[i][1])] + [c[i] for c in cols]))
+        return "\n".join(lines) + "\n"
+    assert target == "derived"
+    out_cnt = counts[pop_names[-1]][0]
+    in_cnt = sum(counts[p][0] for p in pop_names[:-1])
+    base = np.full(L, np.nan)
+    for i in range(L):                                            # derivedAllele, genomics.py:636-662
+        ina = np.where(in_cnt[i] > 0)[0]
+        outa = np.where(out_cnt[i] > 0)[0]
+        if len(outa) == 1 and len(ina) == 2 and outa[0] in ina:
+            base[i] = ina[ina != outa[0]][0]
+    good_site = ~np.isnan(base)
+    cols = []
+    for p in pop_names:
+        cnt, n = counts[p]
+        good = good_site & (n >= min_data)                        # freq.py:80 compares the COUNT with the proportion
+        tf = np.zeros(L, dtype=int) if as_counts else np.full(L, np.nan)
+        idx = np.where(good)[0]
+        if len(idx):
+            b = base[idx].astype(int)
+            if as_counts:
+                tf[idx] = cnt[idx, b]
+            else:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tf[idx] = 1. * cnt[idx, b] / n[idx]
+        cols.append(np.around(tf, 4))
+    allf = np.column_stack(cols)
+    if threshold and not as_counts:
+        hi_ = allf >= threshold
+        lo_ = allf < threshold
+        allf[hi_] = 1
+        allf[lo_] = 0
+    if keep_nan:
+        keep = np.arange(L)
+    elif not as_counts:
+        keep = np.where(~np.all(np.isnan(allf), axis=1))[0]
+    else:
+        keep = np.where(~np.all(allf == 0, axis=1))[0]
+    txt = allf.astype(str)
+    for i in keep:
+        lines.append("\t".join([sites[i][0], str(sites[i][1])] + list(txt[i])))
+    return "\n".join(lines) + "\n"

@@ -97,6 +97,20 @@ CASES = [
          argv=["-g", "{geno}", "-f", "phased", "--windType", "cat", "--outFormat", "nexus", "--roundTo", "8"]),
 ]
 
+CASES += [
+    # ---- freq.py ----
+    dict(name="abba_freq_counts", tool="freq.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased"] + pops_args(16, 4)),
+    dict(name="abba_freq_derived", tool="freq.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "--target", "derived"] + pops_args(16, 4)),
+    dict(name="abba_freq_derived_counts_keepnan", tool="freq.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "--target", "derived", "--asCounts", "--keepNanLines", "--minData", "0.5"] + pops_args(16, 4)),
+    dict(name="holes_freq_derived_threshold", tool="freq.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "--target", "derived", "--threshold", "0.5"] + pops_args(6, 2)),
+    dict(name="abba_pairs_freq_alleles_allpop", tool="freq.py", fixture="abba_pairs",
+         argv=["-g", "{geno}", "-f", "alleles"]),
+]
+
 AUX_FILES = {
     "sparse_coords.txt": "chr1 100 900 first\nchr1 500 1500 second\nchr1 4000 4100 third\nchr3 1 1000 onThree\nchr3 2000 2600 lastOne\n",
     "sparse_exclude.txt": "chr2\n",

@@ -93,4 +93,14 @@ def run(tool, argv):
                                 wind_type=_take(argv, "--windType", default="coordinate"),
                                 out_format=_take(argv, "--outFormat", default="phylip"),
                                 round_to=int(r) if r else 4, include_same="--includeSameWithSame" in argv)
+    if tool == "freq.py":
+        pops = _pops(argv, ("-p",))
+        if not pops:
+            with orc.open_text(geno) as fh:
+                names = fh.readline().split()[2:]
+            pops = [("all", names)]
+        md, th = _take(argv, "--minData"), _take(argv, "--threshold")
+        return orc.freq_tsv(geno, fmt, pops, target=_take(argv, "--target"), as_counts="--asCounts" in argv,
+                            min_data=float(md) if md else 0, threshold=float(th) if th else None,
+                            keep_nan="--keepNanLines" in argv)
     raise ValueError(tool)

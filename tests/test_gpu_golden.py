@@ -12,7 +12,8 @@ from genomics_general_amd import cli
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MAINS = {"popgenWindows.py": cli.popgen_main, "ABBABABAwindows.py": cli.abbababa_main, "distMat.py": cli.distmat_main}
+MAINS = {"popgenWindows.py": cli.popgen_main, "ABBABABAwindows.py": cli.abbababa_main, "distMat.py": cli.distmat_main,
+         "freq.py": cli.freq_main}
 
 
 def round_digits(case):
