@@ -193,10 +193,6 @@ def popgen_main(argv=None):
     minSites = args.minSites
     if not minSites:
         minSites = args.windSize
-    for a in args.analysis:
-        if a in ("indHet", "hapStats"):
-            raise SystemExit("--analysis %s is not implemented by the MI355X engine yet (SURVEY.md 8f, 'next' rows)" % a)
-
     # samples and populations (popgenWindows.py:259-291)
     popNames, popInds, allInds = [], [], []
     if args.population is not None:
@@ -243,6 +239,11 @@ def popgen_main(argv=None):
         stats += ["Fst_" + x + "_" + y for x, y in itertools.combinations(popNames, 2)]
     if "indPairDist" in args.analysis:
         stats += ["_".join(["d", i, j]) for i, j in itertools.combinations_with_replacement(sorted(allInds), 2)]
+    if "indHet" in args.analysis:
+        stats += ["het_" + n for n in allInds]
+    if "hapStats" in args.analysis:
+        for pre in ("H1_", "H12_", "H2_"):
+            stats += [pre + n for n in popNames]
     int_stat = [s.startswith("l_") or s.startswith("S_") for s in stats]
 
     run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=3)
@@ -261,6 +262,11 @@ def popgen_main(argv=None):
             pdd = wb.indPairDists()
             for i, j in itertools.combinations_with_replacement(sorted(pdd.keys()), 2):
                 sd["_".join(["d", i, j])] = pdd[i][j]
+        if "indHet" in args.analysis:
+            for k, v in wb.sampleHet().items():
+                sd["het_" + k] = v
+        if "hapStats" in args.analysis:
+            sd.update(wb.H12stats(maxDist=args.hapDist))
         for c, s in enumerate(stats):
             table[good, c] = sd[s]
     full = run.gather(table)

@@ -145,6 +145,7 @@ class WindowBatch:
         self.hi = np.ascontiguousarray(win_hi, dtype=np.int64)
         self.n = len(self.lo)
         self._popdist_min_sites = None     # set once groupDistStats has "masked the cached matrix"
+        self._diag_nan = False             # indPairDists() without includeSameWithSame leaves a nan diagonal in the cache
 
     # -- integers ---------------------------------------------------------------------------------
     def pairCounts(self, reference_order=True):
@@ -230,6 +231,73 @@ class WindowBatch:
             out["TajD_" + name] = taj
         return out
 
+    # -- indHet / hapStats: host finalisers of the integer matrices ------------------------
+    def _masked_dist(self, reference_order=True):
+        """float64 distance matrices as the reference's cached `_distMat_` looks at this point of its worker: D/C (nan
+        where nothing is jointly called), zero diagonal; after groupDistStats: pairs below its minSites and the diagonal nan
+        (genomics.py:959-963 mutate the cache)."""
+        D, Cc = self.pairCounts(reference_order=reference_order)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dm = D.astype(np.float64) / Cc.astype(np.float64)
+        idx = np.arange(self.lay.n_hap)
+        dm[:, idx, idx] = 0.0
+        if self._popdist_min_sites:
+            dm[Cc < self._popdist_min_sites] = np.nan
+        if self._popdist_min_sites is not None or self._diag_nan:
+            dm[:, idx, idx] = np.nan
+        return dm, Cc
+
+    def sampleHet(self):
+        """{individual: array over windows} like Alignment.sampleHet() (genomics.py:918-929), including its operator
+        precedence: `len(x)==2 & np.sum(...) >= _minSites` parses as `len(x) == (2 & C) >= 1`, so an individual's
+        heterozygosity is reported only when it is diploid and bit 1 of its jointly-called site count is set."""
+        lay = self.lay
+        dm, Cc = self._masked_dist(reference_order=False)
+        out = {}
+        for name in lay.ind_order:
+            sl = lay.ind_slots[name]
+            if len(sl) == 2:
+                c = Cc[:, sl[0], sl[1]]
+                out[name] = np.where((c & 2) == 2, dm[:, sl[0], sl[1]], np.nan)
+            else:
+                out[name] = np.full(self.n, np.nan)
+        return out
+
+    def H12stats(self, maxDist=0):
+        """H1 / H12 / H2 per population like Alignment.H12stats (genomics.py:1079-1098) with the greedy clustering of
+        distMat_to_cluster_sizes (genomics.py:1239-1261), in the reference's row order (haplotype names sorted)."""
+        lay = self.lay
+        dm, _ = self._masked_dist(reference_order=True)
+        groups = np.array([lay.hap_group[i] for i in lay.ref_order], dtype=object)
+        out = {}
+        for name in np.unique(np.array([g for g in lay.hap_group if g is not None])):
+            rows = np.where(groups == name)[0]
+            H1, H12, H2 = np.zeros(self.n), np.zeros(self.n), np.zeros(self.n)
+            for w in range(self.n):
+                with np.errstate(invalid="ignore"):
+                    match = dm[w][np.ix_(rows, rows)] <= maxDist
+                sizes = []
+                while match.shape[0] > 0:
+                    most = match.sum(axis=1).argmax()
+                    matches = match[most, ].sum()
+                    if matches > 1:
+                        sizes.append(matches)
+                        keep = np.invert(match[most, ])
+                        match = match[np.ix_(keep, keep)]
+                    else:
+                        sizes += [1] * match.shape[0]
+                        break
+                sizes = np.array(sizes)
+                f = sizes / sizes.sum()
+                H1[w] = (f ** 2).sum()
+                if len(f) > 1:
+                    H12[w] = H1[w] + 2 * f[0] * f[1]
+                    H2[w] = (f[1:] ** 2).sum()
+                else:
+                    H12[w], H2[w] = H1[w], 0
+            out["H1_" + name], out["H12_" + name], out["H2_" + name] = H1, H12, H2
+        return out
+
     def indPairSums(self, minSites=None):
         """Raw K6 output (pg_indpairdist): sums of D/C and valid-pair counts per unordered individual pair."""
         n = self.lay.n_samp
@@ -254,6 +322,10 @@ class WindowBatch:
         if self._popdist_min_sites is not None:
             ms = max(ms, self._popdist_min_sites)
             diag_nan = True
+        if diag_nan:
+            self._diag_nan = True
+        if minSites:
+            self._popdist_min_sites = max(int(minSites), self._popdist_min_sites or 0)   # the mask stays in the cache
         check(self.e._L.pg_indpairdist(self.e._h, self.lo, self.hi, self.n, ms, sums, cnts))
         out = {a: {} for a in lay.ind_order}
         for s in range(n):

@@ -345,6 +345,52 @@ def ind_pair_dists(aln, dm, include_same=False):
     return out, dm
 
 
+def sample_het(aln, dm, C):
+    """genomics.py:918-929 sampleHet with a cached distance matrix, operator precedence included:
+    `len(x)==2 & np.sum(mask & mask) >= _minSites` is `len(x) == (2 & C) >= 1`."""
+    first = {}
+    for k, s in enumerate(aln.sample_names):
+        first.setdefault(s, []).append(k)
+    out = {}
+    for s, x in first.items():
+        ok = False
+        if len(x) >= 2:
+            c = int(C[x[0], x[1]])
+            ok = (len(x) == (2 & c)) and ((2 & c) >= 1)
+        out["het_" + s] = dm[x[0], x[1]] if ok else np.nan
+    return out
+
+
+def h12_stats(aln, dm, max_dist=0):
+    """genomics.py:1079-1098 H12stats + 1239-1261 distMat_to_cluster_sizes."""
+    g = np.array(aln.groups, dtype=object)
+    out = {}
+    for name in np.unique(np.array(aln.groups)):
+        idx = np.where(g == name)[0]
+        with np.errstate(invalid="ignore"):
+            match = dm[np.ix_(idx, idx)] <= max_dist
+        sizes = []
+        while match.shape[0] > 0:
+            most = match.sum(axis=1).argmax()
+            m = match[most, ].sum()
+            if m > 1:
+                sizes.append(m)
+                keep = np.invert(match[most, ])
+                match = match[np.ix_(keep, keep)]
+            else:
+                sizes += [1] * match.shape[0]
+                break
+        sizes = np.array(sizes)
+        f = sizes / sizes.sum()
+        H1 = (f ** 2).sum()
+        if len(f) > 1:
+            H12, H2 = H1 + 2 * f[0] * f[1], (f[1:] ** 2).sum()
+        else:
+            H12, H2 = H1, 0
+        out["H1_" + name], out["H12_" + name], out["H2_" + name] = H1, H12, H2
+    return out
+
+
 def site_pop_counts(aln, members):
     """genomics.py:1049-1052 siteFreqs(asCounts) / 592-599 binBaseFreqs for the haplotype rows `members`:
     cnt[L][4] and n[L]."""
@@ -460,7 +506,8 @@ def make_windows(sites, wind_type, wind_size, step=None, overlap=0, max_dist=flo
 def popgen_windows_csv(geno_path, fmt, pops, wind_size, step=None, min_sites=1, min_data=0.01,
                        analysis=("popDist", "popPairDist"), round_to=4, wind_type="coordinate",
                        overlap=0, max_dist=float("inf"), coords=None, add_id=False, write_failed=False,
-                       ploidy=None, include=None, exclude=None, counts_fn=pair_counts_gemm, samples_only=None):
+                       ploidy=None, include=None, exclude=None, counts_fn=pair_counts_gemm, samples_only=None,
+                       hap_dist=0):
     """popgenWindows.py:28-75 (stats_wrapper) + 216-354 (setup, header).  pops: [(name, [samples])] in
     CLI order, or None for the single population 'all'."""
     with open_text(geno_path) as fh:
@@ -500,6 +547,11 @@ def popgen_windows_csv(geno_path, fmt, pops, wind_size, step=None, min_sites=1, 
         stats += ["Fst_%s_%s" % (x, y) for x, y in itertools.combinations(pop_names, 2)]
     if "indPairDist" in analysis:
         stats += ["_".join(["d", i, j]) for i, j in itertools.combinations_with_replacement(sorted(ind_names), 2)]
+    if "indHet" in analysis:
+        stats += ["het_" + n for n in ind_names]          # the reference's order is that of a Python set (hash dependent)
+    if "hapStats" in analysis:
+        for pre in ("H1_", "H12_", "H2_"):
+            stats += [pre + n for n in pop_names]
     lines = [("windowID," if add_id else "") + "scaffold,start,end,mid,sites," + ",".join(stats)]
     wins = make_windows(sites, wind_type, wind_size, step, overlap, max_dist, min_sites, coords, include, exclude)
     for w in wins:
@@ -520,6 +572,15 @@ def popgen_windows_csv(geno_path, fmt, pops, wind_size, step=None, min_sites=1, 
                 pdd, _ = ind_pair_dists(aln, base)
                 for i, j in itertools.combinations_with_replacement(sorted(pdd.keys()), 2):
                     sd["_".join(["d", i, j])] = pdd[i][j]
+            if "indHet" in analysis or "hapStats" in analysis:
+                # the cached matrix as the reference leaves it at this point (genomics.py:959-963, 940)
+                cache = dm.copy() if dm is not None else dist_from_counts(D, C)
+                if dm is None and "indPairDist" in analysis:
+                    np.fill_diagonal(cache, np.nan)
+                if "indHet" in analysis:
+                    sd.update(sample_het(aln, cache, C))
+                if "hapStats" in analysis:
+                    sd.update(h12_stats(aln, cache, hap_dist))
             vals = [_round(sd[s], round_to) for s in stats]
         else:
             good = False

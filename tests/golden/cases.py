@@ -111,6 +111,17 @@ CASES += [
          argv=["-g", "{geno}", "-f", "alleles"]),
 ]
 
+CASES += [
+    # ---- popgenWindows --analysis indHet / hapStats ----
+    dict(name="sparse_het_hap_after_popdist", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--analysis", "popDist", "popPairDist", "indHet", "hapStats",
+               "--hapDist", "0.05", "--roundTo", "8"] + pops_args(12, 3)),
+    dict(name="holes_het_hap_only", tool="popgenWindows.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "600", "-m", "30", "--analysis", "indHet", "hapStats", "--roundTo", "8"] + pops_args(6, 2)),
+    dict(name="c1_indpair_hap_exact", tool="popgenWindows.py", fixture="c1",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "2500", "-m", "50", "--analysis", "indPairDist", "hapStats", "--roundTo", "8"] + pops_args(8, 2)),
+]
+
 AUX_FILES = {
     "sparse_coords.txt": "chr1 100 900 first\nchr1 500 1500 second\nchr1 4000 4100 third\nchr3 1 1000 onThree\nchr3 2000 2600 lastOne\n",
     "sparse_exclude.txt": "chr2\n",

