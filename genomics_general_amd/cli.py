@@ -126,16 +126,25 @@ class Run:
     """Shared plumbing: input -> layout -> windows -> engine (+ multi-GPU shard of the window list)."""
 
     def __init__(self, args, sampleData, wparams, minSites, header_line=None, coords_keep=4, windows_fn=None):
+        import time
         self.world = dist.world_from_env()
+        self.timing = {}                                  # seconds per phase; printed as JSON on stderr when PG_TIMING=1
+        t0 = time.perf_counter()
         raw = genoio.read_all(args.genoFile)
         names, body = genoio.split_header(raw, header_line)
+        self.timing["read_s"], t0 = time.perf_counter() - t0, time.perf_counter()
+        self.timing["text_bytes"] = len(raw)
         self.layout = HapLayout(sampleData, names, args.genoFormat)
         self.data = genoio.encode(body, self.layout)
+        self.timing["tokenize_s"], t0 = time.perf_counter() - t0, time.perf_counter()
         wparams = dict(wparams, include=args.include, exclude=args.exclude)
         self.T = windows_fn(self.data) if windows_fn else _make_windows(wparams, self.data, minSites, coords_keep)
+        self.timing["windows_s"], t0 = time.perf_counter() - t0, time.perf_counter()
+        self.timing["sites"], self.timing["windows"] = int(self.data.n_sites), int(self.T.n)
         dev = args.device if args.device is not None else self.world.local_rank
         self.engine = Engine(dev)
         self.engine.set_layout(self.layout)
+        self._t_upload0 = time.perf_counter()
         self.comm = dist.RcclComm(self.engine, self.world) if self.world.size > 1 else dist.SoloComm()
         # this rank's windows (contiguous range) and only the sites they cover
         self.w0, self.w1 = dist.shard_range(self.T.n, self.world.size, self.world.rank)
@@ -150,6 +159,17 @@ class Run:
         self.lo, self.hi = lo - s0, hi - s0
         self.lo[~nz] = 0
         self.hi[~nz] = 0
+        self.timing["engine_and_upload_s"] = time.perf_counter() - self._t_upload0
+        self._t_compute0 = time.perf_counter()
+
+    def report_timing(self):
+        """Tier-T2 evidence (text end to end): per-phase wall seconds as one JSON line on stderr when PG_TIMING=1."""
+        import json
+        import os
+        import time
+        if os.environ.get("PG_TIMING") and self.world.rank == 0:
+            self.timing["compute_and_write_s"] = time.perf_counter() - self._t_compute0
+            sys.stderr.write("PG_TIMING " + json.dumps(self.timing) + "\n")
 
     def batch(self, mask):
         """WindowBatch over this rank's windows selected by boolean `mask`."""
@@ -294,6 +314,7 @@ def popgen_main(argv=None):
         sys.stderr.write(str(T.n) + " windows were tested.\n")
         sys.stderr.write(str(written) + " results were written.\n")
         sys.stderr.write("\nDone.\n")
+    run.report_timing()
     run.comm.barrier()
     return 0
 
@@ -374,6 +395,7 @@ def abbababa_main(argv=None):
         if out is not sys.stdout:
             out.close()
         sys.stderr.write("%d windows were tested\n%d results were written\n\nDone.\n" % (T.n, written))
+    run.report_timing()
     run.comm.barrier()
     return 0
 
@@ -492,6 +514,7 @@ def distmat_main(argv=None):
             if f is not None and f is not sys.stdout:
                 f.close()
         sys.stderr.write("{} windows were tested.\n{} results were written.\n\n### Done. ###\n".format(T.n, written))
+    run.report_timing()
     run.comm.barrier()
     return 0
 

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Tier T2 (text end to end): write a synthetic `.geno` file, run the drop-in popgenWindows.py on it, print the per-phase wall
+times (PG_TIMING).  python tools/t2_bench.py [n_sites] [n_dip]"""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from genomics_general_amd import synth  # noqa: E402
+
+
+def write_fast(path, n_sites, n_dip, n_pops, seed=7):
+    """vectorised writer: fixed-width phased cells"""
+    names = ["s%d" % d for d in range(n_dip)]
+    with open(path, "wb") as f:
+        f.write(("#CHROM\tPOS\t" + "\t".join(names) + "\n").encode())
+        step = 100000
+        for a in range(0, n_sites, step):
+            b = min(n_sites, a + step)
+            pos = np.arange(a + 1, b + 1)
+            codes = synth.gen_codes(seed, np.zeros(b - a, dtype=np.int64), pos, n_dip, n_pops)
+            letters = synth.codes_to_letters(codes)                                    # [L][2n] uint8
+            L = b - a
+            cell = np.empty((L, n_dip, 4), dtype=np.uint8)
+            cell[:, :, 0] = letters[:, 0::2]
+            cell[:, :, 1] = ord("/")
+            cell[:, :, 2] = letters[:, 1::2]
+            cell[:, :, 3] = ord("\t")
+            cell[:, -1, 3] = ord("\n")
+            body = cell.reshape(L, -1)
+            prefix = np.array([("chr1\t%d\t" % p).encode() for p in pos], dtype=object)
+            f.write(b"".join(prefix[i] + body[i].tobytes() for i in range(L)))
+    return names
+
+
+def main():
+    n_sites = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    n_dip = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    path = "/tmp/t2_%d_%d.geno" % (n_sites, n_dip)
+    t0 = time.time()
+    names = write_fast(path, n_sites, n_dip, 4)
+    print("wrote %s: %.1f MB in %.1f s" % (path, os.path.getsize(path) / 1e6, time.time() - t0))
+    per = n_dip // 4
+    cmd = [sys.executable, os.path.join(ROOT, "popgenWindows.py"), "-g", path, "-o", "/tmp/t2_out.csv", "-f", "phased", "-w", "50000",
+           "-m", "100"]
+    for k in range(4):
+        cmd += ["-p", "pop%d" % k, ",".join(names[k * per:(k + 1) * per])]
+    for rep in range(2):
+        t0 = time.time()
+        r = subprocess.run(cmd, env=dict(os.environ, PG_TIMING="1"), stderr=subprocess.PIPE)
+        wall = time.time() - t0
+        line = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING")]
+        print("run %d: wall %.2f s (incl. interpreter start)  %s" % (rep, wall, line[-1] if line else r.stderr.decode()[-400:]))
+    with open("/tmp/t2_out.csv") as f:
+        rows = f.readlines()
+    print("rows:", len(rows) - 1, "| windows/s end to end:", round((len(rows) - 1) / wall, 2), "| sites/s:", round(n_sites / wall))
+
+
+if __name__ == "__main__":
+    main()
