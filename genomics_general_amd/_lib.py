@@ -57,6 +57,8 @@ SIGNATURES = {
     "pg_popdist_stats": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_double, C.c_int, _f64p]),
     "pg_indpairdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
     "pg_abbababa": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _f64p, _i64p]),
+    "pg_fourpop": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _f64p,
+                             _i64p]),
     "pg_popfreq": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p, _i64p, _i64p]),
     "pg_hap_called": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p]),
     "pg_site_counts": (C.c_int, [_P, C.c_int64, C.c_int64, _i32p]),

@@ -322,8 +322,20 @@ def popgen_main(argv=None):
 # ==========================================================================================================
 # ABBABABAwindows.py
 # ==========================================================================================================
+FOURPOP_STATS = ["ABBA", "BABA", "ABAA", "BAAA", "D", "fd", "fd'", "fdm", "fdm'", "fdh", "fdh2", "fh"]   # fourPopWindows.py:241
+
+
 def abbababa_main(argv=None):
-    ap = argparse.ArgumentParser(prog="ABBABABAwindows.py")
+    return _quartet_main(argv, "ABBABABAwindows.py", ["ABBA", "BABA", "D", "fd", "fdM"], fourpop=False)
+
+
+def fourpop_main(argv=None):
+    """fourPopWindows.py:105-150 flag table; statistics genomics.py:1585-1643."""
+    return _quartet_main(argv, "fourPopWindows.py", FOURPOP_STATS, fourpop=True)
+
+
+def _quartet_main(argv, prog, stats, fourpop):
+    ap = argparse.ArgumentParser(prog=prog)
     _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined"))})
     ap.add_argument("--overlap", type=int, metavar="sites", help="Overlap for sites sliding window")
     ap.add_argument("--minData", type=float, metavar="proportion", default=0.01,
@@ -336,6 +348,9 @@ def abbababa_main(argv=None):
     ap.add_argument("--haploid", metavar="sample names", help="Samples that are haploid (comma separated)")
     ap.add_argument("--header", help="Header text if no header in input")
     ap.add_argument("-T", "--Threads", type=int, default=1, help="accepted for compatibility")
+    if fourpop:
+        ap.add_argument("--polarize", action="store_true", help="Ensure outgroup is fixed for ancestral allele")
+        ap.add_argument("--fixed", action="store_true", help="Only count fixed SNPs")
     _add(ap, IO_FLAGS)
     args = ap.parse_args(argv)
 
@@ -367,12 +382,15 @@ def abbababa_main(argv=None):
 
     run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=4)
     T = run.T
-    stats = ["ABBA", "BABA", "D", "fd", "fdM"]
     sites_local = T.sites[run.w0:run.w1]
     good = sites_local >= minSites
-    table = np.full((run.w1 - run.w0, 1 + len(stats)), np.nan)           # sitesUsed + 5 statistics
+    table = np.full((run.w1 - run.w0, 1 + len(stats)), np.nan)           # sitesUsed + the statistics
     if np.any(good):
-        sd = run.batch(good).ABBABABA(popNames[0], popNames[1], popNames[2], popNames[3], minData)
+        if fourpop:
+            sd = run.batch(good).fourPop(popNames[0], popNames[1], popNames[2], popNames[3], minData,
+                                         polarize=args.polarize, fixed=args.fixed)
+        else:
+            sd = run.batch(good).ABBABABA(popNames[0], popNames[1], popNames[2], popNames[3], minData)
         table[good, 0] = sd["sitesUsed"]
         for c, s in enumerate(stats):
             table[good, 1 + c] = sd[s]
@@ -380,11 +398,11 @@ def abbababa_main(argv=None):
 
     if run.world.rank == 0:
         out = _open_out(args.outFile)
-        out.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites,sitesUsed,ABBA,BABA,D,fd,fdM\n")
+        out.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites,sitesUsed," + ",".join(stats) + "\n")
         written = 0
         for k in range(T.n):
             used = full[k, 0]
-            ok = T.sites[k] >= minSites and used >= minSites           # ABBABABAwindows.py:35-46
+            ok = T.sites[k] >= minSites and used >= minSites           # ABBABABAwindows.py:35-46, fourPopWindows.py:36-48
             if not (ok or args.writeFailedWindows):
                 continue
             vals = [round(np.float64(v), 4) for v in full[k, 1:]] if ok else [np.nan] * len(stats)

@@ -730,13 +730,14 @@ extern "C" int pg_indpairdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, i
 }
 
 // ---- site statistics --------------------------------------------------------------------------------
-extern "C" int pg_abbababa(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int p1, int p2, int p3, int p4,
-                           double min_data, double *sums_out, int64_t *used_out) {
+static int quartet_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int p1, int p2, int p3, int p4,
+                         double min_data, int sel, int nsum, double *sums_out, int64_t *used_out) {
     int rc = check_windows(c, lo, hi, n_win);
     if (rc != PG_OK) return rc;
     const int ps[4] = {p1, p2, p3, p4};
     for (int k = 0; k < 4; ++k)
         if (ps[k] < 0 || ps[k] >= c->n_pops) return pg_fail(PG_ERR_ARG, "population id %d out of range [0,%d)", ps[k], c->n_pops);
+    if (sel != PG_SEL_MINOR && sel != PG_SEL_POLARIZE && sel != PG_SEL_FIXED) return pg_fail(PG_ERR_ARG, "unknown allele_sel %d", sel);
     if (n_win == 0) return PG_OK;
     if (!sums_out || !used_out) return pg_fail(PG_ERR_ARG, "null output");
     HIPCHK(hipSetDevice(c->device));
@@ -747,22 +748,32 @@ extern "C" int pg_abbababa(pg_ctx *c, const int64_t *lo, const int64_t *hi, int 
         int64_t max_len = 0;
         if ((rc = stage_windows(c, lo, hi, w0, w1, nullptr, nullptr, &max_len)) != PG_OK) return rc;
         int max_chunks = (int)((max_len + PG_SITES_PER_BLOCK - 1) / PG_SITES_PER_BLOCK);
-        if ((rc = c->part_f64.ensure((size_t)nb * std::max(max_chunks, 1) * PG_ABBA_NSUM)) != PG_OK) return rc;
+        if ((rc = c->part_f64.ensure((size_t)nb * std::max(max_chunks, 1) * nsum)) != PG_OK) return rc;
         if ((rc = c->part_i64.ensure((size_t)nb * std::max(max_chunks, 1))) != PG_OK) return rc;
-        if ((rc = c->res_f64.ensure((size_t)nb * PG_ABBA_NSUM)) != PG_OK) return rc;
+        if ((rc = c->res_f64.ensure((size_t)nb * nsum)) != PG_OK) return rc;
         if ((rc = c->res_i64.ensure((size_t)nb)) != PG_OK) return rc;
         hipEvent_t e0, e1;
         if ((rc = pg_time_begin(c, PG_K_SITESTATS, &e0, &e1)) != PG_OK) return rc;
         pg_launch_abba(c->stream, c->gt.p, c->S, c->win.p, c->win.p + nb, nb, max_chunks, c->pop_start.p, p1, p2, p3, p4,
-                       min_data, c->part_f64.p, c->part_i64.p, c->res_f64.p, c->res_i64.p);
+                       min_data, sel, nsum, c->part_f64.p, c->part_i64.p, c->res_f64.p, c->res_i64.p);
         if ((rc = pg_time_end(c, PG_K_SITESTATS, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(sums_out + (size_t)w0 * PG_ABBA_NSUM, c->res_f64.p, (size_t)nb * PG_ABBA_NSUM * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(sums_out + (size_t)w0 * nsum, c->res_f64.p, (size_t)nb * nsum * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(used_out + w0, c->res_i64.p, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         w0 = w1;
     }
     return PG_OK;
+}
+
+extern "C" int pg_abbababa(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int p1, int p2, int p3, int p4,
+                           double min_data, double *sums_out, int64_t *used_out) {
+    return quartet_stats(c, lo, hi, n_win, p1, p2, p3, p4, min_data, PG_SEL_POLARIZE, PG_ABBA_NSUM, sums_out, used_out);
+}
+
+extern "C" int pg_fourpop(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int p1, int p2, int p3, int p4,
+                          double min_data, int allele_sel, double *sums_out, int64_t *used_out) {
+    return quartet_stats(c, lo, hi, n_win, p1, p2, p3, p4, min_data, allele_sel, PG_FOURPOP_NSUM, sums_out, used_out);
 }
 
 extern "C" int pg_popfreq(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int64_t *l_out, int64_t *S_out,

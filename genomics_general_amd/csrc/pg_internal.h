@@ -2,10 +2,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/popgen_hip.h"
 
 #define PG_MAX_POPS 16          // populations handled by the site-statistics kernels (K3/K6 take any number)
 #define PG_SITES_PER_BLOCK 1024 // sites reduced by one block of the site-statistics kernels
 #define PG_ABBA_NSUM 6
+#define PG_FOURPOP_NSUM 14
 
 struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,row0+8*nsub) x cols [col0,col0+64)
     int32_t row0, nsub, col0, pad;
@@ -45,7 +47,8 @@ void pg_launch_mirror(hipStream_t st, int32_t *Cmat, int32_t *Dmat, int N, int n
 
 void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                     int n_win, int max_chunks, const int32_t *pop_start, int p1, int p2, int p3, int p4,
-                    double min_data, double *part_sums, int64_t *part_used, double *sums_out, int64_t *used_out);
+                    double min_data, int sel, int nsum, double *part_sums, int64_t *part_used, double *sums_out,
+                    int64_t *used_out);
 
 void pg_launch_popfreq(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
                        const int64_t *win_hi, int n_win, int max_chunks, const int32_t *pop_start, int n_pops,

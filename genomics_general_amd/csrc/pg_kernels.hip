@@ -542,17 +542,28 @@ __device__ __forceinline__ double f4_term(double a, double b, double c, double d
     return (1 - a) * b * c * (1 - d) - a * (1 - b) * c * (1 - d);
 }
 
-struct AbbaAcc {
-    double acc[PG_ABBA_NSUM];
+template <int NSUM>
+struct QuartetAcc {
+    double acc[NSUM];
     unsigned long long used;
 };
 
-// Float64 phase for one usable site (operation order of genomics.py:1409-1475, 1565-1569).
-__device__ __forceinline__ void abba_terms(const uint32_t e[7], AbbaAcc &A) {
+// Float64 phase for one usable site.  e = { c1, c2, c3, n1, n2, n3, n4, c4 }: allele counts / called counts of the chosen
+// allele in P1, P2, P3, P4.  The first six sums are the ones genomics.ABBABABA needs (operation order of
+// genomics.py:1409-1475, 1565-1569); with NSUM == PG_FOURPOP_NSUM the remaining terms of genomics.fourPop
+// (genomics.py:1413-1563) follow, again operation for operation.
+__device__ __forceinline__ double np_max(double a, double b) { return a != a ? a : (b != b ? b : (a > b ? a : b)); }
+
+__device__ __forceinline__ double f4c_term(double a, double b, double c, double d) {
+    return f4_term(a, b, c, d) + f4_term(1 - a, 1 - b, 1 - c, 1 - d);                   // :1413-1418
+}
+
+template <int NSUM>
+__device__ __forceinline__ void quartet_terms(const uint32_t e[8], QuartetAcc<NSUM> &A) {
     const double p1 = (double)e[0] / (double)e[3];
     const double p2 = (double)e[1] / (double)e[4];
     const double p3 = (double)e[2] / (double)e[5];
-    const double p4 = (double)0u / (double)e[6];
+    const double p4 = (double)e[7] / (double)e[6];
     const double abba = (1 - p1) * p2 * p3 * (1 - p4);
     const double baba = p1 * (1 - p2) * p3 * (1 - p4);
     A.acc[0] += f4_term(p1, p2, p3, p4);
@@ -568,6 +579,25 @@ __device__ __forceinline__ void abba_terms(const uint32_t e[7], AbbaAcc &A) {
     A.acc[3] += f4_term(pdm1, pdm2, pdm3, p4);
     A.acc[4] += abba;
     A.acc[5] += baba;
+    if constexpr (NSUM > PG_ABBA_NSUM) {
+        const double num = f4c_term(p1, p2, p3, p4);
+        A.acc[6] += num;                                                              // fd', fdm', fdh, fdh2, fh numerators
+        A.acc[7] += f4c_term(p1, pd, pd, p4);                                         // :1455-1456
+        A.acc[8] += f4c_term(pdm1, pdm2, pdm3, p4);                                   // :1483-1486
+        const double t11 = f4c_term(p1, p3, p3, p4), t12 = f4c_term(p4, p2, p3, p4);
+        const double t21 = f4c_term(p3, p2, p3, p4), t22 = f4c_term(p1, p4, p3, p4);
+        double m = np_max(np_max(np_max(t11, t12), t21), t22);                        // np.amax: NaN propagates
+        A.acc[9] += m;                                                                // :1495-1502
+        const double t31 = f4c_term(p1, p2, p2, p4), t32 = f4c_term(p1, p2, p3, p1);
+        const double t41 = f4c_term(p1, p2, p1, p4), t42 = f4c_term(p1, p2, p3, p2);
+        m = np_max(np_max(np_max(np_max(m, t31), t32), t41), t42);
+        A.acc[10] += m;                                                               // :1511-1523
+        const double t1 = fabs(p1 - p2), t2 = fabs(p3 - p4);
+        const double den = t1 * (double)(t1 > t2) + t2 * (double)(t2 >= t1);
+        A.acc[11] += den * den;                                                       // :1551-1554
+        A.acc[12] += (1 - p1) * p2 * (1 - p3) * (1 - p4);                             // ABAA :1557
+        A.acc[13] += p1 * (1 - p2) * (1 - p3) * (1 - p4);                             // BAAA :1560
+    }
     ++A.used;
 }
 
@@ -603,10 +633,17 @@ __device__ __forceinline__ void range_counts_x4(const int8_t *__restrict__ rowb,
 
 #define PG_ABBA_RING 128          // per-wave ring of usable sites waiting for the float64 phase
 
+// Allele choice per site (sel):
+//   PG_SEL_POLARIZE  the allele present in the four populations and absent from P4 (genomics.py:1672 / :1610)
+//   PG_SEL_FIXED     same, and fixed (frequency 0 or 1) in each of P1, P2, P3 (genomics.py:1611-1614)
+//   PG_SEL_MINOR     np.argsort(all4freqs)[:,2], i.e. the rarer of the two alleles (genomics.py:1615); a tie is resolved the
+//                    way NumPy >= 2.0's x86 (AVX2 / AVX-512) argsort network resolves it for a 4-element row, which is what
+//                    the reference produces on current hardware: {A,C}->C, {A,G}->A, {A,T}->A, {C,G}->C, {C,T}->C, {G,T}->G
+template <int NSUM>
 __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
                                                 const int64_t *__restrict__ win_hi, int max_chunks,
                                                 const int32_t *__restrict__ pop_start, int q1, int q2, int q3, int q4,
-                                                double min_data, double *__restrict__ part_sums,
+                                                double min_data, int sel, double *__restrict__ part_sums,
                                                 int64_t *__restrict__ part_used) {
     __shared__ double shd[256];
     __shared__ unsigned long long shu[256];
@@ -614,9 +651,9 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
     const int win = blockIdx.y, chunk = blockIdx.x;
     const int64_t lo = win_lo[win], hi = win_hi[win];
     const int64_t c0 = lo + (int64_t)chunk * PG_SITES_PER_BLOCK;
-    AbbaAcc A;
+    QuartetAcc<NSUM> A;
 #pragma unroll
-    for (int k = 0; k < PG_ABBA_NSUM; ++k) A.acc[k] = 0.0;
+    for (int k = 0; k < NSUM; ++k) A.acc[k] = 0.0;
     A.used = 0;
     const int qs[4] = {q1, q2, q3, q4};
     const int q = threadIdx.x & 3;
@@ -650,65 +687,89 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
             }
             const uint32_t n_o = (uint32_t)__shfl((int)n, qbase + 3, 64);
             const int nall = (tot[0] > 0) + (tot[1] > 0) + (tot[2] > 0) + (tot[3] > 0);
-            int der = -1;                                // allele present overall, absent from the outgroup (genomics.py:1672)
+            int der = -1;
+            bool good = ok && nall == 2;
+            if (sel == PG_SEL_MINOR) {
+                int lo_b = -1, hi_b = -1;                // the two alleles present, lo_b < hi_b
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (tot[b] > 0 && c3[b] == 0) der = b;
-            const bool good = ok && nall == 2 && n_o > 0 && der >= 0;
+                for (int b = 3; b >= 0; --b)
+                    if (tot[b] > 0) { if (hi_b < 0) hi_b = b; else lo_b = b; }
+                if (good) {
+                    uint32_t tl = 0u, th = 0u;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { if (b == lo_b) tl = tot[b]; if (b == hi_b) th = tot[b]; }
+                    if (tl < th) der = lo_b;
+                    else if (th < tl) der = hi_b;
+                    else der = (lo_b == 0 && hi_b == 1) ? 1 : lo_b;
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (tot[b] > 0 && c3[b] == 0) der = b;
+                good = good && n_o > 0 && der >= 0;
+            }
             uint32_t cder = 0u;
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 if (b == der) cder = cnt[b];
-            // gather the quad's derived-allele counts and called counts into its lane 0
+            if (sel == PG_SEL_FIXED) {                   // P1,P2,P3 frequency exactly 0 or 1; 0/0 (nan) is neither
+                int fx = (q == 3) || (n > 0 && (cder == 0u || cder == n));
+                fx &= __shfl_xor(fx, 1, 64);
+                fx &= __shfl_xor(fx, 2, 64);
+                good = good && fx;
+            }
+            // gather the quad's chosen-allele counts and called counts into its lane 0
             const uint32_t c_p2 = (uint32_t)__shfl((int)cder, qbase + 1, 64), c_p3 = (uint32_t)__shfl((int)cder, qbase + 2, 64);
+            const uint32_t c_p4 = (uint32_t)__shfl((int)cder, qbase + 3, 64);
             const uint32_t n_p2 = (uint32_t)__shfl((int)n, qbase + 1, 64), n_p3 = (uint32_t)__shfl((int)n, qbase + 2, 64);
             const bool writer = good && q == 0;
             const unsigned long long bal = __ballot(writer);
             if (writer) {
                 const int before = __popcll(bal & ((1ull << lane) - 1ull));
                 uint32_t *e = my_ring[(tail + before) & (PG_ABBA_RING - 1)];
-                e[0] = cder; e[1] = c_p2; e[2] = c_p3; e[3] = n; e[4] = n_p2; e[5] = n_p3; e[6] = n_o;
+                e[0] = cder; e[1] = c_p2; e[2] = c_p3; e[3] = n; e[4] = n_p2; e[5] = n_p3; e[6] = n_o; e[7] = c_p4;
             }
             tail += (int)__popcll(bal);
             if (tail - head >= 64) {                     // a full wave of usable sites: float64 phase
-                uint32_t f[7];
+                uint32_t f[8];
                 const uint32_t *e = my_ring[(head + lane) & (PG_ABBA_RING - 1)];
 #pragma unroll
-                for (int k = 0; k < 7; ++k) f[k] = e[k];
-                abba_terms(f, A);
+                for (int k = 0; k < 8; ++k) f[k] = e[k];
+                quartet_terms<NSUM>(f, A);
                 head += 64;
             }
         }
         if (lane < tail - head) {
-            uint32_t f[7];
+            uint32_t f[8];
             const uint32_t *e = my_ring[(head + lane) & (PG_ABBA_RING - 1)];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) f[k] = e[k];
-            abba_terms(f, A);
+            for (int k = 0; k < 8; ++k) f[k] = e[k];
+            quartet_terms<NSUM>(f, A);
         }
     }
     const size_t o = (size_t)win * max_chunks + chunk;
 #pragma unroll
-    for (int k = 0; k < PG_ABBA_NSUM; ++k) {
+    for (int k = 0; k < NSUM; ++k) {
         const double r = block_sum_f64(A.acc[k], shd);
-        if (threadIdx.x == 0) part_sums[o * PG_ABBA_NSUM + k] = r;
+        if (threadIdx.x == 0) part_sums[o * NSUM + k] = r;
     }
     const unsigned long long u = block_sum_u64(A.used, shu);
     if (threadIdx.x == 0) part_used[o] = (int64_t)u;
 }
 
 __global__ void k_abba_reduce(const double *__restrict__ part_sums, const int64_t *__restrict__ part_used, int n_win,
-                              int max_chunks, const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
-                              double *__restrict__ sums_out, int64_t *__restrict__ used_out) {
+                              int max_chunks, int nsum, const int64_t *__restrict__ win_lo,
+                              const int64_t *__restrict__ win_hi, double *__restrict__ sums_out,
+                              int64_t *__restrict__ used_out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int win = idx / (PG_ABBA_NSUM + 1), k = idx % (PG_ABBA_NSUM + 1);
+    const int win = idx / (nsum + 1), k = idx % (nsum + 1);
     if (win >= n_win) return;
     const int64_t len = win_hi[win] - win_lo[win];
     const int nch = (int)((len + PG_SITES_PER_BLOCK - 1) / PG_SITES_PER_BLOCK);
-    if (k < PG_ABBA_NSUM) {
+    if (k < nsum) {
         double s = 0.0;
-        for (int c = 0; c < nch; ++c) s += part_sums[((size_t)win * max_chunks + c) * PG_ABBA_NSUM + k];
-        sums_out[(size_t)win * PG_ABBA_NSUM + k] = s;
+        for (int c = 0; c < nch; ++c) s += part_sums[((size_t)win * max_chunks + c) * nsum + k];
+        sums_out[(size_t)win * nsum + k] = s;
     } else {
         int64_t u = 0;
         for (int c = 0; c < nch; ++c) u += part_used[(size_t)win * max_chunks + c];
@@ -718,15 +779,20 @@ __global__ void k_abba_reduce(const double *__restrict__ part_sums, const int64_
 
 void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                     int n_win, int max_chunks, const int32_t *pop_start, int p1, int p2, int p3, int p4,
-                    double min_data, double *part_sums, int64_t *part_used, double *sums_out, int64_t *used_out) {
+                    double min_data, int sel, int nsum, double *part_sums, int64_t *part_used, double *sums_out,
+                    int64_t *used_out) {
     if (n_win <= 0) return;
     if (max_chunks > 0) {
-        hipLaunchKernelGGL(k_abba_q, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi, max_chunks,
-                           pop_start, p1, p2, p3, p4, min_data, part_sums, part_used);
+        if (nsum == PG_ABBA_NSUM)
+            hipLaunchKernelGGL(k_abba_q<PG_ABBA_NSUM>, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi,
+                               max_chunks, pop_start, p1, p2, p3, p4, min_data, sel, part_sums, part_used);
+        else
+            hipLaunchKernelGGL(k_abba_q<PG_FOURPOP_NSUM>, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi,
+                               max_chunks, pop_start, p1, p2, p3, p4, min_data, sel, part_sums, part_used);
     }
-    int total = n_win * (PG_ABBA_NSUM + 1);
+    int total = n_win * (nsum + 1);
     hipLaunchKernelGGL(k_abba_reduce, dim3((total + 255) / 256), dim3(256), 0, st, part_sums, part_used, n_win,
-                       max_chunks, win_lo, win_hi, sums_out, used_out);
+                       max_chunks, nsum, win_lo, win_hi, sums_out, used_out);
 }
 
 // ------------------------------------------------------------------------------------------------------

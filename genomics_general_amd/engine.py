@@ -356,6 +356,25 @@ class WindowBatch:
                    "ABBA": sums[:, 4], "BABA": sums[:, 5], "sitesUsed": used}
         return out
 
+    # -- four-population statistics ----------------------------------------------------------------------------
+    def fourPop(self, P1, P2, P3, P4, minData, polarize=False, fixed=False):
+        """genomics.fourPop (genomics.py:1585-1643): the window sums come from pg_fourpop, the ratios are formed here exactly
+        as `x.sum()*1./y.sum()` in genomics.py:1420-1554."""
+        names = self.lay.sampleData.popNames
+        ids = [names.index(p) for p in (P1, P2, P3, P4)]
+        sel = 1 if polarize else 2 if fixed else 0             # genomics.py:1610-1615: polarize wins over fixed
+        sums = np.zeros((self.n, 14), dtype=np.float64)
+        used = np.zeros(self.n, dtype=np.int64)
+        check(self.e._L.pg_fourpop(self.e._h, self.lo, self.hi, self.n, ids[0], ids[1], ids[2], ids[3], float(minData), sel,
+                                   sums, used))
+        f4, f4c = sums[:, 0], sums[:, 6]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out = {"D": f4 * 1. / sums[:, 1], "fd": f4 * 1. / sums[:, 2], "fdm": f4 * 1. / sums[:, 3],
+                   "fd'": f4c * 1. / sums[:, 7], "fdm'": f4c * 1. / sums[:, 8], "fdh": f4c * 1. / sums[:, 9],
+                   "fdh2": f4c * 1. / sums[:, 10], "fh": f4c * 1. / sums[:, 11],
+                   "ABBA": sums[:, 4], "BABA": sums[:, 5], "ABAA": sums[:, 12], "BAAA": sums[:, 13], "sitesUsed": used}
+        return out                       # windows with sitesUsed == 0 carry 0.0 / nan; the drivers never print them
+
 
 def _tajima_d(n, S, theta_pi):
     """genomics.py:619-632 on arrays (n scalar)."""

@@ -137,6 +137,19 @@ int pg_indpairdist(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, in
 int pg_abbababa(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int p1, int p2, int p3,
                 int p4, double min_data, double *sums_out, int64_t *sites_used_out);
 
+/* ---- K1+K4': four-population window sums (fourPopWindows.py) ---------------------------------------- */
+/* Replaces genomics.fourPop (genomics.py:1585-1643) and its per-site terms (genomics.py:1409-1563).
+ * allele_sel chooses the allele whose frequencies p1..p4 enter the terms:
+ *   PG_SEL_MINOR    default of the reference: np.argsort(all4freqs)[:,2] (genomics.py:1615)
+ *   PG_SEL_POLARIZE --polarize: allele absent from P4 (genomics.py:1610)
+ *   PG_SEL_FIXED    --fixed: as polarize and fixed (0 or 1) in P1, P2, P3 (genomics.py:1611-1614)
+ * sums_out[n_win][14] = { sum f4, sum (ABBA+BABA), sum f4(p1,pd,pd,p4), sum f4(pdm1,pdm2,pdm3,p4), sum ABBA,
+ * sum BABA, sum f4_c, sum f4_c(p1,pd,pd,p4), sum f4_c(pdm1,pdm2,pdm3,p4), sum fdh-denominator, sum
+ * fdh2-denominator, sum fh-denominator, sum ABAA, sum BAAA }; sites_used_out[n_win]. */
+enum pg_allele_sel { PG_SEL_MINOR = 0, PG_SEL_POLARIZE = 1, PG_SEL_FIXED = 2 };
+int pg_fourpop(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int p1, int p2, int p3,
+               int p4, double min_data, int allele_sel, double *sums_out, int64_t *sites_used_out);
+
 /* ---- K1+K5: site-frequency window sums -------------------------------------------------------------- */
 /* Replaces Alignment.groupFreqStats (genomics.py:1002-1028) + baseCountPi (609-616).  Sites used are those
  * with no missing call in ANY haplotype slot.  l_out[n_win]; S_out[n_win][n_pops] = #sites with >1 allele

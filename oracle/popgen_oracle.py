@@ -435,6 +435,79 @@ def abbababa(aln, P1, P2, P3, P4, min_data):
     return dict(D=Dv, fd=fdv, fdM=fdm, ABBA=abba_t.sum(), BABA=baba_t.sum(), sitesUsed=len(ai[0]))
 
 
+FOURPOP_STATS = ["ABBA", "BABA", "ABAA", "BAAA", "D", "fd", "fd'", "fdm", "fdm'", "fdh", "fdh2", "fh"]   # fourPopWindows.py:241
+
+# np.argsort(all4freqs, axis=1)[:, 2] on a row with two equal positive entries at bases (i, j): NumPy >= 2.0's x86 SIMD
+# argsort network (AVX2 and AVX-512 alike) returns this base; the scalar fallback would return i.  The goldens were
+# generated with the SIMD path, which is what current hardware runs.
+MINOR_TIE = {(0, 1): 1, (0, 2): 0, (0, 3): 0, (1, 2): 1, (1, 3): 1, (2, 3): 2}
+
+
+def four_pop(aln, P1, P2, P3, P4, min_data, polarize=False, fixed=False):
+    """genomics.py:1585-1643 fourPop with the per-site terms of genomics.py:1409-1563."""
+    g = np.array(aln.groups, dtype=object)
+    rows = [np.where(g == p)[0] for p in (P1, P2, P3, P4)]
+    cnts, ns = zip(*[site_pop_counts(aln, r) for r in rows])
+    tot = cnts[0] + cnts[1] + cnts[2] + cnts[3]
+    biallelic = (tot > 0).sum(axis=1) == 2                                   # :1593
+    enough = np.ones(aln.L, dtype=bool)
+    for k in range(4):
+        enough &= (ns[k] * 1. / len(rows[k]) >= min_data)                    # :1595-1598
+    good = np.where(biallelic & enough)[0]
+    if len(good) < 1:
+        out = {k: np.nan for k in FOURPOP_STATS}
+        out["sitesUsed"] = 0
+        return out
+    with np.errstate(divide="ignore", invalid="ignore"):
+        freqs = [1. * cnts[k][good] / ns[k][good][:, None] for k in range(4)]
+    totg = tot[good]
+    if polarize:
+        ai = np.where((totg > 0) & (freqs[3] == 0))                          # :1610
+    elif fixed:
+        ai = np.where((totg > 0) & (freqs[3] == 0) & ((freqs[0] == 0) | (freqs[0] == 1)) &
+                      ((freqs[1] == 0) | (freqs[1] == 1)) & ((freqs[2] == 0) | (freqs[2] == 1)))   # :1611-1614
+    else:
+        pick = np.zeros(len(good), dtype=np.int64)                            # :1615, second largest of four
+        for r in range(len(good)):
+            i, j = np.where(totg[r] > 0)[0]
+            pick[r] = i if totg[r, i] < totg[r, j] else j if totg[r, j] < totg[r, i] else MINOR_TIE[(i, j)]
+        ai = (np.arange(len(good)), pick)
+    p1, p2, p3, p4 = (f[ai[0], ai[1]] for f in freqs)
+
+    def f4(a, b, c, d):
+        return (1 - a) * b * c * (1 - d) - a * (1 - b) * c * (1 - d)
+
+    def f4c(a, b, c, d):
+        return f4(a, b, c, d) + f4(1 - a, 1 - b, 1 - c, 1 - d)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        abba_t = (1 - p1) * p2 * p3 * (1 - p4)
+        baba_t = p1 * (1 - p2) * p3 * (1 - p4)
+        pd = p2 * (p2 > p3) + p3 * (p3 >= p2)
+        a, b, x = (p3 > p1), (p3 > p2), (p1 > p2)
+        y = ~x
+        pdm1 = p3 * (x & a) + p1 * (~(x & a))
+        pdm2 = p3 * (y & b) + p2 * (~(y & b))
+        pdm3 = -p3 * (x & a) + p3 * (y & b) - p1 * (x & ~a) + p2 * (y & ~b)
+        num, numc = f4(p1, p2, p3, p4).sum(), f4c(p1, p2, p3, p4).sum()
+        h4 = [f4c(p1, p3, p3, p4), f4c(p4, p2, p3, p4), f4c(p3, p2, p3, p4), f4c(p1, p4, p3, p4)]
+        h8 = h4 + [f4c(p1, p2, p2, p4), f4c(p1, p2, p3, p1), f4c(p1, p2, p1, p4), f4c(p1, p2, p3, p2)]
+        t1, t2 = np.abs(p1 - p2), np.abs(p3 - p4)
+        out = {
+            "D": num * 1. / (abba_t + baba_t).sum(),
+            "fd": num * 1. / f4(p1, pd, pd, p4).sum(),
+            "fd'": numc * 1. / f4c(p1, pd, pd, p4).sum(),
+            "fdm": num * 1. / f4(pdm1, pdm2, pdm3, p4).sum(),
+            "fdm'": numc * 1. / f4c(pdm1, pdm2, pdm3, p4).sum(),
+            "fdh": numc * 1. / (np.amax(h4, axis=0).sum() if len(p1) else np.float64(0)),
+            "fdh2": numc * 1. / (np.amax(h8, axis=0).sum() if len(p1) else np.float64(0)),
+            "fh": numc * 1. / ((t1 * (t1 > t2) + t2 * (t2 >= t1)) ** 2).sum(),
+            "ABBA": abba_t.sum(), "BABA": baba_t.sum(),
+            "ABAA": ((1 - p1) * p2 * (1 - p3) * (1 - p4)).sum(), "BAAA": (p1 * (1 - p2) * (1 - p3) * (1 - p4)).sum(),
+            "sitesUsed": len(ai[0]),
+        }
+    return out
+
+
 def tajima_d(n, S, theta_pi):
     """genomics.py:619-632."""
     a = sum(1. / i for i in range(1, n))
@@ -621,6 +694,42 @@ def abbababa_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=
             if used >= min_sites:
                 good = True
                 vals = [round(np.float64(sd[s]), 4) for s in ("ABBA", "BABA", "D", "fd", "fdM")]
+        row = ([w.ID] if add_id else []) + [w.scaffold, w.start, w.end, w.mid(), n_sites, used] + vals
+        if good or write_failed:
+            lines.append(",".join(_fmt(x) for x in row))
+    return "\n".join(lines) + "\n"
+
+
+def fourpop_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=1, min_data=0.01,
+                        wind_type="coordinate", overlap=0, max_dist=float("inf"), coords=None,
+                        add_id=False, write_failed=False, include=None, exclude=None, polarize=False, fixed=False):
+    """fourPopWindows.py:28-55 (wrapper) + 238-243 (header).  pops4: [(name,[samples])]*4 = P1,P2,P3,O."""
+    with open_text(geno_path) as fh:
+        file_names, sites = read_sites(fh)
+    if not min_sites:
+        min_sites = wind_size
+    ind_names = []
+    for _, members in pops4:
+        for m in members:
+            if m not in ind_names:
+                ind_names.append(m)
+    pop_of = {nm: [p for p, mem in pops4 if nm in mem][0] for nm in ind_names}
+    ploidy_of = {nm: (1 if fmt == "haplo" else 2) for nm in ind_names}
+    names4 = [p[0] for p in pops4]
+    lines = [("windowID," if add_id else "") + "scaffold,start,end,mid,sites,sitesUsed," + ",".join(FOURPOP_STATS)]
+    wins = make_windows(sites, wind_type, wind_size, step, overlap, max_dist, min_sites, coords, include, exclude)
+    for w in wins:
+        n_sites = len(w.positions)
+        used = np.nan
+        good = False
+        vals = [np.nan] * len(FOURPOP_STATS)
+        if n_sites >= min_sites:
+            aln = window_to_aln(w, file_names, ind_names, pop_of, ploidy_of, fmt)
+            sd = four_pop(aln, names4[0], names4[1], names4[2], names4[3], min_data, polarize, fixed)
+            used = sd["sitesUsed"]
+            if used >= min_sites:
+                good = True
+                vals = [round(np.float64(sd[s]), 4) for s in FOURPOP_STATS]
         row = ([w.ID] if add_id else []) + [w.scaffold, w.start, w.end, w.mid(), n_sites, used] + vals
         if good or write_failed:
             lines.append(",".join(_fmt(x) for x in row))

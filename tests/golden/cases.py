@@ -88,6 +88,18 @@ CASES = [
          argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "400", "--overlap", "100", "-m", "50"] + abba_args(16)),
     dict(name="abba_windows_diplo", tool="ABBABABAwindows.py", fixture="abba_diplo",
          argv=["-g", "{geno}", "-f", "diplo", "-w", "1000", "-m", "20", "--minData", "0.5"] + abba_args(16)),
+    # ---- fourPopWindows.py (the reference needs np.NaN injected by the harness under NumPy 2) ----
+    dict(name="fourpop_minor", tool="fourPopWindows.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--minData", "0.5"] + abba_args(16)),
+    dict(name="fourpop_polarize", tool="fourPopWindows.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--polarize"] + abba_args(16)),
+    dict(name="fourpop_fixed_failed_id", tool="fourPopWindows.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "2000", "-s", "1000", "-m", "8", "--fixed", "--writeFailedWindows", "--addWindowID"] + abba_args(16)),
+    dict(name="fourpop_sites_diplo", tool="fourPopWindows.py", fixture="abba_diplo",
+         argv=["-g", "{geno}", "-f", "diplo", "--windType", "sites", "-w", "400", "--overlap", "100", "-m", "50"] + abba_args(16)),
+    dict(name="fourpop_holes_mindata0", tool="fourPopWindows.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "500", "-m", "5", "--minData", "0", "--writeFailedWindows",
+               "-P1", "a", "s0", "-P2", "b", "s1", "-P3", "c", "s2,s3", "-O", "o", "s4,s5"]),
     # ---- distMat.py ----
     dict(name="holes_distmat_phylip", tool="distMat.py", fixture="holes",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "10", "--windowDataOutFile", "{out}.windows"]),

@@ -86,6 +86,12 @@ def run(tool, argv):
         kw["overlap"] = int(o) if o else 0
         pops4 = _pops(argv, ("-P1", "-P2", "-P3", "-O"))
         return orc.abbababa_windows_csv(geno, fmt, pops4, **kw)
+    if tool == "fourPopWindows.py":
+        kw = _common(argv)
+        o = _take(argv, "--overlap")
+        kw["overlap"] = int(o) if o else 0
+        pops4 = _pops(argv, ("-P1", "-P2", "-P3", "-O"))
+        return orc.fourpop_windows_csv(geno, fmt, pops4, polarize="--polarize" in argv, fixed="--fixed" in argv, **kw)
     if tool == "distMat.py":
         w, s, m = _take(argv, "-w"), _take(argv, "-s"), _take(argv, "-m")
         r = _take(argv, "--roundTo")

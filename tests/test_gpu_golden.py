@@ -14,11 +14,11 @@ from genomics_general_amd import cli
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MAINS = {"popgenWindows.py": cli.popgen_main, "ABBABABAwindows.py": cli.abbababa_main, "distMat.py": cli.distmat_main,
-         "freq.py": cli.freq_main}
+         "freq.py": cli.freq_main, "fourPopWindows.py": cli.fourpop_main}
 
 
 def round_digits(case):
-    if case["tool"] == "ABBABABAwindows.py":
+    if case["tool"] in ("ABBABABAwindows.py", "fourPopWindows.py"):
         return 4
     if "--roundTo" in case["argv"]:
         return int(case["argv"][case["argv"].index("--roundTo") + 1])

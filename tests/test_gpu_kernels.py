@@ -100,6 +100,27 @@ def test_abbababa_sums(min_data, miss):
     e.close()
 
 
+@pytest.mark.parametrize("mode", ["minor", "polarize", "fixed"])
+@pytest.mark.parametrize("n_dip,min_data,miss", [(16, 0.01, 5000), (16, 0.5, 20000), (8, 0.0, 50000), (40, 0.9, 3000)])
+def test_fourpop_sums(mode, n_dip, min_data, miss):
+    """genomics.fourPop: all 12 statistics + sitesUsed in the three allele-choice modes, incl. the argsort tie rule (8 or 16
+    diploids give many 50:50 sites) and 0/0 frequencies under --minData 0"""
+    e, lay, codes, _ = G.make_engine(n_dip, 4, 6000, seed=45 + n_dip, var_thr=45000, miss_thr=miss)
+    wins = [(0, 3000), (3000, 3010), (3010, 6000), (10, 10), (1, 2100)]
+    wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
+    got = wb.fourPop("p0", "p1", "p2", "p3", min_data, polarize=mode == "polarize", fixed=mode == "fixed")
+    for k, (a, b) in enumerate(wins):
+        if b == a:
+            assert got["sitesUsed"][k] == 0
+            continue
+        want = orc.four_pop(oracle_aln(lay, codes, a, b), "p0", "p1", "p2", "p3", min_data, mode == "polarize", mode == "fixed")
+        assert got["sitesUsed"][k] == want["sitesUsed"], (k, got["sitesUsed"][k], want["sitesUsed"])
+        if want["sitesUsed"] > 0:
+            for key in orc.FOURPOP_STATS:
+                assert G.close(got[key][k], want[key]), (key, k, got[key][k], want[key])
+    e.close()
+
+
 def test_group_freq_stats_exact_integers():
     e, lay, codes, _ = G.make_engine(10, 2, 5000, seed=55, miss_thr=400)
     wins = [(0, 2500), (2500, 5000), (17, 18)]
