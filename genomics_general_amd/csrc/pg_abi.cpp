@@ -98,6 +98,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->tasks.release();
     c->tasks2.release();
     c->tasksC.release();
+    c->tasksCh.release();
     c->flag.release();
     c->Cfull.release();
     c->Dfull.release();
@@ -229,8 +230,10 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
     for (size_t k = 0; k + 1 < sstart.size() && c->all_diploid; ++k)
         if (sstart[k + 1] - sstart[k] != 2) c->all_diploid = false;
     std::vector<PgTask2> tasksC;
-    if (c->all_diploid) tasksC = pg_make_tasks2(n_hap / 2, 2, 1);
+    if (c->all_diploid) tasksC = pg_make_tasks2(n_hap / 2, 1, 1);      // k_pairC works on 8-row tasks
     c->n_tasksC = (int)tasksC.size();
+    std::vector<PgTask2> tasksCh = pg_make_tasks2(n_hap, 1, 0);
+    c->n_tasksCh = (int)tasksCh.size();
     int rc;
     if ((rc = c->hap_pop.upload(hap_pop, n_hap, c->stream)) != PG_OK) return rc;
     if ((rc = c->pop_start.upload(pstart.data(), pstart.size(), c->stream)) != PG_OK) return rc;
@@ -238,6 +241,7 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
     if (!tasks.empty() && (rc = c->tasks.upload(tasks.data(), tasks.size(), c->stream)) != PG_OK) return rc;
     if (!tasks2.empty() && (rc = c->tasks2.upload(tasks2.data(), tasks2.size(), c->stream)) != PG_OK) return rc;
     if (!tasksC.empty() && (rc = c->tasksC.upload(tasksC.data(), tasksC.size(), c->stream)) != PG_OK) return rc;
+    if (!tasksCh.empty() && (rc = c->tasksCh.upload(tasksCh.data(), tasksCh.size(), c->stream)) != PG_OK) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     // the resident buffer layout depends on S: drop it
     c->gt.release();
@@ -498,8 +502,8 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     c->cN = n_units;
     c->cshift = dip ? 1 : 0;
     const int64_t mat_bytes = 4ll * N * N + 4ll * n_units * n_units;
-    // scratch bytes per 32-site input word of one slot: called plane + worst-case (all polymorphic) 5 planes
-    const int64_t word_bytes = (int64_t)NP * 4 * 5 + (int64_t)NPv * 4;
+    // scratch bytes per 32-site input word of one slot: called plane + worst-case (all polymorphic) allele planes
+    const int64_t word_bytes = (int64_t)NP * 4 * PG_XV_PLANES + (int64_t)NPv * 4;
     // sub-batch size: at most half the scratch budget per slot, and at least ~8 sub-batches per call so the two
     // streams have something to overlap (but not so small that a sub-batch cannot fill the GPU)
     int64_t total_words_all = 0;
@@ -555,8 +559,9 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         if ((rc = sl.win.upload(h.data(), h.size(), c->stream2)) != PG_OK) return rc;
         const int64_t *d_lo = sl.win.p, *d_hi = sl.win.p + nb, *d_goff = sl.win.p + 2 * (size_t)nb,
                       *d_vgoff = sl.win.p + 3 * (size_t)nb + 1;
-        if ((rc = sl.Vp.ensure((size_t)std::max<int64_t>(va, 1) * NPv * 4)) != PG_OK) return rc;
-        if ((rc = sl.XV.ensure((size_t)std::max<int64_t>(ga, 1) * PG_GROUP * 5 * NP)) != PG_OK) return rc;
+        // + 2 word groups: k_pairC's look-ahead loads read one group past a wave's range
+        if ((rc = sl.Vp.ensure((size_t)(std::max<int64_t>(va, 1) + 2) * NPv * 4)) != PG_OK) return rc;
+        if ((rc = sl.XV.ensure((size_t)std::max<int64_t>(ga, 1) * PG_GROUP * PG_XV_PLANES * NP)) != PG_OK) return rc;
         if ((rc = sl.nw.ensure((size_t)std::max<int64_t>(ga, 1))) != PG_OK) return rc;
         if ((rc = c->Cmat.ensure((size_t)nb * n_units * n_units)) != PG_OK) return rc;
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
@@ -576,7 +581,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         HIPCHK(hipStreamWaitEvent(c->stream, sl.packed, 0));
         if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
         if (dip) pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasksC.p, c->n_tasksC, NPv, n_units, 1, va / nb, c->Cmat.p);
-        else pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasks2.p, c->n_tasks2, NPv, n_units, 0, va / nb, c->Cmat.p);
+        else pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasksCh.p, c->n_tasksCh, NPv, n_units, 0, va / nb, c->Cmat.p);
         if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
         // (running k_pairD beside k_pairC on a third stream was measured: +3 % throughput, but overlapping kernels make the
         // per-kernel timings ambiguous; kept sequential)

@@ -61,6 +61,8 @@ struct pg_ctx {
     int n_tasks2 = 0;
     DevBuf<PgTask2> tasksC;      // v2 k_pairC when its units are diploid individuals (diagonal included)
     int n_tasksC = 0;
+    DevBuf<PgTask2> tasksCh;     // v2 k_pairC on haplotype units (no diagonal)
+    int n_tasksCh = 0;
     bool all_diploid = false;    // every individual owns exactly slots (2k, 2k+1)
     DevBuf<uint32_t> Vp, XY;     // v2 planes (slot 0; also used by nothing else)
     DevBuf<int32_t> nw;          // v2: compacted words per group

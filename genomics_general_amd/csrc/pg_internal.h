@@ -8,6 +8,7 @@
 #define PG_SITES_PER_BLOCK 1024 // sites reduced by one block of the site-statistics kernels
 #define PG_ABBA_NSUM 6
 #define PG_FOURPOP_NSUM 14
+#define PG_XV_PLANES 3        // compacted polymorphic-site planes per word: allele-index bit 0, bit 1, called
 
 struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,row0+8*nsub) x cols [col0,col0+64)
     int32_t row0, nsub, col0, pad;

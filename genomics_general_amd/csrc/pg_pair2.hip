@@ -20,47 +20,82 @@
 typedef __attribute__((address_space(4))) const uint32_t CU32;
 
 // ------------------------------------------------------------------------------------------------------
-// k_pack2.  Thread = 4 haplotype slots; block = all slots of one compaction group (64 input words) of one window.
-//   SWAR transposition: two sites are merged per dword (one-hot nibbles -> one byte), so each allele plane gathers two
-//   site bits per op; after 4 merged pairs a byte holds 8 site bits of one haplotype (bit order inside a word is a fixed
-//   permutation, identical for every haplotype and plane, which is all popcount needs).
+// k_pack2.  Thread = 4 haplotype slots (one dword of a site row); block = all slots of one compaction group (64 input
+// words = 2048 sites) of one window.  Two phases, both on the same raw-buffer descriptor (base = first row of the group,
+// scalar offset = row * S, lane offset = h0: no VALU address arithmetic; rows past the end of the window read as zero):
+//
+//   phase A, every word (32 rows): two rows are merged per dword (one-hot nibbles -> one byte), four merged dwords are
+//     byte-transposed with v_perm_b32 so that a dword holds 8 sites of ONE haplotype; from that (i) the called bit of every
+//     site (nibble != 0) -> called plane Vp, (ii) the OR over all haplotypes -> per-site allele presence nibbles, reduced
+//     over the wave with DPP and over the block through LDS.  A site is polymorphic when its presence nibble has >= 2 bits;
+//     that test and the list bookkeeping run on the scalar unit.
+//   phase B, every 32 polymorphic sites: their rows are loaded again (scalar row offsets read from a lane-resident list;
+//     they were touched a few words ago) and the four allele planes + called plane are transposed the same way and stored
+//     as one dense word of XV.  k_pairD therefore only ever sees polymorphic sites, and the expensive 5-plane
+//     transposition runs on ~10 % of the rows of typical whole-genome data instead of all of them.
+//
+//   The bit order inside a produced word is a fixed permutation of the 32 sites, identical for every haplotype and plane,
+//   which is all the popcounts of k_pairC / k_pairD need.
 //   DIP = 1: every individual is diploid and owns slots (2k,2k+1); the called plane is written per INDIVIDUAL (k_pairC then
 //   works on n_hap/2 units, 4x fewer pairs).  A window in which the two haplotypes of some individual differ in calledness
 //   raises *mismatch; the host then redoes the batch with DIP = 0.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t bgather(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, int k) {
-    return ((a0 >> (8 * k)) & 0xFFu) | (((a1 >> (8 * k)) & 0xFFu) << 8) | (((a2 >> (8 * k)) & 0xFFu) << 16) |
-           (((a3 >> (8 * k)) & 0xFFu) << 24);
+// 4x4 byte transpose: r[k] = { t0.byte k, t1.byte k, t2.byte k, t3.byte k }
+__device__ __forceinline__ void btrans4(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t r[4]) {
+    const uint32_t lo01 = __builtin_amdgcn_perm(t1, t0, 0x05010400u), hi01 = __builtin_amdgcn_perm(t1, t0, 0x07030602u);
+    const uint32_t lo23 = __builtin_amdgcn_perm(t3, t2, 0x05010400u), hi23 = __builtin_amdgcn_perm(t3, t2, 0x07030602u);
+    r[0] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+    r[1] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+    r[2] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+    r[3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
 }
 
-// 32 sites x 4 haplotypes -> x[a][k] (allele plane a of haplotype k); sites >= ns are zero bits.
-// The 32 loads are raw buffer loads: descriptor base = the word's first site row (wave-uniform, SGPRs), scalar offset =
-// row * S, lane offset = h0 -> no VALU address arithmetic at all (a flat load needs a 64-bit add per load).  The descriptor's
-// size is ns rows, so rows past the end of a window read as zero without a select.
-__device__ __forceinline__ void load_word(const int8_t *__restrict__ rows, int h0, int S, int ns, uint32_t x[4][4]) {
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(rows), 0, ns * S, 0x00020000);
-    uint32_t acc[4][4];
+// Phase A for one word: v[k] = called bits of haplotype h0+k (site q*8+j at bit 4j+q), pq[q] = this lane's presence nibbles
+// of sites q*8..q*8+7 (site q*8+j in nibble j).
+__device__ __forceinline__ void word_called_presence(__amdgpu_buffer_rsrc_t rsrc, int h0, int S, int row0, uint32_t v[4],
+                                                     uint32_t pq[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         uint32_t d[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) d[s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, h0, (q * 8 + s) * S, 0);
-        uint32_t a0 = 0u, a1 = 0u, a2 = 0u, a3 = 0u;
+        for (int s = 0; s < 8; ++s) d[s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, h0, (row0 + q * 8 + s) * S, 0);
+        uint32_t r[4];
+        btrans4(d[0] | (d[1] << 4), d[2] | (d[3] << 4), d[4] | (d[5] << 4), d[6] | (d[7] << 4), r);
+        pq[q] = r[0] | r[1] | r[2] | r[3];
 #pragma unroll
-        for (int pr = 0; pr < 4; ++pr) {
-            const uint32_t t = d[2 * pr] | (d[2 * pr + 1] << 4);
-            a0 = (a0 << 1) | (t & 0x11111111u);
-            a1 = (a1 << 1) | ((t >> 1) & 0x11111111u);
-            a2 = (a2 << 1) | ((t >> 2) & 0x11111111u);
-            a3 = (a3 << 1) | ((t >> 3) & 0x11111111u);
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = r[k] | (r[k] >> 1);
+            const uint32_t c = (u | (u >> 2)) & 0x11111111u;
+            v[k] = q ? (v[k] | (c << q)) : c;
         }
-        acc[0][q] = a0; acc[1][q] = a1; acc[2][q] = a2; acc[3][q] = a3;
     }
+}
+
+// Phase B: lane i of vlist holds the group-relative row of list entry i (entries past the end hold a row beyond the
+// descriptor and read as zero).  x[p][k], p = 0,1: bit p of the allele index (one-hot nibble A,C,G,T = 1,2,4,8 -> index 0..3),
+// p = 2: called, of haplotype h0+k over the 32 listed sites.
+__device__ __forceinline__ void poly_word(__amdgpu_buffer_rsrc_t rsrc, int h0, int S, uint32_t vlist, uint32_t x[PG_XV_PLANES][4]) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int q = 0; q < 4; ++q) {
+        uint32_t d[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[p][k] = bgather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], k);
+        for (int s = 0; s < 8; ++s) {
+            const int row = __builtin_amdgcn_readlane((int)vlist, q * 8 + s);
+            d[s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, h0, row * S, 0);
+        }
+        uint32_t r[4];
+        btrans4(d[0] | (d[1] << 4), d[2] | (d[3] << 4), d[4] | (d[5] << 4), d[6] | (d[7] << 4), r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t n1 = r[k] >> 1, n2 = r[k] >> 2, n3 = r[k] >> 3;
+            const uint32_t b0 = (n1 | n3) & 0x11111111u;                 // C or T
+            const uint32_t b1 = (n2 | n3) & 0x11111111u;                 // G or T
+            const uint32_t cv = (r[k] | n1 | n2 | n3) & 0x11111111u;     // any allele
+            x[0][k] = q ? (x[0][k] | (b0 << q)) : b0;
+            x[1][k] = q ? (x[1][k] | (b1 << q)) : b1;
+            x[2][k] = q ? (x[2][k] | (cv << q)) : cv;
+        }
+    }
 }
 
 // OR over the 64 lanes of a wave with DPP row shifts / broadcasts (six VALU ops, no LDS traffic); the total ends in lane 63.
@@ -76,10 +111,21 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-#define PG_DENSE_BITS 14      // a word with at least this many polymorphic sites is emitted whole instead of bit by bit
+// presence nibbles of 8 sites (uniform) -> 8-bit mask of the sites whose nibble has at least two bits set (scalar unit)
+__device__ __forceinline__ uint32_t poly_mask8(uint32_t x) {
+    uint32_t e = (x & (x >> 1) & 0x77777777u) | (x & (x >> 2) & 0x33333333u) | (x & (x >> 3) & 0x11111111u);
+    e = (e | (e >> 1) | (e >> 2)) & 0x11111111u;
+    e = (e | (e >> 3)) & 0x03030303u;
+    e = (e | (e >> 6)) & 0x000F000Fu;
+    return (e | (e >> 12)) & 0xFFu;
+}
 
-// More than 1024 haplotype slots do not fit one block: k_presence (same loads and transposition, grid.z = blocks of 1024 slots)
-// first ORs the per-site allele-presence words of all slot blocks into pres[word][4]; k_pack2<.,.,PRES=1> then reads them.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t group_rsrc(const int8_t *gt, int S, int64_t first_row, int nrows) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(gt + first_row * (int64_t)S), 0, nrows * S, 0x00020000);
+}
+
+// More than 1024 haplotype slots do not fit one block: k_presence (phase A only, grid.z = blocks of 1024 slots) first ORs the
+// presence nibbles of all slot blocks into pres[word][4]; k_pack2<.,.,PRES=1> then reads them.
 __global__ __launch_bounds__(256) void k_presence(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
                                                   const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
                                                   uint32_t *__restrict__ pres) {
@@ -90,22 +136,17 @@ __global__ __launch_bounds__(256) void k_presence(const int8_t *__restrict__ gt,
     if (w_begin >= W) return;
     const int w_end = (w_begin + PG_GROUP < W) ? w_begin + PG_GROUP : W;
     const int h0 = 4 * (blockIdx.z * 256 + threadIdx.x);
+    const int64_t first = lo + 32ll * w_begin;
+    const int nrows = (int)((hi - first) < 32ll * PG_GROUP ? (hi - first) : 32ll * PG_GROUP);
+    const __amdgpu_buffer_rsrc_t rsrc = group_rsrc(gt, S, first, nrows);
     uint32_t *dst = pres + (size_t)(goff[b] + g) * PG_GROUP * 4u;
     for (int w = w_begin; w < w_end; ++w) {
-        uint32_t x[4][4];
+        uint32_t v[4], pq[4] = {0u, 0u, 0u, 0u};
+        if (h0 < S) word_called_presence(rsrc, h0, S, (w - w_begin) * 32, v, pq);
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[p][k] = 0u;
-        if (h0 < S) {
-            const int64_t s0 = lo + 32ll * w;
-            const int ns = (int)((hi - s0) < 32 ? (hi - s0) : 32);
-            load_word(gt + s0 * (int64_t)S, h0, S, ns, x);
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const uint32_t pr = wave_or(x[p][0] | x[p][1] | x[p][2] | x[p][3]);
-            if ((threadIdx.x & 63) == 0 && pr) atomicOr(&dst[(size_t)(w - w_begin) * 4u + p], pr);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t pr = wave_or(pq[q]);
+            if ((threadIdx.x & 63) == 0 && pr) atomicOr(&dst[(size_t)(w - w_begin) * 4u + q], pr);
         }
     }
 }
@@ -125,121 +166,85 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
     if (w_begin >= W) return;
     const int w_end = (w_begin + PG_GROUP < W) ? w_begin + PG_GROUP : W;
     const int t = blockIdx.z * TPB + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int h0 = 4 * t;
     const bool has_data = h0 < S;            // pad threads (h0 >= S) still write zero planes up to NP
     const bool in_np = h0 < NP;
     const int u0 = DIP ? 2 * t : h0;         // first unit of the called plane owned by this thread
     const bool in_npv = u0 < NPv;
-    uint32_t out[5][4];
-#pragma unroll
-    for (int p = 0; p < 5; ++p)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[p][k] = 0u;
+    const int64_t first = lo + 32ll * w_begin;
+    const int nrows = (int)((hi - first) < 32ll * PG_GROUP ? (hi - first) : 32ll * PG_GROUP);
+    const __amdgpu_buffer_rsrc_t rsrc = group_rsrc(gt, S, first, nrows);
+    uint32_t vlist = (uint32_t)nrows;        // lane i = list entry i; "nrows" is one row past the descriptor: reads as zero
     int cnt = 0, nflush = 0, parity = 0;
     uint32_t bad = 0u;
-    uint32_t *xv_base = XV + (size_t)(goff[b] + g) * PG_GROUP * 5u * (size_t)NP;
+    uint32_t *xv_base = XV + (size_t)(goff[b] + g) * PG_GROUP * PG_XV_PLANES * (size_t)NP;
     const int64_t vg_base = vgoff[b] + (int64_t)(w_begin >> 2);
+    auto flush = [&]() {                     // the first 32 list entries become one dense word of XV
+        if (in_np) {
+            uint32_t x[PG_XV_PLANES][4];
+#pragma unroll
+            for (int p = 0; p < PG_XV_PLANES; ++p)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[p][k] = 0u;
+            if (has_data) poly_word(rsrc, h0, S, vlist, x);
+            uint32_t *o = xv_base + (size_t)nflush * PG_XV_PLANES * (size_t)NP + h0;
+#pragma unroll
+            for (int p = 0; p < PG_XV_PLANES; ++p)
+                *reinterpret_cast<uint4 *>(o + (size_t)p * NP) = make_uint4(x[p][0], x[p][1], x[p][2], x[p][3]);
+        }
+        ++nflush;
+    };
     for (int wq = 0; 4 * wq + w_begin < w_end; ++wq) {
         uint32_t vhold[4][4];
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const int w = w_begin + 4 * wq + k4;
-            uint32_t x[4][4], v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = 0u;
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[p][k] = 0u;
+            uint32_t v[4] = {0u, 0u, 0u, 0u}, pq[4] = {0u, 0u, 0u, 0u};
             const bool live = w < w_end;            // block-uniform
-            if (live && has_data) {
-                const int64_t s0 = lo + 32ll * w;
-                const int ns = (int)((hi - s0) < 32 ? (hi - s0) : 32);
-                load_word(gt + s0 * (int64_t)S, h0, S, ns, x);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = x[0][k] | x[1][k] | x[2][k] | x[3][k];
-            }
+            if (live && has_data) word_called_presence(rsrc, h0, S, (w - w_begin) * 32, v, pq);
 #pragma unroll
             for (int k = 0; k < 4; ++k) vhold[k][k4] = v[k];
             if (DIP) bad |= (v[0] ^ v[1]) | (v[2] ^ v[3]);
             if (live) {
-                // alleles present among called haplotypes, per site, across the whole block
+                // allele presence nibbles per site across the whole block (uniform)
                 uint32_t pr[4];
                 if (PRES) {
                     const uint32_t *src = pres + ((size_t)(goff[b] + g) * PG_GROUP + (size_t)(w - w_begin)) * 4u;
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) pr[p] = src[p];
+                    for (int q = 0; q < 4; ++q) pr[q] = __builtin_amdgcn_readfirstlane(src[q]);
                 } else {
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) pr[p] = wave_or(x[p][0] | x[p][1] | x[p][2] | x[p][3]);
+                    for (int q = 0; q < 4; ++q) pr[q] = wave_or(pq[q]);
                 }
                 if (!PRES && NWAVE > 1) {
-                    if ((t & 63) == 0) {
+                    if (lane == 0) {
 #pragma unroll
-                        for (int p = 0; p < 4; ++p) sh_pres[parity][t >> 6][p] = pr[p];
+                        for (int q = 0; q < 4; ++q) sh_pres[parity][threadIdx.x >> 6][q] = pr[q];
                     }
                     __syncthreads();
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
+                    for (int q = 0; q < 4; ++q) {
                         uint32_t a = 0u;
 #pragma unroll
-                        for (int wv = 0; wv < NWAVE; ++wv) a |= sh_pres[parity][wv][p];
-                        pr[p] = a;
+                        for (int wv = 0; wv < NWAVE; ++wv) a |= sh_pres[parity][wv][q];
+                        pr[q] = __builtin_amdgcn_readfirstlane(a);
                     }
                     parity ^= 1;
                 }
-                uint32_t m = (pr[0] & pr[1]) | (pr[0] & pr[2]) | (pr[0] & pr[3]) | (pr[1] & pr[2]) | (pr[1] & pr[3]) | (pr[2] & pr[3]);
-                m = __builtin_amdgcn_readfirstlane(m);
-                const bool dense = __builtin_popcount(m) >= PG_DENSE_BITS;
-                if (dense) {
-                    // flush the partial word, then emit this word verbatim (monomorphic sites add nothing to D)
-                    if (cnt) {
-                        if (in_np) {
-                            uint32_t *o = xv_base + (size_t)nflush * 5u * (size_t)NP + h0;
-#pragma unroll
-                            for (int p = 0; p < 5; ++p)
-                                *reinterpret_cast<uint4 *>(o + (size_t)p * NP) = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
-                        }
-#pragma unroll
-                        for (int p = 0; p < 5; ++p)
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) out[p][k] = 0u;
-                        cnt = 0;
-                        ++nflush;
-                    }
-                    if (in_np) {
-                        uint32_t *o = xv_base + (size_t)nflush * 5u * (size_t)NP + h0;
-#pragma unroll
-                        for (int p = 0; p < 4; ++p)
-                            *reinterpret_cast<uint4 *>(o + (size_t)p * NP) = make_uint4(x[p][0], x[p][1], x[p][2], x[p][3]);
-                        *reinterpret_cast<uint4 *>(o + (size_t)4 * NP) = make_uint4(v[0], v[1], v[2], v[3]);
-                    }
-                    ++nflush;
-                    m = 0u;
-                }
-                while (m) {
+                uint32_t m = poly_mask8(pr[0]) | (poly_mask8(pr[1]) << 8) | (poly_mask8(pr[2]) << 16) | (poly_mask8(pr[3]) << 24);
+                const int row_w = (w - w_begin) * 32;
+                while (m) {                          // scalar loop: append the word's polymorphic rows to the list
                     const int bit = __builtin_ctz(m);
                     m &= m - 1u;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) out[p][k] = (out[p][k] << 1) | ((x[p][k] >> bit) & 1u);
-                        out[4][k] = (out[4][k] << 1) | ((v[k] >> bit) & 1u);
-                    }
-                    if (++cnt == 32) {
-                        if (in_np) {
-                            uint32_t *o = xv_base + (size_t)nflush * 5u * (size_t)NP + h0;
-#pragma unroll
-                            for (int p = 0; p < 5; ++p)
-                                *reinterpret_cast<uint4 *>(o + (size_t)p * NP) = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
-                        }
-#pragma unroll
-                        for (int p = 0; p < 5; ++p)
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) out[p][k] = 0u;
-                        cnt = 0;
-                        ++nflush;
-                    }
+                    vlist = lane == cnt ? (uint32_t)(row_w + bit) : vlist;
+                    ++cnt;
+                }
+                if (cnt >= 32) {
+                    flush();
+                    const uint32_t up = (uint32_t)__shfl((int)vlist, (lane + 32) & 63, 64);
+                    vlist = lane < 32 ? up : (uint32_t)nrows;
+                    cnt -= 32;
                 }
             }
         }
@@ -256,15 +261,7 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
             }
         }
     }
-    if (cnt) {
-        if (in_np) {
-            uint32_t *o = xv_base + (size_t)nflush * 5u * (size_t)NP + h0;
-#pragma unroll
-            for (int p = 0; p < 5; ++p)
-                *reinterpret_cast<uint4 *>(o + (size_t)p * NP) = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
-        }
-        ++nflush;
-    }
+    if (cnt) flush();
     if (t == 0) nw[goff[b] + g] = nflush;
     if (DIP && bad) atomicOr(mismatch, 1);
 }
@@ -306,26 +303,40 @@ struct PairCtx {
     int win, row0, nsub, col0, lower, lane, ks;
 };
 
-// ksplit > 1: the word range of a window is cut into ksplit parts handled by different waves (more waves in flight
-// when there are few windows); partial counts are then combined with integer atomics (exact, order independent).
-__device__ __forceinline__ bool pair_decode(const PgTask2 *__restrict__ tasks, int n_tasks, int tasks_wg, int ksplit, int n_win,
-                                            PairCtx &c) {
+// A block of 4 waves owns one task (8*nsub rows x 64 columns of one window); each wave takes a quarter of the word range
+// and the four partial results meet in LDS (block_reduce), so the common case needs neither atomics nor a zeroed matrix.
+// kso > 1 additionally cuts the word range across blocks (more waves in flight when there are few windows x tasks); those
+// partial counts are combined with integer atomics (exact, order independent).
+__device__ __forceinline__ bool pair_decode(const PgTask2 *__restrict__ tasks, int n_tasks, int kso, int n_win, PairCtx &c) {
     const int xcd = blockIdx.x & 7;
     const int v = blockIdx.x >> 3;
-    const int per_win = tasks_wg * ksplit;
+    const int per_win = n_tasks * kso;
     c.win = (v / per_win) * 8 + xcd;
-    if (c.win >= n_win) return false;
+    if (c.win >= n_win) return false;                  // block-uniform
     const int rem = v % per_win;
-    c.ks = rem / tasks_wg;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.ks = (rem / n_tasks) * 4 + wave;                 // this wave's part of the 4*kso parts of the word range
     c.lane = threadIdx.x & 63;
-    const int t = (rem % tasks_wg) * 4 + wave;
-    if (t >= n_tasks) return false;
-    const PgTask2 tk = tasks[t];
+    const PgTask2 tk = tasks[rem % n_tasks];
     c.row0 = __builtin_amdgcn_readfirstlane(tk.row0);
     c.nsub = __builtin_amdgcn_readfirstlane(tk.nsub);
     c.col0 = __builtin_amdgcn_readfirstlane(tk.col0);
     c.lower = __builtin_amdgcn_readfirstlane(tk.lower);
+    return true;
+}
+
+// sum of the four waves' acc[] into wave 0 (returns true there)
+template <int R>
+__device__ __forceinline__ bool block_reduce(uint32_t (&acc)[R], uint32_t (*red)[64], int lane) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) red[(wave - 1) * R + r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave) return false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] += red[r][lane] + red[R + r][lane] + red[2 * R + r][lane];
     return true;
 }
 
@@ -349,114 +360,140 @@ __device__ __forceinline__ void pair_store(const uint32_t (&acc)[R], int row0, i
 // ------------------------------------------------------------------------------------------------------
 // k_pairC: units x units "both called" counts.  Wave = 8*NSUB rows (SGPR operands) x 64 columns, 4 words per iteration.
 // ------------------------------------------------------------------------------------------------------
-template <int NSUB>
+// popcount with accumulate in ONE VALU op (v_bcnt_u32_b32 d = popcount(s0) + s1); the compiler otherwise reassociates a row's
+// four popcounts into bcnt + v_add3 (2.5 ops per word instead of 2).
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+// The inner loop is hand-scheduled assembly (pg_pairc_loop.inc, generated by gen_pairc_asm.py): 8 rows x 4 words of row
+// operands live in SGPRs, ping-ponged between two sets so that the s_load_dwordx16 pair and the column's
+// global_load_dwordx4 of word group g+1 complete under the 64 VALU ops (v_and + accumulating v_bcnt) of group g.  The
+// look-ahead reads one word group past the wave's range: the called plane is allocated with padding.
+#include "pg_pairc_loop.inc"
+
 __device__ __forceinline__ void pairC_body(const uint32_t *__restrict__ Vp, int64_t vg0, int nwq, int NPv, const PairCtx &c,
-                                           int n_units, int diag, int atomic, int32_t *__restrict__ Cw) {
-    constexpr int R = 8 * NSUB;
-    uint32_t acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0u;
+                                           uint32_t (&acc)[8]) {
     const int j = c.col0 + c.lane;
-    const uint32_t *base = Vp + (size_t)vg0 * NPv * 4u;
-    for (int wq = 0; wq < nwq; ++wq) {
-        const uint32_t *pw = base + (size_t)wq * NPv * 4u;
-        const uint4 jv = *reinterpret_cast<const uint4 *>(pw + (size_t)j * 4u);
-        const CU32 *pr = (const CU32 *)(pw + (size_t)c.row0 * 4u);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            acc[r] += __popc(pr[4 * r + 0] & jv.x);
-            acc[r] += __popc(pr[4 * r + 1] & jv.y);
-            acc[r] += __popc(pr[4 * r + 2] & jv.z);
-            acc[r] += __popc(pr[4 * r + 3] & jv.w);
-        }
+    const uint32_t stride = (uint32_t)NPv * 16u;                       // bytes per word group
+    // 32-bit byte offsets inside the asm loop: at most PG_PAIRC_CHUNK word groups per call (NPv <= 4096 -> < 4 GiB)
+    constexpr int PG_PAIRC_CHUNK = 32768;
+    for (int q0 = 0; q0 < nwq; q0 += PG_PAIRC_CHUNK) {
+        const int nq = (nwq - q0 < PG_PAIRC_CHUNK) ? nwq - q0 : PG_PAIRC_CHUNK;
+        const uint32_t *base = Vp + (size_t)(vg0 + q0) * NPv * 4u;
+        const uint64_t b64 = (uint64_t)base;
+        const uint64_t ubase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
+        uint32_t soff = (uint32_t)c.row0 * 16u, voff = (uint32_t)j * 16u;
+        uint32_t npairs = (uint32_t)__builtin_amdgcn_readfirstlane(nq >> 1), odd = (uint32_t)__builtin_amdgcn_readfirstlane(nq & 1);
+        asm volatile(PG_PAIRC_LOOP_ASM
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                       "+v"(acc[7]), "+s"(soff), "+v"(voff), "+s"(npairs)
+                     : "s"(ubase), "s"(stride), "s"(odd)
+                     : PG_PAIRC_LOOP_CLOBBERS);
     }
-    pair_store<R>(acc, c.row0, j, n_units, c.lower, diag, atomic, Cw);
 }
 
 __global__ __launch_bounds__(256) void k_pairC(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vgoff, int n_win,
-                                               const PgTask2 *__restrict__ tasks, int n_tasks, int tasks_wg, int ksplit, int NPv,
-                                               int n_units, int diag, int32_t *__restrict__ Cmat) {
+                                               const PgTask2 *__restrict__ tasks, int n_tasks, int kso, int NPv, int n_units,
+                                               int diag, int32_t *__restrict__ Cmat) {
+    __shared__ uint32_t red[3 * 8][64];
     PairCtx c;
-    if (!pair_decode(tasks, n_tasks, tasks_wg, ksplit, n_win, c)) return;
+    if (!pair_decode(tasks, n_tasks, kso, n_win, c)) return;
     const int64_t vg_all = vgoff[c.win];
     const int nwq_all = (int)(vgoff[c.win + 1] - vg_all);
-    const int q0 = (int)((long long)nwq_all * c.ks / ksplit), q1 = (int)((long long)nwq_all * (c.ks + 1) / ksplit);
-    int32_t *Cw = Cmat + (size_t)c.win * n_units * n_units;
-    if (c.nsub == 1) pairC_body<1>(Vp, vg_all + q0, q1 - q0, NPv, c, n_units, diag, ksplit > 1, Cw);
-    else pairC_body<2>(Vp, vg_all + q0, q1 - q0, NPv, c, n_units, diag, ksplit > 1, Cw);
+    const int parts = 4 * kso;
+    const int q0 = (int)((long long)nwq_all * c.ks / parts), q1 = (int)((long long)nwq_all * (c.ks + 1) / parts);
+    uint32_t acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0u;
+    if (q1 > q0) pairC_body(Vp, vg_all + q0, q1 - q0, NPv, c, acc);       // tasks of k_pairC have nsub == 1
+    if (block_reduce<8>(acc, red, c.lane))
+        pair_store<8>(acc, c.row0, c.col0 + c.lane, n_units, c.lower, diag, kso > 1, Cmat + (size_t)c.win * n_units * n_units);
 }
 
-// waves wanted in flight: 256 CUs x 4 SIMDs x 8
-static int pick_ksplit(int n_win, int n_tasks, int64_t steps_per_wave, int min_steps) {
-    int64_t waves = (int64_t)n_win * n_tasks;
+// extra cut of the word range across blocks: wanted when windows x tasks x 4 waves cannot fill 256 CUs x 4 SIMDs x 8
+static int pick_kso(int n_win, int n_tasks, int64_t steps_per_window, int min_steps) {
+    int64_t waves = (int64_t)n_win * n_tasks * 4;
     int ks = 1;
-    while (ks < 16 && waves * ks < 8192 && steps_per_wave / (ks * 2) >= min_steps) ks *= 2;
+    while (ks < 16 && waves * ks < 8192 && steps_per_window / (ks * 8) >= min_steps) ks *= 2;
     return ks;
 }
 
 void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, const PgTask2 *tasks, int n_tasks,
                      int NPv, int n_units, int diag, int64_t avg_wq, int32_t *Cmat) {
     if (n_win <= 0 || n_tasks <= 0) return;
-    const int tasks_wg = (n_tasks + 3) / 4;
-    const int ks = pick_ksplit(n_win, n_tasks, avg_wq, 24);
-    if (ks > 1) (void)hipMemsetAsync(Cmat, 0, (size_t)n_win * n_units * n_units * 4, st);
-    const int64_t blocks = (int64_t)((n_win + 7) / 8) * tasks_wg * ks * 8;
-    hipLaunchKernelGGL(k_pairC, dim3((unsigned)blocks), dim3(256), 0, st, Vp, vgoff, n_win, tasks, n_tasks, tasks_wg, ks, NPv,
-                       n_units, diag, Cmat);
+    const int kso = pick_kso(n_win, n_tasks, avg_wq, 24);
+    if (kso > 1) (void)hipMemsetAsync(Cmat, 0, (size_t)n_win * n_units * n_units * 4, st);
+    const int64_t blocks = (int64_t)((n_win + 7) / 8) * n_tasks * kso * 8;
+    hipLaunchKernelGGL(k_pairC, dim3((unsigned)blocks), dim3(256), 0, st, Vp, vgoff, n_win, tasks, n_tasks, kso, NPv, n_units,
+                       diag, Cmat);
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_pairD: haplotype x haplotype difference counts over the compacted polymorphic words of a window.
-//   differ & both called == OR_a (X_a,i & Y_a,j) with Y_a,j = called_j & ~X_a,j = V_j ^ X_a,j, formed once per column word.
+// k_pairD: haplotype x haplotype difference counts over the compacted polymorphic words of a window.  Planes per word:
+// b0, b1 = the two bits of the allele index (A,C,G,T = 0..3), v = called.
+//   differ & both called == ((b0_i ^ b0_j) | (b1_i ^ b1_j)) & v_i & v_j   -> v_xor, 2 x v_bitop3, accumulating v_bcnt
 // ------------------------------------------------------------------------------------------------------
 template <int NSUB>
 __device__ __forceinline__ void pairD_body(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw, int64_t g0, int ng,
-                                           int NP, const PairCtx &c, int N, int atomic, int32_t *__restrict__ Dw) {
+                                           int NP, const PairCtx &c, uint32_t (&acc)[8 * NSUB]) {
     constexpr int R = 8 * NSUB;
-    uint32_t acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0u;
     const int j = c.col0 + c.lane;
-    const size_t wstride = (size_t)5 * NP;
+    const size_t wstride = (size_t)PG_XV_PLANES * NP;
     for (int g = 0; g < ng; ++g) {
         const int n = __builtin_amdgcn_readfirstlane(nw[g0 + g]);
         const uint32_t *gb = XV + (size_t)(g0 + g) * PG_GROUP * wstride;
         for (int w = 0; w < n; ++w) {
             const uint32_t *pw = gb + (size_t)w * wstride;
-            const uint32_t jv = pw[(size_t)4 * NP + j];
-            const uint32_t y0 = jv ^ pw[j], y1 = jv ^ pw[(size_t)NP + j], y2 = jv ^ pw[(size_t)2 * NP + j],
-                           y3 = jv ^ pw[(size_t)3 * NP + j];
+            const uint32_t c0 = pw[j], c1 = pw[(size_t)NP + j], cv = pw[(size_t)2 * NP + j];
             const CU32 *pr = (const CU32 *)(pw + c.row0);
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                acc[r] += __popc((pr[r] & y0) | (pr[NP + r] & y1) | (pr[2 * NP + r] & y2) | (pr[3 * NP + r] & y3));
+                acc[r] = bcnt_acc((((pr[r] ^ c0) | (pr[NP + r] ^ c1)) & pr[2 * NP + r]) & cv, acc[r]);
         }
     }
-    pair_store<R>(acc, c.row0, j, N, c.lower, 0, atomic, Dw);
 }
 
 __global__ __launch_bounds__(256) void k_pairD(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw,
                                                const int64_t *__restrict__ goff, int n_win, const PgTask2 *__restrict__ tasks,
-                                               int n_tasks, int tasks_wg, int ksplit, int NP, int N, int32_t *__restrict__ Dmat) {
+                                               int n_tasks, int kso, int NP, int N, int32_t *__restrict__ Dmat) {
+    __shared__ uint32_t red[3 * 16][64];
     PairCtx c;
-    if (!pair_decode(tasks, n_tasks, tasks_wg, ksplit, n_win, c)) return;
+    if (!pair_decode(tasks, n_tasks, kso, n_win, c)) return;
     const int64_t g_all = goff[c.win];
     const int ng_all = (int)(goff[c.win + 1] - g_all);
-    const int a = (int)((long long)ng_all * c.ks / ksplit), b = (int)((long long)ng_all * (c.ks + 1) / ksplit);
+    const int parts = 4 * kso;
+    const int a = (int)((long long)ng_all * c.ks / parts), b = (int)((long long)ng_all * (c.ks + 1) / parts);
     int32_t *Dw = Dmat + (size_t)c.win * N * N;
-    if (c.nsub == 1) pairD_body<1>(XV, nw, g_all + a, b - a, NP, c, N, ksplit > 1, Dw);
-    else pairD_body<2>(XV, nw, g_all + a, b - a, NP, c, N, ksplit > 1, Dw);
+    uint32_t acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0u;
+    if (c.nsub == 1) {                                     // block-uniform
+        uint32_t (&a8)[8] = reinterpret_cast<uint32_t (&)[8]>(acc);
+        pairD_body<1>(XV, nw, g_all + a, b - a, NP, c, a8);
+    } else {
+        pairD_body<2>(XV, nw, g_all + a, b - a, NP, c, acc);
+    }
+    if (block_reduce<16>(acc, red, c.lane)) {
+        if (c.nsub == 1) {
+            uint32_t (&a8)[8] = reinterpret_cast<uint32_t (&)[8]>(acc);
+            pair_store<8>(a8, c.row0, c.col0 + c.lane, N, c.lower, 0, kso > 1, Dw);
+        } else {
+            pair_store<16>(acc, c.row0, c.col0 + c.lane, N, c.lower, 0, kso > 1, Dw);
+        }
+    }
 }
 
 void pg_launch_pairD(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win,
                      const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat) {
     if (n_win <= 0 || n_tasks <= 0) return;
-    const int tasks_wg = (n_tasks + 3) / 4;
-    const int ks = pick_ksplit(n_win, n_tasks, avg_groups, 4);
-    if (ks > 1) (void)hipMemsetAsync(Dmat, 0, (size_t)n_win * N * N * 4, st);
-    const int64_t blocks = (int64_t)((n_win + 7) / 8) * tasks_wg * ks * 8;
-    hipLaunchKernelGGL(k_pairD, dim3((unsigned)blocks), dim3(256), 0, st, XV, nw, goff, n_win, tasks, n_tasks, tasks_wg, ks, NP, N,
-                       Dmat);
+    const int kso = pick_kso(n_win, n_tasks, avg_groups, 1);
+    if (kso > 1) (void)hipMemsetAsync(Dmat, 0, (size_t)n_win * N * N * 4, st);
+    const int64_t blocks = (int64_t)((n_win + 7) / 8) * n_tasks * kso * 8;
+    hipLaunchKernelGGL(k_pairD, dim3((unsigned)blocks), dim3(256), 0, st, XV, nw, goff, n_win, tasks, n_tasks, kso, NP, N, Dmat);
 }
 
 // ------------------------------------------------------------------------------------------------------
