@@ -63,6 +63,7 @@ SIGNATURES = {
     "pg_hap_called": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p]),
     "pg_site_counts": (C.c_int, [_P, C.c_int64, C.c_int64, _i32p]),
     "pg_kernel_time": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pg_kernel_time_select": (C.c_int, [_P, C.c_uint32]),
     "pg_kernel_time_reset": (C.c_int, [_P]),
     "pg_set_scratch_limit": (C.c_int, [_P, C.c_int64]),
     "pg_comm_unique_id": (C.c_int, [C.c_char_p]),

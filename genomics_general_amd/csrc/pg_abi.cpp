@@ -84,6 +84,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
         c->slot[k].Vp.release();
         c->slot[k].XV.release();
         c->slot[k].pres.release();
+        c->slot[k].host.release();
         c->slot[k].nw.release();
         c->slot[k].win.release();
         if (c->slot[k].packed) (void)hipEventDestroy(c->slot[k].packed);
@@ -100,6 +101,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->tasksC.release();
     c->tasksCh.release();
     c->flag.release();
+    c->out_pin.release();
     c->Cfull.release();
     c->Dfull.release();
     c->Vp.release();
@@ -298,6 +300,8 @@ static int event_get(pg_ctx *c, hipEvent_t *e) {
 
 int pg_time_begin(pg_ctx *c, int k, hipEvent_t *e0, hipEvent_t *e1) {
     int rc;
+    *e0 = *e1 = nullptr;
+    if (!((c->time_mask >> k) & 1u)) return PG_OK;
     if ((rc = event_get(c, e0)) != PG_OK) return rc;
     if ((rc = event_get(c, e1)) != PG_OK) return rc;
     HIPCHK(hipEventRecord(*e0, c->stream));
@@ -306,6 +310,7 @@ int pg_time_begin(pg_ctx *c, int k, hipEvent_t *e0, hipEvent_t *e1) {
 }
 
 int pg_time_end(pg_ctx *c, int k, hipEvent_t e0, hipEvent_t e1, int launches) {
+    if (!e0) return PG_OK;
     HIPCHK(hipEventRecord(e1, c->stream));
     c->events[k].push_back(std::make_pair(e0, e1));
     c->acc_launches[k] += launches;
@@ -327,6 +332,12 @@ static int fold_events(pg_ctx *c) {
         }
         c->events[k].clear();
     }
+    return PG_OK;
+}
+
+extern "C" int pg_kernel_time_select(pg_ctx *c, uint32_t mask) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    c->time_mask = mask;
     return PG_OK;
 }
 
@@ -532,15 +543,20 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         const int nb = w1 - w0;
         pg_ctx::Slot &sl = c->slot[bi & 1];
         int rc;
+        // everything in one batch: nothing to overlap, so the pack kernel goes on the same stream as its consumers
+        // (saves the cross-stream event hand-over)
+        const bool single = (w0 == 0 && w1 == n_win);
+        hipStream_t ps = single ? c->stream : c->stream2;
         // the slot's previous occupant (sub-batch bi-2) must be fully consumed before its planes are overwritten, and
         // its staging vector must have been copied before it is rebuilt
         if (sl.used) {
-            HIPCHK(hipStreamWaitEvent(c->stream2, sl.consumed, 0));
+            HIPCHK(hipStreamWaitEvent(ps, sl.consumed, 0));
             HIPCHK(hipEventSynchronize(sl.packed));
         }
         // stage [lo | hi | goff(n+1) | vgoff(n+1)]
-        std::vector<int64_t> &h = sl.host;
-        h.assign(4 * (size_t)nb + 2, 0);
+        if ((rc = sl.host.ensure(4 * (size_t)nb + 2)) != PG_OK) return rc;
+        int64_t *h = sl.host.p;
+        const size_t h_len = 4 * (size_t)nb + 2;
         int64_t ga = 0, va = 0;
         int max_groups = 0;
         for (int k = 0; k < nb; ++k) {
@@ -556,7 +572,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         }
         h[3 * (size_t)nb] = ga;
         h[4 * (size_t)nb + 1] = va;
-        if ((rc = sl.win.upload(h.data(), h.size(), c->stream2)) != PG_OK) return rc;
+        if ((rc = sl.win.upload(h, h_len, ps)) != PG_OK) return rc;
         const int64_t *d_lo = sl.win.p, *d_hi = sl.win.p + nb, *d_goff = sl.win.p + 2 * (size_t)nb,
                       *d_vgoff = sl.win.p + 3 * (size_t)nb + 1;
         // + 2 word groups: k_pairC's look-ahead loads read one group past a wave's range
@@ -567,18 +583,23 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
         hipEvent_t e0, e1;
         // ---- stream2: pack ----
-        if ((rc = event_get(c, &e0)) != PG_OK) return rc;
-        if ((rc = event_get(c, &e1)) != PG_OK) return rc;
-        HIPCHK(hipEventRecord(e0, c->stream2));
+        const bool time_pack = (c->time_mask >> PG_K_PACK) & 1u;
+        if (time_pack) {
+            if ((rc = event_get(c, &e0)) != PG_OK) return rc;
+            if ((rc = event_get(c, &e1)) != PG_OK) return rc;
+            HIPCHK(hipEventRecord(e0, ps));
+        }
         if (NP > 1024 && (rc = sl.pres.ensure((size_t)std::max<int64_t>(ga, 1) * PG_GROUP * 4)) != PG_OK) return rc;
-        pg_launch_pack2(c->stream2, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, ga, sl.Vp.p, NPv, sl.XV.p, NP,
+        pg_launch_pack2(ps, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, ga, sl.Vp.p, NPv, sl.XV.p, NP,
                         sl.nw.p, dip ? 1 : 0, c->flag.p, sl.pres.p);
-        HIPCHK(hipEventRecord(e1, c->stream2));
-        c->events[PG_K_PACK].push_back(std::make_pair(e0, e1));
-        c->acc_launches[PG_K_PACK] += 1;
-        HIPCHK(hipEventRecord(sl.packed, c->stream2));
+        if (time_pack) {
+            HIPCHK(hipEventRecord(e1, ps));
+            c->events[PG_K_PACK].push_back(std::make_pair(e0, e1));
+            c->acc_launches[PG_K_PACK] += 1;
+        }
+        HIPCHK(hipEventRecord(sl.packed, ps));
         // ---- stream: pair kernels + consume ----
-        HIPCHK(hipStreamWaitEvent(c->stream, sl.packed, 0));
+        if (!single) HIPCHK(hipStreamWaitEvent(c->stream, sl.packed, 0));
         if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
         if (dip) pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasksC.p, c->n_tasksC, NPv, n_units, 1, va / nb, c->Cmat.p);
         else pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasksCh.p, c->n_tasksCh, NPv, n_units, 0, va / nb, c->Cmat.p);
@@ -601,18 +622,29 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     return PG_OK;
 }
 
+// The diploid-shortcut flag (raised by k_pack2) is zero whenever no call is in flight: zeroed when allocated and again, on
+// ctx->stream, right after each read; every entry point synchronises ctx->stream before it returns.
+static int flag_ready(pg_ctx *c) {
+    if (c->flag.p) return PG_OK;
+    int rc = c->flag.ensure(1);
+    if (rc != PG_OK) return rc;
+    HIPCHK(hipMemsetAsync(c->flag.p, 0, 4, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
 // Diploid fast path first (called counts per individual); if any window turns out to hold an individual whose two
 // haplotypes differ in calledness (e.g. phased `A|N`), everything is recomputed with per-haplotype called counts.
 template <class F>
 static int pairwise_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, F consume) {
     const bool dip = use_v2(c) && c->all_diploid && getenv("PG_NO_DIP") == nullptr;
     int rc;
-    if ((rc = c->flag.ensure(1)) != PG_OK) return rc;
+    if ((rc = flag_ready(c)) != PG_OK) return rc;
     if (dip) {
-        HIPCHK(hipMemsetAsync(c->flag.p, 0, 4, c->stream2));      // k_pack2 (stream2) raises it
         if ((rc = pairwise_batches(c, lo, hi, n_win, true, consume)) != PG_OK) return rc;
         int32_t flag = 0;
         HIPCHK(hipMemcpyAsync(&flag, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemsetAsync(c->flag.p, 0, 4, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (!flag) return PG_OK;
     }
@@ -679,8 +711,8 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
     const int P = c->n_pops, npairs = P * (P + 1) / 2, ncols = P + (do_pairs ? P * (P - 1) : 0);
     if ((rc = c->res_f64.ensure((size_t)n_win * npairs)) != PG_OK) return rc;
     if ((rc = c->res_i64.ensure((size_t)n_win * npairs)) != PG_OK) return rc;
-    if ((rc = c->stats.ensure((size_t)n_win * ncols)) != PG_OK) return rc;
-    if ((rc = c->flag.ensure(1)) != PG_OK) return rc;
+    if ((rc = c->stats.ensure((size_t)n_win * ncols + 1)) != PG_OK) return rc;
+    if ((rc = flag_ready(c)) != PG_OK) return rc;
     if (c->events[PG_K_PACK].size() > 4096 && (rc = fold_events(c)) != PG_OK) return rc;
     auto consume = [&](int w0, int nb) -> int {
         hipEvent_t e0, e1;
@@ -695,20 +727,24 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
         return PG_OK;
     };
     const bool dip = use_v2(c) && c->all_diploid && getenv("PG_NO_DIP") == nullptr;
-    int32_t flag = 0;
-    if (dip) {
-        HIPCHK(hipMemsetAsync(c->flag.p, 0, 4, c->stream2));
-        if ((rc = pairwise_batches(c, lo, hi, n_win, true, consume)) != PG_OK) return rc;
-        // one synchronisation for both the result table and the diploid-shortcut verdict
-        HIPCHK(hipMemcpyAsync(stats_out, c->stats.p, (size_t)n_win * ncols * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(&flag, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+    const size_t n_out = (size_t)n_win * ncols;
+    if ((rc = c->out_pin.ensure(n_out + 1)) != PG_OK) return rc;
+    // one device-to-host copy (into pinned memory) and one synchronisation per pass: the diploid-shortcut verdict travels
+    // in the slot after the table (k_flag_export also re-arms the flag)
+    auto fetch = [&]() -> int {
+        pg_launch_flag_export(c->stream, c->flag.p, c->stats.p + n_out);
+        HIPCHK(hipMemcpyAsync(c->out_pin.p, c->stats.p, (n_out + 1) * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (!flag) return PG_OK;
+        memcpy(stats_out, c->out_pin.p, n_out * 8);
+        return PG_OK;
+    };
+    if (dip) {
+        if ((rc = pairwise_batches(c, lo, hi, n_win, true, consume)) != PG_OK) return rc;
+        if ((rc = fetch()) != PG_OK) return rc;
+        if (c->out_pin.p[n_out] == 0.0) return PG_OK;
     }
     if ((rc = pairwise_batches(c, lo, hi, n_win, false, consume)) != PG_OK) return rc;
-    HIPCHK(hipMemcpyAsync(stats_out, c->stats.p, (size_t)n_win * ncols * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return PG_OK;
+    return fetch();
 }
 
 extern "C" int pg_indpairdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites,

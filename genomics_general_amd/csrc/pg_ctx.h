@@ -46,6 +46,30 @@ struct DevBuf {
     }
 };
 
+// page-locked host staging (async copies from/to pageable memory go through a runtime bounce buffer and cost ~20 us each)
+template <class T>
+struct HostPin {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return PG_OK;
+        release();
+        if (n < 1024) n = 1024;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return pg_fail(PG_ERR_HIP, "hipHostMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+        }
+        cap = n;
+        return PG_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct pg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -73,7 +97,7 @@ struct pg_ctx {
         DevBuf<uint32_t> Vp, XV, pres;
         DevBuf<int32_t> nw;
         DevBuf<int64_t> win;
-        std::vector<int64_t> host;        // staging of [lo | hi | goff | vgoff], alive until its H2D copy completed
+        HostPin<int64_t> host;            // pinned staging of [lo | hi | goff | vgoff], alive until its H2D copy completed
         hipEvent_t packed = nullptr, consumed = nullptr;
         bool used = false;
     } slot[2];
@@ -92,7 +116,9 @@ struct pg_ctx {
     DevBuf<double> res_f64, part_f64, stats;
     std::vector<hipEvent_t> event_pool;
     DevBuf<int64_t> res_i64, part_i64;
+    HostPin<double> out_pin;     // pinned landing zone of small result tables
     // timing
+    uint32_t time_mask = 0xFFFFFFFFu;   // bit k: kernel family k is bracketed by HIP events (pg_kernel_time_select)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[PG_K_COUNT_];
     double acc_ms[PG_K_COUNT_] = {0, 0, 0, 0, 0, 0};
     int64_t acc_launches[PG_K_COUNT_] = {0, 0, 0, 0, 0, 0};

@@ -14,7 +14,9 @@ struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,r
     int32_t row0, nsub, col0, pad;
 };
 
-#define PG_GROUP 64             // input words (of 32 sites) per compaction group of k_pack2
+#ifndef PG_GROUP
+#define PG_GROUP 64
+#endif             // input words (of 32 sites) per compaction group of k_pack2
 
 struct PgTask2 {                // one wave of k_pairC / k_pairD: rows [row0,row0+8*nsub) x cols [col0,col0+64)
     int32_t row0, nsub, col0, lower;   // lower = 1: remainder rows, the valid pairs are those with col < row
@@ -72,5 +74,6 @@ void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, i
 void pg_launch_pairD(hipStream_t st, const uint32_t *XY, const int32_t *nw, const int64_t *goff, int n_win,
                      const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat);
 
+void pg_launch_flag_export(hipStream_t st, int32_t *flag, double *dst);
 void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts, int n_win, const int32_t *pop_start,
                         int n_pops, double min_data, int do_pairs, double *out);

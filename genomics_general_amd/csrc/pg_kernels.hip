@@ -405,6 +405,16 @@ __global__ __launch_bounds__(256) void k_popstats(const double *__restrict__ sum
     O[n_pops + npo + k] = 1 - pi_s / pi_t;
 }
 
+// the diploid-shortcut verdict as a double next to the result table; re-arms the flag
+__global__ void k_flag_export(int32_t *__restrict__ flag, double *__restrict__ dst) {
+    dst[0] = (double)flag[0];
+    flag[0] = 0;
+}
+
+void pg_launch_flag_export(hipStream_t st, int32_t *flag, double *dst) {
+    hipLaunchKernelGGL(k_flag_export, dim3(1), dim3(1), 0, st, flag, dst);
+}
+
 void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts, int n_win, const int32_t *pop_start,
                         int n_pops, double min_data, int do_pairs, double *out) {
     if (n_win <= 0 || n_pops <= 0) return;

@@ -50,18 +50,44 @@ __device__ __forceinline__ void btrans4(uint32_t t0, uint32_t t1, uint32_t t2, u
     r[3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
 }
 
-// Phase A for one word: v[k] = called bits of haplotype h0+k (site q*8+j at bit 4j+q), pq[q] = this lane's presence nibbles
-// of sites q*8..q*8+7 (site q*8+j in nibble j).
-__device__ __forceinline__ void word_called_presence(__amdgpu_buffer_rsrc_t rsrc, int h0, int S, int row0, uint32_t v[4],
-                                                     uint32_t pq[4]) {
+// The 32 row dwords of a word (issued one word ahead of their use, see k_pack2).  ro[s] = s * S are computed once per kernel
+// and kept in SGPRs; the word's base goes into the lane offset (two VALU adds per word), so the loads need no scalar
+// address arithmetic at all.
+struct RowOff { int v[16]; };
+
+__device__ __forceinline__ RowOff make_row_off(int S) {
+    RowOff ro;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        int t = s * S;
+        asm volatile("" : "+s"(t));          // opaque: stays in an SGPR instead of being rematerialised per load
+        ro.v[s] = t;
+    }
+    return ro;
+}
+
+__device__ __forceinline__ void word_load(__amdgpu_buffer_rsrc_t rsrc, int h0, int S, int row0, const RowOff &ro, uint32_t d[32]) {
+    const int v0 = h0 + row0 * S, v1 = v0 + 16 * S;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) d[s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, v0, ro.v[s], 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) d[16 + s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, v1, ro.v[s], 0);
+}
+
+// Phase A for one word, bit 4j+q of every produced word <-> site q*8+j:
+//   v[k]  = called bits of haplotype h0+k,   pa[a] = sites at which allele a occurs among this lane's four haplotypes.
+__device__ __forceinline__ void word_called_presence(const uint32_t d[32], uint32_t v[4], uint32_t pa[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        uint32_t d[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) d[s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, h0, (row0 + q * 8 + s) * S, 0);
+        const uint32_t *e = d + 8 * q;
         uint32_t r[4];
-        btrans4(d[0] | (d[1] << 4), d[2] | (d[3] << 4), d[4] | (d[5] << 4), d[6] | (d[7] << 4), r);
-        pq[q] = r[0] | r[1] | r[2] | r[3];
+        btrans4(e[0] | (e[1] << 4), e[2] | (e[3] << 4), e[4] | (e[5] << 4), e[6] | (e[7] << 4), r);
+        const uint32_t o = r[0] | r[1] | r[2] | r[3];                    // 8 sites x presence nibble
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const uint32_t piece = (a >= q ? (o >> (a - q)) : (o << (q - a))) & (0x11111111u << q);
+            pa[a] = q ? (pa[a] | piece) : piece;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t u = r[k] | (r[k] >> 1);
@@ -98,26 +124,26 @@ __device__ __forceinline__ void poly_word(__amdgpu_buffer_rsrc_t rsrc, int h0, i
     }
 }
 
-// OR over the 64 lanes of a wave with DPP row shifts / broadcasts (six VALU ops, no LDS traffic); the total ends in lane 63.
-__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
-#define PG_DPP_OR(ctrl, rmask) v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false)
-    PG_DPP_OR(0x111, 0xf);      // row_shr:1
-    PG_DPP_OR(0x112, 0xf);      // row_shr:2
-    PG_DPP_OR(0x114, 0xf);      // row_shr:4
-    PG_DPP_OR(0x118, 0xf);      // row_shr:8   -> lane 15 of each row holds the row total
-    PG_DPP_OR(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
-    PG_DPP_OR(0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
-#undef PG_DPP_OR
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+// OR over the 64 lanes of a wave with DPP row shifts / broadcasts (six VALU ops per value, no LDS traffic); four values go
+// through the steps in lockstep so that no DPP read follows the write of its own operand (no s_nop wait states).
+__device__ __forceinline__ void wave_or4(uint32_t v[4]) {
+#define PG_DPP_OR4(ctrl, rmask)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        v[i] |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[i], ctrl, rmask, 0xf, false)
+    PG_DPP_OR4(0x111, 0xf);      // row_shr:1
+    PG_DPP_OR4(0x112, 0xf);      // row_shr:2
+    PG_DPP_OR4(0x114, 0xf);      // row_shr:4
+    PG_DPP_OR4(0x118, 0xf);      // row_shr:8   -> lane 15 of each row holds the row total
+    PG_DPP_OR4(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    PG_DPP_OR4(0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+#undef PG_DPP_OR4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (uint32_t)__builtin_amdgcn_readlane((int)v[i], 63);
 }
 
-// presence nibbles of 8 sites (uniform) -> 8-bit mask of the sites whose nibble has at least two bits set (scalar unit)
-__device__ __forceinline__ uint32_t poly_mask8(uint32_t x) {
-    uint32_t e = (x & (x >> 1) & 0x77777777u) | (x & (x >> 2) & 0x33333333u) | (x & (x >> 3) & 0x11111111u);
-    e = (e | (e >> 1) | (e >> 2)) & 0x11111111u;
-    e = (e | (e >> 3)) & 0x03030303u;
-    e = (e | (e >> 6)) & 0x000F000Fu;
-    return (e | (e >> 12)) & 0xFFu;
+// sites (bits) at which at least two of the four alleles occur: scalar unit, 7 ops
+__device__ __forceinline__ uint32_t poly_mask(const uint32_t p[4]) {
+    return (p[0] & p[1]) | (p[2] & p[3]) | ((p[0] ^ p[1]) & (p[2] ^ p[3]));
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t group_rsrc(const int8_t *gt, int S, int64_t first_row, int nrows) {
@@ -140,14 +166,18 @@ __global__ __launch_bounds__(256) void k_presence(const int8_t *__restrict__ gt,
     const int nrows = (int)((hi - first) < 32ll * PG_GROUP ? (hi - first) : 32ll * PG_GROUP);
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc(gt, S, first, nrows);
     uint32_t *dst = pres + (size_t)(goff[b] + g) * PG_GROUP * 4u;
+    const RowOff ro = make_row_off(S);
     for (int w = w_begin; w < w_end; ++w) {
-        uint32_t v[4], pq[4] = {0u, 0u, 0u, 0u};
-        if (h0 < S) word_called_presence(rsrc, h0, S, (w - w_begin) * 32, v, pq);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t pr = wave_or(pq[q]);
-            if ((threadIdx.x & 63) == 0 && pr) atomicOr(&dst[(size_t)(w - w_begin) * 4u + q], pr);
+        uint32_t v[4], pa[4] = {0u, 0u, 0u, 0u};
+        if (h0 < S) {
+            uint32_t d[32];
+            word_load(rsrc, h0, S, (w - w_begin) * 32, ro, d);
+            word_called_presence(d, v, pa);
         }
+        wave_or4(pa);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if ((threadIdx.x & 63) == 0 && pa[a]) atomicOr(&dst[(size_t)(w - w_begin) * 4u + a], pa[a]);
     }
 }
 
@@ -195,49 +225,61 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
         }
         ++nflush;
     };
+    // the rows of word w+1 are requested before word w is processed (rows past the group read as zero, so the look-ahead
+    // needs no bounds test); a wave therefore always has 32 row loads in flight
+    uint32_t dn[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) dn[s] = 0u;
+    const RowOff ro = make_row_off(S);
+    if (has_data) word_load(rsrc, h0, S, 0, ro, dn);
     for (int wq = 0; 4 * wq + w_begin < w_end; ++wq) {
         uint32_t vhold[4][4];
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const int w = w_begin + 4 * wq + k4;
-            uint32_t v[4] = {0u, 0u, 0u, 0u}, pq[4] = {0u, 0u, 0u, 0u};
+            uint32_t v[4] = {0u, 0u, 0u, 0u}, pa[4] = {0u, 0u, 0u, 0u};
             const bool live = w < w_end;            // block-uniform
-            if (live && has_data) word_called_presence(rsrc, h0, S, (w - w_begin) * 32, v, pq);
+            uint32_t d[32];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) d[s] = dn[s];
+            if (has_data) word_load(rsrc, h0, S, (w + 1 - w_begin) * 32, ro, dn);
+            if (live && has_data) word_called_presence(d, v, pa);
 #pragma unroll
             for (int k = 0; k < 4; ++k) vhold[k][k4] = v[k];
             if (DIP) bad |= (v[0] ^ v[1]) | (v[2] ^ v[3]);
             if (live) {
-                // allele presence nibbles per site across the whole block (uniform)
+                // sites at which each allele occurs, across the whole block (uniform)
                 uint32_t pr[4];
                 if (PRES) {
                     const uint32_t *src = pres + ((size_t)(goff[b] + g) * PG_GROUP + (size_t)(w - w_begin)) * 4u;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) pr[q] = __builtin_amdgcn_readfirstlane(src[q]);
+                    for (int a = 0; a < 4; ++a) pr[a] = __builtin_amdgcn_readfirstlane(src[a]);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) pr[q] = wave_or(pq[q]);
+                    for (int a = 0; a < 4; ++a) pr[a] = pa[a];
+                    wave_or4(pr);
                 }
                 if (!PRES && NWAVE > 1) {
                     if (lane == 0) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) sh_pres[parity][threadIdx.x >> 6][q] = pr[q];
+                        for (int a = 0; a < 4; ++a) sh_pres[parity][threadIdx.x >> 6][a] = pr[a];
                     }
                     __syncthreads();
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t a = 0u;
+                    for (int a = 0; a < 4; ++a) {
+                        uint32_t x = 0u;
 #pragma unroll
-                        for (int wv = 0; wv < NWAVE; ++wv) a |= sh_pres[parity][wv][q];
-                        pr[q] = __builtin_amdgcn_readfirstlane(a);
+                        for (int wv = 0; wv < NWAVE; ++wv) x |= sh_pres[parity][wv][a];
+                        pr[a] = __builtin_amdgcn_readfirstlane(x);
                     }
                     parity ^= 1;
                 }
-                uint32_t m = poly_mask8(pr[0]) | (poly_mask8(pr[1]) << 8) | (poly_mask8(pr[2]) << 16) | (poly_mask8(pr[3]) << 24);
+                uint32_t m = poly_mask(pr);
                 const int row_w = (w - w_begin) * 32;
                 while (m) {                          // scalar loop: append the word's polymorphic rows to the list
                     const int bit = __builtin_ctz(m);
                     m &= m - 1u;
-                    vlist = lane == cnt ? (uint32_t)(row_w + bit) : vlist;
+                    vlist = lane == cnt ? (uint32_t)(row_w + (bit & 3) * 8 + (bit >> 2)) : vlist;
                     ++cnt;
                 }
                 if (cnt >= 32) {

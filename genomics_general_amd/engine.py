@@ -102,6 +102,11 @@ class Engine:
         check(self._L.pg_kernel_time(self._h, kernel_id, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernel_time_select(self, kernel_ids=None):
+        """Bracket only these kernel families with HIP events (None = all)."""
+        mask = 0xFFFFFFFF if kernel_ids is None else sum(1 << int(k) for k in kernel_ids)
+        check(self._L.pg_kernel_time_select(self._h, mask))
+
     def kernel_time_reset(self):
         check(self._L.pg_kernel_time_reset(self._h))
 

@@ -170,6 +170,9 @@ int pg_hap_called(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* Accumulated HIP-event time (ms) and launch count of a kernel family since the last reset. */
 int pg_kernel_time(pg_ctx *ctx, int kernel_id, double *ms_out, int64_t *launches_out);
+/* Which kernel families are bracketed by events (bit k = family k, default all).  Event records between kernels cost a few
+ * microseconds of GPU idle time each; a throughput run can restrict them to the family it reports. */
+int pg_kernel_time_select(pg_ctx *ctx, uint32_t mask);
 int pg_kernel_time_reset(pg_ctx *ctx);
 /* scratch budget (bytes) for per-batch bit-planes + matrices; default 16 GiB */
 int pg_set_scratch_limit(pg_ctx *ctx, int64_t bytes);
