@@ -788,7 +788,7 @@ static int quartet_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_
         int nb = w1 - w0;
         int64_t max_len = 0;
         if ((rc = stage_windows(c, lo, hi, w0, w1, nullptr, nullptr, &max_len)) != PG_OK) return rc;
-        int max_chunks = (int)((max_len + PG_SITES_PER_BLOCK - 1) / PG_SITES_PER_BLOCK);
+        int max_chunks = (int)((max_len + PG_ABBA_SITES_PER_BLOCK - 1) / PG_ABBA_SITES_PER_BLOCK);
         if ((rc = c->part_f64.ensure((size_t)nb * std::max(max_chunks, 1) * nsum)) != PG_OK) return rc;
         if ((rc = c->part_i64.ensure((size_t)nb * std::max(max_chunks, 1))) != PG_OK) return rc;
         if ((rc = c->res_f64.ensure((size_t)nb * nsum)) != PG_OK) return rc;

@@ -6,6 +6,7 @@
 
 #define PG_MAX_POPS 16          // populations handled by the site-statistics kernels (K3/K6 take any number)
 #define PG_SITES_PER_BLOCK 1024 // sites reduced by one block of the site-statistics kernels
+#define PG_ABBA_SITES_PER_BLOCK 4096   // k_abba_q: fewer, longer blocks (prologue masks + epilogue reduction per block)
 #define PG_ABBA_NSUM 6
 #define PG_FOURPOP_NSUM 14
 #define PG_XV_PLANES 3        // compacted polymorphic-site planes per word: allele-index bit 0, bit 1, called

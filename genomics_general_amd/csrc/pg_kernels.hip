@@ -291,6 +291,31 @@ __device__ __forceinline__ double block_sum_f64(double v, double *sh) {
     return r;
 }
 
+// N sums at once: a fixed xor-butterfly inside each wave (shuffles, no barrier), then the waves' totals through LDS in wave
+// order.  One barrier instead of ten per value; the result (valid in thread 0) depends only on the thread partition.
+template <int N>
+__device__ __forceinline__ void block_sum_multi(double (&v)[N], double *sh /* [waves][N] */) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v[k] += __shfl_xor(v[k], m, 64);
+    }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) sh[wave * N + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double t = sh[k];
+            for (int w = 1; w < nw; ++w) t += sh[w * N + k];
+            v[k] = t;
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh) {
     const int t = threadIdx.x;
     sh[t] = v;
@@ -641,7 +666,34 @@ __device__ __forceinline__ void range_counts_x4(const int8_t *__restrict__ rowb,
     }
 }
 
+// OR of the bytes [s,e) of a row: the alleles present among those haplotypes (low 4 bits)
+__device__ __forceinline__ uint32_t range_presence_x4(const int8_t *__restrict__ rowb, int s, int e) {
+    if (e <= s) return 0u;
+    const int b0 = s & ~3;
+    const int last = (e - 1) & ~3;
+    const uint32_t m_first = ~((1u << (8 * (s & 3))) - 1u);
+    const int hi = ((e - 1) & 3) + 1;
+    const uint32_t m_last = hi == 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
+    uint32_t acc = 0u;
+    for (int b = b0; b <= last; b += 16) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(rowb + b);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (b == b0) w[0] &= m_first;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int off = b + 4 * k;
+            if (off == last) w[k] &= m_last;
+            if (off > last) w[k] = 0u;
+        }
+        acc |= w[0] | w[1] | w[2] | w[3];
+    }
+    acc |= acc >> 16;
+    acc |= acc >> 8;
+    return acc & 0xFu;
+}
+
 #define PG_ABBA_RING 128          // per-wave ring of usable sites waiting for the float64 phase
+#define PG_ABBA_CAND 128          // per-wave ring of candidate (biallelic) sites waiting for the counting pass
 
 // Allele choice per site (sel):
 //   PG_SEL_POLARIZE  the allele present in the four populations and absent from P4 (genomics.py:1672 / :1610)
@@ -649,18 +701,21 @@ __device__ __forceinline__ void range_counts_x4(const int8_t *__restrict__ rowb,
 //   PG_SEL_MINOR     np.argsort(all4freqs)[:,2], i.e. the rarer of the two alleles (genomics.py:1615); a tie is resolved the
 //                    way NumPy >= 2.0's x86 (AVX2 / AVX-512) argsort network resolves it for a 4-element row, which is what
 //                    the reference produces on current hardware: {A,C}->C, {A,G}->A, {A,T}->A, {C,G}->C, {C,T}->C, {G,T}->G
-template <int NSUM>
+// NPASS > 0: the screening pass reads whole rows with fully coalesced 16-byte loads (16 lanes per row, NPASS passes of 256
+// bytes) and ORs them over the 16 lanes with DPP row shifts; NPASS == 0: rows longer than 1024 bytes, screened with the
+// counting pass's quad layout.
+template <int NSUM, int NPASS>
 __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
                                                 const int64_t *__restrict__ win_hi, int max_chunks,
                                                 const int32_t *__restrict__ pop_start, int q1, int q2, int q3, int q4,
                                                 double min_data, int sel, double *__restrict__ part_sums,
                                                 int64_t *__restrict__ part_used) {
-    __shared__ double shd[256];
-    __shared__ unsigned long long shu[256];
+    __shared__ double shd[4 * (NSUM + 1)];
     __shared__ uint32_t ring[4][PG_ABBA_RING][8];
+    __shared__ int64_t cand[4][PG_ABBA_CAND];
     const int win = blockIdx.y, chunk = blockIdx.x;
     const int64_t lo = win_lo[win], hi = win_hi[win];
-    const int64_t c0 = lo + (int64_t)chunk * PG_SITES_PER_BLOCK;
+    const int64_t c0 = lo + (int64_t)chunk * PG_ABBA_SITES_PER_BLOCK;
     QuartetAcc<NSUM> A;
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) A.acc[k] = 0.0;
@@ -676,16 +731,16 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qbase = lane & ~3;
     uint32_t(*my_ring)[8] = ring[wave];
+    int64_t *my_cand = cand[wave];
     int head = 0, tail = 0;                             // wave-uniform ring cursors (entries [head,tail) are pending)
-    if (c0 < hi) {
-        const int64_t c1 = (c0 + PG_SITES_PER_BLOCK < hi) ? c0 + PG_SITES_PER_BLOCK : hi;
-        // a wave owns 16 consecutive sites per step; the whole loop is wave-synchronous (no block barrier)
-        for (int64_t t0 = c0 + 16 * wave; t0 < c1; t0 += 64) {
-            const int64_t site = t0 + (lane >> 2);
+    int chead = 0, ctail = 0;                           // same for the candidate ring
+    // Counting pass for 16 sites (one per quad): per-population allele counts, the reference's site filters, and the
+    // usable sites appended to the float64 ring.
+    auto count_sites = [&](int64_t site, bool valid) {
             uint32_t cnt[4] = {0u, 0u, 0u, 0u};
-            if (site < c1) range_counts_x4(gt + site * (int64_t)S, my_s, my_e, cnt);
+            if (valid) range_counts_x4(gt + site * (int64_t)S, my_s, my_e, cnt);
             const uint32_t n = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-            int ok = (site < c1) && ((int)n >= my_nmin);
+            int ok = valid && ((int)n >= my_nmin);
             ok &= __shfl_xor(ok, 1, 64);
             ok &= __shfl_xor(ok, 2, 64);
             uint32_t tot[4], c3[4];
@@ -748,6 +803,88 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
                 quartet_terms<NSUM>(f, A);
                 head += 64;
             }
+    };
+    if (c0 < hi) {
+        const int64_t c1 = (c0 + PG_ABBA_SITES_PER_BLOCK < hi) ? c0 + PG_ABBA_SITES_PER_BLOCK : hi;
+        // Screening pass, every site: which alleles occur among the called haplotypes of the four populations (an OR of the
+        // row bytes, a fraction of the counting work).  Only sites with exactly two alleles can pass genomics.py:1655 / :1593;
+        // they are queued in site order and counted 16 at a time (their rows are re-read, from cache where possible).
+        // A wave owns 16 consecutive sites per step; the whole loop is wave-synchronous (no block barrier).
+        // bytes of this lane's 16-byte pieces that belong to one of the four populations
+        uint32_t umask[NPASS > 0 ? NPASS : 1][4];
+        const int sub = lane & 15, rsel = lane >> 4;
+        if (NPASS > 0) {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t m = 0u;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int x = p * 256 + sub * 16 + 4 * k + b;
+                        bool in = false;
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) in = in || (x >= pop_start[qs[z]] && x < pop_start[qs[z] + 1]);
+                        if (in) m |= 0xFFu << (8 * b);
+                    }
+                    umask[p][k] = m;
+                }
+        }
+        // sites per wave step: 16 row loads are in flight per lane before the first one is used
+        constexpr int GROUPS = NPASS > 0 ? 16 / NPASS : 4, SPW = 4 * GROUPS;
+        for (int64_t t0 = c0 + SPW * wave; t0 < c1; t0 += 4 * SPW) {
+            if (NPASS > 0) {
+                uint4 v[GROUPS][NPASS > 0 ? NPASS : 1];
+#pragma unroll
+                for (int g = 0; g < GROUPS; ++g) {
+                    const int64_t site = t0 + 4 * g + rsel;
+                    const int8_t *rowb = gt + site * (int64_t)S;
+#pragma unroll
+                    for (int p = 0; p < NPASS; ++p) {
+                        const int off = p * 256 + sub * 16;
+                        v[g][p] = make_uint4(0u, 0u, 0u, 0u);
+                        if (site < c1 && off < S) v[g][p] = *reinterpret_cast<const uint4 *>(rowb + off);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < GROUPS; ++g) {
+                    const int64_t site = t0 + 4 * g + rsel;
+                    uint32_t acc = 0u;
+#pragma unroll
+                    for (int p = 0; p < NPASS; ++p)
+                        acc |= (v[g][p].x & umask[p][0]) | (v[g][p].y & umask[p][1]) | (v[g][p].z & umask[p][2]) |
+                               (v[g][p].w & umask[p][3]);
+#define PG_DPP_ROW_OR(ctrl) acc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, ctrl, 0xf, 0xf, false)
+                    PG_DPP_ROW_OR(0x111);        // row_shr:1
+                    PG_DPP_ROW_OR(0x112);        // row_shr:2
+                    PG_DPP_ROW_OR(0x114);        // row_shr:4
+                    PG_DPP_ROW_OR(0x118);        // row_shr:8 -> lane 15 of each 16-lane row holds the site's OR
+#undef PG_DPP_ROW_OR
+                    acc |= acc >> 16;
+                    acc |= acc >> 8;
+                    const bool is_cand = sub == 15 && site < c1 && __popc(acc & 0xFu) == 2;
+                    const unsigned long long bal = __ballot(is_cand);
+                    if (is_cand) my_cand[(ctail + __popcll(bal & ((1ull << lane) - 1ull))) & (PG_ABBA_CAND - 1)] = site;
+                    ctail += (int)__popcll(bal);
+                }
+            } else {                                     // SPW == 16
+                const int64_t site = t0 + (lane >> 2);
+                uint32_t pres = site < c1 ? range_presence_x4(gt + site * (int64_t)S, my_s, my_e) : 0u;
+                pres |= (uint32_t)__shfl_xor((int)pres, 1, 64);
+                pres |= (uint32_t)__shfl_xor((int)pres, 2, 64);
+                const bool is_cand = q == 0 && __popc(pres) == 2;
+                const unsigned long long bal = __ballot(is_cand);
+                if (is_cand) my_cand[(ctail + __popcll(bal & ((1ull << lane) - 1ull))) & (PG_ABBA_CAND - 1)] = site;
+                ctail += (int)__popcll(bal);
+            }
+            while (ctail - chead >= 16) {
+                count_sites(my_cand[(chead + (lane >> 2)) & (PG_ABBA_CAND - 1)], true);
+                chead += 16;
+            }
+        }
+        if (ctail > chead) {
+            const bool valid = (lane >> 2) < ctail - chead;
+            count_sites(valid ? my_cand[(chead + (lane >> 2)) & (PG_ABBA_CAND - 1)] : c0, valid);
         }
         if (lane < tail - head) {
             uint32_t f[8];
@@ -758,13 +895,16 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
         }
     }
     const size_t o = (size_t)win * max_chunks + chunk;
+    double tot[NSUM + 1];
 #pragma unroll
-    for (int k = 0; k < NSUM; ++k) {
-        const double r = block_sum_f64(A.acc[k], shd);
-        if (threadIdx.x == 0) part_sums[o * NSUM + k] = r;
+    for (int k = 0; k < NSUM; ++k) tot[k] = A.acc[k];
+    tot[NSUM] = (double)A.used;                          // <= PG_ABBA_SITES_PER_BLOCK, exact in a double
+    block_sum_multi<NSUM + 1>(tot, shd);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NSUM; ++k) part_sums[o * NSUM + k] = tot[k];
+        part_used[o] = (int64_t)tot[NSUM];
     }
-    const unsigned long long u = block_sum_u64(A.used, shu);
-    if (threadIdx.x == 0) part_used[o] = (int64_t)u;
 }
 
 __global__ void k_abba_reduce(const double *__restrict__ part_sums, const int64_t *__restrict__ part_used, int n_win,
@@ -775,7 +915,7 @@ __global__ void k_abba_reduce(const double *__restrict__ part_sums, const int64_
     const int win = idx / (nsum + 1), k = idx % (nsum + 1);
     if (win >= n_win) return;
     const int64_t len = win_hi[win] - win_lo[win];
-    const int nch = (int)((len + PG_SITES_PER_BLOCK - 1) / PG_SITES_PER_BLOCK);
+    const int nch = (int)((len + PG_ABBA_SITES_PER_BLOCK - 1) / PG_ABBA_SITES_PER_BLOCK);
     if (k < nsum) {
         double s = 0.0;
         for (int c = 0; c < nch; ++c) s += part_sums[((size_t)win * max_chunks + c) * nsum + k];
@@ -793,12 +933,23 @@ void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_
                     int64_t *used_out) {
     if (n_win <= 0) return;
     if (max_chunks > 0) {
-        if (nsum == PG_ABBA_NSUM)
-            hipLaunchKernelGGL(k_abba_q<PG_ABBA_NSUM>, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi,
-                               max_chunks, pop_start, p1, p2, p3, p4, min_data, sel, part_sums, part_used);
-        else
-            hipLaunchKernelGGL(k_abba_q<PG_FOURPOP_NSUM>, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi,
-                               max_chunks, pop_start, p1, p2, p3, p4, min_data, sel, part_sums, part_used);
+        const dim3 grid(max_chunks, n_win);
+#define PG_ABBA_LAUNCH(NS, NP)                                                                                          \
+    hipLaunchKernelGGL((k_abba_q<NS, NP>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, max_chunks, pop_start, p1, p2, \
+                       p3, p4, min_data, sel, part_sums, part_used)
+        const int npass = (S + 255) / 256;
+        if (nsum == PG_ABBA_NSUM) {
+            if (npass == 1) PG_ABBA_LAUNCH(PG_ABBA_NSUM, 1);
+            else if (npass == 2) PG_ABBA_LAUNCH(PG_ABBA_NSUM, 2);
+            else if (npass <= 4) PG_ABBA_LAUNCH(PG_ABBA_NSUM, 4);
+            else PG_ABBA_LAUNCH(PG_ABBA_NSUM, 0);
+        } else {
+            if (npass == 1) PG_ABBA_LAUNCH(PG_FOURPOP_NSUM, 1);
+            else if (npass == 2) PG_ABBA_LAUNCH(PG_FOURPOP_NSUM, 2);
+            else if (npass <= 4) PG_ABBA_LAUNCH(PG_FOURPOP_NSUM, 4);
+            else PG_ABBA_LAUNCH(PG_FOURPOP_NSUM, 0);
+        }
+#undef PG_ABBA_LAUNCH
     }
     int total = n_win * (nsum + 1);
     hipLaunchKernelGGL(k_abba_reduce, dim3((total + 255) / 256), dim3(256), 0, st, part_sums, part_used, n_win,

@@ -82,9 +82,12 @@ def test_ind_pair_dists_with_and_without_popdist_mask():
     e.close()
 
 
-@pytest.mark.parametrize("min_data,miss", [(0.01, 5000), (0.5, 20000), (0.9, 9000), (0.0, 50000)])
-def test_abbababa_sums(min_data, miss):
-    e, lay, codes, _ = G.make_engine(16, 4, 6000, seed=44, var_thr=45000, miss_thr=miss)
+@pytest.mark.parametrize("n_dip,min_data,miss", [(16, 0.01, 5000), (16, 0.5, 20000), (16, 0.9, 9000), (16, 0.0, 50000),
+                                                 (150, 0.3, 9000),      # 304-byte rows: two screening passes
+                                                 (300, 0.3, 9000),      # 608-byte rows: three of four
+                                                 (600, 0.3, 9000)])     # 1200-byte rows: quad-layout screening
+def test_abbababa_sums(n_dip, min_data, miss):
+    e, lay, codes, _ = G.make_engine(n_dip, 4, 6000, seed=44, var_thr=45000, miss_thr=miss)
     wins = [(0, 3000), (3000, 3010), (3010, 6000), (10, 10)]
     wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
     got = wb.ABBABABA("p0", "p1", "p2", "p3", min_data)
