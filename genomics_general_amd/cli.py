@@ -123,44 +123,98 @@ def _make_windows(p, data, minSites, coords_keep=4):
 
 
 class Run:
-    """Shared plumbing: input -> layout -> windows -> engine (+ multi-GPU shard of the window list)."""
+    """Shared plumbing: input -> layout -> windows -> engine (+ multi-GPU shard of the window list).
 
-    def __init__(self, args, sampleData, wparams, minSites, header_line=None, coords_keep=4, windows_fn=None):
+    The input is consumed in blocks of PG_STREAM_BYTES bytes of text (default 1 GiB) when the window type allows it
+    (coordinate windows: windows.CoordWindowStream), so host memory stays bounded for inputs of any size; sites /
+    predefined / cat windows read the whole input as one block.  Drivers iterate `for _ in run.chunks():`; inside the loop
+    T, w0, w1, lo, hi, batch() and gather() refer to the windows that became certain with the current block.  Drivers that
+    do not stream construct Run(..., stream=False): the single chunk is loaded by the constructor."""
+
+    def __init__(self, args, sampleData, wparams, minSites, header_line=None, coords_keep=4, windows_fn=None, stream=False):
+        import os
         import time
         self.world = dist.world_from_env()
-        self.timing = {}                                  # seconds per phase; printed as JSON on stderr when PG_TIMING=1
+        self.timing = {"read_s": 0.0, "text_bytes": 0, "tokenize_s": 0.0, "windows_s": 0.0, "sites": 0, "windows": 0,
+                       "engine_and_upload_s": 0.0, "chunks": 0}   # printed as JSON on stderr when PG_TIMING=1
         t0 = time.perf_counter()
-        raw = genoio.read_all(args.genoFile)
-        names, body = genoio.split_header(raw, header_line)
-        self.timing["read_s"], t0 = time.perf_counter() - t0, time.perf_counter()
-        self.timing["text_bytes"] = len(raw)
+        self._reader = genoio.BlockReader(args.genoFile)
+        if header_line:
+            names = header_line.split()[2:]
+        else:
+            names = self._reader.read_header().decode("utf-8", "replace").split()[2:]
+        self.timing["read_s"] += time.perf_counter() - t0
         self.layout = HapLayout(sampleData, names, args.genoFormat)
-        self.data = genoio.encode(body, self.layout)
-        self.timing["tokenize_s"], t0 = time.perf_counter() - t0, time.perf_counter()
-        wparams = dict(wparams, include=args.include, exclude=args.exclude)
-        self.T = windows_fn(self.data) if windows_fn else _make_windows(wparams, self.data, minSites, coords_keep)
-        self.timing["windows_s"], t0 = time.perf_counter() - t0, time.perf_counter()
-        self.timing["sites"], self.timing["windows"] = int(self.data.n_sites), int(self.T.n)
+        self._wparams = dict(wparams, include=args.include, exclude=args.exclude)
+        self._minSites, self._coords_keep, self._windows_fn = minSites, coords_keep, windows_fn
+        self._streamer = None
+        self._block_bytes = None
+        if stream and windows_fn is None and wparams["windType"] == "coordinate":
+            inc = _lines(args.include) if args.include else None
+            exc = _lines(args.exclude) if args.exclude else None
+            self._streamer = windows.CoordWindowStream(wparams["windSize"], wparams["stepSize"], inc, exc)
+            self._block_bytes = int(os.environ.get("PG_STREAM_BYTES", 1 << 30))
+        t0 = time.perf_counter()
         dev = args.device if args.device is not None else self.world.local_rank
         self.engine = Engine(dev)
         self.engine.set_layout(self.layout)
-        self._t_upload0 = time.perf_counter()
         self.comm = dist.RcclComm(self.engine, self.world) if self.world.size > 1 else dist.SoloComm()
-        # this rank's windows (contiguous range) and only the sites they cover
-        self.w0, self.w1 = dist.shard_range(self.T.n, self.world.size, self.world.rank)
-        lo, hi = self.T.lo[self.w0:self.w1], self.T.hi[self.w0:self.w1]
-        nz = hi > lo
-        if np.any(nz):
-            s0, s1 = int(lo[nz].min()), int(hi[nz].max())
-        else:
-            s0 = s1 = 0
-        self.engine.load_sites(self.data.gt[s0:s1])
-        self.site0 = s0
-        self.lo, self.hi = lo - s0, hi - s0
-        self.lo[~nz] = 0
-        self.hi[~nz] = 0
-        self.timing["engine_and_upload_s"] = time.perf_counter() - self._t_upload0
+        self.timing["engine_and_upload_s"] += time.perf_counter() - t0
         self._t_compute0 = time.perf_counter()
+        self.n_tested = 0
+        if not stream:
+            for _ in self.chunks():
+                break
+
+    def chunks(self):
+        """Generator over the pieces of the input; see the class docstring."""
+        import time
+        carry = None
+        while True:
+            t0 = time.perf_counter()
+            body = self._reader.read_block(self._block_bytes)
+            final = self._streamer is None or len(body) == 0
+            self.timing["read_s"] += time.perf_counter() - t0
+            self.timing["text_bytes"] = self._reader.bytes_read
+            t0 = time.perf_counter()
+            block = genoio.encode(body, self.layout)
+            del body
+            self.data = genoio.concat(carry, block)
+            self.timing["tokenize_s"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            if self._streamer is not None:
+                self.T, keep_from = self._streamer.feed(self.data.run_starts, self.data.run_names, self.data.pos, final)
+            else:
+                self.T = (self._windows_fn(self.data) if self._windows_fn
+                          else _make_windows(self._wparams, self.data, self._minSites, self._coords_keep))
+                self.T.dup = np.zeros(self.T.n, dtype=bool)
+                keep_from = self.data.n_sites
+            self.timing["windows_s"] += time.perf_counter() - t0
+            self.timing["sites"] += int(block.n_sites)
+            self.timing["windows"] += int(self.T.n)
+            self.timing["chunks"] += 1
+            self.n_tested += int(self.T.n)
+            t0 = time.perf_counter()
+            # this rank's windows (contiguous range) and only the sites they cover
+            self.w0, self.w1 = dist.shard_range(self.T.n, self.world.size, self.world.rank)
+            lo, hi = self.T.lo[self.w0:self.w1], self.T.hi[self.w0:self.w1]
+            nz = hi > lo
+            if np.any(nz):
+                s0, s1 = int(lo[nz].min()), int(hi[nz].max())
+            else:
+                s0 = s1 = 0
+            self.engine.load_sites(self.data.gt[s0:s1])
+            self.site0 = s0
+            self.lo, self.hi = lo - s0, hi - s0
+            self.lo[~nz] = 0
+            self.hi[~nz] = 0
+            self.timing["engine_and_upload_s"] += time.perf_counter() - t0
+            if self.T.n:
+                yield self
+            if final:
+                break
+            carry = genoio.tail(self.data, keep_from)
+        self._reader.close()
 
     def report_timing(self):
         """Tier-T2 evidence (text end to end): per-phase wall seconds as one JSON line on stderr when PG_TIMING=1."""
@@ -168,8 +222,10 @@ class Run:
         import os
         import time
         if os.environ.get("PG_TIMING") and self.world.rank == 0:
-            self.timing["compute_and_write_s"] = time.perf_counter() - self._t_compute0
-            sys.stderr.write("PG_TIMING " + json.dumps(self.timing) + "\n")
+            t = dict(self.timing)
+            t["compute_and_write_s"] = (time.perf_counter() - self._t_compute0 - t["read_s"] - t["tokenize_s"] - t["windows_s"]
+                                        - t["engine_and_upload_s"])
+            sys.stderr.write("PG_TIMING " + json.dumps(t) + "\n")
 
     def batch(self, mask):
         """WindowBatch over this rank's windows selected by boolean `mask`."""
@@ -266,52 +322,62 @@ def popgen_main(argv=None):
             stats += [pre + n for n in popNames]
     int_stat = [s.startswith("l_") or s.startswith("S_") for s in stats]
 
-    run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=3)
-    T = run.T
-    sites_local = T.sites[run.w0:run.w1]
-    good = sites_local >= minSites
-    table = np.full((run.w1 - run.w0, len(stats)), np.nan)
-    if np.any(good) and stats:
-        wb = run.batch(good)
-        sd = {}
-        if "popFreq" in args.analysis:
-            sd.update(wb.groupFreqStats())
-        if "popDist" in args.analysis or "popPairDist" in args.analysis:
-            sd.update(wb.groupDistStats(doPairs="popPairDist" in args.analysis, minSites=minSites, minData=args.minData))
-        if "indPairDist" in args.analysis:
-            pdd = wb.indPairDists()
-            for i, j in itertools.combinations_with_replacement(sorted(pdd.keys()), 2):
-                sd["_".join(["d", i, j])] = pdd[i][j]
-        if "indHet" in args.analysis:
-            for k, v in wb.sampleHet().items():
-                sd["het_" + k] = v
-        if "hapStats" in args.analysis:
-            sd.update(wb.H12stats(maxDist=args.hapDist))
-        for c, s in enumerate(stats):
-            table[good, c] = sd[s]
-    full = run.gather(table)
-
+    run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=3, stream=True)
+    out = None
     if run.world.rank == 0:
         out = _open_out(args.outFile)
         out.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites," + ",".join(stats) + "\n")
-        written = 0
+    written = 0
+    last_row = None                      # (ok, text) of the previously emitted window: a dup row repeats it verbatim
+    for _ in run.chunks():
+        T = run.T
+        sites_local = T.sites[run.w0:run.w1]
+        good = sites_local >= minSites
+        table = np.full((run.w1 - run.w0, len(stats)), np.nan)
+        if np.any(good) and stats:
+            wb = run.batch(good)
+            sd = {}
+            if "popFreq" in args.analysis:
+                sd.update(wb.groupFreqStats())
+            if "popDist" in args.analysis or "popPairDist" in args.analysis:
+                sd.update(wb.groupDistStats(doPairs="popPairDist" in args.analysis, minSites=minSites, minData=args.minData))
+            if "indPairDist" in args.analysis:
+                pdd = wb.indPairDists()
+                for i, j in itertools.combinations_with_replacement(sorted(pdd.keys()), 2):
+                    sd["_".join(["d", i, j])] = pdd[i][j]
+            if "indHet" in args.analysis:
+                for k, v in wb.sampleHet().items():
+                    sd["het_" + k] = v
+            if "hapStats" in args.analysis:
+                sd.update(wb.H12stats(maxDist=args.hapDist))
+            for c, s in enumerate(stats):
+                table[good, c] = sd[s]
+        full = run.gather(table)
+        if run.world.rank != 0:
+            continue
         for k in range(T.n):
-            ok = T.sites[k] >= minSites
+            if T.dup[k]:
+                ok, text = last_row
+            else:
+                ok = T.sites[k] >= minSites
+                vals = []
+                for c in range(len(stats)):
+                    v = full[k, c]
+                    if int_stat[c] and v == v:
+                        vals.append(int(v))
+                    else:
+                        vals.append(round(np.float64(v), args.roundTo))
+                row = ([T.ID[k]] if args.addWindowID else []) + [T.scaffold[k], T.start[k], T.end[k], T.mid[k], int(T.sites[k])] + vals
+                text = ",".join(_fmt_cell(x) for x in row) + "\n"
+                last_row = (ok, text)
             if not (ok or args.writeFailedWindows):
                 continue
-            vals = []
-            for c in range(len(stats)):
-                v = full[k, c]
-                if int_stat[c] and v == v:
-                    vals.append(int(v))
-                else:
-                    vals.append(round(np.float64(v), args.roundTo))
-            row = ([T.ID[k]] if args.addWindowID else []) + [T.scaffold[k], T.start[k], T.end[k], T.mid[k], int(T.sites[k])] + vals
-            out.write(",".join(_fmt_cell(x) for x in row) + "\n")
+            out.write(text)
             written += 1
+    if run.world.rank == 0:
         if out is not sys.stdout:
             out.close()
-        sys.stderr.write(str(T.n) + " windows were tested.\n")
+        sys.stderr.write(str(run.n_tested) + " windows were tested.\n")
         sys.stderr.write(str(written) + " results were written.\n")
         sys.stderr.write("\nDone.\n")
     run.report_timing()
@@ -380,39 +446,49 @@ def _quartet_main(argv, prog, stats, fourpop):
     ploidyDict = _ploidy_dict(args, allInds, args.haploid.split(",") if args.haploid else None)
     sampleData = SampleData(popNames=popNames, popInds=popInds, ploidyDict=ploidyDict)
 
-    run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=4)
-    T = run.T
-    sites_local = T.sites[run.w0:run.w1]
-    good = sites_local >= minSites
-    table = np.full((run.w1 - run.w0, 1 + len(stats)), np.nan)           # sitesUsed + the statistics
-    if np.any(good):
-        if fourpop:
-            sd = run.batch(good).fourPop(popNames[0], popNames[1], popNames[2], popNames[3], minData,
-                                         polarize=args.polarize, fixed=args.fixed)
-        else:
-            sd = run.batch(good).ABBABABA(popNames[0], popNames[1], popNames[2], popNames[3], minData)
-        table[good, 0] = sd["sitesUsed"]
-        for c, s in enumerate(stats):
-            table[good, 1 + c] = sd[s]
-    full = run.gather(table)
-
+    run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=4, stream=True)
+    out = None
     if run.world.rank == 0:
         out = _open_out(args.outFile)
         out.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites,sitesUsed," + ",".join(stats) + "\n")
-        written = 0
+    written = 0
+    last_row = None                      # (ok, text) of the previously emitted window: a dup row repeats it verbatim
+    for _ in run.chunks():
+        T = run.T
+        sites_local = T.sites[run.w0:run.w1]
+        good = sites_local >= minSites
+        table = np.full((run.w1 - run.w0, 1 + len(stats)), np.nan)           # sitesUsed + the statistics
+        if np.any(good):
+            if fourpop:
+                sd = run.batch(good).fourPop(popNames[0], popNames[1], popNames[2], popNames[3], minData,
+                                             polarize=args.polarize, fixed=args.fixed)
+            else:
+                sd = run.batch(good).ABBABABA(popNames[0], popNames[1], popNames[2], popNames[3], minData)
+            table[good, 0] = sd["sitesUsed"]
+            for c, s in enumerate(stats):
+                table[good, 1 + c] = sd[s]
+        full = run.gather(table)
+        if run.world.rank != 0:
+            continue
         for k in range(T.n):
-            used = full[k, 0]
-            ok = T.sites[k] >= minSites and used >= minSites           # ABBABABAwindows.py:35-46, fourPopWindows.py:36-48
+            if T.dup[k]:
+                ok, text = last_row
+            else:
+                used = full[k, 0]
+                ok = T.sites[k] >= minSites and used >= minSites           # ABBABABAwindows.py:35-46, fourPopWindows.py:36-48
+                vals = [round(np.float64(v), 4) for v in full[k, 1:]] if ok else [np.nan] * len(stats)
+                used_cell = int(used) if used == used else np.nan
+                row = ([T.ID[k]] if args.addWindowID else []) + [T.scaffold[k], T.start[k], T.end[k], T.mid[k], int(T.sites[k]), used_cell] + vals
+                text = ",".join(_fmt_cell(x) for x in row) + "\n"
+                last_row = (ok, text)
             if not (ok or args.writeFailedWindows):
                 continue
-            vals = [round(np.float64(v), 4) for v in full[k, 1:]] if ok else [np.nan] * len(stats)
-            used_cell = int(used) if used == used else np.nan
-            row = ([T.ID[k]] if args.addWindowID else []) + [T.scaffold[k], T.start[k], T.end[k], T.mid[k], int(T.sites[k]), used_cell] + vals
-            out.write(",".join(_fmt_cell(x) for x in row) + "\n")
+            out.write(text)
             written += 1
+    if run.world.rank == 0:
         if out is not sys.stdout:
             out.close()
-        sys.stderr.write("%d windows were tested\n%d results were written\n\nDone.\n" % (T.n, written))
+        sys.stderr.write("%d windows were tested\n%d results were written\n\nDone.\n" % (run.n_tested, written))
     run.report_timing()
     run.comm.barrier()
     return 0

@@ -25,6 +25,39 @@ def read_all(path):
         return f.read()
 
 
+class BlockReader:
+    """The input as a sequence of byte blocks that end at line boundaries (gunzipped when the name ends in .gz; stdin when
+    path is None).  read_block(None) returns everything that is left."""
+
+    def __init__(self, path):
+        if path is None:
+            self.f = sys.stdin.buffer
+        elif str(path).endswith(".gz"):
+            self.f = gzip.open(path, "rb")
+        else:
+            self.f = open(path, "rb")
+        self.bytes_read = 0
+
+    def read_header(self):
+        line = self.f.readline()
+        self.bytes_read += len(line)
+        return line
+
+    def read_block(self, nbytes=None):
+        if nbytes is None:
+            data = self.f.read()
+        else:
+            data = self.f.read(nbytes)
+            if data and not data.endswith(b"\n"):
+                data += self.f.readline()
+        self.bytes_read += len(data)
+        return data
+
+    def close(self):
+        if self.f is not sys.stdin.buffer:
+            self.f.close()
+
+
 def read_header_names(path):
     """Sample names of the file's first line (popgenWindows.py:284-286, distMat.py:205-206)."""
     opener = gzip.open if str(path).endswith(".gz") else open
@@ -49,6 +82,27 @@ class GenoData:
     def __init__(self, gt, pos, run_starts, run_names):
         self.gt, self.pos, self.run_starts, self.run_names = gt, pos, run_starts, run_names
         self.n_sites = len(pos)
+
+
+def concat(a, b):
+    """Rows of GenoData a followed by those of b (a run that continues across the seam is merged)."""
+    if a is None or a.n_sites == 0:
+        return b
+    if b.n_sites == 0:
+        return a
+    merge = a.run_names[-1] == b.run_names[0]
+    starts = np.concatenate([a.run_starts, (b.run_starts[1:] if merge else b.run_starts) + a.n_sites]).astype(np.int64)
+    names = list(a.run_names) + list(b.run_names[1:] if merge else b.run_names)
+    return GenoData(np.concatenate([a.gt, b.gt]), np.concatenate([a.pos, b.pos]), starts, names)
+
+
+def tail(d, keep_from):
+    """Rows [keep_from, n) of GenoData d."""
+    if keep_from >= d.n_sites:
+        return None
+    r = int(np.searchsorted(d.run_starts, keep_from, side="right")) - 1
+    starts = np.concatenate([[0], d.run_starts[r + 1:] - keep_from]).astype(np.int64)
+    return GenoData(d.gt[keep_from:].copy(), d.pos[keep_from:].copy(), starts, list(d.run_names[r:]))
 
 
 def encode(data, layout, n_threads=0):

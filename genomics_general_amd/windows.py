@@ -207,3 +207,80 @@ def predefined_windows(run_starts, run_names, positions, windCoords):
         if cur >= n:
             break
     return T.finish(positions)
+
+
+class CoordWindowStream:
+    """slidingCoordWindows over an input that arrives in consecutive pieces (bounded host memory).
+
+    feed() gets the current buffer = rows carried over from the previous call + the new rows, as scaffold runs and
+    positions, and returns the windows that are certain by now together with the first buffer row the caller has to keep
+    for the next call.  A window [a,b] of the buffer's last run is certain once a site beyond b has been seen (that is when
+    the reference's generator yields it, genomics.py:2001-2005); the last run's remaining windows follow when the run ends
+    (next call starts with another scaffold, or final=True).  Concatenating the tables of all calls gives exactly
+    coord_windows() of the whole input, IDs included.  The reference's re-emission of the last window after a skipped
+    scaffold appears as a row with T.dup[i] = True: it repeats the previously emitted row verbatim (its sites may no longer
+    be in the buffer, so lo = hi = 0 there)."""
+
+    def __init__(self, windSize, stepSize, include=None, exclude=None):
+        self.w, self.step, self.include, self.exclude = int(windSize), int(stepSize), include, exclude
+        self.done = 0
+        self.have_pending = False        # some window has been emitted (it can be re-emitted after a skipped scaffold)
+        self.skipped_since = False
+        self.cont_name = None            # scaffold run that was still open at the end of the previous buffer
+        self.cont_k0 = 0                 # its next window index
+        self.cont_last = 0               # its last position seen
+
+    def feed(self, run_starts, run_names, positions, final):
+        positions = np.asarray(positions)
+        n = len(positions)
+        T = WindowTable()
+        T.dup = []
+        runs = _runs(run_starts, n) if n else []
+        keep_from = n
+        cont_name, cont_k0, cont_last = None, 0, 0
+        if self.cont_name is not None and (not runs or run_names[0] != self.cont_name):
+            # the open run ended exactly at the buffer boundary and none of its rows had to be carried (stepSize > windSize):
+            # its remaining windows are empty but still emitted
+            kl = 0 if self.cont_last <= self.w else -((self.w - self.cont_last) // self.step)
+            for k in range(self.cont_k0, kl + 1):
+                T.add(self.cont_name, 1 + k * self.step, self.w + k * self.step, 0, 0, self.done + 1)
+                T.dup.append(False)
+                self.done += 1
+                self.have_pending = True
+            self.cont_name = None
+        for r, (a, b) in enumerate(runs):
+            scaf = run_names[r]
+            is_cont = r == 0 and scaf == self.cont_name
+            is_open = r == len(runs) - 1 and not final
+            if not _wanted(scaf, self.include, self.exclude):
+                self.skipped_since = True
+                continue
+            if self.skipped_since and self.have_pending and not is_cont:
+                self.done += 1
+                T.add("", 0, 0, 0, 0, 0)
+                T.dup.append(True)
+            self.skipped_since = False
+            _check_sorted(positions, a, b, scaf)
+            p = positions[a:b].astype(np.int64)
+            last = int(p[-1])
+            k0 = self.cont_k0 if is_cont else 0
+            kl = 0 if last <= self.w else -((self.w - last) // self.step)          # ceil((last-w)/step)
+            k_end = kl if is_open else kl + 1                                       # windows k0 .. k_end-1 are certain
+            if k_end > k0:
+                k = np.arange(k0, k_end, dtype=np.int64)
+                starts = 1 + k * self.step
+                ends = self.w + k * self.step
+                lo = a + np.searchsorted(p, starts, side="left")
+                hi = a + np.searchsorted(p, ends, side="right")
+                for i in range(len(k)):
+                    T.add(scaf, int(starts[i]), int(ends[i]), int(lo[i]), int(hi[i]), self.done + 1)
+                    T.dup.append(False)
+                    self.done += 1
+                self.have_pending = True
+            if is_open:
+                cont_name, cont_k0, cont_last = scaf, max(k0, kl), last
+                keep_from = a + int(np.searchsorted(p, 1 + cont_k0 * self.step, side="left"))
+        self.cont_name, self.cont_k0, self.cont_last = cont_name, cont_k0, cont_last
+        T.finish(positions)
+        T.dup = np.asarray(T.dup, dtype=bool)
+        return T, keep_from

@@ -57,7 +57,9 @@ def main():
             traffic["_source"][wl] = tag
     with open(tpath, "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
-    log = os.path.join(src, "bench_prof.log")
+    log = os.path.join(src, "bench_prof_%s.log" % wl)
+    if not os.path.exists(log):
+        log = os.path.join(src, "bench_prof.log")
     if os.path.exists(log):
         with open(log) as f, open(os.path.join(dst, "%s_bench_line_under_rocprof.json" % wl), "w") as g:
             g.writelines(ln for ln in f if '"metric"' in ln)

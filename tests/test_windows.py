@@ -95,3 +95,62 @@ def test_predefined_windows_match_reference_generator(seed):
             coords.append((sc, a, a + int(rng.integers(0, 400)), "w%d" % len(coords)))
     T = W.predefined_windows(rs, rn, pos, coords)
     compare(T, orc.predefined_windows(sites, coords))
+
+
+# ---- streaming: the concatenation of CoordWindowStream tables equals coord_windows of the whole input --------------
+def _stream_rows(T, hist, off=0):
+    out = []
+    for i in range(T.n):
+        if getattr(T, "dup", None) is not None and len(T.dup) and T.dup[i]:
+            out.append(hist[-1])
+            continue
+        lo, hi = int(T.lo[i]), int(T.hi[i])
+        r = (T.scaffold[i], T.start[i], T.end[i], (lo + off, hi + off) if hi > lo else None, T.ID[i],
+             T.mid[i] if T.mid[i] == T.mid[i] else None)
+        out.append(r)
+        hist.append(r)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_coord_window_stream_equals_whole_input(seed):
+    from genomics_general_amd import windows as W
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(250):
+        names, starts, pos, prev = [], [], [], None
+        for _r in range(int(rng.integers(1, 6))):
+            nm = str(rng.choice([x for x in ("c0", "c1", "c2", "c3") if x != prev]))
+            prev = nm
+            starts.append(len(pos))
+            names.append(nm)
+            pos += list(np.sort(rng.integers(1, 400, size=int(rng.integers(1, 60)))))
+        rs, pos = np.array(starts), np.array(pos, dtype=np.int32)
+        w = int(rng.integers(5, 120))
+        step = int(rng.integers(1, 2 * w))                      # also step > window (gaps between windows)
+        inc = exc = None
+        z = int(rng.integers(0, 3))
+        if z == 1:
+            inc = [str(x) for x in rng.choice(["c0", "c1", "c2", "c3"], size=2, replace=False)]
+        if z == 2:
+            exc = [str(x) for x in rng.choice(["c0", "c1", "c2", "c3"], size=1)]
+        want = _stream_rows(W.coord_windows(rs, names, pos, w, step, inc, exc), [])
+        n = len(pos)
+        cuts = sorted(set(rng.integers(0, n + 1, size=int(rng.integers(0, 6))).tolist() + [n]))
+        run_of = np.zeros(n, dtype=int)
+        for r, (a, b) in enumerate(W._runs(rs, n)):
+            run_of[a:b] = r
+        S = W.CoordWindowStream(w, step, inc, exc)
+        got, hist, keep = [], [], 0
+        for ci, c in enumerate(cuts):
+            a, b = keep, max(c, keep)
+            if b > a:
+                ro = run_of[a:b]
+                chg = np.flatnonzero(np.concatenate([[True], ro[1:] != ro[:-1]]))
+                brs, bn = chg, [names[ro[i]] for i in chg]
+            else:
+                brs, bn = np.array([], dtype=int), []
+            T, kf = S.feed(brs, bn, pos[a:b], final=(ci == len(cuts) - 1))
+            got += _stream_rows(T, hist, a)
+            assert kf <= b - a
+            keep = a + kf
+        assert got == want, (w, step, inc, exc, cuts)
