@@ -135,6 +135,7 @@ class Run:
         import os
         import time
         self.world = dist.world_from_env()
+        self._t_start = time.perf_counter()
         self.timing = {"read_s": 0.0, "text_bytes": 0, "tokenize_s": 0.0, "windows_s": 0.0, "sites": 0, "windows": 0,
                        "engine_and_upload_s": 0.0, "chunks": 0}   # printed as JSON on stderr when PG_TIMING=1
         t0 = time.perf_counter()
@@ -160,7 +161,6 @@ class Run:
         self.engine.set_layout(self.layout)
         self.comm = dist.RcclComm(self.engine, self.world) if self.world.size > 1 else dist.SoloComm()
         self.timing["engine_and_upload_s"] += time.perf_counter() - t0
-        self._t_compute0 = time.perf_counter()
         self.n_tested = 0
         if not stream:
             for _ in self.chunks():
@@ -168,16 +168,34 @@ class Run:
 
     def chunks(self):
         """Generator over the pieces of the input; see the class docstring."""
+        import queue
+        import threading
         import time
         carry = None
+        # the next block is read (and gunzipped) by a helper thread while this one is tokenised and computed
+        blocks = queue.Queue(maxsize=1)
+
+        def produce():
+            try:
+                while True:
+                    b = self._reader.read_block(self._block_bytes)
+                    blocks.put(b)
+                    if self._block_bytes is None or len(b) == 0:
+                        return
+            except BaseException as exc:                  # surfaced in the consumer
+                blocks.put(exc)
+
+        threading.Thread(target=produce, daemon=True).start()
         while True:
             t0 = time.perf_counter()
-            body = self._reader.read_block(self._block_bytes)
+            body = blocks.get()
+            if isinstance(body, BaseException):
+                raise body
             final = self._streamer is None or len(body) == 0
-            self.timing["read_s"] += time.perf_counter() - t0
+            self.timing["read_s"] += time.perf_counter() - t0          # time this thread waited for the reader
             self.timing["text_bytes"] = self._reader.bytes_read
             t0 = time.perf_counter()
-            block = genoio.encode(body, self.layout)
+            block = genoio.encode(body, self.layout, head_rows=carry.n_sites if carry is not None else 0)
             del body
             self.data = genoio.concat(carry, block)
             self.timing["tokenize_s"] += time.perf_counter() - t0
@@ -223,8 +241,8 @@ class Run:
         import time
         if os.environ.get("PG_TIMING") and self.world.rank == 0:
             t = dict(self.timing)
-            t["compute_and_write_s"] = (time.perf_counter() - self._t_compute0 - t["read_s"] - t["tokenize_s"] - t["windows_s"]
-                                        - t["engine_and_upload_s"])
+            t["total_s"] = time.perf_counter() - self._t_start
+            t["compute_and_write_s"] = t["total_s"] - t["read_s"] - t["tokenize_s"] - t["windows_s"] - t["engine_and_upload_s"]
             sys.stderr.write("PG_TIMING " + json.dumps(t) + "\n")
 
     def batch(self, mask):

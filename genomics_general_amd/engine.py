@@ -19,15 +19,17 @@ from . import _lib
 from ._lib import check
 
 
-def encode_text(buf, layout, n_threads=0):
+def encode_text(buf, layout, n_threads=0, head_rows=0):
     """K0 host tokenizer.  buf: bytes of complete `.geno` data lines (no header).
-    Returns (gt int8 [L][n_hap] in slot order, pos int32 [L], scaf_off int64 [L], scaf_len int32 [L])."""
+    Returns (gt int8 [L][n_hap] in slot order, pos int32 [L], scaf_off int64 [L], scaf_len int32 [L]).
+    head_rows > 0: gt and pos are views into arrays with that many spare rows in front (gt.base / pos.base), so that a
+    caller can put carried-over rows before the new ones without copying the new ones."""
     L = _lib.lib()
     n = C.c_int64(0)
     check(L.pg_count_lines(buf, len(buf), C.byref(n)))
     cap = max(int(n.value), 1)
-    gt = np.zeros((cap, layout.n_hap), dtype=np.int8)
-    pos = np.zeros(cap, dtype=np.int32)
+    gt = np.zeros((head_rows + cap, layout.n_hap), dtype=np.int8)[head_rows:]
+    pos = np.zeros(head_rows + cap, dtype=np.int32)[head_rows:]
     soff = np.zeros(cap, dtype=np.int64)
     slen = np.zeros(cap, dtype=np.int32)
     got = C.c_int64(0)

@@ -85,7 +85,8 @@ class GenoData:
 
 
 def concat(a, b):
-    """Rows of GenoData a followed by those of b (a run that continues across the seam is merged)."""
+    """Rows of GenoData a followed by those of b (a run that continues across the seam is merged).  When b was encoded
+    with head_rows = a.n_sites the rows of a are copied into the spare rows in front of b's arrays (no copy of b)."""
     if a is None or a.n_sites == 0:
         return b
     if b.n_sites == 0:
@@ -93,6 +94,13 @@ def concat(a, b):
     merge = a.run_names[-1] == b.run_names[0]
     starts = np.concatenate([a.run_starts, (b.run_starts[1:] if merge else b.run_starts) + a.n_sites]).astype(np.int64)
     names = list(a.run_names) + list(b.run_names[1:] if merge else b.run_names)
+    n = a.n_sites
+    gbase, pbase = b.gt.base, b.pos.base
+    if (gbase is not None and pbase is not None and gbase.ndim == 2 and gbase.shape[0] >= n + b.n_sites
+            and b.gt.ctypes.data == gbase.ctypes.data + n * gbase.shape[1] and b.pos.ctypes.data == pbase.ctypes.data + 4 * n):
+        gbase[:n] = a.gt
+        pbase[:n] = a.pos
+        return GenoData(gbase[:n + b.n_sites], pbase[:n + b.n_sites], starts, names)
     return GenoData(np.concatenate([a.gt, b.gt]), np.concatenate([a.pos, b.pos]), starts, names)
 
 
@@ -105,8 +113,8 @@ def tail(d, keep_from):
     return GenoData(d.gt[keep_from:].copy(), d.pos[keep_from:].copy(), starts, list(d.run_names[r:]))
 
 
-def encode(data, layout, n_threads=0):
-    gt, pos, soff, slen = encode_text(data, layout, n_threads)
+def encode(data, layout, n_threads=0, head_rows=0):
+    gt, pos, soff, slen = encode_text(data, layout, n_threads, head_rows)
     n = len(pos)
     L = _lib.lib()
     cap = 1024

@@ -70,6 +70,43 @@ def test_tokenizer_matches_oracle_parser(name, fmt, n):
         assert list(data.gt[row]) == want
 
 
+@pytest.mark.parametrize("name", ["sparse", "abba"])
+def test_block_wise_encoding_with_carried_rows_equals_whole_file(name, tmp_path):
+    """genoio.BlockReader + encode(head_rows) + concat + tail: the streaming plumbing of cli.Run, without a GPU"""
+    path = os.path.join(GOLD, name + ".geno.gz")
+    raw = genoio.read_all(path)
+    names, body = genoio.split_header(raw)
+    lay = HapLayout(SampleData(indNames=list(names)), names, "phased")
+    whole = genoio.encode(body, lay)
+    rd = genoio.BlockReader(path)
+    assert rd.read_header().decode().split()[2:] == names
+    carry, seen, first_global = None, 0, 0
+    rows_gt, rows_pos = [], []
+    k = 0
+    while True:
+        blk = rd.read_block(7000)
+        if not blk:
+            break
+        assert blk.endswith(b"\n")
+        b = genoio.encode(blk, lay, head_rows=carry.n_sites if carry is not None else 0)
+        buf = genoio.concat(carry, b)
+        n_carry = carry.n_sites if carry is not None else 0
+        assert buf.n_sites == n_carry + b.n_sites
+        # the buffer is rows [first_global, first_global + n) of the whole file, runs included
+        a0 = first_global
+        assert np.array_equal(buf.gt, whole.gt[a0:a0 + buf.n_sites]) and np.array_equal(buf.pos, whole.pos[a0:a0 + buf.n_sites])
+        r0 = int(np.searchsorted(whole.run_starts, a0, side="right")) - 1
+        want_starts = [0] + [int(x) - a0 for x in whole.run_starts[r0 + 1:] if x < a0 + buf.n_sites]
+        assert list(buf.run_starts) == want_starts
+        assert buf.run_names == whole.run_names[r0:r0 + len(want_starts)]
+        keep = (buf.n_sites * (3 + k % 5)) // 8            # carry a varying tail
+        carry = genoio.tail(buf, keep)
+        first_global = a0 + keep
+        k += 1
+    assert first_global + (carry.n_sites if carry is not None else 0) == whole.n_sites
+    rd.close()
+
+
 def test_tokenizer_thread_count_does_not_change_output():
     raw = genoio.read_all(os.path.join(GOLD, "abba.geno.gz"))
     names, body = genoio.split_header(raw)

@@ -49,14 +49,23 @@ def main():
            "-m", "100"]
     for k in range(4):
         cmd += ["-p", "pop%d" % k, ",".join(names[k * per:(k + 1) * per])]
-    for rep in range(2):
+    ref_rows = None
+    for rep, block in enumerate([None, None, 64 << 20]):       # twice with the default block size, once in 64 MiB blocks
+        env = dict(os.environ, PG_TIMING="1")
+        if block:
+            env["PG_STREAM_BYTES"] = str(block)
         t0 = time.time()
-        r = subprocess.run(cmd, env=dict(os.environ, PG_TIMING="1"), stderr=subprocess.PIPE)
+        r = subprocess.run(cmd, env=env, stderr=subprocess.PIPE)
         wall = time.time() - t0
         line = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING")]
-        print("run %d: wall %.2f s (incl. interpreter start)  %s" % (rep, wall, line[-1] if line else r.stderr.decode()[-400:]))
-    with open("/tmp/t2_out.csv") as f:
-        rows = f.readlines()
+        print("run %d (%s): wall %.2f s (incl. interpreter start)  %s" % (
+            rep, "blocks of %d MiB" % (block >> 20) if block else "default blocks", wall,
+            line[-1] if line else r.stderr.decode()[-400:]))
+        with open("/tmp/t2_out.csv") as f:
+            rows = f.readlines()
+        if ref_rows is None:
+            ref_rows = rows
+        print("   output identical to run 0:", rows == ref_rows)
     print("rows:", len(rows) - 1, "| windows/s end to end:", round((len(rows) - 1) / wall, 2), "| sites/s:", round(n_sites / wall))
 
 
