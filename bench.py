@@ -42,6 +42,9 @@ WORKLOADS = {
     # BASELINE.json configs[3]: distMat pairwise-kernel stress
     "c4": dict(n_sites=1_000_000, n_scaf=1, n_dip=1000, n_pops=1, wind=100_000, min_sites=1, tool="distmat",
                desc="distMat full pairwise distance: 1e6 sites x 1000 diploids (2000 haplotypes), 100 kb windows"),
+    # --analysis popFreq on the C2 data set (k_popfreq; not a BASELINE.json config)
+    "popfreq": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=50_000, min_sites=100, tool="popfreq",
+                    desc="popgenWindows --analysis popFreq: 1e7 sites x 100 diploids (200 haplotypes), 4 pops, 50 kb windows"),
     # small variant for quick checks
     "tiny": dict(n_sites=400_000, n_scaf=2, n_dip=20, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
                  desc="tiny smoke workload"),
@@ -95,6 +98,8 @@ def main():
         wb = eng.batch(lo, hi)
         if wl["tool"] == "popgen":
             st = wb.groupDistStats(doPairs=True, minSites=wl["min_sites"], minData=0.01)
+        elif wl["tool"] == "popfreq":
+            st = wb.groupFreqStats()
         elif wl["tool"] == "distmat":
             sums, cnts = wb.indPairSums()
             with np.errstate(divide="ignore", invalid="ignore"):
@@ -198,6 +203,8 @@ def main():
             if wl["tool"] == "popgen":
                 D, C = orc.pair_counts_loop(aln)                     # genomics.py:903-916 + 1042-1047, pair by pair
                 so, _ = orc.group_dist_stats(aln, D, C, True, wl["min_sites"], 0.01)
+            elif wl["tool"] == "popfreq":
+                so = orc.group_freq_stats(aln)
             elif wl["tool"] == "distmat":
                 D, C = orc.pair_counts_loop(aln)
                 so = {}

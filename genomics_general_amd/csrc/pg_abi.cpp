@@ -90,6 +90,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
         if (c->slot[k].packed) (void)hipEventDestroy(c->slot[k].packed);
         if (c->slot[k].consumed) (void)hipEventDestroy(c->slot[k].consumed);
     }
+    if (c->win_ev) (void)hipEventDestroy(c->win_ev);
     (void)hipStreamDestroy(c->stream2);
     drop_events(c);
     c->gt.release();
@@ -102,6 +103,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->tasksCh.release();
     c->flag.release();
     c->out_pin.release();
+    c->win_pin.release();
     c->Cfull.release();
     c->Dfull.release();
     c->Vp.release();
@@ -401,7 +403,13 @@ static int check_windows(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_
 static int stage_windows(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w0, int w1, int64_t *total_words,
                          int *max_words, int64_t *max_len) {
     int n = w1 - w0;
-    std::vector<int64_t> h(3 * (size_t)n + 1);
+    // pinned staging: the copy is asynchronous and needs no synchronisation here (every entry point synchronises
+    // ctx->stream before it returns or before it stages again, so the buffer is never rewritten while in flight)
+    if (c->win_ev) HIPCHK(hipEventSynchronize(c->win_ev));          // previous copy out of the staging buffer is done
+    else HIPCHK(hipEventCreateWithFlags(&c->win_ev, hipEventDisableTiming));
+    int rc0 = c->win_pin.ensure(3 * (size_t)n + 1);
+    if (rc0 != PG_OK) return rc0;
+    int64_t *h = c->win_pin.p;
     int64_t acc = 0;
     int mw = 0;
     int64_t ml = 0;
@@ -419,10 +427,9 @@ static int stage_windows(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w0
     if (total_words) *total_words = acc;
     if (max_words) *max_words = mw;
     if (max_len) *max_len = ml;
-    int rc = c->win.upload(h.data(), h.size(), c->stream);
-    if (rc != PG_OK) return rc;
-    // the host vector dies at return: the copy must have completed
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc0 = c->win.upload(h, 3 * (size_t)n + 1, c->stream);
+    if (rc0 != PG_OK) return rc0;
+    HIPCHK(hipEventRecord(c->win_ev, c->stream));
     return PG_OK;
 }
 
@@ -799,9 +806,12 @@ static int quartet_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_
                        min_data, sel, nsum, c->part_f64.p, c->part_i64.p, c->res_f64.p, c->res_i64.p);
         if ((rc = pg_time_end(c, PG_K_SITESTATS, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(sums_out + (size_t)w0 * nsum, c->res_f64.p, (size_t)nb * nsum * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(used_out + w0, c->res_i64.p, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = c->out_pin.ensure((size_t)nb * (nsum + 1))) != PG_OK) return rc;
+        HIPCHK(hipMemcpyAsync(c->out_pin.p, c->res_f64.p, (size_t)nb * nsum * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->out_pin.p + (size_t)nb * nsum, c->res_i64.p, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(sums_out + (size_t)w0 * nsum, c->out_pin.p, (size_t)nb * nsum * 8);
+        memcpy(used_out + w0, c->out_pin.p + (size_t)nb * nsum, (size_t)nb * 8);
         w0 = w1;
     }
     return PG_OK;
@@ -843,10 +853,13 @@ extern "C" int pg_popfreq(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n
         pg_launch_popfreq(c->stream, c->gt.p, c->S, c->n_hap, c->win.p, c->win.p + nb, nb, max_chunks, c->pop_start.p, P, dl, dS, dP);
         if ((rc = pg_time_end(c, PG_K_SITESTATS, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(l_out + w0, dl, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(S_out + (size_t)w0 * P, dS, (size_t)nb * P * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(pairsum_out + (size_t)w0 * P, dP, (size_t)nb * P * 8, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = c->out_pin.ensure(nres)) != PG_OK) return rc;
+        HIPCHK(hipMemcpyAsync(c->out_pin.p, dl, nres * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        const int64_t *hp = reinterpret_cast<const int64_t *>(c->out_pin.p);
+        memcpy(l_out + w0, hp, (size_t)nb * 8);
+        memcpy(S_out + (size_t)w0 * P, hp + nb, (size_t)nb * P * 8);
+        memcpy(pairsum_out + (size_t)w0 * P, hp + nb + (size_t)nb * P, (size_t)nb * P * 8);
         w0 = w1;
     }
     return PG_OK;

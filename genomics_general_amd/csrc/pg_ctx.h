@@ -117,6 +117,8 @@ struct pg_ctx {
     std::vector<hipEvent_t> event_pool;
     DevBuf<int64_t> res_i64, part_i64;
     HostPin<double> out_pin;     // pinned landing zone of small result tables
+    HostPin<int64_t> win_pin;    // pinned staging of the window table of the site-statistics kernels
+    hipEvent_t win_ev = nullptr; // completion of the last copy out of win_pin
     // timing
     uint32_t time_mask = 0xFFFFFFFFu;   // bit k: kernel family k is bracketed by HIP events (pg_kernel_time_select)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[PG_K_COUNT_];

@@ -523,53 +523,6 @@ __device__ __forceinline__ void range_counts(const uint32_t *__restrict__ row, i
 }
 
 // ------------------------------------------------------------------------------------------------------
-// LDS tile staging for the site-statistics kernels: a block copies TS consecutive site rows (one contiguous TS*S byte
-// region of the site-major buffer) into LDS with fully coalesced 16-byte loads, then each thread owns one site row.
-// (A thread reading its own row straight from global memory touches 64 different cache lines per wave instruction:
-// measured 0.45 TB/s; the staged version is bandwidth-bound.)
-// ------------------------------------------------------------------------------------------------------
-// Double-buffered LDS-DMA tile stream.  A tile = TS = blockDim.x consecutive site rows = one contiguous TS*S byte region,
-// copied with `global_load_lds_dwordx4` (no VGPR staging, 1 KiB per wave instruction, LDS image linear).  Wave w issues
-// K = S/16 instructions per tile, instruction j covering 16-byte chunks [(j*nw+w)*64, +64).  Loop shape per tile:
-//     s_waitcnt vmcnt(0)  ->  s_barrier  ->  issue tile t+1 into the other buffer  ->  compute tile t
-// so the next tile's loads are in flight during the whole compute phase, and the single barrier also guarantees that
-// every wave has finished reading the buffer about to be overwritten.  hipcc does not count asm loads (guide 5.7): the
-// waits are ours.
-#define PG_TILE_LDS_BUDGET (52 * 1024)      // both buffers; keeps 3 blocks per CU
-
-__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-__device__ __forceinline__ void tile_issue(const int8_t *__restrict__ gt, int S, int64_t site0, int ns, uint32_t lds_byte) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6, lane = threadIdx.x & 63;
-    const int K = S >> 4;
-    const int last = ns * K - 1;                         // rows beyond ns are filled with a copy of the last chunk
-    const int8_t *base = gt + site0 * (int64_t)S;
-    for (int j = 0; j < K; ++j) {
-        const int blk = j * nw + wave;
-        int c = blk * 64 + lane;
-        c = c < last ? c : last;
-        glds16(base + (size_t)c * 16u, lds_byte + (uint32_t)blk * 1024u);
-    }
-}
-
-__device__ __forceinline__ void tile_wait_and_sync() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
-static int tile_sites(int S) {              // sites per tile = threads per block (multiple of 64), 0 = row too long for LDS
-    if (S > 1008) return 0;                 // K = S/16 LDS-DMA instructions per wave must stay below the vmcnt range
-    int ts = PG_TILE_LDS_BUDGET / (2 * S);
-    ts = (ts / 64) * 64;
-    if (ts < 64) ts = 64;
-    return ts > 256 ? 256 : ts;
-}
-
-// ------------------------------------------------------------------------------------------------------
 // K_abba: grid (chunk, window).  Per-site terms follow genomics.py:1409-1475 and 1565-1569 operation for operation;
 // per-block partial sums are combined by k_abba_reduce in chunk order (deterministic).
 // ------------------------------------------------------------------------------------------------------
@@ -983,14 +936,13 @@ __device__ __forceinline__ void popfreq_site(const uint32_t *__restrict__ row, i
     }
 }
 
-template <int TILED>
+// Rows longer than 1024 bytes (more than 1024 haplotype slots): one thread per site straight from global memory.
 __global__ __launch_bounds__(256) void k_popfreq(const int8_t *__restrict__ gt, int S, int n_hap,
                                                  const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
                                                  const int32_t *__restrict__ pop_start, int n_pops,
                                                  unsigned long long *__restrict__ l_out,
                                                  unsigned long long *__restrict__ S_out,
                                                  unsigned long long *__restrict__ pairsum_out) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
     __shared__ unsigned long long shu[256];
     const int win = blockIdx.y, chunk = blockIdx.x;
     const int64_t lo = win_lo[win], hi = win_hi[win];
@@ -1001,29 +953,8 @@ __global__ __launch_bounds__(256) void k_popfreq(const int8_t *__restrict__ gt, 
 #pragma unroll
     for (int q = 0; q < PG_MAX_POPS; ++q) { F.Sx[q] = 0; F.Px[q] = 0; }
     const int64_t c1 = (c0 + PG_SITES_PER_BLOCK < hi) ? c0 + PG_SITES_PER_BLOCK : hi;
-    const int TS = blockDim.x;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)tile;
-    const uint32_t buf_bytes = (uint32_t)TS * (uint32_t)S;
-    int it = 0;
-    if (TILED) {
-        const int ns0 = (int)((c1 - c0) < (int64_t)TS ? (c1 - c0) : (int64_t)TS);
-        tile_issue(gt, S, c0, ns0, lds0);
-    }
-    for (int64_t t0 = c0; t0 < c1; t0 += TS, ++it) {
-        const int ns = (int)((c1 - t0) < (int64_t)TS ? (c1 - t0) : (int64_t)TS);
-        if (TILED) {
-            tile_wait_and_sync();
-            if (t0 + TS < c1) {
-                const int nsn = (int)((c1 - t0 - TS) < (int64_t)TS ? (c1 - t0 - TS) : (int64_t)TS);
-                tile_issue(gt, S, t0 + TS, nsn, lds0 + ((it + 1) & 1) * buf_bytes);
-            }
-            const uint32_t *rows = tile + (size_t)(it & 1) * (buf_bytes >> 2);
-            if ((int)threadIdx.x < ns) popfreq_site(rows + (size_t)threadIdx.x * (S >> 2), n_hap, pop_start, n_pops, F);
-        } else {
-            if ((int)threadIdx.x < ns)
-                popfreq_site(reinterpret_cast<const uint32_t *>(gt + (t0 + threadIdx.x) * (int64_t)S), n_hap, pop_start, n_pops, F);
-        }
-    }
+    for (int64_t t = c0 + threadIdx.x; t < c1; t += blockDim.x)
+        popfreq_site(reinterpret_cast<const uint32_t *>(gt + t * (int64_t)S), n_hap, pop_start, n_pops, F);
     __syncthreads();
     unsigned long long r = block_sum_u64(F.l, shu);
     if (threadIdx.x == 0 && r) atomicAdd(&l_out[win], r);
@@ -1035,17 +966,142 @@ __global__ __launch_bounds__(256) void k_popfreq(const int8_t *__restrict__ gt, 
     }
 }
 
+// k_popfreq_q: same structure as k_abba_q.  Screening pass: a site takes part iff every haplotype slot is called
+// (genomics.py:1010); called codes are one-hot and pad bytes zero, so that is popcount(row) == n_hap -- four accumulating
+// v_bcnt per 16-byte piece on fully coalesced loads, summed over the 16 lanes of a row with DPP.  Counting pass, 16 queued
+// sites at a time: lane q of a site's quad counts populations q, q+4, q+8, q+12.
+template <int NPASS>
+__global__ __launch_bounds__(256) void k_popfreq_q(const int8_t *__restrict__ gt, int S, int n_hap,
+                                                   const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
+                                                   const int32_t *__restrict__ pop_start, int n_pops,
+                                                   unsigned long long *__restrict__ l_out,
+                                                   unsigned long long *__restrict__ S_out,
+                                                   unsigned long long *__restrict__ pairsum_out) {
+    __shared__ int64_t cand[4][PG_ABBA_CAND];
+    __shared__ unsigned long long shu[4][4][9];
+    // per-lane accumulators live in LDS (slot k of lane l at [k][l]): the counting pass is the rare path on typical data, and
+    // keeping its state out of the register file lets the screening loop hold more row loads in flight
+    __shared__ unsigned long long lacc[4][9][64];
+    const int win = blockIdx.y, chunk = blockIdx.x;
+    const int64_t lo = win_lo[win], hi = win_hi[win];
+    const int64_t c0 = lo + (int64_t)chunk * PG_ABBA_SITES_PER_BLOCK;
+    if (c0 >= hi) return;
+    const int64_t c1 = (c0 + PG_ABBA_SITES_PER_BLOCK < hi) ? c0 + PG_ABBA_SITES_PER_BLOCK : hi;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane & 3, sub = lane & 15, rsel = lane >> 4;
+    int64_t *my_cand = cand[wave];
+    int chead = 0, ctail = 0;
+    unsigned long long (*my_acc)[64] = lacc[wave];
+#pragma unroll
+    for (int z = 0; z < 9; ++z) my_acc[z][lane] = 0ull;          // l, Sx[0..3], Px[0..3] for populations q, q+4, q+8, q+12
+    auto count_sites = [&](int64_t site, bool valid) {
+        if (!valid) return;
+        const int8_t *rowb = gt + site * (int64_t)S;
+        if (q == 0) my_acc[0][lane] += 1ull;
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int p = q + 4 * j;
+            if (p < n_pops) {
+                uint32_t c[4];
+                range_counts_x4(rowb, pop_start[p], pop_start[p + 1], c);
+                const unsigned long long pr = (unsigned long long)c[0] * c[1] + (unsigned long long)c[0] * c[2] +
+                                              (unsigned long long)c[0] * c[3] + (unsigned long long)c[1] * c[2] +
+                                              (unsigned long long)c[1] * c[3] + (unsigned long long)c[2] * c[3];
+                my_acc[1 + j][lane] += (pr != 0ull);
+                my_acc[5 + j][lane] += pr;
+            }
+        }
+    };
+    constexpr int GROUPS = 16 / NPASS, SPW = 4 * GROUPS;
+    for (int64_t t0 = c0 + SPW * wave; t0 < c1; t0 += 4 * SPW) {
+        uint4 v[GROUPS][NPASS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const int64_t site = t0 + 4 * g + rsel;
+            const int8_t *rowb = gt + site * (int64_t)S;
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const int off = p * 256 + sub * 16;
+                v[g][p] = make_uint4(0u, 0u, 0u, 0u);
+                if (site < c1 && off < S) v[g][p] = *reinterpret_cast<const uint4 *>(rowb + off);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const int64_t site = t0 + 4 * g + rsel;
+            uint32_t cnt = 0u;
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p)
+                cnt += __popc(v[g][p].x) + __popc(v[g][p].y) + __popc(v[g][p].z) + __popc(v[g][p].w);
+#define PG_DPP_ROW_ADD(ctrl) cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, ctrl, 0xf, 0xf, false)
+            PG_DPP_ROW_ADD(0x111);        // row_shr:1
+            PG_DPP_ROW_ADD(0x112);        // row_shr:2
+            PG_DPP_ROW_ADD(0x114);        // row_shr:4
+            PG_DPP_ROW_ADD(0x118);        // row_shr:8 -> lane 15 of each 16-lane row holds the row's popcount
+#undef PG_DPP_ROW_ADD
+            const bool is_cand = sub == 15 && site < c1 && (int)cnt == n_hap;
+            const unsigned long long bal = __ballot(is_cand);
+            if (is_cand) my_cand[(ctail + __popcll(bal & ((1ull << lane) - 1ull))) & (PG_ABBA_CAND - 1)] = site;
+            ctail += (int)__popcll(bal);
+        }
+        while (ctail - chead >= 16) {
+            count_sites(my_cand[(chead + (lane >> 2)) & (PG_ABBA_CAND - 1)], true);
+            chead += 16;
+        }
+    }
+    if (ctail > chead) {
+        const bool valid = (lane >> 2) < ctail - chead;
+        count_sites(valid ? my_cand[(chead + (lane >> 2)) & (PG_ABBA_CAND - 1)] : c0, valid);
+    }
+    // lanes with equal q: butterfly over lane bits 2..5, then the four waves through LDS; exact integers, any order
+    unsigned long long acc[9];
+#pragma unroll
+    for (int z = 0; z < 9; ++z) acc[z] = my_acc[z][lane];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int m = 32; m >= 4; m >>= 1) acc[k] += __shfl_xor(acc[k], m, 64);
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) shu[wave][lane][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        unsigned long long t[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t[k] = shu[0][q][k] + shu[1][q][k] + shu[2][q][k] + shu[3][q][k];
+        if (q == 0 && t[0]) atomicAdd(&l_out[win], t[0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = q + 4 * j;
+            if (p < n_pops) {
+                if (t[1 + j]) atomicAdd(&S_out[(size_t)win * n_pops + p], t[1 + j]);
+                if (t[5 + j]) atomicAdd(&pairsum_out[(size_t)win * n_pops + p], t[5 + j]);
+            }
+        }
+    }
+}
+
 void pg_launch_popfreq(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
                        const int64_t *win_hi, int n_win, int max_chunks, const int32_t *pop_start, int n_pops,
                        unsigned long long *l_out, unsigned long long *S_out, unsigned long long *pairsum_out) {
     if (n_win <= 0 || max_chunks <= 0) return;
-    const int ts = tile_sites(S);
-    if (ts >= 64)
-        hipLaunchKernelGGL(k_popfreq<1>, dim3(max_chunks, n_win), dim3(ts), (size_t)2 * ts * S, st, gt, S, n_hap, win_lo, win_hi,
-                           pop_start, n_pops, l_out, S_out, pairsum_out);
-    else
-        hipLaunchKernelGGL(k_popfreq<0>, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, n_hap, win_lo, win_hi, pop_start,
-                           n_pops, l_out, S_out, pairsum_out);
+    const int npass = (S + 255) / 256;
+    if (npass <= 4) {                 // rows up to 1024 bytes: screening + counting kernel, 4096-site blocks
+        const int chunks_q = (int)(((int64_t)max_chunks * PG_SITES_PER_BLOCK + PG_ABBA_SITES_PER_BLOCK - 1) / PG_ABBA_SITES_PER_BLOCK);
+        const dim3 grid(chunks_q, n_win);
+#define PG_POPFREQ_LAUNCH(NP)                                                                                           \
+    hipLaunchKernelGGL((k_popfreq_q<NP>), grid, dim3(256), 0, st, gt, S, n_hap, win_lo, win_hi, pop_start, n_pops, l_out, \
+                       S_out, pairsum_out)
+        if (npass == 1) PG_POPFREQ_LAUNCH(1);
+        else if (npass == 2) PG_POPFREQ_LAUNCH(2);
+        else PG_POPFREQ_LAUNCH(4);
+#undef PG_POPFREQ_LAUNCH
+        return;
+    }
+    hipLaunchKernelGGL(k_popfreq, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, n_hap, win_lo, win_hi, pop_start, n_pops,
+                       l_out, S_out, pairsum_out);
 }
 
 // ------------------------------------------------------------------------------------------------------

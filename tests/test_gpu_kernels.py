@@ -124,8 +124,11 @@ def test_fourpop_sums(mode, n_dip, min_data, miss):
     e.close()
 
 
-def test_group_freq_stats_exact_integers():
-    e, lay, codes, _ = G.make_engine(10, 2, 5000, seed=55, miss_thr=400)
+@pytest.mark.parametrize("n_dip,n_pops,miss", [(10, 2, 400), (24, 6, 150),      # six populations: lanes own pops q and q+4
+                                                (150, 3, 20), (300, 3, 10),      # 304- and 608-byte rows
+                                                (600, 2, 5)])                    # 1200-byte rows: thread-per-site kernel
+def test_group_freq_stats_exact_integers(n_dip, n_pops, miss):
+    e, lay, codes, _ = G.make_engine(n_dip, n_pops, 5000, seed=55, miss_thr=miss)
     wins = [(0, 2500), (2500, 5000), (17, 18)]
     got = e.batch([w[0] for w in wins], [w[1] for w in wins]).groupFreqStats()
     for k, (a, b) in enumerate(wins):
