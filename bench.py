@@ -101,9 +101,8 @@ def main():
         elif wl["tool"] == "popfreq":
             st = wb.groupFreqStats()
         elif wl["tool"] == "distmat":
-            sums, cnts = wb.indPairSums()
-            with np.errstate(divide="ignore", invalid="ignore"):
-                return {"d": sums / cnts}, sums
+            tab = wb.indPairTable()                  # finished individual-pair means, [window][pair]
+            return {"d": tab}, tab
         else:
             st = wb.ABBABABA("pop0", "pop1", "pop2", "pop3", 0.01)
         keys = sorted(k for k in st if k != "sitesUsed")

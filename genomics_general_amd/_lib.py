@@ -56,6 +56,7 @@ SIGNATURES = {
     "pg_popdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
     "pg_popdist_stats": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_double, C.c_int, _f64p]),
     "pg_indpairdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
+    "pg_indpairdist_mean": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, _f64p]),
     "pg_abbababa": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _f64p, _i64p]),
     "pg_fourpop": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _f64p,
                              _i64p]),
@@ -63,6 +64,8 @@ SIGNATURES = {
     "pg_hap_called": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p]),
     "pg_site_counts": (C.c_int, [_P, C.c_int64, C.c_int64, _i32p]),
     "pg_kernel_time": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pg_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pg_host_free": (C.c_int, [C.c_void_p]),
     "pg_kernel_time_select": (C.c_int, [_P, C.c_uint32]),
     "pg_kernel_time_reset": (C.c_int, [_P]),
     "pg_set_scratch_limit": (C.c_int, [_P, C.c_int64]),

@@ -592,12 +592,13 @@ def distmat_main(argv=None):
         if args.minPerInd:
             called = wb.hapCalled()
             table[good, npairs] = (called.min(axis=1) >= args.minPerInd).astype(np.float64)
-        pdd = wb.indPairDists(includeSameWithSame=args.includeSameWithSame)
-        col = 0
-        for i in range(n):
-            for j in range(i, n):
-                table[good, col] = pdd[samples[i]][samples[j]]
-                col += 1
+        tab = wb.indPairTable(includeSameWithSame=args.includeSameWithSame)
+        # column (i<=j in --samples order) <- pair index in the engine's slot order of the individuals
+        pos_of = {nm: k for k, nm in enumerate(lay.ind_order)}
+        si = np.array([pos_of[nm] for nm in samples], dtype=np.int64)
+        iu0 = np.triu_indices(n)
+        a, b = np.minimum(si[iu0[0]], si[iu0[1]]), np.maximum(si[iu0[0]], si[iu0[1]])
+        table[good, :npairs] = tab[:, a * n - a * (a - 1) // 2 + (b - a)]
     full = run.gather(table)
 
     if run.world.rank == 0:

@@ -131,6 +131,18 @@ extern "C" int pg_sync(pg_ctx *c) {
     return PG_OK;
 }
 
+extern "C" int pg_host_alloc(size_t bytes, void **ptr_out) {
+    if (!ptr_out) return pg_fail(PG_ERR_ARG, "pg_host_alloc: null argument");
+    *ptr_out = nullptr;
+    HIPCHK(hipHostMalloc(ptr_out, bytes ? bytes : 1, hipHostMallocDefault));
+    return PG_OK;
+}
+
+extern "C" int pg_host_free(void *ptr) {
+    if (ptr) HIPCHK(hipHostFree(ptr));
+    return PG_OK;
+}
+
 extern "C" int pg_set_scratch_limit(pg_ctx *c, int64_t bytes) {
     if (!c || bytes < (64ll << 20)) return pg_fail(PG_ERR_ARG, "scratch limit must be >= 64 MiB");
     c->scratch_limit = bytes;
@@ -754,27 +766,38 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
     return fetch();
 }
 
-extern "C" int pg_indpairdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites,
-                              double *sum_out, int64_t *cnt_out) {
+static int indpair_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites, int mean_mode,
+                       double *sum_out, int64_t *cnt_out) {
     int rc = check_windows(c, lo, hi, n_win);
     if (rc != PG_OK) return rc;
-    if (n_win > 0 && (!sum_out || !cnt_out)) return pg_fail(PG_ERR_ARG, "null output");
+    if (n_win > 0 && (!sum_out || (!cnt_out && mean_mode == 0))) return pg_fail(PG_ERR_ARG, "null output");
     HIPCHK(hipSetDevice(c->device));
     const size_t npairs = (size_t)c->n_samp * (c->n_samp + 1) / 2;
     // results are copied back per batch (they can be large for distMat-sized inputs)
     rc = pairwise_run(c, lo, hi, n_win, [&](int w0, int nb) -> int {
         int r;
         if ((r = c->res_f64.ensure((size_t)nb * npairs)) != PG_OK) return r;
-        if ((r = c->res_i64.ensure((size_t)nb * npairs)) != PG_OK) return r;
+        if (mean_mode == 0 && (r = c->res_i64.ensure((size_t)nb * npairs)) != PG_OK) return r;
         pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->samp_start.p, c->n_samp, min_pair_sites,
-                              c->res_f64.p, c->res_i64.p);
+                              c->res_f64.p, c->res_i64.p, mean_mode);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sum_out + (size_t)w0 * npairs, c->res_f64.p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(cnt_out + (size_t)w0 * npairs, c->res_i64.p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->stream));
+        if (mean_mode == 0)
+            HIPCHK(hipMemcpyAsync(cnt_out + (size_t)w0 * npairs, c->res_i64.p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         return PG_OK;
     });
     return rc;
+}
+
+extern "C" int pg_indpairdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites,
+                              double *sum_out, int64_t *cnt_out) {
+    return indpair_run(c, lo, hi, n_win, min_pair_sites, 0, sum_out, cnt_out);
+}
+
+extern "C" int pg_indpairdist_mean(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites,
+                                   int diag_counts_zeros, double *d_out) {
+    return indpair_run(c, lo, hi, n_win, min_pair_sites, diag_counts_zeros ? 2 : 1, d_out, nullptr);
 }
 
 // ---- site statistics --------------------------------------------------------------------------------

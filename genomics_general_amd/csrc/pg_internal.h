@@ -45,7 +45,7 @@ void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *D
 
 void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,
-                           int64_t *cnt_out);
+                           int64_t *cnt_out, int mean_mode);
 
 void pg_launch_mirror(hipStream_t st, int32_t *Cmat, int32_t *Dmat, int N, int n_win);
 

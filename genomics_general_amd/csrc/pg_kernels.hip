@@ -454,7 +454,7 @@ void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts,
 __global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat,
                                                      int N, int cN, int cshift, const int32_t *__restrict__ samp_start, int n_samp,
                                                      int min_pair_sites, double *__restrict__ sum_out,
-                                                     int64_t *__restrict__ cnt_out) {
+                                                     int64_t *__restrict__ cnt_out, int mean_mode) {
     const int win = blockIdx.y;
     const long long npairs = (long long)n_samp * (n_samp + 1) / 2;
     const int32_t *Cw = Cmat + (size_t)win * cN * cN;
@@ -479,20 +479,31 @@ __global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__
                 const int c = Cw[(size_t)(a >> cshift) * cN + (b >> cshift)];
                 if (c >= thr) { sum += (double)Dw[(size_t)a * N + b] / (double)c; ++cnt; }
             }
-        sum_out[(size_t)win * npairs + pidx] = sum;
-        cnt_out[(size_t)win * npairs + pidx] = cnt;
+        if (mean_mode == 0) {
+            sum_out[(size_t)win * npairs + pidx] = sum;
+            cnt_out[(size_t)win * npairs + pidx] = cnt;
+        } else {
+            // nanmean of the haplotype block (genomics.py:946-947): within an individual the symmetric block holds every pair
+            // twice, plus, when the diagonal counts as data (includeSameWithSame, genomics.py:940), one zero per haplotype
+            const double nan = __longlong_as_double(0x7ff8000000000000ll);
+            double v;
+            if (s != t) v = cnt > 0 ? sum / (double)cnt : nan;
+            else if (mean_mode == 1) v = cnt > 0 ? (2 * sum) / (double)(2 * cnt) : nan;
+            else v = (2 * sum) / (double)(2 * cnt + (samp_start[s + 1] - samp_start[s]));
+            sum_out[(size_t)win * npairs + pidx] = v;
+        }
     }
 }
 
 void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,
-                           int64_t *cnt_out) {
+                           int64_t *cnt_out, int mean_mode) {
     if (n_win <= 0 || n_samp <= 0) return;
     long long npairs = (long long)n_samp * (n_samp + 1) / 2;
     int bx = (int)((npairs + 255) / 256);
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(k_indpair_fin, dim3(bx, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, samp_start, n_samp,
-                       min_pair_sites, sum_out, cnt_out);
+                       min_pair_sites, sum_out, cnt_out, mean_mode);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -40,6 +40,47 @@ def encode_text(buf, layout, n_threads=0, head_rows=0):
     return gt[:k], pos[:k], soff[:k], slen[:k]
 
 
+class PinnedPool:
+    """NumPy arrays in page-locked host memory (pg_host_alloc) for large results: device-to-host copies into them run at
+    PCIe speed.  A buffer returns to the pool when its array is garbage collected; the pool keeps at most `keep` bytes."""
+
+    def __init__(self, keep=1 << 30):
+        self._free = {}                  # nbytes -> [address]
+        self._held = 0
+        self._keep = keep
+        self._L = _lib.lib()
+
+    def _release(self, addr, nbytes):
+        if self._held + nbytes <= self._keep:
+            self._free.setdefault(nbytes, []).append(addr)
+            self._held += nbytes
+        else:
+            self._L.pg_host_free(C.c_void_p(addr))
+
+    def zeros(self, shape, dtype):
+        arr = self.empty(shape, dtype)
+        arr[...] = 0
+        return arr
+
+    def empty(self, shape, dtype):
+        import weakref
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape))
+        nbytes = max(count * dtype.itemsize, 1)
+        lst = self._free.get(nbytes)
+        if lst:
+            addr = lst.pop()
+            self._held -= nbytes
+        else:
+            p = C.c_void_p()
+            check(self._L.pg_host_alloc(nbytes, C.byref(p)))
+            addr = p.value
+        buf = (C.c_char * nbytes).from_address(addr)
+        arr = np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+        weakref.finalize(buf, self._release, addr, nbytes)        # buf lives as long as any view of it
+        return arr
+
+
 class Engine:
     """One device context (pg_ctx).  Not thread-safe; one per GPU."""
 
@@ -51,6 +92,7 @@ class Engine:
         self.device = device
         self.layout = None
         self.n_sites = 0
+        self.pinned = PinnedPool()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -309,21 +351,24 @@ class WindowBatch:
         """Raw K6 output (pg_indpairdist): sums of D/C and valid-pair counts per unordered individual pair."""
         n = self.lay.n_samp
         npairs = n * (n + 1) // 2
-        sums = np.zeros((self.n, npairs), dtype=np.float64)
-        cnts = np.zeros((self.n, npairs), dtype=np.int64)
+        big = self.n * npairs * 8 >= (1 << 20)            # large tables land in page-locked memory (direct DMA)
+        alloc = self.e.pinned.empty if big else np.zeros   # fully overwritten by the copy back
+        sums = alloc((self.n, npairs), np.float64)
+        cnts = alloc((self.n, npairs), np.int64)
         check(self.e._L.pg_indpairdist(self.e._h, self.lo, self.hi, self.n, int(minSites) if minSites else 0, sums, cnts))
         return sums, cnts
 
     # -- indPairDist -------------------------------------------------------------------------------------
-    def indPairDists(self, includeSameWithSame=False, minSites=None):
-        """{name: {name: array over windows}} like Alignment.indPairDists(asDict=True).  As in the reference
-        (which mutates its cached distance matrix), a preceding groupDistStats leaves its minSites mask and nan
-        diagonal in force."""
+    def indPairTable(self, includeSameWithSame=False, minSites=None):
+        """Alignment.indPairDists as one array [window][pair]: the nanmean of every individual pair's haplotype block, finished
+        on the device (pg_indpairdist_mean).  Pair (s<=t) in slot order of the individuals sits at lay.sample_pair_index(s,t).
+        As in the reference (which mutates its cached distance matrix), a preceding groupDistStats leaves its minSites mask
+        and nan diagonal in force."""
         lay = self.lay
         n = lay.n_samp
         npairs = n * (n + 1) // 2
-        sums = np.zeros((self.n, npairs), dtype=np.float64)
-        cnts = np.zeros((self.n, npairs), dtype=np.int64)
+        # fully overwritten by the copy back; large tables land in page-locked memory (direct DMA)
+        tab = (self.e.pinned.empty if self.n * npairs * 8 >= (1 << 20) else np.zeros)((self.n, npairs), np.float64)
         ms = int(minSites) if minSites else 0
         diag_nan = not includeSameWithSame
         if self._popdist_min_sites is not None:
@@ -333,19 +378,18 @@ class WindowBatch:
             self._diag_nan = True
         if minSites:
             self._popdist_min_sites = max(int(minSites), self._popdist_min_sites or 0)   # the mask stays in the cache
-        check(self.e._L.pg_indpairdist(self.e._h, self.lo, self.hi, self.n, ms, sums, cnts))
+        check(self.e._L.pg_indpairdist_mean(self.e._h, self.lo, self.hi, self.n, ms, 0 if diag_nan else 1, tab))
+        return tab
+
+    def indPairDists(self, includeSameWithSame=False, minSites=None):
+        """{name: {name: array over windows}} like Alignment.indPairDists(asDict=True); views into indPairTable()."""
+        lay = self.lay
+        n = lay.n_samp
+        tab = self.indPairTable(includeSameWithSame, minSites)
         out = {a: {} for a in lay.ind_order}
         for s in range(n):
-            pl = len(lay.ind_slots[lay.ind_order[s]])
             for t in range(s, n):
-                k = lay.sample_pair_index(s, t)
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    if s != t:
-                        v = np.where(cnts[:, k] > 0, sums[:, k] / cnts[:, k], np.nan)
-                    elif diag_nan:
-                        v = np.where(cnts[:, k] > 0, (2 * sums[:, k]) / (2 * cnts[:, k]), np.nan)
-                    else:       # the zero diagonal of distMatrix() counts as data (genomics.py:940)
-                        v = (2 * sums[:, k]) / (2 * cnts[:, k] + pl)
+                v = tab[:, lay.sample_pair_index(s, t)]
                 out[lay.ind_order[s]][lay.ind_order[t]] = v
                 out[lay.ind_order[t]][lay.ind_order[s]] = v
         return out

@@ -130,6 +130,13 @@ int pg_popdist_stats(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, 
 int pg_indpairdist(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites,
                    double *sum_out, int64_t *cnt_out);
 
+/* The finished means instead of sums and counts (one array, half the bytes to copy back): d_out[n_win][pairs] =
+ * nanmean of the haplotype-pair block of individuals (s,t) exactly as Alignment.indPairDists forms it (genomics.py:946-947):
+ * s != t: sum/count (nan when no haplotype pair qualifies); s == t: the symmetric block holds every pair twice, and with
+ * diag_counts_zeros != 0 (includeSameWithSame, genomics.py:940) one zero per haplotype counts as data. */
+int pg_indpairdist_mean(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites,
+                        int diag_counts_zeros, double *d_out);
+
 /* ---- K1+K4: ABBA-BABA window sums ------------------------------------------------------------------ */
 /* Replaces genomics.ABBABABA(polarize=True) (genomics.py:1647-1695) with f4/D/fd/fdm/ABBA/BABA
  * (genomics.py:1409-1475, 1565-1569).  sums_out[n_win][6] = { sum f4(p1,p2,p3,p4), sum (ABBA+BABA),
@@ -176,6 +183,13 @@ int pg_kernel_time_select(pg_ctx *ctx, uint32_t mask);
 int pg_kernel_time_reset(pg_ctx *ctx);
 /* scratch budget (bytes) for per-batch bit-planes + matrices; default 16 GiB */
 int pg_set_scratch_limit(pg_ctx *ctx, int64_t bytes);
+
+/* ---- page-locked host memory ---------------------------------------------------------------------------- */
+/* Output arrays handed to this library may live anywhere; when they are page-locked (allocated here) the device-to-host
+ * copies of large results (pg_indpairdist, pg_pairwise) run as direct DMA at PCIe speed instead of through the runtime's
+ * bounce buffer.  Plain hipHostMalloc / hipHostFree, exposed so that a host without HIP bindings can use them. */
+int pg_host_alloc(size_t bytes, void **ptr_out);
+int pg_host_free(void *ptr);
 
 /* ---- C1: multi-GPU result gather (RCCL over xGMI), one process per GPU ----------------------------- */
 /* Replaces the sorter/writer threads' re-ordering role (popgenWindows.py:108-157).  uid is 128 bytes. */
