@@ -21,6 +21,7 @@ struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,r
 
 struct PgTask2 {                // one wave of k_pairC / k_pairD: rows [row0,row0+8*nsub) x cols [col0,col0+64)
     int32_t row0, nsub, col0, lower;   // lower = 1: remainder rows, the valid pairs are those with col < row
+                                       // lower = 2: circulant task of k_pairC (pair_store_circ), nsub = number of valid columns
 };
 
 struct PgSynthParams {

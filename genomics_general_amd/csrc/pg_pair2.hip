@@ -399,6 +399,30 @@ __device__ __forceinline__ void pair_store(const uint32_t (&acc)[R], int row0, i
     }
 }
 
+// Circulant tasks (k_pairC): row i owns the unordered pairs {i, i+d}, d = 1 .. floor(n/2) (indices mod n; for even n the pairs
+// at distance n/2 belong to the smaller index), plus the diagonal when asked for.  The columns of a task are
+// col0, col0+1, ... (mod n), `nvalid` of them; a row block of 8 therefore needs 8 + floor(n/2) consecutive columns, i.e. one
+// wave up to 112 units, instead of the rectangles of a triangular tiling that leave half of the diagonal blocks' lanes idle.
+__device__ __forceinline__ void pair_store_circ(const uint32_t (&acc)[8], int row0, int col0, int lane, int nvalid, int n, int diag,
+                                                int atomic, int32_t *__restrict__ M) {
+    if (lane >= nvalid) return;
+    int j = col0 + lane;
+    if (j >= n) j -= n;
+    const int h = n >> 1;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = row0 + r;
+        if (i >= n) continue;
+        int d = j - i;
+        if (d < 0) d += n;
+        const bool keep = d == 0 ? (diag != 0) : (d <= h && !(2 * d == n && i > j));
+        if (!keep) continue;
+        int32_t *dst = i <= j ? &M[(size_t)i * n + j] : &M[(size_t)j * n + i];
+        if (atomic) { if (acc[r]) atomicAdd(dst, (int32_t)acc[r]); }
+        else *dst = (int32_t)acc[r];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // k_pairC: units x units "both called" counts.  Wave = 8*NSUB rows (SGPR operands) x 64 columns, 4 words per iteration.
 // ------------------------------------------------------------------------------------------------------
@@ -417,8 +441,9 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
 #include "pg_pairc_loop.inc"
 
 __device__ __forceinline__ void pairC_body(const uint32_t *__restrict__ Vp, int64_t vg0, int nwq, int NPv, const PairCtx &c,
-                                           uint32_t (&acc)[8]) {
-    const int j = c.col0 + c.lane;
+                                           uint32_t (&acc)[8], int n_units) {
+    int j = c.col0 + c.lane;
+    if (c.lower == 2 && j >= n_units) j -= n_units;                  // circulant task: columns wrap around
     const uint32_t stride = (uint32_t)NPv * 16u;                       // bytes per word group
     // 32-bit byte offsets inside the asm loop: at most PG_PAIRC_CHUNK word groups per call (NPv <= 4096 -> < 4 GiB)
     constexpr int PG_PAIRC_CHUNK = 32768;
@@ -451,9 +476,12 @@ __global__ __launch_bounds__(256) void k_pairC(const uint32_t *__restrict__ Vp, 
     uint32_t acc[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = 0u;
-    if (q1 > q0) pairC_body(Vp, vg_all + q0, q1 - q0, NPv, c, acc);       // tasks of k_pairC have nsub == 1
-    if (block_reduce<8>(acc, red, c.lane))
-        pair_store<8>(acc, c.row0, c.col0 + c.lane, n_units, c.lower, diag, kso > 1, Cmat + (size_t)c.win * n_units * n_units);
+    if (q1 > q0) pairC_body(Vp, vg_all + q0, q1 - q0, NPv, c, acc, n_units);
+    if (block_reduce<8>(acc, red, c.lane)) {
+        int32_t *Cw = Cmat + (size_t)c.win * n_units * n_units;
+        if (c.lower == 2) pair_store_circ(acc, c.row0, c.col0, c.lane, c.nsub, n_units, diag, kso > 1, Cw);
+        else pair_store<8>(acc, c.row0, c.col0 + c.lane, n_units, c.lower, diag, kso > 1, Cw);
+    }
 }
 
 // extra cut of the word range across blocks: wanted when windows x tasks x 4 waves cannot fill 256 CUs x 4 SIMDs x 8
