@@ -40,6 +40,11 @@ typedef __attribute__((address_space(4))) const uint32_t CU32;
 //   works on n_hap/2 units, 4x fewer pairs).  A window in which the two haplotypes of some individual differ in calledness
 //   raises *mismatch; the host then redoes the batch with DIP = 0.
 // ------------------------------------------------------------------------------------------------------
+// 16-byte store of plane words (non-temporal stores and non-temporal row loads were measured: no gain / slower)
+__device__ __forceinline__ void store16(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    *reinterpret_cast<uint4 *>(p) = make_uint4(a, b, c, d);
+}
+
 // 4x4 byte transpose: r[k] = { t0.byte k, t1.byte k, t2.byte k, t3.byte k }
 __device__ __forceinline__ void btrans4(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t r[4]) {
     const uint32_t lo01 = __builtin_amdgcn_perm(t1, t0, 0x05010400u), hi01 = __builtin_amdgcn_perm(t1, t0, 0x07030602u);
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
             uint32_t *o = xv_base + (size_t)nflush * PG_XV_PLANES * (size_t)NP + h0;
 #pragma unroll
             for (int p = 0; p < PG_XV_PLANES; ++p)
-                *reinterpret_cast<uint4 *>(o + (size_t)p * NP) = make_uint4(x[p][0], x[p][1], x[p][2], x[p][3]);
+                store16(o + (size_t)p * NP, x[p][0], x[p][1], x[p][2], x[p][3]);
         }
         ++nflush;
     };
@@ -293,13 +298,13 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
         if (in_npv) {
             if (DIP) {
                 uint32_t *o = Vp + ((size_t)(vg_base + wq) * NPv + u0) * 4u;
-                *reinterpret_cast<uint4 *>(o) = make_uint4(vhold[0][0], vhold[0][1], vhold[0][2], vhold[0][3]);
-                *reinterpret_cast<uint4 *>(o + 4) = make_uint4(vhold[2][0], vhold[2][1], vhold[2][2], vhold[2][3]);
+                store16(o, vhold[0][0], vhold[0][1], vhold[0][2], vhold[0][3]);
+                store16(o + 4, vhold[2][0], vhold[2][1], vhold[2][2], vhold[2][3]);
             } else {
                 uint32_t *o = Vp + ((size_t)(vg_base + wq) * NPv + u0) * 4u;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    *reinterpret_cast<uint4 *>(o + 4 * k) = make_uint4(vhold[k][0], vhold[k][1], vhold[k][2], vhold[k][3]);
+                    store16(o + 4 * k, vhold[k][0], vhold[k][1], vhold[k][2], vhold[k][3]);
             }
         }
     }
