@@ -88,11 +88,16 @@ extern "C" int pg_comm_allgather_f64(pg_ctx *c, const double *send, double *recv
     if (count == 0) return PG_OK;
     HIPCHK(hipSetDevice(c->device));
     int rc;
-    if ((rc = c->comm_send.upload(send, (size_t)count, c->stream)) != PG_OK) return rc;
-    if ((rc = c->comm_recv.ensure((size_t)count * c->comm_ranks)) != PG_OK) return rc;
+    // page-locked staging on both sides: [send | recv], asynchronous copies, one synchronisation
+    const size_t n_recv = (size_t)count * c->comm_ranks;
+    if ((rc = c->comm_pin.ensure((size_t)count + n_recv)) != PG_OK) return rc;
+    memcpy(c->comm_pin.p, send, (size_t)count * 8);
+    if ((rc = c->comm_send.upload(c->comm_pin.p, (size_t)count, c->stream)) != PG_OK) return rc;
+    if ((rc = c->comm_recv.ensure(n_recv)) != PG_OK) return rc;
     RCCLCHK(api.AllGather(c->comm_send.p, c->comm_recv.p, (size_t)count, RCCL_FLOAT64, c->comm, c->stream));
-    HIPCHK(hipMemcpyAsync(recv, c->comm_recv.p, (size_t)count * c->comm_ranks * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->comm_pin.p + count, c->comm_recv.p, n_recv * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(recv, c->comm_pin.p + count, n_recv * 8);
     return PG_OK;
 }
 
@@ -114,5 +119,6 @@ extern "C" int pg_comm_destroy(pg_ctx *c) {
     c->comm = nullptr;
     c->comm_send.release();
     c->comm_recv.release();
+    c->comm_pin.release();
     return PG_OK;
 }

@@ -128,6 +128,7 @@ struct pg_ctx {
     void *comm = nullptr;
     int comm_ranks = 0, comm_rank = 0;
     DevBuf<double> comm_send, comm_recv;
+    HostPin<double> comm_pin;    // page-locked staging of the all-gather
 };
 
 std::vector<PgTask2> pg_make_tasks2(int n, int max_nsub, int diag);

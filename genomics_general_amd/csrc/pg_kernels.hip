@@ -656,6 +656,44 @@ __device__ __forceinline__ uint32_t range_presence_x4(const int8_t *__restrict__
     return acc & 0xFu;
 }
 
+// Row loads of the screening passes (k_abba_q, k_popfreq_q): 16 lanes per row, NPASS passes of 256 bytes, 4 rows per
+// instruction, GROUPS instructions per pass and step.
+typedef uint32_t pg_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int GROUPS, int NPASS>
+struct ScreenLoads {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff[NPASS];                  // lane offset of pass p; beyond the descriptor for lanes past the end of a row
+    int soff[GROUPS];                 // g * 4 rows, kept in SGPRs
+    int S;
+    int64_t c0;
+    __device__ __forceinline__ ScreenLoads(const int8_t *gt, int S_, int64_t c0_, int64_t c1, int sub, int rsel) : S(S_), c0(c0_) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(gt + c0_ * (int64_t)S_), 0, (int)(c1 - c0_) * S_, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int off = p * 256 + sub * 16;
+            voff[p] = off < S_ ? rsel * S_ + off : 0x7ffffff0;
+        }
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            int t = g * 4 * S_;
+            asm volatile("" : "+s"(t));
+            soff[g] = t;
+        }
+    }
+    __device__ __forceinline__ void issue(int64_t t0, uint4 (&v)[GROUPS][NPASS]) const {
+        const int64_t rel = t0 - c0;
+        const int base = rel < (1 << 20) ? (int)rel * S : 0x7ffffff0;          // far past the block: everything reads as zero
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g)
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const pg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[p] + base, soff[g], 0);
+                v[g][p] = make_uint4(r.x, r.y, r.z, r.w);
+            }
+    }
+};
+
 #define PG_ABBA_RING 128          // per-wave ring of usable sites waiting for the float64 phase
 #define PG_ABBA_CAND 128          // per-wave ring of candidate (biallelic) sites waiting for the counting pass
 
@@ -794,28 +832,17 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
                     umask[p][k] = m;
                 }
         }
-        // sites per wave step: 16 row loads are in flight per lane before the first one is used
-        constexpr int GROUPS = NPASS > 0 ? 16 / NPASS : 4, SPW = 4 * GROUPS;
-        for (int64_t t0 = c0 + SPW * wave; t0 < c1; t0 += 4 * SPW) {
-            if (NPASS > 0) {
-                uint4 v[GROUPS][NPASS > 0 ? NPASS : 1];
-#pragma unroll
-                for (int g = 0; g < GROUPS; ++g) {
-                    const int64_t site = t0 + 4 * g + rsel;
-                    const int8_t *rowb = gt + site * (int64_t)S;
-#pragma unroll
-                    for (int p = 0; p < NPASS; ++p) {
-                        const int off = p * 256 + sub * 16;
-                        v[g][p] = make_uint4(0u, 0u, 0u, 0u);
-                        if (site < c1 && off < S) v[g][p] = *reinterpret_cast<const uint4 *>(rowb + off);
-                    }
-                }
+        if (NPASS > 0) {
+            // see ScreenLoads: zero-filling buffer loads, the loads of step k+1 issued before step k is processed
+            constexpr int GROUPS = NPASS > 0 ? 8 / NPASS : 1, SPW = 4 * GROUPS, NP1 = NPASS > 0 ? NPASS : 1;
+            const ScreenLoads<GROUPS, NP1> sl(gt, S, c0, c1, sub, rsel);
+            auto process = [&](int64_t t0, const uint4 (&v)[GROUPS][NP1]) {
 #pragma unroll
                 for (int g = 0; g < GROUPS; ++g) {
                     const int64_t site = t0 + 4 * g + rsel;
                     uint32_t acc = 0u;
 #pragma unroll
-                    for (int p = 0; p < NPASS; ++p)
+                    for (int p = 0; p < NP1; ++p)
                         acc |= (v[g][p].x & umask[p][0]) | (v[g][p].y & umask[p][1]) | (v[g][p].z & umask[p][2]) |
                                (v[g][p].w & umask[p][3]);
 #define PG_DPP_ROW_OR(ctrl) acc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, ctrl, 0xf, 0xf, false)
@@ -831,7 +858,25 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
                     if (is_cand) my_cand[(ctail + __popcll(bal & ((1ull << lane) - 1ull))) & (PG_ABBA_CAND - 1)] = site;
                     ctail += (int)__popcll(bal);
                 }
-            } else {                                     // SPW == 16
+                while (ctail - chead >= 16) {
+                    count_sites(my_cand[(chead + (lane >> 2)) & (PG_ABBA_CAND - 1)], true);
+                    chead += 16;
+                }
+            };
+            uint4 va[GROUPS][NP1], vb[GROUPS][NP1];
+            int64_t t0 = c0 + SPW * wave;
+            sl.issue(t0, va);
+            while (t0 < c1) {
+                sl.issue(t0 + 4 * SPW, vb);
+                process(t0, va);
+                t0 += 4 * SPW;
+                if (t0 >= c1) break;
+                sl.issue(t0 + 4 * SPW, va);
+                process(t0, vb);
+                t0 += 4 * SPW;
+            }
+        } else {
+            for (int64_t t0 = c0 + 16 * wave; t0 < c1; t0 += 64) {
                 const int64_t site = t0 + (lane >> 2);
                 uint32_t pres = site < c1 ? range_presence_x4(gt + site * (int64_t)S, my_s, my_e) : 0u;
                 pres |= (uint32_t)__shfl_xor((int)pres, 1, 64);
@@ -840,10 +885,10 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
                 const unsigned long long bal = __ballot(is_cand);
                 if (is_cand) my_cand[(ctail + __popcll(bal & ((1ull << lane) - 1ull))) & (PG_ABBA_CAND - 1)] = site;
                 ctail += (int)__popcll(bal);
-            }
-            while (ctail - chead >= 16) {
-                count_sites(my_cand[(chead + (lane >> 2)) & (PG_ABBA_CAND - 1)], true);
-                chead += 16;
+                while (ctail - chead >= 16) {
+                    count_sites(my_cand[(chead + (lane >> 2)) & (PG_ABBA_CAND - 1)], true);
+                    chead += 16;
+                }
             }
         }
         if (ctail > chead) {
@@ -1023,20 +1068,12 @@ __global__ __launch_bounds__(256) void k_popfreq_q(const int8_t *__restrict__ gt
             }
         }
     };
-    constexpr int GROUPS = 16 / NPASS, SPW = 4 * GROUPS;
-    for (int64_t t0 = c0 + SPW * wave; t0 < c1; t0 += 4 * SPW) {
-        uint4 v[GROUPS][NPASS];
-#pragma unroll
-        for (int g = 0; g < GROUPS; ++g) {
-            const int64_t site = t0 + 4 * g + rsel;
-            const int8_t *rowb = gt + site * (int64_t)S;
-#pragma unroll
-            for (int p = 0; p < NPASS; ++p) {
-                const int off = p * 256 + sub * 16;
-                v[g][p] = make_uint4(0u, 0u, 0u, 0u);
-                if (site < c1 && off < S) v[g][p] = *reinterpret_cast<const uint4 *>(rowb + off);
-            }
-        }
+    // Screening loads: raw buffer loads on a descriptor of the block's rows (rows past the window and the lanes past the end
+    // of a row read as zero: no predication, no address arithmetic beyond one add per step), and the loads of step k+1 are
+    // issued before step k is processed, so a wave always has GROUPS*NPASS .. 2*GROUPS*NPASS 16-byte loads in flight.
+    constexpr int GROUPS = 8 / NPASS, SPW = 4 * GROUPS;
+    const ScreenLoads<GROUPS, NPASS> sl(gt, S, c0, c1, sub, rsel);
+    auto process = [&](int64_t t0, const uint4 (&v)[GROUPS][NPASS]) {
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const int64_t site = t0 + 4 * g + rsel;
@@ -1058,6 +1095,20 @@ __global__ __launch_bounds__(256) void k_popfreq_q(const int8_t *__restrict__ gt
         while (ctail - chead >= 16) {
             count_sites(my_cand[(chead + (lane >> 2)) & (PG_ABBA_CAND - 1)], true);
             chead += 16;
+        }
+    };
+    {
+        uint4 va[GROUPS][NPASS], vb[GROUPS][NPASS];
+        int64_t t0 = c0 + SPW * wave;
+        sl.issue(t0, va);
+        while (t0 < c1) {
+            sl.issue(t0 + 4 * SPW, vb);
+            process(t0, va);
+            t0 += 4 * SPW;
+            if (t0 >= c1) break;
+            sl.issue(t0 + 4 * SPW, va);
+            process(t0, vb);
+            t0 += 4 * SPW;
         }
     }
     if (ctail > chead) {
