@@ -126,8 +126,8 @@ class Run:
     """Shared plumbing: input -> layout -> windows -> engine (+ multi-GPU shard of the window list).
 
     The input is consumed in blocks of PG_STREAM_BYTES bytes of text (default 1 GiB) when the window type allows it
-    (coordinate windows: windows.CoordWindowStream), so host memory stays bounded for inputs of any size; sites /
-    predefined / cat windows read the whole input as one block.  Drivers iterate `for _ in run.chunks():`; inside the loop
+    (coordinate and sites windows: windows.CoordWindowStream / SitesWindowStream), so host memory stays bounded for inputs of
+    any size; predefined / cat windows read the whole input as one block.  Drivers iterate `for _ in run.chunks():`; inside the loop
     T, w0, w1, lo, hi, batch() and gather() refer to the windows that became certain with the current block.  Drivers that
     do not stream construct Run(..., stream=False): the single chunk is loaded by the constructor."""
 
@@ -150,10 +150,16 @@ class Run:
         self._minSites, self._coords_keep, self._windows_fn = minSites, coords_keep, windows_fn
         self._streamer = None
         self._block_bytes = None
-        if stream and windows_fn is None and wparams["windType"] == "coordinate":
+        # every rank of a multi-GPU run tokenises the input itself: share the host cores instead of oversubscribing them
+        self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size) if self.world.size > 1 else 0
+        if stream and windows_fn is None and wparams["windType"] in ("coordinate", "sites"):
             inc = _lines(args.include) if args.include else None
             exc = _lines(args.exclude) if args.exclude else None
-            self._streamer = windows.CoordWindowStream(wparams["windSize"], wparams["stepSize"], inc, exc)
+            if wparams["windType"] == "coordinate":
+                self._streamer = windows.CoordWindowStream(wparams["windSize"], wparams["stepSize"], inc, exc)
+            else:
+                self._streamer = windows.SitesWindowStream(wparams["windSize"], wparams["overlap"], wparams["maxDist"],
+                                                           minSites, inc, exc)
             self._block_bytes = int(os.environ.get("PG_STREAM_BYTES", 1 << 30))
         t0 = time.perf_counter()
         dev = args.device if args.device is not None else self.world.local_rank
@@ -195,7 +201,8 @@ class Run:
             self.timing["read_s"] += time.perf_counter() - t0          # time this thread waited for the reader
             self.timing["text_bytes"] = self._reader.bytes_read
             t0 = time.perf_counter()
-            block = genoio.encode(body, self.layout, head_rows=carry.n_sites if carry is not None else 0)
+            block = genoio.encode(body, self.layout, n_threads=self._tok_threads,
+                                  head_rows=carry.n_sites if carry is not None else 0)
             del body
             self.data = genoio.concat(carry, block)
             self.timing["tokenize_s"] += time.perf_counter() - t0

@@ -284,3 +284,107 @@ class CoordWindowStream:
         T.finish(positions)
         T.dup = np.asarray(T.dup, dtype=bool)
         return T, keep_from
+
+
+class SitesWindowStream:
+    """slidingSitesWindows over an input that arrives in consecutive pieces; same contract as CoordWindowStream.feed().
+    A window of the buffer's last (still open) run is certain when it is full (windSites rows) or closed by maxDist, i.e. a
+    row beyond it has been seen; otherwise it waits for more rows: its rows are carried, together with how far the window
+    state had grown (the generator's `hi` never shrinks) and the ID it was created with."""
+
+    def __init__(self, windSites, overlap, maxDist=np.inf, minSites=None, include=None, exclude=None):
+        self.w, self.overlap, self.maxDist = int(windSites), int(overlap), maxDist
+        self.minSites = int(minSites) if minSites else int(windSites)
+        if self.overlap >= self.w:
+            raise ValueError("overlap must be smaller than the window size (the reference would loop forever)")
+        self.include, self.exclude = include, exclude
+        self.done = 0
+        self.have_pending = False
+        self.skipped_since = False
+        self.cont_name = None
+        self.cont_hi = 0                  # rows of the open window state at the start of the carried rows
+        self.cont_wid = 0
+        self.cont_after_emit = False      # the open run stopped right after a full window that ended at the buffer's end
+
+    def feed(self, run_starts, run_names, positions, final):
+        positions = np.asarray(positions)
+        n_all = len(positions)
+        T = WindowTable()
+        T.dup = []
+        runs = _runs(run_starts, n_all) if n_all else []
+        keep_from = n_all
+        finite = not np.isinf(self.maxDist)
+        cont_name, cont_hi, cont_wid, cont_after_emit = None, 0, 0, False
+        if self.cont_name is not None and (not runs or run_names[0] != self.cont_name):
+            # the open run had no rows left to carry and nothing of it follows: it ended at the buffer boundary
+            self.have_pending = self.cont_after_emit
+            self.cont_name = None
+        for r, (a, b) in enumerate(runs):
+            scaf = run_names[r]
+            is_cont = r == 0 and scaf == self.cont_name
+            is_open = r == len(runs) - 1 and not final
+            if not _wanted(scaf, self.include, self.exclude):
+                self.skipped_since = True
+                continue
+            if self.skipped_since and self.have_pending and not is_cont:
+                self.done += 1
+                T.add("", 0, 0, 0, 0, 0)
+                T.dup.append(True)
+            self.skipped_since = False
+            if not is_cont:
+                self.have_pending = False
+            _check_sorted(positions, a, b, scaf)
+            p = positions[a:b].astype(np.int64)
+            n = b - a
+            lo = 0
+            hi = self.cont_hi if is_cont else 0
+            wid = self.cont_wid if is_cont else self.done + 1
+            stopped = False
+            if is_cont and self.cont_after_emit and n == hi:
+                # no new row of this run has arrived since its last (full) window was emitted: for the generator that
+                # emission was the run's last event (it breaks before trimming, genomics.py:2052-2056)
+                if is_open:
+                    cont_name, cont_hi, cont_wid, cont_after_emit = scaf, hi, wid, True
+                    keep_from = a
+                else:
+                    self.have_pending = True
+                continue
+            while True:
+                if hi < n:                    # grow (genomics.py:2052)
+                    cap = min(n, lo + self.w)
+                    if finite:
+                        cap = min(cap, int(np.searchsorted(p, p[lo] + self.maxDist, side="right")))
+                    hi = max(hi, cap)
+                if is_open and hi >= n and (hi - lo) < self.w:
+                    stopped = True            # not full and no row beyond it yet: wait for more rows
+                    break
+                emitted = (hi - lo) >= self.minSites
+                if emitted:
+                    self.done += 1
+                    T.add(scaf, int(p[lo]), int(p[hi - 1]), a + lo, a + hi, wid)
+                    T.dup.append(False)
+                if hi >= n and not is_open:   # next line is another scaffold or EOF: the window object is left as it is
+                    self.have_pending = emitted
+                    break
+                if emitted:                   # GenoWindow.trim(leave=overlap)
+                    self.have_pending = True
+                    remove = (hi - lo) - self.overlap
+                    if remove <= 0:
+                        raise ValueError("sites window of %d rows cannot advance with overlap %d under maxDist "
+                                         "(the reference yields this window forever)" % (hi - lo, self.overlap))
+                    lo = min(lo + remove, hi)
+                    wid = self.done + 1
+                elif hi > lo:
+                    lo += 1                   # trim(remove=1)
+                if is_open and hi >= n:       # a full window ended exactly at the buffer's end: its successor needs more rows
+                    stopped = True
+                    cont_after_emit = emitted
+                    break
+            if is_open:
+                assert stopped
+                cont_name, cont_hi, cont_wid = scaf, hi - lo, wid
+                keep_from = a + lo
+        self.cont_name, self.cont_hi, self.cont_wid, self.cont_after_emit = cont_name, cont_hi, cont_wid, cont_after_emit
+        T.finish(positions)
+        T.dup = np.asarray(T.dup, dtype=bool)
+        return T, keep_from

@@ -67,13 +67,21 @@ def test_cli_reproduces_reference_output(case, tmp_path):
             assert f.read() == g.read()
 
 
-STREAMABLE = [c for c in CASES if c["tool"] in ("popgenWindows.py", "ABBABABAwindows.py", "fourPopWindows.py")
-              and "--windType" not in c["argv"]]
+def _streamable(c):
+    if c["tool"] not in ("popgenWindows.py", "ABBABABAwindows.py", "fourPopWindows.py"):
+        return False
+    if "--windType" not in c["argv"]:
+        return True
+    return c["argv"][c["argv"].index("--windType") + 1] in ("coordinate", "sites")
+
+
+STREAMABLE = [c for c in CASES if _streamable(c)]
 
 
 @pytest.mark.parametrize("case", STREAMABLE, ids=[c["name"] for c in STREAMABLE])
 @pytest.mark.parametrize("block", [3000, 50000])
 def test_cli_streaming_in_small_blocks_reproduces_reference_output(case, block, tmp_path, monkeypatch):
-    """the same goldens with the input consumed in blocks of a few kilobytes (windows.CoordWindowStream + carried rows)"""
+    """the same goldens with the input consumed in blocks of a few kilobytes (windows.CoordWindowStream / SitesWindowStream +
+    carried rows)"""
     monkeypatch.setenv("PG_STREAM_BYTES", str(block))
     test_cli_reproduces_reference_output(case, tmp_path)

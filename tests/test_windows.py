@@ -154,3 +154,54 @@ def test_coord_window_stream_equals_whole_input(seed):
             assert kf <= b - a
             keep = a + kf
         assert got == want, (w, step, inc, exc, cuts)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_sites_window_stream_equals_whole_input(seed):
+    from genomics_general_amd import windows as W
+    rng = np.random.default_rng(2000 + seed)
+    tested = 0
+    for _ in range(300):
+        names, starts, pos, prev = [], [], [], None
+        for _r in range(int(rng.integers(1, 6))):
+            nm = str(rng.choice([x for x in ("c0", "c1", "c2", "c3") if x != prev]))
+            prev = nm
+            starts.append(len(pos))
+            names.append(nm)
+            pos += list(np.sort(rng.integers(1, 400, size=int(rng.integers(1, 60)))))
+        rs, pos = np.array(starts), np.array(pos, dtype=np.int32)
+        w = int(rng.integers(2, 40))
+        ov = int(rng.integers(0, w))
+        ms = max(int(rng.integers(1, w + 1)), ov + 1)
+        md = np.inf if rng.integers(0, 2) else int(rng.integers(5, 200))
+        inc = exc = None
+        z = int(rng.integers(0, 3))
+        if z == 1:
+            inc = [str(x) for x in rng.choice(["c0", "c1", "c2", "c3"], size=2, replace=False)]
+        if z == 2:
+            exc = [str(x) for x in rng.choice(["c0", "c1", "c2", "c3"], size=1)]
+        try:
+            want = _stream_rows(W.sites_windows(rs, names, pos, w, ov, md, ms, inc, exc), [])
+        except ValueError:
+            continue                                        # a window that cannot advance: both variants raise
+        tested += 1
+        n = len(pos)
+        cuts = sorted(set(rng.integers(0, n + 1, size=int(rng.integers(0, 6))).tolist() + [n]))
+        run_of = np.zeros(n, dtype=int)
+        for r, (a, b) in enumerate(W._runs(rs, n)):
+            run_of[a:b] = r
+        S = W.SitesWindowStream(w, ov, md, ms, inc, exc)
+        got, hist, keep = [], [], 0
+        for ci, c in enumerate(cuts):
+            a, b = keep, max(c, keep)
+            if b > a:
+                ro = run_of[a:b]
+                chg = np.flatnonzero(np.concatenate([[True], ro[1:] != ro[:-1]]))
+                brs, bn = chg, [names[ro[i]] for i in chg]
+            else:
+                brs, bn = np.array([], dtype=int), []
+            T, kf = S.feed(brs, bn, pos[a:b], final=(ci == len(cuts) - 1))
+            got += _stream_rows(T, hist, a)
+            keep = a + kf
+        assert got == want, (w, ov, ms, md, inc, exc, cuts)
+    assert tested > 200
