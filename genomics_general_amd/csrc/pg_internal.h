@@ -48,7 +48,6 @@ void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *D
                            const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,
                            int64_t *cnt_out, int mean_mode);
 
-void pg_launch_mirror(hipStream_t st, int32_t *Cmat, int32_t *Dmat, int N, int n_win);
 
 void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                     int n_win, int max_chunks, const int32_t *pop_start, int p1, int p2, int p3, int p4,

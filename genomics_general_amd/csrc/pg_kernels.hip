@@ -1,14 +1,14 @@
-// Hand-written gfx950 (CDNA4, wave64) kernels of the per-window statistics path.
+// Hand-written gfx950 (CDNA4, wave64) kernels of the per-window statistics path (the v2 pairwise kernels are in pg_pair2.hip).
 //
-//   K_pack      site-major one-hot int8 rows  ->  per-window bit-planes [word][plane A,C,G,T,V][hap]
-//   K_pairwise  bit-planes -> C[i][j] (#sites both called) and D[i][j] (#both called & differ)
-//               (replaces genomics.py:903-916, 1042-1047, 1219-1221)
-//   K_popdist   D,C -> per population-pair float64 sums of D/C + valid-pair counts (genomics.py:956-995)
-//   K_indpair   D,C -> per individual-pair sums/counts (genomics.py:934-954)
-//   K_abba      per-site population base counts -> ABBA/BABA/f4 window sums (genomics.py:1647-1695)
-//   K_popfreq   per-site population base counts -> l, S, sum of allele-pair products (genomics.py:1002-1028)
-//   K_counts    raw per-site per-population base counts (genomics.py:1049-1052)
-//   K_synth     counter-based synthetic genotype generator (spec: genomics_general_amd/synth.py)
+//   k_synth          counter-based synthetic genotype generator (spec: genomics_general_amd/synth.py)
+//   k_pack / k_pairwise   first-generation pairwise path (5 bit-planes per word, 7 VALU per 32 pair-sites), kept as the A/B
+//                    reference of the v2 pipeline (PG_PAIR_V1=1)
+//   k_popdist_fin, k_popstats   D,C -> per population-pair float64 sums of D/C + valid-pair counts -> pi / dxy / Fst
+//                    (genomics.py:956-995, 88-90)
+//   k_indpair_fin    D,C -> per individual-pair sums / counts or finished nanmeans (genomics.py:934-954)
+//   k_abba_q         screening pass + per-population base counts -> ABBA/BABA/f4... window sums (genomics.py:1647-1695, 1585-1643)
+//   k_popfreq_q      screening pass + per-population base counts -> l, S, sum of allele-pair products (genomics.py:1002-1028)
+//   k_site_counts    raw per-site per-population base counts (genomics.py:1049-1052);  k_hap_called (genomics.py:1038-1040)
 //
 // Integer work is exact; float64 work is compiled with -ffp-contract=off so the per-site products are the
 // same IEEE operations, in the same order, as the NumPy expressions of the reference.
@@ -255,24 +255,6 @@ void pg_launch_pairwise(hipStream_t st, const uint32_t *planes, const int64_t *w
     int64_t blocks = (int64_t)((n_win + 7) / 8) * tasks_wg * 8;
     hipLaunchKernelGGL(k_pairwise, dim3((unsigned)blocks), dim3(256), 0, st, planes, woff, n_win, tasks, n_tasks,
                        tasks_wg, NP, N, Cmat, Dmat);
-}
-
-// Fill the lower triangle and the diagonal (pg_pairwise returns full symmetric matrices to the host).
-__global__ __launch_bounds__(256) void k_mirror(int32_t *__restrict__ Cmat, int32_t *__restrict__ Dmat, int N) {
-    int32_t *Cw = Cmat + (size_t)blockIdx.y * N * N;
-    int32_t *Dw = Dmat + (size_t)blockIdx.y * N * N;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N * N; idx += gridDim.x * blockDim.x) {
-        int i = idx / N, j = idx - i * N;
-        if (i == j) { Cw[idx] = 0; Dw[idx] = 0; }
-        else if (i > j) { Cw[idx] = Cw[(size_t)j * N + i]; Dw[idx] = Dw[(size_t)j * N + i]; }
-    }
-}
-
-void pg_launch_mirror(hipStream_t st, int32_t *Cmat, int32_t *Dmat, int N, int n_win) {
-    if (n_win <= 0) return;
-    int bx = (N * N + 255) / 256;
-    if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(k_mirror, dim3(bx, n_win), dim3(256), 0, st, Cmat, Dmat, N);
 }
 
 // ------------------------------------------------------------------------------------------------------

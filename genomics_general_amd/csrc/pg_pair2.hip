@@ -1,20 +1,21 @@
 // v2 pairwise pipeline: the pairwise matrices split into the two terms that need different amounts of work.
 //
-//   C[i][j] = sum over ALL sites of v_i & v_j                      -> k_pairC on the "called" plane only (2 VALU / 32 pair-sites)
-//   D[i][j] = sum over POLYMORPHIC sites of differ(i,j) & v_i & v_j -> k_pairD on compacted allele planes (5 VALU / 32 pair-sites)
+//   C[i][j] = sum over ALL sites of v_i & v_j                       -> k_pairC on the "called" plane only (2 VALU / 32 pair-sites)
+//   D[i][j] = sum over POLYMORPHIC sites of differ(i,j) & v_i & v_j -> k_pairD on the polymorphic-site planes (4 VALU / 32 pair-sites)
 //
 // A site whose called haplotypes all carry the same allele adds the same amount to C and to "same allele", i.e. nothing to D
 // (genomics.py:903-905, 1219-1221: numHamming counts differences among jointly called sites).  k_pack2 therefore detects
-// polymorphic sites (>= 2 alleles present among the called haplotypes of the window's slots) while it transposes, and
-// bit-compacts only those into the allele planes.  Data-dependent, exact, and the algorithmic pair-sites stay the denominator
-// of every reported rate.
+// polymorphic sites (>= 2 alleles present among the called haplotypes of the window's slots) while it builds the called
+// plane, and transposes the allele planes of those sites only.  Data-dependent, exact, and the algorithmic pair-sites stay the
+// denominator of every reported rate.
 //
 // Layouts (uint32 words, 32 sites per word):
-//   Vp[(vgoff[b] + wq) * NPv + unit][4]        called plane, 4 consecutive words of one unit contiguous (one 16-byte load per
-//                                               lane per 128 sites; 16 rows x 4 words = 4 x s_load_dwordx16)
-//   XV[((goff[b] + g) * PG_GROUP + k) * 5 + p][NP]  compacted planes of group g (64 input words): p = 0..3 X_a (allele a called),
-//                                               p = 4 V (called);  nw[goff[b]+g] = words used (0..64)
-// differ & both called  ==  OR_a (X_a,i & Y_a,j), Y_a = V ^ X_a: row operands X in SGPRs, column operands Y in VGPRs.
+//   Vp[(vgoff[b] + wq) * NPv + unit][4]   called plane, 4 consecutive words of one unit contiguous (one 16-byte load per lane per
+//                                          128 sites; 8 rows x 4 words = 2 x s_load_dwordx16); two padding word groups at the end
+//   XV[((goff[b] + g) * PG_GROUP + k) * PG_XV_PLANES + p][NP]   dense words of the polymorphic sites of group g (2048 sites):
+//                                          p = 0,1 bits of the allele index (A,C,G,T = 0..3), p = 2 called;
+//                                          nw[goff[b]+g] = words used (0..64)
+//   differ & both called == ((b0_i ^ b0_j) | (b1_i ^ b1_j)) & v_i & v_j: row operands in SGPRs, column operands in VGPRs.
 #include "pg_internal.h"
 
 typedef __attribute__((address_space(4))) const uint32_t CU32;
