@@ -451,10 +451,10 @@ __device__ __forceinline__ void pairC_body(const uint32_t *__restrict__ Vp, int6
     int j = c.col0 + c.lane;
     if (c.lower == 2 && j >= n_units) j -= n_units;                  // circulant task: columns wrap around
     const uint32_t stride = (uint32_t)NPv * 16u;                       // bytes per word group
-    // 32-bit byte offsets inside the asm loop: at most PG_PAIRC_CHUNK word groups per call (NPv <= 4096 -> < 4 GiB)
-    constexpr int PG_PAIRC_CHUNK = 32768;
-    for (int q0 = 0; q0 < nwq; q0 += PG_PAIRC_CHUNK) {
-        const int nq = (nwq - q0 < PG_PAIRC_CHUNK) ? nwq - q0 : PG_PAIRC_CHUNK;
+    // 32-bit byte offsets inside the asm loop: a call covers at most 2 GiB of the plane
+    const int chunk = (int)(0x7fffffffu / stride) > 2 ? (int)(0x7fffffffu / stride) - 2 : 1;
+    for (int q0 = 0; q0 < nwq; q0 += chunk) {
+        const int nq = (nwq - q0 < chunk) ? nwq - q0 : chunk;
         const uint32_t *base = Vp + (size_t)(vg0 + q0) * NPv * 4u;
         const uint64_t b64 = (uint64_t)base;
         const uint64_t ubase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
