@@ -3,6 +3,7 @@
 #include "pg_ctx.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -657,6 +658,24 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     return PG_OK;
 }
 
+// End-of-call wait on ctx->stream.  The result table is a few kilobytes and the caller's next call follows immediately, so the
+// wake-up latency of a blocking wait (tens of microseconds) is a visible fraction of a millisecond-scale pass: poll the stream
+// for a short while first (PG_SPIN_US microseconds, default 2000; 0 = block at once).
+static int stream_wait(pg_ctx *c) {
+    static const long spin_us = getenv("PG_SPIN_US") ? atol(getenv("PG_SPIN_US")) : 2000;
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) return PG_OK;
+            if (e != hipErrorNotReady) return pg_fail(PG_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
 // The diploid-shortcut flag (raised by k_pack2) is zero whenever no call is in flight: zeroed when allocated and again, on
 // ctx->stream, right after each read; every entry point synchronises ctx->stream before it returns.
 static int flag_ready(pg_ctx *c) {
@@ -769,7 +788,8 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
     auto fetch = [&]() -> int {
         pg_launch_flag_export(c->stream, c->flag.p, c->stats.p + n_out);
         HIPCHK(hipMemcpyAsync(c->out_pin.p, c->stats.p, (n_out + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        int rw = stream_wait(c);
+        if (rw != PG_OK) return rw;
         memcpy(stats_out, c->out_pin.p, n_out * 8);
         return PG_OK;
     };
@@ -848,7 +868,7 @@ static int quartet_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_
         if ((rc = c->out_pin.ensure((size_t)nb * (nsum + 1))) != PG_OK) return rc;
         HIPCHK(hipMemcpyAsync(c->out_pin.p, c->res_f64.p, (size_t)nb * nsum * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(c->out_pin.p + (size_t)nb * nsum, c->res_i64.p, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((rc = stream_wait(c)) != PG_OK) return rc;
         memcpy(sums_out + (size_t)w0 * nsum, c->out_pin.p, (size_t)nb * nsum * 8);
         memcpy(used_out + w0, c->out_pin.p + (size_t)nb * nsum, (size_t)nb * 8);
         w0 = w1;
@@ -894,7 +914,7 @@ extern "C" int pg_popfreq(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n
         HIPCHK(hipGetLastError());
         if ((rc = c->out_pin.ensure(nres)) != PG_OK) return rc;
         HIPCHK(hipMemcpyAsync(c->out_pin.p, dl, nres * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((rc = stream_wait(c)) != PG_OK) return rc;
         const int64_t *hp = reinterpret_cast<const int64_t *>(c->out_pin.p);
         memcpy(l_out + w0, hp, (size_t)nb * 8);
         memcpy(S_out + (size_t)w0 * P, hp + nb, (size_t)nb * P * 8);
