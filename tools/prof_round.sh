@@ -7,7 +7,7 @@ for wl in c2 c3 northstar; do
   B="python bench.py --workload $wl --steps $ST --warmup 2 --no-cpu-baseline"
   timeout 150 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o $wl --output-format csv -- $B > gpurun_out/bench_prof_$wl.log 2>&1
   tail -1 gpurun_out/bench_prof_$wl.log | cut -c1-150
-  if [ $wl != northstar ]; then
+  if true; then
     timeout 150 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o $wl --output-format csv -- $B > gpurun_out/pmc_fetch_$wl.log 2>&1
     timeout 150 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -o $wl --output-format csv -- $B > gpurun_out/pmc_write_$wl.log 2>&1
     timeout 150 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d gpurun_out/pmc_sq -o $wl --output-format csv -- $B > gpurun_out/pmc_sq_$wl.log 2>&1
