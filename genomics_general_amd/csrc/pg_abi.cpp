@@ -555,9 +555,12 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     // streams have something to overlap (but not so small that a sub-batch cannot fill the GPU)
     int64_t total_words_all = 0;
     for (int w = 0; w < n_win; ++w) total_words_all += ((hi[w] - lo[w] + 31) / 32 + PG_GROUP - 1) / PG_GROUP * PG_GROUP;
-    // measured on MI355X (profiles/): k_pack2 is itself ~75 % VALU-issue bound, so running it beside the pair kernels
-    // gains nothing yet; sub-batching stays opt-in until the pack kernel is HBM-bound
-    const bool overlap = getenv("PG_OVERLAP") != nullptr;
+    // A job that fits one batch runs as one batch on one stream: splitting it only to overlap the pack kernel with the pair
+    // kernels is slower (measured: C2 1.44 vs 0.99 ms).  A job that needs several batches anyway is cut into at least 8, so
+    // that all but the first pack kernel and all but the last pair kernels run beside each other on the two streams
+    // (measured on the north-star shape: 13.3 ms with 8 sub-batches vs 14.0 ms with the 3 that the scratch limit forces).
+    const bool multi = total_words_all * word_bytes + (int64_t)n_win * mat_bytes > c->scratch_limit / 2;
+    const bool overlap = multi || getenv("PG_OVERLAP") != nullptr;
     int64_t target_words = overlap ? std::max<int64_t>(total_words_all / 8, 32768) : total_words_all;
     for (int k = 0; k < 2; ++k) {
         if (!c->slot[k].packed) HIPCHK(hipEventCreateWithFlags(&c->slot[k].packed, hipEventDisableTiming));
