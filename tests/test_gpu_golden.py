@@ -85,3 +85,27 @@ def test_cli_streaming_in_small_blocks_reproduces_reference_output(case, block, 
     carried rows)"""
     monkeypatch.setenv("PG_STREAM_BYTES", str(block))
     test_cli_reproduces_reference_output(case, tmp_path)
+
+
+def test_cli_reads_stdin_and_writes_gzip_and_stdout(tmp_path):
+    """-g absent = stdin, -o absent = stdout, -o *.gz = gzip (popgenWindows.py:311-316)"""
+    import gzip
+    import subprocess
+    import sys
+    case = [c for c in CASES if c["tool"] == "popgenWindows.py" and c["fixture"] == "c1"][0]
+    root = os.path.dirname(os.path.dirname(GOLD))
+    with gzip.open(os.path.join(GOLD, "c1.geno.gz"), "rb") as f:
+        text = f.read()
+    argv = [a for a in case["argv"] if a not in ("-g", "{geno}")]
+    with open(os.path.join(GOLD, case["name"] + ".out")) as f:
+        want = f.read()
+    r = subprocess.run([sys.executable, os.path.join(root, "popgenWindows.py")] + argv, input=text, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, cwd=root, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    compare_text(align_columns(r.stdout.decode(), want), want, round_digits(case))
+    out = str(tmp_path / "o.csv.gz")
+    r = subprocess.run([sys.executable, os.path.join(root, "popgenWindows.py")] + argv + ["-o", out], input=text,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root, timeout=300)
+    assert r.returncode == 0 and r.stdout == b"", r.stderr.decode()[-500:]
+    with gzip.open(out, "rt") as f:
+        compare_text(align_columns(f.read(), want), want, round_digits(case))
