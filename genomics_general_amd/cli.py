@@ -542,7 +542,7 @@ def distmat_main(argv=None):
     ap = argparse.ArgumentParser(prog="distMat.py")
     _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined", "cat")),
                               "-m": dict(default=None)})
-    ap.add_argument("--overlap", type=int, metavar="sites", help="Overlap for sites sliding window")
+    ap.add_argument("-O", "--overlap", type=int, metavar="sites", help="Overlap for sites sliding window")
     ap.add_argument("-Mi", "--minPerInd", type=int, metavar="sites", help="Minimum sites per individual")
     ap.add_argument("--includeSameWithSame", action="store_true", help="Include comparisons of each haplotype to itself")
     ap.add_argument("--outFormat", choices=("raw", "phylip", "nexus"), default="phylip")
