@@ -107,6 +107,50 @@ def test_block_wise_encoding_with_carried_rows_equals_whole_file(name, tmp_path)
     rd.close()
 
 
+def _bgzf_write(path, data, blk=60000):
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for a in range(0, len(data), blk):
+            chunk = data[a:a + blk]
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = c.compress(chunk) + c.flush()
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp +
+                    struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))      # bgzip's EOF member
+
+
+def test_bgzf_input_is_inflated_member_wise_and_equals_gzip(tmp_path):
+    """a .geno.gz written by bgzip (BGZF) goes through the parallel reader; a plain gzip file through the gzip module"""
+    raw = genoio.read_all(os.path.join(GOLD, "abba.geno.gz"))
+    path = str(tmp_path / "x.geno.gz")
+    _bgzf_write(path, raw, blk=7000)
+    assert genoio.BgzfFile.is_bgzf(path) and not genoio.BgzfFile.is_bgzf(os.path.join(GOLD, "abba.geno.gz"))
+    with gzip.open(path, "rb") as f:
+        assert f.read() == raw                               # a valid multi-member gzip file for everybody else
+    rd = genoio.BlockReader(path)
+    assert isinstance(rd.f, genoio.BgzfFile)
+    parts = [rd.read_header()]
+    while True:
+        b = rd.read_block(50000)
+        if not b:
+            break
+        assert b.endswith(b"\n")
+        parts.append(b)
+    rd.close()
+    assert b"".join(parts) == raw
+    rd = genoio.BlockReader(path)
+    assert rd.read_block(None) == raw                        # whole-input mode
+    rd.close()
+    with open(path, "rb") as f:
+        cut = f.read()[:-40]
+    with open(path, "wb") as f:
+        f.write(cut)
+    rd = genoio.BlockReader(path)
+    with pytest.raises(ValueError):
+        rd.read_block(None)
+
+
 def test_tokenizer_thread_count_does_not_change_output():
     raw = genoio.read_all(os.path.join(GOLD, "abba.geno.gz"))
     names, body = genoio.split_header(raw)
