@@ -737,8 +737,9 @@ def fourpop_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=1
 
 
 def distmat_text(geno_path, fmt, wind_size=None, step=None, min_sites=1, wind_type="coordinate",
-                 out_format="phylip", round_to=4, include_same=False, min_per_ind=None, samples=None):
-    """distMat.py:28-60 (stats_wrapper) + genomics.py:2288-2306 (matrix strings); coordinate and cat windows."""
+                 out_format="phylip", round_to=4, include_same=False, min_per_ind=None, samples=None, overlap=0,
+                 max_dist=float("inf")):
+    """distMat.py:28-60 (stats_wrapper) + genomics.py:2288-2306 (matrix strings); coordinate, sites and cat windows."""
     with open_text(geno_path) as fh:
         file_names, sites = read_sites(fh)
     ind_names = list(samples) if samples else list(file_names)
@@ -750,7 +751,10 @@ def distmat_text(geno_path, fmt, wind_size=None, step=None, min_sites=1, wind_ty
     else:
         if not min_sites:
             min_sites = wind_size
-        wins = coord_windows(sites, wind_size, step or wind_size)
+        if wind_type == "sites":
+            wins = sites_windows(sites, wind_size, overlap, max_dist, min_sites)
+        else:
+            wins = coord_windows(sites, wind_size, step or wind_size)
     n = len(ind_names)
     chunks = []
     for w in wins:

@@ -88,6 +88,19 @@ CASES = [
          argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "400", "--overlap", "100", "-m", "50"] + abba_args(16)),
     dict(name="abba_windows_diplo", tool="ABBABABAwindows.py", fixture="abba_diplo",
          argv=["-g", "{geno}", "-f", "diplo", "-w", "1000", "-m", "20", "--minData", "0.5"] + abba_args(16)),
+    # ---- less common flags ----
+    dict(name="sparse_popsfile", tool="popgenWindows.py", fixture="sparse",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "10", "--popsFile", "{dir}/sparse_pops.txt",
+               "-p", "north", "-p", "south", "--roundTo", "6"]),
+    dict(name="abba_popsfile_exclude", tool="ABBABABAwindows.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--popsFile", "{dir}/abba_pops.txt",
+               "--exclude", "{dir}/abba_exclude.txt", "-P1", "pop0", "-P2", "pop1", "-P3", "pop2", "-O", "pop3"]),
+    dict(name="holes_distmat_minperind_samples", tool="distMat.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "10", "-Mi", "200", "--samples", "s0", "s2", "s3", "s5"]),
+    dict(name="holes_distmat_sites", tool="distMat.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "300", "-O", "50", "-m", "100", "--outFormat", "nexus"]),
+    dict(name="abba_freq_indfreqs", tool="freq.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "--indFreqs", "--target", "derived"]),
     # ---- fourPopWindows.py (the reference needs np.NaN injected by the harness under NumPy 2) ----
     dict(name="fourpop_minor", tool="fourPopWindows.py", fixture="abba",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--minData", "0.5"] + abba_args(16)),
@@ -138,4 +151,7 @@ AUX_FILES = {
     "sparse_coords.txt": "chr1 100 900 first\nchr1 500 1500 second\nchr1 4000 4100 third\nchr3 1 1000 onThree\nchr3 2000 2600 lastOne\n",
     "sparse_exclude.txt": "chr2\n",
     "sparse_include.txt": "chr1\nchr2\n",
+    "sparse_pops.txt": "".join("s%d %s\n" % (d, "north" if d < 5 else "south" if d < 10 else "elsewhere") for d in range(12)),
+    "abba_pops.txt": "".join("s%d pop%d\n" % (d, d // 4) for d in range(16)),
+    "abba_exclude.txt": "chr2\n",
 }

@@ -27,6 +27,43 @@ def _pops(argv, flags):
     return out
 
 
+def _pops_with_file(argv, flags):
+    """-p/-P name [samples] plus --popsFile (popgenWindows.py:262-273, ABBABABAwindows.py:203-216)."""
+    out = []
+    i = 0
+    while i < len(argv):
+        if argv[i] in flags:
+            name = argv[i + 1]
+            members = []
+            if i + 2 < len(argv) and not argv[i + 2].startswith("-"):
+                members = argv[i + 2].split(",")
+                i += 1
+            out.append((name, members))
+            i += 2
+        else:
+            i += 1
+    pf = _take(argv, "--popsFile")
+    if pf:
+        names = [p[0] for p in out]
+        with open(pf) as f:
+            for ln in f:
+                parts = ln.split()
+                if len(parts) >= 2 and parts[1] in names:
+                    out[names.index(parts[1])][1].append(parts[0])
+    return out
+
+
+def _multi(argv, flag):
+    if flag not in argv:
+        return None
+    i = argv.index(flag) + 1
+    vals = []
+    while i < len(argv) and not argv[i].startswith("-"):
+        vals.append(argv[i])
+        i += 1
+    return vals
+
+
 def _lines(path):
     with open(path) as f:
         return [ln.rstrip() for ln in f.readlines()]
@@ -64,7 +101,7 @@ def run(tool, argv):
             kw["coords"] = [c[:3] for c in kw["coords"]]        # popgenWindows.py:240 keeps 3 columns
         o = _take(argv, "-O")
         kw["overlap"] = int(o) if o else 0
-        pops = _pops(argv, ("-p",)) or None
+        pops = (_pops_with_file(argv, ("-p",)) if "--popsFile" in argv else _pops(argv, ("-p",))) or None
         samples = _take(argv, "--samples")
         analysis = ("popDist", "popPairDist")
         if "--analysis" in argv:
@@ -84,7 +121,8 @@ def run(tool, argv):
         kw = _common(argv)
         o = _take(argv, "--overlap")
         kw["overlap"] = int(o) if o else 0
-        pops4 = _pops(argv, ("-P1", "-P2", "-P3", "-O"))
+        pops4 = (_pops_with_file(argv, ("-P1", "-P2", "-P3", "-O")) if "--popsFile" in argv
+                 else _pops(argv, ("-P1", "-P2", "-P3", "-O")))
         return orc.abbababa_windows_csv(geno, fmt, pops4, **kw)
     if tool == "fourPopWindows.py":
         kw = _common(argv)
@@ -95,14 +133,21 @@ def run(tool, argv):
     if tool == "distMat.py":
         w, s, m = _take(argv, "-w"), _take(argv, "-s"), _take(argv, "-m")
         r = _take(argv, "--roundTo")
+        mi, ov = _take(argv, "-Mi"), _take(argv, "-O")
         return orc.distmat_text(geno, fmt, wind_size=int(w) if w else None, step=int(s) if s else None,
                                 min_sites=int(m) if m is not None else 1,
                                 wind_type=_take(argv, "--windType", default="coordinate"),
                                 out_format=_take(argv, "--outFormat", default="phylip"),
-                                round_to=int(r) if r else 4, include_same="--includeSameWithSame" in argv)
+                                round_to=int(r) if r else 4, include_same="--includeSameWithSame" in argv,
+                                min_per_ind=int(mi) if mi else None, samples=_multi(argv, "--samples"),
+                                overlap=int(ov) if ov else 0)
     if tool == "freq.py":
         pops = _pops(argv, ("-p",))
-        if not pops:
+        if "--indFreqs" in argv:                                 # freq.py:250-253: every individual is its own population
+            with orc.open_text(geno) as fh:
+                names = fh.readline().split()[2:]
+            pops = [(nm, [nm]) for nm in names]
+        elif not pops:
             with orc.open_text(geno) as fh:
                 names = fh.readline().split()[2:]
             pops = [("all", names)]
