@@ -122,9 +122,10 @@ def codes_to_letters(codes):
     return lut[codes.astype(np.uint8)]
 
 
-def write_geno(path_or_file, scaf_names, scaf_id, pos, codes, sample_names, sep="/", fmt="phased"):
+def write_geno(path_or_file, scaf_names, scaf_id, pos, codes, sample_names, sep="/", fmt="phased", haploid=()):
     """Render generator output as `.geno` text (README.md:32-40 of the reference).
-    codes: [L][2*n_samples] in generator order; fmt in phased|pairs|diplo|haplo."""
+    codes: [L][2*n_samples] in generator order; fmt in phased|pairs|diplo|haplo.  Samples whose index is in `haploid` get
+    one-character cells (their first allele) in the phased / pairs formats (mixed ploidy, e.g. a sex chromosome)."""
     import gzip
     letters = codes_to_letters(codes)
     L, H = letters.shape
@@ -144,9 +145,9 @@ def write_geno(path_or_file, scaf_names, scaf_id, pos, codes, sample_names, sep=
         else:
             pairs = [row[j:j + 2] for j in range(0, H, 2)]
             if fmt == "phased":
-                cells = [p[0] + sep + p[1] for p in pairs]
+                cells = [p[0] if k in haploid else p[0] + sep + p[1] for k, p in enumerate(pairs)]
             elif fmt == "pairs":
-                cells = pairs
+                cells = [p[0] if k in haploid else p for k, p in enumerate(pairs)]
             else:
                 cells = [iupac[p] for p in pairs]
         f.write(scaf_names[int(scaf_id[i])] + "\t" + str(int(pos[i])) + "\t" + "\t".join(cells) + "\n")

@@ -738,12 +738,14 @@ def fourpop_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=1
 
 def distmat_text(geno_path, fmt, wind_size=None, step=None, min_sites=1, wind_type="coordinate",
                  out_format="phylip", round_to=4, include_same=False, min_per_ind=None, samples=None, overlap=0,
-                 max_dist=float("inf")):
+                 max_dist=float("inf"), ploidy=None):
     """distMat.py:28-60 (stats_wrapper) + genomics.py:2288-2306 (matrix strings); coordinate, sites and cat windows."""
     with open_text(geno_path) as fh:
         file_names, sites = read_sites(fh)
     ind_names = list(samples) if samples else list(file_names)
     ploidy_of = {nm: (1 if fmt == "haplo" else 2) for nm in ind_names}
+    if ploidy:
+        ploidy_of.update(ploidy)
     pop_of = {}
     if wind_type == "cat":
         wins = [Win(None, None, None, [s[2] for s in sites], [float("nan")] * len(sites), None)]

@@ -16,6 +16,9 @@ FIXTURES = {
     "abba_pairs": dict(seed=20260928, n_dip=16, n_pops=4, scaf_len=[8000, 4000], density=0.6, var_thr=45000, miss_thr=5000, fmt="pairs", sep=""),
     "abba_diplo": dict(seed=20260928, n_dip=16, n_pops=4, scaf_len=[8000, 4000], density=0.6, var_thr=45000, miss_thr=5000, fmt="diplo", sep=""),
     # haploid cells
+    # mixed ploidy: samples 1, 6 and 9 have one-character cells (--haploid / --ploidyFile)
+    "mixed": dict(seed=20260930, n_dip=10, n_pops=2, scaf_len=[3000, 1500], density=0.7, var_thr=30000, miss_thr=5000, fmt="phased", sep="/",
+                  haploid=(1, 6, 9)),
     "haplo": dict(seed=20260929, n_dip=5, n_pops=2, scaf_len=[4000], density=0.5, var_thr=30000, miss_thr=4000, fmt="haplo", sep=""),
 }
 
@@ -92,6 +95,11 @@ CASES = [
     dict(name="sparse_popsfile", tool="popgenWindows.py", fixture="sparse",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "10", "--popsFile", "{dir}/sparse_pops.txt",
                "-p", "north", "-p", "south", "--roundTo", "6"]),
+    dict(name="mixed_haploid_flag", tool="popgenWindows.py", fixture="mixed",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--haploid", "s1,s6,s9", "--roundTo", "6",
+               "--analysis", "popDist", "popPairDist", "popFreq", "indPairDist"] + pops_args(10, 2)),
+    dict(name="mixed_ploidyfile_distmat", tool="distMat.py", fixture="mixed",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1500", "-m", "20", "--ploidyFile", "{dir}/mixed_ploidy.txt", "--includeSameWithSame"]),
     dict(name="abba_popsfile_exclude", tool="ABBABABAwindows.py", fixture="abba",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--popsFile", "{dir}/abba_pops.txt",
                "--exclude", "{dir}/abba_exclude.txt", "-P1", "pop0", "-P2", "pop1", "-P3", "pop2", "-O", "pop3"]),
@@ -154,4 +162,5 @@ AUX_FILES = {
     "sparse_pops.txt": "".join("s%d %s\n" % (d, "north" if d < 5 else "south" if d < 10 else "elsewhere") for d in range(12)),
     "abba_pops.txt": "".join("s%d pop%d\n" % (d, d // 4) for d in range(16)),
     "abba_exclude.txt": "chr2\n",
+    "mixed_ploidy.txt": "".join("s%d %d\n" % (d, 1 if d in (1, 6, 9) else 2) for d in range(10)),
 }

@@ -55,7 +55,7 @@ def make_fixture(name):
     with gzip.GzipFile(path, "wb", mtime=0) as raw:
         import io
         txt = io.TextIOWrapper(raw, newline="\n")
-        synth.write_geno(txt, scaf_names, sid, pos, codes, names, sep=p["sep"], fmt=p["fmt"])
+        synth.write_geno(txt, scaf_names, sid, pos, codes, names, sep=p["sep"], fmt=p["fmt"], haploid=tuple(p.get("haploid", ())))
         txt.flush()
     return path
 

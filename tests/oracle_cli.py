@@ -64,6 +64,23 @@ def _multi(argv, flag):
     return vals
 
 
+def _ploidy(argv, haploid_is_list):
+    """--haploid (comma list in popgenWindows / ABBA, space list in distMat / freq) and --ploidyFile."""
+    out = {}
+    pf = _take(argv, "--ploidyFile")
+    if pf:
+        with open(pf) as f:
+            for ln in f:
+                parts = ln.split()
+                if len(parts) >= 2:
+                    out[parts[0]] = int(parts[1])
+    if "--haploid" in argv:
+        names = _multi(argv, "--haploid") if haploid_is_list else _take(argv, "--haploid").split(",")
+        for nm in names:
+            out[nm] = 1
+    return out or None
+
+
 def _lines(path):
     with open(path) as f:
         return [ln.rstrip() for ln in f.readlines()]
@@ -115,6 +132,7 @@ def run(tool, argv):
             pops = []
             kw["_samples"] = samples.split(",")
         hd = _take(argv, "--hapDist")
+        kw["ploidy"] = _ploidy(argv, False)
         return orc.popgen_windows_csv(geno, fmt, pops, analysis=tuple(analysis), round_to=int(r) if r else 4,
                                       samples_only=kw.pop("_samples", None), hap_dist=float(hd) if hd else 0, **kw)
     if tool == "ABBABABAwindows.py":
@@ -140,7 +158,7 @@ def run(tool, argv):
                                 out_format=_take(argv, "--outFormat", default="phylip"),
                                 round_to=int(r) if r else 4, include_same="--includeSameWithSame" in argv,
                                 min_per_ind=int(mi) if mi else None, samples=_multi(argv, "--samples"),
-                                overlap=int(ov) if ov else 0)
+                                overlap=int(ov) if ov else 0, ploidy=_ploidy(argv, True))
     if tool == "freq.py":
         pops = _pops(argv, ("-p",))
         if "--indFreqs" in argv:                                 # freq.py:250-253: every individual is its own population
