@@ -441,9 +441,9 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
 }
 
 // The inner loop is hand-scheduled assembly (pg_pairc_loop.inc, generated by gen_pairc_asm.py): 8 rows x 4 words of row
-// operands live in SGPRs, ping-ponged between two sets so that the s_load_dwordx16 pair and the column's
-// global_load_dwordx4 of word group g+1 complete under the 64 VALU ops (v_and + accumulating v_bcnt) of group g.  The
-// look-ahead reads one word group past the wave's range: the called plane is allocated with padding.
+// operands live in SGPRs, ping-ponged between two sets so that the s_load_dwordx16 pair of word group g+1 completes under the
+// 64 VALU ops (v_and + accumulating v_bcnt) of group g; the column's global_load_dwordx4 runs two groups ahead in three
+// rotating VGPR sets.  The look-ahead reads two word groups past the wave's range: the called plane is allocated with padding.
 #include "pg_pairc_loop.inc"
 
 __device__ __forceinline__ void pairC_body(const uint32_t *__restrict__ Vp, int64_t vg0, int nwq, int NPv, const PairCtx &c,
@@ -460,11 +460,11 @@ __device__ __forceinline__ void pairC_body(const uint32_t *__restrict__ Vp, int6
         const uint64_t ubase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
         uint32_t soff = (uint32_t)c.row0 * 16u, voff = (uint32_t)j * 16u;
-        uint32_t npairs = (uint32_t)__builtin_amdgcn_readfirstlane(nq >> 1), odd = (uint32_t)__builtin_amdgcn_readfirstlane(nq & 1);
+        uint32_t n6 = (uint32_t)__builtin_amdgcn_readfirstlane(nq / 6), rem = (uint32_t)__builtin_amdgcn_readfirstlane(nq % 6);
         asm volatile(PG_PAIRC_LOOP_ASM
                      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
-                       "+v"(acc[7]), "+s"(soff), "+v"(voff), "+s"(npairs)
-                     : "s"(ubase), "s"(stride), "s"(odd)
+                       "+v"(acc[7]), "+s"(soff), "+v"(voff), "+s"(n6)
+                     : "s"(ubase), "s"(stride), "s"(rem)
                      : PG_PAIRC_LOOP_CLOBBERS);
     }
 }
