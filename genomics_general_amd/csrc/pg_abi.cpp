@@ -46,6 +46,7 @@ extern "C" int pg_ctx_create(pg_ctx **out, int device) {
     HIPCHK(hipSetDevice(device));
     pg_ctx *c = new pg_ctx();
     c->device = device;
+    if (getenv("PG_SCRATCH_GIB")) c->scratch_limit = (int64_t)atol(getenv("PG_SCRATCH_GIB")) << 30;    // default 16 GiB
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
