@@ -185,10 +185,15 @@ def main():
     cpu = None
     if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:
         from oracle import popgen_oracle as orc
-        nw = max(1, min(args.cpu_windows, n_win))
-        t_cpu = 0.0
+        # at least --cpu-windows windows, then more until about 10 s of CPU work have been sampled (at most 8 windows)
+        nw_min, nw_max = max(1, min(args.cpu_windows, n_win)), max(1, min(max(args.cpu_windows, 8), n_win))
+        t_cpu, t_wall = 0.0, 0.0
         ok = True
-        for w in range(nw):
+        nw = 0
+        for w in range(nw_max):
+            if w >= nw_min and t_wall >= 10.0:
+                break
+            nw += 1
             codes = eng.download(int(lo[w]), int(hi[w] - lo[w]))
             scale = 1.0
             if wl["tool"] == "distmat" and n_hap > CPU_DISTMAT_HAPS:
@@ -209,7 +214,9 @@ def main():
                 so = {}
             else:
                 so = orc.abbababa(aln, "pop0", "pop1", "pop2", "pop3", 0.01)
-            t_cpu += (time.perf_counter() - c0) * scale
+            dt = time.perf_counter() - c0
+            t_wall += dt
+            t_cpu += dt * scale
             for k, v in so.items():
                 if k == "sitesUsed":
                     ok = ok and int(st[k][w]) == int(v)
