@@ -32,6 +32,7 @@ _P = C.c_void_p
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 
 # name -> (restype, argtypes); every name here must be declared in include/popgen_hip.h
@@ -52,6 +53,7 @@ SIGNATURES = {
                                  _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_scaffold_runs": (C.c_int, [C.c_char_p, _i64p, _i32p, C.c_int64, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
     "pg_count_lines": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]),
+    "pg_decode_packed": (C.c_int, [_u8p, C.c_int64, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i8p, C.c_int]),
     "pg_pairwise": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i32p, _i32p]),
     "pg_popdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
     "pg_popdist_stats": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_double, C.c_int, _f64p]),

@@ -137,9 +137,9 @@ class Run:
         self.world = dist.world_from_env()
         self._t_start = time.perf_counter()
         self.timing = {"read_s": 0.0, "text_bytes": 0, "tokenize_s": 0.0, "windows_s": 0.0, "sites": 0, "windows": 0,
-                       "engine_and_upload_s": 0.0, "chunks": 0}   # printed as JSON on stderr when PG_TIMING=1
+                       "engine_and_upload_s": 0.0, "upload_s": 0.0, "chunks": 0}   # printed as JSON on stderr when PG_TIMING=1
         t0 = time.perf_counter()
-        self._reader = genoio.BlockReader(args.genoFile)
+        self._reader = genoio.open_input(args.genoFile)
         if header_line:
             names = header_line.split()[2:]
         else:
@@ -201,8 +201,8 @@ class Run:
             self.timing["read_s"] += time.perf_counter() - t0          # time this thread waited for the reader
             self.timing["text_bytes"] = self._reader.bytes_read
             t0 = time.perf_counter()
-            block = genoio.encode(body, self.layout, n_threads=self._tok_threads,
-                                  head_rows=carry.n_sites if carry is not None else 0)
+            block = self._reader.to_geno(body, self.layout, n_threads=self._tok_threads,
+                                         head_rows=carry.n_sites if carry is not None else 0)
             del body
             self.data = genoio.concat(carry, block)
             self.timing["tokenize_s"] += time.perf_counter() - t0
@@ -228,7 +228,9 @@ class Run:
                 s0, s1 = int(lo[nz].min()), int(hi[nz].max())
             else:
                 s0 = s1 = 0
+            t1 = time.perf_counter()
             self.engine.load_sites(self.data.gt[s0:s1])
+            self.timing["upload_s"] += time.perf_counter() - t1          # part of engine_and_upload_s
             self.site0 = s0
             self.lo, self.hi = lo - s0, hi - s0
             self.lo[~nz] = 0
@@ -669,8 +671,12 @@ def freq_main(argv=None):
     ap.add_argument("--device", type=int, default=None, help="GPU index (MI355X engine)")
     args = ap.parse_args(argv)
 
-    raw = genoio.read_all(args.genoFile)
-    headerInds, body = genoio.split_header(raw)
+    packed = genoio.open_input(args.genoFile) if str(args.genoFile).endswith(".pgeno") else None
+    if packed is not None:
+        headerInds, body = list(packed.names), packed.read_block(None)
+    else:
+        raw = genoio.read_all(args.genoFile)
+        headerInds, body = genoio.split_header(raw)
     if not args.indFreqs and not args.population:
         if args.target == "derived":
             popNames, popInds = ["ingroup", "outgroup"], [headerInds[:-1], [headerInds[-1]]]
@@ -709,7 +715,7 @@ def freq_main(argv=None):
     sampleData = SampleData(popNames=popNames, popInds=popInds, ploidyDict=ploidyDict)
     fmt = "pairs" if args.genoFormat == "alleles" else args.genoFormat
     layout = HapLayout(sampleData, headerInds, fmt)
-    data = genoio.encode(body, layout)
+    data = packed.to_geno(body, layout) if packed is not None else genoio.encode(body, layout)
     asCounts = args.asCounts if args.target else True                      # freq.py:222-224
     keepNan = args.keepNanLines if args.target else True
     minData = args.minData if args.target else 0

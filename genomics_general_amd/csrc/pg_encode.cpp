@@ -203,3 +203,38 @@ extern "C" int pg_scaffold_runs(const char *buf, const int64_t *scaf_off, const 
     if (n > max_runs) return pg_fail(PG_ERR_ARG, "%lld scaffold runs exceed capacity %lld", (long long)n, (long long)max_runs);
     return PG_OK;
 }
+
+// ---- packed `.pgeno` blocks -> engine codes --------------------------------------------------------------------------
+// cells[n_rows][n_cols]: one byte per genotype cell, first allele in the low nibble, second in the high nibble, both as the
+// engine's one-hot code (written by genomics_general_amd/genoio.PackedWriter from the output of pg_encode_text).
+extern "C" int pg_decode_packed(const uint8_t *cells, int64_t n_rows, int n_cols, int max_ploidy, const int32_t *col_slot,
+                                const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int n_threads) {
+    if (n_rows < 0 || n_cols < 0 || max_ploidy < 1 || max_ploidy > 2 || n_hap < 1)
+        return pg_fail(PG_ERR_ARG, "pg_decode_packed: bad shape");
+    if (n_rows == 0) return PG_OK;
+    if (!cells || !col_slot || !col_ploidy || !gt_out) return pg_fail(PG_ERR_ARG, "pg_decode_packed: null argument");
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if ((int64_t)nt > n_rows) nt = (int)n_rows;
+    auto work = [&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+            const uint8_t *c = cells + r * n_cols;
+            int8_t *o = gt_out + r * n_hap;
+            memset(o, 0, (size_t)n_hap);
+            for (int k = 0; k < n_cols; ++k) {
+                const int pl = col_ploidy[k];
+                if (pl <= 0) continue;
+                const int s0 = col_slot[k * max_ploidy];
+                if (s0 >= 0) o[s0] = (int8_t)(c[k] & 15);
+                if (pl > 1) {
+                    const int s1 = col_slot[k * max_ploidy + 1];
+                    if (s1 >= 0) o[s1] = (int8_t)(c[k] >> 4);
+                }
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 0; i < nt; ++i) th.emplace_back(work, n_rows * i / nt, n_rows * (i + 1) / nt);
+    for (auto &t : th) t.join();
+    return PG_OK;
+}

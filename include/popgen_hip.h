@@ -101,6 +101,12 @@ int pg_scaffold_runs(const char *buf, const int64_t *scaf_off, const int32_t *sc
 /* Count data rows (non-'#', non-empty) in a text buffer so the caller can size the outputs. */
 int pg_count_lines(const char *buf, size_t len, int64_t *n_rows_out);
 
+/* Packed `.pgeno` input (genomics_general_amd/genoio.py: a tokenised `.geno` file kept on disk, one byte per genotype cell =
+ * first allele code | second allele code << 4, in file column order): block of cells -> one-hot codes in slot order, same
+ * col_slot / col_ploidy tables as pg_encode_text. */
+int pg_decode_packed(const uint8_t *cells, int64_t n_rows, int n_cols, int max_ploidy, const int32_t *col_slot,
+                     const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int n_threads);
+
 /* ---- K2: pairwise matrices ----------------------------------------------------------------------- */
 /* Replaces Alignment.distMatrix / pairDist / numHamming (genomics.py:907-916, 903-905, 1219-1221) and
  * Alignment.pairNonNan (genomics.py:1042-1047).  For each window: D[i][j] = #sites where i and j are

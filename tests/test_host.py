@@ -332,3 +332,47 @@ def test_tokenizer_throughput_report(capsys):
     with capsys.disabled():
         print("\n[tokenizer] %.0f MB/s, %.2f M sites/s (%d diploids, %d host threads)" % (rate, n_lines / dt / 1e6, n_dip, os.cpu_count()))
     assert rate > 20
+
+
+@pytest.mark.parametrize("name,fmt,haploid", [("c1", "phased", ()), ("abba_diplo", "diplo", ()), ("abba_pairs", "pairs", ()),
+                                              ("haplo", "haplo", ()), ("mixed", "phased", ("s1", "s6", "s9")), ("holes", "phased", ())])
+def test_packed_pgeno_round_trip_equals_the_tokenizer(name, fmt, haploid, tmp_path):
+    """genoio.pack_geno -> PackedReader.to_geno (pg_decode_packed) == pg_encode_text of the text, for a layout that reorders,
+    drops and regroups samples; block seams inside scaffolds; carried rows in front"""
+    path = os.path.join(GOLD, name + ".geno.gz")
+    names, body = genoio.split_header(genoio.read_all(path))
+    pl = {nm: (1 if (fmt == "haplo" or nm in haploid) else 2) for nm in names}
+    out = str(tmp_path / "x.pgeno")
+    n = genoio.pack_geno(path, out, fmt, {nm: 1 for nm in haploid}, block_bytes=5000)
+    assert genoio.read_header_names(out) == list(names)
+    sub = list(names[::-1][: max(2, len(names) - 3)])                         # reversed, three samples dropped
+    sd = SampleData(popNames=["x", "y"], popInds=[sub[1::2], sub[0::2]], ploidyDict=pl)
+    lay = HapLayout(sd, names, fmt)
+    whole = genoio.encode(body, lay)
+    assert n == whole.n_sites
+    for block_bytes in (None, 3000, 40000):
+        rd = genoio.open_input(out)
+        assert rd.packed and rd.read_header().decode().split()[2:] == list(names)
+        got, carry = None, None
+        while True:
+            raw = rd.read_block(block_bytes)
+            blk = rd.to_geno(raw, lay, n_threads=3, head_rows=got.n_sites if got is not None else 0)
+            got = genoio.concat(got, blk)
+            if block_bytes is None or not raw:
+                break
+        rd.close()
+        assert np.array_equal(got.gt, whole.gt) and np.array_equal(got.pos, whole.pos)
+        assert list(got.run_starts) == list(whole.run_starts) and got.run_names == whole.run_names
+    # a ploidy that differs from the packed one is refused, so is a file that is not .pgeno
+    if fmt == "phased" and not haploid:
+        bad = dict(pl)
+        bad[sub[0]] = 1
+        lay1 = HapLayout(SampleData(popNames=["x"], popInds=[sub], ploidyDict=bad), names, fmt)
+        rd = genoio.open_input(out)
+        with pytest.raises(ValueError):
+            rd.to_geno(rd.read_block(None), lay1)
+    notp = str(tmp_path / "y.pgeno")
+    with open(notp, "wb") as f:
+        f.write(b"#CHROM\tPOS\ta\n")
+    with pytest.raises(ValueError):
+        genoio.open_input(notp)

@@ -66,6 +66,21 @@ def main():
         if ref_rows is None:
             ref_rows = rows
         print("   output identical to run 0:", rows == ref_rows)
+    # the same job from a packed .pgeno file (tokenised once by tools/geno_pack.py)
+    packed = path[:-5] + ".pgeno"
+    t0 = time.time()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "geno_pack.py"), "-g", path, "-o", packed, "-f", "phased"], check=True)
+    print("packed %s: %.1f MB in %.1f s" % (packed, os.path.getsize(packed) / 1e6, time.time() - t0))
+    pcmd = [packed if c == path else c for c in cmd]
+    for rep in range(2):
+        t0 = time.time()
+        r = subprocess.run(pcmd, env=dict(os.environ, PG_TIMING="1"), stderr=subprocess.PIPE)
+        pwall = time.time() - t0
+        line = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING")]
+        print("packed run %d: wall %.2f s  %s" % (rep, pwall, line[-1] if line else r.stderr.decode()[-400:]))
+        with open("/tmp/t2_out.csv") as f:
+            print("   output identical to run 0:", f.readlines() == ref_rows)
+    print("packed input: windows/s end to end:", round((len(rows) - 1) / pwall, 2), "| sites/s:", round(n_sites / pwall))
     print("rows:", len(rows) - 1, "| windows/s end to end:", round((len(rows) - 1) / wall, 2), "| sites/s:", round(n_sites / wall))
 
 
