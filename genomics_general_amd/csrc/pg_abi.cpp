@@ -175,10 +175,10 @@ std::vector<PgTask2> pg_make_tasks2(int n, int max_nsub, int diag) {
 }
 
 // Circulant task table of k_pairC (see pair_store_circ): 8-row blocks x runs of 64 consecutive columns (mod n).
-std::vector<PgTask2> pg_make_tasks_circ(int n) {
+std::vector<PgTask2> pg_make_tasks_circ(int n, int rows) {
     std::vector<PgTask2> out;
-    const int ncols = std::min(n, 8 + n / 2);              // columns row0 .. row0 + 7 + floor(n/2)
-    for (int r0 = 0; r0 < n; r0 += 8)
+    const int ncols = std::min(n, rows + n / 2);           // columns row0 .. row0 + rows - 1 + floor(n/2)
+    for (int r0 = 0; r0 < n; r0 += rows)
         for (int k = 0; k < ncols; k += 64) {
             PgTask2 t;
             t.row0 = r0;
@@ -258,15 +258,15 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
         }
     }
     c->n_tasks = (int)tasks.size();
-    std::vector<PgTask2> tasks2 = pg_make_tasks2(n_hap, 2, 0);
+    std::vector<PgTask2> tasks2 = getenv("PG_D_TRI") ? pg_make_tasks2(n_hap, 2, 0) : pg_make_tasks_circ(n_hap, 16);
     c->n_tasks2 = (int)tasks2.size();
     c->all_diploid = (n_hap % 2 == 0);
     for (size_t k = 0; k + 1 < sstart.size() && c->all_diploid; ++k)
         if (sstart[k + 1] - sstart[k] != 2) c->all_diploid = false;
     std::vector<PgTask2> tasksC;
-    if (c->all_diploid) tasksC = pg_make_tasks_circ(n_hap / 2);         // k_pairC works on 8-row circulant tasks
+    if (c->all_diploid) tasksC = pg_make_tasks_circ(n_hap / 2, 8);         // k_pairC works on 8-row circulant tasks
     c->n_tasksC = (int)tasksC.size();
-    std::vector<PgTask2> tasksCh = pg_make_tasks_circ(n_hap);
+    std::vector<PgTask2> tasksCh = pg_make_tasks_circ(n_hap, 8);
     c->n_tasksCh = (int)tasksCh.size();
     int rc;
     if ((rc = c->hap_pop.upload(hap_pop, n_hap, c->stream)) != PG_OK) return rc;

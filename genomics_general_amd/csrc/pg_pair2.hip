@@ -409,14 +409,15 @@ __device__ __forceinline__ void pair_store(const uint32_t (&acc)[R], int row0, i
 // at distance n/2 belong to the smaller index), plus the diagonal when asked for.  The columns of a task are
 // col0, col0+1, ... (mod n), `nvalid` of them; a row block of 8 therefore needs 8 + floor(n/2) consecutive columns, i.e. one
 // wave up to 112 units, instead of the rectangles of a triangular tiling that leave half of the diagonal blocks' lanes idle.
-__device__ __forceinline__ void pair_store_circ(const uint32_t (&acc)[8], int row0, int col0, int lane, int nvalid, int n, int diag,
+template <int R>
+__device__ __forceinline__ void pair_store_circ(const uint32_t (&acc)[R], int row0, int col0, int lane, int nvalid, int n, int diag,
                                                 int atomic, int32_t *__restrict__ M) {
     if (lane >= nvalid) return;
     int j = col0 + lane;
     if (j >= n) j -= n;
     const int h = n >> 1;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int i = row0 + r;
         if (i >= n) continue;
         int d = j - i;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(256) void k_pairC(const uint32_t *__restrict__ Vp, 
     if (q1 > q0) pairC_body(Vp, vg_all + q0, q1 - q0, NPv, c, acc, n_units);
     if (block_reduce<8>(acc, red, c.lane)) {
         int32_t *Cw = Cmat + (size_t)c.win * n_units * n_units;
-        if (c.lower == 2) pair_store_circ(acc, c.row0, c.col0, c.lane, c.nsub, n_units, diag, kso > 1, Cw);
+        if (c.lower == 2) pair_store_circ<8>(acc, c.row0, c.col0, c.lane, c.nsub, n_units, diag, kso > 1, Cw);
         else pair_store<8>(acc, c.row0, c.col0 + c.lane, n_units, c.lower, diag, kso > 1, Cw);
     }
 }
@@ -515,9 +516,10 @@ void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, i
 // ------------------------------------------------------------------------------------------------------
 template <int NSUB>
 __device__ __forceinline__ void pairD_body(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw, int64_t g0, int ng,
-                                           int NP, const PairCtx &c, uint32_t (&acc)[8 * NSUB]) {
+                                           int NP, int N, const PairCtx &c, uint32_t (&acc)[8 * NSUB]) {
     constexpr int R = 8 * NSUB;
-    const int j = c.col0 + c.lane;
+    int j = c.col0 + c.lane;
+    if (c.lower == 2 && j >= N) j -= N;                    // circulant task: columns wrap around
     const size_t wstride = (size_t)PG_XV_PLANES * NP;
     for (int g = 0; g < ng; ++g) {
         const int n = __builtin_amdgcn_readfirstlane(nw[g0 + g]);
@@ -547,14 +549,16 @@ __global__ __launch_bounds__(256) void k_pairD(const uint32_t *__restrict__ XV, 
     uint32_t acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0u;
-    if (c.nsub == 1) {                                     // block-uniform
+    if (c.lower != 2 && c.nsub == 1) {                     // block-uniform
         uint32_t (&a8)[8] = reinterpret_cast<uint32_t (&)[8]>(acc);
-        pairD_body<1>(XV, nw, g_all + a, b - a, NP, c, a8);
+        pairD_body<1>(XV, nw, g_all + a, b - a, NP, N, c, a8);
     } else {
-        pairD_body<2>(XV, nw, g_all + a, b - a, NP, c, acc);
+        pairD_body<2>(XV, nw, g_all + a, b - a, NP, N, c, acc);
     }
     if (block_reduce<16>(acc, red, c.lane)) {
-        if (c.nsub == 1) {
+        if (c.lower == 2) {                                // circulant task: 16 rows, nsub = valid columns
+            pair_store_circ<16>(acc, c.row0, c.col0, c.lane, c.nsub, N, 0, kso > 1, Dw);
+        } else if (c.nsub == 1) {
             uint32_t (&a8)[8] = reinterpret_cast<uint32_t (&)[8]>(acc);
             pair_store<8>(a8, c.row0, c.col0 + c.lane, N, c.lower, 0, kso > 1, Dw);
         } else {
