@@ -618,7 +618,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         // + 2 word groups: k_pairC's look-ahead loads read one group past a wave's range
         if ((rc = sl.Vp.ensure((size_t)(std::max<int64_t>(va, 1) + 2) * NPv * 4)) != PG_OK) return rc;
         if ((rc = sl.XV.ensure((size_t)std::max<int64_t>(ga, 1) * PG_GROUP * PG_XV_PLANES * NP)) != PG_OK) return rc;
-        if ((rc = sl.nw.ensure((size_t)std::max<int64_t>(ga, 1))) != PG_OK) return rc;
+        if ((rc = sl.nw.ensure((size_t)std::max<int64_t>(ga, 1) + nb)) != PG_OK) return rc;   // [window] words, [nb + group] first word
         if ((rc = c->Cmat.ensure((size_t)nb * n_units * n_units)) != PG_OK) return rc;
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
         hipEvent_t e0, e1;

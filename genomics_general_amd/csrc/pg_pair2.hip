@@ -12,9 +12,10 @@
 // Layouts (uint32 words, 32 sites per word):
 //   Vp[(vgoff[b] + wq) * NPv + unit][4]   called plane, 4 consecutive words of one unit contiguous (one 16-byte load per lane per
 //                                          128 sites; 8 rows x 4 words = 2 x s_load_dwordx16); two padding word groups at the end
-//   XV[((goff[b] + g) * PG_GROUP + k) * PG_XV_PLANES + p][NP]   dense words of the polymorphic sites of group g (2048 sites):
-//                                          p = 0,1 bits of the allele index (A,C,G,T = 0..3), p = 2 called;
-//                                          nw[goff[b]+g] = words used (0..64)
+//   XV[(goff[b] * PG_GROUP + k) * PG_XV_PLANES + p][NP]   dense words of the polymorphic sites of window b, k = 0 .. nw[b]-1, in no
+//                                          particular order (a compaction group of 2048 sites takes the next free word of its
+//                                          window whenever it has collected 32 polymorphic sites, and once more for its last,
+//                                          partial word); p = 0,1 bits of the allele index (A,C,G,T = 0..3), p = 2 called
 //   differ & both called == ((b0_i ^ b0_j) | (b1_i ^ b1_j)) & v_i & v_j: row operands in SGPRs, column operands in VGPRs.
 #include "pg_internal.h"
 
@@ -187,6 +188,48 @@ __global__ __launch_bounds__(256) void k_presence(const int8_t *__restrict__ gt,
     }
 }
 
+// PRES mode: words of XV each group will produce (from the presence nibbles of k_presence) and their exclusive prefix inside
+// the window -> nw[n_win + group] = first word of the group, nw[window] = words of the window.  Block = one window.
+__global__ __launch_bounds__(256) void k_word_scan(const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
+                                                   const int64_t *__restrict__ goff, const uint32_t *__restrict__ pres,
+                                                   int32_t *__restrict__ nw) {
+    __shared__ int sh[256];
+    __shared__ int carry;
+    const int b = blockIdx.x, n_win = gridDim.x;
+    const int64_t lo = win_lo[b], hi = win_hi[b];
+    const int W = (int)((hi - lo + 31) >> 5);
+    const int G = (W + PG_GROUP - 1) / PG_GROUP;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int g0 = 0; g0 < G; g0 += 256) {
+        const int g = g0 + threadIdx.x;
+        int words = 0;
+        if (g < G) {
+            const int nwords = (W - g * PG_GROUP < PG_GROUP) ? W - g * PG_GROUP : PG_GROUP;
+            const uint32_t *src = pres + (size_t)(goff[b] + g) * PG_GROUP * 4u;
+            int cnt = 0;
+            for (int w = 0; w < nwords; ++w) {
+                const uint32_t p[4] = {src[4 * w], src[4 * w + 1], src[4 * w + 2], src[4 * w + 3]};
+                cnt += __builtin_popcount(poly_mask(p));
+            }
+            words = (cnt + 31) >> 5;
+        }
+        sh[threadIdx.x] = words;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {                 // inclusive scan
+            const int v = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (g < G) nw[n_win + goff[b] + g] = carry + sh[threadIdx.x] - words;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nw[b] = carry;
+}
+
 template <int TPB, int DIP, int PRES>
 __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
                                                const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
@@ -195,7 +238,8 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                                                int32_t *__restrict__ mismatch, const uint32_t *__restrict__ pres) {
     constexpr int NWAVE = TPB / 64;
     __shared__ uint32_t sh_pres[2][NWAVE][4];
-    const int b = blockIdx.y, g = blockIdx.x;
+    __shared__ int sh_slot;
+    const int b = blockIdx.y, g = blockIdx.x, n_win = gridDim.y;
     const int64_t lo = win_lo[b], hi = win_hi[b];
     const int W = (int)((hi - lo + 31) >> 5);
     const int w_begin = g * PG_GROUP;
@@ -214,9 +258,26 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
     uint32_t vlist = (uint32_t)nrows;        // lane i = list entry i; "nrows" is one row past the descriptor: reads as zero
     int cnt = 0, nflush = 0, parity = 0;
     uint32_t bad = 0u;
-    uint32_t *xv_base = XV + (size_t)(goff[b] + g) * PG_GROUP * PG_XV_PLANES * (size_t)NP;
+    uint32_t *xv_base = XV + (size_t)goff[b] * PG_GROUP * PG_XV_PLANES * (size_t)NP;
     const int64_t vg_base = vgoff[b] + (int64_t)(w_begin >> 2);
+    // PRES: the group's words start at gbase (k_word_scan); otherwise every flush takes the window's next free word
+    const int gbase = PRES ? nw[n_win + goff[b] + g] : 0;
     auto flush = [&]() {                     // the first 32 list entries become one dense word of XV
+        int slot;
+        if (PRES) {
+            slot = gbase + nflush;
+        } else {
+            if (NWAVE == 1) {
+                int s0 = 0;
+                if (lane == 0) s0 = atomicAdd(&nw[b], 1);
+                slot = __builtin_amdgcn_readfirstlane(s0);
+            } else {
+                if (threadIdx.x == 0) sh_slot = atomicAdd(&nw[b], 1);
+                __syncthreads();
+                slot = __builtin_amdgcn_readfirstlane(sh_slot);
+                __syncthreads();
+            }
+        }
         if (in_np) {
             uint32_t x[PG_XV_PLANES][4];
 #pragma unroll
@@ -224,7 +285,7 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
 #pragma unroll
                 for (int k = 0; k < 4; ++k) x[p][k] = 0u;
             if (has_data) poly_word(rsrc, h0, S, vlist, x);
-            uint32_t *o = xv_base + (size_t)nflush * PG_XV_PLANES * (size_t)NP + h0;
+            uint32_t *o = xv_base + (size_t)slot * PG_XV_PLANES * (size_t)NP + h0;
 #pragma unroll
             for (int p = 0; p < PG_XV_PLANES; ++p)
                 store16(o + (size_t)p * NP, x[p][0], x[p][1], x[p][2], x[p][3]);
@@ -310,7 +371,6 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
         }
     }
     if (cnt) flush();
-    if (t == 0) nw[goff[b] + g] = nflush;
     if (DIP && bad) atomicOr(mismatch, 1);
 }
 
@@ -327,6 +387,7 @@ static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *g
     else {
         grid.z = (threads + 255) / 256;
         hipLaunchKernelGGL(k_presence, grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, pres);
+        hipLaunchKernelGGL(k_word_scan, dim3(grid.y), dim3(256), 0, st, win_lo, win_hi, goff, pres, nw);
         hipLaunchKernelGGL((k_pack2<256, DIP, 1>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
     }
 }
@@ -338,6 +399,7 @@ void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win
     if (n_win <= 0 || max_groups <= 0) return;
     const int threads = NP / 4;
     if (threads > 256) (void)hipMemsetAsync(pres, 0, (size_t)total_groups * PG_GROUP * 16u, st);
+    else (void)hipMemsetAsync(nw, 0, (size_t)n_win * 4u, st);          // per-window word counters (atomic allocation)
     dim3 grid(max_groups, n_win);
     if (dip) launch_pack2<1>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
     else launch_pack2<0>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
@@ -515,23 +577,19 @@ void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, i
 //   differ & both called == ((b0_i ^ b0_j) | (b1_i ^ b1_j)) & v_i & v_j   -> v_xor, 2 x v_bitop3, accumulating v_bcnt
 // ------------------------------------------------------------------------------------------------------
 template <int NSUB>
-__device__ __forceinline__ void pairD_body(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw, int64_t g0, int ng,
-                                           int NP, int N, const PairCtx &c, uint32_t (&acc)[8 * NSUB]) {
+__device__ __forceinline__ void pairD_body(const uint32_t *__restrict__ XVw, int w0, int w1, int NP, int N, const PairCtx &c,
+                                           uint32_t (&acc)[8 * NSUB]) {
     constexpr int R = 8 * NSUB;
     int j = c.col0 + c.lane;
     if (c.lower == 2 && j >= N) j -= N;                    // circulant task: columns wrap around
     const size_t wstride = (size_t)PG_XV_PLANES * NP;
-    for (int g = 0; g < ng; ++g) {
-        const int n = __builtin_amdgcn_readfirstlane(nw[g0 + g]);
-        const uint32_t *gb = XV + (size_t)(g0 + g) * PG_GROUP * wstride;
-        for (int w = 0; w < n; ++w) {
-            const uint32_t *pw = gb + (size_t)w * wstride;
-            const uint32_t c0 = pw[j], c1 = pw[(size_t)NP + j], cv = pw[(size_t)2 * NP + j];
-            const CU32 *pr = (const CU32 *)(pw + c.row0);
+    for (int w = w0; w < w1; ++w) {
+        const uint32_t *pw = XVw + (size_t)w * wstride;
+        const uint32_t c0 = pw[j], c1 = pw[(size_t)NP + j], cv = pw[(size_t)2 * NP + j];
+        const CU32 *pr = (const CU32 *)(pw + c.row0);
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                acc[r] = bcnt_acc((((pr[r] ^ c0) | (pr[NP + r] ^ c1)) & pr[2 * NP + r]) & cv, acc[r]);
-        }
+        for (int r = 0; r < R; ++r)
+            acc[r] = bcnt_acc((((pr[r] ^ c0) | (pr[NP + r] ^ c1)) & pr[2 * NP + r]) & cv, acc[r]);
     }
 }
 
@@ -541,19 +599,19 @@ __global__ __launch_bounds__(256) void k_pairD(const uint32_t *__restrict__ XV, 
     __shared__ uint32_t red[3 * 16][64];
     PairCtx c;
     if (!pair_decode(tasks, n_tasks, kso, n_win, c)) return;
-    const int64_t g_all = goff[c.win];
-    const int ng_all = (int)(goff[c.win + 1] - g_all);
+    const uint32_t *XVw = XV + (size_t)goff[c.win] * PG_GROUP * PG_XV_PLANES * (size_t)NP;      // the window's words
+    const int n_words = __builtin_amdgcn_readfirstlane(nw[c.win]);
     const int parts = 4 * kso;
-    const int a = (int)((long long)ng_all * c.ks / parts), b = (int)((long long)ng_all * (c.ks + 1) / parts);
+    const int a = (int)((long long)n_words * c.ks / parts), b = (int)((long long)n_words * (c.ks + 1) / parts);
     int32_t *Dw = Dmat + (size_t)c.win * N * N;
     uint32_t acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0u;
     if (c.lower != 2 && c.nsub == 1) {                     // block-uniform
         uint32_t (&a8)[8] = reinterpret_cast<uint32_t (&)[8]>(acc);
-        pairD_body<1>(XV, nw, g_all + a, b - a, NP, N, c, a8);
+        pairD_body<1>(XVw, a, b, NP, N, c, a8);
     } else {
-        pairD_body<2>(XV, nw, g_all + a, b - a, NP, N, c, acc);
+        pairD_body<2>(XVw, a, b, NP, N, c, acc);
     }
     if (block_reduce<16>(acc, red, c.lane)) {
         if (c.lower == 2) {                                // circulant task: 16 rows, nsub = valid columns
