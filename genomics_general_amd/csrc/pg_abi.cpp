@@ -155,26 +155,7 @@ extern "C" int pg_set_scratch_limit(pg_ctx *c, int64_t bytes) {
 // Units [0,n).  Full 64-column chunks cover columns [0, 64*floor(n/64)) with the rows above them (i<j); the remaining
 // R = n mod 64 units are handled as ROWS against every column chunk (pairs j<i, written at (j,i)), so no wave runs with
 // only R of its 64 lanes useful.  Rows come in sub-tiles of 8, up to max_nsub sub-tiles per wave.
-std::vector<PgTask2> pg_make_tasks2(int n, int max_nsub, int diag) {
-    std::vector<PgTask2> out;
-    const int full = (n / 64) * 64;
-    auto push_rows = [&](int row_begin, int row_end, int col0, int lower) {       // rows [row_begin,row_end), 8-aligned begin
-        for (int r = row_begin; r < row_end; r += 8 * max_nsub) {
-            PgTask2 t;
-            t.row0 = r;
-            t.nsub = std::min(max_nsub, (row_end - r + 7) / 8);
-            t.col0 = col0;
-            t.lower = lower;
-            out.push_back(t);
-        }
-    };
-    for (int c0 = 0; c0 < full; c0 += 64) push_rows(0, c0 + 63 + (diag ? 1 : 0), c0, 0);   // rows i < c0+63 (<= with diag)
-    if (n > full)
-        for (int c0 = 0; c0 < n; c0 += 64) push_rows(full, n, c0, 1);
-    return out;
-}
-
-// Circulant task table of k_pairC (see pair_store_circ): 8-row blocks x runs of 64 consecutive columns (mod n).
+// Circulant task table of k_pairC / k_pairD (see pair_store_circ): `rows`-row blocks x runs of 64 consecutive columns (mod n).
 std::vector<PgTask2> pg_make_tasks_circ(int n, int rows) {
     std::vector<PgTask2> out;
     const int ncols = std::min(n, rows + n / 2);           // columns row0 .. row0 + rows - 1 + floor(n/2)
@@ -258,7 +239,7 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
         }
     }
     c->n_tasks = (int)tasks.size();
-    std::vector<PgTask2> tasks2 = getenv("PG_D_TRI") ? pg_make_tasks2(n_hap, 2, 0) : pg_make_tasks_circ(n_hap, 16);
+    std::vector<PgTask2> tasks2 = pg_make_tasks_circ(n_hap, 16);       // k_pairD: 16-row circulant tasks
     c->n_tasks2 = (int)tasks2.size();
     c->all_diploid = (n_hap % 2 == 0);
     for (size_t k = 0; k + 1 < sstart.size() && c->all_diploid; ++k)
@@ -550,8 +531,8 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     c->cN = n_units;
     c->cshift = dip ? 1 : 0;
     const int64_t mat_bytes = 4ll * N * N + 4ll * n_units * n_units;
-    // scratch bytes per 32-site input word of one slot: called plane + worst-case (all polymorphic) allele planes
-    const int64_t word_bytes = (int64_t)NP * 4 * PG_XV_PLANES + (int64_t)NPv * 4;
+    // scratch bytes per 32-site input word of one slot: called plane + worst-case (four alleles at every site) virtual-site planes
+    const int64_t word_bytes = (int64_t)NP * 4 * PG_XV_PLANES * (PG_XV_CAP / PG_GROUP) + (int64_t)NPv * 4;
     // sub-batch size: at most half the scratch budget per slot, and at least ~8 sub-batches per call so the two
     // streams have something to overlap (but not so small that a sub-batch cannot fill the GPU)
     int64_t total_words_all = 0;
@@ -617,7 +598,8 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
                       *d_vgoff = sl.win.p + 3 * (size_t)nb + 1;
         // + 2 word groups: k_pairC's look-ahead loads read one group past a wave's range
         if ((rc = sl.Vp.ensure((size_t)(std::max<int64_t>(va, 1) + 2) * NPv * 4)) != PG_OK) return rc;
-        if ((rc = sl.XV.ensure((size_t)std::max<int64_t>(ga, 1) * PG_GROUP * PG_XV_PLANES * NP)) != PG_OK) return rc;
+        // + 2 words: k_pairD's look-ahead loads read two words past a wave's range
+        if ((rc = sl.XV.ensure(((size_t)std::max<int64_t>(ga, 1) * PG_XV_CAP + 2) * PG_XV_PLANES * NP)) != PG_OK) return rc;
         if ((rc = sl.nw.ensure((size_t)std::max<int64_t>(ga, 1) + nb)) != PG_OK) return rc;   // [window] words, [nb + group] first word
         if ((rc = c->Cmat.ensure((size_t)nb * n_units * n_units)) != PG_OK) return rc;
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;

@@ -9,7 +9,7 @@
 #define PG_ABBA_SITES_PER_BLOCK 4096   // k_abba_q: fewer, longer blocks (prologue masks + epilogue reduction per block)
 #define PG_ABBA_NSUM 6
 #define PG_FOURPOP_NSUM 14
-#define PG_XV_PLANES 3        // compacted polymorphic-site planes per word: allele-index bit 0, bit 1, called
+#define PG_XV_PLANES 2        // planes per word of virtual biallelic sites: x ("carries the tested allele"), v (called, not excluded)
 
 struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,row0+8*nsub) x cols [col0,col0+64)
     int32_t row0, nsub, col0, pad;
@@ -18,10 +18,10 @@ struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,r
 #ifndef PG_GROUP
 #define PG_GROUP 64
 #endif             // input words (of 32 sites) per compaction group of k_pack2
+#define PG_XV_CAP (3 * PG_GROUP)   // worst-case words of virtual sites per group (every site with four alleles)
 
-struct PgTask2 {                // one wave of k_pairC / k_pairD: rows [row0,row0+8*nsub) x cols [col0,col0+64)
-    int32_t row0, nsub, col0, lower;   // lower = 1: remainder rows, the valid pairs are those with col < row
-                                       // lower = 2: circulant task of k_pairC (pair_store_circ), nsub = number of valid columns
+struct PgTask2 {                // one block of k_pairC (8 rows) / k_pairD (16 rows): circulant task, see pair_store_circ
+    int32_t row0, nsub, col0, lower;   // rows row0.., columns col0, col0+1, ... (mod n), nsub = number of valid columns; lower = 2
 };
 
 struct PgSynthParams {

@@ -1,22 +1,29 @@
 // v2 pairwise pipeline: the pairwise matrices split into the two terms that need different amounts of work.
 //
 //   C[i][j] = sum over ALL sites of v_i & v_j                       -> k_pairC on the "called" plane only (2 VALU / 32 pair-sites)
-//   D[i][j] = sum over POLYMORPHIC sites of differ(i,j) & v_i & v_j -> k_pairD on the polymorphic-site planes (4 VALU / 32 pair-sites)
+//   D[i][j] = sum over POLYMORPHIC sites of differ(i,j) & v_i & v_j -> k_pairD on the polymorphic-site planes (3 VALU / 32 pair-sites)
 //
 // A site whose called haplotypes all carry the same allele adds the same amount to C and to "same allele", i.e. nothing to D
 // (genomics.py:903-905, 1219-1221: numHamming counts differences among jointly called sites).  k_pack2 therefore detects
 // polymorphic sites (>= 2 alleles present among the called haplotypes of the window's slots) while it builds the called
-// plane, and transposes the allele planes of those sites only.  Data-dependent, exact, and the algorithmic pair-sites stay the
-// denominator of every reported rate.
+// plane, and transposes those sites only.  Data-dependent, exact, and the algorithmic pair-sites stay the denominator of every
+// reported rate.
+//
+// Every polymorphic site becomes k-1 VIRTUAL BIALLELIC sites (k = alleles present, a_0 < a_1 < ... in A,C,G,T order):
+//   virtual site t:  x = "carries a_t",  v = "called and carries none of a_0 .. a_(t-1)"
+//   differ(i,j) & both called  ==  sum over t of (x_i ^ x_j) & v_i & v_j
+// (a pair with alleles (a_0, other) differs at t = 0 and is excluded afterwards; a pair without a_0 is compared at t = 1; ...),
+// so k_pairD needs two planes and three VALU ops per 32 pair-sites whatever the number of alleles; real data is almost entirely
+// biallelic (k - 1 = 1).
 //
 // Layouts (uint32 words, 32 sites per word):
 //   Vp[(vgoff[b] + wq) * NPv + unit][4]   called plane, 4 consecutive words of one unit contiguous (one 16-byte load per lane per
 //                                          128 sites; 8 rows x 4 words = 2 x s_load_dwordx16); two padding word groups at the end
-//   XV[(goff[b] * PG_GROUP + k) * PG_XV_PLANES + p][NP]   dense words of the polymorphic sites of window b, k = 0 .. nw[b]-1, in no
+//   XV[(goff[b] * PG_XV_CAP + k) * 2 * NP + 2 * hap + p]   dense words of the virtual sites of window b, k = 0 .. nw[b]-1, in no
 //                                          particular order (a compaction group of 2048 sites takes the next free word of its
-//                                          window whenever it has collected 32 polymorphic sites, and once more for its last,
-//                                          partial word); p = 0,1 bits of the allele index (A,C,G,T = 0..3), p = 2 called
-//   differ & both called == ((b0_i ^ b0_j) | (b1_i ^ b1_j)) & v_i & v_j: row operands in SGPRs, column operands in VGPRs.
+//                                          window whenever it has collected 32 virtual sites, and once more for its last,
+//                                          partial word); p = 0: x, p = 1: v; the planes of a haplotype are adjacent (rows: two
+//                                          s_load_dwordx16 per 16 haplotypes, column: one 8-byte load); two padding words at the end
 #include "pg_internal.h"
 
 typedef __attribute__((address_space(4))) const uint32_t CU32;
@@ -31,10 +38,12 @@ typedef __attribute__((address_space(4))) const uint32_t CU32;
 //     site (nibble != 0) -> called plane Vp, (ii) the OR over all haplotypes -> per-site allele presence nibbles, reduced
 //     over the wave with DPP and over the block through LDS.  A site is polymorphic when its presence nibble has >= 2 bits;
 //     that test and the list bookkeeping run on the scalar unit.
-//   phase B, every 32 polymorphic sites: their rows are loaded again (scalar row offsets read from a lane-resident list;
-//     they were touched a few words ago) and the four allele planes + called plane are transposed the same way and stored
-//     as one dense word of XV.  k_pairD therefore only ever sees polymorphic sites, and the expensive 5-plane
-//     transposition runs on ~10 % of the rows of typical whole-genome data instead of all of them.
+//   phase B, every 32 virtual sites: their rows are loaded again (scalar row offsets read from a lane-resident list; they were
+//     touched a few words ago), the four allele planes are transposed the same way, and x / v of each virtual site are
+//     selected from them with per-word masks (which allele a virtual site tests and which it excludes: computed per list
+//     entry from the word's presence nibbles, turned into masks with v_cmp ballots) and stored as one dense word of XV.
+//     k_pairD therefore only ever sees polymorphic sites, and the expensive transposition runs on ~10 % of the rows of
+//     typical whole-genome data instead of all of them.
 //
 //   The bit order inside a produced word is a fixed permutation of the 32 sites, identical for every haplotype and plane,
 //   which is all the popcounts of k_pairC / k_pairD need.
@@ -104,30 +113,36 @@ __device__ __forceinline__ void word_called_presence(const uint32_t d[32], uint3
     }
 }
 
-// Phase B: lane i of vlist holds the group-relative row of list entry i (entries past the end hold a row beyond the
-// descriptor and read as zero).  x[p][k], p = 0,1: bit p of the allele index (one-hot nibble A,C,G,T = 1,2,4,8 -> index 0..3),
-// p = 2: called, of haplotype h0+k over the 32 listed sites.
-__device__ __forceinline__ void poly_word(__amdgpu_buffer_rsrc_t rsrc, int h0, int S, uint32_t vlist, uint32_t x[PG_XV_PLANES][4]) {
+// Phase B: lane i of vlist holds list entry i: group-relative row | (ordinal t of the virtual site << 16); entries past the end
+// hold a row beyond the descriptor and read as zero.  SA[a]: entries (bits, in output order) whose tested allele is a (A, C or
+// G: the highest allele present is never tested); SE[a]: entries that exclude allele a (A or C).
+//   x[0][k] = x, x[1][k] = v of haplotype h0+k over the 32 listed virtual sites.
+__device__ __forceinline__ void poly_word(__amdgpu_buffer_rsrc_t rsrc, int h0, int S, uint32_t vlist, const uint32_t SA[3],
+                                          const uint32_t SE[2], uint32_t x[PG_XV_PLANES][4]) {
+    uint32_t al[4][4];                                                   // [allele][haplotype]: carries the allele
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         uint32_t d[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int row = __builtin_amdgcn_readlane((int)vlist, q * 8 + s);
+            const int row = __builtin_amdgcn_readlane((int)vlist, q * 8 + s) & 0xffff;
             d[s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, h0, row * S, 0);
         }
         uint32_t r[4];
         btrans4(d[0] | (d[1] << 4), d[2] | (d[3] << 4), d[4] | (d[5] << 4), d[6] | (d[7] << 4), r);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t n1 = r[k] >> 1, n2 = r[k] >> 2, n3 = r[k] >> 3;
-            const uint32_t b0 = (n1 | n3) & 0x11111111u;                 // C or T
-            const uint32_t b1 = (n2 | n3) & 0x11111111u;                 // G or T
-            const uint32_t cv = (r[k] | n1 | n2 | n3) & 0x11111111u;     // any allele
-            x[0][k] = q ? (x[0][k] | (b0 << q)) : b0;
-            x[1][k] = q ? (x[1][k] | (b1 << q)) : b1;
-            x[2][k] = q ? (x[2][k] | (cv << q)) : cv;
-        }
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const uint32_t piece = (a >= q ? (r[k] >> (a - q)) : (r[k] << (q - a))) & (0x11111111u << q);
+                al[a][k] = q ? (al[a][k] | piece) : piece;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t ex = (al[0][k] & SE[0]) | (al[1][k] & SE[1]);
+        x[0][k] = (al[0][k] & SA[0]) | (al[1][k] & SA[1]) | (al[2][k] & SA[2]);
+        x[1][k] = (al[0][k] | al[1][k] | al[2][k] | al[3][k]) & ~ex;
     }
 }
 
@@ -152,6 +167,12 @@ __device__ __forceinline__ void wave_or4(uint32_t v[4]) {
 __device__ __forceinline__ uint32_t poly_mask(const uint32_t p[4]) {
     return (p[0] & p[1]) | (p[2] & p[3]) | ((p[0] ^ p[1]) & (p[2] ^ p[3]));
 }
+
+// sites at which at least three / all four alleles occur
+__device__ __forceinline__ uint32_t tri_mask(const uint32_t p[4]) {
+    return (p[0] & p[1] & (p[2] | p[3])) | (p[2] & p[3] & (p[0] | p[1]));
+}
+__device__ __forceinline__ uint32_t quad_mask(const uint32_t p[4]) { return p[0] & p[1] & p[2] & p[3]; }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t group_rsrc(const int8_t *gt, int S, int64_t first_row, int nrows) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(gt + first_row * (int64_t)S), 0, nrows * S, 0x00020000);
@@ -188,7 +209,7 @@ __global__ __launch_bounds__(256) void k_presence(const int8_t *__restrict__ gt,
     }
 }
 
-// PRES mode: words of XV each group will produce (from the presence nibbles of k_presence) and their exclusive prefix inside
+// PRES mode (32 virtual sites per word; a site with k alleles is k-1 virtual sites): words of XV each group will produce (from the presence nibbles of k_presence) and their exclusive prefix inside
 // the window -> nw[n_win + group] = first word of the group, nw[window] = words of the window.  Block = one window.
 __global__ __launch_bounds__(256) void k_word_scan(const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
                                                    const int64_t *__restrict__ goff, const uint32_t *__restrict__ pres,
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256) void k_word_scan(const int64_t *__restrict__ w
             int cnt = 0;
             for (int w = 0; w < nwords; ++w) {
                 const uint32_t p[4] = {src[4 * w], src[4 * w + 1], src[4 * w + 2], src[4 * w + 3]};
-                cnt += __builtin_popcount(poly_mask(p));
+                cnt += __builtin_popcount(poly_mask(p)) + __builtin_popcount(tri_mask(p)) + __builtin_popcount(quad_mask(p));
             }
             words = (cnt + 31) >> 5;
         }
@@ -238,6 +259,7 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                                                int32_t *__restrict__ mismatch, const uint32_t *__restrict__ pres) {
     constexpr int NWAVE = TPB / 64;
     __shared__ uint32_t sh_pres[2][NWAVE][4];
+    __shared__ uint4 sh_gp[PRES ? 1 : PG_GROUP];          // presence nibbles of the group's words (PRES: read from `pres`)
     __shared__ int sh_slot;
     const int b = blockIdx.y, g = blockIdx.x, n_win = gridDim.y;
     const int64_t lo = win_lo[b], hi = win_hi[b];
@@ -258,7 +280,8 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
     uint32_t vlist = (uint32_t)nrows;        // lane i = list entry i; "nrows" is one row past the descriptor: reads as zero
     int cnt = 0, nflush = 0, parity = 0;
     uint32_t bad = 0u;
-    uint32_t *xv_base = XV + (size_t)goff[b] * PG_GROUP * PG_XV_PLANES * (size_t)NP;
+    uint32_t *xv_base = XV + (size_t)goff[b] * PG_XV_CAP * PG_XV_PLANES * (size_t)NP;
+    const uint32_t *pres_g = pres + (size_t)(goff[b] + g) * PG_GROUP * 4u;       // PRES only
     const int64_t vg_base = vgoff[b] + (int64_t)(w_begin >> 2);
     // PRES: the group's words start at gbase (k_word_scan); otherwise every flush takes the window's next free word
     const int gbase = PRES ? nw[n_win + goff[b] + g] : 0;
@@ -278,17 +301,38 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                 __syncthreads();
             }
         }
+        // which allele each of the 32 entries tests (A) and which alleles it excludes (E), from the presence nibble of its site
+        uint32_t A = 0u, E = 0u;
+        {
+            const int row = (int)(vlist & 0xffffu), ord = (int)(vlist >> 16);
+            if (row < nrows) {
+                const int wi = row >> 5, st = row & 31, bit = 4 * (st & 7) + (st >> 3);
+                const uint4 pp = PRES ? *reinterpret_cast<const uint4 *>(pres_g + 4 * wi) : sh_gp[PRES ? 0 : wi];
+                const uint32_t P = ((pp.x >> bit) & 1u) | (((pp.y >> bit) & 1u) << 1) | (((pp.z >> bit) & 1u) << 2) |
+                                   (((pp.w >> bit) & 1u) << 3);
+                const uint32_t A0 = P & (0u - P), P1 = P ^ A0, A1 = P1 & (0u - P1), P2 = P1 ^ A1, A2 = P2 & (0u - P2);
+                A = ord == 0 ? A0 : (ord == 1 ? A1 : A2);
+                E = (A - 1u) & P;
+            }
+        }
+        // output bit 4j+q <-> entry q*8+j: lane 4j+q fetches that entry's A / E, the ballots then are the masks
+        const int src = (lane & 3) * 8 + ((lane >> 2) & 7);
+        A = (uint32_t)__shfl((int)A, src, 64);
+        E = (uint32_t)__shfl((int)E, src, 64);
+        const uint32_t SA[3] = {(uint32_t)__builtin_amdgcn_ballot_w64(A == 1u), (uint32_t)__builtin_amdgcn_ballot_w64(A == 2u),
+                                (uint32_t)__builtin_amdgcn_ballot_w64(A == 4u)};
+        const uint32_t SE[2] = {(uint32_t)__builtin_amdgcn_ballot_w64((E & 1u) != 0u),
+                                (uint32_t)__builtin_amdgcn_ballot_w64((E & 2u) != 0u)};
         if (in_np) {
             uint32_t x[PG_XV_PLANES][4];
 #pragma unroll
             for (int p = 0; p < PG_XV_PLANES; ++p)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) x[p][k] = 0u;
-            if (has_data) poly_word(rsrc, h0, S, vlist, x);
-            uint32_t *o = xv_base + (size_t)slot * PG_XV_PLANES * (size_t)NP + h0;
-#pragma unroll
-            for (int p = 0; p < PG_XV_PLANES; ++p)
-                store16(o + (size_t)p * NP, x[p][0], x[p][1], x[p][2], x[p][3]);
+            if (has_data) poly_word(rsrc, h0, S, vlist, SA, SE, x);
+            uint32_t *o = xv_base + (size_t)slot * PG_XV_PLANES * (size_t)NP + 2 * h0;
+            store16(o, x[0][0], x[1][0], x[0][1], x[1][1]);
+            store16(o + 4, x[0][2], x[1][2], x[0][3], x[1][3]);
         }
         ++nflush;
     };
@@ -341,19 +385,28 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                     }
                     parity ^= 1;
                 }
-                uint32_t m = poly_mask(pr);
+                if (!PRES && threadIdx.x == 0) sh_gp[PRES ? 0 : w - w_begin] = make_uint4(pr[0], pr[1], pr[2], pr[3]);
                 const int row_w = (w - w_begin) * 32;
-                while (m) {                          // scalar loop: append the word's polymorphic rows to the list
-                    const int bit = __builtin_ctz(m);
-                    m &= m - 1u;
-                    vlist = lane == cnt ? (uint32_t)(row_w + (bit & 3) * 8 + (bit >> 2)) : vlist;
-                    ++cnt;
-                }
-                if (cnt >= 32) {
-                    flush();
-                    const uint32_t up = (uint32_t)__shfl((int)vlist, (lane + 32) & 63, 64);
-                    vlist = lane < 32 ? up : (uint32_t)nrows;
-                    cnt -= 32;
+                auto append = [&](uint32_t m, uint32_t tag) {   // scalar loop: the word's sites in m join the list (<= 32 of them)
+                    while (m) {
+                        const int bit = __builtin_ctz(m);
+                        m &= m - 1u;
+                        vlist = lane == cnt ? ((uint32_t)(row_w + (bit & 3) * 8 + (bit >> 2)) | tag) : vlist;
+                        ++cnt;
+                    }
+                    if (cnt >= 32) {
+                        flush();
+                        const uint32_t up = (uint32_t)__shfl((int)vlist, (lane + 32) & 63, 64);
+                        vlist = lane < 32 ? up : (uint32_t)nrows;
+                        cnt -= 32;
+                    }
+                };
+                append(poly_mask(pr), 0u);                       // virtual site 0 of every polymorphic site
+                const uint32_t m3 = tri_mask(pr);
+                if (m3) {                                        // rare: second / third virtual site of sites with 3 / 4 alleles
+                    append(m3, 1u << 16);
+                    const uint32_t m4 = quad_mask(pr);
+                    if (m4) append(m4, 2u << 16);
                 }
             }
         }
@@ -450,24 +503,7 @@ __device__ __forceinline__ bool block_reduce(uint32_t (&acc)[R], uint32_t (*red)
     return true;
 }
 
-// store acc[r] for pair (row0+r, j): upper tasks keep i<j (i<=j with diag), lower tasks keep j<i (j<=i) and write (j,i)
-template <int R>
-__device__ __forceinline__ void pair_store(const uint32_t (&acc)[R], int row0, int j, int n, int lower, int diag, int atomic,
-                                           int32_t *__restrict__ M) {
-    if (j >= n) return;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = row0 + r;
-        if (i >= n) continue;
-        const bool keep = lower ? (j < i || (diag && i == j)) : (i < j || (diag && i == j));
-        if (!keep) continue;
-        int32_t *dst = lower ? &M[(size_t)j * n + i] : &M[(size_t)i * n + j];
-        if (atomic) { if (acc[r]) atomicAdd(dst, (int32_t)acc[r]); }
-        else *dst = (int32_t)acc[r];
-    }
-}
-
-// Circulant tasks (k_pairC): row i owns the unordered pairs {i, i+d}, d = 1 .. floor(n/2) (indices mod n; for even n the pairs
+// Circulant tasks: row i owns the unordered pairs {i, i+d}, d = 1 .. floor(n/2) (indices mod n; for even n the pairs
 // at distance n/2 belong to the smaller index), plus the diagonal when asked for.  The columns of a task are
 // col0, col0+1, ... (mod n), `nvalid` of them; a row block of 8 therefore needs 8 + floor(n/2) consecutive columns, i.e. one
 // wave up to 112 units, instead of the rectangles of a triangular tiling that leave half of the diagonal blocks' lanes idle.
@@ -512,7 +548,7 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
 __device__ __forceinline__ void pairC_body(const uint32_t *__restrict__ Vp, int64_t vg0, int nwq, int NPv, const PairCtx &c,
                                            uint32_t (&acc)[8], int n_units) {
     int j = c.col0 + c.lane;
-    if (c.lower == 2 && j >= n_units) j -= n_units;                  // circulant task: columns wrap around
+    if (j >= n_units) j -= n_units;                                  // circulant task: columns wrap around
     const uint32_t stride = (uint32_t)NPv * 16u;                       // bytes per word group
     // 32-bit byte offsets inside the asm loop: a call covers at most 2 GiB of the plane
     const int chunk = (int)(0x7fffffffu / stride) > 2 ? (int)(0x7fffffffu / stride) - 2 : 1;
@@ -548,8 +584,7 @@ __global__ __launch_bounds__(256) void k_pairC(const uint32_t *__restrict__ Vp, 
     if (q1 > q0) pairC_body(Vp, vg_all + q0, q1 - q0, NPv, c, acc, n_units);
     if (block_reduce<8>(acc, red, c.lane)) {
         int32_t *Cw = Cmat + (size_t)c.win * n_units * n_units;
-        if (c.lower == 2) pair_store_circ<8>(acc, c.row0, c.col0, c.lane, c.nsub, n_units, diag, kso > 1, Cw);
-        else pair_store<8>(acc, c.row0, c.col0 + c.lane, n_units, c.lower, diag, kso > 1, Cw);
+        pair_store_circ<8>(acc, c.row0, c.col0, c.lane, c.nsub, n_units, diag, kso > 1, Cw);
     }
 }
 
@@ -576,30 +611,42 @@ void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, i
 // b0, b1 = the two bits of the allele index (A,C,G,T = 0..3), v = called.
 //   differ & both called == ((b0_i ^ b0_j) | (b1_i ^ b1_j)) & v_i & v_j   -> v_xor, 2 x v_bitop3, accumulating v_bcnt
 // ------------------------------------------------------------------------------------------------------
-template <int NSUB>
+// The inner loop is hand-scheduled assembly (pg_paird_loop.inc, generated by gen_paird_asm.py): the same software pipeline as
+// k_pairC's, 16 rows x {x, v} of one word in 32 SGPRs, ping-ponged between two sets.
+#include "pg_paird_loop.inc"
+
 __device__ __forceinline__ void pairD_body(const uint32_t *__restrict__ XVw, int w0, int w1, int NP, int N, const PairCtx &c,
-                                           uint32_t (&acc)[8 * NSUB]) {
-    constexpr int R = 8 * NSUB;
+                                           uint32_t (&acc)[16]) {
     int j = c.col0 + c.lane;
-    if (c.lower == 2 && j >= N) j -= N;                    // circulant task: columns wrap around
-    const size_t wstride = (size_t)PG_XV_PLANES * NP;
-    for (int w = w0; w < w1; ++w) {
-        const uint32_t *pw = XVw + (size_t)w * wstride;
-        const uint32_t c0 = pw[j], c1 = pw[(size_t)NP + j], cv = pw[(size_t)2 * NP + j];
-        const CU32 *pr = (const CU32 *)(pw + c.row0);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            acc[r] = bcnt_acc((((pr[r] ^ c0) | (pr[NP + r] ^ c1)) & pr[2 * NP + r]) & cv, acc[r]);
+    if (j >= N) j -= N;                                    // circulant task: columns wrap around
+    const uint32_t stride = (uint32_t)NP * 4u * PG_XV_PLANES;              // bytes per word
+    // 32-bit byte offsets inside the asm loop: a call covers at most 2 GiB of the planes
+    const int chunk = (int)(0x7fffffffu / stride) > 2 ? (int)(0x7fffffffu / stride) - 2 : 1;
+    for (int q0 = w0; q0 < w1; q0 += chunk) {
+        const int nq = (w1 - q0 < chunk) ? w1 - q0 : chunk;
+        const uint32_t *base = XVw + (size_t)q0 * NP * PG_XV_PLANES;
+        const uint64_t b64 = (uint64_t)base;
+        const uint64_t ubase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
+        uint32_t soff = (uint32_t)c.row0 * 8u, voff = (uint32_t)j * 8u;
+        uint32_t n6 = (uint32_t)__builtin_amdgcn_readfirstlane(nq / 6), rem = (uint32_t)__builtin_amdgcn_readfirstlane(nq % 6);
+        asm volatile(PG_PAIRD_LOOP_ASM
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                       "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]),
+                       "+v"(acc[14]), "+v"(acc[15]), "+s"(soff), "+v"(voff), "+s"(n6)
+                     : "s"(ubase), "s"(stride), "s"(rem)
+                     : PG_PAIRD_LOOP_CLOBBERS);
     }
 }
 
+// Tasks are circulant (16 rows x up to 64 consecutive columns mod N, PgTask2.nsub = valid columns), see pair_store_circ.
 __global__ __launch_bounds__(256) void k_pairD(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw,
                                                const int64_t *__restrict__ goff, int n_win, const PgTask2 *__restrict__ tasks,
                                                int n_tasks, int kso, int NP, int N, int32_t *__restrict__ Dmat) {
     __shared__ uint32_t red[3 * 16][64];
     PairCtx c;
     if (!pair_decode(tasks, n_tasks, kso, n_win, c)) return;
-    const uint32_t *XVw = XV + (size_t)goff[c.win] * PG_GROUP * PG_XV_PLANES * (size_t)NP;      // the window's words
+    const uint32_t *XVw = XV + (size_t)goff[c.win] * PG_XV_CAP * PG_XV_PLANES * (size_t)NP;      // the window's words
     const int n_words = __builtin_amdgcn_readfirstlane(nw[c.win]);
     const int parts = 4 * kso;
     const int a = (int)((long long)n_words * c.ks / parts), b = (int)((long long)n_words * (c.ks + 1) / parts);
@@ -607,22 +654,8 @@ __global__ __launch_bounds__(256) void k_pairD(const uint32_t *__restrict__ XV, 
     uint32_t acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0u;
-    if (c.lower != 2 && c.nsub == 1) {                     // block-uniform
-        uint32_t (&a8)[8] = reinterpret_cast<uint32_t (&)[8]>(acc);
-        pairD_body<1>(XVw, a, b, NP, N, c, a8);
-    } else {
-        pairD_body<2>(XVw, a, b, NP, N, c, acc);
-    }
-    if (block_reduce<16>(acc, red, c.lane)) {
-        if (c.lower == 2) {                                // circulant task: 16 rows, nsub = valid columns
-            pair_store_circ<16>(acc, c.row0, c.col0, c.lane, c.nsub, N, 0, kso > 1, Dw);
-        } else if (c.nsub == 1) {
-            uint32_t (&a8)[8] = reinterpret_cast<uint32_t (&)[8]>(acc);
-            pair_store<8>(a8, c.row0, c.col0 + c.lane, N, c.lower, 0, kso > 1, Dw);
-        } else {
-            pair_store<16>(acc, c.row0, c.col0 + c.lane, N, c.lower, 0, kso > 1, Dw);
-        }
-    }
+    if (b > a) pairD_body(XVw, a, b, NP, N, c, acc);
+    if (block_reduce<16>(acc, red, c.lane)) pair_store_circ<16>(acc, c.row0, c.col0, c.lane, c.nsub, N, 0, kso > 1, Dw);
 }
 
 void pg_launch_pairD(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win,

@@ -35,6 +35,41 @@ def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins):
     e.close()
 
 
+@pytest.mark.parametrize("n_dip,L,p_miss,mix", [
+    (12, 3000, 0.1, "uniform"),        # nearly every site carries all four alleles: three virtual sites per site
+    (40, 5000, 0.3, "mixed"),          # mono-, bi-, tri- and tetra-allelic sites side by side, heavy missingness
+    (9, 700, 0.0, "uniform"),          # haploid-called mismatch impossible, no missing data
+    (530, 1300, 0.05, "mixed"),        # > 1024 haplotype slots: presence pre-pass + word prefix scan
+])
+def test_pairwise_counts_with_three_and_four_alleles_per_site(n_dip, L, p_miss, mix):
+    """sites with k alleles become k-1 virtual biallelic sites in k_pack2; D must still be the plain Hamming count"""
+    rng = np.random.default_rng(1000 + n_dip)
+    names, lay = G.make_layout(n_dip, 2)
+    H = lay.n_hap
+    if mix == "uniform":
+        idx = rng.integers(0, 4, size=(L, H))
+    else:
+        k = rng.integers(1, 5, size=L)                                    # alleles per site
+        perm = np.argsort(rng.random((L, 4)), axis=1)                     # which alleles
+        pick = (rng.random((L, H)) * k[:, None]).astype(np.int64)         # skewed towards few alleles at many sites
+        pick = np.where(rng.random((L, H)) < 0.8, 0, pick)
+        idx = np.take_along_axis(perm, pick, axis=1)
+    codes = (1 << idx).astype(np.int8)
+    codes[rng.random((L, H)) < p_miss] = 0
+    codes[::2, 1] = codes[::2, 0]                                         # keep the diploid shortcut honest on some rows
+    e = G.Engine(0)
+    e.set_layout(lay)
+    e.load_sites(codes)
+    wins = [(0, L), (L // 3, L // 3 + 70), (L - 40, L), (5, 5)]
+    lo = np.array([w[0] for w in wins]); hi = np.array([w[1] for w in wins])
+    D, C = e.batch(lo, hi).pairCounts(reference_order=True)
+    for kk, (a, b) in enumerate(wins):
+        Do, Co = orc.pair_counts_gemm(oracle_aln(lay, codes, a, b))
+        assert np.array_equal(C[kk], Co), "C differs in window %d" % kk
+        assert np.array_equal(D[kk], Do), "D differs in window %d" % kk
+    e.close()
+
+
 def test_pairwise_matches_reference_pair_loop_small():
     """the faithful pair-by-pair loop of the reference (not the GEMM shortcut) on a small case"""
     e, lay, codes, _ = G.make_engine(6, 2, 700, seed=5, miss_thr=20000)
