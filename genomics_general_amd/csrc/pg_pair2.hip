@@ -460,7 +460,7 @@ void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win
 
 // ------------------------------------------------------------------------------------------------------
 // Task decoding shared by k_pairC / k_pairD.  1-D XCD-aware grid: block b runs on XCD b % 8; all waves of a window go
-// to one XCD so its planes are served by that XCD's L2.
+// to one XCD so its planes are served by that XCD's L2 (except the last n_win % 8 windows, which are spread over all XCDs).
 // ------------------------------------------------------------------------------------------------------
 struct PairCtx {
     int win, row0, nsub, col0, lower, lane, ks;
@@ -474,9 +474,20 @@ __device__ __forceinline__ bool pair_decode(const PgTask2 *__restrict__ tasks, i
     const int xcd = blockIdx.x & 7;
     const int v = blockIdx.x >> 3;
     const int per_win = n_tasks * kso;
-    c.win = (v / per_win) * 8 + xcd;
-    if (c.win >= n_win) return false;                  // block-uniform
-    const int rem = v % per_win;
+    const int full = n_win >> 3;                       // rows of 8 windows: window 8*row + xcd runs on XCD xcd
+    int rem;
+    if (v < full * per_win) {
+        c.win = (v / per_win) * 8 + xcd;
+        rem = v % per_win;
+    } else {
+        // the last n_win % 8 windows (all of them when a job has fewer than 8, e.g. a whole-genome distMat): their blocks are
+        // dealt to the 8 XCDs in equal contiguous runs, so that no XCD idles and neighbouring tasks still share an L2
+        const int total = (n_win & 7) * per_win, q = (total + 7) >> 3;
+        const int vt = v - full * per_win, lin = xcd * q + vt;
+        if (vt >= q || lin >= total) return false;     // block-uniform
+        c.win = full * 8 + lin / per_win;
+        rem = lin % per_win;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.ks = (rem / n_tasks) * 4 + wave;                 // this wave's part of the 4*kso parts of the word range
     c.lane = threadIdx.x & 63;
