@@ -270,10 +270,10 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
     const int t = blockIdx.z * TPB + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int h0 = 4 * t;
-    const bool has_data = h0 < S;            // pad threads (h0 >= S) still write zero planes up to NP
-    const bool in_np = h0 < NP;
+    // pad threads (h0 >= S = round_up(n_hap, 16)) neither load nor store: the pair kernels read pad units / haplotypes only as rows
+    // of their last 8- / 16-row task (all below S) and discard those rows
+    const bool has_data = h0 < S;
     const int u0 = DIP ? 2 * t : h0;         // first unit of the called plane owned by this thread
-    const bool in_npv = u0 < NPv;
     const int64_t first = lo + 32ll * w_begin;
     const int nrows = (int)((hi - first) < 32ll * PG_GROUP ? (hi - first) : 32ll * PG_GROUP);
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc(gt, S, first, nrows);
@@ -323,13 +323,9 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                                 (uint32_t)__builtin_amdgcn_ballot_w64(A == 4u)};
         const uint32_t SE[2] = {(uint32_t)__builtin_amdgcn_ballot_w64((E & 1u) != 0u),
                                 (uint32_t)__builtin_amdgcn_ballot_w64((E & 2u) != 0u)};
-        if (in_np) {
+        if (has_data) {
             uint32_t x[PG_XV_PLANES][4];
-#pragma unroll
-            for (int p = 0; p < PG_XV_PLANES; ++p)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[p][k] = 0u;
-            if (has_data) poly_word(rsrc, h0, S, vlist, SA, SE, x);
+            poly_word(rsrc, h0, S, vlist, SA, SE, x);
             uint32_t *o = xv_base + (size_t)slot * PG_XV_PLANES * (size_t)NP + 2 * h0;
             store16(o, x[0][0], x[1][0], x[0][1], x[1][1]);
             store16(o + 4, x[0][2], x[1][2], x[0][3], x[1][3]);
@@ -410,7 +406,7 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                 }
             }
         }
-        if (in_npv) {
+        if (has_data) {
             if (DIP) {
                 uint32_t *o = Vp + ((size_t)(vg_base + wq) * NPv + u0) * 4u;
                 store16(o, vhold[0][0], vhold[0][1], vhold[0][2], vhold[0][3]);
