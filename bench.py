@@ -97,7 +97,10 @@ def main():
     def step():
         wb = eng.batch(lo, hi)
         if wl["tool"] == "popgen":
-            st = wb.groupDistStats(doPairs=True, minSites=wl["min_sites"], minData=0.01)
+            table, cols = wb.groupDistTable(doPairs=True, minSites=wl["min_sites"], minData=0.01)
+            if world.size > 1:
+                table = comm.allgather(table.ravel())
+            return None, table                       # the named statistics for the oracle check: stats_for_check()
         elif wl["tool"] == "popfreq":
             st = wb.groupFreqStats()
         elif wl["tool"] == "distmat":
@@ -110,6 +113,12 @@ def main():
         if world.size > 1:
             table = dist.gather_table(comm, table, n_win * world.size) if False else comm.allgather(table.ravel())
         return st, table
+
+    def stats_for_check():
+        """{statistic: array over windows} of one (untimed) pass, for the comparison with the CPU port"""
+        if wl["tool"] == "popgen":
+            return eng.batch(lo, hi).groupDistStats(doPairs=True, minSites=wl["min_sites"], minData=0.01)
+        return step()[0]
 
     # warm-up with every kernel family bracketed by events: it tells which family is the dominant one; the timed region then
     # brackets only that family (an event record between two kernels costs a few microseconds of GPU idle time), and the
@@ -185,6 +194,7 @@ def main():
     cpu = None
     if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:
         from oracle import popgen_oracle as orc
+        st = stats_for_check()
         # at least --cpu-windows windows, then more until about 10 s of CPU work have been sampled (at most 8 windows)
         nw_min, nw_max = max(1, min(args.cpu_windows, n_win)), max(1, min(max(args.cpu_windows, 8), n_win))
         t_cpu, t_wall = 0.0, 0.0

@@ -445,10 +445,12 @@ static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *g
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                      const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, int64_t total_groups, uint32_t *Vp,
                      int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres) {
-    if (n_win <= 0 || max_groups <= 0) return;
+    if (n_win <= 0) return;
+    // per-window word counters: zero for the atomic allocation, and for k_pairD when every window of the batch is empty
+    (void)hipMemsetAsync(nw, 0, (size_t)n_win * 4u, st);
+    if (max_groups <= 0) return;
     const int threads = NP / 4;
     if (threads > 256) (void)hipMemsetAsync(pres, 0, (size_t)total_groups * PG_GROUP * 16u, st);
-    else (void)hipMemsetAsync(nw, 0, (size_t)n_win * 4u, st);          // per-window word counters (atomic allocation)
     dim3 grid(max_groups, n_win);
     if (dip) launch_pack2<1>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
     else launch_pack2<0>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);

@@ -222,9 +222,10 @@ class WindowBatch:
         return out
 
     # -- popDist / popPairDist ----------------------------------------------------------------------
-    def groupDistStats(self, doPairs=True, minSites=None, minData=0.01):
-        """pi / dxy / Fst of every window, finished on the device (k_popstats: the float64 operations of genomics.py:976-993
-        in the reference's order).  Returns {stat name: array over windows}, both key orders for the pair statistics."""
+    def groupDistTable(self, doPairs=True, minSites=None, minData=0.01):
+        """pi / dxy / Fst of every window as one float64 table [window][column], finished on the device (k_popstats: the float64
+        operations of genomics.py:976-993 in the reference's order).  Returns (table, column names); columns: pi per population,
+        then dxy and Fst per unordered population pair."""
         lay = self.lay
         P = lay.n_pops
         ms = int(minSites) if minSites else 0
@@ -233,15 +234,31 @@ class WindowBatch:
         tab = np.zeros((self.n, ncols), dtype=np.float64)
         check(self.e._L.pg_popdist_stats(self.e._h, self.lo, self.hi, self.n, ms, float(minData), 1 if pairs else 0, tab))
         self._popdist_min_sites = ms
-        names = lay.sampleData.popNames
-        out = {"pi_" + names[x]: tab[:, x] for x in range(P)}
-        if pairs:
+        cols = lay.__dict__.setdefault("_dist_cols", {}).get(pairs)
+        if cols is None:
+            names = lay.sampleData.popNames
+            cols = ["pi_" + names[x] for x in range(P)]
+            if pairs:
+                pr = [(names[x], names[y]) for x in range(P - 1) for y in range(x + 1, P)]
+                cols += ["dxy_%s_%s" % ab for ab in pr] + ["Fst_%s_%s" % ab for ab in pr]
+            lay._dist_cols[pairs] = cols
+        return tab, cols
+
+    def groupDistStats(self, doPairs=True, minSites=None, minData=0.01):
+        """groupDistTable as {stat name: array over windows}, both key orders for the pair statistics."""
+        tab, cols = self.groupDistTable(doPairs, minSites, minData)
+        out = {}
+        for k, name in enumerate(cols):
+            out[name] = tab[:, k]
+        P = self.lay.n_pops
+        if len(cols) > P:
+            names = self.lay.sampleData.popNames
             npo = P * (P - 1) // 2
             k = 0
             for x in range(P - 1):
                 for y in range(x + 1, P):
-                    out["dxy_%s_%s" % (names[x], names[y])] = out["dxy_%s_%s" % (names[y], names[x])] = tab[:, P + k]
-                    out["Fst_%s_%s" % (names[x], names[y])] = out["Fst_%s_%s" % (names[y], names[x])] = tab[:, P + npo + k]
+                    out["dxy_%s_%s" % (names[y], names[x])] = tab[:, P + k]
+                    out["Fst_%s_%s" % (names[y], names[x])] = tab[:, P + npo + k]
                     k += 1
         return out
 

@@ -70,6 +70,16 @@ def test_pairwise_counts_with_three_and_four_alleles_per_site(n_dip, L, p_miss, 
     e.close()
 
 
+def test_batch_of_empty_windows_after_a_real_batch_gives_zero_matrices():
+    """the per-window word counters of the previous call must not leak into a batch whose windows are all empty"""
+    e, lay, codes, _ = G.make_engine(10, 2, 2100, seed=3)
+    D, C = e.batch([0, 300], [2100, 900]).pairCounts(reference_order=False)
+    assert D.any() and C.any()
+    D, C = e.batch([5, 700, 2100], [5, 700, 2100]).pairCounts(reference_order=False)
+    assert not D.any() and not C.any()
+    e.close()
+
+
 def test_pairwise_matches_reference_pair_loop_small():
     """the faithful pair-by-pair loop of the reference (not the GEMM shortcut) on a small case"""
     e, lay, codes, _ = G.make_engine(6, 2, 700, seed=5, miss_thr=20000)
