@@ -75,7 +75,7 @@ def main():
                     popInds=[names[k * per:(k + 1) * per] for k in range(n_pops)])
     lay = HapLayout(sd, names, "phased")
     slot_gen = np.array([2 * names.index(nm) + k for nm in lay.ind_order for k in range(2)], dtype=np.int32)
-    eng = Engine(world.local_rank)
+    eng = Engine(dist.device_for(world))
     eng.set_layout(lay)
     comm = dist.RcclComm(eng, world) if world.size > 1 else dist.SoloComm()
     n_sites = wl["n_sites"]

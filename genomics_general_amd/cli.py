@@ -162,7 +162,7 @@ class Run:
                                                            minSites, inc, exc)
             self._block_bytes = int(os.environ.get("PG_STREAM_BYTES", 1 << 30))
         t0 = time.perf_counter()
-        dev = args.device if args.device is not None else self.world.local_rank
+        dev = args.device if args.device is not None else dist.device_for(self.world)
         self.engine = Engine(dev)
         self.engine.set_layout(self.layout)
         self.comm = dist.RcclComm(self.engine, self.world) if self.world.size > 1 else dist.SoloComm()

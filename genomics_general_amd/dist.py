@@ -26,6 +26,14 @@ def world_from_env(env=None):
     return World(rank, size, int(env.get("LOCAL_RANK", str(rank))))
 
 
+def device_for(world):
+    """GPU index of this rank: LOCAL_RANK, folded into the visible devices when a launcher has already restricted them
+    (e.g. one device per rank through HIP_VISIBLE_DEVICES)."""
+    from . import _lib
+    n = _lib.device_count()
+    return world.local_rank % n if n > 0 else world.local_rank
+
+
 def shard_range(n_items, size, rank):
     """Contiguous balanced split: ranks [0, n%size) get one extra item."""
     base, extra = divmod(n_items, size)
