@@ -47,10 +47,14 @@ def shard_counts(n_items, size):
 
 # ---- rendezvous of the RCCL unique id ------------------------------------------------------------------
 def _rdzv_path():
+    """File through which rank 0 hands the RCCL unique id to the other ranks of the node.  Under torch.distributed.run all ranks
+    are children of one agent process, whose pid makes the name unique per launch; other launchers (ranks started from separate
+    shells, mpirun wrappers) are keyed by MASTER_ADDR / MASTER_PORT alone, or name the file themselves with PG_RDZV_FILE."""
     if os.environ.get("PG_RDZV_FILE"):
         return os.environ["PG_RDZV_FILE"]
-    key = "%s_%s_%s_%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"),
-                           os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+    key = "%s_%s" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"))
+    if "TORCHELASTIC_RUN_ID" in os.environ:
+        key += "_%s_%d" % (os.environ["TORCHELASTIC_RUN_ID"], os.getppid())
     return os.path.join("/tmp", "pg_rdzv_" + key.replace("/", "_"))
 
 
@@ -58,6 +62,10 @@ def exchange_unique_id(world, make_id, timeout_s=180.0):
     """rank 0 creates the id and publishes it; the others wait for the file.  Single node only."""
     path = _rdzv_path()
     if world.rank == 0:
+        try:
+            os.remove(path)                  # a leftover of a launch that died before its hand-over completed
+        except OSError:
+            pass
         uid = make_id()
         tmp = path + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as f:
