@@ -87,7 +87,6 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
         c->slot[k].XV.release();
         c->slot[k].pres.release();
         c->slot[k].host.release();
-        c->slot[k].nw.release();
         c->slot[k].win.release();
         if (c->slot[k].packed) (void)hipEventDestroy(c->slot[k].packed);
         if (c->slot[k].consumed) (void)hipEventDestroy(c->slot[k].consumed);
@@ -574,10 +573,14 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
             HIPCHK(hipStreamWaitEvent(ps, sl.consumed, 0));
             HIPCHK(hipEventSynchronize(sl.packed));
         }
-        // stage [lo | hi | goff(n+1) | vgoff(n+1)]
-        if ((rc = sl.host.ensure(4 * (size_t)nb + 2)) != PG_OK) return rc;
+        // stage [lo | hi | goff(n+1) | vgoff(n+1) | nw]: nw = int32 word counters of k_pack2, zero per window (and, in the
+        // > 1024-slot mode, one slot per group for k_word_scan) -- they ride in the same copy instead of a memset
+        int64_t ga_pre = 0;
+        for (int k = 0; k < nb; ++k) ga_pre += ((hi[w0 + k] - lo[w0 + k] + 31) / 32 + PG_GROUP - 1) / PG_GROUP;
+        const size_t n_nw = (size_t)nb + (NP > 1024 ? (size_t)ga_pre : 0);
+        const size_t h_len = 4 * (size_t)nb + 2 + (n_nw + 1) / 2;
+        if ((rc = sl.host.ensure(h_len)) != PG_OK) return rc;
         int64_t *h = sl.host.p;
-        const size_t h_len = 4 * (size_t)nb + 2;
         int64_t ga = 0, va = 0;
         int max_groups = 0;
         for (int k = 0; k < nb; ++k) {
@@ -593,14 +596,15 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         }
         h[3 * (size_t)nb] = ga;
         h[4 * (size_t)nb + 1] = va;
+        memset(h + 4 * (size_t)nb + 2, 0, ((n_nw + 1) / 2) * 8);
         if ((rc = sl.win.upload(h, h_len, ps)) != PG_OK) return rc;
         const int64_t *d_lo = sl.win.p, *d_hi = sl.win.p + nb, *d_goff = sl.win.p + 2 * (size_t)nb,
                       *d_vgoff = sl.win.p + 3 * (size_t)nb + 1;
+        int32_t *d_nw = reinterpret_cast<int32_t *>(sl.win.p + 4 * (size_t)nb + 2);
         // + 2 word groups: k_pairC's look-ahead loads read one group past a wave's range
         if ((rc = sl.Vp.ensure((size_t)(std::max<int64_t>(va, 1) + 2) * NPv * 4)) != PG_OK) return rc;
         // + 2 words: k_pairD's look-ahead loads read two words past a wave's range
         if ((rc = sl.XV.ensure(((size_t)std::max<int64_t>(ga, 1) * PG_XV_CAP + 2) * PG_XV_PLANES * NP)) != PG_OK) return rc;
-        if ((rc = sl.nw.ensure((size_t)std::max<int64_t>(ga, 1) + nb)) != PG_OK) return rc;   // [window] words, [nb + group] first word
         if ((rc = c->Cmat.ensure((size_t)nb * n_units * n_units)) != PG_OK) return rc;
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
         hipEvent_t e0, e1;
@@ -613,7 +617,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         }
         if (NP > 1024 && (rc = sl.pres.ensure((size_t)std::max<int64_t>(ga, 1) * PG_GROUP * 4)) != PG_OK) return rc;
         pg_launch_pack2(ps, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, ga, sl.Vp.p, NPv, sl.XV.p, NP,
-                        sl.nw.p, dip ? 1 : 0, c->flag.p, sl.pres.p);
+                        d_nw, dip ? 1 : 0, c->flag.p, sl.pres.p);
         if (time_pack) {
             HIPCHK(hipEventRecord(e1, ps));
             c->events[PG_K_PACK].push_back(std::make_pair(e0, e1));
@@ -629,7 +633,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         // (running k_pairD beside k_pairC on a third stream was measured: +3 % throughput, but overlapping kernels make the
         // per-kernel timings ambiguous; kept sequential)
         if ((rc = pg_time_begin(c, PG_K_PAIRD, &e0, &e1)) != PG_OK) return rc;
-        pg_launch_pairD(c->stream, sl.XV.p, sl.nw.p, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, ga / nb, c->Dmat.p);
+        pg_launch_pairD(c->stream, sl.XV.p, d_nw, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, ga / nb, c->Dmat.p);
         if ((rc = pg_time_end(c, PG_K_PAIRD, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
         if ((rc = consume(w0, nb)) != PG_OK) return rc;

@@ -95,7 +95,6 @@ struct pg_ctx {
     hipStream_t stream2 = nullptr;
     struct Slot {
         DevBuf<uint32_t> Vp, XV, pres;
-        DevBuf<int32_t> nw;
         DevBuf<int64_t> win;
         HostPin<int64_t> host;            // pinned staging of [lo | hi | goff | vgoff], alive until its H2D copy completed
         hipEvent_t packed = nullptr, consumed = nullptr;

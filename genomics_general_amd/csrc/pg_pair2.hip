@@ -445,10 +445,9 @@ static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *g
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                      const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, int64_t total_groups, uint32_t *Vp,
                      int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres) {
-    if (n_win <= 0) return;
-    // per-window word counters: zero for the atomic allocation, and for k_pairD when every window of the batch is empty
-    (void)hipMemsetAsync(nw, 0, (size_t)n_win * 4u, st);
-    if (max_groups <= 0) return;
+    // nw[0 .. n_win): the caller hands over zeroed per-window word counters (atomic allocation; k_pairD reads them even when
+    // every window of the batch is empty); nw[n_win ..): one slot per group in the > 1024-slot mode (k_word_scan)
+    if (n_win <= 0 || max_groups <= 0) return;
     const int threads = NP / 4;
     if (threads > 256) (void)hipMemsetAsync(pres, 0, (size_t)total_groups * PG_GROUP * 16u, st);
     dim3 grid(max_groups, n_win);
