@@ -333,9 +333,13 @@ __global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__
     const int thr = min_pair_sites > 1 ? min_pair_sites : 1;
     double sum = 0.0;
     unsigned long long cnt = 0;
-    const long long total = (long long)nx * ny;
-    for (long long idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        const int i = xs + (int)(idx / ny), j = ys + (int)(idx % ny);
+    // thread t takes the pairs t, t + 256, ... of the nx x ny rectangle (fixed partition: the float64 sum is reproducible);
+    // row / column advance incrementally instead of dividing (nx, ny <= PG_MAX_HAP, so 256 / ny steps stay small)
+    const int total = nx * ny;
+    const int qi = 256 / (ny > 0 ? ny : 1), qj = 256 - qi * (ny > 0 ? ny : 1);
+    int i = xs + (ny > 0 ? (int)threadIdx.x / ny : 0), j = ys + (ny > 0 ? (int)threadIdx.x % ny : 0);
+    for (int idx = threadIdx.x; idx < total; idx += 256, i += qi, j += qj) {
+        if (j >= ye) { j -= ny; ++i; }
         if (x == y && i >= j) continue;
         const int c = Cw[(size_t)(i >> cshift) * cN + (j >> cshift)];
         if (c >= thr) {
