@@ -19,6 +19,10 @@ FIXTURES = {
     # mixed ploidy: samples 1, 6 and 9 have one-character cells (--haploid / --ploidyFile)
     "mixed": dict(seed=20260930, n_dip=10, n_pops=2, scaf_len=[3000, 1500], density=0.7, var_thr=30000, miss_thr=5000, fmt="phased", sep="/",
                   haploid=(1, 6, 9)),
+    # many sites with three and four alleles (multi_frac of the sites get alleles drawn uniformly from A,C,G,T): the pairwise
+    # difference counts of multi-allelic sites (k_pairD's virtual biallelic sites) against the reference's numHamming
+    "multi": dict(seed=20261001, n_dip=9, n_pops=3, scaf_len=[2500, 1200], density=0.8, var_thr=30000, miss_thr=6000, fmt="phased", sep="/",
+                  multi_frac=0.5),
     "haplo": dict(seed=20260929, n_dip=5, n_pops=2, scaf_len=[4000], density=0.5, var_thr=30000, miss_thr=4000, fmt="haplo", sep=""),
 }
 
@@ -82,6 +86,11 @@ CASES = [
     dict(name="haplo_popgen", tool="popgenWindows.py", fixture="haplo",
          argv=["-g", "{geno}", "-f", "haplo", "-w", "1000", "-m", "20", "--roundTo", "8", "-p", "a", "s0_A,s0_B,s1_A,s1_B,s2_A",
                "-p", "b", "s2_B,s3_A,s3_B,s4_A,s4_B"]),
+    dict(name="multi_popgen_all", tool="popgenWindows.py", fixture="multi",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "600", "-m", "20", "--roundTo", "8", "--analysis", "popDist", "popPairDist",
+               "popFreq", "indPairDist", "indHet"] + pops_args(9, 3)),
+    dict(name="multi_distmat", tool="distMat.py", fixture="multi",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1500", "-m", "20", "--outFormat", "raw"]),
     # ---- ABBABABAwindows.py ----
     dict(name="abba_windows", tool="ABBABABAwindows.py", fixture="abba",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--minData", "0.5"] + abba_args(16)),

@@ -47,6 +47,12 @@ def make_fixture(name):
     path = os.path.join(HERE, name + ".geno.gz")
     sid, pos = fixture_sites(p)
     codes = synth.gen_codes(p["seed"], sid, pos, p["n_dip"], p["n_pops"], var_thr=p["var_thr"], miss_thr=p["miss_thr"])
+    if p.get("multi_frac"):
+        # a share of the sites gets alleles drawn uniformly from A,C,G,T (missing calls stay missing): three and four alleles per site
+        rng = np.random.default_rng(p["seed"])
+        pick = rng.random(len(pos)) < p["multi_frac"]
+        rnd = (1 << rng.integers(0, 4, size=codes.shape)).astype(np.int8)
+        codes = np.where(pick[:, None] & (codes != 0), rnd, codes).astype(np.int8)
     if p["fmt"] == "haplo":
         names = ["s%d_%s" % (d, ab) for d in range(p["n_dip"]) for ab in "AB"]
     else:
