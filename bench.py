@@ -34,6 +34,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]: 10^7 sites x 100 diploids, 4 pops, 50 kb windows
     "c2": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
                desc="popgenWindows pi/Fst/Dxy: 1e7 sites x 100 diploids (200 haplotypes), 4 pops, 50 kb windows"),
+    # the C2 data set in 5 kb windows (2000 windows of 157 words): per-window fixed costs of the pair kernels; not a BASELINE.json config
+    "c2_w5k": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=5_000, min_sites=100, tool="popgen",
+                   desc="popgenWindows pi/Fst/Dxy: 1e7 sites x 100 diploids (200 haplotypes), 4 pops, 5 kb windows"),
     # north-star single-GPU shape: first 10^8 sites of config 5 (200 diploids)
     "northstar": dict(n_sites=100_000_000, n_scaf=4, n_dip=200, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
                       desc="popgenWindows pi/Fst/Dxy: 1e8 sites x 200 diploids (400 haplotypes), 4 pops, 50 kb windows"),
