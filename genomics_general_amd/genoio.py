@@ -5,6 +5,7 @@ whitespace separated, first line `#CHROM POS name...` (or `--header` text), `.gz
 """
 import ctypes as C
 import gzip
+import os
 import sys
 
 import numpy as np
@@ -151,25 +152,38 @@ class BlockReader:
 
 
 # ---- packed `.pgeno` files: a tokenised `.geno` kept on disk ---------------------------------------------------------------
-# SURVEY.md 8f row 4.  Layout (little endian): magic, u32 length + JSON header {"names": [...], "ploidy": [...]} (file column
-# order), then blocks { u64 n_rows, u32 n_runs, n_runs x (u64 first_row, u16 len, scaffold name), int32 pos[n_rows],
-# u8 cells[n_rows][n_cols] }, terminated by a block with n_rows = 0.  A cell byte = first allele code | second << 4 (one-hot
+# SURVEY.md 8f row 4.  Layout (little endian): magic, u32 length + JSON header {"names": [...], "ploidy": [...], "codec": ...}
+# (file column order), then blocks { u64 n_rows, u32 n_runs, n_runs x (u64 first_row, u16 len, scaffold name),
+# payload }, terminated by a block with n_rows = 0; payload = pos || u8 cells[n_rows][n_cols], stored raw (codec "none") or as
+# independently deflated 4 MiB chunks (codec "zlib", the default: u32 n_chunks, n_chunks x (u32 stored, u32 raw), data; both sides
+# work on the chunks with a thread pool).  A cell byte = first allele code | second << 4 (one-hot
 # codes A=1 C=2 G=4 T=8, 0 = missing), independent of the text format it came from and of any population layout, so one packed
-# file serves every later run.  4x smaller than the text, no gunzip, no tokenizer: tools/geno_pack.py writes it, the drivers
+# file serves every later run.  4x (raw) to ~30x (deflated) smaller than the text, no serial gunzip, no tokenizer: tools/geno_pack.py writes it, the drivers
 # read it when the input name ends in .pgeno (-f is then only used for the default ploidy).
 PGENO_MAGIC = b"PGENO1\n"
 
 
+PGENO_CHUNK = 4 << 20
+
+
+def _pool():
+    from concurrent.futures import ThreadPoolExecutor
+    return ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1)))
+
+
 class PackedWriter:
-    def __init__(self, path, names, ploidy):
+    def __init__(self, path, names, ploidy, codec="zlib"):
         import json
+        assert codec in ("none", "zlib")
         self.f = open(path, "wb")
         self.n_cols = len(names)
-        head = json.dumps({"names": list(names), "ploidy": [int(p) for p in ploidy]}).encode()
+        self.codec = codec
+        head = json.dumps({"names": list(names), "ploidy": [int(p) for p in ploidy], "codec": codec}).encode()
         self.f.write(PGENO_MAGIC + len(head).to_bytes(4, "little") + head)
 
     def write_block(self, data, cells):
         """data: GenoData of the block (pos, run_starts, run_names); cells: uint8 [n_rows][n_cols]."""
+        import zlib
         n = int(data.n_sites)
         if n == 0:
             return
@@ -178,8 +192,18 @@ class PackedWriter:
             b = nm.encode()
             out += [int(st).to_bytes(8, "little"), len(b).to_bytes(2, "little"), b]
         self.f.write(b"".join(out))
-        self.f.write(np.ascontiguousarray(data.pos, dtype="<i4").tobytes())
-        self.f.write(np.ascontiguousarray(cells, dtype=np.uint8).tobytes())
+        payload = np.ascontiguousarray(data.pos, dtype="<i4").tobytes() + np.ascontiguousarray(cells, dtype=np.uint8).tobytes()
+        if self.codec == "none":
+            self.f.write(payload)
+            return
+        view = memoryview(payload)
+        parts = [view[a:a + PGENO_CHUNK] for a in range(0, len(payload), PGENO_CHUNK)]
+        with _pool() as ex:
+            comp = list(ex.map(lambda p: zlib.compress(p, 1), parts))          # zlib releases the GIL
+        self.f.write(len(parts).to_bytes(4, "little"))
+        self.f.write(b"".join(len(c).to_bytes(4, "little") + len(p).to_bytes(4, "little") for c, p in zip(comp, parts)))
+        for c in comp:
+            self.f.write(c)
 
     def close(self):
         self.f.write((0).to_bytes(8, "little"))
@@ -199,6 +223,9 @@ class PackedReader:
         hl = int.from_bytes(self.f.read(4), "little")
         self.head = json.loads(self.f.read(hl).decode())
         self.names, self.ploidy = self.head["names"], np.asarray(self.head["ploidy"], dtype=np.int32)
+        self.codec = self.head.get("codec", "none")
+        if self.codec not in ("none", "zlib"):
+            raise ValueError("%s: unknown codec %r" % (path, self.codec))
         self.n_cols = len(self.names)
         self.bytes_read = len(PGENO_MAGIC) + 4 + hl
         self.done = False
@@ -218,11 +245,24 @@ class PackedReader:
             starts.append(int.from_bytes(self.f.read(8), "little"))
             ln = int.from_bytes(self.f.read(2), "little")
             names.append(self.f.read(ln).decode())
-        pos = np.frombuffer(self.f.read(4 * n), dtype="<i4")
-        cells = np.frombuffer(self.f.read(n * self.n_cols), dtype=np.uint8).reshape(n, self.n_cols)
-        if len(pos) != n or cells.shape[0] != n:
+        want = 4 * n + n * self.n_cols
+        if self.codec == "none":
+            payload = self.f.read(want)
+            self.bytes_read += 12 + len(payload)
+        else:
+            import zlib
+            n_chunks = int.from_bytes(self.f.read(4), "little")
+            table = np.frombuffer(self.f.read(8 * n_chunks), dtype="<u4").reshape(-1, 2)
+            if table.shape[0] != n_chunks or int(table[:, 1].sum()) != want:
+                raise ValueError("damaged .pgeno block")
+            comp = [self.f.read(int(c)) for c in table[:, 0]]
+            self.bytes_read += 16 + 8 * n_chunks + int(table[:, 0].sum())
+            with _pool() as ex:
+                payload = b"".join(ex.map(zlib.decompress, comp))               # zlib releases the GIL
+        if len(payload) != want:
             raise ValueError("truncated .pgeno file")
-        self.bytes_read += 12 + 4 * n + n * self.n_cols
+        pos = np.frombuffer(payload, dtype="<i4", count=n)
+        cells = np.frombuffer(payload, dtype=np.uint8, offset=4 * n).reshape(n, self.n_cols)
         return (np.asarray(starts, dtype=np.int64), names, pos, cells)
 
     def read_block(self, nbytes=None):
@@ -267,7 +307,7 @@ class PackedReader:
         self.f.close()
 
 
-def pack_geno(src_path, dst_path, fmt, ploidy_of=None, header_line=None, block_bytes=256 << 20):
+def pack_geno(src_path, dst_path, fmt, ploidy_of=None, header_line=None, block_bytes=256 << 20, codec="zlib"):
     """Tokenise a `.geno(.gz)` file once and keep the result (tools/geno_pack.py).  ploidy_of: {sample: 1|2} overrides of the
     format's default (2, or 1 for `haplo`)."""
     from .samples import HapLayout, SampleData
@@ -280,7 +320,7 @@ def pack_geno(src_path, dst_path, fmt, ploidy_of=None, header_line=None, block_b
     if any(pl[nm] not in (1, 2) for nm in names):
         raise ValueError(".pgeno holds ploidy 1 or 2 only")
     lay = HapLayout(SampleData(indNames=list(names), ploidyDict=pl), names, fmt)      # slot order == file order
-    wr = PackedWriter(dst_path, names, [pl[nm] for nm in names])
+    wr = PackedWriter(dst_path, names, [pl[nm] for nm in names], codec)
     n_rows = 0
     while True:
         body = rd.read_block(block_bytes)

@@ -336,14 +336,15 @@ def test_tokenizer_throughput_report(capsys):
 
 @pytest.mark.parametrize("name,fmt,haploid", [("c1", "phased", ()), ("abba_diplo", "diplo", ()), ("abba_pairs", "pairs", ()),
                                               ("haplo", "haplo", ()), ("mixed", "phased", ("s1", "s6", "s9")), ("holes", "phased", ())])
-def test_packed_pgeno_round_trip_equals_the_tokenizer(name, fmt, haploid, tmp_path):
+def test_packed_pgeno_round_trip_equals_the_tokenizer(name, fmt, haploid, tmp_path, monkeypatch):
+    monkeypatch.setattr(genoio, "PGENO_CHUNK", 1000)                          # several deflate chunks per block
     """genoio.pack_geno -> PackedReader.to_geno (pg_decode_packed) == pg_encode_text of the text, for a layout that reorders,
     drops and regroups samples; block seams inside scaffolds; carried rows in front"""
     path = os.path.join(GOLD, name + ".geno.gz")
     names, body = genoio.split_header(genoio.read_all(path))
     pl = {nm: (1 if (fmt == "haplo" or nm in haploid) else 2) for nm in names}
     out = str(tmp_path / "x.pgeno")
-    n = genoio.pack_geno(path, out, fmt, {nm: 1 for nm in haploid}, block_bytes=5000)
+    n = genoio.pack_geno(path, out, fmt, {nm: 1 for nm in haploid}, block_bytes=5000, codec="none" if name == "holes" else "zlib")
     assert genoio.read_header_names(out) == list(names)
     sub = list(names[::-1][: max(2, len(names) - 3)])                         # reversed, three samples dropped
     sd = SampleData(popNames=["x", "y"], popInds=[sub[1::2], sub[0::2]], ploidyDict=pl)

@@ -21,6 +21,7 @@ def main(argv=None):
     ap.add_argument("--ploidyFile", help="sample <tab> ploidy per line")
     ap.add_argument("--header", help="header line if the file has none")
     ap.add_argument("--blockMiB", type=int, default=256, help="text bytes per block")
+    ap.add_argument("--codec", default="zlib", choices=("zlib", "none"), help="deflate the blocks (default) or store them raw")
     a = ap.parse_args(argv)
     pl = {}
     if a.ploidyFile:
@@ -32,7 +33,7 @@ def main(argv=None):
     if a.haploid:
         for nm in a.haploid.split(","):
             pl[nm] = 1
-    n = genoio.pack_geno(a.genoFile, a.outFile, a.genoFormat, pl, a.header, a.blockMiB << 20)
+    n = genoio.pack_geno(a.genoFile, a.outFile, a.genoFormat, pl, a.header, a.blockMiB << 20, a.codec)
     sys.stderr.write("%d sites -> %s (%d bytes)\n" % (n, a.outFile, os.path.getsize(a.outFile)))
 
 
