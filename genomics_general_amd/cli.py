@@ -113,21 +113,26 @@ def _make_windows(p, data, minSites, coords_keep=4):
     if p["windType"] == "sites":
         return windows.sites_windows(data.run_starts, data.run_names, data.pos, p["windSize"], p["overlap"],
                                      p["maxDist"], minSites, inc, exc)
-    with open(p["windCoords"], "rt") as wc:
-        coords = []
+    return windows.predefined_windows(data.run_starts, data.run_names, data.pos, _read_coords(p["windCoords"], coords_keep))
+
+
+def _read_coords(path, coords_keep=4):
+    """Windows file of --windCoords: scaffold, start, end[, ID] per line."""
+    coords = []
+    with open(path, "rt") as wc:
         for line in wc:
             f = line.split()[:coords_keep]
             if len(f) >= 3:
                 coords.append(tuple([f[0], int(f[1]), int(f[2])] + f[3:4]))
-    return windows.predefined_windows(data.run_starts, data.run_names, data.pos, coords)
+    return coords
 
 
 class Run:
     """Shared plumbing: input -> layout -> windows -> engine (+ multi-GPU shard of the window list).
 
     The input is consumed in blocks of PG_STREAM_BYTES bytes of text (default 1 GiB) when the window type allows it
-    (coordinate and sites windows: windows.CoordWindowStream / SitesWindowStream), so host memory stays bounded for inputs of
-    any size; predefined / cat windows read the whole input as one block.  Drivers iterate `for _ in run.chunks():`; inside the loop
+    (coordinate, sites and predefined windows: windows.CoordWindowStream / SitesWindowStream / PredefinedWindowStream), so host
+    memory stays bounded for inputs of any size; cat windows read the whole input as one block.  Drivers iterate `for _ in run.chunks():`; inside the loop
     T, w0, w1, lo, hi, batch() and gather() refer to the windows that became certain with the current block.  Drivers that
     do not stream construct Run(..., stream=False): the single chunk is loaded by the constructor."""
 
@@ -152,11 +157,13 @@ class Run:
         self._block_bytes = None
         # every rank of a multi-GPU run tokenises the input itself: share the host cores instead of oversubscribing them
         self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size) if self.world.size > 1 else 0
-        if stream and windows_fn is None and wparams["windType"] in ("coordinate", "sites"):
+        if stream and windows_fn is None and wparams["windType"] in ("coordinate", "sites", "predefined"):
             inc = _lines(args.include) if args.include else None
             exc = _lines(args.exclude) if args.exclude else None
             if wparams["windType"] == "coordinate":
                 self._streamer = windows.CoordWindowStream(wparams["windSize"], wparams["stepSize"], inc, exc)
+            elif wparams["windType"] == "predefined":
+                self._streamer = windows.PredefinedWindowStream(_read_coords(wparams["windCoords"], coords_keep))
             else:
                 self._streamer = windows.SitesWindowStream(wparams["windSize"], wparams["overlap"], wparams["maxDist"],
                                                            minSites, inc, exc)

@@ -388,3 +388,87 @@ class SitesWindowStream:
         T.finish(positions)
         T.dup = np.asarray(T.dup, dtype=bool)
         return T, keep_from
+
+
+class PredefinedWindowStream:
+    """predefinedCoordWindows over an input that arrives in consecutive pieces (bounded host memory); same feed() contract as
+    CoordWindowStream.  The generator walks the windows file and the genotype file in step ("line in hand"), so a window is
+    certain as soon as the buffer holds a row behind its end on its scaffold, or a later scaffold run, or the input is over;
+    the rows of the previous window stay in the buffer because the next window of the same scaffold keeps them (left trim only)."""
+
+    def __init__(self, windCoords):
+        self.coords = list(windCoords)
+        all_scafs = [w[0] for w in self.coords]
+        self.scafs = sorted(set(all_scafs), key=all_scafs.index)
+        self.rank = {s: k for k, s in enumerate(self.scafs)}
+        self.wi = 0                          # next window
+        self.cur = 0                         # the "line in hand", buffer row
+        self.prev = None                     # (scaffold, lo, hi) of the previous window's rows, buffer rows
+        self.done = False                    # the generator has returned (genotype file exhausted while looking for a window)
+
+    def feed(self, run_starts, run_names, positions, final):
+        positions = np.asarray(positions)
+        n = len(positions)
+        runs = _runs(run_starts, n)
+        starts = np.asarray([a for a, _ in runs], dtype=np.int64)
+        T = WindowTable()
+        cur, prev = self.cur, self.prev
+        while self.wi < len(self.coords) and not self.done:
+            w = self.coords[self.wi]
+            scaf, start, end = w[0], int(w[1]), int(w[2])
+            ID = w[3] if len(w) > 3 else "NA"
+            widx = self.rank[scaf]
+            c = cur
+            while c < n:                      # genomics.py:2142-2145: skip the runs of scaffolds before this window's
+                r = int(np.searchsorted(starts, c, side="right")) - 1
+                name = run_names[r]
+                if name not in self.rank or self.rank[name] < widx:
+                    c = runs[r][1]
+                else:
+                    break
+            if c >= n and not final:
+                cur = c                       # skipped rows are never looked at again; the window waits for more input
+                break
+            new = None
+            if c < n:
+                r = int(np.searchsorted(starts, c, side="right")) - 1
+                if run_names[r] == scaf:
+                    a, b = runs[r]
+                    _check_sorted(positions, a, b, scaf)
+                    p = positions[c:b]
+                    x = c + int(np.searchsorted(p, start, side="left"))
+                    y = c + int(np.searchsorted(p, end, side="right"))
+                    if y == b and b == n and not final:
+                        cur = c               # the run may go on in the next piece
+                        break
+                    if y > x:
+                        new = (x, y)
+                        c = y
+                    else:
+                        c = x
+            kept = None
+            if prev is not None and prev[0] == scaf and prev[2] > prev[1]:
+                k_lo = prev[1] + int(np.searchsorted(positions[prev[1]:prev[2]], start, side="left"))
+                if prev[2] > k_lo:
+                    kept = (k_lo, prev[2])
+            if kept and new:
+                rows = (kept[0], new[1])
+            elif kept:
+                rows = kept
+            elif new:
+                rows = new
+            else:
+                rows = (c, c) if c <= n else (n, n)
+            T.add(scaf, start, end, rows[0], rows[1], ID)
+            prev = (scaf, rows[0], rows[1])
+            cur = c
+            self.wi += 1
+            if cur >= n and final:
+                self.done = True
+        T.finish(positions)
+        T.dup = np.zeros(T.n, dtype=bool)
+        keep_from = cur if prev is None else min(cur, prev[1])
+        keep_from = min(keep_from, n)
+        self.cur = cur - keep_from
+        self.prev = None if prev is None else (prev[0], prev[1] - keep_from, prev[2] - keep_from)
+        return T, keep_from

@@ -72,7 +72,7 @@ def _streamable(c):
         return False
     if "--windType" not in c["argv"]:
         return True
-    return c["argv"][c["argv"].index("--windType") + 1] in ("coordinate", "sites")
+    return c["argv"][c["argv"].index("--windType") + 1] in ("coordinate", "sites", "predefined")
 
 
 STREAMABLE = [c for c in CASES if _streamable(c)]

@@ -205,3 +205,49 @@ def test_sites_window_stream_equals_whole_input(seed):
             keep = a + kf
         assert got == want, (w, ov, ms, md, inc, exc, cuts)
     assert tested > 200
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_predefined_window_stream_equals_whole_input(seed):
+    from genomics_general_amd import windows as W
+    rng = np.random.default_rng(3000 + seed)
+    for _ in range(250):
+        names, starts, pos, prev = [], [], [], None
+        for _r in range(int(rng.integers(1, 6))):
+            nm = str(rng.choice([x for x in ("c0", "c1", "c2", "c3") if x != prev]))
+            prev = nm
+            starts.append(len(pos))
+            names.append(nm)
+            pos += list(np.sort(rng.integers(1, 400, size=int(rng.integers(1, 60)))))
+        rs, pos = np.array(starts), np.array(pos, dtype=np.int32)
+        # windows file: a few scaffolds (one possibly absent from the data), windows per scaffold sorted or not, overlapping, empty
+        coords = []
+        for sc in rng.permutation(["c0", "c1", "c2", "c3", "zz"])[: int(rng.integers(1, 5))]:
+            k = int(rng.integers(1, 6))
+            st = rng.integers(1, 420, size=k)
+            if rng.integers(0, 4):
+                st = np.sort(st)
+            for j, a in enumerate(st):
+                ln = int(rng.integers(0, 150))
+                coords.append((str(sc), int(a), int(a) + ln) + (("w%d" % j,) if rng.integers(0, 2) else ()))
+        want = _stream_rows(W.predefined_windows(rs, names, pos, coords), [])
+        n = len(pos)
+        cuts = sorted(set(rng.integers(0, n + 1, size=int(rng.integers(0, 6))).tolist() + [n]))
+        run_of = np.zeros(n, dtype=int)
+        for r, (a, b) in enumerate(W._runs(rs, n)):
+            run_of[a:b] = r
+        S = W.PredefinedWindowStream(coords)
+        got, hist, keep = [], [], 0
+        for ci, c in enumerate(cuts):
+            a, b = keep, max(c, keep)
+            if b > a:
+                ro = run_of[a:b]
+                chg = np.flatnonzero(np.concatenate([[True], ro[1:] != ro[:-1]]))
+                brs, bn = chg, [names[ro[i]] for i in chg]
+            else:
+                brs, bn = np.array([], dtype=int), []
+            T, kf = S.feed(brs, bn, pos[a:b], final=(ci == len(cuts) - 1))
+            got += _stream_rows(T, hist, a)
+            assert 0 <= kf <= b - a
+            keep = a + kf
+        assert got == want, (coords, cuts, list(zip(names, starts)))
