@@ -594,55 +594,65 @@ def distmat_main(argv=None):
         return T
 
     run = Run(args, sampleData, wp, minSites, header_line=header_line, coords_keep=3,
-              windows_fn=cat_window if args.windType == "cat" else None)
-    T = run.T
+              windows_fn=cat_window if args.windType == "cat" else None, stream=True)
     lay = run.layout
     n = len(samples)
     npairs = n * (n + 1) // 2
-    sites_local = T.sites[run.w0:run.w1]
-    good = sites_local >= minSites
-    table = np.full((run.w1 - run.w0, npairs + 1), np.nan)               # pair means + minPerInd verdict
-    table[:, npairs] = 1.0
-    if np.any(good):
-        wb = run.batch(good)
-        if args.minPerInd:
-            called = wb.hapCalled()
-            table[good, npairs] = (called.min(axis=1) >= args.minPerInd).astype(np.float64)
-        tab = wb.indPairTable(includeSameWithSame=args.includeSameWithSame)
-        # column (i<=j in --samples order) <- pair index in the engine's slot order of the individuals
-        pos_of = {nm: k for k, nm in enumerate(lay.ind_order)}
-        si = np.array([pos_of[nm] for nm in samples], dtype=np.int64)
-        iu0 = np.triu_indices(n)
-        a, b = np.minimum(si[iu0[0]], si[iu0[1]]), np.maximum(si[iu0[0]], si[iu0[1]])
-        table[good, :npairs] = tab[:, a * n - a * (a - 1) // 2 + (b - a)]
-    full = run.gather(table)
-
+    # column (i<=j in --samples order) <- pair index in the engine's slot order of the individuals
+    pos_of = {nm: k for k, nm in enumerate(lay.ind_order)}
+    si = np.array([pos_of[nm] for nm in samples], dtype=np.int64)
+    iu = np.triu_indices(n)
+    a, b = np.minimum(si[iu[0]], si[iu[1]]), np.maximum(si[iu[0]], si[iu[1]])
+    pair_col = a * n - a * (a - 1) // 2 + (b - a)
+    out = wout = None
     if run.world.rank == 0:
         out = _open_out(args.outFile)
-        wout = None
         if args.windowDataOutFile:
             wout = _open_out(args.windowDataOutFile)
             # the reference writes this header without a newline and tab-separated rows after it (distMat.py:238-239, 58)
             wout.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites,")
-        written = 0
-        iu = np.triu_indices(n)
+    written = 0
+    last = None                          # (ok, matrix text, window-data text) of the previously emitted window (dup rows)
+    for _ in run.chunks():
+        T = run.T
+        sites_local = T.sites[run.w0:run.w1]
+        good = sites_local >= minSites
+        table = np.full((run.w1 - run.w0, npairs + 1), np.nan)               # pair means + minPerInd verdict
+        table[:, npairs] = 1.0
+        if np.any(good):
+            wb = run.batch(good)
+            if args.minPerInd:
+                called = wb.hapCalled()
+                table[good, npairs] = (called.min(axis=1) >= args.minPerInd).astype(np.float64)
+            tab = wb.indPairTable(includeSameWithSame=args.includeSameWithSame)
+            table[good, :npairs] = tab[:, pair_col]
+        full = run.gather(table)
+        if run.world.rank != 0:
+            continue
         for k in range(T.n):
-            ok = T.sites[k] >= minSites and full[k, npairs] > 0
+            if T.dup[k]:
+                ok, mtext, wtext = last
+            else:
+                ok = T.sites[k] >= minSites and full[k, npairs] > 0
+                M = np.full((n, n), np.nan)
+                if ok:
+                    M[iu] = full[k, :npairs]
+                    M[(iu[1], iu[0])] = full[k, :npairs]
+                mtext = _matrix_text(M, samples, args.outFormat, args.roundTo) if (ok or args.writeFailedWindows) else ""
+                wd = ([T.ID[k]] if args.addWindowID else []) + [T.scaffold[k], T.start[k], T.end[k], T.mid[k], int(T.sites[k])]
+                wtext = "\t".join(str(x) for x in wd) + "\n"
+                last = (ok, mtext, wtext)
             if not (ok or args.writeFailedWindows):
                 continue
-            M = np.full((n, n), np.nan)
-            if ok:
-                M[iu] = full[k, :npairs]
-                M[(iu[1], iu[0])] = full[k, :npairs]
-            out.write(_matrix_text(M, samples, args.outFormat, args.roundTo))
+            out.write(mtext)
             if wout is not None:
-                wd = ([T.ID[k]] if args.addWindowID else []) + [T.scaffold[k], T.start[k], T.end[k], T.mid[k], int(T.sites[k])]
-                wout.write("\t".join(str(x) for x in wd) + "\n")
+                wout.write(wtext)
             written += 1
+    if run.world.rank == 0:
         for f in (out, wout):
             if f is not None and f is not sys.stdout:
                 f.close()
-        sys.stderr.write("{} windows were tested.\n{} results were written.\n\n### Done. ###\n".format(T.n, written))
+        sys.stderr.write("{} windows were tested.\n{} results were written.\n\n### Done. ###\n".format(run.n_tested, written))
     run.report_timing()
     run.comm.barrier()
     return 0
