@@ -9,6 +9,7 @@ Additive flags: --device N (GPU index; default LOCAL_RANK or 0).  Under a one-pr
 import argparse
 import gzip
 import itertools
+import os
 import sys
 
 import numpy as np
@@ -688,12 +689,8 @@ def freq_main(argv=None):
     ap.add_argument("--device", type=int, default=None, help="GPU index (MI355X engine)")
     args = ap.parse_args(argv)
 
-    packed = genoio.open_input(args.genoFile) if str(args.genoFile).endswith(".pgeno") else None
-    if packed is not None:
-        headerInds, body = list(packed.names), packed.read_block(None)
-    else:
-        raw = genoio.read_all(args.genoFile)
-        headerInds, body = genoio.split_header(raw)
+    reader = genoio.open_input(args.genoFile)                              # blocks of PG_STREAM_BYTES: bounded host memory
+    headerInds = reader.read_header().decode("utf-8", "replace").split()[2:]
     if not args.indFreqs and not args.population:
         if args.target == "derived":
             popNames, popInds = ["ingroup", "outgroup"], [headerInds[:-1], [headerInds[-1]]]
@@ -732,7 +729,6 @@ def freq_main(argv=None):
     sampleData = SampleData(popNames=popNames, popInds=popInds, ploidyDict=ploidyDict)
     fmt = "pairs" if args.genoFormat == "alleles" else args.genoFormat
     layout = HapLayout(sampleData, headerInds, fmt)
-    data = packed.to_geno(body, layout) if packed is not None else genoio.encode(body, layout)
     asCounts = args.asCounts if args.target else True                      # freq.py:222-224
     keepNan = args.keepNanLines if args.target else True
     minData = args.minData if args.target else 0
@@ -741,11 +737,23 @@ def freq_main(argv=None):
     eng.set_layout(layout)
     out = _open_out(args.outFile)
     out.write("scaffold\tposition\t" + "\t".join(popNames) + "\n")
-    run_of_row = np.repeat(np.arange(len(data.run_starts)), np.diff(np.append(data.run_starts, data.n_sites)))
     P = len(popNames)
     CH = 1 << 20
-    for a in range(0, data.n_sites, CH):
-        b = min(data.n_sites, a + CH)
+    block_bytes = int(os.environ.get("PG_STREAM_BYTES", 1 << 30))
+
+    def site_blocks():
+        """(GenoData of an input block, run index of each of its rows, a, b) for sub-blocks [a,b) of at most CH sites"""
+        while True:
+            body = reader.read_block(block_bytes)
+            if len(body) == 0:
+                return
+            data = reader.to_geno(body, layout)
+            del body
+            run_of_row = np.repeat(np.arange(len(data.run_starts)), np.diff(np.append(data.run_starts, data.n_sites)))
+            for a in range(0, data.n_sites, CH):
+                yield data, run_of_row, a, min(data.n_sites, a + CH)
+
+    for data, run_of_row, a, b in site_blocks():
         eng.load_sites(data.gt[a:b])
         cnt = eng.batch([0], [0]).siteCounts(0, b - a).astype(np.int64)        # [n][P][4]
         n = cnt.sum(axis=2)
@@ -792,6 +800,7 @@ def freq_main(argv=None):
         names = data.run_names
         for i in keep:
             out.write(names[run_of_row[a + i]] + "\t" + str(int(data.pos[a + i])) + "\t" + "\t".join(cells[i]) + "\n")
+    reader.close()
     if out is not sys.stdout:
         out.close()
     sys.stderr.write("\nDone\n")

@@ -68,7 +68,7 @@ def test_cli_reproduces_reference_output(case, tmp_path, geno=None):
 
 
 def _streamable(c):
-    if c["tool"] not in ("popgenWindows.py", "ABBABABAwindows.py", "fourPopWindows.py", "distMat.py"):
+    if c["tool"] not in ("popgenWindows.py", "ABBABABAwindows.py", "fourPopWindows.py", "distMat.py", "freq.py"):
         return False
     if "--windType" not in c["argv"]:
         return True
