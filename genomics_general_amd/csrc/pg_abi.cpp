@@ -109,7 +109,6 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->Dfull.release();
     c->Vp.release();
     c->XY.release();
-    c->nw.release();
     c->planes.release();
     c->Cmat.release();
     c->Dmat.release();

@@ -89,7 +89,6 @@ struct pg_ctx {
     int n_tasksCh = 0;
     bool all_diploid = false;    // every individual owns exactly slots (2k, 2k+1)
     DevBuf<uint32_t> Vp, XY;     // v2 planes (slot 0; also used by nothing else)
-    DevBuf<int32_t> nw;          // v2: compacted words per group
     // v2 software pipeline: k_pack2 of sub-batch k+1 (HBM-bound, stream2) overlaps the pair kernels of sub-batch k
     // (VALU-bound, stream).  Two slots of planes / window tables.
     hipStream_t stream2 = nullptr;

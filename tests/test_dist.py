@@ -66,3 +66,51 @@ def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
     uid0, path = dist.exchange_unique_id(dist.World(0, 2, 0), lambda: bytes(range(128)))
     uid1, _ = dist.exchange_unique_id(dist.World(1, 2, 1), lambda: b"", timeout_s=5)
     assert uid0 == uid1 == bytes(range(128)) and os.path.exists(path)
+
+
+def test_rendezvous_path_and_device_folding(monkeypatch):
+    """the RCCL unique-id hand-over file: keyed by the launcher under torch.distributed.run, by MASTER_ADDR/PORT otherwise,
+    PG_RDZV_FILE wins; LOCAL_RANK folds into the visible devices"""
+    import os
+    from genomics_general_amd import _lib, dist
+    for k in ("PG_RDZV_FILE", "TORCHELASTIC_RUN_ID"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    plain = dist._rdzv_path()
+    assert plain == "/tmp/pg_rdzv_127.0.0.1_29999"
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    assert dist._rdzv_path() == plain + "_none_%d" % os.getppid()
+    monkeypatch.setenv("PG_RDZV_FILE", "/tmp/x_y")
+    assert dist._rdzv_path() == "/tmp/x_y"
+    monkeypatch.setattr(_lib, "device_count", lambda: 1)
+    assert dist.device_for(dist.World(3, 8, 3)) == 0
+    monkeypatch.setattr(_lib, "device_count", lambda: 8)
+    assert dist.device_for(dist.World(3, 8, 3)) == 3
+    monkeypatch.setattr(_lib, "device_count", lambda: 0)
+    assert dist.device_for(dist.World(3, 8, 3)) == 3
+
+
+def test_unique_id_handover_between_processes(tmp_path, monkeypatch):
+    """rank 0 publishes, another process picks the 128 bytes up; a stale file of a dead launch is replaced, not read"""
+    import multiprocessing as mp
+    import os
+    from genomics_general_amd import dist
+    path = str(tmp_path / "rdzv")
+    monkeypatch.setenv("PG_RDZV_FILE", path)
+    with open(path, "wb") as f:
+        f.write(b"\\x01" * 128)                                            # leftover
+    uid = bytes(range(128))
+    got0, p0 = dist.exchange_unique_id(dist.World(0, 2, 0), lambda: uid)
+    assert got0 == uid and p0 == path
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+
+    def other():
+        q.put(dist.exchange_unique_id(dist.World(1, 2, 1), None, timeout_s=20.0)[0])
+
+    pr = ctx.Process(target=other)
+    pr.start()
+    assert q.get(timeout=30) == uid
+    pr.join(10)
+    os.remove(path)
