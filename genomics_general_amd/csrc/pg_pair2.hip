@@ -383,8 +383,15 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                 }
                 if (!PRES && threadIdx.x == 0) sh_gp[PRES ? 0 : w - w_begin] = make_uint4(pr[0], pr[1], pr[2], pr[3]);
                 const int row_w = (w - w_begin) * 32;
-                auto append = [&](uint32_t m, uint32_t tag) {   // scalar loop: the word's sites in m join the list (<= 32 of them)
-                    while (m) {
+                // pass 0: virtual site 0 of every polymorphic site; passes 1, 2 (rare): the second / third virtual site of the
+                // sites with three / four alleles.  One rolled loop: a single copy of the list and flush code per word slot.
+                const uint32_t m3 = tri_mask(pr);
+#pragma unroll 1
+                for (int pass = 0; pass < 3; ++pass) {
+                    uint32_t m = pass == 0 ? poly_mask(pr) : (pass == 1 ? m3 : quad_mask(pr));
+                    if (pass && !m3) break;
+                    const uint32_t tag = (uint32_t)pass << 16;
+                    while (m) {                      // scalar loop: the word's sites in m join the list (<= 32 of them)
                         const int bit = __builtin_ctz(m);
                         m &= m - 1u;
                         vlist = lane == cnt ? ((uint32_t)(row_w + (bit & 3) * 8 + (bit >> 2)) | tag) : vlist;
@@ -396,13 +403,6 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                         vlist = lane < 32 ? up : (uint32_t)nrows;
                         cnt -= 32;
                     }
-                };
-                append(poly_mask(pr), 0u);                       // virtual site 0 of every polymorphic site
-                const uint32_t m3 = tri_mask(pr);
-                if (m3) {                                        // rare: second / third virtual site of sites with 3 / 4 alleles
-                    append(m3, 1u << 16);
-                    const uint32_t m4 = quad_mask(pr);
-                    if (m4) append(m4, 2u << 16);
                 }
             }
         }
