@@ -1,0 +1,43 @@
+"""Command-line helpers under tools/ that need no GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from genomics_general_amd import genoio
+from genomics_general_amd.samples import HapLayout, SampleData
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_geno_pack_tool_writes_a_file_the_reader_decodes(tmp_path):
+    """tools/geno_pack.py end to end: mixed ploidy through --ploidyFile, raw and deflated blocks give the same rows"""
+    src = os.path.join(GOLD, "mixed.geno.gz")
+    names, body = genoio.split_header(genoio.read_all(src))
+    pl = {nm: (1 if nm in ("s1", "s6", "s9") else 2) for nm in names}
+    lay = HapLayout(SampleData(indNames=list(names), ploidyDict=pl), names, "phased")
+    want = genoio.encode(body, lay)
+    sizes = {}
+    for codec in ("zlib", "none"):
+        out = str(tmp_path / ("m_%s.pgeno" % codec))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "geno_pack.py"), "-g", src, "-o", out, "-f", "phased",
+                            "--ploidyFile", os.path.join(GOLD, "mixed_ploidy.txt"), "--codec", codec, "--blockMiB", "1"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=str(tmp_path), timeout=120)
+        assert r.returncode == 0, r.stderr.decode()[-400:]
+        assert ("%d sites" % want.n_sites) in r.stderr.decode()
+        rd = genoio.open_input(out)
+        assert rd.codec == codec and list(rd.ploidy) == [pl[nm] for nm in names]
+        got = rd.to_geno(rd.read_block(None), lay)
+        rd.close()
+        assert np.array_equal(got.gt, want.gt) and np.array_equal(got.pos, want.pos) and got.run_names == want.run_names
+        sizes[codec] = os.path.getsize(out)
+    assert sizes["zlib"] < sizes["none"]
+    # --haploid gives the same file as the ploidy file
+    out2 = str(tmp_path / "m2.pgeno")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "geno_pack.py"), "-g", src, "-o", out2, "-f", "phased",
+                        "--haploid", "s1,s6,s9", "--codec", "none", "--blockMiB", "1"], stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    with open(out2, "rb") as f, open(str(tmp_path / "m_none.pgeno"), "rb") as g:
+        assert f.read() == g.read()
