@@ -40,6 +40,8 @@ def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins):
     (40, 5000, 0.3, "mixed"),          # mono-, bi-, tri- and tetra-allelic sites side by side, heavy missingness
     (9, 700, 0.0, "uniform"),          # haploid-called mismatch impossible, no missing data
     (530, 1300, 0.05, "mixed"),        # > 1024 haplotype slots: presence pre-pass + word prefix scan
+    (150, 1500, 0.1, "uniform"),       # two waves per block: list / flush code behind block barriers
+    (300, 800, 0.2, "mixed"),          # four waves per block
 ])
 def test_pairwise_counts_with_three_and_four_alleles_per_site(n_dip, L, p_miss, mix):
     """sites with k alleles become k-1 virtual biallelic sites in k_pack2; D must still be the plain Hamming count"""
