@@ -1,0 +1,111 @@
+"""CPU stand-in for genomics_general_amd.engine.Engine, for the `-m "not gpu"` tests of the command-line drivers only: the
+windows, streaming, argument handling and output formatting of genomics_general_amd/cli.py run end to end on a machine without a
+GPU, with the per-window numbers supplied by the oracle (tests/ may use it; the product never does).  The HIP path itself and
+the host finalisers of engine.WindowBatch are covered by the -m gpu tests."""
+import numpy as np
+
+from oracle import popgen_oracle as orc
+
+
+class CpuEngine:
+    def __init__(self, device=0):
+        self.device = device
+        self.gt = None
+
+    def set_layout(self, layout):
+        self.layout = layout
+
+    def load_sites(self, gt):
+        self.gt = np.array(gt, dtype=np.int8, copy=True)
+
+    def batch(self, lo, hi):
+        return CpuBatch(self, lo, hi)
+
+    def close(self):
+        pass
+
+
+def _stack(dicts, n):
+    keys = dicts[0].keys() if dicts else []
+    return {k: np.array([d[k] for d in dicts], dtype=np.float64).reshape(n) for k in keys}
+
+
+class CpuBatch:
+    def __init__(self, e, lo, hi):
+        self.e, self.lay = e, e.layout
+        self.lo, self.hi = np.asarray(lo, dtype=np.int64), np.asarray(hi, dtype=np.int64)
+        self.n = len(self.lo)
+        lay = self.lay
+        groups = [g if g is not None else "~none" for g in lay.hap_group]
+        self.alns = [orc.aln_from_codes(e.gt[a:b], lay.hap_names, lay.hap_sample_name, groups)[0]
+                     for a, b in zip(self.lo, self.hi)]
+        self._counts = None
+        self._dm = None                    # per window: the cached distance matrix as groupDistStats leaves it
+        self._diag_nan = False
+
+    def _dc(self):
+        if self._counts is None:
+            self._counts = [orc.pair_counts_gemm(a) for a in self.alns]
+        return self._counts
+
+    def _cache(self):
+        if self._dm is not None:
+            return [d.copy() for d in self._dm]
+        out = [orc.dist_from_counts(D, C) for D, C in self._dc()]
+        if self._diag_nan:
+            for d in out:
+                np.fill_diagonal(d, np.nan)
+        return out
+
+    def groupFreqStats(self):
+        return _stack([orc.group_freq_stats(a) for a in self.alns], self.n)
+
+    def groupDistStats(self, doPairs=True, minSites=None, minData=0.01):
+        res = [orc.group_dist_stats(a, D, C, doPairs, minSites, minData) for a, (D, C) in zip(self.alns, self._dc())]
+        self._dm = [r[1] for r in res]
+        out = _stack([{k: v for k, v in r[0].items() if "~none" not in k} for r in res], self.n)
+        return out
+
+    def indPairDists(self, includeSameWithSame=False, minSites=None):
+        assert not minSites
+        per = [orc.ind_pair_dists(a, d, includeSameWithSame)[0] for a, d in zip(self.alns, self._cache())]
+        if not includeSameWithSame:
+            self._diag_nan = True
+        names = list(per[0].keys()) if per else list(self.lay.ind_order)
+        return {a: {b: np.array([p[a][b] for p in per], dtype=np.float64) for b in names} for a in names}
+
+    def indPairTable(self, includeSameWithSame=False, minSites=None):
+        lay = self.lay
+        d = self.indPairDists(includeSameWithSame, minSites)
+        n = lay.n_samp
+        tab = np.full((self.n, n * (n + 1) // 2), np.nan)
+        for s in range(n):
+            for t in range(s, n):
+                tab[:, lay.sample_pair_index(s, t)] = d[lay.ind_order[s]][lay.ind_order[t]]
+        return tab
+
+    def sampleHet(self):
+        st = _stack([orc.sample_het(a, d, C) for a, d, (_, C) in zip(self.alns, self._cache(), self._dc())], self.n)
+        return {(k[4:] if k.startswith("het_") else k): v for k, v in st.items()}          # WindowBatch keys are bare names
+
+    def H12stats(self, maxDist=0):
+        return _stack([orc.h12_stats(a, d, maxDist) for a, d in zip(self.alns, self._cache())], self.n)
+
+    def ABBABABA(self, P1, P2, P3, P4, minData):
+        return _stack([orc.abbababa(a, P1, P2, P3, P4, minData) for a in self.alns], self.n)
+
+    def fourPop(self, P1, P2, P3, P4, minData, polarize=False, fixed=False):
+        return _stack([orc.four_pop(a, P1, P2, P3, P4, minData, polarize, fixed) for a in self.alns], self.n)
+
+    def hapCalled(self):
+        return np.array([(self.e.gt[a:b] != 0).sum(axis=0) for a, b in zip(self.lo, self.hi)], dtype=np.int64).reshape(self.n, -1)
+
+    def siteCounts(self, a, b):
+        lay = self.lay
+        gt = self.e.gt[a:b]
+        out = np.zeros((b - a, lay.n_pops, 4), dtype=np.int32)
+        for p in range(lay.n_pops):
+            cols = np.flatnonzero(lay.hap_pop == p)
+            for k, code in enumerate((1, 2, 4, 8)):
+                out[:, p, k] = (gt[:, cols] == code).sum(axis=1)
+        return out

@@ -1,0 +1,59 @@
+"""The command-line drivers (genomics_general_amd/cli.py: arguments, windows, streaming in small blocks, packed input, output
+formatting) end to end WITHOUT a GPU: the engine is replaced by tests/cpu_engine.CpuEngine, whose per-window numbers come from
+the oracle.  The same reference goldens as the -m gpu run, so a regression in the host logic shows up on every machine; the HIP
+kernels and engine.WindowBatch are what tests/test_gpu_golden.py adds on an MI355X."""
+import os
+
+import pytest
+
+from cases import CASES
+from cpu_engine import CpuEngine
+from golden_util import align_columns
+from genomics_general_amd import cli, genoio
+
+import test_gpu_golden as G
+
+GOLD = G.GOLD
+
+
+def run_case(case, tmp_path, monkeypatch, geno=None):
+    monkeypatch.setattr(cli, "Engine", CpuEngine)
+    geno = geno or os.path.join(GOLD, case["fixture"] + ".geno.gz")
+    out = str(tmp_path / (case["name"] + ".out"))
+    argv = [a.format(geno=geno, dir=GOLD, out=out) for a in case["argv"]] + ["-o", out]
+    G.MAINS[case["tool"]](argv)
+    with open(out) as f:
+        got = f.read()
+    with open(os.path.join(GOLD, case["name"] + ".out")) as f:
+        want = f.read()
+    n_inexact = G.compare_text(align_columns(got, want), want, G.round_digits(case))
+    assert n_inexact <= max(2, len(want.split()) // 50), "%d cells differ in the last digit" % n_inexact
+    side = os.path.join(GOLD, case["name"] + ".out.windows")
+    if os.path.exists(side):
+        with open(out + ".windows") as f, open(side) as g:
+            assert f.read() == g.read()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_drivers_reproduce_reference_output_on_the_cpu_engine(case, tmp_path, monkeypatch):
+    run_case(case, tmp_path, monkeypatch)
+
+
+@pytest.mark.parametrize("case", G.STREAMABLE, ids=[c["name"] for c in G.STREAMABLE])
+def test_drivers_streaming_in_small_blocks_on_the_cpu_engine(case, tmp_path, monkeypatch):
+    monkeypatch.setenv("PG_STREAM_BYTES", "4000")
+    run_case(case, tmp_path, monkeypatch)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("c1_popgen", "sparse_sites_windows", "mixed_haploid_flag",
+                                                                     "abba_windows_diplo", "multi_distmat", "haplo_popgen")],
+                         ids=lambda c: c["name"])
+def test_drivers_on_packed_input_on_the_cpu_engine(case, tmp_path, monkeypatch):
+    argv = case["argv"]
+    fmt = argv[argv.index("-f") + 1] if "-f" in argv else "phased"
+    haploid = {"s1": 1, "s6": 1, "s9": 1} if case["fixture"] == "mixed" else {}
+    packed = str(tmp_path / (case["fixture"] + ".pgeno"))
+    genoio.pack_geno(os.path.join(GOLD, case["fixture"] + ".geno.gz"), packed, "pairs" if fmt == "alleles" else fmt, haploid,
+                     block_bytes=20000)
+    monkeypatch.setenv("PG_STREAM_BYTES", "30000")
+    run_case(case, tmp_path, monkeypatch, geno=packed)
