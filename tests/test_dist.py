@@ -114,3 +114,51 @@ def test_unique_id_handover_between_processes(tmp_path, monkeypatch):
     assert q.get(timeout=30) == uid
     pr.join(10)
     os.remove(path)
+
+
+CLI_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, os.path.join(%r, "tests", "golden"))
+from genomics_general_amd import cli, dist
+from cpu_engine import CpuEngine
+cli.Engine = CpuEngine                                        # numbers from the oracle: this test is about sharding and gathering
+dist.RcclComm = lambda engine, world: dist.GlooComm(world)
+tool, argv = sys.argv[1], sys.argv[2:]
+rc = {"popgenWindows.py": cli.popgen_main, "ABBABABAwindows.py": cli.abbababa_main, "distMat.py": cli.distmat_main}[tool](argv)
+sys.exit(rc or 0)
+''' % (ROOT, ROOT, ROOT)
+
+
+def _run_two_ranks(tool, argv, port):
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PG_STREAM_BYTES="6000")
+        procs.append(subprocess.Popen([sys.executable, "-c", CLI_WORKER, tool] + argv, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        assert p.returncode == 0, o.decode()[-1500:]
+
+
+def test_drivers_with_two_ranks_write_the_single_rank_output(tmp_path):
+    """popgenWindows / ABBABABAwindows / distMat with WORLD_SIZE=2 (gloo stand-in communicator, CPU stand-in engine), input
+    streamed in 6 kB blocks: every block's windows are split over the ranks, gathered, and rank 0 writes the reference's file"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from cases import CASES
+    from golden_util import align_columns
+    import test_gpu_golden as G
+    gold = os.path.join(ROOT, "tests", "golden")
+    for k, name in enumerate(("sparse_overlap_failed_id", "abba_windows_sites", "multi_distmat", "sparse_predefined")):
+        case = [c for c in CASES if c["name"] == name][0]
+        out = str(tmp_path / (name + ".out"))
+        geno = os.path.join(gold, case["fixture"] + ".geno.gz")
+        argv = [a.format(geno=geno, dir=gold, out=out) for a in case["argv"]] + ["-o", out]
+        _run_two_ranks(case["tool"], argv, 31000 + (os.getpid() + 7 * k) % 2000)
+        with open(out) as f, open(os.path.join(gold, name + ".out")) as g:
+            got, want = f.read(), g.read()
+        G.compare_text(align_columns(got, want), want, G.round_digits(case))
