@@ -1,19 +1,28 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: popgenWindows pi / dxy / Fst over 50 kb coordinate windows (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|northstar|c3]
+    python bench.py --gpus N --steps K --warmup W [--workload northstar|c2|c3|c4|c5|popfreq|c2_w5k|tiny]
 
 One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the launcher).  A step is one pass of the whole per-window
-statistics path over the rank's resident synthetic data set: pack -> pairwise D/C -> population sums on the GPU,
-the float64 finalisation (pi, dxy, Fst) on the GPU and D2H of the result table.  The data path has no collective (windows are
-independent): at N>1 the ranks meet in an RCCL barrier on both sides of the timed region, and the per-window tables are
-all-gathered once after it (what the drivers do once per input block before rank 0 writes the CSV).  Inputs are generated on the device before the timed region (counter-based generator,
-genomics_general_amd/synth.py) and stay resident in HBM.  Weak scaling: every rank owns a full-size data set
-(different sites), `value` = windows of all ranks / max-over-ranks time.
+statistics path over the rank's resident synthetic data set: pack -> pairwise D/C -> population sums on the GPU, the float64
+finalisation (pi, dxy, Fst) on the GPU and D2H of the result table.  Measurement tier T0: the inputs are
+generated on the device before the timed region (counter-based generator, genomics_general_amd/synth.py) and stay resident
+in HBM.  The data path has no collective (windows are independent): at N>1 the ranks meet in an RCCL barrier on both sides
+of the timed region, and the per-window tables are all-gathered once after it (what the drivers do before rank 0 writes the
+CSV).  Weak scaling: every rank owns a full-size data set (different scaffolds), `value` = windows of all ranks /
+max-over-ranks time.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, timed with HIP events on the
-stream it runs on (the kernel family with the most GPU time in the timed region); `cpu_baseline` is the CPU oracle's faithful pair-loop port timed on a bounded sample
-(N=1, rank 0 only).  No torch anywhere: barriers and the gather go through RCCL in libpopgen_hip.so.
+Default workload = the north-star single-GPU shape (BASELINE.json `north_star` "Target": 10^8 sites x 200 diploids, 4
+populations, 50 kb windows = the first 10^8 sites of configs[4]); `--workload c2` is configs[1], c3 configs[2], c4 configs[3],
+c5 the rank's share of configs[4] (3*10^9 sites / N, needs N >= 8).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the kernel family with the most GPU time), timed with HIP
+events on the stream it runs on: an HBM-bound family (k_pack3, k_abba_q, k_popfreq_q) is priced in algorithmic bytes against
+8 TB/s, a VALU-bound one (k_pairC, k_pairD) in VALU wave-instructions against the guide's issue ceiling and against the
+measured ceiling of its instruction mix (profiles/: tools/valu_rate.hip).  `cpu_baseline` is the CPU oracle's restatement of
+the reference's FULL path (.geno text -> parse -> windows -> alignment -> pair-by-pair loop -> statistics) run on all host
+cores, one window per worker process (N=1, rank 0 only).  No torch anywhere: barriers and the gather go through RCCL in
+libpopgen_hip.so.
 """
 import argparse
 import json
@@ -26,20 +35,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from genomics_general_amd import _lib, dist, synth, windows  # noqa: E402
-from genomics_general_amd.engine import Engine  # noqa: E402
-from genomics_general_amd.samples import HapLayout, SampleData  # noqa: E402
-
 WORKLOADS = {
+    # north-star single-GPU shape: first 10^8 sites of config 5 (200 diploids)
+    "northstar": dict(n_sites=100_000_000, n_scaf=4, n_dip=200, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
+                      desc="popgenWindows pi/Fst/Dxy: 1e8 sites x 200 diploids (400 haplotypes), 4 pops, 50 kb windows"),
     # BASELINE.json configs[1]: 10^7 sites x 100 diploids, 4 pops, 50 kb windows
     "c2": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
                desc="popgenWindows pi/Fst/Dxy: 1e7 sites x 100 diploids (200 haplotypes), 4 pops, 50 kb windows"),
     # the C2 data set in 5 kb windows (2000 windows of 157 words): per-window fixed costs of the pair kernels; not a BASELINE.json config
     "c2_w5k": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=5_000, min_sites=100, tool="popgen",
                    desc="popgenWindows pi/Fst/Dxy: 1e7 sites x 100 diploids (200 haplotypes), 4 pops, 5 kb windows"),
-    # north-star single-GPU shape: first 10^8 sites of config 5 (200 diploids)
-    "northstar": dict(n_sites=100_000_000, n_scaf=4, n_dip=200, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
-                      desc="popgenWindows pi/Fst/Dxy: 1e8 sites x 200 diploids (400 haplotypes), 4 pops, 50 kb windows"),
+    # BASELINE.json configs[4]: 3*10^9 sites x 200 diploids sharded over the ranks (n_sites is per rank, set in main)
+    "c5": dict(n_sites=None, n_scaf=3, n_dip=200, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
+               desc="popgenWindows pi/Fst/Dxy: this rank's share of 3e9 sites x 200 diploids (400 haplotypes), 4 pops, 50 kb windows"),
     # BASELINE.json configs[2]: ABBA-BABA
     "c3": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=50_000, min_sites=100, tool="abba",
                desc="ABBABABAwindows D/fd: 1e7 sites, P1/P2/P3/O x 25 diploids, 50 kb windows"),
@@ -54,22 +62,138 @@ WORKLOADS = {
                  desc="tiny smoke workload"),
 }
 CPU_DISTMAT_HAPS = 120          # distMat CPU sample: 7140 pairs x 100 kb ~ 5 s per window
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PAIRSITES_PEAK = 3.6e14   # 7 lane-ops per 32 pair-sites at 7.9e13 lane-ops/s
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_GUIDE = 1024 * 2.4e9 / 2      # wave64 VALU instructions per second: 256 CUs x 4 SIMD-32, 2 cycles each, 2.4 GHz (guide)
+VALU_PAIRSITES_PEAK = 3.6e14    # 7 lane-ops per 32 pair-sites at 7.9e13 lane-ops/s
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline worker (spawned process: no GPU, no engine; only the oracle).  One window of the workload: rendered as
+# `.geno` text (untimed), then the oracle's restatement of the reference's whole path on it (timed).
+# ---------------------------------------------------------------------------------------------------------------
+def _cpu_window_job(job):
+    import tempfile
+    sys.path.insert(0, ROOT)
+    from genomics_general_amd import synth
+    from oracle import popgen_oracle as orc
+    codes, names, pops, wind, min_sites, tool, scaf, pos0 = job
+    L = codes.shape[0]
+    fd, path = tempfile.mkstemp(suffix=".geno", prefix="pg_cpu_baseline_")
+    os.close(fd)
+    try:
+        synth.write_geno(path, [scaf], np.zeros(L, dtype=np.int64), np.arange(pos0, pos0 + L), codes, names, sep="/", fmt="phased")
+        t0 = time.time()
+        if tool == "popgen":          # popgenWindows.py:28-75 on the file: parse, windows, genoToAlignment, pair loop, statistics
+            csv = orc.popgen_windows_csv(path, "phased", pops, wind, min_sites=min_sites, min_data=0.01, round_to=12,
+                                         counts_fn=orc.pair_counts_loop, write_failed=True)
+        elif tool == "popfreq":
+            csv = orc.popgen_windows_csv(path, "phased", pops, wind, min_sites=min_sites, analysis=("popFreq",), round_to=12,
+                                         write_failed=True)
+        else:                         # ABBABABAwindows.py:27-52
+            csv = orc.abbababa_windows_csv(path, "phased", pops, wind, min_sites=min_sites, min_data=0.01, write_failed=True)
+        t1 = time.time()
+    finally:
+        os.unlink(path)
+    return t0, t1, csv
+
+
+def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, stats, max_workers):
+    """W = #workers windows of the workload through the oracle's full path, one per worker process on all host cores."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    workers = cores
+    try:
+        import psutil
+        # a worker holds one window as Python strings + int64 alignment: ~2.5 kB per site-individual pair at the 400-haplotype shape
+        per_worker = 160 * wl["wind"] * lay.n_hap // 2 + (1 << 28)
+        workers = max(1, min(workers, int(psutil.virtual_memory().available * 0.6 // per_worker)))
+    except Exception:
+        pass
+    workers = max(1, min(workers, max_workers, len(lo)))
+    per = len(names) // lay.n_pops
+    pops = [(p, names[k * per:(k + 1) * per]) for k, p in enumerate(lay.sampleData.popNames)]
+    # generator order of the columns: sample d owns columns (2d, 2d+1)
+    col_of_slot = np.array([2 * names.index(lay.hap_sample_name[s]) + (s - lay.ind_slots[lay.hap_sample_name[s]][0])
+                            for s in range(lay.n_hap)])
+    sel = np.linspace(0, len(lo) - 1, workers).astype(int) if workers > 1 else np.array([0])
+    jobs = []
+    for w in sel:
+        slot_codes = eng.download(int(lo[w]), int(hi[w] - lo[w]))
+        codes = np.zeros_like(slot_codes)
+        codes[:, col_of_slot] = slot_codes
+        scaf, pos0 = "chr%d" % (int(lo[w]) // scaf_len + 1), int(lo[w]) % scaf_len + 1
+        # a window file starts at position pos0: render it with positions 1.. so that it is exactly one window of the tool
+        jobs.append((codes, names, pops, wl["wind"], wl["min_sites"], wl["tool"], scaf, 1))
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(workers) as pool:
+        res = pool.map(_cpu_window_job, jobs, chunksize=1)
+    wall = max(r[1] for r in res) - min(r[0] for r in res)
+    busy = sum(r[1] - r[0] for r in res)
+    ok = True
+    for w, (_, _, csv) in zip(sel, res):
+        rows = csv.strip().split("\n")
+        head, vals = rows[0].split(","), rows[1].split(",")
+        for k, v in zip(head, vals):
+            if k in ("scaffold", "start", "end", "mid", "sites"):
+                continue
+            v = float(v)
+            if k == "sitesUsed":
+                ok = ok and (int(stats[k][w]) == int(v) if v == v else True)
+                continue
+            if k not in stats:
+                continue
+            g = float(stats[k][w])
+            # the ABBA-BABA driver rounds to 4 decimals (ABBABABAwindows.py:42), the popgenWindows leg is run with --roundTo 12
+            tol = 0.5e-4 + 1e-6 if wl["tool"] == "abba" else 1e-6 * max(1.0, abs(v))
+            ok = ok and (abs(g - v) <= tol or (g != g and v != v))
+    W = len(sel)
+    return {"value": round(W / wall, 5), "unit": "windows/s", "sites_per_sec": round(W * wl["wind"] / wall, 1),
+            "cores": workers, "host_cores": cores, "kind": "port",
+            "sample": "%d windows of the workload (%d sites x %d haplotypes each), each rendered as .geno text and run through the "
+                      "oracle's restatement of the reference's whole path (text parse -> window -> genoToAlignment -> pair-by-pair "
+                      "loop -> statistics; popgenWindows.py:28-75, genomics.py:1884-1945, 1101-1127, 903-916, 956-995), one window "
+                      "per worker process, %d worker processes in parallel" % (W, wl["wind"], lay.n_hap, workers),
+            "wall_seconds": round(wall, 2), "cpu_seconds": round(busy, 2), "gpu_matches_oracle_on_sample": bool(ok)}
+
+
+def cpu_baseline_distmat(eng, lay, wl, lo, hi, stats):
+    """distMat (2000 haplotypes): the pair loop is quadratic in haplotypes, a window costs ~20 minutes on one core; time the first
+    CPU_DISTMAT_HAPS haplotypes of one window and scale by the pair count (numeric core only)."""
+    from oracle import popgen_oracle as orc
+    n_hap = lay.n_hap
+    codes = eng.download(int(lo[0]), int(hi[0] - lo[0]))
+    scale = (n_hap * (n_hap - 1) / 2) / (CPU_DISTMAT_HAPS * (CPU_DISTMAT_HAPS - 1) / 2)
+    aln, _ = orc.aln_from_codes(codes[:, :CPU_DISTMAT_HAPS], lay.hap_names[:CPU_DISTMAT_HAPS],
+                                lay.hap_sample_name[:CPU_DISTMAT_HAPS], lay.hap_group[:CPU_DISTMAT_HAPS])
+    c0 = time.perf_counter()
+    orc.pair_counts_loop(aln)
+    dt = (time.perf_counter() - c0) * scale
+    return {"value": round(1.0 / dt, 6), "unit": "windows/s", "cores": 1, "kind": "port",
+            "sample": "numeric core only (no text parsing / alignment build): the pair-by-pair loop (genomics.py:903-916) of one window "
+                      "(%d sites) timed on its first %d haplotypes and scaled by the pair count to %d haplotypes" % (
+                          wl["wind"], CPU_DISTMAT_HAPS, n_hap),
+            "seconds": round(dt, 2), "gpu_matches_oracle_on_sample": None}
 
 
 def main():
+    from genomics_general_amd import _lib, dist, synth, windows
+    from genomics_general_amd.engine import Engine
+    from genomics_general_amd.samples import HapLayout, SampleData
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="northstar", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-windows", type=int, default=2, help="windows of the workload timed on the CPU port")
+    ap.add_argument("--cpu-workers", type=int, default=1 << 30, help="upper bound of the CPU baseline's worker processes")
     args = ap.parse_args()
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
     world = dist.world_from_env()
     assert world.size == args.gpus, "WORLD_SIZE (%d) must equal --gpus (%d)" % (world.size, args.gpus)
+    if args.workload == "c5":
+        assert world.size >= 8, "the c5 workload is 3e9 sites sharded over the ranks: 150 GB per rank at 8 ranks, needs --gpus >= 8"
+        wl["n_sites"] = 3_000_000_000 // world.size // (wl["n_scaf"] * wl["wind"]) * (wl["n_scaf"] * wl["wind"])
 
     # ---- setup (untimed) ---------------------------------------------------------------------------
     n_dip, n_pops = wl["n_dip"], wl["n_pops"]
@@ -82,6 +206,8 @@ def main():
     eng = Engine(dist.device_for(world))
     eng.set_layout(lay)
     comm = dist.RcclComm(eng, world) if world.size > 1 else dist.SoloComm()
+    if world.size > 1:
+        assert eng._comm_ranks() == world.size, "the RCCL communicator has %d ranks, expected %d" % (eng._comm_ranks(), world.size)
     n_sites = wl["n_sites"]
     scaf_len = n_sites // wl["n_scaf"]
     eng.reserve(n_sites)
@@ -143,9 +269,11 @@ def main():
     for _ in range(args.steps):
         st, _tab = step()
     eng.sync()
+    my_elapsed = time.perf_counter() - t0
     comm.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = float(np.max(comm.allgather(np.array([elapsed])))) if world.size > 1 else elapsed
+    per_rank = comm.allgather(np.array([my_elapsed, elapsed])) if world.size > 1 else np.array([[my_elapsed, elapsed]])
+    elapsed = float(np.max(per_rank[:, 1]))
     gather_ms = None
     if world.size > 1:                                     # the result exchange of the drivers, once, outside the timed region
         g0 = time.perf_counter()
@@ -164,27 +292,47 @@ def main():
     n_hap = lay.n_hap
     roofline = None
     extra = {}
+    # rocprofv3's names of the kernel behind each family, for this workload
+    pack_name = "k_pack2" if (os.environ.get("PG_PACK2") or n_hap > 1024) else "k_pack3"
+    if os.environ.get("PG_PAIR_V1"):
+        rocprof_name = {_lib.K_PACK: "k_pack", _lib.K_PAIRWISE: "k_pairwise"}
+    else:
+        rocprof_name = {_lib.K_PACK: pack_name, _lib.K_PAIRWISE: "k_pairC", _lib.K_PAIRD: "k_pairD",
+                        _lib.K_SITESTATS: "k_popfreq_q" if wl["tool"] == "popfreq" else "k_abba_q"}
+    pmc = {}
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                pmc = json.load(f)
+        except Exception:
+            pmc = {}
     if dom_n > 0:
         per_launch_s = dom_ms / dom_n / 1e3
         launches_per_step = dom_n / args.steps
-        alg_bytes_launch = n_hap * sites_per_step / launches_per_step       # 1 byte per haplotype allele call
-        achieved = alg_bytes_launch / per_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f).get(args.workload, {})
-                # rocprof kernel names of the family (the v2 pack kernel is k_pack2, the ABBA kernel k_abba_q)
-                alias = {_lib.K_PACK: ["k_pack2", "k_pack"], _lib.K_PAIRWISE: ["k_pairC", "k_pairwise"],
-                         _lib.K_PAIRD: ["k_pairD"], _lib.K_SITESTATS: ["k_abba_q", "k_popfreq"]}
-                traffic = next((tj[n] for n in alias.get(dom_id, []) if n in tj), None)
-            except Exception:
-                traffic = None
-        roofline = {"kernel": _lib.KERNEL_NAMES[dom_id], "bound": "hbm", "achieved": round(achieved, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "avg_launch_ms": round(dom_ms / dom_n, 4), "launches": int(dom_n),
-                    "algorithmic_bytes_per_launch": int(alg_bytes_launch)}
+        kname = rocprof_name.get(dom_id, _lib.KERNEL_NAMES[dom_id])
+        alg_bytes_launch = n_hap * sites_per_step / launches_per_step       # 1 byte per haplotype allele call (SURVEY.md 8d)
+        if dom_id in (_lib.K_PAIRWISE, _lib.K_PAIRD) and not os.environ.get("PG_PAIR_V1"):
+            # VALU-bound pair kernel: wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU), live launch time
+            insts = pmc.get("_valu", {}).get(args.workload, {}).get(kname)
+            peak_meas = pmc.get("_valu_peak_measured", {}).get(kname)
+            roofline = {"kernel": kname, "bound": "valu", "unit": "wave-instr/s", "peak": VALU_PEAK_GUIDE,
+                        "peak_source": "256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)",
+                        "achieved": (insts / per_launch_s) if insts else None,
+                        "frac": round(insts / per_launch_s / VALU_PEAK_GUIDE, 5) if insts else None,
+                        "peak_measured_mix": peak_meas,
+                        "frac_of_measured_mix": round(insts / per_launch_s / peak_meas, 5) if insts and peak_meas else None,
+                        "valu_wave_instructions_per_launch": insts, "traffic": pmc.get(args.workload, {}).get(kname),
+                        "hbm_equivalent": {"achieved_GBps": round(alg_bytes_launch / per_launch_s / 1e9, 2),
+                                           "frac_of_8TBps": round(alg_bytes_launch / per_launch_s / 1e9 / HBM_PEAK_GBS, 5),
+                                           "note": "algorithmic bytes / launch time; this kernel is not HBM-bound"},
+                        "avg_launch_ms": round(dom_ms / dom_n, 4), "launches": int(dom_n)}
+        else:
+            achieved = alg_bytes_launch / per_launch_s / 1e9
+            roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "traffic": pmc.get(args.workload, {}).get(kname), "avg_launch_ms": round(dom_ms / dom_n, 4),
+                        "launches": int(dom_n), "algorithmic_bytes_per_launch": int(alg_bytes_launch)}
         if wl["tool"] == "popgen":
             pair_ms = sum(kt[_lib.KERNEL_NAMES[k]][0] for k in (_lib.K_PAIRWISE, _lib.K_PAIRD)) / n_warm
             pair_sites = n_hap * (n_hap - 1) / 2 * sites_per_step
@@ -194,60 +342,23 @@ def main():
                                              "polymorphic-site compaction and per-individual called counts do less work than that"}
     if gather_ms is not None:
         extra["result_allgather_ms_once_untimed"] = round(gather_ms, 3)
-    extra["kernel_ms_per_step"] = {k: round(v[0] / n_warm, 4) for k, v in kt.items() if v[1] > 0}
+        extra["per_rank_ms_per_step"] = {"min": round(1e3 * float(per_rank[:, 0].min()) / args.steps, 4),
+                                         "max": round(1e3 * float(per_rank[:, 0].max()) / args.steps, 4)}
+        extra["comm_ranks"] = int(eng._comm_ranks())
+    extra["kernel_ms_per_step"] = {rocprof_name.get(kid, k): round(kt[k][0] / n_warm, 4)
+                                   for kid, k in _lib.KERNEL_NAMES.items() if kt[k][1] > 0}
     extra["kernel_ms_per_step_source"] = ("last warm-up step (all families bracketed by events); roofline.avg_launch_ms is from the timed region"
                                            if args.warmup >= 1 else "timed region")
+    extra["whole_step_hbm_frac"] = round(n_hap * sites_per_step / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)
 
-    # ---- CPU baseline: the oracle's faithful port of the reference algorithm, bounded sample -------------
+    # ---- CPU baseline: the oracle's restatement of the reference's whole path on all host cores, bounded sample -------------
     cpu = None
     if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:
-        from oracle import popgen_oracle as orc
-        st = stats_for_check()
-        # at least --cpu-windows windows, then more until about 10 s of CPU work have been sampled (at most 8 windows)
-        nw_min, nw_max = max(1, min(args.cpu_windows, n_win)), max(1, min(max(args.cpu_windows, 8), n_win))
-        t_cpu, t_wall = 0.0, 0.0
-        ok = True
-        nw = 0
-        for w in range(nw_max):
-            if w >= nw_min and t_wall >= 10.0:
-                break
-            nw += 1
-            codes = eng.download(int(lo[w]), int(hi[w] - lo[w]))
-            scale = 1.0
-            if wl["tool"] == "distmat" and n_hap > CPU_DISTMAT_HAPS:
-                # the pair loop is quadratic in haplotypes: time the first CPU_DISTMAT_HAPS of them and scale by the pair count
-                scale = (n_hap * (n_hap - 1) / 2) / (CPU_DISTMAT_HAPS * (CPU_DISTMAT_HAPS - 1) / 2)
-                aln, _ = orc.aln_from_codes(codes[:, :CPU_DISTMAT_HAPS], lay.hap_names[:CPU_DISTMAT_HAPS],
-                                            lay.hap_sample_name[:CPU_DISTMAT_HAPS], lay.hap_group[:CPU_DISTMAT_HAPS])
-            else:
-                aln, _ = orc.aln_from_codes(codes, lay.hap_names, lay.hap_sample_name, lay.hap_group)
-            c0 = time.perf_counter()
-            if wl["tool"] == "popgen":
-                D, C = orc.pair_counts_loop(aln)                     # genomics.py:903-916 + 1042-1047, pair by pair
-                so, _ = orc.group_dist_stats(aln, D, C, True, wl["min_sites"], 0.01)
-            elif wl["tool"] == "popfreq":
-                so = orc.group_freq_stats(aln)
-            elif wl["tool"] == "distmat":
-                D, C = orc.pair_counts_loop(aln)
-                so = {}
-            else:
-                so = orc.abbababa(aln, "pop0", "pop1", "pop2", "pop3", 0.01)
-            dt = time.perf_counter() - c0
-            t_wall += dt
-            t_cpu += dt * scale
-            for k, v in so.items():
-                if k == "sitesUsed":
-                    ok = ok and int(st[k][w]) == int(v)
-                    continue
-                g = st[k][w]
-                ok = ok and (abs(g - v) <= 1e-6 * max(1.0, abs(v)) or (g != g and v != v))
-        cpu = {"value": round(nw / t_cpu, 5), "unit": "windows/s", "cores": 1, "kind": "port",
-               "sample": "first %d windows (%d sites x %d haplotypes each) of the workload, numeric core only "
-                         "(no text parsing / alignment build, which dominate the real reference)%s" % (
-                             nw, wl["wind"], n_hap,
-                             "; pair loop timed on the first %d haplotypes and scaled by the pair count" % CPU_DISTMAT_HAPS
-                             if wl["tool"] == "distmat" and n_hap > CPU_DISTMAT_HAPS else ""),
-               "seconds": round(t_cpu, 2), "gpu_matches_oracle_on_sample": bool(ok)}
+        stc = stats_for_check()
+        if wl["tool"] == "distmat":
+            cpu = cpu_baseline_distmat(eng, lay, wl, lo, hi, stc)
+        else:
+            cpu = cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, stc, args.cpu_workers)
 
     if world.rank == 0:
         total_windows = n_win * world.size * args.steps
@@ -258,8 +369,9 @@ def main():
             "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 bit-planes / int32 counts / f64 statistics", "data": "synthetic",
-            "config": {"workload": wl["desc"], "name": args.workload, "windows_per_gpu": n_win,
-                       "sites_per_gpu": sites_per_step, "haplotypes": n_hap, "parallelism": "windows sharded, dp%d" % world.size},
+            "config": {"workload": wl["desc"], "name": args.workload, "tier": "T0 (inputs resident in HBM; SURVEY.md 8d)",
+                       "windows_per_gpu": n_win, "sites_per_gpu": sites_per_step, "haplotypes": n_hap,
+                       "parallelism": "windows sharded, dp%d" % world.size},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)

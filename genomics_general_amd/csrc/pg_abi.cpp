@@ -46,7 +46,7 @@ extern "C" int pg_ctx_create(pg_ctx **out, int device) {
     HIPCHK(hipSetDevice(device));
     pg_ctx *c = new pg_ctx();
     c->device = device;
-    if (getenv("PG_SCRATCH_GIB")) c->scratch_limit = (int64_t)atol(getenv("PG_SCRATCH_GIB")) << 30;    // default 16 GiB
+    if (getenv("PG_SCRATCH_GIB")) c->scratch_limit = (int64_t)atol(getenv("PG_SCRATCH_GIB")) << 30;    // default 48 GiB
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -442,38 +442,10 @@ static int stage_windows(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w0
     return PG_OK;
 }
 
-// Upload [lo | hi | goff(n+1) | vgoff(n+1)] of windows [w0,w1) for the v2 pipeline.
-static int stage_windows2(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w0, int w1, int64_t *total_groups,
-                          int64_t *total_vg, int *max_groups) {
-    const int n = w1 - w0;
-    std::vector<int64_t> h(4 * (size_t)n + 2);
-    int64_t ga = 0, va = 0;
-    int mg = 0;
-    for (int k = 0; k < n; ++k) {
-        h[k] = lo[w0 + k];
-        h[n + k] = hi[w0 + k];
-        const int64_t words = (hi[w0 + k] - lo[w0 + k] + 31) / 32;
-        h[2 * (size_t)n + k] = ga;
-        h[3 * (size_t)n + 1 + k] = va;
-        const int64_t groups = (words + PG_GROUP - 1) / PG_GROUP;
-        ga += groups;
-        va += (words + 3) / 4;
-        mg = std::max<int64_t>(mg, groups);
-    }
-    h[3 * (size_t)n] = ga;
-    h[4 * (size_t)n + 1] = va;
-    *total_groups = ga;
-    *total_vg = va;
-    *max_groups = mg;
-    int rc = c->win.upload(h.data(), h.size(), c->stream);
-    if (rc != PG_OK) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return PG_OK;
-}
-
 static bool use_v2(const pg_ctx *c) { (void)c; return getenv("PG_PAIR_V1") == nullptr; }
 
-// v1 path (more than 1024 haplotype slots): pack + k_pairwise, one batch after the other on ctx->stream.
+// v1 path (first-generation 7-op kernel, kept as an A/B reference: PG_PAIR_V1=1): pack + k_pairwise, one batch after the
+// other on ctx->stream.
 template <class F>
 static int pairwise_batches_v1(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, F consume) {
     const int N = c->n_hap, NP = c->NP;
@@ -529,8 +501,9 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     c->cN = n_units;
     c->cshift = dip ? 1 : 0;
     const int64_t mat_bytes = 4ll * N * N + 4ll * n_units * n_units;
-    // scratch bytes per 32-site input word of one slot: called plane + worst-case (four alleles at every site) virtual-site planes
-    const int64_t word_bytes = (int64_t)NP * 4 * PG_XV_PLANES * (PG_XV_CAP / PG_GROUP) + (int64_t)NPv * 4;
+    // scratch bytes per 32-site input word of one slot: called plane + reserved virtual-site planes (capg words per group)
+    const int capg = c->xv_capg;
+    const int64_t word_bytes = ((int64_t)NP * 4 * PG_XV_PLANES * capg + PG_GROUP - 1) / PG_GROUP + (int64_t)NPv * 4;
     // sub-batch size: at most half the scratch budget per slot, and at least ~8 sub-batches per call so the two
     // streams have something to overlap (but not so small that a sub-batch cannot fill the GPU)
     int64_t total_words_all = 0;
@@ -539,7 +512,8 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     // kernels is slower (measured: C2 1.44 vs 0.99 ms).  A job that needs several batches anyway is cut into at least 8, so
     // that all but the first pack kernel and all but the last pair kernels run beside each other on the two streams
     // (measured on the north-star shape: 13.3 ms with 8 sub-batches vs 14.0 ms with the 3 that the scratch limit forces).
-    const bool multi = total_words_all * word_bytes + (int64_t)n_win * mat_bytes > c->scratch_limit / 2;
+    // (one batch uses one slot: it may take the whole scratch budget; sub-batches share it between the two slots)
+    const bool multi = total_words_all * word_bytes + (int64_t)n_win * mat_bytes > c->scratch_limit;
     const bool overlap = multi || getenv("PG_OVERLAP") != nullptr;
     int64_t target_words = overlap ? std::max<int64_t>(total_words_all / 8, 32768) : total_words_all;
     for (int k = 0; k < 2; ++k) {
@@ -554,7 +528,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         while (w1 < n_win) {
             int64_t wlen = ((hi[w1] - lo[w1] + 31) / 32 + PG_GROUP - 1) / PG_GROUP * PG_GROUP;
             int64_t nbytes = (words + wlen) * word_bytes + (int64_t)(w1 - w0 + 1) * mat_bytes;
-            if (w1 > w0 && (nbytes > c->scratch_limit / 2 || words + wlen > target_words)) break;
+            if (w1 > w0 && (nbytes > (overlap ? c->scratch_limit / 2 : c->scratch_limit) || words + wlen > target_words)) break;
             words += wlen;
             ++w1;
             if (w1 - w0 >= 65535) break;                      // gridDim.y limit
@@ -603,7 +577,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         // + 2 word groups: k_pairC's look-ahead loads read one group past a wave's range
         if ((rc = sl.Vp.ensure((size_t)(std::max<int64_t>(va, 1) + 2) * NPv * 4)) != PG_OK) return rc;
         // + 2 words: k_pairD's look-ahead loads read two words past a wave's range
-        if ((rc = sl.XV.ensure(((size_t)std::max<int64_t>(ga, 1) * PG_XV_CAP + 2) * PG_XV_PLANES * NP)) != PG_OK) return rc;
+        if ((rc = sl.XV.ensure(((size_t)std::max<int64_t>(ga, 1) * capg + 2) * PG_XV_PLANES * NP)) != PG_OK) return rc;
         if ((rc = c->Cmat.ensure((size_t)nb * n_units * n_units)) != PG_OK) return rc;
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
         hipEvent_t e0, e1;
@@ -616,7 +590,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         }
         if (NP > 1024 && (rc = sl.pres.ensure((size_t)std::max<int64_t>(ga, 1) * PG_GROUP * 4)) != PG_OK) return rc;
         pg_launch_pack2(ps, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, ga, sl.Vp.p, NPv, sl.XV.p, NP,
-                        d_nw, dip ? 1 : 0, c->flag.p, sl.pres.p);
+                        d_nw, dip ? 1 : 0, c->flag.p, sl.pres.p, capg);
         if (time_pack) {
             HIPCHK(hipEventRecord(e1, ps));
             c->events[PG_K_PACK].push_back(std::make_pair(e0, e1));
@@ -632,7 +606,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         // (running k_pairD beside k_pairC on a third stream was measured: +3 % throughput, but overlapping kernels make the
         // per-kernel timings ambiguous; kept sequential)
         if ((rc = pg_time_begin(c, PG_K_PAIRD, &e0, &e1)) != PG_OK) return rc;
-        pg_launch_pairD(c->stream, sl.XV.p, d_nw, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, ga / nb, c->Dmat.p);
+        pg_launch_pairD(c->stream, sl.XV.p, d_nw, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, ga / nb, c->Dmat.p, capg);
         if ((rc = pg_time_end(c, PG_K_PAIRD, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
         if ((rc = consume(w0, nb)) != PG_OK) return rc;
@@ -677,21 +651,40 @@ static int flag_ready(pg_ctx *c) {
 }
 
 // Diploid fast path first (called counts per individual); if any window turns out to hold an individual whose two
-// haplotypes differ in calledness (e.g. phased `A|N`), everything is recomputed with per-haplotype called counts.
+// haplotypes differ in calledness (e.g. phased `A|N`), everything is recomputed with per-haplotype called counts.  Likewise a
+// window with more virtual sites than the default reservation (PG_XV_CAP_DEFAULT words per group) makes the call start over
+// with the worst-case reservation.
+static int note_flags(pg_ctx *c, int flag, bool *dip, bool *again) {
+    *again = false;
+    if (flag & PG_FLAG_XV_OVERFLOW) {
+        if (c->xv_capg >= PG_XV_CAP) return pg_fail(PG_ERR_STATE, "XV overflow with the worst-case reservation");
+        c->xv_capg = PG_XV_CAP;
+        for (int k = 0; k < 2; ++k) c->slot[k].XV.release();
+        *again = true;
+    }
+    if (*dip && (flag & PG_FLAG_MISMATCH)) {
+        *dip = false;
+        *again = true;
+    }
+    return PG_OK;
+}
+
 template <class F>
 static int pairwise_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, F consume) {
-    const bool dip = use_v2(c) && c->all_diploid && getenv("PG_NO_DIP") == nullptr;
+    bool dip = use_v2(c) && c->all_diploid && getenv("PG_NO_DIP") == nullptr;
     int rc;
     if ((rc = flag_ready(c)) != PG_OK) return rc;
-    if (dip) {
-        if ((rc = pairwise_batches(c, lo, hi, n_win, true, consume)) != PG_OK) return rc;
+    for (;;) {
+        if ((rc = pairwise_batches(c, lo, hi, n_win, dip, consume)) != PG_OK) return rc;
+        if (!use_v2(c)) return PG_OK;
         int32_t flag = 0;
         HIPCHK(hipMemcpyAsync(&flag, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemsetAsync(c->flag.p, 0, 4, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (!flag) return PG_OK;
+        bool again;
+        if ((rc = note_flags(c, flag, &dip, &again)) != PG_OK) return rc;
+        if (!again) return PG_OK;
     }
-    return pairwise_batches(c, lo, hi, n_win, false, consume);
 }
 
 extern "C" int pg_pairwise(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int32_t *D_out, int32_t *C_out) {
@@ -769,26 +762,22 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
         HIPCHK(hipGetLastError());
         return PG_OK;
     };
-    const bool dip = use_v2(c) && c->all_diploid && getenv("PG_NO_DIP") == nullptr;
+    bool dip = use_v2(c) && c->all_diploid && getenv("PG_NO_DIP") == nullptr;
     const size_t n_out = (size_t)n_win * ncols;
     if ((rc = c->out_pin.ensure(n_out + 1)) != PG_OK) return rc;
-    // one device-to-host copy (into pinned memory) and one synchronisation per pass: the diploid-shortcut verdict travels
-    // in the slot after the table (k_flag_export also re-arms the flag)
-    auto fetch = [&]() -> int {
+    // one device-to-host copy (into pinned memory) and one synchronisation per pass: the flag word of the pack kernels (diploid
+    // shortcut verdict, XV overflow) travels in the slot after the table (k_flag_export also re-arms the flag)
+    for (;;) {
+        if ((rc = pairwise_batches(c, lo, hi, n_win, dip, consume)) != PG_OK) return rc;
         pg_launch_flag_export(c->stream, c->flag.p, c->stats.p + n_out);
         HIPCHK(hipMemcpyAsync(c->out_pin.p, c->stats.p, (n_out + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-        int rw = stream_wait(c);
-        if (rw != PG_OK) return rw;
+        if ((rc = stream_wait(c)) != PG_OK) return rc;
+        bool again;
+        if ((rc = note_flags(c, use_v2(c) ? (int)c->out_pin.p[n_out] : 0, &dip, &again)) != PG_OK) return rc;
+        if (again) continue;
         memcpy(stats_out, c->out_pin.p, n_out * 8);
         return PG_OK;
-    };
-    if (dip) {
-        if ((rc = pairwise_batches(c, lo, hi, n_win, true, consume)) != PG_OK) return rc;
-        if ((rc = fetch()) != PG_OK) return rc;
-        if (c->out_pin.p[n_out] == 0.0) return PG_OK;
     }
-    if ((rc = pairwise_batches(c, lo, hi, n_win, false, consume)) != PG_OK) return rc;
-    return fetch();
 }
 
 static int indpair_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites, int mean_mode,

@@ -99,7 +99,8 @@ struct pg_ctx {
         hipEvent_t packed = nullptr, consumed = nullptr;
         bool used = false;
     } slot[2];
-    DevBuf<int32_t> flag;        // v2: [0] = some window had haplotypes of one individual with different calledness
+    DevBuf<int32_t> flag;        // v2: PG_FLAG_MISMATCH | PG_FLAG_XV_OVERFLOW, raised by the pack kernels
+    int xv_capg = PG_XV_CAP_DEFAULT;   // XV words reserved per compaction group (PG_XV_CAP after an overflow)
     DevBuf<int32_t> Cfull, Dfull;  // pg_pairwise staging
     // how the matrices of the last batch are laid out (set by pairwise_batches)
     int cN = 0, cshift = 0;
@@ -107,7 +108,7 @@ struct pg_ctx {
     DevBuf<int8_t> gt;
     int64_t cap_sites = 0;
     // scratch
-    int64_t scratch_limit = 16ll << 30;
+    int64_t scratch_limit = 48ll << 30;
     DevBuf<uint32_t> planes;
     DevBuf<int32_t> Cmat, Dmat;
     DevBuf<int64_t> win;        // [lo | hi | woff]

@@ -19,6 +19,12 @@ struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,r
 #define PG_GROUP 64
 #endif             // input words (of 32 sites) per compaction group of k_pack2
 #define PG_XV_CAP (3 * PG_GROUP)   // worst-case words of virtual sites per group (every site with four alleles)
+// Words reserved per group by default: enough whenever a window has no more virtual sites than sites (a biallelic site is
+// one virtual site; + 1 for the group's partial last word).  k_pack2 / k_pack3 raise bit 1 of the flag word when a window needs
+// more; the host then repeats the call with PG_XV_CAP (and keeps that reservation for the rest of the context's life).
+#define PG_XV_CAP_DEFAULT (PG_GROUP + 1)
+#define PG_FLAG_MISMATCH 1      // some individual's two haplotypes differ in calledness: the diploid shortcut does not apply
+#define PG_FLAG_XV_OVERFLOW 2   // a window produced more XV words than reserved
 
 struct PgTask2 {                // one block of k_pairC (8 rows) / k_pairD (16 rows): circulant task, see pair_store_circ
     int32_t row0, nsub, col0, lower;   // rows row0.., columns col0, col0+1, ... (mod n), nsub = number of valid columns; lower = 2
@@ -67,13 +73,13 @@ void pg_launch_hap_called(hipStream_t st, const int8_t *gt, int S, int n_hap, co
 // ---- v2 pairwise pipeline (pg_pair2.hip) ---------------------------------------------------------------
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                      const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, int64_t total_groups, uint32_t *Vp,
-                     int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres);
+                     int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres, int capg);
 void pg_launch_expand(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                       int32_t *Cfull, int32_t *Dfull);
 void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, const PgTask2 *tasks, int n_tasks,
                      int NPv, int n_units, int diag, int64_t avg_wq, int32_t *Cmat);
 void pg_launch_pairD(hipStream_t st, const uint32_t *XY, const int32_t *nw, const int64_t *goff, int n_win,
-                     const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat);
+                     const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat, int capg);
 
 void pg_launch_flag_export(hipStream_t st, int32_t *flag, double *dst);
 void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts, int n_win, const int32_t *pop_start,

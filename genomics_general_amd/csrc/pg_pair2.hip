@@ -256,7 +256,7 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                                                const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
                                                const int64_t *__restrict__ vgoff, uint32_t *__restrict__ Vp, int NPv,
                                                uint32_t *__restrict__ XV, int NP, int32_t *__restrict__ nw,
-                                               int32_t *__restrict__ mismatch, const uint32_t *__restrict__ pres) {
+                                               int32_t *__restrict__ mismatch, const uint32_t *__restrict__ pres, int capg) {
     constexpr int NWAVE = TPB / 64;
     __shared__ uint32_t sh_pres[2][NWAVE][4];
     __shared__ uint4 sh_gp[PRES ? 1 : PG_GROUP];          // presence nibbles of the group's words (PRES: read from `pres`)
@@ -280,7 +280,8 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
     uint32_t vlist = (uint32_t)nrows;        // lane i = list entry i; "nrows" is one row past the descriptor: reads as zero
     int cnt = 0, nflush = 0, parity = 0;
     uint32_t bad = 0u;
-    uint32_t *xv_base = XV + (size_t)goff[b] * PG_XV_CAP * PG_XV_PLANES * (size_t)NP;
+    uint32_t *xv_base = XV + (size_t)goff[b] * capg * PG_XV_PLANES * (size_t)NP;
+    const int capw = (int)(goff[b + 1] - goff[b]) * capg;          // words reserved for this window
     const uint32_t *pres_g = pres + (size_t)(goff[b] + g) * PG_GROUP * 4u;       // PRES only
     const int64_t vg_base = vgoff[b] + (int64_t)(w_begin >> 2);
     // PRES: the group's words start at gbase (k_word_scan); otherwise every flush takes the window's next free word
@@ -323,7 +324,9 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                                 (uint32_t)__builtin_amdgcn_ballot_w64(A == 4u)};
         const uint32_t SE[2] = {(uint32_t)__builtin_amdgcn_ballot_w64((E & 1u) != 0u),
                                 (uint32_t)__builtin_amdgcn_ballot_w64((E & 2u) != 0u)};
-        if (has_data) {
+        if (slot >= capw) {                  // more virtual sites than reserved: the host redoes the batch with the worst-case reservation
+            if (threadIdx.x == 0) atomicOr(mismatch, 2);
+        } else if (has_data) {
             uint32_t x[PG_XV_PLANES][4];
             poly_word(rsrc, h0, S, vlist, SA, SE, x);
             uint32_t *o = xv_base + (size_t)slot * PG_XV_PLANES * (size_t)NP + 2 * h0;
@@ -423,36 +426,262 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
     if (DIP && bad) atomicOr(mismatch, 1);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_pack3: k_pack2 without its second visit of the polymorphic rows.  Phase A is k_pack2's; but the byte-transposed dwords
+// r[q][k] (8 sites x one-hot nibble of haplotype h0+k) stay in registers until the block-wide polymorphic mask of the word is
+// known, and the nibbles of the polymorphic sites are then copied, with two VALU ops per haplotype (v_bfe_u32 / v_lshl_or_b32,
+// bit positions in SGPRs), into `cur[k]` = the next 8 list entries of haplotype h0+k.  Every 8 entries the dword is turned
+// into 8 bits of the two output planes with nibble masks kept on the scalar unit (MA: the allele each entry tests, ME: the
+// alleles it excludes; both derived from the site's presence nibble when the entry is appended):
+//     x = nibble & MA != 0,   v = nibble & ~ME != 0,   "nibble != 0" = bit 3 of nibble + 7 (nibbles are 0 or one-hot).
+// Every 32 entries the two planes are stored as one dense word of XV.  No list, no LDS, no second fetch: the kernel reads
+// every row exactly once (k_pack2 fetched the ~11 % polymorphic rows of typical data a second time, PMC FETCH_SIZE).
+// The entries of a word are appended q-major (sites q*8+j share r[q]): the bit order inside an XV word is arbitrary as
+// long as it is the same for every haplotype and both planes.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void word_called_presence_keep(const uint32_t d[32], uint32_t v[4], uint32_t pa[4], uint32_t R[4][4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t *e = d + 8 * q;
+        btrans4(e[0] | (e[1] << 4), e[2] | (e[3] << 4), e[4] | (e[5] << 4), e[6] | (e[7] << 4), R[q]);
+        const uint32_t o = R[q][0] | R[q][1] | R[q][2] | R[q][3];          // 8 sites x presence nibble
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const uint32_t piece = (a >= q ? (o >> (a - q)) : (o << (q - a))) & (0x11111111u << q);
+            pa[a] = q ? (pa[a] | piece) : piece;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // called = nibble != 0 = bit 3 of (nibble + 7); moved to bit q of the nibble
+            const uint32_t t = R[q][k] + 0x77777777u;
+            const uint32_t c = (q == 3 ? t : (t >> (3 - q))) & (0x11111111u << q);
+            v[k] = q ? (v[k] | c) : c;
+        }
+    }
+}
+
+template <int TPB, int DIP>
+__global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
+                                               const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
+                                               const int64_t *__restrict__ vgoff, uint32_t *__restrict__ Vp, int NPv,
+                                               uint32_t *__restrict__ XV, int NP, int32_t *__restrict__ nw,
+                                               int32_t *__restrict__ mismatch, int capg) {
+    constexpr int NWAVE = TPB / 64;
+    __shared__ uint32_t sh_pres[2][NWAVE][4];
+    __shared__ int sh_slot;
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int64_t lo = win_lo[b], hi = win_hi[b];
+    const int W = (int)((hi - lo + 31) >> 5);
+    const int w_begin = g * PG_GROUP;
+    if (w_begin >= W) return;
+    const int w_end = (w_begin + PG_GROUP < W) ? w_begin + PG_GROUP : W;
+    const int t = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int h0 = 4 * t;
+    const bool has_data = h0 < S;
+    const int u0 = DIP ? 2 * t : h0;
+    const int64_t first = lo + 32ll * w_begin;
+    const int nrows = (int)((hi - first) < 32ll * PG_GROUP ? (hi - first) : 32ll * PG_GROUP);
+    const __amdgpu_buffer_rsrc_t rsrc = group_rsrc(gt, S, first, nrows);
+    int cnt = 0, parity = 0;                 // cnt: entries of the pending output word (uniform, 0..31)
+    uint32_t MA = 0u, ME = 0u;               // nibble masks of the pending 8-entry dword (uniform)
+    uint32_t cur[4] = {0u, 0u, 0u, 0u}, xo[4] = {0u, 0u, 0u, 0u}, vo[4] = {0u, 0u, 0u, 0u};
+    uint32_t bad = 0u;
+    uint32_t *xv_base = XV + (size_t)goff[b] * capg * PG_XV_PLANES * (size_t)NP;
+    const int capw = (int)(goff[b + 1] - goff[b]) * capg;          // words reserved for this window
+    const int64_t vg_base = vgoff[b] + (int64_t)(w_begin >> 2);
+    auto store_word = [&]() {                // the pending planes become one dense word of XV (the window's next free word)
+        int slot;
+        if (NWAVE == 1) {
+            int s0 = 0;
+            if (lane == 0) s0 = atomicAdd(&nw[b], 1);
+            slot = __builtin_amdgcn_readfirstlane(s0);
+        } else {
+            if (threadIdx.x == 0) sh_slot = atomicAdd(&nw[b], 1);
+            __syncthreads();
+            slot = __builtin_amdgcn_readfirstlane(sh_slot);
+            __syncthreads();
+        }
+        if (slot >= capw) {                  // more virtual sites than reserved: the host redoes the batch with the worst-case reservation
+            if (threadIdx.x == 0) atomicOr(mismatch, 2);
+        } else if (has_data) {
+            uint32_t *o = xv_base + (size_t)slot * PG_XV_PLANES * (size_t)NP + 2 * h0;
+            store16(o, xo[0], vo[0], xo[1], vo[1]);
+            store16(o + 4, xo[2], vo[2], xo[3], vo[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xo[k] = vo[k] = 0u;
+    };
+    auto finish_dword = [&](int qd) {        // 8 entries (nibbles of cur[k]) -> bits 4j+qd of the two planes
+        const uint32_t nME = ~ME;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t cx = (((cur[k] & MA) + 0x77777777u) >> 3) & 0x11111111u;
+            const uint32_t cv = (((cur[k] & nME) + 0x77777777u) >> 3) & 0x11111111u;
+            xo[k] |= cx << qd;
+            vo[k] |= cv << qd;
+            cur[k] = 0u;
+        }
+        MA = 0u;
+        ME = 0u;
+    };
+    auto append = [&](const uint32_t (&Rq)[4], int j, uint32_t A, uint32_t E) {       // j, A, E uniform
+        const int sh = 4 * (cnt & 7);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] |= __builtin_amdgcn_ubfe(Rq[k], 4 * j, 4) << sh;
+        MA |= A << sh;
+        ME |= E << sh;
+        ++cnt;
+        if ((cnt & 7) == 0) {
+            finish_dword((cnt >> 3) - 1);
+            if (cnt == 32) {
+                store_word();
+                cnt = 0;
+            }
+        }
+    };
+    uint32_t dn[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) dn[s] = 0u;
+    const RowOff ro = make_row_off(S);
+    if (has_data) word_load(rsrc, h0, S, 0, ro, dn);
+    for (int wq = 0; 4 * wq + w_begin < w_end; ++wq) {
+        uint32_t vhold[4][4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int w = w_begin + 4 * wq + k4;
+            uint32_t v[4] = {0u, 0u, 0u, 0u}, pa[4] = {0u, 0u, 0u, 0u};
+            uint32_t R[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) R[q][k] = 0u;
+            const bool live = w < w_end;            // block-uniform
+            uint32_t d[32];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) d[s] = dn[s];
+            if (has_data) word_load(rsrc, h0, S, (w + 1 - w_begin) * 32, ro, dn);
+            if (live && has_data) word_called_presence_keep(d, v, pa, R);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vhold[k][k4] = v[k];
+            if (DIP) bad |= (v[0] ^ v[1]) | (v[2] ^ v[3]);
+            if (live) {
+                uint32_t pr[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) pr[a] = pa[a];
+                wave_or4(pr);
+                if (NWAVE > 1) {
+                    if (lane == 0) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) sh_pres[parity][threadIdx.x >> 6][a] = pr[a];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        uint32_t x = 0u;
+#pragma unroll
+                        for (int wv = 0; wv < NWAVE; ++wv) x |= sh_pres[parity][wv][a];
+                        pr[a] = __builtin_amdgcn_readfirstlane(x);
+                    }
+                    parity ^= 1;
+                }
+                // presence nibble of the site at mask bit `bit`
+                auto nib = [&](int bit) -> uint32_t {
+                    return ((pr[0] >> bit) & 1u) | (((pr[1] >> bit) & 1u) << 1) | (((pr[2] >> bit) & 1u) << 2) |
+                           (((pr[3] >> bit) & 1u) << 3);
+                };
+                const uint32_t m0 = poly_mask(pr);
+                if (m0) {
+                    // virtual site 0 of every polymorphic site: tests the lowest allele present, excludes nothing
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t mq = m0 & (0x11111111u << q);
+                        while (mq) {
+                            const int bit = __builtin_ctz(mq);
+                            mq &= mq - 1u;
+                            const uint32_t P = nib(bit);
+                            append(R[q], bit >> 2, P & (0u - P), 0u);
+                        }
+                    }
+                    // rare: the second / third virtual site of the sites with three / four alleles
+                    const uint32_t m3 = tri_mask(pr);
+                    if (m3) {
+#pragma unroll 1
+                        for (int pass = 1; pass < 3; ++pass) {
+                            uint32_t m = pass == 1 ? m3 : quad_mask(pr);
+                            while (m) {
+                                const int bit = __builtin_ctz(m);
+                                m &= m - 1u;
+                                const uint32_t P = nib(bit);
+                                const uint32_t A0 = P & (0u - P), P1 = P ^ A0, A1 = P1 & (0u - P1), P2 = P1 ^ A1, A2 = P2 & (0u - P2);
+                                const uint32_t A = pass == 1 ? A1 : A2;
+                                const int q = bit & 3;                        // uniform
+                                if (q == 0) append(R[0], bit >> 2, A, (A - 1u) & P);
+                                else if (q == 1) append(R[1], bit >> 2, A, (A - 1u) & P);
+                                else if (q == 2) append(R[2], bit >> 2, A, (A - 1u) & P);
+                                else append(R[3], bit >> 2, A, (A - 1u) & P);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (has_data) {
+            uint32_t *o = Vp + ((size_t)(vg_base + wq) * NPv + u0) * 4u;
+            if (DIP) {
+                store16(o, vhold[0][0], vhold[0][1], vhold[0][2], vhold[0][3]);
+                store16(o + 4, vhold[2][0], vhold[2][1], vhold[2][2], vhold[2][3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store16(o + 4 * k, vhold[k][0], vhold[k][1], vhold[k][2], vhold[k][3]);
+            }
+        }
+    }
+    if (cnt & 7) finish_dword(cnt >> 3);
+    if (cnt) store_word();
+    if (DIP && bad) atomicOr(mismatch, 1);
+}
+
 template <int DIP>
 static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *gt, int S, const int64_t *win_lo,
                          const int64_t *win_hi, const int64_t *goff, const int64_t *vgoff, uint32_t *Vp, int NPv, uint32_t *XV,
-                         int NP, int32_t *nw, int32_t *mismatch, uint32_t *pres) {
+                         int NP, int32_t *nw, int32_t *mismatch, uint32_t *pres, int capg) {
+    const bool pack2 = getenv("PG_PACK2") != nullptr;               // A/B: the two-visit kernel
+    if (!pack2 && threads <= 256) {
+        if (threads <= 64)
+            hipLaunchKernelGGL((k_pack3<64, DIP>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg);
+        else if (threads <= 128)
+            hipLaunchKernelGGL((k_pack3<128, DIP>), grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg);
+        else
+            hipLaunchKernelGGL((k_pack3<256, DIP>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg);
+        return;
+    }
     if (threads <= 64)
-        hipLaunchKernelGGL((k_pack2<64, DIP, 0>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
+        hipLaunchKernelGGL((k_pack2<64, DIP, 0>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
     else if (threads <= 128)
-        hipLaunchKernelGGL((k_pack2<128, DIP, 0>), grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
+        hipLaunchKernelGGL((k_pack2<128, DIP, 0>), grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
     else if (threads <= 256)
-        hipLaunchKernelGGL((k_pack2<256, DIP, 0>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
+        hipLaunchKernelGGL((k_pack2<256, DIP, 0>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
     else {
         grid.z = (threads + 255) / 256;
         hipLaunchKernelGGL(k_presence, grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, pres);
         hipLaunchKernelGGL(k_word_scan, dim3(grid.y), dim3(256), 0, st, win_lo, win_hi, goff, pres, nw);
-        hipLaunchKernelGGL((k_pack2<256, DIP, 1>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
+        hipLaunchKernelGGL((k_pack2<256, DIP, 1>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
     }
 }
 
 // pres: scratch of total_groups * PG_GROUP * 4 words, only used (and zeroed here) when there are more than 1024 slots
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                      const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, int64_t total_groups, uint32_t *Vp,
-                     int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres) {
+                     int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres, int capg) {
     // nw[0 .. n_win): the caller hands over zeroed per-window word counters (atomic allocation; k_pairD reads them even when
     // every window of the batch is empty); nw[n_win ..): one slot per group in the > 1024-slot mode (k_word_scan)
     if (n_win <= 0 || max_groups <= 0) return;
     const int threads = NP / 4;
     if (threads > 256) (void)hipMemsetAsync(pres, 0, (size_t)total_groups * PG_GROUP * 16u, st);
     dim3 grid(max_groups, n_win);
-    if (dip) launch_pack2<1>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
-    else launch_pack2<0>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres);
+    if (dip) launch_pack2<1>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
+    else launch_pack2<0>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -650,12 +879,15 @@ __device__ __forceinline__ void pairD_body(const uint32_t *__restrict__ XVw, int
 // Tasks are circulant (16 rows x up to 64 consecutive columns mod N, PgTask2.nsub = valid columns), see pair_store_circ.
 __global__ __launch_bounds__(256) void k_pairD(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw,
                                                const int64_t *__restrict__ goff, int n_win, const PgTask2 *__restrict__ tasks,
-                                               int n_tasks, int kso, int NP, int N, int32_t *__restrict__ Dmat) {
+                                               int n_tasks, int kso, int NP, int N, int32_t *__restrict__ Dmat, int capg) {
     __shared__ uint32_t red[3 * 16][64];
     PairCtx c;
     if (!pair_decode(tasks, n_tasks, kso, n_win, c)) return;
-    const uint32_t *XVw = XV + (size_t)goff[c.win] * PG_XV_CAP * PG_XV_PLANES * (size_t)NP;      // the window's words
-    const int n_words = __builtin_amdgcn_readfirstlane(nw[c.win]);
+    const uint32_t *XVw = XV + (size_t)goff[c.win] * capg * PG_XV_PLANES * (size_t)NP;      // the window's words
+    // (a window that overflowed its reservation is recomputed by the host; never read past the reservation)
+    const int capw = (int)(goff[c.win + 1] - goff[c.win]) * capg;
+    const int n_all = __builtin_amdgcn_readfirstlane(nw[c.win]);
+    const int n_words = n_all < capw ? n_all : capw;
     const int parts = 4 * kso;
     const int a = (int)((long long)n_words * c.ks / parts), b = (int)((long long)n_words * (c.ks + 1) / parts);
     int32_t *Dw = Dmat + (size_t)c.win * N * N;
@@ -667,12 +899,12 @@ __global__ __launch_bounds__(256) void k_pairD(const uint32_t *__restrict__ XV, 
 }
 
 void pg_launch_pairD(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win,
-                     const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat) {
+                     const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat, int capg) {
     if (n_win <= 0 || n_tasks <= 0) return;
     const int kso = pick_kso(n_win, n_tasks, avg_groups, 1);
     if (kso > 1) (void)hipMemsetAsync(Dmat, 0, (size_t)n_win * N * N * 4, st);
     const int64_t blocks = (int64_t)((n_win + 7) / 8) * n_tasks * kso * 8;
-    hipLaunchKernelGGL(k_pairD, dim3((unsigned)blocks), dim3(256), 0, st, XV, nw, goff, n_win, tasks, n_tasks, kso, NP, N, Dmat);
+    hipLaunchKernelGGL(k_pairD, dim3((unsigned)blocks), dim3(256), 0, st, XV, nw, goff, n_win, tasks, n_tasks, kso, NP, N, Dmat, capg);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -187,7 +187,8 @@ int pg_kernel_time(pg_ctx *ctx, int kernel_id, double *ms_out, int64_t *launches
  * microseconds of GPU idle time each; a throughput run can restrict them to the family it reports. */
 int pg_kernel_time_select(pg_ctx *ctx, uint32_t mask);
 int pg_kernel_time_reset(pg_ctx *ctx);
-/* scratch budget (bytes) for per-batch bit-planes + matrices; default 16 GiB */
+/* scratch budget (bytes) for per-batch bit-planes + matrices; default 48 GiB (a job that fits runs as one batch; a larger one is
+ * cut into at least eight sub-batches that alternate between two slots of half the budget each) */
 int pg_set_scratch_limit(pg_ctx *ctx, int64_t bytes);
 
 /* ---- page-locked host memory ---------------------------------------------------------------------------- */

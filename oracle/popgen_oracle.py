@@ -261,14 +261,18 @@ def pair_counts_loop(aln):
     return D, C
 
 
-def pair_counts_gemm(aln):
+def pair_counts_gemm(aln, dtype=np.float64):
     """Same integers as pair_counts_loop via D = C - sum_b X_b X_b^T, C = V V^T (exact in float64 for
-    counts < 2^53; SURVEY.md 8c verified the identity against Alignment.distMatrix)."""
-    V = aln.mask.astype(np.float64)
+    counts < 2^53; SURVEY.md 8c verified the identity against Alignment.distMatrix).  dtype=np.float32 is exact as
+    long as a window has fewer than 2^24 sites (every partial sum is an integer below 2^24) and halves time and memory
+    for the 2000-haplotype windows of BASELINE.json's distMat configuration."""
+    if dtype == np.float32:
+        assert aln.L < (1 << 24)
+    V = aln.mask.astype(dtype)
     C = V @ V.T
     same = np.zeros_like(C)
     for b in range(4):
-        X = (aln.num == b).astype(np.float64)
+        X = (aln.num == b).astype(dtype)
         same += X @ X.T
     D = C - same
     C = C.astype(np.int64)

@@ -55,6 +55,10 @@ def main():
             name = k.split("<")[0]
             traffic[wl][name] = int((2 * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024)
             traffic["_source"][wl] = tag
+    # VALU wave-instructions per launch (SQ_INSTS_VALU) of the pair kernels: bench.py prices a VALU-bound dominant kernel with them
+    for k, v in out.items():
+        if "SQ_INSTS_VALU" in v:
+            traffic.setdefault("_valu", {}).setdefault(wl, {})[k.split("<")[0]] = int(v["SQ_INSTS_VALU"]["mean_per_launch"])
     with open(tpath, "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
     log = os.path.join(src, "bench_prof_%s.log" % wl)

@@ -1,11 +1,15 @@
-"""-m gpu: size-independent properties at BASELINE.json's C2 size (10^7 sites x 200 haplotypes, 50 kb windows), where the
-CPU oracle is far too slow to run: run-to-run bit identity, additivity of the integer matrices over a split window, agreement of
-the independent pairwise pipelines, bounds and symmetry."""
+"""-m gpu: parity at BASELINE.json's full sizes.  Every configuration (C2 popgenWindows, C3 ABBA-BABA, C4 distMat, the
+north-star single-GPU shape of C5) is run through the HIP path at its full size and sampled windows are downloaded and
+compared with the CPU oracle: the integer matrices D / C, l / S / pair sums and sitesUsed bit-exact, pi / dxy / Fst, the
+ABBA-BABA statistics, theta / Tajima's D and the individual-pair means within 1e-9 relative (north-star tolerance: 1e-6).
+Size-independent properties (run-to-run bit identity, additivity of D and C over a split window, agreement of the independent
+pairwise code paths) ride along as secondary checks."""
 import numpy as np
 import pytest
 
 from genomics_general_amd import synth
 from genomics_general_amd.engine import Engine
+from oracle import popgen_oracle as orc
 
 import gpu_util as G
 
@@ -14,32 +18,94 @@ pytestmark = pytest.mark.gpu
 N_SITES, N_DIP, N_POPS, WIND = 10_000_000, 100, 4, 50_000
 
 
-@pytest.fixture(scope="module")
-def c2():
-    names, lay = G.make_layout(N_DIP, N_POPS)
+def resident(n_sites, n_dip, n_pops, n_scaf):
+    names, lay = G.make_layout(n_dip, n_pops)
     e = Engine(0)
     e.set_layout(lay)
-    e.reserve(N_SITES)
-    e.synth_fill(0, N_SITES, 0, synth.SEED_DEFAULT, N_SITES // 4, N_DIP, N_POPS, G.slot_gen_hap(names, lay), synth.VAR_THR, synth.MISS_THR)
+    e.reserve(n_sites)
+    e.synth_fill(0, n_sites, 0, synth.SEED_DEFAULT, n_sites // n_scaf, n_dip, n_pops, G.slot_gen_hap(names, lay), synth.VAR_THR,
+                 synth.MISS_THR)
+    return e, lay
+
+
+def oracle_window(e, lay, a, b):
+    """the reference-order alignment of resident sites [a,b) (downloaded from the device) and its integer matrices"""
+    codes = e.download(int(a), int(b - a))
+    aln, _ = orc.aln_from_codes(codes, lay.hap_names, lay.hap_sample_name, lay.hap_group)
+    return aln
+
+
+def check_popdist(e, lay, lo, hi, sel, st, min_sites):
+    """D / C bit-exact and pi / dxy / Fst within 1e-9 of the oracle on the windows `sel` of a full-size batch whose statistics
+    `st` were computed over ALL windows of the batch"""
+    D, C = e.batch(lo[sel], hi[sel]).pairCounts(reference_order=True)
+    for k, w in enumerate(sel):
+        aln = oracle_window(e, lay, lo[w], hi[w])
+        Do, Co = orc.pair_counts_gemm(aln)                       # genomics.py:903-916, 1042-1047
+        assert np.array_equal(C[k], Co), "C differs in window %d" % w
+        assert np.array_equal(D[k], Do), "D differs in window %d" % w
+        so, _ = orc.group_dist_stats(aln, Do, Co, True, min_sites, 0.01)     # genomics.py:956-995
+        for key, v in so.items():
+            assert G.close(st[key][w], v), (key, w, st[key][w], v)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# C2 (popgenWindows pi / dxy / Fst) and C3 (ABBA-BABA): 10^7 sites x 200 haplotypes, 200 windows of 50 kb
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c2():
+    e, lay = resident(N_SITES, N_DIP, N_POPS, 4)
     lo = np.arange(0, N_SITES, WIND, dtype=np.int64)
     yield e, lay, lo, lo + WIND
     e.close()
 
 
-def test_full_size_statistics_are_bit_identical_run_to_run(c2):
+def test_c2_popdist_windows_match_the_oracle(c2):
     e, lay, lo, hi = c2
-    a = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
-    b = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
-    assert len(a) == 4 + 2 * 12
-    for k in a:
-        assert a[k].shape == (200,) and np.array_equal(a[k], b[k]), k
-        assert np.all(np.isfinite(a[k]))
-    # pi within [0,1], dxy >= 0, Fst <= 1
-    for k, v in a.items():
-        if k.startswith("pi_") or k.startswith("dxy_"):
-            assert np.all((v >= 0) & (v <= 1))
-        else:
-            assert np.all(v <= 1)
+    st = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
+    assert len(st) == 4 + 2 * 12
+    check_popdist(e, lay, lo, hi, [0, 113, 199], st, 100)
+    # run-to-run bit identity and bounds over all 200 windows
+    again = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
+    for k, v in st.items():
+        assert v.shape == (200,) and np.array_equal(v, again[k]) and np.all(np.isfinite(v)), k
+        assert np.all(v <= 1) and (k.startswith("Fst_") or np.all(v >= 0)), k
+
+
+def test_c3_abbababa_windows_match_the_oracle(c2):
+    """BASELINE.json configs[2]: P1/P2/P3/O of 25 diploids each on 10^7 sites, 50 kb windows (genomics.py:1647-1695)"""
+    e, lay, lo, hi = c2
+    got = e.batch(lo, hi).ABBABABA("p0", "p1", "p2", "p3", 0.5)
+    for w in (1, 77, 198):
+        want = orc.abbababa(oracle_window(e, lay, lo[w], hi[w]), "p0", "p1", "p2", "p3", 0.5)
+        assert int(got["sitesUsed"][w]) == want["sitesUsed"] and want["sitesUsed"] > 100
+        for key in ("D", "fd", "fdM", "ABBA", "BABA"):
+            assert G.close(got[key][w], want[key]), (key, w, got[key][w], want[key])
+    again = e.batch(lo, hi).ABBABABA("p0", "p1", "p2", "p3", 0.5)
+    for k in got:
+        assert np.array_equal(got[k], again[k], equal_nan=True), k
+
+
+def test_c2_popfreq_and_indpair_windows_match_the_oracle(c2):
+    e, lay, lo, hi = c2
+    sel = [5, 150]
+    f = e.batch(lo[sel], hi[sel]).groupFreqStats()
+    wb = e.batch(lo[sel], hi[sel])
+    ip = wb.indPairTable(includeSameWithSame=True)
+    for k, w in enumerate(sel):
+        aln = oracle_window(e, lay, lo[w], hi[w])
+        want = orc.group_freq_stats(aln)                          # genomics.py:1002-1028
+        for name in lay.sampleData.popNames:
+            assert int(f["l_" + name][k]) == want["l_" + name]
+            if want["l_" + name] >= 1:
+                assert int(f["S_int_" + name][k]) == want["S_" + name]
+                for key in ("thetaPi_", "thetaW_", "TajD_"):
+                    assert G.close(f[key + name][k], want[key + name]), (key, name, w)
+        Do, Co = orc.pair_counts_gemm(aln)
+        dmo, _ = orc.ind_pair_dists(aln, orc.dist_from_counts(Do, Co), include_same=True)    # genomics.py:934-954
+        for s in range(0, lay.n_samp, 7):
+            for t in range(s, lay.n_samp, 5):
+                assert G.close(ip[k, lay.sample_pair_index(s, t)], dmo[lay.ind_order[s]][lay.ind_order[t]]), (w, s, t)
 
 
 def test_integer_matrices_are_additive_over_a_split_window_and_bounded(c2):
@@ -53,7 +119,7 @@ def test_integer_matrices_are_additive_over_a_split_window_and_bounded(c2):
     assert C[0].sum() > 0 and D[0].sum() > 0
 
 
-@pytest.mark.parametrize("env", ["PG_PAIR_V1", "PG_NO_DIP", "PG_OVERLAP"])
+@pytest.mark.parametrize("env", ["PG_PAIR_V1", "PG_NO_DIP", "PG_OVERLAP", "PG_PACK2"])
 def test_independent_pipelines_agree_at_full_window_size(c2, env, monkeypatch):
     e, lay, lo, hi = c2
     sel = [0, 61, 199]
@@ -67,14 +133,45 @@ def test_independent_pipelines_agree_at_full_window_size(c2, env, monkeypatch):
         assert np.array_equal(st_got[k], st_want[k]), k
 
 
-def test_abbababa_and_popfreq_full_size_determinism(c2):
-    e, lay, lo, hi = c2
-    a = e.batch(lo, hi).ABBABABA("p0", "p1", "p2", "p3", 0.01)
-    b = e.batch(lo, hi).ABBABABA("p0", "p1", "p2", "p3", 0.01)
-    for k in a:
-        assert np.array_equal(a[k], b[k], equal_nan=True), k
-    assert np.all(a["sitesUsed"] > 100) and np.all(np.abs(a["D"]) <= 1)
-    f = e.batch(lo[:20], hi[:20]).groupFreqStats()
-    g = e.batch(lo[:20], hi[:20]).groupFreqStats()
-    for k in f:
-        assert np.array_equal(f[k], g[k], equal_nan=True), k
+# ---------------------------------------------------------------------------------------------------------
+# C4 (distMat): 10^6 sites x 2000 haplotypes, 10 windows of 100 kb
+# ---------------------------------------------------------------------------------------------------------
+def test_c4_distmat_window_matches_the_oracle():
+    e, lay = resident(1_000_000, 1000, 1, 1)
+    lo = np.arange(0, 1_000_000, 100_000, dtype=np.int64)
+    hi = lo + 100_000
+    tab = e.batch(lo, hi).indPairTable(includeSameWithSame=False)            # what distMat.py prints (distMat.py:42)
+    w = 6
+    D, C = e.batch(lo[w:w + 1], hi[w:w + 1]).pairCounts(reference_order=True)
+    aln = oracle_window(e, lay, lo[w], hi[w])
+    e.close()
+    Do, Co = orc.pair_counts_gemm(aln, dtype=np.float32)          # 1 999 000 pairs x 100 000 sites; exact (counts < 2^24)
+    assert np.array_equal(C[0], Co) and np.array_equal(D[0], Do)
+    # individual-pair means: the oracle's block-by-block nanmean (genomics.py:934-954) on a sample of 60 of the 1000 individuals
+    dm = orc.dist_from_counts(Do, Co)
+    rng = np.random.default_rng(4)
+    inds = np.sort(rng.choice(lay.n_samp, 60, replace=False))
+    ref_pos = {nm: k for k, nm in enumerate(aln.names)}
+    rows = [ref_pos[lay.hap_names[s]] for i in inds for s in lay.ind_slots[lay.ind_order[i]]]
+    sub = orc.Aln(aln.num[rows][:, :1], [aln.names[r] for r in rows], [aln.sample_names[r] for r in rows], ["all"] * len(rows))
+    want, _ = orc.ind_pair_dists(sub, dm[np.ix_(rows, rows)], include_same=False)
+    for i in inds:
+        for j in inds:
+            a, b = lay.ind_order[i], lay.ind_order[j]
+            assert G.close(tab[w, lay.sample_pair_index(i, j)], want[a][b]), (a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# north-star single-GPU shape (first 10^8 sites of C5): 10^8 sites x 400 haplotypes, 2000 windows of 50 kb
+# ---------------------------------------------------------------------------------------------------------
+def test_northstar_shape_windows_match_the_oracle():
+    n_sites = 100_000_000
+    e, lay = resident(n_sites, 200, 4, 4)
+    lo = np.arange(0, n_sites, WIND, dtype=np.int64)
+    hi = lo + WIND
+    st = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
+    check_popdist(e, lay, lo, hi, [3, 1999], st, 100)
+    again = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
+    for k, v in st.items():
+        assert v.shape == (2000,) and np.array_equal(v, again[k]) and np.all(np.isfinite(v)), k
+    e.close()
