@@ -107,6 +107,9 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->win_pin.release();
     c->Cfull.release();
     c->Dfull.release();
+    c->hapbits.release();
+    c->hap_order.release();
+    c->site_tmp.release();
     c->Vp.release();
     c->XY.release();
     c->planes.release();
@@ -814,6 +817,67 @@ extern "C" int pg_indpairdist_mean(pg_ctx *c, const int64_t *lo, const int64_t *
     return indpair_run(c, lo, hi, n_win, min_pair_sites, diag_counts_zeros ? 2 : 1, d_out, nullptr);
 }
 
+// ---- indHet / hapStats: device finalisers of the pairwise matrices ------------------------------------------
+extern "C" int pg_sample_het(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites, double *het_out) {
+    int rc = check_windows(c, lo, hi, n_win);
+    if (rc != PG_OK) return rc;
+    if (n_win == 0) return PG_OK;
+    if (!het_out) return pg_fail(PG_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t ns = (size_t)c->n_samp;
+    return pairwise_run(c, lo, hi, n_win, [&](int w0, int nb) -> int {
+        int r;
+        if ((r = c->res_f64.ensure((size_t)nb * ns)) != PG_OK) return r;
+        pg_launch_sample_het(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->samp_start.p, c->n_samp,
+                             min_pair_sites, c->res_f64.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(het_out + (size_t)w0 * ns, c->res_f64.p, (size_t)nb * ns * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return PG_OK;
+    });
+}
+
+extern "C" int pg_hapstats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites, int diag_nan,
+                           double max_dist, const int32_t *pop_row_order, double *h_out) {
+    int rc = check_windows(c, lo, hi, n_win);
+    if (rc != PG_OK) return rc;
+    if (c->n_pops < 1) return pg_fail(PG_ERR_STATE, "pg_hapstats needs at least one population");
+    if (n_win == 0) return PG_OK;
+    if (!h_out || !pop_row_order) return pg_fail(PG_ERR_ARG, "null argument");
+    const int P = c->n_pops, n_in = c->h_pop_start[P];
+    // every population's range must be a permutation of its own slots
+    {
+        std::vector<char> seen((size_t)std::max(n_in, 1), 0);
+        for (int p = 0; p < P; ++p)
+            for (int k = c->h_pop_start[p]; k < c->h_pop_start[p + 1]; ++k) {
+                const int s = pop_row_order[k];
+                if (s < c->h_pop_start[p] || s >= c->h_pop_start[p + 1] || seen[s])
+                    return pg_fail(PG_ERR_ARG, "pop_row_order[%d] = %d is not a permutation of population %d's slots", k, s, p);
+                seen[s] = 1;
+            }
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if ((rc = c->hap_order.upload(pop_row_order, (size_t)std::max(n_in, 1), c->stream)) != PG_OK) return rc;
+    size_t per_win = 0;
+    int max_pop = 0;
+    for (int p = 0; p < P; ++p) {
+        const size_t n = c->h_pop_start[p + 1] - c->h_pop_start[p];
+        per_win += n * ((n + 31) / 32);
+        max_pop = std::max<int>(max_pop, (int)n);
+    }
+    return pairwise_run(c, lo, hi, n_win, [&](int w0, int nb) -> int {
+        int r;
+        if ((r = c->hapbits.ensure((size_t)nb * std::max<size_t>(per_win, 1))) != PG_OK) return r;
+        if ((r = c->res_f64.ensure((size_t)nb * P * 3)) != PG_OK) return r;
+        pg_launch_hapstats(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, P, max_pop,
+                           c->hap_order.p, min_pair_sites, diag_nan, max_dist, c->hapbits.p, per_win, c->res_f64.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_out + (size_t)w0 * P * 3, c->res_f64.p, (size_t)nb * P * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return PG_OK;
+    });
+}
+
 // ---- site statistics --------------------------------------------------------------------------------
 static int quartet_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int p1, int p2, int p3, int p4,
                          double min_data, int sel, int nsum, double *sums_out, int64_t *used_out) {
@@ -912,8 +976,8 @@ extern "C" int pg_site_counts(pg_ctx *c, int64_t site_lo, int64_t site_hi, int32
     if (!cnt_out) return pg_fail(PG_ERR_ARG, "null output");
     HIPCHK(hipSetDevice(c->device));
     const int64_t chunk = 1 << 22;
-    DevBuf<int32_t> tmp;
-    int rc = tmp.alloc((size_t)std::min(n, chunk) * c->n_pops * 4);
+    DevBuf<int32_t> &tmp = c->site_tmp;          // kept in the context: freq.py calls this once per block of sites
+    int rc = tmp.ensure((size_t)std::min(n, chunk) * c->n_pops * 4);
     if (rc != PG_OK) return rc;
     for (int64_t s = site_lo; s < site_hi; s += chunk) {
         int64_t e = std::min(site_hi, s + chunk);
@@ -922,9 +986,8 @@ extern "C" int pg_site_counts(pg_ctx *c, int64_t site_lo, int64_t site_hi, int32
         if (err == hipSuccess)
             err = hipMemcpyAsync(cnt_out + (size_t)(s - site_lo) * c->n_pops * 4, tmp.p, (size_t)(e - s) * c->n_pops * 16, hipMemcpyDeviceToHost, c->stream);
         if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
-        if (err != hipSuccess) { tmp.release(); return pg_fail(PG_ERR_HIP, "pg_site_counts: %s", hipGetErrorString(err)); }
+        if (err != hipSuccess) return pg_fail(PG_ERR_HIP, "pg_site_counts: %s", hipGetErrorString(err));
     }
-    tmp.release();
     return PG_OK;
 }
 

@@ -102,6 +102,9 @@ struct pg_ctx {
     DevBuf<int32_t> flag;        // v2: PG_FLAG_MISMATCH | PG_FLAG_XV_OVERFLOW, raised by the pack kernels
     int xv_capg = PG_XV_CAP_DEFAULT;   // XV words reserved per compaction group (PG_XV_CAP after an overflow)
     DevBuf<int32_t> Cfull, Dfull;  // pg_pairwise staging
+    DevBuf<uint32_t> hapbits;      // k_hapstats: match matrices as bit rows
+    DevBuf<int32_t> hap_order;     // k_hapstats: each population's slots in the reference's row order
+    DevBuf<int32_t> site_tmp;      // pg_site_counts staging
     // how the matrices of the last batch are laid out (set by pairwise_batches)
     int cN = 0, cshift = 0;
     // resident sites

@@ -81,6 +81,11 @@ void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, i
 void pg_launch_pairD(hipStream_t st, const uint32_t *XY, const int32_t *nw, const int64_t *goff, int n_win,
                      const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat, int capg);
 
+void pg_launch_sample_het(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
+                          const int32_t *samp_start, int n_samp, int min_pair_sites, double *out);
+void pg_launch_hapstats(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
+                        const int32_t *pop_start, int n_pops, int max_pop, const int32_t *order, int min_pair_sites, int diag_nan,
+                        double max_dist, uint32_t *bits, size_t bits_per_window, double *out);
 void pg_launch_flag_export(hipStream_t st, int32_t *flag, double *dst);
 void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts, int n_win, const int32_t *pop_start,
                         int n_pops, double min_data, int do_pairs, double *out);

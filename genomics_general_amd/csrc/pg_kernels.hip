@@ -416,6 +416,152 @@ __global__ __launch_bounds__(256) void k_popstats(const double *__restrict__ sum
     O[n_pops + npo + k] = 1 - pi_s / pi_t;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K_sample_het: Alignment.sampleHet (genomics.py:918-929) on the cached matrix: thread per (window, individual).
+// The reference's `len(x)==2 & np.sum(mask & mask) >= _minSites` parses as `len(x) == (2 & C) >= 1`: a value is reported only
+// for a diploid individual whose jointly called site count has bit 1 set; the value is the cached distance of its two
+// haplotypes, i.e. D/C, nan where a preceding groupDistStats masked the pair (C < its minSites, genomics.py:959-961).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample_het(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat, int N,
+                                                    int cN, int cshift, int n_win, const int32_t *__restrict__ samp_start,
+                                                    int n_samp, int min_pair_sites, double *__restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n_win * n_samp) return;
+    const int win = (int)(idx / n_samp), s = (int)(idx % n_samp);
+    const int a = samp_start[s], pl = samp_start[s + 1] - a;
+    double v = __longlong_as_double(0x7FF8000000000000ll);
+    if (pl == 2) {
+        const int c = Cmat[(size_t)win * cN * cN + (size_t)(a >> cshift) * cN + ((a + 1) >> cshift)];
+        if ((c & 2) && c >= (min_pair_sites > 1 ? min_pair_sites : 1))
+            v = (double)Dmat[(size_t)win * N * N + (size_t)a * N + a + 1] / (double)c;
+    }
+    out[idx] = v;
+}
+
+void pg_launch_sample_het(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
+                          const int32_t *samp_start, int n_samp, int min_pair_sites, double *out) {
+    if (n_win <= 0 || n_samp <= 0) return;
+    const long long total = (long long)n_win * n_samp;
+    hipLaunchKernelGGL(k_sample_het, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, n_win,
+                       samp_start, n_samp, min_pair_sites, out);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_hapstats: Alignment.H12stats (genomics.py:1079-1098) with the greedy clustering of distMat_to_cluster_sizes
+// (genomics.py:1239-1261).  Block per (population, window):
+//   1. match[i][j] = dist(i,j) <= maxDist as bit rows (global scratch, L2 resident); dist = D/C in float64 as the reference
+//      forms it, nan (no match) where nothing is jointly called or a preceding groupDistStats masked the pair; the diagonal
+//      is 0.0 (a match when maxDist >= 0) unless an earlier step of the reference's worker left it nan (diag_nan);
+//   2. greedy extraction: the alive row with the most alive matches (ties: the first row in the reference's row order, i.e.
+//      haplotype names sorted) founds a cluster of that size and its matches leave; a best row with <= 1 match ends the
+//      loop, every remaining row is a singleton;
+//   3. f = sizes / n;  H1 = sum f^2,  H12 = H1 + 2 f0 f1,  H2 = sum_{k>=1} f_k^2  (H12 = H1, H2 = 0 for a single cluster).
+// `order[pop_start[p] .. pop_start[p+1])` = the population's slots in the reference's row order.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hapstats(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat, int N,
+                                                  int cN, int cshift, const int32_t *__restrict__ pop_start, int n_pops,
+                                                  const int32_t *__restrict__ order, int min_pair_sites, int diag_nan,
+                                                  double max_dist, uint32_t *__restrict__ bits, size_t bits_per_window,
+                                                  double *__restrict__ out) {
+    extern __shared__ uint32_t alive[];                    // ceil(n/32) words
+    __shared__ int best_c[256], best_i[256];
+    const int p = blockIdx.x, win = blockIdx.y, tid = threadIdx.x;
+    const int s0 = pop_start[p], n = pop_start[p + 1] - s0, nw = (n + 31) >> 5;
+    size_t off = 0;
+    for (int q = 0; q < p; ++q) {
+        const size_t nq = pop_start[q + 1] - pop_start[q];
+        off += nq * ((nq + 31) >> 5);
+    }
+    uint32_t *M = bits + (size_t)win * bits_per_window + off;
+    const int32_t *Cw = Cmat + (size_t)win * cN * cN;
+    const int32_t *Dw = Dmat + (size_t)win * N * N;
+    const int thr = min_pair_sites > 1 ? min_pair_sites : 1;
+    double *O = out + ((size_t)win * n_pops + p) * 3;
+    if (n == 0) {
+        if (tid == 0) O[0] = O[1] = O[2] = 0.0;
+        return;
+    }
+    for (int idx = tid; idx < n * nw; idx += 256) {
+        const int i = idx / nw, wd = idx - i * nw;
+        const int hi = order[s0 + i];
+        uint32_t word = 0u;
+        for (int b = 0; b < 32; ++b) {
+            const int j = wd * 32 + b;
+            if (j >= n) break;
+            bool m;
+            if (j == i) {
+                m = !diag_nan && 0.0 <= max_dist;
+            } else {
+                const int hj = order[s0 + j];
+                const int lo = hi < hj ? hi : hj, up = hi < hj ? hj : hi;
+                const int c = Cw[(size_t)(lo >> cshift) * cN + (up >> cshift)];
+                m = c >= thr && (double)Dw[(size_t)lo * N + up] / (double)c <= max_dist;
+            }
+            word |= (uint32_t)m << b;
+        }
+        M[idx] = word;
+    }
+    for (int w = tid; w < nw; w += 256) alive[w] = (w == nw - 1 && (n & 31)) ? ((1u << (n & 31)) - 1u) : 0xFFFFFFFFu;
+    __syncthreads();
+    double sumsq = 0.0, f0 = 0.0, f1 = 0.0;                 // kept by every thread identically (block-uniform control flow)
+    int k = 0;
+    const double dn = (double)n;
+    for (;;) {
+        int bc = -1, bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 256) {
+            if (!((alive[i >> 5] >> (i & 31)) & 1u)) continue;
+            int c = 0;
+            for (int w = 0; w < nw; ++w) c += __popc(M[(size_t)i * nw + w] & alive[w]);
+            if (c > bc) { bc = c; bi = i; }                 // rows visited in increasing order: the first maximum stays
+        }
+        best_c[tid] = bc;
+        best_i[tid] = bi;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                const int c2 = best_c[tid + s], i2 = best_i[tid + s];
+                if (c2 > best_c[tid] || (c2 == best_c[tid] && i2 < best_i[tid])) { best_c[tid] = c2; best_i[tid] = i2; }
+            }
+            __syncthreads();
+        }
+        const int matches = best_c[0], most = best_i[0];
+        __syncthreads();
+        if (matches < 0) break;                             // no row left
+        if (matches > 1) {
+            const double f = (double)matches / dn;
+            if (k == 0) f0 = f; else if (k == 1) f1 = f;
+            sumsq += f * f;
+            ++k;
+            for (int w = tid; w < nw; w += 256) alive[w] &= ~M[(size_t)most * nw + w];
+            __syncthreads();
+        } else {
+            int rem = 0;
+            for (int w = 0; w < nw; ++w) rem += __popc(alive[w]);
+            const double f = 1.0 / dn;
+            for (int r = 0; r < rem; ++r) {
+                if (k == 0) f0 = f; else if (k == 1) f1 = f;
+                sumsq += f * f;
+                ++k;
+            }
+            break;
+        }
+    }
+    if (tid == 0) {
+        O[0] = sumsq;
+        O[1] = k > 1 ? sumsq + 2 * f0 * f1 : sumsq;
+        O[2] = k > 1 ? sumsq - f0 * f0 : 0.0;
+    }
+}
+
+void pg_launch_hapstats(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
+                        const int32_t *pop_start, int n_pops, int max_pop, const int32_t *order, int min_pair_sites, int diag_nan,
+                        double max_dist, uint32_t *bits, size_t bits_per_window, double *out) {
+    if (n_win <= 0 || n_pops <= 0) return;
+    const size_t lds = (size_t)((max_pop + 31) / 32 + 1) * 4;
+    hipLaunchKernelGGL(k_hapstats, dim3(n_pops, n_win), dim3(256), lds, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops, order,
+                       min_pair_sites, diag_nan, max_dist, bits, bits_per_window, out);
+}
+
 // the diploid-shortcut verdict as a double next to the result table; re-arms the flag
 __global__ void k_flag_export(int32_t *__restrict__ flag, double *__restrict__ dst) {
     dst[0] = (double)flag[0];

@@ -297,71 +297,41 @@ class WindowBatch:
             out["TajD_" + name] = taj
         return out
 
-    # -- indHet / hapStats: host finalisers of the integer matrices ------------------------
-    def _masked_dist(self, reference_order=True):
-        """float64 distance matrices as the reference's cached `_distMat_` looks at this point of its worker: D/C (nan
-        where nothing is jointly called), zero diagonal; after groupDistStats: pairs below its minSites and the diagonal nan
-        (genomics.py:959-963 mutate the cache)."""
-        D, Cc = self.pairCounts(reference_order=reference_order)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            dm = D.astype(np.float64) / Cc.astype(np.float64)
-        idx = np.arange(self.lay.n_hap)
-        dm[:, idx, idx] = 0.0
-        if self._popdist_min_sites:
-            dm[Cc < self._popdist_min_sites] = np.nan
-        if self._popdist_min_sites is not None or self._diag_nan:
-            dm[:, idx, idx] = np.nan
-        return dm, Cc
+    # -- indHet / hapStats: finished on the device, nothing N x N leaves the GPU ---------------------
+    def _cache_state(self):
+        """What the reference worker's cached `_distMat_` carries at this point: the minSites mask of a preceding
+        groupDistStats (genomics.py:959-961) and a nan diagonal (genomics.py:963, or indPairDists without
+        includeSameWithSame, genomics.py:940)."""
+        ms = self._popdist_min_sites or 0
+        return int(ms), bool(self._popdist_min_sites is not None or self._diag_nan)
 
     def sampleHet(self):
-        """{individual: array over windows} like Alignment.sampleHet() (genomics.py:918-929), including its operator
-        precedence: `len(x)==2 & np.sum(...) >= _minSites` parses as `len(x) == (2 & C) >= 1`, so an individual's
-        heterozygosity is reported only when it is diploid and bit 1 of its jointly-called site count is set."""
+        """{individual: array over windows} like Alignment.sampleHet() (genomics.py:918-929); pg_sample_het keeps the
+        reference's operator precedence (a value only where bit 1 of the jointly called site count is set)."""
         lay = self.lay
-        dm, Cc = self._masked_dist(reference_order=False)
-        out = {}
-        for name in lay.ind_order:
-            sl = lay.ind_slots[name]
-            if len(sl) == 2:
-                c = Cc[:, sl[0], sl[1]]
-                out[name] = np.where((c & 2) == 2, dm[:, sl[0], sl[1]], np.nan)
-            else:
-                out[name] = np.full(self.n, np.nan)
-        return out
+        ms, _ = self._cache_state()
+        tab = np.zeros((self.n, lay.n_samp), dtype=np.float64)
+        check(self.e._L.pg_sample_het(self.e._h, self.lo, self.hi, self.n, ms, tab))
+        return {name: tab[:, k] for k, name in enumerate(lay.ind_order)}
 
     def H12stats(self, maxDist=0):
-        """H1 / H12 / H2 per population like Alignment.H12stats (genomics.py:1079-1098) with the greedy clustering of
-        distMat_to_cluster_sizes (genomics.py:1239-1261), in the reference's row order (haplotype names sorted)."""
+        """H1 / H12 / H2 per population like Alignment.H12stats (genomics.py:1079-1098): pg_hapstats clusters every window's
+        match matrix on the device, ties broken in the reference's row order (haplotype names sorted)."""
         lay = self.lay
-        dm, _ = self._masked_dist(reference_order=True)
-        groups = np.array([lay.hap_group[i] for i in lay.ref_order], dtype=object)
+        ms, diag_nan = self._cache_state()
+        order = lay.__dict__.get("_pop_row_order")
+        if order is None:
+            rank = np.empty(lay.n_hap, dtype=np.int64)
+            rank[lay.ref_order] = np.arange(lay.n_hap)
+            in_pop = np.where(lay.hap_pop >= 0)[0]
+            order = in_pop[np.lexsort((rank[in_pop], lay.hap_pop[in_pop]))].astype(np.int32)
+            lay._pop_row_order = order
+        tab = np.zeros((self.n, lay.n_pops, 3), dtype=np.float64)
+        check(self.e._L.pg_hapstats(self.e._h, self.lo, self.hi, self.n, ms, 1 if diag_nan else 0, float(maxDist),
+                                    np.ascontiguousarray(order), tab))
         out = {}
-        for name in np.unique(np.array([g for g in lay.hap_group if g is not None])):
-            rows = np.where(groups == name)[0]
-            H1, H12, H2 = np.zeros(self.n), np.zeros(self.n), np.zeros(self.n)
-            for w in range(self.n):
-                with np.errstate(invalid="ignore"):
-                    match = dm[w][np.ix_(rows, rows)] <= maxDist
-                sizes = []
-                while match.shape[0] > 0:
-                    most = match.sum(axis=1).argmax()
-                    matches = match[most, ].sum()
-                    if matches > 1:
-                        sizes.append(matches)
-                        keep = np.invert(match[most, ])
-                        match = match[np.ix_(keep, keep)]
-                    else:
-                        sizes += [1] * match.shape[0]
-                        break
-                sizes = np.array(sizes)
-                f = sizes / sizes.sum()
-                H1[w] = (f ** 2).sum()
-                if len(f) > 1:
-                    H12[w] = H1[w] + 2 * f[0] * f[1]
-                    H2[w] = (f[1:] ** 2).sum()
-                else:
-                    H12[w], H2[w] = H1[w], 0
-            out["H1_" + name], out["H12_" + name], out["H2_" + name] = H1, H12, H2
+        for x, name in enumerate(lay.sampleData.popNames):
+            out["H1_" + name], out["H12_" + name], out["H2_" + name] = tab[:, x, 0], tab[:, x, 1], tab[:, x, 2]
         return out
 
     def indPairSums(self, minSites=None):
@@ -445,17 +415,12 @@ class WindowBatch:
 
 
 def _tajima_d(n, S, theta_pi):
-    """genomics.py:619-632 on arrays (n scalar)."""
+    """Tajima's D of genomics.TajimaD (genomics.py:619-632) for arrays over windows (n = haplotypes of the population):
+    (thetaPi - S/h1) / sqrt(v1*S + v2*S*(S-1)) with the usual constants from the harmonic sums h1 = sum 1/i, h2 = sum 1/i^2."""
     if n < 2:
         return np.full_like(theta_pi, np.nan)
-    a = sum(1. / i for i in range(1, n))
-    theta_w = 1. * S / a
-    a2 = sum(1. / (i ** 2) for i in range(1, n))
-    b1 = (n + 1.) / (3 * (n - 1))
-    b2 = (2. * (n ** 2 + n + 3)) / (9 * n * (n - 1))
-    c1 = b1 - (1. / a)
-    c2 = b2 - ((n + 2) / (a * n)) + a2 / (a ** 2)
-    e1 = c1 / a
-    e2 = c2 / (a ** 2 + a2)
-    d = theta_pi - theta_w
-    return d / np.sqrt(e1 * S + e2 * S * (S - 1))
+    i = np.arange(1, n, dtype=np.float64)
+    h1, h2 = float(np.sum(1.0 / i)), float(np.sum(1.0 / i ** 2))
+    v1 = ((n + 1.0) / (3 * (n - 1)) - 1.0 / h1) / h1
+    v2 = (2.0 * (n * n + n + 3) / (9 * n * (n - 1)) - (n + 2) / (h1 * n) + h2 / h1 ** 2) / (h1 ** 2 + h2)
+    return (theta_pi - S / h1) / np.sqrt(v1 * S + v2 * S * (S - 1))

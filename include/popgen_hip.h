@@ -143,6 +143,20 @@ int pg_indpairdist(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, in
 int pg_indpairdist_mean(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites,
                         int diag_counts_zeros, double *d_out);
 
+/* ---- indHet / hapStats finished on the device (no N x N matrices leave the GPU) ------------------------------- */
+/* Replaces Alignment.sampleHet (genomics.py:918-929) on the reference worker's cached distance matrix:
+ * het_out[n_win][n_individuals] (slot order of the individuals) = D/C of a diploid individual's two haplotypes where bit 1 of
+ * their jointly called site count is set (the reference's `len(x)==2 & C >= _minSites` precedence), nan otherwise and where
+ * C < min_pair_sites (the mask a preceding groupDistStats(minSites) leaves on the cache, genomics.py:959-961; 0 = none). */
+int pg_sample_het(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites, double *het_out);
+/* Replaces Alignment.H12stats (genomics.py:1079-1098) + distMat_to_cluster_sizes (genomics.py:1239-1261):
+ * h_out[n_win][n_pops][3] = H1, H12, H2 of every population.  pop_row_order[slots in populations]: for each population the
+ * slots of its haplotypes in the reference's row order (haplotype names sorted, genomics.py:1122) -- the greedy clustering
+ * breaks ties by row order.  min_pair_sites as above; diag_nan != 0 when an earlier step of the reference's worker left a nan
+ * diagonal on the cached matrix (groupDistStats, or indPairDists without includeSameWithSame). */
+int pg_hapstats(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites, int diag_nan,
+                double max_dist, const int32_t *pop_row_order, double *h_out);
+
 /* ---- K1+K4: ABBA-BABA window sums ------------------------------------------------------------------ */
 /* Replaces genomics.ABBABABA(polarize=True) (genomics.py:1647-1695) with f4/D/fd/fdm/ABBA/BABA
  * (genomics.py:1409-1475, 1565-1569).  sums_out[n_win][6] = { sum f4(p1,p2,p3,p4), sum (ABBA+BABA),

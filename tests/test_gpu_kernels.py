@@ -301,3 +301,40 @@ def test_rccl_communicator_single_rank_roundtrip(tmp_path, monkeypatch):
     tab = dist.gather_table(comm, x.reshape(4, 3), 4)
     assert tab.shape == (4, 3)
     e.close()
+
+
+@pytest.mark.parametrize("after_popdist,after_indpair,max_dist,var_thr", [
+    (False, False, 0, 2500), (True, False, 0, 2500), (False, True, 0.002, 6000), (True, True, 0.01, 20000)])
+def test_sample_het_and_h12_finished_on_the_device_match_the_oracle(after_popdist, after_indpair, max_dist, var_thr):
+    """pg_sample_het / pg_hapstats (genomics.py:918-929, 1079-1098, 1239-1261) on the matrix the reference's worker has cached
+    at that point: plain, masked by a preceding groupDistStats(minSites), or with the nan diagonal indPairDists leaves"""
+    e, lay, codes, names = G.make_engine(17, 3, 2600, seed=71, var_thr=var_thr, miss_thr=2500, extra_nopop=2)
+    wins = [(0, 300), (300, 340), (340, 2600), (7, 8), (1000, 1064)]
+    ms = 25
+    wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
+    if after_popdist:
+        wb.groupDistStats(True, ms, 0.01)
+    if after_indpair:
+        wb.indPairDists(includeSameWithSame=False)
+    het = wb.sampleHet()
+    h = wb.H12stats(max_dist)
+    sizes_seen = set()
+    for k, (a, b) in enumerate(wins):
+        aln = oracle_aln(lay, codes, a, b)
+        Do, Co = orc.pair_counts_gemm(aln)
+        if after_popdist:
+            _, dm = orc.group_dist_stats(aln, Do, Co, True, ms, 0.01)
+        else:
+            dm = orc.dist_from_counts(Do, Co)
+        if after_indpair:
+            np.fill_diagonal(dm, np.nan)
+        want_het = orc.sample_het(aln, dm, Co)
+        for nm in names:
+            assert G.close(het[nm][k], want_het["het_" + nm]), (nm, k, het[nm][k], want_het["het_" + nm])
+        want_h = orc.h12_stats(aln, dm, max_dist)
+        for p in lay.sampleData.popNames:
+            for st in ("H1_", "H12_", "H2_"):
+                assert G.close(h[st + p][k], want_h[st + p]), (st + p, k, h[st + p][k], want_h[st + p])
+            sizes_seen.add(round(float(want_h["H1_" + p]), 6))
+    assert len(sizes_seen) > 3                      # the cases are not all "every haplotype its own cluster"
+    e.close()
