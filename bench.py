@@ -62,6 +62,7 @@ WORKLOADS = {
                  desc="tiny smoke workload"),
 }
 CPU_DISTMAT_HAPS = 120          # distMat CPU sample: 7140 pairs x 100 kb ~ 5 s per window
+CPU_SLICE_SITES = 10_000        # CPU sample: the first 10 000 sites of a window per worker (~10 s of CPU work at 400 haplotypes)
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GUIDE = 1024 * 2.4e9 / 2      # wave64 VALU instructions per second: 256 CUs x 4 SIMD-32, 2 cycles each, 2.4 GHz (guide)
 VALU_PAIRSITES_PEAK = 3.6e14    # 7 lane-ops per 32 pair-sites at 7.9e13 lane-ops/s
@@ -97,15 +98,19 @@ def _cpu_window_job(job):
     return t0, t1, csv
 
 
-def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, stats, max_workers):
-    """W = #workers windows of the workload through the oracle's full path, one per worker process on all host cores."""
+def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, max_workers):
+    """One slice of CPU_SLICE_SITES sites (the head of a window of the workload) per worker process, all host cores at once,
+    through the oracle's restatement of the reference's whole path; the GPU statistics of the same slices are compared with it.
+    Every stage of the reference is linear in the sites of a window, so sites/s is measured directly and windows/s is that rate
+    divided by the workload's sites per window."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
     workers = cores
+    slice_sites = int(min(CPU_SLICE_SITES, wl["wind"]))
     try:
         import psutil
-        # a worker holds one window as Python strings + int64 alignment: ~2.5 kB per site-individual pair at the 400-haplotype shape
-        per_worker = 160 * wl["wind"] * lay.n_hap // 2 + (1 << 28)
+        # a worker holds its slice as Python strings + int64 alignment: ~160 B per genotype cell, plus the interpreter
+        per_worker = 160 * slice_sites * lay.n_hap // 2 + (1 << 28)
         workers = max(1, min(workers, int(psutil.virtual_memory().available * 0.6 // per_worker)))
     except Exception:
         pass
@@ -116,47 +121,59 @@ def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, stats, max_wor
     col_of_slot = np.array([2 * names.index(lay.hap_sample_name[s]) + (s - lay.ind_slots[lay.hap_sample_name[s]][0])
                             for s in range(lay.n_hap)])
     sel = np.linspace(0, len(lo) - 1, workers).astype(int) if workers > 1 else np.array([0])
+    s_lo = lo[sel].copy()
+    s_hi = np.minimum(s_lo + slice_sites, hi[sel])
+    # the GPU's numbers for the same slices
+    wb = eng.batch(s_lo, s_hi)
+    if wl["tool"] == "popgen":
+        stats = wb.groupDistStats(doPairs=True, minSites=wl["min_sites"], minData=0.01)
+    elif wl["tool"] == "popfreq":
+        stats = wb.groupFreqStats()
+    else:
+        stats = wb.ABBABABA("pop0", "pop1", "pop2", "pop3", 0.01)
     jobs = []
-    for w in sel:
-        slot_codes = eng.download(int(lo[w]), int(hi[w] - lo[w]))
+    for a, b in zip(s_lo, s_hi):
+        slot_codes = eng.download(int(a), int(b - a))
         codes = np.zeros_like(slot_codes)
         codes[:, col_of_slot] = slot_codes
-        scaf, pos0 = "chr%d" % (int(lo[w]) // scaf_len + 1), int(lo[w]) % scaf_len + 1
-        # a window file starts at position pos0: render it with positions 1.. so that it is exactly one window of the tool
-        jobs.append((codes, names, pops, wl["wind"], wl["min_sites"], wl["tool"], scaf, 1))
+        # the slice is rendered with positions 1.. on one scaffold: exactly one window of `slice_sites` for the tool
+        jobs.append((codes, names, pops, slice_sites, wl["min_sites"], wl["tool"], "chr%d" % (int(a) // scaf_len + 1), 1))
     ctx = mp.get_context("spawn")
     with ctx.Pool(workers) as pool:
         res = pool.map(_cpu_window_job, jobs, chunksize=1)
     wall = max(r[1] for r in res) - min(r[0] for r in res)
     busy = sum(r[1] - r[0] for r in res)
     ok = True
-    for w, (_, _, csv) in zip(sel, res):
+    for k, (_, _, csv) in enumerate(res):
         rows = csv.strip().split("\n")
         head, vals = rows[0].split(","), rows[1].split(",")
-        for k, v in zip(head, vals):
-            if k in ("scaffold", "start", "end", "mid", "sites"):
+        for name, v in zip(head, vals):
+            if name in ("scaffold", "start", "end", "mid", "sites"):
                 continue
             v = float(v)
-            if k == "sitesUsed":
-                ok = ok and (int(stats[k][w]) == int(v) if v == v else True)
+            if name == "sitesUsed":
+                ok = ok and (int(stats[name][k]) == int(v) if v == v else True)
                 continue
-            if k not in stats:
+            if name not in stats:
                 continue
-            g = float(stats[k][w])
+            g = float(stats[name][k])
             # the ABBA-BABA driver rounds to 4 decimals (ABBABABAwindows.py:42), the popgenWindows leg is run with --roundTo 12
             tol = 0.5e-4 + 1e-6 if wl["tool"] == "abba" else 1e-6 * max(1.0, abs(v))
             ok = ok and (abs(g - v) <= tol or (g != g and v != v))
-    W = len(sel)
-    return {"value": round(W / wall, 5), "unit": "windows/s", "sites_per_sec": round(W * wl["wind"] / wall, 1),
+    n_slices = len(sel)
+    sites_s = n_slices * slice_sites / wall
+    return {"value": round(sites_s / wl["wind"], 5), "unit": "windows/s", "sites_per_sec": round(sites_s, 1),
             "cores": workers, "host_cores": cores, "kind": "port",
-            "sample": "%d windows of the workload (%d sites x %d haplotypes each), each rendered as .geno text and run through the "
-                      "oracle's restatement of the reference's whole path (text parse -> window -> genoToAlignment -> pair-by-pair "
-                      "loop -> statistics; popgenWindows.py:28-75, genomics.py:1884-1945, 1101-1127, 903-916, 956-995), one window "
-                      "per worker process, %d worker processes in parallel" % (W, wl["wind"], lay.n_hap, workers),
+            "sample": "%d slices of %d sites x %d haplotypes (the heads of %d evenly spaced windows of the workload), each rendered as "
+                      ".geno text and run through the oracle's restatement of the reference's whole path (text parse -> window -> "
+                      "genoToAlignment -> pair-by-pair loop -> statistics; popgenWindows.py:28-75, genomics.py:1884-1945, 1101-1127, "
+                      "903-916, 956-995), one slice per worker process, %d worker processes at once; sites/s is measured, windows/s = "
+                      "sites/s / %d sites per window (every stage of the reference is linear in the sites of a window)" % (
+                          n_slices, slice_sites, lay.n_hap, n_slices, workers, wl["wind"]),
             "wall_seconds": round(wall, 2), "cpu_seconds": round(busy, 2), "gpu_matches_oracle_on_sample": bool(ok)}
 
 
-def cpu_baseline_distmat(eng, lay, wl, lo, hi, stats):
+def cpu_baseline_distmat(eng, lay, wl, lo, hi):
     """distMat (2000 haplotypes): the pair loop is quadratic in haplotypes, a window costs ~20 minutes on one core; time the first
     CPU_DISTMAT_HAPS haplotypes of one window and scale by the pair count (numeric core only)."""
     from oracle import popgen_oracle as orc
@@ -228,7 +245,7 @@ def main():
         wb = eng.batch(lo, hi)
         if wl["tool"] == "popgen":
             table, cols = wb.groupDistTable(doPairs=True, minSites=wl["min_sites"], minData=0.01)
-            return None, table                       # the named statistics for the oracle check: stats_for_check()
+            return None, table
         elif wl["tool"] == "popfreq":
             st = wb.groupFreqStats()
         elif wl["tool"] == "distmat":
@@ -239,12 +256,6 @@ def main():
         keys = sorted(k for k in st if k != "sitesUsed")
         table = np.stack([st[k] for k in keys], axis=1)
         return st, table
-
-    def stats_for_check():
-        """{statistic: array over windows} of one (untimed) pass, for the comparison with the CPU port"""
-        if wl["tool"] == "popgen":
-            return eng.batch(lo, hi).groupDistStats(doPairs=True, minSites=wl["min_sites"], minData=0.01)
-        return step()[0]
 
     # warm-up with every kernel family bracketed by events: it tells which family is the dominant one; the timed region then
     # brackets only that family (an event record between two kernels costs a few microseconds of GPU idle time), and the
@@ -354,11 +365,10 @@ def main():
     # ---- CPU baseline: the oracle's restatement of the reference's whole path on all host cores, bounded sample -------------
     cpu = None
     if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:
-        stc = stats_for_check()
         if wl["tool"] == "distmat":
-            cpu = cpu_baseline_distmat(eng, lay, wl, lo, hi, stc)
+            cpu = cpu_baseline_distmat(eng, lay, wl, lo, hi)
         else:
-            cpu = cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, stc, args.cpu_workers)
+            cpu = cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, args.cpu_workers)
 
     if world.rank == 0:
         total_windows = n_win * world.size * args.steps

@@ -13,6 +13,7 @@
 // Integer work is exact; float64 work is compiled with -ffp-contract=off so the per-site products are the
 // same IEEE operations, in the same order, as the NumPy expressions of the reference.
 #include "pg_internal.h"
+#include <algorithm>
 
 #define WAVE 64
 
@@ -75,10 +76,18 @@ __global__ __launch_bounds__(256) void k_synth(int8_t *__restrict__ gt, int S, i
 
 void pg_launch_synth(hipStream_t st, int8_t *gt, int S, int n_hap, int64_t site0, int64_t n_sites,
                      const int32_t *slot_gen_hap, PgSynthParams p) {
-    int64_t total = n_sites * (S >> 2);
-    if (total <= 0) return;
-    int64_t blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, st, gt, S, n_hap, site0, n_sites, slot_gen_hap, p);
+    // a launch holds at most 2^30 threads: a grid of 2^32 threads or more is silently truncated by the runtime (1e8 sites x 400
+    // haplotypes = 1e10 threads filled 14 % of the rows in one launch)
+    const int64_t groups = S >> 2;
+    if (n_sites <= 0 || groups <= 0) return;
+    const int64_t sites_per_launch = std::max<int64_t>(1, (1ll << 30) / groups);
+    for (int64_t a = 0; a < n_sites; a += sites_per_launch) {
+        const int64_t n = std::min(sites_per_launch, n_sites - a);
+        const int64_t blocks = (n * groups + 255) / 256;
+        PgSynthParams q = p;
+        q.first_site_index = p.first_site_index + a;
+        hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, st, gt, S, n_hap, site0 + a, n, slot_gen_hap, q);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------

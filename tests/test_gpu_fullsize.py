@@ -45,7 +45,9 @@ def check_popdist(e, lay, lo, hi, sel, st, min_sites):
         assert np.array_equal(C[k], Co), "C differs in window %d" % w
         assert np.array_equal(D[k], Do), "D differs in window %d" % w
         so, _ = orc.group_dist_stats(aln, Do, Co, True, min_sites, 0.01)     # genomics.py:956-995
+        assert Do.max() > 0 and Co.min() >= 0 and Co.max() > (hi[w] - lo[w]) // 2, "window %d holds no called data" % w
         for key, v in so.items():
+            assert np.isfinite(v), (key, w)
             assert G.close(st[key][w], v), (key, w, st[key][w], v)
 
 

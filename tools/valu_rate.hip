@@ -1,9 +1,9 @@
 // Micro-benchmark: sustained issue rate of the integer VALU ops the pair kernels are made of (gfx950).
 //   hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o tools/valu_rate && tools/valu_rate
-// Every mode runs 16 independent accumulator chains per lane, 8 waves per SIMD (2048 blocks x 256 threads on 256 CUs), and
-// reports (i) wave-instructions per second by wall clock and (ii) SIMD cycles per wave-instruction by the shader clock
-// (s_memtime of the first and last instruction of one wave: independent of where DVFS puts the clock), next to the
-// guide's 2 cycles per wave64 instruction on a SIMD-32.
+// Every mode runs 16 independent accumulator chains per lane at 8 / 4 / 2 waves per SIMD (blocks of 256 threads on 256 CUs) and
+// reports wave-instructions per second by wall clock (HIP events), and what that is in SIMD cycles per instruction if the
+// clock were the nominal 2.4 GHz (the guide's figure is 2 cycles per wave64 instruction on a SIMD-32; the part clocks lower
+// under a dense VALU stream, v_add_u32 / v_fma_f32 are the reference lines).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -11,6 +11,7 @@
 enum {
     M_AND_BCNT_DEP,     // v_and(sgpr) -> v_bcnt(acc) back to back on the same temporary        (naive k_pairC body)
     M_AND_BCNT_ILV,     // 8 x v_and into 8 temporaries, then 8 x v_bcnt(acc)                     (k_pairC as scheduled)
+    M_ANDV_BCNT_ILV,    // the same with the row operand in a VGPR instead of an SGPR
     M_AND_SGPR,         // v_and_b32 v, s, v
     M_AND_VGPR,         // v_and_b32 v, v, v
     M_BCNT_ACC,         // v_bcnt_u32_b32 acc, v, acc
@@ -34,13 +35,15 @@ __global__ __launch_bounds__(256) void k_rate(uint32_t *out, unsigned long long 
     for (int k = 0; k < 8; ++k) t[k] = k;
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
-        if (MODE == M_AND_BCNT_ILV || MODE == M_XOR_BITOP_BCNT) {
+        if (MODE == M_AND_BCNT_ILV || MODE == M_ANDV_BCNT_ILV || MODE == M_XOR_BITOP_BCNT) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     if (MODE == M_AND_BCNT_ILV)
                         asm volatile("v_and_b32 %0, %1, %2" : "=v"(t[k]) : "s"(s0 + k), "v"(x));
+                    else if (MODE == M_ANDV_BCNT_ILV)
+                        asm volatile("v_and_b32 %0, %1, %2" : "=v"(t[k]) : "v"(y), "v"(x));
                     else
                         asm volatile("v_xor_b32 %0, %1, %2" : "=v"(t[k]) : "s"(s0 + k), "v"(x));
                 }
@@ -113,8 +116,9 @@ void run(const char *name, int ops_per_iter, int waves_per_simd) {
     const double per_wave = (double)iters * ops_per_iter;
     const double winstr = (double)blocks * 4 * per_wave;
     // a wave's loop takes `cyc` shader cycles while waves_per_simd waves share its SIMD
-    printf("%-34s %d waves/SIMD %8.3f ms  %.3e wave-instr/s  %.2f SIMD cycles/instr (s_memtime)  clock %.2f GHz\n", name,
-           waves_per_simd, ms, winstr / (ms * 1e-3), cyc / (per_wave * waves_per_simd), cyc / (ms * 1e6));
+    (void)cyc;
+    printf("%-36s %d waves/SIMD %8.3f ms  %.3e wave-instr/s  = %.2f SIMD cycles/instr at 2.4 GHz\n", name, waves_per_simd, ms,
+           winstr / (ms * 1e-3), 2.4e9 * 1024 / (winstr / (ms * 1e-3)));
     hipFree(d); hipFree(clk);
 }
 
@@ -123,6 +127,7 @@ int main() {
         if (wps == 8) {
             run<M_AND_BCNT_DEP>("v_and(s)->v_bcnt(acc) dependent", 32, 8);
             run<M_AND_BCNT_ILV>("8 v_and(s); 8 v_bcnt(acc)", 32, 8);
+            run<M_ANDV_BCNT_ILV>("8 v_and(v); 8 v_bcnt(acc)", 32, 8);
             run<M_AND_SGPR>("v_and_b32 v,s,v", 16, 8);
             run<M_AND_VGPR>("v_and_b32 v,v,v", 16, 8);
             run<M_BCNT_ACC>("v_bcnt_u32_b32 acc", 16, 8);
@@ -136,6 +141,7 @@ int main() {
         } else if (wps == 4) {
             run<M_AND_BCNT_DEP>("v_and(s)->v_bcnt(acc) dependent", 32, 4);
             run<M_AND_BCNT_ILV>("8 v_and(s); 8 v_bcnt(acc)", 32, 4);
+            run<M_ANDV_BCNT_ILV>("8 v_and(v); 8 v_bcnt(acc)", 32, 4);
             run<M_XOR_BITOP_BCNT>("8 v_xor(s); 8 v_bitop3(s); 8 v_bcnt", 48, 4);
             run<M_ADD>("v_add_u32", 16, 4);
         } else {
