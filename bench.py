@@ -62,7 +62,8 @@ WORKLOADS = {
                  desc="tiny smoke workload"),
 }
 CPU_DISTMAT_HAPS = 120          # distMat CPU sample: 7140 pairs x 100 kb ~ 5 s per window
-CPU_SLICE_SITES = 10_000        # CPU sample: the first 10 000 sites of a window per worker (~10 s of CPU work at 400 haplotypes)
+CPU_SLICE_SITES = 4_000         # CPU sample: the first 4000 sites of a window per worker (~4 s of CPU work at 400 haplotypes on an idle core,
+                                # ~10x that with every hardware thread of a 256-thread host busy)
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GUIDE = 1024 * 2.4e9 / 2      # wave64 VALU instructions per second: 256 CUs x 4 SIMD-32, 2 cycles each, 2.4 GHz (guide)
 VALU_PAIRSITES_PEAK = 3.6e14    # 7 lane-ops per 32 pair-sites at 7.9e13 lane-ops/s
@@ -304,7 +305,8 @@ def main():
     roofline = None
     extra = {}
     # rocprofv3's names of the kernel behind each family, for this workload
-    pack_name = "k_pack2" if (os.environ.get("PG_PACK2") or n_hap > 1024) else "k_pack3"
+    pack_name = "k_pack3" if ((lay.n_hap + 15) // 16 * 4 <= 64 and not os.environ.get("PG_PACK2")) or (
+        os.environ.get("PG_PACK3") and n_hap <= 1024) else "k_pack2"
     if os.environ.get("PG_PAIR_V1"):
         rocprof_name = {_lib.K_PACK: "k_pack", _lib.K_PAIRWISE: "k_pairwise"}
     else:

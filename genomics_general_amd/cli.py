@@ -143,7 +143,7 @@ class Run:
         self.world = dist.world_from_env()
         self._t_start = time.perf_counter()
         self.timing = {"read_s": 0.0, "text_bytes": 0, "tokenize_s": 0.0, "windows_s": 0.0, "sites": 0, "windows": 0,
-                       "engine_and_upload_s": 0.0, "upload_s": 0.0, "chunks": 0}   # printed as JSON on stderr when PG_TIMING=1
+                       "engine_and_upload_s": 0.0, "upload_s": 0.0, "prep_wait_s": 0.0, "chunks": 0}   # printed as JSON on stderr when PG_TIMING=1
         t0 = time.perf_counter()
         self._reader = genoio.open_input(args.genoFile)
         if header_line:
@@ -181,74 +181,164 @@ class Run:
                 break
 
     def chunks(self):
-        """Generator over the pieces of the input; see the class docstring."""
+        """Generator over the pieces of the input; see the class docstring.
+
+        Three stages run beside each other: a reader thread fetches (and gunzips) block k+2, a tokenizer thread turns block k+1
+        into rows and finds its windows (K0 + windows.*Stream), and this thread uploads and computes block k.  With an engine
+        that offers them (Engine.upload_async / upload_wait; tests/cpu_engine.py mimics them), the rows are tokenised straight
+        into page-locked memory at the engine's row pitch and go down asynchronously into one half of the resident rows while
+        the windows of the previous block are still being computed in the other half; packed `.pgeno` cells are uploaded as
+        they are and expanded on the device (PG_HOST_UNPACK=1 keeps the host decoder)."""
+        import os
         import queue
         import threading
         import time
-        carry = None
+        eng = self.engine
+        piped = hasattr(eng, "upload_async")
+        pitch = eng.row_pitch if piped else None
+        alloc = eng.pinned.empty if piped else None
+        keep_packed = bool(piped and getattr(self._reader, "packed", False) and not os.environ.get("PG_HOST_UNPACK"))
         # the next block is read (and gunzipped) by a helper thread while this one is tokenised and computed
         blocks = queue.Queue(maxsize=1)
+        prepared = queue.Queue(maxsize=1)
+        stop = threading.Event()
+
+        def put(q, item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
                 while True:
                     b = self._reader.read_block(self._block_bytes)
-                    blocks.put(b)
-                    if self._block_bytes is None or len(b) == 0:
+                    if not put(blocks, b) or self._block_bytes is None or len(b) == 0:
                         return
             except BaseException as exc:                  # surfaced in the consumer
-                blocks.put(exc)
+                put(blocks, exc)
+
+        def prepare():
+            """tokenise block after block behind the rows carried over from the previous one; find the windows that are certain"""
+            carry = None
+            try:
+                while True:
+                    t0 = time.perf_counter()
+                    body = blocks.get()
+                    if isinstance(body, BaseException):
+                        raise body
+                    final = self._streamer is None or len(body) == 0
+                    tm = {"read_s": time.perf_counter() - t0}             # time this stage waited for the reader
+                    t0 = time.perf_counter()
+                    block = self._reader.to_geno(body, self.layout, n_threads=self._tok_threads,
+                                                 head_rows=carry.n_sites if carry is not None else 0, pitch=pitch, alloc=alloc,
+                                                 keep_packed=keep_packed)
+                    del body
+                    data = genoio.concat(carry, block)
+                    tm["tokenize_s"] = time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    if self._streamer is not None:
+                        T, keep_from = self._streamer.feed(data.run_starts, data.run_names, data.pos, final)
+                    else:
+                        T = (self._windows_fn(data) if self._windows_fn
+                             else _make_windows(self._wparams, data, self._minSites, self._coords_keep))
+                        T.dup = np.zeros(T.n, dtype=bool)
+                        keep_from = data.n_sites
+                    tm["windows_s"] = time.perf_counter() - t0
+                    carry = None if final else genoio.tail(data, keep_from)
+                    if not put(prepared, (data, T, final, int(block.n_sites), tm)) or final:
+                        return
+            except BaseException as exc:
+                put(prepared, exc)
 
         threading.Thread(target=produce, daemon=True).start()
-        while True:
-            t0 = time.perf_counter()
-            body = blocks.get()
-            if isinstance(body, BaseException):
-                raise body
-            final = self._streamer is None or len(body) == 0
-            self.timing["read_s"] += time.perf_counter() - t0          # time this thread waited for the reader
-            self.timing["text_bytes"] = self._reader.bytes_read
-            t0 = time.perf_counter()
-            block = self._reader.to_geno(body, self.layout, n_threads=self._tok_threads,
-                                         head_rows=carry.n_sites if carry is not None else 0)
-            del body
-            self.data = genoio.concat(carry, block)
-            self.timing["tokenize_s"] += time.perf_counter() - t0
-            t0 = time.perf_counter()
-            if self._streamer is not None:
-                self.T, keep_from = self._streamer.feed(self.data.run_starts, self.data.run_names, self.data.pos, final)
-            else:
-                self.T = (self._windows_fn(self.data) if self._windows_fn
-                          else _make_windows(self._wparams, self.data, self._minSites, self._coords_keep))
-                self.T.dup = np.zeros(self.T.n, dtype=bool)
-                keep_from = self.data.n_sites
-            self.timing["windows_s"] += time.perf_counter() - t0
-            self.timing["sites"] += int(block.n_sites)
-            self.timing["windows"] += int(self.T.n)
-            self.timing["chunks"] += 1
-            self.n_tested += int(self.T.n)
-            t0 = time.perf_counter()
-            # this rank's windows (contiguous range) and only the sites they cover
-            self.w0, self.w1 = dist.shard_range(self.T.n, self.world.size, self.world.rank)
-            lo, hi = self.T.lo[self.w0:self.w1], self.T.hi[self.w0:self.w1]
+        threading.Thread(target=prepare, daemon=True).start()
+
+        def take(block=True):
+            try:
+                item = prepared.get(block=block)
+            except queue.Empty:
+                return None
+            if isinstance(item, BaseException):
+                raise item
+            return item
+
+        def stage(item, k, other_half_busy):
+            """this rank's windows of the chunk, the rows they cover, and (piped) the start of their upload into half k % 2 of the
+            resident rows; returns None when the rows do not fit and the other half cannot be given up yet"""
+            data, T, final, n_new, tm = item
+            w0, w1 = dist.shard_range(T.n, self.world.size, self.world.rank)
+            lo, hi = T.lo[w0:w1], T.hi[w0:w1]
             nz = hi > lo
-            if np.any(nz):
-                s0, s1 = int(lo[nz].min()), int(hi[nz].max())
-            else:
-                s0 = s1 = 0
+            s0, s1 = (int(lo[nz].min()), int(hi[nz].max())) if np.any(nz) else (0, 0)
+            base = 0
             t1 = time.perf_counter()
-            self.engine.load_sites(self.data.gt[s0:s1])
-            self.timing["upload_s"] += time.perf_counter() - t1          # part of engine_and_upload_s
-            self.site0 = s0
-            self.lo, self.hi = lo - s0, hi - s0
-            self.lo[~nz] = 0
-            self.hi[~nz] = 0
-            self.timing["engine_and_upload_s"] += time.perf_counter() - t0
-            if self.T.n:
-                yield self
-            if final:
-                break
-            carry = genoio.tail(self.data, keep_from)
+            if piped:
+                rows = s1 - s0
+                if rows > self._half:
+                    if other_half_busy:
+                        return None
+                    self._half = max(rows + rows // 4, 1 << 16)
+                    eng.reserve(2 * self._half)
+                base = (k % 2) * self._half
+                if rows > 0 and data.packed:
+                    eng.upload_packed_async(data.gt[s0:s1], base, self.layout.slot_src)
+                elif rows > 0:
+                    eng.upload_async(data.gt[s0:s1], base)
+            lo, hi = lo - s0 + base, hi - s0 + base
+            lo[~nz] = 0
+            hi[~nz] = 0
+            return dict(data=data, T=T, final=final, n_new=n_new, tm=tm, w0=w0, w1=w1, lo=lo, hi=hi, s0=s0, s1=s1, base=base,
+                        t_stage=time.perf_counter() - t1)
+
+        self._half = 0
+        k = 0
+        staged, waiting = None, None          # chunk k+1: upload already queued / taken from the queue but not yet uploadable
+        try:
+            while True:
+                t0 = time.perf_counter()
+                if staged is not None:
+                    cur, staged = staged, None
+                else:
+                    item = waiting if waiting is not None else take()
+                    waiting = None
+                    cur = stage(item, k, other_half_busy=False)
+                self.timing["prep_wait_s"] += time.perf_counter() - t0      # time this thread waited for the tokenizer stage
+                t0 = time.perf_counter()
+                if piped:
+                    eng.upload_wait()
+                else:
+                    eng.load_sites(cur["data"].gt[cur["s0"]:cur["s1"]])
+                self.timing["upload_s"] += time.perf_counter() - t0 + cur["t_stage"]
+                self.timing["engine_and_upload_s"] += time.perf_counter() - t0 + cur["t_stage"]
+                for key in ("read_s", "tokenize_s", "windows_s"):
+                    self.timing[key] += cur["tm"][key]
+                self.timing["text_bytes"] = self._reader.bytes_read
+                self.data, self.T, self.w0, self.w1 = cur["data"], cur["T"], cur["w0"], cur["w1"]
+                self.lo, self.hi, self.site0 = cur["lo"], cur["hi"], cur["s0"] - cur["base"]
+                self.timing["sites"] += cur["n_new"]
+                self.timing["windows"] += int(self.T.n)
+                self.timing["chunks"] += 1
+                self.n_tested += int(self.T.n)
+                # when the tokenizer is ahead, the next chunk's rows go down while this chunk's windows are computed
+                if piped and not cur["final"]:
+                    waiting = take(block=False)
+                    if waiting is not None:
+                        staged = stage(waiting, k + 1, other_half_busy=True)
+                        if staged is not None:
+                            waiting = None
+                if self.T.n:
+                    yield self
+                if cur["final"]:
+                    break
+                k += 1
+        finally:
+            stop.set()
+            if piped:
+                eng.upload_wait()
         self._reader.close()
 
     def report_timing(self):
@@ -259,7 +349,9 @@ class Run:
         if os.environ.get("PG_TIMING") and self.world.rank == 0:
             t = dict(self.timing)
             t["total_s"] = time.perf_counter() - self._t_start
-            t["compute_and_write_s"] = t["total_s"] - t["read_s"] - t["tokenize_s"] - t["windows_s"] - t["engine_and_upload_s"]
+            # read / tokenize / windows run in their own threads: what this thread spent is the wait for them, the uploads it
+            # waited for, and the statistics + output
+            t["compute_and_write_s"] = t["total_s"] - t["prep_wait_s"] - t["engine_and_upload_s"]
             sys.stderr.write("PG_TIMING " + json.dumps(t) + "\n")
 
     def batch(self, mask):

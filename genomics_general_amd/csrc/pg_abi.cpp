@@ -58,6 +58,18 @@ extern "C" int pg_ctx_create(pg_ctx **out, int device) {
         delete c;
         return pg_fail(PG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    e = hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->up_ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        (void)hipStreamDestroy(c->stream2);
+    (void)hipStreamDestroy(c->stream_up);
+    if (c->up_ev) (void)hipEventDestroy(c->up_ev);
+    c->cells_stage.release();
+    c->slot_src.release();
+        delete c;
+        return pg_fail(PG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
     *out = c;
     return PG_OK;
 }
@@ -81,6 +93,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamSynchronize(c->stream_up);
     pg_comm_destroy(c);
     for (int k = 0; k < 2; ++k) {
         c->slot[k].Vp.release();
@@ -137,7 +150,7 @@ extern "C" int pg_sync(pg_ctx *c) {
 extern "C" int pg_host_alloc(size_t bytes, void **ptr_out) {
     if (!ptr_out) return pg_fail(PG_ERR_ARG, "pg_host_alloc: null argument");
     *ptr_out = nullptr;
-    HIPCHK(hipHostMalloc(ptr_out, bytes ? bytes : 1, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(ptr_out, bytes ? bytes : 1, hipHostMallocPortable));       // usable by every device and host thread
     return PG_OK;
 }
 
@@ -272,6 +285,8 @@ extern "C" int pg_reserve_sites(pg_ctx *c, int64_t n_sites) {
     if (n_sites < 0) return pg_fail(PG_ERR_ARG, "n_sites < 0");
     HIPCHK(hipSetDevice(c->device));
     if (n_sites <= c->cap_sites) return PG_OK;
+    HIPCHK(hipStreamSynchronize(c->stream_up));
+    c->up_pending = false;
     c->gt.release();
     int rc = c->gt.alloc((size_t)(n_sites + 32) * c->S);     // +32 rows so a word tile never reads past the end
     if (rc != PG_OK) return rc;
@@ -297,6 +312,66 @@ extern "C" int pg_download_sites(pg_ctx *c, int64_t off, int8_t *gt_out, int64_t
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy2DAsync(gt_out, c->n_hap, c->gt.p + off * c->S, c->S, c->n_hap, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+extern "C" int pg_row_pitch(pg_ctx *c, int *pitch_out) {
+    if (!c || !pitch_out) return pg_fail(PG_ERR_ARG, "pg_row_pitch: null argument");
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    *pitch_out = c->S;
+    return PG_OK;
+}
+
+// Asynchronous upload on the context's copy stream.  The host rows must stay valid (and should be page-locked: pg_host_alloc)
+// until pg_upload_wait returns.  Rows whose pitch equals pg_row_pitch (pad bytes zero) go down as one linear copy.
+extern "C" int pg_upload_sites_async(pg_ctx *c, int64_t off, const int8_t *gt, int64_t n, int64_t row_pitch) {
+    if (!c || (!gt && n > 0)) return pg_fail(PG_ERR_ARG, "pg_upload_sites_async: null argument");
+    if (off < 0 || n < 0 || off + n > c->cap_sites) return pg_fail(PG_ERR_ARG, "sites [%lld,%lld) exceed reserved %lld", (long long)off, (long long)(off + n), (long long)c->cap_sites);
+    if (row_pitch < c->n_hap) return pg_fail(PG_ERR_ARG, "row pitch %lld is smaller than the %d haplotypes of a row", (long long)row_pitch, c->n_hap);
+    if (n == 0) return PG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (row_pitch == c->S)
+        HIPCHK(hipMemcpyAsync(c->gt.p + off * c->S, gt, (size_t)n * c->S, hipMemcpyHostToDevice, c->stream_up));
+    else
+        HIPCHK(hipMemcpy2DAsync(c->gt.p + off * c->S, c->S, gt, (size_t)row_pitch, c->n_hap, (size_t)n, hipMemcpyHostToDevice, c->stream_up));
+    HIPCHK(hipEventRecord(c->up_ev, c->stream_up));
+    c->up_pending = true;
+    return PG_OK;
+}
+
+// Packed cells (one byte per genotype cell: first allele's one-hot code | second << 4, the `.pgeno` payload) are copied as they
+// are -- half the PCIe bytes of a diploid data set -- and expanded into resident rows by k_unpack on the copy stream.
+extern "C" int pg_upload_packed_async(pg_ctx *c, int64_t off, const uint8_t *cells, int64_t n, int n_cols, const int32_t *slot_src) {
+    if (!c || ((!cells || !slot_src) && n > 0)) return pg_fail(PG_ERR_ARG, "pg_upload_packed_async: null argument");
+    if (off < 0 || n < 0 || off + n > c->cap_sites) return pg_fail(PG_ERR_ARG, "sites [%lld,%lld) exceed reserved %lld", (long long)off, (long long)(off + n), (long long)c->cap_sites);
+    if (n_cols < 1) return pg_fail(PG_ERR_ARG, "n_cols < 1");
+    if (n == 0) return PG_OK;
+    for (int h = 0; h < c->n_hap; ++h)
+        if (slot_src[h] < -1 || slot_src[h] >= 2 * n_cols) return pg_fail(PG_ERR_ARG, "slot_src[%d] = %d out of range", h, slot_src[h]);
+    HIPCHK(hipSetDevice(c->device));
+    // the staging buffer and the table are reused by every upload: earlier users on the copy stream are done in stream order,
+    // a reallocation waits for them explicitly
+    if ((size_t)n * n_cols > c->cells_stage.cap) {
+        HIPCHK(hipStreamSynchronize(c->stream_up));
+        int rc = c->cells_stage.alloc((size_t)n * n_cols);
+        if (rc != PG_OK) return rc;
+    }
+    int rc = c->slot_src.upload(slot_src, (size_t)c->n_hap, c->stream_up);
+    if (rc != PG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(c->cells_stage.p, cells, (size_t)n * n_cols, hipMemcpyHostToDevice, c->stream_up));
+    pg_launch_unpack(c->stream_up, c->cells_stage.p, n_cols, n, c->slot_src.p, c->n_hap, c->gt.p + off * c->S, c->S);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->up_ev, c->stream_up));
+    c->up_pending = true;
+    return PG_OK;
+}
+
+extern "C" int pg_upload_wait(pg_ctx *c) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (!c->up_pending) return PG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->up_ev));
+    c->up_pending = false;
     return PG_OK;
 }
 

@@ -92,6 +92,13 @@ struct pg_ctx {
     // v2 software pipeline: k_pack2 of sub-batch k+1 (HBM-bound, stream2) overlaps the pair kernels of sub-batch k
     // (VALU-bound, stream).  Two slots of planes / window tables.
     hipStream_t stream2 = nullptr;
+    // ingestion: host -> device copies (and the device-side expansion of packed cells) run on their own stream, so that the
+    // upload of input block k+1 overlaps the kernels of block k; up_ev = end of the last queued upload
+    hipStream_t stream_up = nullptr;
+    hipEvent_t up_ev = nullptr;
+    bool up_pending = false;
+    DevBuf<uint8_t> cells_stage;     // packed cells of the upload in flight
+    DevBuf<int32_t> slot_src;        // pg_upload_packed_async: slot -> 2 * cell column + allele
     struct Slot {
         DevBuf<uint32_t> Vp, XV, pres;
         DevBuf<int64_t> win;

@@ -86,6 +86,8 @@ void pg_launch_sample_het(hipStream_t st, const int32_t *Cmat, const int32_t *Dm
 void pg_launch_hapstats(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                         const int32_t *pop_start, int n_pops, int max_pop, const int32_t *order, int min_pair_sites, int diag_nan,
                         double max_dist, uint32_t *bits, size_t bits_per_window, double *out);
+void pg_launch_unpack(hipStream_t st, const uint8_t *cells, int n_cols, int64_t n_rows, const int32_t *slot_src, int n_hap,
+                      int8_t *gt, int S);
 void pg_launch_flag_export(hipStream_t st, int32_t *flag, double *dst);
 void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts, int n_win, const int32_t *pop_start,
                         int n_pops, double min_data, int do_pairs, double *out);

@@ -571,6 +571,45 @@ void pg_launch_hapstats(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat
                        min_pair_sites, diag_nan, max_dist, bits, bits_per_window, out);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K_unpack: packed genotype cells -> resident rows, on the device (the host ships 1 byte per diploid
+// genotype -- first allele's one-hot code in the low nibble, second allele's in the high nibble, the `.pgeno` cell -- instead of
+// 1 byte per allele; replaces the host half of what splitSeq / seqArrayToNumArray do in the reference, genomics.py:390-396,
+// 74-77).  Thread = 4 slots of one row; slot_src[slot] = 2 * cell column + allele (or -1: slot stays 0 = missing).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ cells, int n_cols, int64_t n_rows,
+                                                const int32_t *__restrict__ slot_src, int n_hap, int8_t *__restrict__ gt, int S) {
+    const int groups = S >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = idx / groups;
+    if (row >= n_rows) return;
+    const int g = (int)(idx - row * groups);
+    const uint8_t *c = cells + row * n_cols;
+    uint32_t word = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = 4 * g + k;
+        if (h >= n_hap) break;
+        const int src = slot_src[h];
+        if (src < 0) continue;
+        const uint32_t cell = c[src >> 1];
+        word |= ((src & 1) ? (cell >> 4) : (cell & 15u)) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(gt + row * (int64_t)S + 4 * g) = word;
+}
+
+void pg_launch_unpack(hipStream_t st, const uint8_t *cells, int n_cols, int64_t n_rows, const int32_t *slot_src, int n_hap,
+                      int8_t *gt, int S) {
+    const int64_t groups = S >> 2;
+    if (n_rows <= 0 || groups <= 0) return;
+    const int64_t rows_per_launch = std::max<int64_t>(1, (1ll << 30) / groups);     // a launch holds at most 2^30 threads
+    for (int64_t a = 0; a < n_rows; a += rows_per_launch) {
+        const int64_t n = std::min(rows_per_launch, n_rows - a);
+        hipLaunchKernelGGL(k_unpack, dim3((unsigned)((n * groups + 255) / 256)), dim3(256), 0, st, cells + a * n_cols, n_cols, n,
+                           slot_src, n_hap, gt + a * (int64_t)S, S);
+    }
+}
+
 // the diploid-shortcut verdict as a double next to the result table; re-arms the flag
 __global__ void k_flag_export(int32_t *__restrict__ flag, double *__restrict__ dst) {
     dst[0] = (double)flag[0];

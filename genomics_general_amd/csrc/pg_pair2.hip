@@ -646,8 +646,12 @@ template <int DIP>
 static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *gt, int S, const int64_t *win_lo,
                          const int64_t *win_hi, const int64_t *goff, const int64_t *vgoff, uint32_t *Vp, int NPv, uint32_t *XV,
                          int NP, int32_t *nw, int32_t *mismatch, uint32_t *pres, int capg) {
-    const bool pack2 = getenv("PG_PACK2") != nullptr;               // A/B: the two-visit kernel
-    if (!pack2 && threads <= 256) {
+    // One wave per block (<= 256 slots): k_pack3 -- no barriers, every row fetched once (PMC: 2.27 instead of 2.56 GB per C2 pass;
+    // same speed within the box-to-box spread).  Two and four waves per block: k_pack2 -- k_pack3's per-entry scalar loop runs in
+    // every wave and its flushes meet in block barriers; measured on the north-star shape (400 slots) 8.3-9.0 ms against
+    // k_pack2's 8.0 ms.  PG_PACK2=1 / PG_PACK3=1 force one kernel for A/B runs and tests.
+    const bool force2 = getenv("PG_PACK2") != nullptr, force3 = getenv("PG_PACK3") != nullptr;
+    if (threads <= 256 && !force2 && (threads <= 64 || force3)) {
         if (threads <= 64)
             hipLaunchKernelGGL((k_pack3<64, DIP>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg);
         else if (threads <= 128)

@@ -19,22 +19,30 @@ from . import _lib
 from ._lib import check
 
 
-def encode_text(buf, layout, n_threads=0, head_rows=0):
+def encode_text(buf, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, full_out=None):
     """K0 host tokenizer.  buf: bytes of complete `.geno` data lines (no header).
-    Returns (gt int8 [L][n_hap] in slot order, pos int32 [L], scaf_off int64 [L], scaf_len int32 [L]).
+    Returns (gt int8 [L][pitch or n_hap] in slot order, pos int32 [L], scaf_off int64 [L], scaf_len int32 [L]).
     head_rows > 0: gt and pos are views into arrays with that many spare rows in front (gt.base / pos.base), so that a
-    caller can put carried-over rows before the new ones without copying the new ones."""
+    caller can put carried-over rows before the new ones without copying the new ones.
+    pitch: bytes per output row (the engine's row pitch: columns past n_hap stay zero, and the rows can be uploaded with one
+    linear copy); alloc(shape, dtype): allocator of the two big arrays (page-locked memory for asynchronous uploads);
+    full_out: a list that receives (gt_full, pos_full), the arrays including the spare head rows."""
     L = _lib.lib()
     n = C.c_int64(0)
     check(L.pg_count_lines(buf, len(buf), C.byref(n)))
     cap = max(int(n.value), 1)
-    gt = np.zeros((head_rows + cap, layout.n_hap), dtype=np.int8)[head_rows:]
-    pos = np.zeros(head_rows + cap, dtype=np.int32)[head_rows:]
+    width = int(pitch) if pitch else layout.n_hap
+    assert width >= layout.n_hap
+    alloc = alloc or np.zeros                   # (the tokenizer clears every row it writes, pad columns included)
+    gt_full, pos_full = alloc((head_rows + cap, width), np.int8), alloc((head_rows + cap,), np.int32)
+    if full_out is not None:
+        full_out.append((gt_full, pos_full))
+    gt, pos = gt_full[head_rows:], pos_full[head_rows:]
     soff = np.zeros(cap, dtype=np.int64)
     slen = np.zeros(cap, dtype=np.int32)
     got = C.c_int64(0)
     check(L.pg_encode_text(buf, len(buf), _lib.FMT[layout.genoFormat], len(layout.col_ploidy), layout.max_ploidy,
-                           np.ascontiguousarray(layout.col_slot), layout.col_ploidy, layout.n_hap, gt, pos, soff, slen,
+                           np.ascontiguousarray(layout.col_slot), layout.col_ploidy, width, gt, pos, soff, slen,
                            cap, C.byref(got), n_threads))
     k = int(got.value)
     return gt[:k], pos[:k], soff[:k], slen[:k]
@@ -45,17 +53,20 @@ class PinnedPool:
     PCIe speed.  A buffer returns to the pool when its array is garbage collected; the pool keeps at most `keep` bytes."""
 
     def __init__(self, keep=1 << 30):
+        import threading
         self._free = {}                  # nbytes -> [address]
         self._held = 0
         self._keep = keep
         self._L = _lib.lib()
+        self._lock = threading.Lock()    # arrays are allocated by the tokenizer thread and released wherever they die
 
     def _release(self, addr, nbytes):
-        if self._held + nbytes <= self._keep:
-            self._free.setdefault(nbytes, []).append(addr)
-            self._held += nbytes
-        else:
-            self._L.pg_host_free(C.c_void_p(addr))
+        with self._lock:
+            if self._held + nbytes <= self._keep:
+                self._free.setdefault(nbytes, []).append(addr)
+                self._held += nbytes
+                return
+        self._L.pg_host_free(C.c_void_p(addr))
 
     def zeros(self, shape, dtype):
         arr = self.empty(shape, dtype)
@@ -67,11 +78,13 @@ class PinnedPool:
         dtype = np.dtype(dtype)
         count = int(np.prod(shape))
         nbytes = max(count * dtype.itemsize, 1)
-        lst = self._free.get(nbytes)
-        if lst:
-            addr = lst.pop()
-            self._held -= nbytes
-        else:
+        addr = None
+        with self._lock:
+            lst = self._free.get(nbytes)
+            if lst:
+                addr = lst.pop()
+                self._held -= nbytes
+        if addr is None:
             p = C.c_void_p()
             check(self._L.pg_host_alloc(nbytes, C.byref(p)))
             addr = p.value
@@ -123,6 +136,33 @@ class Engine:
     def load_sites(self, gt):
         self.reserve(len(gt))
         self.upload(gt, 0)
+
+    # ---- streamed ingestion (uploads on the context's copy stream) ---------------------------------------------
+    @property
+    def row_pitch(self):
+        p = C.c_int(0)
+        check(self._L.pg_row_pitch(self._h, C.byref(p)))
+        return p.value
+
+    def upload_async(self, gt, offset=0):
+        """Queue the upload of int8 rows [n][pitch >= n_hap] (C-contiguous; page-locked for a real DMA) to resident rows
+        offset.. and return; `gt` must stay alive and unchanged until upload_wait()."""
+        assert gt.ndim == 2 and gt.dtype == np.int8 and gt.shape[1] >= self.layout.n_hap
+        assert gt.strides[1] == 1 and gt.strides[0] >= gt.shape[1]
+        check(self._L.pg_upload_sites_async(self._h, int(offset), C.c_void_p(gt.ctypes.data), gt.shape[0], gt.strides[0]))
+        self._in_flight = gt
+
+    def upload_packed_async(self, cells, offset, slot_src):
+        """Queue the upload of packed cells uint8 [n][n_cols] (`.pgeno` payload); they are expanded into slot order on the
+        device.  slot_src: layout.slot_src (2 * column + allele index per slot)."""
+        assert cells.ndim == 2 and cells.dtype == np.uint8 and cells.flags.c_contiguous
+        check(self._L.pg_upload_packed_async(self._h, int(offset), C.c_void_p(cells.ctypes.data), cells.shape[0], cells.shape[1],
+                                             np.ascontiguousarray(slot_src, dtype=np.int32)))
+        self._in_flight = cells
+
+    def upload_wait(self):
+        check(self._L.pg_upload_wait(self._h))
+        self._in_flight = None
 
     def download(self, offset, n):
         out = np.zeros((n, self.layout.n_hap), dtype=np.int8)

@@ -143,8 +143,8 @@ class BlockReader:
 
     packed = False
 
-    def to_geno(self, body, layout, n_threads=0, head_rows=0):
-        return encode(body, layout, n_threads, head_rows)
+    def to_geno(self, body, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, keep_packed=False):
+        return encode(body, layout, n_threads, head_rows, pitch, alloc)
 
     def close(self):
         if self.f is not sys.stdin.buffer:
@@ -276,7 +276,10 @@ class PackedReader:
             got += b[3].size
         return out
 
-    def to_geno(self, raw_blocks, layout, n_threads=0, head_rows=0):
+    def to_geno(self, raw_blocks, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, keep_packed=False):
+        """GenoData of the raw blocks.  keep_packed: the cells stay packed (GenoData.packed, gt = uint8 [n][n_cols]) for
+        Engine.upload_packed_async, which expands them on the device; otherwise pg_decode_packed scatters the nibbles into slot
+        order on host threads (rows of `pitch` bytes when given).  alloc(shape, dtype): allocator of the big arrays."""
         if len(layout.col_ploidy) != self.n_cols:
             raise ValueError("layout was built for %d columns, the file has %d" % (len(layout.col_ploidy), self.n_cols))
         wanted = layout.col_ploidy > 0
@@ -285,15 +288,21 @@ class PackedReader:
             raise ValueError("sample %s was packed with ploidy %d but ploidy %d is requested" % (
                 self.names[bad], int(self.ploidy[bad]), int(layout.col_ploidy[bad])))
         n = sum(int(b[2].shape[0]) for b in raw_blocks)
-        gt = np.zeros((head_rows + max(n, 1), layout.n_hap), dtype=np.int8)[head_rows:head_rows + n]
-        pos = np.zeros(head_rows + max(n, 1), dtype=np.int32)[head_rows:head_rows + n]
+        alloc = alloc or np.zeros
+        width = self.n_cols if keep_packed else (int(pitch) if pitch else layout.n_hap)
+        gt_full = alloc((head_rows + max(n, 1), width), np.uint8 if keep_packed else np.int8)
+        pos_full = alloc((head_rows + max(n, 1),), np.int32)
+        gt, pos = gt_full[head_rows:head_rows + n], pos_full[head_rows:head_rows + n]
         starts, names, row = [], [], 0
         L = _lib.lib()
         for st, nm, p, cells in raw_blocks:
             k = int(p.shape[0])
-            check(L.pg_decode_packed(np.ascontiguousarray(cells), k, self.n_cols, layout.max_ploidy,
-                                     np.ascontiguousarray(layout.col_slot), layout.col_ploidy, layout.n_hap,
-                                     gt[row:row + k], n_threads))
+            if keep_packed:
+                gt[row:row + k] = cells
+            else:
+                check(L.pg_decode_packed(np.ascontiguousarray(cells), k, self.n_cols, layout.max_ploidy,
+                                         np.ascontiguousarray(layout.col_slot), layout.col_ploidy, width,
+                                         gt[row:row + k], n_threads))
             pos[row:row + k] = p
             for s_, n_ in zip(st, nm):
                 if names and names[-1] == n_ and int(s_) == 0:
@@ -301,7 +310,9 @@ class PackedReader:
                 starts.append(row + int(s_))
                 names.append(n_)
             row += k
-        return GenoData(gt, pos, np.asarray(starts, dtype=np.int64), names)
+        d = GenoData(gt, pos, np.asarray(starts, dtype=np.int64), names, packed=keep_packed)
+        d.spare = (gt_full, pos_full, head_rows)
+        return d
 
     def close(self):
         self.f.close()
@@ -372,9 +383,11 @@ def split_header(data, header_line=None):
 class GenoData:
     """Encoded input: one-hot int8 genotypes in device slot order, positions and scaffold runs."""
 
-    def __init__(self, gt, pos, run_starts, run_names):
+    def __init__(self, gt, pos, run_starts, run_names, packed=False):
         self.gt, self.pos, self.run_starts, self.run_names = gt, pos, run_starts, run_names
         self.n_sites = len(pos)
+        self.packed = packed              # gt holds packed `.pgeno` cells (uint8 [n][n_cols]) instead of slot-order codes
+        self.spare = None                 # (gt_full, pos_full, head_rows): the arrays gt / pos are views of, with spare rows in front
 
 
 def concat(a, b):
@@ -388,13 +401,14 @@ def concat(a, b):
     starts = np.concatenate([a.run_starts, (b.run_starts[1:] if merge else b.run_starts) + a.n_sites]).astype(np.int64)
     names = list(a.run_names) + list(b.run_names[1:] if merge else b.run_names)
     n = a.n_sites
-    gbase, pbase = b.gt.base, b.pos.base
-    if (gbase is not None and pbase is not None and gbase.ndim == 2 and gbase.shape[0] >= n + b.n_sites
-            and b.gt.ctypes.data == gbase.ctypes.data + n * gbase.shape[1] and b.pos.ctypes.data == pbase.ctypes.data + 4 * n):
-        gbase[:n] = a.gt
-        pbase[:n] = a.pos
-        return GenoData(gbase[:n + b.n_sites], pbase[:n + b.n_sites], starts, names)
-    return GenoData(np.concatenate([a.gt, b.gt]), np.concatenate([a.pos, b.pos]), starts, names)
+    if b.spare is not None and b.spare[2] >= n:
+        gfull, pfull, head = b.spare
+        gfull[head - n:head] = a.gt
+        pfull[head - n:head] = a.pos
+        d = GenoData(gfull[head - n:head + b.n_sites], pfull[head - n:head + b.n_sites], starts, names, b.packed)
+        d.spare = (gfull, pfull, head - n)
+        return d
+    return GenoData(np.concatenate([a.gt, b.gt]), np.concatenate([a.pos, b.pos]), starts, names, b.packed)
 
 
 def tail(d, keep_from):
@@ -403,11 +417,12 @@ def tail(d, keep_from):
         return None
     r = int(np.searchsorted(d.run_starts, keep_from, side="right")) - 1
     starts = np.concatenate([[0], d.run_starts[r + 1:] - keep_from]).astype(np.int64)
-    return GenoData(d.gt[keep_from:].copy(), d.pos[keep_from:].copy(), starts, list(d.run_names[r:]))
+    return GenoData(d.gt[keep_from:].copy(), d.pos[keep_from:].copy(), starts, list(d.run_names[r:]), d.packed)
 
 
-def encode(data, layout, n_threads=0, head_rows=0):
-    gt, pos, soff, slen = encode_text(data, layout, n_threads, head_rows)
+def encode(data, layout, n_threads=0, head_rows=0, pitch=None, alloc=None):
+    full = []
+    gt, pos, soff, slen = encode_text(data, layout, n_threads, head_rows, pitch, alloc, full)
     n = len(pos)
     L = _lib.lib()
     cap = 1024
@@ -422,4 +437,6 @@ def encode(data, layout, n_threads=0, head_rows=0):
         break
     starts = starts[:nr.value]
     names = [data[int(soff[i]):int(soff[i]) + int(slen[i])].decode("utf-8", "replace") for i in starts]
-    return GenoData(gt, pos, starts, names)
+    d = GenoData(gt, pos, starts, names)
+    d.spare = (full[0][0], full[0][1], head_rows)
+    return d

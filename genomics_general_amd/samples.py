@@ -105,6 +105,11 @@ class HapLayout:
             sl = self.ind_slots[nm]
             self.col_ploidy[c] = len(sl)
             self.col_slot[c, :len(sl)] = sl
+        # device-side expansion of packed `.pgeno` cells (pg_upload_packed_async): slot -> 2 * file column + allele index
+        self.slot_src = np.full(self.n_hap, -1, dtype=np.int32)
+        for c in range(n_cols):
+            for k in range(int(self.col_ploidy[c])):
+                self.slot_src[self.col_slot[c, k]] = 2 * c + k
         # order of the reference's Alignment rows: haplotypes sorted by name (genomics.py:1122)
         self.ref_order = np.argsort(np.array(self.hap_names))
 

@@ -71,6 +71,25 @@ int pg_reserve_sites(pg_ctx *ctx, int64_t n_sites);
 /* Copy gt[n_sites][n_hap] (tightly packed rows) to sites [site_offset, site_offset+n_sites). */
 int pg_upload_sites(pg_ctx *ctx, int64_t site_offset, const int8_t *gt, int64_t n_sites);
 int pg_download_sites(pg_ctx *ctx, int64_t site_offset, int8_t *gt_out, int64_t n_sites);
+/* ---- streamed ingestion: uploads that overlap the kernels of the previous input block ------------------------------------ */
+/* Bytes per resident row (n_hap rounded up to 16; pad bytes zero).  A tokenizer / decoder that is told n_hap = this pitch
+ * writes rows that pg_upload_sites_async copies in one piece. */
+int pg_row_pitch(pg_ctx *ctx, int *pitch_out);
+/* pg_upload_sites on the context's copy stream, returning at once: gt[n_sites] rows of row_pitch bytes (>= n_hap; == pg_row_pitch
+ * for a single linear copy), which must stay valid -- page-locked (pg_host_alloc) for a real DMA -- until pg_upload_wait.  The
+ * window calls of the context do not wait for it: upload block k+1 into rows the windows of block k do not touch (e.g. the
+ * other half of the reserved rows), call pg_upload_wait before using them.  Replaces, together with pg_encode_text, the
+ * reference's serial parse -> queue -> genoToAlignment hand-over (popgenWindows.py:386-403, 445-447, genomics.py:1101-1127). */
+int pg_upload_sites_async(pg_ctx *ctx, int64_t site_offset, const int8_t *gt, int64_t n_sites, int64_t row_pitch);
+/* The same for packed genotype cells (the `.pgeno` payload: cells[n_sites][n_cols], one byte per cell = first allele's one-hot
+ * code | second allele's << 4): the cells cross PCIe as they are (0.5 byte per allele call of a diploid) and are expanded into
+ * resident rows on the device (k_unpack; the host half of genomics.py:390-396, 74-77).  slot_src[n_hap]: 2 * column + allele
+ * index (0/1) feeding each slot, -1 = slot unused. */
+int pg_upload_packed_async(pg_ctx *ctx, int64_t site_offset, const uint8_t *cells, int64_t n_sites, int n_cols,
+                           const int32_t *slot_src);
+/* Block until every queued asynchronous upload of the context has landed. */
+int pg_upload_wait(pg_ctx *ctx);
+
 /* Fill sites on device with the counter-based synthetic generator (genomics_general_amd/synth.py is
  * the specification).  Dense layout: site i is scaffold i / scaf_len, position i % scaf_len + 1.
  * slot_gen_hap[h] = generator haplotype index held by device slot h. */

@@ -7,18 +7,64 @@ import numpy as np
 from oracle import popgen_oracle as orc
 
 
+class _Pool:
+    @staticmethod
+    def empty(shape, dtype):
+        return np.full(shape, 0x55, dtype=dtype)        # like page-locked memory: not cleared
+
+
 class CpuEngine:
+    """Mimics the ingestion interface of engine.Engine (reserve / row_pitch / upload_async / upload_packed_async / upload_wait
+    next to load_sites), so that cli.Run's pipelined path -- rows tokenised at the row pitch, uploads into alternating halves of
+    the resident rows -- runs in the CPU tests; an upload only becomes visible at upload_wait(), and the rows must be unchanged
+    by then."""
+
     def __init__(self, device=0):
         self.device = device
         self.gt = None
+        self.pinned = _Pool()
+        self._queued = []
 
     def set_layout(self, layout):
         self.layout = layout
 
+    @property
+    def row_pitch(self):
+        return (self.layout.n_hap + 15) // 16 * 16
+
+    def reserve(self, n_sites):
+        assert not self._queued, "reserve with uploads in flight"
+        if self.gt is None or len(self.gt) < n_sites:
+            self.gt = np.zeros((n_sites, self.layout.n_hap), dtype=np.int8)
+
     def load_sites(self, gt):
-        self.gt = np.array(gt, dtype=np.int8, copy=True)
+        self.gt = np.array(gt, dtype=np.int8, copy=True)[:, :self.layout.n_hap]
+
+    def upload_async(self, gt, offset=0):
+        assert gt.dtype == np.int8 and gt.shape[1] >= self.layout.n_hap and offset + len(gt) <= len(self.gt)
+        assert not gt[:, self.layout.n_hap:].any(), "pad columns must be zero"
+        self._queued.append((offset, gt, gt.copy(), None))
+
+    def upload_packed_async(self, cells, offset, slot_src):
+        assert cells.dtype == np.uint8 and offset + len(cells) <= len(self.gt)
+        self._queued.append((offset, cells, cells.copy(), np.asarray(slot_src)))
+
+    def upload_wait(self):
+        for offset, live, snap, slot_src in self._queued:
+            assert np.array_equal(live, snap), "host rows changed while their upload was in flight"
+            if slot_src is None:
+                self.gt[offset:offset + len(snap)] = snap[:, :self.layout.n_hap]
+            else:
+                col, k = slot_src >> 1, slot_src & 1
+                rows = np.where(k[None, :] == 1, snap[:, col] >> 4, snap[:, col] & 15).astype(np.int8)
+                rows[:, slot_src < 0] = 0
+                self.gt[offset:offset + len(snap)] = rows
+        self._queued = []
 
     def batch(self, lo, hi):
+        lo_a, hi_a = np.asarray(lo, dtype=np.int64), np.asarray(hi, dtype=np.int64)
+        for offset, live, _, _ in self._queued:              # an upload in flight may only target rows no window reads
+            assert not np.any((hi_a > lo_a) & (lo_a < offset + len(live)) & (hi_a > offset)), "window reads rows being uploaded"
         return CpuBatch(self, lo, hi)
 
     def close(self):
