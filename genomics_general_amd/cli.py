@@ -137,7 +137,8 @@ class Run:
     T, w0, w1, lo, hi, batch() and gather() refer to the windows that became certain with the current block.  Drivers that
     do not stream construct Run(..., stream=False): the single chunk is loaded by the constructor."""
 
-    def __init__(self, args, sampleData, wparams, minSites, header_line=None, coords_keep=4, windows_fn=None, stream=False):
+    def __init__(self, args, sampleData, wparams, minSites, header_line=None, coords_keep=4, windows_fn=None, stream=False,
+                 shardable=False):
         import os
         import time
         self.world = dist.world_from_env()
@@ -176,6 +177,21 @@ class Run:
         self.comm = dist.RcclComm(self.engine, self.world) if self.world.size > 1 else dist.SoloComm()
         self.timing["engine_and_upload_s"] += time.perf_counter() - t0
         self.n_tested = 0
+        # Multi-GPU ingestion.  Sharded (a driver that writes its rows through open_sink(), coordinate or sites windows, plain
+        # text or `.pgeno` on disk, enough scaffold runs): every rank reads, tokenises and computes only its own run-aligned
+        # slice of the input and formats its own rows; ONE gather of the finished rows at the end, rank 0 writes.  Otherwise
+        # replicated: every rank tokenises the whole input, the windows of every block are split over the ranks, one all-gather
+        # of the statistics per block.
+        self.sharded = False
+        self._wshare = (self.world.size, self.world.rank)
+        if (shardable and self.world.size > 1 and self._streamer is not None and wparams["windType"] in ("coordinate", "sites")
+                and os.environ.get("PG_SHARD_INPUT", "1") != "0"):
+            inc = set(_lines(args.include)) if args.include else None
+            exc = set(_lines(args.exclude)) if args.exclude else None
+            self.sharded = self._reader.shard(self.world, self.comm, lambda nm: windows._wanted(nm, inc, exc))
+            if self.sharded:
+                self._wshare = (1, 0)
+                self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size)
         if not stream:
             for _ in self.chunks():
                 break
@@ -270,7 +286,7 @@ class Run:
             """this rank's windows of the chunk, the rows they cover, and (piped) the start of their upload into half k % 2 of the
             resident rows; returns None when the rows do not fit and the other half cannot be given up yet"""
             data, T, final, n_new, tm = item
-            w0, w1 = dist.shard_range(T.n, self.world.size, self.world.rank)
+            w0, w1 = dist.shard_range(T.n, self._wshare[0], self._wshare[1])
             lo, hi = T.lo[w0:w1], T.hi[w0:w1]
             nz = hi > lo
             s0, s1 = (int(lo[nz].min()), int(hi[nz].max())) if np.any(nz) else (0, 0)
@@ -346,8 +362,9 @@ class Run:
         import json
         import os
         import time
-        if os.environ.get("PG_TIMING") and self.world.rank == 0:
+        if os.environ.get("PG_TIMING") and (self.world.rank == 0 or self.sharded):
             t = dict(self.timing)
+            t["rank"], t["sharded_input"], t["input_bytes"] = self.world.rank, self.sharded, self._reader.input_size()
             t["total_s"] = time.perf_counter() - self._t_start
             # read / tokenize / windows run in their own threads: what this thread spent is the wait for them, the uploads it
             # waited for, and the statistics + output
@@ -359,7 +376,56 @@ class Run:
         return self.engine.batch(self.lo[mask], self.hi[mask])
 
     def gather(self, table):
+        """the statistics of ALL windows of the current chunk on every rank (replicated ingestion: one all-gather per chunk);
+        with sharded ingestion the chunk's windows are this rank's alone"""
+        if self.sharded:
+            return np.asarray(table, dtype=np.float64)
         return dist.gather_table(self.comm, table, self.T.n)
+
+    def open_sink(self, path, header_text, id_column=False):
+        return _RowSink(self, path, header_text, id_column)
+
+
+class _RowSink:
+    """Where a table driver's finished rows go.  Replicated ingestion: rank 0 formats and writes everything (`local` is true
+    there only).  Sharded ingestion: every rank formats the rows of its own slice; rank 0 writes its own as it goes, the others
+    keep theirs, and close() brings them to rank 0 in ONE gather (rank order = input order) -- the sorter / writer threads of
+    popgenWindows.py:108-157.  Window IDs count the windows of the whole input (genomics.py:2011): the ranks' local IDs are
+    shifted by the number of windows of the ranks before them."""
+
+    def __init__(self, run, path, header_text, id_column):
+        self.run, self.id_column = run, id_column
+        self.local = run.sharded or run.world.rank == 0
+        self.rows, self.written = [], 0
+        self.out = None
+        if run.world.rank == 0:
+            self.out = _open_out(path)
+            self.out.write(header_text)
+
+    def write(self, text):
+        if self.out is not None:
+            self.out.write(text)
+        else:
+            self.rows.append(text)
+        self.written += 1
+
+    def close(self):
+        """-> (windows tested, rows written) of the whole job"""
+        run = self.run
+        tested, written = run.n_tested, self.written
+        if run.sharded:
+            counts = run.comm.allgather(np.array([float(run.n_tested), float(self.written)])).reshape(run.world.size, 2)
+            if self.id_column and run.world.rank > 0:
+                shift = int(counts[:run.world.rank, 0].sum())
+                self.rows = [str(int(r[:r.index(",")]) + shift) + r[r.index(","):] for r in self.rows]
+            parts = dist.gather_bytes(run.comm, "".join(self.rows).encode() if run.world.rank > 0 else b"")
+            if self.out is not None:
+                for part in parts[1:]:
+                    self.out.write(part.decode())
+            tested, written = int(counts[:, 0].sum()), int(counts[:, 1].sum())
+        if self.out is not None and self.out is not sys.stdout:
+            self.out.close()
+        return tested, written
 
 
 def _fmt_cell(v):
@@ -449,12 +515,9 @@ def popgen_main(argv=None):
             stats += [pre + n for n in popNames]
     int_stat = [s.startswith("l_") or s.startswith("S_") for s in stats]
 
-    run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=3, stream=True)
-    out = None
-    if run.world.rank == 0:
-        out = _open_out(args.outFile)
-        out.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites," + ",".join(stats) + "\n")
-    written = 0
+    run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=3, stream=True, shardable=True)
+    sink = run.open_sink(args.outFile, ("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites," + ",".join(stats) + "\n",
+                         id_column=args.addWindowID)
     last_row = None                      # (ok, text) of the previously emitted window: a dup row repeats it verbatim
     for _ in run.chunks():
         T = run.T
@@ -480,7 +543,7 @@ def popgen_main(argv=None):
             for c, s in enumerate(stats):
                 table[good, c] = sd[s]
         full = run.gather(table)
-        if run.world.rank != 0:
+        if not sink.local:
             continue
         for k in range(T.n):
             if T.dup[k]:
@@ -499,12 +562,10 @@ def popgen_main(argv=None):
                 last_row = (ok, text)
             if not (ok or args.writeFailedWindows):
                 continue
-            out.write(text)
-            written += 1
+            sink.write(text)
+    tested, written = sink.close()
     if run.world.rank == 0:
-        if out is not sys.stdout:
-            out.close()
-        sys.stderr.write(str(run.n_tested) + " windows were tested.\n")
+        sys.stderr.write(str(tested) + " windows were tested.\n")
         sys.stderr.write(str(written) + " results were written.\n")
         sys.stderr.write("\nDone.\n")
     run.report_timing()
@@ -573,12 +634,9 @@ def _quartet_main(argv, prog, stats, fourpop):
     ploidyDict = _ploidy_dict(args, allInds, args.haploid.split(",") if args.haploid else None)
     sampleData = SampleData(popNames=popNames, popInds=popInds, ploidyDict=ploidyDict)
 
-    run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=4, stream=True)
-    out = None
-    if run.world.rank == 0:
-        out = _open_out(args.outFile)
-        out.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites,sitesUsed," + ",".join(stats) + "\n")
-    written = 0
+    run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=4, stream=True, shardable=True)
+    sink = run.open_sink(args.outFile, ("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites,sitesUsed," +
+                         ",".join(stats) + "\n", id_column=args.addWindowID)
     last_row = None                      # (ok, text) of the previously emitted window: a dup row repeats it verbatim
     for _ in run.chunks():
         T = run.T
@@ -595,7 +653,7 @@ def _quartet_main(argv, prog, stats, fourpop):
             for c, s in enumerate(stats):
                 table[good, 1 + c] = sd[s]
         full = run.gather(table)
-        if run.world.rank != 0:
+        if not sink.local:
             continue
         for k in range(T.n):
             if T.dup[k]:
@@ -610,12 +668,10 @@ def _quartet_main(argv, prog, stats, fourpop):
                 last_row = (ok, text)
             if not (ok or args.writeFailedWindows):
                 continue
-            out.write(text)
-            written += 1
+            sink.write(text)
+    tested, written = sink.close()
     if run.world.rank == 0:
-        if out is not sys.stdout:
-            out.close()
-        sys.stderr.write("%d windows were tested\n%d results were written\n\nDone.\n" % (run.n_tested, written))
+        sys.stderr.write("%d windows were tested\n%d results were written\n\nDone.\n" % (tested, written))
     run.report_timing()
     run.comm.barrier()
     return 0

@@ -173,3 +173,17 @@ def gather_table(comm, local_rows, n_total):
     pad[:local_rows.shape[0]] = local_rows
     allr = comm.allgather(pad.ravel()).reshape(comm.size, width, k)
     return np.concatenate([allr[r, :counts[r]] for r in range(comm.size)], axis=0) if n_total else np.zeros((0, k))
+
+
+def gather_bytes(comm, data):
+    """One byte string per rank -> the list of all of them (in rank order) on every rank: two all-gathers, the sizes and the
+    payload padded to the largest (the bytes travel as the bit patterns of float64 words; an all-gather only copies)."""
+    data = bytes(data)
+    sizes = comm.allgather(np.array([float(len(data))])).ravel().astype(np.int64)
+    width = int((int(sizes.max()) + 7) // 8) if len(sizes) else 0
+    if width == 0:
+        return [b"" for _ in range(comm.size)]
+    buf = np.zeros(width * 8, dtype=np.uint8)
+    buf[:len(data)] = np.frombuffer(data, dtype=np.uint8)
+    allr = np.ascontiguousarray(comm.allgather(buf.view(np.float64))).reshape(comm.size, width)
+    return [allr[r].view(np.uint8)[:int(sizes[r])].tobytes() for r in range(comm.size)]

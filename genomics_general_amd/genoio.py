@@ -118,6 +118,8 @@ class BlockReader:
     left."""
 
     def __init__(self, path):
+        self.path = path
+        self.stop = None                  # byte offset at which this reader ends (restrict()); None = end of file
         if path is None:
             self.f = sys.stdin.buffer
         elif str(path).endswith(".gz"):
@@ -131,7 +133,30 @@ class BlockReader:
         self.bytes_read += len(line)
         return line
 
+    def seekable_text(self):
+        """plain (uncompressed) file on disk: byte ranges of it can be handed to different ranks"""
+        return self.path is not None and not str(self.path).endswith(".gz")
+
+    def restrict(self, start, stop):
+        """read only the bytes [start, stop) of the file from now on (both at line starts)"""
+        self.f.seek(start)
+        self.stop = stop
+
     def read_block(self, nbytes=None):
+        if self.stop is not None:
+            left = max(self.stop - self.f.tell(), 0)
+            if nbytes is None or nbytes >= left:
+                data = self.f.read(left)
+                self.bytes_read += len(data)
+                return data
+            data = self.f.read(nbytes)
+            if data and not data.endswith(b"\n"):
+                data += self.f.readline()
+            over = self.f.tell() - self.stop
+            if over > 0:                                 # cannot happen when stop is a line start; be safe
+                data = data[:len(data) - over]
+            self.bytes_read += len(data)
+            return data
         if nbytes is None:
             data = self.f.read()
         else:
@@ -143,12 +168,97 @@ class BlockReader:
 
     packed = False
 
+    def input_size(self):
+        return os.path.getsize(self.path) if self.path is not None and os.path.exists(str(self.path)) else -1
+
+    def shard(self, world, comm, wanted, max_share=0.75):
+        """Restrict this reader to rank `world.rank`'s slice of the data lines: the byte range between the scaffold-run
+        boundaries nearest to the equal split (find_run_boundary; each rank looks for its own start, one all-gather shares
+        them).  Returns False, leaving the reader untouched, when the input cannot be split (stdin, gzip) or has too few runs
+        for a useful split (some rank would hold more than max_share of the bytes)."""
+        if not self.seekable_text():
+            return False
+        size = os.path.getsize(self.path)
+        start = self.f.tell()                                  # the header line, if any, has been consumed
+        mine, scanned = float(start), 0
+        if world.rank > 0:
+            # the search starts a little before the equal split, so that a boundary sitting exactly on it (equal scaffolds) is
+            # not missed by a few bytes
+            stride = (size - start) // world.size
+            guess = start + stride * world.rank - min(max(stride // 64, 1 << 12), stride // 2)
+            cut, scanned = find_run_boundary(self.path, max(guess, start), wanted)
+            mine = float(cut)
+        cuts = [int(c) for c in comm.allgather(np.array([mine])).ravel()] + [size]
+        for r in range(1, len(cuts)):
+            cuts[r] = max(cuts[r], cuts[r - 1])
+        share = max(cuts[r + 1] - cuts[r] for r in range(world.size)) / max(size - start, 1)
+        self.bytes_read += scanned
+        if share > max_share:
+            return False
+        self.restrict(cuts[world.rank], cuts[world.rank + 1])
+        return True
+
     def to_geno(self, body, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, keep_packed=False):
         return encode(body, layout, n_threads, head_rows, pitch, alloc)
 
     def close(self):
         if self.f is not sys.stdin.buffer:
             self.f.close()
+
+
+def find_run_boundary(path, guess, wanted, chunk=8 << 10, max_chunk=16 << 20):
+    """Byte offset of the first data line at or behind offset `guess` that starts a new scaffold run whose own scaffold and the
+    preceding one are both wanted (`wanted(name) -> bool`: --include / --exclude), or the file size when there is none; and
+    the number of bytes scanned.  Windows never span scaffold runs, and the window generators carry state across a run
+    boundary only around skipped scaffolds (genomics.py:2016-2023), so such a boundary is a place where the input can be
+    split between ranks (the slice-parallel ingestion of the reference's freq.py:23-28, here on run boundaries)."""
+    import re
+    size = os.path.getsize(path)
+    scanned = 0
+    with open(path, "rb") as f:
+        # start at the line that holds the byte before `guess`: it names the run to the left of the first candidate line
+        back = min(guess, 4 << 20)
+        f.seek(guess - back)
+        head = f.read(back)
+        f.seek(guess - back + head.rfind(b"\n", 0, max(back - 1, 0)) + 1)
+        cur, pat = None, None
+        while True:
+            base = f.tell()
+            data = f.read(chunk)
+            chunk = min(2 * chunk, max_chunk)            # small reads first: the boundary is usually near
+            if not data:
+                return size, scanned
+            if not data.endswith(b"\n"):
+                data += f.readline()
+            scanned += len(data)
+            at = 0
+            while at < len(data):
+                if cur is None:                              # first data line of the scan: it only names the current run
+                    nl = data.find(b"\n", at)
+                    line = data[at:nl if nl >= 0 else len(data)]
+                    tok = line.split(None, 1)
+                    if tok and not line.startswith(b"#"):
+                        cur = tok[0]
+                        pat = re.compile(rb"\n(?!" + re.escape(cur) + rb"[ \t])")
+                    at = (nl + 1) if nl >= 0 else len(data)
+                    continue
+                m = pat.search(data, max(at - 1, 0))
+                if m is None:
+                    break
+                at = m.end()                                  # start of a line that does not begin with `cur` + blank
+                if at >= len(data):
+                    break
+                nl = data.find(b"\n", at)
+                line = data[at:nl if nl >= 0 else len(data)]
+                tok = line.split(None, 1)
+                if not tok or line.startswith(b"#"):          # blank or comment line: not a data row
+                    at = (nl + 1) if nl >= 0 else len(data)
+                    continue
+                prev, cur = cur, tok[0]
+                pat = re.compile(rb"\n(?!" + re.escape(cur) + rb"[ \t])")
+                if wanted(prev.decode("utf-8", "replace")) and wanted(cur.decode("utf-8", "replace")):
+                    return base + at, scanned
+                at = (nl + 1) if nl >= 0 else len(data)
 
 
 # ---- packed `.pgeno` files: a tokenised `.geno` kept on disk ---------------------------------------------------------------
@@ -217,6 +327,7 @@ class PackedReader:
 
     def __init__(self, path):
         import json
+        self.path = path
         self.f = open(path, "rb")
         if self.f.read(len(PGENO_MAGIC)) != PGENO_MAGIC:
             raise ValueError("%s is not a .pgeno file" % path)
@@ -229,9 +340,75 @@ class PackedReader:
         self.n_cols = len(self.names)
         self.bytes_read = len(PGENO_MAGIC) + 4 + hl
         self.done = False
+        self._rows = None                 # (first, last + 1) global row of this reader's share (shard()); None = everything
+        self._g = 0                       # global row of the next block
 
     def read_header(self):
         return ("#CHROM\tPOS\t" + "\t".join(self.names) + "\n").encode()
+
+    def input_size(self):
+        return os.path.getsize(self.path)
+
+    def _index(self):
+        """[(file offset, first global row, n_rows, run starts, run names)] of every block, read from the block headers alone
+        (payloads are skipped), and the file position restored"""
+        f, here, out, g = self.f, self.f.tell(), [], 0
+        while True:
+            off = f.tell()
+            raw = f.read(8)
+            n = int.from_bytes(raw, "little") if len(raw) == 8 else 0
+            if n == 0:
+                break
+            n_runs = int.from_bytes(f.read(4), "little")
+            starts, names = [], []
+            for _ in range(n_runs):
+                starts.append(int.from_bytes(f.read(8), "little"))
+                ln = int.from_bytes(f.read(2), "little")
+                names.append(f.read(ln).decode())
+            if self.codec == "none":
+                f.seek(4 * n + n * self.n_cols, 1)
+            else:
+                n_chunks = int.from_bytes(f.read(4), "little")
+                table = np.frombuffer(f.read(8 * n_chunks), dtype="<u4").reshape(-1, 2)
+                f.seek(int(table[:, 0].sum()), 1)
+            out.append((off, g, n, starts, names))
+            g += n
+        f.seek(here)
+        return out, g
+
+    def shard(self, world, comm, wanted, max_share=0.75):
+        """Restrict this reader to rank `world.rank`'s rows: the row range between the scaffold-run boundaries (both neighbours
+        wanted) nearest to the equal split, found from the block headers alone -- every rank computes the same plan, nothing is
+        exchanged.  Blocks that straddle a cut are inflated by both neighbours and trimmed.  False (reader untouched) when some
+        rank would hold more than max_share of the rows."""
+        blocks, total = self._index()
+        if total == 0:
+            return False
+        run_row, run_name = [], []                       # scaffold runs of the whole file
+        for _, g, _, starts, names in blocks:
+            for s_, n_ in zip(starts, names):
+                if run_name and run_name[-1] == n_ and s_ == 0:
+                    continue                             # the run continues across the block seam
+                run_row.append(g + s_)
+                run_name.append(n_)
+        ok = [run_row[k] for k in range(1, len(run_row)) if wanted(run_name[k - 1]) and wanted(run_name[k])]
+        cuts = [0]
+        for r in range(1, world.size):
+            stride = total // world.size
+            guess = stride * r - min(max(stride // 64, 1), stride // 2)
+            nxt = [c for c in ok if c >= guess]
+            cuts.append(max(nxt[0] if nxt else total, cuts[-1]))
+        cuts.append(total)
+        if max(cuts[r + 1] - cuts[r] for r in range(world.size)) / total > max_share:
+            return False
+        self._rows = (cuts[world.rank], cuts[world.rank + 1])
+        first = [b for b in blocks if b[1] + b[2] > self._rows[0]]
+        if first and self._rows[1] > self._rows[0]:
+            self.f.seek(first[0][0])
+            self._g = first[0][1]
+        else:
+            self.done = True
+        return True
 
     def _one(self):
         raw = self.f.read(8)
@@ -263,7 +440,20 @@ class PackedReader:
             raise ValueError("truncated .pgeno file")
         pos = np.frombuffer(payload, dtype="<i4", count=n)
         cells = np.frombuffer(payload, dtype=np.uint8, offset=4 * n).reshape(n, self.n_cols)
-        return (np.asarray(starts, dtype=np.int64), names, pos, cells)
+        starts = np.asarray(starts, dtype=np.int64)
+        g0, self._g = self._g, self._g + n
+        if self._rows is not None:                       # trim the block to this reader's rows
+            a, b = max(self._rows[0] - g0, 0), min(self._rows[1] - g0, n)
+            if g0 + n >= self._rows[1]:
+                self.done = True
+            if b <= a:
+                return self._one() if not self.done else None
+            if a > 0 or b < n:
+                keep = np.flatnonzero((starts < b) & (np.append(starts[1:], n) > a))
+                names = [names[k] for k in keep]
+                starts = np.maximum(starts[keep] - a, 0)
+                pos, cells = pos[a:b], cells[a:b]
+        return (starts, names, pos, cells)
 
     def read_block(self, nbytes=None):
         """list of raw blocks ([] at the end of the file); nbytes counts text bytes (about 4 per cell) like BlockReader's"""

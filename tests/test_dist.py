@@ -162,3 +162,50 @@ def test_drivers_with_two_ranks_write_the_single_rank_output(tmp_path):
         with open(out) as f, open(os.path.join(gold, name + ".out")) as g:
             got, want = f.read(), g.read()
         G.compare_text(align_columns(got, want), want, G.round_digits(case))
+
+
+def test_two_ranks_shard_the_input_at_scaffold_runs_and_gather_rows_once(tmp_path):
+    """Plain-text input on disk: each rank reads, tokenises and computes only its own run-aligned slice (cf. the slice-parallel
+    freq.py:23-28 of the reference), formats its own rows, and ONE gather at the end lets rank 0 write the reference's file --
+    window IDs, failed windows and the stderr totals included.  On the two-scaffold fixture each rank must have consumed at most
+    60 % of the input bytes."""
+    import gzip
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from cases import CASES
+    from golden_util import align_columns
+    import test_gpu_golden as G
+    gold = os.path.join(ROOT, "tests", "golden")
+    from genomics_general_amd import genoio
+    for k, (name, packed) in enumerate((("c1_popgen", False), ("sparse_overlap_failed_id", False), ("abba_windows_sites", False),
+                                        ("sparse_stepgap", False), ("c1_popgen", True), ("sparse_overlap_failed_id", True))):
+        case = [c for c in CASES if c["name"] == name][0]
+        geno = str(tmp_path / (case["fixture"] + ".geno"))
+        with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f, open(geno, "wb") as g:
+            g.write(f.read())
+        if packed:                                     # the same from a packed file: row ranges from the block headers
+            fmt = case["argv"][case["argv"].index("-f") + 1]
+            genoio.pack_geno(geno, geno[:-5] + ".pgeno", fmt, block_bytes=30000)
+            geno = geno[:-5] + ".pgeno"
+        out = str(tmp_path / (name + ".out"))
+        argv = [a.format(geno=geno, dir=gold, out=out) for a in case["argv"]] + ["-o", out]
+        procs = []
+        port = 33000 + (os.getpid() + 11 * k) % 2000
+        for rank in range(2):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       PG_STREAM_BYTES="20000", PG_TIMING="1")
+            procs.append(subprocess.Popen([sys.executable, "-c", CLI_WORKER, case["tool"]] + argv, env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE))
+        timing = []
+        for p in procs:
+            o, e = p.communicate(timeout=300)
+            assert p.returncode == 0, e.decode()[-1500:]
+            timing += [json.loads(ln[len("PG_TIMING "):]) for ln in e.decode().splitlines() if ln.startswith("PG_TIMING ")]
+        with open(out) as f, open(os.path.join(gold, name + ".out")) as g:
+            got, want = f.read(), g.read()
+        G.compare_text(align_columns(got, want), want, G.round_digits(case))
+        assert len(timing) == 2 and all(t["sharded_input"] for t in timing), timing
+        if name == "c1_popgen":
+            for t in timing:
+                assert t["text_bytes"] <= (0.65 if packed else 0.6) * t["input_bytes"], timing
+        assert sum(t["sites"] for t in timing) == sum(1 for ln in gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"))) - 1

@@ -41,3 +41,37 @@ def test_geno_pack_tool_writes_a_file_the_reader_decodes(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-400:]
     with open(out2, "rb") as f, open(str(tmp_path / "m_none.pgeno"), "rb") as g:
         assert f.read() == g.read()
+
+
+def test_packed_reader_row_shards_concatenate_to_the_whole(tmp_path):
+    """PackedReader.shard: run-aligned row ranges from the block headers alone; blocks straddling a cut are trimmed"""
+    import numpy as np
+    from genomics_general_amd import dist, genoio
+    from genomics_general_amd.samples import HapLayout, SampleData
+    src = os.path.join(ROOT, "tests", "golden", "sparse.geno.gz")
+    for codec in ("zlib", "none"):
+        dst = str(tmp_path / ("s_%s.pgeno" % codec))
+        genoio.pack_geno(src, dst, "phased", block_bytes=9000, codec=codec)
+        rd = genoio.PackedReader(dst)
+        lay = HapLayout(SampleData(indNames=list(rd.names)), rd.names, "phased")
+        whole = rd.to_geno(rd.read_block(None), lay)
+        for n_ranks in (2, 3):
+            parts, read = [], 0
+            for r in range(n_ranks):
+                q = genoio.PackedReader(dst)
+                assert q.shard(dist.World(r, n_ranks, r), None, lambda nm: True, max_share=0.9)
+                blocks = []
+                while True:
+                    b = q.read_block(5000)
+                    if not b:
+                        break
+                    blocks += b
+                parts.append(q.to_geno(blocks, lay))
+                read += q.bytes_read
+            assert np.array_equal(np.concatenate([p.gt for p in parts]), whole.gt)
+            assert np.array_equal(np.concatenate([p.pos for p in parts]), whole.pos)
+            assert sum([p.run_names for p in parts], []) == whole.run_names
+            assert read < 1.6 * os.path.getsize(dst)
+        # a skipped scaffold next to every cut candidate: no split
+        q = genoio.PackedReader(dst)
+        assert not q.shard(dist.World(1, 2, 1), None, lambda nm: nm != "chr2")

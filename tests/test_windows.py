@@ -251,3 +251,61 @@ def test_predefined_window_stream_equals_whole_input(seed):
             assert 0 <= kf <= b - a
             keep = a + kf
         assert got == want, (coords, cuts, list(zip(names, starts)))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_windows_of_run_aligned_input_shards_concatenate_to_the_whole(seed):
+    """Sharded multi-GPU ingestion (genoio.BlockReader.shard): the input is cut at scaffold-run boundaries whose two
+    neighbours are both wanted; every rank generates the windows of its slice on its own, and the concatenation -- IDs shifted by
+    the number of windows of the slices before -- must be the window list of the whole input, for coordinate and sites windows,
+    with --include / --exclude lists, empty windows and the re-emission after a skipped scaffold."""
+    from genomics_general_amd import windows as W
+    rng = np.random.default_rng(5000 + seed)
+    pool = ("c0", "c1", "c2", "c3", "c4")
+    for _ in range(300):
+        names, starts, pos, prev = [], [], [], None
+        for _r in range(int(rng.integers(2, 9))):
+            nm = str(rng.choice([x for x in pool if x != prev]))
+            prev = nm
+            starts.append(len(pos))
+            names.append(nm)
+            pos += list(np.sort(rng.integers(1, 400, size=int(rng.integers(1, 50)))))
+        rs, pos = np.array(starts), np.array(pos, dtype=np.int32)
+        n = len(pos)
+        inc = exc = None
+        z = int(rng.integers(0, 3))
+        if z == 1:
+            inc = [str(x) for x in rng.choice(pool, size=3, replace=False)]
+        if z == 2:
+            exc = [str(x) for x in rng.choice(pool, size=int(rng.integers(1, 3)), replace=False)]
+        ok_cut = [r for r in range(1, len(names)) if W._wanted(names[r - 1], inc, exc) and W._wanted(names[r], inc, exc)]
+        picks = sorted(set(rng.choice(ok_cut, size=min(len(ok_cut), int(rng.integers(0, 4))), replace=False).tolist())) if ok_cut else []
+        bounds = [0] + picks + [len(names)]                      # run indices at which a new rank starts
+        sites_mode = bool(rng.integers(0, 2))
+        if sites_mode:
+            ws = int(rng.integers(3, 40))
+            ov = int(rng.integers(0, ws))
+            md = np.inf if rng.integers(0, 2) else int(rng.integers(5, 200))
+            ms = max(int(rng.integers(1, ws + 1)), ov + 1)
+            gen = lambda a, b, c: W.sites_windows(a, b, c, ws, ov, md, ms, inc, exc)     # noqa: E731
+        else:
+            w = int(rng.integers(5, 120))
+            step = int(rng.integers(1, 2 * w))
+            gen = lambda a, b, c: W.coord_windows(a, b, c, w, step, inc, exc)             # noqa: E731
+        try:
+            want = _stream_rows(gen(rs, names, pos), [])
+        except ValueError:                                       # a sites window that cannot advance: the reference loops forever
+            continue
+        got, id_shift = [], 0
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            if a == b:
+                continue
+            r0 = int(rs[a])
+            r1 = int(rs[b]) if b < len(names) else n
+            T = gen(rs[a:b] - r0, names[a:b], pos[r0:r1])
+            if getattr(T, "dup", None) is None or not len(T.dup):
+                T.dup = np.zeros(T.n, dtype=bool)
+            rows = _stream_rows(T, [], r0)
+            got += [(s, st, en, rng_, i + id_shift, m) for (s, st, en, rng_, i, m) in rows]
+            id_shift += T.n
+        assert got == want, (sites_mode, inc, exc, names, bounds)
