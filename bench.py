@@ -62,6 +62,9 @@ WORKLOADS = {
                  desc="tiny smoke workload"),
 }
 CPU_DISTMAT_HAPS = 120          # distMat CPU sample: 7140 pairs x 100 kb ~ 5 s per window
+T1_BLOCK_SITES = 1 << 20        # T1 sample: host blocks of about a million sites, eight of them
+T1_BLOCKS = 8
+T2_SITES = 400_000              # T2 sample: this many sites of the workload as `.geno` text (8 windows of 50 kb)
 CPU_SLICE_SITES = 4_000         # CPU sample: the first 4000 sites of a window per worker (~4 s of CPU work at 400 haplotypes on an idle core,
                                 # ~10x that with every hardware thread of a 256-thread host busy)
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -193,6 +196,85 @@ def cpu_baseline_distmat(eng, lay, wl, lo, hi):
             "seconds": round(dt, 2), "gpu_matches_oracle_on_sample": None}
 
 
+def tier_samples(eng, lay, wl, names, slot_gen, scaf_len, n_sites, t1_block, t0_table):
+    """Tiers T1 and T2 of SURVEY.md 8d on bounded samples of the workload (the T0 value above is the headline):
+    T1  host int8 blocks (page-locked, at the engine's row pitch) -> asynchronous H2D into alternating halves of a device buffer
+        -> kernels -> result table D2H, block k+1 uploading while block k computes (Engine.upload_async / upload_wait);
+    T2  `.geno` text on disk -> the drop-in popgenWindows.py (reader thread, tokenizer thread, uploads, kernels) -> CSV,
+        timed inside the driver process (PG_TIMING total_s: from opening the input to the last row), and its rows compared
+        with the T0 statistics of the same windows."""
+    import subprocess
+    import tempfile
+    out = {}
+    wind = wl["wind"]
+    pitch = eng.row_pitch
+    n_blocks = int(min(T1_BLOCKS, n_sites // t1_block))
+    host = eng.pinned.empty((n_blocks * t1_block, pitch), np.int8)
+    host[:, lay.n_hap:] = 0
+    for k in range(n_blocks):                                  # untimed: the sample's rows, from the resident data set
+        host[k * t1_block:(k + 1) * t1_block, :lay.n_hap] = eng.download(k * t1_block, t1_block)
+    base = [n_sites, n_sites + t1_block]
+    lo = np.arange(0, t1_block, wind, dtype=np.int64)
+    for rep in range(2):                                       # second pass is the measurement (first: allocations)
+        t0 = time.perf_counter()
+        eng.upload_async(host[0:t1_block], base[0])
+        for k in range(n_blocks):
+            eng.upload_wait()
+            if k + 1 < n_blocks:
+                eng.upload_async(host[(k + 1) * t1_block:(k + 2) * t1_block], base[(k + 1) % 2])
+            tab, _ = eng.batch(lo + base[k % 2], lo + base[k % 2] + wind).groupDistTable(True, wl["min_sites"], 0.01)
+        dt = time.perf_counter() - t0
+    ok = bool(np.array_equal(tab, t0_table[(n_blocks - 1) * len(lo):n_blocks * len(lo)], equal_nan=True))
+    out["t1"] = {"sites_per_sec": round(n_blocks * t1_block / dt, 1), "windows_per_sec": round(n_blocks * len(lo) / dt, 2),
+                 "h2d_GBps": round(n_blocks * t1_block * pitch / dt / 1e9, 2), "matches_t0": ok,
+                 "sample": "%d page-locked host blocks of %d sites x %d haplotypes (int8, 1 byte per call), uploaded into alternating "
+                           "halves of a device buffer while the previous block's windows are computed; PCIe-bound" % (
+                               n_blocks, t1_block, lay.n_hap)}
+    # ---- T2 ----
+    n_txt = int(min(T2_SITES, t1_block * n_blocks, scaf_len) // wind * wind)
+    col_of_slot = np.array([2 * names.index(lay.hap_sample_name[s]) + (s - lay.ind_slots[lay.hap_sample_name[s]][0])
+                            for s in range(lay.n_hap)])
+    codes = np.zeros((n_txt, lay.n_hap), dtype=np.int8)
+    codes[:, col_of_slot] = host[:n_txt, :lay.n_hap]
+    tmp = tempfile.mkdtemp(prefix="pg_bench_t2_")
+    geno, csv = os.path.join(tmp, "sample.geno"), os.path.join(tmp, "out.csv")
+    from genomics_general_amd import synth
+    synth.write_geno_fast(geno, codes, names, "chr1", 1)
+    per = len(names) // lay.n_pops
+    cmd = [sys.executable, os.path.join(ROOT, "popgenWindows.py"), "-g", geno, "-o", csv, "-f", "phased", "-w", str(wind),
+           "-m", str(wl["min_sites"]), "--roundTo", "12"]
+    for k, p in enumerate(lay.sampleData.popNames):
+        cmd += ["-p", p, ",".join(names[k * per:(k + 1) * per])]
+    try:
+        r = subprocess.run(cmd, env=dict(os.environ, PG_TIMING="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE, timeout=300)
+        line = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")]
+        tm = json.loads(line[-1][len("PG_TIMING "):])
+        with open(csv) as f:
+            rows = [ln.strip().split(",") for ln in f.readlines()]
+        head, rows = rows[0], rows[1:]
+        _, cols = eng.batch(lo[:1], lo[:1] + wind).groupDistTable(True, wl["min_sites"], 0.01)
+        same = len(rows) == n_txt // wind
+        for w, row in enumerate(rows):
+            for name, v in zip(head[5:], row[5:]):
+                g = t0_table[w, cols.index(name)]
+                same = same and (abs(float(v) - g) <= 1e-9 * max(1.0, abs(g)) or (g != g and float(v) != float(v)))
+        out["t2"] = {"sites_per_sec": round(n_txt / tm["total_s"], 1), "windows_per_sec": round(len(rows) / tm["total_s"], 3),
+                     "text_MBps": round(os.path.getsize(geno) / tm["total_s"] / 1e6, 1), "matches_t0": bool(same),
+                     "seconds": {k: round(tm[k], 4) for k in ("total_s", "read_s", "tokenize_s", "windows_s", "prep_wait_s",
+                                                               "engine_and_upload_s", "compute_and_write_s") if k in tm},
+                     "sample": "the first %d sites of the workload as %.0f MB of `.geno` text (%d windows) through popgenWindows.py, "
+                               "timed inside the driver (context creation ~0.1 s included, interpreter start excluded)" % (
+                                   n_txt, os.path.getsize(geno) / 1e6, len(rows))}
+    except Exception as exc:                                    # the tiers are side information: never lose the main line
+        out["t2"] = {"error": repr(exc)[:300]}
+    finally:
+        for pth in (geno, csv):
+            if os.path.exists(pth):
+                os.remove(pth)
+        os.rmdir(tmp)
+    return out
+
+
 def main():
     from genomics_general_amd import _lib, dist, synth, windows
     from genomics_general_amd.engine import Engine
@@ -204,6 +286,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="northstar", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tiers", action="store_true", help="skip the T1 (host blocks -> H2D -> kernels) and T2 (text -> CSV) samples")
     ap.add_argument("--cpu-workers", type=int, default=1 << 30, help="upper bound of the CPU baseline's worker processes")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
@@ -228,7 +311,9 @@ def main():
         assert eng._comm_ranks() == world.size, "the RCCL communicator has %d ranks, expected %d" % (eng._comm_ranks(), world.size)
     n_sites = wl["n_sites"]
     scaf_len = n_sites // wl["n_scaf"]
-    eng.reserve(n_sites)
+    tiers = world.size == 1 and not args.no_tiers and wl["tool"] == "popgen"
+    t1_block = min(T1_BLOCK_SITES, n_sites // wl["wind"] * wl["wind"]) // wl["wind"] * wl["wind"]
+    eng.reserve(n_sites + (2 * t1_block if tiers else 0))    # the two halves of the T1 upload buffer sit behind the data set
     # rank r owns global sites [r*n_sites, (r+1)*n_sites): distinct scaffolds, same shape
     eng.synth_fill(0, n_sites, world.rank * n_sites, synth.SEED_DEFAULT, scaf_len, n_dip, n_pops, slot_gen,
                    synth.VAR_THR, synth.MISS_THR)
@@ -372,6 +457,11 @@ def main():
         else:
             cpu = cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, args.cpu_workers)
 
+    if tiers:
+        try:
+            extra.update(tier_samples(eng, lay, wl, names, slot_gen, scaf_len, n_sites, t1_block, np.asarray(_tab)))
+        except Exception as exc:
+            extra["t1"] = {"error": repr(exc)[:300]}
     if world.rank == 0:
         total_windows = n_win * world.size * args.steps
         total_sites = sites_per_step * world.size * args.steps

@@ -153,3 +153,24 @@ def write_geno(path_or_file, scaf_names, scaf_id, pos, codes, sample_names, sep=
         f.write(scaf_names[int(scaf_id[i])] + "\t" + str(int(pos[i])) + "\t" + "\t".join(cells) + "\n")
     if close:
         f.close()
+
+
+def write_geno_fast(path, codes, sample_names, scaf="chr1", pos0=1):
+    """Vectorised `.geno` writer for benchmarks: phased cells `A/C` of fixed width, one scaffold, positions pos0, pos0+1, ...
+    codes: one-hot int8 [L][2 * n_samples] in sample order (columns 2d, 2d+1 = the alleles of sample d)."""
+    letters = codes_to_letters(codes)
+    L, H = letters.shape
+    n = H // 2
+    with open(path, "wb") as f:
+        f.write(("#CHROM\tPOS\t" + "\t".join(sample_names) + "\n").encode())
+        step = 100000
+        for a in range(0, L, step):
+            b = min(L, a + step)
+            cell = np.empty((b - a, n, 4), dtype=np.uint8)
+            cell[:, :, 0] = letters[a:b, 0::2]
+            cell[:, :, 1] = ord("/")
+            cell[:, :, 2] = letters[a:b, 1::2]
+            cell[:, :, 3] = ord("\t")
+            cell[:, -1, 3] = ord("\n")
+            body = cell.reshape(b - a, -1)
+            f.write(b"".join(("%s\t%d\t" % (scaf, pos0 + i)).encode() + body[i - a].tobytes() for i in range(a, b)))
