@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpopgen_hip.so")
+LIB_PATH = os.environ.get("PG_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpopgen_hip.so")   # PG_LIBRARY: e.g. the sanitizer build (make asan)
 
 
 class PopgenError(RuntimeError):
