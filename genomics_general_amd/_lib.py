@@ -53,10 +53,10 @@ SIGNATURES = {
     "pg_upload_wait": (C.c_int, [_P]),
     "pg_synth_fill": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32,
                                 _i32p, C.c_int32, C.c_int32]),
-    "pg_encode_text": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i8p, _i32p,
+    "pg_encode_text": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i8p, _i32p,
                                  _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
-    "pg_scaffold_runs": (C.c_int, [C.c_char_p, _i64p, _i32p, C.c_int64, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
-    "pg_count_lines": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]),
+    "pg_scaffold_runs": (C.c_int, [C.c_void_p, _i64p, _i32p, C.c_int64, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
+    "pg_count_lines": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "pg_decode_packed": (C.c_int, [_u8p, C.c_int64, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i8p, C.c_int]),
     "pg_pairwise": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i32p, _i32p]),
     "pg_popdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
@@ -102,6 +102,13 @@ def lib():
             raise ImportError("libpopgen_hip.so ABI version %d != 1" % L.pg_abi_version())
         _lib = L
     return _lib
+
+
+def text_ptr(buf):
+    """(address, length, keep-alive) of a bytes-like object -- bytes, memoryview, mmap -- for the `const char *` arguments of the
+    tokenizer (a memory-mapped input file goes in without a copy)"""
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    return C.c_void_p(arr.ctypes.data if arr.size else 0), int(arr.size), arr
 
 
 def check(rc):

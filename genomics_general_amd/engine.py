@@ -29,7 +29,8 @@ def encode_text(buf, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, f
     full_out: a list that receives (gt_full, pos_full), the arrays including the spare head rows."""
     L = _lib.lib()
     n = C.c_int64(0)
-    check(L.pg_count_lines(buf, len(buf), C.byref(n)))
+    ptr, nbytes, _keep = _lib.text_ptr(buf)
+    check(L.pg_count_lines(ptr, nbytes, C.byref(n)))
     cap = max(int(n.value), 1)
     width = int(pitch) if pitch else layout.n_hap
     assert width >= layout.n_hap
@@ -41,7 +42,7 @@ def encode_text(buf, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, f
     soff = np.zeros(cap, dtype=np.int64)
     slen = np.zeros(cap, dtype=np.int32)
     got = C.c_int64(0)
-    check(L.pg_encode_text(buf, len(buf), _lib.FMT[layout.genoFormat], len(layout.col_ploidy), layout.max_ploidy,
+    check(L.pg_encode_text(ptr, nbytes, _lib.FMT[layout.genoFormat], len(layout.col_ploidy), layout.max_ploidy,
                            np.ascontiguousarray(layout.col_slot), layout.col_ploidy, width, gt, pos, soff, slen,
                            cap, C.byref(got), n_threads))
     k = int(got.value)
@@ -52,7 +53,7 @@ class PinnedPool:
     """NumPy arrays in page-locked host memory (pg_host_alloc) for large results: device-to-host copies into them run at
     PCIe speed.  A buffer returns to the pool when its array is garbage collected; the pool keeps at most `keep` bytes."""
 
-    def __init__(self, keep=1 << 30):
+    def __init__(self, keep=8 << 30):
         import threading
         self._free = {}                  # nbytes -> [address]
         self._held = 0
@@ -78,6 +79,11 @@ class PinnedPool:
         dtype = np.dtype(dtype)
         count = int(np.prod(shape))
         nbytes = max(count * dtype.itemsize, 1)
+        if nbytes >= (1 << 20):
+            # size classes (1/8 steps between powers of two) so that the slightly different blocks of a streamed input reuse
+            # each other's buffers: page-locking a fresh gigabyte costs more than tokenising into it
+            step = 1 << max(nbytes.bit_length() - 4, 0)
+            nbytes = (nbytes + step - 1) // step * step
         addr = None
         with self._lock:
             lst = self._free.get(nbytes)

@@ -120,16 +120,20 @@ class BlockReader:
     def __init__(self, path):
         self.path = path
         self.stop = None                  # byte offset at which this reader ends (restrict()); None = end of file
+        self.mm = None                    # plain files are memory-mapped: blocks are views of the page cache, not copies
         if path is None:
             self.f = sys.stdin.buffer
         elif str(path).endswith(".gz"):
             self.f = BgzfFile(path) if BgzfFile.is_bgzf(path) else gzip.open(path, "rb")
         else:
+            import mmap
             self.f = open(path, "rb")
+            if os.path.getsize(path) > 0:
+                self.mm = mmap.mmap(self.f.fileno(), 0, access=mmap.ACCESS_READ)
         self.bytes_read = 0
 
     def read_header(self):
-        line = self.f.readline()
+        line = self.mm.readline() if self.mm is not None else self.f.readline()
         self.bytes_read += len(line)
         return line
 
@@ -137,12 +141,31 @@ class BlockReader:
         """plain (uncompressed) file on disk: byte ranges of it can be handed to different ranks"""
         return self.path is not None and not str(self.path).endswith(".gz")
 
+    def tell(self):
+        return self.mm.tell() if self.mm is not None else self.f.tell()
+
     def restrict(self, start, stop):
         """read only the bytes [start, stop) of the file from now on (both at line starts)"""
-        self.f.seek(start)
+        (self.mm if self.mm is not None else self.f).seek(start)
         self.stop = stop
 
     def read_block(self, nbytes=None):
+        """the next block of whole lines (about nbytes of them; everything that is left when None); b"" at the end.  For a
+        memory-mapped file the block is a memoryview of the mapping: the reader thread copies nothing, the tokenizer's threads
+        fault the pages in."""
+        if self.mm is not None:
+            mm = self.mm
+            pos = mm.tell()
+            limit = len(mm) if self.stop is None else min(self.stop, len(mm))
+            end = limit if nbytes is None else min(pos + nbytes, limit)
+            if pos >= limit:
+                return b""
+            if end < limit:
+                nl = mm.find(b"\n", max(end - 1, pos), limit)
+                end = limit if nl < 0 else nl + 1
+            mm.seek(end)
+            self.bytes_read += end - pos
+            return memoryview(mm)[pos:end]
         if self.stop is not None:
             left = max(self.stop - self.f.tell(), 0)
             if nbytes is None or nbytes >= left:
@@ -179,7 +202,7 @@ class BlockReader:
         if not self.seekable_text():
             return False
         size = os.path.getsize(self.path)
-        start = self.f.tell()                                  # the header line, if any, has been consumed
+        start = self.tell()                                    # the header line, if any, has been consumed
         mine, scanned = float(start), 0
         if world.rank > 0:
             # the search starts a little before the equal split, so that a boundary sitting exactly on it (equal scaffolds) is
@@ -202,6 +225,11 @@ class BlockReader:
         return encode(body, layout, n_threads, head_rows, pitch, alloc)
 
     def close(self):
+        if self.mm is not None:
+            try:
+                self.mm.close()
+            except BufferError:            # a block is still referenced somewhere: the mapping goes with its last view
+                pass
         if self.f is not sys.stdin.buffer:
             self.f.close()
 
@@ -615,18 +643,19 @@ def encode(data, layout, n_threads=0, head_rows=0, pitch=None, alloc=None):
     gt, pos, soff, slen = encode_text(data, layout, n_threads, head_rows, pitch, alloc, full)
     n = len(pos)
     L = _lib.lib()
+    ptr, _, _keep = _lib.text_ptr(data)
     cap = 1024
     while True:
         starts = np.zeros(cap, dtype=np.int64)
         nr = C.c_int64(0)
-        rc = L.pg_scaffold_runs(data, soff, slen, n, starts, cap, C.byref(nr))
+        rc = L.pg_scaffold_runs(ptr, soff, slen, n, starts, cap, C.byref(nr))
         if nr.value > cap:
             cap = int(nr.value)
             continue
         check(rc)
         break
     starts = starts[:nr.value]
-    names = [data[int(soff[i]):int(soff[i]) + int(slen[i])].decode("utf-8", "replace") for i in starts]
+    names = [bytes(data[int(soff[i]):int(soff[i]) + int(slen[i])]).decode("utf-8", "replace") for i in starts]
     d = GenoData(gt, pos, starts, names)
     d.spare = (full[0][0], full[0][1], head_rows)
     return d
