@@ -1,0 +1,424 @@
+// VCF -> genotype cells: the native half of the parseVCF.py drop-in ("parseVCF-compatible writer").
+// Replaces, for a buffer of complete VCF lines, what the reference does per line in Python:
+//   VcfSite.__init__ / getSiteType / getGenotype   VCF_processing/parseVCF.py:49-191
+//   the per-site filters of its main loop            VCF_processing/parseVCF.py:367-377
+// Output is one row per kept site: CHROM / REF / ALT token locations, POS, and per selected sample the allele CHARACTERS the
+// reference would print (missing = 'N') plus the phase character of the genotype; genomics_general_amd/vcf.py renders `.geno`
+// text from them or packs them into `.pgeno` cells.  An allele longer than one base cannot be held in a character: its
+// character is the missing one, the row is flagged and the allele INDICES of the row's calls (idx_out) let the text renderer
+// print the strings as the reference does (e.g. a homozygous-reference call at a deletion site, `GG/GG`, even under
+// --skipIndels); the packed form stores such calls as missing.
+#include "pg_ctx.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+
+namespace {
+
+struct Tok { const char *p; int n; };
+
+inline bool ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+// str.split(): tokens separated by runs of whitespace
+int split_ws(const char *b, const char *e, Tok *out, int cap) {
+    int n = 0;
+    const char *p = b;
+    while (p < e) {
+        while (p < e && ws(*p)) ++p;
+        if (p >= e) break;
+        const char *s = p;
+        while (p < e && !ws(*p)) ++p;
+        if (n < cap) { out[n].p = s; out[n].n = (int)(p - s); }
+        ++n;
+    }
+    return n;
+}
+
+inline bool tok_eq(const Tok &t, const char *s, int n) { return t.n == n && memcmp(t.p, s, (size_t)n) == 0; }
+
+// the k-th piece of a ':' separated token (FORMAT / sample column); false when there are fewer pieces
+bool colon_piece(const Tok &t, int k, Tok *out) {
+    const char *p = t.p, *e = t.p + t.n;
+    for (int i = 0; i < k; ++i) {
+        p = static_cast<const char *>(memchr(p, ':', (size_t)(e - p)));
+        if (!p) return false;
+        ++p;
+    }
+    const char *q = static_cast<const char *>(memchr(p, ':', (size_t)(e - p)));
+    out->p = p;
+    out->n = (int)((q ? q : e) - p);
+    return true;
+}
+
+// index of the LAST piece of FORMAT equal to `name` (dict(zip(...)) keeps the last duplicate), -1 if absent
+int format_index(const Tok &fmt, const char *name, int nlen) {
+    int idx = -1, k = 0;
+    const char *p = fmt.p, *e = fmt.p + fmt.n;
+    while (p <= e) {
+        const char *q = static_cast<const char *>(memchr(p, ':', (size_t)(e - p)));
+        const char *pe = q ? q : e;
+        if ((int)(pe - p) == nlen && memcmp(p, name, (size_t)nlen) == 0) idx = k;
+        ++k;
+        if (!q) break;
+        p = q + 1;
+    }
+    return idx;
+}
+
+// Python float(): the whole (stripped) token must be a number
+bool py_float(const char *p, int n, double *v) {
+    if (n <= 0 || n > 63) return false;
+    char tmp[64];
+    memcpy(tmp, p, (size_t)n);
+    tmp[n] = 0;
+    char *end = nullptr;
+    *v = strtod(tmp, &end);
+    return end == tmp + n && end != tmp;
+}
+
+struct Shared {
+    const char *buf;
+    int n_vcf_samples, n_sel;
+    const int32_t *sel_col, *sel_ploidy;
+    int flags;
+    double min_qual;
+    int max_ref_len;
+    const pg_vcf_filter *filters;
+    int n_filters;
+    const char *contigs;        // names separated by '\n'
+    int n_contig_bytes, contig_mode;
+    char missing;
+    uint8_t *chars, *phase, *row_flag;
+    int8_t *idx;
+    int32_t *pos;
+    int64_t *chrom_off, *ref_off, *alt_off;
+    int32_t *chrom_len, *ref_len, *alt_len;
+    int64_t cap;
+    std::atomic<int> err;
+    std::atomic<long long> multibase;
+    char msg[320];
+};
+
+void set_err(Shared &sh, const char *what, const Tok *chrom, const Tok *pos) {
+    int expected = 0;
+    if (sh.err.compare_exchange_strong(expected, 1)) {
+        if (chrom && pos) snprintf(sh.msg, sizeof(sh.msg), "%s (site %.*s:%.*s)", what, chrom->n, chrom->p, pos->n, pos->p);
+        else snprintf(sh.msg, sizeof(sh.msg), "%s", what);
+    }
+}
+
+bool contig_listed(const Shared &sh, const Tok &c) {
+    const char *p = sh.contigs, *e = sh.contigs + sh.n_contig_bytes;
+    while (p < e) {
+        const char *q = static_cast<const char *>(memchr(p, '\n', (size_t)(e - p)));
+        const char *pe = q ? q : e;
+        if ((int)(pe - p) == c.n && memcmp(p, c.p, (size_t)c.n) == 0) return true;
+        if (!q) break;
+        p = q + 1;
+    }
+    return false;
+}
+
+// Does the site of this line pass the per-site filters of the reference's main loop (parseVCF.py:367-370)?
+// prev: the data line before this one (for --excludeDuplicates), may be empty.
+bool site_kept(const Shared &sh, const Tok *t, int nt, const Tok *prev_chrom, const Tok *prev_pos) {
+    (void)nt;
+    if ((sh.flags & PG_VCF_EXCLUDE_DUPLICATES) && prev_chrom && prev_chrom->p && tok_eq(t[0], prev_chrom->p, prev_chrom->n) &&
+        tok_eq(t[1], prev_pos->p, prev_pos->n))
+        return false;
+    if (sh.contig_mode == 1 && !contig_listed(sh, t[0])) return false;            // --include
+    if (sh.contig_mode == 2 && contig_listed(sh, t[0])) return false;             // --exclude
+    if (sh.min_qual > 0) {                                                        // `if args.minQual and canFloat(QUAL) and ...`
+        double q;
+        if (py_float(t[5].p, t[5].n, &q) && q < sh.min_qual) return false;
+    }
+    if (sh.max_ref_len > 0 && t[3].n > sh.max_ref_len) return false;
+    return true;
+}
+
+struct Line { const char *b, *e; };
+
+inline bool data_line(const char *b, const char *e) {
+    const char *p = b;
+    while (p < e && ws(*p)) ++p;
+    return p < e && *b != '#';              // `len(elements) == 0 or elements[0][0] == "#"` are skipped
+}
+
+// Walk the lines of [b,e).  count_only: number of kept sites; else write rows starting at `row`.
+// prev0: first two tokens of the data line before the range.
+long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok prev_pos, bool count_only, long long row) {
+    const int need = 9 + sh.n_vcf_samples;
+    std::vector<Tok> tk((size_t)need + 1);
+    std::vector<Tok> alt;
+    long long kept = 0;
+    while (b < e && !sh.err.load(std::memory_order_relaxed)) {
+        const char *nl = static_cast<const char *>(memchr(b, '\n', (size_t)(e - b)));
+        const char *le = nl ? nl : e;
+        if (data_line(b, le)) {
+            int nt;
+            if (count_only) {
+                Tok head[6];
+                nt = split_ws(b, le, head, 6);
+                if (nt < 6) { set_err(sh, "VCF line with fewer than 6 columns", nullptr, nullptr); return kept; }
+                if (site_kept(sh, head, nt, &prev_chrom, &prev_pos)) ++kept;
+                prev_chrom = head[0];
+                prev_pos = head[1];
+                b = le + 1;
+                continue;
+            }
+            nt = split_ws(b, le, tk.data(), need + 1);
+            if (nt < 6) { set_err(sh, "VCF line with fewer than 6 columns", nullptr, nullptr); return kept; }
+            const bool keep = site_kept(sh, tk.data(), nt, &prev_chrom, &prev_pos);
+            prev_chrom = tk[0];
+            prev_pos = tk[1];
+            if (keep) {
+                const Tok *t = tk.data();
+                if (nt < need) { set_err(sh, "VCF line has fewer columns than the #CHROM header", &t[0], &t[1]); return kept; }
+                if (row >= sh.cap) { set_err(sh, "more sites than output capacity", nullptr, nullptr); return kept; }
+                // POS: int()
+                {
+                    const char *p = t[1].p, *pe = p + t[1].n;
+                    bool neg = false;
+                    if (p < pe && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
+                    long long v = 0;
+                    if (p >= pe) { set_err(sh, "POS is not an integer", &t[0], &t[1]); return kept; }
+                    for (; p < pe; ++p) {
+                        if (*p < '0' || *p > '9') { set_err(sh, "POS is not an integer", &t[0], &t[1]); return kept; }
+                        v = v * 10 + (*p - '0');
+                        if (v > 0x7FFFFFFFll) { set_err(sh, "POS does not fit 32 bits", &t[0], &t[1]); return kept; }
+                    }
+                    sh.pos[row] = (int32_t)(neg ? -v : v);
+                }
+                sh.chrom_off[row] = t[0].p - sh.buf;
+                sh.chrom_len[row] = t[0].n;
+                sh.ref_off[row] = t[3].p - sh.buf;
+                sh.ref_len[row] = t[3].n;
+                sh.alt_off[row] = t[4].p - sh.buf;
+                sh.alt_len[row] = t[4].n;
+                bool row_multibase = false;
+                // alleles: REF + ALT.split(",") (ALT "." = none)
+                alt.clear();
+                alt.push_back(t[3]);
+                if (!(t[4].n == 1 && t[4].p[0] == '.')) {
+                    const char *p = t[4].p, *pe = p + t[4].n;
+                    for (;;) {
+                        const char *q = static_cast<const char *>(memchr(p, ',', (size_t)(pe - p)));
+                        Tok a = {p, (int)((q ? q : pe) - p)};
+                        alt.push_back(a);
+                        if (!q) break;
+                        p = q + 1;
+                    }
+                }
+                const int n_all = (int)alt.size();
+                bool all_match = true;
+                for (int i = 0; i < n_all; ++i) all_match = all_match && alt[i].n == t[3].n;
+                const int site_type = n_all == 1 ? 1 : (all_match ? 2 : 4);            // MONO / SNP / INDEL
+                const int gt_idx = format_index(t[8], "GT", 2);
+                uint8_t *oc = sh.chars + (size_t)row * 2 * sh.n_sel;
+                int8_t *oi = sh.idx + (size_t)row * 2 * sh.n_sel;
+                uint8_t *op = sh.phase + (size_t)row * sh.n_sel;
+                for (int s = 0; s < sh.n_sel; ++s) {
+                    const Tok &cell = t[9 + sh.sel_col[s]];
+                    const int ploidy = sh.sel_ploidy[s];
+                    Tok gt = {nullptr, 0};
+                    if (gt_idx < 0 || !colon_piece(cell, gt_idx, &gt)) {
+                        set_err(sh, "genotype without a GT field (the reference raises KeyError here)", &t[0], &t[1]);
+                        return kept;
+                    }
+                    // alleles = re.split("[/|]", GT); phase = "|" if "|" in GT else "/"
+                    Tok al[4];
+                    int na = 0;
+                    bool phased = false;
+                    {
+                        const char *p = gt.p, *pe = p + gt.n, *s0 = p;
+                        for (;; ++p) {
+                            if (p == pe || *p == '/' || *p == '|') {
+                                if (na < 4) { al[na].p = s0; al[na].n = (int)(p - s0); }
+                                ++na;
+                                if (p == pe) break;
+                                if (*p == '|') phased = true;
+                                s0 = p + 1;
+                            }
+                        }
+                    }
+                    op[s] = phased ? '|' : '/';
+                    // GTtype (parseVCF.py:13-18) for the gtTypes selector of the genotype filters
+                    int gt_type;
+                    {
+                        bool distinct = false, has0 = false, hasdot = false;
+                        for (int i = 0; i < na && i < 4; ++i) {
+                            if (i && !(al[i].n == al[0].n && memcmp(al[i].p, al[0].p, (size_t)al[0].n) == 0)) distinct = true;
+                            if (al[i].n == 1 && al[i].p[0] == '0') has0 = true;
+                            if (al[i].n == 1 && al[i].p[0] == '.') hasdot = true;
+                        }
+                        gt_type = distinct ? 1 : (has0 ? 2 : (hasdot ? 4 : 8));          // Het / HomRef / Missing / HomAlt
+                    }
+                    bool passed = true;
+                    for (int f = 0; f < sh.n_filters && passed; ++f) {
+                        const pg_vcf_filter &F = sh.filters[f];
+                        if (F.site_types && !(F.site_types & site_type)) continue;
+                        if (F.gt_types && !(F.gt_types & gt_type)) continue;
+                        if (F.samples && !F.samples[s]) continue;
+                        const int fi = format_index(t[8], F.flag, (int)strlen(F.flag));
+                        Tok v;
+                        if (fi < 0 || !colon_piece(cell, fi, &v)) { passed = false; break; }
+                        // np.array(value.split(","), dtype=float): every piece must parse and lie in [min, max]
+                        const char *p = v.p, *pe = p + v.n;
+                        for (;;) {
+                            const char *q = static_cast<const char *>(memchr(p, ',', (size_t)(pe - p)));
+                            double x;
+                            if (!py_float(p, (int)((q ? q : pe) - p), &x) || !(F.min <= x && x <= F.max)) { passed = false; break; }
+                            if (!q) break;
+                            p = q + 1;
+                        }
+                    }
+                    if (na != ploidy) {
+                        if (sh.flags & PG_VCF_MISMATCH_TO_MISSING) passed = false;
+                        else { set_err(sh, "a genotype does not match the expected ploidy (--ploidyMismatchToMissing turns such genotypes into missing data)", &t[0], &t[1]); return kept; }
+                    }
+                    // out: the characters printed (missing for an allele that is longer than one base: only the index form below can
+                    // name it); ai: the allele indices behind them (-1 = missing) for rows that need the allele strings
+                    char out[2] = {sh.missing, sh.missing};
+                    int ai[2] = {-1, -1};
+                    if (passed) {
+                        bool any_missing = false, bad_key = false;
+                        for (int i = 0; i < ploidy; ++i) {
+                            // alleleDict[a]: a must be the decimal index of an allele, written as str(i) writes it
+                            int idx = -1;
+                            if (al[i].n >= 1 && al[i].n <= 3 && !(al[i].n > 1 && al[i].p[0] == '0')) {
+                                idx = 0;
+                                for (int k = 0; k < al[i].n; ++k) {
+                                    if (al[i].p[k] < '0' || al[i].p[k] > '9') { idx = -1; break; }
+                                    idx = idx * 10 + (al[i].p[k] - '0');
+                                }
+                            }
+                            if (idx < 0 || idx >= n_all || idx > 127) { bad_key = true; break; }
+                            if ((sh.flags & PG_VCF_SKIP_INDELS) && alt[idx].n != t[3].n) { any_missing = true; continue; }
+                            ai[i] = idx;
+                            if (alt[idx].n == 1) {
+                                out[i] = alt[idx].p[0];
+                                if (out[i] == sh.missing) any_missing = true;        // `missing not in sampleAlleles`
+                            } else if (alt[idx].n == 0) {
+                                any_missing = any_missing || false;                   // an empty allele string prints as nothing
+                            }
+                        }
+                        if (bad_key || (any_missing && !(sh.flags & PG_VCF_KEEP_PARTIAL))) {
+                            out[0] = out[1] = sh.missing;
+                            ai[0] = ai[1] = -1;
+                        }
+                        for (int i = 0; i < ploidy; ++i)
+                            if (ai[i] >= 0 && alt[ai[i]].n != 1) {
+                                row_multibase = true;
+                                sh.multibase.fetch_add(1, std::memory_order_relaxed);
+                            }
+                    }
+                    oc[2 * s] = (uint8_t)out[0];
+                    oc[2 * s + 1] = ploidy > 1 ? (uint8_t)out[1] : 0;
+                    oi[2 * s] = (int8_t)ai[0];
+                    oi[2 * s + 1] = (int8_t)(ploidy > 1 ? ai[1] : -1);
+                }
+                sh.row_flag[row] = row_multibase ? 1 : 0;
+                ++row;
+                ++kept;
+            }
+        }
+        b = le + 1;
+    }
+    return kept;
+}
+
+// first two tokens of the last data line of [b,e) (empty if none)
+void last_key(const char *b, const char *e, Tok *chrom, Tok *pos) {
+    chrom->p = pos->p = nullptr;
+    chrom->n = pos->n = 0;
+    const char *p = e;
+    while (p > b) {
+        const char *le = p;
+        if (le > b && le[-1] == '\n') --le;
+        const char *ls = le;
+        while (ls > b && ls[-1] != '\n') --ls;
+        if (data_line(ls, le)) {
+            Tok t[2];
+            if (split_ws(ls, le, t, 2) >= 2) { *chrom = t[0]; *pos = t[1]; }
+            return;
+        }
+        p = ls;
+    }
+}
+
+}  // namespace
+
+extern "C" int pg_encode_vcf(const char *buf, size_t len, int n_vcf_samples, int n_sel, const int32_t *sel_col,
+                             const int32_t *sel_ploidy, int flags, double min_qual, int max_ref_len, const pg_vcf_filter *filters,
+                             int n_filters, const char *contigs, int n_contig_bytes, int contig_mode, char missing,
+                             const char *prev_chrom, int prev_chrom_len, const char *prev_pos, int prev_pos_len, uint8_t *chars_out,
+                             int8_t *idx_out, uint8_t *phase_out, uint8_t *row_flag_out, int32_t *pos_out, int64_t *chrom_off,
+                             int32_t *chrom_len, int64_t *ref_off, int32_t *ref_len, int64_t *alt_off, int32_t *alt_len,
+                             int64_t cap_sites, int64_t *n_sites_out, int64_t *n_multibase_out, int n_threads) {
+    if ((!buf && len) || !n_sites_out) return pg_fail(PG_ERR_ARG, "pg_encode_vcf: null argument");
+    if (n_vcf_samples < 0 || n_sel < 0 || (n_sel > 0 && (!sel_col || !sel_ploidy))) return pg_fail(PG_ERR_ARG, "pg_encode_vcf: bad sample selection");
+    for (int s = 0; s < n_sel; ++s) {
+        if (sel_col[s] < 0 || sel_col[s] >= n_vcf_samples) return pg_fail(PG_ERR_ARG, "sel_col[%d] out of range", s);
+        if (sel_ploidy[s] < 1 || sel_ploidy[s] > 2) return pg_fail(PG_ERR_ARG, "ploidy of selected sample %d must be 1 or 2", s);
+    }
+    if (n_filters < 0 || (n_filters > 0 && !filters)) return pg_fail(PG_ERR_ARG, "pg_encode_vcf: bad filter list");
+    for (int f = 0; f < n_filters; ++f)
+        if (!filters[f].flag) return pg_fail(PG_ERR_ARG, "genotype filter %d has no flag", f);
+    if (contig_mode < 0 || contig_mode > 2 || (contig_mode && !contigs)) return pg_fail(PG_ERR_ARG, "pg_encode_vcf: bad contig list");
+    *n_sites_out = 0;
+    if (n_multibase_out) *n_multibase_out = 0;
+    if (len == 0) return PG_OK;
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if ((size_t)nt > len / (1 << 16) + 1) nt = (int)(len / (1 << 16) + 1);
+    std::vector<size_t> cut(nt + 1, len);
+    cut[0] = 0;
+    for (int t = 1; t < nt; ++t) {
+        size_t guess = len / nt * t;
+        if (guess < cut[t - 1]) guess = cut[t - 1];
+        const char *nl = static_cast<const char *>(memchr(buf + guess, '\n', len - guess));
+        cut[t] = nl ? (size_t)(nl - buf) + 1 : len;
+    }
+    Shared sh;
+    sh.buf = buf; sh.n_vcf_samples = n_vcf_samples; sh.n_sel = n_sel; sh.sel_col = sel_col; sh.sel_ploidy = sel_ploidy;
+    sh.flags = flags; sh.min_qual = min_qual; sh.max_ref_len = max_ref_len; sh.filters = filters; sh.n_filters = n_filters;
+    sh.contigs = contigs; sh.n_contig_bytes = n_contig_bytes; sh.contig_mode = contig_mode; sh.missing = missing ? missing : 'N';
+    sh.chars = chars_out; sh.idx = idx_out; sh.phase = phase_out; sh.row_flag = row_flag_out; sh.pos = pos_out;
+    sh.chrom_off = chrom_off; sh.chrom_len = chrom_len; sh.ref_off = ref_off; sh.ref_len = ref_len; sh.alt_off = alt_off;
+    sh.alt_len = alt_len; sh.cap = cap_sites; sh.err = 0; sh.multibase = 0; sh.msg[0] = 0;
+    // the data line before each thread's range (for --excludeDuplicates)
+    std::vector<Tok> pc(nt), pp(nt);
+    pc[0].p = prev_chrom; pc[0].n = prev_chrom ? prev_chrom_len : 0;
+    pp[0].p = prev_pos; pp[0].n = prev_pos ? prev_pos_len : 0;
+    for (int t = 1; t < nt; ++t) {
+        last_key(buf, buf + cut[t], &pc[t], &pp[t]);
+        if (!pc[t].p) { pc[t] = pc[0]; pp[t] = pp[0]; }
+    }
+    std::vector<long long> cnt(nt, 0);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() { cnt[t] = walk(sh, buf + cut[t], buf + cut[t + 1], pc[t], pp[t], true, 0); });
+        for (auto &x : th) x.join();
+    }
+    if (sh.err.load()) return pg_fail(PG_ERR_PARSE, "%s", sh.msg);
+    std::vector<long long> base(nt + 1, 0);
+    for (int t = 0; t < nt; ++t) base[t + 1] = base[t] + cnt[t];
+    *n_sites_out = base[nt];
+    if (cap_sites == 0) return PG_OK;                       // counting pass
+    if (!chars_out || !idx_out || !phase_out || !row_flag_out || !pos_out || !chrom_off || !chrom_len || !ref_off || !ref_len || !alt_off ||
+        !alt_len)
+        return pg_fail(PG_ERR_ARG, "pg_encode_vcf: null output");
+    if (base[nt] > cap_sites) return pg_fail(PG_ERR_ARG, "VCF text holds %lld kept sites but output capacity is %lld", base[nt], (long long)cap_sites);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() { walk(sh, buf + cut[t], buf + cut[t + 1], pc[t], pp[t], false, base[t]); });
+        for (auto &x : th) x.join();
+    }
+    if (sh.err.load()) return pg_fail(PG_ERR_PARSE, "%s", sh.msg);
+    if (n_multibase_out) *n_multibase_out = sh.multibase.load();
+    return PG_OK;
+}

@@ -120,6 +120,38 @@ int pg_scaffold_runs(const char *buf, const int64_t *scaf_off, const int32_t *sc
 /* Count data rows (non-'#', non-empty) in a text buffer so the caller can size the outputs. */
 int pg_count_lines(const char *buf, size_t len, int64_t *n_rows_out);
 
+/* ---- VCF -> genotype cells (host only): the native half of the parseVCF.py drop-in ------------------------------------------- */
+/* Replaces, for a buffer of complete VCF lines (header lines may be included, they are skipped), VcfSite.__init__ / getSiteType /
+ * getGenotype and the per-site filters of VCF_processing/parseVCF.py:49-191, 367-377.  One output row per kept site:
+ *   chars_out[cap][2 * n_sel]   the allele characters the reference would print for selected sample s at [2s], [2s+1] (missing =
+ *                               `missing`, second character 0 for a haploid sample); phase_out[cap][n_sel] '/' or '|'
+ *   idx_out[cap][2 * n_sel]     the allele indices behind those characters (-1 = missing); row_flag_out[cap] = 1 when some printed
+ *                               allele of the row is longer than one character (its character is `missing`; a text renderer takes
+ *                               the strings from REF / ALT through idx_out)
+ *   pos_out, chrom_off/len, ref_off/len, alt_off/len   POS and the locations of the CHROM, REF and ALT tokens in buf
+ * sel_col[n_sel]: index of each selected sample among the VCF's sample columns; sel_ploidy: its expected ploidy (1 or 2).
+ * flags: PG_VCF_*.  min_qual <= 0 / max_ref_len <= 0: no such filter.  contigs: names separated by '\n', contig_mode 0 none,
+ * 1 include list, 2 exclude list.  prev_chrom / prev_pos: CHROM and POS tokens of the data line before the buffer (for
+ * --excludeDuplicates across blocks; NULL at the start).  n_multibase_out: printed allele calls longer than one character.
+ * cap_sites = 0: only count the kept sites. */
+#define PG_VCF_SKIP_INDELS 1
+#define PG_VCF_KEEP_PARTIAL 2
+#define PG_VCF_MISMATCH_TO_MISSING 4
+#define PG_VCF_EXCLUDE_DUPLICATES 8
+typedef struct pg_vcf_filter {      /* --gtf flag=X min=X max=X siteTypes=.. gtTypes=.. samples=..  (parseVCF.py:255-266, 117-131) */
+    const char *flag;               /* FORMAT field, e.g. "DP" */
+    double min, max;
+    int site_types;                 /* bit mask 1 MONO | 2 SNP | 4 INDEL, 0 = every site type */
+    int gt_types;                   /* bit mask 1 Het | 2 HomRef | 4 Missing | 8 HomAlt, 0 = every genotype type */
+    const uint8_t *samples;         /* per selected sample 0/1, NULL = every sample */
+} pg_vcf_filter;
+int pg_encode_vcf(const char *buf, size_t len, int n_vcf_samples, int n_sel, const int32_t *sel_col, const int32_t *sel_ploidy,
+                  int flags, double min_qual, int max_ref_len, const pg_vcf_filter *filters, int n_filters, const char *contigs,
+                  int n_contig_bytes, int contig_mode, char missing, const char *prev_chrom, int prev_chrom_len, const char *prev_pos,
+                  int prev_pos_len, uint8_t *chars_out, int8_t *idx_out, uint8_t *phase_out, uint8_t *row_flag_out, int32_t *pos_out,
+                  int64_t *chrom_off, int32_t *chrom_len, int64_t *ref_off, int32_t *ref_len, int64_t *alt_off, int32_t *alt_len,
+                  int64_t cap_sites, int64_t *n_sites_out, int64_t *n_multibase_out, int n_threads);
+
 /* Packed `.pgeno` input (genomics_general_amd/genoio.py: a tokenised `.geno` file kept on disk, one byte per genotype cell =
  * first allele code | second allele code << 4, in file column order): block of cells -> one-hot codes in slot order, same
  * col_slot / col_ploidy tables as pg_encode_text. */

@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+"""Golden outputs of the UNMODIFIED reference VCF_processing/parseVCF.py on two seeded synthetic VCF files.
+
+    python tests/golden/make_golden_vcf.py        (needs /root/reference; writes tests/golden/vcf/*)
+
+main.vcf.gz: diploid genotypes, phased and unphased, missing and half-missing calls, allele indices beyond the ALT list, MONO /
+SNP / multi-allelic / indel / '*' sites, QUAL floats and '.', duplicated positions, FORMAT orders GT:DP:GQ, GT:GQ:DP:AD and GT.
+hap.vcf.gz: one haploid sample (--ploidyFile) and a few genotypes of the wrong ploidy (--ploidyMismatchToMissing)."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "vcf")
+REF = "/root/reference/VCF_processing/parseVCF.py"
+
+VCF_CASES = [
+    ("main_skipindels", "main", ["--skipIndels"]),
+    ("main_filters", "main", ["--skipIndels", "--minQual", "30", "--gtf", "flag=DP", "min=5", "--gtf", "flag=GQ", "min=20", "gtTypes=Het"]),
+    ("main_subset_dups", "main", ["--skipIndels", "--excludeDuplicates", "--include", "chr1,chr3", "-s", "s3,s1,s5"]),
+    ("main_partial_reftrack", "main", ["--skipIndels", "--keepPartial", "--exclude", "chr2", "--maxREFlen", "1", "--noHeader",
+                                       "--outSep", " ", "--addRefTrack"]),
+    ("main_missing_sitetypes", "main", ["--skipIndels", "--missing", "X", "--gtf", "flag=DP", "max=30", "siteTypes=SNP", "samples=s0,s2"]),
+    ("main_ad_list", "main", ["--skipIndels", "--gtf", "flag=AD", "min=1", "gtTypes=Het,HomAlt"]),
+    ("snps_default", "snps", []),
+    ("hap_ploidyfile", "hap", ["--skipIndels", "--ploidyFile", "{dir}/hap.ploidy", "--ploidyMismatchToMissing"]),
+]
+
+
+def make_vcf(path, seed, n_samples=6, hap_sample=None, snps_only=False, wrong_ploidy=0.0):
+    rng = np.random.default_rng(seed)
+    names = ["s%d" % k for k in range(n_samples)]
+    lines = ["##fileformat=VCFv4.2", "##contig=<ID=chr1,length=100000>", "##contig=<ID=chr2,length=50000>",
+             "##source=make_golden_vcf", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names)]
+    bases = "ACGT"
+    for chrom, n in (("chr1", 220), ("chr2", 120), ("chr3", 90)):
+        pos = 0
+        for _ in range(n):
+            pos += int(rng.integers(0 if rng.random() < 0.06 else 1, 40))        # a few duplicated positions
+            pos = max(pos, 1)
+            ref = bases[rng.integers(0, 4)]
+            kind = rng.random()
+            if kind < 0.15:
+                alt = "."
+            elif kind < 0.70 or snps_only:
+                alt = bases[(bases.index(ref) + int(rng.integers(1, 4))) % 4]
+            elif kind < 0.80:
+                a1 = bases[(bases.index(ref) + 1) % 4]
+                a2 = bases[(bases.index(ref) + 2) % 4]
+                alt = a1 + "," + a2
+            elif kind < 0.88:
+                alt = ref + bases[rng.integers(0, 4)] + "," + bases[(bases.index(ref) + 1) % 4]     # insertion + SNP
+            elif kind < 0.94:
+                ref = ref + bases[rng.integers(0, 4)]                                                   # deletion
+                alt = ref[0]
+            else:
+                alt = bases[(bases.index(ref) + 1) % 4] + ",*"
+            n_alt = 0 if alt == "." else len(alt.split(","))
+            qual = "." if rng.random() < 0.1 else ("%.1f" % (rng.random() * 100) if rng.random() < 0.7 else str(int(rng.integers(1, 99))))
+            fk = rng.random()
+            fmt = "GT:DP:GQ" if fk < 0.6 else ("GT:GQ:DP:AD" if fk < 0.9 else "GT")
+            cells = []
+            for s in range(n_samples):
+                ploidy = 1 if s == hap_sample else 2
+                if rng.random() < wrong_ploidy:
+                    ploidy = 3 - ploidy
+                al = []
+                for _a in range(ploidy):
+                    r = rng.random()
+                    al.append("." if r < 0.08 else str(int(rng.integers(0, n_alt + 1)) if r < 0.97 else n_alt + 1))
+                if rng.random() < 0.05:
+                    al = ["."] * ploidy
+                gt = ("|" if rng.random() < 0.4 else "/").join(al)
+                dp = "." if rng.random() < 0.05 else str(int(rng.integers(0, 40)))
+                gq = "." if rng.random() < 0.05 else str(int(rng.integers(0, 99)))
+                ad = ",".join(str(int(rng.integers(0, 12))) for _ in range(n_alt + 1))
+                cells.append({"GT:DP:GQ": "%s:%s:%s" % (gt, dp, gq), "GT:GQ:DP:AD": "%s:%s:%s:%s" % (gt, gq, dp, ad), "GT": gt}[fmt])
+            lines.append("\t".join([chrom, str(pos), ".", ref, alt, qual, "PASS", "NS=%d" % n_samples, fmt] + cells))
+        lines.append("")                                                                                 # an empty line
+    with gzip.open(path, "wt") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    make_vcf(os.path.join(OUT, "main.vcf.gz"), 11)
+    make_vcf(os.path.join(OUT, "snps.vcf.gz"), 12, snps_only=True)
+    make_vcf(os.path.join(OUT, "hap.vcf.gz"), 13, hap_sample=2, wrong_ploidy=0.03)
+    with open(os.path.join(OUT, "hap.ploidy"), "wt") as f:
+        f.write("s2 1\ns4 2\n")
+    for name, vcf, argv in VCF_CASES:
+        cmd = [sys.executable, REF, "-i", os.path.join(OUT, vcf + ".vcf.gz"), "-o", os.path.join(OUT, name + ".geno")]
+        cmd += [a.format(dir=OUT) for a in argv]
+        subprocess.run(cmd, check=True, timeout=300, stderr=subprocess.DEVNULL)
+        print(name, os.path.getsize(os.path.join(OUT, name + ".geno")))
+
+
+if __name__ == "__main__":
+    main()
