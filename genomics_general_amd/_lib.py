@@ -57,6 +57,8 @@ SIGNATURES = {
                                  _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_scaffold_runs": (C.c_int, [C.c_void_p, _i64p, _i32p, C.c_int64, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
     "pg_count_lines": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
+    # (struct array + many pointers: genomics_general_amd/vcf.py passes explicit ctypes objects)
+    "pg_encode_vcf": (C.c_int, None),
     "pg_decode_packed": (C.c_int, [_u8p, C.c_int64, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i8p, C.c_int]),
     "pg_pairwise": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i32p, _i32p]),
     "pg_popdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
@@ -97,7 +99,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res
-            fn.argtypes = args
+            if args is not None:
+                fn.argtypes = args
         if L.pg_abi_version() != 1:
             raise ImportError("libpopgen_hip.so ABI version %d != 1" % L.pg_abi_version())
         _lib = L
