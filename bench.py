@@ -390,8 +390,7 @@ def main():
     roofline = None
     extra = {}
     # rocprofv3's names of the kernel behind each family, for this workload
-    pack_name = "k_pack3" if ((lay.n_hap + 15) // 16 * 4 <= 64 and not os.environ.get("PG_PACK2")) or (
-        os.environ.get("PG_PACK3") and n_hap <= 1024) else "k_pack2"
+    pack_name = "k_pack2" if (os.environ.get("PG_PACK2") or n_hap > 1024) else "k_pack3"
     if os.environ.get("PG_PAIR_V1"):
         rocprof_name = {_lib.K_PACK: "k_pack", _lib.K_PAIRWISE: "k_pairwise"}
     else:

@@ -585,13 +585,15 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
                     }
                     parity ^= 1;
                 }
-                // presence nibble of the site at mask bit `bit`
-                auto nib = [&](int bit) -> uint32_t {
-                    return ((pr[0] >> bit) & 1u) | (((pr[1] >> bit) & 1u) << 1) | (((pr[2] >> bit) & 1u) << 2) |
-                           (((pr[3] >> bit) & 1u) << 3);
-                };
                 const uint32_t m0 = poly_mask(pr);
                 if (m0) {
+                    // lane l (mod 32) works out the presence nibble of the site at mask bit l and its lowest allele, so that the
+                    // scalar loop below fetches them with one v_readlane per entry instead of a dozen scalar bit operations
+                    const int lb = lane & 31;
+                    const uint32_t Pl = __builtin_amdgcn_ubfe(pr[0], lb, 1) | (__builtin_amdgcn_ubfe(pr[1], lb, 1) << 1) |
+                                        (__builtin_amdgcn_ubfe(pr[2], lb, 1) << 2) | (__builtin_amdgcn_ubfe(pr[3], lb, 1) << 3);
+                    const uint32_t A0l = Pl & (0u - Pl);
+                    auto nib = [&](int bit) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)Pl, bit); };
                     // virtual site 0 of every polymorphic site: tests the lowest allele present, excludes nothing
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -599,8 +601,7 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
                         while (mq) {
                             const int bit = __builtin_ctz(mq);
                             mq &= mq - 1u;
-                            const uint32_t P = nib(bit);
-                            append(R[q], bit >> 2, P & (0u - P), 0u);
+                            append(R[q], bit >> 2, (uint32_t)__builtin_amdgcn_readlane((int)A0l, bit), 0u);
                         }
                     }
                     // rare: the second / third virtual site of the sites with three / four alleles
@@ -646,12 +647,13 @@ template <int DIP>
 static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *gt, int S, const int64_t *win_lo,
                          const int64_t *win_hi, const int64_t *goff, const int64_t *vgoff, uint32_t *Vp, int NPv, uint32_t *XV,
                          int NP, int32_t *nw, int32_t *mismatch, uint32_t *pres, int capg) {
-    // One wave per block (<= 256 slots): k_pack3 -- no barriers, every row fetched once (PMC: 2.27 instead of 2.56 GB per C2 pass;
-    // same speed within the box-to-box spread).  Two and four waves per block: k_pack2 -- k_pack3's per-entry scalar loop runs in
-    // every wave and its flushes meet in block barriers; measured on the north-star shape (400 slots) 8.3-9.0 ms against
-    // k_pack2's 8.0 ms.  PG_PACK2=1 / PG_PACK3=1 force one kernel for A/B runs and tests.
-    const bool force2 = getenv("PG_PACK2") != nullptr, force3 = getenv("PG_PACK3") != nullptr;
-    if (threads <= 256 && !force2 && (threads <= 64 || force3)) {
+    // Up to 1024 slots: k_pack3 (every row fetched once; PMC: 2.27 instead of 2.56 GB per C2 pass, 44.5 instead of 49.2 GB per
+    // north-star pass).  Same-box A/B (profiles/r02/ab_pack_*.txt): C2 0.450-0.485 vs 0.457-0.463 ms, north-star shape 7.7-7.9 vs
+    // 8.0-9.2 ms -- once the per-entry allele look-up had moved from the scalar unit to a lane-parallel table (before that
+    // k_pack3 lost on two-wave blocks, 8.3-9.0 ms: every wave of a block runs the per-entry scalar loop).  More than 1024 slots:
+    // k_pack2 behind the presence pre-pass.  PG_PACK2=1 forces k_pack2 (A/B runs and tests).
+    const bool force2 = getenv("PG_PACK2") != nullptr;
+    if (threads <= 256 && !force2) {
         if (threads <= 64)
             hipLaunchKernelGGL((k_pack3<64, DIP>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg);
         else if (threads <= 128)
