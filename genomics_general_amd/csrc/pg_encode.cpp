@@ -128,9 +128,37 @@ void parse_range(Shared &sh, const char *b, const char *e, int64_t row) {
 
 }  // namespace
 
+// line-start cuts of a buffer for `nt` threads
+static std::vector<size_t> line_cuts(const char *buf, size_t len, int nt) {
+    std::vector<size_t> cut(nt + 1, len);
+    cut[0] = 0;
+    for (int t = 1; t < nt; ++t) {
+        size_t guess = len / nt * t;
+        if (guess < cut[t - 1]) guess = cut[t - 1];
+        const char *nl = static_cast<const char *>(memchr(buf + guess, '\n', len - guess));
+        cut[t] = nl ? (size_t)(nl - buf) + 1 : len;
+    }
+    return cut;
+}
+
 extern "C" int pg_count_lines(const char *buf, size_t len, int64_t *n_rows_out) {
     if ((!buf && len) || !n_rows_out) return pg_fail(PG_ERR_ARG, "pg_count_lines: null argument");
-    *n_rows_out = count_rows(buf, buf + len);
+    // all host threads: on a gigabyte block a single-threaded count costs as much as the parallel parse that follows it
+    int nt = (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if ((size_t)nt > len / (1 << 20) + 1) nt = (int)(len / (1 << 20) + 1);
+    if (nt == 1) {
+        *n_rows_out = count_rows(buf, buf + len);
+        return PG_OK;
+    }
+    const std::vector<size_t> cut = line_cuts(buf, len, nt);
+    std::vector<int64_t> cnt(nt, 0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() { cnt[t] = count_rows(buf + cut[t], buf + cut[t + 1]); });
+    for (auto &x : th) x.join();
+    int64_t n = 0;
+    for (int t = 0; t < nt; ++t) n += cnt[t];
+    *n_rows_out = n;
     return PG_OK;
 }
 
@@ -190,15 +218,32 @@ extern "C" int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, 
 extern "C" int pg_scaffold_runs(const char *buf, const int64_t *scaf_off, const int32_t *scaf_len, int64_t n_sites,
                                 int64_t *run_start_out, int64_t max_runs, int64_t *n_runs_out) {
     if (!n_runs_out || (n_sites > 0 && (!buf || !scaf_off || !scaf_len))) return pg_fail(PG_ERR_ARG, "pg_scaffold_runs: null argument");
+    // row i starts a run when its scaffold token differs from row i-1's: independent per row, so the rows are cut into ranges for
+    // the host threads (every row's token sits in a different cache line of the text) and the ranges' run starts concatenated
+    int nt = (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if ((int64_t)nt > n_sites / 65536 + 1) nt = (int)(n_sites / 65536 + 1);
+    std::vector<std::vector<int64_t>> found(nt);
+    auto work = [&](int t) {
+        const int64_t a = n_sites * t / nt, b = n_sites * (t + 1) / nt;
+        for (int64_t i = a; i < b; ++i) {
+            const bool same = i > 0 && scaf_len[i] == scaf_len[i - 1] &&
+                              memcmp(buf + scaf_off[i], buf + scaf_off[i - 1], (size_t)scaf_len[i]) == 0;
+            if (!same) found[t].push_back(i);
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
     int64_t n = 0;
-    for (int64_t i = 0; i < n_sites; ++i) {
-        bool same = i > 0 && scaf_len[i] == scaf_len[i - 1] &&
-                    memcmp(buf + scaf_off[i], buf + scaf_off[i - 1], (size_t)scaf_len[i]) == 0;
-        if (!same) {
+    for (int t = 0; t < nt; ++t)
+        for (int64_t i : found[t]) {
             if (n < max_runs && run_start_out) run_start_out[n] = i;
             ++n;
         }
-    }
     *n_runs_out = n;
     if (n > max_runs) return pg_fail(PG_ERR_ARG, "%lld scaffold runs exceed capacity %lld", (long long)n, (long long)max_runs);
     return PG_OK;
