@@ -41,7 +41,8 @@ IO_FLAGS = [
 PLOIDY_FLAGS = [
     (("--ploidy",), dict(type=int, nargs="+", help="Ploidy for each sample")),
     (("--ploidyFile",), dict(help="File with samples names and ploidy as columns")),
-    (("--inferPloidy",), dict(action="store_true", help="(not supported by the GPU engine)")),
+    (("--inferPloidy",), dict(action="store_true", help="Ploidy is inferred from the cells of the first data row (the reference infers it "
+                                                         "window by window, NOT RECOMMENDED there)")),
 ]
 
 
@@ -99,7 +100,15 @@ def _ploidy_dict(args, inds, haploid_list):
         with open(args.ploidyFile, "rt") as pf:
             return dict([[s[0], int(s[1])] for s in [ln.split() for ln in pf]])
     if args.inferPloidy:
-        raise SystemExit("--inferPloidy is not supported by the MI355X engine (the reference itself marks it NOT RECOMMENDED)")
+        # The reference leaves the ploidy open and genoToAlignment takes the number of sequences splitSeq returns for the window
+        # (genomics.py:1110, 390-396), i.e. what the cell width says.  Here the widths of the first data row decide once for the
+        # whole file; a later cell of another width is a tokenizer error (the reference would zip-truncate the window to its
+        # shortest cell).
+        header = getattr(args, "header", None) or (" ".join(args.headers) if getattr(args, "headers", None) else None)
+        inferred = genoio.first_row_ploidy(args.genoFile, args.genoFormat, header)
+        for s in inds:
+            assert s in inferred, "sample %s is not in the genotype file header" % s
+        return {s: inferred[s] for s in inds}
     d = dict(zip(inds, [1 if args.genoFormat == "haplo" else 2] * len(inds)))
     for s in haploid_list or []:
         d[s] = 1

@@ -587,6 +587,26 @@ def read_header_names(path):
         return f.readline().split()[2:]
 
 
+def first_row_ploidy(path, fmt, header_line=None):
+    """{sample name: ploidy its cell in the first data row implies} (for --inferPloidy); needs a file, not a pipe"""
+    if path is None:
+        raise SystemExit("--inferPloidy needs -g FILE: the first data row is read ahead of the run")
+    if str(path).endswith(".pgeno"):
+        rd = PackedReader(path)
+        rd.close()
+        return {nm: int(p) for nm, p in zip(rd.names, rd.ploidy)}
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "rt") as f:
+        names = header_line.split()[2:] if header_line else f.readline().split()[2:]
+        for line in f:
+            if line.strip() and not line.startswith("#"):
+                w = [len(c) for c in line.split()[2:]]
+                # splitSeq (genomics.py:390-396): phased cells hold their alleles at every other character, pairs one per character
+                return {nm: ((x + 1) // 2 if fmt == "phased" else x if fmt == "pairs" else 1 if fmt == "haplo" else 2)
+                        for nm, x in zip(names, w)}
+    return {nm: (1 if fmt == "haplo" else 2) for nm in names}
+
+
 def split_header(data, header_line=None):
     """(sample names, data bytes after the header).  With --header the file has no header line
     (GenoFileReader.__init__, genomics.py:1917-1919)."""

@@ -72,7 +72,7 @@ class HapLayout:
         for s, nm in enumerate(self.ind_order):
             pl = sampleData.ploidy.get(nm)
             if pl is None:
-                raise ValueError("--inferPloidy is not supported by the MI355X engine: give --ploidy/--ploidyFile/--haploid")
+                raise ValueError("ploidy of %s is not known: give --ploidy / --ploidyFile / --haploid (or --inferPloidy)" % nm)
             if pl < 1 or pl > 26:
                 raise ValueError("ploidy of %s must be in 1..26" % nm)
             if genoFormat == "diplo" and pl != 2:

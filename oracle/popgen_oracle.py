@@ -220,6 +220,12 @@ def window_to_aln(win, file_names, ind_names, pop_of, ploidy_of, fmt):
     for nm in ind_names:
         pl = ploidy_of[nm]
         cells = [row[col[nm]] for row in win.rows]
+        if pl is None:
+            # ploidy left open (--inferPloidy): the number of sequences splitSeq returns for the window, genomics.py:1110 --
+            # zip(*cells) stops at the shortest cell (390-396)
+            short = min((len(IUPAC_PAIR[c]) if fmt == "diplo" else len(c)) for c in cells) if cells else 0
+            pl = (short + 1) // 2 if fmt == "phased" else short
+            cells = [c if fmt == "diplo" else c[:(2 * pl - 1 if fmt == "phased" else pl)] for c in cells]
         per_site = [split_cell(c, fmt, pl) for c in cells]
         if pl != 1:
             for k in range(pl):
@@ -611,7 +617,9 @@ def popgen_windows_csv(geno_path, fmt, pops, wind_size, step=None, min_sites=1, 
         hit = [p for p, mem in pops if nm in mem]
         pop_of[nm] = hit[0] if len(hit) == 1 else (tuple(hit) if hit else None)
     ploidy_of = {nm: (1 if fmt == "haplo" else 2) for nm in ind_names}
-    if ploidy:
+    if ploidy == "infer":                                          # --inferPloidy, popgenWindows.py:299-300
+        ploidy_of = {nm: None for nm in ind_names}
+    elif ploidy:
         ploidy_of.update(ploidy)
     stats = []
     if "popFreq" in analysis:

@@ -107,6 +107,9 @@ CASES = [
     dict(name="mixed_haploid_flag", tool="popgenWindows.py", fixture="mixed",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--haploid", "s1,s6,s9", "--roundTo", "6",
                "--analysis", "popDist", "popPairDist", "popFreq", "indPairDist"] + pops_args(10, 2)),
+    dict(name="mixed_inferploidy", tool="popgenWindows.py", fixture="mixed",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--inferPloidy", "--roundTo", "6",
+               "--analysis", "popDist", "popPairDist", "indPairDist"] + pops_args(10, 2)),
     dict(name="mixed_ploidyfile_distmat", tool="distMat.py", fixture="mixed",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1500", "-m", "20", "--ploidyFile", "{dir}/mixed_ploidy.txt", "--includeSameWithSame"]),
     dict(name="abba_popsfile_exclude", tool="ABBABABAwindows.py", fixture="abba",

@@ -74,6 +74,8 @@ def _ploidy(argv, haploid_is_list):
                 parts = ln.split()
                 if len(parts) >= 2:
                     out[parts[0]] = int(parts[1])
+    if "--inferPloidy" in argv:                       # popgenWindows.py:299-300: ploidy None for every sample
+        return "infer"
     if "--haploid" in argv:
         names = _multi(argv, "--haploid") if haploid_is_list else _take(argv, "--haploid").split(",")
         for nm in names:
