@@ -42,6 +42,12 @@ class BgzfFile:
         self.pending = b""               # compressed bytes not yet split into whole members
         self.buf = bytearray()           # inflated bytes not yet handed out
         self.eof = False
+        self.cpos = 0                    # file offset of pending[0]
+        self.produced = 0                # inflated bytes since the last seek_member()
+        self.track = []                  # (inflated offset, member file offset) of the members behind the bytes still buffered
+        self.keep_track = False          # ... of every member since seek_member (a scan that needs virtual positions)
+        self.stop = None                 # (member file offset, bytes of that member to keep): where a rank's share ends
+        self.size = os.path.getsize(path)
 
     @staticmethod
     def is_bgzf(path):
@@ -64,22 +70,112 @@ class BgzfFile:
         if not data:
             self.eof = True
             return
-        members, off, n = [], 0, len(data)
+        members, starts, off, n = [], [], 0, len(data)
+        last_keep = None
         while off + 18 <= n:
             if data[off:off + 4] != b"\x1f\x8b\x08\x04" or data[off + 12:off + 14] != b"BC":
                 raise ValueError("input stops being BGZF in the middle (bad member header)")
             size = int.from_bytes(data[off + 16:off + 18], "little") + 1
             if off + size > n:
                 break
+            if self.stop is not None and self.cpos + off >= self.stop[0]:
+                # the share ends inside this member (or right before it): keep its first stop[1] bytes and finish
+                if self.cpos + off == self.stop[0] and self.stop[1] > 0:
+                    members.append(data[off:off + size])
+                    starts.append(self.cpos + off)
+                    last_keep = self.stop[1]
+                self.eof = True
+                break
             members.append(data[off:off + size])
+            starts.append(self.cpos + off)
             off += size
         self.pending = data[off:]
-        if not new:
+        self.cpos += off
+        if not new and not self.eof:
             if self.pending:
                 raise ValueError("truncated BGZF input")
             self.eof = True
-        for part in self.pool.map(self._inflate, members):
+        parts = list(self.pool.map(self._inflate, members))
+        if last_keep is not None:
+            parts[-1] = parts[-1][:last_keep]
+        for st, part in zip(starts, parts):
+            self.track.append((self.produced, st))
+            self.produced += len(part)
             self.buf += part
+        if not self.keep_track and len(self.track) > 4096:
+            consumed = self.produced - len(self.buf)
+            k = 0
+            while k + 1 < len(self.track) and self.track[k + 1][0] <= consumed:
+                k += 1
+            del self.track[:k]
+
+    def set_stop(self, coffset, uoffset):
+        """end this reader's share at byte `uoffset` of the member at file offset `coffset` (which may already be buffered)"""
+        self.stop = (coffset, uoffset)
+        for at, st in self.track:
+            if st == coffset:
+                consumed = self.produced - len(self.buf)
+                keep = max(at + uoffset - consumed, 0)
+                if keep < len(self.buf):
+                    del self.buf[keep:]
+                self.produced = consumed + len(self.buf)
+                self.eof = True
+                return
+        if self.cpos > coffset:                                   # already past it, nothing of it buffered: an empty share
+            self.buf = bytearray()
+            self.eof = True
+
+    def seek_member(self, guess):
+        """continue reading at the first member that starts at or behind file offset `guess` (the end of the file if none)"""
+        pos = guess
+        self.raw.seek(pos)
+        window = b""
+        base = pos
+        found = None
+        while found is None:
+            more = self.raw.read(1 << 20)
+            window += more
+            at = 0
+            while True:
+                k = window.find(b"\x1f\x8b\x08\x04", at)
+                if k < 0 or k + 18 > len(window):
+                    break
+                if window[k + 10:k + 16] == b"\x06\x00BC\x02\x00":
+                    size = int.from_bytes(window[k + 16:k + 18], "little") + 1
+                    nxt = base + k + size
+                    if nxt == self.size:
+                        found = base + k
+                        break
+                    if nxt + 4 <= self.size:                      # the next member must start where this one says it ends
+                        here = self.raw.tell()
+                        self.raw.seek(nxt)
+                        good = self.raw.read(4) == b"\x1f\x8b\x08\x04"
+                        self.raw.seek(here)
+                        if good:
+                            found = base + k
+                            break
+                at = k + 1
+            if found is None and not more:
+                found = self.size
+            if found is None and len(window) > (2 << 20):
+                cutoff = len(window) - 64
+                base += cutoff
+                window = window[cutoff:]
+        self.raw.seek(found)
+        self.pending, self.buf, self.eof = b"", bytearray(), False
+        self.cpos, self.produced = found, 0
+        self.track = []
+        return found
+
+    def virtual_of(self, offset):
+        """(member file offset, offset inside the member) of inflated byte `offset` since seek_member (needs track)"""
+        import bisect
+        if not self.track:
+            return self.size, 0
+        k = bisect.bisect_right([t[0] for t in self.track], offset) - 1
+        if k < 0:
+            k = 0
+        return self.track[k][1], offset - self.track[k][0]
 
     def read(self, n=-1):
         if n is None or n < 0:
@@ -199,6 +295,8 @@ class BlockReader:
         boundaries nearest to the equal split (find_run_boundary; each rank looks for its own start, one all-gather shares
         them).  Returns False, leaving the reader untouched, when the input cannot be split (stdin, gzip) or has too few runs
         for a useful split (some rank would hold more than max_share of the bytes)."""
+        if isinstance(self.f, BgzfFile):
+            return self._shard_bgzf(world, comm, wanted, max_share)
         if not self.seekable_text():
             return False
         size = os.path.getsize(self.path)
@@ -221,6 +319,35 @@ class BlockReader:
         self.restrict(cuts[world.rank], cuts[world.rank + 1])
         return True
 
+    def _shard_bgzf(self, world, comm, wanted, max_share):
+        """BGZF (bgzip) input: the cuts are (member file offset, offset inside the member) pairs; a rank starts by seeking to its
+        member and dropping the bytes in front of its first line, and stops inside the member its successor starts in"""
+        bz = self.f
+        size = bz.size
+        mine = (0.0, 0.0)
+        scanned = 0
+        if world.rank > 0:
+            stride = size // world.size
+            guess = stride * world.rank - min(max(stride // 64, 1 << 12), stride // 2)
+            (c, u), scanned = find_run_boundary_bgzf(self.path, max(guess, 0), wanted)
+            mine = (float(c), float(u))
+        allc = comm.allgather(np.array(mine)).reshape(world.size, 2)
+        cuts = [(int(c), int(u)) for c, u in allc] + [(size, 0)]
+        for r in range(2, len(cuts)):
+            cuts[r] = max(cuts[r], cuts[r - 1])
+        starts = [0] + [c for c, _ in cuts[1:]]
+        if max(starts[r + 1] - starts[r] for r in range(world.size)) / max(size, 1) > max_share:
+            return False
+        self.bytes_read += scanned
+        if world.rank > 0:
+            bz.seek_member(cuts[world.rank][0])
+            bz.read(cuts[world.rank][1])
+        if cuts[world.rank] >= cuts[world.rank + 1] and world.rank > 0:
+            bz.buf, bz.eof = bytearray(), True                 # an empty share
+        elif world.rank + 1 < world.size:
+            bz.set_stop(*cuts[world.rank + 1])
+        return True
+
     def to_geno(self, body, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, keep_packed=False):
         return encode(body, layout, n_threads, head_rows, pitch, alloc)
 
@@ -234,59 +361,94 @@ class BlockReader:
             self.f.close()
 
 
-def find_run_boundary(path, guess, wanted, chunk=8 << 10, max_chunk=16 << 20):
+def _scan_run_boundary(next_chunk, wanted, chunk=8 << 10, max_chunk=16 << 20):
+    """Walk whole lines from `next_chunk(nbytes)` (bytes ending at a line boundary, b"" at the end) and return (offset of the first
+    data line that starts a new scaffold run whose own scaffold and the preceding one are both wanted -- relative to the start of
+    the walk, None if there is none --, bytes walked).  The first data line only names the current run."""
+    import re
+    scanned, base = 0, 0
+    cur, pat = None, None
+    while True:
+        data = next_chunk(chunk)
+        chunk = min(2 * chunk, max_chunk)                # small reads first: the boundary is usually near
+        if not data:
+            return None, scanned
+        scanned += len(data)
+        at = 0
+        while at < len(data):
+            if cur is None:                              # first data line of the scan: it only names the current run
+                nl = data.find(b"\n", at)
+                line = data[at:nl if nl >= 0 else len(data)]
+                tok = line.split(None, 1)
+                if tok and not line.startswith(b"#"):
+                    cur = tok[0]
+                    pat = re.compile(rb"\n(?!" + re.escape(cur) + rb"[ \t])")
+                at = (nl + 1) if nl >= 0 else len(data)
+                continue
+            m = pat.search(data, max(at - 1, 0))
+            if m is None:
+                break
+            at = m.end()                                  # start of a line that does not begin with `cur` + blank
+            if at >= len(data):
+                break
+            nl = data.find(b"\n", at)
+            line = data[at:nl if nl >= 0 else len(data)]
+            tok = line.split(None, 1)
+            if not tok or line.startswith(b"#"):          # blank or comment line: not a data row
+                at = (nl + 1) if nl >= 0 else len(data)
+                continue
+            prev, cur = cur, tok[0]
+            pat = re.compile(rb"\n(?!" + re.escape(cur) + rb"[ \t])")
+            if wanted(prev.decode("utf-8", "replace")) and wanted(cur.decode("utf-8", "replace")):
+                return base + at, scanned
+            at = (nl + 1) if nl >= 0 else len(data)
+        base += len(data)
+
+
+def find_run_boundary(path, guess, wanted):
     """Byte offset of the first data line at or behind offset `guess` that starts a new scaffold run whose own scaffold and the
     preceding one are both wanted (`wanted(name) -> bool`: --include / --exclude), or the file size when there is none; and
     the number of bytes scanned.  Windows never span scaffold runs, and the window generators carry state across a run
     boundary only around skipped scaffolds (genomics.py:2016-2023), so such a boundary is a place where the input can be
     split between ranks (the slice-parallel ingestion of the reference's freq.py:23-28, here on run boundaries)."""
-    import re
     size = os.path.getsize(path)
-    scanned = 0
     with open(path, "rb") as f:
         # start at the line that holds the byte before `guess`: it names the run to the left of the first candidate line
         back = min(guess, 4 << 20)
         f.seek(guess - back)
         head = f.read(back)
-        f.seek(guess - back + head.rfind(b"\n", 0, max(back - 1, 0)) + 1)
-        cur, pat = None, None
-        while True:
-            base = f.tell()
-            data = f.read(chunk)
-            chunk = min(2 * chunk, max_chunk)            # small reads first: the boundary is usually near
-            if not data:
-                return size, scanned
-            if not data.endswith(b"\n"):
+        start = guess - back + head.rfind(b"\n", 0, max(back - 1, 0)) + 1
+        f.seek(start)
+
+        def next_chunk(n):
+            data = f.read(n)
+            if data and not data.endswith(b"\n"):
                 data += f.readline()
-            scanned += len(data)
-            at = 0
-            while at < len(data):
-                if cur is None:                              # first data line of the scan: it only names the current run
-                    nl = data.find(b"\n", at)
-                    line = data[at:nl if nl >= 0 else len(data)]
-                    tok = line.split(None, 1)
-                    if tok and not line.startswith(b"#"):
-                        cur = tok[0]
-                        pat = re.compile(rb"\n(?!" + re.escape(cur) + rb"[ \t])")
-                    at = (nl + 1) if nl >= 0 else len(data)
-                    continue
-                m = pat.search(data, max(at - 1, 0))
-                if m is None:
-                    break
-                at = m.end()                                  # start of a line that does not begin with `cur` + blank
-                if at >= len(data):
-                    break
-                nl = data.find(b"\n", at)
-                line = data[at:nl if nl >= 0 else len(data)]
-                tok = line.split(None, 1)
-                if not tok or line.startswith(b"#"):          # blank or comment line: not a data row
-                    at = (nl + 1) if nl >= 0 else len(data)
-                    continue
-                prev, cur = cur, tok[0]
-                pat = re.compile(rb"\n(?!" + re.escape(cur) + rb"[ \t])")
-                if wanted(prev.decode("utf-8", "replace")) and wanted(cur.decode("utf-8", "replace")):
-                    return base + at, scanned
-                at = (nl + 1) if nl >= 0 else len(data)
+            return data
+
+        rel, scanned = _scan_run_boundary(next_chunk, wanted)
+    return (size if rel is None else start + rel), scanned
+
+
+def find_run_boundary_bgzf(path, guess, wanted):
+    """The same on a BGZF file: the walk starts at the first line that begins in or behind the member at compressed offset >=
+    `guess`; returns ((member file offset, offset inside the member) of the boundary line -- (file size, 0) if none --,
+    inflated bytes walked)."""
+    bz = BgzfFile(path)
+    bz.keep_track = True
+    bz.seek_member(guess)
+    skipped = len(bz.readline())                           # the line that straddles into this member belongs to the left
+
+    def next_chunk(n):
+        data = bz.read(n)
+        if data and not data.endswith(b"\n"):
+            data += bz.readline()
+        return data
+
+    rel, scanned = _scan_run_boundary(next_chunk, wanted)
+    out = (bz.size, 0) if rel is None else bz.virtual_of(skipped + rel)
+    bz.close()
+    return out, scanned + skipped
 
 
 # ---- packed `.pgeno` files: a tokenised `.geno` kept on disk ---------------------------------------------------------------

@@ -377,3 +377,47 @@ def test_packed_pgeno_round_trip_equals_the_tokenizer(name, fmt, haploid, tmp_pa
         f.write(b"#CHROM\tPOS\ta\n")
     with pytest.raises(ValueError):
         genoio.open_input(notp)
+
+
+class _FakeComm:
+    """all ranks' contributions are computed in this process: allgather returns what the ranks would have sent"""
+
+    def __init__(self, rows):
+        self.rows = rows
+
+    def allgather(self, arr):
+        return np.array(self.rows, dtype=np.float64)
+
+
+def test_bgzf_input_shards_at_scaffold_runs(tmp_path):
+    """BlockReader.shard on a bgzip file: cuts are (member offset, offset inside the member) pairs; the ranks' slices
+    concatenate to the data lines of the whole file, each slice starts on a scaffold-run boundary"""
+    from genomics_general_amd import dist
+    raw = genoio.read_all(os.path.join(GOLD, "sparse.geno.gz"))
+    path = str(tmp_path / "s.geno.gz")
+    _bgzf_write(path, raw, blk=3000)
+    body = raw[raw.index(b"\n") + 1:]
+    for n_ranks in (2, 3):
+        size = os.path.getsize(path)
+        mine = [(0.0, 0.0)]
+        for r in range(1, n_ranks):
+            stride = size // n_ranks
+            guess = stride * r - min(max(stride // 64, 1 << 12), stride // 2)
+            (c, u), _ = genoio.find_run_boundary_bgzf(path, max(guess, 0), lambda nm: True)
+            mine.append((float(c), float(u)))
+        parts = []
+        for r in range(n_ranks):
+            rd = genoio.BlockReader(path)
+            rd.read_header()
+            assert rd.shard(dist.World(r, n_ranks, r), _FakeComm(mine), lambda nm: True, max_share=0.95)
+            got = b""
+            while True:
+                b = rd.read_block(4000)
+                if not b:
+                    break
+                got += bytes(b)
+            rd.close()
+            parts.append(got)
+        assert b"".join(parts) == body
+        firsts = [p.split(None, 1)[0] for p in parts if p]
+        assert len(set(firsts)) == len(firsts) and all(p.endswith(b"\n") for p in parts if p)

@@ -2,7 +2,7 @@
 # GPU call D of round 2: suite, rocprofv3 stats + PMC passes of the final kernel selection (c2, northstar), T2 text bench, bench lines.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02d
+O=gpurun_out/r02f
 mkdir -p $O/prof_stats $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1
 tail -6 $O/pytest_gpu.log
@@ -20,3 +20,10 @@ rm -f $O/*/*agent_info.csv $O/prof_stats/*kernel_trace.csv
 cat $O/t2_10M_100.txt | cut -c1-600
 ( time timeout 600 python bench.py ) > $O/bench_default.json 2> $O/bench_default.err
 tail -c 1800 $O/bench_default.json; tail -3 $O/bench_default.err
+echo "== overlap experiment: north-star shape forced into >= 8 pipelined sub-batches"
+PG_OVERLAP=1 timeout 300 python bench.py --workload northstar --steps 6 --warmup 2 --no-cpu-baseline --no-tiers 2>&1 | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); print('PG_OVERLAP=1', d['ms_per_step'], d.get('kernel_ms_per_step'))"
+timeout 300 python bench.py --workload northstar --steps 6 --warmup 2 --no-cpu-baseline --no-tiers 2>&1 | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); print('one batch   ', d['ms_per_step'], d.get('kernel_ms_per_step'))"
