@@ -225,6 +225,30 @@ def tier_samples(eng, lay, wl, names, slot_gen, scaf_len, n_sites, t1_block, t0_
             tab, _ = eng.batch(lo + base[k % 2], lo + base[k % 2] + wind).groupDistTable(True, wl["min_sites"], 0.01)
         dt = time.perf_counter() - t0
     ok = bool(np.array_equal(tab, t0_table[(n_blocks - 1) * len(lo):n_blocks * len(lo)], equal_nan=True))
+    # the same blocks as packed cells (the `.pgeno` payload: one byte per diploid genotype, expanded on the device by k_unpack)
+    t1p = None
+    if lay.n_hap == 2 * lay.n_samp:
+        cells = eng.pinned.empty((n_blocks * t1_block, lay.n_samp), np.uint8)
+        slot0 = np.array([lay.ind_slots[nm][0] for nm in lay.ind_order])
+        np.bitwise_or(host[:, slot0].view(np.uint8), host[:, slot0 + 1].view(np.uint8) << 4, out=cells)
+        slot_src = np.empty(lay.n_hap, dtype=np.int32)
+        slot_src[slot0], slot_src[slot0 + 1] = 2 * np.arange(lay.n_samp), 2 * np.arange(lay.n_samp) + 1
+        for rep in range(2):
+            t0 = time.perf_counter()
+            eng.upload_packed_async(cells[0:t1_block], base[0], slot_src)
+            for k in range(n_blocks):
+                eng.upload_wait()
+                if k + 1 < n_blocks:
+                    eng.upload_packed_async(cells[(k + 1) * t1_block:(k + 2) * t1_block], base[(k + 1) % 2], slot_src)
+                tabp, _ = eng.batch(lo + base[k % 2], lo + base[k % 2] + wind).groupDistTable(True, wl["min_sites"], 0.01)
+            dtp = time.perf_counter() - t0
+        t1p = {"sites_per_sec": round(n_blocks * t1_block / dtp, 1), "windows_per_sec": round(n_blocks * len(lo) / dtp, 2),
+               "h2d_GBps": round(n_blocks * t1_block * lay.n_samp / dtp / 1e9, 2),
+               "matches_t0": bool(np.array_equal(tabp, t0_table[(n_blocks - 1) * len(lo):n_blocks * len(lo)], equal_nan=True)),
+               "sample": "the same blocks as packed cells (1 byte per diploid genotype = 0.5 byte per call over PCIe), expanded into "
+                         "resident rows on the device (pg_upload_packed_async / k_unpack)"}
+        del cells
+    out["t1_packed"] = t1p
     out["t1"] = {"sites_per_sec": round(n_blocks * t1_block / dt, 1), "windows_per_sec": round(n_blocks * len(lo) / dt, 2),
                  "h2d_GBps": round(n_blocks * t1_block * pitch / dt / 1e9, 2), "matches_t0": ok,
                  "sample": "%d page-locked host blocks of %d sites x %d haplotypes (int8, 1 byte per call), uploaded into alternating "
