@@ -10,6 +10,8 @@
 #include <cstring>
 #include <thread>
 
+#include <zlib.h>
+
 namespace {
 
 struct CodeTables {
@@ -281,5 +283,50 @@ extern "C" int pg_decode_packed(const uint8_t *cells, int64_t n_rows, int n_cols
     std::vector<std::thread> th;
     for (int i = 0; i < nt; ++i) th.emplace_back(work, n_rows * i / nt, n_rows * (i + 1) / nt);
     for (auto &t : th) t.join();
+    return PG_OK;
+}
+
+// ---- deflated `.pgeno` chunks -> their destinations, on all host threads ---------------------------------------------------
+// A block's payload is pos || cells, deflated in independent chunks (genoio.PackedWriter).  The logical output of the chunks,
+// concatenated, is written to two destinations: the first len_a bytes to dst_a (the block's positions), the rest to dst_b (its
+// cells, e.g. rows of the page-locked array an upload will read) -- no intermediate copy of the gigabyte.
+extern "C" int pg_inflate_chunks(const uint8_t *src, const int64_t *src_off, const int64_t *src_len, const int64_t *raw_len,
+                                 int n_chunks, uint8_t *dst_a, int64_t len_a, uint8_t *dst_b, int64_t len_b, int n_threads) {
+    if (n_chunks < 0 || (n_chunks > 0 && (!src || !src_off || !src_len || !raw_len)) || len_a < 0 || len_b < 0)
+        return pg_fail(PG_ERR_ARG, "pg_inflate_chunks: bad argument");
+    if ((len_a > 0 && !dst_a) || (len_b > 0 && !dst_b)) return pg_fail(PG_ERR_ARG, "pg_inflate_chunks: null destination");
+    std::vector<int64_t> at(n_chunks + 1, 0);
+    for (int i = 0; i < n_chunks; ++i) {
+        if (src_len[i] < 0 || raw_len[i] < 0) return pg_fail(PG_ERR_ARG, "pg_inflate_chunks: negative size");
+        at[i + 1] = at[i] + raw_len[i];
+    }
+    if (at[n_chunks] != len_a + len_b) return pg_fail(PG_ERR_ARG, "pg_inflate_chunks: the chunks hold %lld bytes, the destinations %lld", (long long)at[n_chunks], (long long)(len_a + len_b));
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > n_chunks) nt = n_chunks > 0 ? n_chunks : 1;
+    std::atomic<int> next(0), bad(0);
+    auto work = [&]() {
+        std::vector<uint8_t> tmp;
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_chunks || bad.load()) return;
+            const int64_t a = at[i], b = at[i + 1];
+            uint8_t *out;
+            const bool straddles = a < len_a && b > len_a;
+            if (straddles) { tmp.resize((size_t)(b - a)); out = tmp.data(); }
+            else out = a >= len_a ? dst_b + (a - len_a) : dst_a + a;
+            uLongf got = (uLongf)(b - a);
+            const int rc = uncompress(out, &got, src + src_off[i], (uLong)src_len[i]);
+            if (rc != Z_OK || (int64_t)got != b - a) { bad.store(1); return; }
+            if (straddles) {
+                memcpy(dst_a + a, tmp.data(), (size_t)(len_a - a));
+                memcpy(dst_b, tmp.data() + (len_a - a), (size_t)(b - len_a));
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work);
+    for (auto &x : th) x.join();
+    if (bad.load()) return pg_fail(PG_ERR_PARSE, "pg_inflate_chunks: a chunk does not inflate to its recorded size (damaged .pgeno block)");
     return PG_OK;
 }

@@ -510,6 +510,45 @@ class PackedWriter:
         self.f.close()
 
 
+class _PackedBlock:
+    """One block of a `.pgeno` file as read from disk: scaffold runs + either the materialised arrays (pos, cells) or the still
+    deflated chunks (comp, table), which PackedReader.to_geno inflates straight into their destination (pg_inflate_chunks)."""
+
+    def __init__(self, starts, names, n, n_cols, pos=None, cells=None, comp=None, table=None):
+        self.starts, self.names, self.n, self.n_cols = starts, names, n, n_cols
+        self.pos, self.cells, self.comp, self.table = pos, cells, comp, table
+
+    def inflate_into(self, pos_dst, cells_dst, n_threads=0):
+        """positions -> pos_dst[n] (int32), cells -> cells_dst[n][n_cols] (uint8, C-contiguous rows)"""
+        if self.comp is None:
+            pos_dst[...] = self.pos
+            cells_dst[...] = self.cells
+            return
+        assert pos_dst.flags.c_contiguous and cells_dst.flags.c_contiguous
+        stored = self.table[:, 0].astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(stored)[:-1]]).astype(np.int64)
+        src = np.frombuffer(self.comp, dtype=np.uint8)
+        check(_lib.lib().pg_inflate_chunks(C.c_void_p(src.ctypes.data), off, np.ascontiguousarray(stored),
+                                           np.ascontiguousarray(self.table[:, 1].astype(np.int64)), len(stored),
+                                           C.c_void_p(pos_dst.ctypes.data), 4 * self.n, C.c_void_p(cells_dst.ctypes.data),
+                                           self.n * self.n_cols, n_threads))
+
+    def materialise(self):
+        if self.comp is not None:
+            pos, cells = np.empty(self.n, dtype=np.int32), np.empty((self.n, self.n_cols), dtype=np.uint8)
+            self.inflate_into(pos, cells)
+            self.pos, self.cells, self.comp, self.table = pos, cells, None, None
+        return self
+
+    def trim(self, a, b):
+        """rows [a, b) of the block (materialised)"""
+        self.materialise()
+        keep = np.flatnonzero((self.starts < b) & (np.append(self.starts[1:], self.n) > a))
+        names = [self.names[k] for k in keep]
+        starts = np.maximum(self.starts[keep] - a, 0)
+        return _PackedBlock(starts, names, b - a, self.n_cols, self.pos[a:b], self.cells[a:b])
+
+
 class PackedReader:
     """Counterpart of BlockReader for `.pgeno` files: read_header() returns a `.geno`-style header line, read_block(nbytes)
     returns the raw blocks (about nbytes of cells) and to_geno() decodes them into slot order (pg_decode_packed)."""
@@ -613,24 +652,24 @@ class PackedReader:
             ln = int.from_bytes(self.f.read(2), "little")
             names.append(self.f.read(ln).decode())
         want = 4 * n + n * self.n_cols
+        starts = np.asarray(starts, dtype=np.int64)
         if self.codec == "none":
             payload = self.f.read(want)
             self.bytes_read += 12 + len(payload)
+            if len(payload) != want:
+                raise ValueError("truncated .pgeno file")
+            blk = _PackedBlock(starts, names, n, self.n_cols, np.frombuffer(payload, dtype="<i4", count=n),
+                               np.frombuffer(payload, dtype=np.uint8, offset=4 * n).reshape(n, self.n_cols))
         else:
-            import zlib
             n_chunks = int.from_bytes(self.f.read(4), "little")
             table = np.frombuffer(self.f.read(8 * n_chunks), dtype="<u4").reshape(-1, 2)
             if table.shape[0] != n_chunks or int(table[:, 1].sum()) != want:
                 raise ValueError("damaged .pgeno block")
-            comp = [self.f.read(int(c)) for c in table[:, 0]]
-            self.bytes_read += 16 + 8 * n_chunks + int(table[:, 0].sum())
-            with _pool() as ex:
-                payload = b"".join(ex.map(zlib.decompress, comp))               # zlib releases the GIL
-        if len(payload) != want:
-            raise ValueError("truncated .pgeno file")
-        pos = np.frombuffer(payload, dtype="<i4", count=n)
-        cells = np.frombuffer(payload, dtype=np.uint8, offset=4 * n).reshape(n, self.n_cols)
-        starts = np.asarray(starts, dtype=np.int64)
+            comp = self.f.read(int(table[:, 0].sum()))               # still deflated: inflated into place by to_geno
+            if len(comp) != int(table[:, 0].sum()):
+                raise ValueError("truncated .pgeno file")
+            self.bytes_read += 16 + 8 * n_chunks + len(comp)
+            blk = _PackedBlock(starts, names, n, self.n_cols, comp=comp, table=table)
         g0, self._g = self._g, self._g + n
         if self._rows is not None:                       # trim the block to this reader's rows
             a, b = max(self._rows[0] - g0, 0), min(self._rows[1] - g0, n)
@@ -639,11 +678,8 @@ class PackedReader:
             if b <= a:
                 return self._one() if not self.done else None
             if a > 0 or b < n:
-                keep = np.flatnonzero((starts < b) & (np.append(starts[1:], n) > a))
-                names = [names[k] for k in keep]
-                starts = np.maximum(starts[keep] - a, 0)
-                pos, cells = pos[a:b], cells[a:b]
-        return (starts, names, pos, cells)
+                blk = blk.trim(a, b)
+        return blk
 
     def read_block(self, nbytes=None):
         """list of raw blocks ([] at the end of the file); nbytes counts text bytes (about 4 per cell) like BlockReader's"""
@@ -653,7 +689,7 @@ class PackedReader:
             if b is None:
                 break
             out.append(b)
-            got += b[3].size
+            got += b.n * b.n_cols
         return out
 
     def to_geno(self, raw_blocks, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, keep_packed=False):
@@ -667,7 +703,7 @@ class PackedReader:
             bad = int(np.flatnonzero(wanted & (layout.col_ploidy != self.ploidy))[0])
             raise ValueError("sample %s was packed with ploidy %d but ploidy %d is requested" % (
                 self.names[bad], int(self.ploidy[bad]), int(layout.col_ploidy[bad])))
-        n = sum(int(b[2].shape[0]) for b in raw_blocks)
+        n = sum(b.n for b in raw_blocks)
         alloc = alloc or np.zeros
         width = self.n_cols if keep_packed else (int(pitch) if pitch else layout.n_hap)
         gt_full = alloc((head_rows + max(n, 1), width), np.uint8 if keep_packed else np.int8)
@@ -675,16 +711,17 @@ class PackedReader:
         gt, pos = gt_full[head_rows:head_rows + n], pos_full[head_rows:head_rows + n]
         starts, names, row = [], [], 0
         L = _lib.lib()
-        for st, nm, p, cells in raw_blocks:
-            k = int(p.shape[0])
+        for blk in raw_blocks:
+            k = blk.n
             if keep_packed:
-                gt[row:row + k] = cells
+                blk.inflate_into(pos[row:row + k], gt[row:row + k], n_threads)      # deflated chunks -> their final rows
             else:
-                check(L.pg_decode_packed(np.ascontiguousarray(cells), k, self.n_cols, layout.max_ploidy,
+                cells = np.empty((k, self.n_cols), dtype=np.uint8)
+                blk.inflate_into(pos[row:row + k], cells, n_threads)
+                check(L.pg_decode_packed(cells, k, self.n_cols, layout.max_ploidy,
                                          np.ascontiguousarray(layout.col_slot), layout.col_ploidy, width,
                                          gt[row:row + k], n_threads))
-            pos[row:row + k] = p
-            for s_, n_ in zip(st, nm):
+            for s_, n_ in zip(blk.starts, blk.names):
                 if names and names[-1] == n_ and int(s_) == 0:
                     continue                                     # the run continues across the block seam
                 starts.append(row + int(s_))

@@ -152,6 +152,12 @@ int pg_encode_vcf(const char *buf, size_t len, int n_vcf_samples, int n_sel, con
                   int64_t *chrom_off, int32_t *chrom_len, int64_t *ref_off, int32_t *ref_len, int64_t *alt_off, int32_t *alt_len,
                   int64_t cap_sites, int64_t *n_sites_out, int64_t *n_multibase_out, int n_threads);
 
+/* Inflate the independently deflated chunks of a `.pgeno` block (zlib streams; genoio.PackedWriter) on all host threads: the
+ * concatenated output goes to dst_a (first len_a bytes: the block's int32 positions) and dst_b (the rest: its cells, e.g. rows of
+ * the page-locked array an upload will read).  src_off / src_len locate chunk i in src, raw_len[i] is its inflated size. */
+int pg_inflate_chunks(const uint8_t *src, const int64_t *src_off, const int64_t *src_len, const int64_t *raw_len, int n_chunks,
+                      uint8_t *dst_a, int64_t len_a, uint8_t *dst_b, int64_t len_b, int n_threads);
+
 /* Packed `.pgeno` input (genomics_general_amd/genoio.py: a tokenised `.geno` file kept on disk, one byte per genotype cell =
  * first allele code | second allele code << 4, in file column order): block of cells -> one-hot codes in slot order, same
  * col_slot / col_ploidy tables as pg_encode_text. */

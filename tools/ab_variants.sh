@@ -15,10 +15,10 @@ SRCS="pg_kernels.hip pg_pair2.hip pg_abi.cpp pg_encode.cpp pg_vcf.cpp pg_comm.cp
 case "$1" in
 build)
   shift; mkdir -p ab
-  (cd $CS && /opt/rocm/bin/hipcc $FLAGS $SRCS -shared -o ../../ab/libBASE.so -ldl -lpthread)
+  (cd $CS && /opt/rocm/bin/hipcc $FLAGS $SRCS -shared -o ../../ab/libBASE.so -ldl -lpthread -lz)
   for spec in "$@"; do
     name="${spec%%=*}"; defs="${spec#*=}"
-    (cd $CS && /opt/rocm/bin/hipcc $FLAGS $defs $SRCS -shared -o ../../ab/lib$name.so -ldl -lpthread)
+    (cd $CS && /opt/rocm/bin/hipcc $FLAGS $defs $SRCS -shared -o ../../ab/lib$name.so -ldl -lpthread -lz)
     echo "built ab/lib$name.so  ($defs)"
   done ;;
 run)
