@@ -33,21 +33,26 @@ class _Filter(C.Structure):
                 ("samples", C.c_void_p)]
 
 
-def _parse_gtf(arg):
-    """parseGenotypeFilterArg (parseVCF.py:255-266): flag=X min=X max=X siteTypes=X,X gtTypes=X,X samples=X,X"""
-    try:
-        d = dict(tuple(i.split("=")) for i in arg)
-        for key in d:
-            assert key in ("flag", "min", "max", "siteTypes", "gtTypes", "samples")
-        for key in ("siteTypes", "gtTypes", "samples"):
-            if key in d:
-                d[key] = d[key].split(",")
-        d["min"] = float(d["min"]) if "min" in d else -np.inf
-        d["max"] = float(d["max"]) if "max" in d else np.inf
-        assert "flag" in d
-        return d
-    except Exception:
+def _parse_gtf(tokens):
+    """One --gtf option (the `key=value` words of parseVCF.py:255-266) -> the fields of a pg_vcf_filter: FORMAT flag, closed
+    value range, and the optional selectors (site types, genotype types, samples) the filter is restricted to."""
+    spec = {"min": -np.inf, "max": np.inf}
+    for tok in tokens:
+        key, eq, value = tok.partition("=")
+        if not eq or key not in ("flag", "min", "max", "siteTypes", "gtTypes", "samples"):
+            raise ValueError("Bad genotype filter specification. See help.")
+        if key in ("min", "max"):
+            try:
+                spec[key] = float(value)
+            except ValueError:
+                raise ValueError("Bad genotype filter specification. See help.")
+        elif key == "flag":
+            spec[key] = value
+        else:
+            spec[key] = value.split(",")
+    if "flag" not in spec:
         raise ValueError("Bad genotype filter specification. See help.")
+    return spec
 
 
 def _open_out(path):
