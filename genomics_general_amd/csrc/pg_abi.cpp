@@ -579,13 +579,23 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     c->cN = n_units;
     c->cshift = dip ? 1 : 0;
     const int64_t mat_bytes = 4ll * N * N + 4ll * n_units * n_units;
+    // compaction group = words per pack block: 128 when that still oversubscribes the chip's wave slots several times (see
+    // pg_internal.h), else 64; PG_GROUP_WORDS overrides (A/B runs)
+    int grp = PG_GROUP;
+    {
+        int64_t blocks64 = 0;
+        for (int w = 0; w < n_win; ++w) blocks64 += ((hi[w] - lo[w] + 31) / 32 + PG_GROUP - 1) / PG_GROUP;
+        const int waves_per_block = (NP / 4 + 63) / 64;
+        if (blocks64 * waves_per_block >= 32768) grp = PG_GROUP_MAX;
+        if (const char *g = getenv("PG_GROUP_WORDS")) grp = atoi(g) >= PG_GROUP_MAX ? PG_GROUP_MAX : PG_GROUP;
+    }
     // scratch bytes per 32-site input word of one slot: called plane + reserved virtual-site planes (capg words per group)
-    const int capg = c->xv_capg;
-    const int64_t word_bytes = ((int64_t)NP * 4 * PG_XV_PLANES * capg + PG_GROUP - 1) / PG_GROUP + (int64_t)NPv * 4;
+    const int capg = c->xv_worst ? PG_XV_CAP(grp) : PG_XV_CAP_DEFAULT(grp);
+    const int64_t word_bytes = ((int64_t)NP * 4 * PG_XV_PLANES * capg + grp - 1) / grp + (int64_t)NPv * 4;
     // sub-batch size: at most half the scratch budget per slot, and at least ~8 sub-batches per call so the two
     // streams have something to overlap (but not so small that a sub-batch cannot fill the GPU)
     int64_t total_words_all = 0;
-    for (int w = 0; w < n_win; ++w) total_words_all += ((hi[w] - lo[w] + 31) / 32 + PG_GROUP - 1) / PG_GROUP * PG_GROUP;
+    for (int w = 0; w < n_win; ++w) total_words_all += ((hi[w] - lo[w] + 31) / 32 + grp - 1) / grp * grp;
     // A job that fits one batch runs as one batch on one stream: splitting it only to overlap the pack kernel with the pair
     // kernels is slower (measured: C2 1.44 vs 0.99 ms).  A job that needs several batches anyway is cut into at least 8, so
     // that all but the first pack kernel and all but the last pair kernels run beside each other on the two streams
@@ -604,7 +614,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         int64_t words = 0;
         int w1 = w0;
         while (w1 < n_win) {
-            int64_t wlen = ((hi[w1] - lo[w1] + 31) / 32 + PG_GROUP - 1) / PG_GROUP * PG_GROUP;
+            int64_t wlen = ((hi[w1] - lo[w1] + 31) / 32 + grp - 1) / grp * grp;
             int64_t nbytes = (words + wlen) * word_bytes + (int64_t)(w1 - w0 + 1) * mat_bytes;
             if (w1 > w0 && (nbytes > (overlap ? c->scratch_limit / 2 : c->scratch_limit) || words + wlen > target_words)) break;
             words += wlen;
@@ -627,7 +637,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         // stage [lo | hi | goff(n+1) | vgoff(n+1) | nw]: nw = int32 word counters of k_pack2, zero per window (and, in the
         // > 1024-slot mode, one slot per group for k_word_scan) -- they ride in the same copy instead of a memset
         int64_t ga_pre = 0;
-        for (int k = 0; k < nb; ++k) ga_pre += ((hi[w0 + k] - lo[w0 + k] + 31) / 32 + PG_GROUP - 1) / PG_GROUP;
+        for (int k = 0; k < nb; ++k) ga_pre += ((hi[w0 + k] - lo[w0 + k] + 31) / 32 + grp - 1) / grp;
         const size_t n_nw = (size_t)nb + (NP > 1024 ? (size_t)ga_pre : 0);
         const size_t h_len = 4 * (size_t)nb + 2 + (n_nw + 1) / 2;
         if ((rc = sl.host.ensure(h_len)) != PG_OK) return rc;
@@ -640,7 +650,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
             const int64_t wds = (hi[w0 + k] - lo[w0 + k] + 31) / 32;
             h[2 * (size_t)nb + k] = ga;
             h[3 * (size_t)nb + 1 + k] = va;
-            const int64_t groups = (wds + PG_GROUP - 1) / PG_GROUP;
+            const int64_t groups = (wds + grp - 1) / grp;
             ga += groups;
             va += (wds + 3) / 4;
             max_groups = (int)std::max<int64_t>(max_groups, groups);
@@ -666,9 +676,9 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
             if ((rc = event_get(c, &e1)) != PG_OK) return rc;
             HIPCHK(hipEventRecord(e0, ps));
         }
-        if (NP > 1024 && (rc = sl.pres.ensure((size_t)std::max<int64_t>(ga, 1) * PG_GROUP * 4)) != PG_OK) return rc;
+        if (NP > 1024 && (rc = sl.pres.ensure((size_t)std::max<int64_t>(ga, 1) * grp * 4)) != PG_OK) return rc;
         pg_launch_pack2(ps, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, ga, sl.Vp.p, NPv, sl.XV.p, NP,
-                        d_nw, dip ? 1 : 0, c->flag.p, sl.pres.p, capg);
+                        d_nw, dip ? 1 : 0, c->flag.p, sl.pres.p, capg, grp);
         if (time_pack) {
             HIPCHK(hipEventRecord(e1, ps));
             c->events[PG_K_PACK].push_back(std::make_pair(e0, e1));
@@ -735,8 +745,8 @@ static int flag_ready(pg_ctx *c) {
 static int note_flags(pg_ctx *c, int flag, bool *dip, bool *again) {
     *again = false;
     if (flag & PG_FLAG_XV_OVERFLOW) {
-        if (c->xv_capg >= PG_XV_CAP) return pg_fail(PG_ERR_STATE, "XV overflow with the worst-case reservation");
-        c->xv_capg = PG_XV_CAP;
+        if (c->xv_worst) return pg_fail(PG_ERR_STATE, "XV overflow with the worst-case reservation");
+        c->xv_worst = true;
         for (int k = 0; k < 2; ++k) c->slot[k].XV.release();
         *again = true;
     }

@@ -107,7 +107,7 @@ struct pg_ctx {
         bool used = false;
     } slot[2];
     DevBuf<int32_t> flag;        // v2: PG_FLAG_MISMATCH | PG_FLAG_XV_OVERFLOW, raised by the pack kernels
-    int xv_capg = PG_XV_CAP_DEFAULT;   // XV words reserved per compaction group (PG_XV_CAP after an overflow)
+    bool xv_worst = false;       // XV words reserved per compaction group: PG_XV_CAP_DEFAULT, PG_XV_CAP after an overflow
     DevBuf<int32_t> Cfull, Dfull;  // pg_pairwise staging
     DevBuf<uint32_t> hapbits;      // k_hapstats: match matrices as bit rows
     DevBuf<int32_t> hap_order;     // k_hapstats: each population's slots in the reference's row order

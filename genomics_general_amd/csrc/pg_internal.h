@@ -15,14 +15,18 @@ struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,r
     int32_t row0, nsub, col0, pad;
 };
 
-#ifndef PG_GROUP
+// Input words (of 32 sites) per compaction group of the pack kernels = per block: 64 (2048 sites), or 128 when that still leaves
+// the chip several times oversubscribed with blocks (pg_pick_group): larger groups end in fewer partial XV words (k_pairD's work)
+// and amortise a block's start-up; measured on the north-star shape (50 000 -> 25 000 two-wave blocks): k_pack3 -5 %, k_pairD
+// -3.5 %; on C2 (5000 -> 2600 one-wave blocks, fewer than the chip holds) k_pack3 +5 %.
 #define PG_GROUP 64
-#endif             // input words (of 32 sites) per compaction group of k_pack2
-#define PG_XV_CAP (3 * PG_GROUP)   // worst-case words of virtual sites per group (every site with four alleles)
+#define PG_GROUP_MAX 128
+// words of virtual sites reserved per group: worst case (every site with four alleles) / default
 // Words reserved per group by default: enough whenever a window has no more virtual sites than sites (a biallelic site is
 // one virtual site; + 1 for the group's partial last word).  k_pack2 / k_pack3 raise bit 1 of the flag word when a window needs
 // more; the host then repeats the call with PG_XV_CAP (and keeps that reservation for the rest of the context's life).
-#define PG_XV_CAP_DEFAULT (PG_GROUP + 1)
+#define PG_XV_CAP(grp) (3 * (grp))
+#define PG_XV_CAP_DEFAULT(grp) ((grp) + 1)
 #define PG_FLAG_MISMATCH 1      // some individual's two haplotypes differ in calledness: the diploid shortcut does not apply
 #define PG_FLAG_XV_OVERFLOW 2   // a window produced more XV words than reserved
 
@@ -73,7 +77,7 @@ void pg_launch_hap_called(hipStream_t st, const int8_t *gt, int S, int n_hap, co
 // ---- v2 pairwise pipeline (pg_pair2.hip) ---------------------------------------------------------------
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                      const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, int64_t total_groups, uint32_t *Vp,
-                     int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres, int capg);
+                     int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres, int capg, int grp);
 void pg_launch_expand(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                       int32_t *Cfull, int32_t *Dfull);
 void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, const PgTask2 *tasks, int n_tasks,

@@ -347,14 +347,25 @@ __global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__
     const int total = nx * ny;
     const int qi = 256 / (ny > 0 ? ny : 1), qj = 256 - qi * (ny > 0 ? ny : 1);
     int i = xs + (ny > 0 ? (int)threadIdx.x / ny : 0), j = ys + (ny > 0 ? (int)threadIdx.x % ny : 0);
-    for (int idx = threadIdx.x; idx < total; idx += 256, i += qi, j += qj) {
-        if (j >= ye) { j -= ny; ++i; }
-        if (x == y && i >= j) continue;
-        const int c = Cw[(size_t)(i >> cshift) * cN + (j >> cshift)];
-        if (c >= thr) {
-            sum += (double)Dw[(size_t)i * N + j] / (double)c;
-            ++cnt;
+    // four pairs per trip: their eight loads are issued before the first division (the loop was bound by the latency of one
+    // dependent load -> divide chain per trip); the quotients are added in the order the one-pair loop added them
+    for (int idx = threadIdx.x; idx < total; idx += 1024) {
+        int c[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j >= ye) { j -= ny; ++i; }
+            const bool live = idx + 256 * u < total && !(x == y && i >= j);
+            c[u] = live ? Cw[(size_t)(i >> cshift) * cN + (j >> cshift)] : 0;
+            d[u] = live ? Dw[(size_t)i * N + j] : 0;
+            i += qi;
+            j += qj;
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c[u] >= thr) {
+                sum += (double)d[u] / (double)c[u];
+                ++cnt;
+            }
     }
     sum = block_sum_f64(sum, shd);
     cnt = block_sum_u64(cnt, shu);

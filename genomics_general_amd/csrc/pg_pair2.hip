@@ -182,18 +182,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t group_rsrc(const int8_t *gt, i
 // presence nibbles of all slot blocks into pres[word][4]; k_pack2<.,.,PRES=1> then reads them.
 __global__ __launch_bounds__(256) void k_presence(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
                                                   const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
-                                                  uint32_t *__restrict__ pres) {
+                                                  uint32_t *__restrict__ pres, int grp) {
     const int b = blockIdx.y, g = blockIdx.x;
     const int64_t lo = win_lo[b], hi = win_hi[b];
     const int W = (int)((hi - lo + 31) >> 5);
-    const int w_begin = g * PG_GROUP;
+    const int w_begin = g * grp;
     if (w_begin >= W) return;
-    const int w_end = (w_begin + PG_GROUP < W) ? w_begin + PG_GROUP : W;
+    const int w_end = (w_begin + grp < W) ? w_begin + grp : W;
     const int h0 = 4 * (blockIdx.z * 256 + threadIdx.x);
     const int64_t first = lo + 32ll * w_begin;
-    const int nrows = (int)((hi - first) < 32ll * PG_GROUP ? (hi - first) : 32ll * PG_GROUP);
+    const int nrows = (int)((hi - first) < 32ll * grp ? (hi - first) : 32ll * grp);
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc(gt, S, first, nrows);
-    uint32_t *dst = pres + (size_t)(goff[b] + g) * PG_GROUP * 4u;
+    uint32_t *dst = pres + (size_t)(goff[b] + g) * grp * 4u;
     const RowOff ro = make_row_off(S);
     for (int w = w_begin; w < w_end; ++w) {
         uint32_t v[4], pa[4] = {0u, 0u, 0u, 0u};
@@ -213,21 +213,21 @@ __global__ __launch_bounds__(256) void k_presence(const int8_t *__restrict__ gt,
 // the window -> nw[n_win + group] = first word of the group, nw[window] = words of the window.  Block = one window.
 __global__ __launch_bounds__(256) void k_word_scan(const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
                                                    const int64_t *__restrict__ goff, const uint32_t *__restrict__ pres,
-                                                   int32_t *__restrict__ nw) {
+                                                   int32_t *__restrict__ nw, int grp) {
     __shared__ int sh[256];
     __shared__ int carry;
     const int b = blockIdx.x, n_win = gridDim.x;
     const int64_t lo = win_lo[b], hi = win_hi[b];
     const int W = (int)((hi - lo + 31) >> 5);
-    const int G = (W + PG_GROUP - 1) / PG_GROUP;
+    const int G = (W + grp - 1) / grp;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int g0 = 0; g0 < G; g0 += 256) {
         const int g = g0 + threadIdx.x;
         int words = 0;
         if (g < G) {
-            const int nwords = (W - g * PG_GROUP < PG_GROUP) ? W - g * PG_GROUP : PG_GROUP;
-            const uint32_t *src = pres + (size_t)(goff[b] + g) * PG_GROUP * 4u;
+            const int nwords = (W - g * grp < grp) ? W - g * grp : grp;
+            const uint32_t *src = pres + (size_t)(goff[b] + g) * grp * 4u;
             int cnt = 0;
             for (int w = 0; w < nwords; ++w) {
                 const uint32_t p[4] = {src[4 * w], src[4 * w + 1], src[4 * w + 2], src[4 * w + 3]};
@@ -256,17 +256,17 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                                                const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
                                                const int64_t *__restrict__ vgoff, uint32_t *__restrict__ Vp, int NPv,
                                                uint32_t *__restrict__ XV, int NP, int32_t *__restrict__ nw,
-                                               int32_t *__restrict__ mismatch, const uint32_t *__restrict__ pres, int capg) {
+                                               int32_t *__restrict__ mismatch, const uint32_t *__restrict__ pres, int capg, int grp) {
     constexpr int NWAVE = TPB / 64;
     __shared__ uint32_t sh_pres[2][NWAVE][4];
-    __shared__ uint4 sh_gp[PRES ? 1 : PG_GROUP];          // presence nibbles of the group's words (PRES: read from `pres`)
+    __shared__ uint4 sh_gp[PRES ? 1 : PG_GROUP_MAX];          // presence nibbles of the group's words (PRES: read from `pres`)
     __shared__ int sh_slot;
     const int b = blockIdx.y, g = blockIdx.x, n_win = gridDim.y;
     const int64_t lo = win_lo[b], hi = win_hi[b];
     const int W = (int)((hi - lo + 31) >> 5);
-    const int w_begin = g * PG_GROUP;
+    const int w_begin = g * grp;
     if (w_begin >= W) return;
-    const int w_end = (w_begin + PG_GROUP < W) ? w_begin + PG_GROUP : W;
+    const int w_end = (w_begin + grp < W) ? w_begin + grp : W;
     const int t = blockIdx.z * TPB + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int h0 = 4 * t;
@@ -275,14 +275,14 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
     const bool has_data = h0 < S;
     const int u0 = DIP ? 2 * t : h0;         // first unit of the called plane owned by this thread
     const int64_t first = lo + 32ll * w_begin;
-    const int nrows = (int)((hi - first) < 32ll * PG_GROUP ? (hi - first) : 32ll * PG_GROUP);
+    const int nrows = (int)((hi - first) < 32ll * grp ? (hi - first) : 32ll * grp);
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc(gt, S, first, nrows);
     uint32_t vlist = (uint32_t)nrows;        // lane i = list entry i; "nrows" is one row past the descriptor: reads as zero
     int cnt = 0, nflush = 0, parity = 0;
     uint32_t bad = 0u;
     uint32_t *xv_base = XV + (size_t)goff[b] * capg * PG_XV_PLANES * (size_t)NP;
     const int capw = (int)(goff[b + 1] - goff[b]) * capg;          // words reserved for this window
-    const uint32_t *pres_g = pres + (size_t)(goff[b] + g) * PG_GROUP * 4u;       // PRES only
+    const uint32_t *pres_g = pres + (size_t)(goff[b] + g) * grp * 4u;       // PRES only
     const int64_t vg_base = vgoff[b] + (int64_t)(w_begin >> 2);
     // PRES: the group's words start at gbase (k_word_scan); otherwise every flush takes the window's next free word
     const int gbase = PRES ? nw[n_win + goff[b] + g] : 0;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(TPB) void k_pack2(const int8_t *__restrict__ gt, in
                 // sites at which each allele occurs, across the whole block (uniform)
                 uint32_t pr[4];
                 if (PRES) {
-                    const uint32_t *src = pres + ((size_t)(goff[b] + g) * PG_GROUP + (size_t)(w - w_begin)) * 4u;
+                    const uint32_t *src = pres + ((size_t)(goff[b] + g) * grp + (size_t)(w - w_begin)) * 4u;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) pr[a] = __builtin_amdgcn_readfirstlane(src[a]);
                 } else {
@@ -465,23 +465,23 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
                                                const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
                                                const int64_t *__restrict__ vgoff, uint32_t *__restrict__ Vp, int NPv,
                                                uint32_t *__restrict__ XV, int NP, int32_t *__restrict__ nw,
-                                               int32_t *__restrict__ mismatch, int capg) {
+                                               int32_t *__restrict__ mismatch, int capg, int grp) {
     constexpr int NWAVE = TPB / 64;
     __shared__ uint32_t sh_pres[2][NWAVE][4];
     __shared__ int sh_slot;
     const int b = blockIdx.y, g = blockIdx.x;
     const int64_t lo = win_lo[b], hi = win_hi[b];
     const int W = (int)((hi - lo + 31) >> 5);
-    const int w_begin = g * PG_GROUP;
+    const int w_begin = g * grp;
     if (w_begin >= W) return;
-    const int w_end = (w_begin + PG_GROUP < W) ? w_begin + PG_GROUP : W;
+    const int w_end = (w_begin + grp < W) ? w_begin + grp : W;
     const int t = threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int h0 = 4 * t;
     const bool has_data = h0 < S;
     const int u0 = DIP ? 2 * t : h0;
     const int64_t first = lo + 32ll * w_begin;
-    const int nrows = (int)((hi - first) < 32ll * PG_GROUP ? (hi - first) : 32ll * PG_GROUP);
+    const int nrows = (int)((hi - first) < 32ll * grp ? (hi - first) : 32ll * grp);
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc(gt, S, first, nrows);
     int cnt = 0, parity = 0;                 // cnt: entries of the pending output word (uniform, 0..31)
     uint32_t MA = 0u, ME = 0u;               // nibble masks of the pending 8-entry dword (uniform)
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
 template <int DIP>
 static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *gt, int S, const int64_t *win_lo,
                          const int64_t *win_hi, const int64_t *goff, const int64_t *vgoff, uint32_t *Vp, int NPv, uint32_t *XV,
-                         int NP, int32_t *nw, int32_t *mismatch, uint32_t *pres, int capg) {
+                         int NP, int32_t *nw, int32_t *mismatch, uint32_t *pres, int capg, int grp) {
     // Up to 1024 slots: k_pack3 (every row fetched once; PMC: 2.27 instead of 2.56 GB per C2 pass, 44.5 instead of 49.2 GB per
     // north-star pass).  Same-box A/B (profiles/r02/ab_pack_*.txt): C2 0.450-0.485 vs 0.457-0.463 ms, north-star shape 7.7-7.9 vs
     // 8.0-9.2 ms -- once the per-entry allele look-up had moved from the scalar unit to a lane-parallel table (before that
@@ -655,39 +655,39 @@ static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *g
     const bool force2 = getenv("PG_PACK2") != nullptr;
     if (threads <= 256 && !force2) {
         if (threads <= 64)
-            hipLaunchKernelGGL((k_pack3<64, DIP>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg);
+            hipLaunchKernelGGL((k_pack3<64, DIP>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp);
         else if (threads <= 128)
-            hipLaunchKernelGGL((k_pack3<128, DIP>), grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg);
+            hipLaunchKernelGGL((k_pack3<128, DIP>), grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp);
         else
-            hipLaunchKernelGGL((k_pack3<256, DIP>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg);
+            hipLaunchKernelGGL((k_pack3<256, DIP>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp);
         return;
     }
     if (threads <= 64)
-        hipLaunchKernelGGL((k_pack2<64, DIP, 0>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
+        hipLaunchKernelGGL((k_pack2<64, DIP, 0>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg, grp);
     else if (threads <= 128)
-        hipLaunchKernelGGL((k_pack2<128, DIP, 0>), grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
+        hipLaunchKernelGGL((k_pack2<128, DIP, 0>), grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg, grp);
     else if (threads <= 256)
-        hipLaunchKernelGGL((k_pack2<256, DIP, 0>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
+        hipLaunchKernelGGL((k_pack2<256, DIP, 0>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg, grp);
     else {
         grid.z = (threads + 255) / 256;
-        hipLaunchKernelGGL(k_presence, grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, pres);
-        hipLaunchKernelGGL(k_word_scan, dim3(grid.y), dim3(256), 0, st, win_lo, win_hi, goff, pres, nw);
-        hipLaunchKernelGGL((k_pack2<256, DIP, 1>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
+        hipLaunchKernelGGL(k_presence, grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, pres, grp);
+        hipLaunchKernelGGL(k_word_scan, dim3(grid.y), dim3(256), 0, st, win_lo, win_hi, goff, pres, nw, grp);
+        hipLaunchKernelGGL((k_pack2<256, DIP, 1>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg, grp);
     }
 }
 
 // pres: scratch of total_groups * PG_GROUP * 4 words, only used (and zeroed here) when there are more than 1024 slots
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                      const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, int64_t total_groups, uint32_t *Vp,
-                     int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres, int capg) {
+                     int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres, int capg, int grp) {
     // nw[0 .. n_win): the caller hands over zeroed per-window word counters (atomic allocation; k_pairD reads them even when
     // every window of the batch is empty); nw[n_win ..): one slot per group in the > 1024-slot mode (k_word_scan)
     if (n_win <= 0 || max_groups <= 0) return;
     const int threads = NP / 4;
-    if (threads > 256) (void)hipMemsetAsync(pres, 0, (size_t)total_groups * PG_GROUP * 16u, st);
+    if (threads > 256) (void)hipMemsetAsync(pres, 0, (size_t)total_groups * grp * 16u, st);
     dim3 grid(max_groups, n_win);
-    if (dip) launch_pack2<1>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
-    else launch_pack2<0>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg);
+    if (dip) launch_pack2<1>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg, grp);
+    else launch_pack2<0>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg, grp);
 }
 
 // ------------------------------------------------------------------------------------------------------

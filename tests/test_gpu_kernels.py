@@ -24,10 +24,10 @@ def oracle_aln(lay, codes, lo, hi):
     (150, 4, 1500, [(0, 700), (700, 1500)]),                                     # several 64-column chunks
     (530, 3, 2200, [(0, 2200), (100, 421), (2150, 2200)]),                        # > 1024 haplotype slots: presence pre-pass
 ])
-@pytest.mark.parametrize("pack", ["default", "PG_PACK2"])
+@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS"])
 def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins, pack, monkeypatch):
     if pack != "default":
-        monkeypatch.setenv(pack, "1")
+        monkeypatch.setenv(pack, "128" if pack == "PG_GROUP_WORDS" else "1")
     e, lay, codes, _ = G.make_engine(n_dip, n_pops, L, seed=11 + n_dip)
     lo = np.array([w[0] for w in wins]); hi = np.array([w[1] for w in wins])
     D, C = e.batch(lo, hi).pairCounts(reference_order=True)
@@ -46,13 +46,13 @@ def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins, pack, monkeypatch):
     (150, 1500, 0.1, "uniform"),       # two waves per block: list / flush code behind block barriers
     (300, 800, 0.2, "mixed"),          # four waves per block
 ])
-@pytest.mark.parametrize("pack", ["default", "PG_PACK2"])
+@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS"])
 def test_pairwise_counts_with_three_and_four_alleles_per_site(n_dip, L, p_miss, mix, pack, monkeypatch):
     """sites with k alleles become k-1 virtual biallelic sites in k_pack2 / k_pack3 (both kernels at every block size: one, two
     and four waves); D must still be the plain Hamming count.  The uniform cases overflow the default XV reservation: the
     call is repeated with the worst-case reservation"""
     if pack != "default":
-        monkeypatch.setenv(pack, "1")
+        monkeypatch.setenv(pack, "128" if pack == "PG_GROUP_WORDS" else "1")
     rng = np.random.default_rng(1000 + n_dip)
     names, lay = G.make_layout(n_dip, 2)
     H = lay.n_hap
