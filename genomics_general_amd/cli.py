@@ -910,14 +910,27 @@ def freq_main(argv=None):
             for a in range(0, data.n_sites, CH):
                 yield data, run_of_row, a, min(data.n_sites, a + CH)
 
+    import ctypes as C
+    from ._lib import check, lib
+    L = lib()
+    out.flush()
+    sink = out.buffer                                       # rows are written as bytes behind the header
+    text_buf = np.empty(0, dtype=np.uint8)
+    cur_data = None
     for data, run_of_row, a, b in site_blocks():
+        if data is not cur_data:                            # scaffold names of the block as one byte string + offsets
+            cur_data = data
+            enc = [nm.encode() for nm in data.run_names]
+            names_blob = b"".join(enc)
+            name_off = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.int64)
+            name_max, run0 = max([len(e) for e in enc] + [1]), 0
         eng.load_sites(data.gt[a:b])
-        cnt = eng.batch([0], [0]).siteCounts(0, b - a).astype(np.int64)        # [n][P][4]
+        cnt32 = eng.batch([0], [0]).siteCounts(0, b - a)                        # int32 [n][P][4]
+        cnt = cnt32.astype(np.int64)
         n = cnt.sum(axis=2)
+        keep = None                                                           # uint8 mask of the rows that are written
         if not args.target:
-            cols = [[",".join(r) for r in cnt[:, q, :].astype(str)] for q in range(P)]
-            keep = np.arange(b - a)
-            cells = list(zip(*cols))
+            mode, values = 0, np.ascontiguousarray(cnt32)
         else:
             if args.target == "derived":                                        # derivedAllele, genomics.py:636-662
                 outc = cnt[:, P - 1, :] > 0
@@ -947,17 +960,21 @@ def freq_main(argv=None):
                 hi_, lo_ = allf >= args.threshold, allf < args.threshold
                 allf[hi_] = 1
                 allf[lo_] = 0
-            if keepNan:
-                keep = np.arange(b - a)
-            elif not asCounts:
-                keep = np.where(~np.all(np.isnan(allf), axis=1))[0]
-            else:
-                keep = np.where(~np.all(allf == 0, axis=1))[0]
-            cells = allf.astype(str)
-        names = data.run_names
-        for i in keep:
-            out.write(names[run_of_row[a + i]] + "\t" + str(int(data.pos[a + i])) + "\t" + "\t".join(cells[i]) + "\n")
+            if not keepNan:
+                keep = (~np.all(np.isnan(allf), axis=1) if not asCounts else ~np.all(allf == 0, axis=1)).astype(np.uint8)
+            mode, values = (1, np.ascontiguousarray(allf, dtype=np.int64)) if asCounts else (2, np.ascontiguousarray(allf, dtype=np.float64))
+        # the rows as text, formatted natively on all host threads (pg_format_freq_rows)
+        cap = (b - a) * (name_max + 13 + P * (45 if mode == 0 else 22)) + 64
+        if len(text_buf) < cap:
+            text_buf = np.empty(cap, dtype=np.uint8)
+        got = C.c_int64(0)
+        check(L.pg_format_freq_rows(mode, b - a, P, C.c_void_p(values.ctypes.data), np.ascontiguousarray(data.pos[a:b]),
+                                    np.ascontiguousarray(run_of_row[a:b], dtype=np.int32) - run0, names_blob, name_off,
+                                    C.c_void_p(keep.ctypes.data) if keep is not None else None,
+                                    C.c_void_p(text_buf.ctypes.data), cap, C.byref(got), 0))
+        sink.write(memoryview(text_buf)[:got.value])
     reader.close()
+    sink.flush()
     if out is not sys.stdout:
         out.close()
     sys.stderr.write("\nDone\n")

@@ -7,7 +7,9 @@
 #include "pg_ctx.h"
 
 #include <atomic>
+#include <cmath>
 #include <cstring>
+#include <string>
 #include <thread>
 
 #include <zlib.h>
@@ -328,5 +330,95 @@ extern "C" int pg_inflate_chunks(const uint8_t *src, const int64_t *src_off, con
     for (int t = 0; t < nt; ++t) th.emplace_back(work);
     for (auto &x : th) x.join();
     if (bad.load()) return pg_fail(PG_ERR_PARSE, "pg_inflate_chunks: a chunk does not inflate to its recorded size (damaged .pgeno block)");
+    return PG_OK;
+}
+
+// ---- freq.py rows: numbers -> text on all host threads ---------------------------------------------------------------------
+// One output row per kept site: scaffold name, position, then one cell per population, tab separated (freq.py:98-113).
+//   mode 0  cells = the four base counts "a,c,g,t" (values[n][n_pops][4], --asCounts without --target)
+//   mode 1  cells = one integer per population (values[n][n_pops], --target with --asCounts)
+//   mode 2  cells = one float per population as NumPy prints a double that has been rounded to four decimals (`nan`, `0.0`,
+//           `0.3333`): the shortest repr of the double nearest to k / 10000 is k / 10000 written out
+// run_of_row[i] indexes the scaffold names (names = concatenated bytes, name_off[r] .. name_off[r+1]); keep[i] == 0 drops row i.
+namespace {
+inline void put_int(std::string &o, long long v) {
+    char buf[24];
+    int n = 0;
+    bool neg = v < 0;
+    unsigned long long u = neg ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (neg) o.push_back('-');
+    while (n) o.push_back(buf[--n]);
+}
+inline void put_round4(std::string &o, double v) {
+    if (std::isnan(v)) { o += "nan"; return; }
+    if (std::isinf(v)) { o += v < 0 ? "-inf" : "inf"; return; }
+    if (std::signbit(v)) o.push_back('-');
+    const double a = std::fabs(v);
+    if (a >= 1e15) { char b[40]; snprintf(b, sizeof(b), "%.17g", a); o += b; return; }       // (never a frequency)
+    const unsigned long long k = (unsigned long long)std::llround(a * 1e4);
+    put_int(o, (long long)(k / 10000));
+    o.push_back('.');
+    unsigned f = (unsigned)(k % 10000);
+    char d[4] = {(char)('0' + f / 1000), (char)('0' + f / 100 % 10), (char)('0' + f / 10 % 10), (char)('0' + f % 10)};
+    int nd = 4;
+    while (nd > 1 && d[nd - 1] == '0') --nd;
+    o.append(d, (size_t)nd);
+}
+}  // namespace
+
+extern "C" int pg_format_freq_rows(int mode, int64_t n_rows, int n_pops, const void *values, const int32_t *pos,
+                                   const int32_t *run_of_row, const char *names, const int64_t *name_off, const uint8_t *keep,
+                                   char *out, int64_t out_cap, int64_t *out_len, int n_threads) {
+    if (mode < 0 || mode > 2 || n_rows < 0 || n_pops < 1 || !out_len) return pg_fail(PG_ERR_ARG, "pg_format_freq_rows: bad argument");
+    *out_len = 0;
+    if (n_rows == 0) return PG_OK;
+    if (!values || !pos || !run_of_row || !names || !name_off || !out) return pg_fail(PG_ERR_ARG, "pg_format_freq_rows: null argument");
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if ((int64_t)nt > n_rows / 4096 + 1) nt = (int)(n_rows / 4096 + 1);
+    std::vector<std::string> part(nt);
+    auto work = [&](int t) {
+        std::string &o = part[t];
+        const int64_t a = n_rows * t / nt, b = n_rows * (t + 1) / nt;
+        o.reserve((size_t)(b - a) * (size_t)(24 + n_pops * (mode == 0 ? 16 : 8)));
+        for (int64_t i = a; i < b; ++i) {
+            if (keep && !keep[i]) continue;
+            const int r = run_of_row[i];
+            o.append(names + name_off[r], (size_t)(name_off[r + 1] - name_off[r]));
+            o.push_back('\t');
+            put_int(o, pos[i]);
+            for (int q = 0; q < n_pops; ++q) {
+                o.push_back('\t');
+                if (mode == 0) {
+                    const int32_t *c = static_cast<const int32_t *>(values) + ((size_t)i * n_pops + q) * 4;
+                    for (int k = 0; k < 4; ++k) {
+                        if (k) o.push_back(',');
+                        put_int(o, c[k]);
+                    }
+                } else if (mode == 1) {
+                    put_int(o, static_cast<const int64_t *>(values)[(size_t)i * n_pops + q]);
+                } else {
+                    put_round4(o, static_cast<const double *>(values)[(size_t)i * n_pops + q]);
+                }
+            }
+            o.push_back('\n');
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    int64_t total = 0;
+    for (auto &x : part) total += (int64_t)x.size();
+    *out_len = total;
+    if (total > out_cap) return pg_fail(PG_ERR_ARG, "pg_format_freq_rows: %lld bytes of rows, capacity %lld", (long long)total, (long long)out_cap);
+    int64_t at = 0;
+    for (auto &x : part) {
+        memcpy(out + at, x.data(), x.size());
+        at += (int64_t)x.size();
+    }
     return PG_OK;
 }

@@ -152,6 +152,15 @@ int pg_encode_vcf(const char *buf, size_t len, int n_vcf_samples, int n_sel, con
                   int64_t *chrom_off, int32_t *chrom_len, int64_t *ref_off, int32_t *ref_len, int64_t *alt_off, int32_t *alt_len,
                   int64_t cap_sites, int64_t *n_sites_out, int64_t *n_multibase_out, int n_threads);
 
+/* freq.py's output rows (freq.py:98-113) formatted on all host threads: "scaffold\tposition\tcell\tcell...\n" per kept site.
+ * mode 0: values = int32 [n][n_pops][4], cells "a,c,g,t"; mode 1: values = int64 [n][n_pops]; mode 2: values = double [n][n_pops]
+ * printed as NumPy prints a double rounded to four decimals (nan, 0.0, 0.3333).  run_of_row[i] indexes the scaffold names
+ * (names[name_off[r] .. name_off[r+1])); keep[i] == 0 drops row i (NULL keeps all).  *out_len = bytes needed; PG_ERR_ARG when that
+ * exceeds out_cap. */
+int pg_format_freq_rows(int mode, int64_t n_rows, int n_pops, const void *values, const int32_t *pos, const int32_t *run_of_row,
+                        const char *names, const int64_t *name_off, const uint8_t *keep, char *out, int64_t out_cap, int64_t *out_len,
+                        int n_threads);
+
 /* Inflate the independently deflated chunks of a `.pgeno` block (zlib streams; genoio.PackedWriter) on all host threads: the
  * concatenated output goes to dst_a (first len_a bytes: the block's int32 positions) and dst_b (the rest: its cells, e.g. rows of
  * the page-locked array an upload will read).  src_off / src_len locate chunk i in src, raw_len[i] is its inflated size. */

@@ -2,7 +2,7 @@
 # GPU call D of round 2: suite, rocprofv3 stats + PMC passes of the final kernel selection (c2, northstar), T2 text bench, bench lines.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02f
+O=gpurun_out/r02j
 mkdir -p $O/prof_stats $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1
 tail -6 $O/pytest_gpu.log
