@@ -471,7 +471,7 @@ def main():
     extra["kernel_ms_per_step_source"] = ("last warm-up step (all families bracketed by events); roofline.avg_launch_ms is from the timed region"
                                            if args.warmup >= 1 else "timed region")
     extra["whole_step_hbm_frac"] = round(n_hap * sites_per_step / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)
-    if wl["tool"] == "popgen" and n_hap * sites_per_step >= (8 << 30) and not os.environ.get("PG_OVERLAP"):
+    if wl["tool"] == "popgen" and n_hap * sites_per_step >= (8 << 30) and not os.environ.get("PG_OVERLAP") and not args.no_tiers:
         # side information: the same pass cut into >= 8 sub-batches whose pack kernel runs on a second stream beside the pair
         # kernels of the previous sub-batch (PG_OVERLAP=1).  Not the default: the kernels then share the GPU and a per-kernel
         # event bracket no longer times one kernel
