@@ -81,6 +81,8 @@ SIGNATURES = {
     "pg_host_free": (C.c_int, [C.c_void_p]),
     "pg_kernel_time_select": (C.c_int, [_P, C.c_uint32]),
     "pg_kernel_time_reset": (C.c_int, [_P]),
+    "pg_debug_address": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "pg_debug_place": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "pg_set_scratch_limit": (C.c_int, [_P, C.c_int64]),
     "pg_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pg_comm_init": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p]),

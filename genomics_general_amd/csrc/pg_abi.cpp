@@ -375,6 +375,33 @@ extern "C" int pg_upload_wait(pg_ctx *c) {
     return PG_OK;
 }
 
+// ---- placement experiments (tools/pack_variance.py): where the big buffers sit, and a way to shift them ----------------------
+// which: 0 resident rows, 1 called plane (slot 0), 2 XV planes (slot 0).  pg_debug_place releases the buffer and makes its next
+// allocation start lead_bytes behind what hipMalloc returns (the resident rows are lost: fill them again).
+extern "C" int pg_debug_address(pg_ctx *c, int which, uint64_t *addr_out, uint64_t *bytes_out) {
+    if (!c || !addr_out || !bytes_out) return pg_fail(PG_ERR_ARG, "pg_debug_address: null argument");
+    switch (which) {
+        case 0: *addr_out = (uint64_t)c->gt.p; *bytes_out = c->gt.cap; break;
+        case 1: *addr_out = (uint64_t)c->slot[0].Vp.p; *bytes_out = c->slot[0].Vp.cap * 4; break;
+        case 2: *addr_out = (uint64_t)c->slot[0].XV.p; *bytes_out = c->slot[0].XV.cap * 4; break;
+        default: return pg_fail(PG_ERR_ARG, "pg_debug_address: which = %d", which);
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_debug_place(pg_ctx *c, int which, uint64_t lead_bytes) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    switch (which) {
+        case 0: c->gt.release(); c->gt.lead = lead_bytes; c->cap_sites = 0; break;
+        case 1: c->slot[0].Vp.release(); c->slot[0].Vp.lead = lead_bytes / 4; break;
+        case 2: c->slot[0].XV.release(); c->slot[0].XV.lead = lead_bytes / 4; break;
+        default: return pg_fail(PG_ERR_ARG, "pg_debug_place: which = %d", which);
+    }
+    return PG_OK;
+}
+
 // ---- kernel timing ----------------------------------------------------------------------------------
 // timing events are pooled: creating a pair per launch costs more host time than a small kernel
 static int event_get(pg_ctx *c, hipEvent_t *e) {

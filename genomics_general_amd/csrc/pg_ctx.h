@@ -19,15 +19,18 @@ int pg_fail(int code, const char *fmt, ...);
 template <class T>
 struct DevBuf {
     T *p = nullptr;
-    size_t cap = 0;   // elements
+    T *base = nullptr;   // what hipMalloc returned: p = base + lead
+    size_t cap = 0;      // elements
+    size_t lead = 0;     // elements in front of p (placement experiments: tools/pack_variance.py, pg_debug_place)
     int alloc(size_t n) {
         release();
         if (n == 0) n = 1;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&base), (n + lead) * sizeof(T));
         if (e != hipSuccess) {
-            p = nullptr;
-            return pg_fail(PG_ERR_HIP, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+            base = p = nullptr;
+            return pg_fail(PG_ERR_HIP, "hipMalloc(%zu bytes): %s", (n + lead) * sizeof(T), hipGetErrorString(e));
         }
+        p = base + lead;
         cap = n;
         return PG_OK;
     }
@@ -40,8 +43,8 @@ struct DevBuf {
         return PG_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
+        if (base) (void)hipFree(base);
+        base = p = nullptr;
         cap = 0;
     }
 };

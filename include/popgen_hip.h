@@ -267,6 +267,10 @@ int pg_kernel_time(pg_ctx *ctx, int kernel_id, double *ms_out, int64_t *launches
  * microseconds of GPU idle time each; a throughput run can restrict them to the family it reports. */
 int pg_kernel_time_select(pg_ctx *ctx, uint32_t mask);
 int pg_kernel_time_reset(pg_ctx *ctx);
+/* Placement experiments (tools/pack_variance.py; not used by the drivers): device address / size of a big buffer (which: 0 resident
+ * rows, 1 called plane, 2 XV planes), and a way to make its next allocation start lead_bytes behind what hipMalloc returns. */
+int pg_debug_address(pg_ctx *ctx, int which, uint64_t *addr_out, uint64_t *bytes_out);
+int pg_debug_place(pg_ctx *ctx, int which, uint64_t lead_bytes);
 /* scratch budget (bytes) for per-batch bit-planes + matrices; default 48 GiB (a job that fits runs as one batch; a larger one is
  * cut into at least eight sub-batches that alternate between two slots of half the budget each) */
 int pg_set_scratch_limit(pg_ctx *ctx, int64_t bytes);
