@@ -898,17 +898,48 @@ def freq_main(argv=None):
     CH = 1 << 20
     block_bytes = int(os.environ.get("PG_STREAM_BYTES", 1 << 30))
 
+    piped = hasattr(eng, "upload_async")                    # (tests/cpu_engine.py's stand-in mimics the interface)
+    pitch = eng.row_pitch if piped else None
+    alloc = eng.pinned.empty if piped else None
+
     def site_blocks():
-        """(GenoData of an input block, run index of each of its rows, a, b) for sub-blocks [a,b) of at most CH sites"""
+        """(GenoData of an input block, run index of each of its rows, a, b) for sub-blocks [a,b) of at most CH sites.  The next
+        block is tokenised (into page-locked rows at the engine's pitch) by a helper thread while this one is counted and
+        written."""
+        import queue
+        import threading
+        ready = queue.Queue(maxsize=1)
+
+        def prepare():
+            try:
+                while True:
+                    body = reader.read_block(block_bytes)
+                    if len(body) == 0:
+                        ready.put(None)
+                        return
+                    ready.put(reader.to_geno(body, layout, pitch=pitch, alloc=alloc))
+                    del body
+            except BaseException as exc:
+                ready.put(exc)
+
+        threading.Thread(target=prepare, daemon=True).start()
         while True:
-            body = reader.read_block(block_bytes)
-            if len(body) == 0:
+            data = ready.get()
+            if data is None:
                 return
-            data = reader.to_geno(body, layout)
-            del body
+            if isinstance(data, BaseException):
+                raise data
             run_of_row = np.repeat(np.arange(len(data.run_starts)), np.diff(np.append(data.run_starts, data.n_sites)))
             for a in range(0, data.n_sites, CH):
                 yield data, run_of_row, a, min(data.n_sites, a + CH)
+
+    def load(rows):
+        if piped:
+            eng.reserve(len(rows))
+            eng.upload_async(rows, 0)                       # one linear DMA out of page-locked memory
+            eng.upload_wait()
+        else:
+            eng.load_sites(rows)
 
     import ctypes as C
     from ._lib import check, lib
@@ -924,7 +955,7 @@ def freq_main(argv=None):
             names_blob = b"".join(enc)
             name_off = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.int64)
             name_max, run0 = max([len(e) for e in enc] + [1]), 0
-        eng.load_sites(data.gt[a:b])
+        load(data.gt[a:b])
         cnt32 = eng.batch([0], [0]).siteCounts(0, b - a)                        # int32 [n][P][4]
         cnt = cnt32.astype(np.int64)
         n = cnt.sum(axis=2)
