@@ -56,10 +56,23 @@ def pack_ms(e, passes=6):
     return ms / n
 
 
+def read_ms(e, passes=4):
+    """a read-only stream over the same rows: k_popfreq_q (screening pass: every row once, no plane stores)"""
+    e.batch(T.lo, T.hi).groupFreqStats()
+    e.sync()
+    e.kernel_time_reset()
+    for _ in range(passes):
+        e.batch(T.lo, T.hi).groupFreqStats()
+    e.sync()
+    ms, n = e.kernel_time(_lib.K_SITESTATS)
+    return ms / n
+
+
 def show(tag, e):
     t = pack_ms(e)
+    tag = "%s [read-only stream %.4f ms]" % (tag, read_ms(e))
     a = [addr(e, w)[0] for w in range(3)]
-    print("%-34s pack %.4f ms   gt %#x  Vp %#x  XV %#x   (Vp-gt) mod 1MiB %#x  (XV-gt) mod 1MiB %#x" % (
+    print("%-62s pack %.4f ms   gt %#x  Vp %#x  XV %#x   (Vp-gt) mod 1MiB %#x  (XV-gt) mod 1MiB %#x" % (
         tag, t, a[0], a[1], a[2], (a[1] - a[0]) & 0xFFFFF, (a[2] - a[0]) & 0xFFFFF), flush=True)
     return t
 
@@ -74,10 +87,10 @@ for k in range(n_eng):
     show("engine %d again" % k, e)
 e = engines[0]
 for which, name in ((1, "Vp"), (2, "XV")):
-    for lead in (4096, 65536, 256 << 10, (1 << 20) + 8192, 0):
+    for lead in (65536, 0):
         check(L.pg_debug_place(e._h, which, lead))
         show("engine 0, %s shifted by %d" % (name, lead), e)
-for lead in (4096, 128 << 10, (2 << 20) + 4096, 0):
+for lead in (4096, 128 << 10, (2 << 20) + 4096, 0, (4 << 20), 0, 8192, 0):
     check(L.pg_debug_place(e._h, 0, lead))
     fill(e)
     show("engine 0, rows shifted by %d" % lead, e)
