@@ -67,6 +67,9 @@ extern "C" int pg_ctx_create(pg_ctx **out, int device) {
     if (c->up_ev) (void)hipEventDestroy(c->up_ev);
     c->cells_stage.release();
     c->slot_src.release();
+    c->tok_text.release(); c->tok_flag.release(); c->tok_i32.release(); c->tok_cols.release(); c->tok_pos.release();
+    c->tok_i64.release(); c->tok_nl.release(); c->tok_off.release(); c->tok_pin[0].release(); c->tok_pin[1].release();
+    for (int k = 0; k < 2; ++k) if (c->tok_ev[k]) (void)hipEventDestroy(c->tok_ev[k]);
         delete c;
         return pg_fail(PG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
@@ -311,6 +314,28 @@ extern "C" int pg_download_sites(pg_ctx *c, int64_t off, int8_t *gt_out, int64_t
     if (n == 0) return PG_OK;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy2DAsync(gt_out, c->n_hap, c->gt.p + off * c->S, c->S, c->n_hap, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+extern "C" int pg_move_rows(pg_ctx *c, int64_t src_row, int64_t dst_row, int64_t n) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (n < 0 || src_row < 0 || dst_row < 0 || src_row + n > c->cap_sites || dst_row + n > c->cap_sites)
+        return pg_fail(PG_ERR_ARG, "pg_move_rows: rows out of the reserved range");
+    if (n == 0 || src_row == dst_row) return PG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * c->S;
+    const bool overlap = src_row < dst_row + n && dst_row < src_row + n;
+    if (!overlap) {
+        HIPCHK(hipMemcpyAsync(c->gt.p + dst_row * c->S, c->gt.p + src_row * c->S, bytes, hipMemcpyDeviceToDevice, c->stream));
+    } else {                                                       // through the (idle) staging buffer of the packed uploads
+        if (bytes > c->cells_stage.cap) {
+            int rc = c->cells_stage.alloc(bytes);
+            if (rc != PG_OK) return rc;
+        }
+        HIPCHK(hipMemcpyAsync(c->cells_stage.p, c->gt.p + src_row * c->S, bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->gt.p + dst_row * c->S, c->cells_stage.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return PG_OK;
 }

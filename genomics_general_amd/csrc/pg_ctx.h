@@ -101,6 +101,12 @@ struct pg_ctx {
     hipEvent_t up_ev = nullptr;
     bool up_pending = false;
     DevBuf<uint8_t> cells_stage;     // packed cells of the upload in flight
+    // device-side tokenizer (pg_tokenize_text): the block's text, line feeds, per-line outputs
+    DevBuf<uint8_t> tok_text, tok_flag;
+    DevBuf<int32_t> tok_i32, tok_cols, tok_pos;
+    DevBuf<int64_t> tok_i64, tok_nl, tok_off;
+    HostPin<uint8_t> tok_pin[2];
+    hipEvent_t tok_ev[2] = {nullptr, nullptr};
     DevBuf<int32_t> slot_src;        // pg_upload_packed_async: slot -> 2 * cell column + allele
     struct Slot {
         DevBuf<uint32_t> Vp, XV, pres;

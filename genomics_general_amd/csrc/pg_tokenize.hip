@@ -1,0 +1,288 @@
+// K0 on the device: `.geno` text -> resident rows ("GPU-side text tokenizer").
+// Replaces, like the host tokenizer (pg_encode.cpp), GenoFileReader.nextSite / parseGenoLine (genomics.py:1940-1945, 1884-1904) +
+// splitSeq / forceHomo / seqArrayToNumArray (genomics.py:390-396, 407-408, 74-77) -- for the regular case: every data line is
+//     scaffold <ws> position <ws> cell <sep> cell <sep> ... cell '\n'
+// with ONE separator character between cells and cells of one width (what parseVCF.py writes).  Anything else -- comment or
+// blank lines inside the block, runs of blanks between cells, '\r', cells of mixed width (mixed ploidy) -- makes the kernels
+// raise a status bit, and the caller takes the host tokenizer for that block: the fast path never guesses.
+//
+//   k_nl_count / k_nl_scan / k_nl_write   positions of the line feeds (tile counts, one-block scan, compacted write)
+//   k_tok_parse                           one wave per line: lane 0 reads scaffold + position, the lanes take the cells
+//                                         c, c+64, ... -> one-hot codes written into the row at the slots of the layout
+#include "pg_ctx.h"
+
+#include <algorithm>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr int NL_TILE = 4096;            // bytes per 256-thread block of the line-feed passes (16 bytes per thread)
+
+__device__ __forceinline__ int count_nl16(const uint8_t *text, int64_t at, int64_t len, uint32_t *mask_out) {
+    uint32_t mask = 0u;                                   // bit k: text[at + k] == '\n'
+    if (at + 16 <= len) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(text + at);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (((w[q] >> (8 * b)) & 0xFFu) == 10u) mask |= 1u << (4 * q + b);
+    } else {
+        for (int k = 0; k < 16 && at + k < len; ++k)
+            if (text[at + k] == 10) mask |= 1u << k;
+    }
+    *mask_out = mask;
+    return __popc(mask);
+}
+
+__global__ __launch_bounds__(256) void k_nl_count(const uint8_t *__restrict__ text, int64_t len, int32_t *__restrict__ tile_count) {
+    __shared__ int sh[256];
+    const int64_t at = (int64_t)blockIdx.x * NL_TILE + threadIdx.x * 16;
+    uint32_t m;
+    sh[threadIdx.x] = at < len ? count_nl16(text, at, len, &m) : 0;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = sh[0];
+}
+
+// exclusive prefix of the tile counts (one block; n_tiles is a few hundred thousand at most per call)
+__global__ __launch_bounds__(256) void k_nl_scan(const int32_t *__restrict__ tile_count, int64_t n_tiles, int64_t *__restrict__ tile_base,
+                                                 int64_t *__restrict__ total) {
+    __shared__ long long sh[256];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t t0 = 0; t0 < n_tiles; t0 += 256) {
+        const int64_t t = t0 + threadIdx.x;
+        const long long v = t < n_tiles ? tile_count[t] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const long long x = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (t < n_tiles) tile_base[t] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_nl_write(const uint8_t *__restrict__ text, int64_t len, const int64_t *__restrict__ tile_base,
+                                                  int64_t *__restrict__ nl_pos) {
+    __shared__ int sh[256];
+    const int64_t at = (int64_t)blockIdx.x * NL_TILE + threadIdx.x * 16;
+    uint32_t mask = 0u;
+    const int mine = at < len ? count_nl16(text, at, len, &mask) : 0;
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int x = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += x;
+        __syncthreads();
+    }
+    int64_t k = tile_base[blockIdx.x] + sh[threadIdx.x] - mine;
+    while (mask) {
+        const int b = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        nl_pos[k++] = at + b;
+    }
+}
+
+__device__ __forceinline__ bool blank(uint8_t ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f'; }
+__device__ __forceinline__ int8_t base_code(uint8_t ch) { return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 4 : ch == 'T' ? 8 : 0; }
+
+// status bits (host: any bit set -> this block goes through the host tokenizer instead)
+enum { TOK_IRREGULAR = 1, TOK_BAD_POS = 2, TOK_COMMENT = 4 };
+
+// dip[ch]: the two one-hot codes of IUPAC diploid character ch, low nibble | high nibble << 4 (genomics.py:14-15)
+struct DipTable { uint8_t v[256]; };
+
+__global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ text, const int64_t *__restrict__ nl_pos, int64_t n_lines,
+                                                   int fmt, int n_cols, int cellw, int ploidy, int max_ploidy,
+                                                   const int32_t *__restrict__ col_slot, const int32_t *__restrict__ col_ploidy,
+                                                   int8_t *__restrict__ rows, int S, int32_t *__restrict__ pos_out,
+                                                   int64_t *__restrict__ scaf_off, int32_t *__restrict__ scaf_len,
+                                                   uint8_t *__restrict__ newrun, int32_t *__restrict__ status, DipTable dip) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_lines) return;
+    const int64_t ls = row ? nl_pos[row - 1] + 1 : 0, le = nl_pos[row];            // [ls, le): the line without its '\n'
+    int64_t cells_at = -1;
+    int bad = 0;
+    if (lane == 0) {
+        int64_t p = ls;
+        if (p >= le || text[p] == '#') bad |= TOK_COMMENT;
+        while (p < le && blank(text[p])) ++p;
+        const int64_t s0 = p;
+        while (p < le && !blank(text[p])) ++p;
+        if (p == s0) bad |= TOK_COMMENT;                                         // blank line
+        scaf_off[row] = s0;
+        scaf_len[row] = (int32_t)(p - s0);
+        // a new scaffold run starts where the token differs from the previous line's
+        bool differs = row == 0;
+        if (row > 0) {
+            int64_t q = row > 1 ? nl_pos[row - 2] + 1 : 0;
+            const int64_t qe = nl_pos[row - 1];
+            while (q < qe && blank(text[q])) ++q;
+            int64_t a = s0;
+            while (a < p && q < qe && text[a] == text[q]) { ++a; ++q; }
+            differs = !(a == p && (q == qe || blank(text[q])));
+        }
+        newrun[row] = differs ? 1 : 0;
+        while (p < le && blank(text[p])) ++p;
+        bool neg = false;
+        if (p < le && (text[p] == '+' || text[p] == '-')) { neg = text[p] == '-'; ++p; }
+        long long v = 0;
+        const int64_t d0 = p;
+        while (p < le && text[p] >= '0' && text[p] <= '9' && v <= 0x7FFFFFFFll) { v = v * 10 + (text[p] - '0'); ++p; }
+        if (p == d0 || v > 0x7FFFFFFFll || (p < le && !blank(text[p]))) bad |= TOK_BAD_POS;
+        pos_out[row] = (int32_t)(neg ? -v : v);
+        while (p < le && blank(text[p])) ++p;
+        cells_at = p;
+        // the regular layout: n_cols cells of cellw characters, one separator between them, the last cell ends the line
+        if (le - p != (int64_t)n_cols * (cellw + 1) - 1) bad |= TOK_IRREGULAR;
+    }
+    cells_at = ((int64_t)__builtin_amdgcn_readfirstlane((int)(cells_at >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cells_at);
+    bad = __builtin_amdgcn_readfirstlane(bad);
+    if (!bad) {
+        int8_t *out = rows + row * (int64_t)S;
+        for (int c = lane; c < n_cols; c += 64) {
+            const uint8_t *cell = text + cells_at + (int64_t)c * (cellw + 1);
+            if (c + 1 < n_cols && !blank(cell[cellw])) bad |= TOK_IRREGULAR;
+            for (int k = 0; k < cellw; ++k)
+                if (blank(cell[k])) bad |= TOK_IRREGULAR;                       // a shorter cell: mixed widths
+            const int pl = col_ploidy[c];
+            if (pl <= 0) continue;
+            if (pl != ploidy) { bad |= TOK_IRREGULAR; continue; }
+            const int32_t *slots = col_slot + (size_t)c * max_ploidy;
+            if (fmt == PG_FMT_DIPLO) {
+                const uint8_t d = dip.v[cell[0]];
+                out[slots[0]] = (int8_t)(d & 15);
+                out[slots[1]] = (int8_t)(d >> 4);
+            } else {
+                const int step = fmt == PG_FMT_PHASED ? 2 : 1;
+                for (int k = 0; k < pl; ++k) out[slots[k]] = base_code(cell[step * k]);
+            }
+        }
+    }
+    if (bad) atomicOr(status, bad);
+}
+
+}  // namespace
+
+// Tokenise `len` bytes of complete `.geno` data lines (no header) into resident rows row_offset .. on the context's copy stream.
+// The text travels to the device in pieces through two page-locked staging buffers (host threads copy piece k+1 while piece k is
+// in flight).  Returns through *ok_out whether the regular-layout fast path applied; if not, nothing may be assumed about the
+// rows and the caller tokenises the block on the host.
+extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fmt, int n_cols, int max_ploidy,
+                                const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out,
+                                int64_t *scaf_off_out, int32_t *scaf_len_out, uint8_t *newrun_out, int64_t row_capacity,
+                                int64_t *n_rows_out, int *ok_out) {
+    if (!c || (!text && len) || !col_slot || !col_ploidy || !n_rows_out || !ok_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null argument");
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    if (fmt < PG_FMT_PHASED || fmt > PG_FMT_DIPLO || n_cols < 1 || max_ploidy < 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: bad format description");
+    *n_rows_out = 0;
+    *ok_out = 0;
+    if (len == 0) { *ok_out = 1; return PG_OK; }
+    // one ploidy for every wanted column, or no fast path
+    int ploidy = 0;
+    for (int k = 0; k < n_cols; ++k) {
+        if (col_ploidy[k] <= 0) continue;
+        if (ploidy == 0) ploidy = col_ploidy[k];
+        else if (col_ploidy[k] != ploidy) return PG_OK;
+        for (int a = 0; a < col_ploidy[k]; ++a) {
+            const int s = col_slot[(size_t)k * max_ploidy + a];
+            if (s < 0 || s >= c->n_hap) return pg_fail(PG_ERR_ARG, "col_slot[%d][%d]=%d out of range", k, a, s);
+        }
+    }
+    if (ploidy == 0 || text[len - 1] != '\n') return PG_OK;
+    if (fmt == PG_FMT_DIPLO && ploidy != 2) return PG_OK;
+    if (fmt == PG_FMT_HAPLO && ploidy != 1) return PG_OK;
+    const int cellw = fmt == PG_FMT_PHASED ? 2 * ploidy - 1 : (fmt == PG_FMT_PAIRS ? ploidy : 1);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream_up;
+    int rc;
+    // ---- text to the device, double-buffered through page-locked staging ----
+    if ((rc = c->tok_text.ensure((size_t)len + 32)) != PG_OK) return rc;
+    const size_t piece = 64u << 20;
+    for (int k = 0; k < 2; ++k)
+        if ((rc = c->tok_pin[k].ensure(std::min<size_t>(piece, (size_t)len))) != PG_OK) return rc;
+    if (!c->tok_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->tok_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->tok_ev[1], hipEventDisableTiming)); }
+    int nt = (int)std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
+    int64_t done = 0;
+    for (int k = 0; done < len; ++k) {
+        const size_t n = (size_t)std::min<int64_t>((int64_t)piece, len - done);
+        uint8_t *pin = c->tok_pin[k & 1].p;
+        if (k >= 2) HIPCHK(hipEventSynchronize(c->tok_ev[k & 1]));              // the copy out of this staging buffer is done
+        {
+            std::vector<std::thread> th;
+            const int use = (int)std::min<size_t>((size_t)nt, n / (1 << 20) + 1);
+            for (int t = 0; t < use; ++t)
+                th.emplace_back([&, t]() { const size_t a = n * t / use, b = n * (t + 1) / use; memcpy(pin + a, text + done + a, b - a); });
+            for (auto &x : th) x.join();
+        }
+        HIPCHK(hipMemcpyAsync(c->tok_text.p + done, pin, n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(c->tok_ev[k & 1], st));
+        done += (int64_t)n;
+    }
+    // ---- line feeds ----
+    const int64_t n_tiles = (len + NL_TILE - 1) / NL_TILE;
+    if ((rc = c->tok_i32.ensure((size_t)n_tiles + 2)) != PG_OK) return rc;
+    if ((rc = c->tok_i64.ensure((size_t)n_tiles + 2)) != PG_OK) return rc;
+    int32_t *d_status = c->tok_i32.p + n_tiles;
+    int64_t *d_total = c->tok_i64.p + n_tiles;
+    HIPCHK(hipMemsetAsync(d_status, 0, 4, st));
+    hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_tiles), dim3(256), 0, st, c->tok_text.p, len, c->tok_i32.p);
+    hipLaunchKernelGGL(k_nl_scan, dim3(1), dim3(256), 0, st, c->tok_i32.p, n_tiles, c->tok_i64.p, d_total);
+    int64_t n_lines = 0;
+    HIPCHK(hipMemcpyAsync(&n_lines, d_total, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *n_rows_out = n_lines;
+    if (n_lines == 0) { *ok_out = 1; return PG_OK; }
+    if (n_lines > row_capacity || row_offset < 0 || row_offset + n_lines > c->cap_sites) return PG_OK;   // (caller sizes from pg_count_lines)
+    if (!pos_out || !scaf_off_out || !scaf_len_out || !newrun_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null output");
+    if ((rc = c->tok_nl.ensure((size_t)n_lines)) != PG_OK) return rc;
+    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(256), 0, st, c->tok_text.p, len, c->tok_i64.p, c->tok_nl.p);
+    // ---- parse ----
+    if ((rc = c->tok_cols.ensure((size_t)n_cols * (max_ploidy + 1))) != PG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(c->tok_cols.p, col_slot, (size_t)n_cols * max_ploidy * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->tok_cols.p + (size_t)n_cols * max_ploidy, col_ploidy, (size_t)n_cols * 4, hipMemcpyHostToDevice, st));
+    if ((rc = c->tok_pos.ensure((size_t)n_lines * 2 + 8)) != PG_OK) return rc;         // pos + scaf_len (int32 each)
+    if ((rc = c->tok_off.ensure((size_t)n_lines)) != PG_OK) return rc;
+    if ((rc = c->tok_flag.ensure((size_t)n_lines)) != PG_OK) return rc;
+    HIPCHK(hipMemsetAsync(c->gt.p + row_offset * c->S, 0, (size_t)n_lines * c->S, st));
+    DipTable dip;
+    memset(dip.v, 0, sizeof(dip.v));
+    {
+        const char *d = "ACGKMNSRTWY";
+        const char *pr[] = {"AA", "CC", "GG", "GT", "AC", "NN", "CG", "AG", "TT", "AT", "CT"};
+        auto code = [](char ch) { return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 4 : ch == 'T' ? 8 : 0; };
+        for (int k = 0; d[k]; ++k) dip.v[(int)d[k]] = (uint8_t)(code(pr[k][0]) | (code(pr[k][1]) << 4));
+    }
+    hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, c->tok_text.p, c->tok_nl.p, n_lines, fmt, n_cols,
+                       cellw, ploidy, max_ploidy, c->tok_cols.p, c->tok_cols.p + (size_t)n_cols * max_ploidy, c->gt.p + row_offset * c->S, c->S,
+                       c->tok_pos.p, c->tok_off.p, c->tok_pos.p + n_lines, c->tok_flag.p, d_status, dip);
+    HIPCHK(hipGetLastError());
+    int32_t status = 0;
+    HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(pos_out, c->tok_pos.p, (size_t)n_lines * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(scaf_len_out, c->tok_pos.p + n_lines, (size_t)n_lines * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(scaf_off_out, c->tok_off.p, (size_t)n_lines * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(newrun_out, c->tok_flag.p, (size_t)n_lines, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *ok_out = status == 0 ? 1 : 0;
+    return PG_OK;
+}

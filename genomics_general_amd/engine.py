@@ -170,6 +170,34 @@ class Engine:
         check(self._L.pg_upload_wait(self._h))
         self._in_flight = None
 
+    def tokenize_text(self, buf, row_offset=0, n_rows=None):
+        """K0 on the device: complete `.geno` data lines (bytes-like: bytes, memoryview, mmap) -> resident rows row_offset ..;
+        returns (n, pos int32 [n], scaf_off int64 [n], scaf_len int32 [n], newrun uint8 [n]) or None when the block is not of the
+        regular layout the device tokenizer handles (the caller then takes the host tokenizer).  The rows must be reserved:
+        n_rows = number of data lines (pg_count_lines) if known."""
+        lay = self.layout
+        ptr, nbytes, _keep = _lib.text_ptr(buf)
+        if n_rows is None:
+            n = C.c_int64(0)
+            check(self._L.pg_count_lines(ptr, nbytes, C.byref(n)))
+            n_rows = int(n.value)
+        cap = max(int(n_rows), 1)
+        pos = np.zeros(cap, dtype=np.int32)
+        soff = np.zeros(cap, dtype=np.int64)
+        slen = np.zeros(cap, dtype=np.int32)
+        newrun = np.zeros(cap, dtype=np.uint8)
+        got, ok = C.c_int64(0), C.c_int(0)
+        check(self._L.pg_tokenize_text(self._h, ptr, nbytes, _lib.FMT[lay.genoFormat], len(lay.col_ploidy), lay.max_ploidy,
+                                       np.ascontiguousarray(lay.col_slot), lay.col_ploidy, int(row_offset), pos, soff, slen, newrun,
+                                       cap, C.byref(got), C.byref(ok)))
+        if not ok.value or got.value != n_rows:
+            return None
+        k = int(got.value)
+        return k, pos[:k], soff[:k], slen[:k], newrun[:k]
+
+    def move_rows(self, src_row, dst_row, n):
+        check(self._L.pg_move_rows(self._h, int(src_row), int(dst_row), int(n)))
+
     def download(self, offset, n):
         out = np.zeros((n, self.layout.n_hap), dtype=np.int8)
         check(self._L.pg_download_sites(self._h, int(offset), out, n))

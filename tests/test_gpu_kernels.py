@@ -346,3 +346,67 @@ def test_sample_het_and_h12_finished_on_the_device_match_the_oracle(after_popdis
             sizes_seen.add(round(float(want_h["H1_" + p]), 6))
     assert len(sizes_seen) >= 2                     # the cases are not all "every haplotype its own cluster"
     e.close()
+
+
+@pytest.mark.parametrize("fixture,fmt", [("c1", "phased"), ("sparse", "phased"), ("abba_pairs", "pairs"), ("abba_diplo", "diplo"),
+                                         ("haplo", "haplo")])
+def test_device_tokenizer_equals_the_host_tokenizer(fixture, fmt):
+    """pg_tokenize_text (K0 on the device) against pg_encode_text on the reference-golden fixtures in the four genotype formats:
+    rows, positions, scaffold runs; with a layout that reorders and drops samples; written behind rows that are already there"""
+    import gzip
+    import os
+    from genomics_general_amd import genoio
+    from genomics_general_amd.engine import Engine
+    from genomics_general_amd.samples import HapLayout, SampleData
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    raw = gzip.open(os.path.join(gold, fixture + ".geno.gz"), "rb").read()
+    names = raw[:raw.index(b"\n")].decode().split()[2:]
+    body = raw[raw.index(b"\n") + 1:]
+    pl = {nm: (1 if fmt == "haplo" else 2) for nm in names}
+    for order in (list(names), names[3:] + names[1:2]):
+        lay = HapLayout(SampleData(indNames=order, ploidyDict={nm: pl[nm] for nm in order}), names, fmt)
+        want = genoio.encode(body, lay)
+        e = Engine(0)
+        e.set_layout(lay)
+        e.reserve(want.n_sites + 100)
+        got = e.tokenize_text(body, row_offset=37)
+        assert got is not None, "regular fixture refused by the device tokenizer"
+        n, pos, soff, slen, newrun = got
+        assert n == want.n_sites and np.array_equal(pos, want.pos)
+        assert np.array_equal(e.download(37, n), want.gt)
+        assert np.array_equal(np.flatnonzero(newrun), want.run_starts)
+        assert [bytes(body[int(soff[i]):int(soff[i]) + int(slen[i])]).decode() for i in want.run_starts] == want.run_names
+        e.close()
+
+
+def test_device_tokenizer_refuses_irregular_blocks():
+    """mixed ploidy (cells of two widths), a comment line, doubled separators, a missing final line feed: the fast path says no
+    (the drivers then use the host tokenizer); a position that is not a number likewise"""
+    import gzip
+    import os
+    from genomics_general_amd.engine import Engine
+    from genomics_general_amd.samples import HapLayout, SampleData
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    raw = gzip.open(os.path.join(gold, "c1.geno.gz"), "rb").read()
+    names = raw[:raw.index(b"\n")].decode().split()[2:]
+    body = raw[raw.index(b"\n") + 1:]
+    lines = body.split(b"\n")
+    lay = HapLayout(SampleData(indNames=list(names)), names, "phased")
+    e = Engine(0)
+    e.set_layout(lay)
+    e.reserve(len(lines) + 10)
+    assert e.tokenize_text(body) is not None
+    bad = [b"\n".join(lines[:50] + [b"# a comment"] + lines[50:]),
+           b"\n".join(lines[:50] + [lines[50].replace(b"\t", b"\t\t", 3)] + lines[51:]),
+           b"\n".join(lines[:50] + [lines[50][:-3] + b"A"] + lines[51:]),
+           body[:-1],
+           b"\n".join(lines[:7] + [lines[7].replace(lines[7].split()[1], b"12x")] + lines[8:])]
+    for k, text in enumerate(bad):
+        assert e.tokenize_text(text) is None, k
+    mixed = gzip.open(os.path.join(gold, "mixed.geno.gz"), "rb").read()
+    mnames = mixed[:mixed.index(b"\n")].decode().split()[2:]
+    ml = HapLayout(SampleData(indNames=list(mnames), ploidyDict={nm: (1 if nm in ("s1", "s6", "s9") else 2) for nm in mnames}), mnames, "phased")
+    e.set_layout(ml)
+    e.reserve(5000)
+    assert e.tokenize_text(mixed[mixed.index(b"\n") + 1:]) is None
+    e.close()
