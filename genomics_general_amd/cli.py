@@ -7,6 +7,7 @@ Additive flags: --device N (GPU index; default LOCAL_RANK or 0).  Under a one-pr
 (RANK/WORLD_SIZE set) windows are sharded across ranks and rank 0 writes the output.
 """
 import argparse
+import ctypes as C
 import gzip
 import itertools
 import os
@@ -14,7 +15,7 @@ import sys
 
 import numpy as np
 
-from . import dist, genoio, windows
+from . import _lib, dist, genoio, windows
 from .engine import Engine
 from .samples import HapLayout, SampleData
 
@@ -219,6 +220,9 @@ class Run:
         import threading
         import time
         eng = self.engine
+        if self._device_tokenizer():
+            yield from self._chunks_device()
+            return
         piped = hasattr(eng, "upload_async")
         pitch = eng.row_pitch if piped else None
         alloc = eng.pinned.empty if piped else None
@@ -364,6 +368,124 @@ class Run:
             stop.set()
             if piped:
                 eng.upload_wait()
+        self._reader.close()
+
+    def _device_tokenizer(self):
+        """K0 on the device (PG_GPU_TOKENIZER=1; Engine.tokenize_text): plain or gzipped text in one of the regular layouts -- one
+        ploidy for all wanted samples, which is what the layout says up front; what only the text can tell (comment lines, runs
+        of blanks, carriage returns) is found by the kernels block by block, and such a block goes through the host tokenizer."""
+        import os
+        if os.environ.get("PG_GPU_TOKENIZER", "0") != "1" or not hasattr(self.engine, "tokenize_text"):
+            return False
+        if getattr(self._reader, "packed", False):
+            return False
+        pl = set(int(x) for x in self.layout.col_ploidy if x > 0)
+        fmt = self.layout.genoFormat
+        return len(pl) == 1 and not (fmt == "diplo" and pl != {2}) and not (fmt == "haplo" and pl != {1})
+
+    def _chunks_device(self):
+        """chunks() with the tokenizer on the device: the reader thread hands over block k+1 (memory-mapped text, or gunzipped
+        bytes) while this thread has block k copied down, tokenised straight into the resident rows behind the rows carried over
+        from block k-1 (pg_move_rows, pg_tokenize_text), finds the windows that are certain and computes them.  The host keeps
+        positions and scaffold runs only; no row ever exists in host memory."""
+        import queue
+        import threading
+        import time
+        eng = self.engine
+        L = _lib.lib()
+        blocks = queue.Queue(maxsize=1)
+        stop = threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    blocks.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def produce():
+            try:
+                while True:
+                    b = self._reader.read_block(self._block_bytes)
+                    if not put(b) or self._block_bytes is None or len(b) == 0:
+                        return
+            except BaseException as exc:
+                put(exc)
+
+        threading.Thread(target=produce, daemon=True).start()
+        carry, carry_row0, cap = None, 0, 0
+        self.timing["device_tokenizer"] = 1
+        self.timing["host_tokenized_blocks"] = 0
+        try:
+            while True:
+                t0 = time.perf_counter()
+                body = blocks.get()
+                if isinstance(body, BaseException):
+                    raise body
+                final = self._streamer is None or len(body) == 0
+                self.timing["read_s"] += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                ptr, nbytes, _keep = _lib.text_ptr(body)
+                cnt = C.c_int64(0)
+                if nbytes:
+                    _lib.check(L.pg_count_lines(ptr, nbytes, C.byref(cnt)))
+                n_new, c_n = int(cnt.value), (carry.n_sites if carry is not None else 0)
+                if c_n + n_new > cap:                         # grow: the carried rows travel through the host once
+                    saved = eng.download(carry_row0, c_n) if c_n else None
+                    cap = c_n + n_new + (c_n + n_new) // 4 + 1024
+                    eng.reserve(cap)
+                    if saved is not None:
+                        eng.upload(saved, 0)
+                elif c_n and carry_row0:
+                    eng.move_rows(carry_row0, 0, c_n)
+                got = eng.tokenize_text(body, row_offset=c_n, n_rows=n_new) if n_new else None
+                if got is not None:
+                    n, pos, soff, slen, newrun = got
+                    starts = np.flatnonzero(newrun).astype(np.int64)
+                    names = [bytes(body[int(soff[i]):int(soff[i]) + int(slen[i])]).decode("utf-8", "replace") for i in starts]
+                    block = genoio.GenoData(None, pos, starts, names)
+                else:                                         # a block the fast path refuses (or an empty one): host tokenizer
+                    block = self._reader.to_geno(body, self.layout, n_threads=self._tok_threads)
+                    if block.n_sites:
+                        self.timing["host_tokenized_blocks"] += 1
+                        if c_n + block.n_sites > cap:         # (lines the counter does not see as data lines cannot add rows)
+                            raise RuntimeError("tokenizer row count exceeds the line count of the block")
+                        eng.upload(np.ascontiguousarray(block.gt[:, :self.layout.n_hap]), c_n)
+                    block = genoio.GenoData(None, block.pos, block.run_starts, block.run_names)
+                del body, _keep
+                data = genoio.concat_meta(carry, block)
+                self.timing["tokenize_s"] += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                if self._streamer is not None:
+                    T, keep_from = self._streamer.feed(data.run_starts, data.run_names, data.pos, final)
+                else:
+                    T = (self._windows_fn(data) if self._windows_fn
+                         else _make_windows(self._wparams, data, self._minSites, self._coords_keep))
+                    T.dup = np.zeros(T.n, dtype=bool)
+                    keep_from = data.n_sites
+                self.timing["windows_s"] += time.perf_counter() - t0
+                carry = None if final else genoio.tail_meta(data, keep_from)
+                carry_row0 = keep_from
+                w0, w1 = dist.shard_range(T.n, self._wshare[0], self._wshare[1])
+                lo, hi = T.lo[w0:w1].copy(), T.hi[w0:w1].copy()
+                nz = hi > lo
+                lo[~nz] = 0
+                hi[~nz] = 0
+                self.timing["text_bytes"] = self._reader.bytes_read
+                self.data, self.T, self.w0, self.w1 = data, T, w0, w1
+                self.lo, self.hi, self.site0 = lo, hi, 0
+                self.timing["sites"] += int(block.n_sites)
+                self.timing["windows"] += int(T.n)
+                self.timing["chunks"] += 1
+                self.n_tested += int(T.n)
+                if T.n:
+                    yield self
+                if final:
+                    break
+        finally:
+            stop.set()
         self._reader.close()
 
     def report_timing(self):

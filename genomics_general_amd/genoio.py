@@ -857,6 +857,27 @@ def tail(d, keep_from):
     return GenoData(d.gt[keep_from:].copy(), d.pos[keep_from:].copy(), starts, list(d.run_names[r:]), d.packed)
 
 
+def concat_meta(a, b):
+    """concat() of the positions and scaffold runs only (rows that live on the device: gt is None)"""
+    if a is None or a.n_sites == 0:
+        return b
+    if b.n_sites == 0:
+        return a
+    merge = a.run_names[-1] == b.run_names[0]
+    starts = np.concatenate([a.run_starts, (b.run_starts[1:] if merge else b.run_starts) + a.n_sites]).astype(np.int64)
+    names = list(a.run_names) + list(b.run_names[1:] if merge else b.run_names)
+    return GenoData(None, np.concatenate([a.pos, b.pos]), starts, names)
+
+
+def tail_meta(d, keep_from):
+    """tail() of the positions and scaffold runs only"""
+    if keep_from >= d.n_sites:
+        return None
+    r = int(np.searchsorted(d.run_starts, keep_from, side="right")) - 1
+    starts = np.concatenate([[0], d.run_starts[r + 1:] - keep_from]).astype(np.int64)
+    return GenoData(None, d.pos[keep_from:].copy(), starts, list(d.run_names[r:]))
+
+
 def encode(data, layout, n_threads=0, head_rows=0, pitch=None, alloc=None):
     full = []
     gt, pos, soff, slen = encode_text(data, layout, n_threads, head_rows, pitch, alloc, full)

@@ -19,6 +19,8 @@ class CpuEngine:
     the resident rows -- runs in the CPU tests; an upload only becomes visible at upload_wait(), and the rows must be unchanged
     by then."""
 
+    tokenizer_calls = 0
+
     def __init__(self, device=0):
         self.device = device
         self.gt = None
@@ -35,7 +37,36 @@ class CpuEngine:
     def reserve(self, n_sites):
         assert not self._queued, "reserve with uploads in flight"
         if self.gt is None or len(self.gt) < n_sites:
-            self.gt = np.zeros((n_sites, self.layout.n_hap), dtype=np.int8)
+            self.gt = np.zeros((n_sites, self.layout.n_hap), dtype=np.int8)      # like pg_reserve_sites: the old rows are gone
+
+    # ---- the device tokenizer's interface (cli.Run._chunks_device), numbers from the host tokenizer ----
+    def upload(self, gt, offset=0):
+        self.gt[offset:offset + len(gt)] = gt
+
+    def download(self, offset, n):
+        return self.gt[offset:offset + n].copy()
+
+    def move_rows(self, src, dst, n):
+        assert src + n <= len(self.gt) and dst + n <= len(self.gt)
+        self.gt[dst:dst + n] = self.gt[src:src + n].copy()
+
+    def tokenize_text(self, buf, row_offset=0, n_rows=None):
+        from genomics_general_amd import genoio
+        body = bytes(buf)
+        CpuEngine.tokenizer_calls += 1
+        if b"#" in body or b"\r" in body or b"\t\t" in body or not body.endswith(b"\n"):
+            return None                                                          # what the kernels refuse
+        d = genoio.encode(body, self.layout)
+        if n_rows is not None and d.n_sites != n_rows:
+            return None
+        assert row_offset + d.n_sites <= len(self.gt), "tokenised rows exceed the reserved rows"
+        self.gt[row_offset:row_offset + d.n_sites] = d.gt[:, :self.layout.n_hap]
+        newrun = np.zeros(d.n_sites, dtype=np.uint8)
+        newrun[d.run_starts] = 1
+        lines = body.split(b"\n")[:-1]
+        off = np.cumsum([0] + [len(ln) + 1 for ln in lines])[:-1].astype(np.int64)
+        slen = np.array([len(ln.split()[0]) for ln in lines], dtype=np.int32)
+        return d.n_sites, d.pos.copy(), off, slen, newrun
 
     def load_sites(self, gt):
         self.gt = np.array(gt, dtype=np.int8, copy=True)[:, :self.layout.n_hap]

@@ -87,6 +87,17 @@ def test_cli_streaming_in_small_blocks_reproduces_reference_output(case, block, 
     test_cli_reproduces_reference_output(case, tmp_path)
 
 
+@pytest.mark.parametrize("case", STREAMABLE, ids=[c["name"] for c in STREAMABLE])
+@pytest.mark.parametrize("block", [3000, 50000, None])
+def test_cli_with_the_device_tokenizer_reproduces_reference_output(case, block, tmp_path, monkeypatch):
+    """the same goldens with K0 on the device (PG_GPU_TOKENIZER=1: pg_tokenize_text writes the resident rows, carried rows moved
+    by pg_move_rows); the mixed-ploidy fixtures take the host path by layout"""
+    if block:
+        monkeypatch.setenv("PG_STREAM_BYTES", str(block))
+    monkeypatch.setenv("PG_GPU_TOKENIZER", "1")
+    test_cli_reproduces_reference_output(case, tmp_path)
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_cli_on_packed_pgeno_input_reproduces_reference_output(case, tmp_path, monkeypatch):
     """every golden again with the text tokenised once into a `.pgeno` file (genoio.pack_geno, tools/geno_pack.py) and the driver

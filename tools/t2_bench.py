@@ -60,6 +60,20 @@ def main():
         if ref_rows is None:
             ref_rows = rows
         print("   output identical to run 0:", rows == ref_rows)
+    # K0 on the device (PG_GPU_TOKENIZER=1): the text goes down as it is, pg_tokenize_text writes the resident rows
+    for rep, block in enumerate([None, None, 256 << 20]):
+        env = dict(os.environ, PG_TIMING="1", PG_GPU_TOKENIZER="1")
+        if block:
+            env["PG_STREAM_BYTES"] = str(block)
+        t0 = time.time()
+        r = subprocess.run(cmd, env=env, stderr=subprocess.PIPE)
+        dwall = time.time() - t0
+        line = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING")]
+        print("device tokenizer run %d (%s): wall %.2f s  %s" % (rep, "blocks of %d MiB" % (block >> 20) if block else "default blocks",
+                                                                 dwall, line[-1] if line else r.stderr.decode()[-400:]))
+        with open("/tmp/t2_out.csv") as f:
+            print("   output identical to run 0:", f.readlines() == ref_rows)
+    print("device tokenizer: windows/s end to end:", round((len(ref_rows) - 1) / dwall, 2), "| sites/s:", round(n_sites / dwall))
     # the same job from a packed .pgeno file (tokenised once by tools/geno_pack.py)
     packed = path[:-5] + ".pgeno"
     t0 = time.time()
