@@ -284,6 +284,7 @@ def tier_samples(eng, lay, wl, names, slot_gen, scaf_len, n_sites, t1_block, t0_
                 same = same and (abs(float(v) - g) <= 1e-9 * max(1.0, abs(g)) or (g != g and float(v) != float(v)))
         out["t2"] = {"sites_per_sec": round(n_txt / tm["total_s"], 1), "windows_per_sec": round(len(rows) / tm["total_s"], 3),
                      "text_MBps": round(os.path.getsize(geno) / tm["total_s"] / 1e6, 1), "matches_t0": bool(same),
+                     "tokenizer": "device (pg_tokenize_text)" if tm.get("device_tokenizer") else "host threads (pg_encode_text)",
                      "seconds": {k: round(tm[k], 4) for k in ("total_s", "read_s", "tokenize_s", "windows_s", "prep_wait_s",
                                                                "engine_and_upload_s", "compute_and_write_s") if k in tm},
                      "sample": "the first %d sites of the workload as %.0f MB of `.geno` text (%d windows) through popgenWindows.py, "

@@ -51,8 +51,8 @@ SIGNATURES = {
     "pg_upload_sites_async": (C.c_int, [_P, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]),
     "pg_upload_packed_async": (C.c_int, [_P, C.c_int64, C.c_void_p, C.c_int64, C.c_int, _i32p]),
     "pg_upload_wait": (C.c_int, [_P]),
-    "pg_tokenize_text": (C.c_int, [_P, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int64, _i32p, _i64p, _i32p,
-                                   _u8p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "pg_tokenize_text": (C.c_int, [_P, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int64, _i32p, C.c_int64,
+                                   _i64p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "pg_move_rows": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64]),
     "pg_synth_fill": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32,
                                 _i32p, C.c_int32, C.c_int32]),

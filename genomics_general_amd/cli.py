@@ -371,11 +371,12 @@ class Run:
         self._reader.close()
 
     def _device_tokenizer(self):
-        """K0 on the device (PG_GPU_TOKENIZER=1; Engine.tokenize_text): plain or gzipped text in one of the regular layouts -- one
-        ploidy for all wanted samples, which is what the layout says up front; what only the text can tell (comment lines, runs
-        of blanks, carriage returns) is found by the kernels block by block, and such a block goes through the host tokenizer."""
+        """K0 on the device (Engine.tokenize_text; PG_GPU_TOKENIZER=0 keeps the host tokenizer): plain or gzipped text in one of the
+        regular layouts -- one ploidy for all wanted samples, which is what the layout says up front; what only the text can tell
+        (comment lines, runs of blanks, carriage returns) is found by the kernels block by block, and such a block goes through
+        the host tokenizer."""
         import os
-        if os.environ.get("PG_GPU_TOKENIZER", "0") != "1" or not hasattr(self.engine, "tokenize_text"):
+        if os.environ.get("PG_GPU_TOKENIZER", "1") == "0" or not hasattr(self.engine, "tokenize_text"):
             return False
         if getattr(self._reader, "packed", False):
             return False
@@ -442,9 +443,7 @@ class Run:
                     eng.move_rows(carry_row0, 0, c_n)
                 got = eng.tokenize_text(body, row_offset=c_n, n_rows=n_new) if n_new else None
                 if got is not None:
-                    n, pos, soff, slen, newrun = got
-                    starts = np.flatnonzero(newrun).astype(np.int64)
-                    names = [bytes(body[int(soff[i]):int(soff[i]) + int(slen[i])]).decode("utf-8", "replace") for i in starts]
+                    n, pos, starts, names = got
                     block = genoio.GenoData(None, pos, starts, names)
                 else:                                         # a block the fast path refuses (or an empty one): host tokenizer
                     block = self._reader.to_geno(body, self.layout, n_threads=self._tok_threads)
@@ -499,7 +498,10 @@ class Run:
             t["total_s"] = time.perf_counter() - self._t_start
             # read / tokenize / windows run in their own threads: what this thread spent is the wait for them, the uploads it
             # waited for, and the statistics + output
-            t["compute_and_write_s"] = t["total_s"] - t["prep_wait_s"] - t["engine_and_upload_s"]
+            if t.get("device_tokenizer"):                 # everything on this thread: reading aside, the phases add up
+                t["compute_and_write_s"] = t["total_s"] - t["engine_and_upload_s"] - t["tokenize_s"] - t["windows_s"] - t["read_s"]
+            else:
+                t["compute_and_write_s"] = t["total_s"] - t["prep_wait_s"] - t["engine_and_upload_s"]
             sys.stderr.write("PG_TIMING " + json.dumps(t) + "\n")
 
     def batch(self, mask):

@@ -67,7 +67,7 @@ extern "C" int pg_ctx_create(pg_ctx **out, int device) {
     if (c->up_ev) (void)hipEventDestroy(c->up_ev);
     c->cells_stage.release();
     c->slot_src.release();
-    c->tok_text.release(); c->tok_flag.release(); c->tok_i32.release(); c->tok_cols.release(); c->tok_pos.release();
+    c->tok_text.release(); c->tok_i32.release(); c->tok_cols.release(); c->tok_pos.release();
     c->tok_i64.release(); c->tok_nl.release(); c->tok_off.release(); c->tok_pin[0].release(); c->tok_pin[1].release();
     for (int k = 0; k < 2; ++k) if (c->tok_ev[k]) (void)hipEventDestroy(c->tok_ev[k]);
         delete c;

@@ -102,7 +102,7 @@ struct pg_ctx {
     bool up_pending = false;
     DevBuf<uint8_t> cells_stage;     // packed cells of the upload in flight
     // device-side tokenizer (pg_tokenize_text): the block's text, line feeds, per-line outputs
-    DevBuf<uint8_t> tok_text, tok_flag;
+    DevBuf<uint8_t> tok_text;
     DevBuf<int32_t> tok_i32, tok_cols, tok_pos;
     DevBuf<int64_t> tok_i64, tok_nl, tok_off;
     HostPin<uint8_t> tok_pin[2];

@@ -18,7 +18,9 @@
 
 namespace {
 
-constexpr int NL_TILE = 4096;            // bytes per 256-thread block of the line-feed passes (16 bytes per thread)
+constexpr int NL_SUB = 4096;             // bytes per pass of a 256-thread block over its tile (16 bytes per thread)
+constexpr int NL_PASSES = 4;
+constexpr int NL_TILE = NL_SUB * NL_PASSES;
 
 __device__ __forceinline__ int count_nl16(const uint8_t *text, int64_t at, int64_t len, uint32_t *mask_out) {
     uint32_t mask = 0u;                                   // bit k: text[at + k] == '\n'
@@ -40,9 +42,14 @@ __device__ __forceinline__ int count_nl16(const uint8_t *text, int64_t at, int64
 
 __global__ __launch_bounds__(256) void k_nl_count(const uint8_t *__restrict__ text, int64_t len, int32_t *__restrict__ tile_count) {
     __shared__ int sh[256];
-    const int64_t at = (int64_t)blockIdx.x * NL_TILE + threadIdx.x * 16;
-    uint32_t m;
-    sh[threadIdx.x] = at < len ? count_nl16(text, at, len, &m) : 0;
+    int mine = 0;
+#pragma unroll
+    for (int ps = 0; ps < NL_PASSES; ++ps) {
+        const int64_t at = (int64_t)blockIdx.x * NL_TILE + ps * NL_SUB + threadIdx.x * 16;
+        uint32_t m;
+        if (at < len) mine += count_nl16(text, at, len, &m);
+    }
+    sh[threadIdx.x] = mine;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
@@ -51,7 +58,7 @@ __global__ __launch_bounds__(256) void k_nl_count(const uint8_t *__restrict__ te
     if (threadIdx.x == 0) tile_count[blockIdx.x] = sh[0];
 }
 
-// exclusive prefix of the tile counts (one block; n_tiles is a few hundred thousand at most per call)
+// exclusive prefix of the tile counts (one block; a 1 GiB block of text has 65 536 tiles)
 __global__ __launch_bounds__(256) void k_nl_scan(const int32_t *__restrict__ tile_count, int64_t n_tiles, int64_t *__restrict__ tile_base,
                                                  int64_t *__restrict__ total) {
     __shared__ long long sh[256];
@@ -80,22 +87,27 @@ __global__ __launch_bounds__(256) void k_nl_scan(const int32_t *__restrict__ til
 __global__ __launch_bounds__(256) void k_nl_write(const uint8_t *__restrict__ text, int64_t len, const int64_t *__restrict__ tile_base,
                                                   int64_t *__restrict__ nl_pos) {
     __shared__ int sh[256];
-    const int64_t at = (int64_t)blockIdx.x * NL_TILE + threadIdx.x * 16;
-    uint32_t mask = 0u;
-    const int mine = at < len ? count_nl16(text, at, len, &mask) : 0;
-    sh[threadIdx.x] = mine;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const int x = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    int64_t base = tile_base[blockIdx.x];
+    for (int ps = 0; ps < NL_PASSES; ++ps) {
+        const int64_t at = (int64_t)blockIdx.x * NL_TILE + ps * NL_SUB + threadIdx.x * 16;
+        uint32_t mask = 0u;
+        const int mine = at < len ? count_nl16(text, at, len, &mask) : 0;
+        sh[threadIdx.x] = mine;
         __syncthreads();
-        sh[threadIdx.x] += x;
+        for (int d = 1; d < 256; d <<= 1) {
+            const int x = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += x;
+            __syncthreads();
+        }
+        int64_t k = base + sh[threadIdx.x] - mine;
+        while (mask) {
+            const int b = __builtin_ctz(mask);
+            mask &= mask - 1u;
+            nl_pos[k++] = at + b;
+        }
+        base += sh[255];
         __syncthreads();
-    }
-    int64_t k = tile_base[blockIdx.x] + sh[threadIdx.x] - mine;
-    while (mask) {
-        const int b = __builtin_ctz(mask);
-        mask &= mask - 1u;
-        nl_pos[k++] = at + b;
     }
 }
 
@@ -108,27 +120,82 @@ enum { TOK_IRREGULAR = 1, TOK_BAD_POS = 2, TOK_COMMENT = 4 };
 // dip[ch]: the two one-hot codes of IUPAC diploid character ch, low nibble | high nibble << 4 (genomics.py:14-15)
 struct DipTable { uint8_t v[256]; };
 
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane)); }
+
+// One wave per line.  The first 64 bytes of the line (scaffold, position, start of the cells) are read one byte per lane and
+// taken apart with ballots: the ends of the two tokens are bit scans, the position is a short scalar loop over readlane.  A line
+// whose prefix does not fit the 64 bytes (or starts with blanks) goes through the byte-by-byte walk on lane 0.
 __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ text, const int64_t *__restrict__ nl_pos, int64_t n_lines,
                                                    int fmt, int n_cols, int cellw, int ploidy, int max_ploidy,
                                                    const int32_t *__restrict__ col_slot, const int32_t *__restrict__ col_ploidy,
                                                    int8_t *__restrict__ rows, int S, int32_t *__restrict__ pos_out,
-                                                   int64_t *__restrict__ scaf_off, int32_t *__restrict__ scaf_len,
-                                                   uint8_t *__restrict__ newrun, int32_t *__restrict__ status, DipTable dip) {
+                                                   int64_t *__restrict__ run_row, int64_t *__restrict__ run_off, int32_t *__restrict__ run_len,
+                                                   int32_t *__restrict__ n_runs, int64_t run_cap, int32_t *__restrict__ status, DipTable dip) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_lines) return;
     const int64_t ls = row ? nl_pos[row - 1] + 1 : 0, le = nl_pos[row];            // [ls, le): the line without its '\n'
     int64_t cells_at = -1;
     int bad = 0;
-    if (lane == 0) {
+    const int nv = (int)(le - ls < 64 ? le - ls : 64);
+    const int ch = lane < nv ? (int)text[ls + lane] : 10;
+    const uint64_t valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+    const uint64_t bl = __ballot(blank((uint8_t)ch)) & valid, nb = ~bl & valid;
+    bool fast = false;
+    if (nv > 0 && (nb & 1ull) && bl) {
+        const int p1 = __builtin_ctzll(bl);                                       // end of the scaffold token
+        const uint64_t r1 = nb & ~((1ull << p1) - 1ull);
+        if (r1) {
+            int d0 = __builtin_ctzll(r1);                                         // start of the position
+            const uint64_t b2 = bl & ~((1ull << d0) - 1ull);
+            if (b2) {
+                const int p2 = __builtin_ctzll(b2);                               // its end
+                const uint64_t r2 = nb & ~((1ull << p2) - 1ull);
+                // the previous line's scaffold token, for the run flag
+                bool differs = row == 0, prev_ok = true;
+                if (row > 0) {
+                    const int64_t pls = row > 1 ? nl_pos[row - 2] + 1 : 0, ple = nl_pos[row - 1];
+                    const int pnv = (int)(ple - pls < 64 ? ple - pls : 64);
+                    const int pch = lane < pnv ? (int)text[pls + lane] : 10;
+                    const int p0 = rl(pch, 0);
+                    prev_ok = pnv > 0 && !blank((uint8_t)p0);
+                    const uint64_t neq = __ballot(ch != pch) & ((1ull << p1) - 1ull);
+                    const bool ends = p1 >= pnv ? (p1 == pnv && ple - pls == p1) : blank((uint8_t)rl(pch, p1));
+                    differs = neq != 0ull || !ends;
+                }
+                if (r2 && prev_ok) {
+                    fast = true;
+                    if (rl(ch, 0) == '#') bad |= TOK_COMMENT;
+                    const int c0 = rl(ch, d0);
+                    const bool neg = c0 == '-';
+                    if (c0 == '+' || c0 == '-') ++d0;
+                    const uint64_t dg = __ballot(ch >= '0' && ch <= '9');
+                    const uint64_t range = ((1ull << p2) - 1ull) & ~((1ull << d0) - 1ull);
+                    long long v = 0;
+                    if (p2 <= d0 || (dg & range) != range) bad |= TOK_BAD_POS;
+                    else
+                        for (int k = d0; k < p2 && v <= 0x7FFFFFFFll; ++k) v = v * 10 + (rl(ch, k) - '0');
+                    if (v > 0x7FFFFFFFll) bad |= TOK_BAD_POS;
+                    cells_at = ls + __builtin_ctzll(r2);
+                    if (le - cells_at != (int64_t)n_cols * (cellw + 1) - 1) bad |= TOK_IRREGULAR;
+                    if (lane == 0) {
+                        pos_out[row] = (int32_t)(neg ? -v : v);
+                        if (differs) {
+                            const int k = atomicAdd(n_runs, 1);
+                            if (k < run_cap) { run_row[k] = row; run_off[k] = ls; run_len[k] = p1; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!fast && lane == 0) {
         int64_t p = ls;
         if (p >= le || text[p] == '#') bad |= TOK_COMMENT;
         while (p < le && blank(text[p])) ++p;
         const int64_t s0 = p;
         while (p < le && !blank(text[p])) ++p;
         if (p == s0) bad |= TOK_COMMENT;                                         // blank line
-        scaf_off[row] = s0;
-        scaf_len[row] = (int32_t)(p - s0);
         // a new scaffold run starts where the token differs from the previous line's
         bool differs = row == 0;
         if (row > 0) {
@@ -139,7 +206,10 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
             while (a < p && q < qe && text[a] == text[q]) { ++a; ++q; }
             differs = !(a == p && (q == qe || blank(text[q])));
         }
-        newrun[row] = differs ? 1 : 0;
+        if (differs) {
+            const int k = atomicAdd(n_runs, 1);
+            if (k < run_cap) { run_row[k] = row; run_off[k] = s0; run_len[k] = (int32_t)(p - s0); }
+        }
         while (p < le && blank(text[p])) ++p;
         bool neg = false;
         if (p < le && (text[p] == '+' || text[p] == '-')) { neg = text[p] == '-'; ++p; }
@@ -188,12 +258,14 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
 // rows and the caller tokenises the block on the host.
 extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fmt, int n_cols, int max_ploidy,
                                 const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out,
-                                int64_t *scaf_off_out, int32_t *scaf_len_out, uint8_t *newrun_out, int64_t row_capacity,
-                                int64_t *n_rows_out, int *ok_out) {
-    if (!c || (!text && len) || !col_slot || !col_ploidy || !n_rows_out || !ok_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null argument");
+                                int64_t row_capacity, int64_t *run_row_out, int64_t *run_off_out, int32_t *run_len_out,
+                                int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out) {
+    if (!c || (!text && len) || !col_slot || !col_ploidy || !n_rows_out || !n_runs_out || !ok_out)
+        return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null argument");
     if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
     if (fmt < PG_FMT_PHASED || fmt > PG_FMT_DIPLO || n_cols < 1 || max_ploidy < 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: bad format description");
     *n_rows_out = 0;
+    *n_runs_out = 0;
     *ok_out = 0;
     if (len == 0) { *ok_out = 1; return PG_OK; }
     // one ploidy for every wanted column, or no fast path
@@ -216,12 +288,12 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
     int rc;
     // ---- text to the device, double-buffered through page-locked staging ----
     if ((rc = c->tok_text.ensure((size_t)len + 32)) != PG_OK) return rc;
-    const size_t piece = 64u << 20;
+    const size_t piece = 32u << 20;
     for (int k = 0; k < 2; ++k)
         if ((rc = c->tok_pin[k].ensure(std::min<size_t>(piece, (size_t)len))) != PG_OK) return rc;
     if (!c->tok_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->tok_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->tok_ev[1], hipEventDisableTiming)); }
     int nt = (int)std::thread::hardware_concurrency();
-    nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
     int64_t done = 0;
     for (int k = 0; done < len; ++k) {
         const size_t n = (size_t)std::min<int64_t>((int64_t)piece, len - done);
@@ -230,8 +302,9 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
         {
             std::vector<std::thread> th;
             const int use = (int)std::min<size_t>((size_t)nt, n / (1 << 20) + 1);
-            for (int t = 0; t < use; ++t)
-                th.emplace_back([&, t]() { const size_t a = n * t / use, b = n * (t + 1) / use; memcpy(pin + a, text + done + a, b - a); });
+            auto part = [&](int t) { const size_t a = n * t / use, b = n * (t + 1) / use; memcpy(pin + a, text + done + a, b - a); };
+            for (int t = 1; t < use; ++t) th.emplace_back(part, t);
+            part(0);
             for (auto &x : th) x.join();
         }
         HIPCHK(hipMemcpyAsync(c->tok_text.p + done, pin, n, hipMemcpyHostToDevice, st));
@@ -240,11 +313,11 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
     }
     // ---- line feeds ----
     const int64_t n_tiles = (len + NL_TILE - 1) / NL_TILE;
-    if ((rc = c->tok_i32.ensure((size_t)n_tiles + 2)) != PG_OK) return rc;
+    if ((rc = c->tok_i32.ensure((size_t)n_tiles + 4)) != PG_OK) return rc;
     if ((rc = c->tok_i64.ensure((size_t)n_tiles + 2)) != PG_OK) return rc;
-    int32_t *d_status = c->tok_i32.p + n_tiles;
+    int32_t *d_status = c->tok_i32.p + n_tiles;                                  // [0] status bits, [1] number of runs
     int64_t *d_total = c->tok_i64.p + n_tiles;
-    HIPCHK(hipMemsetAsync(d_status, 0, 4, st));
+    HIPCHK(hipMemsetAsync(d_status, 0, 8, st));
     hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_tiles), dim3(256), 0, st, c->tok_text.p, len, c->tok_i32.p);
     hipLaunchKernelGGL(k_nl_scan, dim3(1), dim3(256), 0, st, c->tok_i32.p, n_tiles, c->tok_i64.p, d_total);
     int64_t n_lines = 0;
@@ -253,16 +326,16 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
     *n_rows_out = n_lines;
     if (n_lines == 0) { *ok_out = 1; return PG_OK; }
     if (n_lines > row_capacity || row_offset < 0 || row_offset + n_lines > c->cap_sites) return PG_OK;   // (caller sizes from pg_count_lines)
-    if (!pos_out || !scaf_off_out || !scaf_len_out || !newrun_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null output");
+    if (!pos_out || !run_row_out || !run_off_out || !run_len_out || run_capacity < 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null output");
     if ((rc = c->tok_nl.ensure((size_t)n_lines)) != PG_OK) return rc;
     hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(256), 0, st, c->tok_text.p, len, c->tok_i64.p, c->tok_nl.p);
     // ---- parse ----
     if ((rc = c->tok_cols.ensure((size_t)n_cols * (max_ploidy + 1))) != PG_OK) return rc;
     HIPCHK(hipMemcpyAsync(c->tok_cols.p, col_slot, (size_t)n_cols * max_ploidy * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->tok_cols.p + (size_t)n_cols * max_ploidy, col_ploidy, (size_t)n_cols * 4, hipMemcpyHostToDevice, st));
-    if ((rc = c->tok_pos.ensure((size_t)n_lines * 2 + 8)) != PG_OK) return rc;         // pos + scaf_len (int32 each)
-    if ((rc = c->tok_off.ensure((size_t)n_lines)) != PG_OK) return rc;
-    if ((rc = c->tok_flag.ensure((size_t)n_lines)) != PG_OK) return rc;
+    const int64_t run_cap = std::min<int64_t>(run_capacity, n_lines);
+    if ((rc = c->tok_pos.ensure((size_t)n_lines + (size_t)run_cap + 8)) != PG_OK) return rc;   // pos [n_lines] + run_len [run_cap] (int32 each)
+    if ((rc = c->tok_off.ensure((size_t)run_cap * 2)) != PG_OK) return rc;                      // run_row, run_off
     HIPCHK(hipMemsetAsync(c->gt.p + row_offset * c->S, 0, (size_t)n_lines * c->S, st));
     DipTable dip;
     memset(dip.v, 0, sizeof(dip.v));
@@ -274,15 +347,33 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
     }
     hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, c->tok_text.p, c->tok_nl.p, n_lines, fmt, n_cols,
                        cellw, ploidy, max_ploidy, c->tok_cols.p, c->tok_cols.p + (size_t)n_cols * max_ploidy, c->gt.p + row_offset * c->S, c->S,
-                       c->tok_pos.p, c->tok_off.p, c->tok_pos.p + n_lines, c->tok_flag.p, d_status, dip);
+                       c->tok_pos.p, c->tok_off.p, c->tok_off.p + run_cap, c->tok_pos.p + n_lines, d_status + 1, run_cap, d_status, dip);
     HIPCHK(hipGetLastError());
-    int32_t status = 0;
-    HIPCHK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+    int32_t status[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(status, d_status, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(pos_out, c->tok_pos.p, (size_t)n_lines * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(scaf_len_out, c->tok_pos.p + n_lines, (size_t)n_lines * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(scaf_off_out, c->tok_off.p, (size_t)n_lines * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(newrun_out, c->tok_flag.p, (size_t)n_lines, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    *ok_out = status == 0 ? 1 : 0;
+    if (status[0] != 0) return PG_OK;
+    const int64_t nr = status[1];
+    *n_runs_out = nr;
+    if (nr > run_cap) return PG_OK;                                             // more runs than the caller has room for
+    std::vector<int64_t> rr((size_t)nr), ro((size_t)nr);
+    std::vector<int32_t> rlen((size_t)nr);
+    if (nr) {
+        HIPCHK(hipMemcpyAsync(rr.data(), c->tok_off.p, (size_t)nr * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(ro.data(), c->tok_off.p + run_cap, (size_t)nr * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(rlen.data(), c->tok_pos.p + n_lines, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    std::vector<int64_t> order((size_t)nr);
+    for (int64_t k = 0; k < nr; ++k) order[(size_t)k] = k;
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return rr[(size_t)a] < rr[(size_t)b]; });   // the appends arrive in any order
+    for (int64_t k = 0; k < nr; ++k) {
+        const size_t j = (size_t)order[(size_t)k];
+        run_row_out[k] = rr[j];
+        run_off_out[k] = ro[j];
+        run_len_out[k] = rlen[j];
+    }
+    *ok_out = 1;
     return PG_OK;
 }

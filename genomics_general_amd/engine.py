@@ -170,11 +170,11 @@ class Engine:
         check(self._L.pg_upload_wait(self._h))
         self._in_flight = None
 
-    def tokenize_text(self, buf, row_offset=0, n_rows=None):
+    def tokenize_text(self, buf, row_offset=0, n_rows=None, max_runs=1 << 16):
         """K0 on the device: complete `.geno` data lines (bytes-like: bytes, memoryview, mmap) -> resident rows row_offset ..;
-        returns (n, pos int32 [n], scaf_off int64 [n], scaf_len int32 [n], newrun uint8 [n]) or None when the block is not of the
-        regular layout the device tokenizer handles (the caller then takes the host tokenizer).  The rows must be reserved:
-        n_rows = number of data lines (pg_count_lines) if known."""
+        returns (n, pos int32 [n], run_starts int64 [r], run_names) or None when the block is not of the regular layout the device
+        tokenizer handles (the caller then takes the host tokenizer).  The rows must be reserved: n_rows = number of data lines
+        (pg_count_lines) if known."""
         lay = self.layout
         ptr, nbytes, _keep = _lib.text_ptr(buf)
         if n_rows is None:
@@ -182,18 +182,22 @@ class Engine:
             check(self._L.pg_count_lines(ptr, nbytes, C.byref(n)))
             n_rows = int(n.value)
         cap = max(int(n_rows), 1)
-        pos = np.zeros(cap, dtype=np.int32)
-        soff = np.zeros(cap, dtype=np.int64)
-        slen = np.zeros(cap, dtype=np.int32)
-        newrun = np.zeros(cap, dtype=np.uint8)
-        got, ok = C.c_int64(0), C.c_int(0)
-        check(self._L.pg_tokenize_text(self._h, ptr, nbytes, _lib.FMT[lay.genoFormat], len(lay.col_ploidy), lay.max_ploidy,
-                                       np.ascontiguousarray(lay.col_slot), lay.col_ploidy, int(row_offset), pos, soff, slen, newrun,
-                                       cap, C.byref(got), C.byref(ok)))
+        pos = np.empty(cap, dtype=np.int32)
+        while True:
+            rrow, roff, rlen = np.empty(max_runs, dtype=np.int64), np.empty(max_runs, dtype=np.int64), np.empty(max_runs, dtype=np.int32)
+            got, nr, ok = C.c_int64(0), C.c_int64(0), C.c_int(0)
+            check(self._L.pg_tokenize_text(self._h, ptr, nbytes, _lib.FMT[lay.genoFormat], len(lay.col_ploidy), lay.max_ploidy,
+                                           np.ascontiguousarray(lay.col_slot), lay.col_ploidy, int(row_offset), pos, cap, rrow, roff, rlen,
+                                           max_runs, C.byref(got), C.byref(nr), C.byref(ok)))
+            if not ok.value and nr.value > max_runs and max_runs < cap:          # a block of very many short scaffolds: once more
+                max_runs = cap
+                continue
+            break
         if not ok.value or got.value != n_rows:
             return None
-        k = int(got.value)
-        return k, pos[:k], soff[:k], slen[:k], newrun[:k]
+        k, r = int(got.value), int(nr.value)
+        names = [bytes(buf[int(roff[i]):int(roff[i]) + int(rlen[i])]).decode("utf-8", "replace") for i in range(r)]
+        return k, pos[:k], rrow[:r].copy(), names
 
     def move_rows(self, src_row, dst_row, n):
         check(self._L.pg_move_rows(self._h, int(src_row), int(dst_row), int(n)))

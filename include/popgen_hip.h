@@ -96,11 +96,13 @@ int pg_upload_wait(pg_ctx *ctx);
  * 407-408, 74-77, 1884-1904), for the regular layout only: one separator character between cells, cells of one width, one
  * ploidy for every wanted column, no comment or blank lines in the block.  *ok_out = 1 when the layout was regular and the rows
  * are valid; 0 otherwise (nothing may be assumed about the rows: tokenise the block with pg_encode_text and upload it).
- * Outputs (host arrays of row_capacity entries): positions, location of each row's scaffold token in text, and newrun_out[i] =
- * 1 where row i's scaffold differs from row i-1's.  Call pg_count_lines first to reserve the rows.  Blocks on the copy stream. */
+ * Outputs: pos_out[row_capacity] the positions; the scaffold runs of the block as (first row, offset and length of the scaffold
+ * token in text), sorted by row, run_capacity entries each (*ok_out = 0 when there are more).  Call pg_count_lines first to
+ * reserve the rows.  Blocks on the copy stream. */
 int pg_tokenize_text(pg_ctx *ctx, const char *text, int64_t len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
-                     const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out, int64_t *scaf_off_out, int32_t *scaf_len_out,
-                     uint8_t *newrun_out, int64_t row_capacity, int64_t *n_rows_out, int *ok_out);
+                     const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out, int64_t row_capacity, int64_t *run_row_out,
+                     int64_t *run_off_out, int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out,
+                     int *ok_out);
 /* Copy n resident rows from src_row to dst_row (ranges may overlap): the rows carried over to the next block of a stream. */
 int pg_move_rows(pg_ctx *ctx, int64_t src_row, int64_t dst_row, int64_t n);
 

@@ -61,12 +61,7 @@ class CpuEngine:
             return None
         assert row_offset + d.n_sites <= len(self.gt), "tokenised rows exceed the reserved rows"
         self.gt[row_offset:row_offset + d.n_sites] = d.gt[:, :self.layout.n_hap]
-        newrun = np.zeros(d.n_sites, dtype=np.uint8)
-        newrun[d.run_starts] = 1
-        lines = body.split(b"\n")[:-1]
-        off = np.cumsum([0] + [len(ln) + 1 for ln in lines])[:-1].astype(np.int64)
-        slen = np.array([len(ln.split()[0]) for ln in lines], dtype=np.int32)
-        return d.n_sites, d.pos.copy(), off, slen, newrun
+        return d.n_sites, d.pos.copy(), d.run_starts.astype(np.int64), list(d.run_names)
 
     def load_sites(self, gt):
         self.gt = np.array(gt, dtype=np.int8, copy=True)[:, :self.layout.n_hap]

@@ -63,13 +63,24 @@ def test_drivers_on_packed_input_on_the_cpu_engine(case, tmp_path, monkeypatch):
 @pytest.mark.parametrize("case", [c for c in G.STREAMABLE if c["fixture"] != "mixed" and c["tool"] != "freq.py"],
                          ids=lambda c: c["name"])
 def test_drivers_with_the_device_tokenizer_interface(case, block, tmp_path, monkeypatch):
-    """PG_GPU_TOKENIZER=1 (cli.Run._chunks_device): rows tokenised behind the carried rows, carried rows moved to the front, growth
-    of the reservation through the host -- on the stand-in engine, whose tokenize_text is the host tokenizer"""
+    """the default (cli.Run._chunks_device): rows tokenised behind the carried rows, carried rows moved to the front, growth of the
+    reservation through the host -- on the stand-in engine, whose tokenize_text is the host tokenizer"""
     monkeypatch.setenv("PG_STREAM_BYTES", block)
-    monkeypatch.setenv("PG_GPU_TOKENIZER", "1")
     before = CpuEngine.tokenizer_calls
     run_case(case, tmp_path, monkeypatch)
     assert CpuEngine.tokenizer_calls > before, "the driver did not take the device-tokenizer path"
+
+
+@pytest.mark.parametrize("block", ["4000", "70000", None])
+@pytest.mark.parametrize("case", G.STREAMABLE, ids=lambda c: c["name"])
+def test_drivers_with_the_host_tokenizer_pipeline(case, block, tmp_path, monkeypatch):
+    """PG_GPU_TOKENIZER=0: reader || tokenizer || asynchronous uploads into alternating halves of the resident rows"""
+    if block:
+        monkeypatch.setenv("PG_STREAM_BYTES", block)
+    monkeypatch.setenv("PG_GPU_TOKENIZER", "0")
+    before = CpuEngine.tokenizer_calls
+    run_case(case, tmp_path, monkeypatch)
+    assert CpuEngine.tokenizer_calls == before
 
 
 def test_device_tokenizer_path_falls_back_block_by_block(tmp_path, monkeypatch):
@@ -82,7 +93,6 @@ def test_device_tokenizer_path_falls_back_block_by_block(tmp_path, monkeypatch):
     with open(dirty, "wb") as f:
         f.write(b"\n".join(raw[:300] + [b"# not a site"] + raw[300:]))
     monkeypatch.setenv("PG_STREAM_BYTES", "20000")
-    monkeypatch.setenv("PG_GPU_TOKENIZER", "1")
     before = CpuEngine.tokenizer_calls
     run_case(case, tmp_path, monkeypatch, geno=dirty)
     assert CpuEngine.tokenizer_calls > before + 2

@@ -89,12 +89,13 @@ def test_cli_streaming_in_small_blocks_reproduces_reference_output(case, block, 
 
 @pytest.mark.parametrize("case", STREAMABLE, ids=[c["name"] for c in STREAMABLE])
 @pytest.mark.parametrize("block", [3000, 50000, None])
-def test_cli_with_the_device_tokenizer_reproduces_reference_output(case, block, tmp_path, monkeypatch):
-    """the same goldens with K0 on the device (PG_GPU_TOKENIZER=1: pg_tokenize_text writes the resident rows, carried rows moved
-    by pg_move_rows); the mixed-ploidy fixtures take the host path by layout"""
+def test_cli_with_the_host_tokenizer_reproduces_reference_output(case, block, tmp_path, monkeypatch):
+    """the same goldens with K0 on the host (PG_GPU_TOKENIZER=0: reader || tokenizer threads || asynchronous uploads into
+    alternating halves of the resident rows); by default pg_tokenize_text writes the resident rows on the device, and only the
+    mixed-ploidy fixtures take the host path, by layout"""
     if block:
         monkeypatch.setenv("PG_STREAM_BYTES", str(block))
-    monkeypatch.setenv("PG_GPU_TOKENIZER", "1")
+    monkeypatch.setenv("PG_GPU_TOKENIZER", "0")
     test_cli_reproduces_reference_output(case, tmp_path)
 
 

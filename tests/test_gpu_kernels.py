@@ -371,11 +371,12 @@ def test_device_tokenizer_equals_the_host_tokenizer(fixture, fmt):
         e.reserve(want.n_sites + 100)
         got = e.tokenize_text(body, row_offset=37)
         assert got is not None, "regular fixture refused by the device tokenizer"
-        n, pos, soff, slen, newrun = got
+        n, pos, starts, run_names = got
         assert n == want.n_sites and np.array_equal(pos, want.pos)
         assert np.array_equal(e.download(37, n), want.gt)
-        assert np.array_equal(np.flatnonzero(newrun), want.run_starts)
-        assert [bytes(body[int(soff[i]):int(soff[i]) + int(slen[i])]).decode() for i in want.run_starts] == want.run_names
+        assert np.array_equal(starts, want.run_starts) and run_names == want.run_names
+        tiny = e.tokenize_text(body, row_offset=37, max_runs=1)                  # more runs than room: asked again with room
+        assert tiny is not None and np.array_equal(tiny[2], want.run_starts)
         e.close()
 
 
@@ -409,4 +410,47 @@ def test_device_tokenizer_refuses_irregular_blocks():
     e.set_layout(ml)
     e.reserve(5000)
     assert e.tokenize_text(mixed[mixed.index(b"\n") + 1:]) is None
+    e.close()
+
+
+def test_device_tokenizer_line_prefixes_beyond_the_fast_path():
+    """scaffold names longer than the 64 bytes the ballots see, blanks in front of the scaffold, several blanks between scaffold
+    and position, signed positions: the byte-by-byte walk gives what the host tokenizer gives, also next to fast-path lines"""
+    import gzip
+    import os
+    from genomics_general_amd import genoio
+    from genomics_general_amd.engine import Engine
+    from genomics_general_amd.samples import HapLayout, SampleData
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    raw = gzip.open(os.path.join(gold, "c1.geno.gz"), "rb").read()
+    names = raw[:raw.index(b"\n")].decode().split()[2:]
+    lines = raw[raw.index(b"\n") + 1:].split(b"\n")[:-1]
+    long_a, long_b = b"scaffold_" + b"x" * 70 + b"_a", b"scaffold_" + b"x" * 70 + b"_b"
+    out = []
+    for k, ln in enumerate(lines):
+        scaf, pos, cells = ln.split(None, 2)
+        if 100 <= k < 160:
+            scaf = long_a if k < 130 else long_b
+        if 200 <= k < 230:
+            ln = b" " + scaf + b"\t" + pos + b"\t" + cells
+        elif 300 <= k < 330:
+            ln = scaf + b" \t " + pos + b"  " + cells
+        elif 400 <= k < 410:
+            ln = scaf + b"\t+" + pos + b"\t" + cells
+        elif k == 420:
+            ln = b"q" * 50 + b"\t" + pos + b"\t" + cells           # the position straddles the 64-byte window
+        else:
+            ln = scaf + b"\t" + pos + b"\t" + cells
+        out.append(ln)
+    body = b"\n".join(out) + b"\n"
+    lay = HapLayout(SampleData(indNames=list(names)), names, "phased")
+    want = genoio.encode(body, lay)
+    e = Engine(0)
+    e.set_layout(lay)
+    e.reserve(want.n_sites)
+    got = e.tokenize_text(body)
+    assert got is not None
+    n, pos, starts, run_names = got
+    assert n == want.n_sites and np.array_equal(pos, want.pos) and np.array_equal(e.download(0, n), want.gt)
+    assert np.array_equal(starts, want.run_starts) and run_names == want.run_names
     e.close()

@@ -45,14 +45,14 @@ def main():
         cmd += ["-p", "pop%d" % k, ",".join(names[k * per:(k + 1) * per])]
     ref_rows = None
     for rep, block in enumerate([None, None, 64 << 20]):       # twice with the default block size, once in 64 MiB blocks
-        env = dict(os.environ, PG_TIMING="1")
+        env = dict(os.environ, PG_TIMING="1", PG_GPU_TOKENIZER="0")             # K0 on the host (reader || tokenizer || upload)
         if block:
             env["PG_STREAM_BYTES"] = str(block)
         t0 = time.time()
         r = subprocess.run(cmd, env=env, stderr=subprocess.PIPE)
         wall = time.time() - t0
         line = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING")]
-        print("run %d (%s): wall %.2f s (incl. interpreter start)  %s" % (
+        print("host tokenizer run %d (%s): wall %.2f s (incl. interpreter start)  %s" % (
             rep, "blocks of %d MiB" % (block >> 20) if block else "default blocks", wall,
             line[-1] if line else r.stderr.decode()[-400:]))
         with open("/tmp/t2_out.csv") as f:
@@ -60,9 +60,9 @@ def main():
         if ref_rows is None:
             ref_rows = rows
         print("   output identical to run 0:", rows == ref_rows)
-    # K0 on the device (PG_GPU_TOKENIZER=1): the text goes down as it is, pg_tokenize_text writes the resident rows
+    # K0 on the device (the default): the text goes down as it is, pg_tokenize_text writes the resident rows
     for rep, block in enumerate([None, None, 256 << 20]):
-        env = dict(os.environ, PG_TIMING="1", PG_GPU_TOKENIZER="1")
+        env = dict(os.environ, PG_TIMING="1")
         if block:
             env["PG_STREAM_BYTES"] = str(block)
         t0 = time.time()
