@@ -63,13 +63,7 @@ extern "C" int pg_ctx_create(pg_ctx **out, int device) {
     if (e != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         (void)hipStreamDestroy(c->stream2);
-    (void)hipStreamDestroy(c->stream_up);
-    if (c->up_ev) (void)hipEventDestroy(c->up_ev);
-    c->cells_stage.release();
-    c->slot_src.release();
-    c->tok_text.release(); c->tok_i32.release(); c->tok_cols.release(); c->tok_pos.release();
-    c->tok_i64.release(); c->tok_nl.release(); c->tok_off.release(); c->tok_pin[0].release(); c->tok_pin[1].release();
-    for (int k = 0; k < 2; ++k) if (c->tok_ev[k]) (void)hipEventDestroy(c->tok_ev[k]);
+        if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
         delete c;
         return pg_fail(PG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
@@ -109,6 +103,21 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     }
     if (c->win_ev) (void)hipEventDestroy(c->win_ev);
     (void)hipStreamDestroy(c->stream2);
+    (void)hipStreamDestroy(c->stream_up);
+    if (c->up_ev) (void)hipEventDestroy(c->up_ev);
+    for (int k = 0; k < 2; ++k)
+        if (c->tok_ev[k]) (void)hipEventDestroy(c->tok_ev[k]);
+    c->cells_stage.release();
+    c->slot_src.release();
+    c->tok_text.release();
+    c->tok_i32.release();
+    c->tok_cols.release();
+    c->tok_pos.release();
+    c->tok_i64.release();
+    c->tok_nl.release();
+    c->tok_off.release();
+    c->tok_pin[0].release();
+    c->tok_pin[1].release();
     drop_events(c);
     c->gt.release();
     c->hap_pop.release();
