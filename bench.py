@@ -69,6 +69,7 @@ CPU_SLICE_SITES = 4_000         # CPU sample: the first 4000 sites of a window p
                                 # ~10x that with every hardware thread of a 256-thread host busy)
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GUIDE = 1024 * 2.4e9 / 2      # wave64 VALU instructions per second: 256 CUs x 4 SIMD-32, 2 cycles each, 2.4 GHz (guide)
+MFMA_I8_PEAK_TOPS = 5000.0     # int8 MFMA, dense: 2 x the guide's bf16 dense peak (~2.5 PFLOP/s); its measured ceiling is 4404 (32x32x32)
 VALU_PAIRSITES_PEAK = 3.6e14    # 7 lane-ops per 32 pair-sites at 7.9e13 lane-ops/s
 
 
@@ -419,7 +420,8 @@ def main():
     if os.environ.get("PG_PAIR_V1"):
         rocprof_name = {_lib.K_PACK: "k_pack", _lib.K_PAIRWISE: "k_pairwise"}
     else:
-        rocprof_name = {_lib.K_PACK: pack_name, _lib.K_PAIRWISE: "k_pairC", _lib.K_PAIRD: "k_pairD",
+        sfx = "" if os.environ.get("PG_PAIR_VALU") else "_mfma"          # pair counts: matrix cores by default, popcount kernels as A/B
+        rocprof_name = {_lib.K_PACK: pack_name, _lib.K_PAIRWISE: "k_pairC" + sfx, _lib.K_PAIRD: "k_pairD" + sfx,
                         _lib.K_SITESTATS: "k_popfreq_q" if wl["tool"] == "popfreq" else "k_abba_q"}
     pmc = {}
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -434,7 +436,18 @@ def main():
         launches_per_step = dom_n / args.steps
         kname = rocprof_name.get(dom_id, _lib.KERNEL_NAMES[dom_id])
         alg_bytes_launch = n_hap * sites_per_step / launches_per_step       # 1 byte per haplotype allele call
-        if dom_id in (_lib.K_PAIRWISE, _lib.K_PAIRD) and not os.environ.get("PG_PAIR_V1"):
+        if dom_id in (_lib.K_PAIRWISE, _lib.K_PAIRD) and not os.environ.get("PG_PAIR_V1") and not os.environ.get("PG_PAIR_VALU"):
+            # pair kernel on the matrix cores: algorithmic int8 multiply-accumulates (k_pairC_mfma: unordered unit pairs incl. the
+            # diagonal x sites; k_pairD_mfma: two products per haplotype pair and virtual site, whose number only the device knows)
+            units = n_hap // 2 if (lay.n_hap == 2 * lay.n_samp and not os.environ.get("PG_NO_DIP")) else n_hap
+            macs = units * (units + 1) / 2 * sites_per_step / launches_per_step if dom_id == _lib.K_PAIRWISE else None
+            roofline = {"kernel": kname, "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_I8_PEAK_TOPS,
+                        "peak_source": "int8 dense = 2 x the bf16 dense peak (MI355X_MICROARCH.md; measured ceiling there: 4404)",
+                        "achieved": round(2 * macs / per_launch_s / 1e12, 2) if macs else None,
+                        "frac": round(2 * macs / per_launch_s / 1e12 / MFMA_I8_PEAK_TOPS, 5) if macs else None,
+                        "algorithmic_int8_macs_per_launch": macs, "traffic": pmc.get(args.workload, {}).get(kname),
+                        "avg_launch_ms": round(dom_ms / dom_n, 4), "launches": int(dom_n)}
+        elif dom_id in (_lib.K_PAIRWISE, _lib.K_PAIRD) and not os.environ.get("PG_PAIR_V1"):
             # VALU-bound pair kernel: wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU), live launch time
             insts = pmc.get("_valu", {}).get(args.workload, {}).get(kname)
             peak_meas = pmc.get("_valu_peak_measured", {}).get(kname)
@@ -460,8 +473,10 @@ def main():
             pair_sites = n_hap * (n_hap - 1) / 2 * sites_per_step
             extra["pair_kernels"] = {"ms_per_step": round(pair_ms, 4), "algorithmic_pair_sites_per_s": pair_sites / (pair_ms / 1e3),
                                      "naive_valu_bound": VALU_PAIRSITES_PEAK,
-                                     "note": "k_pairC + k_pairD together vs SURVEY 8d's 7-lane-op-per-32-pair-sites bound; "
-                                             "polymorphic-site compaction and per-individual called counts do less work than that"}
+                                     "engine": "VALU popcount (PG_PAIR_VALU)" if os.environ.get("PG_PAIR_VALU") else "int8 MFMA on the bit planes",
+                                     "note": "pair-count kernels C + D together vs SURVEY 8d's 7-lane-op-per-32-pair-sites VALU bound; "
+                                             "polymorphic-site compaction and per-individual called counts do less work than that, "
+                                             "and the matrix cores are not bound by it"}
     if gather_ms is not None:
         extra["result_allgather_ms_once_untimed"] = round(gather_ms, 3)
         extra["per_rank_ms_per_step"] = {"min": round(1e3 * float(per_rank[:, 0].min()) / args.steps, 4),

@@ -1,0 +1,375 @@
+// Pairwise counts on the matrix cores: C = V V^T and D = A B^T + B A^T as exact int8 x int8 -> int32 products.
+//
+// The bit-plane kernels of pg_pair2.hip (k_pairC: v_and + accumulating v_bcnt, k_pairD: v_xor + 2 x v_bitop3 + v_bcnt) sit at
+// 0.94 / 0.99 of the measured VALU issue ceiling of their instruction mixes (profiles/r02/valu_rate.txt): the vector ALU cannot
+// count pairs faster.  The counts are Gram matrices of 0/1 vectors (D = C - sum_b X_b X_b^T is array_equal to the
+// reference's pair loop, genomics.py:903-916, 1219-1221, 1042-1047), and v_mfma_i32_32x32x32_i8 multiplies 32 x 32 x 32 of them
+// per instruction at ~2.2e15 MAC/s (guide: 4404 TOPS measured) against 32 pair-sites per VALU lane-op = ~6e14 pair-sites/s.
+//
+// The planes stay what k_pack3 writes (1 bit per call / virtual site: no extra HBM bytes); a wave expands the words it needs
+// into 0/1 bytes in registers, two VALU ops per dword:
+//     fragment dword m of lane (r, kb) = (word >> (4 kb + m)) & 0x01010101,  m = 0..3
+// i.e. lane (r, kb) holds 16 of the word's 32 sites of unit r, in a permuted order -- the same order in the A and the B operand
+// (both are "row/column = lane & 31, K block = lane >> 5"), which is all a dot product needs.
+//
+//   k_pairC_mfma   units x units "both called" counts from the called plane Vp:   C(I,J) += V_I V_J^T
+//   k_pairD_mfma   haplotype x haplotype differences from the virtual-site planes XV (x = carries the tested allele,
+//                  v = called and not excluded):  a = x & v, b = ~x & v,  D(I,J) += a_I b_J^T + b_I a_J^T
+//                  ((x_i ^ x_j) & v_i & v_j = a_i b_j + b_i a_j, bit by bit)
+// A wave (= a block) owns up to 3 x 3 tiles of 32 x 32 of the upper triangle and keeps their accumulators in registers over its part of the window's words; int32 sums are exact (counts < 2^31 are guarded by the host).
+#include "pg_internal.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#ifndef PG_MFMA_TB
+#define PG_MFMA_TB 2
+#endif
+#define PG_MFMA_WAVES (PG_MFMA_TB == 2 ? 4 : 2)
+constexpr int TB = PG_MFMA_TB;         // a wave owns up to TB x TB tiles of 32 x 32: 9 x 16 accumulator registers, 6 fragments per 9 products
+
+// s-th task of the upper triangle of T x T tiles: tile rows I0 .. I0+nr-1, tile columns J0 .. J0+nc-1; the first task of a
+// block row starts on the diagonal (J0 == I0, nr == nc: the row fragments are the column fragments, the tiles below the diagonal
+// are skipped)
+__device__ __forceinline__ bool task_decode(int T, int s, int &I0, int &J0, int &nr, int &nc) {
+    for (int i0 = 0; i0 < T; i0 += TB) {
+        const int n = T - i0, k = (n + TB - 1) / TB;
+        if (s < k) {
+            I0 = i0;
+            nr = n < TB ? n : TB;
+            J0 = i0 + s * TB;
+            nc = T - J0 < TB ? T - J0 : TB;
+            return true;
+        }
+        s -= k;
+    }
+    return false;
+}
+
+int task_count(int T) {
+    int n = 0;
+    for (int i0 = 0; i0 < T; i0 += TB) n += (T - i0 + TB - 1) / TB;
+    return n;
+}
+
+// XCD-aware block -> (window, rest): block b runs on XCD b % 8; all blocks of a window go to one XCD, so the window's planes are
+// served by that XCD's L2 (the last n_win % 8 windows are dealt over all XCDs in contiguous runs).  Same dealing as pair_decode.
+__device__ __forceinline__ bool win_decode(int per_win, int n_win, int &win, int &rem) {
+    const int xcd = blockIdx.x & 7;
+    const int v = blockIdx.x >> 3;
+    const int full = n_win >> 3;
+    if (v < full * per_win) {
+        win = (v / per_win) * 8 + xcd;
+        rem = v % per_win;
+        return true;
+    }
+    const int total = (n_win & 7) * per_win, q = (total + 7) >> 3;
+    const int vt = v - full * per_win, lin = xcd * q + vt;
+    if (vt >= q || lin >= total) return false;
+    win = full * 8 + lin / per_win;
+    rem = lin % per_win;
+    return true;
+}
+
+__device__ __forceinline__ v4i expand(uint32_t w, int sh) {
+    const uint32_t x = w >> sh;
+    v4i f;
+    f.x = (int)(x & 0x01010101u);
+    f.y = (int)((x >> 1) & 0x01010101u);
+    f.z = (int)((x >> 2) & 0x01010101u);
+    f.w = (int)((x >> 3) & 0x01010101u);
+    return f;
+}
+
+// accumulator tile -> upper triangle of the window's matrix.  C/D layout of the 32x32 MFMA: column = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ void store_tile(const v16i &acc, int I, int J, int lane, int n, int diag, int atomic, int32_t *__restrict__ M) {
+    const int col = 32 * J + (lane & 31);
+    if (col >= n) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = 32 * I + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (row >= n || row > col || (row == col && !diag)) continue;
+        int32_t *dst = &M[(size_t)row * n + col];
+        if (atomic) { if (acc[reg]) atomicAdd(dst, acc[reg]); }
+        else *dst = acc[reg];
+    }
+}
+
+__device__ __forceinline__ uint32_t comp(const uint4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+
+// ---- C ----
+template <int NR, int NC, bool DG>
+struct WordsC {
+    uint4 r[DG ? 1 : NR], c[NC];
+    __device__ __forceinline__ void load(const uint4 *__restrict__ prow, const uint4 *__restrict__ pcol) {
+        if (!DG) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) r[i] = prow[32 * i];
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) c[j] = pcol[32 * j];
+    }
+};
+
+template <int NR, int NC, bool DG>
+__device__ __forceinline__ void pairC_group(const WordsC<NR, NC, DG> &w, int sh, v16i (&acc)[NR][NC]) {
+#pragma unroll
+    for (int wi = 0; wi < 4; ++wi) {
+        v4i fc[NC], fr[NR];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) fc[j] = expand(comp(w.c[j], wi), sh);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) fr[i] = DG ? fc[i] : expand(comp(w.r[DG ? 0 : i], wi), sh);
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+                if (!DG || j >= i) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[i], fc[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// groups q0 .. q1-1 (4 words = 128 sites each) in two register sets: the words of group q+1 are requested before the products
+// of group q are issued (the last look-ahead re-reads the last group: always inside the plane)
+template <int NR, int NC, bool DG>
+__device__ __forceinline__ void pairC_task(const uint4 *__restrict__ base, int q0, int q1, int NPv, int I0, int J0, int lane,
+                                           int n_units, int diag, int atomic, int32_t *__restrict__ Cw) {
+    const int r = lane & 31, sh = 4 * (lane >> 5);
+    v16i acc[NR][NC];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+    const uint4 *prow = base + (size_t)q0 * NPv + 32 * I0 + r;
+    const uint4 *pcol = base + (size_t)q0 * NPv + 32 * J0 + r;
+    WordsC<NR, NC, DG> wa, wb;
+    wa.load(prow, pcol);
+    for (int q = q0; q < q1; q += 2) {
+        size_t step = q + 1 < q1 ? (size_t)NPv : 0;
+        prow += step;
+        pcol += step;
+        wb.load(prow, pcol);
+        pairC_group<NR, NC, DG>(wa, sh, acc);
+        if (q + 1 >= q1) break;
+        step = q + 2 < q1 ? (size_t)NPv : 0;
+        prow += step;
+        pcol += step;
+        wa.load(prow, pcol);
+        pairC_group<NR, NC, DG>(wb, sh, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (!DG || j >= i) store_tile(acc[i][j], I0 + i, J0 + j, lane, n_units, diag, atomic, Cw);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVES, PG_MFMA_WAVES))) void k_pairC_mfma(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vgoff, int n_win,
+                                                   int T, int ntask, int kparts, int NPv, int n_units, int diag,
+                                                   int32_t *__restrict__ Cmat) {
+    int win, rem;
+    if (!win_decode(ntask * kparts, n_win, win, rem)) return;
+    const int s = rem % ntask, kp = rem / ntask;
+    int I0, J0, nr, nc;
+    if (!task_decode(T, s, I0, J0, nr, nc)) return;
+    const int64_t vg = vgoff[win];
+    const int nwq = (int)(vgoff[win + 1] - vg);
+    const int q0 = (int)((long long)nwq * kp / kparts), q1 = (int)((long long)nwq * (kp + 1) / kparts);
+    const int lane = threadIdx.x & 63, atomic = kparts > 1;
+    int32_t *Cw = Cmat + (size_t)win * n_units * n_units;
+    if (q1 <= q0) {
+        // no words in this part (an empty window): the counts are zero, and without the extra cut nobody else writes them
+        if (!atomic) {
+            v16i z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0;
+            for (int i = 0; i < nr; ++i)
+                for (int j = 0; j < nc; ++j) store_tile(z, I0 + i, J0 + j, lane, n_units, diag, 0, Cw);
+        }
+        return;
+    }
+    const uint4 *base = reinterpret_cast<const uint4 *>(Vp) + (size_t)vg * NPv;
+#define PG_C_TASK(NR, NC, DG) pairC_task<NR, NC, DG>(base, q0, q1, NPv, I0, J0, lane, n_units, diag, atomic, Cw)
+    if (J0 == I0) {
+        if (TB >= 3 && nr == 3) PG_C_TASK(3, 3, true);
+        else if (nr == 2) PG_C_TASK(2, 2, true);
+        else PG_C_TASK(1, 1, true);
+    } else if (TB >= 3 && nr == 3) {
+        if (nc == 3) PG_C_TASK(3, 3, false);
+        else if (nc == 2) PG_C_TASK(3, 2, false);
+        else PG_C_TASK(3, 1, false);
+    } else if (nr == 2) {
+        if (TB >= 3 && nc == 3) PG_C_TASK(2, 3, false);
+        else if (nc == 2) PG_C_TASK(2, 2, false);
+        else PG_C_TASK(2, 1, false);
+    } else {
+        if (TB >= 3 && nc == 3) PG_C_TASK(1, 3, false);
+        else if (nc == 2) PG_C_TASK(1, 2, false);
+        else PG_C_TASK(1, 1, false);
+    }
+#undef PG_C_TASK
+}
+
+// ---- D ----
+template <int NR, int NC, bool DG>
+struct WordsD {
+    uint2 r[DG ? 1 : NR], c[NC];
+    __device__ __forceinline__ void load(const uint2 *__restrict__ prow, const uint2 *__restrict__ pcol) {
+        if (!DG) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) r[i] = prow[32 * i];
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) c[j] = pcol[32 * j];
+    }
+};
+
+template <int NR, int NC, bool DG>
+__device__ __forceinline__ void pairD_word(const WordsD<NR, NC, DG> &w, int sh, v16i (&acc)[NR][NC]) {
+    v4i ca[NC], cb[NC], ra[NR], rb[NR];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const uint32_t a = w.c[j].x & w.c[j].y, b = w.c[j].y ^ a;          // a = x & v, b = ~x & v
+        ca[j] = expand(a, sh);
+        cb[j] = expand(b, sh);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        if (DG) {
+            ra[i] = ca[i];
+            rb[i] = cb[i];
+        } else {
+            const uint32_t a = w.r[DG ? 0 : i].x & w.r[DG ? 0 : i].y, b = w.r[DG ? 0 : i].y ^ a;
+            ra[i] = expand(a, sh);
+            rb[i] = expand(b, sh);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (!DG || j >= i) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ra[i], cb[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (!DG || j >= i) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(rb[i], ca[j], acc[i][j], 0, 0, 0);
+}
+
+template <int NR, int NC, bool DG>
+__device__ __forceinline__ void pairD_task(const uint2 *__restrict__ xv, int s0, int s1, int NP, int I0, int J0, int lane, int N,
+                                           int atomic, int32_t *__restrict__ Dw) {
+    const int r = lane & 31, sh = 4 * (lane >> 5);
+    v16i acc[NR][NC];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+    const uint2 *prow = xv + (size_t)s0 * NP + 32 * I0 + r;
+    const uint2 *pcol = xv + (size_t)s0 * NP + 32 * J0 + r;
+    WordsD<NR, NC, DG> wa, wb;
+    wa.load(prow, pcol);
+    for (int s = s0; s < s1; s += 2) {
+        size_t step = s + 1 < s1 ? (size_t)NP : 0;
+        prow += step;
+        pcol += step;
+        wb.load(prow, pcol);
+        pairD_word<NR, NC, DG>(wa, sh, acc);
+        if (s + 1 >= s1) break;
+        step = s + 2 < s1 ? (size_t)NP : 0;
+        prow += step;
+        pcol += step;
+        wa.load(prow, pcol);
+        pairD_word<NR, NC, DG>(wb, sh, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (!DG || j >= i) store_tile(acc[i][j], I0 + i, J0 + j, lane, N, 0, atomic, Dw);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVES, PG_MFMA_WAVES))) void k_pairD_mfma(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw,
+                                                   const int64_t *__restrict__ goff, int n_win, int T, int ntask, int kparts, int NP,
+                                                   int N, int32_t *__restrict__ Dmat, int capg) {
+    int win, rem;
+    if (!win_decode(ntask * kparts, n_win, win, rem)) return;
+    const int s = rem % ntask, kp = rem / ntask;
+    int I0, J0, nr, nc;
+    if (!task_decode(T, s, I0, J0, nr, nc)) return;
+    const uint2 *xv = reinterpret_cast<const uint2 *>(XV + (size_t)goff[win] * capg * PG_XV_PLANES * (size_t)NP);
+    // (a window that overflowed its reservation is recomputed by the host; never read past the reservation)
+    const int capw = (int)(goff[win + 1] - goff[win]) * capg;
+    const int n_all = __builtin_amdgcn_readfirstlane(nw[win]);
+    const int n_words = n_all < capw ? n_all : capw;
+    const int a = (int)((long long)n_words * kp / kparts), b = (int)((long long)n_words * (kp + 1) / kparts);
+    int32_t *Dw = Dmat + (size_t)win * N * N;
+    const int lane = threadIdx.x & 63, atomic = kparts > 1;
+    if (b <= a) {
+        // no virtual sites in this part: the counts are zero, and without the extra cut nobody else writes them
+        if (!atomic) {
+            v16i z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0;
+            for (int i = 0; i < nr; ++i)
+                for (int j = 0; j < nc; ++j) store_tile(z, I0 + i, J0 + j, lane, N, 0, 0, Dw);
+        }
+        return;
+    }
+#define PG_D_TASK(NR, NC, DG) pairD_task<NR, NC, DG>(xv, a, b, NP, I0, J0, lane, N, atomic, Dw)
+    if (J0 == I0) {
+        if (TB >= 3 && nr == 3) PG_D_TASK(3, 3, true);
+        else if (nr == 2) PG_D_TASK(2, 2, true);
+        else PG_D_TASK(1, 1, true);
+    } else if (TB >= 3 && nr == 3) {
+        if (nc == 3) PG_D_TASK(3, 3, false);
+        else if (nc == 2) PG_D_TASK(3, 2, false);
+        else PG_D_TASK(3, 1, false);
+    } else if (nr == 2) {
+        if (TB >= 3 && nc == 3) PG_D_TASK(2, 3, false);
+        else if (nc == 2) PG_D_TASK(2, 2, false);
+        else PG_D_TASK(2, 1, false);
+    } else {
+        if (TB >= 3 && nc == 3) PG_D_TASK(1, 3, false);
+        else if (nc == 2) PG_D_TASK(1, 2, false);
+        else PG_D_TASK(1, 1, false);
+    }
+#undef PG_D_TASK
+}
+
+// extra cut of the word range across blocks: wanted when windows x segments cannot give every SIMD a few waves
+int pick_parts(int n_win, int ntask, int64_t steps_per_window, int min_steps) {
+    const int64_t waves = (int64_t)n_win * ntask;
+    int kp = 1;
+    while (kp < 64 && waves * kp < 4096 && steps_per_window / (kp * 2) >= min_steps) kp *= 2;
+    return kp;
+}
+
+}  // namespace
+
+void pg_launch_pairC_mfma(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, int NPv, int n_units, int diag,
+                          int64_t avg_wq, int32_t *Cmat) {
+    if (n_win <= 0 || n_units <= 0) return;
+    const int T = (n_units + 31) / 32, ntask = task_count(T);
+    const int kparts = pick_parts(n_win, ntask, avg_wq, 8);
+    if (kparts > 1) (void)hipMemsetAsync(Cmat, 0, (size_t)n_win * n_units * n_units * 4, st);
+    const int64_t blocks = (int64_t)((n_win + 7) / 8) * ntask * kparts * 8;
+    hipLaunchKernelGGL(k_pairC_mfma, dim3((unsigned)blocks), dim3(64), 0, st, Vp, vgoff, n_win, T, ntask, kparts, NPv, n_units, diag,
+                       Cmat);
+}
+
+void pg_launch_pairD_mfma(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win, int NP, int N,
+                          int64_t avg_words, int32_t *Dmat, int capg) {
+    if (n_win <= 0 || N <= 0) return;
+    const int T = (N + 31) / 32, ntask = task_count(T);
+    const int kparts = pick_parts(n_win, ntask, avg_words, 8);
+    if (kparts > 1) (void)hipMemsetAsync(Dmat, 0, (size_t)n_win * N * N * 4, st);
+    const int64_t blocks = (int64_t)((n_win + 7) / 8) * ntask * kparts * 8;
+    hipLaunchKernelGGL(k_pairD_mfma, dim3((unsigned)blocks), dim3(64), 0, st, XV, nw, goff, n_win, T, ntask, kparts, NP, N, Dmat, capg);
+}

@@ -11,7 +11,7 @@ set -e
 cd "$(dirname "$0")/.."
 CS=genomics_general_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -x hip --offload-arch=gfx950"
-SRCS="pg_kernels.hip pg_pair2.hip pg_tokenize.hip pg_abi.cpp pg_encode.cpp pg_vcf.cpp pg_comm.cpp"
+SRCS="pg_kernels.hip pg_pair2.hip pg_pair_mfma.hip pg_tokenize.hip pg_abi.cpp pg_encode.cpp pg_vcf.cpp pg_comm.cpp"
 case "$1" in
 build)
   shift; mkdir -p ab
