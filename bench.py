@@ -69,6 +69,7 @@ CPU_SLICE_SITES = 4_000         # CPU sample: the first 4000 sites of a window p
                                 # ~10x that with every hardware thread of a 256-thread host busy)
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GUIDE = 1024 * 2.4e9 / 2      # wave64 VALU instructions per second: 256 CUs x 4 SIMD-32, 2 cycles each, 2.4 GHz (guide)
+MFMA_FP4_PEAK_TFLOPS = 10000.0  # MX fp4 MFMA, dense (guide: ~10 PF; measured ceiling 9099 with 32x32x64)
 MFMA_I8_PEAK_TOPS = 5000.0     # int8 MFMA, dense: 2 x the guide's bf16 dense peak (~2.5 PFLOP/s); its measured ceiling is 4404 (32x32x32)
 VALU_PAIRSITES_PEAK = 3.6e14    # 7 lane-ops per 32 pair-sites at 7.9e13 lane-ops/s
 
@@ -420,7 +421,8 @@ def main():
     if os.environ.get("PG_PAIR_V1"):
         rocprof_name = {_lib.K_PACK: "k_pack", _lib.K_PAIRWISE: "k_pairwise"}
     else:
-        sfx = "" if os.environ.get("PG_PAIR_VALU") else "_mfma"          # pair counts: matrix cores by default, popcount kernels as A/B
+        # pair counts: matrix cores by default (MX fp4; int8 with PG_PAIR_I8), popcount kernels as A/B
+        sfx = "" if os.environ.get("PG_PAIR_VALU") else "_mfma" if os.environ.get("PG_PAIR_I8") else "_fp4"
         rocprof_name = {_lib.K_PACK: pack_name, _lib.K_PAIRWISE: "k_pairC" + sfx, _lib.K_PAIRD: "k_pairD" + sfx,
                         _lib.K_SITESTATS: "k_popfreq_q" if wl["tool"] == "popfreq" else "k_abba_q"}
     pmc = {}
@@ -441,11 +443,14 @@ def main():
             # diagonal x sites; k_pairD_mfma: two products per haplotype pair and virtual site, whose number only the device knows)
             units = n_hap // 2 if (lay.n_hap == 2 * lay.n_samp and not os.environ.get("PG_NO_DIP")) else n_hap
             macs = units * (units + 1) / 2 * sites_per_step / launches_per_step if dom_id == _lib.K_PAIRWISE else None
-            roofline = {"kernel": kname, "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_I8_PEAK_TOPS,
-                        "peak_source": "int8 dense = 2 x the bf16 dense peak (MI355X_MICROARCH.md; measured ceiling there: 4404)",
+            fp4 = not os.environ.get("PG_PAIR_I8")
+            peak = MFMA_FP4_PEAK_TFLOPS if fp4 else MFMA_I8_PEAK_TOPS
+            roofline = {"kernel": kname, "bound": "mfma", "unit": "TFLOP/s", "peak": peak,
+                        "peak_source": ("MX fp4 dense (MI355X_MICROARCH.md: ~10 PF; measured ceiling there 9099)" if fp4 else
+                                        "int8 dense = 2 x the bf16 dense peak (MI355X_MICROARCH.md; measured ceiling there: 4404)"),
                         "achieved": round(2 * macs / per_launch_s / 1e12, 2) if macs else None,
-                        "frac": round(2 * macs / per_launch_s / 1e12 / MFMA_I8_PEAK_TOPS, 5) if macs else None,
-                        "algorithmic_int8_macs_per_launch": macs, "traffic": pmc.get(args.workload, {}).get(kname),
+                        "frac": round(2 * macs / per_launch_s / 1e12 / peak, 5) if macs else None,
+                        "algorithmic_macs_per_launch": macs, "traffic": pmc.get(args.workload, {}).get(kname),
                         "avg_launch_ms": round(dom_ms / dom_n, 4), "launches": int(dom_n)}
         elif dom_id in (_lib.K_PAIRWISE, _lib.K_PAIRD) and not os.environ.get("PG_PAIR_V1"):
             # VALU-bound pair kernel: wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU), live launch time
@@ -473,7 +478,9 @@ def main():
             pair_sites = n_hap * (n_hap - 1) / 2 * sites_per_step
             extra["pair_kernels"] = {"ms_per_step": round(pair_ms, 4), "algorithmic_pair_sites_per_s": pair_sites / (pair_ms / 1e3),
                                      "naive_valu_bound": VALU_PAIRSITES_PEAK,
-                                     "engine": "VALU popcount (PG_PAIR_VALU)" if os.environ.get("PG_PAIR_VALU") else "int8 MFMA on the bit planes",
+                                     "engine": ("VALU popcount (PG_PAIR_VALU)" if os.environ.get("PG_PAIR_VALU") else
+                                                "int8 MFMA on the bit planes (PG_PAIR_I8)" if os.environ.get("PG_PAIR_I8") else
+                                                "MX fp4 MFMA on the bit planes (exact: parts below 2^23 sites, integer atomics between parts)"),
                                      "note": "pair-count kernels C + D together vs SURVEY 8d's 7-lane-op-per-32-pair-sites VALU bound; "
                                              "polymorphic-site compaction and per-individual called counts do less work than that, "
                                              "and the matrix cores are not bound by it"}

@@ -749,17 +749,17 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         // ---- stream: pair kernels + consume ----
         if (!single) HIPCHK(hipStreamWaitEvent(c->stream, sl.packed, 0));
         if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
-        // the pair counts run on the matrix cores (exact int8 products of the bit planes, pg_pair_mfma.hip); PG_PAIR_VALU=1 keeps the
-        // popcount kernels (A/B runs, tests)
+        // the pair counts run on the matrix cores (exact products of the bit planes, pg_pair_mfma.hip: MX fp4, or int8 with
+        // PG_PAIR_I8=1); PG_PAIR_VALU=1 keeps the popcount kernels (A/B runs, tests)
         const bool valu_pairs = getenv("PG_PAIR_VALU") != nullptr;
-        if (!valu_pairs) pg_launch_pairC_mfma(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, c->Cmat.p);
+        if (!valu_pairs) pg_launch_pairC_mfma(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p);
         else if (dip) pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasksC.p, c->n_tasksC, NPv, n_units, 1, va / nb, c->Cmat.p);
         else pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasksCh.p, c->n_tasksCh, NPv, n_units, 0, va / nb, c->Cmat.p);
         if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
         // (running k_pairD beside k_pairC on a third stream was measured: +3 % throughput, but overlapping kernels make the
         // per-kernel timings ambiguous; kept sequential)
         if ((rc = pg_time_begin(c, PG_K_PAIRD, &e0, &e1)) != PG_OK) return rc;
-        if (!valu_pairs) pg_launch_pairD_mfma(c->stream, sl.XV.p, d_nw, d_goff, nb, NP, N, ga / nb * grp / 10, c->Dmat.p, capg);
+        if (!valu_pairs) pg_launch_pairD_mfma(c->stream, sl.XV.p, d_nw, d_goff, nb, NP, N, ga / nb * grp / 10, (int64_t)max_groups * capg * 32, c->Dmat.p, capg);
         else pg_launch_pairD(c->stream, sl.XV.p, d_nw, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, ga / nb, c->Dmat.p, capg);
         if ((rc = pg_time_end(c, PG_K_PAIRD, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());

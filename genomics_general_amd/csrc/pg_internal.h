@@ -86,9 +86,9 @@ void pg_launch_pairD(hipStream_t st, const uint32_t *XY, const int32_t *nw, cons
                      const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat, int capg);
 // the same counts on the matrix cores (pg_pair_mfma.hip): exact int8 x int8 -> int32 products of the bit planes, expanded in registers
 void pg_launch_pairC_mfma(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, int NPv, int n_units, int diag,
-                          int64_t avg_wq, int32_t *Cmat);
+                          int64_t avg_wq, int64_t max_sites, int32_t *Cmat);
 void pg_launch_pairD_mfma(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win, int NP, int N,
-                          int64_t avg_words, int32_t *Dmat, int capg);
+                          int64_t avg_words, int64_t max_vsites, int32_t *Dmat, int capg);
 
 void pg_launch_sample_het(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                           const int32_t *samp_start, int n_samp, int min_pair_sites, double *out);

@@ -19,6 +19,9 @@
 // A wave (= a block) owns up to 3 x 3 tiles of 32 x 32 of the upper triangle and keeps their accumulators in registers over its part of the window's words; int32 sums are exact (counts < 2^31 are guarded by the host).
 #include "pg_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -131,8 +134,7 @@ __device__ __forceinline__ void pairC_group(const WordsC<NR, NC, DG> &w, int sh,
     }
 }
 
-// groups q0 .. q1-1 (4 words = 128 sites each) in two register sets: the words of group q+1 are requested before the products
-// of group q are issued (the last look-ahead re-reads the last group: always inside the plane)
+// groups q0 .. q1-1 (4 words = 128 sites each)
 template <int NR, int NC, bool DG>
 __device__ __forceinline__ void pairC_task(const uint4 *__restrict__ base, int q0, int q1, int NPv, int I0, int J0, int lane,
                                            int n_units, int diag, int atomic, int32_t *__restrict__ Cw) {
@@ -146,20 +148,23 @@ __device__ __forceinline__ void pairC_task(const uint4 *__restrict__ base, int q
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
     const uint4 *prow = base + (size_t)q0 * NPv + 32 * I0 + r;
     const uint4 *pcol = base + (size_t)q0 * NPv + 32 * J0 + r;
-    WordsC<NR, NC, DG> wa, wb;
-    wa.load(prow, pcol);
-    for (int q = q0; q < q1; q += 2) {
-        size_t step = q + 1 < q1 ? (size_t)NPv : 0;
-        prow += step;
-        pcol += step;
-        wb.load(prow, pcol);
-        pairC_group<NR, NC, DG>(wa, sh, acc);
-        if (q + 1 >= q1) break;
-        step = q + 2 < q1 ? (size_t)NPv : 0;
-        prow += step;
-        pcol += step;
+    // two groups per trip, both requested at its top: the second group's words arrive under the first group's products (a
+    // look-ahead carried around the loop is waited for with vmcnt(0) at the loop head by hipcc, i.e. not a look-ahead)
+    int q = q0;
+    for (; q + 1 < q1; q += 2) {
+        WordsC<NR, NC, DG> wa, wb;
         wa.load(prow, pcol);
+        wb.load(prow + NPv, pcol + NPv);
+        __builtin_amdgcn_sched_barrier(0);             // both requests stay in front of the first group's products
+        pairC_group<NR, NC, DG>(wa, sh, acc);
         pairC_group<NR, NC, DG>(wb, sh, acc);
+        prow += 2 * (size_t)NPv;
+        pcol += 2 * (size_t)NPv;
+    }
+    if (q < q1) {
+        WordsC<NR, NC, DG> wa;
+        wa.load(prow, pcol);
+        pairC_group<NR, NC, DG>(wa, sh, acc);
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i)
@@ -273,20 +278,21 @@ __device__ __forceinline__ void pairD_task(const uint2 *__restrict__ xv, int s0,
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
     const uint2 *prow = xv + (size_t)s0 * NP + 32 * I0 + r;
     const uint2 *pcol = xv + (size_t)s0 * NP + 32 * J0 + r;
-    WordsD<NR, NC, DG> wa, wb;
-    wa.load(prow, pcol);
-    for (int s = s0; s < s1; s += 2) {
-        size_t step = s + 1 < s1 ? (size_t)NP : 0;
-        prow += step;
-        pcol += step;
-        wb.load(prow, pcol);
-        pairD_word<NR, NC, DG>(wa, sh, acc);
-        if (s + 1 >= s1) break;
-        step = s + 2 < s1 ? (size_t)NP : 0;
-        prow += step;
-        pcol += step;
+    int s = s0;
+    for (; s + 1 < s1; s += 2) {
+        WordsD<NR, NC, DG> wa, wb;
         wa.load(prow, pcol);
+        wb.load(prow + NP, pcol + NP);
+        __builtin_amdgcn_sched_barrier(0);             // both requests stay in front of the first group's products
+        pairD_word<NR, NC, DG>(wa, sh, acc);
         pairD_word<NR, NC, DG>(wb, sh, acc);
+        prow += 2 * (size_t)NP;
+        pcol += 2 * (size_t)NP;
+    }
+    if (s < s1) {
+        WordsD<NR, NC, DG> wa;
+        wa.load(prow, pcol);
+        pairD_word<NR, NC, DG>(wa, sh, acc);
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i)
@@ -343,6 +349,233 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVE
 #undef PG_D_TASK
 }
 
+// ---- the same two kernels on the MX fp4 path (v_mfma_scale_f32_32x32x64_f8f6f4, both operands e2m1, scales 2^0) -----------------
+// A site is one nibble: 0b0001 = 0.5, so a product of two set sites is 0.25 and an accumulator holds count / 4 -- exact in f32
+// while count < 2^24, which the launcher guarantees by cutting the word range (integer atomics combine the parts).  Twice the
+// sites per instruction at about the issue time of the int8 form, and 8 instead of 18 VALU ops per fragment and 64 sites:
+//     fragment dword m of lane (r, kb) = (word_{kb} >> m) & 0x11111111,  m = 0..3     (lane half kb takes the K step's word kb)
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ v8i expand4(uint32_t w) {
+    v8i f;                                   // fp4 operands are the first four registers; the others are not read
+    f[0] = (int)(w & 0x11111111u);
+    f[1] = (int)((w >> 1) & 0x11111111u);
+    f[2] = (int)((w >> 2) & 0x11111111u);
+    f[3] = (int)((w >> 3) & 0x11111111u);
+    return f;
+}
+
+__device__ __forceinline__ v16f mfma4(const v8i &a, const v8i &b, const v16f &c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+__device__ __forceinline__ void store_tile4(const v16f &acc, int I, int J, int lane, int n, int diag, int atomic, int32_t *__restrict__ M) {
+    v16i q;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) q[e] = (int)(acc[e] * 4.0f);
+    store_tile(q, I, J, lane, n, diag, atomic, M);
+}
+
+template <int NR, int NC, bool DG>
+__device__ __forceinline__ void pairC4_group(const WordsC<NR, NC, DG> &w, bool hi, v16f (&acc)[NR][NC]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        v8i fc[NC], fr[NR];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) fc[j] = expand4(hi ? comp(w.c[j], 2 * t + 1) : comp(w.c[j], 2 * t));
+#pragma unroll
+        for (int i = 0; i < NR; ++i) fr[i] = DG ? fc[i] : expand4(hi ? comp(w.r[DG ? 0 : i], 2 * t + 1) : comp(w.r[DG ? 0 : i], 2 * t));
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+                if (!DG || j >= i) acc[i][j] = mfma4(fr[i], fc[j], acc[i][j]);
+    }
+}
+
+template <int NR, int NC, bool DG>
+__device__ __forceinline__ void pairC4_task(const uint4 *__restrict__ base, int q0, int q1, int NPv, int I0, int J0, int lane,
+                                            int n_units, int diag, int atomic, int32_t *__restrict__ Cw) {
+    const int r = lane & 31;
+    const bool hi = lane >= 32;
+    v16f acc[NR][NC];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const uint4 *prow = base + (size_t)q0 * NPv + 32 * I0 + r;
+    const uint4 *pcol = base + (size_t)q0 * NPv + 32 * J0 + r;
+    int q = q0;
+    for (; q + 1 < q1; q += 2) {
+        WordsC<NR, NC, DG> wa, wb;
+        wa.load(prow, pcol);
+        wb.load(prow + NPv, pcol + NPv);
+        __builtin_amdgcn_sched_barrier(0);             // both requests stay in front of the first group's products
+        pairC4_group<NR, NC, DG>(wa, hi, acc);
+        pairC4_group<NR, NC, DG>(wb, hi, acc);
+        prow += 2 * (size_t)NPv;
+        pcol += 2 * (size_t)NPv;
+    }
+    if (q < q1) {
+        WordsC<NR, NC, DG> wa;
+        wa.load(prow, pcol);
+        pairC4_group<NR, NC, DG>(wa, hi, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (!DG || j >= i) store_tile4(acc[i][j], I0 + i, J0 + j, lane, n_units, diag, atomic, Cw);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVES, PG_MFMA_WAVES)))
+void k_pairC_fp4(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vgoff, int n_win, int T, int ntask, int kparts, int NPv,
+                 int n_units, int diag, int32_t *__restrict__ Cmat) {
+    int win, rem;
+    if (!win_decode(ntask * kparts, n_win, win, rem)) return;
+    const int s = rem % ntask, kp = rem / ntask;
+    int I0, J0, nr, nc;
+    if (!task_decode(T, s, I0, J0, nr, nc)) return;
+    const int64_t vg = vgoff[win];
+    const int nwq = (int)(vgoff[win + 1] - vg);
+    const int q0 = (int)((long long)nwq * kp / kparts), q1 = (int)((long long)nwq * (kp + 1) / kparts);
+    const int lane = threadIdx.x & 63, atomic = kparts > 1;
+    int32_t *Cw = Cmat + (size_t)win * n_units * n_units;
+    if (q1 <= q0) {
+        if (!atomic) {
+            v16i z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0;
+            for (int i = 0; i < nr; ++i)
+                for (int j = 0; j < nc; ++j) store_tile(z, I0 + i, J0 + j, lane, n_units, diag, 0, Cw);
+        }
+        return;
+    }
+    const uint4 *base = reinterpret_cast<const uint4 *>(Vp) + (size_t)vg * NPv;
+#define PG_C_TASK(NR, NC, DG) pairC4_task<NR, NC, DG>(base, q0, q1, NPv, I0, J0, lane, n_units, diag, atomic, Cw)
+    if (J0 == I0) {
+        if (nr == 2) PG_C_TASK(2, 2, true);
+        else PG_C_TASK(1, 1, true);
+    } else if (nr == 2) {
+        if (nc == 2) PG_C_TASK(2, 2, false);
+        else PG_C_TASK(2, 1, false);
+    } else {
+        if (nc == 2) PG_C_TASK(1, 2, false);
+        else PG_C_TASK(1, 1, false);
+    }
+#undef PG_C_TASK
+}
+
+// D: a K step is two slots (64 virtual sites); lane half kb reads slot s + kb (zeros past the end of an odd range)
+template <int NR, int NC, bool DG>
+__device__ __forceinline__ void pairD4_step(const WordsD<NR, NC, DG> &w, bool live, v16f (&acc)[NR][NC]) {
+    v8i ca[NC], cb[NC], ra[NR], rb[NR];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const uint32_t v = live ? w.c[j].y : 0u, a = w.c[j].x & v, b = v ^ a;
+        ca[j] = expand4(a);
+        cb[j] = expand4(b);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        if (DG) {
+            ra[i] = ca[i];
+            rb[i] = cb[i];
+        } else {
+            const uint32_t v = live ? w.r[DG ? 0 : i].y : 0u, a = w.r[DG ? 0 : i].x & v, b = v ^ a;
+            ra[i] = expand4(a);
+            rb[i] = expand4(b);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (!DG || j >= i) acc[i][j] = mfma4(ra[i], cb[j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (!DG || j >= i) acc[i][j] = mfma4(rb[i], ca[j], acc[i][j]);
+}
+
+template <int NR, int NC, bool DG>
+__device__ __forceinline__ void pairD4_task(const uint2 *__restrict__ xv, int s0, int s1, int NP, int I0, int J0, int lane, int N,
+                                            int atomic, int32_t *__restrict__ Dw) {
+    const int r = lane & 31, kb = lane >> 5;
+    v16f acc[NR][NC];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    // this lane's slot of step k: s0 + 2 k + kb, clamped into the range (its planes are masked when it is past the end)
+    auto at = [&](int s) { const int t = s + kb < s1 ? s + kb : s1 - 1; return (size_t)t * NP; };
+    const uint2 *prow = xv + 32 * I0 + r, *pcol = xv + 32 * J0 + r;
+    int s = s0;
+    for (; s + 2 < s1; s += 4) {
+        WordsD<NR, NC, DG> wa, wb;
+        wa.load(prow + at(s), pcol + at(s));
+        wb.load(prow + at(s + 2), pcol + at(s + 2));
+        __builtin_amdgcn_sched_barrier(0);             // both requests stay in front of the first group's products
+        pairD4_step<NR, NC, DG>(wa, true, acc);
+        pairD4_step<NR, NC, DG>(wb, s + 2 + kb < s1, acc);
+    }
+    if (s < s1) {
+        WordsD<NR, NC, DG> wa;
+        wa.load(prow + at(s), pcol + at(s));
+        pairD4_step<NR, NC, DG>(wa, s + kb < s1, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (!DG || j >= i) store_tile4(acc[i][j], I0 + i, J0 + j, lane, N, 0, atomic, Dw);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVES, PG_MFMA_WAVES)))
+void k_pairD_fp4(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw, const int64_t *__restrict__ goff, int n_win, int T,
+                 int ntask, int kparts, int NP, int N, int32_t *__restrict__ Dmat, int capg) {
+    int win, rem;
+    if (!win_decode(ntask * kparts, n_win, win, rem)) return;
+    const int s = rem % ntask, kp = rem / ntask;
+    int I0, J0, nr, nc;
+    if (!task_decode(T, s, I0, J0, nr, nc)) return;
+    const uint2 *xv = reinterpret_cast<const uint2 *>(XV + (size_t)goff[win] * capg * PG_XV_PLANES * (size_t)NP);
+    const int capw = (int)(goff[win + 1] - goff[win]) * capg;
+    const int n_all = __builtin_amdgcn_readfirstlane(nw[win]);
+    const int n_words = n_all < capw ? n_all : capw;
+    const int a = (int)((long long)n_words * kp / kparts), b = (int)((long long)n_words * (kp + 1) / kparts);
+    int32_t *Dw = Dmat + (size_t)win * N * N;
+    const int lane = threadIdx.x & 63, atomic = kparts > 1;
+    if (b <= a) {
+        if (!atomic) {
+            v16i z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0;
+            for (int i = 0; i < nr; ++i)
+                for (int j = 0; j < nc; ++j) store_tile(z, I0 + i, J0 + j, lane, N, 0, 0, Dw);
+        }
+        return;
+    }
+#define PG_D_TASK(NR, NC, DG) pairD4_task<NR, NC, DG>(xv, a, b, NP, I0, J0, lane, N, atomic, Dw)
+    if (J0 == I0) {
+        if (nr == 2) PG_D_TASK(2, 2, true);
+        else PG_D_TASK(1, 1, true);
+    } else if (nr == 2) {
+        if (nc == 2) PG_D_TASK(2, 2, false);
+        else PG_D_TASK(2, 1, false);
+    } else {
+        if (nc == 2) PG_D_TASK(1, 2, false);
+        else PG_D_TASK(1, 1, false);
+    }
+#undef PG_D_TASK
+}
+
 // extra cut of the word range across blocks: wanted when windows x segments cannot give every SIMD a few waves
 int pick_parts(int n_win, int ntask, int64_t steps_per_window, int min_steps) {
     const int64_t waves = (int64_t)n_win * ntask;
@@ -351,25 +584,38 @@ int pick_parts(int n_win, int ntask, int64_t steps_per_window, int min_steps) {
     return kp;
 }
 
+// fp4 path: an f32 accumulator holds count / 4 exactly while count < 2^24; no part of any window may see more sites than that
+// (2^23 keeps a margin); the parts are combined by integer atomics
+bool use_fp4() { return TB == 2 && getenv("PG_PAIR_I8") == nullptr; }
+int exact_parts(int64_t max_sites_per_window) { return (int)((max_sites_per_window + (1 << 23) - 1) >> 23); }
+
 }  // namespace
 
 void pg_launch_pairC_mfma(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, int NPv, int n_units, int diag,
-                          int64_t avg_wq, int32_t *Cmat) {
+                          int64_t avg_wq, int64_t max_sites, int32_t *Cmat) {
     if (n_win <= 0 || n_units <= 0) return;
     const int T = (n_units + 31) / 32, ntask = task_count(T);
-    const int kparts = pick_parts(n_win, ntask, avg_wq, 8);
+    const bool fp4 = use_fp4();
+    const int kparts = std::max(pick_parts(n_win, ntask, avg_wq, 8), fp4 ? exact_parts(max_sites) : 1);
     if (kparts > 1) (void)hipMemsetAsync(Cmat, 0, (size_t)n_win * n_units * n_units * 4, st);
     const int64_t blocks = (int64_t)((n_win + 7) / 8) * ntask * kparts * 8;
-    hipLaunchKernelGGL(k_pairC_mfma, dim3((unsigned)blocks), dim3(64), 0, st, Vp, vgoff, n_win, T, ntask, kparts, NPv, n_units, diag,
-                       Cmat);
+    if (fp4)
+        hipLaunchKernelGGL(k_pairC_fp4, dim3((unsigned)blocks), dim3(64), 0, st, Vp, vgoff, n_win, T, ntask, kparts, NPv, n_units, diag, Cmat);
+    else
+        hipLaunchKernelGGL(k_pairC_mfma, dim3((unsigned)blocks), dim3(64), 0, st, Vp, vgoff, n_win, T, ntask, kparts, NPv, n_units, diag,
+                           Cmat);
 }
 
 void pg_launch_pairD_mfma(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win, int NP, int N,
-                          int64_t avg_words, int32_t *Dmat, int capg) {
+                          int64_t avg_words, int64_t max_vsites, int32_t *Dmat, int capg) {
     if (n_win <= 0 || N <= 0) return;
     const int T = (N + 31) / 32, ntask = task_count(T);
-    const int kparts = pick_parts(n_win, ntask, avg_words, 8);
+    const bool fp4 = use_fp4();
+    const int kparts = std::max(pick_parts(n_win, ntask, avg_words, 8), fp4 ? exact_parts(max_vsites) : 1);
     if (kparts > 1) (void)hipMemsetAsync(Dmat, 0, (size_t)n_win * N * N * 4, st);
     const int64_t blocks = (int64_t)((n_win + 7) / 8) * ntask * kparts * 8;
-    hipLaunchKernelGGL(k_pairD_mfma, dim3((unsigned)blocks), dim3(64), 0, st, XV, nw, goff, n_win, T, ntask, kparts, NP, N, Dmat, capg);
+    if (fp4)
+        hipLaunchKernelGGL(k_pairD_fp4, dim3((unsigned)blocks), dim3(64), 0, st, XV, nw, goff, n_win, T, ntask, kparts, NP, N, Dmat, capg);
+    else
+        hipLaunchKernelGGL(k_pairD_mfma, dim3((unsigned)blocks), dim3(64), 0, st, XV, nw, goff, n_win, T, ntask, kparts, NP, N, Dmat, capg);
 }

@@ -121,7 +121,7 @@ def test_integer_matrices_are_additive_over_a_split_window_and_bounded(c2):
     assert C[0].sum() > 0 and D[0].sum() > 0
 
 
-@pytest.mark.parametrize("env", ["PG_PAIR_V1", "PG_NO_DIP", "PG_OVERLAP", "PG_PACK2", "PG_GROUP_WORDS", "PG_PAIR_VALU"])
+@pytest.mark.parametrize("env", ["PG_PAIR_V1", "PG_NO_DIP", "PG_OVERLAP", "PG_PACK2", "PG_GROUP_WORDS", "PG_PAIR_VALU", "PG_PAIR_I8"])
 def test_independent_pipelines_agree_at_full_window_size(c2, env, monkeypatch):
     e, lay, lo, hi = c2
     sel = [0, 61, 199]
@@ -176,4 +176,30 @@ def test_northstar_shape_windows_match_the_oracle():
     again = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
     for k, v in st.items():
         assert v.shape == (2000,) and np.array_equal(v, again[k]) and np.all(np.isfinite(v)), k
+    e.close()
+
+
+@pytest.mark.parametrize("mode", ["default", "PG_NO_DIP"])
+def test_one_window_beyond_the_exact_range_of_an_f32_accumulator(mode, monkeypatch):
+    """2.2e7 sites in ONE window: more jointly called sites than an f32 accumulator of the fp4 matrix-core path can count exactly
+    (it holds count / 4: exact below 2^24 = 1.68e7).  The launcher cuts the word range into parts below 2^23 sites and the parts
+    meet in integer atomics; D and C must still equal the site-by-site counts of the downloaded rows."""
+    if mode != "default":
+        monkeypatch.setenv(mode, "1")
+    n = 22_000_000
+    names, lay = G.make_layout(4, 2)
+    e = Engine(0)
+    e.set_layout(lay)
+    e.reserve(n)
+    e.synth_fill(0, n, 0, synth.SEED_DEFAULT, n, 4, 2, G.slot_gen_hap(names, lay), synth.VAR_THR, 300)     # 1 % missing
+    D, C = e.batch([0], [n]).pairCounts(reference_order=False)
+    rows = e.download(0, n)
+    called = rows != 0
+    N = lay.n_hap
+    assert called[:, 0].sum() > (1 << 24)
+    for i in range(N):
+        for j in range(i + 1, N):
+            both = called[:, i] & called[:, j]
+            assert C[0, i, j] == int(both.sum()) == C[0, j, i], (i, j)
+            assert D[0, i, j] == int((both & (rows[:, i] != rows[:, j])).sum()) == D[0, j, i], (i, j)
     e.close()

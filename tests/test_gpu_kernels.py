@@ -24,7 +24,7 @@ def oracle_aln(lay, codes, lo, hi):
     (150, 4, 1500, [(0, 700), (700, 1500)]),                                     # several 64-column chunks
     (530, 3, 2200, [(0, 2200), (100, 421), (2150, 2200)]),                        # > 1024 haplotype slots: presence pre-pass
 ])
-@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS", "PG_PAIR_VALU"])
+@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS", "PG_PAIR_VALU", "PG_PAIR_I8"])
 def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins, pack, monkeypatch):
     if pack != "default":
         monkeypatch.setenv(pack, "128" if pack == "PG_GROUP_WORDS" else "1")
@@ -46,7 +46,7 @@ def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins, pack, monkeypatch):
     (150, 1500, 0.1, "uniform"),       # two waves per block: list / flush code behind block barriers
     (300, 800, 0.2, "mixed"),          # four waves per block
 ])
-@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS", "PG_PAIR_VALU"])
+@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS", "PG_PAIR_VALU", "PG_PAIR_I8"])
 def test_pairwise_counts_with_three_and_four_alleles_per_site(n_dip, L, p_miss, mix, pack, monkeypatch):
     """sites with k alleles become k-1 virtual biallelic sites in k_pack2 / k_pack3 (both kernels at every block size: one, two
     and four waves); D must still be the plain Hamming count.  The uniform cases overflow the default XV reservation: the
@@ -241,7 +241,7 @@ def test_errors_are_loud_not_fatal():
     e.close()
 
 
-@pytest.mark.parametrize("mode", ["default", "PG_NO_DIP", "PG_PAIR_V1", "PG_PAIR_VALU"])
+@pytest.mark.parametrize("mode", ["default", "PG_NO_DIP", "PG_PAIR_V1", "PG_PAIR_VALU", "PG_PAIR_I8"])
 def test_every_pairwise_code_path_gives_the_same_integers(mode, monkeypatch):
     """diploid fast path (called counts per individual), per-haplotype v2 path, and the v1 kernel"""
     if mode != "default":
