@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVE
 // A site is one nibble: 0b0001 = 0.5, so a product of two set sites is 0.25 and an accumulator holds count / 4 -- exact in f32
 // while count < 2^24, which the launcher guarantees by cutting the word range (integer atomics combine the parts).  Twice the
 // sites per instruction at about the issue time of the int8 form, and 8 instead of 18 VALU ops per fragment and 64 sites:
-//     fragment dword m of lane (r, kb) = (word_{kb} >> m) & 0x11111111,  m = 0..3     (lane half kb takes the K step's word kb)
+//     fragment dword m of lane (r, kb) = (word >> m) & 0x11111111,  m = 0..3     (each lane half expands its own words)
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -370,22 +370,27 @@ __device__ __forceinline__ v16f mfma4(const v8i &a, const v8i &b, const v16f &c)
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
+template <int UNIT4>     // UNIT4 = 1: the accumulator holds count / 4 (0.5 x 0.5 products, scales 2^0); 0: the count itself
 __device__ __forceinline__ void store_tile4(const v16f &acc, int I, int J, int lane, int n, int diag, int atomic, int32_t *__restrict__ M) {
     v16i q;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) q[e] = (int)(acc[e] * 4.0f);
+    for (int e = 0; e < 16; ++e) q[e] = UNIT4 ? (int)(acc[e] * 4.0f) : (int)acc[e];
     store_tile(q, I, J, lane, n, diag, atomic, M);
 }
 
+// C: the two lane halves work on DIFFERENT word groups -- lanes 0..31 on group g, lanes 32..63 on group g+1 -- so that a 16-byte
+// load per lane fetches 1 KiB of distinct words (both halves reading the same group left half of the L1 / TA cycles to
+// duplicates) and K step t is simply word t of the lane's own group: any fixed assignment of sites to (step, half) is a valid
+// dot product as long as both operands use it.  `live` = this lane's group exists (an odd range ends on a half pair).
 template <int NR, int NC, bool DG>
-__device__ __forceinline__ void pairC4_group(const WordsC<NR, NC, DG> &w, bool hi, v16f (&acc)[NR][NC]) {
+__device__ __forceinline__ void pairC4_pair(const WordsC<NR, NC, DG> &w, bool live, v16f (&acc)[NR][NC]) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 4; ++t) {
         v8i fc[NC], fr[NR];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) fc[j] = expand4(hi ? comp(w.c[j], 2 * t + 1) : comp(w.c[j], 2 * t));
+        for (int j = 0; j < NC; ++j) fc[j] = expand4(live ? comp(w.c[j], t) : 0u);
 #pragma unroll
-        for (int i = 0; i < NR; ++i) fr[i] = DG ? fc[i] : expand4(hi ? comp(w.r[DG ? 0 : i], 2 * t + 1) : comp(w.r[DG ? 0 : i], 2 * t));
+        for (int i = 0; i < NR; ++i) fr[i] = DG ? fc[i] : expand4(live ? comp(w.r[DG ? 0 : i], t) : 0u);
 #pragma unroll
         for (int i = 0; i < NR; ++i)
 #pragma unroll
@@ -397,8 +402,7 @@ __device__ __forceinline__ void pairC4_group(const WordsC<NR, NC, DG> &w, bool h
 template <int NR, int NC, bool DG>
 __device__ __forceinline__ void pairC4_task(const uint4 *__restrict__ base, int q0, int q1, int NPv, int I0, int J0, int lane,
                                             int n_units, int diag, int atomic, int32_t *__restrict__ Cw) {
-    const int r = lane & 31;
-    const bool hi = lane >= 32;
+    const int r = lane & 31, kb = lane >> 5;
     v16f acc[NR][NC];
 #pragma unroll
     for (int i = 0; i < NR; ++i)
@@ -406,29 +410,33 @@ __device__ __forceinline__ void pairC4_task(const uint4 *__restrict__ base, int 
         for (int j = 0; j < NC; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    const uint4 *prow = base + (size_t)q0 * NPv + 32 * I0 + r;
-    const uint4 *pcol = base + (size_t)q0 * NPv + 32 * J0 + r;
+    // the lane half kb works on group q + kb of the pair that starts at group q
+    const uint4 *prow = base + ((size_t)q0 + kb) * NPv + 32 * I0 + r, *pcol = base + ((size_t)q0 + kb) * NPv + 32 * J0 + r;
     int q = q0;
-    for (; q + 1 < q1; q += 2) {
+    for (; q + 4 <= q1; q += 4) {                          // two pairs per trip, both requested in front of the first pair's products
         WordsC<NR, NC, DG> wa, wb;
         wa.load(prow, pcol);
-        wb.load(prow + NPv, pcol + NPv);
-        __builtin_amdgcn_sched_barrier(0);             // both requests stay in front of the first group's products
-        pairC4_group<NR, NC, DG>(wa, hi, acc);
-        pairC4_group<NR, NC, DG>(wb, hi, acc);
+        wb.load(prow + 2 * (size_t)NPv, pcol + 2 * (size_t)NPv);
+        __builtin_amdgcn_sched_barrier(0);
+        pairC4_pair<NR, NC, DG>(wa, true, acc);
+        pairC4_pair<NR, NC, DG>(wb, true, acc);
+        prow += 4 * (size_t)NPv;
+        pcol += 4 * (size_t)NPv;
+    }
+    for (; q < q1; q += 2) {                               // the last one to three groups: a lane whose group is past the end reads
+        const bool live = q + kb < q1;                     // the pair's first group instead and contributes zeros
+        const size_t back = live ? 0 : (size_t)NPv;
+        WordsC<NR, NC, DG> wa;
+        wa.load(prow - back, pcol - back);
+        pairC4_pair<NR, NC, DG>(wa, live, acc);
         prow += 2 * (size_t)NPv;
         pcol += 2 * (size_t)NPv;
-    }
-    if (q < q1) {
-        WordsC<NR, NC, DG> wa;
-        wa.load(prow, pcol);
-        pairC4_group<NR, NC, DG>(wa, hi, acc);
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int j = 0; j < NC; ++j)
-            if (!DG || j >= i) store_tile4(acc[i][j], I0 + i, J0 + j, lane, n_units, diag, atomic, Cw);
+            if (!DG || j >= i) store_tile4<1>(acc[i][j], I0 + i, J0 + j, lane, n_units, diag, atomic, Cw);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVES, PG_MFMA_WAVES)))
@@ -513,28 +521,33 @@ __device__ __forceinline__ void pairD4_task(const uint2 *__restrict__ xv, int s0
         for (int j = 0; j < NC; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    // this lane's slot of step k: s0 + 2 k + kb, clamped into the range (its planes are masked when it is past the end)
-    auto at = [&](int s) { const int t = s + kb < s1 ? s + kb : s1 - 1; return (size_t)t * NP; };
-    const uint2 *prow = xv + 32 * I0 + r, *pcol = xv + 32 * J0 + r;
+    // the lane half kb works on slot s + kb of the step that starts at slot s
+    const uint2 *prow = xv + ((size_t)s0 + kb) * NP + 32 * I0 + r, *pcol = xv + ((size_t)s0 + kb) * NP + 32 * J0 + r;
     int s = s0;
-    for (; s + 2 < s1; s += 4) {
+    for (; s + 4 <= s1; s += 4) {                          // two steps per trip, both requested in front of the first step's products
         WordsD<NR, NC, DG> wa, wb;
-        wa.load(prow + at(s), pcol + at(s));
-        wb.load(prow + at(s + 2), pcol + at(s + 2));
-        __builtin_amdgcn_sched_barrier(0);             // both requests stay in front of the first group's products
+        wa.load(prow, pcol);
+        wb.load(prow + 2 * (size_t)NP, pcol + 2 * (size_t)NP);
+        __builtin_amdgcn_sched_barrier(0);
         pairD4_step<NR, NC, DG>(wa, true, acc);
-        pairD4_step<NR, NC, DG>(wb, s + 2 + kb < s1, acc);
+        pairD4_step<NR, NC, DG>(wb, true, acc);
+        prow += 4 * (size_t)NP;
+        pcol += 4 * (size_t)NP;
     }
-    if (s < s1) {
+    for (; s < s1; s += 2) {                               // the last one to three slots: a lane whose slot is past the end reads the
+        const bool live = s + kb < s1;                     // step's first slot instead and contributes zeros
+        const size_t back = live ? 0 : (size_t)NP;
         WordsD<NR, NC, DG> wa;
-        wa.load(prow + at(s), pcol + at(s));
-        pairD4_step<NR, NC, DG>(wa, s + kb < s1, acc);
+        wa.load(prow - back, pcol - back);
+        pairD4_step<NR, NC, DG>(wa, live, acc);
+        prow += 2 * (size_t)NP;
+        pcol += 2 * (size_t)NP;
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int j = 0; j < NC; ++j)
-            if (!DG || j >= i) store_tile4(acc[i][j], I0 + i, J0 + j, lane, N, 0, atomic, Dw);
+            if (!DG || j >= i) store_tile4<1>(acc[i][j], I0 + i, J0 + j, lane, N, 0, atomic, Dw);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVES, PG_MFMA_WAVES)))
