@@ -609,7 +609,13 @@ void pg_launch_pairC_mfma(hipStream_t st, const uint32_t *Vp, const int64_t *vgo
     if (n_win <= 0 || n_units <= 0) return;
     const int T = (n_units + 31) / 32, ntask = task_count(T);
     const bool fp4 = use_fp4();
-    const int kparts = std::max(pick_parts(n_win, ntask, avg_wq, 8), fp4 ? exact_parts(max_sites) : 1);
+    int kparts = std::max(pick_parts(n_win, ntask, avg_wq, 8), fp4 ? exact_parts(max_sites) : 1);
+    // L2 locality: the tasks of a window start together and read the same words, but they drift apart (diagonal and edge tasks
+    // issue fewer products per step) and an XCD runs some 50 windows at once against 4 MB of L2 -- PMC: 9.1 GB fetched per
+    // north-star launch for a 2.5 GB plane.  Parts of at most 1 MiB of plane end before the drift matters (measured on the
+    // north-star shape: 1.27-1.32 ms in one part, 1.16-1.18 in two or four, 1.30 in eight, 2.3 in sixteen, zeroing included)
+    const int64_t plane_bytes = avg_wq * (int64_t)NPv * 16;
+    kparts = std::max(kparts, (int)std::min<int64_t>(4, (plane_bytes + (1 << 20) - 1) >> 20));
     if (kparts > 1) (void)hipMemsetAsync(Cmat, 0, (size_t)n_win * n_units * n_units * 4, st);
     const int64_t blocks = (int64_t)((n_win + 7) / 8) * ntask * kparts * 8;
     if (fp4)

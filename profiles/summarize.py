@@ -32,13 +32,13 @@ def main():
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, "%s_%s.csv" % (wl, f)))
     out = {}
-    for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mfma"):
         p = os.path.join(src, name, "%s_counter_collection.csv" % wl)
         if not os.path.exists(p):
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(p)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             if k.startswith("__amd"):

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+for kp in 1 2 4 8 16; do
+  PG_MFMA_KPARTS_C=$kp timeout 300 python bench.py --workload northstar --steps 5 --warmup 2 --no-cpu-baseline --no-tiers 2>/dev/null | python -c "
+import sys, json
+for ln in sys.stdin:
+    if ln.startswith('{'):
+        d = json.loads(ln); print('kparts_C=$kp', d['ms_per_step'], d.get('kernel_ms_per_step'))"
+done
