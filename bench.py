@@ -489,6 +489,10 @@ def main():
         extra["per_rank_ms_per_step"] = {"min": round(1e3 * float(per_rank[:, 0].min()) / args.steps, 4),
                                          "max": round(1e3 * float(per_rank[:, 0].max()) / args.steps, 4)}
         extra["comm_ranks"] = int(eng._comm_ranks())
+    if getattr(eng, "placement", None):
+        extra["placement_trials"] = {"probe_ms": eng.placement[0], "kept": eng.placement[1],
+                                     "note": "reserve() tried these physical placements of the resident rows (empty) and kept the "
+                                             "one the pack + pair path streams fastest from; PG_PLACE_TRIALS=1 takes the first"}
     extra["kernel_ms_per_step"] = {rocprof_name.get(kid, k): round(kt[k][0] / n_warm, 4)
                                    for kid, k in _lib.KERNEL_NAMES.items() if kt[k][1] > 0}
     extra["kernel_ms_per_step_source"] = ("last warm-up step (all families bracketed by events); roofline.avg_launch_ms is from the timed region"

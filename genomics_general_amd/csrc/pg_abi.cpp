@@ -841,6 +841,87 @@ static int pairwise_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_w
     }
 }
 
+// ---- placement of the resident rows ---------------------------------------------------------------------------------------------
+// The pack kernel streams the resident rows once per pass and its time moves by +-6 % with the PHYSICAL pages behind them: the same
+// virtual address, released and allocated again, gives 7.7 ... 8.7 ms on the north-star shape, stable for the life of the
+// allocation (tools/pack_variance.py, tools/placement_probe.py; a read-only stream over the same rows moves by 2 %).  The kernel's
+// time on the freshly zeroed buffer predicts its time with the data in place (probe 7.4-7.5 -> 7.8-7.9 ms, probe 8.0-8.4 -> 8.3-8.6),
+// so a large reservation is tried a few times -- the candidates are held together, so they are different pages -- and the one on
+// which the probe pass (the regular pack + pair path over 50 000-site windows of the empty rows) is fastest is kept.
+extern "C" int pg_reserve_sites_tuned(pg_ctx *c, int64_t n_sites, int max_trials, double *probe_ms_out, int *n_trials_out,
+                                      int *chosen_out) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (n_trials_out) *n_trials_out = 0;
+    if (chosen_out) *chosen_out = -1;
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    if (n_sites < 0) return pg_fail(PG_ERR_ARG, "n_sites < 0");
+    HIPCHK(hipSetDevice(c->device));
+    if (n_sites <= c->cap_sites) return PG_OK;
+    const size_t bytes = (size_t)(n_sites + 32) * c->S;
+    if (max_trials > 8) max_trials = 8;
+    int trials = 1;
+    if (use_v2(c) && c->n_hap <= 4096 && bytes >= ((size_t)4 << 30) && max_trials > 1) {
+        HIPCHK(hipStreamSynchronize(c->stream_up));
+        c->up_pending = false;
+        c->gt.release();                                   // (as in pg_reserve_sites: growing drops the rows)
+        c->cap_sites = 0;
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t keep = (size_t)c->scratch_limit + ((size_t)8 << 30);      // room for the probe's (and the job's) scratch
+        const size_t fit = free_b > keep ? (free_b - keep) / bytes : 0;
+        trials = (int)std::min<size_t>((size_t)max_trials, fit);
+    }
+    if (trials < 2) return pg_reserve_sites(c, n_sites);
+    const int64_t wind = 50000;
+    const int n_win = (int)std::max<int64_t>(1, n_sites / wind);
+    std::vector<int64_t> lo((size_t)n_win), hi((size_t)n_win);
+    for (int w = 0; w < n_win; ++w) { lo[(size_t)w] = w * wind; hi[(size_t)w] = std::min<int64_t>(n_sites, (w + 1) * wind); }
+    std::vector<DevBuf<int8_t>> cand((size_t)trials);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = PG_OK, best = -1, tried = 0;
+    double best_ms = 0.0;
+    auto cleanup = [&](int keep_idx) {
+        for (int t = 0; t < trials; ++t)
+            if (t != keep_idx) cand[(size_t)t].release();
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(-1); return pg_fail(PG_ERR_HIP, "hipEventCreate"); }
+    const uint32_t saved_mask = c->time_mask;
+    c->time_mask = 0;                                      // the probe's launches are not the caller's statistics
+    for (int t = 0; t < trials && rc == PG_OK; ++t) {
+        if (cand[(size_t)t].alloc(bytes) != PG_OK) break;  // out of memory: make do with the candidates so far
+        ++tried;
+        if (hipMemsetAsync(cand[(size_t)t].p, 0, bytes, c->stream) != hipSuccess) { rc = pg_fail(PG_ERR_HIP, "hipMemsetAsync"); break; }
+        c->gt = cand[(size_t)t];                           // (plain pointers: ownership stays with cand[] until the choice is made)
+        c->cap_sites = n_sites;
+        float ms = 0.0f;
+        for (int pass = 0; pass < 2 && rc == PG_OK; ++pass) {                 // the first pass also allocates the scratch
+            if (hipEventRecord(e0, c->stream) != hipSuccess) { rc = pg_fail(PG_ERR_HIP, "hipEventRecord"); break; }
+            rc = pairwise_run(c, lo.data(), hi.data(), n_win, [](int, int) -> int { return PG_OK; });
+            if (rc != PG_OK) break;
+            if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = pg_fail(PG_ERR_HIP, "probe timing"); break; }
+        }
+        if (rc != PG_OK) break;
+        if (probe_ms_out) probe_ms_out[t] = ms;
+        if (best < 0 || ms < best_ms) { best = t; best_ms = ms; }
+    }
+    c->time_mask = saved_mask;
+    c->gt = DevBuf<int8_t>();
+    c->cap_sites = 0;
+    if (rc != PG_OK || best < 0) {
+        cleanup(-1);
+        return rc != PG_OK ? rc : pg_reserve_sites(c, n_sites);
+    }
+    cleanup(best);
+    c->gt = cand[(size_t)best];
+    c->cap_sites = n_sites;
+    if (n_trials_out) *n_trials_out = tried;
+    if (chosen_out) *chosen_out = best;
+    return PG_OK;
+}
+
 extern "C" int pg_pairwise(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int32_t *D_out, int32_t *C_out) {
     int rc = check_windows(c, lo, hi, n_win);
     if (rc != PG_OK) return rc;

@@ -111,6 +111,7 @@ class Engine:
         self.device = device
         self.layout = None
         self.n_sites = 0
+        self.placement = None
         self.pinned = PinnedPool()
 
     def close(self):
@@ -131,7 +132,19 @@ class Engine:
         self.n_sites = 0
 
     def reserve(self, n_sites):
-        check(self._L.pg_reserve_sites(self._h, int(n_sites)))
+        """room for n_sites resident rows (growing drops the rows).  Reservations of 4 GiB and more try up to PG_PLACE_TRIALS
+        (default 4, 1 = off) physical placements and keep the one the pack kernel streams fastest from (pg_reserve_sites_tuned);
+        self.placement = (probe ms per candidate, index kept) of the last such reservation."""
+        import os
+        trials = int(os.environ.get("PG_PLACE_TRIALS", "4"))
+        if trials > 1:
+            ms = (C.c_double * 8)()
+            n, k = C.c_int(0), C.c_int(-1)
+            check(self._L.pg_reserve_sites_tuned(self._h, int(n_sites), trials, ms, C.byref(n), C.byref(k)))
+            if n.value:
+                self.placement = ([round(ms[i], 4) for i in range(n.value)], int(k.value))
+        else:
+            check(self._L.pg_reserve_sites(self._h, int(n_sites)))
         self.n_sites = max(self.n_sites, int(n_sites))
 
     def upload(self, gt, offset=0):

@@ -68,6 +68,12 @@ int pg_set_samples(pg_ctx *ctx, int n_hap, const int32_t *hap_pop, const int32_t
 
 /* ---- resident site buffer ------------------------------------------------------------------------ */
 int pg_reserve_sites(pg_ctx *ctx, int64_t n_sites);
+/* pg_reserve_sites for a large reservation (>= 4 GiB) with a choice of physical placement: up to max_trials (<= 8) allocations are
+ * held together, the regular pack + pair path is timed on each while it is still empty, the fastest is kept (the pack kernel's
+ * time moves by +-6 % with the pages behind the rows; the probe predicts it).  probe_ms_out[max_trials] (may be NULL) receives the
+ * probe times, *n_trials_out the number of candidates, *chosen_out the index kept.  Smaller reservations, or when memory does not
+ * hold two candidates beside the scratch budget: exactly pg_reserve_sites. */
+int pg_reserve_sites_tuned(pg_ctx *ctx, int64_t n_sites, int max_trials, double *probe_ms_out, int *n_trials_out, int *chosen_out);
 /* Copy gt[n_sites][n_hap] (tightly packed rows) to sites [site_offset, site_offset+n_sites). */
 int pg_upload_sites(pg_ctx *ctx, int64_t site_offset, const int8_t *gt, int64_t n_sites);
 int pg_download_sites(pg_ctx *ctx, int64_t site_offset, int8_t *gt_out, int64_t n_sites);
