@@ -169,6 +169,9 @@ def test_c4_distmat_window_matches_the_oracle():
 def test_northstar_shape_windows_match_the_oracle():
     n_sites = 100_000_000
     e, lay = resident(n_sites, 200, 4, 4)
+    # 40 GB of rows: Engine.reserve went through pg_reserve_sites_tuned (several placements probed while empty, one kept)
+    assert e.placement is not None and len(e.placement[0]) >= 2 and 0 <= e.placement[1] < len(e.placement[0]), e.placement
+    assert min(e.placement[0]) == e.placement[0][e.placement[1]] > 0
     lo = np.arange(0, n_sites, WIND, dtype=np.int64)
     hi = lo + WIND
     st = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
@@ -202,4 +205,30 @@ def test_one_window_beyond_the_exact_range_of_an_f32_accumulator(mode, monkeypat
             both = called[:, i] & called[:, j]
             assert C[0, i, j] == int(both.sum()) == C[0, j, i], (i, j)
             assert D[0, i, j] == int((both & (rows[:, i] != rows[:, j])).sum()) == D[0, j, i], (i, j)
+    e.close()
+
+
+def test_reservation_without_placement_trials_and_regrowth(monkeypatch):
+    """PG_PLACE_TRIALS=1 is the plain reservation; a tuned reservation that grows drops the rows like the plain one and the new
+    rows are usable (5 GiB -> 6 GiB of rows at 16 haplotypes)"""
+    names, lay = G.make_layout(8, 2)
+    monkeypatch.setenv("PG_PLACE_TRIALS", "1")
+    e = Engine(0)
+    e.set_layout(lay)
+    e.reserve(300_000_000)
+    assert e.placement is None
+    e.close()
+    monkeypatch.delenv("PG_PLACE_TRIALS")
+    e = Engine(0)
+    e.set_layout(lay)
+    e.reserve(340_000_000)
+    first = e.placement
+    assert first is not None and len(first[0]) >= 2
+    e.reserve(400_000_000)
+    assert e.placement is not None and e.placement is not first
+    n = 400_000_000
+    e.synth_fill(n - 200_000, 200_000, 0, synth.SEED_DEFAULT, 200_000, 8, 2, G.slot_gen_hap(names, lay), synth.VAR_THR, synth.MISS_THR)
+    D, C = e.batch([n - 200_000], [n]).pairCounts(reference_order=True)
+    Do, Co = orc.pair_counts_gemm(oracle_window(e, lay, n - 200_000, n))
+    assert np.array_equal(D[0], Do) and np.array_equal(C[0], Co)
     e.close()
