@@ -18,8 +18,9 @@ c5 the rank's share of configs[4] (3*10^9 sites / N, needs N >= 8).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the kernel family with the most GPU time), timed with HIP
 events on the stream it runs on: an HBM-bound family (k_pack3, k_abba_q, k_popfreq_q) is priced in algorithmic bytes against
-8 TB/s, a VALU-bound one (k_pairC, k_pairD) in VALU wave-instructions against the guide's issue ceiling and against the
-measured ceiling of its instruction mix (profiles/: tools/valu_rate.hip).  `cpu_baseline` is the CPU oracle's restatement of
+8 TB/s; the pair-count kernels run on the matrix cores (k_pairC_fp4 / k_pairD_fp4: algorithmic multiply-accumulates against the
+dense MX fp4 peak; with PG_PAIR_I8 against the int8 peak; the popcount kernels of PG_PAIR_VALU in VALU wave-instructions against
+the guide's issue ceiling and the measured ceiling of their instruction mix, profiles/: tools/valu_rate.hip).  `cpu_baseline` is the CPU oracle's restatement of
 the reference's FULL path (.geno text -> parse -> windows -> alignment -> pair-by-pair loop -> statistics) run on all host
 cores, one window per worker process (N=1, rank 0 only).  No torch anywhere: barriers and the gather go through RCCL in
 libpopgen_hip.so.

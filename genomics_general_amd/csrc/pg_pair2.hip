@@ -2,6 +2,9 @@
 //
 //   C[i][j] = sum over ALL sites of v_i & v_j                       -> k_pairC on the "called" plane only (2 VALU / 32 pair-sites)
 //   D[i][j] = sum over POLYMORPHIC sites of differ(i,j) & v_i & v_j -> k_pairD on the polymorphic-site planes (3 VALU / 32 pair-sites)
+// (The planes are written by the pack kernels of this file; by default they are consumed by the matrix-core kernels of
+// pg_pair_mfma.hip -- the same two sums as exact products -- and the popcount kernels k_pairC / k_pairD below run with
+// PG_PAIR_VALU=1.)
 //
 // A site whose called haplotypes all carry the same allele adds the same amount to C and to "same allele", i.e. nothing to D
 // (genomics.py:903-905, 1219-1221: numHamming counts differences among jointly called sites).  k_pack2 therefore detects
