@@ -1014,10 +1014,21 @@ def freq_main(argv=None):
     keepNan = args.keepNanLines if args.target else True
     minData = args.minData if args.target else 0
 
-    eng = Engine(args.device if args.device is not None else 0)
+    # Multi-GPU: sites are independent, so every rank takes the lines between two line boundaries near the equal split of a
+    # plain-text input (the slice-parallel reading of freq.py:23-28), formats its own rows, and ONE gather brings them to
+    # rank 0 in rank order = input order.  Inputs that cannot be cut (gzip, stdin, .pgeno): rank 0 does the job.
+    world = dist.world_from_env()
+    eng = Engine(args.device if args.device is not None else dist.device_for(world))
     eng.set_layout(layout)
-    out = _open_out(args.outFile)
-    out.write("scaffold\tposition\t" + "\t".join(popNames) + "\n")
+    comm = dist.RcclComm(eng, world) if world.size > 1 else dist.SoloComm()
+    sharded = world.size > 1 and hasattr(reader, "shard_lines") and reader.shard_lines(world)
+    if world.size > 1 and not sharded and world.rank > 0:
+        dist.gather_bytes(comm, b"")
+        reader.close()
+        return 0
+    out = _open_out(args.outFile) if world.rank == 0 else None
+    if out is not None:
+        out.write("scaffold\tposition\t" + "\t".join(popNames) + "\n")
     P = len(popNames)
     CH = 1 << 20
     block_bytes = int(os.environ.get("PG_STREAM_BYTES", 1 << 30))
@@ -1068,8 +1079,10 @@ def freq_main(argv=None):
     import ctypes as C
     from ._lib import check, lib
     L = lib()
-    out.flush()
-    sink = out.buffer                                       # rows are written as bytes behind the header
+    kept = []                                               # ranks > 0: their rows, until the gather
+    if out is not None:
+        out.flush()
+        sink = out.buffer                                   # rows are written as bytes behind the header
     text_buf = np.empty(0, dtype=np.uint8)
     cur_data = None
     for data, run_of_row, a, b in site_blocks():
@@ -1127,10 +1140,20 @@ def freq_main(argv=None):
                                     np.ascontiguousarray(run_of_row[a:b], dtype=np.int32) - run0, names_blob, name_off,
                                     C.c_void_p(keep.ctypes.data) if keep is not None else None,
                                     C.c_void_p(text_buf.ctypes.data), cap, C.byref(got), 0))
-        sink.write(memoryview(text_buf)[:got.value])
+        if out is not None:
+            sink.write(memoryview(text_buf)[:got.value])
+        else:
+            kept.append(bytes(memoryview(text_buf)[:got.value]))
     reader.close()
-    sink.flush()
-    if out is not sys.stdout:
-        out.close()
-    sys.stderr.write("\nDone\n")
+    if world.size > 1:
+        parts = dist.gather_bytes(comm, b"".join(kept))
+        if out is not None:
+            for part in parts[1:]:
+                sink.write(part)
+    if out is not None:
+        sink.flush()
+        if out is not sys.stdout:
+            out.close()
+    if world.rank == 0:
+        sys.stderr.write("\nDone\n")
     return 0

@@ -319,6 +319,33 @@ class BlockReader:
         self.restrict(cuts[world.rank], cuts[world.rank + 1])
         return True
 
+    def shard_lines(self, world):
+        """Restrict this reader to rank `world.rank`'s share of the data lines, cut at ANY line boundary (sites are independent:
+        freq.py, whose reference reads slices of sites in parallel, freq.py:23-28).  Every rank finds its own start and its
+        successor's the same way (the first line that starts at or behind the equal split), so no exchange is needed.  False,
+        and the reader untouched, when the input is not plain text on disk."""
+        if isinstance(self.f, BgzfFile) or not self.seekable_text():
+            return False
+        size = os.path.getsize(self.path)
+        start = self.tell()
+        stride = max((size - start) // world.size, 1)
+
+        def cut(r):
+            if r <= 0:
+                return start
+            if r >= world.size:
+                return size
+            guess = min(start + stride * r, size)
+            with open(self.path, "rb") as f:
+                f.seek(max(guess - 1, start))
+                if guess > start:
+                    f.readline()                               # to the end of the line that holds byte guess - 1
+                return min(f.tell(), size)
+
+        a, b = cut(world.rank), cut(world.rank + 1)
+        self.restrict(a, max(a, b))
+        return True
+
     def _shard_bgzf(self, world, comm, wanted, max_share):
         """BGZF (bgzip) input: the cuts are (member file offset, offset inside the member) pairs; a rank starts by seeking to its
         member and dropping the bytes in front of its first line, and stops inside the member its successor starts in"""

@@ -124,7 +124,8 @@ from cpu_engine import CpuEngine
 cli.Engine = CpuEngine                                        # numbers from the oracle: this test is about sharding and gathering
 dist.RcclComm = lambda engine, world: dist.GlooComm(world)
 tool, argv = sys.argv[1], sys.argv[2:]
-rc = {"popgenWindows.py": cli.popgen_main, "ABBABABAwindows.py": cli.abbababa_main, "distMat.py": cli.distmat_main}[tool](argv)
+rc = {"popgenWindows.py": cli.popgen_main, "ABBABABAwindows.py": cli.abbababa_main, "distMat.py": cli.distmat_main,
+      "freq.py": cli.freq_main}[tool](argv)
 sys.exit(rc or 0)
 ''' % (ROOT, ROOT, ROOT)
 
@@ -217,3 +218,54 @@ def test_two_ranks_shard_the_input_at_scaffold_runs_and_gather_rows_once(tmp_pat
         if packed == "bgzf":                           # (text_bytes counts inflated bytes there) both ranks worked on sites
             assert all(t["sites"] > 0 for t in timing), timing
         assert sum(t["sites"] for t in timing) == sum(1 for ln in gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"))) - 1
+
+
+def test_freq_with_two_ranks_cuts_the_input_at_line_boundaries(tmp_path):
+    """freq.py with WORLD_SIZE=2: plain text is cut at the line boundary nearest to the middle (sites are independent), each rank
+    writes its rows, one gather, rank 0 writes the reference's file; gzipped input cannot be cut: rank 0 does the whole job"""
+    import gzip
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from cases import CASES
+    gold = os.path.join(ROOT, "tests", "golden")
+    for k, (name, plain) in enumerate((("abba_freq_derived", True), ("abba_freq_indfreqs", True), ("abba_freq_counts", True),
+                                       ("abba_freq_derived", False))):
+        case = [c for c in CASES if c["name"] == name]
+        if not case:
+            continue
+        case = case[0]
+        geno = os.path.join(gold, case["fixture"] + ".geno.gz")
+        if plain:
+            geno = str(tmp_path / (case["fixture"] + ".geno"))
+            with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f, open(geno, "wb") as g:
+                g.write(f.read())
+        out = str(tmp_path / (name + ".out"))
+        argv = [a.format(geno=geno, dir=gold, out=out) for a in case["argv"]] + ["-o", out]
+        _run_two_ranks(case["tool"], argv, 35000 + (os.getpid() + 13 * k) % 2000)
+        with open(out) as f, open(os.path.join(gold, name + ".out")) as g:
+            assert f.read() == g.read(), name
+
+
+def test_line_shards_cover_the_input_once():
+    """BlockReader.shard_lines: the ranks' byte ranges are disjoint, start at line starts and cover every data line, for any
+    number of ranks (more ranks than lines included)"""
+    import tempfile
+    from genomics_general_amd import genoio
+    lines = [("chr1\t%d\t" % (i + 1) + "\t".join("A/C" if (i + j) % 3 else "N/N" for j in range(1 + i % 5))).encode() for i in range(57)]
+    text = b"#CHROM\tPOS\ts1\n" + b"\n".join(lines) + b"\n"
+    with tempfile.NamedTemporaryFile(suffix=".geno", delete=False) as f:
+        f.write(text)
+        path = f.name
+    try:
+        for size in (1, 2, 3, 8, 64, 100):
+            got = []
+            for rank in range(size):
+                r = genoio.open_input(path)
+                r.read_header()
+                assert r.shard_lines(dist.World(rank, size, rank))
+                body = bytes(r.read_block(None))
+                assert body == b"" or body.endswith(b"\n")
+                got.append(body)
+                r.close()
+            assert b"".join(got) == b"\n".join(lines) + b"\n", size
+    finally:
+        os.remove(path)
