@@ -303,6 +303,9 @@ extern "C" int pg_reserve_sites(pg_ctx *c, int64_t n_sites) {
     int rc = c->gt.alloc((size_t)(n_sites + 32) * c->S);     // +32 rows so a word tile never reads past the end
     if (rc != PG_OK) return rc;
     HIPCHK(hipMemsetAsync(c->gt.p, 0, (size_t)(n_sites + 32) * c->S, c->stream));
+    // the rows are filled through other streams too (asynchronous uploads, the device tokenizer on the copy stream): nothing may
+    // be queued there while the clearing is still on its way -- it would wipe rows that were already written
+    HIPCHK(hipStreamSynchronize(c->stream));
     c->cap_sites = n_sites;
     return PG_OK;
 }
