@@ -1,0 +1,79 @@
+"""-m gpu: a mid-size random input (three scaffolds x 30 000 sites x 32 diploids, 10 % variable sites, 3 % missing calls; 13 MB of
+`.geno` text) through the drop-in command lines, against the ORACLE's command lines on the same file: the goldens pin the
+reference's behaviour on small fixtures, this pins the whole chain -- device tokenizer (several blocks, carried rows), host
+tokenizer pipeline, packed input, windows across scaffolds, kernels, finalisers, formatting -- at a size where blocks, groups
+and tiles are no longer single."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_cli
+from golden_util import align_columns
+from genomics_general_amd import genoio, synth
+
+import test_gpu_golden as G
+
+pytestmark = pytest.mark.gpu
+N_DIP, N_POPS, PER_SCAF, N_SCAF = 32, 4, 30000, 3
+NAMES = ["s%d" % d for d in range(N_DIP)]
+
+
+@pytest.fixture(scope="module")
+def geno(tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("e2e") / "random.geno")
+    with open(path, "wb") as f:
+        for k in range(N_SCAF):
+            sid = np.full(PER_SCAF, k, dtype=np.int64)
+            codes = synth.gen_codes(4242, sid, np.arange(1, PER_SCAF + 1), N_DIP, N_POPS, var_thr=6500, miss_thr=2000)
+            part = path + ".part"
+            synth.write_geno_fast(part, codes, NAMES, "scaf%d" % (k + 1), 1)
+            with open(part, "rb") as g:
+                if k:
+                    g.readline()
+                f.write(g.read())
+            os.remove(part)
+    return path
+
+
+def popgen_argv(path):
+    per = N_DIP // N_POPS
+    argv = ["-g", path, "-f", "phased", "-w", "4000", "-s", "3000", "-m", "40", "--roundTo", "6", "--analysis", "popDist", "popPairDist",
+            "indHet", "popFreq"]
+    for k in range(N_POPS):
+        argv += ["-p", "p%d" % k, ",".join(NAMES[k * per:(k + 1) * per])]
+    return argv
+
+
+def abba_argv(path):
+    return ["-g", path, "-f", "phased", "--windType", "sites", "-w", "2500", "--overlap", "500", "-m", "100", "--minData", "0.5",
+            "-P1", "a", ",".join(NAMES[0:8]), "-P2", "b", ",".join(NAMES[8:16]), "-P3", "c", ",".join(NAMES[16:24]),
+            "-O", "o", ",".join(NAMES[24:32])]
+
+
+@pytest.fixture(scope="module")
+def want(geno):
+    return {"popgenWindows.py": oracle_cli.run("popgenWindows.py", popgen_argv(geno)),
+            "ABBABABAwindows.py": oracle_cli.run("ABBABABAwindows.py", abba_argv(geno))}
+
+
+@pytest.mark.parametrize("tool", ["popgenWindows.py", "ABBABABAwindows.py"])
+@pytest.mark.parametrize("mode", ["device_tokenizer", "device_tokenizer_one_block", "host_tokenizer", "pgeno"])
+def test_drivers_match_the_oracle_on_a_random_mid_size_input(tool, mode, geno, want, tmp_path, monkeypatch):
+    path = geno
+    if mode == "pgeno":
+        path = str(tmp_path / "random.pgeno")
+        genoio.pack_geno(geno, path, "phased", block_bytes=1 << 20)
+    if mode != "device_tokenizer_one_block":
+        monkeypatch.setenv("PG_STREAM_BYTES", str(3 << 20))                     # several blocks, rows carried across them
+    if mode == "host_tokenizer":
+        monkeypatch.setenv("PG_GPU_TOKENIZER", "0")
+    argv = (popgen_argv if tool == "popgenWindows.py" else abba_argv)(path)
+    out = str(tmp_path / "out.csv")
+    G.MAINS[tool](argv + ["-o", out])
+    with open(out) as f:
+        got = f.read()
+    w = want[tool]
+    assert len(w.splitlines()) > 20
+    n_inexact = G.compare_text(align_columns(got, w), w, 6 if tool == "popgenWindows.py" else 4)
+    assert n_inexact <= max(2, len(w.split()) // 50), "%d cells differ in the last digit" % n_inexact
