@@ -247,7 +247,8 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
     c->n_pops = n_pops;
     c->n_samp = (int)sstart.size() - 1;
     c->S = (n_hap + 15) / 16 * 16;
-    c->NP = (n_hap + 63) / 64 * 64;
+    // plane stride: 32 haplotypes (one tile of the matrix-core pair kernels); the popcount kernels work on 64-lane column chunks
+    c->NP = (getenv("PG_PAIR_VALU") || getenv("PG_PAIR_V1")) ? (n_hap + 63) / 64 * 64 : (n_hap + 31) / 32 * 32;
     c->h_pop_start = pstart;
     c->h_samp_start = sstart;
     // pair-kernel task table: column chunk of 64 x row sub-tiles of 8 strictly above the chunk's last column
@@ -639,7 +640,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     if (!use_v2(c)) return pairwise_batches_v1(c, lo, hi, n_win, consume);
     const int N = c->n_hap, NP = c->NP;
     const int n_units = dip ? N / 2 : N;
-    const int NPv = dip ? (n_units + 63) / 64 * 64 : NP;
+    const int NPv = dip ? (NP % 64 ? (n_units + 31) / 32 * 32 : (n_units + 63) / 64 * 64) : NP;
     c->cN = n_units;
     c->cshift = dip ? 1 : 0;
     const int64_t mat_bytes = 4ll * N * N + 4ll * n_units * n_units;
@@ -726,10 +727,9 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         const int64_t *d_lo = sl.win.p, *d_hi = sl.win.p + nb, *d_goff = sl.win.p + 2 * (size_t)nb,
                       *d_vgoff = sl.win.p + 3 * (size_t)nb + 1;
         int32_t *d_nw = reinterpret_cast<int32_t *>(sl.win.p + 4 * (size_t)nb + 2);
-        // + 2 word groups: k_pairC's look-ahead loads read one group past a wave's range
-        if ((rc = sl.Vp.ensure((size_t)(std::max<int64_t>(va, 1) + 2) * NPv * 4)) != PG_OK) return rc;
-        // + 2 words: k_pairD's look-ahead loads read two words past a wave's range
-        if ((rc = sl.XV.ensure(((size_t)std::max<int64_t>(ga, 1) * capg + 2) * PG_XV_PLANES * NP)) != PG_OK) return rc;
+        // + 4 word groups / words: the last stage (look-ahead load) of the pair kernels reads up to three past a part's range
+        if ((rc = sl.Vp.ensure((size_t)(std::max<int64_t>(va, 1) + 4) * NPv * 4)) != PG_OK) return rc;
+        if ((rc = sl.XV.ensure(((size_t)std::max<int64_t>(ga, 1) * capg + 4) * PG_XV_PLANES * NP)) != PG_OK) return rc;
         if ((rc = c->Cmat.ensure((size_t)nb * n_units * n_units)) != PG_OK) return rc;
         if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
         hipEvent_t e0, e1;
@@ -755,14 +755,20 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         // the pair counts run on the matrix cores (exact products of the bit planes, pg_pair_mfma.hip: MX fp4, or int8 with
         // PG_PAIR_I8=1); PG_PAIR_VALU=1 keeps the popcount kernels (A/B runs, tests)
         const bool valu_pairs = getenv("PG_PAIR_VALU") != nullptr;
-        if (!valu_pairs) pg_launch_pairC_mfma(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p);
+        if (!valu_pairs && pg_pair_tile_fits(NPv, 0)) {
+            if (pg_launch_pairC_tile(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p))
+                return pg_fail(PG_ERR_HIP, "pair-kernel program upload failed");
+        } else if (!valu_pairs) pg_launch_pairC_mfma(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p);
         else if (dip) pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasksC.p, c->n_tasksC, NPv, n_units, 1, va / nb, c->Cmat.p);
         else pg_launch_pairC(c->stream, sl.Vp.p, d_vgoff, nb, c->tasksCh.p, c->n_tasksCh, NPv, n_units, 0, va / nb, c->Cmat.p);
         if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
         // (running k_pairD beside k_pairC on a third stream was measured: +3 % throughput, but overlapping kernels make the
         // per-kernel timings ambiguous; kept sequential)
         if ((rc = pg_time_begin(c, PG_K_PAIRD, &e0, &e1)) != PG_OK) return rc;
-        if (!valu_pairs) pg_launch_pairD_mfma(c->stream, sl.XV.p, d_nw, d_goff, nb, NP, N, ga / nb * grp / 10, (int64_t)max_groups * capg * 32, c->Dmat.p, capg);
+        if (!valu_pairs && pg_pair_tile_fits(NP, 1)) {
+            if (pg_launch_pairD_tile(c->stream, sl.XV.p, d_nw, d_goff, nb, NP, N, ga / nb * grp / 10, (int64_t)max_groups * capg * 32, c->Dmat.p, capg))
+                return pg_fail(PG_ERR_HIP, "pair-kernel program upload failed");
+        } else if (!valu_pairs) pg_launch_pairD_mfma(c->stream, sl.XV.p, d_nw, d_goff, nb, NP, N, ga / nb * grp / 10, (int64_t)max_groups * capg * 32, c->Dmat.p, capg);
         else pg_launch_pairD(c->stream, sl.XV.p, d_nw, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, ga / nb, c->Dmat.p, capg);
         if ((rc = pg_time_end(c, PG_K_PAIRD, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());

@@ -1,0 +1,454 @@
+// Pairwise counts on the matrix cores, every plane word fetched ONCE per window part: k_pairC_tile / k_pairD_tile.
+//
+// Same arithmetic as k_pairC_fp4 / k_pairD_fp4 (pg_pair_mfma.hip): the counts are Gram matrices of 0/1 vectors
+// (genomics.py:903-916, 1219-1221, 1042-1047), C = V V^T over the called plane, D = A B^T + B A^T over the
+// virtual-site planes (a = x & v, b = ~x & v), multiplied as exact MX fp4 products (a set site is the e2m1 nibble 0b0001 = 0.5, an
+// accumulator holds count / 4, exact in f32 below 2^24; the launcher cuts the word range into parts below 2^23 sites).
+//
+// What is different is who reads the planes.  The one-wave blocks of pg_pair_mfma.hip each read the row and column words of their
+// 2 x 2 tiles; the ten tasks of a 200-unit window walk the words at different speeds (1 .. 4 products per step), so an XCD's L2
+// (4 MB against ~50 windows in flight) serves little of the re-reading: 7.7 GB fetched per north-star launch for a 2.8 GB
+// plane, the kernel at the fabric's limit with the matrix cores 45 % busy (profiles/r02/northstar_pmc_summary.json).  Here a
+// BLOCK owns a window part: its waves stream the part's words into LDS with `global_load_lds_dwordx4` (the planes are already in
+// the order the fragments want, so a stage is one linear copy: no registers, no ds_write), three stages deep, and every wave
+// reads the fragments of its tiles from LDS.
+//
+//   tile      32 x 32 units, K = 64 sites per v_mfma_scale_f32_32x32x64_f8f6f4; lane (r = lane & 31, kb = lane >> 5) holds unit
+//             32 t + r and the step's word kb: C: one ds_read_b128 = the four words of group 2 p + kb = four K steps;
+//             D: one ds_read_b64 = (x, v) of word 2 s + kb.  Fragment dword m = (word >> m) & 0x11111111 (7 VALU per fragment).
+//   strip     two tile rows (64 units) r0, r0+1 and the columns j >= r0; a SLOT is one column of a strip = two products per step
+//             (the first slot of a strip, j == r0, has only the diagonal tile: `one` = 1).  The row fragments of a strip stay
+//             in registers while its slots stream through: 7 VALU ops per two 32-cycle matrix instructions (the one-wave kernels:
+//             per one).
+//   program   the host deals the slots of the upper triangle, in strip order, to the W waves of `nblk` blocks in equal runs of at
+//             most CS slots (accumulators: 32 registers per slot); a table in device memory tells every wave its run.
+//   pipeline  iteration i: wait for the own copies of stage i (counted vmcnt: the copies of stage i+1 stay in flight), barrier,
+//             queue the copies of stage i+2 into the ring slot that stage i-1 has just left, compute stage i from LDS.
+//
+// The lane halves of a step hold different words, both operands in the same (permuted) site order: all a dot product needs.
+#include "pg_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int NSTG = 3;                // ring depth (stages)
+
+// One LDS-DMA copy: 64 lanes x 16 bytes from each lane's `gsrc` to the wave-uniform LDS byte address `lds_dst` + 16 * lane.  Issued
+// from inline assembly on purpose: hipcc orders every ds_read behind ALL outstanding LDS-DMA it knows of (s_waitcnt vmcnt(0) in
+// front of the first fragment read), which would serialise the ring; these copies are invisible to its bookkeeping and are
+// ordered by the counted waits + barriers of the stage loop instead.  (M0 = destination base, written in the same statement.)
+__device__ __forceinline__ void glds16(const uint4 *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+// at most n vector-memory operations of this wave still in flight (n is small and block-uniform)
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+#define PG_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        PG_VM(0) PG_VM(1) PG_VM(2) PG_VM(3) PG_VM(4) PG_VM(5) PG_VM(6) PG_VM(7) PG_VM(8) PG_VM(9) PG_VM(10) PG_VM(11) PG_VM(12)
+        PG_VM(13) PG_VM(14) PG_VM(15) PG_VM(16)
+#undef PG_VM
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// XCD-aware block -> (window, rest): block b runs on XCD b % 8; all blocks of a window go to one XCD (the last n_win % 8 windows
+// are dealt over all XCDs in contiguous runs).  Same dealing as pg_pair_mfma.hip.
+__device__ __forceinline__ bool win_decode(int per_win, int n_win, int &win, int &rem) {
+    const int xcd = blockIdx.x & 7;
+    const int v = blockIdx.x >> 3;
+    const int full = n_win >> 3;
+    if (v < full * per_win) {
+        win = (v / per_win) * 8 + xcd;
+        rem = v % per_win;
+        return true;
+    }
+    const int total = (n_win & 7) * per_win, q = (total + 7) >> 3;
+    const int vt = v - full * per_win, lin = xcd * q + vt;
+    if (vt >= q || lin >= total) return false;
+    win = full * 8 + lin / per_win;
+    rem = lin % per_win;
+    return true;
+}
+
+// fragment of one word: dword m = the word's bits m, m+4, ... as e2m1 nibbles; M = 0x11111111, or 0 for a lane whose word lies
+// beyond the part (the lane then contributes zeros)
+__device__ __forceinline__ v8i expand4(uint32_t w, uint32_t M) {
+    v8i f;                                   // fp4 operands are the first four registers; the others are not read
+    f[0] = (int)(w & M);
+    f[1] = (int)((w >> 1) & M);
+    f[2] = (int)((w >> 2) & M);
+    f[3] = (int)((w >> 3) & M);
+    return f;
+}
+
+__device__ __forceinline__ v16f mfma4(const v8i &a, const v8i &b, const v16f &c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+__device__ __forceinline__ uint32_t comp(const uint4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+
+// accumulator tile (count / 4) -> upper triangle of the window's matrix.  C/D layout of the 32 x 32 product: column = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ void store_tile(const v16f &acc, int I, int J, int lane, int n, int diag, int atomic, int32_t *__restrict__ M) {
+    const int col = 32 * J + (lane & 31);
+    if (col >= n) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = 32 * I + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (row >= n || row > col || (row == col && !diag)) continue;
+        const int32_t v = (int32_t)(acc[reg] * 4.0f);
+        int32_t *dst = &M[(size_t)row * n + col];
+        if (atomic) { if (v) atomicAdd(dst, v); }
+        else *dst = v;
+    }
+}
+
+struct Slot { int r0, j, one; };
+__device__ __forceinline__ Slot slot_of(int32_t e) { return Slot{e & 0xff, (e >> 8) & 0xff, (e >> 16) & 1}; }
+
+// Copies of one stage: `bytes` of plane words starting at gsrc -> lds_stage, 1 KiB per wave instruction, dealt round-robin to
+// the W waves; every wave issues exactly nl instructions (the surplus ones repeat the last chunk), so that one counted vmcnt
+// fits all of them.
+template <int W>
+__device__ __forceinline__ void stage_copy(const uint4 *__restrict__ gsrc, uint4 *lds_stage, int chunks, int nl, int wave, int lane) {
+    for (int c = 0; c < nl; ++c) {
+        int ch = wave + c * W;
+        ch = ch < chunks ? ch : chunks - 1;
+        glds16(gsrc + (size_t)ch * 64 + lane, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr(lds_stage) + (uint32_t)ch * 1024u)));
+    }
+}
+
+// ---- C: called counts of unit pairs ------------------------------------------------------------------------------------------
+// Vp[(vgoff[win] + q) * NPv + unit] = the four words of group q (128 sites) of one unit.  A stage = GP pairs of groups; the lane
+// half kb works on group 2 p + kb of pair p; K step t = word t of the lane's own group.
+template <int CS, int W, int GP>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pairC_tile(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vgoff, int n_win,
+                                                       int T, int nblk, int kparts, int NPv, int n_units, int diag,
+                                                       const int32_t *__restrict__ prog, int nl, int32_t *__restrict__ Cmat) {
+    extern __shared__ uint4 lds[];
+    int win, rem;
+    if (!win_decode(nblk * kparts, n_win, win, rem)) return;
+    const int bp = rem % nblk, kp = rem / nblk;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const int32_t *my = prog + (size_t)(bp * W + wave) * (CS + 1);
+    const int ns = my[0];
+    const int64_t vg = vgoff[win];
+    const int nwq = (int)(vgoff[win + 1] - vg);
+    const int q0 = (int)((long long)nwq * kp / kparts), q1 = (int)((long long)nwq * (kp + 1) / kparts);
+    const int atomic = kparts > 1;
+    int32_t *Cw = Cmat + (size_t)win * n_units * n_units;
+    v16f acc[CS][2];
+#pragma unroll
+    for (int s = 0; s < CS; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[s][i][e] = 0.0f;
+    const int stage_groups = 2 * GP;
+    const int stage_u4 = stage_groups * NPv;                  // uint4 elements per stage
+    const int chunks = stage_u4 / 64;                         // NPv is a multiple of 32
+    const int nstage = (q1 - q0 + stage_groups - 1) / stage_groups;
+    const uint4 *base = reinterpret_cast<const uint4 *>(Vp) + ((size_t)vg + q0) * NPv;
+    if (nstage > 0) {
+        // (copies past the last stage repeat it into a ring slot nobody reads: the counted waits stay uniform; a stage may reach
+        // up to stage_groups - 1 groups past q1: those words exist (next part / window / padding) and their lanes are masked)
+        for (int st = 0; st < NSTG - 1; ++st) {
+            const int src = st < nstage ? st : nstage - 1;
+            stage_copy<W>(base + (size_t)src * stage_u4, lds + (size_t)st * stage_u4, chunks, nl, wave, lane);
+        }
+        for (int st = 0; st < nstage; ++st) {
+            wait_vm(nl * (NSTG - 2));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            {
+                const int nx = st + NSTG - 1, src = nx < nstage ? nx : nstage - 1;
+                stage_copy<W>(base + (size_t)src * stage_u4, lds + (size_t)(nx % NSTG) * stage_u4, chunks, nl, wave, lane);
+            }
+            const uint4 *sb = lds + (size_t)(st % NSTG) * stage_u4;
+#pragma unroll 1
+            for (int p = 0; p < GP; ++p) {
+                const bool live = q0 + st * stage_groups + 2 * p + kb < q1;
+                const uint32_t M = live ? 0x11111111u : 0u;
+                const uint4 *pb = sb + (size_t)(2 * p + kb) * NPv + r;
+                int cur = -1;
+                v8i fr[2][4];
+                uint4 craw = pb[32 * slot_of(my[1]).j];
+#pragma unroll
+                for (int s = 0; s < CS; ++s) {
+                    if (s < ns) {
+                        const Slot sl = slot_of(my[1 + s]);
+                        if (sl.r0 != cur) {
+                            cur = sl.r0;
+                            const int t1 = sl.r0 + 1 < T ? sl.r0 + 1 : sl.r0;
+                            const uint4 a = pb[32 * sl.r0], b = pb[32 * t1];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                fr[0][t] = expand4(comp(a, t), M);
+                                fr[1][t] = expand4(comp(b, t), M);
+                            }
+                        }
+                        const uint4 cw = craw;
+                        if (s + 1 < CS) craw = pb[32 * slot_of(my[1 + (s + 1 < ns ? s + 1 : s)]).j];    // the next slot's words
+                        if (sl.one) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc[s][0] = mfma4(fr[0][t], expand4(comp(cw, t), M), acc[s][0]);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const v8i fc = expand4(comp(cw, t), M);
+                                acc[s][0] = mfma4(fr[0][t], fc, acc[s][0]);
+                                acc[s][1] = mfma4(fr[1][t], fc, acc[s][1]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        wait_vm(0);                                           // the surplus copies of the last iterations land before the block ends
+    }
+    const bool zero_fill = nstage <= 0 && !atomic;            // an empty window: the counts are zero and nobody else writes them
+    if (nstage > 0 || zero_fill) {
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            if (s < ns) {
+                const Slot sl = slot_of(my[1 + s]);
+                store_tile(acc[s][0], sl.r0, sl.j, lane, n_units, diag, atomic, Cw);
+                if (!sl.one) store_tile(acc[s][1], sl.r0 + 1, sl.j, lane, n_units, diag, atomic, Cw);
+            }
+        }
+    }
+}
+
+// ---- D: differences of haplotype pairs ------------------------------------------------------------------------------------------
+// XV word k of a window: [slot][x, v] (8 bytes per haplotype).  A stage = KD steps of two words; the lane half kb works on word
+// 2 s + kb of step s.
+template <int CS, int W, int KD>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pairD_tile(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw,
+                                                       const int64_t *__restrict__ goff, int n_win, int T, int nblk, int kparts, int NP,
+                                                       int N, const int32_t *__restrict__ prog, int nl, int32_t *__restrict__ Dmat,
+                                                       int capg) {
+    extern __shared__ uint4 lds[];
+    int win, rem;
+    if (!win_decode(nblk * kparts, n_win, win, rem)) return;
+    const int bp = rem % nblk, kp = rem / nblk;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, kb = lane >> 5;
+    const int32_t *my = prog + (size_t)(bp * W + wave) * (CS + 1);
+    const int ns = my[0];
+    // (a window that overflowed its reservation is recomputed by the host; never read past the reservation)
+    const int capw = (int)(goff[win + 1] - goff[win]) * capg;
+    const int n_all = __builtin_amdgcn_readfirstlane(nw[win]);
+    const int n_words = n_all < capw ? n_all : capw;
+    const int w0 = (int)((long long)n_words * kp / kparts), w1 = (int)((long long)n_words * (kp + 1) / kparts);
+    const int atomic = kparts > 1;
+    int32_t *Dw = Dmat + (size_t)win * N * N;
+    v16f acc[CS][2];
+#pragma unroll
+    for (int s = 0; s < CS; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[s][i][e] = 0.0f;
+    const int stage_words = 2 * KD;
+    const int stage_u4 = stage_words * NP / 2;                // 8 bytes per haplotype and word
+    const int chunks = stage_u4 / 64;                         // NP is a multiple of 32
+    const int nstage = (w1 - w0 + stage_words - 1) / stage_words;
+    const uint4 *base = reinterpret_cast<const uint4 *>(XV + ((size_t)goff[win] * capg + w0) * PG_XV_PLANES * (size_t)NP);
+    if (nstage > 0) {
+        for (int st = 0; st < NSTG - 1; ++st) {
+            const int src = st < nstage ? st : nstage - 1;
+            stage_copy<W>(base + (size_t)src * stage_u4, lds + (size_t)st * stage_u4, chunks, nl, wave, lane);
+        }
+        for (int st = 0; st < nstage; ++st) {
+            wait_vm(nl * (NSTG - 2));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            {
+                const int nx = st + NSTG - 1, src = nx < nstage ? nx : nstage - 1;
+                stage_copy<W>(base + (size_t)src * stage_u4, lds + (size_t)(nx % NSTG) * stage_u4, chunks, nl, wave, lane);
+            }
+            const uint2 *sb = reinterpret_cast<const uint2 *>(lds + (size_t)(st % NSTG) * stage_u4);
+#pragma unroll 1
+            for (int p = 0; p < KD; ++p) {
+                const bool live = w0 + st * stage_words + 2 * p + kb < w1;
+                const uint32_t M = live ? 0x11111111u : 0u;
+                const uint2 *pb = sb + (size_t)(2 * p + kb) * NP + r;
+                int cur = -1;
+                v8i ra[2], rb[2];
+                uint2 craw = pb[32 * slot_of(my[1]).j];
+#pragma unroll
+                for (int s = 0; s < CS; ++s) {
+                    if (s < ns) {
+                        const Slot sl = slot_of(my[1 + s]);
+                        if (sl.r0 != cur) {
+                            cur = sl.r0;
+                            const int t1 = sl.r0 + 1 < T ? sl.r0 + 1 : sl.r0;
+                            const uint2 u0 = pb[32 * sl.r0], u1 = pb[32 * t1];
+                            const uint32_t a0 = u0.x & u0.y, a1 = u1.x & u1.y;            // a = x & v, b = ~x & v
+                            ra[0] = expand4(a0, M);
+                            rb[0] = expand4(u0.y ^ a0, M);
+                            ra[1] = expand4(a1, M);
+                            rb[1] = expand4(u1.y ^ a1, M);
+                        }
+                        const uint2 cw = craw;
+                        if (s + 1 < CS) craw = pb[32 * slot_of(my[1 + (s + 1 < ns ? s + 1 : s)]).j];
+                        const uint32_t a = cw.x & cw.y;
+                        const v8i ca = expand4(a, M), cb = expand4(cw.y ^ a, M);
+                        acc[s][0] = mfma4(ra[0], cb, acc[s][0]);
+                        if (!sl.one) acc[s][1] = mfma4(ra[1], cb, acc[s][1]);
+                        acc[s][0] = mfma4(rb[0], ca, acc[s][0]);
+                        if (!sl.one) acc[s][1] = mfma4(rb[1], ca, acc[s][1]);
+                    }
+                }
+            }
+        }
+        wait_vm(0);
+    }
+    const bool zero_fill = nstage <= 0 && !atomic;
+    if (nstage > 0 || zero_fill) {
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            if (s < ns) {
+                const Slot sl = slot_of(my[1 + s]);
+                store_tile(acc[s][0], sl.r0, sl.j, lane, N, 0, atomic, Dw);
+                if (!sl.one) store_tile(acc[s][1], sl.r0 + 1, sl.j, lane, N, 0, atomic, Dw);
+            }
+        }
+    }
+}
+
+// ---- host: slot programs ---------------------------------------------------------------------------------------------------
+// Slots of the upper triangle of T x T tiles in strip order (strip = tile rows r0, r0+1; slot = column j >= r0; the slot j == r0
+// holds the diagonal tile only, as does every slot of a last strip of one row), dealt in equal runs to nblk * W waves of at most
+// CS slots each.  Entry = r0 | j << 8 | one << 16; a wave's record = [count, CS entries].
+struct Program {
+    std::vector<int32_t> tab;
+    int nblk = 0;
+};
+
+Program make_program(int T, int CS, int W) {
+    std::vector<int32_t> slots;
+    for (int r0 = 0; r0 < T; r0 += 2)
+        for (int j = r0; j < T; ++j) slots.push_back(r0 | (j << 8) | ((j == r0 || r0 + 1 >= T) ? 1 << 16 : 0));
+    const int n = (int)slots.size();
+    Program p;
+    p.nblk = (n + CS * W - 1) / (CS * W);
+    const int waves = p.nblk * W;
+    p.tab.assign((size_t)waves * (CS + 1), 0);
+    for (int w = 0; w < waves; ++w) {
+        const int a = (int)((long long)n * w / waves), b = (int)((long long)n * (w + 1) / waves);
+        int32_t *rec = &p.tab[(size_t)w * (CS + 1)];
+        rec[0] = b - a;
+        for (int s = 0; s < CS; ++s) rec[1 + s] = slots[(size_t)std::min(a + s, n - 1)];
+    }
+    return p;
+}
+
+// device copy of the program of (T, CS, W); a handful of shapes per process, kept for its lifetime
+struct ProgCache {
+    int T = -1, CS = 0, W = 0, nblk = 0, device = -1;
+    int32_t *d = nullptr;
+};
+ProgCache g_prog[8];
+
+int get_program(int T, int CS, int W, const int32_t **d_out, int *nblk_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    ProgCache *slot = nullptr;
+    for (ProgCache &c : g_prog) {
+        if (c.d && c.T == T && c.CS == CS && c.W == W && c.device == dev) {
+            *d_out = c.d;
+            *nblk_out = c.nblk;
+            return 0;
+        }
+        if (!c.d && !slot) slot = &c;
+    }
+    if (!slot) {                                             // recycle the first entry (shapes rarely change within a process)
+        slot = &g_prog[0];
+        (void)hipFree(slot->d);
+        slot->d = nullptr;
+    }
+    const Program p = make_program(T, CS, W);
+    if (hipMalloc(reinterpret_cast<void **>(&slot->d), p.tab.size() * 4) != hipSuccess) return -1;
+    if (hipMemcpy(slot->d, p.tab.data(), p.tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    slot->T = T;
+    slot->CS = CS;
+    slot->W = W;
+    slot->nblk = p.nblk;
+    slot->device = dev;
+    *d_out = slot->d;
+    *nblk_out = p.nblk;
+    return 0;
+}
+
+// extra cut of the word range across blocks: wanted when windows x blocks cannot give every SIMD a few waves
+int pick_parts(int n_win, int waves_per_win, int64_t steps_per_window, int min_steps) {
+    const int64_t waves = (int64_t)n_win * waves_per_win;
+    int kp = 1;
+    while (kp < 64 && waves * kp < 4096 && steps_per_window / (kp * 2) >= min_steps) kp *= 2;
+    return kp;
+}
+// an f32 accumulator holds count / 4 exactly while count < 2^24; no part of any window may see more sites than 2^23
+int exact_parts(int64_t max_sites_per_window) { return (int)((max_sites_per_window + (1 << 23) - 1) >> 23); }
+
+constexpr int CS_C = 4, W_C = 4, GP_C = 2;      // C: 4 waves x 4 slots, stage = 2 pairs of groups (512 sites)
+constexpr int CS_D = 4, W_D = 4, KD_D = 2;      // D: 4 waves x 4 slots, stage = 2 steps (128 virtual sites)
+
+}  // namespace
+
+// the LDS-staged kernels take planes of up to this many units per word (a stage must fit the ring)
+bool pg_pair_tile_fits(int NPv_or_NP, int is_d) {
+    if (getenv("PG_PAIR_ONEWAVE")) return false;
+    const int64_t stage = is_d ? (int64_t)2 * KD_D * NPv_or_NP * 8 : (int64_t)2 * GP_C * NPv_or_NP * 16;
+    return NPv_or_NP % 32 == 0 && stage * NSTG <= 64 * 1024;
+}
+
+int pg_launch_pairC_tile(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, int NPv, int n_units, int diag,
+                         int64_t avg_wq, int64_t max_sites, int32_t *Cmat) {
+    if (n_win <= 0 || n_units <= 0) return 0;
+    const int T = (n_units + 31) / 32;
+    const int32_t *prog;
+    int nblk;
+    if (get_program(T, CS_C, W_C, &prog, &nblk) != 0) return -1;
+    const int kparts = std::max(pick_parts(n_win, nblk * W_C, avg_wq / 2, 16), exact_parts(max_sites));
+    if (kparts > 1) (void)hipMemsetAsync(Cmat, 0, (size_t)n_win * n_units * n_units * 4, st);
+    const int stage_u4 = 2 * GP_C * NPv, chunks = stage_u4 / 64, nl = (chunks + W_C - 1) / W_C;
+    const size_t lds_bytes = (size_t)NSTG * stage_u4 * 16;
+    const int64_t blocks = (int64_t)((n_win + 7) / 8) * nblk * kparts * 8;
+    hipLaunchKernelGGL((k_pairC_tile<CS_C, W_C, GP_C>), dim3((unsigned)blocks), dim3(64 * W_C), lds_bytes, st, Vp, vgoff, n_win, T, nblk,
+                       kparts, NPv, n_units, diag, prog, nl, Cmat);
+    return 0;
+}
+
+int pg_launch_pairD_tile(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win, int NP, int N,
+                         int64_t avg_words, int64_t max_vsites, int32_t *Dmat, int capg) {
+    if (n_win <= 0 || N <= 0) return 0;
+    const int T = (N + 31) / 32;
+    const int32_t *prog;
+    int nblk;
+    if (get_program(T, CS_D, W_D, &prog, &nblk) != 0) return -1;
+    const int kparts = std::max(pick_parts(n_win, nblk * W_D, avg_words / 2, 16), exact_parts(max_vsites));
+    if (kparts > 1) (void)hipMemsetAsync(Dmat, 0, (size_t)n_win * N * N * 4, st);
+    const int stage_u4 = 2 * KD_D * NP / 2, chunks = stage_u4 / 64, nl = (chunks + W_D - 1) / W_D;
+    const size_t lds_bytes = (size_t)NSTG * stage_u4 * 16;
+    const int64_t blocks = (int64_t)((n_win + 7) / 8) * nblk * kparts * 8;
+    hipLaunchKernelGGL((k_pairD_tile<CS_D, W_D, KD_D>), dim3((unsigned)blocks), dim3(64 * W_D), lds_bytes, st, XV, nw, goff, n_win, T, nblk,
+                       kparts, NP, N, prog, nl, Dmat, capg);
+    return 0;
+}

@@ -401,7 +401,12 @@ def _scan_run_boundary(next_chunk, wanted, chunk=8 << 10, max_chunk=16 << 20):
         if not data:
             return None, scanned
         scanned += len(data)
-        at = 0
+        # the pattern needs the line feed in front of a line: behind the first chunk, give the chunk's first line the one that
+        # ended the previous chunk (a run that ends exactly at a chunk seam would otherwise be cut one line late)
+        lead = 0 if cur is None else 1
+        if lead:
+            data = b"\n" + data
+        at = lead
         while at < len(data):
             if cur is None:                              # first data line of the scan: it only names the current run
                 nl = data.find(b"\n", at)
@@ -427,9 +432,9 @@ def _scan_run_boundary(next_chunk, wanted, chunk=8 << 10, max_chunk=16 << 20):
             prev, cur = cur, tok[0]
             pat = re.compile(rb"\n(?!" + re.escape(cur) + rb"[ \t])")
             if wanted(prev.decode("utf-8", "replace")) and wanted(cur.decode("utf-8", "replace")):
-                return base + at, scanned
+                return base + at - lead, scanned
             at = (nl + 1) if nl >= 0 else len(data)
-        base += len(data)
+        base += len(data) - lead
 
 
 def find_run_boundary(path, guess, wanted):

@@ -421,3 +421,47 @@ def test_bgzf_input_shards_at_scaffold_runs(tmp_path):
         assert b"".join(parts) == body
         firsts = [p.split(None, 1)[0] for p in parts if p]
         assert len(set(firsts)) == len(firsts) and all(p.endswith(b"\n") for p in parts if p)
+
+
+def test_run_boundary_at_a_chunk_seam(tmp_path):
+    """A scaffold run that ends exactly where a scan chunk ends: the cut is the FIRST line of the next scaffold (the pattern needs
+    the line feed in front of a line; the chunk's first line must still be tested), for plain text and for BGZF input."""
+    line = lambda sc, k: ("%s\t%d\tA/A\tC/C\n" % (sc, k)).encode()
+    for n_a in (1, 4, 37):
+        a = b"".join(line("scafA", k + 1) for k in range(n_a))
+        b = b"".join(line("scafB", k + 1) for k in range(50))
+        text = a + b
+        # chunks that end exactly at the seam, one line before it and one line behind it
+        for first in (len(a), len(a) - len(line("scafA", n_a)) if n_a > 1 else len(a), len(a) + len(line("scafB", 1))):
+            pos = [0]
+
+            def next_chunk(n, first=first):
+                if pos[0] == 0:
+                    out = text[:first]
+                else:
+                    end = text.find(b"\n", min(pos[0] + 40, len(text) - 1)) + 1
+                    out = text[pos[0]:end if end > 0 else len(text)]
+                pos[0] += len(out)
+                return out
+
+            rel, scanned = genoio._scan_run_boundary(next_chunk, lambda nm: True)
+            assert rel == len(a), (n_a, first, rel)
+    # through the file front ends: every guess up to the seam finds the seam
+    header = b"#CHROM\tPOS\ts1\ts2\n"
+    a = b"".join(line("scafA", k + 1) for k in range(300))
+    b = b"".join(line("scafB", k + 1) for k in range(300))
+    path = str(tmp_path / "seam.geno")
+    with open(path, "wb") as f:
+        f.write(header + a + b)
+    seam = len(header) + len(a)
+    for guess in (len(header) + 5, seam - 8192, seam - 8192 - 17, seam - 1, seam):
+        off, _ = genoio.find_run_boundary(path, max(guess, len(header)), lambda nm: True)
+        assert off == seam, (guess, off)
+    gz = str(tmp_path / "seam.geno.gz")
+    _bgzf_write(gz, header + a + b, blk=len(header) + len(a))          # the first member ends exactly at the seam
+    for guess in (0,):
+        (c, u), _ = genoio.find_run_boundary_bgzf(gz, guess, lambda nm: True)
+        bz = genoio.BgzfFile(gz)
+        bz.seek_member(int(c))
+        data = bz.read(1 << 20)
+        assert data[int(u):].startswith(b"scafB\t1\t"), (guess, c, u)
