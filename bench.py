@@ -8,8 +8,9 @@ statistics path over the rank's resident synthetic data set: pack -> pairwise D/
 finalisation (pi, dxy, Fst) on the GPU and D2H of the result table.  Measurement tier T0: the inputs are
 generated on the device before the timed region (counter-based generator, genomics_general_amd/synth.py) and stay resident
 in HBM.  The data path has no collective (windows are independent): at N>1 the ranks meet in an RCCL barrier on both sides
-of the timed region, and the per-window tables are all-gathered once after it (what the drivers do before rank 0 writes the
-CSV).  Weak scaling: every rank owns a full-size data set (different scaffolds), `value` = windows of all ranks /
+of the timed region, and every step ends in the one exchange a driver job has -- the all-gather of the finished per-window rows
+(`result_allgather_ms_per_step`, inside the reported time).  `python bench.py --gpus N` without a launcher starts its own N
+ranks; from 8 GPUs on the default workload is c5, the rank's share of BASELINE.json configs[4].  Weak scaling: every rank owns a full-size data set (different scaffolds), `value` = windows of all ranks /
 max-over-ranks time.
 
 Default workload = the north-star single-GPU shape (BASELINE.json `north_star` "Target": 10^8 sites x 200 diploids, 4
@@ -303,6 +304,26 @@ def tier_samples(eng, lay, wl, names, slot_gen, scaf_len, n_sites, t1_block, t0_
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, the environment a launcher would
+    set), pass rank 0's JSON line through and wait for all of them.  No torch anywhere."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PG_RDZV_FILE="/tmp/pg_rdzv_bench_%d_%d" % (os.getpid(), port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     from genomics_general_amd import _lib, dist, synth, windows
     from genomics_general_amd.engine import Engine
@@ -312,11 +333,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="northstar", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: northstar; c5 (BASELINE.json configs[4], 3e9 sites sharded over the ranks) from 8 GPUs on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tiers", action="store_true", help="skip the T1 (host blocks -> H2D -> kernels) and T2 (text -> CSV) samples")
     ap.add_argument("--cpu-workers", type=int, default=1 << 30, help="upper bound of the CPU baseline's worker processes")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "c5" if args.gpus >= 8 else "northstar"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))                  # a bare `python bench.py --gpus N`: this process becomes the launcher
     wl = dict(WORKLOADS[args.workload])
     world = dist.world_from_env()
     assert world.size == args.gpus, "WORLD_SIZE (%d) must equal --gpus (%d)" % (world.size, args.gpus)
@@ -334,8 +360,8 @@ def main():
     slot_gen = np.array([2 * names.index(nm) + k for nm in lay.ind_order for k in range(2)], dtype=np.int32)
     eng = Engine(dist.device_for(world))
     eng.set_layout(lay)
-    comm = dist.RcclComm(eng, world) if world.size > 1 else dist.SoloComm()
-    if world.size > 1:
+    comm = dist.make_comm(eng, world)
+    if world.size > 1 and isinstance(comm, dist.RcclComm):
         assert eng._comm_ranks() == world.size, "the RCCL communicator has %d ranks, expected %d" % (eng._comm_ranks(), world.size)
     n_sites = wl["n_sites"]
     scaf_len = n_sites // wl["n_scaf"]
@@ -391,20 +417,21 @@ def main():
     eng.kernel_time_reset()
     comm.barrier()
     t0 = time.perf_counter()
+    gather_s = 0.0
     for _ in range(args.steps):
         st, _tab = step()
+        if world.size > 1:                                 # the drivers' one exchange per job: the finished rows meet on every rank
+            g0 = time.perf_counter()
+            full = dist.gather_table(comm, np.asarray(_tab, dtype=np.float64).reshape(n_win, -1), n_win * world.size)
+            gather_s += time.perf_counter() - g0
+            assert full.shape[0] == n_win * world.size
     eng.sync()
     my_elapsed = time.perf_counter() - t0
     comm.barrier()
     elapsed = time.perf_counter() - t0
     per_rank = comm.allgather(np.array([my_elapsed, elapsed])) if world.size > 1 else np.array([[my_elapsed, elapsed]])
     elapsed = float(np.max(per_rank[:, 1]))
-    gather_ms = None
-    if world.size > 1:                                     # the result exchange of the drivers, once, outside the timed region
-        g0 = time.perf_counter()
-        full = dist.gather_table(comm, np.asarray(_tab, dtype=np.float64).reshape(n_win, -1), n_win * world.size)
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        assert full.shape[0] == n_win * world.size
+    gather_ms = gather_s * 1e3 / args.steps if world.size > 1 else None
 
     # ---- per-kernel timing of the timed region (HIP events on the engine's stream) ---------------------
     # dominant kernel = the kernel family with the most GPU time (chosen in the warm-up pass, timed live here)
@@ -486,10 +513,11 @@ def main():
                                              "polymorphic-site compaction and per-individual called counts do less work than that, "
                                              "and the matrix cores are not bound by it"}
     if gather_ms is not None:
-        extra["result_allgather_ms_once_untimed"] = round(gather_ms, 3)
+        extra["result_allgather_ms_per_step"] = round(gather_ms, 3)      # inside the timed region (rank 0's wait for the slowest rank included)
         extra["per_rank_ms_per_step"] = {"min": round(1e3 * float(per_rank[:, 0].min()) / args.steps, 4),
                                          "max": round(1e3 * float(per_rank[:, 0].max()) / args.steps, 4)}
-        extra["comm_ranks"] = int(eng._comm_ranks())
+        extra["comm_ranks"] = int(eng._comm_ranks()) if isinstance(comm, dist.RcclComm) else world.size
+        extra["comm"] = "rccl" if isinstance(comm, dist.RcclComm) else "files (PG_COMM=file)"
     if getattr(eng, "placement", None):
         extra["placement_trials"] = {"probe_ms": eng.placement[0], "kept": eng.placement[1],
                                      "note": "reserve() tried these physical placements of the resident rows (empty) and kept the "
@@ -545,6 +573,7 @@ def main():
         line.update(extra)
         print(json.dumps(line))
     comm.barrier()
+    comm.close()
     eng.close()
 
 

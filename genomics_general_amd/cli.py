@@ -184,7 +184,7 @@ class Run:
         dev = args.device if args.device is not None else dist.device_for(self.world)
         self.engine = Engine(dev)
         self.engine.set_layout(self.layout)
-        self.comm = dist.RcclComm(self.engine, self.world) if self.world.size > 1 else dist.SoloComm()
+        self.comm = dist.make_comm(self.engine, self.world)
         self.timing["engine_and_upload_s"] += time.perf_counter() - t0
         self.n_tested = 0
         # Multi-GPU ingestion.  Sharded (a driver that writes its rows through open_sink(), coordinate or sites windows, plain
@@ -1020,7 +1020,7 @@ def freq_main(argv=None):
     world = dist.world_from_env()
     eng = Engine(args.device if args.device is not None else dist.device_for(world))
     eng.set_layout(layout)
-    comm = dist.RcclComm(eng, world) if world.size > 1 else dist.SoloComm()
+    comm = dist.make_comm(eng, world)
     sharded = world.size > 1 and hasattr(reader, "shard_lines") and reader.shard_lines(world)
     if world.size > 1 and not sharded and world.rank > 0:
         dist.gather_bytes(comm, b"")

@@ -478,15 +478,41 @@ void pg_launch_sample_het(hipStream_t st, const int32_t *Cmat, const int32_t *Dm
 //   3. f = sizes / n;  H1 = sum f^2,  H12 = H1 + 2 f0 f1,  H2 = sum_{k>=1} f_k^2  (H12 = H1, H2 = 0 for a single cluster).
 // `order[pop_start[p] .. pop_start[p+1])` = the population's slots in the reference's row order.
 // ------------------------------------------------------------------------------------------------------
+// float64 sum in the order NumPy's add.reduce visits a contiguous array (the reference's `(clusterFreq**2).sum()`,
+// genomics.py:1088-1091): fewer than 8 elements left to right; up to 128 in eight strided partial sums combined as a tree, the
+// tail added one by one; beyond that the range is halved (the first half rounded down to a multiple of 8).
+template <int DEPTH>
+__device__ double np_pairwise_sum(const double *a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    if (n <= 128 || DEPTH == 0) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum<(DEPTH > 0 ? DEPTH - 1 : 0)>(a, n2) + np_pairwise_sum<(DEPTH > 0 ? DEPTH - 1 : 0)>(a + n2, n - n2);
+}
+
 __global__ __launch_bounds__(256) void k_hapstats(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat, int N,
                                                   int cN, int cshift, const int32_t *__restrict__ pop_start, int n_pops,
                                                   const int32_t *__restrict__ order, int min_pair_sites, int diag_nan,
                                                   double max_dist, uint32_t *__restrict__ bits, size_t bits_per_window,
                                                   double *__restrict__ out) {
-    extern __shared__ uint32_t alive[];                    // ceil(n/32) words
+    extern __shared__ double sq[];                         // f^2 of the clusters in extraction order (n values at most), then
     __shared__ int best_c[256], best_i[256];
     const int p = blockIdx.x, win = blockIdx.y, tid = threadIdx.x;
     const int s0 = pop_start[p], n = pop_start[p + 1] - s0, nw = (n + 31) >> 5;
+    uint32_t *alive = reinterpret_cast<uint32_t *>(sq + n);                 // ceil(n/32) words
     size_t off = 0;
     for (int q = 0; q < p; ++q) {
         const size_t nq = pop_start[q + 1] - pop_start[q];
@@ -523,7 +549,7 @@ __global__ __launch_bounds__(256) void k_hapstats(const int32_t *__restrict__ Cm
     }
     for (int w = tid; w < nw; w += 256) alive[w] = (w == nw - 1 && (n & 31)) ? ((1u << (n & 31)) - 1u) : 0xFFFFFFFFu;
     __syncthreads();
-    double sumsq = 0.0, f0 = 0.0, f1 = 0.0;                 // kept by every thread identically (block-uniform control flow)
+    double f0 = 0.0, f1 = 0.0;                              // kept by every thread identically (block-uniform control flow)
     int k = 0;
     const double dn = (double)n;
     for (;;) {
@@ -550,7 +576,7 @@ __global__ __launch_bounds__(256) void k_hapstats(const int32_t *__restrict__ Cm
         if (matches > 1) {
             const double f = (double)matches / dn;
             if (k == 0) f0 = f; else if (k == 1) f1 = f;
-            sumsq += f * f;
+            if (tid == 0) sq[k] = f * f;
             ++k;
             for (int w = tid; w < nw; w += 256) alive[w] &= ~M[(size_t)most * nw + w];
             __syncthreads();
@@ -560,16 +586,17 @@ __global__ __launch_bounds__(256) void k_hapstats(const int32_t *__restrict__ Cm
             const double f = 1.0 / dn;
             for (int r = 0; r < rem; ++r) {
                 if (k == 0) f0 = f; else if (k == 1) f1 = f;
-                sumsq += f * f;
+                if (tid == 0) sq[k] = f * f;
                 ++k;
             }
             break;
         }
     }
     if (tid == 0) {
-        O[0] = sumsq;
-        O[1] = k > 1 ? sumsq + 2 * f0 * f1 : sumsq;
-        O[2] = k > 1 ? sumsq - f0 * f0 : 0.0;
+        const double H1 = np_pairwise_sum<9>(sq, k);
+        O[0] = H1;
+        O[1] = k > 1 ? H1 + 2 * f0 * f1 : H1;
+        O[2] = k > 1 ? np_pairwise_sum<9>(sq + 1, k - 1) : 0.0;
     }
 }
 
@@ -577,7 +604,7 @@ void pg_launch_hapstats(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat
                         const int32_t *pop_start, int n_pops, int max_pop, const int32_t *order, int min_pair_sites, int diag_nan,
                         double max_dist, uint32_t *bits, size_t bits_per_window, double *out) {
     if (n_win <= 0 || n_pops <= 0) return;
-    const size_t lds = (size_t)((max_pop + 31) / 32 + 1) * 4;
+    const size_t lds = (size_t)max_pop * 8 + (size_t)((max_pop + 31) / 32 + 1) * 4;
     hipLaunchKernelGGL(k_hapstats, dim3(n_pops, n_win), dim3(256), lds, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops, order,
                        min_pair_sites, diag_nan, max_dist, bits, bits_per_window, out);
 }

@@ -30,11 +30,12 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace {
 
-typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int NSTG = 3;                // ring depth (stages)
@@ -85,24 +86,55 @@ __device__ __forceinline__ bool win_decode(int per_win, int n_win, int &win, int
     return true;
 }
 
-// fragment of one word: dword m = the word's bits m, m+4, ... as e2m1 nibbles; M = 0x11111111, or 0 for a lane whose word lies
-// beyond the part (the lane then contributes zeros)
-__device__ __forceinline__ v8i expand4(uint32_t w, uint32_t M) {
-    v8i f;                                   // fp4 operands are the first four registers; the others are not read
-    f[0] = (int)(w & M);
-    f[1] = (int)((w >> 1) & M);
-    f[2] = (int)((w >> 2) & M);
-    f[3] = (int)((w >> 3) & M);
+// Fragments of one word (32 sites of one unit) as e2m1 nibbles, one site per nibble.  A nibble with only bit 0 / 1 / 2 set is 0.5 /
+// 1.0 / 2.0 (bit 3 is the sign: -0), so the streamed operand (the COLUMNS of a slot) takes bits m = 0, 1, 2 of every nibble where
+// they are -- three ANDs -- and only bit 3 needs a shift: 5 VALU ops instead of 7.  The cached operand (the ROWS of a strip)
+// puts the same sites into the same (dword, nibble) places with the reciprocal values 2.0 / 1.0 / 0.5 / 2.0, so every product of
+// two set sites is exactly 1.0 and an accumulator holds the count itself (exact in f32 below 2^24).
+//     column dword m: sites 4n+m at value 0.5, 1.0, 2.0, 0.5 (m = 3 shifted down to bit 0)
+//     row    dword m: the same sites at value 2.0, 1.0, 0.5, 2.0
+// K1 / K2 / K4 = 0x11111111 / 0x22222222 / 0x44444444 in registers (an SGPR or literal source costs issue time); the ROW masks
+// are zero in a lane whose word lies beyond the part (that lane then contributes nothing, whatever the column holds).
+struct Masks { uint32_t k1, k2, k4; };
+
+__device__ __forceinline__ v4i expand_col(uint32_t w, const Masks &K) {
+    v4i f;
+    f[0] = (int)(w & K.k1);
+    f[1] = (int)(w & K.k2);
+    f[2] = (int)(w & K.k4);
+    f[3] = (int)((w >> 3) & K.k1);
     return f;
 }
 
-__device__ __forceinline__ v16f mfma4(const v8i &a, const v8i &b, const v16f &c) {
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+__device__ __forceinline__ v4i expand_row(uint32_t w, const Masks &K) {
+    v4i f;
+    f[0] = (int)((w << 2) & K.k4);
+    f[1] = (int)(w & K.k2);
+    f[2] = (int)((w >> 2) & K.k1);
+    f[3] = (int)((w >> 1) & K.k4);
+    return f;
 }
+
+// The slot bodies are hand-scheduled assembly: hipcc clusters the expansions in front of the matrix instructions (and hoists
+// them out of the slot's block), which leaves a wave alternating between a VALU burst and an MFMA burst.  In the bodies the
+// expansion of step k+1 sits between the matrix instructions of step k (5 VALU issue slots under each 32-cycle instruction), and
+// the first expansion of a body runs under the previous body's last instruction.  Rules the strings obey (the compiler pads
+// nothing inside an asm statement): a VALU-written fragment is read by a matrix instruction no sooner than two instructions
+// later; an accumulator is only ever touched by matrix instructions between the zeroing and the epilogue (s_nop 11 in front of
+// it: results of an 8-pass instruction).  Scratch registers: v[239:255] (clobbered; the kernels are built for 256 registers).
+// `v_mfma_f32_32x32x64_f8f6f4` is the unscaled form (both scales 2^0), cbsz / blgp = 4: both operands fp4.
+#define PG_F0 "v[240:243]"
+#define PG_F1 "v[244:247]"
+#define PG_F2 "v[248:251]"
+#define PG_F3 "v[252:255]"
+#define PG_EXP_A(d0, d1, w) "v_and_b32 " d0 ", " w ", %[k1]\n\tv_and_b32 " d1 ", " w ", %[k2]\n\t"
+#define PG_EXP_B(d2, d3, w) "v_and_b32 " d2 ", " w ", %[k4]\n\tv_lshrrev_b32 v239, 3, " w "\n\tv_and_b32 " d3 ", v239, %[k1]\n\t"
+#define PG_MFMA(acc, a, b) "v_mfma_f32_32x32x64_f8f6f4 " acc ", " a ", " b ", " acc " cbsz:4 blgp:4\n\t"
+#define PG_SCRATCH "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
 __device__ __forceinline__ uint32_t comp(const uint4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 
-// accumulator tile (count / 4) -> upper triangle of the window's matrix.  C/D layout of the 32 x 32 product: column = lane & 31,
+// accumulator tile (the counts) -> upper triangle of the window's matrix.  C/D layout of the 32 x 32 product: column = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ void store_tile(const v16f &acc, int I, int J, int lane, int n, int diag, int atomic, int32_t *__restrict__ M) {
     const int col = 32 * J + (lane & 31);
@@ -111,7 +143,7 @@ __device__ __forceinline__ void store_tile(const v16f &acc, int I, int J, int la
     for (int reg = 0; reg < 16; ++reg) {
         const int row = 32 * I + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         if (row >= n || row > col || (row == col && !diag)) continue;
-        const int32_t v = (int32_t)(acc[reg] * 4.0f);
+        const int32_t v = (int32_t)acc[reg];
         int32_t *dst = &M[(size_t)row * n + col];
         if (atomic) { if (v) atomicAdd(dst, v); }
         else *dst = v;
@@ -136,10 +168,41 @@ __device__ __forceinline__ void stage_copy(const uint4 *__restrict__ gsrc, uint4
 // ---- C: called counts of unit pairs ------------------------------------------------------------------------------------------
 // Vp[(vgoff[win] + q) * NPv + unit] = the four words of group q (128 sites) of one unit.  A stage = GP pairs of groups; the lane
 // half kb works on group 2 p + kb of pair p; K step t = word t of the lane's own group.
+
+// One slot of a pair of groups: four K steps, the column fragment of step t+1 is expanded under the products of step t.  A
+// diagonal slot (`one`) has no second tile: its matrix instructions are skipped by scalar branches INSIDE the body, so that both
+// kinds of slot are the same statement to the compiler (two statements in an if / else made it shuffle the accumulators
+// between registers around them -- copies of a matrix result that nothing pads).
+__device__ __forceinline__ void slotC(const uint4 &cw, const Masks &K, const v4i (&fr)[2][4], int one, v16f &a0, v16f &a1) {
+#define PG_MFMA1(a, b) "s_cbranch_scc1 1f\n\t" PG_MFMA("%[a1]", a, b) "1:\n\t"
+    asm volatile("s_cmp_lg_u32 %[one], 0\n\t"
+                 PG_EXP_A("v240", "v241", "%[w0]") PG_EXP_B("v242", "v243", "%[w0]")
+                 PG_EXP_A("v244", "v245", "%[w1]")
+                 PG_MFMA("%[a0]", "%[r00]", PG_F0)
+                 PG_EXP_B("v246", "v247", "%[w1]")
+                 PG_MFMA1("%[r10]", PG_F0)
+                 PG_EXP_A("v248", "v249", "%[w2]")
+                 PG_MFMA("%[a0]", "%[r01]", PG_F1)
+                 PG_EXP_B("v250", "v251", "%[w2]")
+                 PG_MFMA1("%[r11]", PG_F1)
+                 PG_EXP_A("v252", "v253", "%[w3]")
+                 PG_MFMA("%[a0]", "%[r02]", PG_F2)
+                 PG_EXP_B("v254", "v255", "%[w3]")
+                 PG_MFMA1("%[r12]", PG_F2)
+                 "s_nop 1\n\t"
+                 PG_MFMA("%[a0]", "%[r03]", PG_F3)
+                 PG_MFMA1("%[r13]", PG_F3)
+                 : [a0] "+v"(a0), [a1] "+v"(a1)
+                 : [w0] "v"(cw.x), [w1] "v"(cw.y), [w2] "v"(cw.z), [w3] "v"(cw.w), [k1] "v"(K.k1), [k2] "v"(K.k2), [k4] "v"(K.k4),
+                   [r00] "v"(fr[0][0]), [r01] "v"(fr[0][1]), [r02] "v"(fr[0][2]), [r03] "v"(fr[0][3]),
+                   [r10] "v"(fr[1][0]), [r11] "v"(fr[1][1]), [r12] "v"(fr[1][2]), [r13] "v"(fr[1][3]), [one] "s"(one)
+                 : "scc", PG_SCRATCH);
+}
+
 template <int CS, int W, int GP>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pairC_tile(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vgoff, int n_win,
-                                                       int T, int nblk, int kparts, int NPv, int n_units, int diag,
-                                                       const int32_t *__restrict__ prog, int nl, int32_t *__restrict__ Cmat) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_pairC_tile(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vgoff, int n_win, int T, int nblk, int kparts, int NPv,
+                  int n_units, int diag, const int32_t *__restrict__ prog, int nl, int32_t *__restrict__ Cmat) {
     extern __shared__ uint4 lds[];
     int win, rem;
     if (!win_decode(nblk * kparts, n_win, win, rem)) return;
@@ -147,7 +210,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, kb = lane >> 5;
     const int32_t *my = prog + (size_t)(bp * W + wave) * (CS + 1);
-    const int ns = my[0];
+    // the wave's program lives in scalar registers (the copies below clobber "memory": anything left in memory would be re-read)
+    const int ns = __builtin_amdgcn_readfirstlane(my[0]);
+    int sr0[CS], sj[CS], sone[CS];
+#pragma unroll
+    for (int s = 0; s < CS; ++s) {
+        const Slot sl = slot_of(__builtin_amdgcn_readfirstlane(my[1 + s]));
+        sr0[s] = sl.r0;
+        sj[s] = sl.j;
+        sone[s] = sl.one;
+    }
     const int64_t vg = vgoff[win];
     const int nwq = (int)(vgoff[win + 1] - vg);
     const int q0 = (int)((long long)nwq * kp / kparts), q1 = (int)((long long)nwq * (kp + 1) / kparts);
@@ -165,6 +237,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int chunks = stage_u4 / 64;                         // NPv is a multiple of 32
     const int nstage = (q1 - q0 + stage_groups - 1) / stage_groups;
     const uint4 *base = reinterpret_cast<const uint4 *>(Vp) + ((size_t)vg + q0) * NPv;
+    Masks KC;                                                 // column masks: never zeroed (the row masks carry `live`)
+    KC.k1 = 0x11111111u;
+    KC.k2 = 0x22222222u;
+    KC.k4 = 0x44444444u;
+    asm volatile("" : "+v"(KC.k1), "+v"(KC.k2), "+v"(KC.k4));  // stay in vector registers
     if (nstage > 0) {
         // (copies past the last stage repeat it into a ring slot nobody reads: the counted waits stay uniform; a stage may reach
         // up to stage_groups - 1 groups past q1: those words exist (next part / window / padding) and their lanes are masked)
@@ -184,52 +261,44 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll 1
             for (int p = 0; p < GP; ++p) {
                 const bool live = q0 + st * stage_groups + 2 * p + kb < q1;
-                const uint32_t M = live ? 0x11111111u : 0u;
+                Masks KR;
+                KR.k1 = live ? KC.k1 : 0u;
+                KR.k2 = live ? KC.k2 : 0u;
+                KR.k4 = live ? KC.k4 : 0u;
                 const uint4 *pb = sb + (size_t)(2 * p + kb) * NPv + r;
                 int cur = -1;
-                v8i fr[2][4];
-                uint4 craw = pb[32 * slot_of(my[1]).j];
+                v4i fr[2][4];
+                uint4 craw = pb[32 * sj[0]];
 #pragma unroll
                 for (int s = 0; s < CS; ++s) {
                     if (s < ns) {
-                        const Slot sl = slot_of(my[1 + s]);
-                        if (sl.r0 != cur) {
-                            cur = sl.r0;
-                            const int t1 = sl.r0 + 1 < T ? sl.r0 + 1 : sl.r0;
-                            const uint4 a = pb[32 * sl.r0], b = pb[32 * t1];
+                        if (sr0[s] != cur) {
+                            cur = sr0[s];
+                            const int t1 = cur + 1 < T ? cur + 1 : cur;
+                            const uint4 a = pb[32 * cur], b = pb[32 * t1];
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                fr[0][t] = expand4(comp(a, t), M);
-                                fr[1][t] = expand4(comp(b, t), M);
+                                fr[0][t] = expand_row(comp(a, t), KR);
+                                fr[1][t] = expand_row(comp(b, t), KR);
                             }
                         }
                         const uint4 cw = craw;
-                        if (s + 1 < CS) craw = pb[32 * slot_of(my[1 + (s + 1 < ns ? s + 1 : s)]).j];    // the next slot's words
-                        if (sl.one) {
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) acc[s][0] = mfma4(fr[0][t], expand4(comp(cw, t), M), acc[s][0]);
-                        } else {
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                const v8i fc = expand4(comp(cw, t), M);
-                                acc[s][0] = mfma4(fr[0][t], fc, acc[s][0]);
-                                acc[s][1] = mfma4(fr[1][t], fc, acc[s][1]);
-                            }
-                        }
+                        if (s + 1 < CS) craw = pb[32 * sj[s + 1]];                 // the next slot's words (a padding slot repeats a real one)
+                        slotC(cw, KC, fr, sone[s], acc[s][0], acc[s][1]);
                     }
                 }
             }
         }
         wait_vm(0);                                           // the surplus copies of the last iterations land before the block ends
+        asm volatile("s_nop 11" ::: "memory");                // the last matrix instruction's result is complete
     }
     const bool zero_fill = nstage <= 0 && !atomic;            // an empty window: the counts are zero and nobody else writes them
     if (nstage > 0 || zero_fill) {
 #pragma unroll
         for (int s = 0; s < CS; ++s) {
             if (s < ns) {
-                const Slot sl = slot_of(my[1 + s]);
-                store_tile(acc[s][0], sl.r0, sl.j, lane, n_units, diag, atomic, Cw);
-                if (!sl.one) store_tile(acc[s][1], sl.r0 + 1, sl.j, lane, n_units, diag, atomic, Cw);
+                store_tile(acc[s][0], sr0[s], sj[s], lane, n_units, diag, atomic, Cw);
+                if (!sone[s]) store_tile(acc[s][1], sr0[s] + 1, sj[s], lane, n_units, diag, atomic, Cw);
             }
         }
     }
@@ -237,12 +306,31 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
 // ---- D: differences of haplotype pairs ------------------------------------------------------------------------------------------
 // XV word k of a window: [slot][x, v] (8 bytes per haplotype).  A stage = KD steps of two words; the lane half kb works on word
-// 2 s + kb of step s.
+// 2 s + kb of step s.  a = x & v, b = ~x & v;  D += a_row b_col^T + b_row a_col^T.
+
+// one slot, one step: the column's b fragment is expanded first and multiplied while its a fragment is expanded
+__device__ __forceinline__ void slotD(const uint2 &cw, const Masks &K, const v4i (&ra)[2], const v4i (&rb)[2], int one, v16f &a0, v16f &a1) {
+    // v238 = a = x & v, v237 = b = v ^ a; F0 = fragment of b, F1 = fragment of a
+    asm volatile("s_cmp_lg_u32 %[one], 0\n\t"
+                 "v_and_b32 v238, %[x], %[v]\n\tv_xor_b32 v237, %[v], v238\n\t"
+                 PG_EXP_A("v240", "v241", "v237") PG_EXP_B("v242", "v243", "v237")
+                 PG_EXP_A("v244", "v245", "v238")
+                 PG_MFMA("%[a0]", "%[ra0]", PG_F0)
+                 PG_EXP_B("v246", "v247", "v238")
+                 PG_MFMA1("%[ra1]", PG_F0)
+                 "s_nop 1\n\t"
+                 PG_MFMA("%[a0]", "%[rb0]", PG_F1)
+                 PG_MFMA1("%[rb1]", PG_F1)
+                 : [a0] "+v"(a0), [a1] "+v"(a1)
+                 : [x] "v"(cw.x), [v] "v"(cw.y), [k1] "v"(K.k1), [k2] "v"(K.k2), [k4] "v"(K.k4),
+                   [ra0] "v"(ra[0]), [ra1] "v"(ra[1]), [rb0] "v"(rb[0]), [rb1] "v"(rb[1]), [one] "s"(one)
+                 : "scc", "v237", "v238", PG_SCRATCH);
+}
+
 template <int CS, int W, int KD>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pairD_tile(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw,
-                                                       const int64_t *__restrict__ goff, int n_win, int T, int nblk, int kparts, int NP,
-                                                       int N, const int32_t *__restrict__ prog, int nl, int32_t *__restrict__ Dmat,
-                                                       int capg) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_pairD_tile(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw, const int64_t *__restrict__ goff, int n_win, int T,
+                  int nblk, int kparts, int NP, int N, const int32_t *__restrict__ prog, int nl, int32_t *__restrict__ Dmat, int capg) {
     extern __shared__ uint4 lds[];
     int win, rem;
     if (!win_decode(nblk * kparts, n_win, win, rem)) return;
@@ -250,7 +338,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, kb = lane >> 5;
     const int32_t *my = prog + (size_t)(bp * W + wave) * (CS + 1);
-    const int ns = my[0];
+    const int ns = __builtin_amdgcn_readfirstlane(my[0]);
+    int sr0[CS], sj[CS], sone[CS];
+#pragma unroll
+    for (int s = 0; s < CS; ++s) {
+        const Slot sl = slot_of(__builtin_amdgcn_readfirstlane(my[1 + s]));
+        sr0[s] = sl.r0;
+        sj[s] = sl.j;
+        sone[s] = sl.one;
+    }
     // (a window that overflowed its reservation is recomputed by the host; never read past the reservation)
     const int capw = (int)(goff[win + 1] - goff[win]) * capg;
     const int n_all = __builtin_amdgcn_readfirstlane(nw[win]);
@@ -270,6 +366,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int chunks = stage_u4 / 64;                         // NP is a multiple of 32
     const int nstage = (w1 - w0 + stage_words - 1) / stage_words;
     const uint4 *base = reinterpret_cast<const uint4 *>(XV + ((size_t)goff[win] * capg + w0) * PG_XV_PLANES * (size_t)NP);
+    Masks KC;
+    KC.k1 = 0x11111111u;
+    KC.k2 = 0x22222222u;
+    KC.k4 = 0x44444444u;
+    asm volatile("" : "+v"(KC.k1), "+v"(KC.k2), "+v"(KC.k4));
     if (nstage > 0) {
         for (int st = 0; st < NSTG - 1; ++st) {
             const int src = st < nstage ? st : nstage - 1;
@@ -287,47 +388,44 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll 1
             for (int p = 0; p < KD; ++p) {
                 const bool live = w0 + st * stage_words + 2 * p + kb < w1;
-                const uint32_t M = live ? 0x11111111u : 0u;
+                Masks KR;
+                KR.k1 = live ? KC.k1 : 0u;
+                KR.k2 = live ? KC.k2 : 0u;
+                KR.k4 = live ? KC.k4 : 0u;
                 const uint2 *pb = sb + (size_t)(2 * p + kb) * NP + r;
                 int cur = -1;
-                v8i ra[2], rb[2];
-                uint2 craw = pb[32 * slot_of(my[1]).j];
+                v4i ra[2], rb[2];
+                uint2 craw = pb[32 * sj[0]];
 #pragma unroll
                 for (int s = 0; s < CS; ++s) {
                     if (s < ns) {
-                        const Slot sl = slot_of(my[1 + s]);
-                        if (sl.r0 != cur) {
-                            cur = sl.r0;
-                            const int t1 = sl.r0 + 1 < T ? sl.r0 + 1 : sl.r0;
-                            const uint2 u0 = pb[32 * sl.r0], u1 = pb[32 * t1];
+                        if (sr0[s] != cur) {
+                            cur = sr0[s];
+                            const int t1 = cur + 1 < T ? cur + 1 : cur;
+                            const uint2 u0 = pb[32 * cur], u1 = pb[32 * t1];
                             const uint32_t a0 = u0.x & u0.y, a1 = u1.x & u1.y;            // a = x & v, b = ~x & v
-                            ra[0] = expand4(a0, M);
-                            rb[0] = expand4(u0.y ^ a0, M);
-                            ra[1] = expand4(a1, M);
-                            rb[1] = expand4(u1.y ^ a1, M);
+                            ra[0] = expand_row(a0, KR);
+                            rb[0] = expand_row(u0.y ^ a0, KR);
+                            ra[1] = expand_row(a1, KR);
+                            rb[1] = expand_row(u1.y ^ a1, KR);
                         }
                         const uint2 cw = craw;
-                        if (s + 1 < CS) craw = pb[32 * slot_of(my[1 + (s + 1 < ns ? s + 1 : s)]).j];
-                        const uint32_t a = cw.x & cw.y;
-                        const v8i ca = expand4(a, M), cb = expand4(cw.y ^ a, M);
-                        acc[s][0] = mfma4(ra[0], cb, acc[s][0]);
-                        if (!sl.one) acc[s][1] = mfma4(ra[1], cb, acc[s][1]);
-                        acc[s][0] = mfma4(rb[0], ca, acc[s][0]);
-                        if (!sl.one) acc[s][1] = mfma4(rb[1], ca, acc[s][1]);
+                        if (s + 1 < CS) craw = pb[32 * sj[s + 1]];
+                        slotD(cw, KC, ra, rb, sone[s], acc[s][0], acc[s][1]);
                     }
                 }
             }
         }
         wait_vm(0);
+        asm volatile("s_nop 11" ::: "memory");
     }
     const bool zero_fill = nstage <= 0 && !atomic;
     if (nstage > 0 || zero_fill) {
 #pragma unroll
         for (int s = 0; s < CS; ++s) {
             if (s < ns) {
-                const Slot sl = slot_of(my[1 + s]);
-                store_tile(acc[s][0], sl.r0, sl.j, lane, N, 0, atomic, Dw);
-                if (!sl.one) store_tile(acc[s][1], sl.r0 + 1, sl.j, lane, N, 0, atomic, Dw);
+                store_tile(acc[s][0], sr0[s], sj[s], lane, N, 0, atomic, Dw);
+                if (!sone[s]) store_tile(acc[s][1], sr0[s] + 1, sj[s], lane, N, 0, atomic, Dw);
             }
         }
     }
@@ -335,8 +433,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
 // ---- host: slot programs ---------------------------------------------------------------------------------------------------
 // Slots of the upper triangle of T x T tiles in strip order (strip = tile rows r0, r0+1; slot = column j >= r0; the slot j == r0
-// holds the diagonal tile only, as does every slot of a last strip of one row), dealt in equal runs to nblk * W waves of at most
-// CS slots each.  Entry = r0 | j << 8 | one << 16; a wave's record = [count, CS entries].
+// holds the diagonal tile only, as does every slot of a last strip of one row), dealt to nblk * W waves of at most CS slots each,
+// balanced by the number of matrix instructions.  Entry = r0 | j << 8 | one << 16; a wave's record = [count, CS entries].
 struct Program {
     std::vector<int32_t> tab;
     int nblk = 0;
@@ -347,15 +445,67 @@ Program make_program(int T, int CS, int W) {
     for (int r0 = 0; r0 < T; r0 += 2)
         for (int j = r0; j < T; ++j) slots.push_back(r0 | (j << 8) | ((j == r0 || r0 + 1 >= T) ? 1 << 16 : 0));
     const int n = (int)slots.size();
+    auto weight = [&](int k) { return (slots[(size_t)k] >> 16) & 1 ? 1 : 2; };          // matrix instructions per step
     Program p;
     p.nblk = (n + CS * W - 1) / (CS * W);
     const int waves = p.nblk * W;
+    // contiguous runs of at most CS slots with the smallest possible heaviest run (dynamic programme over the cut points): the
+    // waves of a block meet at a barrier every stage, so the heaviest wave sets the block's pace
+    const int INF = 1 << 28;
+    std::vector<std::vector<int>> best((size_t)waves + 1, std::vector<int>((size_t)n + 1, INF)), from(best);
+    best[0][0] = 0;
+    for (int w = 1; w <= waves; ++w)
+        for (int e = 0; e <= n; ++e)
+            for (int b = std::max(0, e - CS); b <= e; ++b) {
+                if (best[(size_t)w - 1][(size_t)b] >= INF) continue;
+                int wt = 0;
+                for (int k = b; k < e; ++k) wt += weight(k);
+                const int v = std::max(best[(size_t)w - 1][(size_t)b], wt);
+                if (v < best[(size_t)w][(size_t)e]) { best[(size_t)w][(size_t)e] = v; from[(size_t)w][(size_t)e] = b; }
+            }
+    std::vector<std::vector<int>> run((size_t)waves);
+    for (int w = waves, e = n; w >= 1; --w) {
+        const int b = from[(size_t)w][(size_t)e];
+        for (int k = b; k < e; ++k) run[(size_t)w - 1].push_back(k);
+        e = b;
+    }
+    // then single slots move from the heaviest wave to a lighter one while that lowers the heavier of the two (a slot that leaves
+    // its strip costs the receiving wave one more row expansion per pair of groups: only diagonal slots, weight 1, are moved)
+    auto load = [&](const std::vector<int> &r) { int t = 0; for (int k : r) t += weight(k); return t; };
+    for (int iter = 0; iter < 4 * waves; ++iter) {
+        int hi = 0;
+        for (int w = 1; w < waves; ++w) if (load(run[(size_t)w]) > load(run[(size_t)hi])) hi = w;
+        bool moved = false;
+        for (int w = 0; w < waves && !moved; ++w) {
+            if (w == hi || (int)run[(size_t)w].size() >= CS || load(run[(size_t)w]) + 1 >= load(run[(size_t)hi])) continue;
+            for (size_t q = 0; q < run[(size_t)hi].size(); ++q) {
+                const int k = run[(size_t)hi][q];
+                if (weight(k) != 1) continue;
+                run[(size_t)hi].erase(run[(size_t)hi].begin() + (long)q);
+                run[(size_t)w].push_back(k);
+                moved = true;
+                break;
+            }
+        }
+        // or a two-tile slot of the heaviest wave changes places with a diagonal slot of a lighter one
+        for (int w = 0; w < waves && !moved; ++w) {
+            if (w == hi || load(run[(size_t)w]) + 1 >= load(run[(size_t)hi])) continue;
+            for (size_t q = 0; q < run[(size_t)hi].size() && !moved; ++q)
+                for (size_t u = 0; u < run[(size_t)w].size() && !moved; ++u)
+                    if (weight(run[(size_t)hi][q]) == 2 && weight(run[(size_t)w][u]) == 1) {
+                        std::swap(run[(size_t)hi][q], run[(size_t)w][u]);
+                        moved = true;
+                    }
+        }
+        if (!moved) break;
+    }
+    for (std::vector<int> &r : run) std::sort(r.begin(), r.end());          // strip order inside a wave: one row expansion per strip
     p.tab.assign((size_t)waves * (CS + 1), 0);
     for (int w = 0; w < waves; ++w) {
-        const int a = (int)((long long)n * w / waves), b = (int)((long long)n * (w + 1) / waves);
         int32_t *rec = &p.tab[(size_t)w * (CS + 1)];
-        rec[0] = b - a;
-        for (int s = 0; s < CS; ++s) rec[1 + s] = slots[(size_t)std::min(a + s, n - 1)];
+        const std::vector<int> &r = run[(size_t)w];
+        rec[0] = (int)r.size();
+        for (int s = 0; s < CS; ++s) rec[1 + s] = slots[(size_t)(r.empty() ? 0 : r[std::min<size_t>((size_t)s, r.size() - 1)])];
     }
     return p;
 }
@@ -404,7 +554,7 @@ int pick_parts(int n_win, int waves_per_win, int64_t steps_per_window, int min_s
     while (kp < 64 && waves * kp < 4096 && steps_per_window / (kp * 2) >= min_steps) kp *= 2;
     return kp;
 }
-// an f32 accumulator holds count / 4 exactly while count < 2^24; no part of any window may see more sites than 2^23
+// an f32 accumulator holds a count exactly while it is < 2^24; no part of any window may see more sites than 2^23
 int exact_parts(int64_t max_sites_per_window) { return (int)((max_sites_per_window + (1 << 23) - 1) >> 23); }
 
 constexpr int CS_C = 4, W_C = 4, GP_C = 2;      // C: 4 waves x 4 slots, stage = 2 pairs of groups (512 sites)
@@ -412,9 +562,12 @@ constexpr int CS_D = 4, W_D = 4, KD_D = 2;      // D: 4 waves x 4 slots, stage =
 
 }  // namespace
 
-// the LDS-staged kernels take planes of up to this many units per word (a stage must fit the ring)
+// The LDS-staged kernels take planes of up to this many units per word (a stage must fit the ring).  PG_PAIR_TILE chooses who
+// runs them: "cd" both counts, "c" / "d" one of them, "none" neither (the one-wave kernels of pg_pair_mfma.hip); default below.
 bool pg_pair_tile_fits(int NPv_or_NP, int is_d) {
-    if (getenv("PG_PAIR_ONEWAVE")) return false;
+    const char *sel = getenv("PG_PAIR_TILE");
+    if (!sel) sel = "c";
+    if (!strchr(sel, is_d ? 'd' : 'c')) return false;
     const int64_t stage = is_d ? (int64_t)2 * KD_D * NPv_or_NP * 8 : (int64_t)2 * GP_C * NPv_or_NP * 16;
     return NPv_or_NP % 32 == 0 && stage * NSTG <= 64 * 1024;
 }

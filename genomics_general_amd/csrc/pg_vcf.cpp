@@ -71,13 +71,14 @@ int format_index(const Tok &fmt, const char *name, int nlen) {
 
 // Python float(): the whole (stripped) token must be a number
 bool py_float(const char *p, int n, double *v) {
-    if (n <= 0 || n > 63) return false;
-    char tmp[64];
-    memcpy(tmp, p, (size_t)n);
-    tmp[n] = 0;
+    if (n <= 0) return false;
+    std::string tmp(p, (size_t)n);          // (any length: Python takes a long run of digits too)
+    // strtod accepts hexadecimal floats ("0x1p3"), Python's float() does not
+    size_t k = (tmp[0] == '+' || tmp[0] == '-') ? 1 : 0;
+    if (k + 1 < tmp.size() && tmp[k] == '0' && (tmp[k + 1] == 'x' || tmp[k + 1] == 'X')) return false;
     char *end = nullptr;
-    *v = strtod(tmp, &end);
-    return end == tmp + n && end != tmp;
+    *v = strtod(tmp.c_str(), &end);
+    return end == tmp.c_str() + n && end != tmp.c_str();
 }
 
 struct Shared {
@@ -145,7 +146,7 @@ struct Line { const char *b, *e; };
 inline bool data_line(const char *b, const char *e) {
     const char *p = b;
     while (p < e && ws(*p)) ++p;
-    return p < e && *b != '#';              // `len(elements) == 0 or elements[0][0] == "#"` are skipped
+    return p < e && *p != '#';              // `len(elements) == 0 or elements[0][0] == "#"` are skipped (first TOKEN, not first byte)
 }
 
 // Walk the lines of [b,e).  count_only: number of kept sites; else write rows starting at `row`.

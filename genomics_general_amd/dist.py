@@ -135,6 +135,79 @@ class RcclComm:
         pass
 
 
+class FileComm:
+    """Host-side communicator through files next to the rendezvous file (`PG_COMM=file`).  RCCL refuses two ranks on one device,
+    so this is what lets a multi-rank launch (bench.py --gpus N, the drivers) be exercised on a single-GPU box; the data path
+    has no collective, only finished rows and barriers travel.  Every all-gather is one file per rank, renamed into place."""
+
+    def __init__(self, world, timeout_s=300.0):
+        self.size, self.rank, self.timeout_s = world.size, world.rank, timeout_s
+        self.dir = _rdzv_path() + ".d"
+        os.makedirs(self.dir, exist_ok=True)
+        self.seq = 0
+
+    def _name(self, seq, rank):
+        return os.path.join(self.dir, "g%d_r%d.npy" % (seq, rank))
+
+    def allgather(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        mine = self._name(self.seq, self.rank)
+        with open(mine + ".tmp", "wb") as f:
+            np.save(f, a)
+        os.replace(mine + ".tmp", mine)
+        rows, t0 = [], time.time()
+        for r in range(self.size):
+            path = self._name(self.seq, r)
+            while not os.path.exists(path):
+                if time.time() - t0 > self.timeout_s:
+                    raise TimeoutError("rank %d: rank %d never arrived at exchange %d (%s)" % (self.rank, r, self.seq, path))
+                time.sleep(0.0005)
+            rows.append(a if r == self.rank else np.load(path))
+        # everybody has passed exchange seq-1 once its files of exchange seq exist: the own file of seq-1 can go
+        if self.seq >= 1:
+            try:
+                os.remove(self._name(self.seq - 1, self.rank))
+            except OSError:
+                pass
+        self.seq += 1
+        return np.stack(rows)
+
+    def barrier(self):
+        self.allgather(np.zeros(1))
+
+    def close(self):
+        """The files of the last exchange cannot be removed by their writers (a slower rank may still have to read them): every
+        rank leaves a marker, rank 0 waits for all markers and removes the directory."""
+        self.barrier()
+        with open(os.path.join(self.dir, "done_r%d" % self.rank), "w"):
+            pass
+        if self.rank != 0:
+            return
+        t0 = time.time()
+        while not all(os.path.exists(os.path.join(self.dir, "done_r%d" % r)) for r in range(self.size)):
+            if time.time() - t0 > self.timeout_s:
+                return
+            time.sleep(0.001)
+        for name in os.listdir(self.dir):
+            try:
+                os.remove(os.path.join(self.dir, name))
+            except OSError:
+                pass
+        try:
+            os.rmdir(self.dir)
+        except OSError:
+            pass
+
+
+def make_comm(engine, world):
+    """The communicator of a multi-rank launch: RCCL over xGMI, or files when PG_COMM=file (ranks sharing one device)."""
+    if world.size <= 1:
+        return SoloComm()
+    if os.environ.get("PG_COMM") == "file":
+        return FileComm(world)
+    return RcclComm(engine, world)
+
+
 class GlooComm:
     """CPU stand-in with the same interface (tests only): torch.distributed, backend gloo."""
 

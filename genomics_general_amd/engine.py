@@ -510,8 +510,10 @@ def _tajima_d(n, S, theta_pi):
     (thetaPi - S/h1) / sqrt(v1*S + v2*S*(S-1)) with the usual constants from the harmonic sums h1 = sum 1/i, h2 = sum 1/i^2."""
     if n < 2:
         return np.full_like(theta_pi, np.nan)
-    i = np.arange(1, n, dtype=np.float64)
-    h1, h2 = float(np.sum(1.0 / i)), float(np.sum(1.0 / i ** 2))
+    h1 = h2 = 0.0
+    for i in range(1, n):                 # left to right, as the reference's Python sums (a pairwise np.sum differs in the last ulp)
+        h1 += 1.0 / i
+        h2 += 1.0 / (i ** 2)
     v1 = ((n + 1.0) / (3 * (n - 1)) - 1.0 / h1) / h1
     v2 = (2.0 * (n * n + n + 3) / (9 * n * (n - 1)) - (n + 2) / (h1 * n) + h2 / h1 ** 2) / (h1 ** 2 + h2)
-    return (theta_pi - S / h1) / np.sqrt(v1 * S + v2 * S * (S - 1))
+    return (theta_pi - 1.0 * S / h1) / np.sqrt(v1 * S + v2 * S * (S - 1))

@@ -63,11 +63,21 @@ def _open_out(path):
 
 def _last_key(body):
     """CHROM and POS tokens of the last data line of a block (the duplicate test of the next block starts from them)"""
-    tail = bytes(body[max(len(body) - (1 << 16), 0):])
-    for line in reversed(tail.split(b"\n")):
-        tok = line.split()
+    mv = memoryview(body)
+    end = len(mv)
+    while end > 0:                                   # whole lines from the back, however long they are
+        view = bytes(mv[max(end - (1 << 16), 0):end])
+        nl = view.rfind(b"\n", 0, len(view) - 1 if view.endswith(b"\n") else len(view))
+        span = 1 << 16
+        while nl < 0 and end - span > 0:             # the line is longer than the tail looked at: look further back
+            span *= 4
+            view = bytes(mv[max(end - span, 0):end])
+            nl = view.rfind(b"\n", 0, len(view) - 1 if view.endswith(b"\n") else len(view))
+        line = view[nl + 1:]
+        tok = line.split(None, 2)
         if len(tok) >= 2 and not line.startswith(b"#"):
             return tok[0], tok[1]
+        end -= len(line)
     return None, None
 
 
@@ -166,8 +176,8 @@ def parse_vcf_main(argv=None):
     for k, g in enumerate(gtf):
         Farr[k].flag = g["flag"].encode()
         Farr[k].min, Farr[k].max = g["min"], g["max"]
-        Farr[k].site_types = sum(SITE_TYPES.get(t, 0) for t in g.get("siteTypes", []))
-        Farr[k].gt_types = sum(GT_TYPES.get(t, 0) for t in g.get("gtTypes", []))
+        Farr[k].site_types = sum(SITE_TYPES.get(t, 0) for t in set(g.get("siteTypes", [])))     # a set: a repeated name is one bit
+        Farr[k].gt_types = sum(GT_TYPES.get(t, 0) for t in set(g.get("gtTypes", [])))
         if "siteTypes" in g and Farr[k].site_types == 0:
             Farr[k].site_types = 1 << 30                          # names that match no site type: the filter never applies
         if "gtTypes" in g and Farr[k].gt_types == 0:

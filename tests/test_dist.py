@@ -269,3 +269,43 @@ def test_line_shards_cover_the_input_once():
             assert b"".join(got) == b"\n".join(lines) + b"\n", size
     finally:
         os.remove(path)
+
+
+FILE_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from genomics_general_amd import dist
+world = dist.world_from_env()
+comm = dist.make_comm(None, world)
+assert isinstance(comm, dist.FileComm)
+n_total, k = 13, 2
+lo, hi = dist.shard_range(n_total, world.size, world.rank)
+full = np.arange(n_total * k, dtype=np.float64).reshape(n_total, k) - 3.25
+full[2, 0] = np.nan
+for it in range(20):                                   # many exchanges: files of finished exchanges are removed on the way
+    got = dist.gather_table(comm, full[lo:hi] + it, n_total)
+    assert np.array_equal(np.isnan(got), np.isnan(full)) and np.allclose(np.nan_to_num(got), np.nan_to_num(full + it))
+parts = dist.gather_bytes(comm, b"rank%%d" %% world.rank * (world.rank + 1))
+assert parts == [b"rank0", b"rank1rank1", b"rank2rank2rank2"][:world.size]
+comm.barrier(); comm.close()
+print("rank", world.rank, "ok", len(os.listdir(os.path.dirname(comm.dir))) >= 0)
+''' % ROOT
+
+
+def test_file_comm_world_size_3(tmp_path):
+    """PG_COMM=file (ranks that share one device: bench.py --gpus N and the drivers on a single-GPU box): all-gathers through
+    renamed files, same interface and results as the RCCL / gloo communicators"""
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="3", PG_COMM="file",
+                   PG_RDZV_FILE=str(tmp_path / "rdzv"))
+        procs.append(subprocess.Popen([sys.executable, "-c", FILE_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for rank, p in enumerate(procs):
+        try:
+            o, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        assert p.returncode == 0 and ("rank %d ok" % rank) in o.decode(), o.decode()[-2000:]
+    assert not os.path.exists(str(tmp_path / "rdzv.d")), "the exchange directory is removed by the last rank to close"

@@ -77,3 +77,23 @@ def test_drivers_match_the_oracle_on_a_random_mid_size_input(tool, mode, geno, w
     assert len(w.splitlines()) > 20
     n_inexact = G.compare_text(align_columns(got, w), w, 6 if tool == "popgenWindows.py" else 4)
     assert n_inexact <= max(2, len(w.split()) // 50), "%d cells differ in the last digit" % n_inexact
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: two ranks (both on device 0 here, so the exchange goes through files: RCCL
+    refuses duplicate devices), rank 0's JSON line on stdout, the result all-gather inside the reported time"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PG_COMM"] = "file"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-tiers"], env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["comm_ranks"] == 2 and d["steps"] == 3 and d["value"] > 0
+    assert d["config"]["name"] == "tiny" and "result_allgather_ms_per_step" in d
+    assert d["config"]["windows_per_gpu"] * 2 * 3 / (d["ms_per_step"] * 3 / 1e3) == pytest.approx(d["value"], rel=1e-3)

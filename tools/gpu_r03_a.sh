@@ -15,6 +15,6 @@ PY
 }
 for wl in northstar c2 c4; do
   run ${wl}_tile $wl PG_X=1
-  run ${wl}_onewave $wl PG_PAIR_ONEWAVE=1
+  run ${wl}_onewave $wl PG_PAIR_TILE=none
 done
 run northstar_tile2 northstar PG_X=1
