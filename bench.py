@@ -19,8 +19,8 @@ c5 the rank's share of configs[4] (3*10^9 sites / N, needs N >= 8).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the kernel family with the most GPU time), timed with HIP
 events on the stream it runs on: an HBM-bound family (k_pack3, k_abba_q, k_popfreq_q) is priced in algorithmic bytes against
-8 TB/s; the pair-count kernels run on the matrix cores (k_pairC_fp4 / k_pairD_fp4: algorithmic multiply-accumulates against the
-dense MX fp4 peak; with PG_PAIR_I8 against the int8 peak; the popcount kernels of PG_PAIR_VALU in VALU wave-instructions against
+8 TB/s; the pair-count kernels run on the matrix cores (k_pairC_tile / k_pairD_fp4: algorithmic multiply-accumulates against the
+dense MX fp4 peak; the popcount kernels of PG_PAIR_VALU in VALU wave-instructions against
 the guide's issue ceiling and the measured ceiling of their instruction mix, profiles/: tools/valu_rate.hip).  `cpu_baseline` is the CPU oracle's restatement of
 the reference's FULL path (.geno text -> parse -> windows -> alignment -> pair-by-pair loop -> statistics) run on all host
 cores, one window per worker process (N=1, rank 0 only).  No torch anywhere: barriers and the gather go through RCCL in
@@ -66,13 +66,13 @@ WORKLOADS = {
 CPU_DISTMAT_HAPS = 120          # distMat CPU sample: 7140 pairs x 100 kb ~ 5 s per window
 T1_BLOCK_SITES = 1 << 20        # T1 sample: host blocks of about a million sites, eight of them
 T1_BLOCKS = 8
-T2_SITES = 400_000              # T2 sample: this many sites of the workload as `.geno` text (8 windows of 50 kb)
+T2_SITES = 4_000_000            # T2 sample: this many sites of the workload as `.geno` text (80 windows of 50 kb; 3.3 GB at 400 haplotypes)
+CPU_WHOLE_WINDOWS = 8           # CPU sample: this many whole windows, one per worker on an otherwise idle host (~60 s at 400 haplotypes)
 CPU_SLICE_SITES = 4_000         # CPU sample: the first 4000 sites of a window per worker (~4 s of CPU work at 400 haplotypes on an idle core,
                                 # ~10x that with every hardware thread of a 256-thread host busy)
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GUIDE = 1024 * 2.4e9 / 2      # wave64 VALU instructions per second: 256 CUs x 4 SIMD-32, 2 cycles each, 2.4 GHz (guide)
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # MX fp4 MFMA, dense (guide: ~10 PF; measured ceiling 9099 with 32x32x64)
-MFMA_I8_PEAK_TOPS = 5000.0     # int8 MFMA, dense: 2 x the guide's bf16 dense peak (~2.5 PFLOP/s); its measured ceiling is 4404 (32x32x32)
 VALU_PAIRSITES_PEAK = 3.6e14    # 7 lane-ops per 32 pair-sites at 7.9e13 lane-ops/s
 
 
@@ -106,32 +106,16 @@ def _cpu_window_job(job):
     return t0, t1, csv
 
 
-def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, max_workers):
-    """One slice of CPU_SLICE_SITES sites (the head of a window of the workload) per worker process, all host cores at once,
-    through the oracle's restatement of the reference's whole path; the GPU statistics of the same slices are compared with it.
-    Every stage of the reference is linear in the sites of a window, so sites/s is measured directly and windows/s is that rate
-    divided by the workload's sites per window."""
+def _cpu_leg(eng, lay, wl, names, scaf_len, s_lo, s_hi, workers):
+    """The oracle's restatement of the reference's whole path on the site ranges [s_lo[k], s_hi[k]) (each rendered as its own
+    one-window `.geno` file), `workers` processes at once.  Returns (wall seconds, summed busy seconds, CSVs, GPU statistics of the
+    same ranges)."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
-    workers = cores
-    slice_sites = int(min(CPU_SLICE_SITES, wl["wind"]))
-    try:
-        import psutil
-        # a worker holds its slice as Python strings + int64 alignment: ~160 B per genotype cell, plus the interpreter
-        per_worker = 160 * slice_sites * lay.n_hap // 2 + (1 << 28)
-        workers = max(1, min(workers, int(psutil.virtual_memory().available * 0.6 // per_worker)))
-    except Exception:
-        pass
-    workers = max(1, min(workers, max_workers, len(lo)))
     per = len(names) // lay.n_pops
     pops = [(p, names[k * per:(k + 1) * per]) for k, p in enumerate(lay.sampleData.popNames)]
     # generator order of the columns: sample d owns columns (2d, 2d+1)
     col_of_slot = np.array([2 * names.index(lay.hap_sample_name[s]) + (s - lay.ind_slots[lay.hap_sample_name[s]][0])
                             for s in range(lay.n_hap)])
-    sel = np.linspace(0, len(lo) - 1, workers).astype(int) if workers > 1 else np.array([0])
-    s_lo = lo[sel].copy()
-    s_hi = np.minimum(s_lo + slice_sites, hi[sel])
-    # the GPU's numbers for the same slices
     wb = eng.batch(s_lo, s_hi)
     if wl["tool"] == "popgen":
         stats = wb.groupDistStats(doPairs=True, minSites=wl["min_sites"], minData=0.01)
@@ -144,15 +128,19 @@ def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, max_workers):
         slot_codes = eng.download(int(a), int(b - a))
         codes = np.zeros_like(slot_codes)
         codes[:, col_of_slot] = slot_codes
-        # the slice is rendered with positions 1.. on one scaffold: exactly one window of `slice_sites` for the tool
-        jobs.append((codes, names, pops, slice_sites, wl["min_sites"], wl["tool"], "chr%d" % (int(a) // scaf_len + 1), 1))
+        # the range is rendered with positions 1.. on one scaffold: exactly one window of its length for the tool
+        jobs.append((codes, names, pops, int(b - a), wl["min_sites"], wl["tool"], "chr%d" % (int(a) // scaf_len + 1), 1))
     ctx = mp.get_context("spawn")
     with ctx.Pool(workers) as pool:
         res = pool.map(_cpu_window_job, jobs, chunksize=1)
     wall = max(r[1] for r in res) - min(r[0] for r in res)
     busy = sum(r[1] - r[0] for r in res)
+    return wall, busy, [r[2] for r in res], stats
+
+
+def _cpu_matches(wl, csvs, stats):
     ok = True
-    for k, (_, _, csv) in enumerate(res):
+    for k, csv in enumerate(csvs):
         rows = csv.strip().split("\n")
         head, vals = rows[0].split(","), rows[1].split(",")
         for name, v in zip(head, vals):
@@ -168,17 +156,66 @@ def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, max_workers):
             # the ABBA-BABA driver rounds to 4 decimals (ABBABABAwindows.py:42), the popgenWindows leg is run with --roundTo 12
             tol = 0.5e-4 + 1e-6 if wl["tool"] == "abba" else 1e-6 * max(1.0, abs(v))
             ok = ok and (abs(g - v) <= tol or (g != g and v != v))
+    return bool(ok)
+
+
+def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, max_workers):
+    """Three legs of the oracle's restatement of the reference's whole path (text parse -> window -> genoToAlignment -> pair-by-pair
+    loop -> statistics), each compared with the GPU statistics of the same sites:
+      A  one slice of CPU_SLICE_SITES sites (the head of a window) per worker, one worker per hardware thread of the host, all at
+         once: the host's throughput in sites/s;
+      B  a few WHOLE windows, one per worker, the rest of the host idle;   C  the heads of the same windows as slices, same workers:
+         B against C is the measured cost of a whole window relative to a slice (every stage of the reference is linear in the
+         sites of a window; this shows it instead of asserting it).
+    windows/s of the host = A's sites/s / sites per window / (B's seconds per site / C's seconds per site)."""
+    cores = os.cpu_count() or 1
+    phys = cores
+    workers = cores
+    slice_sites = int(min(CPU_SLICE_SITES, wl["wind"]))
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or cores
+        # a worker holds its slice as Python strings + int64 alignment: ~160 B per genotype cell, plus the interpreter
+        per_worker = 160 * slice_sites * lay.n_hap // 2 + (1 << 28)
+        workers = max(1, min(workers, int(psutil.virtual_memory().available * 0.6 // per_worker)))
+    except Exception:
+        pass
+    workers = max(1, min(workers, max_workers, len(lo)))
+    sel = np.linspace(0, len(lo) - 1, workers).astype(int) if workers > 1 else np.array([0])
+    s_lo = lo[sel].copy()
+    s_hi = np.minimum(s_lo + slice_sites, hi[sel])
+    wall, busy, csvs, stats = _cpu_leg(eng, lay, wl, names, scaf_len, s_lo, s_hi, workers)
+    ok = _cpu_matches(wl, csvs, stats)
     n_slices = len(sel)
     sites_s = n_slices * slice_sites / wall
-    return {"value": round(sites_s / wl["wind"], 5), "unit": "windows/s", "sites_per_sec": round(sites_s, 1),
-            "cores": workers, "host_cores": cores, "kind": "port",
-            "sample": "%d slices of %d sites x %d haplotypes (the heads of %d evenly spaced windows of the workload), each rendered as "
+    # legs B and C: whole windows against their heads, on an otherwise idle host
+    n_whole = int(max(1, min(CPU_WHOLE_WINDOWS, phys, max_workers, len(lo))))
+    wsel = np.linspace(0, len(lo) - 1, n_whole).astype(int) if n_whole > 1 else np.array([0])
+    w_lo, w_hi = lo[wsel].copy(), hi[wsel].copy()
+    wall_b, busy_b, csv_b, stats_b = _cpu_leg(eng, lay, wl, names, scaf_len, w_lo, w_hi, n_whole)
+    wall_c, busy_c, csv_c, stats_c = _cpu_leg(eng, lay, wl, names, scaf_len, w_lo, np.minimum(w_lo + slice_sites, w_hi), n_whole)
+    ok = ok and _cpu_matches(wl, csv_b, stats_b) and _cpu_matches(wl, csv_c, stats_c)
+    per_site_whole = busy_b / float((w_hi - w_lo).sum())
+    per_site_slice = busy_c / float(n_whole * slice_sites)
+    ratio = per_site_whole / per_site_slice
+    return {"value": round(sites_s / wl["wind"] / ratio, 5), "unit": "windows/s", "sites_per_sec": round(sites_s / ratio, 1),
+            "cores": workers, "host_cores": cores, "host_cores_physical": phys, "kind": "port",
+            "sample": "A: %d slices of %d sites x %d haplotypes (the heads of %d evenly spaced windows of the workload), each rendered as "
                       ".geno text and run through the oracle's restatement of the reference's whole path (text parse -> window -> "
                       "genoToAlignment -> pair-by-pair loop -> statistics; popgenWindows.py:28-75, genomics.py:1884-1945, 1101-1127, "
-                      "903-916, 956-995), one slice per worker process, %d worker processes at once; sites/s is measured, windows/s = "
-                      "sites/s / %d sites per window (every stage of the reference is linear in the sites of a window)" % (
-                          n_slices, slice_sites, lay.n_hap, n_slices, workers, wl["wind"]),
-            "wall_seconds": round(wall, 2), "cpu_seconds": round(busy, 2), "gpu_matches_oracle_on_sample": bool(ok)}
+                      "903-916, 956-995), one slice per worker process, %d worker processes at once (one per hardware thread).  "
+                      "B: %d WHOLE windows of %d sites, one per worker, the rest of the host idle; C: the heads of the same windows as "
+                      "slices, same workers.  value = A's sites/s / %d sites per window / (B's seconds per site / C's seconds per "
+                      "site)" % (n_slices, slice_sites, lay.n_hap, n_slices, workers, n_whole, wl["wind"], wl["wind"]),
+            "all_threads_slices": {"workers": workers, "wall_seconds": round(wall, 2), "cpu_seconds": round(busy, 2),
+                                   "sites_per_sec": round(sites_s, 1)},
+            "whole_windows": {"workers": n_whole, "windows": n_whole, "wall_seconds": round(wall_b, 2), "cpu_seconds": round(busy_b, 2),
+                              "windows_per_sec": round(n_whole / wall_b, 5), "seconds_per_site_per_worker": per_site_whole},
+            "slices_same_workers": {"workers": n_whole, "wall_seconds": round(wall_c, 2), "cpu_seconds": round(busy_c, 2),
+                                    "seconds_per_site_per_worker": per_site_slice},
+            "whole_window_cost_relative_to_slices": round(ratio, 4),
+            "wall_seconds": round(wall + wall_b + wall_c, 2), "cpu_seconds": round(busy + busy_b + busy_c, 2),
+            "gpu_matches_oracle_on_sample": bool(ok)}
 
 
 def cpu_baseline_distmat(eng, lay, wl, lo, hi):
@@ -274,7 +311,9 @@ def tier_samples(eng, lay, wl, names, slot_gen, scaf_len, n_sites, t1_block, t0_
     for k, p in enumerate(lay.sampleData.popNames):
         cmd += ["-p", p, ",".join(names[k * per:(k + 1) * per])]
     try:
-        r = subprocess.run(cmd, env=dict(os.environ, PG_TIMING="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE, timeout=300)
+        # (PG_PLACE_TRIALS=1: the driver reserves its rows once, without the placement probes of a long-lived resident data set)
+        r = subprocess.run(cmd, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE,
+                           timeout=600)
         line = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")]
         tm = json.loads(line[-1][len("PG_TIMING "):])
         with open(csv) as f:
@@ -286,13 +325,17 @@ def tier_samples(eng, lay, wl, names, slot_gen, scaf_len, n_sites, t1_block, t0_
             for name, v in zip(head[5:], row[5:]):
                 g = t0_table[w, cols.index(name)]
                 same = same and (abs(float(v) - g) <= 1e-9 * max(1.0, abs(g)) or (g != g and float(v) != float(v)))
+        work_s = tm["total_s"] - tm.get("context_s", 0.0)
         out["t2"] = {"sites_per_sec": round(n_txt / tm["total_s"], 1), "windows_per_sec": round(len(rows) / tm["total_s"], 3),
                      "text_MBps": round(os.path.getsize(geno) / tm["total_s"] / 1e6, 1), "matches_t0": bool(same),
+                     "without_context_creation": {"seconds": round(work_s, 4), "sites_per_sec": round(n_txt / work_s, 1),
+                                                  "text_GBps": round(os.path.getsize(geno) / work_s / 1e9, 2)},
+                     "tokenizer_text_GBps": round(os.path.getsize(geno) / max(tm.get("tokenize_s", 0.0), 1e-9) / 1e9, 2),
                      "tokenizer": "device (pg_tokenize_text)" if tm.get("device_tokenizer") else "host threads (pg_encode_text)",
-                     "seconds": {k: round(tm[k], 4) for k in ("total_s", "read_s", "tokenize_s", "windows_s", "prep_wait_s",
+                     "seconds": {k: round(tm[k], 4) for k in ("total_s", "context_s", "read_s", "tokenize_s", "windows_s", "prep_wait_s",
                                                                "engine_and_upload_s", "compute_and_write_s") if k in tm},
                      "sample": "the first %d sites of the workload as %.0f MB of `.geno` text (%d windows) through popgenWindows.py, "
-                               "timed inside the driver (context creation ~0.1 s included, interpreter start excluded)" % (
+                               "timed inside the driver (total_s: context creation included, interpreter start excluded; the file is written before the clock starts)" % (
                                    n_txt, os.path.getsize(geno) / 1e6, len(rows))}
     except Exception as exc:                                    # the tiers are side information: never lose the main line
         out["t2"] = {"error": repr(exc)[:300]}
@@ -401,13 +444,17 @@ def main():
     # brackets only that family (an event record between two kernels costs a few microseconds of GPU idle time), and the
     # per-family breakdown reported next to it comes from the warm-up pass
     cand = [_lib.K_PACK, _lib.K_PAIRWISE, _lib.K_PAIRD] if wl["tool"] in ("popgen", "distmat") else [_lib.K_SITESTATS]
+    # (the finalisers and the copy of a large result table are bracketed in the breakdown pass, never "dominant": roofline is for kernels)
+    # (the warm-up steps keep their result tables alive exactly as the timed loop does: a large table lands in page-locked memory
+    # from a pool of two buffers, and the first DMA into a fresh page-locked buffer runs at a tenth of the PCIe rate)
+    st = _tab = None
     for _ in range(max(args.warmup - 1, 0)):
-        step()
+        st, _tab = step()
     eng.sync()
     eng.kernel_time_reset()
     n_warm = 0
     if args.warmup >= 1:                                   # the last warm-up step is the breakdown pass
-        step()
+        st, _tab = step()
         eng.sync()
         n_warm = 1
     kt = {name: eng.kernel_time(kid) for kid, name in _lib.KERNEL_NAMES.items()}
@@ -444,15 +491,20 @@ def main():
     n_hap = lay.n_hap
     roofline = None
     extra = {}
-    # rocprofv3's names of the kernel behind each family, for this workload
-    pack_name = "k_pack2" if (os.environ.get("PG_PACK2") or n_hap > 1024) else "k_pack3"
-    if os.environ.get("PG_PAIR_V1"):
-        rocprof_name = {_lib.K_PACK: "k_pack", _lib.K_PAIRWISE: "k_pairwise"}
+    # rocprofv3's names of the kernel behind each family, for this workload (the library's own choices, restated)
+    dip = lay.n_hap == 2 * lay.n_samp and not os.environ.get("PG_NO_DIP")
+    pack_name = "k_pack2" if (os.environ.get("PG_PACK2") or n_hap > 4096) else "k_pack3"
+    if os.environ.get("PG_PAIR_VALU"):
+        pair_c, pair_d = "k_pairC", "k_pairD"
     else:
-        # pair counts: matrix cores by default (MX fp4; int8 with PG_PAIR_I8), popcount kernels as A/B
-        sfx = "" if os.environ.get("PG_PAIR_VALU") else "_mfma" if os.environ.get("PG_PAIR_I8") else "_fp4"
-        rocprof_name = {_lib.K_PACK: pack_name, _lib.K_PAIRWISE: "k_pairC" + sfx, _lib.K_PAIRD: "k_pairD" + sfx,
-                        _lib.K_SITESTATS: "k_popfreq_q" if wl["tool"] == "popfreq" else "k_abba_q"}
+        # matrix cores: LDS-staged block kernels where the plane fits their ring (PG_PAIR_TILE, default "c"), else one wave per block
+        tile_sel = os.environ.get("PG_PAIR_TILE", "c")
+        np32 = (n_hap + 31) // 32 * 32
+        npv = (n_hap // 2 + 31) // 32 * 32 if dip else np32
+        pair_c = "k_pairC_tile" if ("c" in tile_sel and 3 * 4 * npv * 16 <= 65536) else "k_pairC_fp4"
+        pair_d = "k_pairD_tile" if ("d" in tile_sel and 3 * 4 * np32 * 8 <= 65536) else "k_pairD_fp4"
+    rocprof_name = {_lib.K_PACK: pack_name, _lib.K_PAIRWISE: pair_c, _lib.K_PAIRD: pair_d,
+                    _lib.K_SITESTATS: "k_popfreq_q" if wl["tool"] == "popfreq" else "k_abba_q"}
     pmc = {}
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
@@ -466,21 +518,19 @@ def main():
         launches_per_step = dom_n / args.steps
         kname = rocprof_name.get(dom_id, _lib.KERNEL_NAMES[dom_id])
         alg_bytes_launch = n_hap * sites_per_step / launches_per_step       # 1 byte per haplotype allele call
-        if dom_id in (_lib.K_PAIRWISE, _lib.K_PAIRD) and not os.environ.get("PG_PAIR_V1") and not os.environ.get("PG_PAIR_VALU"):
-            # pair kernel on the matrix cores: algorithmic int8 multiply-accumulates (k_pairC_mfma: unordered unit pairs incl. the
-            # diagonal x sites; k_pairD_mfma: two products per haplotype pair and virtual site, whose number only the device knows)
-            units = n_hap // 2 if (lay.n_hap == 2 * lay.n_samp and not os.environ.get("PG_NO_DIP")) else n_hap
+        if dom_id in (_lib.K_PAIRWISE, _lib.K_PAIRD) and not os.environ.get("PG_PAIR_VALU"):
+            # pair kernel on the matrix cores: algorithmic multiply-accumulates (called counts: unordered unit pairs incl. the
+            # diagonal x sites; differences: two products per haplotype pair and virtual site, whose number only the device knows)
+            units = n_hap // 2 if dip else n_hap
             macs = units * (units + 1) / 2 * sites_per_step / launches_per_step if dom_id == _lib.K_PAIRWISE else None
-            fp4 = not os.environ.get("PG_PAIR_I8")
-            peak = MFMA_FP4_PEAK_TFLOPS if fp4 else MFMA_I8_PEAK_TOPS
+            peak = MFMA_FP4_PEAK_TFLOPS
             roofline = {"kernel": kname, "bound": "mfma", "unit": "TFLOP/s", "peak": peak,
-                        "peak_source": ("MX fp4 dense (MI355X_MICROARCH.md: ~10 PF; measured ceiling there 9099)" if fp4 else
-                                        "int8 dense = 2 x the bf16 dense peak (MI355X_MICROARCH.md; measured ceiling there: 4404)"),
+                        "peak_source": "MX fp4 dense (MI355X_MICROARCH.md: ~10 PF; measured ceiling there 9099)",
                         "achieved": round(2 * macs / per_launch_s / 1e12, 2) if macs else None,
                         "frac": round(2 * macs / per_launch_s / 1e12 / peak, 5) if macs else None,
                         "algorithmic_macs_per_launch": macs, "traffic": pmc.get(args.workload, {}).get(kname),
                         "avg_launch_ms": round(dom_ms / dom_n, 4), "launches": int(dom_n)}
-        elif dom_id in (_lib.K_PAIRWISE, _lib.K_PAIRD) and not os.environ.get("PG_PAIR_V1"):
+        elif dom_id in (_lib.K_PAIRWISE, _lib.K_PAIRD):
             # VALU-bound pair kernel: wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU), live launch time
             insts = pmc.get("_valu", {}).get(args.workload, {}).get(kname)
             peak_meas = pmc.get("_valu_peak_measured", {}).get(kname)
@@ -507,7 +557,6 @@ def main():
             extra["pair_kernels"] = {"ms_per_step": round(pair_ms, 4), "algorithmic_pair_sites_per_s": pair_sites / (pair_ms / 1e3),
                                      "naive_valu_bound": VALU_PAIRSITES_PEAK,
                                      "engine": ("VALU popcount (PG_PAIR_VALU)" if os.environ.get("PG_PAIR_VALU") else
-                                                "int8 MFMA on the bit planes (PG_PAIR_I8)" if os.environ.get("PG_PAIR_I8") else
                                                 "MX fp4 MFMA on the bit planes (exact: parts below 2^23 sites, integer atomics between parts)"),
                                      "note": "pair-count kernels C + D together vs SURVEY 8d's 7-lane-op-per-32-pair-sites VALU bound; "
                                              "polymorphic-site compaction and per-individual called counts do less work than that, "

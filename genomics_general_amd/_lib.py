@@ -22,9 +22,10 @@ class PopgenError(RuntimeError):
 
 PG_ERR_ARG, PG_ERR_HIP, PG_ERR_NODEV, PG_ERR_PARSE, PG_ERR_RCCL, PG_ERR_STATE = -1, -2, -3, -4, -5, -6
 FMT = {"phased": 0, "pairs": 1, "haplo": 2, "diplo": 3}
-K_PACK, K_PAIRWISE, K_POPDIST_FIN, K_SITESTATS, K_SYNTH, K_PAIRD = 0, 1, 2, 3, 4, 5
+K_PACK, K_PAIRWISE, K_POPDIST_FIN, K_SITESTATS, K_SYNTH, K_PAIRD, K_INDPAIR_FIN, K_RESULT_D2H = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_NAMES = {K_PACK: "k_pack", K_PAIRWISE: "k_pairC", K_POPDIST_FIN: "k_popdist_fin",
-                K_SITESTATS: "k_sitestats", K_SYNTH: "k_synth", K_PAIRD: "k_pairD"}
+                K_SITESTATS: "k_sitestats", K_SYNTH: "k_synth", K_PAIRD: "k_pairD", K_INDPAIR_FIN: "k_indpair_fin",
+                K_RESULT_D2H: "result_d2h"}
 
 _lib = None
 

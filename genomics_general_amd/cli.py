@@ -185,6 +185,7 @@ class Run:
         self.engine = Engine(dev)
         self.engine.set_layout(self.layout)
         self.comm = dist.make_comm(self.engine, self.world)
+        self.timing["context_s"] = time.perf_counter() - t0          # device context, streams, communicator (part of engine_and_upload_s)
         self.timing["engine_and_upload_s"] += time.perf_counter() - t0
         self.n_tested = 0
         # Multi-GPU ingestion.  Sharded (a driver that writes its rows through open_sink(), coordinate or sites windows, plain
@@ -515,8 +516,8 @@ class Run:
             return np.asarray(table, dtype=np.float64)
         return dist.gather_table(self.comm, table, self.T.n)
 
-    def open_sink(self, path, header_text, id_column=False):
-        return _RowSink(self, path, header_text, id_column)
+    def open_sink(self, path, header_text, id_column=False, id_sep=","):
+        return _RowSink(self, path, header_text, id_column, id_sep)
 
 
 class _RowSink:
@@ -526,8 +527,8 @@ class _RowSink:
     popgenWindows.py:108-157.  Window IDs count the windows of the whole input (genomics.py:2011): the ranks' local IDs are
     shifted by the number of windows of the ranks before them."""
 
-    def __init__(self, run, path, header_text, id_column):
-        self.run, self.id_column = run, id_column
+    def __init__(self, run, path, header_text, id_column, id_sep=","):
+        self.run, self.id_column, self.id_sep = run, id_column, id_sep
         self.local = run.sharded or run.world.rank == 0
         self.rows, self.written = [], 0
         self.out = None
@@ -550,7 +551,8 @@ class _RowSink:
             counts = run.comm.allgather(np.array([float(run.n_tested), float(self.written)])).reshape(run.world.size, 2)
             if self.id_column and run.world.rank > 0:
                 shift = int(counts[:run.world.rank, 0].sum())
-                self.rows = [str(int(r[:r.index(",")]) + shift) + r[r.index(","):] for r in self.rows]
+                sep = self.id_sep
+                self.rows = [str(int(r[:r.index(sep)]) + shift) + r[r.index(sep):] for r in self.rows]
             parts = dist.gather_bytes(run.comm, "".join(self.rows).encode() if run.world.rank > 0 else b"")
             if self.out is not None:
                 for part in parts[1:]:
@@ -875,8 +877,10 @@ def distmat_main(argv=None):
         T.mid = [float("nan")]
         return T
 
+    # (coordinate and sites windows: the input is sharded over the ranks at scaffold-run boundaries like popgenWindows.py's, every
+    # rank formats the matrices of its own windows, one gather per output file at the end: distMat.py:28-60, 284-289)
     run = Run(args, sampleData, wp, minSites, header_line=header_line, coords_keep=3,
-              windows_fn=cat_window if args.windType == "cat" else None, stream=True)
+              windows_fn=cat_window if args.windType == "cat" else None, stream=True, shardable=True)
     lay = run.layout
     n = len(samples)
     npairs = n * (n + 1) // 2
@@ -886,14 +890,10 @@ def distmat_main(argv=None):
     iu = np.triu_indices(n)
     a, b = np.minimum(si[iu[0]], si[iu[1]]), np.maximum(si[iu[0]], si[iu[1]])
     pair_col = a * n - a * (a - 1) // 2 + (b - a)
-    out = wout = None
-    if run.world.rank == 0:
-        out = _open_out(args.outFile)
-        if args.windowDataOutFile:
-            wout = _open_out(args.windowDataOutFile)
-            # the reference writes this header without a newline and tab-separated rows after it (distMat.py:238-239, 58)
-            wout.write(("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites,")
-    written = 0
+    out = run.open_sink(args.outFile, "")
+    # the reference writes the side file's header without a newline and tab-separated rows after it (distMat.py:238-239, 58)
+    wout = (run.open_sink(args.windowDataOutFile, ("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites,",
+                          id_column=args.addWindowID, id_sep="\t") if args.windowDataOutFile else None)
     last = None                          # (ok, matrix text, window-data text) of the previously emitted window (dup rows)
     for _ in run.chunks():
         T = run.T
@@ -909,7 +909,7 @@ def distmat_main(argv=None):
             tab = wb.indPairTable(includeSameWithSame=args.includeSameWithSame)
             table[good, :npairs] = tab[:, pair_col]
         full = run.gather(table)
-        if run.world.rank != 0:
+        if not out.local:
             continue
         for k in range(T.n):
             if T.dup[k]:
@@ -929,12 +929,11 @@ def distmat_main(argv=None):
             out.write(mtext)
             if wout is not None:
                 wout.write(wtext)
-            written += 1
+    tested, written = out.close()
+    if wout is not None:
+        wout.close()
     if run.world.rank == 0:
-        for f in (out, wout):
-            if f is not None and f is not sys.stdout:
-                f.close()
-        sys.stderr.write("{} windows were tested.\n{} results were written.\n\n### Done. ###\n".format(run.n_tested, written))
+        sys.stderr.write("{} windows were tested.\n{} results were written.\n\n### Done. ###\n".format(tested, written))
     run.report_timing()
     run.comm.barrier()
     return 0

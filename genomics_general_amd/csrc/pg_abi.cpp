@@ -123,7 +123,6 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->hap_pop.release();
     c->pop_start.release();
     c->samp_start.release();
-    c->tasks.release();
     c->tasks2.release();
     c->tasksC.release();
     c->tasksCh.release();
@@ -137,7 +136,6 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->site_tmp.release();
     c->Vp.release();
     c->XY.release();
-    c->planes.release();
     c->Cmat.release();
     c->Dmat.release();
     c->win.release();
@@ -248,24 +246,9 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
     c->n_samp = (int)sstart.size() - 1;
     c->S = (n_hap + 15) / 16 * 16;
     // plane stride: 32 haplotypes (one tile of the matrix-core pair kernels); the popcount kernels work on 64-lane column chunks
-    c->NP = (getenv("PG_PAIR_VALU") || getenv("PG_PAIR_V1")) ? (n_hap + 63) / 64 * 64 : (n_hap + 31) / 32 * 32;
+    c->NP = getenv("PG_PAIR_VALU") ? (n_hap + 63) / 64 * 64 : (n_hap + 31) / 32 * 32;
     c->h_pop_start = pstart;
     c->h_samp_start = sstart;
-    // pair-kernel task table: column chunk of 64 x row sub-tiles of 8 strictly above the chunk's last column
-    std::vector<PgPairTask> tasks;
-    for (int col0 = 0; col0 < n_hap; col0 += 64) {
-        int jmax = std::min(col0 + 63, n_hap - 1);
-        int nsub_total = (jmax + 7) / 8;                 // rows 0 .. jmax-1
-        for (int s = 0; s < nsub_total; s += 4) {
-            PgPairTask t;
-            t.row0 = 8 * s;
-            t.nsub = std::min(4, nsub_total - s);
-            t.col0 = col0;
-            t.pad = 0;
-            tasks.push_back(t);
-        }
-    }
-    c->n_tasks = (int)tasks.size();
     std::vector<PgTask2> tasks2 = pg_make_tasks_circ(n_hap, 16);       // k_pairD: 16-row circulant tasks
     c->n_tasks2 = (int)tasks2.size();
     c->all_diploid = (n_hap % 2 == 0);
@@ -280,7 +263,6 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
     if ((rc = c->hap_pop.upload(hap_pop, n_hap, c->stream)) != PG_OK) return rc;
     if ((rc = c->pop_start.upload(pstart.data(), pstart.size(), c->stream)) != PG_OK) return rc;
     if ((rc = c->samp_start.upload(sstart.data(), sstart.size(), c->stream)) != PG_OK) return rc;
-    if (!tasks.empty() && (rc = c->tasks.upload(tasks.data(), tasks.size(), c->stream)) != PG_OK) return rc;
     if (!tasks2.empty() && (rc = c->tasks2.upload(tasks2.data(), tasks2.size(), c->stream)) != PG_OK) return rc;
     if (!tasksC.empty() && (rc = c->tasksC.upload(tasksC.data(), tasksC.size(), c->stream)) != PG_OK) return rc;
     if (!tasksCh.empty() && (rc = c->tasksCh.upload(tasksCh.data(), tasksCh.size(), c->stream)) != PG_OK) return rc;
@@ -585,59 +567,12 @@ static int stage_windows(pg_ctx *c, const int64_t *lo, const int64_t *hi, int w0
     return PG_OK;
 }
 
-static bool use_v2(const pg_ctx *c) { (void)c; return getenv("PG_PAIR_V1") == nullptr; }
-
-// v1 path (first-generation 7-op kernel, kept as an A/B reference: PG_PAIR_V1=1): pack + k_pairwise, one batch after the
-// other on ctx->stream.
-template <class F>
-static int pairwise_batches_v1(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, F consume) {
-    const int N = c->n_hap, NP = c->NP;
-    c->cN = N;
-    c->cshift = 0;
-    const int64_t mat_bytes = 8ll * N * N;
-    const int64_t word_bytes = (int64_t)NP * 4 * 5;
-    int w0 = 0;
-    while (w0 < n_win) {
-        int64_t words = 0;
-        int w1 = w0;
-        while (w1 < n_win) {
-            int64_t wlen = (hi[w1] - lo[w1] + 31) / 32;
-            int64_t nb = (words + wlen) * word_bytes + (int64_t)(w1 - w0 + 1) * mat_bytes;
-            if (w1 > w0 && nb > c->scratch_limit) break;
-            words += wlen;
-            ++w1;
-            if (w1 - w0 >= 65535) break;
-        }
-        const int nb = w1 - w0;
-        int rc;
-        if ((rc = c->Cmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
-        if ((rc = c->Dmat.ensure((size_t)nb * N * N)) != PG_OK) return rc;
-        hipEvent_t e0, e1;
-        int64_t total_words = 0, max_len = 0;
-        int max_words = 0;
-        if ((rc = stage_windows(c, lo, hi, w0, w1, &total_words, &max_words, &max_len)) != PG_OK) return rc;
-        const int64_t *d_lo = c->win.p, *d_hi = c->win.p + nb, *d_woff = c->win.p + 2 * (size_t)nb;
-        if ((rc = c->planes.ensure((size_t)std::max<int64_t>(total_words, 1) * 5 * NP)) != PG_OK) return rc;
-        if ((rc = pg_time_begin(c, PG_K_PACK, &e0, &e1)) != PG_OK) return rc;
-        pg_launch_pack(c->stream, c->gt.p, c->S, d_lo, d_hi, d_woff, nb, max_words, c->planes.p, NP);
-        if ((rc = pg_time_end(c, PG_K_PACK, e0, e1, 1)) != PG_OK) return rc;
-        if ((rc = pg_time_begin(c, PG_K_PAIRWISE, &e0, &e1)) != PG_OK) return rc;
-        pg_launch_pairwise(c->stream, c->planes.p, d_woff, nb, c->tasks.p, c->n_tasks, NP, N, c->Cmat.p, c->Dmat.p);
-        if ((rc = pg_time_end(c, PG_K_PAIRWISE, e0, e1, 1)) != PG_OK) return rc;
-        HIPCHK(hipGetLastError());
-        if ((rc = consume(w0, nb)) != PG_OK) return rc;
-        w0 = w1;
-    }
-    return PG_OK;
-}
-
-// v2 path.  Windows are cut into sub-batches; k_pack2 of sub-batch k+1 runs on ctx->stream2 while k_pairC / k_pairD and
+// Windows are cut into sub-batches; k_pack2 of sub-batch k+1 runs on ctx->stream2 while k_pairC / k_pairD and
 // `consume` of sub-batch k run on ctx->stream (two slots of planes).  `consume(batch_w0, batch_n)` is called with the
 // batch's matrices queued on ctx->stream: D in ctx->Dmat ([N][N] per window, upper triangle) and the called counts in
 // ctx->Cmat ([cN][cN] per window, upper triangle, entry of haplotypes (i,j) at (i>>cshift, j>>cshift)).
 template <class F>
 static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, bool dip, F consume) {
-    if (!use_v2(c)) return pairwise_batches_v1(c, lo, hi, n_win, consume);
     const int N = c->n_hap, NP = c->NP;
     const int n_units = dip ? N / 2 : N;
     const int NPv = dip ? (NP % 64 ? (n_units + 31) / 32 * 32 : (n_units + 63) / 64 * 64) : NP;
@@ -700,10 +635,10 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
             HIPCHK(hipEventSynchronize(sl.packed));
         }
         // stage [lo | hi | goff(n+1) | vgoff(n+1) | nw]: nw = int32 word counters of k_pack2, zero per window (and, in the
-        // > 1024-slot mode, one slot per group for k_word_scan) -- they ride in the same copy instead of a memset
+        // presence-pre-pass mode, one slot per group for k_word_scan) -- they ride in the same copy instead of a memset
         int64_t ga_pre = 0;
         for (int k = 0; k < nb; ++k) ga_pre += ((hi[w0 + k] - lo[w0 + k] + 31) / 32 + grp - 1) / grp;
-        const size_t n_nw = (size_t)nb + (NP > 1024 ? (size_t)ga_pre : 0);
+        const size_t n_nw = (size_t)nb + (pg_pack_needs_presence(NP) ? (size_t)ga_pre : 0);
         const size_t h_len = 4 * (size_t)nb + 2 + (n_nw + 1) / 2;
         if ((rc = sl.host.ensure(h_len)) != PG_OK) return rc;
         int64_t *h = sl.host.p;
@@ -740,7 +675,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
             if ((rc = event_get(c, &e1)) != PG_OK) return rc;
             HIPCHK(hipEventRecord(e0, ps));
         }
-        if (NP > 1024 && (rc = sl.pres.ensure((size_t)std::max<int64_t>(ga, 1) * grp * 4)) != PG_OK) return rc;
+        if (pg_pack_needs_presence(NP) && (rc = sl.pres.ensure((size_t)std::max<int64_t>(ga, 1) * grp * 4)) != PG_OK) return rc;
         pg_launch_pack2(ps, c->gt.p, c->S, d_lo, d_hi, d_goff, d_vgoff, nb, max_groups, ga, sl.Vp.p, NPv, sl.XV.p, NP,
                         d_nw, dip ? 1 : 0, c->flag.p, sl.pres.p, capg, grp);
         if (time_pack) {
@@ -755,6 +690,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         // the pair counts run on the matrix cores (exact products of the bit planes, pg_pair_mfma.hip: MX fp4, or int8 with
         // PG_PAIR_I8=1); PG_PAIR_VALU=1 keeps the popcount kernels (A/B runs, tests)
         const bool valu_pairs = getenv("PG_PAIR_VALU") != nullptr;
+        if (valu_pairs && NP % 64) return pg_fail(PG_ERR_STATE, "PG_PAIR_VALU must be set before pg_set_samples (plane stride %d)", NP);
         if (!valu_pairs && pg_pair_tile_fits(NPv, 0)) {
             if (pg_launch_pairC_tile(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p))
                 return pg_fail(PG_ERR_HIP, "pair-kernel program upload failed");
@@ -834,12 +770,11 @@ static int note_flags(pg_ctx *c, int flag, bool *dip, bool *again) {
 
 template <class F>
 static int pairwise_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, F consume) {
-    bool dip = use_v2(c) && c->all_diploid && getenv("PG_NO_DIP") == nullptr;
+    bool dip = c->all_diploid && getenv("PG_NO_DIP") == nullptr;
     int rc;
     if ((rc = flag_ready(c)) != PG_OK) return rc;
     for (;;) {
         if ((rc = pairwise_batches(c, lo, hi, n_win, dip, consume)) != PG_OK) return rc;
-        if (!use_v2(c)) return PG_OK;
         int32_t flag = 0;
         HIPCHK(hipMemcpyAsync(&flag, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemsetAsync(c->flag.p, 0, 4, c->stream));
@@ -869,7 +804,7 @@ extern "C" int pg_reserve_sites_tuned(pg_ctx *c, int64_t n_sites, int max_trials
     const size_t bytes = (size_t)(n_sites + 32) * c->S;
     if (max_trials > 8) max_trials = 8;
     int trials = 1;
-    if (use_v2(c) && c->n_hap <= 4096 && bytes >= ((size_t)4 << 30) && max_trials > 1) {
+    if (c->n_hap <= 4096 && bytes >= ((size_t)4 << 30) && max_trials > 1) {
         HIPCHK(hipStreamSynchronize(c->stream_up));
         c->up_pending = false;
         c->gt.release();                                   // (as in pg_reserve_sites: growing drops the rows)
@@ -1006,7 +941,7 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
         HIPCHK(hipGetLastError());
         return PG_OK;
     };
-    bool dip = use_v2(c) && c->all_diploid && getenv("PG_NO_DIP") == nullptr;
+    bool dip = c->all_diploid && getenv("PG_NO_DIP") == nullptr;
     const size_t n_out = (size_t)n_win * ncols;
     if ((rc = c->out_pin.ensure(n_out + 1)) != PG_OK) return rc;
     // one device-to-host copy (into pinned memory) and one synchronisation per pass: the flag word of the pack kernels (diploid
@@ -1017,7 +952,7 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
         HIPCHK(hipMemcpyAsync(c->out_pin.p, c->stats.p, (n_out + 1) * 8, hipMemcpyDeviceToHost, c->stream));
         if ((rc = stream_wait(c)) != PG_OK) return rc;
         bool again;
-        if ((rc = note_flags(c, use_v2(c) ? (int)c->out_pin.p[n_out] : 0, &dip, &again)) != PG_OK) return rc;
+        if ((rc = note_flags(c, (int)c->out_pin.p[n_out], &dip, &again)) != PG_OK) return rc;
         if (again) continue;
         memcpy(stats_out, c->out_pin.p, n_out * 8);
         return PG_OK;
@@ -1036,12 +971,18 @@ static int indpair_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_wi
         int r;
         if ((r = c->res_f64.ensure((size_t)nb * npairs)) != PG_OK) return r;
         if (mean_mode == 0 && (r = c->res_i64.ensure((size_t)nb * npairs)) != PG_OK) return r;
+        hipEvent_t e0, e1;
+        if ((r = pg_time_begin(c, PG_K_INDPAIR_FIN, &e0, &e1)) != PG_OK) return r;
         pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->samp_start.p, c->n_samp, min_pair_sites,
                               c->res_f64.p, c->res_i64.p, mean_mode);
+        if ((r = pg_time_end(c, PG_K_INDPAIR_FIN, e0, e1, 1)) != PG_OK) return r;
         HIPCHK(hipGetLastError());
+        // (the table can be tens of megabytes -- 40 MB per distMat pass over 1000 diploids --: PCIe time, timed as its own family)
+        if ((r = pg_time_begin(c, PG_K_RESULT_D2H, &e0, &e1)) != PG_OK) return r;
         HIPCHK(hipMemcpyAsync(sum_out + (size_t)w0 * npairs, c->res_f64.p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->stream));
         if (mean_mode == 0)
             HIPCHK(hipMemcpyAsync(cnt_out + (size_t)w0 * npairs, c->res_i64.p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->stream));
+        if ((r = pg_time_end(c, PG_K_RESULT_D2H, e0, e1, 1)) != PG_OK) return r;
         HIPCHK(hipStreamSynchronize(c->stream));
         return PG_OK;
     });

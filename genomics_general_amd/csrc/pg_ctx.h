@@ -79,11 +79,9 @@ struct pg_ctx {
     // samples
     int n_hap = 0, n_pops = 0, n_samp = 0;
     int S = 0;    // bytes per site row of the resident buffer (multiple of 16, pad = 0)
-    int NP = 0;   // haplotype stride of the bit-planes (multiple of 64, pad = 0)
-    int n_tasks = 0;
+    int NP = 0;   // haplotype stride of the bit-planes (multiple of 32; of 64 for the popcount kernels)
     std::vector<int32_t> h_pop_start, h_samp_start;
     DevBuf<int32_t> hap_pop, pop_start, samp_start, slot_gen;
-    DevBuf<PgPairTask> tasks;
     DevBuf<PgTask2> tasks2;      // v2 pair kernels (haplotype units)
     int n_tasks2 = 0;
     DevBuf<PgTask2> tasksC;      // v2 k_pairC when its units are diploid individuals (diagonal included)
@@ -128,7 +126,6 @@ struct pg_ctx {
     int64_t cap_sites = 0;
     // scratch
     int64_t scratch_limit = 48ll << 30;
-    DevBuf<uint32_t> planes;
     DevBuf<int32_t> Cmat, Dmat;
     DevBuf<int64_t> win;        // [lo | hi | woff]
     DevBuf<double> res_f64, part_f64, stats;
@@ -140,8 +137,8 @@ struct pg_ctx {
     // timing
     uint32_t time_mask = 0xFFFFFFFFu;   // bit k: kernel family k is bracketed by HIP events (pg_kernel_time_select)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[PG_K_COUNT_];
-    double acc_ms[PG_K_COUNT_] = {0, 0, 0, 0, 0, 0};
-    int64_t acc_launches[PG_K_COUNT_] = {0, 0, 0, 0, 0, 0};
+    double acc_ms[PG_K_COUNT_] = {};
+    int64_t acc_launches[PG_K_COUNT_] = {};
     // RCCL (opaque here)
     void *comm = nullptr;
     int comm_ranks = 0, comm_rank = 0;

@@ -11,10 +11,6 @@
 #define PG_FOURPOP_NSUM 14
 #define PG_XV_PLANES 2        // planes per word of virtual biallelic sites: x ("carries the tested allele"), v (called, not excluded)
 
-struct PgPairTask {             // one wave of the pairwise kernel: rows [row0,row0+8*nsub) x cols [col0,col0+64)
-    int32_t row0, nsub, col0, pad;
-};
-
 // Input words (of 32 sites) per compaction group of the pack kernels = per block: 64 (2048 sites), or 128 when that still leaves
 // the chip several times oversubscribed with blocks (pg_pick_group): larger groups end in fewer partial XV words (k_pairD's work)
 // and amortise a block's start-up; measured on the north-star shape (50 000 -> 25 000 two-wave blocks): k_pack3 -5 %, k_pairD
@@ -44,12 +40,6 @@ struct PgSynthParams {
 void pg_launch_synth(hipStream_t st, int8_t *gt, int S, int n_hap, int64_t site0, int64_t n_sites,
                      const int32_t *slot_gen_hap, PgSynthParams p);
 
-void pg_launch_pack(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
-                    const int64_t *woff, int n_win, int max_words, uint32_t *planes, int NP);
-
-void pg_launch_pairwise(hipStream_t st, const uint32_t *planes, const int64_t *woff, int n_win,
-                        const PgPairTask *tasks, int n_tasks, int NP, int N, int32_t *Cmat, int32_t *Dmat);
-
 void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *pop_start, int n_pops, int min_pair_sites, double *sum_out,
                            int64_t *cnt_out);
@@ -74,17 +64,18 @@ void pg_launch_site_counts(hipStream_t st, const int8_t *gt, int S, int64_t site
 void pg_launch_hap_called(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
                           const int64_t *win_hi, int n_win, int max_chunks, unsigned long long *out);
 
-// ---- v2 pairwise pipeline (pg_pair2.hip) ---------------------------------------------------------------
+// ---- pairwise pipeline (pg_pair2.hip) ---------------------------------------------------------------
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                      const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, int64_t total_groups, uint32_t *Vp,
                      int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres, int capg, int grp);
+bool pg_pack_needs_presence(int NP);
 void pg_launch_expand(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                       int32_t *Cfull, int32_t *Dfull);
 void pg_launch_pairC(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, const PgTask2 *tasks, int n_tasks,
                      int NPv, int n_units, int diag, int64_t avg_wq, int32_t *Cmat);
 void pg_launch_pairD(hipStream_t st, const uint32_t *XY, const int32_t *nw, const int64_t *goff, int n_win,
                      const PgTask2 *tasks, int n_tasks, int NP, int N, int64_t avg_groups, int32_t *Dmat, int capg);
-// the same counts on the matrix cores (pg_pair_mfma.hip): exact int8 x int8 -> int32 products of the bit planes, expanded in registers
+// the same counts on the matrix cores (pg_pair_mfma.hip): exact MX fp4 products of the bit planes, expanded in registers, one wave per block
 void pg_launch_pairC_mfma(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, int NPv, int n_units, int diag,
                           int64_t avg_wq, int64_t max_sites, int32_t *Cmat);
 void pg_launch_pairD_mfma(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win, int NP, int N,

@@ -1,8 +1,7 @@
-// Hand-written gfx950 (CDNA4, wave64) kernels of the per-window statistics path (the v2 pairwise kernels are in pg_pair2.hip).
+// Hand-written gfx950 (CDNA4, wave64) kernels of the per-window statistics path (the pack + pairwise kernels are in pg_pair2.hip,
+// pg_pair_mfma.hip and pg_pair_tile.hip).
 //
 //   k_synth          counter-based synthetic genotype generator (spec: genomics_general_amd/synth.py)
-//   k_pack / k_pairwise   first-generation pairwise path (5 bit-planes per word, 7 VALU per 32 pair-sites), kept as the A/B
-//                    reference of the v2 pipeline (PG_PAIR_V1=1)
 //   k_popdist_fin, k_popstats   D,C -> per population-pair float64 sums of D/C + valid-pair counts -> pi / dxy / Fst
 //                    (genomics.py:956-995, 88-90)
 //   k_indpair_fin    D,C -> per individual-pair sums / counts or finished nanmeans (genomics.py:934-954)
@@ -88,182 +87,6 @@ void pg_launch_synth(hipStream_t st, int8_t *gt, int S, int n_hap, int64_t site0
         q.first_site_index = p.first_site_index + a;
         hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, st, gt, S, n_hap, site0 + a, n, slot_gen_hap, q);
     }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// K_pack: 32 sites x 4 haplotypes per thread, SWAR bit gathering.
-//   gt row = S bytes (S % 16 == 0, pad bytes zero).  A thread owns haplotypes 4g..4g+3 and builds, for each
-//   of the four allele planes, the 32-site word of each of its haplotypes.  Bit order inside a word is
-//   arbitrary but identical for every haplotype, which is all popcount needs.  Tail sites of a window are
-//   zero bits (not called) so they contribute to neither C nor D.
-//   planes[(woff[b]+w)*5*NP + p*NP + h], p = 0..3 allele planes, 4 = valid (called) plane.
-// ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t byte_gather(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, int k) {
-    return ((a0 >> (8 * k)) & 0xFFu) | (((a1 >> (8 * k)) & 0xFFu) << 8) | (((a2 >> (8 * k)) & 0xFFu) << 16) |
-           (((a3 >> (8 * k)) & 0xFFu) << 24);
-}
-
-template <int TPW>
-__global__ __launch_bounds__(256) void k_pack(const int8_t *__restrict__ gt, int S,
-                                              const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
-                                              const int64_t *__restrict__ woff, uint32_t *__restrict__ planes, int NP) {
-    constexpr int WPB = 256 / TPW;                       // words per block
-    const int b = blockIdx.y;
-    const int64_t lo = win_lo[b], hi = win_hi[b];
-    const int nwords = (int)(woff[b + 1] - woff[b]);
-    const int w = blockIdx.x * WPB + threadIdx.x / TPW;
-    if (w >= nwords) return;
-    const int t = threadIdx.x % TPW;
-    const int64_t s0 = lo + 32ll * w;
-    const int ns = (int)((hi - s0) < 32 ? (hi - s0) : 32);
-    uint32_t *outw = planes + (size_t)(woff[b] + w) * 5u * (size_t)NP;
-    const int ngroups = NP >> 2;
-    for (int g = t; g < ngroups; g += TPW) {
-        uint32_t acc[4][4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[p][q] = 0u;
-        if (4 * g < S) {
-            const int8_t *src = gt + s0 * (int64_t)S + 4 * g;
-            if (ns == 32) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t d[8];
-#pragma unroll
-                    for (int s = 0; s < 8; ++s)
-                        d[s] = *reinterpret_cast<const uint32_t *>(src + (int64_t)(q * 8 + s) * S);
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) acc[p][q] = (acc[p][q] << 1) | ((d[s] >> p) & 0x01010101u);
-                    }
-                }
-            } else {
-                for (int si = 0; si < ns; ++si) {
-                    uint32_t d = *reinterpret_cast<const uint32_t *>(src + (int64_t)si * S);
-                    int q = si >> 3;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        uint32_t bit = (d >> p) & 0x01010101u;
-#pragma unroll
-                        for (int qq = 0; qq < 4; ++qq)
-                            if (qq == q) acc[p][qq] = (acc[p][qq] << 1) | bit;
-                    }
-                }
-            }
-        }
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            uint4 o;
-            o.x = byte_gather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], 0);
-            o.y = byte_gather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], 1);
-            o.z = byte_gather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], 2);
-            o.w = byte_gather(acc[p][0], acc[p][1], acc[p][2], acc[p][3], 3);
-            v.x |= o.x; v.y |= o.y; v.z |= o.z; v.w |= o.w;
-            *reinterpret_cast<uint4 *>(outw + (size_t)p * NP + 4 * g) = o;
-        }
-        *reinterpret_cast<uint4 *>(outw + (size_t)4 * NP + 4 * g) = v;
-    }
-}
-
-void pg_launch_pack(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
-                    const int64_t *woff, int n_win, int max_words, uint32_t *planes, int NP) {
-    if (n_win <= 0 || max_words <= 0) return;
-    int groups = NP >> 2;
-    if (groups <= 64) {
-        hipLaunchKernelGGL(k_pack<64>, dim3((max_words + 3) / 4, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi, woff, planes, NP);
-    } else if (groups <= 128) {
-        hipLaunchKernelGGL(k_pack<128>, dim3((max_words + 1) / 2, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi, woff, planes, NP);
-    } else {
-        hipLaunchKernelGGL(k_pack<256>, dim3(max_words, n_win), dim3(256), 0, st, gt, S, win_lo, win_hi, woff, planes, NP);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// K_pairwise.  One wave = rows [row0, row0+8*NSUB) x 64 columns of one window.
-//   Column (j) operands: one VGPR per plane per lane, coalesced 256-byte loads (hap-minor layout).
-//   Row (i) operands: wave-uniform -> scalar loads into SGPRs, used directly as VALU source operands, so the
-//   row side costs no vector memory traffic, no LDS and no VGPRs.
-//   Per (row, word): v_and + v_bcnt (C) ; v_and + 3 x v_and_or + v_bcnt (same-allele) = 7 VALU for 32 sites
-//   of 64 pairs.  D = C - same.  Accumulators: 2 x 8*NSUB VGPRs.
-//   Grid is 1-D and XCD-aware: hardware places block b on XCD b % 8; all waves of one window are given to
-//   the same XCD so the window's planes are fetched from HBM once into that XCD's L2 and re-read from there.
-// ------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(4))) const uint32_t CU32;
-
-template <int NSUB>
-__device__ __forceinline__ void pair_body(const uint32_t *__restrict__ base, int nwords, int NP, int row0, int j,
-                                          int lane_valid, int N, int col_j, int32_t *__restrict__ Cw,
-                                          int32_t *__restrict__ Dw) {
-    constexpr int R = 8 * NSUB;
-    uint32_t accC[R], accS[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { accC[r] = 0u; accS[r] = 0u; }
-    const size_t wstride = (size_t)5 * NP;
-    for (int w = 0; w < nwords; ++w) {
-        const uint32_t *pw = base + (size_t)w * wstride;
-        const uint32_t ja = pw[j], jc = pw[NP + j], jg = pw[2 * NP + j], jt = pw[3 * NP + j], jv = pw[4 * NP + j];
-        // wave-uniform address in the constant address space -> s_load_dwordx8 into SGPRs
-        const CU32 *pr = (const CU32 *)(pw + row0);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t ia = pr[r], ic = pr[NP + r], ig = pr[2 * NP + r], it = pr[3 * NP + r], iv = pr[4 * NP + r];
-            accC[r] += __popc(iv & jv);
-            accS[r] += __popc((ia & ja) | (ic & jc) | (ig & jg) | (it & jt));
-        }
-    }
-    if (lane_valid) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = row0 + r;
-            if (i < col_j && i < N) {
-                Cw[(size_t)i * N + col_j] = (int32_t)accC[r];
-                Dw[(size_t)i * N + col_j] = (int32_t)(accC[r] - accS[r]);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_pairwise(const uint32_t *__restrict__ planes, const int64_t *__restrict__ woff,
-                                                  int n_win, const PgPairTask *__restrict__ tasks, int n_tasks,
-                                                  int tasks_wg, int NP, int N, int32_t *__restrict__ Cmat,
-                                                  int32_t *__restrict__ Dmat) {
-    const int xcd = blockIdx.x & 7;
-    const int v = blockIdx.x >> 3;
-    const int win = (v / tasks_wg) * 8 + xcd;
-    if (win >= n_win) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int t = (v % tasks_wg) * 4 + wave;
-    if (t >= n_tasks) return;
-    const PgPairTask tk = tasks[t];
-    const int row0 = __builtin_amdgcn_readfirstlane(tk.row0);
-    const int nsub = __builtin_amdgcn_readfirstlane(tk.nsub);
-    const int col0 = __builtin_amdgcn_readfirstlane(tk.col0);
-    const int64_t w0 = woff[win];
-    const int nwords = (int)(woff[win + 1] - w0);
-    const uint32_t *base = planes + (size_t)w0 * 5u * (size_t)NP;
-    const int j = col0 + lane;
-    const int lane_valid = j < N;
-    int32_t *Cw = Cmat + (size_t)win * N * N;
-    int32_t *Dw = Dmat + (size_t)win * N * N;
-    switch (nsub) {
-        case 1: pair_body<1>(base, nwords, NP, row0, j, lane_valid, N, j, Cw, Dw); break;
-        case 2: pair_body<2>(base, nwords, NP, row0, j, lane_valid, N, j, Cw, Dw); break;
-        case 3: pair_body<3>(base, nwords, NP, row0, j, lane_valid, N, j, Cw, Dw); break;
-        default: pair_body<4>(base, nwords, NP, row0, j, lane_valid, N, j, Cw, Dw); break;
-    }
-}
-
-void pg_launch_pairwise(hipStream_t st, const uint32_t *planes, const int64_t *woff, int n_win,
-                        const PgPairTask *tasks, int n_tasks, int NP, int N, int32_t *Cmat, int32_t *Dmat) {
-    if (n_win <= 0 || n_tasks <= 0) return;
-    int tasks_wg = (n_tasks + 3) / 4;
-    int64_t blocks = (int64_t)((n_win + 7) / 8) * tasks_wg * 8;
-    hipLaunchKernelGGL(k_pairwise, dim3((unsigned)blocks), dim3(256), 0, st, planes, woff, n_win, tasks, n_tasks,
-                       tasks_wg, NP, N, Cmat, Dmat);
 }
 
 // ------------------------------------------------------------------------------------------------------

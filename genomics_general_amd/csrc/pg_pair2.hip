@@ -650,19 +650,21 @@ template <int DIP>
 static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *gt, int S, const int64_t *win_lo,
                          const int64_t *win_hi, const int64_t *goff, const int64_t *vgoff, uint32_t *Vp, int NPv, uint32_t *XV,
                          int NP, int32_t *nw, int32_t *mismatch, uint32_t *pres, int capg, int grp) {
-    // Up to 1024 slots: k_pack3 (every row fetched once; PMC: 2.27 instead of 2.56 GB per C2 pass, 44.5 instead of 49.2 GB per
+    // Up to 4096 slots: k_pack3 (one block of up to 16 waves per group; every row fetched once; PMC: 2.27 instead of 2.56 GB per C2 pass, 44.5 instead of 49.2 GB per
     // north-star pass).  Same-box A/B (profiles/r02/ab_pack_*.txt): C2 0.450-0.485 vs 0.457-0.463 ms, north-star shape 7.7-7.9 vs
     // 8.0-9.2 ms -- once the per-entry allele look-up had moved from the scalar unit to a lane-parallel table (before that
-    // k_pack3 lost on two-wave blocks, 8.3-9.0 ms: every wave of a block runs the per-entry scalar loop).  More than 1024 slots:
-    // k_pack2 behind the presence pre-pass.  PG_PACK2=1 forces k_pack2 (A/B runs and tests).
+    // k_pack3 lost on two-wave blocks, 8.3-9.0 ms: every wave of a block runs the per-entry scalar loop).  More than 4096 slots:
+    // k_pack2 behind the presence pre-pass (round 2 took that route from 1024 slots on: C4 read its rows twice, 0.27 of HBM).
+    // PG_PACK2=1 forces k_pack2 (A/B runs and tests).
     const bool force2 = getenv("PG_PACK2") != nullptr;
-    if (threads <= 256 && !force2) {
-        if (threads <= 64)
-            hipLaunchKernelGGL((k_pack3<64, DIP>), grid, dim3(64), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp);
-        else if (threads <= 128)
-            hipLaunchKernelGGL((k_pack3<128, DIP>), grid, dim3(128), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp);
-        else
-            hipLaunchKernelGGL((k_pack3<256, DIP>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp);
+    if (threads <= 1024 && !force2) {
+#define PG_PACK3(T) hipLaunchKernelGGL((k_pack3<T, DIP>), grid, dim3(T), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp)
+        if (threads <= 64) PG_PACK3(64);
+        else if (threads <= 128) PG_PACK3(128);
+        else if (threads <= 256) PG_PACK3(256);
+        else if (threads <= 512) PG_PACK3(512);            // up to 2048 slots (C4: 2000 haplotypes): eight waves meet in LDS per word
+        else PG_PACK3(1024);                               // up to 4096 slots
+#undef PG_PACK3
         return;
     }
     if (threads <= 64)
@@ -679,7 +681,10 @@ static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *g
     }
 }
 
-// pres: scratch of total_groups * PG_GROUP * 4 words, only used (and zeroed here) when there are more than 1024 slots
+// more slots than one k_pack3 block takes (or k_pack2 forced beyond one of ITS blocks): the presence pre-pass runs
+bool pg_pack_needs_presence(int NP) { return NP / 4 > 1024 || (getenv("PG_PACK2") != nullptr && NP / 4 > 256); }
+
+// pres: scratch of total_groups * PG_GROUP * 4 words, only used (and zeroed here) in that mode
 void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                      const int64_t *goff, const int64_t *vgoff, int n_win, int max_groups, int64_t total_groups, uint32_t *Vp,
                      int NPv, uint32_t *XV, int NP, int32_t *nw, int dip, int32_t *mismatch, uint32_t *pres, int capg, int grp) {
@@ -687,7 +692,7 @@ void pg_launch_pack2(hipStream_t st, const int8_t *gt, int S, const int64_t *win
     // every window of the batch is empty); nw[n_win ..): one slot per group in the > 1024-slot mode (k_word_scan)
     if (n_win <= 0 || max_groups <= 0) return;
     const int threads = NP / 4;
-    if (threads > 256) (void)hipMemsetAsync(pres, 0, (size_t)total_groups * grp * 16u, st);
+    if (pg_pack_needs_presence(NP)) (void)hipMemsetAsync(pres, 0, (size_t)total_groups * grp * 16u, st);
     dim3 grid(max_groups, n_win);
     if (dip) launch_pack2<1>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg, grp);
     else launch_pack2<0>(st, threads, grid, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, pres, capg, grp);

@@ -1,22 +1,26 @@
-// Pairwise counts on the matrix cores: C = V V^T and D = A B^T + B A^T as exact int8 x int8 -> int32 products.
+// Pairwise counts on the matrix cores, one wave per block: C = V V^T and D = A B^T + B A^T as exact MX fp4 products.
 //
 // The bit-plane kernels of pg_pair2.hip (k_pairC: v_and + accumulating v_bcnt, k_pairD: v_xor + 2 x v_bitop3 + v_bcnt) sit at
 // 0.94 / 0.99 of the measured VALU issue ceiling of their instruction mixes (profiles/r02/valu_rate.txt): the vector ALU cannot
 // count pairs faster.  The counts are Gram matrices of 0/1 vectors (D = C - sum_b X_b X_b^T is array_equal to the
-// reference's pair loop, genomics.py:903-916, 1219-1221, 1042-1047), and v_mfma_i32_32x32x32_i8 multiplies 32 x 32 x 32 of them
-// per instruction at ~2.2e15 MAC/s (guide: 4404 TOPS measured) against 32 pair-sites per VALU lane-op = ~6e14 pair-sites/s.
+// reference's pair loop, genomics.py:903-916, 1219-1221, 1042-1047), and v_mfma_scale_f32_32x32x64_f8f6f4 multiplies
+// 32 x 32 x 64 of them per instruction (both operands e2m1, scales 2^0).
 //
 // The planes stay what k_pack3 writes (1 bit per call / virtual site: no extra HBM bytes); a wave expands the words it needs
-// into 0/1 bytes in registers, two VALU ops per dword:
-//     fragment dword m of lane (r, kb) = (word >> (4 kb + m)) & 0x01010101,  m = 0..3
-// i.e. lane (r, kb) holds 16 of the word's 32 sites of unit r, in a permuted order -- the same order in the A and the B operand
-// (both are "row/column = lane & 31, K block = lane >> 5"), which is all a dot product needs.
+// into fp4 nibbles in registers: a site is one nibble, 0b0001 = 0.5, so a product of two set sites is 0.25 and an accumulator
+// holds count / 4 -- exact in f32 while count < 2^24, which the launcher guarantees by cutting the word range (integer atomics
+// combine the parts):
+//     fragment dword m of lane (r, kb) = (word >> m) & 0x11111111,  m = 0..3     (each lane half expands its own words)
+// i.e. the lane halves hold different words, in the same (permuted) site order in the A and the B operand, which is all a dot
+// product needs.
 //
-//   k_pairC_mfma   units x units "both called" counts from the called plane Vp:   C(I,J) += V_I V_J^T
-//   k_pairD_mfma   haplotype x haplotype differences from the virtual-site planes XV (x = carries the tested allele,
-//                  v = called and not excluded):  a = x & v, b = ~x & v,  D(I,J) += a_I b_J^T + b_I a_J^T
-//                  ((x_i ^ x_j) & v_i & v_j = a_i b_j + b_i a_j, bit by bit)
-// A wave (= a block) owns up to 3 x 3 tiles of 32 x 32 of the upper triangle and keeps their accumulators in registers over its part of the window's words; int32 sums are exact (counts < 2^31 are guarded by the host).
+//   k_pairC_fp4   units x units "both called" counts from the called plane Vp:   C(I,J) += V_I V_J^T
+//   k_pairD_fp4   haplotype x haplotype differences from the virtual-site planes XV (x = carries the tested allele,
+//                 v = called and not excluded):  a = x & v, b = ~x & v,  D(I,J) += a_I b_J^T + b_I a_J^T
+//                 ((x_i ^ x_j) & v_i & v_j = a_i b_j + b_i a_j, bit by bit)
+// A wave (= a block) owns up to 2 x 2 tiles of 32 x 32 of the upper triangle and keeps their accumulators in registers over its
+// part of the window's words.  These kernels serve the shapes the LDS-staged block kernels of pg_pair_tile.hip do not take
+// (planes of more than ~340 units per word) and, by default, the D counts.
 #include "pg_internal.h"
 
 #include <algorithm>
@@ -24,14 +28,10 @@
 
 namespace {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-#ifndef PG_MFMA_TB
-#define PG_MFMA_TB 2
-#endif
-#define PG_MFMA_WAVES (PG_MFMA_TB == 2 ? 4 : 2)
-constexpr int TB = PG_MFMA_TB;         // a wave owns up to TB x TB tiles of 32 x 32: 9 x 16 accumulator registers, 6 fragments per 9 products
+#define PG_MFMA_WAVES 4
+constexpr int TB = 2;                  // a wave owns up to TB x TB tiles of 32 x 32: 4 x 16 accumulator registers
 
 // s-th task of the upper triangle of T x T tiles: tile rows I0 .. I0+nr-1, tile columns J0 .. J0+nc-1; the first task of a
 // block row starts on the diagonal (J0 == I0, nr == nc: the row fragments are the column fragments, the tiles below the diagonal
@@ -76,16 +76,6 @@ __device__ __forceinline__ bool win_decode(int per_win, int n_win, int &win, int
     return true;
 }
 
-__device__ __forceinline__ v4i expand(uint32_t w, int sh) {
-    const uint32_t x = w >> sh;
-    v4i f;
-    f.x = (int)(x & 0x01010101u);
-    f.y = (int)((x >> 1) & 0x01010101u);
-    f.z = (int)((x >> 2) & 0x01010101u);
-    f.w = (int)((x >> 3) & 0x01010101u);
-    return f;
-}
-
 // accumulator tile -> upper triangle of the window's matrix.  C/D layout of the 32x32 MFMA: column = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ void store_tile(const v16i &acc, int I, int J, int lane, int n, int diag, int atomic, int32_t *__restrict__ M) {
@@ -117,108 +107,6 @@ struct WordsC {
     }
 };
 
-template <int NR, int NC, bool DG>
-__device__ __forceinline__ void pairC_group(const WordsC<NR, NC, DG> &w, int sh, v16i (&acc)[NR][NC]) {
-#pragma unroll
-    for (int wi = 0; wi < 4; ++wi) {
-        v4i fc[NC], fr[NR];
-#pragma unroll
-        for (int j = 0; j < NC; ++j) fc[j] = expand(comp(w.c[j], wi), sh);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) fr[i] = DG ? fc[i] : expand(comp(w.r[DG ? 0 : i], wi), sh);
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-#pragma unroll
-            for (int j = 0; j < NC; ++j)
-                if (!DG || j >= i) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[i], fc[j], acc[i][j], 0, 0, 0);
-    }
-}
-
-// groups q0 .. q1-1 (4 words = 128 sites each)
-template <int NR, int NC, bool DG>
-__device__ __forceinline__ void pairC_task(const uint4 *__restrict__ base, int q0, int q1, int NPv, int I0, int J0, int lane,
-                                           int n_units, int diag, int atomic, int32_t *__restrict__ Cw) {
-    const int r = lane & 31, sh = 4 * (lane >> 5);
-    v16i acc[NR][NC];
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
-    const uint4 *prow = base + (size_t)q0 * NPv + 32 * I0 + r;
-    const uint4 *pcol = base + (size_t)q0 * NPv + 32 * J0 + r;
-    // two groups per trip, both requested at its top: the second group's words arrive under the first group's products (a
-    // look-ahead carried around the loop is waited for with vmcnt(0) at the loop head by hipcc, i.e. not a look-ahead)
-    int q = q0;
-    for (; q + 1 < q1; q += 2) {
-        WordsC<NR, NC, DG> wa, wb;
-        wa.load(prow, pcol);
-        wb.load(prow + NPv, pcol + NPv);
-        __builtin_amdgcn_sched_barrier(0);             // both requests stay in front of the first group's products
-        pairC_group<NR, NC, DG>(wa, sh, acc);
-        pairC_group<NR, NC, DG>(wb, sh, acc);
-        prow += 2 * (size_t)NPv;
-        pcol += 2 * (size_t)NPv;
-    }
-    if (q < q1) {
-        WordsC<NR, NC, DG> wa;
-        wa.load(prow, pcol);
-        pairC_group<NR, NC, DG>(wa, sh, acc);
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-            if (!DG || j >= i) store_tile(acc[i][j], I0 + i, J0 + j, lane, n_units, diag, atomic, Cw);
-}
-
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVES, PG_MFMA_WAVES))) void k_pairC_mfma(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vgoff, int n_win,
-                                                   int T, int ntask, int kparts, int NPv, int n_units, int diag,
-                                                   int32_t *__restrict__ Cmat) {
-    int win, rem;
-    if (!win_decode(ntask * kparts, n_win, win, rem)) return;
-    const int s = rem % ntask, kp = rem / ntask;
-    int I0, J0, nr, nc;
-    if (!task_decode(T, s, I0, J0, nr, nc)) return;
-    const int64_t vg = vgoff[win];
-    const int nwq = (int)(vgoff[win + 1] - vg);
-    const int q0 = (int)((long long)nwq * kp / kparts), q1 = (int)((long long)nwq * (kp + 1) / kparts);
-    const int lane = threadIdx.x & 63, atomic = kparts > 1;
-    int32_t *Cw = Cmat + (size_t)win * n_units * n_units;
-    if (q1 <= q0) {
-        // no words in this part (an empty window): the counts are zero, and without the extra cut nobody else writes them
-        if (!atomic) {
-            v16i z;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) z[e] = 0;
-            for (int i = 0; i < nr; ++i)
-                for (int j = 0; j < nc; ++j) store_tile(z, I0 + i, J0 + j, lane, n_units, diag, 0, Cw);
-        }
-        return;
-    }
-    const uint4 *base = reinterpret_cast<const uint4 *>(Vp) + (size_t)vg * NPv;
-#define PG_C_TASK(NR, NC, DG) pairC_task<NR, NC, DG>(base, q0, q1, NPv, I0, J0, lane, n_units, diag, atomic, Cw)
-    if (J0 == I0) {
-        if (TB >= 3 && nr == 3) PG_C_TASK(3, 3, true);
-        else if (nr == 2) PG_C_TASK(2, 2, true);
-        else PG_C_TASK(1, 1, true);
-    } else if (TB >= 3 && nr == 3) {
-        if (nc == 3) PG_C_TASK(3, 3, false);
-        else if (nc == 2) PG_C_TASK(3, 2, false);
-        else PG_C_TASK(3, 1, false);
-    } else if (nr == 2) {
-        if (TB >= 3 && nc == 3) PG_C_TASK(2, 3, false);
-        else if (nc == 2) PG_C_TASK(2, 2, false);
-        else PG_C_TASK(2, 1, false);
-    } else {
-        if (TB >= 3 && nc == 3) PG_C_TASK(1, 3, false);
-        else if (nc == 2) PG_C_TASK(1, 2, false);
-        else PG_C_TASK(1, 1, false);
-    }
-#undef PG_C_TASK
-}
-
 // ---- D ----
 template <int NR, int NC, bool DG>
 struct WordsD {
@@ -233,127 +121,7 @@ struct WordsD {
     }
 };
 
-template <int NR, int NC, bool DG>
-__device__ __forceinline__ void pairD_word(const WordsD<NR, NC, DG> &w, int sh, v16i (&acc)[NR][NC]) {
-    v4i ca[NC], cb[NC], ra[NR], rb[NR];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-        const uint32_t a = w.c[j].x & w.c[j].y, b = w.c[j].y ^ a;          // a = x & v, b = ~x & v
-        ca[j] = expand(a, sh);
-        cb[j] = expand(b, sh);
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        if (DG) {
-            ra[i] = ca[i];
-            rb[i] = cb[i];
-        } else {
-            const uint32_t a = w.r[DG ? 0 : i].x & w.r[DG ? 0 : i].y, b = w.r[DG ? 0 : i].y ^ a;
-            ra[i] = expand(a, sh);
-            rb[i] = expand(b, sh);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-            if (!DG || j >= i) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ra[i], cb[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-            if (!DG || j >= i) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(rb[i], ca[j], acc[i][j], 0, 0, 0);
-}
-
-template <int NR, int NC, bool DG>
-__device__ __forceinline__ void pairD_task(const uint2 *__restrict__ xv, int s0, int s1, int NP, int I0, int J0, int lane, int N,
-                                           int atomic, int32_t *__restrict__ Dw) {
-    const int r = lane & 31, sh = 4 * (lane >> 5);
-    v16i acc[NR][NC];
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
-    const uint2 *prow = xv + (size_t)s0 * NP + 32 * I0 + r;
-    const uint2 *pcol = xv + (size_t)s0 * NP + 32 * J0 + r;
-    int s = s0;
-    for (; s + 1 < s1; s += 2) {
-        WordsD<NR, NC, DG> wa, wb;
-        wa.load(prow, pcol);
-        wb.load(prow + NP, pcol + NP);
-        __builtin_amdgcn_sched_barrier(0);             // both requests stay in front of the first group's products
-        pairD_word<NR, NC, DG>(wa, sh, acc);
-        pairD_word<NR, NC, DG>(wb, sh, acc);
-        prow += 2 * (size_t)NP;
-        pcol += 2 * (size_t)NP;
-    }
-    if (s < s1) {
-        WordsD<NR, NC, DG> wa;
-        wa.load(prow, pcol);
-        pairD_word<NR, NC, DG>(wa, sh, acc);
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-            if (!DG || j >= i) store_tile(acc[i][j], I0 + i, J0 + j, lane, N, 0, atomic, Dw);
-}
-
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVES, PG_MFMA_WAVES))) void k_pairD_mfma(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw,
-                                                   const int64_t *__restrict__ goff, int n_win, int T, int ntask, int kparts, int NP,
-                                                   int N, int32_t *__restrict__ Dmat, int capg) {
-    int win, rem;
-    if (!win_decode(ntask * kparts, n_win, win, rem)) return;
-    const int s = rem % ntask, kp = rem / ntask;
-    int I0, J0, nr, nc;
-    if (!task_decode(T, s, I0, J0, nr, nc)) return;
-    const uint2 *xv = reinterpret_cast<const uint2 *>(XV + (size_t)goff[win] * capg * PG_XV_PLANES * (size_t)NP);
-    // (a window that overflowed its reservation is recomputed by the host; never read past the reservation)
-    const int capw = (int)(goff[win + 1] - goff[win]) * capg;
-    const int n_all = __builtin_amdgcn_readfirstlane(nw[win]);
-    const int n_words = n_all < capw ? n_all : capw;
-    const int a = (int)((long long)n_words * kp / kparts), b = (int)((long long)n_words * (kp + 1) / kparts);
-    int32_t *Dw = Dmat + (size_t)win * N * N;
-    const int lane = threadIdx.x & 63, atomic = kparts > 1;
-    if (b <= a) {
-        // no virtual sites in this part: the counts are zero, and without the extra cut nobody else writes them
-        if (!atomic) {
-            v16i z;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) z[e] = 0;
-            for (int i = 0; i < nr; ++i)
-                for (int j = 0; j < nc; ++j) store_tile(z, I0 + i, J0 + j, lane, N, 0, 0, Dw);
-        }
-        return;
-    }
-#define PG_D_TASK(NR, NC, DG) pairD_task<NR, NC, DG>(xv, a, b, NP, I0, J0, lane, N, atomic, Dw)
-    if (J0 == I0) {
-        if (TB >= 3 && nr == 3) PG_D_TASK(3, 3, true);
-        else if (nr == 2) PG_D_TASK(2, 2, true);
-        else PG_D_TASK(1, 1, true);
-    } else if (TB >= 3 && nr == 3) {
-        if (nc == 3) PG_D_TASK(3, 3, false);
-        else if (nc == 2) PG_D_TASK(3, 2, false);
-        else PG_D_TASK(3, 1, false);
-    } else if (nr == 2) {
-        if (TB >= 3 && nc == 3) PG_D_TASK(2, 3, false);
-        else if (nc == 2) PG_D_TASK(2, 2, false);
-        else PG_D_TASK(2, 1, false);
-    } else {
-        if (TB >= 3 && nc == 3) PG_D_TASK(1, 3, false);
-        else if (nc == 2) PG_D_TASK(1, 2, false);
-        else PG_D_TASK(1, 1, false);
-    }
-#undef PG_D_TASK
-}
-
-// ---- the same two kernels on the MX fp4 path (v_mfma_scale_f32_32x32x64_f8f6f4, both operands e2m1, scales 2^0) -----------------
-// A site is one nibble: 0b0001 = 0.5, so a product of two set sites is 0.25 and an accumulator holds count / 4 -- exact in f32
-// while count < 2^24, which the launcher guarantees by cutting the word range (integer atomics combine the parts).  Twice the
-// sites per instruction at about the issue time of the int8 form, and 8 instead of 18 VALU ops per fragment and 64 sites:
-//     fragment dword m of lane (r, kb) = (word >> m) & 0x11111111,  m = 0..3     (each lane half expands its own words)
+// ---- MX fp4 products (v_mfma_scale_f32_32x32x64_f8f6f4, both operands e2m1, scales 2^0) -----------------------------------------
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -599,7 +367,6 @@ int pick_parts(int n_win, int ntask, int64_t steps_per_window, int min_steps) {
 
 // fp4 path: an f32 accumulator holds count / 4 exactly while count < 2^24; no part of any window may see more sites than that
 // (2^23 keeps a margin); the parts are combined by integer atomics
-bool use_fp4() { return TB == 2 && getenv("PG_PAIR_I8") == nullptr; }
 int exact_parts(int64_t max_sites_per_window) { return (int)((max_sites_per_window + (1 << 23) - 1) >> 23); }
 
 }  // namespace
@@ -608,8 +375,7 @@ void pg_launch_pairC_mfma(hipStream_t st, const uint32_t *Vp, const int64_t *vgo
                           int64_t avg_wq, int64_t max_sites, int32_t *Cmat) {
     if (n_win <= 0 || n_units <= 0) return;
     const int T = (n_units + 31) / 32, ntask = task_count(T);
-    const bool fp4 = use_fp4();
-    int kparts = std::max(pick_parts(n_win, ntask, avg_wq, 8), fp4 ? exact_parts(max_sites) : 1);
+    int kparts = std::max(pick_parts(n_win, ntask, avg_wq, 8), exact_parts(max_sites));
     // L2 locality: the tasks of a window start together and read the same words, but they drift apart (diagonal and edge tasks
     // issue fewer products per step) and an XCD runs some 50 windows at once against 4 MB of L2 -- PMC: 9.1 GB fetched per
     // north-star launch for a 2.5 GB plane.  Parts of at most 1 MiB of plane end before the drift matters (measured on the
@@ -618,23 +384,15 @@ void pg_launch_pairC_mfma(hipStream_t st, const uint32_t *Vp, const int64_t *vgo
     kparts = std::max(kparts, (int)std::min<int64_t>(4, (plane_bytes + (1 << 20) - 1) >> 20));
     if (kparts > 1) (void)hipMemsetAsync(Cmat, 0, (size_t)n_win * n_units * n_units * 4, st);
     const int64_t blocks = (int64_t)((n_win + 7) / 8) * ntask * kparts * 8;
-    if (fp4)
-        hipLaunchKernelGGL(k_pairC_fp4, dim3((unsigned)blocks), dim3(64), 0, st, Vp, vgoff, n_win, T, ntask, kparts, NPv, n_units, diag, Cmat);
-    else
-        hipLaunchKernelGGL(k_pairC_mfma, dim3((unsigned)blocks), dim3(64), 0, st, Vp, vgoff, n_win, T, ntask, kparts, NPv, n_units, diag,
-                           Cmat);
+    hipLaunchKernelGGL(k_pairC_fp4, dim3((unsigned)blocks), dim3(64), 0, st, Vp, vgoff, n_win, T, ntask, kparts, NPv, n_units, diag, Cmat);
 }
 
 void pg_launch_pairD_mfma(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win, int NP, int N,
                           int64_t avg_words, int64_t max_vsites, int32_t *Dmat, int capg) {
     if (n_win <= 0 || N <= 0) return;
     const int T = (N + 31) / 32, ntask = task_count(T);
-    const bool fp4 = use_fp4();
-    const int kparts = std::max(pick_parts(n_win, ntask, avg_words, 8), fp4 ? exact_parts(max_vsites) : 1);
+    const int kparts = std::max(pick_parts(n_win, ntask, avg_words, 8), exact_parts(max_vsites));
     if (kparts > 1) (void)hipMemsetAsync(Dmat, 0, (size_t)n_win * N * N * 4, st);
     const int64_t blocks = (int64_t)((n_win + 7) / 8) * ntask * kparts * 8;
-    if (fp4)
-        hipLaunchKernelGGL(k_pairD_fp4, dim3((unsigned)blocks), dim3(64), 0, st, XV, nw, goff, n_win, T, ntask, kparts, NP, N, Dmat, capg);
-    else
-        hipLaunchKernelGGL(k_pairD_mfma, dim3((unsigned)blocks), dim3(64), 0, st, XV, nw, goff, n_win, T, ntask, kparts, NP, N, Dmat, capg);
+    hipLaunchKernelGGL(k_pairD_fp4, dim3((unsigned)blocks), dim3(64), 0, st, XV, nw, goff, n_win, T, ntask, kparts, NP, N, Dmat, capg);
 }

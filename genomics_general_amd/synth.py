@@ -161,16 +161,28 @@ def write_geno_fast(path, codes, sample_names, scaf="chr1", pos0=1):
     letters = codes_to_letters(codes)
     L, H = letters.shape
     n = H // 2
+    head = (scaf + "\t").encode()
     with open(path, "wb") as f:
         f.write(("#CHROM\tPOS\t" + "\t".join(sample_names) + "\n").encode())
         step = 100000
-        for a in range(0, L, step):
-            b = min(L, a + step)
-            cell = np.empty((b - a, n, 4), dtype=np.uint8)
+        a = 0
+        while a < L:
+            # rows whose position has the same number of digits are one fixed-width byte matrix: prefix | digits | tab | cells
+            p0 = pos0 + a
+            nd = len(str(p0))
+            b = min(L, a + step, 10 ** nd - pos0)
+            rows = b - a
+            line = np.empty((rows, len(head) + nd + 1 + 4 * n), dtype=np.uint8)
+            line[:, :len(head)] = np.frombuffer(head, dtype=np.uint8)
+            pos = np.arange(p0, p0 + rows, dtype=np.int64)
+            for k in range(nd):
+                line[:, len(head) + nd - 1 - k] = (pos // 10 ** k % 10 + ord("0")).astype(np.uint8)
+            line[:, len(head) + nd] = ord("\t")
+            cell = line[:, len(head) + nd + 1:].reshape(rows, n, 4)
             cell[:, :, 0] = letters[a:b, 0::2]
             cell[:, :, 1] = ord("/")
             cell[:, :, 2] = letters[a:b, 1::2]
             cell[:, :, 3] = ord("\t")
             cell[:, -1, 3] = ord("\n")
-            body = cell.reshape(b - a, -1)
-            f.write(b"".join(("%s\t%d\t" % (scaf, pos0 + i)).encode() + body[i - a].tobytes() for i in range(a, b)))
+            f.write(line.data)
+            a = b

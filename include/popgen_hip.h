@@ -46,8 +46,10 @@ enum pg_status {
 enum pg_geno_format { PG_FMT_PHASED = 0, PG_FMT_PAIRS = 1, PG_FMT_HAPLO = 2, PG_FMT_DIPLO = 3 };
 
 /* kernels whose HIP-event timings pg_kernel_time reports */
-enum pg_kernel_id { PG_K_PACK = 0, PG_K_PAIRWISE = 1 /* k_pairwise (v1) or k_pairC (v2) */, PG_K_POPDIST_FIN = 2,
-                    PG_K_SITESTATS = 3, PG_K_SYNTH = 4, PG_K_PAIRD = 5, PG_K_COUNT_ = 6 };
+enum pg_kernel_id { PG_K_PACK = 0, PG_K_PAIRWISE = 1 /* the called-count kernel (k_pairC*) */, PG_K_POPDIST_FIN = 2,
+                    PG_K_SITESTATS = 3, PG_K_SYNTH = 4, PG_K_PAIRD = 5 /* the difference-count kernel (k_pairD*) */,
+                    PG_K_INDPAIR_FIN = 6, PG_K_RESULT_D2H = 7 /* copy of a large result table back to the host (indPair means) */,
+                    PG_K_COUNT_ = 8 };
 
 int pg_abi_version(void);
 const char *pg_last_error(void);

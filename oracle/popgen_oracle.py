@@ -750,8 +750,10 @@ def fourpop_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=1
 
 def distmat_text(geno_path, fmt, wind_size=None, step=None, min_sites=1, wind_type="coordinate",
                  out_format="phylip", round_to=4, include_same=False, min_per_ind=None, samples=None, overlap=0,
-                 max_dist=float("inf"), ploidy=None):
-    """distMat.py:28-60 (stats_wrapper) + genomics.py:2288-2306 (matrix strings); coordinate, sites and cat windows."""
+                 max_dist=float("inf"), ploidy=None, write_failed=False):
+    """distMat.py:28-60 (stats_wrapper) + genomics.py:2288-2306 (matrix strings); coordinate, sites and cat windows.  A window
+    that fails (too few sites, or an individual below --minPerInd) is a matrix of nan (distMat.py:47-50) and is written only
+    with --writeFailedWindows (distMat.py:99-100)."""
     with open_text(geno_path) as fh:
         file_names, sites = read_sites(fh)
     ind_names = list(samples) if samples else list(file_names)
@@ -772,16 +774,21 @@ def distmat_text(geno_path, fmt, wind_size=None, step=None, min_sites=1, wind_ty
     n = len(ind_names)
     chunks = []
     for w in wins:
-        if len(w.positions) < min_sites:
+        good = len(w.positions) >= min_sites
+        if good:
+            aln = window_to_aln(w, file_names, ind_names, pop_of, ploidy_of, fmt)
+            if min_per_ind and min(aln.mask.sum(axis=1)) < min_per_ind:
+                good = False
+        if not good and not write_failed:
             continue
-        aln = window_to_aln(w, file_names, ind_names, pop_of, ploidy_of, fmt)
-        if min_per_ind and min(aln.mask.sum(axis=1)) < min_per_ind:
-            continue
-        D, C = pair_counts_gemm(aln)
-        pdd, _ = ind_pair_dists(aln, dist_from_counts(D, C), include_same)
-        M = np.zeros((n, n))
-        for i, j in itertools.combinations_with_replacement(range(n), 2):
-            M[i, j] = M[j, i] = pdd[ind_names[i]][ind_names[j]]
+        if good:
+            D, C = pair_counts_gemm(aln)
+            pdd, _ = ind_pair_dists(aln, dist_from_counts(D, C), include_same)
+            M = np.zeros((n, n))
+            for i, j in itertools.combinations_with_replacement(range(n), 2):
+                M[i, j] = M[j, i] = pdd[ind_names[i]][ind_names[j]]
+        else:
+            M = np.full((n, n), np.nan)
         txt = M.round(round_to).astype(str)
         if out_format == "raw":
             chunks.append("\n".join(" ".join(r) for r in txt) + "\n")

@@ -91,6 +91,9 @@ CASES = [
                "popFreq", "indPairDist", "indHet"] + pops_args(9, 3)),
     dict(name="multi_distmat", tool="distMat.py", fixture="multi",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1500", "-m", "20", "--outFormat", "raw"]),
+    dict(name="multi_distmat_windows_id", tool="distMat.py", fixture="multi",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "700", "-m", "400", "--outFormat", "phylip", "--addWindowID", "--writeFailedWindows",
+               "--windowDataOutFile", "{out}.windows"]),
     # ---- ABBABABAwindows.py ----
     dict(name="abba_windows", tool="ABBABABAwindows.py", fixture="abba",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--minData", "0.5"] + abba_args(16)),

@@ -38,3 +38,10 @@ def close(a, b, tol=1e-9):
         ok = np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))
     same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
     return bool(np.all(ok | both_nan | same_inf))
+
+
+def set_mode(monkeypatch, mode):
+    """`NAME` or `NAME=value`: an environment switch of the library (A/B code paths); "default" sets nothing"""
+    if mode != "default":
+        name, _, val = mode.partition("=")
+        monkeypatch.setenv(name, val or "1")

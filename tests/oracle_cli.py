@@ -160,7 +160,8 @@ def run(tool, argv):
                                 out_format=_take(argv, "--outFormat", default="phylip"),
                                 round_to=int(r) if r else 4, include_same="--includeSameWithSame" in argv,
                                 min_per_ind=int(mi) if mi else None, samples=_multi(argv, "--samples"),
-                                overlap=int(ov) if ov else 0, ploidy=_ploidy(argv, True))
+                                overlap=int(ov) if ov else 0, ploidy=_ploidy(argv, True),
+                                write_failed="--writeFailedWindows" in argv)
     if tool == "freq.py":
         pops = _pops(argv, ("-p",))
         if "--indFreqs" in argv:                                 # freq.py:250-253: every individual is its own population

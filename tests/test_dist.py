@@ -181,7 +181,10 @@ def test_two_ranks_shard_the_input_at_scaffold_runs_and_gather_rows_once(tmp_pat
     from test_host import _bgzf_write
     for k, (name, packed) in enumerate((("c1_popgen", False), ("sparse_overlap_failed_id", False), ("abba_windows_sites", False),
                                         ("sparse_stepgap", False), ("c1_popgen", True), ("sparse_overlap_failed_id", True),
-                                        ("c1_popgen", "bgzf"), ("sparse_overlap_failed_id", "bgzf"))):
+                                        ("c1_popgen", "bgzf"), ("sparse_overlap_failed_id", "bgzf"),
+                                        # distMat.py: matrices and the window side file (IDs shifted per rank) meet in one gather each
+                                        ("multi_distmat", False), ("multi_distmat_windows_id", False),
+                                        ("multi_distmat_windows_id", "bgzf"))):
         case = [c for c in CASES if c["name"] == name][0]
         geno = str(tmp_path / (case["fixture"] + ".geno"))
         with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f, open(geno, "wb") as g:
@@ -211,6 +214,9 @@ def test_two_ranks_shard_the_input_at_scaffold_runs_and_gather_rows_once(tmp_pat
         with open(out) as f, open(os.path.join(gold, name + ".out")) as g:
             got, want = f.read(), g.read()
         G.compare_text(align_columns(got, want), want, G.round_digits(case))
+        if os.path.exists(os.path.join(gold, name + ".out.windows")):
+            with open(out + ".windows") as f, open(os.path.join(gold, name + ".out.windows")) as g:
+                assert f.read() == g.read()
         assert len(timing) == 2 and all(t["sharded_input"] for t in timing), timing
         if name == "c1_popgen" and packed != "bgzf":
             for t in timing:

@@ -121,13 +121,14 @@ def test_integer_matrices_are_additive_over_a_split_window_and_bounded(c2):
     assert C[0].sum() > 0 and D[0].sum() > 0
 
 
-@pytest.mark.parametrize("env", ["PG_PAIR_V1", "PG_NO_DIP", "PG_OVERLAP", "PG_PACK2", "PG_GROUP_WORDS", "PG_PAIR_VALU", "PG_PAIR_I8"])
+@pytest.mark.parametrize("env", ["PG_NO_DIP", "PG_OVERLAP", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none"])
 def test_independent_pipelines_agree_at_full_window_size(c2, env, monkeypatch):
     e, lay, lo, hi = c2
     sel = [0, 61, 199]
     want = e.batch(lo[sel], hi[sel]).pairCounts(reference_order=False)
     st_want = e.batch(lo[:40], hi[:40]).groupDistStats(True, 100, 0.01)
-    monkeypatch.setenv(env, "128" if env == "PG_GROUP_WORDS" else "1")      # (4096-site compaction groups instead of 2048)
+    name, _, val = env.partition("=")                                       # (PG_GROUP_WORDS: 4096-site compaction groups instead of 2048;
+    monkeypatch.setenv(name, val or "1")                                    # the popcount kernels need their own context: test_gpu_kernels)
     got = e.batch(lo[sel], hi[sel]).pairCounts(reference_order=False)
     st_got = e.batch(lo[:40], hi[:40]).groupDistStats(True, 100, 0.01)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])

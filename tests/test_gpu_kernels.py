@@ -24,10 +24,9 @@ def oracle_aln(lay, codes, lo, hi):
     (150, 4, 1500, [(0, 700), (700, 1500)]),                                     # several 64-column chunks
     (530, 3, 2200, [(0, 2200), (100, 421), (2150, 2200)]),                        # > 1024 haplotype slots: presence pre-pass
 ])
-@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS", "PG_PAIR_VALU", "PG_PAIR_I8"])
+@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_VALU", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none"])
 def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins, pack, monkeypatch):
-    if pack != "default":
-        monkeypatch.setenv(pack, "128" if pack == "PG_GROUP_WORDS" else "1")
+    G.set_mode(monkeypatch, pack)
     e, lay, codes, _ = G.make_engine(n_dip, n_pops, L, seed=11 + n_dip)
     lo = np.array([w[0] for w in wins]); hi = np.array([w[1] for w in wins])
     D, C = e.batch(lo, hi).pairCounts(reference_order=True)
@@ -46,13 +45,12 @@ def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins, pack, monkeypatch):
     (150, 1500, 0.1, "uniform"),       # two waves per block: list / flush code behind block barriers
     (300, 800, 0.2, "mixed"),          # four waves per block
 ])
-@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS", "PG_PAIR_VALU", "PG_PAIR_I8"])
+@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_VALU", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none"])
 def test_pairwise_counts_with_three_and_four_alleles_per_site(n_dip, L, p_miss, mix, pack, monkeypatch):
     """sites with k alleles become k-1 virtual biallelic sites in k_pack2 / k_pack3 (both kernels at every block size: one, two
     and four waves); D must still be the plain Hamming count.  The uniform cases overflow the default XV reservation: the
     call is repeated with the worst-case reservation"""
-    if pack != "default":
-        monkeypatch.setenv(pack, "128" if pack == "PG_GROUP_WORDS" else "1")
+    G.set_mode(monkeypatch, pack)
     rng = np.random.default_rng(1000 + n_dip)
     names, lay = G.make_layout(n_dip, 2)
     H = lay.n_hap
@@ -241,11 +239,11 @@ def test_errors_are_loud_not_fatal():
     e.close()
 
 
-@pytest.mark.parametrize("mode", ["default", "PG_NO_DIP", "PG_PAIR_V1", "PG_PAIR_VALU", "PG_PAIR_I8"])
+@pytest.mark.parametrize("mode", ["default", "PG_NO_DIP", "PG_PAIR_VALU", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none"])
 def test_every_pairwise_code_path_gives_the_same_integers(mode, monkeypatch):
-    """diploid fast path (called counts per individual), per-haplotype v2 path, and the v1 kernel"""
-    if mode != "default":
-        monkeypatch.setenv(mode, "1")
+    """diploid fast path (called counts per individual), per-haplotype called counts, popcount kernels, and the matrix-core kernels
+    in both forms (LDS-staged blocks, one-wave blocks)"""
+    G.set_mode(monkeypatch, mode)
     e, lay, codes, _ = G.make_engine(70, 4, 5000, seed=77, var_thr=9000, miss_thr=4000)
     wins = [(0, 2100), (2100, 4167), (4167, 5000), (13, 14)]
     D, C = e.batch([w[0] for w in wins], [w[1] for w in wins]).pairCounts(reference_order=True)
@@ -454,3 +452,49 @@ def test_device_tokenizer_line_prefixes_beyond_the_fast_path():
     assert n == want.n_sites and np.array_equal(pos, want.pos) and np.array_equal(e.download(0, n), want.gt)
     assert np.array_equal(starts, want.run_starts) and run_names == want.run_names
     e.close()
+
+
+def test_uploads_queued_right_behind_a_growing_reservation_are_not_wiped():
+    """Regression (commit 2f55857): pg_reserve_sites clears the new rows on the context's stream; an asynchronous upload or the
+    device tokenizer, queued on the copy stream right after a GROWING reservation, could be overtaken by that clearing -- rare
+    wrong (zeroed) rows in the streaming drivers.  200 growing reservations, each followed at once by an upload of known rows
+    through one of the three routes; every row is read back and compared."""
+    from genomics_general_amd.engine import Engine
+    names, lay = G.make_layout(16, 2)
+    H = lay.n_hap
+    rng = np.random.default_rng(5)
+    e = Engine(0)
+    e.set_layout(lay)
+    pitch = e.row_pitch
+    n_rows = 4096
+    rows = (1 << rng.integers(0, 4, size=(n_rows, H))).astype(np.int8)
+    rows[rng.random((n_rows, H)) < 0.05] = 0
+    staged = e.pinned.empty((n_rows, pitch), np.int8)
+    staged[:] = 0
+    staged[:, :H] = rows
+    # the same rows as `.geno` text for the device tokenizer (phased diploid cells)
+    letters = np.array(list("NACNGNNNT"))
+    lines = []
+    for k in range(n_rows):
+        c = letters[rows[k]]
+        lines.append("sc1\t%d\t%s\n" % (k + 1, "\t".join("%s|%s" % (c[2 * d], c[2 * d + 1]) for d in range(H // 2))))
+    text = "".join(lines).encode()
+    bad = 0
+    for it in range(200):
+        # a reservation larger than every one before: the rows are re-allocated and cleared (tens of megabytes: the clearing is
+        # still running when the next call is queued)
+        e.reserve(600_000 + 3_000 * it)
+        off = int(rng.integers(0, 1000))
+        route = it % 3
+        if route == 0:
+            e.upload_async(staged, off)
+            e.upload_wait()
+        elif route == 1:
+            got = e.tokenize_text(text, row_offset=off, n_rows=n_rows)
+            assert got is not None and got[0] == n_rows
+        else:
+            e.upload(rows, off)
+        back = e.download(off, n_rows)
+        bad += int(not np.array_equal(back, rows))
+    e.close()
+    assert bad == 0, "%d of 200 uploads lost rows to the reservation's clearing" % bad
