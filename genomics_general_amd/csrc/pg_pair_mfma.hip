@@ -134,8 +134,32 @@ __device__ __forceinline__ v8i expand4(uint32_t w) {
     return f;
 }
 
+// Off the diagonal the two operands of a product are different fragments, and they need not be in the same form: a nibble with
+// only bit 0 / 1 / 2 set is 0.5 / 1.0 / 2.0, so the COLUMN fragment keeps bits 0, 1, 2 of every nibble where they are (three
+// ANDs; only bit 3, the sign, is shifted down: 5 operations instead of 7) and the ROW fragment puts the same sites into the same
+// places with the reciprocal values 2.0 / 1.0 / 0.5 / 2.0: every product of two set sites is 1.0, the accumulator is the count.
+// (A diagonal task multiplies a fragment with itself and stays with the form above: count / 4.)
+__device__ __forceinline__ v8i expand_col(uint32_t w) {
+    v8i f;
+    f[0] = (int)(w & 0x11111111u);
+    f[1] = (int)(w & 0x22222222u);
+    f[2] = (int)(w & 0x44444444u);
+    f[3] = (int)((w >> 3) & 0x11111111u);
+    return f;
+}
+__device__ __forceinline__ v8i expand_row(uint32_t w) {
+    v8i f;
+    f[0] = (int)((w << 2) & 0x44444444u);
+    f[1] = (int)(w & 0x22222222u);
+    f[2] = (int)((w >> 2) & 0x11111111u);
+    f[3] = (int)((w >> 1) & 0x44444444u);
+    return f;
+}
+
+// (scale operands 0, 0 select the unscaled encoding v_mfma_f32_32x32x64_f8f6f4 -- both scales 2^0 -- : one instruction word pair
+// less per product than the v_mfma_ld_scale + v_mfma pair, and no scale register to read)
 __device__ __forceinline__ v16f mfma4(const v8i &a, const v8i &b, const v16f &c) {
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0, 0, 0);
 }
 
 template <int UNIT4>     // UNIT4 = 1: the accumulator holds count / 4 (0.5 x 0.5 products, scales 2^0); 0: the count itself
@@ -156,9 +180,9 @@ __device__ __forceinline__ void pairC4_pair(const WordsC<NR, NC, DG> &w, bool li
     for (int t = 0; t < 4; ++t) {
         v8i fc[NC], fr[NR];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) fc[j] = expand4(live ? comp(w.c[j], t) : 0u);
+        for (int j = 0; j < NC; ++j) fc[j] = DG ? expand4(live ? comp(w.c[j], t) : 0u) : expand_col(comp(w.c[j], t));
 #pragma unroll
-        for (int i = 0; i < NR; ++i) fr[i] = DG ? fc[i] : expand4(live ? comp(w.r[DG ? 0 : i], t) : 0u);
+        for (int i = 0; i < NR; ++i) fr[i] = DG ? fc[i] : expand_row(live ? comp(w.r[DG ? 0 : i], t) : 0u);
 #pragma unroll
         for (int i = 0; i < NR; ++i)
 #pragma unroll
@@ -204,7 +228,7 @@ __device__ __forceinline__ void pairC4_task(const uint4 *__restrict__ base, int 
     for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int j = 0; j < NC; ++j)
-            if (!DG || j >= i) store_tile4<1>(acc[i][j], I0 + i, J0 + j, lane, n_units, diag, atomic, Cw);
+            if (!DG || j >= i) store_tile4<DG ? 1 : 0>(acc[i][j], I0 + i, J0 + j, lane, n_units, diag, atomic, Cw);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVES, PG_MFMA_WAVES)))
@@ -251,9 +275,9 @@ __device__ __forceinline__ void pairD4_step(const WordsD<NR, NC, DG> &w, bool li
     v8i ca[NC], cb[NC], ra[NR], rb[NR];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-        const uint32_t v = live ? w.c[j].y : 0u, a = w.c[j].x & v, b = v ^ a;
-        ca[j] = expand4(a);
-        cb[j] = expand4(b);
+        const uint32_t v = (live || !DG) ? w.c[j].y : 0u, a = w.c[j].x & v, b = v ^ a;     // (off the diagonal the rows carry `live`)
+        ca[j] = DG ? expand4(a) : expand_col(a);
+        cb[j] = DG ? expand4(b) : expand_col(b);
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -262,8 +286,8 @@ __device__ __forceinline__ void pairD4_step(const WordsD<NR, NC, DG> &w, bool li
             rb[i] = cb[i];
         } else {
             const uint32_t v = live ? w.r[DG ? 0 : i].y : 0u, a = w.r[DG ? 0 : i].x & v, b = v ^ a;
-            ra[i] = expand4(a);
-            rb[i] = expand4(b);
+            ra[i] = expand_row(a);
+            rb[i] = expand_row(b);
         }
     }
 #pragma unroll
@@ -315,7 +339,7 @@ __device__ __forceinline__ void pairD4_task(const uint2 *__restrict__ xv, int s0
     for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int j = 0; j < NC; ++j)
-            if (!DG || j >= i) store_tile4<1>(acc[i][j], I0 + i, J0 + j, lane, N, 0, atomic, Dw);
+            if (!DG || j >= i) store_tile4<DG ? 1 : 0>(acc[i][j], I0 + i, J0 + j, lane, N, 0, atomic, Dw);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_MFMA_WAVES, PG_MFMA_WAVES)))

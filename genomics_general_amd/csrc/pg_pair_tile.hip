@@ -136,6 +136,7 @@ __device__ __forceinline__ uint32_t comp(const uint4 &v, int k) { return k == 0 
 
 // accumulator tile (the counts) -> upper triangle of the window's matrix.  C/D layout of the 32 x 32 product: column = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+template <int SCALE = 1>
 __device__ __forceinline__ void store_tile(const v16f &acc, int I, int J, int lane, int n, int diag, int atomic, int32_t *__restrict__ M) {
     const int col = 32 * J + (lane & 31);
     if (col >= n) return;
@@ -143,7 +144,7 @@ __device__ __forceinline__ void store_tile(const v16f &acc, int I, int J, int la
     for (int reg = 0; reg < 16; ++reg) {
         const int row = 32 * I + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         if (row >= n || row > col || (row == col && !diag)) continue;
-        const int32_t v = (int32_t)acc[reg];
+        const int32_t v = (int32_t)(SCALE == 1 ? acc[reg] : acc[reg] * (float)SCALE);
         int32_t *dst = &M[(size_t)row * n + col];
         if (atomic) { if (v) atomicAdd(dst, v); }
         else *dst = v;
@@ -199,7 +200,7 @@ __device__ __forceinline__ void slotC(const uint4 &cw, const Masks &K, const v4i
                  : "scc", PG_SCRATCH);
 }
 
-template <int CS, int W, int GP>
+template <int CS, int W, int GP, int NST>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_pairC_tile(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vgoff, int n_win, int T, int nblk, int kparts, int NPv,
                   int n_units, int diag, const int32_t *__restrict__ prog, int nl, int32_t *__restrict__ Cmat) {
@@ -245,19 +246,22 @@ void k_pairC_tile(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ v
     if (nstage > 0) {
         // (copies past the last stage repeat it into a ring slot nobody reads: the counted waits stay uniform; a stage may reach
         // up to stage_groups - 1 groups past q1: those words exist (next part / window / padding) and their lanes are masked)
-        for (int st = 0; st < NSTG - 1; ++st) {
+        for (int st = 0; st < NST - 1; ++st) {
             const int src = st < nstage ? st : nstage - 1;
             stage_copy<W>(base + (size_t)src * stage_u4, lds + (size_t)st * stage_u4, chunks, nl, wave, lane);
         }
+        // (tools/audit_pair_tile_asm.py: no compiler code may touch an accumulator from here on; the operands pin their zeroing above)
+#pragma unroll
+        for (int s = 0; s < CS; ++s) asm volatile("; PG_AUDIT_BEGIN" : "+v"(acc[s][0]), "+v"(acc[s][1])::"memory");
         for (int st = 0; st < nstage; ++st) {
-            wait_vm(nl * (NSTG - 2));
+            wait_vm(nl * (NST - 2));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             {
-                const int nx = st + NSTG - 1, src = nx < nstage ? nx : nstage - 1;
-                stage_copy<W>(base + (size_t)src * stage_u4, lds + (size_t)(nx % NSTG) * stage_u4, chunks, nl, wave, lane);
+                const int nx = st + NST - 1, src = nx < nstage ? nx : nstage - 1;
+                stage_copy<W>(base + (size_t)src * stage_u4, lds + (size_t)(nx % NST) * stage_u4, chunks, nl, wave, lane);
             }
-            const uint4 *sb = lds + (size_t)(st % NSTG) * stage_u4;
+            const uint4 *sb = lds + (size_t)(st % NST) * stage_u4;
 #pragma unroll 1
             for (int p = 0; p < GP; ++p) {
                 const bool live = q0 + st * stage_groups + 2 * p + kb < q1;
@@ -290,7 +294,7 @@ void k_pairC_tile(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ v
             }
         }
         wait_vm(0);                                           // the surplus copies of the last iterations land before the block ends
-        asm volatile("s_nop 11" ::: "memory");                // the last matrix instruction's result is complete
+        asm volatile("s_nop 11 ; PG_AUDIT_END" ::: "memory");  // the last matrix instruction's result is complete
     }
     const bool zero_fill = nstage <= 0 && !atomic;            // an empty window: the counts are zero and nobody else writes them
     if (nstage > 0 || zero_fill) {
@@ -376,6 +380,9 @@ void k_pairD_tile(const uint32_t *__restrict__ XV, const int32_t *__restrict__ n
             const int src = st < nstage ? st : nstage - 1;
             stage_copy<W>(base + (size_t)src * stage_u4, lds + (size_t)st * stage_u4, chunks, nl, wave, lane);
         }
+        // (tools/audit_pair_tile_asm.py: no compiler code may touch an accumulator from here on; the operands pin their zeroing above)
+#pragma unroll
+        for (int s = 0; s < CS; ++s) asm volatile("; PG_AUDIT_BEGIN" : "+v"(acc[s][0]), "+v"(acc[s][1])::"memory");
         for (int st = 0; st < nstage; ++st) {
             wait_vm(nl * (NSTG - 2));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -417,7 +424,7 @@ void k_pairD_tile(const uint32_t *__restrict__ XV, const int32_t *__restrict__ n
             }
         }
         wait_vm(0);
-        asm volatile("s_nop 11" ::: "memory");
+        asm volatile("s_nop 11 ; PG_AUDIT_END" ::: "memory");
     }
     const bool zero_fill = nstage <= 0 && !atomic;
     if (nstage > 0 || zero_fill) {
@@ -535,15 +542,16 @@ int get_program(int T, int CS, int W, const int32_t **d_out, int *nblk_out) {
         slot->d = nullptr;
     }
     const Program p = make_program(T, CS, W);
-    if (hipMalloc(reinterpret_cast<void **>(&slot->d), p.tab.size() * 4) != hipSuccess) return -1;
-    if (hipMemcpy(slot->d, p.tab.data(), p.tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    const std::vector<int32_t> &tab = p.tab;
+    slot->nblk = p.nblk;
+    if (hipMalloc(reinterpret_cast<void **>(&slot->d), tab.size() * 4) != hipSuccess) return -1;
+    if (hipMemcpy(slot->d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
     slot->T = T;
     slot->CS = CS;
     slot->W = W;
-    slot->nblk = p.nblk;
     slot->device = dev;
     *d_out = slot->d;
-    *nblk_out = p.nblk;
+    *nblk_out = slot->nblk;
     return 0;
 }
 
@@ -581,11 +589,22 @@ int pg_launch_pairC_tile(hipStream_t st, const uint32_t *Vp, const int64_t *vgof
     if (get_program(T, CS_C, W_C, &prog, &nblk) != 0) return -1;
     const int kparts = std::max(pick_parts(n_win, nblk * W_C, avg_wq / 2, 16), exact_parts(max_sites));
     if (kparts > 1) (void)hipMemsetAsync(Cmat, 0, (size_t)n_win * n_units * n_units * 4, st);
-    const int stage_u4 = 2 * GP_C * NPv, chunks = stage_u4 / 64, nl = (chunks + W_C - 1) / W_C;
-    const size_t lds_bytes = (size_t)NSTG * stage_u4 * 16;
+    // ring shape (pairs of groups per stage, stages): PG_TILE_CFG = 0: 2 x 3, 1: 4 x 2 (half the barriers), 2: 2 x 2 (default; measured
+    // on the north-star shape: 1.31 / 1.28 / 1.24 ms)
+    const char *cfg_s = getenv("PG_TILE_CFG");
+    int cfg = cfg_s ? atoi(cfg_s) : 2;
+    if (cfg == 1 && (size_t)2 * 2 * 4 * NPv * 16 > 64 * 1024) cfg = 0;
+    const int gp = cfg == 1 ? 4 : 2, nst = cfg == 0 ? 3 : 2;
+    const int stage_u4 = 2 * gp * NPv, chunks = stage_u4 / 64, nl = (chunks + W_C - 1) / W_C;
+    const size_t lds_bytes = (size_t)nst * stage_u4 * 16;
     const int64_t blocks = (int64_t)((n_win + 7) / 8) * nblk * kparts * 8;
-    hipLaunchKernelGGL((k_pairC_tile<CS_C, W_C, GP_C>), dim3((unsigned)blocks), dim3(64 * W_C), lds_bytes, st, Vp, vgoff, n_win, T, nblk,
-                       kparts, NPv, n_units, diag, prog, nl, Cmat);
+#define PG_LAUNCH_C(GP, NST)                                                                                                          \
+    hipLaunchKernelGGL((k_pairC_tile<CS_C, W_C, GP, NST>), dim3((unsigned)blocks), dim3(64 * W_C), lds_bytes, st, Vp, vgoff, n_win, T, nblk, \
+                       kparts, NPv, n_units, diag, prog, nl, Cmat)
+    if (cfg == 1) PG_LAUNCH_C(4, 2);
+    else if (cfg == 2) PG_LAUNCH_C(2, 2);
+    else PG_LAUNCH_C(2, 3);
+#undef PG_LAUNCH_C
     return 0;
 }
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Audit of the hand-scheduled pair kernels (pg_pair_tile.hip): between a kernel's first s_barrier and its `s_nop 11` drain, no
+"""Audit of the hand-scheduled pair kernels (pg_pair_tile.hip): between a kernel's PG_AUDIT_BEGIN and PG_AUDIT_END markers (the
+accumulation loop of the waves that hold accumulators; the drain `s_nop 11` carries the end marker), no
 compiler-generated instruction may touch an accumulator register (a register written by a matrix instruction inside the asm
 statements) -- hipcc pads no hazards around inline asm, so a copy of a fresh matrix result would read garbage on some launches.
 Usage: audit_pair_tile_asm.py <pg_pair_tile-hip-amdgcn-amd-amdhsa-gfx950.s>   (from hipcc -save-temps)"""
@@ -25,8 +26,8 @@ def main(path):
         end = next(i for i in range(k0, len(lines)) if lines[i].startswith(".Lfunc_end"))
         body = lines[k0:end]
         try:
-            b0 = next(i for i, l in enumerate(body) if "s_barrier" in l)
-            b1 = max(i for i, l in enumerate(body) if "s_nop 11" in l)
+            b0 = max(i for i, l in enumerate(body) if "PG_AUDIT_BEGIN" in l)
+            b1 = max(i for i, l in enumerate(body) if "PG_AUDIT_END" in l)
         except (StopIteration, ValueError):
             print("no loop found in", lines[k0])
             bad += 1
