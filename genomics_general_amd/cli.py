@@ -373,17 +373,15 @@ class Run:
 
     def _device_tokenizer(self):
         """K0 on the device (Engine.tokenize_text; PG_GPU_TOKENIZER=0 keeps the host tokenizer): plain or gzipped text in one of the
-        regular layouts -- one ploidy for all wanted samples, which is what the layout says up front; what only the text can tell
-        (comment lines, runs of blanks, carriage returns) is found by the kernels block by block, and such a block goes through
-        the host tokenizer."""
+        regular layouts (cells of their columns' widths: mixed ploidy included); what only the text can tell (comment lines, runs
+        of blanks, carriage returns, a cell of another width) is found by the kernels block by block, and such a block goes
+        through the host tokenizer."""
         import os
         if os.environ.get("PG_GPU_TOKENIZER", "1") == "0" or not hasattr(self.engine, "tokenize_text"):
             return False
         if getattr(self._reader, "packed", False):
             return False
-        pl = set(int(x) for x in self.layout.col_ploidy if x > 0)
-        fmt = self.layout.genoFormat
-        return len(pl) == 1 and not (fmt == "diplo" and pl != {2}) and not (fmt == "haplo" and pl != {1})
+        return device_tokenizer_takes(self.layout)
 
     def _chunks_device(self):
         """chunks() with the tokenizer on the device: the reader thread hands over block k+1 (memory-mapped text, or gunzipped
@@ -518,6 +516,14 @@ class Run:
 
     def open_sink(self, path, header_text, id_column=False, id_sep=","):
         return _RowSink(self, path, header_text, id_column, id_sep)
+
+
+def device_tokenizer_takes(layout):
+    """the layouts pg_tokenize_text handles: any ploidies in the phased / pairs formats, diploid cells only in `diplo`, haploid
+    only in `haplo`"""
+    pl = set(int(x) for x in layout.col_ploidy if x > 0)
+    fmt = layout.genoFormat
+    return len(pl) >= 1 and not (fmt == "diplo" and pl != {2}) and not (fmt == "haplo" and pl != {1})
 
 
 class _RowSink:
@@ -1035,6 +1041,13 @@ def freq_main(argv=None):
     piped = hasattr(eng, "upload_async")                    # (tests/cpu_engine.py's stand-in mimics the interface)
     pitch = eng.row_pitch if piped else None
     alloc = eng.pinned.empty if piped else None
+    import ctypes as C
+    from ._lib import check, lib
+    L = lib()
+    # K0 on the device (default for text in a layout pg_tokenize_text takes; PG_GPU_TOKENIZER=0 keeps the host tokenizer)
+    on_device = (os.environ.get("PG_GPU_TOKENIZER", "1") != "0" and hasattr(eng, "tokenize_text")
+                 and not getattr(reader, "packed", False) and device_tokenizer_takes(layout))
+    stats = {"device_tokenizer": int(on_device), "host_tokenized_blocks": 0, "blocks": 0}
 
     def site_blocks():
         """(GenoData of an input block, run index of each of its rows, a, b) for sub-blocks [a,b) of at most CH sites.  The next
@@ -1051,7 +1064,10 @@ def freq_main(argv=None):
                     if len(body) == 0:
                         ready.put(None)
                         return
-                    ready.put(reader.to_geno(body, layout, pitch=pitch, alloc=alloc))
+                    if on_device:                           # the text itself goes to the device (this thread only reads ahead)
+                        ready.put(body)
+                    else:
+                        ready.put(reader.to_geno(body, layout, pitch=pitch, alloc=alloc))
                     del body
             except BaseException as exc:
                 ready.put(exc)
@@ -1063,6 +1079,21 @@ def freq_main(argv=None):
                 return
             if isinstance(data, BaseException):
                 raise data
+            stats["blocks"] += 1
+            if on_device:
+                # K0 on the device: the rows are written where k_site_counts reads them, only positions and runs come back
+                body = data
+                ptr, nbytes, _keep = _lib.text_ptr(body)
+                cnt = C.c_int64(0)
+                _lib.check(L.pg_count_lines(ptr, nbytes, C.byref(cnt)))
+                eng.reserve(int(cnt.value))
+                got = eng.tokenize_text(body, row_offset=0, n_rows=int(cnt.value)) if cnt.value else None
+                if got is not None:
+                    data = genoio.GenoData(None, got[1], got[2], got[3])
+                else:                                       # a block the device tokenizer refuses: host tokenizer, one upload
+                    data = reader.to_geno(body, layout, pitch=pitch, alloc=alloc)
+                    stats["host_tokenized_blocks"] += 1
+                del body, _keep
             run_of_row = np.repeat(np.arange(len(data.run_starts)), np.diff(np.append(data.run_starts, data.n_sites)))
             for a in range(0, data.n_sites, CH):
                 yield data, run_of_row, a, min(data.n_sites, a + CH)
@@ -1075,9 +1106,6 @@ def freq_main(argv=None):
         else:
             eng.load_sites(rows)
 
-    import ctypes as C
-    from ._lib import check, lib
-    L = lib()
     kept = []                                               # ranks > 0: their rows, until the gather
     if out is not None:
         out.flush()
@@ -1091,8 +1119,11 @@ def freq_main(argv=None):
             names_blob = b"".join(enc)
             name_off = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.int64)
             name_max, run0 = max([len(e) for e in enc] + [1]), 0
-        load(data.gt[a:b])
-        cnt32 = eng.batch([0], [0]).siteCounts(0, b - a)                        # int32 [n][P][4]
+        if data.gt is None:                                 # tokenised on the device: the block's rows are resident
+            cnt32 = eng.batch([0], [0]).siteCounts(a, b)                        # int32 [n][P][4]
+        else:
+            load(data.gt[a:b])
+            cnt32 = eng.batch([0], [0]).siteCounts(0, b - a)
         cnt = cnt32.astype(np.int64)
         n = cnt.sum(axis=2)
         keep = None                                                           # uint8 mask of the rows that are written
@@ -1153,6 +1184,9 @@ def freq_main(argv=None):
         sink.flush()
         if out is not sys.stdout:
             out.close()
+    if os.environ.get("PG_TIMING"):
+        import json
+        sys.stderr.write("PG_TIMING " + json.dumps(dict(stats, rank=world.rank)) + "\n")
     if world.rank == 0:
         sys.stderr.write("\nDone\n")
     return 0

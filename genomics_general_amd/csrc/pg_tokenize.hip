@@ -126,8 +126,9 @@ __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_rea
 // taken apart with ballots: the ends of the two tokens are bit scans, the position is a short scalar loop over readlane.  A line
 // whose prefix does not fit the 64 bytes (or starts with blanks) goes through the byte-by-byte walk on lane 0.
 __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ text, const int64_t *__restrict__ nl_pos, int64_t n_lines,
-                                                   int fmt, int n_cols, int cellw, int ploidy, int max_ploidy,
+                                                   int fmt, int n_cols, int cells_w, int max_ploidy,
                                                    const int32_t *__restrict__ col_slot, const int32_t *__restrict__ col_ploidy,
+                                                   const int32_t *__restrict__ col_off, const int32_t *__restrict__ col_w,
                                                    int8_t *__restrict__ rows, int S, int32_t *__restrict__ pos_out,
                                                    int64_t *__restrict__ run_row, int64_t *__restrict__ run_off, int32_t *__restrict__ run_len,
                                                    int32_t *__restrict__ n_runs, int64_t run_cap, int32_t *__restrict__ status, DipTable dip) {
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
                         for (int k = d0; k < p2 && v <= 0x7FFFFFFFll; ++k) v = v * 10 + (rl(ch, k) - '0');
                     if (v > 0x7FFFFFFFll) bad |= TOK_BAD_POS;
                     cells_at = ls + __builtin_ctzll(r2);
-                    if (le - cells_at != (int64_t)n_cols * (cellw + 1) - 1) bad |= TOK_IRREGULAR;
+                    if (le - cells_at != (int64_t)cells_w) bad |= TOK_IRREGULAR;
                     if (lane == 0) {
                         pos_out[row] = (int32_t)(neg ? -v : v);
                         if (differs) {
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
         pos_out[row] = (int32_t)(neg ? -v : v);
         while (p < le && blank(text[p])) ++p;
         cells_at = p;
-        // the regular layout: n_cols cells of cellw characters, one separator between them, the last cell ends the line
-        if (le - p != (int64_t)n_cols * (cellw + 1) - 1) bad |= TOK_IRREGULAR;
+        // the regular layout: n_cols cells of their columns' widths, one separator between them, the last cell ends the line
+        if (le - p != (int64_t)cells_w) bad |= TOK_IRREGULAR;
     }
     cells_at = ((int64_t)__builtin_amdgcn_readfirstlane((int)(cells_at >> 32)) << 32) |
                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cells_at);
@@ -229,13 +230,15 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
     if (!bad) {
         int8_t *out = rows + row * (int64_t)S;
         for (int c = lane; c < n_cols; c += 64) {
-            const uint8_t *cell = text + cells_at + (int64_t)c * (cellw + 1);
+            // (every column has its own width: the haploid samples of a mixed-ploidy file have shorter cells; col_off / col_w are
+            // what the block's first line shows, and a line that deviates is irregular)
+            const int cellw = col_w[c];
+            const uint8_t *cell = text + cells_at + col_off[c];
             if (c + 1 < n_cols && !blank(cell[cellw])) bad |= TOK_IRREGULAR;
             for (int k = 0; k < cellw; ++k)
-                if (blank(cell[k])) bad |= TOK_IRREGULAR;                       // a shorter cell: mixed widths
+                if (blank(cell[k])) bad |= TOK_IRREGULAR;                       // a shorter cell
             const int pl = col_ploidy[c];
             if (pl <= 0) continue;
-            if (pl != ploidy) { bad |= TOK_IRREGULAR; continue; }
             const int32_t *slots = col_slot + (size_t)c * max_ploidy;
             if (fmt == PG_FMT_DIPLO) {
                 const uint8_t d = dip.v[cell[0]];
@@ -268,21 +271,53 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
     *n_runs_out = 0;
     *ok_out = 0;
     if (len == 0) { *ok_out = 1; return PG_OK; }
-    // one ploidy for every wanted column, or no fast path
-    int ploidy = 0;
+    bool any = false;
     for (int k = 0; k < n_cols; ++k) {
         if (col_ploidy[k] <= 0) continue;
-        if (ploidy == 0) ploidy = col_ploidy[k];
-        else if (col_ploidy[k] != ploidy) return PG_OK;
+        any = true;
+        if (col_ploidy[k] > max_ploidy) return pg_fail(PG_ERR_ARG, "col_ploidy[%d]=%d exceeds max_ploidy", k, col_ploidy[k]);
+        if (fmt == PG_FMT_DIPLO && col_ploidy[k] != 2) return PG_OK;
+        if (fmt == PG_FMT_HAPLO && col_ploidy[k] != 1) return PG_OK;
         for (int a = 0; a < col_ploidy[k]; ++a) {
             const int s = col_slot[(size_t)k * max_ploidy + a];
             if (s < 0 || s >= c->n_hap) return pg_fail(PG_ERR_ARG, "col_slot[%d][%d]=%d out of range", k, a, s);
         }
     }
-    if (ploidy == 0 || text[len - 1] != '\n') return PG_OK;
-    if (fmt == PG_FMT_DIPLO && ploidy != 2) return PG_OK;
-    if (fmt == PG_FMT_HAPLO && ploidy != 1) return PG_OK;
-    const int cellw = fmt == PG_FMT_PHASED ? 2 * ploidy - 1 : (fmt == PG_FMT_PAIRS ? ploidy : 1);
+    if (!any || text[len - 1] != '\n') return PG_OK;
+    // The cell widths of the block, read off its first line (scaffold, position, then n_cols cells with one blank between them):
+    // a wanted column's cell must be as wide as its ploidy says (phased: 2 p - 1 characters, pairs: p, haplo / diplo: 1); a file of
+    // mixed ploidy has narrower cells for its haploid samples.  Every other line is held against these widths on the device.
+    std::vector<int32_t> col_geo((size_t)2 * n_cols);
+    int cells_w = 0;
+    {
+        auto blank_h = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f'; };
+        const char *p = text, *e = static_cast<const char *>(memchr(text, '\n', (size_t)len));
+        for (int tok = 0; tok < 2; ++tok) {                                    // scaffold, position
+            while (p < e && blank_h(*p)) ++p;
+            if (p == e) return PG_OK;
+            while (p < e && !blank_h(*p)) ++p;
+        }
+        while (p < e && blank_h(*p)) ++p;
+        const char *cells0 = p;
+        for (int k = 0; k < n_cols; ++k) {
+            const char *b = p;
+            while (p < e && !blank_h(*p)) ++p;
+            const int w = (int)(p - b);
+            if (w < 1) return PG_OK;
+            if (col_ploidy[k] > 0) {
+                const int want = fmt == PG_FMT_PHASED ? 2 * col_ploidy[k] - 1 : (fmt == PG_FMT_PAIRS ? col_ploidy[k] : 1);
+                if (w != want) return PG_OK;
+            }
+            col_geo[(size_t)k] = (int32_t)(b - cells0);
+            col_geo[(size_t)n_cols + k] = w;
+            if (k + 1 < n_cols) {
+                if (p == e || !blank_h(*p)) return PG_OK;
+                ++p;                                                            // exactly one separator
+            }
+        }
+        if (p != e) return PG_OK;
+        cells_w = (int)(p - cells0);
+    }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream_up;
     int rc;
@@ -330,9 +365,10 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
     if ((rc = c->tok_nl.ensure((size_t)n_lines)) != PG_OK) return rc;
     hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(256), 0, st, c->tok_text.p, len, c->tok_i64.p, c->tok_nl.p);
     // ---- parse ----
-    if ((rc = c->tok_cols.ensure((size_t)n_cols * (max_ploidy + 1))) != PG_OK) return rc;
+    if ((rc = c->tok_cols.ensure((size_t)n_cols * (max_ploidy + 3))) != PG_OK) return rc;
     HIPCHK(hipMemcpyAsync(c->tok_cols.p, col_slot, (size_t)n_cols * max_ploidy * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->tok_cols.p + (size_t)n_cols * max_ploidy, col_ploidy, (size_t)n_cols * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->tok_cols.p + (size_t)n_cols * (max_ploidy + 1), col_geo.data(), (size_t)n_cols * 8, hipMemcpyHostToDevice, st));
     const int64_t run_cap = std::min<int64_t>(run_capacity, n_lines);
     if ((rc = c->tok_pos.ensure((size_t)n_lines + (size_t)run_cap + 8)) != PG_OK) return rc;   // pos [n_lines] + run_len [run_cap] (int32 each)
     if ((rc = c->tok_off.ensure((size_t)run_cap * 2)) != PG_OK) return rc;                      // run_row, run_off
@@ -346,7 +382,9 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
         for (int k = 0; d[k]; ++k) dip.v[(int)d[k]] = (uint8_t)(code(pr[k][0]) | (code(pr[k][1]) << 4));
     }
     hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, c->tok_text.p, c->tok_nl.p, n_lines, fmt, n_cols,
-                       cellw, ploidy, max_ploidy, c->tok_cols.p, c->tok_cols.p + (size_t)n_cols * max_ploidy, c->gt.p + row_offset * c->S, c->S,
+                       cells_w, max_ploidy, c->tok_cols.p, c->tok_cols.p + (size_t)n_cols * max_ploidy,
+                       c->tok_cols.p + (size_t)n_cols * (max_ploidy + 1), c->tok_cols.p + (size_t)n_cols * (max_ploidy + 2),
+                       c->gt.p + row_offset * c->S, c->S,
                        c->tok_pos.p, c->tok_off.p, c->tok_off.p + run_cap, c->tok_pos.p + n_lines, d_status + 1, run_cap, d_status, dip);
     HIPCHK(hipGetLastError());
     int32_t status[2] = {0, 0};

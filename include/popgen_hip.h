@@ -101,8 +101,9 @@ int pg_upload_wait(pg_ctx *ctx);
 /* K0 on the device: `len` bytes of complete `.geno` data lines (no header; the last byte a line feed) are copied to the GPU
  * (page-locked staging, host threads) and tokenised there straight into resident rows row_offset .. (+ n lines): line feeds
  * located by a count / scan / write pass, one wavefront per line.  The same cell decoding as pg_encode_text (genomics.py:390-396,
- * 407-408, 74-77, 1884-1904), for the regular layout only: one separator character between cells, cells of one width, one
- * ploidy for every wanted column, no comment or blank lines in the block.  *ok_out = 1 when the layout was regular and the rows
+ * 407-408, 74-77, 1884-1904), for the regular layout only: one separator character between cells, every column's cells of one
+ * width (the widths are read off the block's first line; a wanted column's width must be what its ploidy says, so a file of mixed
+ * ploidy -- narrower cells for its haploid samples -- is regular too), no comment or blank lines in the block.  *ok_out = 1 when the layout was regular and the rows
  * are valid; 0 otherwise (nothing may be assumed about the rows: tokenise the block with pg_encode_text and upload it).
  * Outputs: pos_out[row_capacity] the positions; the scaffold runs of the block as (first row, offset and length of the scaffold
  * token in text), sorted by row, run_capacity entries each (*ok_out = 0 when there are more).  Call pg_count_lines first to

@@ -161,3 +161,27 @@ def test_cli_reads_stdin_and_writes_gzip_and_stdout(tmp_path):
     assert r.returncode == 0 and r.stdout == b"", r.stderr.decode()[-500:]
     with gzip.open(out, "rt") as f:
         compare_text(align_columns(f.read(), want), want, round_digits(case))
+
+
+@pytest.mark.parametrize("name", ["mixed_haploid_flag", "mixed_ploidyfile_distmat", "abba_freq_counts", "abba_freq_derived"])
+def test_mixed_ploidy_and_freq_are_tokenised_on_the_device(name, tmp_path):
+    """files of mixed ploidy (narrower cells for the haploid samples) and freq.py's site blocks go through pg_tokenize_text like
+    everything else: no block falls back to the host tokenizer, and the output is the reference's"""
+    import json
+    import subprocess
+    import sys
+    case = [c for c in CASES if c["name"] == name][0]
+    root = os.path.dirname(os.path.dirname(GOLD))
+    out = str(tmp_path / (name + ".out"))
+    geno = os.path.join(GOLD, case["fixture"] + ".geno.gz")
+    argv = [a.format(geno=geno, dir=GOLD, out=out) for a in case["argv"]] + ["-o", out]
+    env = dict(os.environ, PG_TIMING="1", PG_STREAM_BYTES="40000")
+    r = subprocess.run([sys.executable, os.path.join(root, case["tool"])] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    tm = [json.loads(ln[len("PG_TIMING "):]) for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")]
+    assert tm and tm[-1].get("device_tokenizer") == 1 and tm[-1]["host_tokenized_blocks"] == 0, tm
+    assert tm[-1].get("chunks", tm[-1].get("blocks", 0)) > 1, tm                 # several blocks: carried rows, run seams
+    with open(out) as f, open(os.path.join(GOLD, name + ".out")) as g:
+        got, want = f.read(), g.read()
+    compare_text(align_columns(got, want), want, round_digits(case))

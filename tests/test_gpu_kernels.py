@@ -379,8 +379,9 @@ def test_device_tokenizer_equals_the_host_tokenizer(fixture, fmt):
 
 
 def test_device_tokenizer_refuses_irregular_blocks():
-    """mixed ploidy (cells of two widths), a comment line, doubled separators, a missing final line feed: the fast path says no
-    (the drivers then use the host tokenizer); a position that is not a number likewise"""
+    """a comment line, doubled separators, a cell of another width than its column's, a missing final line feed: the fast path says
+    no (the drivers then use the host tokenizer); a position that is not a number likewise.  Mixed ploidy (narrower cells for the
+    haploid samples) IS regular: the widths are per column -- unless the declared ploidies do not fit the cells"""
     import gzip
     import os
     from genomics_general_amd.engine import Engine
@@ -405,9 +406,28 @@ def test_device_tokenizer_refuses_irregular_blocks():
     mixed = gzip.open(os.path.join(gold, "mixed.geno.gz"), "rb").read()
     mnames = mixed[:mixed.index(b"\n")].decode().split()[2:]
     ml = HapLayout(SampleData(indNames=list(mnames), ploidyDict={nm: (1 if nm in ("s1", "s6", "s9") else 2) for nm in mnames}), mnames, "phased")
+    from genomics_general_amd import genoio
+    mbody = mixed[mixed.index(b"\n") + 1:]
+    for order in (list(mnames), mnames[4:] + mnames[1:2]):                     # all samples; a subset that starts with diploids
+        ml = HapLayout(SampleData(indNames=order, ploidyDict={nm: (1 if nm in ("s1", "s6", "s9") else 2) for nm in order}), mnames, "phased")
+        want = genoio.encode(mbody, ml)
+        e.set_layout(ml)
+        e.reserve(5000)
+        got = e.tokenize_text(mbody, row_offset=11)
+        assert got is not None and got[0] == want.n_sites and np.array_equal(got[1], want.pos)
+        assert np.array_equal(e.download(11, got[0]), want.gt) and got[3] == want.run_names
+    # every sample declared diploid: the haploid samples' cells are too narrow for that
+    e.set_layout(HapLayout(SampleData(indNames=list(mnames)), mnames, "phased"))
+    e.reserve(5000)
+    assert e.tokenize_text(mbody) is None
+    # one line whose haploid cell became diploid (another width than the block's first line shows)
+    ml = HapLayout(SampleData(indNames=list(mnames), ploidyDict={nm: (1 if nm in ("s1", "s6", "s9") else 2) for nm in mnames}), mnames, "phased")
     e.set_layout(ml)
     e.reserve(5000)
-    assert e.tokenize_text(mixed[mixed.index(b"\n") + 1:]) is None
+    mlines = mbody.split(b"\n")
+    cells = mlines[40].split(b"\t")
+    cells[3] = b"A/C"                                                           # s1 is haploid
+    assert e.tokenize_text(b"\n".join(mlines[:40] + [b"\t".join(cells)] + mlines[41:])) is None
     e.close()
 
 
