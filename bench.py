@@ -561,6 +561,10 @@ def main():
                                      "note": "pair-count kernels C + D together vs SURVEY 8d's 7-lane-op-per-32-pair-sites VALU bound; "
                                              "polymorphic-site compaction and per-individual called counts do less work than that, "
                                              "and the matrix cores are not bound by it"}
+    if roofline is not None and roofline.get("traffic") is not None:
+        roofline["traffic_source"] = ("profiles/hbm_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch from separate "
+                                      "`rocprofv3 --pmc` passes of this command (profiles/%s/), not a live counter"
+                                      % pmc.get("_source", {}).get(args.workload, "?"))
     if gather_ms is not None:
         extra["result_allgather_ms_per_step"] = round(gather_ms, 3)      # inside the timed region (rank 0's wait for the slowest rank included)
         extra["per_rank_ms_per_step"] = {"min": round(1e3 * float(per_rank[:, 0].min()) / args.steps, 4),

@@ -47,6 +47,15 @@ PLOIDY_FLAGS = [
 ]
 
 
+ENGINE_EPILOG = ("MI355X engine: one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as a launcher sets them), "
+                 "the input is split over the ranks at scaffold runs and the finished rows are gathered once.  Environment: "
+                 "PG_STREAM_BYTES text bytes per input block (default 1 GiB); PG_SCRATCH_GIB scratch budget of the pairwise pipeline "
+                 "(default 48); PG_PLACE_TRIALS=1 no placement trials when 4 GiB or more of rows are reserved (default: up to 4 "
+                 "allocations of the rows are held together and probed, the fastest kept -- on a device shared with other jobs set it "
+                 "to 1); PG_GPU_TOKENIZER=0 tokenise on host threads; PG_HOST_THREADS host threads per process; PG_TIMING=1 per-phase "
+                 "times on stderr.  See README.md for the full list.")
+
+
 def _add(parser, table, **override):
     for names, kw in table:
         kw = dict(kw)
@@ -152,6 +161,9 @@ class Run:
         import os
         import time
         self.world = dist.world_from_env()
+        if self.world.size > 1 and not os.environ.get("PG_HOST_THREADS"):
+            # N ranks on one node: the native helpers (line count, tokenizers, staging copies of the device tokenizer) share the cores
+            os.environ["PG_HOST_THREADS"] = str(max(1, (os.cpu_count() or 1) // self.world.size))
         self._t_start = time.perf_counter()
         self.timing = {"read_s": 0.0, "text_bytes": 0, "tokenize_s": 0.0, "windows_s": 0.0, "sites": 0, "windows": 0,
                        "engine_and_upload_s": 0.0, "upload_s": 0.0, "prep_wait_s": 0.0, "chunks": 0}   # printed as JSON on stderr when PG_TIMING=1
@@ -577,7 +589,7 @@ def _fmt_cell(v):
 # popgenWindows.py
 # ==========================================================================================================
 def popgen_main(argv=None):
-    ap = argparse.ArgumentParser(prog="popgenWindows.py")
+    ap = argparse.ArgumentParser(prog="popgenWindows.py", epilog=ENGINE_EPILOG)
     _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined"))})
     ap.add_argument("-O", "--overlap", type=int, metavar="sites", help="Overlap for sites sliding window")
     ap.add_argument("--minData", type=float, metavar="prop", default=0.01,
@@ -730,7 +742,7 @@ def fourpop_main(argv=None):
 
 
 def _quartet_main(argv, prog, stats, fourpop):
-    ap = argparse.ArgumentParser(prog=prog)
+    ap = argparse.ArgumentParser(prog=prog, epilog=ENGINE_EPILOG)
     _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined"))})
     ap.add_argument("--overlap", type=int, metavar="sites", help="Overlap for sites sliding window")
     ap.add_argument("--minData", type=float, metavar="proportion", default=0.01,
@@ -838,7 +850,7 @@ def _matrix_text(M, names, fmt, roundTo):
 
 
 def distmat_main(argv=None):
-    ap = argparse.ArgumentParser(prog="distMat.py")
+    ap = argparse.ArgumentParser(prog="distMat.py", epilog=ENGINE_EPILOG)
     _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined", "cat")),
                               "-m": dict(default=None)})
     ap.add_argument("-O", "--overlap", type=int, metavar="sites", help="Overlap for sites sliding window")
@@ -953,7 +965,7 @@ def freq_main(argv=None):
     frequency / count of a target allele (`--target derived|minor`).  Counts come from k_site_counts (pg_site_counts).
     Divergence: for `--target minor` the reference breaks count ties with np.random.choice (genomics.py:664-669); here the
     tied allele with the lower base index is taken."""
-    ap = argparse.ArgumentParser(prog="freq.py")
+    ap = argparse.ArgumentParser(prog="freq.py", epilog=ENGINE_EPILOG)
     ap.add_argument("-g", "--genoFile", help="Input geno file")
     ap.add_argument("-o", "--outFile", help="Output file")
     ap.add_argument("-f", "--genoFormat", choices=("phased", "diplo", "alleles"), default="phased")
@@ -1023,6 +1035,8 @@ def freq_main(argv=None):
     # plain-text input (the slice-parallel reading of freq.py:23-28), formats its own rows, and ONE gather brings them to
     # rank 0 in rank order = input order.  Inputs that cannot be cut (gzip, stdin, .pgeno): rank 0 does the job.
     world = dist.world_from_env()
+    if world.size > 1 and not os.environ.get("PG_HOST_THREADS"):
+        os.environ["PG_HOST_THREADS"] = str(max(1, (os.cpu_count() or 1) // world.size))
     eng = Engine(args.device if args.device is not None else dist.device_for(world))
     eng.set_layout(layout)
     comm = dist.make_comm(eng, world)

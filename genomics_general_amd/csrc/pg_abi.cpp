@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <thread>
 
 static thread_local char g_err[1024] = "";
 
@@ -17,6 +18,15 @@ int pg_fail(int code, const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
+}
+
+int pg_host_threads() {
+    int nt = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("PG_HOST_THREADS")) {
+        const int v = atoi(e);
+        if (v > 0) nt = v;
+    }
+    return nt < 1 ? 1 : nt;
 }
 
 extern "C" const char *pg_last_error(void) { return g_err; }

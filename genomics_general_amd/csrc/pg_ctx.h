@@ -9,6 +9,9 @@
 #define PG_MAX_HAP 32768
 
 int pg_fail(int code, const char *fmt, ...);
+// host threads the library may start for one call: every hardware thread, or PG_HOST_THREADS (the drivers set it to cores / ranks
+// under a multi-rank launch, so that N ranks on one node do not start N x cores threads)
+int pg_host_threads();
 
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \

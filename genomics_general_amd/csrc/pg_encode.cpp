@@ -148,7 +148,7 @@ static std::vector<size_t> line_cuts(const char *buf, size_t len, int nt) {
 extern "C" int pg_count_lines(const char *buf, size_t len, int64_t *n_rows_out) {
     if ((!buf && len) || !n_rows_out) return pg_fail(PG_ERR_ARG, "pg_count_lines: null argument");
     // all host threads: on a gigabyte block a single-threaded count costs as much as the parallel parse that follows it
-    int nt = (int)std::thread::hardware_concurrency();
+    int nt = pg_host_threads();
     if (nt < 1) nt = 1;
     if ((size_t)nt > len / (1 << 20) + 1) nt = (int)(len / (1 << 20) + 1);
     if (nt == 1) {
@@ -184,7 +184,7 @@ extern "C" int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, 
     }
     *n_sites_out = 0;
     if (len == 0) return PG_OK;
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : pg_host_threads();
     if (nt < 1) nt = 1;
     if ((size_t)nt > len / (1 << 16) + 1) nt = (int)(len / (1 << 16) + 1);
     // chunk boundaries at line starts
@@ -224,7 +224,7 @@ extern "C" int pg_scaffold_runs(const char *buf, const int64_t *scaf_off, const 
     if (!n_runs_out || (n_sites > 0 && (!buf || !scaf_off || !scaf_len))) return pg_fail(PG_ERR_ARG, "pg_scaffold_runs: null argument");
     // row i starts a run when its scaffold token differs from row i-1's: independent per row, so the rows are cut into ranges for
     // the host threads (every row's token sits in a different cache line of the text) and the ranges' run starts concatenated
-    int nt = (int)std::thread::hardware_concurrency();
+    int nt = pg_host_threads();
     if (nt < 1) nt = 1;
     if ((int64_t)nt > n_sites / 65536 + 1) nt = (int)(n_sites / 65536 + 1);
     std::vector<std::vector<int64_t>> found(nt);
@@ -262,7 +262,7 @@ extern "C" int pg_decode_packed(const uint8_t *cells, int64_t n_rows, int n_cols
         return pg_fail(PG_ERR_ARG, "pg_decode_packed: bad shape");
     if (n_rows == 0) return PG_OK;
     if (!cells || !col_slot || !col_ploidy || !gt_out) return pg_fail(PG_ERR_ARG, "pg_decode_packed: null argument");
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : pg_host_threads();
     if (nt < 1) nt = 1;
     if ((int64_t)nt > n_rows) nt = (int)n_rows;
     auto work = [&](int64_t r0, int64_t r1) {
@@ -303,7 +303,7 @@ extern "C" int pg_inflate_chunks(const uint8_t *src, const int64_t *src_off, con
         at[i + 1] = at[i] + raw_len[i];
     }
     if (at[n_chunks] != len_a + len_b) return pg_fail(PG_ERR_ARG, "pg_inflate_chunks: the chunks hold %lld bytes, the destinations %lld", (long long)at[n_chunks], (long long)(len_a + len_b));
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : pg_host_threads();
     if (nt < 1) nt = 1;
     if (nt > n_chunks) nt = n_chunks > 0 ? n_chunks : 1;
     std::atomic<int> next(0), bad(0);
@@ -374,7 +374,7 @@ extern "C" int pg_format_freq_rows(int mode, int64_t n_rows, int n_pops, const v
     *out_len = 0;
     if (n_rows == 0) return PG_OK;
     if (!values || !pos || !run_of_row || !names || !name_off || !out) return pg_fail(PG_ERR_ARG, "pg_format_freq_rows: null argument");
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : pg_host_threads();
     if (nt < 1) nt = 1;
     if ((int64_t)nt > n_rows / 4096 + 1) nt = (int)(n_rows / 4096 + 1);
     std::vector<std::string> part(nt);

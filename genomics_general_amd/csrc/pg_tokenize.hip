@@ -327,7 +327,7 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
     for (int k = 0; k < 2; ++k)
         if ((rc = c->tok_pin[k].ensure(std::min<size_t>(piece, (size_t)len))) != PG_OK) return rc;
     if (!c->tok_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->tok_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->tok_ev[1], hipEventDisableTiming)); }
-    int nt = (int)std::thread::hardware_concurrency();
+    int nt = pg_host_threads();
     nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
     int64_t done = 0;
     for (int k = 0; done < len; ++k) {

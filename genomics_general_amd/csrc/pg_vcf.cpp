@@ -373,7 +373,7 @@ extern "C" int pg_encode_vcf(const char *buf, size_t len, int n_vcf_samples, int
     *n_sites_out = 0;
     if (n_multibase_out) *n_multibase_out = 0;
     if (len == 0) return PG_OK;
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : pg_host_threads();
     if (nt < 1) nt = 1;
     if ((size_t)nt > len / (1 << 16) + 1) nt = (int)(len / (1 << 16) + 1);
     std::vector<size_t> cut(nt + 1, len);
