@@ -497,11 +497,13 @@ def main():
     if os.environ.get("PG_PAIR_VALU"):
         pair_c, pair_d = "k_pairC", "k_pairD"
     else:
-        # matrix cores: LDS-staged block kernels where the plane fits their ring (PG_PAIR_TILE, default "c"), else one wave per block
-        tile_sel = os.environ.get("PG_PAIR_TILE", "c")
+        # matrix cores: one wave per SIMD up to 224 units, LDS-staged block kernels where the plane fits their ring (PG_PAIR_TILE,
+        # default "bc"), else one wave per block
+        tile_sel = os.environ.get("PG_PAIR_TILE", "bc")
         np32 = (n_hap + 31) // 32 * 32
         npv = (n_hap // 2 + 31) // 32 * 32 if dip else np32
-        pair_c = "k_pairC_tile" if ("c" in tile_sel and 3 * 4 * npv * 16 <= 65536) else "k_pairC_fp4"
+        pair_c = ("k_pairC_big" if ("b" in tile_sel and (n_hap // 2 if dip else n_hap) <= 224) else
+                  "k_pairC_tile" if ("c" in tile_sel and 3 * 4 * npv * 16 <= 65536) else "k_pairC_fp4")
         pair_d = "k_pairD_tile" if ("d" in tile_sel and 3 * 4 * np32 * 8 <= 65536) else "k_pairD_fp4"
     rocprof_name = {_lib.K_PACK: pack_name, _lib.K_PAIRWISE: pair_c, _lib.K_PAIRD: pair_d,
                     _lib.K_SITESTATS: "k_popfreq_q" if wl["tool"] == "popfreq" else "k_abba_q"}

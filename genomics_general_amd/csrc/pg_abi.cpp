@@ -701,7 +701,9 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         // PG_PAIR_I8=1); PG_PAIR_VALU=1 keeps the popcount kernels (A/B runs, tests)
         const bool valu_pairs = getenv("PG_PAIR_VALU") != nullptr;
         if (valu_pairs && NP % 64) return pg_fail(PG_ERR_STATE, "PG_PAIR_VALU must be set before pg_set_samples (plane stride %d)", NP);
-        if (!valu_pairs && pg_pair_tile_fits(NPv, 0)) {
+        if (!valu_pairs && pg_pair_big_fits(NPv, n_units)) {
+            pg_launch_pairC_big(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p);
+        } else if (!valu_pairs && pg_pair_tile_fits(NPv, 0)) {
             if (pg_launch_pairC_tile(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p))
                 return pg_fail(PG_ERR_HIP, "pair-kernel program upload failed");
         } else if (!valu_pairs) pg_launch_pairC_mfma(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p);

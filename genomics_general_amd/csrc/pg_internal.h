@@ -88,6 +88,11 @@ int pg_launch_pairC_tile(hipStream_t st, const uint32_t *Vp, const int64_t *vgof
 int pg_launch_pairD_tile(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win, int NP, int N,
                          int64_t avg_words, int64_t max_vsites, int32_t *Dmat, int capg);
 
+// called counts with one wave per SIMD and up to 14 tiles per wave (pg_pair_big.hip): planes of up to 224 units
+bool pg_pair_big_fits(int NPv, int n_units);
+void pg_launch_pairC_big(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, int NPv, int n_units, int diag,
+                         int64_t avg_wq, int64_t max_sites, int32_t *Cmat);
+
 void pg_launch_sample_het(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                           const int32_t *samp_start, int n_samp, int min_pair_sites, double *out);
 void pg_launch_hapstats(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,

@@ -571,10 +571,11 @@ constexpr int CS_D = 4, W_D = 4, KD_D = 2;      // D: 4 waves x 4 slots, stage =
 }  // namespace
 
 // The LDS-staged kernels take planes of up to this many units per word (a stage must fit the ring).  PG_PAIR_TILE chooses who
-// runs them: "cd" both counts, "c" / "d" one of them, "none" neither (the one-wave kernels of pg_pair_mfma.hip); default below.
+// runs them: "cd" both counts, "c" / "d" one of them, "none" neither (the one-wave kernels of pg_pair_mfma.hip); a 'b' lets
+// k_pairC_big (pg_pair_big.hip) take the called counts of planes of up to 224 units first.  Default "bc".
 bool pg_pair_tile_fits(int NPv_or_NP, int is_d) {
     const char *sel = getenv("PG_PAIR_TILE");
-    if (!sel) sel = "c";
+    if (!sel) sel = "bc";
     if (!strchr(sel, is_d ? 'd' : 'c')) return false;
     const int64_t stage = is_d ? (int64_t)2 * KD_D * NPv_or_NP * 8 : (int64_t)2 * GP_C * NPv_or_NP * 16;
     return NPv_or_NP % 32 == 0 && stage * NSTG <= 64 * 1024;

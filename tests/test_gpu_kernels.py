@@ -253,6 +253,30 @@ def test_every_pairwise_code_path_gives_the_same_integers(mode, monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("n_dip", [31, 33, 64, 65, 97, 128, 129, 160, 161, 190, 193, 224])
+def test_called_counts_at_every_tile_count_of_the_one_wave_per_simd_kernel(n_dip):
+    """k_pairC_big: one to seven tile rows (one wave up to 14 tiles, two beyond), windows shorter and longer than its LDS ring,
+    odd group counts, a one-site window"""
+    e, lay, codes, _ = G.make_engine(n_dip, 3, 3300, seed=500 + n_dip, miss_thr=6000)
+    wins = [(0, 3300), (0, 129), (5, 1800), (3290, 3300), (1000, 1001), (640, 2432)]
+    D, C = e.batch([w[0] for w in wins], [w[1] for w in wins]).pairCounts(reference_order=True)
+    for k, (a, b) in enumerate(wins):
+        Do, Co = orc.pair_counts_gemm(oracle_aln(lay, codes, a, b))
+        assert np.array_equal(C[k], Co) and np.array_equal(D[k], Do), (n_dip, k)
+    e.close()
+
+
+@pytest.mark.parametrize("n_dip", [40, 100, 200])
+def test_called_counts_of_one_long_window_are_summed_over_its_parts(n_dip):
+    """few long windows are cut into parts that add into the matrix atomically (both wave counts of k_pairC_big)"""
+    e, lay, codes, _ = G.make_engine(n_dip, 2, 41000, seed=900 + n_dip, miss_thr=5000)
+    D, C = e.batch([0, 20000], [41000, 20500]).pairCounts(reference_order=True)
+    for k, (a, b) in enumerate([(0, 41000), (20000, 20500)]):
+        Do, Co = orc.pair_counts_gemm(oracle_aln(lay, codes, a, b))
+        assert np.array_equal(C[k], Co) and np.array_equal(D[k], Do), (n_dip, k)
+    e.close()
+
+
 def test_half_missing_genotypes_fall_back_to_haplotype_level_called_counts():
     """phased data such as `A|N`: the two haplotypes of an individual differ in calledness, so the per-individual
     called-count shortcut must be abandoned (and the result still be exact)"""
