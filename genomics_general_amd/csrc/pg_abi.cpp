@@ -602,18 +602,21 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     // scratch bytes per 32-site input word of one slot: called plane + reserved virtual-site planes (capg words per group)
     const int capg = c->xv_worst ? PG_XV_CAP(grp) : PG_XV_CAP_DEFAULT(grp);
     const int64_t word_bytes = ((int64_t)NP * 4 * PG_XV_PLANES * capg + grp - 1) / grp + (int64_t)NPv * 4;
-    // sub-batch size: at most half the scratch budget per slot, and at least ~8 sub-batches per call so the two
-    // streams have something to overlap (but not so small that a sub-batch cannot fill the GPU)
+    // sub-batch size: at most half the scratch budget per slot (and, for the two-stream pipeline, at least ~8 sub-batches per
+    // call, but none so small that it cannot fill the GPU)
     int64_t total_words_all = 0;
     for (int w = 0; w < n_win; ++w) total_words_all += ((hi[w] - lo[w] + 31) / 32 + grp - 1) / grp * grp;
     // A job that fits one batch runs as one batch on one stream: splitting it only to overlap the pack kernel with the pair
-    // kernels is slower (measured: C2 1.44 vs 0.99 ms).  A job that needs several batches anyway is cut into at least 8, so
-    // that all but the first pack kernel and all but the last pair kernels run beside each other on the two streams
-    // (measured on the north-star shape: 13.3 ms with 8 sub-batches vs 14.0 ms with the 3 that the scratch limit forces).
-    // (one batch uses one slot: it may take the whole scratch budget; sub-batches share it between the two slots)
+    // kernels is slower (measured: C2 1.44 vs 0.99 ms).  A job that needs several batches is cut at the scratch limit and its
+    // sub-batches follow each other on the one stream: since the pair kernels run on the matrix cores, the pack kernel beside
+    // them on a second stream costs more CU time than it hides (north-star shape 11.2 - 12.1 against 9.8 - 11.0 ms; one rank's
+    // share of config 5, 150 GB: 40.1 ms pipelined).  PG_OVERLAP=1 brings the two-stream pipeline back (at least 8 sub-batches,
+    // all but the first pack kernel beside the pair kernels of the sub-batch before).
+    // (one batch uses one slot: it may take the whole scratch budget; sub-batches alternate between the two slots)
     const bool multi = total_words_all * word_bytes + (int64_t)n_win * mat_bytes > c->scratch_limit;
-    const bool overlap = multi || getenv("PG_OVERLAP") != nullptr;
-    int64_t target_words = overlap ? std::max<int64_t>(total_words_all / 8, 32768) : total_words_all;
+    const bool two_streams = getenv("PG_OVERLAP") != nullptr;
+    const bool split = multi || two_streams;
+    int64_t target_words = two_streams ? std::max<int64_t>(total_words_all / 8, 32768) : total_words_all;
     for (int k = 0; k < 2; ++k) {
         if (!c->slot[k].packed) HIPCHK(hipEventCreateWithFlags(&c->slot[k].packed, hipEventDisableTiming));
         if (!c->slot[k].consumed) HIPCHK(hipEventCreateWithFlags(&c->slot[k].consumed, hipEventDisableTiming));
@@ -626,7 +629,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         while (w1 < n_win) {
             int64_t wlen = ((hi[w1] - lo[w1] + 31) / 32 + grp - 1) / grp * grp;
             int64_t nbytes = (words + wlen) * word_bytes + (int64_t)(w1 - w0 + 1) * mat_bytes;
-            if (w1 > w0 && (nbytes > (overlap ? c->scratch_limit / 2 : c->scratch_limit) || words + wlen > target_words)) break;
+            if (w1 > w0 && (nbytes > (split ? c->scratch_limit / 2 : c->scratch_limit) || words + wlen > target_words)) break;
             words += wlen;
             ++w1;
             if (w1 - w0 >= 65535) break;                      // gridDim.y limit
@@ -634,9 +637,9 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         const int nb = w1 - w0;
         pg_ctx::Slot &sl = c->slot[bi & 1];
         int rc;
-        // everything in one batch: nothing to overlap, so the pack kernel goes on the same stream as its consumers
-        // (saves the cross-stream event hand-over)
-        const bool single = (w0 == 0 && w1 == n_win);
+        // one batch, or sub-batches one after the other: the pack kernel goes on the same stream as its consumers
+        // (no cross-stream event hand-over)
+        const bool single = (w0 == 0 && w1 == n_win) || !two_streams;
         hipStream_t ps = single ? c->stream : c->stream2;
         // the slot's previous occupant (sub-batch bi-2) must be fully consumed before its planes are overwritten, and
         // its staging vector must have been copied before it is rebuilt

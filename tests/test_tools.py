@@ -75,3 +75,34 @@ def test_packed_reader_row_shards_concatenate_to_the_whole(tmp_path):
         # a skipped scaffold next to every cut candidate: no split
         q = genoio.PackedReader(dst)
         assert not q.shard(dist.World(1, 2, 1), None, lambda nm: nm != "chr2")
+
+
+def test_generated_pair_kernel_loops_are_what_the_generator_writes():
+    """csrc/pg_pairc_big.inc (the hand-scheduled main loops of k_pairC_big) is committed; it must be the output of
+    csrc/gen_pairc_big.py as committed, and every loop must keep the hazards the generator promises: a register written by a
+    VALU operation is read by a matrix instruction no sooner than two instructions later"""
+    import re
+    csrc = os.path.join(ROOT, "genomics_general_amd", "csrc")
+    env = {k: v for k, v in os.environ.items() if k != "PG_CBIG_VARIANT"}
+    out = subprocess.run([sys.executable, os.path.join(csrc, "gen_pairc_big.py")], capture_output=True, text=True, env=env, check=True).stdout
+    with open(os.path.join(csrc, "pg_pairc_big.inc")) as f:
+        assert f.read() == out
+    lines = [m.group(1) for m in re.finditer(r'^\s+"(.*?)\\n\\t" \\$', out, re.M)]
+    assert len(lines) > 5000
+    recent = []                                            # registers written by the last two instructions
+    n_mfma = 0
+    for ins in lines:
+        m = re.match(r"v_mfma\S* (\S+), v\[(\d+):(\d+)\], v\[(\d+):(\d+)\]", ins)
+        if m:
+            n_mfma += 1
+            used = set(range(int(m.group(2)), int(m.group(3)) + 1)) | set(range(int(m.group(4)), int(m.group(5)) + 1))
+            for w in recent[-2:]:
+                assert not (used & w), ins
+            recent.append(set())
+            continue
+        if ins.startswith("s_nop"):
+            recent += [set()] * (int(ins.split()[1]) + 1)
+            continue
+        w = re.match(r"v_\w+ v(\d+),", ins)
+        recent.append({int(w.group(1))} if w else set())
+    assert n_mfma == 8 * sum(t * (t + 1) // 2 for t in range(1, 8))        # two unrolled pairs x four K steps x the tiles of T = 1 .. 7
