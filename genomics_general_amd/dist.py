@@ -205,7 +205,15 @@ def make_comm(engine, world):
         return SoloComm()
     if os.environ.get("PG_COMM") == "file":
         return FileComm(world)
-    return RcclComm(engine, world)
+    try:
+        return RcclComm(engine, world)
+    except TimeoutError:
+        raise                                 # a rank never showed up: files would wait for it just as long
+    except Exception as exc:                  # RCCL itself refused (no peer access, IPC mode, ...): such failures hit every rank alike
+        import sys
+        sys.stderr.write("rank %d: RCCL communicator unavailable (%s); the finished rows travel through files instead (PG_COMM=file)\n"
+                         % (world.rank, str(exc)[:200]))
+        return FileComm(world)
 
 
 class GlooComm:

@@ -4,6 +4,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from genomics_general_amd import dist
 
@@ -315,3 +316,24 @@ def test_file_comm_world_size_3(tmp_path):
             o, _ = p.communicate()
         assert p.returncode == 0 and ("rank %d ok" % rank) in o.decode(), o.decode()[-2000:]
     assert not os.path.exists(str(tmp_path / "rdzv.d")), "the exchange directory is removed by the last rank to close"
+
+
+def test_a_refused_rccl_communicator_falls_back_to_files(monkeypatch, tmp_path, capsys):
+    """RCCL refusing to initialise (no peer access, two ranks on one device, ...) must not lose a run whose only exchange is the
+    gather of finished rows: make_comm says so on stderr and hands out the file communicator; a rank that never shows up
+    (TimeoutError of the unique-id hand-over) stays an error"""
+    monkeypatch.delenv("PG_COMM", raising=False)
+    monkeypatch.setenv("PG_RDZV_FILE", str(tmp_path / "rdzv"))
+
+    def refuse(engine, world):
+        raise RuntimeError("ncclCommInitRank: invalid usage")
+    monkeypatch.setattr(dist, "RcclComm", refuse)
+    comm = dist.make_comm(None, dist.World(0, 2, 0))
+    assert isinstance(comm, dist.FileComm) and comm.size == 2
+    assert "travel through files" in capsys.readouterr().err
+
+    def absent(engine, world):
+        raise TimeoutError("rank 1: no RCCL unique id")
+    monkeypatch.setattr(dist, "RcclComm", absent)
+    with pytest.raises(TimeoutError):
+        dist.make_comm(None, dist.World(1, 2, 1))
