@@ -73,6 +73,7 @@ SIGNATURES = {
     "pg_popdist_stats": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_double, C.c_int, _f64p]),
     "pg_indpairdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),
     "pg_indpairdist_mean": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, _f64p]),
+    "pg_indpairdist_mean_from_counts": (C.c_int, [_P, _i32p, _i32p, C.c_int, C.c_int, C.c_int, _f64p]),
     "pg_sample_het": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p]),
     "pg_hapstats": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, C.c_double, _i32p, _f64p]),
     "pg_abbababa": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _f64p, _i64p]),

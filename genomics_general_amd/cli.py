@@ -215,6 +215,15 @@ class Run:
             if self.sharded:
                 self._wshare = (1, 0)
                 self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size)
+        # `cat` (one window = every site of the input): sites are independent and pair counts add, so every rank takes a share of
+        # the LINES, counts its share, and the counts are summed across the ranks before the means are formed (distmat_main)
+        self.cat_sharded = False
+        if (shardable and self.world.size > 1 and wparams["windType"] == "cat" and hasattr(self._reader, "shard_lines")
+                and os.environ.get("PG_SHARD_INPUT", "1") != "0"):
+            self.cat_sharded = bool(self._reader.shard_lines(self.world))
+            if self.cat_sharded:
+                self._wshare = (1, 0)
+                self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size)
         if not stream:
             for _ in self.chunks():
                 break
@@ -503,9 +512,9 @@ class Run:
         import json
         import os
         import time
-        if os.environ.get("PG_TIMING") and (self.world.rank == 0 or self.sharded):
+        if os.environ.get("PG_TIMING") and (self.world.rank == 0 or self.sharded or self.cat_sharded):
             t = dict(self.timing)
-            t["rank"], t["sharded_input"], t["input_bytes"] = self.world.rank, self.sharded, self._reader.input_size()
+            t["rank"], t["sharded_input"], t["input_bytes"] = self.world.rank, self.sharded or self.cat_sharded, self._reader.input_size()
             t["total_s"] = time.perf_counter() - self._t_start
             # read / tokenize / windows run in their own threads: what this thread spent is the wait for them, the uploads it
             # waited for, and the statistics + output
@@ -919,14 +928,32 @@ def distmat_main(argv=None):
         good = sites_local >= minSites
         table = np.full((run.w1 - run.w0, npairs + 1), np.nan)               # pair means + minPerInd verdict
         table[:, npairs] = 1.0
-        if np.any(good):
+        if run.cat_sharded:
+            # this rank's window is its share of the lines: sites, called counts and pair counts are summed over the ranks
+            # (dist.sum_counts: one all-gather each), every rank finishes the one matrix from the sums
+            H = lay.n_hap
+            wb = run.batch(good) if np.any(good) else None
+            called = wb.hapCalled()[0] if wb is not None else np.zeros(H, dtype=np.int64)
+            head = dist.sum_counts(run.comm, np.concatenate([[int(sites_local[0])], called]))
+            D, Cc = wb.pairCounts(reference_order=False) if wb is not None else (np.zeros((1, H, H), np.int32),) * 2
+            D, Cc = dist.sum_counts(run.comm, D), dist.sum_counts(run.comm, Cc)
+            assert head[0] < 2 ** 31, "more than 2^31 sites in one window"
+            T.sites[0] = head[0]
+            if head[0] >= minSites:
+                if args.minPerInd:
+                    table[0, npairs] = float(head[1:].min() >= args.minPerInd)
+                tab = run.engine.indPairTableFromCounts(D, Cc, includeSameWithSame=args.includeSameWithSame)
+                table[0, :npairs] = tab[0, pair_col]
+            full = table
+        elif np.any(good):
             wb = run.batch(good)
             if args.minPerInd:
                 called = wb.hapCalled()
                 table[good, npairs] = (called.min(axis=1) >= args.minPerInd).astype(np.float64)
             tab = wb.indPairTable(includeSameWithSame=args.includeSameWithSame)
             table[good, :npairs] = tab[:, pair_col]
-        full = run.gather(table)
+        if not run.cat_sharded:
+            full = run.gather(table)
         if not out.local:
             continue
         for k in range(T.n):

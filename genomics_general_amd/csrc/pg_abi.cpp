@@ -1014,6 +1014,35 @@ extern "C" int pg_indpairdist_mean(pg_ctx *c, const int64_t *lo, const int64_t *
     return indpair_run(c, lo, hi, n_win, min_pair_sites, diag_counts_zeros ? 2 : 1, d_out, nullptr);
 }
 
+extern "C" int pg_indpairdist_mean_from_counts(pg_ctx *c, const int32_t *D, const int32_t *C, int n_win, int min_pair_sites,
+                                               int diag_counts_zeros, double *d_out) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null context");
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples has not been called");
+    if (n_win < 0) return pg_fail(PG_ERR_ARG, "negative window count");
+    if (n_win == 0) return PG_OK;
+    if (!D || !C || !d_out) return pg_fail(PG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t N = (size_t)c->n_hap, NN = N * N;
+    const size_t npairs = (size_t)c->n_samp * (c->n_samp + 1) / 2;
+    // haplotype-level counts on both sides (cN = n_hap, no unit shift), a bounded number of windows per trip
+    const int per = (int)std::max<size_t>(1, ((size_t)256 << 20) / (NN * 4));
+    int rc;
+    for (int w0 = 0; w0 < n_win; w0 += per) {
+        const int nb = std::min(per, n_win - w0);
+        if ((rc = c->Dmat.ensure((size_t)nb * NN)) != PG_OK) return rc;
+        if ((rc = c->Cmat.ensure((size_t)nb * NN)) != PG_OK) return rc;
+        if ((rc = c->res_f64.ensure((size_t)nb * npairs)) != PG_OK) return rc;
+        HIPCHK(hipMemcpyAsync(c->Dmat.p, D + (size_t)w0 * NN, (size_t)nb * NN * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->Cmat.p, C + (size_t)w0 * NN, (size_t)nb * NN * 4, hipMemcpyHostToDevice, c->stream));
+        pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->n_hap, 0, nb, c->samp_start.p, c->n_samp, min_pair_sites,
+                              c->res_f64.p, nullptr, diag_counts_zeros ? 2 : 1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(d_out + (size_t)w0 * npairs, c->res_f64.p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return PG_OK;
+}
+
 // ---- indHet / hapStats: device finalisers of the pairwise matrices ------------------------------------------
 extern "C" int pg_sample_het(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites, double *het_out) {
     int rc = check_windows(c, lo, hi, n_win);

@@ -256,6 +256,14 @@ def gather_table(comm, local_rows, n_total):
     return np.concatenate([allr[r, :counts[r]] for r in range(comm.size)], axis=0) if n_total else np.zeros((0, k))
 
 
+def sum_counts(comm, counts):
+    """Element-wise sum over the ranks of an integer array (pair counts, site counts: additive over the sites a rank holds), the
+    same on every rank.  One all-gather; the integers travel as float64 (exact below 2^53) and are added in int64."""
+    a = np.ascontiguousarray(counts)
+    allr = comm.allgather(a.ravel().astype(np.float64))
+    return np.rint(allr).astype(np.int64).sum(axis=0).reshape(a.shape)
+
+
 def gather_bytes(comm, data):
     """One byte string per rank -> the list of all of them (in rank order) on every rank: two all-gathers, the sizes and the
     payload padded to the largest (the bytes travel as the bit patterns of float64 words; an all-gather only copies)."""

@@ -274,6 +274,20 @@ class Engine:
     def comm_barrier(self):
         check(self._L.pg_comm_barrier(self._h))
 
+    def indPairTableFromCounts(self, D, C, includeSameWithSame=False, minSites=None):
+        """WindowBatch.indPairTable() from pair counts supplied by the caller (D, C as pairCounts(reference_order=False) returns
+        them): the counts of disjoint parts of a window add, so the ranks of a multi-GPU `distMat.py --windType cat` run sum
+        theirs and finish the means from the sums (pg_indpairdist_mean_from_counts)."""
+        lay = self.layout
+        n = lay.n_samp
+        D = np.ascontiguousarray(D, dtype=np.int32)
+        C = np.ascontiguousarray(C, dtype=np.int32)
+        assert D.shape == C.shape == (D.shape[0], lay.n_hap, lay.n_hap)
+        tab = np.zeros((D.shape[0], n * (n + 1) // 2), np.float64)
+        check(self._L.pg_indpairdist_mean_from_counts(self._h, D, C, D.shape[0], int(minSites) if minSites else 0,
+                                                      1 if includeSameWithSame else 0, tab))
+        return tab
+
 
 class WindowBatch:
     """Statistics of a set of windows [lo,hi) of the engine's resident sites."""

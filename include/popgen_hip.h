@@ -234,6 +234,13 @@ int pg_indpairdist(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, in
 int pg_indpairdist_mean(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites,
                         int diag_counts_zeros, double *d_out);
 
+/* The same means from pair counts the CALLER supplies: D, C as pg_pairwise writes them ([n_win][n_hap][n_hap] int32, device slot
+ * order).  Pair counts are sums over sites, so the counts of disjoint parts of a window add: this is how `distMat.py --windType cat`
+ * (one window = the whole input, distMat.py:284-289 / genomics.py:1949-1967) runs on several GPUs -- every rank counts its share
+ * of the lines (pg_pairwise), the counts are summed across the ranks, every rank finishes the means from the sums. */
+int pg_indpairdist_mean_from_counts(pg_ctx *ctx, const int32_t *D, const int32_t *C, int n_win, int min_pair_sites,
+                                    int diag_counts_zeros, double *d_out);
+
 /* ---- indHet / hapStats finished on the device (no N x N matrices leave the GPU) ------------------------------- */
 /* Replaces Alignment.sampleHet (genomics.py:918-929) on the reference worker's cached distance matrix:
  * het_out[n_win][n_individuals] (slot order of the individuals) = D/C of a diploid individual's two haplotypes where bit 1 of

@@ -87,6 +87,22 @@ class CpuEngine:
                 self.gt[offset:offset + len(snap)] = rows
         self._queued = []
 
+    def indPairTableFromCounts(self, D, C, includeSameWithSame=False, minSites=None):
+        assert not minSites
+        lay = self.layout
+        n = lay.n_samp
+        o = np.asarray(lay.ref_order)
+        tab = np.full((len(D), n * (n + 1) // 2), np.nan)
+        aln = orc.aln_from_codes(self.gt[:0], lay.hap_names, lay.hap_sample_name,
+                                 [g if g is not None else "~none" for g in lay.hap_group])[0]
+        for w in range(len(D)):
+            d = orc.dist_from_counts(np.asarray(D[w])[o][:, o], np.asarray(C[w])[o][:, o])
+            per = orc.ind_pair_dists(aln, d, includeSameWithSame)[0]
+            for s_ in range(n):
+                for t in range(s_, n):
+                    tab[w, lay.sample_pair_index(s_, t)] = per[lay.ind_order[s_]][lay.ind_order[t]]
+        return tab
+
     def batch(self, lo, hi):
         lo_a, hi_a = np.asarray(lo, dtype=np.int64), np.asarray(hi, dtype=np.int64)
         for offset, live, _, _ in self._queued:              # an upload in flight may only target rows no window reads
@@ -168,6 +184,15 @@ class CpuBatch:
 
     def fourPop(self, P1, P2, P3, P4, minData, polarize=False, fixed=False):
         return _stack([orc.four_pop(a, P1, P2, P3, P4, minData, polarize, fixed) for a in self.alns], self.n)
+
+    def pairCounts(self, reference_order=True):
+        DC = self._dc()
+        D = np.array([d for d, _ in DC], dtype=np.int32).reshape(self.n, self.lay.n_hap, self.lay.n_hap)
+        C = np.array([c for _, c in DC], dtype=np.int32).reshape(self.n, self.lay.n_hap, self.lay.n_hap)
+        if not reference_order:
+            inv = np.argsort(np.asarray(self.lay.ref_order))
+            D, C = D[:, inv][:, :, inv], C[:, inv][:, :, inv]
+        return D, C
 
     def hapCalled(self):
         return np.array([(self.e.gt[a:b] != 0).sum(axis=0) for a, b in zip(self.lo, self.hi)], dtype=np.int64).reshape(self.n, -1)

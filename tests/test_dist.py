@@ -337,3 +337,41 @@ def test_a_refused_rccl_communicator_falls_back_to_files(monkeypatch, tmp_path, 
     monkeypatch.setattr(dist, "RcclComm", absent)
     with pytest.raises(TimeoutError):
         dist.make_comm(None, dist.World(1, 2, 1))
+
+
+def test_cat_window_counts_are_summed_over_the_ranks(tmp_path):
+    """`distMat.py --windType cat` (one window = every site of the input): every rank counts a share of the LINES, the pair counts
+    (additive over sites) are summed across the ranks, the matrix is the reference's.  Two and three ranks; with --minPerInd
+    the per-haplotype called counts are summed the same way"""
+    import gzip
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from cases import CASES
+    from golden_util import align_columns
+    import test_gpu_golden as G
+    gold = os.path.join(ROOT, "tests", "golden")
+    case = [c for c in CASES if c["name"] == "holes_distmat_cat_nexus"][0]
+    geno = str(tmp_path / (case["fixture"] + ".geno"))
+    with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f, open(geno, "wb") as g:
+        g.write(f.read())
+    n_lines = sum(1 for _ in open(geno)) - 1
+    for k, (size, extra) in enumerate(((2, []), (3, []), (2, ["--minPerInd", "1"]))):
+        out = str(tmp_path / ("cat%d.out" % k))
+        argv = [a.format(geno=geno, dir=gold, out=out) for a in case["argv"]] + extra + ["-o", out]
+        port = 35000 + (os.getpid() + 13 * k) % 2000
+        procs = []
+        for rank in range(size):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), PG_TIMING="1")
+            procs.append(subprocess.Popen([sys.executable, "-c", CLI_WORKER, case["tool"]] + argv, env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE))
+        timing = []
+        for p in procs:
+            o, e = p.communicate(timeout=300)
+            assert p.returncode == 0, e.decode()[-1500:]
+            timing += [json.loads(ln[len("PG_TIMING "):]) for ln in e.decode().splitlines() if ln.startswith("PG_TIMING ")]
+        with open(out) as f, open(os.path.join(gold, case["name"] + ".out")) as g:
+            got, want = f.read(), g.read()
+        G.compare_text(align_columns(got, want), want, G.round_digits(case))
+        assert len(timing) == size and all(t["sharded_input"] for t in timing), timing
+        assert sum(t["sites"] for t in timing) == n_lines and max(t["sites"] for t in timing) < 0.7 * n_lines, timing

@@ -542,3 +542,20 @@ def test_uploads_queued_right_behind_a_growing_reservation_are_not_wiped():
         bad += int(not np.array_equal(back, rows))
     e.close()
     assert bad == 0, "%d of 200 uploads lost rows to the reservation's clearing" % bad
+
+
+@pytest.mark.parametrize("include_same", [False, True])
+def test_individual_pair_means_from_supplied_counts_equal_the_fused_path(include_same):
+    """pg_indpairdist_mean_from_counts on the counts pg_pairwise hands out == pg_indpairdist_mean on the same windows, and
+    the counts of the two halves of a window add up to the window's (what the ranks of a `cat` run rely on)"""
+    e, lay, codes, _ = G.make_engine(23, 3, 4000, seed=4242, miss_thr=9000)
+    wins = [(0, 4000), (0, 1777), (1777, 4000), (10, 11)]
+    wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
+    D, C = wb.pairCounts(reference_order=False)
+    want = wb.indPairTable(includeSameWithSame=include_same)
+    got = e.indPairTableFromCounts(D, C, includeSameWithSame=include_same)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.array_equal(D[1] + D[2], D[0]) and np.array_equal(C[1] + C[2], C[0])
+    summed = e.indPairTableFromCounts((D[1] + D[2])[None], (C[1] + C[2])[None], includeSameWithSame=include_same)
+    assert np.array_equal(summed[0], want[0], equal_nan=True)
+    e.close()
