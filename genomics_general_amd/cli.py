@@ -215,6 +215,29 @@ class Run:
             if self.sharded:
                 self._wshare = (1, 0)
                 self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size)
+        # predefined windows: shardable when the file's scaffold runs agree with the window list (windows.plan_predefined_shards);
+        # every rank scans its equal share of the bytes for run starts (pg_text_runs), one gather makes the run list of the file
+        self.shift_ids = True
+        if (shardable and self.world.size > 1 and self._streamer is not None and wparams["windType"] == "predefined"
+                and os.environ.get("PG_SHARD_INPUT", "1") != "0" and hasattr(self._reader, "text_runs")):
+            import json
+            mine = self._reader.text_runs(self.world)
+            parts = dist.gather_bytes(self.comm, json.dumps(mine).encode())
+            lists = [json.loads(p.decode()) for p in parts]
+            if all(x is not None for x in lists):
+                runs = []
+                for lst in lists:
+                    for off, name in lst:
+                        if not runs or runs[-1][1] != name:
+                            runs.append((int(off), name))
+                coords = self._streamer.coords
+                plan = windows.plan_predefined_shards(runs, self._reader.tell(), self._reader.input_size(), coords, self.world.size)
+                if plan is not None:
+                    a, b, idx, tail = plan[self.world.rank]
+                    self._reader.restrict(a, b)
+                    self._streamer = windows.PredefinedWindowStream([coords[k] for k in idx], scaf_order=[w[0] for w in coords], tail=tail)
+                    self.sharded, self._wshare, self.shift_ids = True, (1, 0), False
+                    self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size)
         # `cat` (one window = every site of the input): sites are independent and pair counts add, so every rank takes a share of
         # the LINES, counts its share, and the counts are summed across the ranks before the means are formed (distmat_main)
         self.cat_sharded = False
@@ -524,6 +547,12 @@ class Run:
                 t["compute_and_write_s"] = t["total_s"] - t["prep_wait_s"] - t["engine_and_upload_s"]
             sys.stderr.write("PG_TIMING " + json.dumps(t) + "\n")
 
+    def finish(self):
+        """the end of a driver: nobody leaves before everybody's rows are written; the communicator is closed (the file communicator
+        removes its exchange files there)"""
+        self.comm.barrier()
+        self.comm.close()
+
     def batch(self, mask):
         """WindowBatch over this rank's windows selected by boolean `mask`."""
         return self.engine.batch(self.lo[mask], self.hi[mask])
@@ -576,7 +605,7 @@ class _RowSink:
         tested, written = run.n_tested, self.written
         if run.sharded:
             counts = run.comm.allgather(np.array([float(run.n_tested), float(self.written)])).reshape(run.world.size, 2)
-            if self.id_column and run.world.rank > 0:
+            if self.id_column and run.world.rank > 0 and run.shift_ids:           # (predefined windows carry the IDs of their list)
                 shift = int(counts[:run.world.rank, 0].sum())
                 sep = self.id_sep
                 self.rows = [str(int(r[:r.index(sep)]) + shift) + r[r.index(sep):] for r in self.rows]
@@ -731,7 +760,7 @@ def popgen_main(argv=None):
         sys.stderr.write(str(written) + " results were written.\n")
         sys.stderr.write("\nDone.\n")
     run.report_timing()
-    run.comm.barrier()
+    run.finish()
     return 0
 
 
@@ -835,7 +864,7 @@ def _quartet_main(argv, prog, stats, fourpop):
     if run.world.rank == 0:
         sys.stderr.write("%d windows were tested\n%d results were written\n\nDone.\n" % (tested, written))
     run.report_timing()
-    run.comm.barrier()
+    run.finish()
     return 0
 
 
@@ -980,7 +1009,7 @@ def distmat_main(argv=None):
     if run.world.rank == 0:
         sys.stderr.write("{} windows were tested.\n{} results were written.\n\n### Done. ###\n".format(tested, written))
     run.report_timing()
-    run.comm.barrier()
+    run.finish()
     return 0
 
 
@@ -1230,4 +1259,6 @@ def freq_main(argv=None):
         sys.stderr.write("PG_TIMING " + json.dumps(dict(stats, rank=world.rank)) + "\n")
     if world.rank == 0:
         sys.stderr.write("\nDone\n")
+    if world.size > 1:
+        comm.close()
     return 0

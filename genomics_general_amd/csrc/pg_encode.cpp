@@ -166,6 +166,33 @@ extern "C" int pg_count_lines(const char *buf, size_t len, int64_t *n_rows_out) 
     return PG_OK;
 }
 
+// Scaffold runs of raw text: the byte offset of the first data line of every run of data lines that share their first field.
+extern "C" int pg_text_runs(const char *buf, size_t len, int64_t *starts_out, int64_t cap, int64_t *n_out) {
+    if ((!buf && len) || !n_out || (cap > 0 && !starts_out)) return pg_fail(PG_ERR_ARG, "pg_text_runs: null argument");
+    const char *p = buf, *end = buf + len;
+    const char *prev = nullptr;                      // first field of the previous data line
+    size_t prev_len = 0;
+    int64_t n = 0;
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        const char *le = nl ? nl : end;
+        if (le > p && *p != '#' && !(le - p == 1 && *p == '\r')) {
+            const char *q = p;
+            while (q < le && *q != '\t' && *q != ' ') ++q;
+            const size_t fl = (size_t)(q - p);
+            if (!prev || fl != prev_len || memcmp(p, prev, fl) != 0) {
+                if (n < cap) starts_out[n] = (int64_t)(p - buf);
+                ++n;
+                prev = p;
+                prev_len = fl;
+            }
+        }
+        p = nl ? nl + 1 : end;
+    }
+    *n_out = n;
+    return PG_OK;
+}
+
 extern "C" int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
                               const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int32_t *pos_out, int64_t *scaf_off,
                               int32_t *scaf_len, int64_t cap_sites, int64_t *n_sites_out, int n_threads) {

@@ -140,7 +140,9 @@ class FileComm:
     so this is what lets a multi-rank launch (bench.py --gpus N, the drivers) be exercised on a single-GPU box; the data path
     has no collective, only finished rows and barriers travel.  Every all-gather is one file per rank, renamed into place."""
 
-    def __init__(self, world, timeout_s=300.0):
+    def __init__(self, world, timeout_s=None):
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("PG_COMM_TIMEOUT", "300"))        # how long a rank waits for the others at an exchange
         self.size, self.rank, self.timeout_s = world.size, world.rank, timeout_s
         self.dir = _rdzv_path() + ".d"
         os.makedirs(self.dir, exist_ok=True)

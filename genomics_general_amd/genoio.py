@@ -319,6 +319,53 @@ class BlockReader:
         self.restrict(cuts[world.rank], cuts[world.rank + 1])
         return True
 
+    def text_runs(self, world):
+        """[(byte offset, scaffold)] of the first data line of every scaffold run among the lines that START in rank
+        `world.rank`'s equal share of the data bytes (pg_text_runs over the memory-mapped range); None when the input is not
+        plain text on disk.  The ranks' lists, concatenated with a seam run merged into its predecessor of the same name, are
+        the runs of the whole file."""
+        import ctypes as C
+        from . import _lib
+        if isinstance(self.f, BgzfFile) or not self.seekable_text() or self.mm is None:
+            return None
+        size = len(self.mm)
+        start = self.tell()
+        stride = max((size - start) // world.size, 1)
+
+        def cut(r):
+            if r <= 0:
+                return start
+            if r >= world.size:
+                return size
+            guess = min(start + stride * r, size)
+            nl = self.mm.find(b"\n", max(guess - 1, start), size)
+            return size if nl < 0 else nl + 1
+
+        a, b = cut(world.rank), cut(world.rank + 1)
+        if b <= a:
+            return []
+        view = memoryview(self.mm)[a:b]
+        ptr, nbytes, _keep = _lib.text_ptr(view)
+        L = _lib.lib()
+        cap = 1024
+        while True:
+            starts = np.zeros(cap, dtype=np.int64)
+            n = C.c_int64(0)
+            _lib.check(L.pg_text_runs(ptr, nbytes, starts, cap, C.byref(n)))
+            if n.value <= cap:
+                break
+            cap = int(n.value)
+        out = []
+        for off in starts[:n.value]:
+            q = a + int(off)
+            e = q
+            while e < b and self.mm[e] not in (9, 32, 10):
+                e += 1
+            out.append((q, self.mm[q:e].decode("utf-8", "replace")))
+        self.bytes_read += b - a
+        del view, _keep, ptr
+        return out
+
     def shard_lines(self, world):
         """Restrict this reader to rank `world.rank`'s share of the data lines, cut at ANY line boundary (sites are independent:
         freq.py, whose reference reads slices of sites in parallel, freq.py:23-28).  Every rank finds its own start and its

@@ -396,11 +396,16 @@ class PredefinedWindowStream:
     certain as soon as the buffer holds a row behind its end on its scaffold, or a later scaffold run, or the input is over;
     the rows of the previous window stay in the buffer because the next window of the same scaffold keeps them (left trim only)."""
 
-    def __init__(self, windCoords):
+    def __init__(self, windCoords, scaf_order=None, tail=None):
+        """scaf_order / tail: sharded ingestion (plan_predefined_shards).  The windows are this rank's, the order of the scaffolds
+        is the whole window list's, and `tail` says what the reference's reader would still find behind this rank's rows:
+        "wanted" (a run of a scaffold of the window list: the remaining windows come out empty), "rows" (only other rows: the
+        next window skips them, comes out empty and the generator ends) or None (nothing: the end of the file)."""
         self.coords = list(windCoords)
-        all_scafs = [w[0] for w in self.coords]
+        all_scafs = list(scaf_order) if scaf_order is not None else [w[0] for w in self.coords]
         self.scafs = sorted(set(all_scafs), key=all_scafs.index)
         self.rank = {s: k for k, s in enumerate(self.scafs)}
+        self.tail = tail
         self.wi = 0                          # next window
         self.cur = 0                         # the "line in hand", buffer row
         self.prev = None                     # (scaffold, lo, hi) of the previous window's rows, buffer rows
@@ -429,6 +434,8 @@ class PredefinedWindowStream:
             if c >= n and not final:
                 cur = c                       # skipped rows are never looked at again; the window waits for more input
                 break
+            if c == n and final and self.tail == "rows":
+                c = n + 1                     # the rows behind this rank's are skipped: the reader arrives at the end of the file
             new = None
             if c < n:
                 r = int(np.searchsorted(starts, c, side="right")) - 1
@@ -463,12 +470,53 @@ class PredefinedWindowStream:
             prev = (scaf, rows[0], rows[1])
             cur = c
             self.wi += 1
-            if cur >= n and final:
+            if final and (cur > n or (cur >= n and self.tail is None)):
                 self.done = True
         T.finish(positions)
         T.dup = np.zeros(T.n, dtype=bool)
         keep_from = cur if prev is None else min(cur, prev[1])
         keep_from = min(keep_from, n)
+        if self.wi >= len(self.coords) or self.done:          # no window is left to ask for a row: nothing is carried over
+            self.cur, self.prev = 0, None
+            return T, n
         self.cur = cur - keep_from
         self.prev = None if prev is None else (prev[0], prev[1] - keep_from, prev[2] - keep_from)
         return T, keep_from
+
+
+def plan_predefined_shards(runs, data_start, size, coords, n_ranks, max_share=0.75):
+    """Sharded ingestion for `--windType predefined`.  predefinedCoordWindows (genomics.py:2112-2171) walks the window list and the
+    file in step and never goes back, so in general a window's content depends on everything in front of it.  It does NOT when
+    (1) the windows are grouped by scaffold, (2) every scaffold of the window list is one run of the file, (3) those runs come in
+    the order of the window list: then the reader stands at the start of a scaffold's run when its first window is asked for,
+    whatever came before, and the file can be cut at run boundaries.
+    runs: [(byte offset of the run's first line, scaffold)] of the whole file; coords: the window list.  Returns None (replicated
+    ingestion) or, per rank, (first byte, end byte, indices of the rank's windows, tail) -- tail as PredefinedWindowStream takes it."""
+    scaf_seq = [w[0] for w in coords]
+    scafs = sorted(set(scaf_seq), key=scaf_seq.index)
+    order = {s_: k for k, s_ in enumerate(scafs)}
+    widx = [order[s_] for s_ in scaf_seq]
+    if any(a > b for a, b in zip(widx, widx[1:])):
+        return None
+    wanted = [(off, name) for off, name in runs if name in order]
+    names = [name for _, name in wanted]
+    if len(set(names)) != len(names) or set(names) != set(scafs):
+        return None
+    if any(order[a] > order[b] for a, b in zip(names, names[1:])):
+        return None
+    starts = [off for off, _ in runs]
+    cuts = [data_start]
+    for r in range(1, n_ranks):
+        target = data_start + (size - data_start) * r // n_ranks
+        nxt = [o for o in starts if o >= target]
+        cuts.append(max(nxt[0] if nxt else size, cuts[-1]))
+    cuts.append(size)
+    if max(cuts[r + 1] - cuts[r] for r in range(n_ranks)) > max_share * max(size - data_start, 1):
+        return None
+    plan = []
+    for r in range(n_ranks):
+        mine = set(name for off, name in wanted if cuts[r] <= off < cuts[r + 1])
+        tail = ("wanted" if any(off >= cuts[r + 1] for off, _ in wanted) else
+                "rows" if any(off >= cuts[r + 1] for off in starts) else None)
+        plan.append((cuts[r], cuts[r + 1], [k for k, w in enumerate(coords) if w[0] in mine], tail))
+    return plan

@@ -142,6 +142,11 @@ int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, int max_plo
  * restarts its window on, genomics.py:2013-2017).  n_runs_out is always the true count. */
 int pg_scaffold_runs(const char *buf, const int64_t *scaf_off, const int32_t *scaf_len, int64_t n_sites,
                      int64_t *run_start_out, int64_t max_runs, int64_t *n_runs_out);
+/* The same on RAW text (before any tokenising): byte offsets, relative to buf, of the first data line of every run of data lines
+ * ('#' lines and empty lines skipped, genomics.py:1943) that share their first field.  n_out is always the true count (call
+ * again with a larger cap).  Used to plan the sharding of `--windType predefined` input, whose forward-only reader
+ * (genomics.py:2112-2171) makes the windows depend on the order of the runs in the whole file. */
+int pg_text_runs(const char *buf, size_t len, int64_t *starts_out, int64_t cap, int64_t *n_out);
 /* Count data rows (non-'#', non-empty) in a text buffer so the caller can size the outputs. */
 int pg_count_lines(const char *buf, size_t len, int64_t *n_rows_out);
 

@@ -375,3 +375,65 @@ def test_cat_window_counts_are_summed_over_the_ranks(tmp_path):
         G.compare_text(align_columns(got, want), want, G.round_digits(case))
         assert len(timing) == size and all(t["sharded_input"] for t in timing), timing
         assert sum(t["sites"] for t in timing) == n_lines and max(t["sites"] for t in timing) < 0.7 * n_lines, timing
+
+
+def test_predefined_windows_are_sharded_when_the_file_agrees_with_the_window_list(tmp_path):
+    """`--windType predefined` on plain text with 2 and 3 ranks: every rank scans its share of the bytes for scaffold runs
+    (pg_text_runs), the plan cuts the file at run boundaries, every rank streams its own windows (window-list IDs, failed windows
+    and windows beyond a scaffold's last row included) and the reference's output comes out of the one gather.  A window list
+    that disagrees with the file (scaffolds in another order) falls back to replicated ingestion with the same output"""
+    import gzip
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from cases import CASES
+    from golden_util import align_columns
+    import test_gpu_golden as G
+    gold = os.path.join(ROOT, "tests", "golden")
+    case = [c for c in CASES if c["name"] == "sparse_predefined"][0]
+    geno = str(tmp_path / (case["fixture"] + ".geno"))
+    with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f, open(geno, "wb") as g:
+        g.write(f.read())
+    n_lines = sum(1 for _ in open(geno)) - 1
+    for k, size in enumerate((2, 3)):
+        out = str(tmp_path / ("pre%d.out" % k))
+        argv = [a.format(geno=geno, dir=gold, out=out) for a in case["argv"]] + ["-o", out]
+        port = 37000 + (os.getpid() + 17 * k) % 2000
+        procs = []
+        for rank in range(size):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), PG_TIMING="1", PG_STREAM_BYTES="20000")
+            procs.append(subprocess.Popen([sys.executable, "-c", CLI_WORKER, case["tool"]] + argv, env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE))
+        timing = []
+        for p in procs:
+            o, e = p.communicate(timeout=300)
+            assert p.returncode == 0, e.decode()[-1500:]
+            timing += [json.loads(ln[len("PG_TIMING "):]) for ln in e.decode().splitlines() if ln.startswith("PG_TIMING ")]
+        with open(out) as f, open(os.path.join(gold, case["name"] + ".out")) as g:
+            got, want = f.read(), g.read()
+        G.compare_text(align_columns(got, want), want, G.round_digits(case))
+        assert len(timing) == size and all(t["sharded_input"] for t in timing), timing
+        assert sum(t["sites"] for t in timing) == n_lines and max(t["sites"] for t in timing) < 0.8 * n_lines
+    # a window list whose scaffolds come in another order than the file's runs: the forward-only walk leaves the chr1 windows empty
+    # (the reader is past chr1 when they are asked for); the plan refuses, every rank reads everything, the output is the
+    # single-rank one
+    coords = str(tmp_path / "swapped.txt")
+    with open(coords, "w") as f:
+        f.write("chr3 1 1000 a\nchr3 2000 2600 b\nchr1 100 900 c\nchr1 500 1500 d\n")
+    outs = []
+    for k, size in enumerate((1, 2)):
+        out = str(tmp_path / ("swap%d.out" % size))
+        argv = [a.format(geno=geno, dir=gold, out=out) for a in case["argv"]] + ["-o", out]
+        argv[argv.index("--windCoords") + 1] = coords
+        procs = []
+        for rank in range(size):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(38000 + (os.getpid() + 19 * k) % 2000), PG_TIMING="1")
+            procs.append(subprocess.Popen([sys.executable, "-c", CLI_WORKER, case["tool"]] + argv, env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE))
+        for p in procs:
+            o, e = p.communicate(timeout=300)
+            assert p.returncode == 0, e.decode()[-1500:]
+            assert '"sharded_input": true' not in e.decode()
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and outs[0].count("\n") == 5

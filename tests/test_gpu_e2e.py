@@ -99,11 +99,13 @@ def test_bench_starts_its_own_ranks():
     assert d["config"]["windows_per_gpu"] * 2 * 3 / (d["ms_per_step"] * 3 / 1e3) == pytest.approx(d["value"], rel=1e-3)
 
 
-@pytest.mark.parametrize("size", [2, 3])
-def test_distmat_cat_window_on_several_ranks_sums_the_pair_counts(size, tmp_path):
-    """`distMat.py --windType cat` with WORLD_SIZE ranks (all on device 0, so the exchange goes through files): every rank counts its
+@pytest.mark.parametrize("name,tool,size", [("holes_distmat_cat_nexus", "distMat.py", 2), ("holes_distmat_cat_nexus", "distMat.py", 3),
+                                            ("sparse_predefined", "popgenWindows.py", 2), ("sparse_predefined", "popgenWindows.py", 3)])
+def test_cat_and_predefined_windows_on_several_ranks(name, tool, size, tmp_path):
+    """WORLD_SIZE ranks, all on device 0 (so the exchange goes through files).  `distMat.py --windType cat`: every rank counts its
     share of the lines on the GPU (pg_pairwise), the counts are summed across the ranks, the matrix finished from the sums
-    (pg_indpairdist_mean_from_counts) is the reference's"""
+    (pg_indpairdist_mean_from_counts) is the reference's.  `--windType predefined`: the file is cut at the scaffold runs the plan
+    (windows.plan_predefined_shards) allows, every rank streams its own windows, one gather of the rows"""
     import gzip
     import subprocess
     import sys
@@ -111,24 +113,23 @@ def test_distmat_cat_window_on_several_ranks_sums_the_pair_counts(size, tmp_path
     gold = os.path.join(root, "tests", "golden")
     sys.path.insert(0, gold)
     from cases import CASES
-    case = [c for c in CASES if c["name"] == "holes_distmat_cat_nexus"][0]
+    case = [c for c in CASES if c["name"] == name][0]
     geno = str(tmp_path / (case["fixture"] + ".geno"))
     with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f, open(geno, "wb") as g:
         g.write(f.read())
-    out = str(tmp_path / "cat.out")
+    out = str(tmp_path / "ranks.out")
     argv = [a.format(geno=geno, dir=gold, out=out) for a in case["argv"]] + ["-o", out]
     procs = []
     for rank in range(size):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(36000 + (os.getpid() + size) % 2000), PG_COMM="file", PG_TIMING="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "distMat.py")] + argv, env=env, stdout=subprocess.PIPE,
+                   MASTER_PORT=str(36000 + (os.getpid() + size) % 2000), PG_COMM="file", PG_COMM_TIMEOUT="90", PG_TIMING="1",
+                   PG_RDZV_FILE=str(tmp_path / "rdzv"))         # (ranks started by hand: a rendezvous name of their own)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, tool)] + argv, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE))
-    sharded = 0
-    for p in procs:
-        o, e = p.communicate(timeout=600)
-        assert p.returncode == 0, e.decode()[-2000:]
-        sharded += sum('"sharded_input": true' in ln for ln in e.decode().splitlines() if ln.startswith("PG_TIMING "))
-    assert sharded == size
+    errs = [p.communicate(timeout=600)[1].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join("--- rank %d (rc %s)\n%s" % (r, p.returncode, e[-1500:])
+                                                            for r, (p, e) in enumerate(zip(procs, errs)))
+    assert sum('"sharded_input": true' in ln for e in errs for ln in e.splitlines() if ln.startswith("PG_TIMING ")) == size
     with open(out) as f, open(os.path.join(gold, case["name"] + ".out")) as g:
         got, want = f.read(), g.read()
     G.compare_text(align_columns(got, want), want, G.round_digits(case))

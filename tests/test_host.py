@@ -465,3 +465,36 @@ def test_run_boundary_at_a_chunk_seam(tmp_path):
         bz.seek_member(int(c))
         data = bz.read(1 << 20)
         assert data[int(u):].startswith(b"scafB\t1\t"), (guess, c, u)
+
+
+def test_text_runs_of_raw_lines(tmp_path):
+    """pg_text_runs / BlockReader.text_runs: first data line of every run of lines sharing their first field; comment and empty
+    lines skipped, a last line without a line feed counted, the ranks' lists tile the file"""
+    import ctypes as C
+    from genomics_general_amd import _lib, dist
+    txt = b"#CHROM\tPOS\ta\nchr1\t1\tA/A\nchr1\t2\tA/A\n#note\n\nchr2\t1\tA/A\nchr10\t5\tA/A\nchr1\t9\tA/A\nchr1 10 A/A"
+    L = _lib.lib()
+    ptr, n, keep = _lib.text_ptr(txt)
+    for cap in (0, 2, 16):
+        starts = np.zeros(max(cap, 1), dtype=np.int64)
+        cnt = C.c_int64(0)
+        _lib.check(L.pg_text_runs(ptr, n, starts, cap, C.byref(cnt)))
+        assert cnt.value == 4
+        if cap >= 4:
+            assert [txt[o:o + 5] for o in starts[:4]] == [b"chr1\t", b"chr2\t", b"chr10", b"chr1\t"]
+    path = str(tmp_path / "runs.geno")
+    body = b"".join(b"chr%d\t%d\tA/A\n" % (1 + i // 37, i) for i in range(400))
+    with open(path, "wb") as f:
+        f.write(b"#CHROM\tPOS\ta\n" + body)
+    whole = None
+    for size in (1, 2, 3, 7):
+        runs = []
+        for r in range(size):
+            rd = genoio.open_input(path)
+            rd.read_header()
+            for off, name in rd.text_runs(dist.World(r, size, r)):
+                if not runs or runs[-1][1] != name:
+                    runs.append((off, name))
+            rd.close()
+        whole = whole or runs
+        assert runs == whole and [nm for _, nm in runs] == ["chr%d" % k for k in range(1, 12)]

@@ -309,3 +309,63 @@ def test_windows_of_run_aligned_input_shards_concatenate_to_the_whole(seed):
             got += [(s, st, en, rng_, i + id_shift, m) for (s, st, en, rng_, i, m) in rows]
             id_shift += T.n
         assert got == want, (sites_mode, inc, exc, names, bounds)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_predefined_windows_of_planned_shards_concatenate_to_the_whole(seed):
+    """Sharded ingestion of `--windType predefined` (windows.plan_predefined_shards): whenever the plan accepts a file / window
+    list pair, the rows of the ranks' streams (their own windows, the whole list's scaffold order, the tail the plan names),
+    concatenated in rank order, are the rows of the reference's forward-only walk over the whole file -- windows beyond the end
+    of a scaffold, trailing unwanted runs and the generator's stop at the end of the file included.  Byte offsets = row numbers."""
+    from genomics_general_amd import windows as W
+    rng = np.random.default_rng(5000 + seed)
+    accepted = refused = 0
+    for _ in range(400):
+        pool = ["c0", "c1", "c2", "c3", "c4", "u0", "u1"]
+        names, starts, pos, prev = [], [], [], None
+        for _r in range(int(rng.integers(1, 8))):
+            nm = str(rng.choice([x for x in pool if x != prev]))
+            prev = nm
+            starts.append(len(pos))
+            names.append(nm)
+            pos += list(np.sort(rng.integers(1, 400, size=int(rng.integers(1, 40)))))
+        rs, pos = np.array(starts), np.array(pos, dtype=np.int32)
+        n = len(pos)
+        # window list: mostly in the file's order and grouped (what the plan accepts), sometimes shuffled / split / with absentees
+        in_file = [x for x in dict.fromkeys(names) if x.startswith("c")]
+        order = list(in_file) if rng.integers(0, 4) else [str(x) for x in rng.permutation(in_file + ["zz"])]
+        coords = []
+        for sc in order[: int(rng.integers(1, len(order) + 1))] if order else []:
+            for j, a in enumerate(np.sort(rng.integers(1, 460, size=int(rng.integers(1, 5))))):
+                coords.append((sc, int(a), int(a) + int(rng.integers(0, 150)), "w%d" % len(coords)))
+        if not coords:
+            continue
+        if not rng.integers(0, 6):
+            rng.shuffle(coords)
+        size = int(rng.integers(2, 5))
+        plan = W.plan_predefined_shards([(int(a), nm) for a, nm in zip(starts, names)], 0, n, coords, size, max_share=1.0)
+        if plan is None:
+            refused += 1
+            continue
+        accepted += 1
+        want = _stream_rows(W.predefined_windows(rs, names, pos, coords), [])
+        got, hist = [], []
+        assert [p[0] for p in plan] + [n] == sorted([p[0] for p in plan] + [n]) and plan[0][0] == 0 and plan[-1][1] == n
+        assert sorted(k for p in plan for k in p[2]) == list(range(len(coords)))
+        for a, b, idx, tail in plan:
+            S = W.PredefinedWindowStream([coords[k] for k in idx], scaf_order=[w[0] for w in coords], tail=tail)
+            keep = [r for r, s_ in enumerate(starts) if a <= s_ < b]
+            brs = np.array([starts[r] - a for r in keep], dtype=int)
+            bn = [names[r] for r in keep]
+            # in two pieces when the slice is long enough: the stream must wait across the piece seam as it does in one rank
+            mid = a + (b - a) // 2 if (b - a) > 4 and rng.integers(0, 2) else b
+            k0 = 0
+            for lo_, hi_, fin in ((a, mid, mid == b), (mid, b, True)) if mid < b else ((a, b, True),):
+                lo2 = lo_ - k0 if lo_ > a else lo_
+                ro = np.searchsorted(np.array(starts), np.arange(lo2, hi_), side="right") - 1
+                chg = np.flatnonzero(np.concatenate([[True], ro[1:] != ro[:-1]])) if hi_ > lo2 else np.array([], dtype=int)
+                T, kf = S.feed(chg, [names[ro[i]] for i in chg], pos[lo2:hi_], final=fin)
+                got += _stream_rows(T, hist, lo2)
+                k0 = (hi_ - lo2) - kf
+        assert got == want, (coords, list(zip(names, starts)), plan)
+    assert accepted > 100 and refused > 50, (accepted, refused)
