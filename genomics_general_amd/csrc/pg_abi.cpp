@@ -590,14 +590,16 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     c->cshift = dip ? 1 : 0;
     const int64_t mat_bytes = 4ll * N * N + 4ll * n_units * n_units;
     // compaction group = words per pack block: 128 when that still oversubscribes the chip's wave slots several times (see
-    // pg_internal.h), else 64; PG_GROUP_WORDS overrides (A/B runs)
+    // pg_internal.h), else 64, and 32 when 64 would leave fewer than two waves per SIMD slot (C2: 4883 one-wave blocks; measured
+    // 0.44 - 0.47 ms with 32 against 0.465 - 0.484 with 64); PG_GROUP_WORDS overrides (A/B runs)
     int grp = PG_GROUP;
     {
         int64_t blocks64 = 0;
         for (int w = 0; w < n_win; ++w) blocks64 += ((hi[w] - lo[w] + 31) / 32 + PG_GROUP - 1) / PG_GROUP;
         const int waves_per_block = (NP / 4 + 63) / 64;
         if (blocks64 * waves_per_block >= 32768) grp = PG_GROUP_MAX;
-        if (const char *g = getenv("PG_GROUP_WORDS")) grp = atoi(g) >= PG_GROUP_MAX ? PG_GROUP_MAX : PG_GROUP;
+        else if (blocks64 * waves_per_block < 8192) grp = PG_GROUP / 2;
+        if (const char *g = getenv("PG_GROUP_WORDS")) grp = std::min(PG_GROUP_MAX, std::max(8, atoi(g) / 4 * 4));
     }
     // scratch bytes per 32-site input word of one slot: called plane + reserved virtual-site planes (capg words per group)
     const int capg = c->xv_worst ? PG_XV_CAP(grp) : PG_XV_CAP_DEFAULT(grp);
