@@ -918,7 +918,7 @@ extern "C" int pg_popdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n
         int r = pg_time_begin(c, PG_K_POPDIST_FIN, &e0, &e1);
         if (r != PG_OK) return r;
         pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, c->n_pops, min_pair_sites,
-                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs);
+                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, c->all_diploid ? 1 : 0);
         if ((r = pg_time_end(c, PG_K_POPDIST_FIN, e0, e1, 1)) != PG_OK) return r;
         HIPCHK(hipGetLastError());
         return PG_OK;
@@ -951,7 +951,7 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
         int r = pg_time_begin(c, PG_K_POPDIST_FIN, &e0, &e1);
         if (r != PG_OK) return r;
         pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, P, min_pair_sites,
-                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs);
+                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, c->all_diploid ? 1 : 0);
         pg_launch_popstats(c->stream, c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, nb, c->pop_start.p, P,
                            min_data, do_pairs, c->stats.p + (size_t)w0 * ncols);
         if ((r = pg_time_end(c, PG_K_POPDIST_FIN, e0, e1, 1)) != PG_OK) return r;

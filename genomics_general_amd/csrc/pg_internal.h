@@ -42,7 +42,7 @@ void pg_launch_synth(hipStream_t st, int8_t *gt, int S, int n_hap, int64_t site0
 
 void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *pop_start, int n_pops, int min_pair_sites, double *sum_out,
-                           int64_t *cnt_out);
+                           int64_t *cnt_out, int all_diploid);
 
 void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,

@@ -13,6 +13,9 @@
 // same IEEE operations, in the same order, as the NumPy expressions of the reference.
 #include "pg_internal.h"
 #include <algorithm>
+#ifdef PG_DIV_PROBE
+#include <cstdio>
+#endif
 
 #define WAVE 64
 
@@ -146,12 +149,32 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 // ------------------------------------------------------------------------------------------------------
 // K_popdist: one block per (population pair, window).
 // ------------------------------------------------------------------------------------------------------
+// D / C for counts (0 <= D <= C < 2^31): the quotient needs neither the range scaling nor the special-case fix-up of the
+// compiler's IEEE division sequence, and the reciprocal of C serves every D that shares it.  rcp_counts: v_rcp_f64 + two
+// Newton steps (error below one ulp); quot_counts: product, exact residual, one correction -- the step the IEEE sequence ends in.
+__device__ __forceinline__ double rcp_counts(double c) {
+    double r = __builtin_amdgcn_rcp(c);
+    r = __builtin_fma(__builtin_fma(-c, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-c, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double quot_counts(double d, double c, double r) {
+    const double q = d * r;
+    return __builtin_fma(__builtin_fma(-c, q, d), r, q);
+}
+
+__device__ unsigned long long g_div_probe[2];           // PG_DIV_PROBE builds only: quotients compared / differing from d / c
+
+// MODE 0: any layout, one haplotype pair at a time.  MODE 1 / 2: every sample diploid (haplotypes 2u, 2u + 1 of individual u, populations
+// made of whole individuals): the 2 x 2 haplotype pairs of an individual pair together, in one order for both -- 1: called counts per
+// individual pair (one reciprocal for the four), 2: per haplotype pair (PG_NO_DIP, half-missing genotypes) -- so that the two give
+// the same float64 sums.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat,
                                                      int N, int cN, int cshift, const int32_t *__restrict__ pop_start, int n_pops,
                                                      int min_pair_sites, double *__restrict__ sum_out,
                                                      int64_t *__restrict__ cnt_out) {
-    __shared__ double shd[256];
-    __shared__ unsigned long long shu[256];
+    __shared__ double shd[8];
     // decode pair index -> (x<=y)
     int pidx = blockIdx.x, x = 0;
     int rem = pidx;
@@ -165,47 +188,128 @@ __global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__
     const int thr = min_pair_sites > 1 ? min_pair_sites : 1;
     double sum = 0.0;
     unsigned long long cnt = 0;
-    // thread t takes the pairs t, t + 256, ... of the nx x ny rectangle (fixed partition: the float64 sum is reproducible);
-    // row / column advance incrementally instead of dividing (nx, ny <= PG_MAX_HAP, so 256 / ny steps stay small)
-    const int total = nx * ny;
-    const int qi = 256 / (ny > 0 ? ny : 1), qj = 256 - qi * (ny > 0 ? ny : 1);
-    int i = xs + (ny > 0 ? (int)threadIdx.x / ny : 0), j = ys + (ny > 0 ? (int)threadIdx.x % ny : 0);
-    // four pairs per trip: their eight loads are issued before the first division (the loop was bound by the latency of one
-    // dependent load -> divide chain per trip); the quotients are added in the order the one-pair loop added them
-    for (int idx = threadIdx.x; idx < total; idx += 1024) {
-        int c[4], d[4];
+    if (MODE) {
+        // the haplotype pairs of an individual pair (a, b) share their called count (MODE 1).  Thread t takes the
+        // individual pairs t, t + 256, ... of the (nx / 2) x (ny / 2) rectangle: one reciprocal, two 8-byte loads of D, four
+        // quotients added in the fixed order (2a,2b) (2a,2b+1) (2a+1,2b) (2a+1,2b+1); within an individual only (2a, 2a+1)
+        const int ux = nx >> 1, uy = ny >> 1, u0 = xs >> 1, v0 = ys >> 1;
+        const int total = ux * uy;
+        const int qi = 256 / (uy > 0 ? uy : 1), qj = 256 - qi * (uy > 0 ? uy : 1);
+        int a = u0 + (uy > 0 ? (int)threadIdx.x / uy : 0), b = v0 + (uy > 0 ? (int)threadIdx.x % uy : 0);
+        for (int idx = threadIdx.x; idx < total; idx += 512) {
+            int aa[2], bb[2];
+            int2 c0[2], c1[2], d0[2], d1[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (j >= ye) { j -= ny; ++i; }
-            const bool live = idx + 256 * u < total && !(x == y && i >= j);
-            c[u] = live ? Cw[(size_t)(i >> cshift) * cN + (j >> cshift)] : 0;
-            d[u] = live ? Dw[(size_t)i * N + j] : 0;
-            i += qi;
-            j += qj;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (c[u] >= thr) {
-                sum += (double)d[u] / (double)c[u];
-                ++cnt;
+            for (int u = 0; u < 2; ++u) {
+                if (b >= v0 + uy) { b -= uy; ++a; }
+                const bool live = idx + 256 * u < total && !(x == y && a > b);
+                aa[u] = a;
+                bb[u] = b;
+                if (MODE == 1) {
+                    c0[u].x = live ? Cw[(size_t)a * cN + b] : 0;
+                    c0[u].y = c1[u].x = c1[u].y = c0[u].x;
+                } else {
+                    c0[u] = live ? *reinterpret_cast<const int2 *>(Cw + (size_t)(2 * a) * cN + 2 * b) : make_int2(0, 0);
+                    c1[u] = live ? *reinterpret_cast<const int2 *>(Cw + (size_t)(2 * a + 1) * cN + 2 * b) : make_int2(0, 0);
+                }
+                d0[u] = live ? *reinterpret_cast<const int2 *>(Dw + (size_t)(2 * a) * N + 2 * b) : make_int2(0, 0);
+                d1[u] = live ? *reinterpret_cast<const int2 *>(Dw + (size_t)(2 * a + 1) * N + 2 * b) : make_int2(0, 0);
+                a += qi;
+                b += qj;
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool same = x == y && aa[u] == bb[u];          // within an individual: only the pair (2a, 2a + 1)
+                if (MODE == 1) {
+                    if (c0[u].x >= thr) {
+                        const double cd = (double)c0[u].x, r = rcp_counts(cd);
+                        if (!same) sum += quot_counts((double)d0[u].x, cd, r);
+                        sum += quot_counts((double)d0[u].y, cd, r);
+                        if (!same) {
+                            sum += quot_counts((double)d1[u].x, cd, r);
+                            sum += quot_counts((double)d1[u].y, cd, r);
+                        }
+                        cnt += same ? 1 : 4;
+#ifdef PG_DIV_PROBE
+                        const int dd[4] = {d0[u].x, d0[u].y, d1[u].x, d1[u].y};
+                        for (int k = 0; k < 4; ++k) {
+                            atomicAdd(&g_div_probe[0], 1ull);
+                            if (quot_counts((double)dd[k], cd, r) != (double)dd[k] / cd) atomicAdd(&g_div_probe[1], 1ull);
+                        }
+#endif
+                    }
+                } else {
+                    const int cc[4] = {c0[u].x, c0[u].y, c1[u].x, c1[u].y}, dd[4] = {d0[u].x, d0[u].y, d1[u].x, d1[u].y};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((!same || k == 1) && cc[k] >= thr) {
+                            const double cd = (double)cc[k];
+                            sum += quot_counts((double)dd[k], cd, rcp_counts(cd));
+                            ++cnt;
+                        }
+                }
+            }
+        }
+    } else {
+        // thread t takes the pairs t, t + 256, ... of the nx x ny rectangle (fixed partition: the float64 sum is reproducible);
+        // row / column advance incrementally instead of dividing (nx, ny <= PG_MAX_HAP, so 256 / ny steps stay small)
+        const int total = nx * ny;
+        const int qi = 256 / (ny > 0 ? ny : 1), qj = 256 - qi * (ny > 0 ? ny : 1);
+        int i = xs + (ny > 0 ? (int)threadIdx.x / ny : 0), j = ys + (ny > 0 ? (int)threadIdx.x % ny : 0);
+        // four pairs per trip: their eight loads are issued before the first division (the loop was bound by the latency of one
+        // dependent load -> divide chain per trip); the quotients are added in the order the one-pair loop added them
+        for (int idx = threadIdx.x; idx < total; idx += 1024) {
+            int c[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j >= ye) { j -= ny; ++i; }
+                const bool live = idx + 256 * u < total && !(x == y && i >= j);
+                c[u] = live ? Cw[(size_t)(i >> cshift) * cN + (j >> cshift)] : 0;
+                d[u] = live ? Dw[(size_t)i * N + j] : 0;
+                i += qi;
+                j += qj;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c[u] >= thr) {
+                    const double cd = (double)c[u];
+                    sum += quot_counts((double)d[u], cd, rcp_counts(cd));
+                    ++cnt;
+                }
+        }
     }
-    sum = block_sum_f64(sum, shd);
-    cnt = block_sum_u64(cnt, shu);
+    // one barrier for both totals (the count travels as a double: exact); fixed butterfly + wave order: reproducible
+    double tot[2] = {sum, (double)cnt};
+    block_sum_multi<2>(tot, shd);
     if (threadIdx.x == 0) {
         const int npairs = n_pops * (n_pops + 1) / 2;
-        sum_out[(size_t)win * npairs + pidx] = sum;
-        cnt_out[(size_t)win * npairs + pidx] = (int64_t)cnt;
+        sum_out[(size_t)win * npairs + pidx] = tot[0];
+        cnt_out[(size_t)win * npairs + pidx] = (int64_t)tot[1];
     }
 }
 
 void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *pop_start, int n_pops, int min_pair_sites, double *sum_out,
-                           int64_t *cnt_out) {
+                           int64_t *cnt_out, int all_diploid) {
     if (n_win <= 0 || n_pops <= 0) return;
     int npairs = n_pops * (n_pops + 1) / 2;
-    hipLaunchKernelGGL(k_popdist_fin, dim3(npairs, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops,
-                       min_pair_sites, sum_out, cnt_out);
+    if (all_diploid && cshift == 1)
+        hipLaunchKernelGGL(k_popdist_fin<1>, dim3(npairs, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops,
+                           min_pair_sites, sum_out, cnt_out);
+    else if (all_diploid && cshift == 0 && cN == N)
+        hipLaunchKernelGGL(k_popdist_fin<2>, dim3(npairs, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops,
+                           min_pair_sites, sum_out, cnt_out);
+    else
+        hipLaunchKernelGGL(k_popdist_fin<0>, dim3(npairs, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops,
+                           min_pair_sites, sum_out, cnt_out);
+#ifdef PG_DIV_PROBE
+    {
+        unsigned long long h[2];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_div_probe), sizeof h);
+        fprintf(stderr, "k_popdist_fin: %llu quotients compared with d / c, %llu differ\n", h[0], h[1]);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
