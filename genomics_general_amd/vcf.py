@@ -9,8 +9,9 @@ parseVCF.py:268-303), streams the input in blocks and renders the rows.
 
 Supported: -i/-o (.gz by suffix, stdin/stdout), -s/--samples, --include/--exclude(/File), --minQual, --gtf (repeatable), --skipIndels,
 --excludeDuplicates, --maxREFlen, --ploidy, --ploidyFile, --ploidyMismatchToMissing, --keepPartial, --addRefTrack, --noHeader,
---missing (one character), --outSep (one character).  Not supported (they produce multi-site rows / other fields, which the
-engine's formats do not hold): --field, --simplifyALT, --expandMulti.  Alleles longer than one base (indels without --skipIndels;
+--missing (one character), --outSep (one character), and --field NAME (the values of another FORMAT field instead of genotypes:
+plain text out, a line loop on the host -- that output is not an input of the engine).  Not supported (they rewrite alleles from
+freebayes CIGAR strings and produce multi-site rows, which the engine's formats do not hold): --simplifyALT, --expandMulti.  Alleles longer than one base (indels without --skipIndels;
 the homozygous-reference calls of a deletion site even with it) are printed as strings by the text route, exactly as the
 reference prints them; the packed route stores such calls as missing (use --maxREFlen 1 to drop those sites altogether)."""
 import argparse
@@ -81,6 +82,78 @@ def _last_key(body):
     return None, None
 
 
+def _contig_lists(args):
+    """--include / --exclude and their file forms as two lists (parseIncludeExcludeArgs, parseVCF.py:306-330)"""
+    include, exclude = [], []
+    if args.include:
+        include += args.include.split(",")
+    if args.exclude:
+        exclude += args.exclude.split(",")
+    if args.includeFile:
+        with open(args.includeFile, "rt") as f:
+            include += [c.strip() for c in f.read().split("\n")]
+    if args.excludeFile:
+        with open(args.excludeFile, "rt") as f:
+            exclude += [c.strip() for c in f.read().split("\n")]
+    return include, exclude
+
+
+def _field_main(args):
+    """`--field NAME`: one row per site that passes the site filters (contigs, --minQual, --maxREFlen, --excludeDuplicates), the
+    samples' values of FORMAT field NAME (parseVCF.py:371, getGenoField 185-191), `--missing` (default ".") where a sample has
+    none.  Genotype filters, ploidy and indel options play no part, as in the reference."""
+    if args.packed:
+        raise SystemExit("parseVCF.py: --field writes text only (no --packed)")
+    include, exclude = _contig_lists(args)
+    include, exclude = set(include), set(exclude)
+    absent = "." if args.missing is None else args.missing
+    inp = (gzip.open(args.inFile, "rt") if args.inFile.endswith(".gz") else open(args.inFile, "rt")) if args.inFile else sys.stdin
+    out = (gzip.open(args.outFile, "wt") if args.outFile.endswith(".gz") else open(args.outFile, "wt")) if args.outFile else sys.stdout
+    cols = None
+    for line in inp:
+        if line.startswith("#CHROM"):
+            cols = line.split()
+            break
+    assert cols is not None and len(cols) >= 9, "no #CHROM header line in the VCF"
+    col_of = {nm: k for k, nm in enumerate(cols)}               # a repeated sample name: its last column, as dict(zip()) keeps it
+    samples = args.samples.split(",") if args.samples else list(cols[9:])
+    for s in samples:
+        assert s in cols[9:], "Sample {} not in VCF header\n".format(s)
+    where = [col_of[s] for s in samples]
+    if not args.noHeader:
+        out.write(args.outSep.join(["#CHROM", "POS"] + (["REF"] if args.addRefTrack else []) + samples) + "\n")
+    last = None
+    for line in inp:
+        f = line.split()
+        if not f or f[0][0] == "#":
+            continue
+        if args.excludeDuplicates:
+            if (f[0], f[1]) == last:
+                continue
+            last = (f[0], f[1])
+        chrom, ref, qual = f[0], f[3], f[5]
+        if (exclude and chrom in exclude) or (include and chrom not in include):
+            continue
+        if args.minQual:
+            try:
+                if float(qual) < args.minQual:
+                    continue
+            except ValueError:
+                pass
+        if args.maxREFlen and len(ref) > args.maxREFlen:
+            continue
+        keys = f[8].split(":")
+        k = keys.index(args.field) if args.field in keys else -1
+        vals = []
+        for c in where:
+            parts = f[c].split(":")
+            vals.append(parts[k] if 0 <= k < len(parts) else absent)
+        out.write(args.outSep.join([chrom, str(int(f[1]))] + ([ref] if args.addRefTrack else []) + vals) + "\n")
+    if out is not sys.stdout:
+        out.close()
+    return 0
+
+
 def parse_vcf_main(argv=None):
     ap = argparse.ArgumentParser(prog="parseVCF.py")
     ap.add_argument("-o", "--outFile", help="Output .geno file")
@@ -103,16 +176,18 @@ def parse_vcf_main(argv=None):
     ap.add_argument("--keepPartial", help="Keep genotypes where some but not all alleles are missing", action="store_true")
     ap.add_argument("--addRefTrack", help="Add a third column with the header REF and the reference allele", action="store_true")
     ap.add_argument("--noHeader", help="Output without header line", action="store_true")
-    ap.add_argument("--field", help="(not supported)")
+    ap.add_argument("--field", help="Optional - format field to extract instead of genotypes")
     ap.add_argument("--missing", help="Value to use for missing data (one character)")
     ap.add_argument("--outSep", help="Output separator", default="\t")
     ap.add_argument("-i", "--inFile", help="Input vcf file")
     ap.add_argument("--packed", metavar="FILE.pgeno", help="also (or, without -o, only) write the packed form the engine's drivers read")
     ap.add_argument("--threads", type=int, default=0, help="host threads of the native parser (default: all)")
     args = ap.parse_args(argv)
-    for flag in ("simplifyALT", "expandMulti", "field"):
+    for flag in ("simplifyALT", "expandMulti"):
         if getattr(args, flag):
             raise SystemExit("parseVCF.py: --%s is not supported by this drop-in (see genomics_general_amd/vcf.py)" % flag)
+    if args.field is not None:
+        return _field_main(args)
     missing = args.missing if args.missing is not None else "N"
     if len(missing) != 1 or len(args.outSep) != 1:
         raise SystemExit("parseVCF.py: --missing and --outSep must be single characters here")
