@@ -93,7 +93,7 @@ class CpuEngine:
         n = lay.n_samp
         o = np.asarray(lay.ref_order)
         tab = np.full((len(D), n * (n + 1) // 2), np.nan)
-        aln = orc.aln_from_codes(self.gt[:0], lay.hap_names, lay.hap_sample_name,
+        aln = orc.aln_from_codes(np.zeros((0, lay.n_hap), dtype=np.int8), lay.hap_names, lay.hap_sample_name,
                                  [g if g is not None else "~none" for g in lay.hap_group])[0]
         for w in range(len(D)):
             d = orc.dist_from_counts(np.asarray(D[w])[o][:, o], np.asarray(C[w])[o][:, o])

@@ -375,6 +375,24 @@ def test_cat_window_counts_are_summed_over_the_ranks(tmp_path):
         G.compare_text(align_columns(got, want), want, G.round_digits(case))
         assert len(timing) == size and all(t["sharded_input"] for t in timing), timing
         assert sum(t["sites"] for t in timing) == n_lines and max(t["sites"] for t in timing) < 0.7 * n_lines, timing
+    # more ranks than lines: the ranks without a line contribute zero counts and still take part in every exchange
+    small = str(tmp_path / "two_lines.geno")
+    with open(geno) as f, open(small, "w") as g:
+        g.write("".join(f.readlines()[:3]))
+    outs = []
+    for k, size in enumerate((1, 4)):
+        out = str(tmp_path / ("small%d.out" % size))
+        procs = []
+        for rank in range(size):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(39000 + (os.getpid() + 23 * k) % 2000))
+            procs.append(subprocess.Popen([sys.executable, "-c", CLI_WORKER, "distMat.py", "-g", small, "-f", "phased", "--windType", "cat",
+                                           "--outFormat", "raw", "-o", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+        for p in procs:
+            o, e = p.communicate(timeout=300)
+            assert p.returncode == 0, e.decode()[-1500:]
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and len(outs[0]) > 20
 
 
 def test_predefined_windows_are_sharded_when_the_file_agrees_with_the_window_list(tmp_path):
