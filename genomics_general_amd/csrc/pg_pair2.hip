@@ -463,15 +463,26 @@ __device__ __forceinline__ void word_called_presence_keep(const uint32_t d[32], 
     }
 }
 
-template <int TPB, int DIP>
+// BURST: the plane stores of a thread wait in LDS cells of its own (no barrier) and leave together -- the called plane every
+// PACK_FQ word quadruples, the virtual-site words PACK_XC at a time with ONE reservation of consecutive slots -- because a store
+// burst costs the HBM fewer read <-> write turn-arounds than the same bytes trickling out between the row loads
+// (tools/ubench/pack_rw.hip: - 4.5 % on the kernel's bare traffic; the kernel's time does not depend on the waves per CU down to
+// three blocks, so the 48 KB of LDS cost nothing).  Blocks of one or two waves only (LDS).
+constexpr int PACK_FQ = 8, PACK_XC = 4;
+template <int TPB, int DIP, int BURST>
 __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
                                                const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
                                                const int64_t *__restrict__ vgoff, uint32_t *__restrict__ Vp, int NPv,
                                                uint32_t *__restrict__ XV, int NP, int32_t *__restrict__ nw,
                                                int32_t *__restrict__ mismatch, int capg, int grp) {
     constexpr int NWAVE = TPB / 64;
+    constexpr int VN = DIP ? 2 : 4;                      // uint4 of called plane per thread and word quadruple
+    constexpr int FQ = DIP ? PACK_FQ : PACK_FQ / 2;      // quadruples per burst
     __shared__ uint32_t sh_pres[2][NWAVE][4];
     __shared__ int sh_slot;
+    __shared__ uint4 stage[BURST ? (FQ * VN + PACK_XC * 2) * TPB : 1];
+    uint4 *const stage_v = stage, *const stage_x = stage + FQ * VN * TPB;
+    int nq = 0, nxs = 0, wq_first = 0;                   // staged quadruples / virtual-site words (block-uniform), first staged quadruple
     const int b = blockIdx.y, g = blockIdx.x;
     const int64_t lo = win_lo[b], hi = win_hi[b];
     const int W = (int)((hi - lo + 31) >> 5);
@@ -493,27 +504,62 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
     uint32_t *xv_base = XV + (size_t)goff[b] * capg * PG_XV_PLANES * (size_t)NP;
     const int capw = (int)(goff[b + 1] - goff[b]) * capg;          // words reserved for this window
     const int64_t vg_base = vgoff[b] + (int64_t)(w_begin >> 2);
-    auto store_word = [&]() {                // the pending planes become one dense word of XV (the window's next free word)
+    auto reserve = [&](int n) -> int {       // n consecutive words of the window's XV area (block-uniform result)
         int slot;
         if (NWAVE == 1) {
             int s0 = 0;
-            if (lane == 0) s0 = atomicAdd(&nw[b], 1);
+            if (lane == 0) s0 = atomicAdd(&nw[b], n);
             slot = __builtin_amdgcn_readfirstlane(s0);
         } else {
-            if (threadIdx.x == 0) sh_slot = atomicAdd(&nw[b], 1);
+            if (threadIdx.x == 0) sh_slot = atomicAdd(&nw[b], n);
             __syncthreads();
             slot = __builtin_amdgcn_readfirstlane(sh_slot);
             __syncthreads();
         }
-        if (slot >= capw) {                  // more virtual sites than reserved: the host redoes the batch with the worst-case reservation
-            if (threadIdx.x == 0) atomicOr(mismatch, 2);
-        } else if (has_data) {
-            uint32_t *o = xv_base + (size_t)slot * PG_XV_PLANES * (size_t)NP + 2 * h0;
-            store16(o, xo[0], vo[0], xo[1], vo[1]);
-            store16(o + 4, xo[2], vo[2], xo[3], vo[3]);
+        return slot;
+    };
+    auto flush_x = [&]() {                   // BURST: the staged words leave together, into consecutive slots
+        if (!nxs) return;
+        const int slot0 = reserve(nxs);
+        for (int k = 0; k < nxs; ++k) {
+            if (slot0 + k >= capw) {         // more virtual sites than reserved: the host redoes the batch with the worst-case reservation
+                if (threadIdx.x == 0) atomicOr(mismatch, 2);
+            } else if (has_data) {
+                uint4 *o = reinterpret_cast<uint4 *>(xv_base + (size_t)(slot0 + k) * PG_XV_PLANES * (size_t)NP + 2 * h0);
+                o[0] = stage_x[(2 * k) * TPB + t];
+                o[1] = stage_x[(2 * k + 1) * TPB + t];
+            }
+        }
+        nxs = 0;
+    };
+    auto store_word = [&]() {                // the pending planes become one dense word of XV (the window's next free word)
+        if (BURST) {
+            if (has_data) {
+                stage_x[(2 * nxs) * TPB + t] = make_uint4(xo[0], vo[0], xo[1], vo[1]);
+                stage_x[(2 * nxs + 1) * TPB + t] = make_uint4(xo[2], vo[2], xo[3], vo[3]);
+            }
+            if (++nxs == PACK_XC) flush_x();
+        } else {
+            const int slot = reserve(1);
+            if (slot >= capw) {              // more virtual sites than reserved: the host redoes the batch with the worst-case reservation
+                if (threadIdx.x == 0) atomicOr(mismatch, 2);
+            } else if (has_data) {
+                uint32_t *o = xv_base + (size_t)slot * PG_XV_PLANES * (size_t)NP + 2 * h0;
+                store16(o, xo[0], vo[0], xo[1], vo[1]);
+                store16(o + 4, xo[2], vo[2], xo[3], vo[3]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) xo[k] = vo[k] = 0u;
+    };
+    auto flush_v = [&]() {                   // BURST: the staged quadruples of the called plane
+        if (has_data)
+            for (int q = 0; q < nq; ++q) {
+                uint4 *o = reinterpret_cast<uint4 *>(Vp + ((size_t)(vg_base + wq_first + q) * NPv + u0) * 4u);
+#pragma unroll
+                for (int k = 0; k < VN; ++k) o[k] = stage_v[(q * VN + k) * TPB + t];
+            }
+        nq = 0;
     };
     auto finish_dword = [&](int qd) {        // 8 entries (nibbles of cur[k]) -> bits 4j+qd of the two planes
         const uint32_t nME = ~ME;
@@ -630,7 +676,19 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
                 }
             }
         }
-        if (has_data) {
+        if (BURST) {
+            if (nq == 0) wq_first = wq;
+            if (has_data) {
+                if (DIP) {
+                    stage_v[(nq * VN) * TPB + t] = make_uint4(vhold[0][0], vhold[0][1], vhold[0][2], vhold[0][3]);
+                    stage_v[(nq * VN + 1) * TPB + t] = make_uint4(vhold[2][0], vhold[2][1], vhold[2][2], vhold[2][3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) stage_v[(nq * VN + k) * TPB + t] = make_uint4(vhold[k][0], vhold[k][1], vhold[k][2], vhold[k][3]);
+                }
+            }
+            if (++nq == FQ) flush_v();
+        } else if (has_data) {
             uint32_t *o = Vp + ((size_t)(vg_base + wq) * NPv + u0) * 4u;
             if (DIP) {
                 store16(o, vhold[0][0], vhold[0][1], vhold[0][2], vhold[0][3]);
@@ -643,6 +701,10 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
     }
     if (cnt & 7) finish_dword(cnt >> 3);
     if (cnt) store_word();
+    if (BURST) {
+        flush_v();
+        flush_x();
+    }
     if (DIP && bad) atomicOr(mismatch, 1);
 }
 
@@ -658,13 +720,22 @@ static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *g
     // PG_PACK2=1 forces k_pack2 (A/B runs and tests).
     const bool force2 = getenv("PG_PACK2") != nullptr;
     if (threads <= 1024 && !force2) {
-#define PG_PACK3(T) hipLaunchKernelGGL((k_pack3<T, DIP>), grid, dim3(T), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp)
-        if (threads <= 64) PG_PACK3(64);
+        // PG_PACK_BLOCKS_PER_CU=k (A/B runs): unused dynamic LDS so that at most k blocks share a CU (tools/ubench/pack_rw.hip: the
+        // kernel's bare traffic runs 3 % faster with half the waves; the kernel itself does not)
+        const char *bpc = getenv("PG_PACK_BLOCKS_PER_CU");
+        const size_t pad = bpc && atoi(bpc) > 0 ? (size_t)(160 * 1024 / atoi(bpc) - 1024) / 256 * 256 : 0;
+#define PG_PACK3B(T, B) hipLaunchKernelGGL((k_pack3<T, DIP, B>), grid, dim3(T), B ? 0 : std::min<size_t>(pad, 63 * 1024), st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp)
+#define PG_PACK3(T) PG_PACK3B(T, 0)
+        const bool burst = getenv("PG_PACK_BURST") == nullptr || atoi(getenv("PG_PACK_BURST")) != 0;       // (0: A/B)
+        if (threads <= 64 && burst) PG_PACK3B(64, 1);
+        else if (threads <= 128 && burst) PG_PACK3B(128, 1);
+        else if (threads <= 64) PG_PACK3(64);
         else if (threads <= 128) PG_PACK3(128);
         else if (threads <= 256) PG_PACK3(256);
         else if (threads <= 512) PG_PACK3(512);            // up to 2048 slots (C4: 2000 haplotypes): eight waves meet in LDS per word
         else PG_PACK3(1024);                               // up to 4096 slots
 #undef PG_PACK3
+#undef PG_PACK3B
         return;
     }
     if (threads <= 64)
