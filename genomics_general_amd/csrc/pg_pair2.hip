@@ -464,23 +464,23 @@ __device__ __forceinline__ void word_called_presence_keep(const uint32_t d[32], 
 }
 
 // BURST: the plane stores of a thread wait in LDS cells of its own (no barrier) and leave together -- the called plane every
-// PACK_FQ word quadruples, the virtual-site words PACK_XC at a time with ONE reservation of consecutive slots -- because a store
+// `fq` word quadruples, the virtual-site words as many at a time as the rest of the cells hold, with ONE reservation of consecutive slots -- because a store
 // burst costs the HBM fewer read <-> write turn-arounds than the same bytes trickling out between the row loads
 // (tools/ubench/pack_rw.hip: - 4.5 % on the kernel's bare traffic; the kernel's time does not depend on the waves per CU down to
 // three blocks, so the 48 KB of LDS cost nothing).  Blocks of one or two waves only (LDS).
-constexpr int PACK_FQ = 8, PACK_XC = 4;
+constexpr int PACK_CELLS = 24;                       // uint4 LDS cells per thread (48 KB per two-wave block: three blocks per CU)
 template <int TPB, int DIP, int BURST>
 __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
                                                const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
                                                const int64_t *__restrict__ vgoff, uint32_t *__restrict__ Vp, int NPv,
                                                uint32_t *__restrict__ XV, int NP, int32_t *__restrict__ nw,
-                                               int32_t *__restrict__ mismatch, int capg, int grp) {
+                                               int32_t *__restrict__ mismatch, int capg, int grp, int fq) {
     constexpr int NWAVE = TPB / 64;
     constexpr int VN = DIP ? 2 : 4;                      // uint4 of called plane per thread and word quadruple
-    constexpr int FQ = DIP ? PACK_FQ : PACK_FQ / 2;      // quadruples per burst
+    const int FQ = fq, xc = (PACK_CELLS - fq * VN) / 2;  // quadruples per burst of the called plane; virtual-site words per burst
     __shared__ uint32_t sh_pres[2][NWAVE][4];
     __shared__ int sh_slot;
-    __shared__ uint4 stage[BURST ? (FQ * VN + PACK_XC * 2) * TPB : 1];
+    __shared__ uint4 stage[BURST ? PACK_CELLS * TPB : 1];
     uint4 *const stage_v = stage, *const stage_x = stage + FQ * VN * TPB;
     int nq = 0, nxs = 0, wq_first = 0;                   // staged quadruples / virtual-site words (block-uniform), first staged quadruple
     const int b = blockIdx.y, g = blockIdx.x;
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
                 stage_x[(2 * nxs) * TPB + t] = make_uint4(xo[0], vo[0], xo[1], vo[1]);
                 stage_x[(2 * nxs + 1) * TPB + t] = make_uint4(xo[2], vo[2], xo[3], vo[3]);
             }
-            if (++nxs == PACK_XC) flush_x();
+            if (++nxs == xc) flush_x();
         } else {
             const int slot = reserve(1);
             if (slot >= capw) {              // more virtual sites than reserved: the host redoes the batch with the worst-case reservation
@@ -724,8 +724,11 @@ static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *g
         // kernel's bare traffic runs 3 % faster with half the waves; the kernel itself does not)
         const char *bpc = getenv("PG_PACK_BLOCKS_PER_CU");
         const size_t pad = bpc && atoi(bpc) > 0 ? (size_t)(160 * 1024 / atoi(bpc) - 1024) / 256 * 256 : 0;
-#define PG_PACK3B(T, B) hipLaunchKernelGGL((k_pack3<T, DIP, B>), grid, dim3(T), B ? 0 : std::min<size_t>(pad, 63 * 1024), st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp)
+#define PG_PACK3B(T, B) hipLaunchKernelGGL((k_pack3<T, DIP, B>), grid, dim3(T), B ? 0 : std::min<size_t>(pad, 63 * 1024), st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp, fq)
 #define PG_PACK3(T) PG_PACK3B(T, 0)
+        // quadruples of the called plane per burst (the rest of the 24 LDS cells per thread holds virtual-site words); PG_PACK_FQ: A/B
+        const int vn = DIP ? 2 : 4, fq_max = (PACK_CELLS - 2) / vn;
+        const int fq = getenv("PG_PACK_FQ") ? std::min(fq_max, std::max(1, atoi(getenv("PG_PACK_FQ")))) : (DIP ? 8 : 4);
         const bool burst = getenv("PG_PACK_BURST") == nullptr || atoi(getenv("PG_PACK_BURST")) != 0;       // (0: A/B)
         if (threads <= 64 && burst) PG_PACK3B(64, 1);
         else if (threads <= 128 && burst) PG_PACK3B(128, 1);
