@@ -24,7 +24,8 @@ def oracle_aln(lay, codes, lo, hi):
     (150, 4, 1500, [(0, 700), (700, 1500)]),                                     # several 64-column chunks
     (530, 3, 2200, [(0, 2200), (100, 421), (2150, 2200)]),                        # > 1024 haplotype slots: presence pre-pass
 ])
-@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_VALU", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none"])
+@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_VALU", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none", "PG_PACK_BURST=0",
+                                  "PG_PACK_FQ=3", "PG_GROUP_WORDS=20"])
 def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins, pack, monkeypatch):
     G.set_mode(monkeypatch, pack)
     e, lay, codes, _ = G.make_engine(n_dip, n_pops, L, seed=11 + n_dip)
@@ -45,7 +46,8 @@ def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins, pack, monkeypatch):
     (150, 1500, 0.1, "uniform"),       # two waves per block: list / flush code behind block barriers
     (300, 800, 0.2, "mixed"),          # four waves per block
 ])
-@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_VALU", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none"])
+@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_VALU", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none", "PG_PACK_BURST=0",
+                                  "PG_PACK_FQ=3", "PG_GROUP_WORDS=20"])
 def test_pairwise_counts_with_three_and_four_alleles_per_site(n_dip, L, p_miss, mix, pack, monkeypatch):
     """sites with k alleles become k-1 virtual biallelic sites in k_pack2 / k_pack3 (both kernels at every block size: one, two
     and four waves); D must still be the plain Hamming count.  The uniform cases overflow the default XV reservation: the
