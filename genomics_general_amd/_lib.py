@@ -63,6 +63,9 @@ SIGNATURES = {
     "pg_scaffold_runs": (C.c_int, [C.c_void_p, _i64p, _i32p, C.c_int64, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
     "pg_count_lines": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "pg_text_runs": (C.c_int, [C.c_void_p, C.c_size_t, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
+    "pg_text_seek_pos": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pg_text_skip_rows": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     # (struct array + many pointers: genomics_general_amd/vcf.py passes explicit ctypes objects)
     "pg_encode_vcf": (C.c_int, None),
     "pg_format_freq_rows": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_void_p, _i32p, _i32p, C.c_char_p, _i64p, C.c_void_p, C.c_void_p,

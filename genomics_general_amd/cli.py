@@ -207,11 +207,24 @@ class Run:
         # of the statistics per block.
         self.sharded = False
         self._wshare = (self.world.size, self.world.rank)
+        self.shard_plan = None
         if (shardable and self.world.size > 1 and self._streamer is not None and wparams["windType"] in ("coordinate", "sites")
                 and os.environ.get("PG_SHARD_INPUT", "1") != "0"):
+            from . import shardplan
             inc = set(_lines(args.include)) if args.include else None
             exc = set(_lines(args.exclude)) if args.exclude else None
-            self.sharded = self._reader.shard(self.world, self.comm, lambda nm: windows._wanted(nm, inc, exc))
+            wanted = lambda nm: windows._wanted(nm, inc, exc)            # noqa: E731
+            # window ranges (cuts inside scaffold runs: every rank about 1/N of the bytes whatever the number of scaffolds);
+            # PG_SHARD_INPUT=runs keeps to cuts between scaffold runs, which is also what inputs the plan cannot take fall back to
+            if os.environ.get("PG_SHARD_INPUT", "1") != "runs":
+                self.shard_plan = shardplan.shard_reader(self._reader, self.world, self.comm, wparams, wanted)
+            if self.shard_plan is not None:
+                self.sharded = True
+                if wparams["windType"] == "coordinate":
+                    self._streamer = windows.CoordWindowStream(wparams["windSize"], wparams["stepSize"], inc, exc,
+                                                               start=self.shard_plan.start, stop=self.shard_plan.stop)
+            else:
+                self.sharded = self._reader.shard(self.world, self.comm, wanted)
             if self.sharded:
                 self._wshare = (1, 0)
                 self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size)
@@ -538,6 +551,8 @@ class Run:
         if os.environ.get("PG_TIMING") and (self.world.rank == 0 or self.sharded or self.cat_sharded):
             t = dict(self.timing)
             t["rank"], t["sharded_input"], t["input_bytes"] = self.world.rank, self.sharded or self.cat_sharded, self._reader.input_size()
+            t["window_ranges"] = self.shard_plan is not None      # cuts inside scaffold runs (shardplan) / between runs only
+            t["plan_scanned_bytes"] = int(self.shard_plan.scanned) if self.shard_plan is not None else 0
             t["total_s"] = time.perf_counter() - self._t_start
             # read / tokenize / windows run in their own threads: what this thread spent is the wait for them, the uploads it
             # waited for, and the statistics + output
@@ -1099,6 +1114,7 @@ def freq_main(argv=None):
     sharded = world.size > 1 and hasattr(reader, "shard_lines") and reader.shard_lines(world)
     if world.size > 1 and not sharded and world.rank > 0:
         dist.gather_bytes(comm, b"")
+        comm.close()                                          # every rank takes part in the same exchanges, the closing barrier included
         reader.close()
         return 0
     out = _open_out(args.outFile) if world.rank == 0 else None

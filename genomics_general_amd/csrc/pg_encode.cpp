@@ -193,6 +193,67 @@ extern "C" int pg_text_runs(const char *buf, size_t len, int64_t *starts_out, in
     return PG_OK;
 }
 
+// Walk the data lines of raw text that belong to one scaffold run until a position is reached (the window-range cuts of the
+// multi-GPU input plan: a coordinate window is a function of (scaffold, position), genomics.py:1988-2017).
+extern "C" int pg_text_seek_pos(const char *buf, size_t len, int whole, const char *scaf, size_t scaf_len, int64_t pos_min,
+                                int64_t *off_out, int32_t *state_out, int64_t *pos_out, int64_t *rows_out) {
+    if ((!buf && len) || (!scaf && scaf_len) || !off_out || !state_out || !pos_out || !rows_out)
+        return pg_fail(PG_ERR_ARG, "pg_text_seek_pos: null argument");
+    const char *p = buf, *end = buf + len;
+    int64_t rows = 0;
+    *state_out = -1;
+    *pos_out = 0;
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        if (!nl && !whole) break;                     // an incomplete last line: the caller comes back with more text
+        const char *le = nl ? nl : end;
+        if (data_line(p, le)) {
+            const char *s0 = p;
+            while (s0 < le && is_ws(*s0)) ++s0;
+            const char *q = s0;
+            while (q < le && !is_ws(*q)) ++q;
+            if ((size_t)(q - s0) != scaf_len || memcmp(s0, scaf, scaf_len) != 0) {
+                *state_out = 0;
+                break;
+            }
+            while (q < le && is_ws(*q)) ++q;
+            int64_t v = 0;
+            const char *d = q;
+            while (d < le && *d >= '0' && *d <= '9') v = v * 10 + (*d++ - '0');
+            if (d == q) return pg_fail(PG_ERR_PARSE, "pg_text_seek_pos: a data line without a position");
+            if (v >= pos_min) {
+                *state_out = 1;
+                *pos_out = v;
+                break;
+            }
+            ++rows;
+        }
+        p = nl ? nl + 1 : end;
+    }
+    *off_out = (int64_t)(p - buf);
+    *rows_out = rows;
+    return PG_OK;
+}
+
+// Offset of the data line that follows `n_rows` data lines (the row-index cuts of sites windows, genomics.py:2032-2108).
+extern "C" int pg_text_skip_rows(const char *buf, size_t len, int64_t n_rows, int64_t *off_out, int64_t *rows_out) {
+    if ((!buf && len) || !off_out || !rows_out) return pg_fail(PG_ERR_ARG, "pg_text_skip_rows: null argument");
+    const char *p = buf, *end = buf + len;
+    int64_t rows = 0;
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        const char *le = nl ? nl : end;
+        if (data_line(p, le)) {
+            if (rows == n_rows) break;
+            ++rows;
+        }
+        p = nl ? nl + 1 : end;
+    }
+    *off_out = (int64_t)(p - buf);
+    *rows_out = rows;
+    return PG_OK;
+}
+
 extern "C" int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
                               const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int32_t *pos_out, int64_t *scaf_off,
                               int32_t *scaf_len, int64_t cap_sites, int64_t *n_sites_out, int n_threads) {

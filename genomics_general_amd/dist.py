@@ -66,7 +66,15 @@ def exchange_unique_id(world, make_id, timeout_s=180.0):
             os.remove(path)                  # a leftover of a launch that died before its hand-over completed
         except OSError:
             pass
-        uid = make_id()
+        try:
+            uid = make_id()
+        except Exception as exc:
+            # the other ranks are waiting for this file: tell them, so that every rank falls back to files together instead of
+            # timing out one by one
+            with open(path + ".tmp%d" % os.getpid(), "wb") as f:
+                f.write(("RCCL-FAILED " + str(exc)[:200]).encode())
+            os.replace(path + ".tmp%d" % os.getpid(), path)
+            raise
         tmp = path + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as f:
             f.write(uid)
@@ -79,6 +87,8 @@ def exchange_unique_id(world, make_id, timeout_s=180.0):
                 uid = f.read()
             if len(uid) == 128:
                 return uid, path
+            if uid.startswith(b"RCCL-FAILED"):           # rank 0 could not create the id: nobody waits for it (make_comm)
+                raise RuntimeError("rank 0 reported: " + uid.decode("utf-8", "replace")[:200])
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout_s:
@@ -138,15 +148,66 @@ class RcclComm:
 class FileComm:
     """Host-side communicator through files next to the rendezvous file (`PG_COMM=file`).  RCCL refuses two ranks on one device,
     so this is what lets a multi-rank launch (bench.py --gpus N, the drivers) be exercised on a single-GPU box; the data path
-    has no collective, only finished rows and barriers travel.  Every all-gather is one file per rank, renamed into place."""
+    has no collective, only finished rows and barriers travel.  Every all-gather is one file per rank, renamed into place.
+
+    The exchange directory is unique per launch: rank 0 makes a fresh one and publishes its name through `<rendezvous>.dir`; every
+    other rank leaves a hello file with a random token in the directory it finds named there and adopts the directory only when
+    rank 0's `go` file quotes that token -- so the leftovers of a launch that died under the same MASTER_ADDR / MASTER_PORT (a stale
+    pointer, a stale directory with finished exchanges in it) are never read."""
 
     def __init__(self, world, timeout_s=None):
+        import json
+        import tempfile
+        import uuid
         if timeout_s is None:
             timeout_s = float(os.environ.get("PG_COMM_TIMEOUT", "300"))        # how long a rank waits for the others at an exchange
         self.size, self.rank, self.timeout_s = world.size, world.rank, timeout_s
-        self.dir = _rdzv_path() + ".d"
-        os.makedirs(self.dir, exist_ok=True)
+        base = _rdzv_path()
+        self.pointer = base + ".dir"
         self.seq = 0
+        t0 = time.time()
+        if self.rank == 0:
+            self.dir = tempfile.mkdtemp(prefix=os.path.basename(base) + ".d.", dir=os.path.dirname(base) or ".")
+            self._put(self.pointer, self.dir.encode())
+            tokens = {}
+            while len(tokens) < self.size - 1:
+                for r in range(1, self.size):
+                    if r not in tokens:
+                        try:
+                            with open(os.path.join(self.dir, "hello_r%d" % r)) as f:
+                                tokens[r] = f.read()
+                        except OSError:
+                            pass
+                if time.time() - t0 > timeout_s:
+                    raise TimeoutError("rank 0: only %d of %d ranks arrived at %s" % (1 + len(tokens), self.size, self.dir))
+                time.sleep(0.0005)
+            self._put(os.path.join(self.dir, "go"), json.dumps({str(r): t for r, t in tokens.items()}).encode())
+            return
+        token, said = uuid.uuid4().hex, set()
+        while True:
+            try:
+                with open(self.pointer) as f:
+                    d = f.read()
+                if d and os.path.isdir(d):
+                    if d not in said:
+                        self._put(os.path.join(d, "hello_r%d" % self.rank), token.encode())
+                        said.add(d)
+                    with open(os.path.join(d, "go")) as f:
+                        if json.load(f).get(str(self.rank)) == token:
+                            self.dir = d
+                            return
+            except (OSError, ValueError):
+                pass
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError("rank %d: rank 0 never opened an exchange directory through %s" % (self.rank, self.pointer))
+            time.sleep(0.0005)
+
+    @staticmethod
+    def _put(path, data):
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, path)
 
     def _name(self, seq, rank):
         return os.path.join(self.dir, "g%d_r%d.npy" % (seq, rank))
@@ -179,7 +240,7 @@ class FileComm:
 
     def close(self):
         """The files of the last exchange cannot be removed by their writers (a slower rank may still have to read them): every
-        rank leaves a marker, rank 0 waits for all markers and removes the directory."""
+        rank leaves a marker, rank 0 waits for all markers and removes the directory and the pointer to it."""
         self.barrier()
         with open(os.path.join(self.dir, "done_r%d" % self.rank), "w"):
             pass
@@ -197,6 +258,10 @@ class FileComm:
                 pass
         try:
             os.rmdir(self.dir)
+            with open(self.pointer) as f:
+                mine = f.read() == self.dir
+            if mine:
+                os.remove(self.pointer)
         except OSError:
             pass
 
@@ -211,7 +276,8 @@ def make_comm(engine, world):
         return RcclComm(engine, world)
     except TimeoutError:
         raise                                 # a rank never showed up: files would wait for it just as long
-    except Exception as exc:                  # RCCL itself refused (no peer access, IPC mode, ...): such failures hit every rank alike
+    except Exception as exc:                  # RCCL itself refused (no peer access, IPC mode, ...): such failures hit every rank
+        # alike; when rank 0 cannot even create the id it says so through the hand-over file and the others end up here too
         import sys
         sys.stderr.write("rank %d: RCCL communicator unavailable (%s); the finished rows travel through files instead (PG_COMM=file)\n"
                          % (world.rank, str(exc)[:200]))

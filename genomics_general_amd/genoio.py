@@ -422,6 +422,19 @@ class BlockReader:
             bz.set_stop(*cuts[world.rank + 1])
         return True
 
+    def restrict_virtual(self, start, end, first=False):
+        """BGZF: read only the inflated bytes between the virtual positions start and end, (member file offset, offset inside the
+        member) pairs; first: the reader stays where it is (behind the header line) instead of seeking to `start`"""
+        bz = self.f
+        start, end = (int(start[0]), int(start[1])), (int(end[0]), int(end[1]))
+        if not first:
+            bz.seek_member(start[0])
+            bz.read(start[1])
+        if end <= start and not first:
+            bz.buf, bz.eof = bytearray(), True                 # an empty share
+        elif end[0] < bz.size:
+            bz.set_stop(*end)
+
     def to_geno(self, body, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, keep_packed=False):
         return encode(body, layout, n_threads, head_rows, pitch, alloc)
 
@@ -709,14 +722,46 @@ class PackedReader:
         cuts.append(total)
         if max(cuts[r + 1] - cuts[r] for r in range(world.size)) / total > max_share:
             return False
-        self._rows = (cuts[world.rank], cuts[world.rank + 1])
-        first = [b for b in blocks if b[1] + b[2] > self._rows[0]]
+        self.restrict_rows(blocks, cuts[world.rank], cuts[world.rank + 1])
+        return True
+
+    def restrict_rows(self, blocks, a, b):
+        """read only the global rows [a, b) from now on (blocks: _index()); blocks that straddle an end are trimmed"""
+        self._rows = (int(a), int(b))
+        first = [blk for blk in blocks if blk[1] + blk[2] > self._rows[0]]
         if first and self._rows[1] > self._rows[0]:
             self.f.seek(first[0][0])
             self._g = first[0][1]
         else:
             self.done = True
-        return True
+
+    def positions(self, blocks, a, b):
+        """positions of the global rows [a, b): the position arrays are the first 4 * n_rows bytes of the payloads of the blocks that
+        overlap the range (the deflated chunks that hold them are inflated, nothing else is read); the file position is restored"""
+        import zlib
+        f, here, out = self.f, self.f.tell(), []
+        cache = self.__dict__.setdefault("_pos_cache", {})
+        for off, g, n, starts, names in blocks:
+            if g + n <= a or g >= b:
+                continue
+            if off in cache:
+                out.append(cache[off][max(a - g, 0):min(b - g, n)])
+                continue
+            f.seek(off + 12 + sum(10 + len(nm.encode()) for nm in names))
+            if self.codec == "none":
+                pos = np.frombuffer(f.read(4 * n), dtype="<i4")
+            else:
+                n_chunks = int.from_bytes(f.read(4), "little")
+                table = np.frombuffer(f.read(8 * n_chunks), dtype="<u4").reshape(-1, 2)
+                raw, k = b"", 0
+                while len(raw) < 4 * n:
+                    raw += zlib.decompress(f.read(int(table[k, 0])))
+                    k += 1
+                pos = np.frombuffer(raw[:4 * n], dtype="<i4")
+            cache[off] = pos
+            out.append(pos[max(a - g, 0):min(b - g, n)])
+        f.seek(here)
+        return np.concatenate(out) if out else np.zeros(0, dtype=np.int32)
 
     def _one(self):
         raw = self.f.read(8)

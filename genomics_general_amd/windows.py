@@ -221,7 +221,11 @@ class CoordWindowStream:
     scaffold appears as a row with T.dup[i] = True: it repeats the previously emitted row verbatim (its sites may no longer
     be in the buffer, so lo = hi = 0 there)."""
 
-    def __init__(self, windSize, stepSize, include=None, exclude=None):
+    def __init__(self, windSize, stepSize, include=None, exclude=None, start=None, stop=None):
+        """start / stop: this stream sees a window range of the input (shardplan).  start = (scaffold, k0): the first rows continue a
+        run of that scaffold whose windows < k0 are another rank's (all of them exist); stop = (scaffold, k1): the run the input ends
+        in -- of that scaffold, or not begun yet when no row of it is on this side -- goes on elsewhere, its windows < k1 all exist
+        and are this stream's, the others are not."""
         self.w, self.step, self.include, self.exclude = int(windSize), int(stepSize), include, exclude
         self.done = 0
         self.have_pending = False        # some window has been emitted (it can be re-emitted after a skipped scaffold)
@@ -229,6 +233,9 @@ class CoordWindowStream:
         self.cont_name = None            # scaffold run that was still open at the end of the previous buffer
         self.cont_k0 = 0                 # its next window index
         self.cont_last = 0               # its last position seen
+        self.stop = (stop[0], int(stop[1])) if stop else None
+        if start:
+            self.cont_name, self.cont_k0, self.have_pending = start[0], int(start[1]), True
 
     def feed(self, run_starts, run_names, positions, final):
         positions = np.asarray(positions)
@@ -238,10 +245,17 @@ class CoordWindowStream:
         runs = _runs(run_starts, n) if n else []
         keep_from = n
         cont_name, cont_k0, cont_last = None, 0, 0
+        stop = self.stop if final else None          # the cut run is the one the input ends in
+        if n == 0 and not final:                     # a piece without data rows says nothing about the open run
+            T.finish(positions)
+            T.dup = np.zeros(0, dtype=bool)
+            return T, 0
         if self.cont_name is not None and (not runs or run_names[0] != self.cont_name):
             # the open run ended exactly at the buffer boundary and none of its rows had to be carried (stepSize > windSize):
             # its remaining windows are empty but still emitted
             kl = 0 if self.cont_last <= self.w else -((self.w - self.cont_last) // self.step)
+            if stop is not None and not runs and stop[0] == self.cont_name:
+                kl, stop = stop[1] - 1, None
             for k in range(self.cont_k0, kl + 1):
                 T.add(self.cont_name, 1 + k * self.step, self.w + k * self.step, 0, 0, self.done + 1)
                 T.dup.append(False)
@@ -266,6 +280,8 @@ class CoordWindowStream:
             k0 = self.cont_k0 if is_cont else 0
             kl = 0 if last <= self.w else -((self.w - last) // self.step)          # ceil((last-w)/step)
             k_end = kl if is_open else kl + 1                                       # windows k0 .. k_end-1 are certain
+            if stop is not None and r == len(runs) - 1 and scaf == stop[0]:
+                k_end, stop = stop[1], None                                         # (the run goes on on another rank)
             if k_end > k0:
                 k = np.arange(k0, k_end, dtype=np.int64)
                 starts = 1 + k * self.step
@@ -280,6 +296,18 @@ class CoordWindowStream:
             if is_open:
                 cont_name, cont_k0, cont_last = scaf, max(k0, kl), last
                 keep_from = a + int(np.searchsorted(p, 1 + cont_k0 * self.step, side="left"))
+        if stop is not None:
+            # no row of the cut run is on this side (its rows in front of the cut lie in no window): its windows < k1 are empty
+            if self.skipped_since and self.have_pending:
+                self.done += 1
+                T.add("", 0, 0, 0, 0, 0)
+                T.dup.append(True)
+            self.skipped_since = False
+            for k in range(stop[1]):
+                T.add(stop[0], 1 + k * self.step, self.w + k * self.step, 0, 0, self.done + 1)
+                T.dup.append(False)
+                self.done += 1
+                self.have_pending = True
         self.cont_name, self.cont_k0, self.cont_last = cont_name, cont_k0, cont_last
         T.finish(positions)
         T.dup = np.asarray(T.dup, dtype=bool)
@@ -315,6 +343,10 @@ class SitesWindowStream:
         keep_from = n_all
         finite = not np.isinf(self.maxDist)
         cont_name, cont_hi, cont_wid, cont_after_emit = None, 0, 0, False
+        if n_all == 0 and not final:                 # a piece without data rows says nothing about the open run
+            T.finish(positions)
+            T.dup = np.zeros(0, dtype=bool)
+            return T, 0
         if self.cont_name is not None and (not runs or run_names[0] != self.cont_name):
             # the open run had no rows left to carry and nothing of it follows: it ended at the buffer boundary
             self.have_pending = self.cont_after_emit

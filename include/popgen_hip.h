@@ -147,6 +147,17 @@ int pg_scaffold_runs(const char *buf, const int64_t *scaf_off, const int32_t *sc
  * again with a larger cap).  Used to plan the sharding of `--windType predefined` input, whose forward-only reader
  * (genomics.py:2112-2171) makes the windows depend on the order of the runs in the whole file. */
 int pg_text_runs(const char *buf, size_t len, int64_t *starts_out, int64_t cap, int64_t *n_out);
+/* Window-range cuts of the multi-GPU input plan on RAW text.  A coordinate window is a function of (scaffold, position)
+ * (genomics.py:1988-2017) and the reference hands windows, not scaffolds, to its workers (popgenWindows.py:396-403, 445-447), so a
+ * rank's share of the input may start and end inside a scaffold run.  pg_text_seek_pos walks the data lines of buf (offset 0 = a
+ * line start) while their first field equals scaf[0..scaf_len) and their position is < pos_min.  *off_out = offset of the line
+ * it stopped at, *state_out = 1 (that line is of the run and has position *pos_out >= pos_min), 0 (that line belongs to another
+ * scaffold: the run is over) or -1 (end of the buffer; with whole = 0 an unterminated last line is left for the next call),
+ * *rows_out = data lines walked over.  pg_text_skip_rows: offset of the data line that follows n_rows data lines (row-index cuts
+ * of sites windows, genomics.py:2032-2108); *rows_out < n_rows when the buffer ends first (*off_out = len). */
+int pg_text_seek_pos(const char *buf, size_t len, int whole, const char *scaf, size_t scaf_len, int64_t pos_min, int64_t *off_out,
+                     int32_t *state_out, int64_t *pos_out, int64_t *rows_out);
+int pg_text_skip_rows(const char *buf, size_t len, int64_t n_rows, int64_t *off_out, int64_t *rows_out);
 /* Count data rows (non-'#', non-empty) in a text buffer so the caller can size the outputs. */
 int pg_count_lines(const char *buf, size_t len, int64_t *n_rows_out);
 

@@ -750,8 +750,9 @@ def fourpop_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=1
 
 def distmat_text(geno_path, fmt, wind_size=None, step=None, min_sites=1, wind_type="coordinate",
                  out_format="phylip", round_to=4, include_same=False, min_per_ind=None, samples=None, overlap=0,
-                 max_dist=float("inf"), ploidy=None, write_failed=False):
-    """distMat.py:28-60 (stats_wrapper) + genomics.py:2288-2306 (matrix strings); coordinate, sites and cat windows.  A window
+                 max_dist=float("inf"), ploidy=None, write_failed=False, coords=None):
+    """distMat.py:28-60 (stats_wrapper) + genomics.py:2288-2306 (matrix strings); coordinate, sites, predefined (distMat.py:187 keeps
+    three columns of the window list) and cat windows.  A window
     that fails (too few sites, or an individual below --minPerInd) is a matrix of nan (distMat.py:47-50) and is written only
     with --writeFailedWindows (distMat.py:99-100)."""
     with open_text(geno_path) as fh:
@@ -769,6 +770,8 @@ def distmat_text(geno_path, fmt, wind_size=None, step=None, min_sites=1, wind_ty
             min_sites = wind_size
         if wind_type == "sites":
             wins = sites_windows(sites, wind_size, overlap, max_dist, min_sites)
+        elif wind_type == "predefined":
+            wins = predefined_windows(sites, [c[:3] for c in coords])
         else:
             wins = coord_windows(sites, wind_size, step or wind_size)
     n = len(ind_names)

@@ -23,6 +23,12 @@ FIXTURES = {
     # difference counts of multi-allelic sites (k_pairD's virtual biallelic sites) against the reference's numHamming
     "multi": dict(seed=20261001, n_dip=9, n_pops=3, scaf_len=[2500, 1200], density=0.8, var_thr=30000, miss_thr=6000, fmt="phased", sep="/",
                   multi_frac=0.5),
+    # ONE scaffold (with a gap: empty windows) and FOUR equal scaffolds: what the window-range shards of a multi-GPU launch are
+    # tested on (2, 3 and 8 ranks; cuts between scaffold runs alone would leave ranks without data)
+    "one": dict(seed=20261002, n_dip=8, n_pops=2, scaf_len=[12000], density=0.4, var_thr=30000, miss_thr=5000, fmt="phased", sep="/",
+                gap=(5000, 7100)),
+    "four": dict(seed=20261003, n_dip=8, n_pops=4, scaf_len=[3000, 3000, 3000, 3000], density=0.5, var_thr=40000, miss_thr=5000,
+                 fmt="phased", sep="/"),
     "haplo": dict(seed=20260929, n_dip=5, n_pops=2, scaf_len=[4000], density=0.5, var_thr=30000, miss_thr=4000, fmt="haplo", sep=""),
 }
 
@@ -170,7 +176,46 @@ CASES += [
          argv=["-g", "{geno}", "-f", "phased", "-w", "2500", "-m", "50", "--analysis", "indPairDist", "hapStats", "--roundTo", "8"] + pops_args(8, 2)),
 ]
 
+CASES += [
+    # ---- one scaffold / four scaffolds: the multi-rank window-range plan (tests/test_dist.py) ----
+    dict(name="one_popgen_overlap_failed_id", tool="popgenWindows.py", fixture="one",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "400", "-s", "150", "-m", "10", "--writeFailedWindows", "--addWindowID",
+               "--roundTo", "6"] + pops_args(8, 2)),
+    dict(name="one_popgen_stepgap", tool="popgenWindows.py", fixture="one",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "200", "-s", "500", "-m", "5", "--writeFailedWindows"] + pops_args(8, 2)),
+    dict(name="one_popgen_sites", tool="popgenWindows.py", fixture="one",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "150", "-O", "50", "-m", "100", "--roundTo", "8",
+               "--addWindowID"] + pops_args(8, 2)),
+    dict(name="one_distmat_windows_id", tool="distMat.py", fixture="one",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1500", "-m", "20", "--outFormat", "raw", "--addWindowID", "--writeFailedWindows",
+               "--windowDataOutFile", "{out}.windows"]),
+    dict(name="four_popgen_id", tool="popgenWindows.py", fixture="four",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "500", "-m", "10", "--writeFailedWindows", "--addWindowID"] + pops_args(8, 4)),
+    dict(name="four_abba_overlap", tool="ABBABABAwindows.py", fixture="four",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "600", "-s", "300", "-m", "10", "--minData", "0.5", "--writeFailedWindows",
+               "--addWindowID"] + abba_args(8)),
+    dict(name="four_fourpop", tool="fourPopWindows.py", fixture="four",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "10", "--minData", "0.5"] + abba_args(8)),
+    # ---- predefined windows in the other drivers: a list out of file order, a scaffold the file does not hold, a window past
+    #      the end of the file (ABBABABAwindows.py:31,328, distMat.py:33,118) ----
+    dict(name="four_abba_predefined", tool="ABBABABAwindows.py", fixture="four",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "predefined", "--windCoords", "{dir}/four_coords.txt", "-m", "5",
+               "--writeFailedWindows", "--addWindowID"] + abba_args(8)),
+    dict(name="four_fourpop_predefined", tool="fourPopWindows.py", fixture="four",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "predefined", "--windCoords", "{dir}/four_coords.txt", "-m", "5",
+               "--writeFailedWindows", "--addWindowID"] + abba_args(8)),
+    dict(name="four_distmat_predefined", tool="distMat.py", fixture="four",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "predefined", "--windCoords", "{dir}/four_coords.txt", "-m", "5",
+               "--outFormat", "raw", "--addWindowID", "--writeFailedWindows", "--windowDataOutFile", "{out}.windows"]),
+    dict(name="four_abba_predefined_ordered", tool="ABBABABAwindows.py", fixture="four",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "predefined", "--windCoords", "{dir}/four_coords_ordered.txt", "-m", "5",
+               "--writeFailedWindows", "--addWindowID"] + abba_args(8)),
+]
+
 AUX_FILES = {
+    "four_coords.txt": ("chr2 100 900 a\nchr2 500 1500 b\nchr1 1 500 c\nchrX 1 100 d\nchr3 2000 2400 e\nchr4 2500 3500 f\n"
+                        "chr4 5000 6000 g\n"),
+    "four_coords_ordered.txt": "chr1 1 700 a\nchr1 400 1200 b\nchr2 100 900 c\nchr3 2000 2400 d\nchr4 2500 3500 e\nchr4 5000 6000 f\n",
     "sparse_coords.txt": "chr1 100 900 first\nchr1 500 1500 second\nchr1 4000 4100 third\nchr3 1 1000 onThree\nchr3 2000 2600 lastOne\n",
     "sparse_exclude.txt": "chr2\n",
     "sparse_include.txt": "chr1\nchr2\n",

@@ -154,6 +154,8 @@ def run(tool, argv):
         w, s, m = _take(argv, "-w"), _take(argv, "-s"), _take(argv, "-m")
         r = _take(argv, "--roundTo")
         mi, ov = _take(argv, "-Mi"), _take(argv, "-O")
+        c = _take(argv, "--windCoords")
+        coords = [tuple([p[0], int(p[1]), int(p[2])] + p[3:4]) for p in (ln.split() for ln in _lines(c))] if c else None
         return orc.distmat_text(geno, fmt, wind_size=int(w) if w else None, step=int(s) if s else None,
                                 min_sites=int(m) if m is not None else 1,
                                 wind_type=_take(argv, "--windType", default="coordinate"),
@@ -161,7 +163,7 @@ def run(tool, argv):
                                 round_to=int(r) if r else 4, include_same="--includeSameWithSame" in argv,
                                 min_per_ind=int(mi) if mi else None, samples=_multi(argv, "--samples"),
                                 overlap=int(ov) if ov else 0, ploidy=_ploidy(argv, True),
-                                write_failed="--writeFailedWindows" in argv)
+                                write_failed="--writeFailedWindows" in argv, coords=coords)
     if tool == "freq.py":
         pops = _pops(argv, ("-p",))
         if "--indFreqs" in argv:                                 # freq.py:250-253: every individual is its own population

@@ -126,7 +126,7 @@ cli.Engine = CpuEngine                                        # numbers from the
 dist.RcclComm = lambda engine, world: dist.GlooComm(world)
 tool, argv = sys.argv[1], sys.argv[2:]
 rc = {"popgenWindows.py": cli.popgen_main, "ABBABABAwindows.py": cli.abbababa_main, "distMat.py": cli.distmat_main,
-      "freq.py": cli.freq_main}[tool](argv)
+      "freq.py": cli.freq_main, "fourPopWindows.py": cli.fourpop_main}[tool](argv)
 sys.exit(rc or 0)
 ''' % (ROOT, ROOT, ROOT)
 
@@ -224,7 +224,12 @@ def test_two_ranks_shard_the_input_at_scaffold_runs_and_gather_rows_once(tmp_pat
                 assert t["text_bytes"] <= (0.65 if packed else 0.6) * t["input_bytes"], timing
         if packed == "bgzf":                           # (text_bytes counts inflated bytes there) both ranks worked on sites
             assert all(t["sites"] > 0 for t in timing), timing
-        assert sum(t["sites"] for t in timing) == sum(1 for ln in gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"))) - 1
+        n_lines = sum(1 for ln in gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"))) - 1
+        overlapping = "-s" in case["argv"] or "-O" in case["argv"] or "--overlap" in case["argv"]
+        # (window ranges: with -s < -w, or -O, the rows of the windows that straddle a cut are read by both neighbours; with
+        # -s > -w the rows between the last window of one rank and the first of the next are read by nobody)
+        got_rows = sum(t["sites"] for t in timing)
+        assert (0.9 * n_lines <= got_rows <= 1.25 * n_lines) if overlapping else got_rows == n_lines
 
 
 def test_freq_with_two_ranks_cuts_the_input_at_line_boundaries(tmp_path):
@@ -315,7 +320,7 @@ def test_file_comm_world_size_3(tmp_path):
             p.kill()
             o, _ = p.communicate()
         assert p.returncode == 0 and ("rank %d ok" % rank) in o.decode(), o.decode()[-2000:]
-    assert not os.path.exists(str(tmp_path / "rdzv.d")), "the exchange directory is removed by the last rank to close"
+    assert os.listdir(str(tmp_path)) == [], "the exchange directory and the pointer to it are removed by rank 0's close()"
 
 
 def test_a_refused_rccl_communicator_falls_back_to_files(monkeypatch, tmp_path, capsys):
@@ -328,8 +333,17 @@ def test_a_refused_rccl_communicator_falls_back_to_files(monkeypatch, tmp_path, 
     def refuse(engine, world):
         raise RuntimeError("ncclCommInitRank: invalid usage")
     monkeypatch.setattr(dist, "RcclComm", refuse)
-    comm = dist.make_comm(None, dist.World(0, 2, 0))
-    assert isinstance(comm, dist.FileComm) and comm.size == 2
+    import threading
+    comms = [None, None]
+
+    def make(r):
+        comms[r] = dist.make_comm(None, dist.World(r, 2, r))
+    th = [threading.Thread(target=make, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert all(isinstance(c, dist.FileComm) and c.size == 2 for c in comms) and comms[0].dir == comms[1].dir
     assert "travel through files" in capsys.readouterr().err
 
     def absent(engine, world):
@@ -455,3 +469,115 @@ def test_predefined_windows_are_sharded_when_the_file_agrees_with_the_window_lis
             assert '"sharded_input": true' not in e.decode()
         outs.append(open(out).read())
     assert outs[0] == outs[1] and outs[0].count("\n") == 5
+
+
+def test_file_comm_ignores_the_leftovers_of_a_dead_launch(tmp_path, monkeypatch):
+    """a launch that died under the same MASTER_ADDR / MASTER_PORT leaves a pointer, a directory, a `go` file and
+    finished exchanges behind.  A new launch must not read any of it: rank 0 opens a fresh directory, and the other ranks adopt a
+    directory only when its `go` file quotes the token they left there -- whichever of them starts first."""
+    import json
+    import threading
+    import time
+    monkeypatch.setenv("PG_RDZV_FILE", str(tmp_path / "rdzv"))
+    stale = tmp_path / "rdzv.d.dead"
+    stale.mkdir()
+    (tmp_path / "rdzv.dir").write_text(str(stale))
+    (stale / "go").write_text(json.dumps({"1": "an old token"}))
+    np.save(str(stale / "g0_r0.npy"), np.array([666.0]))
+    np.save(str(stale / "g0_r1.npy"), np.array([667.0]))
+    got = [None, None]
+
+    def run(r, delay):
+        time.sleep(delay)
+        c = dist.FileComm(dist.World(r, 2, r), timeout_s=30)
+        got[r] = (c.dir, c.allgather(np.array([float(r + 1)])).ravel().tolist())
+        c.close()
+    th = [threading.Thread(target=run, args=(0, 0.3)), threading.Thread(target=run, args=(1, 0.0))]     # rank 1 meets the stale pointer first
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert got[0][1] == got[1][1] == [1.0, 2.0] and got[0][0] == got[1][0] != str(stale)
+    assert sorted(os.listdir(str(tmp_path))) == ["rdzv.d.dead"]
+
+
+def test_rank_0_failing_to_create_the_rccl_id_tells_the_waiting_ranks(tmp_path, monkeypatch):
+    """when rank 0 cannot create the unique id, the other ranks must not sit out the 180 s hand-over timeout: the
+    failure travels through the hand-over file and every rank ends up in the same fallback"""
+    monkeypatch.setenv("PG_RDZV_FILE", str(tmp_path / "rdzv"))
+
+    def broken():
+        raise RuntimeError("librccl.so not found")
+    with pytest.raises(RuntimeError):
+        dist.exchange_unique_id(dist.World(0, 2, 0), broken)
+    with pytest.raises(RuntimeError, match="rank 0 reported"):
+        dist.exchange_unique_id(dist.World(1, 2, 1), None, timeout_s=5)
+
+
+def _launch(tool, argv, size, port, env_extra=None):
+    """the driver on `size` ranks (CPU stand-in engine); PG_COMM=file from 4 ranks on: no torch import in eight processes"""
+    procs = []
+    for rank in range(size):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PG_TIMING="1", PG_STREAM_BYTES="20000", **(env_extra or {}))
+        if size >= 4:
+            env["PG_COMM"] = "file"
+        procs.append(subprocess.Popen([sys.executable, "-c", CLI_WORKER, tool] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    import json
+    timing = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, e = p.communicate()
+        assert p.returncode == 0, e.decode()[-1500:]
+        timing += [json.loads(ln[len("PG_TIMING "):]) for ln in e.decode().splitlines() if ln.startswith("PG_TIMING ")]
+    return sorted(timing, key=lambda t: t["rank"])
+
+
+@pytest.mark.parametrize("name,sizes", [("one_popgen_overlap_failed_id", (2, 3, 8)), ("one_popgen_stepgap", (8,)), ("one_popgen_sites", (3, 8)),
+                                        ("one_distmat_windows_id", (8,)), ("four_popgen_id", (2, 3, 8)), ("four_abba_overlap", (8,)),
+                                        ("four_fourpop", (3,))])
+def test_window_ranges_shard_one_and_four_scaffolds_over_2_3_and_8_ranks(name, sizes, tmp_path):
+    """SURVEY 8e "else split a scaffold's window range": a ONE-scaffold file and a FOUR-scaffold file (the layout of the north-star
+    data set) on 2, 3 and 8 ranks.  Every rank reads, tokenises and computes only its window range (genomics_general_amd.shardplan:
+    cuts inside scaffold runs), the output is the unmodified reference's (window IDs, failed and empty windows, -s < -w overlap,
+    -s > -w gaps, sites windows, the distMat side file), every rank got data and none read more than 1.3 / N of the bytes plus the
+    lines of one window span.  Cuts between scaffold runs alone (round 3) gave shares [1, 0, ...] and [.25, 0, .25, 0, ...] here."""
+    import gzip
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from cases import CASES, FIXTURES
+    from golden_util import align_columns
+    import test_gpu_golden as G
+    gold = os.path.join(ROOT, "tests", "golden")
+    case = [c for c in CASES if c["name"] == name][0]
+    geno = str(tmp_path / (case["fixture"] + ".geno"))
+    with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f, open(geno, "wb") as g:
+        g.write(f.read())
+    n_lines = sum(1 for _ in open(geno)) - 1
+    size_b = os.path.getsize(geno)
+    av = case["argv"]
+    w = int(av[av.index("-w") + 1])
+    step = int(av[av.index("-s") + 1]) if "-s" in av else w
+    if "sites" in av:                                            # a window span in lines
+        span_lines = w + 1
+    else:
+        span_lines = (w + step) * n_lines / sum(FIXTURES[case["fixture"]]["scaf_len"]) * 1.5 + 2
+    for k, size in enumerate(sizes):
+        out = str(tmp_path / ("%s_%d.out" % (name, size)))
+        argv = [a.format(geno=geno, dir=gold, out=out) for a in av] + ["-o", out]
+        timing = _launch(case["tool"], argv, size, 41000 + (os.getpid() * 7 + 31 * k + len(name)) % 4000,
+                         {"PG_RDZV_FILE": str(tmp_path / ("rdzv%d" % size))})
+        with open(out) as f, open(os.path.join(gold, name + ".out")) as g:
+            got, want = f.read(), g.read()
+        G.compare_text(align_columns(got, want), want, G.round_digits(case))
+        if os.path.exists(os.path.join(gold, name + ".out.windows")):
+            with open(out + ".windows") as f, open(os.path.join(gold, name + ".out.windows")) as g:
+                assert f.read() == g.read()
+        assert len(timing) == size and all(t["sharded_input"] and t["window_ranges"] for t in timing), timing
+        n_windows = want.count("\n") - 1 if case["tool"] != "distMat.py" else open(os.path.join(gold, name + ".out.windows")).read().count("\n")
+        # (ranks whose equal split of the bytes falls into one and the same window have nothing of their own: 8 windows on 8 ranks)
+        assert sum(t["sites"] > 0 for t in timing) >= min(size, n_windows // 2), [t["sites"] for t in timing]
+        for t in timing:
+            assert t["text_bytes"] <= 1.3 / size * size_b + span_lines * size_b / n_lines + 64, (size, [x["text_bytes"] for x in timing], size_b)
