@@ -10,8 +10,10 @@ generated on the device before the timed region (counter-based generator, genomi
 in HBM.  The data path has no collective (windows are independent): at N>1 the ranks meet in an RCCL barrier on both sides
 of the timed region, and every step ends in the one exchange a driver job has -- the all-gather of the finished per-window rows
 (`result_allgather_ms_per_step`, inside the reported time).  `python bench.py --gpus N` without a launcher starts its own N
-ranks; from 8 GPUs on the default workload is c5, the rank's share of BASELINE.json configs[4].  Weak scaling: every rank owns a full-size data set (different scaffolds), `value` = windows of all ranks /
-max-over-ranks time.
+ranks.  Weak scaling (default): every rank owns a full-size data set (different scaffolds), `value` = windows of all ranks /
+max-over-ranks time; the shape is the same at every N (north-star per rank), and from 8 ranks on the rank's share of BASELINE.json
+configs[4] is measured behind the headline and reported as `c5_share`.  `--strong`: ONE data set cut into window ranges by the
+drivers' multi-GPU plan (genomics_general_amd/shardplan.py), `scaling: "strong"`.
 
 Default workload = the north-star single-GPU shape (BASELINE.json `north_star` "Target": 10^8 sites x 200 diploids, 4
 populations, 50 kb windows = the first 10^8 sites of configs[4]); `--workload c2` is configs[1], c3 configs[2], c4 configs[3],
@@ -376,14 +378,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: northstar; c5 (BASELINE.json configs[4], 3e9 sites sharded over the ranks) from 8 GPUs on")
+    ap.add_argument("--workload", default="northstar", choices=sorted(WORKLOADS),
+                    help="default: northstar at every N (one shape per scaling curve); c5 = the rank's share of BASELINE.json configs[4], "
+                         "3e9 sites over >= 8 ranks (also measured after the headline at N >= 8 and reported as `c5_share`)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: ONE data set of the workload's size, cut into window ranges by the drivers' multi-GPU plan "
+                         "(genomics_general_amd.shardplan), every rank holds and computes only its range, the gather of the rows inside the time")
+    ap.add_argument("--no-c5", action="store_true", help="at N >= 8: skip the c5_share measurement behind the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tiers", action="store_true", help="skip the T1 (host blocks -> H2D -> kernels) and T2 (text -> CSV) samples")
     ap.add_argument("--cpu-workers", type=int, default=1 << 30, help="upper bound of the CPU baseline's worker processes")
     args = ap.parse_args()
-    if args.workload is None:
-        args.workload = "c5" if args.gpus >= 8 else "northstar"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))                  # a bare `python bench.py --gpus N`: this process becomes the launcher
     wl = dict(WORKLOADS[args.workload])
@@ -406,25 +411,53 @@ def main():
     comm = dist.make_comm(eng, world)
     if world.size > 1 and isinstance(comm, dist.RcclComm):
         assert eng._comm_ranks() == world.size, "the RCCL communicator has %d ranks, expected %d" % (eng._comm_ranks(), world.size)
-    n_sites = wl["n_sites"]
-    scaf_len = n_sites // wl["n_scaf"]
-    tiers = world.size == 1 and not args.no_tiers and wl["tool"] == "popgen"
-    t1_block = min(T1_BLOCK_SITES, n_sites // wl["wind"] * wl["wind"]) // wl["wind"] * wl["wind"]
-    eng.reserve(n_sites + (2 * t1_block if tiers else 0))    # the two halves of the T1 upload buffer sit behind the data set
-    # rank r owns global sites [r*n_sites, (r+1)*n_sites): distinct scaffolds, same shape
-    eng.synth_fill(0, n_sites, world.rank * n_sites, synth.SEED_DEFAULT, scaf_len, n_dip, n_pops, slot_gen,
-                   synth.VAR_THR, synth.MISS_THR)
-    run_starts = np.arange(wl["n_scaf"], dtype=np.int64) * scaf_len
-    run_names = ["chr%d" % (world.rank * wl["n_scaf"] + k + 1) for k in range(wl["n_scaf"])]
-    positions = np.tile(np.arange(1, scaf_len + 1, dtype=np.int32), wl["n_scaf"])
-    T = windows.coord_windows(run_starts, run_names, positions, wl["wind"], wl["wind"])
-    del positions
-    good = T.sites >= wl["min_sites"]
-    lo, hi = T.lo[good], T.hi[good]
-    n_win = int(len(lo))
-    sites_per_step = int((hi - lo).sum())
+    tiers = world.size == 1 and not args.no_tiers and wl["tool"] == "popgen" and not args.strong
 
-    def step():
+    def setup_data(wl, extra_rows_of=None):
+        """Make the rank's data set resident and find its windows (untimed).  Weak scaling: rank r owns global sites
+        [r*n, (r+1)*n) of an endless dense genome -- distinct scaffolds, the same shape on every rank.  --strong: ONE data set of
+        n sites; the ranks cut it into window ranges with the drivers' plan (shardplan.shard_reader on synth.DenseRows, the
+        `.pgeno` interface), every rank generates only its rows and streams only its windows (windows.CoordWindowStream with the
+        plan's start / stop state)."""
+        n_total = wl["n_sites"]
+        scaf_len = n_total // wl["n_scaf"]
+        d = {"scaf_len": scaf_len, "share": 1.0}
+        if args.strong:
+            from genomics_general_amd import shardplan
+            src = synth.DenseRows(n_total, scaf_len, ["chr%d" % (k + 1) for k in range(wl["n_scaf"])])
+            wp = dict(windType="coordinate", windSize=wl["wind"], stepSize=wl["wind"], overlap=0, maxDist=np.inf)
+            plan = shardplan.shard_reader(src, world, comm, wp, lambda nm: True) if world.size > 1 else shardplan.Plan(None, None, 1.0)
+            first, end = src._rows
+            n_sites = end - first
+            run_starts, run_names, positions = src.local_runs()
+            stream = windows.CoordWindowStream(wl["wind"], wl["wind"], start=plan.start, stop=plan.stop)
+            T, _ = stream.feed(run_starts, run_names, positions, final=True)
+            d["share"] = n_sites / n_total
+        else:
+            n_sites, first = n_total, world.rank * n_total
+            run_starts = np.arange(wl["n_scaf"], dtype=np.int64) * scaf_len
+            run_names = ["chr%d" % (world.rank * wl["n_scaf"] + k + 1) for k in range(wl["n_scaf"])]
+            positions = np.tile(np.arange(1, scaf_len + 1, dtype=np.int32), wl["n_scaf"])
+            T = windows.coord_windows(run_starts, run_names, positions, wl["wind"], wl["wind"])
+        del positions
+        extra_rows = extra_rows_of(n_sites) if extra_rows_of else 0
+        eng.reserve(max(n_sites, 1) + extra_rows)
+        if n_sites:
+            eng.synth_fill(0, n_sites, first, synth.SEED_DEFAULT, scaf_len, n_dip, n_pops, slot_gen, synth.VAR_THR, synth.MISS_THR)
+        good = T.sites >= wl["min_sites"]
+        d.update(n_sites=n_sites, lo=T.lo[good], hi=T.hi[good], n_win=int(good.sum()), sites_per_step=int((T.hi[good] - T.lo[good]).sum()))
+        return d
+
+    t1_block = min(T1_BLOCK_SITES, wl["n_sites"] // wl["wind"] * wl["wind"]) // wl["wind"] * wl["wind"]
+    data = setup_data(wl, (lambda n: 2 * t1_block) if tiers else None)   # the two halves of the T1 upload buffer sit behind the data set
+    n_sites, scaf_len, lo, hi, n_win, sites_per_step = (data[k] for k in ("n_sites", "scaf_len", "lo", "hi", "n_win", "sites_per_step"))
+    counts = comm.allgather(np.array([float(n_win), float(sites_per_step), data["share"]])) if world.size > 1 else np.array(
+        [[float(n_win), float(sites_per_step), 1.0]])
+    total_win, total_sites_step = int(counts[:, 0].sum()), int(counts[:, 1].sum())
+
+    def step(lo=lo, hi=hi):
+        if len(lo) == 0:                                   # (--strong with more ranks than windows: nothing of its own)
+            return None, np.zeros((0, 1))
         wb = eng.batch(lo, hi)
         if wl["tool"] == "popgen":
             table, cols = wb.groupDistTable(doPairs=True, minSites=wl["min_sites"], minData=0.01)
@@ -440,6 +473,22 @@ def main():
         table = np.stack([st[k] for k in keys], axis=1)
         return st, table
 
+    cols_seen = {}
+
+    def gather_rows(tab, n_mine, n_of_rank):
+        """the finished rows of every rank on every rank, in rank order = input order (the shares of --strong differ in size: padded
+        to the largest, one all-gather)"""
+        width = int(max(n_of_rank.max(), 1))
+        a = np.asarray(tab, dtype=np.float64).reshape(n_mine, -1) if n_mine else None
+        if "n" not in cols_seen:                           # (a rank without windows learns the row width from the others, once)
+            cols_seen["n"] = int(comm.allgather(np.array([float(a.shape[1] if a is not None else 0)])).max())
+        n_cols = cols_seen["n"]
+        pad = np.zeros((width, n_cols))
+        if a is not None:
+            pad[:n_mine] = a
+        allr = comm.allgather(pad.ravel()).reshape(world.size, width, n_cols)
+        return np.concatenate([allr[r, :int(n_of_rank[r])] for r in range(world.size)], axis=0)
+
     # warm-up with every kernel family bracketed by events: it tells which family is the dominant one; the timed region then
     # brackets only that family (an event record between two kernels costs a few microseconds of GPU idle time), and the
     # per-family breakdown reported next to it comes from the warm-up pass
@@ -450,12 +499,16 @@ def main():
     st = _tab = None
     for _ in range(max(args.warmup - 1, 0)):
         st, _tab = step()
+        if world.size > 1:
+            gather_rows(_tab, n_win, counts[:, 0])
     eng.sync()
     eng.kernel_time_reset()
     n_warm = 0
     if args.warmup >= 1:                                   # the last warm-up step is the breakdown pass
         st, _tab = step()
         eng.sync()
+        if world.size > 1:
+            gather_rows(_tab, n_win, counts[:, 0])
         n_warm = 1
     kt = {name: eng.kernel_time(kid) for kid, name in _lib.KERNEL_NAMES.items()}
     dom_id = max(cand, key=lambda k: eng.kernel_time(k)[0]) if n_warm else None
@@ -469,9 +522,9 @@ def main():
         st, _tab = step()
         if world.size > 1:                                 # the drivers' one exchange per job: the finished rows meet on every rank
             g0 = time.perf_counter()
-            full = dist.gather_table(comm, np.asarray(_tab, dtype=np.float64).reshape(n_win, -1), n_win * world.size)
+            full = gather_rows(_tab, n_win, counts[:, 0])
             gather_s += time.perf_counter() - g0
-            assert full.shape[0] == n_win * world.size
+            assert full.shape[0] == total_win
     eng.sync()
     my_elapsed = time.perf_counter() - t0
     comm.barrier()
@@ -611,18 +664,49 @@ def main():
             extra.update(tier_samples(eng, lay, wl, names, slot_gen, scaf_len, n_sites, t1_block, np.asarray(_tab)))
         except Exception as exc:
             extra["t1"] = {"error": repr(exc)[:300]}
+    # ---- N >= 8: the rank's share of BASELINE.json configs[4] (3e9 sites / N: 150 GB resident at N = 8) behind the headline.  The
+    # headline stays on ONE shape for N = 1, 2, 4, 8, so that a scaling curve compares like with like; this is the same pass at the
+    # size config 5 asks for, a few steps, the gather inside the time
+    if world.size >= 8 and args.workload == "northstar" and not args.strong and not args.no_c5:
+        try:
+            wl5 = dict(WORKLOADS["c5"])
+            wl5["n_sites"] = 3_000_000_000 // world.size // (wl5["n_scaf"] * wl5["wind"]) * (wl5["n_scaf"] * wl5["wind"])
+            d5 = setup_data(wl5)
+            c5_counts = np.full(world.size, float(d5["n_win"]))
+            cols_seen.clear()
+            step(d5["lo"], d5["hi"])
+            eng.sync()
+            comm.barrier()
+            c0 = time.perf_counter()
+            for _ in range(3):
+                _, tab5 = step(d5["lo"], d5["hi"])
+                gather_rows(tab5, d5["n_win"], c5_counts)
+            eng.sync()
+            comm.barrier()
+            dt5 = float(np.max(comm.allgather(np.array([time.perf_counter() - c0])))) / 3
+            extra["c5_share"] = {"workload": wl5["desc"], "sites_per_gpu": d5["sites_per_step"], "windows_per_gpu": d5["n_win"],
+                                 "resident_GB_per_gpu": round(d5["sites_per_step"] * lay.n_hap / 1e9, 1), "steps": 3,
+                                 "ms_per_step": round(dt5 * 1e3, 3), "windows_per_sec": round(d5["n_win"] * world.size / dt5, 1),
+                                 "sites_per_sec": round(d5["sites_per_step"] * world.size / dt5, 1)}
+        except Exception as exc:                                # side information: never lose the main line
+            extra["c5_share"] = {"error": repr(exc)[:300]}
     if world.rank == 0:
-        total_windows = n_win * world.size * args.steps
-        total_sites = sites_per_step * world.size * args.steps
+        total_windows = total_win * args.steps
+        total_sites = total_sites_step * args.steps
+        if args.strong:
+            extra["strong"] = {"rank_bytes_share": [round(float(x), 4) for x in counts[:, 2]],
+                               "windows_per_rank": [int(x) for x in counts[:, 0]],
+                               "plan": "genomics_general_amd.shardplan (window ranges inside scaffold runs) on the one data set; every rank "
+                                       "generates, holds and computes only its range"}
         line = {
             "metric": "windows_per_sec", "value": round(total_windows / elapsed, 3), "unit": "windows/s",
             "sites_per_sec": round(total_sites / elapsed, 1),
             "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "u32 bit-planes / int32 counts / f64 statistics", "data": "synthetic",
             "config": {"workload": wl["desc"], "name": args.workload, "tier": "T0 (inputs resident in HBM; SURVEY.md 8d)",
                        "windows_per_gpu": n_win, "sites_per_gpu": sites_per_step, "haplotypes": n_hap,
-                       "parallelism": "windows sharded, dp%d" % world.size},
+                       "parallelism": ("one data set cut into %d window ranges" if args.strong else "windows sharded, dp%d") % world.size},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)

@@ -115,6 +115,36 @@ def dense_sites(n_sites, n_scaf):
     return idx // per, idx % per + 1
 
 
+class DenseRows:
+    """The dense benchmark data set (n_scaf equal scaffolds, every position present) as a row-indexed input the multi-GPU plan can
+    cut (genomics_general_amd.shardplan, the `.pgeno` interface: block headers + position arrays), without a file: bench.py
+    --strong lets the ranks plan their window ranges on it exactly as the drivers do on a `.pgeno` file, and every rank then
+    generates only its own rows on its device (the generator is counter-based)."""
+    packed = True
+
+    def __init__(self, n_sites, scaf_len, scaf_names):
+        self.total, self.scaf_len, self.names = int(n_sites), int(scaf_len), list(scaf_names)
+        self._rows = (0, self.total)
+
+    def _index(self):
+        return [(None, k * self.scaf_len, self.scaf_len, [0], [nm]) for k, nm in enumerate(self.names)], self.total
+
+    def positions(self, blocks, a, b):
+        return (np.arange(a, b, dtype=np.int64) % self.scaf_len + 1).astype(np.int32)
+
+    def restrict_rows(self, blocks, a, b):
+        self._rows = (int(a), int(b))
+
+    def local_runs(self):
+        """(run starts, run names, positions) of the rows this reader is restricted to, row 0 = its first row"""
+        a, b = self._rows
+        if b <= a:
+            return np.zeros(0, dtype=np.int64), [], np.zeros(0, dtype=np.int32)
+        k0, k1 = a // self.scaf_len, (b - 1) // self.scaf_len
+        starts = np.array([max(k * self.scaf_len, a) - a for k in range(k0, k1 + 1)], dtype=np.int64)
+        return starts, [self.names[k] for k in range(k0, k1 + 1)], self.positions(None, a, b)
+
+
 def codes_to_letters(codes):
     lut = np.full(256, ord("N"), dtype=np.uint8)
     for b, c in zip(BASES, (1, 2, 4, 8)):

@@ -97,12 +97,27 @@ def test_bench_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["comm_ranks"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert d["config"]["name"] == "tiny" and "result_allgather_ms_per_step" in d
     assert d["config"]["windows_per_gpu"] * 2 * 3 / (d["ms_per_step"] * 3 / 1e3) == pytest.approx(d["value"], rel=1e-3)
+    # --strong: ONE data set, cut into window ranges by the drivers' plan (shardplan); both ranks must get work, together all of it
+    for n in (2, 3):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline", "--no-tiers", "--strong"], env=env, capture_output=True, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
+        assert d["scaling"] == "strong" and d["n_gpus"] == n
+        assert all(w > 0 for w in d["strong"]["windows_per_rank"]) and sum(d["strong"]["windows_per_rank"]) == 8      # 400 000 sites / 50 kb
+        assert sum(d["strong"]["rank_bytes_share"]) == pytest.approx(1.0, abs=1e-3) and max(d["strong"]["rank_bytes_share"]) <= 1.0 / n + 0.13
+        assert 8 * 2 / (d["ms_per_step"] * 2 / 1e3) == pytest.approx(d["value"], rel=1e-3)
 
 
 @pytest.mark.parametrize("name,tool,size", [("holes_distmat_cat_nexus", "distMat.py", 2), ("holes_distmat_cat_nexus", "distMat.py", 3),
-                                            ("sparse_predefined", "popgenWindows.py", 2), ("sparse_predefined", "popgenWindows.py", 3)])
+                                            ("sparse_predefined", "popgenWindows.py", 2), ("sparse_predefined", "popgenWindows.py", 3),
+                                            # window ranges inside scaffold runs (shardplan): one scaffold and four, 2 / 3 / 8 ranks
+                                            ("one_popgen_overlap_failed_id", "popgenWindows.py", 8), ("one_popgen_sites", "popgenWindows.py", 3),
+                                            ("one_distmat_windows_id", "distMat.py", 2), ("four_popgen_id", "popgenWindows.py", 8),
+                                            ("four_abba_overlap", "ABBABABAwindows.py", 3), ("four_fourpop", "fourPopWindows.py", 2)])
 def test_cat_and_predefined_windows_on_several_ranks(name, tool, size, tmp_path):
-    """WORLD_SIZE ranks, all on device 0 (so the exchange goes through files).  `distMat.py --windType cat`: every rank counts its
+    """WORLD_SIZE ranks, all on device 0 (so the exchange goes through files).  Coordinate and sites windows: every rank reads,
+    tokenises (on the device) and computes its window range of the one- or four-scaffold file, one gather of the rows.  `distMat.py --windType cat`: every rank counts its
     share of the lines on the GPU (pg_pairwise), the counts are summed across the ranks, the matrix finished from the sums
     (pg_indpairdist_mean_from_counts) is the reference's.  `--windType predefined`: the file is cut at the scaffold runs the plan
     (windows.plan_predefined_shards) allows, every rank streams its own windows, one gather of the rows"""
@@ -133,3 +148,6 @@ def test_cat_and_predefined_windows_on_several_ranks(name, tool, size, tmp_path)
     with open(out) as f, open(os.path.join(gold, case["name"] + ".out")) as g:
         got, want = f.read(), g.read()
     G.compare_text(align_columns(got, want), want, G.round_digits(case))
+    if os.path.exists(os.path.join(gold, name + ".out.windows")) and "windowDataOutFile" in " ".join(case["argv"]):
+        with open(out + ".windows") as f, open(os.path.join(gold, name + ".out.windows")) as g:
+            assert f.read() == g.read()
