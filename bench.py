@@ -68,7 +68,8 @@ WORKLOADS = {
 CPU_DISTMAT_HAPS = 120          # distMat CPU sample: 7140 pairs x 100 kb ~ 5 s per window
 T1_BLOCK_SITES = 1 << 20        # T1 sample: host blocks of about a million sites, eight of them
 T1_BLOCKS = 8
-T2_SITES = 4_000_000            # T2 sample: this many sites of the workload as `.geno` text (80 windows of 50 kb; 3.3 GB at 400 haplotypes)
+T2_SITES = 25_000_000           # T2 sample: this many sites of the workload as `.geno` text (500 windows of 50 kb; 20.3 GB at 400 haplotypes),
+                                # less when the temporary directory or the host memory is short of room for it (PG_BENCH_T2_SITES overrides)
 CPU_WHOLE_WINDOWS = 8           # CPU sample: this many whole windows, one per worker on an otherwise idle host (~60 s at 400 haplotypes)
 CPU_SLICE_SITES = 4_000         # CPU sample: the first 4000 sites of a window per worker (~4 s of CPU work at 400 haplotypes on an idle core,
                                 # ~10x that with every hardware thread of a 256-thread host busy)
@@ -161,6 +162,115 @@ def _cpu_matches(wl, csvs, stats):
     return bool(ok)
 
 
+def effective_cpus():
+    """How many CPUs this process may really use, and where the number comes from: the logical CPUs of the host, cut by the
+    scheduler affinity mask and by the cgroup's CPU quota (a container on a 256-thread host may be limited to a handful of CPUs'
+    worth of time: more busy processes than that share the quota and gain nothing)."""
+    logical = os.cpu_count() or 1
+    info = {"logical": logical}
+    n = float(logical)
+    try:
+        aff = len(os.sched_getaffinity(0))
+        info["affinity"] = aff
+        n = min(n, aff)
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt and txt[0] != "max":
+                    info["cgroup_quota_cpus"] = round(int(txt[0]) / int(txt[1]), 2)
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        info["cgroup_quota_cpus"] = round(q / int(f.read()), 2)
+        except Exception:
+            continue
+    if "cgroup_quota_cpus" in info:
+        n = min(n, info["cgroup_quota_cpus"])
+    try:
+        with open("/proc/pressure/cpu") as f:
+            info["pressure_cpu"] = f.readline().strip()
+    except Exception:
+        pass
+    info["usable"] = max(1, int(n + 0.5))
+    return info
+
+
+REF_WRAP = ("import sys, runpy, numpy as np; np.NaN = np.nan; sys.path.insert(0, %r); "
+            "sys.argv = sys.argv[1:]; runpy.run_path(sys.argv[0], run_name='__main__')")
+
+
+def cpu_baseline_reference(wl, names, n_pops, ref_dir, cores, budget_s=420.0):
+    """The UNMODIFIED reference (/root/reference/popgenWindows.py:386-460: reader -> window queue -> -T worker
+    processes -> sorter -> writer) on a W-window prefix of the workload rendered as `.geno` text by the host statement of the
+    generator (no GPU involved), `-T cores` and `-T 1`, wall clock around the whole process, under `timeout`.  Only where the
+    reference is present (the build container; it does not travel to the GPU box)."""
+    import subprocess
+    import tempfile
+    from genomics_general_amd import synth
+    tool = {"popgen": "popgenWindows.py", "abba": "ABBABABAwindows.py"}[wl["tool"]]
+    wind, n_dip = wl["wind"], wl["n_dip"]
+    per = n_dip // n_pops
+    W = int(max(2, min(cores, 16)))                            # one window per worker process
+    tmp = tempfile.mkdtemp(prefix="pg_ref_baseline_")
+    geno = os.path.join(tmp, "prefix.geno")
+    sid, pos = np.zeros(W * wind + 1, dtype=np.int64), np.arange(1, W * wind + 2)      # one site beyond: the last window is full
+    with open(geno, "w") as f:
+        step = 50_000
+        for a in range(0, len(pos), step):
+            codes = synth.gen_codes(synth.SEED_DEFAULT, sid[a:a + step], pos[a:a + step], n_dip, n_pops)
+            part = geno + ".part"
+            synth.write_geno(part, ["chr1"], sid[a:a + step], pos[a:a + step], codes, names, sep="/", fmt="phased")
+            with open(part) as g:
+                if a:
+                    g.readline()
+                f.write(g.read())
+            os.remove(part)
+    argv = ["-g", geno, "-f", "phased", "-w", str(wind), "-m", str(wl["min_sites"]), "--roundTo", "12"]
+    if tool == "popgenWindows.py":
+        for k in range(n_pops):
+            argv += ["-p", "pop%d" % k, ",".join(names[k * per:(k + 1) * per])]
+    else:
+        for flag, k in (("-P1", 0), ("-P2", 1), ("-P3", 2), ("-O", 3)):
+            argv += [flag, "pop%d" % k, ",".join(names[k * per:(k + 1) * per])]
+    runs = {}
+    try:
+        for label, T, n_win in (("T_all", cores, W), ("T_1", 1, 2)):
+            out = os.path.join(tmp, label + ".csv")
+            a = list(argv)
+            if n_win < W:                                       # -T 1 on the first two windows only
+                short = os.path.join(tmp, "two.geno")
+                with open(geno) as f, open(short, "w") as g:
+                    for i, ln in enumerate(f):
+                        if i > n_win * wind + 1:
+                            break
+                        g.write(ln)
+                a[1] = short
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, "-c", REF_WRAP % ref_dir, os.path.join(ref_dir, tool)] + a + ["-o", out, "-T", str(T)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s, cwd=tmp)
+            dt = time.perf_counter() - t0
+            with open(out) as f:
+                rows = max(sum(1 for _ in f) - 1, 0)
+            runs[label] = {"threads": T, "windows": rows, "wall_seconds": round(dt, 2), "windows_per_sec": round(rows / dt, 5),
+                           "sites_per_sec": round(rows * wind / dt, 1), "returncode": r.returncode}
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    best = max(runs.values(), key=lambda x: x["windows_per_sec"])
+    return {"value": best["windows_per_sec"], "unit": "windows/s", "sites_per_sec": best["sites_per_sec"], "cores": best["threads"],
+            "kind": "reference", "runs": runs,
+            "sample": "the unmodified %s/%s on the first %d windows of the workload (%d sites x %d haplotypes each) as `.geno` text, -T %d and "
+                      "-T 1 (first 2 windows), wall clock around the process (interpreter start, the serial reader and the %s of the "
+                      "reference included), under a %d s timeout" % (ref_dir, tool, W, wind, 2 * n_dip, cores,
+                                                                     "sorter / writer threads" if tool == "popgenWindows.py" else "5 s polling sleeps",
+                                                                     int(budget_s))}
+
+
 def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, max_workers):
     """Three legs of the oracle's restatement of the reference's whole path (text parse -> window -> genoToAlignment -> pair-by-pair
     loop -> statistics), each compared with the GPU statistics of the same sites:
@@ -170,7 +280,8 @@ def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, max_workers):
          B against C is the measured cost of a whole window relative to a slice (every stage of the reference is linear in the
          sites of a window; this shows it instead of asserting it).
     windows/s of the host = A's sites/s / sites per window / (B's seconds per site / C's seconds per site)."""
-    cores = os.cpu_count() or 1
+    cpus = effective_cpus()
+    cores = cpus["logical"]
     phys = cores
     workers = cores
     slice_sites = int(min(CPU_SLICE_SITES, wl["wind"]))
@@ -183,13 +294,27 @@ def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, max_workers):
     except Exception:
         pass
     workers = max(1, min(workers, max_workers, len(lo)))
-    sel = np.linspace(0, len(lo) - 1, workers).astype(int) if workers > 1 else np.array([0])
-    s_lo = lo[sel].copy()
-    s_hi = np.minimum(s_lo + slice_sites, hi[sel])
-    wall, busy, csvs, stats = _cpu_leg(eng, lay, wl, names, scaf_len, s_lo, s_hi, workers)
-    ok = _cpu_matches(wl, csvs, stats)
-    n_slices = len(sel)
-    sites_s = n_slices * slice_sites / wall
+    # Leg A is a sweep over the number of worker processes: the host's best is what counts, and one process per LOGICAL CPU is not
+    # it when the process may only use a few CPUs' worth of time (cgroup quota, affinity) or when SMT siblings share a core.
+    # Every point runs one slice per worker, all at once; value = the best point's sites/s.
+    points = sorted(set(w for w in (cpus["usable"], 8, 16, 32, 64, 128, 256, phys, workers) if 1 <= w <= workers))
+    sweep, ok, stale = [], True, 0
+    for wk in points:
+        sel = np.linspace(0, len(lo) - 1, wk).astype(int) if wk > 1 else np.array([0])
+        s_lo = lo[sel].copy()
+        s_hi = np.minimum(s_lo + slice_sites, hi[sel])
+        wall, busy, csvs, stats = _cpu_leg(eng, lay, wl, names, scaf_len, s_lo, s_hi, wk)
+        ok = ok and _cpu_matches(wl, csvs, stats)
+        sweep.append({"workers": wk, "wall_seconds": round(wall, 2), "busy_seconds": round(busy, 2),
+                      "sites_per_sec": round(len(sel) * slice_sites / wall, 1),
+                      "busy_seconds_per_site_per_worker": busy / float(len(sel) * slice_sites)})
+        rate = sweep[-1]["sites_per_sec"]
+        prev_best = max([x["sites_per_sec"] for x in sweep[:-1]] or [0.0])
+        stale = stale + 1 if rate < 1.1 * prev_best else 0
+        if stale >= 2 or wall > 60:                              # two points in a row without a 10 % gain: more workers only share the same CPUs
+            break
+    best = max(sweep, key=lambda x: x["sites_per_sec"])
+    workers, wall, busy, n_slices, sites_s = best["workers"], best["wall_seconds"], best["busy_seconds"], best["workers"], best["sites_per_sec"]
     # legs B and C: whole windows against their heads, on an otherwise idle host
     n_whole = int(max(1, min(CPU_WHOLE_WINDOWS, phys, max_workers, len(lo))))
     wsel = np.linspace(0, len(lo) - 1, n_whole).astype(int) if n_whole > 1 else np.array([0])
@@ -201,11 +326,14 @@ def cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, max_workers):
     per_site_slice = busy_c / float(n_whole * slice_sites)
     ratio = per_site_whole / per_site_slice
     return {"value": round(sites_s / wl["wind"] / ratio, 5), "unit": "windows/s", "sites_per_sec": round(sites_s / ratio, 1),
-            "cores": workers, "host_cores": cores, "host_cores_physical": phys, "kind": "port",
-            "sample": "A: %d slices of %d sites x %d haplotypes (the heads of %d evenly spaced windows of the workload), each rendered as "
+            "cores": workers, "host_cores": cores, "host_cores_physical": phys, "host_cpus": cpus, "kind": "port",
+            "worker_sweep": sweep,
+            "worker_sweep_note": "busy_seconds = summed wall time of the workers' timed regions: when it grows with the worker count "
+                                 "at constant work per worker, the workers are sharing CPUs (quota / SMT / memory), not computing more",
+            "sample": "A (best point of a sweep over the worker count): %d slices of %d sites x %d haplotypes (the heads of %d evenly spaced windows of the workload), each rendered as "
                       ".geno text and run through the oracle's restatement of the reference's whole path (text parse -> window -> "
                       "genoToAlignment -> pair-by-pair loop -> statistics; popgenWindows.py:28-75, genomics.py:1884-1945, 1101-1127, "
-                      "903-916, 956-995), one slice per worker process, %d worker processes at once (one per hardware thread).  "
+                      "903-916, 956-995), one slice per worker process, %d worker processes at once.  "
                       "B: %d WHOLE windows of %d sites, one per worker, the rest of the host idle; C: the heads of the same windows as "
                       "slices, same workers.  value = A's sites/s / %d sites per window / (B's seconds per site / C's seconds per "
                       "site)" % (n_slices, slice_sites, lay.n_hap, n_slices, workers, n_whole, wl["wind"], wl["wind"]),
@@ -297,56 +425,136 @@ def tier_samples(eng, lay, wl, names, slot_gen, scaf_len, n_sites, t1_block, t0_
                  "sample": "%d page-locked host blocks of %d sites x %d haplotypes (int8, 1 byte per call), uploaded into alternating "
                            "halves of a device buffer while the previous block's windows are computed; PCIe-bound" % (
                                n_blocks, t1_block, lay.n_hap)}
+    del host
     # ---- T2 ----
-    n_txt = int(min(T2_SITES, t1_block * n_blocks, scaf_len) // wind * wind)
-    col_of_slot = np.array([2 * names.index(lay.hap_sample_name[s]) + (s - lay.ind_slots[lay.hap_sample_name[s]][0])
-                            for s in range(lay.n_hap)])
-    codes = np.zeros((n_txt, lay.n_hap), dtype=np.int8)
-    codes[:, col_of_slot] = host[:n_txt, :lay.n_hap]
+    out["t2"] = t2_sample(eng, lay, wl, names, scaf_len, t0_table)
+    return out
+
+
+def write_geno_resident(path, eng, lay, names, n_rows, scaf="chr1", workers=0):
+    """The first n_rows resident rows of the engine as `.geno` text (phased cells `A/C`, one scaffold, positions 1..): rows are
+    fetched from the device in pieces and rendered by a pool of threads, every piece written at its own offset (lines of positions
+    with the same number of digits have the same length, so the offsets follow from the row numbers)."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from genomics_general_amd import synth
+    n = len(names)
+    s0 = np.array([lay.ind_slots[nm][0] for nm in names])          # file column d <- slots s0[d], s0[d] + 1
+    head = (scaf + "\t").encode()
+    hdr = ("#CHROM\tPOS\t" + "\t".join(names) + "\n").encode()
+    tasks, off, a, step = [], len(hdr), 0, 250_000
+    while a < n_rows:
+        nd = len(str(a + 1))
+        b = min(n_rows, a + step, 10 ** nd - 1)
+        tasks.append((a, b, nd, off))
+        off += (b - a) * (len(head) + nd + 1 + 4 * n)
+        a = b
+    lock = threading.Lock()
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    os.pwrite(fd, hdr, 0)
+
+    def render(task):
+        a, b, nd, off = task
+        with lock:                                                  # one copy out of the device at a time (a context is not thread-safe)
+            rows = eng.download(a, b - a)
+        letters = synth.codes_to_letters(rows)
+        line = np.empty((b - a, len(head) + nd + 1 + 4 * n), dtype=np.uint8)
+        line[:, :len(head)] = np.frombuffer(head, dtype=np.uint8)
+        pos = np.arange(a + 1, b + 1, dtype=np.int64)
+        for k in range(nd):
+            line[:, len(head) + nd - 1 - k] = (pos // 10 ** k % 10 + ord("0")).astype(np.uint8)
+        line[:, len(head) + nd] = ord("\t")
+        cell = line[:, len(head) + nd + 1:].reshape(b - a, n, 4)
+        cell[:, :, 0] = letters[:, s0]
+        cell[:, :, 1] = ord("/")
+        cell[:, :, 2] = letters[:, s0 + 1]
+        cell[:, :, 3] = ord("\t")
+        cell[:, -1, 3] = ord("\n")
+        buf, at = memoryview(line).cast("B"), 0
+        while at < len(buf):
+            at += os.pwrite(fd, buf[at:at + (1 << 30)], off + at)
+    try:
+        with ThreadPoolExecutor(workers or min(32, os.cpu_count() or 1)) as ex:
+            list(ex.map(render, tasks))
+    finally:
+        os.close(fd)
+    return off
+
+
+def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
+    """Tier T2 (the only tier whose work is the reference's: `.geno` text in, CSV out): the head of the workload's
+    first scaffold as text on disk (written before the clock starts, so it sits in the page cache like a file a pipeline has just
+    produced) through the drop-in popgenWindows.py in a process of its own, timed inside the driver (PG_TIMING), its rows compared
+    with the T0 statistics of the same windows."""
+    import shutil
+    import subprocess
+    import tempfile
+    wind = wl["wind"]
+    want = int(os.environ.get("PG_BENCH_T2_SITES", T2_SITES))
     tmp = tempfile.mkdtemp(prefix="pg_bench_t2_")
     geno, csv = os.path.join(tmp, "sample.geno"), os.path.join(tmp, "out.csv")
-    from genomics_general_amd import synth
-    synth.write_geno_fast(geno, codes, names, "chr1", 1)
+    line_bytes = 4 * len(names) + 16
+    room = shutil.disk_usage(tmp).free * 0.4
+    try:
+        import psutil
+        room = min(room, psutil.virtual_memory().available * 0.3)       # the file should stay in the page cache
+    except Exception:
+        pass
+    n_txt = int(min(want, scaf_len, room // line_bytes) // wind * wind)
     per = len(names) // lay.n_pops
     cmd = [sys.executable, os.path.join(ROOT, "popgenWindows.py"), "-g", geno, "-o", csv, "-f", "phased", "-w", str(wind),
            "-m", str(wl["min_sites"]), "--roundTo", "12"]
     for k, p in enumerate(lay.sampleData.popNames):
         cmd += ["-p", p, ",".join(names[k * per:(k + 1) * per])]
     try:
+        if n_txt < wind:
+            raise RuntimeError("no room for a T2 sample in %s" % tmp)
+        w0 = time.perf_counter()
+        size = write_geno_resident(geno, eng, lay, names, n_txt)
+        write_s = time.perf_counter() - w0
         # (PG_PLACE_TRIALS=1: the driver reserves its rows once, without the placement probes of a long-lived resident data set)
         r = subprocess.run(cmd, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE,
-                           timeout=600)
+                           timeout=900)
         line = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")]
+        if not line:
+            raise RuntimeError("popgenWindows.py: " + r.stderr.decode()[-300:])
         tm = json.loads(line[-1][len("PG_TIMING "):])
         with open(csv) as f:
             rows = [ln.strip().split(",") for ln in f.readlines()]
         head, rows = rows[0], rows[1:]
-        _, cols = eng.batch(lo[:1], lo[:1] + wind).groupDistTable(True, wl["min_sites"], 0.01)
+        lo1 = np.zeros(1, dtype=np.int64)
+        _, cols = eng.batch(lo1, lo1 + wind).groupDistTable(True, wl["min_sites"], 0.01)
         same = len(rows) == n_txt // wind
         for w, row in enumerate(rows):
             for name, v in zip(head[5:], row[5:]):
                 g = t0_table[w, cols.index(name)]
                 same = same and (abs(float(v) - g) <= 1e-9 * max(1.0, abs(g)) or (g != g and float(v) != float(v)))
         work_s = tm["total_s"] - tm.get("context_s", 0.0)
-        out["t2"] = {"sites_per_sec": round(n_txt / tm["total_s"], 1), "windows_per_sec": round(len(rows) / tm["total_s"], 3),
-                     "text_MBps": round(os.path.getsize(geno) / tm["total_s"] / 1e6, 1), "matches_t0": bool(same),
-                     "without_context_creation": {"seconds": round(work_s, 4), "sites_per_sec": round(n_txt / work_s, 1),
-                                                  "text_GBps": round(os.path.getsize(geno) / work_s / 1e9, 2)},
-                     "tokenizer_text_GBps": round(os.path.getsize(geno) / max(tm.get("tokenize_s", 0.0), 1e-9) / 1e9, 2),
-                     "tokenizer": "device (pg_tokenize_text)" if tm.get("device_tokenizer") else "host threads (pg_encode_text)",
-                     "seconds": {k: round(tm[k], 4) for k in ("total_s", "context_s", "read_s", "tokenize_s", "windows_s", "prep_wait_s",
-                                                               "engine_and_upload_s", "compute_and_write_s") if k in tm},
-                     "sample": "the first %d sites of the workload as %.0f MB of `.geno` text (%d windows) through popgenWindows.py, "
-                               "timed inside the driver (total_s: context creation included, interpreter start excluded; the file is written before the clock starts)" % (
-                                   n_txt, os.path.getsize(geno) / 1e6, len(rows))}
+        stages = tm.get("tokenize_s", 0.0) + tm.get("windows_s", 0.0) + tm.get("compute_and_write_s", 0.0)
+        t2 = {"sites_per_sec": round(n_txt / tm["total_s"], 1), "windows_per_sec": round(len(rows) / tm["total_s"], 3),
+              "text_GBps": round(size / tm["total_s"] / 1e9, 2), "sites": n_txt, "windows": len(rows), "text_bytes": size,
+              "matches_t0": bool(same),
+              "without_context_creation": {"seconds": round(work_s, 4), "sites_per_sec": round(n_txt / work_s, 1),
+                                           "windows_per_sec": round(len(rows) / work_s, 3), "text_GBps": round(size / work_s / 1e9, 2)},
+              "tokenizer_text_GBps": round(size / max(tm.get("tokenize_s", 0.0), 1e-9) / 1e9, 2),
+              "tokenizer_h2d_GBps": round(size / max(tm.get("tokenizer_h2d_s", 0.0), 1e-9) / 1e9, 2) if tm.get("tokenizer_h2d_s") else None,
+              "tokenizer": "device (pg_tokenize_file)" if tm.get("device_tokenizer") else "host threads (pg_encode_text)",
+              "stages_overlap": bool(stages > work_s * 1.02),
+              "seconds": {k: round(tm[k], 4) for k in ("total_s", "context_s", "context_create_s", "read_s", "tokenize_s", "tokenizer_h2d_s",
+                                                        "tokenizer_kernels_s", "windows_s", "prep_wait_s", "engine_and_upload_s",
+                                                        "compute_and_write_s") if k in tm},
+              "seconds_note": "tokenize_s / windows_s: the ingestion thread; compute_and_write_s: the driver's main thread (kernels, "
+                              "statistics, CSV); prep_wait_s: what the main thread waited for the ingestion thread; they run beside each "
+                              "other, so their sum exceeds total_s - context_s when the stages overlap",
+              "sample": "the first %d sites of the workload as %.1f GB of `.geno` text (%d windows; written in %.1f s before the clock starts) "
+                        "through popgenWindows.py, timed inside the driver (total_s: from opening the input to the last row; the device "
+                        "context is created beside the opening of the input, context_s is what was still waited for)" % (
+                            n_txt, size / 1e9, len(rows), write_s)}
     except Exception as exc:                                    # the tiers are side information: never lose the main line
-        out["t2"] = {"error": repr(exc)[:300]}
+        t2 = {"error": repr(exc)[:300]}
     finally:
-        for pth in (geno, csv):
-            if os.path.exists(pth):
-                os.remove(pth)
-        os.rmdir(tmp)
-    return out
+        shutil.rmtree(tmp, ignore_errors=True)
+    return t2
 
 
 def spawn_ranks(n):
@@ -388,7 +596,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tiers", action="store_true", help="skip the T1 (host blocks -> H2D -> kernels) and T2 (text -> CSV) samples")
     ap.add_argument("--cpu-workers", type=int, default=1 << 30, help="upper bound of the CPU baseline's worker processes")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="no GPU: time the UNMODIFIED reference (BASELINE.json reference_path, where it exists) on a W-window prefix of the "
+                         "workload with -T <usable CPUs> and -T 1 and print {\"cpu_baseline\": ...}")
     args = ap.parse_args()
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        ref_dir = json.load(f).get("reference_path") or ""
+    if args.cpu_baseline_only:
+        wl = dict(WORKLOADS[args.workload])
+        assert os.path.isdir(ref_dir), "the reference (%s) is not on this machine: the default run times the oracle's port instead" % ref_dir
+        assert wl["tool"] in ("popgen", "abba"), "reference baseline: popgenWindows / ABBABABAwindows workloads"
+        cpus = effective_cpus()
+        names = ["s%d" % d for d in range(wl["n_dip"])]
+        cpu = cpu_baseline_reference(wl, names, wl["n_pops"], ref_dir, cpus["usable"])
+        cpu["host_cpus"] = cpus
+        print(json.dumps({"cpu_baseline": cpu, "config": {"workload": wl["desc"], "name": args.workload}}))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))                  # a bare `python bench.py --gpus N`: this process becomes the launcher
     wl = dict(WORKLOADS[args.workload])
@@ -658,6 +881,15 @@ def main():
             cpu = cpu_baseline_distmat(eng, lay, wl, lo, hi)
         else:
             cpu = cpu_baseline_full_path(eng, lay, wl, names, lo, hi, scaf_len, args.cpu_workers)
+            if os.path.isdir(ref_dir) and wl["tool"] in ("popgen", "abba"):
+                # the reference itself is on this machine: it is the baseline, the port's legs stay beside it
+                port = cpu
+                try:
+                    cpu = cpu_baseline_reference(wl, names, n_pops, ref_dir, port["host_cpus"]["usable"])
+                    cpu["host_cpus"], cpu["port"] = port["host_cpus"], port
+                except Exception as exc:
+                    port["reference_error"] = repr(exc)[:300]
+                    cpu = port
 
     if tiers:
         try:
@@ -690,6 +922,13 @@ def main():
                                  "sites_per_sec": round(d5["sites_per_step"] * world.size / dt5, 1)}
         except Exception as exc:                                # side information: never lose the main line
             extra["c5_share"] = {"error": repr(exc)[:300]}
+    t2 = extra.get("t2") or {}
+    if cpu and "windows_per_sec" in t2 and cpu.get("unit") == "windows/s" and cpu.get("value"):
+        # like for like: both read `.geno` text and write the CSV (T0's `value` has its inputs resident in HBM and is NOT comparable)
+        extra["t2_vs_cpu"] = {"ratio": round(t2["windows_per_sec"] / cpu["value"], 1),
+                              "ratio_without_context_creation": round(t2["without_context_creation"]["windows_per_sec"] / cpu["value"], 1),
+                              "gpu_windows_per_sec": t2["windows_per_sec"], "cpu_windows_per_sec": cpu["value"], "cpu_kind": cpu.get("kind"),
+                              "note": "tier T2 (text in, CSV out, one GPU + its host threads) against the CPU baseline's whole path on every host core"}
     if world.rank == 0:
         total_windows = total_win * args.steps
         total_sites = total_sites_step * args.steps

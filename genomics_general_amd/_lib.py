@@ -55,6 +55,14 @@ SIGNATURES = {
     "pg_upload_wait": (C.c_int, [_P]),
     "pg_tokenize_text": (C.c_int, [_P, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int64, _i32p, C.c_int64,
                                    _i64p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "pg_tokenize_file": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int64, _i32p, C.c_int64,
+                                   _i64p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "pg_tokenize_submit": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p,
+                                     C.POINTER(C.c_int)]),
+    "pg_tokenize_parse": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "pg_tokenize_collect": (C.c_int, [_P, C.c_int, _i32p, C.c_int64, _i64p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "pg_tokenize_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pg_move_rows": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64]),
     "pg_synth_fill": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32,
                                 _i32p, C.c_int32, C.c_int32]),
@@ -62,6 +70,7 @@ SIGNATURES = {
                                  _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_scaffold_runs": (C.c_int, [C.c_void_p, _i64p, _i32p, C.c_int64, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
     "pg_count_lines": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
+    "pg_usable_cpus": (C.c_int, []),
     "pg_text_runs": (C.c_int, [C.c_void_p, C.c_size_t, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
     "pg_text_seek_pos": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -143,3 +152,8 @@ def device_count():
         return 0
     check(rc)
     return n.value
+
+
+def usable_cpus():
+    """CPUs this process may really use (affinity mask and cgroup quota applied): what thread pools are sized from"""
+    return int(lib().pg_usable_cpus())

@@ -163,10 +163,24 @@ class Run:
         self.world = dist.world_from_env()
         if self.world.size > 1 and not os.environ.get("PG_HOST_THREADS"):
             # N ranks on one node: the native helpers (line count, tokenizers, staging copies of the device tokenizer) share the cores
-            os.environ["PG_HOST_THREADS"] = str(max(1, (os.cpu_count() or 1) // self.world.size))
+            os.environ["PG_HOST_THREADS"] = str(max(1, _lib.usable_cpus() // self.world.size))
         self._t_start = time.perf_counter()
         self.timing = {"read_s": 0.0, "text_bytes": 0, "tokenize_s": 0.0, "windows_s": 0.0, "sites": 0, "windows": 0,
                        "engine_and_upload_s": 0.0, "upload_s": 0.0, "prep_wait_s": 0.0, "chunks": 0}   # printed as JSON on stderr when PG_TIMING=1
+        # the device context (HIP runtime start-up, streams: 0.1 - 0.2 s) is created by a helper thread while this one opens the input,
+        # reads the header and sets up samples and windows
+        import threading
+        made = {}
+
+        def make_engine():
+            try:
+                t_e = time.perf_counter()
+                made["engine"] = Engine(args.device if args.device is not None else dist.device_for(self.world))
+                made["seconds"] = time.perf_counter() - t_e
+            except BaseException as exc:
+                made["error"] = exc
+        engine_thread = threading.Thread(target=make_engine)
+        engine_thread.start()
         t0 = time.perf_counter()
         self._reader = genoio.open_input(args.genoFile)
         if header_line:
@@ -180,7 +194,7 @@ class Run:
         self._streamer = None
         self._block_bytes = None
         # every rank of a multi-GPU run tokenises the input itself: share the host cores instead of oversubscribing them
-        self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size) if self.world.size > 1 else 0
+        self._tok_threads = max(1, _lib.usable_cpus() // self.world.size) if self.world.size > 1 else 0
         if stream and windows_fn is None and wparams["windType"] in ("coordinate", "sites", "predefined"):
             inc = _lines(args.include) if args.include else None
             exc = _lines(args.exclude) if args.exclude else None
@@ -193,11 +207,14 @@ class Run:
                                                            minSites, inc, exc)
             self._block_bytes = int(os.environ.get("PG_STREAM_BYTES", 1 << 30))
         t0 = time.perf_counter()
-        dev = args.device if args.device is not None else dist.device_for(self.world)
-        self.engine = Engine(dev)
+        engine_thread.join()
+        if "error" in made:
+            raise made["error"]
+        self.engine = made["engine"]
         self.engine.set_layout(self.layout)
         self.comm = dist.make_comm(self.engine, self.world)
-        self.timing["context_s"] = time.perf_counter() - t0          # device context, streams, communicator (part of engine_and_upload_s)
+        self.timing["context_s"] = time.perf_counter() - t0          # what this thread still waited for the device context + the communicator (part of engine_and_upload_s)
+        self.timing["context_create_s"] = made["seconds"]            # what the context took on its thread
         self.timing["engine_and_upload_s"] += time.perf_counter() - t0
         self.n_tested = 0
         # Multi-GPU ingestion.  Sharded (a driver that writes its rows through open_sink(), coordinate or sites windows, plain
@@ -227,7 +244,7 @@ class Run:
                 self.sharded = self._reader.shard(self.world, self.comm, wanted)
             if self.sharded:
                 self._wshare = (1, 0)
-                self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size)
+                self._tok_threads = max(1, _lib.usable_cpus() // self.world.size)
         # predefined windows: shardable when the file's scaffold runs agree with the window list (windows.plan_predefined_shards);
         # every rank scans its equal share of the bytes for run starts (pg_text_runs), one gather makes the run list of the file
         self.shift_ids = True
@@ -250,7 +267,7 @@ class Run:
                     self._reader.restrict(a, b)
                     self._streamer = windows.PredefinedWindowStream([coords[k] for k in idx], scaf_order=[w[0] for w in coords], tail=tail)
                     self.sharded, self._wshare, self.shift_ids = True, (1, 0), False
-                    self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size)
+                    self._tok_threads = max(1, _lib.usable_cpus() // self.world.size)
         # `cat` (one window = every site of the input): sites are independent and pair counts add, so every rank takes a share of
         # the LINES, counts its share, and the counts are summed across the ranks before the means are formed (distmat_main)
         self.cat_sharded = False
@@ -259,7 +276,7 @@ class Run:
             self.cat_sharded = bool(self._reader.shard_lines(self.world))
             if self.cat_sharded:
                 self._wshare = (1, 0)
-                self._tok_threads = max(1, (os.cpu_count() or 1) // self.world.size)
+                self._tok_threads = max(1, _lib.usable_cpus() // self.world.size)
         if not stream:
             for _ in self.chunks():
                 break
@@ -441,22 +458,29 @@ class Run:
         return device_tokenizer_takes(self.layout)
 
     def _chunks_device(self):
-        """chunks() with the tokenizer on the device: the reader thread hands over block k+1 (memory-mapped text, or gunzipped
-        bytes) while this thread has block k copied down, tokenised straight into the resident rows behind the rows carried over
-        from block k-1 (pg_move_rows, pg_tokenize_text), finds the windows that are certain and computes them.  The host keeps
-        positions and scaffold runs only; no row ever exists in host memory."""
+        """chunks() with the tokenizer on the device, three stages beside each other:
+          reader thread     hands over block k+2 (a view of the memory-mapped text, or gunzipped bytes);
+          ingestion thread  has block k+1 copied down and tokenised (pg_tokenize_file / pg_tokenize_text on the copy streams) into ONE
+                            HALF of the resident rows, behind the rows carried over from block k (pg_move_rows), and finds the
+                            windows that are certain by then (windows.*Stream.feed);
+          this thread       computes the windows of block k, whose rows sit in the OTHER half, and writes their rows.
+        The host keeps positions and scaffold runs only; no row ever exists in host memory.  The number of rows a block needs is
+        bounded from its first line (every line of the regular layout is at least that long), the device counts the lines itself.
+        The halves grow at quiet points (when this thread has finished everything handed over so far)."""
         import queue
         import threading
         import time
         eng = self.engine
         L = _lib.lib()
         blocks = queue.Queue(maxsize=1)
+        ready = queue.Queue(maxsize=2)
+        halves = threading.Semaphore(2)           # a half is taken when a block is tokenised into it, given back when its windows are done
         stop = threading.Event()
 
-        def put(item):
+        def put(q, item):
             while not stop.is_set():
                 try:
-                    blocks.put(item, timeout=0.2)
+                    q.put(item, timeout=0.2)
                     return True
                 except queue.Full:
                     pass
@@ -466,81 +490,172 @@ class Run:
             try:
                 while True:
                     b = self._reader.read_block(self._block_bytes)
-                    if not put(b) or self._block_bytes is None or len(b) == 0:
+                    if not put(blocks, b) or self._block_bytes is None or len(b) == 0:
                         return
             except BaseException as exc:
-                put(exc)
+                put(blocks, exc)
 
-        threading.Thread(target=produce, daemon=True).start()
-        carry, carry_row0, cap = None, 0, 0
-        self.timing["device_tokenizer"] = 1
-        self.timing["host_tokenized_blocks"] = 0
-        try:
-            while True:
-                t0 = time.perf_counter()
+        def row_bound(body):
+            """at most this many data lines: a line of the regular layout is its cells + a scaffold, a position and two blanks (>= 4
+            bytes); None when the first line does not look like one"""
+            head = bytes(body[:1 << 16])
+            nl = head.find(b"\n")
+            f = head[:nl if nl >= 0 else len(head)].split(None, 2)
+            if nl < 0 or len(f) < 3 or head.startswith(b"#"):
+                return None
+            return len(body) // (len(f[2]) + 1 + 4) + 1
+
+        def count(body):
+            ptr, nbytes, _keep = _lib.text_ptr(body)
+            cnt = C.c_int64(0)
+            if nbytes:
+                _lib.check(L.pg_count_lines(ptr, nbytes, C.byref(cnt)))
+            return int(cnt.value)
+
+        st = {"half": 0}
+
+        def grow(rows, carry_row0, c_n):
+            """both halves to `rows` rows; the carried rows travel through the host once.  Only at a quiet point: this drops the rows
+            the compute thread may be working on"""
+            ready.join()
+            saved = eng.download(carry_row0, c_n) if c_n else None
+            st["half"] = rows + rows // 4 + 1024
+            eng.reserve(2 * st["half"])
+            return saved
+
+        mapped = getattr(self._reader, "mm", None) is not None       # a block of a memory-mapped file is a view: nothing to read ahead
+        done_reading = []
+
+        def fetch():
+            t0 = time.perf_counter()
+            if mapped:
+                body = b"" if done_reading else self._reader.read_block(self._block_bytes)
+                if self._block_bytes is None or len(body) == 0:
+                    done_reading.append(True)
+            else:
                 body = blocks.get()
                 if isinstance(body, BaseException):
                     raise body
-                final = self._streamer is None or len(body) == 0
-                self.timing["read_s"] += time.perf_counter() - t0
-                t0 = time.perf_counter()
-                ptr, nbytes, _keep = _lib.text_ptr(body)
-                cnt = C.c_int64(0)
-                if nbytes:
-                    _lib.check(L.pg_count_lines(ptr, nbytes, C.byref(cnt)))
-                n_new, c_n = int(cnt.value), (carry.n_sites if carry is not None else 0)
-                if c_n + n_new > cap:                         # grow: the carried rows travel through the host once
-                    saved = eng.download(carry_row0, c_n) if c_n else None
-                    cap = c_n + n_new + (c_n + n_new) // 4 + 1024
-                    eng.reserve(cap)
+            return body, time.perf_counter() - t0
+
+        def submit(body, slot):
+            """the block's text on its way to the device (slot 0 / 1); False: the fast path does not take it"""
+            if not len(body) or not hasattr(eng, "tokenize_submit"):
+                return False
+            return eng.tokenize_submit(body, slot, file=self._reader.file_range(body) if hasattr(self._reader, "file_range") else None)
+
+        def ingest():
+            carry, carry_row0, k = None, 0, 0
+            try:
+                body, read_s = fetch()
+                sub = submit(body, 0)
+                while True:
+                    final = self._streamer is None or len(body) == 0
+                    tm = {"read_s": read_s, "host_tokenized": 0}
+                    t0 = time.perf_counter()
+                    while not halves.acquire(timeout=0.2):    # block k goes where block k-2 was: that one must be done
+                        if stop.is_set():
+                            return
+                    tm["half_wait_s"] = time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    c_n = carry.n_sites if carry is not None else 0
+                    bound = row_bound(body) if len(body) else 0
+                    if bound is None:
+                        bound, sub = count(body), False       # (not a regular first line: the host tokenizer will take the block)
+                    saved = None
+                    if c_n + bound > st["half"]:
+                        saved = grow(c_n + bound, carry_row0, c_n)
+                    base = (k % 2) * st["half"]
                     if saved is not None:
-                        eng.upload(saved, 0)
-                elif c_n and carry_row0:
-                    eng.move_rows(carry_row0, 0, c_n)
-                got = eng.tokenize_text(body, row_offset=c_n, n_rows=n_new) if n_new else None
-                if got is not None:
-                    n, pos, starts, names = got
-                    block = genoio.GenoData(None, pos, starts, names)
-                else:                                         # a block the fast path refuses (or an empty one): host tokenizer
-                    block = self._reader.to_geno(body, self.layout, n_threads=self._tok_threads)
-                    if block.n_sites:
-                        self.timing["host_tokenized_blocks"] += 1
-                        if c_n + block.n_sites > cap:         # (lines the counter does not see as data lines cannot add rows)
-                            raise RuntimeError("tokenizer row count exceeds the line count of the block")
-                        eng.upload(np.ascontiguousarray(block.gt[:, :self.layout.n_hap]), c_n)
-                    block = genoio.GenoData(None, block.pos, block.run_starts, block.run_names)
-                del body, _keep
-                data = genoio.concat_meta(carry, block)
-                self.timing["tokenize_s"] += time.perf_counter() - t0
+                        eng.upload(saved, base)
+                    elif c_n:
+                        eng.move_rows(carry_row0, base, c_n)
+                    # parse(k) is queued, then the text of block k+1 crosses PCIe while those kernels run, then the results of k
+                    n_lines = eng.tokenize_parse(k % 2, base + c_n, bound) if sub else None
+                    nxt, nxt_sub, read_s = None, False, 0.0
+                    if not final:
+                        nxt, read_s = fetch()
+                        nxt_sub = submit(nxt, (k + 1) % 2)
+                    got = eng.tokenize_collect(k % 2, body, n_lines) if n_lines is not None else None
+                    if got is not None:
+                        n, pos, starts, names = got
+                        block = genoio.GenoData(None, pos, starts, names)
+                    else:                                     # a block the fast path refuses (or an empty one): host tokenizer
+                        block = self._reader.to_geno(body, self.layout, n_threads=self._tok_threads)
+                        if block.n_sites:
+                            tm["host_tokenized"] = 1
+                            if c_n + block.n_sites > st["half"]:          # (the bound holds for regular lines only)
+                                saved = grow(c_n + block.n_sites, base, c_n)
+                                base = (k % 2) * st["half"]
+                                if saved is not None:
+                                    eng.upload(saved, base)
+                            eng.upload(np.ascontiguousarray(block.gt[:, :self.layout.n_hap]), base + c_n)
+                        block = genoio.GenoData(None, block.pos, block.run_starts, block.run_names)
+                    del body
+                    data = genoio.concat_meta(carry, block)
+                    if data is None:
+                        data = genoio.GenoData(None, np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int64), [])
+                    tm["tokenize_s"] = time.perf_counter() - t0 - read_s
+                    t0 = time.perf_counter()
+                    if self._streamer is not None:
+                        T, keep_from = self._streamer.feed(data.run_starts, data.run_names, data.pos, final)
+                    else:
+                        T = (self._windows_fn(data) if self._windows_fn
+                             else _make_windows(self._wparams, data, self._minSites, self._coords_keep))
+                        T.dup = np.zeros(T.n, dtype=bool)
+                        keep_from = data.n_sites
+                    tm["windows_s"] = time.perf_counter() - t0
+                    carry = None if final else genoio.tail_meta(data, keep_from)
+                    carry_row0 = base + keep_from
+                    if not put(ready, (data, T, base, final, int(block.n_sites), tm)) or final:
+                        return
+                    body, sub = nxt, nxt_sub
+                    k += 1
+            except BaseException as exc:
+                put(ready, exc)
+
+        if not mapped:
+            threading.Thread(target=produce, daemon=True).start()
+        threading.Thread(target=ingest, daemon=True).start()
+        self.timing["device_tokenizer"] = 1
+        self.timing["host_tokenized_blocks"] = 0
+        import sys
+        switch = sys.getswitchinterval()
+        sys.setswitchinterval(0.0005)             # the ingestion thread needs the interpreter for microseconds between two native calls:
+        try:                                      # it should not wait 5 ms for it while this thread formats rows
+            while True:
                 t0 = time.perf_counter()
-                if self._streamer is not None:
-                    T, keep_from = self._streamer.feed(data.run_starts, data.run_names, data.pos, final)
-                else:
-                    T = (self._windows_fn(data) if self._windows_fn
-                         else _make_windows(self._wparams, data, self._minSites, self._coords_keep))
-                    T.dup = np.zeros(T.n, dtype=bool)
-                    keep_from = data.n_sites
-                self.timing["windows_s"] += time.perf_counter() - t0
-                carry = None if final else genoio.tail_meta(data, keep_from)
-                carry_row0 = keep_from
+                item = ready.get()
+                if isinstance(item, BaseException):
+                    raise item
+                self.timing["prep_wait_s"] += time.perf_counter() - t0      # time this thread waited for the ingestion thread
+                data, T, base, final, n_new, tm = item
+                for key in ("read_s", "tokenize_s", "windows_s"):
+                    self.timing[key] += tm[key]
+                self.timing["host_tokenized_blocks"] += tm["host_tokenized"]
                 w0, w1 = dist.shard_range(T.n, self._wshare[0], self._wshare[1])
-                lo, hi = T.lo[w0:w1].copy(), T.hi[w0:w1].copy()
-                nz = hi > lo
+                lo, hi = T.lo[w0:w1] + base, T.hi[w0:w1] + base
+                nz = T.hi[w0:w1] > T.lo[w0:w1]
                 lo[~nz] = 0
                 hi[~nz] = 0
                 self.timing["text_bytes"] = self._reader.bytes_read
                 self.data, self.T, self.w0, self.w1 = data, T, w0, w1
                 self.lo, self.hi, self.site0 = lo, hi, 0
-                self.timing["sites"] += int(block.n_sites)
+                self.timing["sites"] += n_new
                 self.timing["windows"] += int(T.n)
                 self.timing["chunks"] += 1
                 self.n_tested += int(T.n)
-                if T.n:
-                    yield self
+                try:
+                    if T.n:
+                        yield self
+                finally:
+                    ready.task_done()                         # the rows of this block are no longer needed: its half may be rewritten
+                    halves.release()
                 if final:
                     break
         finally:
             stop.set()
+            sys.setswitchinterval(switch)
         self._reader.close()
 
     def report_timing(self):
@@ -556,10 +671,11 @@ class Run:
             t["total_s"] = time.perf_counter() - self._t_start
             # read / tokenize / windows run in their own threads: what this thread spent is the wait for them, the uploads it
             # waited for, and the statistics + output
-            if t.get("device_tokenizer"):                 # everything on this thread: reading aside, the phases add up
-                t["compute_and_write_s"] = t["total_s"] - t["engine_and_upload_s"] - t["tokenize_s"] - t["windows_s"] - t["read_s"]
-            else:
-                t["compute_and_write_s"] = t["total_s"] - t["prep_wait_s"] - t["engine_and_upload_s"]
+            t["compute_and_write_s"] = t["total_s"] - t["prep_wait_s"] - t["engine_and_upload_s"]
+            if t.get("device_tokenizer") and hasattr(self.engine, "tokenize_stats"):
+                ts = self.engine.tokenize_stats()            # inside tokenize_s: the copies of the text (PCIe) and the kernels behind them
+                t["tokenizer_h2d_s"], t["tokenizer_kernels_s"], t["tokenizer_bytes"] = ts["h2d_s"], ts["kernels_s"], ts["bytes"]
+            # (the stages overlap when tokenize_s + windows_s + compute_and_write_s > total_s - context_s)
             sys.stderr.write("PG_TIMING " + json.dumps(t) + "\n")
 
     def finish(self):
@@ -1107,7 +1223,7 @@ def freq_main(argv=None):
     # rank 0 in rank order = input order.  Inputs that cannot be cut (gzip, stdin, .pgeno): rank 0 does the job.
     world = dist.world_from_env()
     if world.size > 1 and not os.environ.get("PG_HOST_THREADS"):
-        os.environ["PG_HOST_THREADS"] = str(max(1, (os.cpu_count() or 1) // world.size))
+        os.environ["PG_HOST_THREADS"] = str(max(1, _lib.usable_cpus() // world.size))
     eng = Engine(args.device if args.device is not None else dist.device_for(world))
     eng.set_layout(layout)
     comm = dist.make_comm(eng, world)

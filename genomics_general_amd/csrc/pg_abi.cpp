@@ -2,6 +2,8 @@
 // See include/popgen_hip.h for the contract of every entry point.
 #include "pg_ctx.h"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
@@ -20,13 +22,52 @@ int pg_fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// CPUs this process may really use: the logical CPUs, cut by the scheduler's affinity mask and by the cgroup's CPU quota (cpu.max
+// of cgroup v2, cfs_quota_us / cfs_period_us of v1).  A container on a 256-thread host is often given a few CPUs' worth of time:
+// 256 busy threads then share that time, and the CFS bandwidth controller stops ALL of them for the rest of every 100 ms period
+// once the quota is used up (measured on the GPU box of round 4: cpu.max = 16 CPUs; 16 staging threads + the Python threads ran
+// the text copies at 41 GB/s, 4 threads at 56).
+static int usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int a = CPU_COUNT(&set);
+        if (a > 0 && a < n) n = a;
+    }
+    double quota = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[32] = {0};
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) quota = atof(a) / (double)period;
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        long long q = -1, period = 0;
+        if (fscanf(g, "%lld", &q) != 1) q = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(h, "%lld", &period) != 1) period = 0;
+            fclose(h);
+        }
+        if (q > 0 && period > 0) quota = (double)q / (double)period;
+    }
+    if (quota >= 1.0 && quota < n) n = (int)(quota + 0.5);
+    return n < 1 ? 1 : n;
+}
+
 int pg_host_threads() {
-    int nt = (int)std::thread::hardware_concurrency();
+    static const int usable = usable_cpus();
+    int nt = usable;
     if (const char *e = getenv("PG_HOST_THREADS")) {
         const int v = atoi(e);
         if (v > 0) nt = v;
     }
     return nt < 1 ? 1 : nt;
+}
+
+extern "C" int pg_usable_cpus(void) {
+    static const int usable = usable_cpus();
+    return usable;
 }
 
 extern "C" const char *pg_last_error(void) { return g_err; }
@@ -115,19 +156,20 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream_up);
     if (c->up_ev) (void)hipEventDestroy(c->up_ev);
-    for (int k = 0; k < 2; ++k)
-        if (c->tok_ev[k]) (void)hipEventDestroy(c->tok_ev[k]);
+    for (int t = 0; t < PG_TOK_WORKERS; ++t) {
+        if (c->tok_st[t]) (void)hipStreamDestroy(c->tok_st[t]);
+        for (int k = 0; k < 2; ++k)
+            if (c->tok_wev[t][k]) (void)hipEventDestroy(c->tok_wev[t][k]);
+    }
     c->cells_stage.release();
     c->slot_src.release();
-    c->tok_text.release();
-    c->tok_i32.release();
-    c->tok_cols.release();
-    c->tok_pos.release();
-    c->tok_i64.release();
-    c->tok_nl.release();
-    c->tok_off.release();
-    c->tok_pin[0].release();
-    c->tok_pin[1].release();
+    for (int k = 0; k < 2; ++k) {
+        pg_ctx::TokSlot &T = c->tok[k];
+        T.text.release(); T.i32.release(); T.dcols.release(); T.pos.release(); T.i64.release(); T.nl.release(); T.off.release();
+        T.h_total.release(); T.h_pos.release(); T.h_cols.release();
+        if (T.counted) (void)hipEventDestroy(T.counted);
+    }
+    c->tok_pin.release();
     drop_events(c);
     c->gt.release();
     c->hap_pop.release();
@@ -331,17 +373,20 @@ extern "C" int pg_move_rows(pg_ctx *c, int64_t src_row, int64_t dst_row, int64_t
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = (size_t)n * c->S;
     const bool overlap = src_row < dst_row + n && dst_row < src_row + n;
+    // (on the copy stream: the ingestion thread moves the rows it carries into the half of the resident buffer the next block is
+    // tokenised into while the compute stream works on the windows of the current block in the other half)
+    hipStream_t st = c->stream_up;
     if (!overlap) {
-        HIPCHK(hipMemcpyAsync(c->gt.p + dst_row * c->S, c->gt.p + src_row * c->S, bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->gt.p + dst_row * c->S, c->gt.p + src_row * c->S, bytes, hipMemcpyDeviceToDevice, st));
     } else {                                                       // through the (idle) staging buffer of the packed uploads
         if (bytes > c->cells_stage.cap) {
             int rc = c->cells_stage.alloc(bytes);
             if (rc != PG_OK) return rc;
         }
-        HIPCHK(hipMemcpyAsync(c->cells_stage.p, c->gt.p + src_row * c->S, bytes, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->gt.p + dst_row * c->S, c->cells_stage.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->cells_stage.p, c->gt.p + src_row * c->S, bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->gt.p + dst_row * c->S, c->cells_stage.p, bytes, hipMemcpyDeviceToDevice, st));
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(st));
     return PG_OK;
 }
 

@@ -7,6 +7,8 @@
 #include <vector>
 
 #define PG_MAX_HAP 32768
+#define PG_TOK_WORKERS 8       // staging threads of the device tokenizer at most (four already fill PCIe: 56 GB/s of text on the round-4 box)
+#define PG_TOK_STREAMS 4       // copy streams they share (8 streams: 55.6 GB/s, 33 ms to create; 4: 54.8, 20 ms; 2: 50; 1: 36-45)
 
 int pg_fail(int code, const char *fmt, ...);
 // host threads the library may start for one call: every hardware thread, or PG_HOST_THREADS (the drivers set it to cores / ranks
@@ -102,12 +104,24 @@ struct pg_ctx {
     hipEvent_t up_ev = nullptr;
     bool up_pending = false;
     DevBuf<uint8_t> cells_stage;     // packed cells of the upload in flight
-    // device-side tokenizer (pg_tokenize_text): the block's text, line feeds, per-line outputs
-    DevBuf<uint8_t> tok_text;
-    DevBuf<int32_t> tok_i32, tok_cols, tok_pos;
-    DevBuf<int64_t> tok_i64, tok_nl, tok_off;
-    HostPin<uint8_t> tok_pin[2];
-    hipEvent_t tok_ev[2] = {nullptr, nullptr};
+    // device-side tokenizer (pg_tokenize_*): two blocks in flight, each with its text, line feeds, per-line outputs
+    struct TokSlot {
+        DevBuf<uint8_t> text;
+        DevBuf<int32_t> i32, dcols, pos;
+        DevBuf<int64_t> i64, nl, off;
+        HostPin<int64_t> h_total;          // page-locked landing: [0] lines, [1] status | runs
+        HostPin<int32_t> h_pos, h_cols;
+        std::vector<int32_t> cols;         // col_slot | col_ploidy | cell offsets | cell widths of the submitted block
+        hipEvent_t counted = nullptr;
+        int state = 0;                     // 0 idle, 1 empty block, 2 submitted, 3 parse queued, 4 empty result
+        int fmt = 0, n_cols = 0, max_ploidy = 0, cells_w = 0;
+        int64_t len = 0, n_lines = 0, n_tiles = 0, run_cap = 0;
+    } tok[2];
+    HostPin<uint8_t> tok_pin;                              // two 4 MiB page-locked buffers per staging thread
+    hipStream_t tok_st[PG_TOK_WORKERS] = {};               // one copy stream per staging thread
+    hipEvent_t tok_wev[PG_TOK_WORKERS][2] = {};
+    double tok_stage_s = 0, tok_kernel_s = 0;              // pg_tokenize_stats: wall seconds of the copies / of everything behind them
+    int64_t tok_bytes = 0;
     DevBuf<int32_t> slot_src;        // pg_upload_packed_async: slot -> 2 * cell column + allele
     struct Slot {
         DevBuf<uint32_t> Vp, XV, pres;

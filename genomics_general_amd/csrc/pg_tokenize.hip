@@ -12,9 +12,13 @@
 #include "pg_ctx.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 namespace {
 
@@ -255,22 +259,49 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
 
 }  // namespace
 
-// Tokenise `len` bytes of complete `.geno` data lines (no header) into resident rows row_offset .. on the context's copy stream.
-// The text travels to the device in pieces through two page-locked staging buffers (host threads copy piece k+1 while piece k is
-// in flight).  Returns through *ok_out whether the regular-layout fast path applied; if not, nothing may be assumed about the
-// rows and the caller tokenises the block on the host.
-extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fmt, int n_cols, int max_ploidy,
-                                const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out,
-                                int64_t row_capacity, int64_t *run_row_out, int64_t *run_off_out, int32_t *run_len_out,
-                                int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out) {
-    if (!c || (!text && len) || !col_slot || !col_ploidy || !n_rows_out || !n_runs_out || !ok_out)
-        return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null argument");
+// ---- host side: three steps per block, two blocks in flight ------------------------------------------------------------------
+//   submit   the block's text goes to the device (self-paced staging threads, their own copy streams) into text slot 0 or 1; the
+//            line feeds are counted behind the copies (k_nl_count / k_nl_scan, the total on its way back)
+//   parse    (needs the number of lines: waits for that one number) positions of the line feeds, rows cleared, k_tok_parse --
+//            all queued on the context's copy stream, nothing waited for
+//   collect  waits for the parse, hands back positions and scaffold runs
+// The ingestion thread of the drivers runs   parse(k) -> submit(k+1) -> collect(k):   the kernels of block k work while the text
+// of block k+1 crosses PCIe.  pg_tokenize_text / pg_tokenize_file are the three steps in a row on slot 0.
+
+// where the block's text is: memory (bytes, a gunzipped buffer, a memory-mapped file) or a file descriptor + offset (plain text on
+// disk: the staging threads pread() straight from the page cache into their page-locked buffers -- no page faults of a mapping,
+// no second pass over the text)
+struct TokSource {
+    const char *text;
+    int fd;
+    int64_t off;
+    bool read(int64_t at, void *dst, size_t n) const {
+        if (text) {
+            memcpy(dst, text + at, n);
+            return true;
+        }
+        size_t got = 0;
+        while (got < n) {
+            const ssize_t r = pread(fd, static_cast<char *>(dst) + got, n - got, (off_t)(off + at + (int64_t)got));
+            if (r <= 0) return false;
+            got += (size_t)r;
+        }
+        return true;
+    }
+};
+
+static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, int fmt, int n_cols, int max_ploidy,
+                      const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out) {
+    if (!c || !col_slot || !col_ploidy || !ok_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit: null argument");
+    if (slot < 0 || slot > 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit: slot %d", slot);
     if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
     if (fmt < PG_FMT_PHASED || fmt > PG_FMT_DIPLO || n_cols < 1 || max_ploidy < 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: bad format description");
-    *n_rows_out = 0;
-    *n_runs_out = 0;
+    pg_ctx::TokSlot &T = c->tok[slot];
+    T.state = 0;
+    T.len = len;
+    T.n_lines = 0;
     *ok_out = 0;
-    if (len == 0) { *ok_out = 1; return PG_OK; }
+    if (len == 0) { T.state = 1; *ok_out = 1; return PG_OK; }
     bool any = false;
     for (int k = 0; k < n_cols; ++k) {
         if (col_ploidy[k] <= 0) continue;
@@ -283,15 +314,32 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
             if (s < 0 || s >= c->n_hap) return pg_fail(PG_ERR_ARG, "col_slot[%d][%d]=%d out of range", k, a, s);
         }
     }
-    if (!any || text[len - 1] != '\n') return PG_OK;
+    char last = 0;
+    if (!src.read(len - 1, &last, 1)) return pg_fail(PG_ERR_ARG, "pg_tokenize_file: cannot read %lld bytes at offset %lld", (long long)len, (long long)src.off);
+    if (!any || last != '\n') return PG_OK;
+    // the block's first line (in memory: where it is; from a file: read ahead, 64 KiB and more until its line feed shows)
+    std::vector<char> head;
+    const char *text = src.text;
+    if (!text) {
+        size_t n = (size_t)std::min<int64_t>(len, 1 << 16);
+        for (;;) {
+            head.resize(n);
+            if (!src.read(0, head.data(), n)) return pg_fail(PG_ERR_ARG, "pg_tokenize_file: read failed");
+            if (memchr(head.data(), '\n', n) || (int64_t)n == len) break;
+            n = (size_t)std::min<int64_t>(len, (int64_t)n * 4);
+        }
+        text = head.data();
+    }
     // The cell widths of the block, read off its first line (scaffold, position, then n_cols cells with one blank between them):
     // a wanted column's cell must be as wide as its ploidy says (phased: 2 p - 1 characters, pairs: p, haplo / diplo: 1); a file of
     // mixed ploidy has narrower cells for its haploid samples.  Every other line is held against these widths on the device.
-    std::vector<int32_t> col_geo((size_t)2 * n_cols);
-    int cells_w = 0;
+    T.cols.assign((size_t)n_cols * (max_ploidy + 3), 0);         // col_slot | col_ploidy | cell offsets | cell widths
+    memcpy(T.cols.data(), col_slot, (size_t)n_cols * max_ploidy * 4);
+    memcpy(T.cols.data() + (size_t)n_cols * max_ploidy, col_ploidy, (size_t)n_cols * 4);
+    int32_t *col_off = T.cols.data() + (size_t)n_cols * (max_ploidy + 1), *col_w = col_off + n_cols;
     {
         auto blank_h = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f'; };
-        const char *p = text, *e = static_cast<const char *>(memchr(text, '\n', (size_t)len));
+        const char *p = text, *e = static_cast<const char *>(memchr(text, '\n', head.empty() ? (size_t)len : head.size()));
         for (int tok = 0; tok < 2; ++tok) {                                    // scaffold, position
             while (p < e && blank_h(*p)) ++p;
             if (p == e) return PG_OK;
@@ -308,70 +356,139 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
                 const int want = fmt == PG_FMT_PHASED ? 2 * col_ploidy[k] - 1 : (fmt == PG_FMT_PAIRS ? col_ploidy[k] : 1);
                 if (w != want) return PG_OK;
             }
-            col_geo[(size_t)k] = (int32_t)(b - cells0);
-            col_geo[(size_t)n_cols + k] = w;
+            col_off[k] = (int32_t)(b - cells0);
+            col_w[k] = w;
             if (k + 1 < n_cols) {
                 if (p == e || !blank_h(*p)) return PG_OK;
                 ++p;                                                            // exactly one separator
             }
         }
         if (p != e) return PG_OK;
-        cells_w = (int)(p - cells0);
+        T.cells_w = (int)(p - cells0);
     }
+    T.fmt = fmt;
+    T.n_cols = n_cols;
+    T.max_ploidy = max_ploidy;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream_up;
     int rc;
-    // ---- text to the device, double-buffered through page-locked staging ----
-    if ((rc = c->tok_text.ensure((size_t)len + 32)) != PG_OK) return rc;
-    const size_t piece = 32u << 20;
-    for (int k = 0; k < 2; ++k)
-        if ((rc = c->tok_pin[k].ensure(std::min<size_t>(piece, (size_t)len))) != PG_OK) return rc;
-    if (!c->tok_ev[0]) { HIPCHK(hipEventCreateWithFlags(&c->tok_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->tok_ev[1], hipEventDisableTiming)); }
-    int nt = pg_host_threads();
-    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
-    int64_t done = 0;
-    for (int k = 0; done < len; ++k) {
-        const size_t n = (size_t)std::min<int64_t>((int64_t)piece, len - done);
-        uint8_t *pin = c->tok_pin[k & 1].p;
-        if (k >= 2) HIPCHK(hipEventSynchronize(c->tok_ev[k & 1]));              // the copy out of this staging buffer is done
-        {
-            std::vector<std::thread> th;
-            const int use = (int)std::min<size_t>((size_t)nt, n / (1 << 20) + 1);
-            auto part = [&](int t) { const size_t a = n * t / use, b = n * (t + 1) / use; memcpy(pin + a, text + done + a, b - a); };
-            for (int t = 1; t < use; ++t) th.emplace_back(part, t);
-            part(0);
-            for (auto &x : th) x.join();
+    // ---- text to the device: self-paced staging threads ----
+    // Every thread takes the next 4 MiB chunk of the block, brings it into one of its two page-locked buffers (pread / memcpy) and
+    // queues its copy to the device on a copy stream of its own (four streams serve the eight threads: a stream costs 4 ms to
+    // create and four reach the link's rate), while its other buffer is still in flight: no thread waits for another, the queue
+    // of copies stays deep enough to keep PCIe busy, and the threads are started once per block (the first version started up to
+    // 16 threads per 32 MiB piece and copied one piece at a time: 41 GB/s of text on a 57 GB/s link; this one 55).
+    const bool dbg = getenv("PG_TOK_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    const auto t_stage0 = now();
+    if ((rc = T.text.ensure((size_t)len + 32)) != PG_OK) return rc;
+    {
+        constexpr size_t CH = 4u << 20;
+        int nt = pg_host_threads();
+        nt = nt < 1 ? 1 : (nt > PG_TOK_WORKERS ? PG_TOK_WORKERS : nt);
+        const int64_t n_chunks = (len + (int64_t)CH - 1) / (int64_t)CH;
+        const int use = (int)std::min<int64_t>(nt, n_chunks);
+        int n_streams = std::min(use, PG_TOK_STREAMS);
+        if (const char *e = getenv("PG_TOK_STREAMS")) n_streams = std::max(1, std::min(use, atoi(e)));
+        auto t1 = now();
+        if ((rc = c->tok_pin.ensure((size_t)use * 2 * CH)) != PG_OK) return rc;
+        if (dbg) fprintf(stderr, "tok: page-locked staging %.2f ms\n", ms_since(t1));
+        t1 = now();
+        for (int t = 0; t < use; ++t) {
+            if (t < n_streams && !c->tok_st[t]) HIPCHK(hipStreamCreateWithFlags(&c->tok_st[t], hipStreamNonBlocking));
+            for (int b = 0; b < 2; ++b)
+                if (!c->tok_wev[t][b]) HIPCHK(hipEventCreateWithFlags(&c->tok_wev[t][b], hipEventDisableTiming));
         }
-        HIPCHK(hipMemcpyAsync(c->tok_text.p + done, pin, n, hipMemcpyHostToDevice, st));
-        HIPCHK(hipEventRecord(c->tok_ev[k & 1], st));
-        done += (int64_t)n;
+        if (dbg) fprintf(stderr, "tok: streams + events %.2f ms\n", ms_since(t1));
+        t1 = now();
+        std::atomic<int64_t> next{0};
+        std::atomic<int> failed{0};                              // 1 = read error, 2 = HIP error
+        uint8_t *dtext = T.text.p;
+        auto work = [&](int t) {
+            if (hipSetDevice(c->device) != hipSuccess) { failed.store(2); return; }
+            hipStream_t ws = c->tok_st[t % n_streams];
+            bool used[2] = {false, false};
+            int b = 0;
+            for (;;) {
+                const int64_t ci = next.fetch_add(1);
+                if (ci >= n_chunks || failed.load()) break;
+                const int64_t a = ci * (int64_t)CH;
+                const size_t n = (size_t)std::min<int64_t>((int64_t)CH, len - a);
+                uint8_t *pin = c->tok_pin.p + ((size_t)t * 2 + b) * CH;
+                if (used[b] && hipEventSynchronize(c->tok_wev[t][b]) != hipSuccess) { failed.store(2); break; }
+                if (!src.read(a, pin, n)) { failed.store(1); break; }
+                if (hipMemcpyAsync(dtext + a, pin, n, hipMemcpyHostToDevice, ws) != hipSuccess ||
+                    hipEventRecord(c->tok_wev[t][b], ws) != hipSuccess) { failed.store(2); break; }
+                used[b] = true;
+                b ^= 1;
+            }
+            for (int k = 0; k < 2; ++k)                          // (the stream is shared: wait for the own copies, not for the stream)
+                if (used[k] && hipEventSynchronize(c->tok_wev[t][k]) != hipSuccess) failed.store(2);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < use; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        if (dbg) fprintf(stderr, "tok: copies %.2f ms (%d threads, %d streams)\n", ms_since(t1), use, n_streams);
+        if (failed.load() == 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_file: cannot read %lld bytes at offset %lld", (long long)len, (long long)src.off);
+        if (failed.load()) return pg_fail(PG_ERR_HIP, "pg_tokenize_text: a staging copy failed: %s", hipGetErrorString(hipGetLastError()));
     }
-    // ---- line feeds ----
+    c->tok_stage_s += std::chrono::duration<double>(now() - t_stage0).count();
+    c->tok_bytes += len;
+    // ---- line feeds: counted behind the copies, the total on its way to the host ----
     const int64_t n_tiles = (len + NL_TILE - 1) / NL_TILE;
-    if ((rc = c->tok_i32.ensure((size_t)n_tiles + 4)) != PG_OK) return rc;
-    if ((rc = c->tok_i64.ensure((size_t)n_tiles + 2)) != PG_OK) return rc;
-    int32_t *d_status = c->tok_i32.p + n_tiles;                                  // [0] status bits, [1] number of runs
-    int64_t *d_total = c->tok_i64.p + n_tiles;
+    T.n_tiles = n_tiles;
+    if ((rc = T.i32.ensure((size_t)n_tiles + 4)) != PG_OK) return rc;
+    if ((rc = T.i64.ensure((size_t)n_tiles + 2)) != PG_OK) return rc;
+    if ((rc = T.h_total.ensure(8)) != PG_OK) return rc;           // [0] lines, page-locked landing of small results: [2..3] status, runs
+    int32_t *d_status = T.i32.p + n_tiles;                          // [0] status bits, [1] number of runs
+    int64_t *d_total = T.i64.p + n_tiles;
     HIPCHK(hipMemsetAsync(d_status, 0, 8, st));
-    hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_tiles), dim3(256), 0, st, c->tok_text.p, len, c->tok_i32.p);
-    hipLaunchKernelGGL(k_nl_scan, dim3(1), dim3(256), 0, st, c->tok_i32.p, n_tiles, c->tok_i64.p, d_total);
-    int64_t n_lines = 0;
-    HIPCHK(hipMemcpyAsync(&n_lines, d_total, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_tiles), dim3(256), 0, st, T.text.p, len, T.i32.p);
+    hipLaunchKernelGGL(k_nl_scan, dim3(1), dim3(256), 0, st, T.i32.p, n_tiles, T.i64.p, d_total);
+    HIPCHK(hipMemcpyAsync(T.h_total.p, d_total, 8, hipMemcpyDeviceToHost, st));
+    if (!T.counted) HIPCHK(hipEventCreateWithFlags(&T.counted, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(T.counted, st));
+    T.state = 2;                                                    // text on the device, lines being counted
+    *ok_out = 1;
+    return PG_OK;
+}
+
+static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capacity, int64_t run_capacity, int64_t *n_rows_out, int *ok_out) {
+    if (!c || !n_rows_out || !ok_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_parse: null argument");
+    if (slot < 0 || slot > 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_parse: slot %d", slot);
+    pg_ctx::TokSlot &T = c->tok[slot];
+    *n_rows_out = 0;
+    *ok_out = 0;
+    if (T.state == 1) { T.state = 4; T.n_lines = 0; *ok_out = 1; return PG_OK; }          // an empty block
+    if (T.state != 2) return pg_fail(PG_ERR_STATE, "pg_tokenize_parse: nothing submitted to slot %d", slot);
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream_up;
+    HIPCHK(hipEventSynchronize(T.counted));
+    const int64_t n_lines = T.h_total.p[0];
+    T.n_lines = n_lines;
     *n_rows_out = n_lines;
-    if (n_lines == 0) { *ok_out = 1; return PG_OK; }
-    if (n_lines > row_capacity || row_offset < 0 || row_offset + n_lines > c->cap_sites) return PG_OK;   // (caller sizes from pg_count_lines)
-    if (!pos_out || !run_row_out || !run_off_out || !run_len_out || run_capacity < 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null output");
-    if ((rc = c->tok_nl.ensure((size_t)n_lines)) != PG_OK) return rc;
-    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(256), 0, st, c->tok_text.p, len, c->tok_i64.p, c->tok_nl.p);
-    // ---- parse ----
-    if ((rc = c->tok_cols.ensure((size_t)n_cols * (max_ploidy + 3))) != PG_OK) return rc;
-    HIPCHK(hipMemcpyAsync(c->tok_cols.p, col_slot, (size_t)n_cols * max_ploidy * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->tok_cols.p + (size_t)n_cols * max_ploidy, col_ploidy, (size_t)n_cols * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->tok_cols.p + (size_t)n_cols * (max_ploidy + 1), col_geo.data(), (size_t)n_cols * 8, hipMemcpyHostToDevice, st));
+    T.state = 0;
+    if (n_lines == 0) { T.state = 4; *ok_out = 1; return PG_OK; }
+    if (n_lines > row_capacity || row_offset < 0 || row_offset + n_lines > c->cap_sites) return PG_OK;   // (caller sizes the rows from a bound)
+    if (run_capacity < 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_parse: run_capacity < 1");
+    int rc;
+    const int n_cols = T.n_cols, max_ploidy = T.max_ploidy;
+    const int64_t n_tiles = T.n_tiles;
+    int32_t *d_status = T.i32.p + n_tiles;
+    if ((rc = T.nl.ensure((size_t)n_lines)) != PG_OK) return rc;
+    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(256), 0, st, T.text.p, T.len, T.i64.p, T.nl.p);
+    if ((rc = T.dcols.ensure(T.cols.size())) != PG_OK) return rc;
+    if ((rc = T.h_cols.ensure(T.cols.size())) != PG_OK) return rc;
+    memcpy(T.h_cols.p, T.cols.data(), T.cols.size() * 4);
+    HIPCHK(hipMemcpyAsync(T.dcols.p, T.h_cols.p, T.cols.size() * 4, hipMemcpyHostToDevice, st));
     const int64_t run_cap = std::min<int64_t>(run_capacity, n_lines);
-    if ((rc = c->tok_pos.ensure((size_t)n_lines + (size_t)run_cap + 8)) != PG_OK) return rc;   // pos [n_lines] + run_len [run_cap] (int32 each)
-    if ((rc = c->tok_off.ensure((size_t)run_cap * 2)) != PG_OK) return rc;                      // run_row, run_off
+    T.run_cap = run_cap;
+    if ((rc = T.pos.ensure((size_t)n_lines + (size_t)run_cap + 8)) != PG_OK) return rc;      // pos [n_lines] + run_len [run_cap] (int32 each)
+    if ((rc = T.off.ensure((size_t)run_cap * 2)) != PG_OK) return rc;                         // run_row, run_off
+    if ((rc = T.h_pos.ensure((size_t)n_lines)) != PG_OK) return rc;
     HIPCHK(hipMemsetAsync(c->gt.p + row_offset * c->S, 0, (size_t)n_lines * c->S, st));
     DipTable dip;
     memset(dip.v, 0, sizeof(dip.v));
@@ -381,26 +498,56 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
         auto code = [](char ch) { return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 4 : ch == 'T' ? 8 : 0; };
         for (int k = 0; d[k]; ++k) dip.v[(int)d[k]] = (uint8_t)(code(pr[k][0]) | (code(pr[k][1]) << 4));
     }
-    hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, c->tok_text.p, c->tok_nl.p, n_lines, fmt, n_cols,
-                       cells_w, max_ploidy, c->tok_cols.p, c->tok_cols.p + (size_t)n_cols * max_ploidy,
-                       c->tok_cols.p + (size_t)n_cols * (max_ploidy + 1), c->tok_cols.p + (size_t)n_cols * (max_ploidy + 2),
+    hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, T.text.p, T.nl.p, n_lines, T.fmt, n_cols,
+                       T.cells_w, max_ploidy, T.dcols.p, T.dcols.p + (size_t)n_cols * max_ploidy,
+                       T.dcols.p + (size_t)n_cols * (max_ploidy + 1), T.dcols.p + (size_t)n_cols * (max_ploidy + 2),
                        c->gt.p + row_offset * c->S, c->S,
-                       c->tok_pos.p, c->tok_off.p, c->tok_off.p + run_cap, c->tok_pos.p + n_lines, d_status + 1, run_cap, d_status, dip);
+                       T.pos.p, T.off.p, T.off.p + run_cap, T.pos.p + n_lines, d_status + 1, run_cap, d_status, dip);
     HIPCHK(hipGetLastError());
-    int32_t status[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(status, d_status, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(pos_out, c->tok_pos.p, (size_t)n_lines * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(T.h_total.p + 1, d_status, 8, hipMemcpyDeviceToHost, st));            // status | runs, as two int32
+    HIPCHK(hipMemcpyAsync(T.h_pos.p, T.pos.p, (size_t)n_lines * 4, hipMemcpyDeviceToHost, st));
+    T.state = 3;
+    *ok_out = 1;
+    c->tok_kernel_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PG_OK;
+}
+
+static int tok_collect(pg_ctx *c, int slot, int32_t *pos_out, int64_t pos_capacity, int64_t *run_row_out, int64_t *run_off_out,
+                       int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out) {
+    if (!c || !n_rows_out || !n_runs_out || !ok_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_collect: null argument");
+    if (slot < 0 || slot > 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_collect: slot %d", slot);
+    pg_ctx::TokSlot &T = c->tok[slot];
+    *n_rows_out = T.n_lines;
+    *n_runs_out = 0;
+    *ok_out = 0;
+    if (T.state == 4) { T.state = 0; *ok_out = 1; return PG_OK; }                            // an empty block
+    if (T.state != 3) return PG_OK;                                                          // refused earlier: nothing to collect
+    T.state = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Clock {
+        pg_ctx *c;
+        std::chrono::steady_clock::time_point t0;
+        ~Clock() { c->tok_kernel_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    } clock{c, t0};
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream_up;
     HIPCHK(hipStreamSynchronize(st));
+    const int64_t n_lines = T.n_lines;
+    if (!pos_out || !run_row_out || !run_off_out || !run_len_out || pos_capacity < n_lines)
+        return pg_fail(PG_ERR_ARG, "pg_tokenize_collect: outputs too small for %lld rows", (long long)n_lines);
+    int32_t status[2];
+    memcpy(status, T.h_total.p + 1, 8);
     if (status[0] != 0) return PG_OK;
-    const int64_t nr = status[1];
+    memcpy(pos_out, T.h_pos.p, (size_t)n_lines * 4);
+    const int64_t nr = status[1], run_cap = T.run_cap;
     *n_runs_out = nr;
-    if (nr > run_cap) return PG_OK;                                             // more runs than the caller has room for
+    if (nr > run_cap || nr > run_capacity) return PG_OK;                                     // more runs than the caller has room for
     std::vector<int64_t> rr((size_t)nr), ro((size_t)nr);
     std::vector<int32_t> rlen((size_t)nr);
     if (nr) {
-        HIPCHK(hipMemcpyAsync(rr.data(), c->tok_off.p, (size_t)nr * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(ro.data(), c->tok_off.p + run_cap, (size_t)nr * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(rlen.data(), c->tok_pos.p + n_lines, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(rr.data(), T.off.p, (size_t)nr * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(ro.data(), T.off.p + run_cap, (size_t)nr * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(rlen.data(), T.pos.p + n_lines, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     std::vector<int64_t> order((size_t)nr);
@@ -413,5 +560,69 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
         run_len_out[k] = rlen[j];
     }
     *ok_out = 1;
+    return PG_OK;
+}
+
+static int tokenize_block(pg_ctx *c, const TokSource &src, int64_t len, int fmt, int n_cols, int max_ploidy,
+                          const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out,
+                          int64_t row_capacity, int64_t *run_row_out, int64_t *run_off_out, int32_t *run_len_out,
+                          int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out) {
+    if (!n_rows_out || !n_runs_out || !ok_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null argument");
+    *n_rows_out = 0;
+    *n_runs_out = 0;
+    *ok_out = 0;
+    int ok = 0;
+    int rc = tok_submit(c, 0, src, len, fmt, n_cols, max_ploidy, col_slot, col_ploidy, &ok);
+    if (rc != PG_OK || !ok) return rc;
+    rc = tok_parse(c, 0, row_offset, row_capacity, run_capacity < 1 ? 1 : run_capacity, n_rows_out, &ok);
+    if (rc != PG_OK || !ok) return rc;
+    if (*n_rows_out > 0 && (!pos_out || !run_row_out || !run_off_out || !run_len_out || run_capacity < 1))
+        return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null output");
+    return tok_collect(c, 0, pos_out, row_capacity, run_row_out, run_off_out, run_len_out, run_capacity, n_rows_out, n_runs_out, ok_out);
+}
+
+extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fmt, int n_cols, int max_ploidy,
+                                const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out,
+                                int64_t row_capacity, int64_t *run_row_out, int64_t *run_off_out, int32_t *run_len_out,
+                                int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out) {
+    if (!text && len) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null argument");
+    const TokSource src{text ? text : "", -1, 0};
+    return tokenize_block(c, src, len, fmt, n_cols, max_ploidy, col_slot, col_ploidy, row_offset, pos_out, row_capacity, run_row_out,
+                          run_off_out, run_len_out, run_capacity, n_rows_out, n_runs_out, ok_out);
+}
+
+extern "C" int pg_tokenize_file(pg_ctx *c, int fd, int64_t file_offset, int64_t len, int fmt, int n_cols, int max_ploidy,
+                                const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out,
+                                int64_t row_capacity, int64_t *run_row_out, int64_t *run_off_out, int32_t *run_len_out,
+                                int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out) {
+    if (fd < 0 || file_offset < 0 || len < 0) return pg_fail(PG_ERR_ARG, "pg_tokenize_file: bad file range");
+    const TokSource src{nullptr, fd, file_offset};
+    return tokenize_block(c, src, len, fmt, n_cols, max_ploidy, col_slot, col_ploidy, row_offset, pos_out, row_capacity, run_row_out,
+                          run_off_out, run_len_out, run_capacity, n_rows_out, n_runs_out, ok_out);
+}
+
+extern "C" int pg_tokenize_submit(pg_ctx *c, int slot, const char *text, int fd, int64_t file_offset, int64_t len, int fmt, int n_cols,
+                                  int max_ploidy, const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out) {
+    if ((!text && fd < 0 && len) || file_offset < 0 || len < 0) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit: no text");
+    const TokSource src{text ? text : (fd < 0 ? "" : nullptr), fd, file_offset};
+    return tok_submit(c, slot, src, len, fmt, n_cols, max_ploidy, col_slot, col_ploidy, ok_out);
+}
+
+extern "C" int pg_tokenize_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capacity, int64_t run_capacity,
+                                 int64_t *n_rows_out, int *ok_out) {
+    return tok_parse(c, slot, row_offset, row_capacity, run_capacity, n_rows_out, ok_out);
+}
+
+extern "C" int pg_tokenize_collect(pg_ctx *c, int slot, int32_t *pos_out, int64_t pos_capacity, int64_t *run_row_out,
+                                   int64_t *run_off_out, int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out,
+                                   int64_t *n_runs_out, int *ok_out) {
+    return tok_collect(c, slot, pos_out, pos_capacity, run_row_out, run_off_out, run_len_out, run_capacity, n_rows_out, n_runs_out, ok_out);
+}
+
+extern "C" int pg_tokenize_stats(pg_ctx *c, double *stage_seconds_out, double *kernel_seconds_out, int64_t *bytes_out) {
+    if (!c || !stage_seconds_out || !kernel_seconds_out || !bytes_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_stats: null argument");
+    *stage_seconds_out = c->tok_stage_s;
+    *kernel_seconds_out = c->tok_kernel_s;
+    *bytes_out = c->tok_bytes;
     return PG_OK;
 }

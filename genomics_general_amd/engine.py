@@ -183,11 +183,13 @@ class Engine:
         check(self._L.pg_upload_wait(self._h))
         self._in_flight = None
 
-    def tokenize_text(self, buf, row_offset=0, n_rows=None, max_runs=1 << 16):
+    def tokenize_text(self, buf, row_offset=0, n_rows=None, max_runs=1 << 16, at_most=False, file=None):
         """K0 on the device: complete `.geno` data lines (bytes-like: bytes, memoryview, mmap) -> resident rows row_offset ..;
         returns (n, pos int32 [n], run_starts int64 [r], run_names) or None when the block is not of the regular layout the device
         tokenizer handles (the caller then takes the host tokenizer).  The rows must be reserved: n_rows = number of data lines
-        (pg_count_lines) if known."""
+        (pg_count_lines) if known; with at_most an upper bound of it (the device counts the lines itself: no pass of the host
+        over the text).  file = (file descriptor, offset of buf in the file) of a plain-text block: the staging threads then read
+        the text with pread() from the page cache instead of copying it out of the mapping (pg_tokenize_file)."""
         lay = self.layout
         ptr, nbytes, _keep = _lib.text_ptr(buf)
         if n_rows is None:
@@ -199,18 +201,58 @@ class Engine:
         while True:
             rrow, roff, rlen = np.empty(max_runs, dtype=np.int64), np.empty(max_runs, dtype=np.int64), np.empty(max_runs, dtype=np.int32)
             got, nr, ok = C.c_int64(0), C.c_int64(0), C.c_int(0)
-            check(self._L.pg_tokenize_text(self._h, ptr, nbytes, _lib.FMT[lay.genoFormat], len(lay.col_ploidy), lay.max_ploidy,
-                                           np.ascontiguousarray(lay.col_slot), lay.col_ploidy, int(row_offset), pos, cap, rrow, roff, rlen,
-                                           max_runs, C.byref(got), C.byref(nr), C.byref(ok)))
+            tail = (_lib.FMT[lay.genoFormat], len(lay.col_ploidy), lay.max_ploidy, np.ascontiguousarray(lay.col_slot), lay.col_ploidy,
+                    int(row_offset), pos, cap, rrow, roff, rlen, max_runs, C.byref(got), C.byref(nr), C.byref(ok))
+            if file is not None:
+                check(self._L.pg_tokenize_file(self._h, int(file[0]), int(file[1]), nbytes, *tail))
+            else:
+                check(self._L.pg_tokenize_text(self._h, ptr, nbytes, *tail))
             if not ok.value and nr.value > max_runs and max_runs < cap:          # a block of very many short scaffolds: once more
                 max_runs = cap
                 continue
             break
-        if not ok.value or got.value != n_rows:
+        if not ok.value or (got.value != n_rows and not at_most):
             return None
         k, r = int(got.value), int(nr.value)
         names = [bytes(buf[int(roff[i]):int(roff[i]) + int(rlen[i])]).decode("utf-8", "replace") for i in range(r)]
         return k, pos[:k], rrow[:r].copy(), names
+
+    # the same in three steps, two blocks in flight: parse(k) -> submit(k+1) -> collect(k) lets the kernels of block k run while the
+    # text of block k+1 crosses PCIe (cli.Run._chunks_device)
+    def tokenize_submit(self, buf, slot, file=None):
+        """text of a block -> device buffer of `slot` (0 / 1), its lines counted behind the copies; False: not the regular layout"""
+        lay = self.layout
+        ptr, nbytes, _keep = _lib.text_ptr(buf)
+        ok = C.c_int(0)
+        check(self._L.pg_tokenize_submit(self._h, int(slot), None if file is not None else ptr, int(file[0]) if file is not None else -1,
+                                         int(file[1]) if file is not None else 0, nbytes, _lib.FMT[lay.genoFormat], len(lay.col_ploidy),
+                                         lay.max_ploidy, np.ascontiguousarray(lay.col_slot), lay.col_ploidy, C.byref(ok)))
+        return bool(ok.value)
+
+    def tokenize_parse(self, slot, row_offset, row_capacity, max_runs=1 << 16):
+        """queue the parse of the block in `slot` into resident rows row_offset .. (at most row_capacity of them); returns the number of
+        its lines, or None when they do not fit"""
+        n, ok = C.c_int64(0), C.c_int(0)
+        check(self._L.pg_tokenize_parse(self._h, int(slot), int(row_offset), int(row_capacity), int(max_runs), C.byref(n), C.byref(ok)))
+        return int(n.value) if ok.value else None
+
+    def tokenize_collect(self, slot, buf, n_rows, max_runs=1 << 16):
+        """wait for the parse of `slot`; (n, pos, run_starts, run_names) or None (irregular text met on the device, too many runs)"""
+        pos = np.empty(max(int(n_rows), 1), dtype=np.int32)
+        rrow, roff, rlen = np.empty(max_runs, dtype=np.int64), np.empty(max_runs, dtype=np.int64), np.empty(max_runs, dtype=np.int32)
+        got, nr, ok = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        check(self._L.pg_tokenize_collect(self._h, int(slot), pos, len(pos), rrow, roff, rlen, max_runs, C.byref(got), C.byref(nr), C.byref(ok)))
+        if not ok.value:
+            return None
+        k, r = int(got.value), int(nr.value)
+        names = [bytes(buf[int(roff[i]):int(roff[i]) + int(rlen[i])]).decode("utf-8", "replace") for i in range(r)]
+        return k, pos[:k], rrow[:r].copy(), names
+
+    def tokenize_stats(self):
+        """{"h2d_s", "kernels_s", "bytes"} of the device tokenizer so far (pg_tokenize_stats)"""
+        a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+        check(self._L.pg_tokenize_stats(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return {"h2d_s": a.value, "kernels_s": b.value, "bytes": int(n.value)}
 
     def move_rows(self, src_row, dst_row, n):
         check(self._L.pg_move_rows(self._h, int(src_row), int(dst_row), int(n)))

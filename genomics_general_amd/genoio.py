@@ -38,7 +38,7 @@ class BgzfFile:
         import os
         from concurrent.futures import ThreadPoolExecutor
         self.raw = open(path, "rb")
-        self.pool = ThreadPoolExecutor(max_workers=n_threads or min(16, os.cpu_count() or 1))
+        self.pool = ThreadPoolExecutor(max_workers=n_threads or min(16, _lib.usable_cpus()))
         self.pending = b""               # compressed bytes not yet split into whole members
         self.buf = bytearray()           # inflated bytes not yet handed out
         self.eof = False
@@ -226,6 +226,9 @@ class BlockReader:
             self.f = open(path, "rb")
             if os.path.getsize(path) > 0:
                 self.mm = mmap.mmap(self.f.fileno(), 0, access=mmap.ACCESS_READ)
+                probe = np.frombuffer(self.mm, dtype=np.uint8)
+                self._mm_addr = int(probe.ctypes.data)       # where the mapping begins: file_range() turns a block into (fd, offset)
+                del probe
         self.bytes_read = 0
 
     def read_header(self):
@@ -286,6 +289,15 @@ class BlockReader:
         return data
 
     packed = False
+
+    def file_range(self, block):
+        """(file descriptor, file offset) of a block read_block() handed out as a view of the memory-mapped file, else None"""
+        if self.mm is None or not isinstance(block, memoryview) or len(block) == 0:
+            return None
+        off = int(np.frombuffer(block, dtype=np.uint8).ctypes.data) - self._mm_addr
+        if off < 0 or off + len(block) > len(self.mm):
+            return None
+        return self.f.fileno(), off
 
     def input_size(self):
         return os.path.getsize(self.path) if self.path is not None and os.path.exists(str(self.path)) else -1
@@ -560,7 +572,7 @@ PGENO_CHUNK = 4 << 20
 
 def _pool():
     from concurrent.futures import ThreadPoolExecutor
-    return ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1)))
+    return ThreadPoolExecutor(max(1, min(16, _lib.usable_cpus())))
 
 
 class PackedWriter:

@@ -36,13 +36,28 @@ class WindowTable:
         self.hi = np.asarray(self.hi, dtype=np.int64)
         self.n = len(self.lo)
         self.sites = self.hi - self.lo
-        # GenoWindow.midPos (genomics.py:1795-1797): int(round(sum/len)), nan when empty
-        csum = np.concatenate([[0], np.cumsum(np.asarray(positions, dtype=np.int64))])
-        tot = csum[self.hi] - csum[self.lo]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            mean = tot / self.sites
-        self.mid = [int(np.rint(m)) if s > 0 else float("nan") for m, s in zip(mean, self.sites)]
+        self._positions, self._mid = positions, None
         return self
+
+    @property
+    def mid(self):
+        """GenoWindow.midPos (genomics.py:1795-1797): int(round(sum/len)), nan when empty.  Computed when first asked for -- by the
+        thread that formats the rows, not by the one that finds the windows of the next block."""
+        if self._mid is None:
+            nz = self.hi > self.lo
+            a = int(self.lo[nz].min()) if np.any(nz) else 0
+            b = int(self.hi[nz].max()) if np.any(nz) else 0
+            csum = np.concatenate([[0], np.cumsum(np.asarray(self._positions[a:b], dtype=np.int64))])
+            tot = csum[np.where(nz, self.hi - a, 0)] - csum[np.where(nz, self.lo - a, 0)]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                mean = tot / self.sites
+            self._mid = [int(np.rint(m)) if s > 0 else float("nan") for m, s in zip(mean, self.sites)]
+            self._positions = None
+        return self._mid
+
+    @mid.setter
+    def mid(self, value):
+        self._mid = value
 
 
 def _wanted(scaf, include, exclude):                 # genomics.py:2016

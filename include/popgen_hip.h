@@ -112,6 +112,30 @@ int pg_tokenize_text(pg_ctx *ctx, const char *text, int64_t len, int fmt, int n_
                      const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out, int64_t row_capacity, int64_t *run_row_out,
                      int64_t *run_off_out, int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out,
                      int *ok_out);
+/* The same for `len` bytes at offset file_offset of an open file (plain text on disk): the staging threads pread() the text from
+ * the page cache straight into their page-locked buffers, so the block never has to be mapped, faulted in or walked by the host.
+ * Offsets in run_off_out are relative to file_offset. */
+int pg_tokenize_file(pg_ctx *ctx, int fd, int64_t file_offset, int64_t len, int fmt, int n_cols, int max_ploidy,
+                     const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out, int64_t row_capacity,
+                     int64_t *run_row_out, int64_t *run_off_out, int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out,
+                     int64_t *n_runs_out, int *ok_out);
+/* The device tokenizer in three steps, two blocks in flight (slot 0 / 1), for a caller that overlaps the kernels of one block with
+ * the copies of the next:   parse(k) -> submit(k+1) -> collect(k).
+ *   submit   text (memory when `text` is given, else `len` bytes at file_offset of fd) -> the slot's device buffer, line feeds
+ *            counted behind the copies; *ok_out = 0: not the regular layout (see pg_tokenize_text), nothing submitted
+ *   parse    line-feed positions, rows row_offset .. cleared, parse kernel: queued on the copy stream, not waited for; waits only
+ *            for the line count (*n_rows_out); *ok_out = 0 when the rows do not fit row_capacity / the reservation
+ *   collect  waits for the parse; outputs as pg_tokenize_text (offsets relative to the block's first byte) */
+int pg_tokenize_submit(pg_ctx *ctx, int slot, const char *text, int fd, int64_t file_offset, int64_t len, int fmt, int n_cols,
+                       int max_ploidy, const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out);
+int pg_tokenize_parse(pg_ctx *ctx, int slot, int64_t row_offset, int64_t row_capacity, int64_t run_capacity, int64_t *n_rows_out,
+                      int *ok_out);
+int pg_tokenize_collect(pg_ctx *ctx, int slot, int32_t *pos_out, int64_t pos_capacity, int64_t *run_row_out, int64_t *run_off_out,
+                        int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out);
+/* What the device tokenizer of this context has spent so far: wall seconds of the host -> device copies of the text (staging
+ * threads start to join: the PCIe-bound part), wall seconds of everything behind them (line feeds, parse kernel, positions and
+ * runs back), and the bytes of text tokenised. */
+int pg_tokenize_stats(pg_ctx *ctx, double *stage_seconds_out, double *kernel_seconds_out, int64_t *bytes_out);
 /* Copy n resident rows from src_row to dst_row (ranges may overlap): the rows carried over to the next block of a stream. */
 int pg_move_rows(pg_ctx *ctx, int64_t src_row, int64_t dst_row, int64_t n);
 
@@ -158,6 +182,9 @@ int pg_text_runs(const char *buf, size_t len, int64_t *starts_out, int64_t cap, 
 int pg_text_seek_pos(const char *buf, size_t len, int whole, const char *scaf, size_t scaf_len, int64_t pos_min, int64_t *off_out,
                      int32_t *state_out, int64_t *pos_out, int64_t *rows_out);
 int pg_text_skip_rows(const char *buf, size_t len, int64_t n_rows, int64_t *off_out, int64_t *rows_out);
+/* CPUs the process may really use: logical CPUs, cut by the affinity mask and the cgroup CPU quota.  What the library's host
+ * thread pools are sized from when PG_HOST_THREADS is not set. */
+int pg_usable_cpus(void);
 /* Count data rows (non-'#', non-empty) in a text buffer so the caller can size the outputs. */
 int pg_count_lines(const char *buf, size_t len, int64_t *n_rows_out);
 

@@ -50,17 +50,49 @@ class CpuEngine:
         assert src + n <= len(self.gt) and dst + n <= len(self.gt)
         self.gt[dst:dst + n] = self.gt[src:src + n].copy()
 
-    def tokenize_text(self, buf, row_offset=0, n_rows=None):
+    def tokenize_text(self, buf, row_offset=0, n_rows=None, at_most=False, file=None):
+        import os
         from genomics_general_amd import genoio
         body = bytes(buf)
+        if file is not None:                                                     # (fd, offset): the same bytes, read from the file
+            assert os.pread(file[0], len(body), file[1]) == body, "file_range() does not name the block's bytes"
         CpuEngine.tokenizer_calls += 1
         if b"#" in body or b"\r" in body or b"\t\t" in body or not body.endswith(b"\n"):
             return None                                                          # what the kernels refuse
         d = genoio.encode(body, self.layout)
-        if n_rows is not None and d.n_sites != n_rows:
+        if n_rows is not None and (d.n_sites > n_rows if at_most else d.n_sites != n_rows):
             return None
         assert row_offset + d.n_sites <= len(self.gt), "tokenised rows exceed the reserved rows"
         self.gt[row_offset:row_offset + d.n_sites] = d.gt[:, :self.layout.n_hap]
+        return d.n_sites, d.pos.copy(), d.run_starts.astype(np.int64), list(d.run_names)
+
+    # the three-step interface (parse(k) -> submit(k+1) -> collect(k)): the rows are written at parse, as on the device
+    def tokenize_submit(self, buf, slot, file=None):
+        import os
+        body = bytes(buf)
+        if file is not None:
+            assert os.pread(file[0], len(body), file[1]) == body, "file_range() does not name the block's bytes"
+        CpuEngine.tokenizer_calls += 1
+        self._slots = getattr(self, "_slots", {})
+        if b"#" in body or b"\r" in body or b"\t\t" in body or (body and not body.endswith(b"\n")):
+            self._slots.pop(slot, None)
+            return False
+        self._slots[slot] = [body, None]
+        return True
+
+    def tokenize_parse(self, slot, row_offset, row_capacity, max_runs=1 << 16):
+        from genomics_general_amd import genoio
+        body = self._slots[slot][0]
+        d = genoio.encode(body, self.layout)
+        if d.n_sites > row_capacity or row_offset + d.n_sites > len(self.gt):
+            return None
+        self.gt[row_offset:row_offset + d.n_sites] = d.gt[:, :self.layout.n_hap]
+        self._slots[slot][1] = d
+        return d.n_sites
+
+    def tokenize_collect(self, slot, buf, n_rows, max_runs=1 << 16):
+        body, d = self._slots.pop(slot)
+        assert bytes(buf) == body and d is not None
         return d.n_sites, d.pos.copy(), d.run_starts.astype(np.int64), list(d.run_names)
 
     def load_sites(self, gt):

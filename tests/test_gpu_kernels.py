@@ -404,6 +404,65 @@ def test_device_tokenizer_equals_the_host_tokenizer(fixture, fmt):
         e.close()
 
 
+def test_device_tokenizer_in_three_steps_two_blocks_in_flight(tmp_path):
+    """pg_tokenize_submit / _parse / _collect in the order the drivers' ingestion thread uses -- parse(k), submit(k+1), collect(k): the
+    kernels of one block run while the text of the next crosses PCIe -- from a file (pread by the staging threads) and from memory,
+    with an upper bound of the rows instead of a count; equal to the host tokenizer block by block.  An irregular block is refused
+    at submit or at collect and leaves the slots usable"""
+    import gzip
+    import os
+    from genomics_general_amd import genoio
+    from genomics_general_amd.engine import Engine
+    from genomics_general_amd.samples import HapLayout, SampleData
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    raw = gzip.open(os.path.join(gold, "abba.geno.gz"), "rb").read()
+    names = raw[:raw.index(b"\n")].decode().split()[2:]
+    head = raw.index(b"\n") + 1
+    path = str(tmp_path / "abba.geno")
+    with open(path, "wb") as f:
+        f.write(raw)
+    lines = raw[head:].split(b"\n")[:-1]
+    cuts = [0, 700, 1500, 1501, 4000, len(lines)]
+    blocks = [b"\n".join(lines[a:b]) + b"\n" for a, b in zip(cuts[:-1], cuts[1:])]
+    offs = [head + sum(len(x) for x in blocks[:k]) for k in range(len(blocks))]
+    lay = HapLayout(SampleData(indNames=names[2:] + names[:1]), names, "phased")
+    e = Engine(0)
+    e.set_layout(lay)
+    e.reserve(len(lines) + 64)
+    fd = os.open(path, os.O_RDONLY)
+    for from_file in (True, False):
+        src = lambda k: dict(file=(fd, offs[k])) if from_file else {}             # noqa: E731
+        row, got = 5, []
+        assert e.tokenize_submit(blocks[0], 0, **src(0))
+        for k in range(len(blocks)):
+            bound = len(blocks[k]) // (4 * len(names) + 4) + 1
+            n = e.tokenize_parse(k % 2, row, bound)
+            assert n == cuts[k + 1] - cuts[k]
+            if k + 1 < len(blocks):
+                assert e.tokenize_submit(blocks[k + 1], (k + 1) % 2, **src(k + 1))
+            got.append(e.tokenize_collect(k % 2, blocks[k], n))
+            row += n
+        row = 5
+        for k, g in enumerate(got):
+            want = genoio.encode(blocks[k], lay)
+            assert g is not None and g[0] == want.n_sites and np.array_equal(g[1], want.pos)
+            assert np.array_equal(g[2], want.run_starts) and g[3] == want.run_names
+            assert np.array_equal(e.download(row, g[0]), want.gt), (from_file, k)
+            row += g[0]
+    os.close(fd)
+    dirty = b"\n".join(lines[:50] + [b"# a comment"] + lines[50:60]) + b"\n"
+    assert e.tokenize_submit(dirty, 1)                                           # the first line is regular: the kernels find the comment
+    n = e.tokenize_parse(1, 0, 100)
+    assert n is not None and e.tokenize_collect(1, dirty, n) is None
+    assert not e.tokenize_submit(blocks[0][:-1], 0)                              # no final line feed: refused at once
+    assert e.tokenize_submit(blocks[0], 0) and e.tokenize_parse(0, 0, 3) is None   # rows that do not fit the bound
+    assert e.tokenize_submit(blocks[0], 0)
+    n = e.tokenize_parse(0, 0, 5000)
+    g = e.tokenize_collect(0, blocks[0], n)
+    assert g is not None and g[0] == cuts[1]
+    e.close()
+
+
 def test_device_tokenizer_refuses_irregular_blocks():
     """a comment line, doubled separators, a cell of another width than its column's, a missing final line feed: the fast path says
     no (the drivers then use the host tokenizer); a position that is not a number likewise.  Mixed ploidy (narrower cells for the
