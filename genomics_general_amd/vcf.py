@@ -10,8 +10,9 @@ parseVCF.py:268-303), streams the input in blocks and renders the rows.
 Supported: -i/-o (.gz by suffix, stdin/stdout), -s/--samples, --include/--exclude(/File), --minQual, --gtf (repeatable), --skipIndels,
 --excludeDuplicates, --maxREFlen, --ploidy, --ploidyFile, --ploidyMismatchToMissing, --keepPartial, --addRefTrack, --noHeader,
 --missing (one character), --outSep (one character), and --field NAME (the values of another FORMAT field instead of genotypes:
-plain text out, a line loop on the host -- that output is not an input of the engine).  Not supported (they rewrite alleles from
-freebayes CIGAR strings and produce multi-site rows, which the engine's formats do not hold): --simplifyALT, --expandMulti.  Alleles longer than one base (indels without --skipIndels;
+plain text out, a line loop on the host -- that output is not an input of the engine), and --simplifyALT / --expandMulti (ALT
+haplotypes of freebayes records rewritten to the length of REF from their CIGAR strings; one row per base with --expandMulti:
+_cigar_main, likewise a line loop on the host).  Alleles longer than one base (indels without --skipIndels;
 the homozygous-reference calls of a deletion site even with it) are printed as strings by the text route, exactly as the
 reference prints them; the packed route stores such calls as missing (use --maxREFlen 1 to drop those sites altogether)."""
 import argparse
@@ -154,6 +155,151 @@ def _field_main(args):
     return 0
 
 
+def _simplify_alt(alt, cigar, missing="N"):
+    """An ALT haplotype brought to the coordinates of REF with its CIGAR string (freebayes; parseVCF.py:25-46): matches and
+    mismatches copy their bases, an insertion skips them, a deletion leaves `missing` in their place."""
+    import re
+    ops = re.findall(r"\d+|[MXDI]", cigar)
+    out, at = [], 0
+    if len(ops) % 2:
+        raise ValueError("Malformed CIGAR: " + cigar)
+    for count, op in zip(ops[0::2], ops[1::2]):
+        if not count.isdigit() or op.isdigit():
+            raise ValueError("Malformed CIGAR: " + cigar)
+        n = int(count)
+        if op in "MX":
+            out.append(alt[at:at + n])
+            at += n
+        elif op == "I":
+            at += n
+        else:
+            out.append(missing * n)
+    return "".join(out)
+
+
+def _gt_type(alleles):
+    kinds = set(alleles)                                            # GTtype, parseVCF.py:13-18
+    return "Het" if len(kinds) > 1 else "HomRef" if "0" in kinds else "Missing" if "." in kinds else "HomAlt"
+
+
+def _cigar_main(args):
+    """`--simplifyALT` / `--expandMulti` (the latter implies the former, parseVCF.py:337): every ALT haplotype of a freebayes
+    record is rewritten to the length of REF from the CIGAR strings of its INFO column (VcfSite.__init__, parseVCF.py:72-77), the
+    genotypes are looked up among the rewritten alleles (getGenotype, parseVCF.py:117-166), and with --expandMulti a record of a
+    REF of n bases becomes n rows of single bases at POS .. POS + n - 1 (parseVCF.py:160-161, 380-386) -- rows the engine's
+    tokenizers take.  A plain line loop on the host, like --field: records of this kind are a small share of a VCF, and their
+    rows are of varying width.  Errors as the reference raises them: a record without CIGAR in INFO (KeyError), an INFO flag
+    without `=` (ValueError), a ploidy mismatch without --ploidyMismatchToMissing (ValueError)."""
+    import re
+    if args.packed:
+        raise SystemExit("parseVCF.py: --simplifyALT / --expandMulti write text only (no --packed)")
+    include, exclude = _contig_lists(args)
+    include, exclude = set(include), set(exclude)
+    if include:
+        sys.stderr.write("{} contigs will be included.".format(len(include)))
+    if exclude:
+        sys.stderr.write("{} contigs will be excluded.".format(len(exclude)))
+    inp = (gzip.open(args.inFile, "rt") if args.inFile.endswith(".gz") else open(args.inFile, "rt")) if args.inFile else sys.stdin
+    out = (gzip.open(args.outFile, "wt") if args.outFile.endswith(".gz") else open(args.outFile, "wt")) if args.outFile else sys.stdout
+    cols = None
+    for line in inp:
+        if line.startswith("#CHROM"):
+            cols = line.split()
+            break
+    assert cols is not None and len(cols) >= 9, "no #CHROM header line in the VCF"
+    col_of = {nm: k for k, nm in enumerate(cols)}
+    samples = args.samples.split(",") if args.samples else list(cols[9:])
+    for s in samples:
+        assert s in cols[9:], "Sample {} not in VCF header\n".format(s)
+    where = [col_of[s] for s in samples]
+    ploidy = {s: args.ploidy for s in samples}
+    if args.ploidyFile:
+        with open(args.ploidyFile, "rt") as pf:
+            for f in (ln.split() for ln in pf):
+                if f:
+                    ploidy[f[0]] = int(f[1])
+    filters = []
+    for g in [_parse_gtf(g) for g in args.gtf] if args.gtf else []:
+        filters.append(g)
+    expand, must_match, keep_partial = args.expandMulti, args.skipIndels, args.keepPartial
+    sep = args.outSep
+    if not args.noHeader:
+        out.write(sep.join(["#CHROM", "POS"] + (["REF"] if args.addRefTrack else []) + samples) + "\n")
+    split_gt = re.compile("[/|]")
+    last = None
+    for line in inp:
+        f = line.split()
+        if not f or f[0][0] == "#":
+            continue
+        if args.excludeDuplicates:
+            if (f[0], f[1]) == last:
+                continue
+            last = (f[0], f[1])
+        chrom, pos, ref, qual = f[0], int(f[1]), f[3], f[5]
+        info = dict(x.split("=") for x in f[7].split(";"))          # (a flag without `=` is a ValueError here as there)
+        alts = f[4].split(",") if f[4] != "." else []
+        cigars = info["CIGAR"].split(",")
+        alts = [_simplify_alt(a, cigars[k]) for k, a in enumerate(alts)]
+        if (exclude and chrom in exclude) or (include and chrom not in include):
+            continue
+        if args.minQual:
+            try:
+                if float(qual) < args.minQual:
+                    continue
+            except ValueError:
+                pass
+        if args.maxREFlen and len(ref) > args.maxREFlen:
+            continue
+        alleles = {str(k): a for k, a in enumerate([ref] + alts)}
+        same_len = {k: len(a) == len(ref) for k, a in alleles.items()}
+        site_type = "MONO" if not alts else "SNP" if all(same_len.values()) else "INDEL"
+        absent = args.missing if args.missing is not None else ("N" if not expand or len(ref) == 1 else ["N"] * len(ref))
+        keys = f[8].split(":")
+        cells = []
+        for s, c in zip(samples, where):
+            data = dict(zip(keys, f[c].split(":")))
+            calls = tuple(split_gt.split(data["GT"]))
+            phase = "|" if "|" in data["GT"] else "/"
+            ok = True
+            for g in filters:
+                if "siteTypes" in g and site_type not in g["siteTypes"]:
+                    continue
+                if "gtTypes" in g and _gt_type(calls) not in g["gtTypes"]:
+                    continue
+                if "samples" in g and s not in g["samples"]:
+                    continue
+                try:
+                    vals = [float(v) for v in data[g["flag"]].split(",")]
+                    ok = all(g["min"] <= v for v in vals) and all(v <= g["max"] for v in vals)
+                except (KeyError, ValueError):
+                    ok = False
+                if not ok:
+                    break
+            if ploidy[s] != len(calls):
+                if not args.ploidyMismatchToMissing:
+                    raise ValueError("Sample {} at {}:{} genotype {} does not match explected ploidy of {}".format(
+                        s, chrom, pos, data["GT"], ploidy[s]))
+                ok = False
+            if ok:
+                try:
+                    got = [alleles[a] if (not must_match or same_len[a]) else absent for a in calls]
+                    if not keep_partial and any(a is absent or a == absent for a in got):
+                        got = [absent] * ploidy[s]
+                except KeyError:                                    # `.` or an index beyond the ALT list
+                    got = [absent] * ploidy[s]
+            else:
+                got = [absent] * ploidy[s]
+            cells.append(tuple(phase.join(a[i] for a in got) for i in range(len(ref))) if expand else phase.join(got))
+        if expand:
+            for x in range(len(ref)):
+                out.write(sep.join([chrom, str(pos + x)] + ([ref[x]] if args.addRefTrack else []) + [c[x] for c in cells]) + "\n")
+        else:
+            out.write(sep.join([chrom, str(pos)] + ([ref] if args.addRefTrack else []) + cells) + "\n")
+    if out is not sys.stdout:
+        out.close()
+    return 0
+
+
 def parse_vcf_main(argv=None):
     ap = argparse.ArgumentParser(prog="parseVCF.py")
     ap.add_argument("-o", "--outFile", help="Output .geno file")
@@ -167,8 +313,8 @@ def parse_vcf_main(argv=None):
                     action="append", nargs="+")
     ap.add_argument("--skipIndels", help="Skip indels", action="store_true")
     ap.add_argument("--excludeDuplicates", help="Only include the first in a series of duplicated positions", action="store_true")
-    ap.add_argument("--simplifyALT", action="store_true", help="(not supported)")
-    ap.add_argument("--expandMulti", action="store_true", help="(not supported)")
+    ap.add_argument("--simplifyALT", action="store_true", help="Simplify multi-site alternate alleles using CIGAR (as in Freebayes output)")
+    ap.add_argument("--expandMulti", action="store_true", help="Expand multi-site alleles (also sets simplifyALT)")
     ap.add_argument("--maxREFlen", help="Maximum length for reference allele", type=int)
     ap.add_argument("--ploidy", help="Ploidy for each sample", type=int, default=2)
     ap.add_argument("--ploidyFile", help="File with samples names and ploidy as columns")
@@ -183,11 +329,10 @@ def parse_vcf_main(argv=None):
     ap.add_argument("--packed", metavar="FILE.pgeno", help="also (or, without -o, only) write the packed form the engine's drivers read")
     ap.add_argument("--threads", type=int, default=0, help="host threads of the native parser (default: all)")
     args = ap.parse_args(argv)
-    for flag in ("simplifyALT", "expandMulti"):
-        if getattr(args, flag):
-            raise SystemExit("parseVCF.py: --%s is not supported by this drop-in (see genomics_general_amd/vcf.py)" % flag)
     if args.field is not None:
         return _field_main(args)
+    if args.simplifyALT or args.expandMulti:
+        return _cigar_main(args)
     missing = args.missing if args.missing is not None else "N"
     if len(missing) != 1 or len(args.outSep) != 1:
         raise SystemExit("parseVCF.py: --missing and --outSep must be single characters here")

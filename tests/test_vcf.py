@@ -58,8 +58,24 @@ def test_packed_route_equals_tokenising_the_text(tmp_path):
 
 def test_unsupported_flags_and_ploidy_errors_are_loud(tmp_path):
     src = os.path.join(GOLD, "hap.vcf.gz")
-    with pytest.raises(SystemExit):
+    with pytest.raises(KeyError):                                  # records without CIGAR in INFO: the reference raises the same
         vcf.parse_vcf_main(["-i", src, "-o", str(tmp_path / "x"), "--expandMulti"])
+    with pytest.raises(SystemExit):
+        vcf.parse_vcf_main(["-i", os.path.join(GOLD, "cigar.vcf.gz"), "--packed", str(tmp_path / "x.pgeno"), "--expandMulti"])
+    with pytest.raises(ValueError):                                # a haploid call where two alleles are expected
+        vcf.parse_vcf_main(["-i", os.path.join(GOLD, "cigarhap.vcf.gz"), "-o", str(tmp_path / "x"), "--simplifyALT"])
     from genomics_general_amd._lib import PopgenError
     with pytest.raises(PopgenError):                               # the reference raises ValueError on the haploid calls
         vcf.parse_vcf_main(["-i", src, "-o", str(tmp_path / "x"), "--skipIndels"])
+
+
+def test_expanded_rows_are_what_the_engine_tokenises():
+    """`--expandMulti` turns multi-base freebayes records into one row per base: every cell of the golden output is one allele
+    character per haplotype, so the host tokenizer (and the device tokenizer's regular layout) takes the file as it is"""
+    with open(os.path.join(GOLD, "cigar_expand.geno"), "rb") as f:
+        names = f.readline().decode().split()[2:]
+        body = f.read()
+    lay = HapLayout(SampleData(indNames=list(names)), names, "phased")
+    d = genoio.encode(body, lay)
+    assert d.n_sites == body.count(b"\n") and d.gt.shape[1] == 2 * len(names)
+    assert set(np.unique(d.gt)) <= {0, 1, 2, 4, 8} and (d.gt != 0).mean() > 0.5
