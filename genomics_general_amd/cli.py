@@ -189,6 +189,7 @@ class Run:
             names = self._reader.read_header().decode("utf-8", "replace").split()[2:]
         self.timing["read_s"] += time.perf_counter() - t0
         self.layout = HapLayout(sampleData, names, args.genoFormat)
+        self._infer_ploidy = bool(getattr(args, "inferPloidy", False))
         self._wparams = dict(wparams, include=args.include, exclude=args.exclude)
         self._minSites, self._coords_keep, self._windows_fn = minSites, coords_keep, windows_fn
         self._streamer = None
@@ -296,7 +297,11 @@ class Run:
         import time
         eng = self.engine
         if self._device_tokenizer():
-            yield from self._chunks_device()
+            try:
+                yield from self._chunks_device()
+            except _lib.PopgenError as exc:
+                self._explain_ploidy_error(exc)
+                raise
             return
         piped = hasattr(eng, "upload_async")
         pitch = eng.row_pitch if piped else None
@@ -366,6 +371,8 @@ class Run:
                 item = prepared.get(block=block)
             except queue.Empty:
                 return None
+            if isinstance(item, _lib.PopgenError):
+                self._explain_ploidy_error(item)
             if isinstance(item, BaseException):
                 raise item
             return item
@@ -444,6 +451,16 @@ class Run:
             if piped:
                 eng.upload_wait()
         self._reader.close()
+
+    def _explain_ploidy_error(self, exc):
+        """--inferPloidy: the reference infers the ploidy of every sample WINDOW BY WINDOW from the shortest cell the window holds
+        (genoToAlignment with ploidy None, genomics.py:1110; splitSeq zips the cells, genomics.py:390-396), so a file whose cell
+        widths change gives windows of different haplotype counts there.  Here the first data row decides for the whole file: a
+        later cell of another width must not pass silently."""
+        if self._infer_ploidy and exc.code == _lib.PG_ERR_PARSE and "ploidy" in str(exc):
+            raise SystemExit("--inferPloidy: %s.\nThis engine infers the ploidy once, from the cell widths of the first data row; the "
+                             "reference infers it window by window (NOT RECOMMENDED there, popgenWindows.py:190).  A file whose cell "
+                             "widths change needs explicit ploidies: --ploidy / --ploidyFile / --haploid." % str(exc))
 
     def _device_tokenizer(self):
         """K0 on the device (Engine.tokenize_text; PG_GPU_TOKENIZER=0 keeps the host tokenizer): plain or gzipped text in one of the

@@ -96,3 +96,28 @@ def test_device_tokenizer_path_falls_back_block_by_block(tmp_path, monkeypatch):
     before = CpuEngine.tokenizer_calls
     run_case(case, tmp_path, monkeypatch, geno=dirty)
     assert CpuEngine.tokenizer_calls > before + 2
+
+
+@pytest.mark.parametrize("host_tokenizer", [False, True])
+def test_infer_ploidy_refuses_a_file_whose_cell_widths_change(host_tokenizer, tmp_path, monkeypatch):
+    """`--inferPloidy`: the reference infers the ploidy window by window from the shortest cell of the window
+    (genomics.py:1110, 390-396); this engine takes it once from the first data row.  A file in which a later window holds a cell of
+    another width (here: a diploid sample's cell written with one allele, far behind the first row) must not pass silently: the
+    drivers stop with a message that names the option and the way out."""
+    import gzip
+    case = [c for c in CASES if c["name"] == "mixed_inferploidy"][0]
+    lines = gzip.open(os.path.join(GOLD, "mixed.geno.gz"), "rb").read().split(b"\n")
+    row = 1500                                                       # a row of a later window, far behind the first block
+    cells = lines[row].split(b"\t")
+    assert len(cells[2]) == 3                                        # s0 is diploid: `A/C`
+    cells[2] = cells[2][:1]
+    odd = str(tmp_path / "odd.geno")
+    with open(odd, "wb") as f:
+        f.write(b"\n".join(lines[:row] + [b"\t".join(cells)] + lines[row + 1:]))
+    monkeypatch.setenv("PG_STREAM_BYTES", "20000")
+    if host_tokenizer:
+        monkeypatch.setenv("PG_GPU_TOKENIZER", "0")
+    with pytest.raises(SystemExit) as err:
+        run_case(case, tmp_path, monkeypatch, geno=odd)
+    assert "--inferPloidy" in str(err.value) and "--ploidyFile" in str(err.value)
+    run_case(case, tmp_path, monkeypatch)                            # the regular file: the golden of the reference

@@ -151,3 +151,25 @@ def test_cat_and_predefined_windows_on_several_ranks(name, tool, size, tmp_path)
     if os.path.exists(os.path.join(gold, name + ".out.windows")) and "windowDataOutFile" in " ".join(case["argv"]):
         with open(out + ".windows") as f, open(os.path.join(gold, name + ".out.windows")) as g:
             assert f.read() == g.read()
+
+
+def test_infer_ploidy_refuses_a_file_whose_cell_widths_change_on_the_device(tmp_path, monkeypatch):
+    """as tests/test_cli_cpu.py, through the device tokenizer: the kernels flag the block (a cell of another width than its
+    column's), the host tokenizer names the row, the driver explains --inferPloidy"""
+    import gzip
+    import sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    from cases import CASES
+    case = [c for c in CASES if c["name"] == "mixed_inferploidy"][0]
+    lines = gzip.open(os.path.join(gold, "mixed.geno.gz"), "rb").read().split(b"\n")
+    cells = lines[1500].split(b"\t")
+    cells[2] = cells[2][:1]
+    odd = str(tmp_path / "odd.geno")
+    with open(odd, "wb") as f:
+        f.write(b"\n".join(lines[:1500] + [b"\t".join(cells)] + lines[1501:]))
+    monkeypatch.setenv("PG_STREAM_BYTES", "20000")
+    out = str(tmp_path / "o.csv")
+    with pytest.raises(SystemExit) as err:
+        G.MAINS[case["tool"]]([a.format(geno=odd, dir=gold, out=out) for a in case["argv"]] + ["-o", out])
+    assert "--inferPloidy" in str(err.value)
