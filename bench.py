@@ -780,7 +780,7 @@ def main():
         npv = (n_hap // 2 + 31) // 32 * 32 if dip else np32
         pair_c = ("k_pairC_big" if ("b" in tile_sel and (n_hap // 2 if dip else n_hap) <= 224) else
                   "k_pairC_tile" if ("c" in tile_sel and 3 * 4 * npv * 16 <= 65536) else "k_pairC_fp4")
-        pair_d = "k_pairD_tile" if ("d" in tile_sel and 3 * 4 * np32 * 8 <= 65536) else "k_pairD_fp4"
+        pair_d = "k_pairD_fp4"
     rocprof_name = {_lib.K_PACK: pack_name, _lib.K_PAIRWISE: pair_c, _lib.K_PAIRD: pair_d,
                     _lib.K_SITESTATS: "k_popfreq_q" if wl["tool"] == "popfreq" else "k_abba_q"}
     pmc = {}

@@ -306,6 +306,12 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
     c->all_diploid = (n_hap % 2 == 0);
     for (size_t k = 0; k + 1 < sstart.size() && c->all_diploid; ++k)
         if (sstart[k + 1] - sstart[k] != 2) c->all_diploid = false;
+    // the fast forms of k_popdist_fin (<1>, <2>) walk a population individual by individual (8-byte loads at its even slots): they
+    // need every population to begin and end on an individual boundary.  A caller of the C-ABI may put the two haplotypes of an
+    // individual into different populations (the Python layout never does): the general form then
+    c->pops_on_individuals = true;
+    for (int p = 0; p <= n_pops; ++p)
+        if (pstart[p] % 2) c->pops_on_individuals = false;
     std::vector<PgTask2> tasksC;
     if (c->all_diploid) tasksC = pg_make_tasks_circ(n_hap / 2, 8);         // k_pairC works on 8-row circulant tasks
     c->n_tasksC = (int)tasksC.size();
@@ -753,7 +759,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         if (valu_pairs && NP % 64) return pg_fail(PG_ERR_STATE, "PG_PAIR_VALU must be set before pg_set_samples (plane stride %d)", NP);
         if (!valu_pairs && pg_pair_big_fits(NPv, n_units)) {
             pg_launch_pairC_big(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p);
-        } else if (!valu_pairs && pg_pair_tile_fits(NPv, 0)) {
+        } else if (!valu_pairs && pg_pair_tile_fits(NPv)) {
             if (pg_launch_pairC_tile(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p))
                 return pg_fail(PG_ERR_HIP, "pair-kernel program upload failed");
         } else if (!valu_pairs) pg_launch_pairC_mfma(c->stream, sl.Vp.p, d_vgoff, nb, NPv, n_units, dip ? 1 : 0, va / nb, (int64_t)max_groups * grp * 32, c->Cmat.p);
@@ -763,10 +769,7 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         // (running k_pairD beside k_pairC on a third stream was measured: +3 % throughput, but overlapping kernels make the
         // per-kernel timings ambiguous; kept sequential)
         if ((rc = pg_time_begin(c, PG_K_PAIRD, &e0, &e1)) != PG_OK) return rc;
-        if (!valu_pairs && pg_pair_tile_fits(NP, 1)) {
-            if (pg_launch_pairD_tile(c->stream, sl.XV.p, d_nw, d_goff, nb, NP, N, ga / nb * grp / 10, (int64_t)max_groups * capg * 32, c->Dmat.p, capg))
-                return pg_fail(PG_ERR_HIP, "pair-kernel program upload failed");
-        } else if (!valu_pairs) pg_launch_pairD_mfma(c->stream, sl.XV.p, d_nw, d_goff, nb, NP, N, ga / nb * grp / 10, (int64_t)max_groups * capg * 32, c->Dmat.p, capg);
+        if (!valu_pairs) pg_launch_pairD_mfma(c->stream, sl.XV.p, d_nw, d_goff, nb, NP, N, ga / nb * grp / 10, (int64_t)max_groups * capg * 32, c->Dmat.p, capg);
         else pg_launch_pairD(c->stream, sl.XV.p, d_nw, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, ga / nb, c->Dmat.p, capg);
         if ((rc = pg_time_end(c, PG_K_PAIRD, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
@@ -963,7 +966,7 @@ extern "C" int pg_popdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n
         int r = pg_time_begin(c, PG_K_POPDIST_FIN, &e0, &e1);
         if (r != PG_OK) return r;
         pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, c->n_pops, min_pair_sites,
-                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, c->all_diploid ? 1 : 0);
+                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, c->all_diploid && c->pops_on_individuals ? 1 : 0);
         if ((r = pg_time_end(c, PG_K_POPDIST_FIN, e0, e1, 1)) != PG_OK) return r;
         HIPCHK(hipGetLastError());
         return PG_OK;
@@ -996,7 +999,7 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
         int r = pg_time_begin(c, PG_K_POPDIST_FIN, &e0, &e1);
         if (r != PG_OK) return r;
         pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, P, min_pair_sites,
-                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, c->all_diploid ? 1 : 0);
+                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, c->all_diploid && c->pops_on_individuals ? 1 : 0);
         pg_launch_popstats(c->stream, c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, nb, c->pop_start.p, P,
                            min_data, do_pairs, c->stats.p + (size_t)w0 * ncols);
         if ((r = pg_time_end(c, PG_K_POPDIST_FIN, e0, e1, 1)) != PG_OK) return r;

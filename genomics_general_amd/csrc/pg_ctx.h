@@ -94,6 +94,7 @@ struct pg_ctx {
     DevBuf<PgTask2> tasksCh;     // v2 k_pairC on haplotype units (no diagonal)
     int n_tasksCh = 0;
     bool all_diploid = false;    // every individual owns exactly slots (2k, 2k+1)
+    bool pops_on_individuals = false;   // ... and every population begins and ends on an individual boundary
     DevBuf<uint32_t> Vp, XY;     // v2 planes (slot 0; also used by nothing else)
     // v2 software pipeline: k_pack2 of sub-batch k+1 (HBM-bound, stream2) overlaps the pair kernels of sub-batch k
     // (VALU-bound, stream).  Two slots of planes / window tables.

@@ -81,12 +81,10 @@ void pg_launch_pairC_mfma(hipStream_t st, const uint32_t *Vp, const int64_t *vgo
 void pg_launch_pairD_mfma(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win, int NP, int N,
                           int64_t avg_words, int64_t max_vsites, int32_t *Dmat, int capg);
 
-// the same products with the planes staged through LDS, one block per window part (pg_pair_tile.hip); 0 = launched
-bool pg_pair_tile_fits(int NPv_or_NP, int is_d);
+// the called-count products with the planes staged through LDS, one block per window part (pg_pair_tile.hip); 0 = launched
+bool pg_pair_tile_fits(int NPv);
 int pg_launch_pairC_tile(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, int NPv, int n_units, int diag,
                          int64_t avg_wq, int64_t max_sites, int32_t *Cmat);
-int pg_launch_pairD_tile(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win, int NP, int N,
-                         int64_t avg_words, int64_t max_vsites, int32_t *Dmat, int capg);
 
 // called counts with one wave per SIMD and up to 14 tiles per wave (pg_pair_big.hip): planes of up to 224 units
 bool pg_pair_big_fits(int NPv, int n_units);

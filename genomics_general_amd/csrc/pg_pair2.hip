@@ -720,16 +720,11 @@ static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *g
     // PG_PACK2=1 forces k_pack2 (A/B runs and tests).
     const bool force2 = getenv("PG_PACK2") != nullptr;
     if (threads <= 1024 && !force2) {
-        // PG_PACK_BLOCKS_PER_CU=k (A/B runs): unused dynamic LDS so that at most k blocks share a CU (tools/ubench/pack_rw.hip: the
-        // kernel's bare traffic runs 3 % faster with half the waves; the kernel itself does not)
-        const char *bpc = getenv("PG_PACK_BLOCKS_PER_CU");
-        const size_t pad = bpc && atoi(bpc) > 0 ? (size_t)(160 * 1024 / atoi(bpc) - 1024) / 256 * 256 : 0;
-#define PG_PACK3B(T, B) hipLaunchKernelGGL((k_pack3<T, DIP, B>), grid, dim3(T), B ? (pad > 49152 + 4096 ? std::min<size_t>(pad - 49152 - 2048, 63 * 1024) : 0) : std::min<size_t>(pad, 63 * 1024), st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp, fq)
+#define PG_PACK3B(T, B) hipLaunchKernelGGL((k_pack3<T, DIP, B>), grid, dim3(T), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp, fq)
 #define PG_PACK3(T) PG_PACK3B(T, 0)
-        // quadruples of the called plane per burst (the rest of the 24 LDS cells per thread holds virtual-site words); PG_PACK_FQ: A/B
-        const int vn = DIP ? 2 : 4, fq_max = (PACK_CELLS - 2) / vn;
-        const int fq = getenv("PG_PACK_FQ") ? std::min(fq_max, std::max(1, atoi(getenv("PG_PACK_FQ")))) : (DIP ? 8 : 4);
-        const bool burst = getenv("PG_PACK_BURST") == nullptr || atoi(getenv("PG_PACK_BURST")) != 0;       // (0: A/B)
+        // quadruples of the called plane per burst (the rest of the 24 LDS cells per thread holds virtual-site words)
+        const int fq = DIP ? 8 : 4;
+        const bool burst = getenv("PG_PACK_BURST") == nullptr || atoi(getenv("PG_PACK_BURST")) != 0;       // (0: A/B runs, tests)
         if (threads <= 64 && burst) PG_PACK3B(64, 1);
         else if (threads <= 128 && burst) PG_PACK3B(128, 1);
         else if (threads <= 64) PG_PACK3(64);

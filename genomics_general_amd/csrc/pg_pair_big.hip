@@ -74,10 +74,6 @@ PG_BIG_TILES_OF(1) PG_BIG_TILES_OF(2) PG_BIG_TILES_OF(3) PG_BIG_TILES_OF(4) PG_B
                    [wave] "s"(wave)                                                                                                        \
                  : PG_CBIG_CLOBBERS)
 
-// PG_PAIR_CLOCK=1: one block reports the cycles and the 100 MHz ticks its main loop took (the shader clock under this load, and
-// with the loop's product count the cycles per product: how DESIGN.md section 4 prices the kernel against the matrix pipe)
-__device__ long long g_clock_probe[4];
-
 template <int T>
 __global__ __launch_bounds__(64 * Tiles<T>::W) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_pairC_big(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vgoff, int n_win, int kparts, int NPv, int n_units,
@@ -103,7 +99,6 @@ void k_pairC_big(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vg
         const uint32_t ring = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds;
         const uint32_t lrd = ring + 16u * lane;
         const int stride = 2 * NPv * 16;
-        const long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
         if constexpr (T == 1) PG_BIG_RUN(PG_CBIG_ASM_T1);
         else if constexpr (T == 2) PG_BIG_RUN(PG_CBIG_ASM_T2);
         else if constexpr (T == 3) PG_BIG_RUN(PG_CBIG_ASM_T3);
@@ -111,8 +106,6 @@ void k_pairC_big(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ vg
         else if constexpr (T == 5) PG_BIG_RUN(PG_CBIG_ASM_T5);
         else if constexpr (T == 6) PG_BIG_RUN(PG_CBIG_ASM_T6);
         else PG_BIG_RUN(PG_CBIG_ASM_T7);
-        const long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
-        if (blockIdx.x == gridDim.x / 3 && threadIdx.x == 0) { g_clock_probe[0] = c1 - c0; g_clock_probe[1] = r1 - r0; g_clock_probe[2] = npair; }
     }
     if (npair > 0 || !atomic) {                               // (an empty window: the counts are zero and nobody else writes them)
         const signed char (*tl)[14][2] = tiles_of<T>();
@@ -165,13 +158,5 @@ void pg_launch_pairC_big(hipStream_t st, const uint32_t *Vp, const int64_t *vgof
         case 5: launch<5>(st, Vp, vgoff, n_win, kparts, NPv, n_units, diag, Cmat); break;
         case 6: launch<6>(st, Vp, vgoff, n_win, kparts, NPv, n_units, diag, Cmat); break;
         default: launch<7>(st, Vp, vgoff, n_win, kparts, NPv, n_units, diag, Cmat); break;
-    }
-    if (getenv("PG_PAIR_CLOCK")) {
-        long long h[4];
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clock_probe), sizeof h);
-        const int tiles = T * (T + 1) / 2, per_wave = (tiles + W - 1) / W;
-        fprintf(stderr, "k_pairC_big<%d>: one block's loop: %lld cycles in %.1f us (%.2f GHz), %lld pairs of groups, %.1f cycles per product\n", T, h[0],
-                h[1] / 100.0, h[1] ? h[0] / (h[1] * 10.0) : 0.0, h[2], h[2] ? (double)h[0] / (h[2] * 4.0 * per_wave) : 0.0);
     }
 }

@@ -1,4 +1,4 @@
-// Pairwise counts on the matrix cores, every plane word fetched ONCE per window part: k_pairC_tile / k_pairD_tile.
+// Pairwise called counts on the matrix cores, every plane word fetched ONCE per window part: k_pairC_tile.
 //
 // Same arithmetic as k_pairC_fp4 / k_pairD_fp4 (pg_pair_mfma.hip): the counts are Gram matrices of 0/1 vectors
 // (genomics.py:903-916, 1219-1221, 1042-1047), C = V V^T over the called plane, D = A B^T + B A^T over the
@@ -14,8 +14,8 @@
 // reads the fragments of its tiles from LDS.
 //
 //   tile      32 x 32 units, K = 64 sites per v_mfma_scale_f32_32x32x64_f8f6f4; lane (r = lane & 31, kb = lane >> 5) holds unit
-//             32 t + r and the step's word kb: C: one ds_read_b128 = the four words of group 2 p + kb = four K steps;
-//             D: one ds_read_b64 = (x, v) of word 2 s + kb.  Fragment dword m = (word >> m) & 0x11111111 (7 VALU per fragment).
+//             32 t + r and the step's word kb: one ds_read_b128 = the four words of group 2 p + kb = four K steps.
+//             Fragment dword m = (word >> m) & 0x11111111 (7 VALU per fragment).
 //   strip     two tile rows (64 units) r0, r0+1 and the columns j >= r0; a SLOT is one column of a strip = two products per step
 //             (the first slot of a strip, j == r0, has only the diagonal tile: `one` = 1).  The row fragments of a strip stay
 //             in registers while its slots stream through: 7 VALU ops per two 32-cycle matrix instructions (the one-wave kernels:
@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -308,136 +309,6 @@ void k_pairC_tile(const uint32_t *__restrict__ Vp, const int64_t *__restrict__ v
     }
 }
 
-// ---- D: differences of haplotype pairs ------------------------------------------------------------------------------------------
-// XV word k of a window: [slot][x, v] (8 bytes per haplotype).  A stage = KD steps of two words; the lane half kb works on word
-// 2 s + kb of step s.  a = x & v, b = ~x & v;  D += a_row b_col^T + b_row a_col^T.
-
-// one slot, one step: the column's b fragment is expanded first and multiplied while its a fragment is expanded
-__device__ __forceinline__ void slotD(const uint2 &cw, const Masks &K, const v4i (&ra)[2], const v4i (&rb)[2], int one, v16f &a0, v16f &a1) {
-    // v238 = a = x & v, v237 = b = v ^ a; F0 = fragment of b, F1 = fragment of a
-    asm volatile("s_cmp_lg_u32 %[one], 0\n\t"
-                 "v_and_b32 v238, %[x], %[v]\n\tv_xor_b32 v237, %[v], v238\n\t"
-                 PG_EXP_A("v240", "v241", "v237") PG_EXP_B("v242", "v243", "v237")
-                 PG_EXP_A("v244", "v245", "v238")
-                 PG_MFMA("%[a0]", "%[ra0]", PG_F0)
-                 PG_EXP_B("v246", "v247", "v238")
-                 PG_MFMA1("%[ra1]", PG_F0)
-                 "s_nop 1\n\t"
-                 PG_MFMA("%[a0]", "%[rb0]", PG_F1)
-                 PG_MFMA1("%[rb1]", PG_F1)
-                 : [a0] "+v"(a0), [a1] "+v"(a1)
-                 : [x] "v"(cw.x), [v] "v"(cw.y), [k1] "v"(K.k1), [k2] "v"(K.k2), [k4] "v"(K.k4),
-                   [ra0] "v"(ra[0]), [ra1] "v"(ra[1]), [rb0] "v"(rb[0]), [rb1] "v"(rb[1]), [one] "s"(one)
-                 : "scc", "v237", "v238", PG_SCRATCH);
-}
-
-template <int CS, int W, int KD>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_pairD_tile(const uint32_t *__restrict__ XV, const int32_t *__restrict__ nw, const int64_t *__restrict__ goff, int n_win, int T,
-                  int nblk, int kparts, int NP, int N, const int32_t *__restrict__ prog, int nl, int32_t *__restrict__ Dmat, int capg) {
-    extern __shared__ uint4 lds[];
-    int win, rem;
-    if (!win_decode(nblk * kparts, n_win, win, rem)) return;
-    const int bp = rem % nblk, kp = rem / nblk;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 31, kb = lane >> 5;
-    const int32_t *my = prog + (size_t)(bp * W + wave) * (CS + 1);
-    const int ns = __builtin_amdgcn_readfirstlane(my[0]);
-    int sr0[CS], sj[CS], sone[CS];
-#pragma unroll
-    for (int s = 0; s < CS; ++s) {
-        const Slot sl = slot_of(__builtin_amdgcn_readfirstlane(my[1 + s]));
-        sr0[s] = sl.r0;
-        sj[s] = sl.j;
-        sone[s] = sl.one;
-    }
-    // (a window that overflowed its reservation is recomputed by the host; never read past the reservation)
-    const int capw = (int)(goff[win + 1] - goff[win]) * capg;
-    const int n_all = __builtin_amdgcn_readfirstlane(nw[win]);
-    const int n_words = n_all < capw ? n_all : capw;
-    const int w0 = (int)((long long)n_words * kp / kparts), w1 = (int)((long long)n_words * (kp + 1) / kparts);
-    const int atomic = kparts > 1;
-    int32_t *Dw = Dmat + (size_t)win * N * N;
-    v16f acc[CS][2];
-#pragma unroll
-    for (int s = 0; s < CS; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[s][i][e] = 0.0f;
-    const int stage_words = 2 * KD;
-    const int stage_u4 = stage_words * NP / 2;                // 8 bytes per haplotype and word
-    const int chunks = stage_u4 / 64;                         // NP is a multiple of 32
-    const int nstage = (w1 - w0 + stage_words - 1) / stage_words;
-    const uint4 *base = reinterpret_cast<const uint4 *>(XV + ((size_t)goff[win] * capg + w0) * PG_XV_PLANES * (size_t)NP);
-    Masks KC;
-    KC.k1 = 0x11111111u;
-    KC.k2 = 0x22222222u;
-    KC.k4 = 0x44444444u;
-    asm volatile("" : "+v"(KC.k1), "+v"(KC.k2), "+v"(KC.k4));
-    if (nstage > 0) {
-        for (int st = 0; st < NSTG - 1; ++st) {
-            const int src = st < nstage ? st : nstage - 1;
-            stage_copy<W>(base + (size_t)src * stage_u4, lds + (size_t)st * stage_u4, chunks, nl, wave, lane);
-        }
-        // (tools/audit_pair_tile_asm.py: no compiler code may touch an accumulator from here on; the operands pin their zeroing above)
-#pragma unroll
-        for (int s = 0; s < CS; ++s) asm volatile("; PG_AUDIT_BEGIN" : "+v"(acc[s][0]), "+v"(acc[s][1])::"memory");
-        for (int st = 0; st < nstage; ++st) {
-            wait_vm(nl * (NSTG - 2));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            {
-                const int nx = st + NSTG - 1, src = nx < nstage ? nx : nstage - 1;
-                stage_copy<W>(base + (size_t)src * stage_u4, lds + (size_t)(nx % NSTG) * stage_u4, chunks, nl, wave, lane);
-            }
-            const uint2 *sb = reinterpret_cast<const uint2 *>(lds + (size_t)(st % NSTG) * stage_u4);
-#pragma unroll 1
-            for (int p = 0; p < KD; ++p) {
-                const bool live = w0 + st * stage_words + 2 * p + kb < w1;
-                Masks KR;
-                KR.k1 = live ? KC.k1 : 0u;
-                KR.k2 = live ? KC.k2 : 0u;
-                KR.k4 = live ? KC.k4 : 0u;
-                const uint2 *pb = sb + (size_t)(2 * p + kb) * NP + r;
-                int cur = -1;
-                v4i ra[2], rb[2];
-                uint2 craw = pb[32 * sj[0]];
-#pragma unroll
-                for (int s = 0; s < CS; ++s) {
-                    if (s < ns) {
-                        if (sr0[s] != cur) {
-                            cur = sr0[s];
-                            const int t1 = cur + 1 < T ? cur + 1 : cur;
-                            const uint2 u0 = pb[32 * cur], u1 = pb[32 * t1];
-                            const uint32_t a0 = u0.x & u0.y, a1 = u1.x & u1.y;            // a = x & v, b = ~x & v
-                            ra[0] = expand_row(a0, KR);
-                            rb[0] = expand_row(u0.y ^ a0, KR);
-                            ra[1] = expand_row(a1, KR);
-                            rb[1] = expand_row(u1.y ^ a1, KR);
-                        }
-                        const uint2 cw = craw;
-                        if (s + 1 < CS) craw = pb[32 * sj[s + 1]];
-                        slotD(cw, KC, ra, rb, sone[s], acc[s][0], acc[s][1]);
-                    }
-                }
-            }
-        }
-        wait_vm(0);
-        asm volatile("s_nop 11 ; PG_AUDIT_END" ::: "memory");
-    }
-    const bool zero_fill = nstage <= 0 && !atomic;
-    if (nstage > 0 || zero_fill) {
-#pragma unroll
-        for (int s = 0; s < CS; ++s) {
-            if (s < ns) {
-                store_tile(acc[s][0], sr0[s], sj[s], lane, N, 0, atomic, Dw);
-                if (!sone[s]) store_tile(acc[s][1], sr0[s] + 1, sj[s], lane, N, 0, atomic, Dw);
-            }
-        }
-    }
-}
-
 // ---- host: slot programs ---------------------------------------------------------------------------------------------------
 // Slots of the upper triangle of T x T tiles in strip order (strip = tile rows r0, r0+1; slot = column j >= r0; the slot j == r0
 // holds the diagonal tile only, as does every slot of a last strip of one row), dealt to nblk * W waves of at most CS slots each,
@@ -523,11 +394,13 @@ struct ProgCache {
     int32_t *d = nullptr;
 };
 ProgCache g_prog[8];
+std::mutex g_prog_lock;                                      // contexts of several devices may be driven from several host threads
 
 int get_program(int T, int CS, int W, const int32_t **d_out, int *nblk_out) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
-    ProgCache *slot = nullptr;
+    std::lock_guard<std::mutex> guard(g_prog_lock);
+    ProgCache *slot = nullptr, *mine = nullptr;
     for (ProgCache &c : g_prog) {
         if (c.d && c.T == T && c.CS == CS && c.W == W && c.device == dev) {
             *d_out = c.d;
@@ -535,17 +408,26 @@ int get_program(int T, int CS, int W, const int32_t **d_out, int *nblk_out) {
             return 0;
         }
         if (!c.d && !slot) slot = &c;
+        if (c.d && c.device == dev && !mine) mine = &c;
     }
-    if (!slot) {                                             // recycle the first entry (shapes rarely change within a process)
-        slot = &g_prog[0];
-        (void)hipFree(slot->d);
-        slot->d = nullptr;
+    if (!slot) {
+        // the cache is full: recycle an entry of THIS device (its table is freed on the device that owns it; kernels that were
+        // launched with it are ordered before the free by the runtime).  No entry of this device to give up: no program.
+        if (!mine) return -1;
+        (void)hipFree(mine->d);
+        mine->d = nullptr;
+        slot = mine;
     }
     const Program p = make_program(T, CS, W);
     const std::vector<int32_t> &tab = p.tab;
+    int32_t *d = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d), tab.size() * 4) != hipSuccess) return -1;
+    if (hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return -1;
+    }
+    slot->d = d;
     slot->nblk = p.nblk;
-    if (hipMalloc(reinterpret_cast<void **>(&slot->d), tab.size() * 4) != hipSuccess) return -1;
-    if (hipMemcpy(slot->d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
     slot->T = T;
     slot->CS = CS;
     slot->W = W;
@@ -566,19 +448,20 @@ int pick_parts(int n_win, int waves_per_win, int64_t steps_per_window, int min_s
 int exact_parts(int64_t max_sites_per_window) { return (int)((max_sites_per_window + (1 << 23) - 1) >> 23); }
 
 constexpr int CS_C = 4, W_C = 4, GP_C = 2;      // C: 4 waves x 4 slots, stage = 2 pairs of groups (512 sites)
-constexpr int CS_D = 4, W_D = 4, KD_D = 2;      // D: 4 waves x 4 slots, stage = 2 steps (128 virtual sites)
 
 }  // namespace
 
-// The LDS-staged kernels take planes of up to this many units per word (a stage must fit the ring).  PG_PAIR_TILE chooses who
-// runs them: "cd" both counts, "c" / "d" one of them, "none" neither (the one-wave kernels of pg_pair_mfma.hip); a 'b' lets
-// k_pairC_big (pg_pair_big.hip) take the called counts of planes of up to 224 units first.  Default "bc".
-bool pg_pair_tile_fits(int NPv_or_NP, int is_d) {
+// The LDS-staged kernel takes planes of up to this many units per word (a stage must fit the ring).  PG_PAIR_TILE (A/B runs, tests)
+// chooses who counts the called pairs: a 'b' lets k_pairC_big (pg_pair_big.hip) take planes of up to 224 units, a 'c' lets
+// k_pairC_tile take what fits its ring, "none" leaves everything to the one-wave kernel of pg_pair_mfma.hip.  Default "bc".
+// (The LDS-staged form of the DIFFERENCE counts lost to the one-wave kernel on every shape -- 1.3 vs 0.85 ms on the north-star
+// shape -- and was removed in round 4; HISTORY.md.)
+bool pg_pair_tile_fits(int NPv) {
     const char *sel = getenv("PG_PAIR_TILE");
     if (!sel) sel = "bc";
-    if (!strchr(sel, is_d ? 'd' : 'c')) return false;
-    const int64_t stage = is_d ? (int64_t)2 * KD_D * NPv_or_NP * 8 : (int64_t)2 * GP_C * NPv_or_NP * 16;
-    return NPv_or_NP % 32 == 0 && stage * NSTG <= 64 * 1024;
+    if (!strchr(sel, 'c')) return false;
+    const int64_t stage = (int64_t)2 * GP_C * NPv * 16;
+    return NPv % 32 == 0 && stage * NSTG <= 64 * 1024;
 }
 
 int pg_launch_pairC_tile(hipStream_t st, const uint32_t *Vp, const int64_t *vgoff, int n_win, int NPv, int n_units, int diag,
@@ -590,38 +473,12 @@ int pg_launch_pairC_tile(hipStream_t st, const uint32_t *Vp, const int64_t *vgof
     if (get_program(T, CS_C, W_C, &prog, &nblk) != 0) return -1;
     const int kparts = std::max(pick_parts(n_win, nblk * W_C, avg_wq / 2, 16), exact_parts(max_sites));
     if (kparts > 1) (void)hipMemsetAsync(Cmat, 0, (size_t)n_win * n_units * n_units * 4, st);
-    // ring shape (pairs of groups per stage, stages): PG_TILE_CFG = 0: 2 x 3, 1: 4 x 2 (half the barriers), 2: 2 x 2 (default; measured
-    // on the north-star shape: 1.31 / 1.28 / 1.24 ms)
-    const char *cfg_s = getenv("PG_TILE_CFG");
-    int cfg = cfg_s ? atoi(cfg_s) : 2;
-    if (cfg == 1 && (size_t)2 * 2 * 4 * NPv * 16 > 64 * 1024) cfg = 0;
-    const int gp = cfg == 1 ? 4 : 2, nst = cfg == 0 ? 3 : 2;
+    // ring shape: 2 pairs of groups per stage, 2 stages (measured on the north-star shape against 2 x 3 and 4 x 2: 1.24 / 1.31 / 1.28 ms)
+    constexpr int gp = 2, nst = 2;
     const int stage_u4 = 2 * gp * NPv, chunks = stage_u4 / 64, nl = (chunks + W_C - 1) / W_C;
     const size_t lds_bytes = (size_t)nst * stage_u4 * 16;
     const int64_t blocks = (int64_t)((n_win + 7) / 8) * nblk * kparts * 8;
-#define PG_LAUNCH_C(GP, NST)                                                                                                          \
-    hipLaunchKernelGGL((k_pairC_tile<CS_C, W_C, GP, NST>), dim3((unsigned)blocks), dim3(64 * W_C), lds_bytes, st, Vp, vgoff, n_win, T, nblk, \
-                       kparts, NPv, n_units, diag, prog, nl, Cmat)
-    if (cfg == 1) PG_LAUNCH_C(4, 2);
-    else if (cfg == 2) PG_LAUNCH_C(2, 2);
-    else PG_LAUNCH_C(2, 3);
-#undef PG_LAUNCH_C
-    return 0;
-}
-
-int pg_launch_pairD_tile(hipStream_t st, const uint32_t *XV, const int32_t *nw, const int64_t *goff, int n_win, int NP, int N,
-                         int64_t avg_words, int64_t max_vsites, int32_t *Dmat, int capg) {
-    if (n_win <= 0 || N <= 0) return 0;
-    const int T = (N + 31) / 32;
-    const int32_t *prog;
-    int nblk;
-    if (get_program(T, CS_D, W_D, &prog, &nblk) != 0) return -1;
-    const int kparts = std::max(pick_parts(n_win, nblk * W_D, avg_words / 2, 16), exact_parts(max_vsites));
-    if (kparts > 1) (void)hipMemsetAsync(Dmat, 0, (size_t)n_win * N * N * 4, st);
-    const int stage_u4 = 2 * KD_D * NP / 2, chunks = stage_u4 / 64, nl = (chunks + W_D - 1) / W_D;
-    const size_t lds_bytes = (size_t)NSTG * stage_u4 * 16;
-    const int64_t blocks = (int64_t)((n_win + 7) / 8) * nblk * kparts * 8;
-    hipLaunchKernelGGL((k_pairD_tile<CS_D, W_D, KD_D>), dim3((unsigned)blocks), dim3(64 * W_D), lds_bytes, st, XV, nw, goff, n_win, T, nblk,
-                       kparts, NP, N, prog, nl, Dmat, capg);
+    hipLaunchKernelGGL((k_pairC_tile<CS_C, W_C, gp, nst>), dim3((unsigned)blocks), dim3(64 * W_C), lds_bytes, st, Vp, vgoff, n_win, T, nblk,
+                       kparts, NPv, n_units, diag, prog, nl, Cmat);
     return 0;
 }

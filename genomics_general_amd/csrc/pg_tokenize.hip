@@ -378,9 +378,7 @@ static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, in
     // create and four reach the link's rate), while its other buffer is still in flight: no thread waits for another, the queue
     // of copies stays deep enough to keep PCIe busy, and the threads are started once per block (the first version started up to
     // 16 threads per 32 MiB piece and copied one piece at a time: 41 GB/s of text on a 57 GB/s link; this one 55).
-    const bool dbg = getenv("PG_TOK_DEBUG") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     const auto t_stage0 = now();
     if ((rc = T.text.ensure((size_t)len + 32)) != PG_OK) return rc;
     {
@@ -389,19 +387,13 @@ static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, in
         nt = nt < 1 ? 1 : (nt > PG_TOK_WORKERS ? PG_TOK_WORKERS : nt);
         const int64_t n_chunks = (len + (int64_t)CH - 1) / (int64_t)CH;
         const int use = (int)std::min<int64_t>(nt, n_chunks);
-        int n_streams = std::min(use, PG_TOK_STREAMS);
-        if (const char *e = getenv("PG_TOK_STREAMS")) n_streams = std::max(1, std::min(use, atoi(e)));
-        auto t1 = now();
+        const int n_streams = std::min(use, PG_TOK_STREAMS);
         if ((rc = c->tok_pin.ensure((size_t)use * 2 * CH)) != PG_OK) return rc;
-        if (dbg) fprintf(stderr, "tok: page-locked staging %.2f ms\n", ms_since(t1));
-        t1 = now();
         for (int t = 0; t < use; ++t) {
             if (t < n_streams && !c->tok_st[t]) HIPCHK(hipStreamCreateWithFlags(&c->tok_st[t], hipStreamNonBlocking));
             for (int b = 0; b < 2; ++b)
                 if (!c->tok_wev[t][b]) HIPCHK(hipEventCreateWithFlags(&c->tok_wev[t][b], hipEventDisableTiming));
         }
-        if (dbg) fprintf(stderr, "tok: streams + events %.2f ms\n", ms_since(t1));
-        t1 = now();
         std::atomic<int64_t> next{0};
         std::atomic<int> failed{0};                              // 1 = read error, 2 = HIP error
         uint8_t *dtext = T.text.p;
@@ -430,7 +422,6 @@ static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, in
         for (int t = 1; t < use; ++t) th.emplace_back(work, t);
         work(0);
         for (auto &x : th) x.join();
-        if (dbg) fprintf(stderr, "tok: copies %.2f ms (%d threads, %d streams)\n", ms_since(t1), use, n_streams);
         if (failed.load() == 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_file: cannot read %lld bytes at offset %lld", (long long)len, (long long)src.off);
         if (failed.load()) return pg_fail(PG_ERR_HIP, "pg_tokenize_text: a staging copy failed: %s", hipGetErrorString(hipGetLastError()));
     }

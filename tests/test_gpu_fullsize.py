@@ -121,7 +121,7 @@ def test_integer_matrices_are_additive_over_a_split_window_and_bounded(c2):
     assert C[0].sum() > 0 and D[0].sum() > 0
 
 
-@pytest.mark.parametrize("env", ["PG_NO_DIP", "PG_OVERLAP", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none"])
+@pytest.mark.parametrize("env", ["PG_NO_DIP", "PG_OVERLAP", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_TILE=c", "PG_PAIR_TILE=none"])
 def test_independent_pipelines_agree_at_full_window_size(c2, env, monkeypatch):
     e, lay, lo, hi = c2
     sel = [0, 61, 199]

@@ -24,8 +24,8 @@ def oracle_aln(lay, codes, lo, hi):
     (150, 4, 1500, [(0, 700), (700, 1500)]),                                     # several 64-column chunks
     (530, 3, 2200, [(0, 2200), (100, 421), (2150, 2200)]),                        # > 1024 haplotype slots: presence pre-pass
 ])
-@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_VALU", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none", "PG_PACK_BURST=0",
-                                  "PG_PACK_FQ=3", "PG_GROUP_WORDS=20"])
+@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_VALU", "PG_PAIR_TILE=c", "PG_PAIR_TILE=none", "PG_PACK_BURST=0",
+                                  "PG_GROUP_WORDS=20"])
 def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins, pack, monkeypatch):
     G.set_mode(monkeypatch, pack)
     e, lay, codes, _ = G.make_engine(n_dip, n_pops, L, seed=11 + n_dip)
@@ -46,8 +46,8 @@ def test_pairwise_counts_bit_exact(n_dip, n_pops, L, wins, pack, monkeypatch):
     (150, 1500, 0.1, "uniform"),       # two waves per block: list / flush code behind block barriers
     (300, 800, 0.2, "mixed"),          # four waves per block
 ])
-@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_VALU", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none", "PG_PACK_BURST=0",
-                                  "PG_PACK_FQ=3", "PG_GROUP_WORDS=20"])
+@pytest.mark.parametrize("pack", ["default", "PG_PACK2", "PG_GROUP_WORDS=128", "PG_PAIR_VALU", "PG_PAIR_TILE=c", "PG_PAIR_TILE=none", "PG_PACK_BURST=0",
+                                  "PG_GROUP_WORDS=20"])
 def test_pairwise_counts_with_three_and_four_alleles_per_site(n_dip, L, p_miss, mix, pack, monkeypatch):
     """sites with k alleles become k-1 virtual biallelic sites in k_pack2 / k_pack3 (both kernels at every block size: one, two
     and four waves); D must still be the plain Hamming count.  The uniform cases overflow the default XV reservation: the
@@ -241,7 +241,7 @@ def test_errors_are_loud_not_fatal():
     e.close()
 
 
-@pytest.mark.parametrize("mode", ["default", "PG_NO_DIP", "PG_PAIR_VALU", "PG_PAIR_TILE=cd", "PG_PAIR_TILE=none"])
+@pytest.mark.parametrize("mode", ["default", "PG_NO_DIP", "PG_PAIR_VALU", "PG_PAIR_TILE=c", "PG_PAIR_TILE=none"])
 def test_every_pairwise_code_path_gives_the_same_integers(mode, monkeypatch):
     """diploid fast path (called counts per individual), per-haplotype called counts, popcount kernels, and the matrix-core kernels
     in both forms (LDS-staged blocks, one-wave blocks)"""
@@ -620,3 +620,46 @@ def test_individual_pair_means_from_supplied_counts_equal_the_fused_path(include
     summed = e.indPairTableFromCounts((D[1] + D[2])[None], (C[1] + C[2])[None], includeSameWithSame=include_same)
     assert np.array_equal(summed[0], want[0], equal_nan=True)
     e.close()
+
+
+def test_populations_that_split_an_individual_take_the_general_finaliser():
+    """pg_set_samples takes per-haplotype populations; a C-ABI caller may put the two haplotypes of a diploid
+    individual into different populations (odd population boundaries).  The individual-wise fast forms of k_popdist_fin (8-byte
+    loads at even slots) must not run then: sums of D / C per population pair == the plain sums over the pair matrices"""
+    import ctypes as C
+    from genomics_general_amd import _lib
+    from genomics_general_amd._lib import check
+    L = _lib.lib()
+    rng = np.random.default_rng(77)
+    n_hap, n_sites = 16, 900
+    hap_pop = np.array([0] * 5 + [1] * 4 + [2] * 7, dtype=np.int32)           # boundaries at slots 5 and 9: inside individuals 2 and 4
+    hap_sample = np.repeat(np.arange(8), 2).astype(np.int32)
+    codes = (1 << rng.integers(0, 2, size=(n_sites, n_hap))).astype(np.int8)
+    miss = rng.random((n_sites, n_hap // 2)) < 0.1
+    codes[np.repeat(miss, 2, axis=1)] = 0                                    # a genotype is missing as a whole
+    h = C.c_void_p()
+    check(L.pg_ctx_create(C.byref(h), 0))
+    check(L.pg_set_samples(h, n_hap, hap_pop, hap_sample, 3))
+    check(L.pg_reserve_sites(h, n_sites))
+    check(L.pg_upload_sites(h, 0, np.ascontiguousarray(codes), n_sites))
+    lo, hi = np.array([0, 300], dtype=np.int64), np.array([300, 900], dtype=np.int64)
+    D = np.zeros((2, n_hap, n_hap), dtype=np.int32)
+    Cc = np.zeros((2, n_hap, n_hap), dtype=np.int32)
+    check(L.pg_pairwise(h, lo, hi, 2, D, Cc))
+    sums, cnts = np.zeros((2, 6)), np.zeros((2, 6), dtype=np.int64)
+    check(L.pg_popdist(h, lo, hi, 2, 1, sums, cnts))
+    L.pg_ctx_destroy(h)
+    start = [0, 5, 9, 16]
+    for w in range(2):
+        k = 0
+        for x in range(3):
+            for y in range(x, 3):
+                tot, n = 0.0, 0
+                for i in range(start[x], start[x + 1]):
+                    for j in range(start[y], start[y + 1]):
+                        if (x == y and j <= i) or Cc[w, i, j] < 1:
+                            continue
+                        tot += D[w, i, j] / Cc[w, i, j]
+                        n += 1
+                assert cnts[w, k] == n and abs(sums[w, k] - tot) < 1e-9, (w, x, y, sums[w, k], tot, cnts[w, k], n)
+                k += 1

@@ -106,3 +106,20 @@ def test_generated_pair_kernel_loops_are_what_the_generator_writes():
         w = re.match(r"v_\w+ v(\d+),", ins)
         recent.append({int(w.group(1))} if w else set())
     assert n_mfma == 8 * sum(t * (t + 1) // 2 for t in range(1, 8))        # two unrolled pairs x four K steps x the tiles of T = 1 .. 7
+
+
+def test_roofline_traffic_comes_from_the_newest_profile_round():
+    """bench.py's roofline.traffic is the committed figure of the last `rocprofv3 --pmc` passes (profiles/hbm_traffic.json), not a
+    live counter: it must not go stale silently -- every workload's `_source` names the newest profiles/rNN directory, and that
+    directory holds the kernel statistics the figure belongs to"""
+    import json
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rounds = sorted(d for d in os.listdir(os.path.join(root, "profiles")) if re.fullmatch(r"r\d\d", d))
+    with open(os.path.join(root, "profiles", "hbm_traffic.json")) as f:
+        t = json.load(f)
+    assert rounds and set(t["_source"].values()) == {rounds[-1]}, (rounds, t["_source"])
+    for wl in t["_source"]:
+        assert os.path.exists(os.path.join(root, "profiles", rounds[-1], wl + "_kernel_stats.csv"))
+        assert os.path.exists(os.path.join(root, "profiles", rounds[-1], wl + "_pmc_summary.json"))
