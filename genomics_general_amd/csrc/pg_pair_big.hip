@@ -2,7 +2,7 @@
 //
 // The same exact products as pg_pair_tile.hip / pg_pair_mfma.hip (C = V V^T over the called plane as MX fp4 nibbles;
 // genomics.py:1042-1047), for planes of up to 224 units (7 tiles of 32: the shapes of BASELINE.json's popgenWindows configs).
-// What the counters say about the other two forms: they spend 5 - 9 vector instructions per matrix
+// What the counters say about the other two forms (HISTORY.md section 4): they spend 5 - 9 vector instructions per matrix
 // instruction and fill 77 % of the chip's issue slots while the matrix pipes idle half the time.  Here a wave owns up to 14 tiles
 // (accumulators in the accumulator half of the register file), so a fragment it expands feeds up to seven products -- 1.75 to 3.5
 // vector instructions per product --, and the whole main loop is one generated, hand-scheduled instruction stream

@@ -1,4 +1,4 @@
-// Micro-benchmark behind DESIGN.md's pricing of the pair kernels against the matrix pipe of gfx950: cycles per instruction
+// Micro-benchmark behind HISTORY.md's pricing of the pair kernels against the matrix pipe of gfx950: cycles per instruction
 // (s_memtime, the shader clock) and the clock itself (against the 100 MHz s_memrealtime) of
 //   * back-to-back independent v_mfma_f32_32x32x64_f8f6f4 / v_mfma_f32_16x16x128_f8f6f4 on fp4 operands,
 //   * the same with VALU operations between them that rewrite the fragment of the product after next (what k_pairC_big does),
