@@ -550,6 +550,31 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
                         "through popgenWindows.py, timed inside the driver (total_s: from opening the input to the last row; the device "
                         "context is created beside the opening of the input, context_s is what was still waited for)" % (
                             n_txt, size / 1e9, len(rows), write_s)}
+        # the same file on TWO ranks (both on this GPU, so the rows travel through files and the ranks share one PCIe link: not a
+        # scaling number): the drivers' multi-GPU plan at the size of real data -- every rank reads, tokenises and computes its
+        # window range of the ONE scaffold, the gathered CSV is the single-rank one
+        try:
+            csv2 = os.path.join(tmp, "out2.csv")
+            cmd2 = [c if c != csv else csv2 for c in cmd]
+            procs = []
+            for r in range(2):
+                env = dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1", PG_COMM="file", RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2",
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", PG_RDZV_FILE=os.path.join(tmp, "rdzv"))
+                procs.append(subprocess.Popen(cmd2, env=env, stderr=subprocess.PIPE, stdout=subprocess.PIPE))
+            tms = []
+            for pr in procs:
+                _, err = pr.communicate(timeout=900)
+                tms += [json.loads(ln[len("PG_TIMING "):]) for ln in err.decode().splitlines() if ln.startswith("PG_TIMING ")]
+            with open(csv) as f, open(csv2) as g:
+                same2 = f.read() == g.read()
+            t2["two_ranks_one_gpu"] = {"csv_equals_single_rank": bool(same2), "window_ranges": all(t.get("window_ranges") for t in tms),
+                                       "rank_bytes_share": [round(t["text_bytes"] / size, 4) for t in sorted(tms, key=lambda t: t["rank"])],
+                                       "rank_sites": [t["sites"] for t in sorted(tms, key=lambda t: t["rank"])],
+                                       "plan_scanned_bytes": [t.get("plan_scanned_bytes") for t in sorted(tms, key=lambda t: t["rank"])],
+                                       "total_s": [round(t["total_s"], 4) for t in sorted(tms, key=lambda t: t["rank"])],
+                                       "note": "both ranks on one GPU and one PCIe link, PG_COMM=file: shows the plan and the gather, not a speed-up"}
+        except Exception as exc:
+            t2["two_ranks_one_gpu"] = {"error": repr(exc)[:300]}
     except Exception as exc:                                    # the tiers are side information: never lose the main line
         t2 = {"error": repr(exc)[:300]}
     finally:
@@ -899,15 +924,30 @@ def main():
     # ---- N >= 8: the rank's share of BASELINE.json configs[4] (3e9 sites / N: 150 GB resident at N = 8) behind the headline.  The
     # headline stays on ONE shape for N = 1, 2, 4, 8, so that a scaling curve compares like with like; this is the same pass at the
     # size config 5 asks for, a few steps, the gather inside the time
-    if world.size >= 8 and args.workload == "northstar" and not args.strong and not args.no_c5:
+    c5_total = int(os.environ.get("PG_BENCH_C5_SITES", 3_000_000_000))        # (a smaller total lets a test run this section on one GPU)
+    if world.size >= 8 and (args.workload == "northstar" or "PG_BENCH_C5_SITES" in os.environ) and not args.strong and not args.no_c5:
+        # (every rank decides together after each phase: a rank that fails -- out of memory on its 150 GB -- must not leave the others
+        # waiting in an exchange it never enters)
+        def all_ranks_ok(fn):
+            ok, out, msg = 1.0, None, ""
+            try:
+                out = fn()
+            except Exception as exc:
+                ok, msg = 0.0, repr(exc)[:300]
+            good = bool(comm.allgather(np.array([ok])).min() > 0)
+            return good, out, msg
         try:
             wl5 = dict(WORKLOADS["c5"])
-            wl5["n_sites"] = 3_000_000_000 // world.size // (wl5["n_scaf"] * wl5["wind"]) * (wl5["n_scaf"] * wl5["wind"])
-            d5 = setup_data(wl5)
+            wl5["n_sites"] = c5_total // world.size // (wl5["n_scaf"] * wl5["wind"]) * (wl5["n_scaf"] * wl5["wind"])
+            if wl["n_dip"] != wl5["n_dip"]:
+                wl5.update(n_dip=wl["n_dip"], n_pops=wl["n_pops"])           # (the layout of the run is the headline workload's)
+            good, d5, msg = all_ranks_ok(lambda: setup_data(wl5))
+            if good:
+                good, _, msg = all_ranks_ok(lambda: (step(d5["lo"], d5["hi"]), eng.sync()))
+            if not good:
+                raise RuntimeError("a rank could not set up its share: " + (msg or "(another rank)"))
             c5_counts = np.full(world.size, float(d5["n_win"]))
             cols_seen.clear()
-            step(d5["lo"], d5["hi"])
-            eng.sync()
             comm.barrier()
             c0 = time.perf_counter()
             for _ in range(3):

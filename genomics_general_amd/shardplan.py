@@ -206,8 +206,13 @@ def coord_cut(text, off, w, step, wanted):
                 return Cut(text.end_token())
             continue
         k0 = max(1, _ceil_div(p, step))                          # the first window that starts behind p (rows in front of the probe may share its position)
-        a, sa, _ = text.seek(off, scaf, 1 + k0 * step)              # the rank's first line
-        b, sb, _ = text.seek(off, scaf, w + (k0 - 1) * step + 1)    # the first line beyond window k0 - 1
+        p0, e1 = 1 + k0 * step, w + (k0 - 1) * step + 1             # the rank's first position; the first position beyond window k0 - 1
+        if e1 <= p0:                                                # (one walk: the farther line is looked for from the nearer one on)
+            b, sb, _ = text.seek(off, scaf, e1)
+            a, sa, _ = text.seek(b, scaf, p0) if sb == 1 else (b, sb, 0)
+        else:
+            a, sa, _ = text.seek(off, scaf, p0)
+            b, sb, _ = text.seek(a, scaf, e1) if sa == 1 else (a, sa, 0)
         if sa == 1 and sb == 1:
             return Cut(text.token(a), text.token(b), k0, name)
         x, st = (a, sa) if sa != 1 else (b, sb)                     # the run ends first: cut where the next run begins

@@ -97,6 +97,15 @@ def test_bench_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["comm_ranks"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert d["config"]["name"] == "tiny" and "result_allgather_ms_per_step" in d
     assert d["config"]["windows_per_gpu"] * 2 * 3 / (d["ms_per_step"] * 3 / 1e3) == pytest.approx(d["value"], rel=1e-3)
+    # 8 ranks: the headline keeps its shape, the rank's share of configs[4] is measured behind it (here a small total, so that eight
+    # ranks fit the one GPU of the box); a share that cannot be set up is an `error` entry, never a hang
+    env8 = dict(env, PG_BENCH_C5_SITES="2400000")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-tiers"], env=env8, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["config"]["name"] == "tiny" and d["scaling"] == "weak"
+    assert d["c5_share"].get("windows_per_gpu") == 6 and d["c5_share"]["windows_per_sec"] > 0, d["c5_share"]
     # --strong: ONE data set, cut into window ranges by the drivers' plan (shardplan); both ranks must get work, together all of it
     for n in (2, 3):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--workload", "tiny", "--steps", "2", "--warmup", "1",
