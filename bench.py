@@ -481,6 +481,47 @@ def write_geno_resident(path, eng, lay, names, n_rows, scaf="chr1", workers=0):
     return off
 
 
+def write_pgeno_resident(path, eng, lay, names, n_rows, scaf="chr1", workers=0):
+    """The first n_rows resident rows as a `.pgeno` file with raw cells (codec none: one byte per diploid genotype, first allele's
+    one-hot code | second << 4; genomics_general_amd/genoio.py, tools/geno_pack.py): blocks of a million rows rendered by a pool of
+    threads, every block written at its own offset."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from genomics_general_amd import genoio
+    n = len(names)
+    s0 = np.array([lay.ind_slots[nm][0] for nm in names])
+    head = json.dumps({"names": list(names), "ploidy": [2] * n, "codec": "none"}).encode()
+    pre = genoio.PGENO_MAGIC + len(head).to_bytes(4, "little") + head
+    sb = scaf.encode()
+    tasks, off, step = [], len(pre), 1_000_000
+    for a in range(0, n_rows, step):
+        b = min(n_rows, a + step)
+        tasks.append((a, b, off))
+        off += 8 + 4 + 8 + 2 + len(sb) + (b - a) * (4 + n)
+    lock = threading.Lock()
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    os.pwrite(fd, pre, 0)
+    os.pwrite(fd, (0).to_bytes(8, "little"), off)                   # the terminating block
+
+    def render(task):
+        a, b, at = task
+        with lock:
+            rows = eng.download(a, b - a).view(np.uint8)
+        blk = ((b - a).to_bytes(8, "little") + (1).to_bytes(4, "little") + (0).to_bytes(8, "little") + len(sb).to_bytes(2, "little") + sb +
+               np.arange(a + 1, b + 1, dtype="<i4").tobytes())
+        os.pwrite(fd, blk, at)
+        cells = rows[:, s0] | (rows[:, s0 + 1] << 4)
+        buf, done = memoryview(np.ascontiguousarray(cells)).cast("B"), 0
+        while done < len(buf):
+            done += os.pwrite(fd, buf[done:done + (1 << 30)], at + len(blk) + done)
+    try:
+        with ThreadPoolExecutor(workers or min(32, os.cpu_count() or 1)) as ex:
+            list(ex.map(render, tasks))
+    finally:
+        os.close(fd)
+    return off + 8
+
+
 def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
     """Tier T2 (the only tier whose work is the reference's: `.geno` text in, CSV out): the head of the workload's
     first scaffold as text on disk (written before the clock starts, so it sits in the page cache like a file a pipeline has just
@@ -493,7 +534,7 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
     want = int(os.environ.get("PG_BENCH_T2_SITES", T2_SITES))
     tmp = tempfile.mkdtemp(prefix="pg_bench_t2_")
     geno, csv = os.path.join(tmp, "sample.geno"), os.path.join(tmp, "out.csv")
-    line_bytes = 4 * len(names) + 16
+    line_bytes = 5 * len(names) + 20                                  # the text + the same sites once more as packed cells
     room = shutil.disk_usage(tmp).free * 0.4
     try:
         import psutil
@@ -550,6 +591,34 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
                         "through popgenWindows.py, timed inside the driver (total_s: from opening the input to the last row; the device "
                         "context is created beside the opening of the input, context_s is what was still waited for)" % (
                             n_txt, size / 1e9, len(rows), write_s)}
+        # the same sites as a `.pgeno` file with raw cells (what `parseVCF.py --packed` / tools/geno_pack.py keep instead of the text:
+        # 1 byte per genotype instead of 4): the staging threads read the cells from the file, k_unpack expands them on the device
+        try:
+            pg, csv3 = os.path.join(tmp, "sample.pgeno"), os.path.join(tmp, "out3.csv")
+            w0 = time.perf_counter()
+            psize = write_pgeno_resident(pg, eng, lay, names, n_txt)
+            pwrite_s = time.perf_counter() - w0
+            cmd3 = [pg if c == geno else csv3 if c == csv else c for c in cmd]
+            r3 = subprocess.run(cmd3, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE,
+                                timeout=900)
+            line3 = [ln for ln in r3.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")]
+            if not line3:
+                raise RuntimeError("popgenWindows.py: " + r3.stderr.decode()[-300:])
+            tp = json.loads(line3[-1][len("PG_TIMING "):])
+            with open(csv) as f, open(csv3) as g:
+                same3 = f.read() == g.read()
+            work3 = tp["total_s"] - tp.get("context_s", 0.0)
+            t2["packed"] = {"sites_per_sec": round(n_txt / tp["total_s"], 1), "windows_per_sec": round(len(rows) / tp["total_s"], 3),
+                            "file_bytes": psize, "cells_GBps": round(psize / tp["total_s"] / 1e9, 2), "csv_equals_text_run": bool(same3),
+                            "from_file_to_device": bool(tp.get("packed_cells_from_file")),
+                            "without_context_creation": {"seconds": round(work3, 4), "sites_per_sec": round(n_txt / work3, 1),
+                                                         "cells_GBps": round(psize / work3 / 1e9, 2)},
+                            "seconds": {k: round(tp[k], 4) for k in ("total_s", "context_s", "read_s", "tokenize_s", "tokenizer_h2d_s", "windows_s",
+                                                                      "prep_wait_s", "compute_and_write_s") if k in tp},
+                            "sample": "the same %d sites as %.1f GB of `.pgeno` (raw cells, written in %.1f s before the clock starts) through "
+                                      "popgenWindows.py" % (n_txt, psize / 1e9, pwrite_s)}
+        except Exception as exc:
+            t2["packed"] = {"error": repr(exc)[:300]}
         # the same file on TWO ranks (both on this GPU, so the rows travel through files and the ranks share one PCIe link: not a
         # scaling number): the drivers' multi-GPU plan at the size of real data -- every rank reads, tokenises and computes its
         # window range of the ONE scaffold, the gathered CSV is the single-rank one

@@ -62,6 +62,9 @@ SIGNATURES = {
     "pg_tokenize_parse": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "pg_tokenize_collect": (C.c_int, [_P, C.c_int, _i32p, C.c_int64, _i64p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "pg_stage_file": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "pg_unpack_staged": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int, _i32p, C.c_int64]),
+    "pg_stage_sync": (C.c_int, [_P]),
     "pg_tokenize_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pg_move_rows": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64]),
     "pg_synth_fill": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32,

@@ -468,9 +468,12 @@ class Run:
         of blanks, carriage returns, a cell of another width) is found by the kernels block by block, and such a block goes
         through the host tokenizer."""
         import os
-        if os.environ.get("PG_GPU_TOKENIZER", "1") == "0" or not hasattr(self.engine, "tokenize_text"):
-            return False
         if getattr(self._reader, "packed", False):
+            # `.pgeno` with raw cells (codec none): the cells go from the file to the device through the same staging threads and
+            # are expanded there (pg_stage_file / pg_unpack_staged); deflated cells are inflated by host threads (chunks())
+            return (getattr(self._reader, "codec", None) == "none" and hasattr(self.engine, "stage_file")
+                    and not os.environ.get("PG_HOST_UNPACK"))
+        if os.environ.get("PG_GPU_TOKENIZER", "1") == "0" or not hasattr(self.engine, "tokenize_text"):
             return False
         return device_tokenizer_takes(self.layout)
 
@@ -555,11 +558,49 @@ class Run:
                     raise body
             return body, time.perf_counter() - t0
 
+        packed = bool(getattr(self._reader, "packed", False))
+        staged = {}                                   # packed route: slot -> [(offset in the staging buffer, rows)], positions
+
         def submit(body, slot):
-            """the block's text on its way to the device (slot 0 / 1); False: the fast path does not take it"""
+            """the block's text (or packed cells) on its way to the device (slot 0 / 1); False: the fast path does not take it"""
+            if packed:
+                if not len(body):
+                    return False
+                nc = self._reader.n_cols
+                total = sum(b.n for b in body) * nc
+                parts, at = [], 0
+                for b in body:
+                    eng.stage_file(slot, b.fd, b.cells_off, b.n * nc, at, total)
+                    parts.append((at, b.n))
+                    at += b.n * nc
+                staged[slot] = (parts, np.concatenate([b.positions() for b in body]).astype(np.int32, copy=False))
+                return True
             if not len(body) or not hasattr(eng, "tokenize_submit"):
                 return False
             return eng.tokenize_submit(body, slot, file=self._reader.file_range(body) if hasattr(self._reader, "file_range") else None)
+
+        def parse(slot, row_offset, cap):
+            if not packed:
+                return eng.tokenize_parse(slot, row_offset, cap)
+            row = row_offset
+            for at, n in staged[slot][0]:             # k_unpack per block of the file, queued on the copy stream
+                eng.unpack_staged(slot, at, n, self._reader.n_cols, self.layout.slot_src, row)
+                row += n
+            return row - row_offset
+
+        def collect(slot, body, n_lines):
+            if not packed:
+                return eng.tokenize_collect(slot, body, n_lines)
+            eng.stage_sync()
+            starts, names, row = [], [], 0
+            for b in body:
+                for s_, n_ in zip(b.starts, b.names):
+                    if names and names[-1] == n_ and int(s_) == 0:
+                        continue                      # the run continues across the seam of two blocks of the file
+                    starts.append(row + int(s_))
+                    names.append(n_)
+                row += b.n
+            return n_lines, staged.pop(slot)[1], np.asarray(starts, dtype=np.int64), names
 
         def ingest():
             carry, carry_row0, k = None, 0, 0
@@ -576,7 +617,10 @@ class Run:
                     tm["half_wait_s"] = time.perf_counter() - t0
                     t0 = time.perf_counter()
                     c_n = carry.n_sites if carry is not None else 0
-                    bound = row_bound(body) if len(body) else 0
+                    if packed:
+                        bound = sum(b.n for b in body)
+                    else:
+                        bound = row_bound(body) if len(body) else 0
                     if bound is None:
                         bound, sub = count(body), False       # (not a regular first line: the host tokenizer will take the block)
                     saved = None
@@ -588,12 +632,12 @@ class Run:
                     elif c_n:
                         eng.move_rows(carry_row0, base, c_n)
                     # parse(k) is queued, then the text of block k+1 crosses PCIe while those kernels run, then the results of k
-                    n_lines = eng.tokenize_parse(k % 2, base + c_n, bound) if sub else None
+                    n_lines = parse(k % 2, base + c_n, bound) if sub else None
                     nxt, nxt_sub, read_s = None, False, 0.0
                     if not final:
                         nxt, read_s = fetch()
                         nxt_sub = submit(nxt, (k + 1) % 2)
-                    got = eng.tokenize_collect(k % 2, body, n_lines) if n_lines is not None else None
+                    got = collect(k % 2, body, n_lines) if n_lines is not None else None
                     if got is not None:
                         n, pos, starts, names = got
                         block = genoio.GenoData(None, pos, starts, names)
@@ -635,7 +679,17 @@ class Run:
             threading.Thread(target=produce, daemon=True).start()
         threading.Thread(target=ingest, daemon=True).start()
         self.timing["device_tokenizer"] = 1
+        self.timing["packed_cells_from_file"] = int(packed)
         self.timing["host_tokenized_blocks"] = 0
+        if packed:
+            lay = self.layout
+            if len(lay.col_ploidy) != self._reader.n_cols:
+                raise ValueError("layout was built for %d columns, the file has %d" % (len(lay.col_ploidy), self._reader.n_cols))
+            wanted_cols = lay.col_ploidy > 0
+            if np.any(lay.col_ploidy[wanted_cols] != self._reader.ploidy[wanted_cols]):
+                bad = int(np.flatnonzero(wanted_cols & (lay.col_ploidy != self._reader.ploidy))[0])
+                raise ValueError("sample %s was packed with ploidy %d but ploidy %d is requested" % (
+                    self._reader.names[bad], int(self._reader.ploidy[bad]), int(lay.col_ploidy[bad])))
         import sys
         switch = sys.getswitchinterval()
         sys.setswitchinterval(0.0005)             # the ingestion thread needs the interpreter for microseconds between two native calls:

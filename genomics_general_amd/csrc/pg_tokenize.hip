@@ -290,6 +290,61 @@ struct TokSource {
     }
 };
 
+// ---- bytes to the device: self-paced staging threads ----
+// Every thread takes the next 4 MiB chunk, brings it into one of its two page-locked buffers (pread / memcpy) and queues its copy
+// to the device on a copy stream (four streams serve the eight threads: a stream costs 4 ms to create and four reach the link's
+// rate), while its other buffer is still in flight: no thread waits for another, the queue of copies stays deep enough to keep PCIe
+// busy, and the threads are started once per call (the first version started up to 16 threads per 32 MiB piece and copied one
+// piece at a time: 41 GB/s of text on a 57 GB/s link; this one 55).  Returns when every byte has landed.
+static int stage_bytes(pg_ctx *c, const TokSource &src, int64_t len, uint8_t *dst) {
+    if (len <= 0) return PG_OK;
+    int rc;
+    constexpr size_t CH = 4u << 20;
+    int nt = pg_host_threads();
+    nt = nt < 1 ? 1 : (nt > PG_TOK_WORKERS ? PG_TOK_WORKERS : nt);
+    const int64_t n_chunks = (len + (int64_t)CH - 1) / (int64_t)CH;
+    const int use = (int)std::min<int64_t>(nt, n_chunks);
+    const int n_streams = std::min(use, PG_TOK_STREAMS);
+    if ((size_t)use * 2 * CH > c->tok_pin.cap) {
+        if ((rc = c->tok_pin.ensure((size_t)PG_TOK_WORKERS * 2 * CH)) != PG_OK) return rc;
+    }
+    for (int t = 0; t < use; ++t) {
+        if (t < n_streams && !c->tok_st[t]) HIPCHK(hipStreamCreateWithFlags(&c->tok_st[t], hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b)
+            if (!c->tok_wev[t][b]) HIPCHK(hipEventCreateWithFlags(&c->tok_wev[t][b], hipEventDisableTiming));
+    }
+    std::atomic<int64_t> next{0};
+    std::atomic<int> failed{0};                              // 1 = read error, 2 = HIP error
+    auto work = [&](int t) {
+        if (hipSetDevice(c->device) != hipSuccess) { failed.store(2); return; }
+        hipStream_t ws = c->tok_st[t % n_streams];
+        bool used[2] = {false, false};
+        int b = 0;
+        for (;;) {
+            const int64_t ci = next.fetch_add(1);
+            if (ci >= n_chunks || failed.load()) break;
+            const int64_t a = ci * (int64_t)CH;
+            const size_t n = (size_t)std::min<int64_t>((int64_t)CH, len - a);
+            uint8_t *pin = c->tok_pin.p + ((size_t)t * 2 + b) * CH;
+            if (used[b] && hipEventSynchronize(c->tok_wev[t][b]) != hipSuccess) { failed.store(2); break; }
+            if (!src.read(a, pin, n)) { failed.store(1); break; }
+            if (hipMemcpyAsync(dst + a, pin, n, hipMemcpyHostToDevice, ws) != hipSuccess ||
+                hipEventRecord(c->tok_wev[t][b], ws) != hipSuccess) { failed.store(2); break; }
+            used[b] = true;
+            b ^= 1;
+        }
+        for (int k = 0; k < 2; ++k)                          // (the stream is shared: wait for the own copies, not for the stream)
+            if (used[k] && hipEventSynchronize(c->tok_wev[t][k]) != hipSuccess) failed.store(2);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < use; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    if (failed.load() == 1) return pg_fail(PG_ERR_ARG, "cannot read %lld bytes at offset %lld of the input", (long long)len, (long long)src.off);
+    if (failed.load()) return pg_fail(PG_ERR_HIP, "a staging copy failed: %s", hipGetErrorString(hipGetLastError()));
+    return PG_OK;
+}
+
 static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, int fmt, int n_cols, int max_ploidy,
                       const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out) {
     if (!c || !col_slot || !col_ploidy || !ok_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit: null argument");
@@ -372,59 +427,10 @@ static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, in
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream_up;
     int rc;
-    // ---- text to the device: self-paced staging threads ----
-    // Every thread takes the next 4 MiB chunk of the block, brings it into one of its two page-locked buffers (pread / memcpy) and
-    // queues its copy to the device on a copy stream of its own (four streams serve the eight threads: a stream costs 4 ms to
-    // create and four reach the link's rate), while its other buffer is still in flight: no thread waits for another, the queue
-    // of copies stays deep enough to keep PCIe busy, and the threads are started once per block (the first version started up to
-    // 16 threads per 32 MiB piece and copied one piece at a time: 41 GB/s of text on a 57 GB/s link; this one 55).
     auto now = [] { return std::chrono::steady_clock::now(); };
     const auto t_stage0 = now();
     if ((rc = T.text.ensure((size_t)len + 32)) != PG_OK) return rc;
-    {
-        constexpr size_t CH = 4u << 20;
-        int nt = pg_host_threads();
-        nt = nt < 1 ? 1 : (nt > PG_TOK_WORKERS ? PG_TOK_WORKERS : nt);
-        const int64_t n_chunks = (len + (int64_t)CH - 1) / (int64_t)CH;
-        const int use = (int)std::min<int64_t>(nt, n_chunks);
-        const int n_streams = std::min(use, PG_TOK_STREAMS);
-        if ((rc = c->tok_pin.ensure((size_t)use * 2 * CH)) != PG_OK) return rc;
-        for (int t = 0; t < use; ++t) {
-            if (t < n_streams && !c->tok_st[t]) HIPCHK(hipStreamCreateWithFlags(&c->tok_st[t], hipStreamNonBlocking));
-            for (int b = 0; b < 2; ++b)
-                if (!c->tok_wev[t][b]) HIPCHK(hipEventCreateWithFlags(&c->tok_wev[t][b], hipEventDisableTiming));
-        }
-        std::atomic<int64_t> next{0};
-        std::atomic<int> failed{0};                              // 1 = read error, 2 = HIP error
-        uint8_t *dtext = T.text.p;
-        auto work = [&](int t) {
-            if (hipSetDevice(c->device) != hipSuccess) { failed.store(2); return; }
-            hipStream_t ws = c->tok_st[t % n_streams];
-            bool used[2] = {false, false};
-            int b = 0;
-            for (;;) {
-                const int64_t ci = next.fetch_add(1);
-                if (ci >= n_chunks || failed.load()) break;
-                const int64_t a = ci * (int64_t)CH;
-                const size_t n = (size_t)std::min<int64_t>((int64_t)CH, len - a);
-                uint8_t *pin = c->tok_pin.p + ((size_t)t * 2 + b) * CH;
-                if (used[b] && hipEventSynchronize(c->tok_wev[t][b]) != hipSuccess) { failed.store(2); break; }
-                if (!src.read(a, pin, n)) { failed.store(1); break; }
-                if (hipMemcpyAsync(dtext + a, pin, n, hipMemcpyHostToDevice, ws) != hipSuccess ||
-                    hipEventRecord(c->tok_wev[t][b], ws) != hipSuccess) { failed.store(2); break; }
-                used[b] = true;
-                b ^= 1;
-            }
-            for (int k = 0; k < 2; ++k)                          // (the stream is shared: wait for the own copies, not for the stream)
-                if (used[k] && hipEventSynchronize(c->tok_wev[t][k]) != hipSuccess) failed.store(2);
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < use; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto &x : th) x.join();
-        if (failed.load() == 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_file: cannot read %lld bytes at offset %lld", (long long)len, (long long)src.off);
-        if (failed.load()) return pg_fail(PG_ERR_HIP, "pg_tokenize_text: a staging copy failed: %s", hipGetErrorString(hipGetLastError()));
-    }
+    if ((rc = stage_bytes(c, src, len, T.text.p)) != PG_OK) return rc;
     c->tok_stage_s += std::chrono::duration<double>(now() - t_stage0).count();
     c->tok_bytes += len;
     // ---- line feeds: counted behind the copies, the total on its way to the host ----
@@ -615,5 +621,60 @@ extern "C" int pg_tokenize_stats(pg_ctx *c, double *stage_seconds_out, double *k
     *stage_seconds_out = c->tok_stage_s;
     *kernel_seconds_out = c->tok_kernel_s;
     *bytes_out = c->tok_bytes;
+    return PG_OK;
+}
+
+
+// ---- packed cells (`.pgeno`, codec none) straight from the file: the same staging threads, then k_unpack --------------------------
+// pg_stage_file: `len` bytes at file_offset of fd -> byte dst_offset of the slot's device staging buffer (capacity bytes are made
+// sure of when dst_offset == 0: stage a block's segments in increasing order).  pg_unpack_staged: n_rows rows of n_cols packed
+// cells at byte src_offset of that buffer -> resident rows row_offset .. (k_unpack, queued on the copy stream).  pg_stage_sync:
+// wait for everything queued on the copy stream.
+extern "C" int pg_stage_file(pg_ctx *c, int slot, int fd, int64_t file_offset, int64_t len, int64_t dst_offset, int64_t capacity) {
+    if (!c || slot < 0 || slot > 1 || fd < 0 || file_offset < 0 || len < 0 || dst_offset < 0 || dst_offset + len > capacity)
+        return pg_fail(PG_ERR_ARG, "pg_stage_file: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    pg_ctx::TokSlot &T = c->tok[slot];
+    T.state = 0;
+    int rc;
+    if ((size_t)capacity + 32 > T.text.cap) {
+        if (dst_offset != 0) return pg_fail(PG_ERR_STATE, "pg_stage_file: the staging buffer can only grow at dst_offset 0");
+        HIPCHK(hipStreamSynchronize(c->stream_up));              // (an earlier expansion may still read the old buffer)
+        if ((rc = T.text.ensure((size_t)capacity + 32)) != PG_OK) return rc;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const TokSource src{nullptr, fd, file_offset};
+    rc = stage_bytes(c, src, len, T.text.p + dst_offset);
+    c->tok_stage_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    c->tok_bytes += len;
+    return rc;
+}
+
+extern "C" int pg_unpack_staged(pg_ctx *c, int slot, int64_t src_offset, int64_t n_rows, int n_cols, const int32_t *slot_src,
+                                int64_t row_offset) {
+    if (!c || slot < 0 || slot > 1 || !slot_src || n_cols < 1 || n_rows < 0 || src_offset < 0) return pg_fail(PG_ERR_ARG, "pg_unpack_staged: bad argument");
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    if (row_offset < 0 || row_offset + n_rows > c->cap_sites) return pg_fail(PG_ERR_ARG, "rows [%lld,%lld) exceed reserved %lld", (long long)row_offset, (long long)(row_offset + n_rows), (long long)c->cap_sites);
+    pg_ctx::TokSlot &T = c->tok[slot];
+    if ((size_t)(src_offset + n_rows * n_cols) > T.text.cap) return pg_fail(PG_ERR_ARG, "pg_unpack_staged: cells beyond the staged bytes");
+    for (int h = 0; h < c->n_hap; ++h)
+        if (slot_src[h] < -1 || slot_src[h] >= 2 * n_cols) return pg_fail(PG_ERR_ARG, "slot_src[%d] = %d out of range", h, slot_src[h]);
+    if (n_rows == 0) return PG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = T.h_cols.ensure((size_t)c->n_hap)) != PG_OK) return rc;
+    if ((rc = T.dcols.ensure((size_t)c->n_hap)) != PG_OK) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream_up));                  // (the table of an earlier call may still be on its way)
+    memcpy(T.h_cols.p, slot_src, (size_t)c->n_hap * 4);
+    HIPCHK(hipMemcpyAsync(T.dcols.p, T.h_cols.p, (size_t)c->n_hap * 4, hipMemcpyHostToDevice, c->stream_up));
+    pg_launch_unpack(c->stream_up, T.text.p + src_offset, n_cols, n_rows, T.dcols.p, c->n_hap, c->gt.p + row_offset * c->S, c->S);
+    HIPCHK(hipGetLastError());
+    return PG_OK;
+}
+
+extern "C" int pg_stage_sync(pg_ctx *c) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream_up));
     return PG_OK;
 }

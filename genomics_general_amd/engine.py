@@ -248,6 +248,17 @@ class Engine:
         names = [bytes(buf[int(roff[i]):int(roff[i]) + int(rlen[i])]).decode("utf-8", "replace") for i in range(r)]
         return k, pos[:k], rrow[:r].copy(), names
 
+    # packed cells (`.pgeno`, codec none) straight from the file: the staging threads of the tokenizer read them, k_unpack expands them
+    def stage_file(self, slot, fd, file_offset, nbytes, dst_offset, capacity):
+        check(self._L.pg_stage_file(self._h, int(slot), int(fd), int(file_offset), int(nbytes), int(dst_offset), int(capacity)))
+
+    def unpack_staged(self, slot, src_offset, n_rows, n_cols, slot_src, row_offset):
+        check(self._L.pg_unpack_staged(self._h, int(slot), int(src_offset), int(n_rows), int(n_cols),
+                                       np.ascontiguousarray(slot_src, dtype=np.int32), int(row_offset)))
+
+    def stage_sync(self):
+        check(self._L.pg_stage_sync(self._h))
+
     def tokenize_stats(self):
         """{"h2d_s", "kernels_s", "bytes"} of the device tokenizer so far (pg_tokenize_stats)"""
         a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)

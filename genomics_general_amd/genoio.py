@@ -618,12 +618,39 @@ class _PackedBlock:
     """One block of a `.pgeno` file as read from disk: scaffold runs + either the materialised arrays (pos, cells) or the still
     deflated chunks (comp, table), which PackedReader.to_geno inflates straight into their destination (pg_inflate_chunks)."""
 
-    def __init__(self, starts, names, n, n_cols, pos=None, cells=None, comp=None, table=None):
+    def __init__(self, starts, names, n, n_cols, pos=None, cells=None, comp=None, table=None, fd=None, pos_off=0, cells_off=0):
         self.starts, self.names, self.n, self.n_cols = starts, names, n, n_cols
         self.pos, self.cells, self.comp, self.table = pos, cells, comp, table
+        # codec "none": the payload stays in the file until somebody wants it -- the device route reads the cells with the staging
+        # threads of the tokenizer (pg_stage_file), the host route straight into its destination
+        self.fd, self.pos_off, self.cells_off = fd, pos_off, cells_off
+
+    def in_file(self):
+        return self.fd is not None and self.pos is None and self.comp is None
+
+    def positions(self):
+        if self.in_file():
+            return np.frombuffer(os.pread(self.fd, 4 * self.n, self.pos_off), dtype="<i4")
+        self.materialise()
+        return self.pos
+
+    @staticmethod
+    def _read_into(fd, dst, off):
+        view = memoryview(dst).cast("B")
+        got = 0
+        while got < len(view):
+            k = os.preadv(fd, [view[got:got + (1 << 30)]], off + got)
+            if k <= 0:
+                raise ValueError("truncated .pgeno file")
+            got += k
 
     def inflate_into(self, pos_dst, cells_dst, n_threads=0):
         """positions -> pos_dst[n] (int32), cells -> cells_dst[n][n_cols] (uint8, C-contiguous rows)"""
+        if self.in_file():
+            assert pos_dst.flags.c_contiguous and cells_dst.flags.c_contiguous
+            self._read_into(self.fd, pos_dst, self.pos_off)
+            self._read_into(self.fd, cells_dst, self.cells_off)
+            return
         if self.comp is None:
             pos_dst[...] = self.pos
             cells_dst[...] = self.cells
@@ -638,6 +665,10 @@ class _PackedBlock:
                                            self.n * self.n_cols, n_threads))
 
     def materialise(self):
+        if self.in_file():
+            pos, cells = np.empty(self.n, dtype=np.int32), np.empty((self.n, self.n_cols), dtype=np.uint8)
+            self.inflate_into(pos, cells)
+            self.pos, self.cells = pos, cells
         if self.comp is not None:
             pos, cells = np.empty(self.n, dtype=np.int32), np.empty((self.n, self.n_cols), dtype=np.uint8)
             self.inflate_into(pos, cells)
@@ -645,11 +676,14 @@ class _PackedBlock:
         return self
 
     def trim(self, a, b):
-        """rows [a, b) of the block (materialised)"""
-        self.materialise()
+        """rows [a, b) of the block (materialised, unless the payload is still in the file: then only the offsets move)"""
         keep = np.flatnonzero((self.starts < b) & (np.append(self.starts[1:], self.n) > a))
         names = [self.names[k] for k in keep]
         starts = np.maximum(self.starts[keep] - a, 0)
+        if self.in_file():
+            return _PackedBlock(starts, names, b - a, self.n_cols, fd=self.fd, pos_off=self.pos_off + 4 * a,
+                                cells_off=self.cells_off + a * self.n_cols)
+        self.materialise()
         return _PackedBlock(starts, names, b - a, self.n_cols, self.pos[a:b], self.cells[a:b])
 
 
@@ -671,6 +705,7 @@ class PackedReader:
         if self.codec not in ("none", "zlib"):
             raise ValueError("%s: unknown codec %r" % (path, self.codec))
         self.n_cols = len(self.names)
+        self._size = os.path.getsize(path)
         self.bytes_read = len(PGENO_MAGIC) + 4 + hl
         self.done = False
         self._rows = None                 # (first, last + 1) global row of this reader's share (shard()); None = everything
@@ -790,12 +825,12 @@ class PackedReader:
         want = 4 * n + n * self.n_cols
         starts = np.asarray(starts, dtype=np.int64)
         if self.codec == "none":
-            payload = self.f.read(want)
-            self.bytes_read += 12 + len(payload)
-            if len(payload) != want:
+            at = self.f.tell()
+            if at + want > self._size:
                 raise ValueError("truncated .pgeno file")
-            blk = _PackedBlock(starts, names, n, self.n_cols, np.frombuffer(payload, dtype="<i4", count=n),
-                               np.frombuffer(payload, dtype=np.uint8, offset=4 * n).reshape(n, self.n_cols))
+            self.f.seek(want, 1)                              # the payload stays where it is: whoever needs it reads it from there
+            self.bytes_read += 12 + want
+            blk = _PackedBlock(starts, names, n, self.n_cols, fd=self.f.fileno(), pos_off=at, cells_off=at + 4 * n)
         else:
             n_chunks = int.from_bytes(self.f.read(4), "little")
             table = np.frombuffer(self.f.read(8 * n_chunks), dtype="<u4").reshape(-1, 2)

@@ -132,6 +132,15 @@ int pg_tokenize_parse(pg_ctx *ctx, int slot, int64_t row_offset, int64_t row_cap
                       int *ok_out);
 int pg_tokenize_collect(pg_ctx *ctx, int slot, int32_t *pos_out, int64_t pos_capacity, int64_t *run_row_out, int64_t *run_off_out,
                         int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out);
+/* Packed cells (`.pgeno` with codec none: one byte per genotype) straight from the file, by the staging
+ * threads of the device tokenizer: pg_stage_file brings `len` bytes at file_offset of fd to byte dst_offset of staging slot 0 / 1
+ * on the device (`capacity` bytes are made sure of when dst_offset == 0; returns when the bytes have landed); pg_unpack_staged
+ * queues the expansion of n_rows rows of n_cols cells at byte src_offset of the slot into resident rows row_offset .. (slot_src as
+ * pg_upload_packed_async) on the copy stream; pg_stage_sync waits for that stream.  The caller alternates the slots so that the
+ * expansion of one block runs while the next block crosses PCIe. */
+int pg_stage_file(pg_ctx *ctx, int slot, int fd, int64_t file_offset, int64_t len, int64_t dst_offset, int64_t capacity);
+int pg_unpack_staged(pg_ctx *ctx, int slot, int64_t src_offset, int64_t n_rows, int n_cols, const int32_t *slot_src, int64_t row_offset);
+int pg_stage_sync(pg_ctx *ctx);
 /* What the device tokenizer of this context has spent so far: wall seconds of the host -> device copies of the text (staging
  * threads start to join: the PCIe-bound part), wall seconds of everything behind them (line feeds, parse kernel, positions and
  * runs back), and the bytes of text tokenised. */

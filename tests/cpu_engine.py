@@ -95,6 +95,29 @@ class CpuEngine:
         assert bytes(buf) == body and d is not None
         return d.n_sites, d.pos.copy(), d.run_starts.astype(np.int64), list(d.run_names)
 
+    # packed cells from the file (pg_stage_file / pg_unpack_staged / pg_stage_sync)
+    def stage_file(self, slot, fd, file_offset, nbytes, dst_offset, capacity):
+        import os
+        self._stage = getattr(self, "_stage", {})
+        if dst_offset == 0 or slot not in self._stage or len(self._stage[slot]) < capacity:
+            assert dst_offset == 0, "the staging buffer can only grow at offset 0"
+            self._stage[slot] = bytearray(capacity)
+        data = os.pread(fd, nbytes, file_offset)
+        assert len(data) == nbytes and dst_offset + nbytes <= capacity
+        self._stage[slot][dst_offset:dst_offset + nbytes] = data
+
+    def unpack_staged(self, slot, src_offset, n_rows, n_cols, slot_src, row_offset):
+        cells = np.frombuffer(bytes(self._stage[slot][src_offset:src_offset + n_rows * n_cols]), dtype=np.uint8).reshape(n_rows, n_cols)
+        slot_src = np.asarray(slot_src)
+        col, k = slot_src >> 1, slot_src & 1
+        rows = np.where(k[None, :] == 1, cells[:, col] >> 4, cells[:, col] & 15).astype(np.int8)
+        rows[:, slot_src < 0] = 0
+        assert row_offset + n_rows <= len(self.gt)
+        self.gt[row_offset:row_offset + n_rows] = rows
+
+    def stage_sync(self):
+        pass
+
     def load_sites(self, gt):
         self.gt = np.array(gt, dtype=np.int8, copy=True)[:, :self.layout.n_hap]
 

@@ -48,13 +48,16 @@ def test_drivers_streaming_in_small_blocks_on_the_cpu_engine(case, tmp_path, mon
 @pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("c1_popgen", "sparse_sites_windows", "mixed_haploid_flag",
                                                                      "abba_windows_diplo", "multi_distmat", "haplo_popgen")],
                          ids=lambda c: c["name"])
-def test_drivers_on_packed_input_on_the_cpu_engine(case, tmp_path, monkeypatch):
+@pytest.mark.parametrize("codec", ["zlib", "none"])
+def test_drivers_on_packed_input_on_the_cpu_engine(case, codec, tmp_path, monkeypatch):
+    """`.pgeno` input: deflated cells are inflated by host threads and uploaded packed (chunks()); raw cells (codec none) go from the
+    file to the device through the staging interface and are expanded there (cli.Run._chunks_device, packed route)"""
     argv = case["argv"]
     fmt = argv[argv.index("-f") + 1] if "-f" in argv else "phased"
     haploid = {"s1": 1, "s6": 1, "s9": 1} if case["fixture"] == "mixed" else {}
     packed = str(tmp_path / (case["fixture"] + ".pgeno"))
     genoio.pack_geno(os.path.join(GOLD, case["fixture"] + ".geno.gz"), packed, "pairs" if fmt == "alleles" else fmt, haploid,
-                     block_bytes=20000)
+                     block_bytes=20000, codec=codec)
     monkeypatch.setenv("PG_STREAM_BYTES", "30000")
     run_case(case, tmp_path, monkeypatch, geno=packed)
 

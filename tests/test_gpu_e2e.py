@@ -58,12 +58,12 @@ def want(geno):
 
 
 @pytest.mark.parametrize("tool", ["popgenWindows.py", "ABBABABAwindows.py"])
-@pytest.mark.parametrize("mode", ["device_tokenizer", "device_tokenizer_one_block", "host_tokenizer", "pgeno"])
+@pytest.mark.parametrize("mode", ["device_tokenizer", "device_tokenizer_one_block", "host_tokenizer", "pgeno", "pgeno_raw"])
 def test_drivers_match_the_oracle_on_a_random_mid_size_input(tool, mode, geno, want, tmp_path, monkeypatch):
     path = geno
-    if mode == "pgeno":
+    if mode.startswith("pgeno"):
         path = str(tmp_path / "random.pgeno")
-        genoio.pack_geno(geno, path, "phased", block_bytes=1 << 20)
+        genoio.pack_geno(geno, path, "phased", block_bytes=1 << 20, codec="none" if mode == "pgeno_raw" else "zlib")
     if mode != "device_tokenizer_one_block":
         monkeypatch.setenv("PG_STREAM_BYTES", str(3 << 20))                     # several blocks, rows carried across them
     if mode == "host_tokenizer":

@@ -123,17 +123,20 @@ def test_cli_with_the_host_tokenizer_reproduces_reference_output(case, block, tm
     test_cli_reproduces_reference_output(case, tmp_path)
 
 
+@pytest.mark.parametrize("codec", ["zlib", "none"])
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-def test_cli_on_packed_pgeno_input_reproduces_reference_output(case, tmp_path, monkeypatch):
+def test_cli_on_packed_pgeno_input_reproduces_reference_output(case, codec, tmp_path, monkeypatch):
     """every golden again with the text tokenised once into a `.pgeno` file (genoio.pack_geno, tools/geno_pack.py) and the driver
-    reading that (PackedReader + pg_decode_packed); streamed in small blocks where the window type streams"""
+    reading that; streamed in small blocks where the window type streams.  Deflated cells: host threads inflate them, the cells are
+    uploaded packed and expanded on the device; raw cells (codec none): the staging threads read them from the file
+    (pg_stage_file) and k_unpack expands them (pg_unpack_staged), two blocks in flight"""
     from genomics_general_amd import genoio
     argv = case["argv"]
     fmt = argv[argv.index("-f") + 1] if "-f" in argv else "phased"
     fmt = "pairs" if fmt == "alleles" else fmt
     haploid = {"s1": 1, "s6": 1, "s9": 1} if case["fixture"] == "mixed" else {}
     packed = str(tmp_path / (case["fixture"] + ".pgeno"))
-    genoio.pack_geno(os.path.join(GOLD, case["fixture"] + ".geno.gz"), packed, fmt, haploid, block_bytes=20000)
+    genoio.pack_geno(os.path.join(GOLD, case["fixture"] + ".geno.gz"), packed, fmt, haploid, block_bytes=20000, codec=codec)
     if _streamable(case):
         monkeypatch.setenv("PG_STREAM_BYTES", "30000")
     test_cli_reproduces_reference_output(case, tmp_path, geno=packed)
