@@ -14,7 +14,10 @@
 
 constexpr int S = 400, LANES = 100;          // bytes per row, lanes that hold data
 
-template <int FLUSH, int PADLDS>
+// PERIOD > 0 (with FLUSH >= 16): a burst may only START while (s_memrealtime mod PERIOD) < SLOT (ticks of 10 ns, one clock for the whole
+// chip): the stores of all blocks are gathered into common time slots, so that between the slots the HBM sees reads only (round 4:
+// does clustering the read <-> write turn-arounds chip-wide help where bursts per block did little?)
+template <int FLUSH, int PADLDS, int PERIOD = 0, int SLOT = 0>
 __global__ __launch_bounds__(128) void k_rw(const int8_t *__restrict__ gt, int64_t n_rows, uint4 *__restrict__ vp,
                                             uint4 *__restrict__ xv, uint32_t *__restrict__ out) {
     constexpr int NV = FLUSH >= 16 ? FLUSH / 4 : 1, NX = FLUSH >= 16 ? (FLUSH + 8) / 9 : 1;     // store events per flush
@@ -51,6 +54,10 @@ __global__ __launch_bounds__(128) void k_rw(const int8_t *__restrict__ gt, int64
         }
         if (FLUSH && (w % 9) == 8) ++nx;
         if (FLUSH >= 16 && (w + 1) % FLUSH == 0) {                     // the burst
+            if (PERIOD > 0) {
+                if (t == 0)
+                    while ((int)(__builtin_amdgcn_s_memrealtime() % (unsigned long long)PERIOD) >= SLOT) __builtin_amdgcn_s_sleep(8);
+            }
             __syncthreads();
             const int v0 = (w + 1 - FLUSH) / 4;
             for (int k = t; k < nv * 2 * LANES; k += 128) vrow[v0 * 2 * LANES + k] = lds[k];
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(128) void k_rw(const int8_t *__restrict__ gt, int64
     if (acc == 0x12345678u) out[0] = acc;
 }
 
-template <int FLUSH, int PADLDS>
+template <int FLUSH, int PADLDS, int PERIOD = 0, int SLOT = 0>
 void run(const char *what, const int8_t *gt, int64_t n_rows, uint4 *vp, uint4 *xv, uint32_t *out) {
     const unsigned blocks = (unsigned)((n_rows + 2047) / 2048);
     hipEvent_t e0, e1;
@@ -72,7 +79,7 @@ void run(const char *what, const int8_t *gt, int64_t n_rows, uint4 *vp, uint4 *x
     float best = 1e30f, worst = 0;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_rw<FLUSH, PADLDS>), dim3(blocks), dim3(128), 0, 0, gt, n_rows, vp, xv, out);
+        hipLaunchKernelGGL((k_rw<FLUSH, PADLDS, PERIOD, SLOT>), dim3(blocks), dim3(128), 0, 0, gt, n_rows, vp, xv, out);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -100,5 +107,14 @@ int main(int argc, char **argv) {
     run<32, 0>("bursts every 32 words (37 KB: 4 blocks per CU)", gt, n_rows, vp, xv, out);
     run<64, 0>("one burst per block (74 KB: 2 blocks per CU)", gt, n_rows, vp, xv, out);
     run<4, 0>("stores as they are produced, again", gt, n_rows, vp, xv, out);
+    // time-slot gating of the bursts (ticks of 10 ns)
+    run<32, 0, 4000, 500>("bursts every 32 words, slots of 5 us every 40 us", gt, n_rows, vp, xv, out);
+    run<32, 0, 2000, 300>("bursts every 32 words, slots of 3 us every 20 us", gt, n_rows, vp, xv, out);
+    run<32, 0, 8000, 1000>("bursts every 32 words, slots of 10 us every 80 us", gt, n_rows, vp, xv, out);
+    run<32, 0, 4000, 1000>("bursts every 32 words, slots of 10 us every 40 us", gt, n_rows, vp, xv, out);
+    run<16, 0, 4000, 500>("bursts every 16 words, slots of 5 us every 40 us", gt, n_rows, vp, xv, out);
+    run<16, 0, 2000, 400>("bursts every 16 words, slots of 4 us every 20 us", gt, n_rows, vp, xv, out);
+    run<64, 0, 8000, 1000>("one burst per block, slots of 10 us every 80 us", gt, n_rows, vp, xv, out);
+    run<32, 0>("bursts every 32 words, no gating, again", gt, n_rows, vp, xv, out);
     return 0;
 }
