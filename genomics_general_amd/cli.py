@@ -543,7 +543,8 @@ class Run:
             eng.reserve(2 * st["half"])
             return saved
 
-        mapped = getattr(self._reader, "mm", None) is not None       # a block of a memory-mapped file is a view: nothing to read ahead
+        # a block of a memory-mapped file is a view, a block of raw `.pgeno` cells a list of file offsets: nothing to read ahead
+        mapped = getattr(self._reader, "mm", None) is not None or bool(getattr(self._reader, "packed", False))
         done_reading = []
 
         def fetch():
@@ -692,8 +693,10 @@ class Run:
                     self._reader.names[bad], int(self._reader.ploidy[bad]), int(lay.col_ploidy[bad])))
         import sys
         switch = sys.getswitchinterval()
-        sys.setswitchinterval(0.0005)             # the ingestion thread needs the interpreter for microseconds between two native calls:
-        try:                                      # it should not wait 5 ms for it while this thread formats rows
+        # the ingestion thread needs the interpreter for microseconds between two native calls, dozens of times per block: every time
+        # it would wait a whole switch interval (5 ms by default) for this thread to let go while it formats rows
+        sys.setswitchinterval(float(os.environ.get("PG_SWITCH_INTERVAL", "0.00005")))
+        try:
             while True:
                 t0 = time.perf_counter()
                 item = ready.get()
@@ -716,12 +719,16 @@ class Run:
                 self.timing["windows"] += int(T.n)
                 self.timing["chunks"] += 1
                 self.n_tested += int(T.n)
+                t_y = time.perf_counter()
                 try:
                     if T.n:
                         yield self
                 finally:
                     ready.task_done()                         # the rows of this block are no longer needed: its half may be rewritten
                     halves.release()
+                if T.n:                                       # (what the caller did with the chunk: kernels, statistics, rows)
+                    key = "compute_first_chunk_s" if "compute_first_chunk_s" not in self.timing else "compute_other_chunks_s"
+                    self.timing[key] = self.timing.get(key, 0.0) + time.perf_counter() - t_y
                 if final:
                     break
         finally:
