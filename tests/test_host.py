@@ -498,3 +498,41 @@ def test_text_runs_of_raw_lines(tmp_path):
             rd.close()
         whole = whole or runs
         assert runs == whole and [nm for _, nm in runs] == ["chr%d" % k for k in range(1, 12)]
+
+
+def test_text_seek_pos_and_skip_rows_walk_data_lines_only():
+    """pg_text_seek_pos / pg_text_skip_rows (the window-range cuts of the multi-GPU plan, genomics_general_amd/shardplan.py): comment
+    and blank lines are not rows, the walk stops at the first line of another scaffold, an unterminated last line is a line only
+    when the caller says the buffer is the whole text"""
+    import ctypes as C
+    from genomics_general_amd import _lib
+    L = _lib.lib()
+    text = (b"chr1\t5\tA/C\n#note\nchr1\t9\tA/C\n\nchr1\t9\tC/C\n  chr1 \t 40\tA/A\nchr10\t2\tA/A\nchr1\t50\tA/A")
+
+    def seek(buf, scaf, pos_min, whole=1):
+        off, st, ps, rows = C.c_int64(0), C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(L.pg_text_seek_pos(buf, len(buf), whole, scaf, len(scaf), pos_min, C.byref(off), C.byref(st), C.byref(ps), C.byref(rows)))
+        return off.value, st.value, ps.value, rows.value
+
+    assert seek(text, b"chr1", 1) == (0, 1, 5, 0)
+    assert seek(text, b"chr1", 9) == (text.index(b"chr1\t9"), 1, 9, 1)                  # the FIRST of two lines at position 9
+    assert seek(text, b"chr1", 10) == (text.index(b"  chr1"), 1, 40, 3)                  # leading blanks, blank-padded fields
+    assert seek(text, b"chr1", 41) == (text.index(b"chr10"), 0, 0, 4)                    # chr10 is not chr1: the run is over
+    assert seek(text, b"chr10", 1) == (0, 0, 0, 0)
+    tail = text[text.index(b"chr1\t50"):]
+    assert seek(tail, b"chr1", 50, whole=1) == (0, 1, 50, 0)                              # unterminated last line: a line of the whole text,
+    assert seek(tail, b"chr1", 50, whole=0) == (0, -1, 0, 0)                              # left for the next call otherwise
+    assert seek(b"", b"chr1", 1) == (0, -1, 0, 0)
+    with pytest.raises(_lib.PopgenError):
+        seek(b"chr1\tx12\tA/A\n", b"chr1", 1)
+
+    def skip(buf, n):
+        off, rows = C.c_int64(0), C.c_int64(0)
+        _lib.check(L.pg_text_skip_rows(buf, len(buf), n, C.byref(off), C.byref(rows)))
+        return off.value, rows.value
+
+    assert skip(text, 0) == (0, 0)
+    assert skip(text, 1) == (text.index(b"chr1\t9"), 1)                                  # (the comment line is walked over, not counted)
+    assert skip(text, 2) == (text.index(b"chr1\t9\tC/C"), 2)
+    assert skip(text, 6) == (len(text), 6) and skip(text, 99) == (len(text), 6)
+    assert 1 <= _lib.usable_cpus() <= (os.cpu_count() or 1)
