@@ -704,6 +704,29 @@ def main():
         names = ["s%d" % d for d in range(wl["n_dip"])]
         cpu = cpu_baseline_reference(wl, names, wl["n_pops"], ref_dir, cpus["usable"])
         cpu["host_cpus"] = cpus
+        # the oracle's port (what the GPU box times, where the reference is absent) on the same windows and the same cores: how a
+        # `kind: "port"` number translates into the reference's
+        try:
+            import multiprocessing as mp
+            from genomics_general_amd import synth
+            W = cpu["runs"]["T_all"]["windows"]
+            per = wl["n_dip"] // wl["n_pops"]
+            pops = [("pop%d" % k, names[k * per:(k + 1) * per]) for k in range(wl["n_pops"])]
+            jobs = []
+            for k in range(W):
+                pos = np.arange(k * wl["wind"] + 1, (k + 1) * wl["wind"] + 1)
+                codes = synth.gen_codes(synth.SEED_DEFAULT, np.zeros(len(pos), dtype=np.int64), pos, wl["n_dip"], wl["n_pops"])
+                jobs.append((codes, names, pops, wl["wind"], wl["min_sites"], wl["tool"], "chr1", 1))
+            with mp.get_context("spawn").Pool(min(W, cpus["usable"])) as pool:
+                res = pool.map(_cpu_window_job, jobs, chunksize=1)
+            wall = max(r[1] for r in res) - min(r[0] for r in res)
+            cpu["port_same_windows"] = {"workers": min(W, cpus["usable"]), "windows": W, "wall_seconds": round(wall, 2),
+                                        "windows_per_sec": round(W / wall, 5),
+                                        "port_over_reference": round((W / wall) / cpu["runs"]["T_all"]["windows_per_sec"], 2),
+                                        "note": "the oracle's restatement of the whole path (what `kind: port` times on the GPU box) on the same "
+                                                "windows, one per worker; the reference's rate includes its serial reader and process start"}
+        except Exception as exc:
+            cpu["port_same_windows"] = {"error": repr(exc)[:300]}
         print(json.dumps({"cpu_baseline": cpu, "config": {"workload": wl["desc"], "name": args.workload}}))
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -327,6 +327,8 @@ def parse_vcf_main(argv=None):
     ap.add_argument("--outSep", help="Output separator", default="\t")
     ap.add_argument("-i", "--inFile", help="Input vcf file")
     ap.add_argument("--packed", metavar="FILE.pgeno", help="also (or, without -o, only) write the packed form the engine's drivers read")
+    ap.add_argument("--packedCodec", choices=("zlib", "none"), default="zlib",
+                    help="cells of the --packed file: deflated chunks (smallest) or raw (1 byte per genotype: read by the drivers at PCIe speed)")
     ap.add_argument("--threads", type=int, default=0, help="host threads of the native parser (default: all)")
     args = ap.parse_args(argv)
     if args.field is not None:
@@ -423,7 +425,7 @@ def parse_vcf_main(argv=None):
     sep = args.outSep.encode()
     if out is not None and not args.noHeader:
         out.write(sep.join([b"#CHROM", b"POS"] + ([b"REF"] if args.addRefTrack else []) + [s.encode() for s in samples]) + b"\n")
-    packer = genoio.PackedWriter(args.packed, samples, [int(p) for p in pl]) if args.packed else None
+    packer = genoio.PackedWriter(args.packed, samples, [int(p) for p in pl], args.packedCodec) if args.packed else None
     lut = np.zeros(256, dtype=np.uint8)
     for ch, code in zip(b"ACGT", (1, 2, 4, 8)):
         lut[ch] = code
