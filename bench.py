@@ -1054,12 +1054,28 @@ def main():
                                  "sites_per_sec": round(d5["sites_per_step"] * world.size / dt5, 1)}
         except Exception as exc:                                # side information: never lose the main line
             extra["c5_share"] = {"error": repr(exc)[:300]}
+    if cpu and cpu.get("kind") == "port" and args.workload in ("northstar", "c2"):
+        # what the port's number means in units of the reference: both were timed on the same windows and the same cores where the
+        # reference exists (bench.py --cpu-baseline-only in the build container; the committed line)
+        try:
+            cal_path = os.path.join(ROOT, "profiles", "r04", "cpu_baseline_reference_%s_build_container.json" % args.workload)
+            with open(cal_path) as f:
+                cal = json.load(f)["cpu_baseline"]
+            ratio = cal["port_same_windows"]["port_over_reference"]
+            cpu["reference_calibration"] = {"port_over_reference": ratio, "reference_equivalent_windows_per_sec": round(cpu["value"] / ratio, 5),
+                                            "source": os.path.relpath(cal_path, ROOT),
+                                            "note": "the unmodified reference (-T 8) and this port on the same 8 windows and the same 8 vCPU of the "
+                                                    "build container: the port is that many times faster; an estimate, not a measurement on this host"}
+        except Exception:
+            pass
     t2 = extra.get("t2") or {}
     if cpu and "windows_per_sec" in t2 and cpu.get("unit") == "windows/s" and cpu.get("value"):
         # like for like: both read `.geno` text and write the CSV (T0's `value` has its inputs resident in HBM and is NOT comparable)
         extra["t2_vs_cpu"] = {"ratio": round(t2["windows_per_sec"] / cpu["value"], 1),
                               "ratio_without_context_creation": round(t2["without_context_creation"]["windows_per_sec"] / cpu["value"], 1),
                               "gpu_windows_per_sec": t2["windows_per_sec"], "cpu_windows_per_sec": cpu["value"], "cpu_kind": cpu.get("kind"),
+                              "ratio_to_reference_equivalent": (round(t2["windows_per_sec"] / cpu["reference_calibration"]["reference_equivalent_windows_per_sec"], 1)
+                                                                if "reference_calibration" in cpu else None),
                               "note": "tier T2 (text in, CSV out, one GPU + its host threads) against the CPU baseline's whole path on every host core"}
     if world.rank == 0:
         total_windows = total_win * args.steps
