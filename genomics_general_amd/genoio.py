@@ -383,7 +383,9 @@ class BlockReader:
         freq.py, whose reference reads slices of sites in parallel, freq.py:23-28).  Every rank finds its own start and its
         successor's the same way (the first line that starts at or behind the equal split), so no exchange is needed.  False,
         and the reader untouched, when the input is not plain text on disk."""
-        if isinstance(self.f, BgzfFile) or not self.seekable_text():
+        if isinstance(self.f, BgzfFile):
+            return self._shard_lines_bgzf(world)
+        if not self.seekable_text():
             return False
         size = os.path.getsize(self.path)
         start = self.tell()
@@ -403,6 +405,30 @@ class BlockReader:
 
         a, b = cut(world.rank), cut(world.rank + 1)
         self.restrict(a, max(a, b))
+        return True
+
+    def _shard_lines_bgzf(self, world):
+        """the same on bgzip-compressed text: rank r's share starts at the first line that begins in or behind the member at r / N of
+        the compressed bytes; a cut is a (member file offset, offset inside the member) pair (every rank finds its own cut and its
+        successor's the same way: no exchange)"""
+        bz = self.f
+        size = bz.size
+
+        def cut(r):
+            if r <= 0:
+                return (0, 0)
+            if r >= world.size:
+                return (size, 0)
+            probe = BgzfFile(self.path)
+            probe.keep_track = True
+            probe.seek_member(size * r // world.size)
+            skipped = len(probe.readline())                    # the line that straddles into the member belongs to the left
+            tok = probe.virtual_of(skipped)                    # (at a member's end: that member and its length -- the same place)
+            probe.close()
+            return (int(tok[0]), int(tok[1]))
+
+        a, b = cut(world.rank), cut(world.rank + 1)
+        self.restrict_virtual(a, max(a, b), first=(world.rank == 0))
         return True
 
     def _shard_bgzf(self, world, comm, wanted, max_share):
@@ -770,6 +796,13 @@ class PackedReader:
         if max(cuts[r + 1] - cuts[r] for r in range(world.size)) / total > max_share:
             return False
         self.restrict_rows(blocks, cuts[world.rank], cuts[world.rank + 1])
+        return True
+
+    def shard_lines(self, world):
+        """rank r's share of the rows, cut anywhere (sites are independent: freq.py, `distMat.py --windType cat`); every rank reads
+        the block headers and computes the same equal split"""
+        blocks, total = self._index()
+        self.restrict_rows(blocks, total * world.rank // world.size, total * (world.rank + 1) // world.size)
         return True
 
     def restrict_rows(self, blocks, a, b):

@@ -239,8 +239,10 @@ def test_freq_with_two_ranks_cuts_the_input_at_line_boundaries(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from cases import CASES
     gold = os.path.join(ROOT, "tests", "golden")
+    from genomics_general_amd import genoio
+    from test_host import _bgzf_write
     for k, (name, plain) in enumerate((("abba_freq_derived", True), ("abba_freq_indfreqs", True), ("abba_freq_counts", True),
-                                       ("abba_freq_derived", False))):
+                                       ("abba_freq_derived", False), ("abba_freq_counts", "bgzf"), ("abba_freq_derived", "pgeno"))):
         case = [c for c in CASES if c["name"] == name]
         if not case:
             continue
@@ -250,11 +252,56 @@ def test_freq_with_two_ranks_cuts_the_input_at_line_boundaries(tmp_path):
             geno = str(tmp_path / (case["fixture"] + ".geno"))
             with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f, open(geno, "wb") as g:
                 g.write(f.read())
+        if plain == "bgzf":                                # bgzip-compressed text and packed rows are cut at line / row boundaries too
+            with open(geno, "rb") as f:
+                _bgzf_write(geno + ".gz", f.read(), blk=15000)
+            geno = geno + ".gz"
+        elif plain == "pgeno":
+            genoio.pack_geno(geno, geno[:-5] + ".pgeno", "phased", block_bytes=30000, codec="none")
+            geno = geno[:-5] + ".pgeno"
         out = str(tmp_path / (name + ".out"))
         argv = [a.format(geno=geno, dir=gold, out=out) for a in case["argv"]] + ["-o", out]
         _run_two_ranks(case["tool"], argv, 35000 + (os.getpid() + 13 * k) % 2000)
         with open(out) as f, open(os.path.join(gold, name + ".out")) as g:
             assert f.read() == g.read(), name
+
+
+def test_line_shards_of_bgzf_and_packed_input_cover_the_input_once(tmp_path):
+    """shard_lines on bgzip-compressed text (cuts = member + offset inside, no exchange) and on `.pgeno` rows (freq.py and
+    `distMat.py --windType cat` on several ranks): the ranks' shares are disjoint and cover every row, for any number of ranks"""
+    from genomics_general_amd import genoio
+    from test_host import _bgzf_write
+    lines = [("chr%d\t%d\t" % (1 + i // 40, i + 1) + "\t".join("A/C" if (i + j) % 3 else "N/N" for j in range(3))).encode() for i in range(131)]
+    text = b"#CHROM\tPOS\ts1\ts2\ts3\n" + b"\n".join(lines) + b"\n"
+    plain = str(tmp_path / "x.geno")
+    with open(plain, "wb") as f:
+        f.write(text)
+    for blk in (300, 1000, 100000):
+        bz = str(tmp_path / ("x%d.geno.gz" % blk))
+        _bgzf_write(bz, text, blk=blk)
+        for size in (1, 2, 3, 8, 50):
+            got = []
+            for rank in range(size):
+                r = genoio.open_input(bz)
+                r.read_header()
+                assert r.shard_lines(dist.World(rank, size, rank))
+                body = bytes(r.read_block(None))
+                assert body == b"" or body.endswith(b"\n")
+                got.append(body)
+                r.close()
+            assert b"".join(got) == b"\n".join(lines) + b"\n", (blk, size)
+    for codec in ("none", "zlib"):
+        pk = str(tmp_path / ("x_%s.pgeno" % codec))
+        genoio.pack_geno(plain, pk, "phased", block_bytes=900, codec=codec)
+        for size in (1, 2, 3, 8, 200):
+            rows = []
+            for rank in range(size):
+                r = genoio.open_input(pk)
+                assert r.shard_lines(dist.World(rank, size, rank))
+                for b in r.read_block(None):
+                    rows += [int(p) for p in b.positions()]
+                r.close()
+            assert rows == list(range(1, 132)), (codec, size)
 
 
 def test_line_shards_cover_the_input_once():
