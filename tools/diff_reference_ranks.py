@@ -47,13 +47,23 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260926)
     tmp = tempfile.mkdtemp(prefix="pg_diff_")
-    bad = 0
+    results = {"bad": 0}
     for case in range(n_cases):
         geno = os.path.join(tmp, "c%d.geno" % case)
         names, n_dip = make_geno(geno, rng)
         half = n_dip // 2
-        tool = str(rng.choice(["popgenWindows.py", "popgenWindows.py", "popgenWindows.py", "distMat.py"]))
+        tools = os.environ.get("PG_DIFF_TOOLS", "popgenWindows.py,popgenWindows.py,popgenWindows.py,distMat.py").split(",")
+        tool = str(rng.choice(tools))
         argv = ["-g", geno, "-f", "phased"]
+        if tool == "freq.py":
+            argv += ["-p", "A", ",".join(names[:half]), "-p", "B", ",".join(names[half:])]
+            if rng.random() < 0.5:
+                argv += ["--target", "derived"]
+                if rng.random() < 0.5:
+                    argv += ["--asCounts"]
+            ref_out = os.path.join(tmp, "ref%d.out" % case)
+            run_case(case, tool, argv, ref_out, tmp, rng, results)
+            continue
         if rng.random() < 0.7:
             w = int(rng.integers(50, 900))
             argv += ["-w", str(w)]
@@ -71,14 +81,27 @@ def main():
             argv += ["--addWindowID"]
         if tool == "popgenWindows.py":
             argv += ["-p", "A", ",".join(names[:half]), "-p", "B", ",".join(names[half:]), "--roundTo", "6"]
+        elif tool in ("ABBABABAwindows.py", "fourPopWindows.py"):
+            argv = [a if a != "-O" else "--overlap" for a in argv]
+            q = max(n_dip // 4, 1)
+            for flag, k in (("-P1", 0), ("-P2", 1), ("-P3", 2), ("-O", 3)):
+                argv += [flag, "p%d" % k, ",".join(names[k * q:(k + 1) * q])]
+            argv += ["--minData", str(float(rng.choice([0.01, 0.5])))]
         else:
             argv += ["--outFormat", "raw", "--windowDataOutFile", "{out}.windows"]
         ref_out = os.path.join(tmp, "ref%d.out" % case)
+        run_case(case, tool, argv, ref_out, tmp, rng, results)
+    print("differences: %d" % results["bad"])
+    return 1 if results["bad"] else 0
+
+
+def run_case(case, tool, argv, ref_out, tmp, rng, results):
+    if True:
         r = subprocess.run([sys.executable, "-c", WRAP, os.path.join(REF, tool)] + [a.format(out=ref_out) for a in argv] + ["-o", ref_out],
                            cwd=tmp, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         if r.returncode != 0:
             print("case %d: the reference failed (%s): skipped" % (case, r.stderr.decode()[-200:].strip().splitlines()[-1:]))
-            continue
+            return
         want = open(ref_out).read()
         want_w = open(ref_out + ".windows").read() if os.path.exists(ref_out + ".windows") else None
         verdicts = []
@@ -97,12 +120,10 @@ def main():
                 ok = open(out + ".windows").read() == want_w
             ranges = sum('"window_ranges": true' in e for e in errs)
             verdicts.append("%d:%s%s" % (size, "ok" if ok else "DIFF", "(ranges)" if ranges == size and size > 1 else ""))
-            bad += 0 if ok else 1
+            results["bad"] += 0 if ok else 1
             if not ok:
                 print("   rank errors:", [e[-300:] for e in errs if "Traceback" in e][:1])
         print("case %2d  %-18s %-60s rows %3d  %s" % (case, tool, " ".join(argv[4:12]), want.count("\n"), " ".join(verdicts)), flush=True)
-    print("differences: %d" % bad)
-    return 1 if bad else 0
 
 
 if __name__ == "__main__":
