@@ -690,6 +690,7 @@ template <int NSUM>
 struct QuartetAcc {
     double acc[NSUM];
     unsigned long long used;
+    unsigned long long good;     // sites that are biallelic with enough data in every population (before the allele choice)
 };
 
 // Float64 phase for one usable site.  e = { c1, c2, c3, n1, n2, n3, n4, c4 }: allele counts / called counts of the chosen
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
                                                 const int32_t *__restrict__ pop_start, int q1, int q2, int q3, int q4,
                                                 double min_data, int sel, double *__restrict__ part_sums,
                                                 int64_t *__restrict__ part_used) {
-    __shared__ double shd[4 * (NSUM + 1)];
+    __shared__ double shd[4 * (NSUM + 2)];
     __shared__ uint32_t ring[4][PG_ABBA_RING][8];
     __shared__ int64_t cand[4][PG_ABBA_CAND];
     const int win = blockIdx.y, chunk = blockIdx.x;
@@ -867,6 +868,7 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) A.acc[k] = 0.0;
     A.used = 0;
+    A.good = 0;
     const int qs[4] = {q1, q2, q3, q4};
     const int q = threadIdx.x & 3;
     const int my_s = pop_start[qs[q]], my_e = pop_start[qs[q] + 1];
@@ -901,6 +903,10 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
             const int nall = (tot[0] > 0) + (tot[1] > 0) + (tot[2] > 0) + (tot[3] > 0);
             int der = -1;
             bool good = ok && nall == 2;
+            // the reference's goodSites (genomics.py:1655-1662): ABBABABA answers a window WITHOUT any with sitesUsed = nan (its
+            // zip() of six names with seven values drops the 0, genomics.py:1693-1695), so the windows' counts of them are kept
+            const unsigned long long gbal = __ballot(good && q == 0);
+            if (lane == 0) A.good += (unsigned long long)__popcll(gbal);
             if (sel == PG_SEL_MINOR) {
                 int lo_b = -1, hi_b = -1;                // the two alleles present, lo_b < hi_b
 #pragma unroll
@@ -1049,15 +1055,16 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
         }
     }
     const size_t o = (size_t)win * max_chunks + chunk;
-    double tot[NSUM + 1];
+    double tot[NSUM + 2];
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) tot[k] = A.acc[k];
     tot[NSUM] = (double)A.used;                          // <= PG_ABBA_SITES_PER_BLOCK, exact in a double
-    block_sum_multi<NSUM + 1>(tot, shd);
+    tot[NSUM + 1] = (double)A.good;
+    block_sum_multi<NSUM + 2>(tot, shd);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < NSUM; ++k) part_sums[o * NSUM + k] = tot[k];
-        part_used[o] = (int64_t)tot[NSUM];
+        part_used[o] = (int64_t)tot[NSUM] | ((int64_t)tot[NSUM + 1] << 32);      // used sites | good sites of the chunk (both < 2^31)
     }
 }
 
@@ -1075,9 +1082,14 @@ __global__ void k_abba_reduce(const double *__restrict__ part_sums, const int64_
         for (int c = 0; c < nch; ++c) s += part_sums[((size_t)win * max_chunks + c) * nsum + k];
         sums_out[(size_t)win * nsum + k] = s;
     } else {
-        int64_t u = 0;
-        for (int c = 0; c < nch; ++c) u += part_used[(size_t)win * max_chunks + c];
-        used_out[win] = u;
+        int64_t u = 0, g = 0;
+        for (int c = 0; c < nch; ++c) {
+            const int64_t pu = part_used[(size_t)win * max_chunks + c];
+            u += pu & 0xffffffffll;
+            g += pu >> 32;
+        }
+        // ABBABABA (six sums): a window without a single good site has sitesUsed = nan in the reference, told here as -1
+        used_out[win] = (nsum == PG_ABBA_NSUM && g == 0) ? -1 : u;
     }
 }
 

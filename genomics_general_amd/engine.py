@@ -547,9 +547,14 @@ class WindowBatch:
         used = np.zeros(self.n, dtype=np.int64)
         check(self.e._L.pg_abbababa(self.e._h, self.lo, self.hi, self.n, ids[0], ids[1], ids[2], ids[3], float(minData),
                                     sums, used))
+        # a window without one good site (biallelic, enough data): genomics.py:1693-1695 zips six names with seven values, so
+        # the reference's sitesUsed there is nan, not 0 (pg_abbababa tells these windows as -1); fourPop's zip is even: 0
+        none_good = used < 0
+        used_f = np.where(none_good, np.nan, used.astype(np.float64))
         with np.errstate(divide="ignore", invalid="ignore"):
             out = {"D": sums[:, 0] * 1. / sums[:, 1], "fd": sums[:, 0] * 1. / sums[:, 2], "fdM": sums[:, 0] * 1. / sums[:, 3],
-                   "ABBA": sums[:, 4], "BABA": sums[:, 5], "sitesUsed": used}
+                   "ABBA": np.where(none_good, np.nan, sums[:, 4]), "BABA": np.where(none_good, np.nan, sums[:, 5]),
+                   "sitesUsed": used_f}
         return out
 
     # -- four-population statistics ----------------------------------------------------------------------------

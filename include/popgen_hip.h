@@ -310,7 +310,9 @@ int pg_hapstats(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n
 /* ---- K1+K4: ABBA-BABA window sums ------------------------------------------------------------------ */
 /* Replaces genomics.ABBABABA(polarize=True) (genomics.py:1647-1695) with f4/D/fd/fdm/ABBA/BABA
  * (genomics.py:1409-1475, 1565-1569).  sums_out[n_win][6] = { sum f4(p1,p2,p3,p4), sum (ABBA+BABA),
- * sum f4(p1,pd,pd,p4), sum f4(pdm1,pdm2,pdm3,p4), sum ABBA, sum BABA }; sites_used_out[n_win]. */
+ * sum f4(p1,pd,pd,p4), sum f4(pdm1,pdm2,pdm3,p4), sum ABBA, sum BABA }; sites_used_out[n_win]: the sites that entered the
+ * sums, or -1 for a window without one good site (biallelic with enough data in all four populations): there the reference
+ * answers sitesUsed = nan (its zip() of six names with seven values drops the 0, genomics.py:1693-1695). */
 int pg_abbababa(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int p1, int p2, int p3,
                 int p4, double min_data, double *sums_out, int64_t *sites_used_out);
 

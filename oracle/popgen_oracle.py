@@ -421,7 +421,8 @@ def abbababa(aln, P1, P2, P3, P4, min_data):
         enough &= (ns[k] * 1. / len(rows[k]) >= min_data)                    # :1657-1660
     good = np.where(biallelic & enough)[0]
     if len(good) < 1:
-        return dict(D=np.nan, fd=np.nan, fdM=np.nan, ABBA=np.nan, BABA=np.nan, sitesUsed=0)
+        # :1693-1695 zips SIX names with SEVEN values ([nan]*6 + [0]): the 0 is dropped and sitesUsed is nan
+        return dict(D=np.nan, fd=np.nan, fdM=np.nan, ABBA=np.nan, BABA=np.nan, sitesUsed=np.nan)
     with np.errstate(divide="ignore", invalid="ignore"):
         freqs = [1. * cnts[k][good] / ns[k][good][:, None] for k in range(4)]
         allf = 1. * tot[good] / (ns[0] + ns[1] + ns[2] + ns[3])[good][:, None]

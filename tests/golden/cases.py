@@ -105,6 +105,10 @@ CASES = [
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--minData", "0.5"] + abba_args(16)),
     dict(name="abba_windows_failed_id", tool="ABBABABAwindows.py", fixture="abba",
          argv=["-g", "{geno}", "-f", "phased", "-w", "500", "-s", "250", "-m", "60", "--minData", "0.9", "--writeFailedWindows", "--addWindowID"] + abba_args(16)),
+    # windows that have sites but not one good site: the reference prints sitesUsed = nan there (genomics.py:1693-1695), 0
+    # only where good sites exist and none survives the derived-allele choice
+    dict(name="abba_windows_none_good", tool="ABBABABAwindows.py", fixture="abba",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "50", "-m", "1", "--minData", "1.0", "--writeFailedWindows"] + abba_args(16)),
     dict(name="abba_windows_sites", tool="ABBABABAwindows.py", fixture="abba",
          argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "400", "--overlap", "100", "-m", "50"] + abba_args(16)),
     dict(name="abba_windows_diplo", tool="ABBABABAwindows.py", fixture="abba_diplo",

@@ -122,7 +122,7 @@ def run_case(case, tool, argv, ref_out, tmp, rng, results):
             verdicts.append("%d:%s%s" % (size, "ok" if ok else "DIFF", "(ranges)" if ranges == size and size > 1 else ""))
             results["bad"] += 0 if ok else 1
             if not ok:
-                print("   rank errors:", [e[-300:] for e in errs if "Traceback" in e][:1])
+                print("   rank errors:", [e[-300:] for e in errs if "Traceback" in e][:1], "| kept:", ref_out, out)
         print("case %2d  %-18s %-60s rows %3d  %s" % (case, tool, " ".join(argv[4:12]), want.count("\n"), " ".join(verdicts)), flush=True)
 
 
