@@ -914,6 +914,9 @@ def popgen_main(argv=None):
         for pre in ("H1_", "H12_", "H2_"):
             stats += [pre + n for n in popNames]
     int_stat = [s.startswith("l_") or s.startswith("S_") for s in stats]
+    # H12stats answers a population that is ONE cluster with the integer `H2 = 0` (genomics.py:1092-1093): printed "0", not "0.0"
+    # (H2 of two or more clusters is a sum of positive squares, never exactly zero)
+    h2_stat = [s.startswith("H2_") and "hapStats" in args.analysis for s in stats]
 
     run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=3, stream=True, shardable=True)
     sink = run.open_sink(args.outFile, ("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites," + ",".join(stats) + "\n",
@@ -953,7 +956,7 @@ def popgen_main(argv=None):
                 vals = []
                 for c in range(len(stats)):
                     v = full[k, c]
-                    if int_stat[c] and v == v:
+                    if (int_stat[c] and v == v) or (h2_stat[c] and v == 0):
                         vals.append(int(v))
                     else:
                         vals.append(round(np.float64(v), args.roundTo))
@@ -1098,8 +1101,7 @@ def _matrix_text(M, names, fmt, roundTo):
 
 def distmat_main(argv=None):
     ap = argparse.ArgumentParser(prog="distMat.py", epilog=ENGINE_EPILOG)
-    _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined", "cat")),
-                              "-m": dict(default=None)})
+    _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined", "cat"))})      # -m: default 1 (distMat.py:123)
     ap.add_argument("-O", "--overlap", type=int, metavar="sites", help="Overlap for sites sliding window")
     ap.add_argument("-Mi", "--minPerInd", type=int, metavar="sites", help="Minimum sites per individual")
     ap.add_argument("--includeSameWithSame", action="store_true", help="Include comparisons of each haplotype to itself")

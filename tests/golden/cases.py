@@ -151,6 +151,9 @@ CASES = [
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "10", "--windowDataOutFile", "{out}.windows"]),
     dict(name="holes_distmat_raw_same", tool="distMat.py", fixture="holes",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1500", "-m", "10", "--outFormat", "raw", "--includeSameWithSame", "--roundTo", "6"]),
+    # no -m: the default is 1 (distMat.py:123), not the window size
+    dict(name="holes_distmat_default_minsites", tool="distMat.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "700", "--outFormat", "raw", "--writeFailedWindows", "--windowDataOutFile", "{out}.windows"]),
     dict(name="holes_distmat_cat_nexus", tool="distMat.py", fixture="holes",
          argv=["-g", "{geno}", "-f", "phased", "--windType", "cat", "--outFormat", "nexus", "--roundTo", "8"]),
 ]
@@ -176,6 +179,9 @@ CASES += [
                "--hapDist", "0.05", "--roundTo", "8"] + pops_args(12, 3)),
     dict(name="holes_het_hap_only", tool="popgenWindows.py", fixture="holes",
          argv=["-g", "{geno}", "-f", "phased", "-w", "600", "-m", "30", "--analysis", "indHet", "hapStats", "--roundTo", "8"] + pops_args(6, 2)),
+    # every population one cluster: H2 is the INTEGER 0 there (genomics.py:1092-1093), printed "0"
+    dict(name="c1_hap_one_cluster", tool="popgenWindows.py", fixture="c1",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "2500", "-m", "50", "--analysis", "hapStats", "--hapDist", "0.9"] + pops_args(8, 2)),
     dict(name="c1_indpair_hap_exact", tool="popgenWindows.py", fixture="c1",
          argv=["-g", "{geno}", "-f", "phased", "-w", "2500", "-m", "50", "--analysis", "indPairDist", "hapStats", "--roundTo", "8"] + pops_args(8, 2)),
 ]

@@ -11,6 +11,7 @@ unit of the rounding digit apart; anything else is a DIFF.
     python tools/diff_reference_fuzz.py [n_cases] [seed] [jobs]"""
 import concurrent.futures
 import os
+import signal
 import subprocess
 import sys
 import tempfile
@@ -20,6 +21,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from genomics_general_amd import synth                                          # noqa: E402
 import test_dist                                                               # noqa: E402  (CLI_WORKER)
 import test_gpu_golden as G                                                    # noqa: E402  (compare_text)
@@ -73,7 +75,8 @@ def make_input(tmp, case, rng, tool):
     synth.write_geno(geno, scafs, sid, pos, codes, names, sep=pick(rng, ["/", "/", "|"]), fmt=fmt, haploid=haploid)
     ploidy_argv = []
     if haploid:
-        how = pick(rng, ["haploid", "ploidy", "file"]) if tool != "freq.py" else pick(rng, ["haploid", "ploidy", "file"])
+        # a --ploidy LIST is dealt to the samples in the hash order of a set once populations are named (popgenWindows.py:277-296)
+        how = pick(rng, ["haploid", "file"])
         if how == "haploid":
             hn = [names[k] for k in haploid]
             ploidy_argv = ["--haploid"] + (hn if tool in ("distMat.py", "freq.py") else [",".join(hn)])
@@ -105,7 +108,7 @@ def window_argv(tmp, case, rng, tool, inp):
         argv += ["--windType", "sites", "-w", str(w)]
         if rng.random() < 0.5:
             argv += [overlap_flag, str(int(rng.integers(1, w)))]
-        if rng.random() < 0.4:
+        elif rng.random() < 0.6:                       # with an overlap a window cut short by -D may never advance (both loop / stop)
             argv += ["-D", str(int(rng.integers(w, 8 * w)))]
     elif kind == "predefined":
         cf = os.path.join(tmp, "c%d.coords" % case)
@@ -134,23 +137,24 @@ def window_argv(tmp, case, rng, tool, inp):
         argv += ["--writeFailedWindows"]
     if rng.random() < 0.5 and kind != "cat":
         argv += ["--addWindowID"]
-    if len(inp["scafs"]) > 1 and rng.random() < 0.25:
+    if len(inp["scafs"]) > 1 and rng.random() < 0.25 and kind in ("coordinate", "sites"):
         lf = os.path.join(tmp, "c%d.scafs" % case)
         with open(lf, "w") as f:
             for s in inp["scafs"]:
                 if rng.random() < 0.5:
                     f.write(s + "\n")
             f.write("other\n")
-        argv += [pick(rng, ["--include", "--exclude"]), lf]
+        # --include with sites windows: the reference never leaves its skip loop at the end of the file (genomics.py:2084-2087)
+        argv += [pick(rng, ["--include", "--exclude"]) if kind == "coordinate" else "--exclude", lf]
     return argv
 
 
-def pops(rng, names, n_pops, tmp, case, flags=None):
+def pops(rng, names, n_pops, tmp, case, flags=None, min_size=1):
     """population arguments: -p NAME s1,s2 ... or --popsFile + bare names"""
     per = max(1, len(names) // n_pops)
     groups = [names[k * per:(k + 1) * per] for k in range(n_pops)]
     if rng.random() < 0.3:                                                       # unequal sizes, a sample left out
-        groups = [g[:max(1, len(g) - int(rng.integers(0, 2)))] for g in groups]
+        groups = [g[:max(min_size, len(g) - int(rng.integers(0, 2)))] for g in groups]
     flags = flags or ["-p"] * n_pops
     pn = [pick(rng, ["pop%d", "P%d", "x%d"]) % k for k in range(n_pops)]
     if rng.random() < 0.25:
@@ -198,13 +202,18 @@ def make_case(tmp, case, rng, tools):
     argv = ["-g", inp["geno"], "-f", inp["fmt"]] + window_argv(tmp, case, rng, tool, inp) + inp["ploidy_argv"]
     if tool == "popgenWindows.py":
         an = [a for a in ANALYSES if rng.random() < 0.4]
+        if inp["haploid"] or inp["fmt"] == "haplo":
+            an = [a for a in an if a != "indHet"]                    # sampleHet indexes a second haplotype: the worker dies
         if an:
             argv += ["--analysis"] + an
             if "hapStats" in an and rng.random() < 0.6:
                 argv += ["--hapDist", str(pick(rng, [0.01, 0.05, 0.3]))]
         r = rng.random()
         if r < 0.8:
-            argv += pops(rng, names, int(pick(rng, [1, 2, 2, 3, 4])), tmp, case)
+            n_pops = int(pick(rng, [1, 2, 2, 3, 4]))
+            if "popFreq" in an and inp["fmt"] == "haplo":
+                n_pops = min(n_pops, 2)                              # Tajima's D of a single haplotype divides by zero there
+            argv += pops(rng, names, n_pops, tmp, case, min_size=2 if "popFreq" in an and (inp["haploid"] or inp["fmt"] == "haplo") else 1)
         if rng.random() < 0.25 and ("indPairDist" in an or "indHet" in an):
             k = int(rng.integers(2, len(names) + 1))
             argv += ["--samples", ",".join(str(x) for x in rng.choice(names, size=k, replace=False))]
@@ -247,13 +256,20 @@ def make_case(tmp, case, rng, tools):
 def run_case(case, tool, argv, digits, tmp, sizes, blocks):
     ref_out = os.path.join(tmp, "ref%d.out" % case)
     env = dict(os.environ, PYTHONHASHSEED="0")
+    # the reference in its own process group: a hang (a dead worker, a loop of the parent) is ended with all its workers
+    pr = subprocess.Popen([sys.executable, "-c", WRAP, os.path.join(REF, tool)] + [a.format(out=ref_out) for a in argv] + ["-o", ref_out],
+                          cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, start_new_session=True)
     try:
-        r = subprocess.run([sys.executable, "-c", WRAP, os.path.join(REF, tool)] + [a.format(out=ref_out) for a in argv] + ["-o", ref_out],
-                           cwd=tmp, timeout=240, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        ref_err = pr.communicate(timeout=100)[1].decode()
+        hung = False
     except subprocess.TimeoutExpired:
-        r = None
-    ref_failed = r is None or r.returncode != 0
-    ref_msg = "timeout (a hang)" if r is None else (r.stderr.decode().strip().splitlines() or ["?"])[-1][:150]
+        os.killpg(pr.pid, signal.SIGKILL)
+        ref_err = pr.communicate()[1].decode()
+        hung = True
+    ref_failed = hung or pr.returncode != 0
+    tb = [ln for ln in ref_err.strip().splitlines() if "Error" in ln]
+    ref_msg = ("hangs" + (": " + tb[-1] if tb else "")) if hung else (ref_err.strip().splitlines() or ["?"])[-1]
+    ref_msg = ref_msg[:170]
     want = open(ref_out).read() if os.path.exists(ref_out) else ""
     want_w = open(ref_out + ".windows").read() if os.path.exists(ref_out + ".windows") else None
     verdicts, bad, notes = [], 0, []
@@ -277,8 +293,10 @@ def run_case(case, tool, argv, digits, tmp, sizes, blocks):
             # the reference stopped (an assert, a crash of a worker = a hang): the driver must stop with an error too, or its output is
             # unchecked; reported, not counted
             verdicts.append("%d:%s" % (size, "both-stop" if ours_failed else "ref-only-stop"))
-            if not ours_failed:
+            if size == sizes[0]:
                 notes.append("reference: " + ref_msg)
+                if ours_failed:
+                    notes.append("driver:    " + ([ln for e in errs for ln in e.strip().splitlines() if ln.strip()] or ["?"])[-1][:150])
             continue
         if ours_failed:
             verdicts.append("%d:FAILED" % size)
