@@ -9,7 +9,7 @@ parseVCF.py:268-303), streams the input in blocks and renders the rows.
 
 Supported: -i/-o (.gz by suffix, stdin/stdout), -s/--samples, --include/--exclude(/File), --minQual, --gtf (repeatable), --skipIndels,
 --excludeDuplicates, --maxREFlen, --ploidy, --ploidyFile, --ploidyMismatchToMissing, --keepPartial, --addRefTrack, --noHeader,
---missing (one character), --outSep (one character), and --field NAME (the values of another FORMAT field instead of genotypes:
+--missing, --outSep (of several characters: the line loop below, text only), and --field NAME (the values of another FORMAT field instead of genotypes:
 plain text out, a line loop on the host -- that output is not an input of the engine), and --simplifyALT / --expandMulti (ALT
 haplotypes of freebayes records rewritten to the length of REF from their CIGAR strings; one row per base with --expandMulti:
 _cigar_main, likewise a line loop on the host).  Alleles longer than one base (indels without --skipIndels;
@@ -222,6 +222,7 @@ def _cigar_main(args):
     for g in [_parse_gtf(g) for g in args.gtf] if args.gtf else []:
         filters.append(g)
     expand, must_match, keep_partial = args.expandMulti, args.skipIndels, args.keepPartial
+    simplify = args.simplifyALT or args.expandMulti                 # neither: a --missing / --outSep of several characters (main)
     sep = args.outSep
     if not args.noHeader:
         out.write(sep.join(["#CHROM", "POS"] + (["REF"] if args.addRefTrack else []) + samples) + "\n")
@@ -236,10 +237,11 @@ def _cigar_main(args):
                 continue
             last = (f[0], f[1])
         chrom, pos, ref, qual = f[0], int(f[1]), f[3], f[5]
-        info = dict(x.split("=") for x in f[7].split(";"))          # (a flag without `=` is a ValueError here as there)
         alts = f[4].split(",") if f[4] != "." else []
-        cigars = info["CIGAR"].split(",")
-        alts = [_simplify_alt(a, cigars[k]) for k, a in enumerate(alts)]
+        if simplify:
+            info = dict(x.split("=") for x in f[7].split(";"))      # (a flag without `=` is a ValueError here as there)
+            cigars = info["CIGAR"].split(",")
+            alts = [_simplify_alt(a, cigars[k]) for k, a in enumerate(alts)]
         if (exclude and chrom in exclude) or (include and chrom not in include):
             continue
         if args.minQual:
@@ -337,7 +339,11 @@ def parse_vcf_main(argv=None):
         return _cigar_main(args)
     missing = args.missing if args.missing is not None else "N"
     if len(missing) != 1 or len(args.outSep) != 1:
-        raise SystemExit("parseVCF.py: --missing and --outSep must be single characters here")
+        # cells of varying width (`NA/NA`): the line loop of --simplifyALT writes them (text only); the native parser and the
+        # packed format are for one-character cells
+        if args.packed:
+            raise SystemExit("parseVCF.py: --packed needs --missing and --outSep of one character")
+        return _cigar_main(args)
     want_text = bool(args.outFile) or not args.packed
     if args.packed and args.addRefTrack and not want_text:
         raise SystemExit("parseVCF.py: --addRefTrack has no meaning for --packed output")

@@ -27,6 +27,10 @@ VCF_CASES = [
     ("main_ad_list", "main", ["--skipIndels", "--gtf", "flag=AD", "min=1", "gtTypes=Het,HomAlt"]),
     ("snps_default", "snps", []),
     ("hap_ploidyfile", "hap", ["--skipIndels", "--ploidyFile", "{dir}/hap.ploidy", "--ploidyMismatchToMissing"]),
+    # cells of varying width: a --missing / --outSep of several characters
+    ("main_missing_na", "main", ["--skipIndels", "--missing", "NA", "--gtf", "flag=DP", "min=5"]),
+    ("hap_outsep_two_partial", "hap", ["--outSep", "::", "--missing", "??", "--keepPartial", "--ploidyFile", "{dir}/hap.ploidy",
+                                       "--ploidyMismatchToMissing", "--addRefTrack"]),
     ("main_field_dp", "main", ["--field", "DP"]),
     ("main_field_gq_subset", "main", ["--field", "GQ", "--missing", "NA", "-s", "s3,s1", "--excludeDuplicates", "--minQual", "30",
                                       "--addRefTrack", "--exclude", "chr2", "--maxREFlen", "1"]),
