@@ -1139,7 +1139,7 @@ def distmat_main(argv=None):
     def cat_window(data):
         # parseGenoFile (genomics.py:1949-1967): every site of the file, positions ignored
         T = windows.WindowTable()
-        T.add(None, None, None, 0, data.n_sites, None)
+        T.add(None, float("nan"), float("nan"), 0, data.n_sites, None)      # first / last of a list of nan positions (distMat.py:36)
         T.finish(data.pos)
         T.mid = [float("nan")]
         return T

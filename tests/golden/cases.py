@@ -154,6 +154,8 @@ CASES = [
     # no -m: the default is 1 (distMat.py:123), not the window size
     dict(name="holes_distmat_default_minsites", tool="distMat.py", fixture="holes",
          argv=["-g", "{geno}", "-f", "phased", "-w", "700", "--outFormat", "raw", "--writeFailedWindows", "--windowDataOutFile", "{out}.windows"]),
+    dict(name="holes_distmat_cat_windows", tool="distMat.py", fixture="holes",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "cat", "--outFormat", "raw", "--windowDataOutFile", "{out}.windows"]),
     dict(name="holes_distmat_cat_nexus", tool="distMat.py", fixture="holes",
          argv=["-g", "{geno}", "-f", "phased", "--windType", "cat", "--outFormat", "nexus", "--roundTo", "8"]),
 ]

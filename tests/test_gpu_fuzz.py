@@ -1,0 +1,70 @@
+"""-m gpu: random command lines (tools/diff_reference_fuzz.py's generator: formats, mixed ploidy, half-missing genotypes, irregular
+text, every --analysis subset, all window types, distMat / fourPop / freq options) through the drop-in drivers on the HIP engine
+against the same drivers on the CPU stand-in engine (tests/cpu_engine.py: the oracle's numbers).  In the build container the
+stand-in side of this comparison is what tools/diff_reference_fuzz.py holds against the unmodified reference, byte for byte
+(profiles/r04/diff_reference_fuzz_120_cases.txt); here the HIP kernels, the device tokenizer and engine.WindowBatch are held against
+the stand-in on command lines no golden has.  Text must be equal; a float cell may sit on the other side of a rounding tie."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import diff_reference_fuzz as F                                                 # noqa: E402
+from cpu_engine import CpuEngine                                                # noqa: E402
+from golden_util import align_columns                                           # noqa: E402
+from genomics_general_amd import cli                                            # noqa: E402
+import test_gpu_golden as G                                                     # noqa: E402
+
+TOOLS = ["popgenWindows.py", "popgenWindows.py", "popgenWindows.py", "distMat.py", "distMat.py", "ABBABABAwindows.py",
+         "fourPopWindows.py", "freq.py"]
+CASES_PER_SEED = 10
+
+
+def _run(tool, argv, out):
+    """-> (error or None, text, side file text)"""
+    try:
+        rc = G.MAINS[tool]([a.format(out=out) for a in argv] + ["-o", out])
+    except (Exception, SystemExit) as e:                                        # an assert of the parent, a refusal of the library
+        return "%s: %s" % (type(e).__name__, str(e)[:200]), None, None
+    if rc:
+        return "rc %s" % rc, None, None
+    with open(out) as f:
+        text = f.read()
+    side = None
+    if os.path.exists(out + ".windows"):
+        with open(out + ".windows") as f:
+            side = f.read()
+    return None, text, side
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_command_lines_on_the_hip_engine_match_the_stand_in(seed, tmp_path, monkeypatch):
+    rng = np.random.default_rng(77000 + seed)
+    compared = 0
+    for case in range(CASES_PER_SEED):
+        tool, argv, digits, inp = F.make_case(str(tmp_path), case, rng, TOOLS)
+        block = int(F.pick(rng, [3000, 30000, 1 << 30]))
+        what = "%s %s (blocks of %d)" % (tool, " ".join(argv), block)
+        monkeypatch.setenv("PG_STREAM_BYTES", str(block))
+        err_hip, got, got_side = _run(tool, argv, str(tmp_path / ("hip%d.out" % case)))
+        with monkeypatch.context() as m:
+            m.setattr(cli, "Engine", CpuEngine)
+            err_cpu, want, want_side = _run(tool, argv, str(tmp_path / ("cpu%d.out" % case)))
+        if err_cpu is not None or err_hip is not None:
+            # a command line both refuse (an assert of the parent: same host code); the stand-in alone stops where the oracle divides
+            # by zero as the reference does (Tajima's D of one haplotype) and the engine answers nan
+            assert err_hip is not None or "ZeroDivisionError" in err_cpu, "%s\n  HIP engine ran, the stand-in stopped: %s" % (what, err_cpu)
+            assert err_cpu is not None, "%s\n  the stand-in ran, the HIP engine stopped: %s" % (what, err_hip)
+            continue
+        try:
+            n = G.compare_text(align_columns(got, want), want, digits)
+        except AssertionError as e:
+            raise AssertionError("%s\n  %s" % (what, e))
+        assert n <= max(2, len(want.split()) // 50), "%s\n  %d cells differ in the last digit" % (what, n)
+        assert got_side == want_side, what
+        compared += 1
+    assert compared >= CASES_PER_SEED // 2, "only %d of %d random command lines ran" % (compared, CASES_PER_SEED)

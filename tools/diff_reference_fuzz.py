@@ -73,6 +73,24 @@ def make_input(tmp, case, rng, tool):
     scafs = [pick(rng, ["chr%d", "scaffold_%d", "%d"]) % (k + 1) for k in range(n_scaf)]
     geno = os.path.join(tmp, "c%d.geno%s" % (case, ".gz" if rng.random() < 0.25 else ""))
     synth.write_geno(geno, scafs, sid, pos, codes, names, sep=pick(rng, ["/", "/", "|"]), fmt=fmt, haploid=haploid)
+    header_argv = []
+    if rng.random() < 0.3:                                       # irregular text: blanks as separators, comment lines, no header line
+        import gzip
+        op = gzip.open if geno.endswith(".gz") else open
+        with op(geno, "rt") as f:
+            lines = f.read().splitlines()
+        # (freq.py reads a comment line as a site: scaffold `#`, garbage counts; the drop-in skips it like the window drivers)
+        how = pick(rng, ["blanks", "comments", "noheader"] if tool != "freq.py" else ["blanks"])
+        if how == "blanks":
+            lines = [ln.replace("\t", " ") for ln in lines]
+        elif how == "comments":
+            for _ in range(int(rng.integers(1, 4))):
+                lines.insert(int(rng.integers(1, len(lines) + 1)), "# a comment line")
+        elif tool != "freq.py":
+            header_argv = (["--headers"] + lines[0].split()) if tool == "distMat.py" else ["--header", lines[0]]
+            lines = lines[1:]
+        with op(geno, "wt") as f:
+            f.write("\n".join(lines) + "\n")
     ploidy_argv = []
     if haploid:
         # a --ploidy LIST is dealt to the samples in the hash order of a set once populations are named (popgenWindows.py:277-296)
@@ -88,7 +106,10 @@ def make_input(tmp, case, rng, tool):
                 for k in range(n_dip):
                     f.write("%s\t%d\n" % (names[k], 1 if k in haploid else 2))
             ploidy_argv = ["--ploidyFile", pf]
-    return dict(geno=geno, fmt=fmt, names=names, scafs=scafs, lens=lens, haploid=haploid, ploidy_argv=ploidy_argv, n_sites=len(pos))
+    elif tool != "freq.py" and fmt != "haplo" and rng.random() < 0.15:
+        ploidy_argv = pick(rng, [["--inferPloidy"], ["--ploidy", "2"]])
+    return dict(geno=geno, fmt=fmt, names=names, scafs=scafs, lens=lens, haploid=haploid, ploidy_argv=ploidy_argv + header_argv,
+                n_sites=len(pos))
 
 
 def window_argv(tmp, case, rng, tool, inp):
