@@ -22,10 +22,10 @@ class PopgenError(RuntimeError):
 
 PG_ERR_ARG, PG_ERR_HIP, PG_ERR_NODEV, PG_ERR_PARSE, PG_ERR_RCCL, PG_ERR_STATE = -1, -2, -3, -4, -5, -6
 FMT = {"phased": 0, "pairs": 1, "haplo": 2, "diplo": 3}
-K_PACK, K_PAIRWISE, K_POPDIST_FIN, K_SITESTATS, K_SYNTH, K_PAIRD, K_INDPAIR_FIN, K_RESULT_D2H = 0, 1, 2, 3, 4, 5, 6, 7
+K_PACK, K_PAIRWISE, K_POPDIST_FIN, K_SITESTATS, K_SYNTH, K_PAIRD, K_INDPAIR_FIN, K_RESULT_D2H, K_ORDERED = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KERNEL_NAMES = {K_PACK: "k_pack", K_PAIRWISE: "k_pairC", K_POPDIST_FIN: "k_popdist_fin",
                 K_SITESTATS: "k_sitestats", K_SYNTH: "k_synth", K_PAIRD: "k_pairD", K_INDPAIR_FIN: "k_indpair_fin",
-                K_RESULT_D2H: "result_d2h"}
+                K_RESULT_D2H: "result_d2h", K_ORDERED: "k_popfreq_ordered"}
 
 _lib = None
 
@@ -95,7 +95,7 @@ SIGNATURES = {
     "pg_abbababa": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _f64p, _i64p]),
     "pg_fourpop": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _f64p,
                              _i64p]),
-    "pg_popfreq": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p, _i64p, _i64p]),
+    "pg_popfreq": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p, _i64p, _i64p, _f64p]),
     "pg_hap_called": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p]),
     "pg_site_counts": (C.c_int, [_P, C.c_int64, C.c_int64, _i32p]),
     "pg_kernel_time": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -186,6 +186,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->hapbits.release();
     c->hap_order.release();
     c->site_tmp.release();
+    c->site_flags.release();
     c->Vp.release();
     c->XY.release();
     c->Cmat.release();
@@ -1205,7 +1206,7 @@ extern "C" int pg_fourpop(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n
 }
 
 extern "C" int pg_popfreq(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int64_t *l_out, int64_t *S_out,
-                          int64_t *pairsum_out) {
+                          int64_t *pairsum_out, double *theta_pi_out) {
     int rc = check_windows(c, lo, hi, n_win);
     if (rc != PG_OK) return rc;
     if (c->n_pops < 1 || c->n_pops > PG_MAX_POPS) return pg_fail(PG_ERR_ARG, "pg_popfreq supports 1..%d populations (got %d)", PG_MAX_POPS, c->n_pops);
@@ -1220,23 +1221,48 @@ extern "C" int pg_popfreq(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n
         int64_t max_len = 0;
         if ((rc = stage_windows(c, lo, hi, w0, w1, nullptr, nullptr, &max_len)) != PG_OK) return rc;
         int max_chunks = (int)((max_len + PG_SITES_PER_BLOCK - 1) / PG_SITES_PER_BLOCK);
-        size_t nres = (size_t)nb * (1 + 2 * P);
-        if ((rc = c->res_i64.ensure(nres)) != PG_OK) return rc;
-        HIPCHK(hipMemsetAsync(c->res_i64.p, 0, nres * 8, c->stream));
+        size_t nres = (size_t)nb * (1 + 2 * P), nall = nres + (theta_pi_out ? (size_t)nb * P : 0);
+        if ((rc = c->res_i64.ensure(nall)) != PG_OK) return rc;
+        HIPCHK(hipMemsetAsync(c->res_i64.p, 0, nall * 8, c->stream));
         unsigned long long *dl = reinterpret_cast<unsigned long long *>(c->res_i64.p);
         unsigned long long *dS = dl + nb, *dP = dS + (size_t)nb * P;
+        double *dT = theta_pi_out ? reinterpret_cast<double *>(dP + (size_t)nb * P) : nullptr;
+        // theta_pi_out: one flag bit per site of the span of these windows, raised by the counting kernel, walked in site order by
+        // k_popfreq_ordered (the reference's sequential sum)
+        uint32_t *flags = nullptr;
+        int64_t base = 0;
+        if (theta_pi_out) {
+            int64_t top = 0;
+            base = INT64_MAX;
+            for (int w = w0; w < w1; ++w)
+                if (hi[w] > lo[w]) { base = std::min(base, lo[w]); top = std::max(top, hi[w]); }
+            if (base == INT64_MAX) base = top = 0;
+            base &= ~(int64_t)127;
+            const size_t words = (size_t)((top - base + 31) / 32) + 64;
+            if ((rc = c->site_flags.ensure(words)) != PG_OK) return rc;
+            HIPCHK(hipMemsetAsync(c->site_flags.p, 0, words * 4, c->stream));
+            flags = c->site_flags.p;
+        }
         hipEvent_t e0, e1;
         if ((rc = pg_time_begin(c, PG_K_SITESTATS, &e0, &e1)) != PG_OK) return rc;
-        pg_launch_popfreq(c->stream, c->gt.p, c->S, c->n_hap, c->win.p, c->win.p + nb, nb, max_chunks, c->pop_start.p, P, dl, dS, dP);
+        pg_launch_popfreq(c->stream, c->gt.p, c->S, c->n_hap, c->win.p, c->win.p + nb, nb, max_chunks, c->pop_start.p, P, dl, dS, dP,
+                          flags, base);
         if ((rc = pg_time_end(c, PG_K_SITESTATS, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
-        if ((rc = c->out_pin.ensure(nres)) != PG_OK) return rc;
-        HIPCHK(hipMemcpyAsync(c->out_pin.p, dl, nres * 8, hipMemcpyDeviceToHost, c->stream));
+        if (flags) {
+            if ((rc = pg_time_begin(c, PG_K_ORDERED, &e0, &e1)) != PG_OK) return rc;
+            pg_launch_popfreq_ordered(c->stream, c->gt.p, c->S, c->win.p, c->win.p + nb, nb, c->pop_start.p, P, flags, base, dT);
+            if ((rc = pg_time_end(c, PG_K_ORDERED, e0, e1, 1)) != PG_OK) return rc;
+            HIPCHK(hipGetLastError());
+        }
+        if ((rc = c->out_pin.ensure(nall)) != PG_OK) return rc;
+        HIPCHK(hipMemcpyAsync(c->out_pin.p, dl, nall * 8, hipMemcpyDeviceToHost, c->stream));
         if ((rc = stream_wait(c)) != PG_OK) return rc;
         const int64_t *hp = reinterpret_cast<const int64_t *>(c->out_pin.p);
         memcpy(l_out + w0, hp, (size_t)nb * 8);
         memcpy(S_out + (size_t)w0 * P, hp + nb, (size_t)nb * P * 8);
         memcpy(pairsum_out + (size_t)w0 * P, hp + nb + (size_t)nb * P, (size_t)nb * P * 8);
+        if (theta_pi_out) memcpy(theta_pi_out + (size_t)w0 * P, hp + nres, (size_t)nb * P * 8);
         w0 = w1;
     }
     return PG_OK;

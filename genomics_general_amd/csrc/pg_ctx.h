@@ -137,6 +137,7 @@ struct pg_ctx {
     DevBuf<uint32_t> hapbits;      // k_hapstats: match matrices as bit rows
     DevBuf<int32_t> hap_order;     // k_hapstats: each population's slots in the reference's row order
     DevBuf<int32_t> site_tmp;      // pg_site_counts staging
+    DevBuf<uint32_t> site_flags;   // pg_popfreq: one bit per site (k_popfreq_ordered)
     // how the matrices of the last batch are laid out (set by pairwise_batches)
     int cN = 0, cshift = 0;
     // resident sites

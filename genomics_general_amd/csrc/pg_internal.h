@@ -56,7 +56,10 @@ void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_
 
 void pg_launch_popfreq(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
                        const int64_t *win_hi, int n_win, int max_chunks, const int32_t *pop_start, int n_pops,
-                       unsigned long long *l_out, unsigned long long *S_out, unsigned long long *pairsum_out);
+                       unsigned long long *l_out, unsigned long long *S_out, unsigned long long *pairsum_out,
+                       uint32_t *flags, int64_t base);
+void pg_launch_popfreq_ordered(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi, int n_win,
+                               const int32_t *pop_start, int n_pops, const uint32_t *flags, int64_t base, double *theta_out);
 
 void pg_launch_site_counts(hipStream_t st, const int8_t *gt, int S, int64_t site_lo, int64_t site_hi,
                            const int32_t *pop_start, int n_pops, int32_t *cnt_out);

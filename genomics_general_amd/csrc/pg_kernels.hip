@@ -1129,12 +1129,18 @@ struct FreqAcc {
     unsigned long long l, Sx[PG_MAX_POPS], Px[PG_MAX_POPS];
 };
 
+// flag_site: the site takes part in k_popfreq_ordered's sums (every slot called, polymorphic within some population)
+__device__ __forceinline__ void flag_site(uint32_t *__restrict__ flags, int64_t rel) {
+    atomicOr(&flags[rel >> 5], 1u << (rel & 31));
+}
+
 __device__ __forceinline__ void popfreq_site(const uint32_t *__restrict__ row, int n_hap, const int32_t *__restrict__ pop_start,
-                                             int n_pops, FreqAcc &F) {
+                                             int n_pops, FreqAcc &F, uint32_t *__restrict__ flags, int64_t rel) {
     uint32_t call[4];
     range_counts(row, 0, n_hap, call);
     if ((int)(call[0] + call[1] + call[2] + call[3]) != n_hap) return;       // genomics.py:1010
     ++F.l;
+    bool poly = false;
 #pragma unroll
     for (int q = 0; q < PG_MAX_POPS; ++q) {
         if (q < n_pops) {
@@ -1145,8 +1151,10 @@ __device__ __forceinline__ void popfreq_site(const uint32_t *__restrict__ row, i
                                           (unsigned long long)c[1] * c[3] + (unsigned long long)c[2] * c[3];
             F.Px[q] += pr;
             F.Sx[q] += (pr != 0ull);
+            poly = poly || pr != 0ull;
         }
     }
+    if (poly && flags) flag_site(flags, rel);
 }
 
 // Rows longer than 1024 bytes (more than 1024 haplotype slots): one thread per site straight from global memory.
@@ -1155,7 +1163,8 @@ __global__ __launch_bounds__(256) void k_popfreq(const int8_t *__restrict__ gt, 
                                                  const int32_t *__restrict__ pop_start, int n_pops,
                                                  unsigned long long *__restrict__ l_out,
                                                  unsigned long long *__restrict__ S_out,
-                                                 unsigned long long *__restrict__ pairsum_out) {
+                                                 unsigned long long *__restrict__ pairsum_out, uint32_t *__restrict__ flags,
+                                                 int64_t base) {
     __shared__ unsigned long long shu[256];
     const int win = blockIdx.y, chunk = blockIdx.x;
     const int64_t lo = win_lo[win], hi = win_hi[win];
@@ -1167,7 +1176,7 @@ __global__ __launch_bounds__(256) void k_popfreq(const int8_t *__restrict__ gt, 
     for (int q = 0; q < PG_MAX_POPS; ++q) { F.Sx[q] = 0; F.Px[q] = 0; }
     const int64_t c1 = (c0 + PG_SITES_PER_BLOCK < hi) ? c0 + PG_SITES_PER_BLOCK : hi;
     for (int64_t t = c0 + threadIdx.x; t < c1; t += blockDim.x)
-        popfreq_site(reinterpret_cast<const uint32_t *>(gt + t * (int64_t)S), n_hap, pop_start, n_pops, F);
+        popfreq_site(reinterpret_cast<const uint32_t *>(gt + t * (int64_t)S), n_hap, pop_start, n_pops, F, flags, t - base);
     __syncthreads();
     unsigned long long r = block_sum_u64(F.l, shu);
     if (threadIdx.x == 0 && r) atomicAdd(&l_out[win], r);
@@ -1189,7 +1198,8 @@ __global__ __launch_bounds__(256) void k_popfreq_q(const int8_t *__restrict__ gt
                                                    const int32_t *__restrict__ pop_start, int n_pops,
                                                    unsigned long long *__restrict__ l_out,
                                                    unsigned long long *__restrict__ S_out,
-                                                   unsigned long long *__restrict__ pairsum_out) {
+                                                   unsigned long long *__restrict__ pairsum_out, uint32_t *__restrict__ flags,
+                                                   int64_t base) {
     __shared__ int64_t cand[4][PG_ABBA_CAND];
     __shared__ unsigned long long shu[4][4][9];
     // per-lane accumulators live in LDS (slot k of lane l at [k][l]): the counting pass is the rare path on typical data, and
@@ -1222,6 +1232,7 @@ __global__ __launch_bounds__(256) void k_popfreq_q(const int8_t *__restrict__ gt
                                               (unsigned long long)c[1] * c[3] + (unsigned long long)c[2] * c[3];
                 my_acc[1 + j][lane] += (pr != 0ull);
                 my_acc[5 + j][lane] += pr;
+                if (pr != 0ull && flags) flag_site(flags, site - base);
             }
         }
     };
@@ -1302,9 +1313,97 @@ __global__ __launch_bounds__(256) void k_popfreq_q(const int8_t *__restrict__ gt
     }
 }
 
+// k_popfreq_ordered: thetaPi as the reference forms it.  Alignment.groupFreqStats takes Python's sum() over the window's
+// per-site values `pairs / (.5*N*(N-1))` (genomics.py:1016-1018, 609-616): a SEQUENTIAL float64 sum in site order, whose
+// roundings no reduction tree reproduces -- and for a population of three haplotypes Tajima's D is that rounding noise over a
+// variance of exactly zero (+-inf or nan in the reference's output).  One wave per window walks the flags the counting kernels
+// left (1 bit per site: every slot called and some population polymorphic; all other sites add 0.0, which changes nothing),
+// 2048 sites per step: the flagged sites are listed in site order, their per-population values are formed 64 sites at a time
+// (one site per lane), and lane p adds the values of population p one after the other.
+__global__ __launch_bounds__(64) void k_popfreq_ordered(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
+                                                        const int64_t *__restrict__ win_hi, const int32_t *__restrict__ pop_start,
+                                                        int n_pops, const uint32_t *__restrict__ flags, int64_t base,
+                                                        double *__restrict__ theta_out) {
+    __shared__ uint16_t list[8192];
+    __shared__ double tile[PG_MAX_POPS][65];
+    const int win = blockIdx.x, lane = threadIdx.x;
+    const int64_t lo = win_lo[win], hi = win_hi[win];
+    double acc = 0.0;
+    if (hi > lo) {
+        // four flag words (128 sites) per lane and step: 8192 sites per step (`base` is a multiple of 128 sites, the flag buffer
+        // ends in slack words)
+        const int64_t q_first = (lo - base) >> 7, q_last = (hi - 1 - base) >> 7;
+        const uint4 *f4 = reinterpret_cast<const uint4 *>(flags);
+        const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+        uint4 vn[4];                                                         // the flag words of the next four steps, in flight
+#pragma unroll
+        for (int a = 0; a < 4; ++a) vn[a] = q_first + 64 * a + lane <= q_last ? f4[q_first + 64 * a + lane] : zero4;
+        for (int64_t q0 = q_first; q0 <= q_last; q0 += 64) {
+            const int64_t q = q0 + lane;
+            uint32_t bits[4] = {0u, 0u, 0u, 0u};
+            const uint4 v = vn[0];
+            vn[0] = vn[1]; vn[1] = vn[2]; vn[2] = vn[3];
+            vn[3] = q + 256 <= q_last ? f4[q + 256] : zero4;
+            if (q <= q_last) {
+                bits[0] = v.x; bits[1] = v.y; bits[2] = v.z; bits[3] = v.w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t s0 = base + (q << 7) + 32 * k;             // the site of bit 0 of word k
+                    if (s0 + 32 <= lo || s0 >= hi) bits[k] = 0u;
+                    else {
+                        if (s0 < lo) bits[k] &= ~0u << (int)(lo - s0);
+                        if (hi - s0 < 32) bits[k] &= (1u << (int)(hi - s0)) - 1u;
+                    }
+                }
+            }
+            const int cnt = __popc(bits[0]) + __popc(bits[1]) + __popc(bits[2]) + __popc(bits[3]);
+            if (__ballot(cnt != 0) == 0ull) continue;                        // (wave-uniform) nothing flagged among these 8192 sites
+            int pre = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(pre, d, 64);
+                if (lane >= d) pre += v;
+            }
+            const int total = __shfl(pre, 63, 64);
+            int k = pre - cnt;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                uint32_t b = bits[x];
+                while (b) {
+                    list[k++] = (uint16_t)(lane * 128 + 32 * x + (__ffs((int)b) - 1));
+                    b &= b - 1u;
+                }
+            }
+            __syncthreads();
+            for (int b0 = 0; b0 < total; b0 += 64) {
+                const int nb = total - b0 < 64 ? total - b0 : 64;
+                if (lane < nb) {
+                    const int8_t *rowb = gt + (base + (q0 << 7) + list[b0 + lane]) * (int64_t)S;
+                    for (int p = 0; p < n_pops; ++p) {
+                        const int ps = pop_start[p], pe = pop_start[p + 1];
+                        uint32_t c[4];
+                        range_counts_x4(rowb, ps, pe, c);
+                        const unsigned long long pr = (unsigned long long)c[0] * c[1] + (unsigned long long)c[0] * c[2] +
+                                                      (unsigned long long)c[0] * c[3] + (unsigned long long)c[1] * c[2] +
+                                                      (unsigned long long)c[1] * c[3] + (unsigned long long)c[2] * c[3];
+                        const double N = (double)(pe - ps);
+                        tile[p][lane] = (double)pr / (.5 * N * (N - 1.0));       // baseCountPi, genomics.py:609-616
+                    }
+                }
+                __syncthreads();
+                if (lane < n_pops)
+                    for (int j = 0; j < nb; ++j) acc = acc + tile[lane][j];
+                __syncthreads();
+            }
+        }
+    }
+    if (lane < n_pops) theta_out[(size_t)win * n_pops + lane] = acc;
+}
+
 void pg_launch_popfreq(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
                        const int64_t *win_hi, int n_win, int max_chunks, const int32_t *pop_start, int n_pops,
-                       unsigned long long *l_out, unsigned long long *S_out, unsigned long long *pairsum_out) {
+                       unsigned long long *l_out, unsigned long long *S_out, unsigned long long *pairsum_out,
+                       uint32_t *flags, int64_t base) {
     if (n_win <= 0 || max_chunks <= 0) return;
     const int npass = (S + 255) / 256;
     if (npass <= 4) {                 // rows up to 1024 bytes: screening + counting kernel, 4096-site blocks
@@ -1312,15 +1411,22 @@ void pg_launch_popfreq(hipStream_t st, const int8_t *gt, int S, int n_hap, const
         const dim3 grid(chunks_q, n_win);
 #define PG_POPFREQ_LAUNCH(NP)                                                                                           \
     hipLaunchKernelGGL((k_popfreq_q<NP>), grid, dim3(256), 0, st, gt, S, n_hap, win_lo, win_hi, pop_start, n_pops, l_out, \
-                       S_out, pairsum_out)
+                       S_out, pairsum_out, flags, base)
         if (npass == 1) PG_POPFREQ_LAUNCH(1);
         else if (npass == 2) PG_POPFREQ_LAUNCH(2);
         else PG_POPFREQ_LAUNCH(4);
 #undef PG_POPFREQ_LAUNCH
-        return;
+    } else {
+        hipLaunchKernelGGL(k_popfreq, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, n_hap, win_lo, win_hi, pop_start, n_pops,
+                           l_out, S_out, pairsum_out, flags, base);
     }
-    hipLaunchKernelGGL(k_popfreq, dim3(max_chunks, n_win), dim3(256), 0, st, gt, S, n_hap, win_lo, win_hi, pop_start, n_pops,
-                       l_out, S_out, pairsum_out);
+}
+
+void pg_launch_popfreq_ordered(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi, int n_win,
+                               const int32_t *pop_start, int n_pops, const uint32_t *flags, int64_t base, double *theta_out) {
+    if (n_win <= 0) return;
+    hipLaunchKernelGGL(k_popfreq_ordered, dim3(n_win), dim3(64), 0, st, gt, S, win_lo, win_hi, pop_start, n_pops, flags, base,
+                       theta_out);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -436,14 +436,16 @@ class WindowBatch:
         l = np.zeros(self.n, dtype=np.int64)
         S = np.zeros((self.n, P), dtype=np.int64)
         prs = np.zeros((self.n, P), dtype=np.int64)
-        check(self.e._L.pg_popfreq(self.e._h, self.lo, self.hi, self.n, l, S, prs))
+        seq = np.zeros((self.n, P), dtype=np.float64)
+        check(self.e._L.pg_popfreq(self.e._h, self.lo, self.hi, self.n, l, S, prs, seq))
         out = {}
         has = l >= 1
         for x, name in enumerate(lay.sampleData.popNames):
             N = lay.pop_sizes[x]
             with np.errstate(divide="ignore", invalid="ignore"):
-                denom = .5 * N * (N - 1)
-                theta_pi = np.where(has, prs[:, x] / np.float64(denom), np.nan)
+                # thetaPi: the reference's site-by-site sum, formed in that order on the device (k_popfreq_ordered); a population
+                # of one haplotype has 0/0 per site there (and a dead worker after it): nan
+                theta_pi = np.where(has, seq[:, x] if N > 1 else np.nan, np.nan)
                 a = np.sum(1. / np.arange(1, N))
                 theta_w = np.where(has, S[:, x] / a, np.nan)
                 taj = np.where(has, _tajima_d(N, S[:, x].astype(np.float64), theta_pi), np.nan)

@@ -49,7 +49,7 @@ enum pg_geno_format { PG_FMT_PHASED = 0, PG_FMT_PAIRS = 1, PG_FMT_HAPLO = 2, PG_
 enum pg_kernel_id { PG_K_PACK = 0, PG_K_PAIRWISE = 1 /* the called-count kernel (k_pairC*) */, PG_K_POPDIST_FIN = 2,
                     PG_K_SITESTATS = 3, PG_K_SYNTH = 4, PG_K_PAIRD = 5 /* the difference-count kernel (k_pairD*) */,
                     PG_K_INDPAIR_FIN = 6, PG_K_RESULT_D2H = 7 /* copy of a large result table back to the host (indPair means) */,
-                    PG_K_COUNT_ = 8 };
+                    PG_K_ORDERED = 8 /* k_popfreq_ordered: thetaPi as the reference's site-by-site sum */, PG_K_COUNT_ = 9 };
 
 int pg_abi_version(void);
 const char *pg_last_error(void);
@@ -332,9 +332,12 @@ int pg_fourpop(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_
 /* ---- K1+K5: site-frequency window sums -------------------------------------------------------------- */
 /* Replaces Alignment.groupFreqStats (genomics.py:1002-1028) + baseCountPi (609-616).  Sites used are those
  * with no missing call in ANY haplotype slot.  l_out[n_win]; S_out[n_win][n_pops] = #sites with >1 allele
- * in the population; pairsum_out[n_win][n_pops] = sum over sites of sum_{a<b} c_a c_b (exact integers). */
+ * in the population; pairsum_out[n_win][n_pops] = sum over sites of sum_{a<b} c_a c_b (exact integers).
+ * theta_pi_out[n_win][n_pops] (may be NULL): thetaPi as the reference forms it -- Python's sum() over the per-site values
+ * `pairs / (.5*N*(N-1))` in site order (genomics.py:1016-1018), a sequential float64 sum, reproduced bit for bit (Tajima's D of
+ * a population of three haplotypes is that sum's rounding noise over a variance of zero). */
 int pg_popfreq(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int64_t *l_out,
-               int64_t *S_out, int64_t *pairsum_out);
+               int64_t *S_out, int64_t *pairsum_out, double *theta_pi_out);
 
 /* ---- K1 raw: per-site per-population base counts ------------------------------------------------- */
 /* Replaces Alignment.siteFreqs(asCounts=True) / binBaseFreqs (genomics.py:1049-1052, 592-599) for every
