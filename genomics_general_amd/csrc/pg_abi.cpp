@@ -187,6 +187,10 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->hap_order.release();
     c->site_tmp.release();
     c->site_flags.release();
+    c->ref_row.release();
+    c->pop_rank.release();
+    c->np_trees.release();
+    c->np_task_tree.release();
     c->Vp.release();
     c->XY.release();
     c->Cmat.release();
@@ -302,6 +306,15 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
     c->NP = getenv("PG_PAIR_VALU") ? (n_hap + 63) / 64 * 64 : (n_hap + 31) / 32 * 32;
     c->h_pop_start = pstart;
     c->h_samp_start = sstart;
+    {   // the reference's row order / population rank: identity until pg_set_reference_order
+        std::vector<int32_t> ident((size_t)std::max(n_hap, n_pops) + 1);
+        for (size_t k = 0; k < ident.size(); ++k) ident[k] = (int32_t)k;
+        int r2;
+        if ((r2 = c->ref_row.upload(ident.data(), (size_t)n_hap, c->stream)) != PG_OK) return r2;
+        if ((r2 = c->pop_rank.upload(ident.data(), (size_t)std::max(n_pops, 1), c->stream)) != PG_OK) return r2;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->np_state = 0;
+    }
     std::vector<PgTask2> tasks2 = pg_make_tasks_circ(n_hap, 16);       // k_pairD: 16-row circulant tasks
     c->n_tasks2 = (int)tasks2.size();
     c->all_diploid = (n_hap % 2 == 0);
@@ -981,6 +994,141 @@ extern "C" int pg_popdist(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n
     return PG_OK;
 }
 
+extern "C" int pg_set_reference_order(pg_ctx *c, const int32_t *pop_row_order, const int32_t *pop_name_rank) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    HIPCHK(hipSetDevice(c->device));
+    const int n_in = c->n_pops > 0 ? c->h_pop_start[c->n_pops] : 0;
+    int rc;
+    if (pop_row_order && n_in > 0) {
+        for (int p = 0; p < c->n_pops; ++p) {                        // a permutation of the population's own slots
+            std::vector<char> seen(c->h_pop_start[p + 1] - c->h_pop_start[p], 0);
+            for (int k = c->h_pop_start[p]; k < c->h_pop_start[p + 1]; ++k) {
+                const int sl = pop_row_order[k] - c->h_pop_start[p];
+                if (sl < 0 || sl >= (int)seen.size() || seen[sl]) return pg_fail(PG_ERR_ARG, "pop_row_order is not a permutation of the slots of population %d", p);
+                seen[sl] = 1;
+            }
+        }
+        if ((rc = c->ref_row.upload(pop_row_order, (size_t)n_in, c->stream)) != PG_OK) return rc;
+    }
+    if (pop_name_rank && c->n_pops > 0) {
+        std::vector<char> seen(c->n_pops, 0);
+        for (int p = 0; p < c->n_pops; ++p) {
+            if (pop_name_rank[p] < 0 || pop_name_rank[p] >= c->n_pops || seen[pop_name_rank[p]]) return pg_fail(PG_ERR_ARG, "pop_name_rank is not a permutation");
+            seen[pop_name_rank[p]] = 1;
+        }
+        if ((rc = c->pop_rank.upload(pop_name_rank, (size_t)c->n_pops, c->stream)) != PG_OK) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+// NumPy's pairwise summation of n values as a tree (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum): fewer than 8 values or at
+// most 128: a run (k_popdist_np adds it up as NumPy's unrolled loop does); more: the first n/2 rounded down to a multiple of 8, then
+// the rest.  blob = [L, n_inner, n_levels, leaf_off[L + 1], node_l[n_inner], node_r[n_inner], level_start[n_levels + 1]]; the inner
+// nodes ordered by height, slots: runs 0 .. L - 1, inner node k at L + k.
+namespace {
+struct NpNode { int l, r, h; };
+int np_build(int off, int n, std::vector<int32_t> &leaf_off, std::vector<NpNode> &inner, int *height) {
+    if (n <= 128) {
+        leaf_off.push_back(off);
+        *height = 0;
+        return (int)leaf_off.size() - 1;                            // a run: its index
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    int hl, hr;
+    const int l = np_build(off, n2, leaf_off, inner, &hl), r = np_build(off + n2, n - n2, leaf_off, inner, &hr);
+    inner.push_back(NpNode{l, r, std::max(hl, hr) + 1});
+    *height = inner.back().h;
+    return -(int)inner.size();                                      // an inner node: -(index + 1)
+}
+std::vector<int32_t> np_tree(int n) {
+    std::vector<int32_t> leaf_off;
+    std::vector<NpNode> inner;
+    int h = 0;
+    // np.add.reduce hands the flattened block to the pairwise sum in pieces of the ufunc buffer size (np.getbufsize(): 8192
+    // values) and adds the pieces' sums one after the other
+    int node = np_build(0, std::min(n, 8192), leaf_off, inner, &h);
+    for (int at = 8192; at < n; at += 8192) {
+        int hc;
+        const int piece = np_build(at, std::min(8192, n - at), leaf_off, inner, &hc);
+        h = std::max(h, hc) + 1;
+        inner.push_back(NpNode{node, piece, h});
+        node = -(int)inner.size();
+    }
+    leaf_off.push_back(n);
+    const int L = (int)leaf_off.size() - 1, ni = (int)inner.size();
+    std::vector<int> order(ni), where(ni);
+    for (int k = 0; k < ni; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return inner[a].h < inner[b].h; });
+    for (int k = 0; k < ni; ++k) where[order[k]] = k;
+    auto slot = [&](int id) { return id >= 0 ? id : L + where[-id - 1]; };
+    std::vector<int32_t> blob;
+    blob.push_back(L); blob.push_back(ni); blob.push_back(h);
+    blob.insert(blob.end(), leaf_off.begin(), leaf_off.end());
+    for (int k = 0; k < ni; ++k) blob.push_back(slot(inner[order[k]].l));
+    for (int k = 0; k < ni; ++k) blob.push_back(slot(inner[order[k]].r));
+    int at = 0;
+    for (int lv = 1; lv <= h; ++lv) {
+        blob.push_back(at);
+        while (at < ni && inner[order[at]].h == lv) ++at;
+    }
+    blob.push_back(at);
+    return blob;
+}
+}  // namespace
+
+#define PG_NP_MAX_LEAVES 1536      // 2 * 1536 + 32 * 128 doubles of LDS = 56 KB per block
+#define PG_NP_MAX_SITES 4096
+
+// the trees of this context's blocks: (x, x), and (x, y) / (x + y, x + y) for every pair: their lengths do not depend on the orientation
+static int np_prepare(pg_ctx *c) {
+    if (c->np_state != 0) return PG_OK;
+    const int P = c->n_pops;
+    std::vector<int> lens;
+    int side = 2;
+    for (int p = 0; p < P; ++p) {
+        const int n = c->h_pop_start[p + 1] - c->h_pop_start[p];
+        if (n > 4096) { c->np_state = -1; return PG_OK; }
+        lens.push_back(n * n);
+        side = std::max(side, 2 * n);
+    }
+    for (int x = 0; x < P; ++x)
+        for (int y = x + 1; y < P; ++y) {
+            const int64_t nx = c->h_pop_start[x + 1] - c->h_pop_start[x], ny = c->h_pop_start[y + 1] - c->h_pop_start[y];
+            if ((nx + ny) * (nx + ny) > (int64_t)PG_NP_MAX_LEAVES * 128) { c->np_state = -1; return PG_OK; }
+            lens.push_back((int)(nx * ny));
+            lens.push_back((int)((nx + ny) * (nx + ny)));
+            side = std::max(side, (int)(2 * (nx + ny)));
+        }
+    for (int n : lens) if ((int64_t)n > (int64_t)PG_NP_MAX_LEAVES * 128) { c->np_state = -1; return PG_OK; }
+    std::vector<int32_t> all, task_tree;
+    std::vector<std::pair<int, int>> known;                            // (n, offset)
+    int max_leaves = 1;
+    for (int n : lens) {
+        int off = -1;
+        for (auto &kv : known) if (kv.first == n) off = kv.second;
+        if (off < 0) {
+            std::vector<int32_t> b = np_tree(n);
+            if (b[0] > PG_NP_MAX_LEAVES) { c->np_state = -1; return PG_OK; }
+            max_leaves = std::max(max_leaves, (int)b[0]);
+            off = (int)all.size();
+            all.insert(all.end(), b.begin(), b.end());
+            known.push_back(std::make_pair(n, off));
+        }
+        task_tree.push_back(off);
+    }
+    int rc;
+    if ((rc = c->np_trees.upload(all.data(), all.size(), c->stream)) != PG_OK) return rc;
+    if ((rc = c->np_task_tree.upload(task_tree.data(), task_tree.size(), c->stream)) != PG_OK) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->np_max_leaves = max_leaves;
+    c->np_max_side = side;
+    c->np_state = 1;
+    return PG_OK;
+}
+
 extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int min_pair_sites, double min_data,
                                 int do_pairs, double *stats_out) {
     int rc = check_windows(c, lo, hi, n_win);
@@ -989,7 +1137,18 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
     if (n_win == 0) return PG_OK;
     if (!stats_out) return pg_fail(PG_ERR_ARG, "null output");
     HIPCHK(hipSetDevice(c->device));
-    const int P = c->n_pops, npairs = P * (P + 1) / 2, ncols = P + (do_pairs ? P * (P - 1) : 0);
+    // the sums in NumPy's order (k_popdist_np) wherever the blocks' trees fit a thread block's LDS: populations of up to a few
+    // hundred haplotypes; PG_POPDIST_TREE=0: the older finisher (upper triangles, a fixed reduction tree: equal within 1e-15)
+    if ((rc = np_prepare(c)) != PG_OK) return rc;
+    int64_t longest = 0;
+    for (int w = 0; w < n_win; ++w) longest = std::max(longest, hi[w] - lo[w]);
+    // NumPy's order where the last bit can show: windows of up to PG_NP_MAX_SITES sites (quotients of small integers sit on rounding
+    // ties of the printed digit; Fst of equal populations is +-0.0).  Longer windows: the older finisher (upper triangles, a fixed
+    // tree; 40 times less work: every quotient is formed once instead of 2 .. 6 times), equal within 1e-15 -- a printed difference
+    // would need a mean within 1e-16 of a tie.  PG_POPDIST_TREE=1 / 0 forces one or the other.
+    const char *force = getenv("PG_POPDIST_TREE");
+    const bool np_order = c->np_state == 1 && (force ? atoi(force) != 0 : longest <= PG_NP_MAX_SITES);
+    const int P = c->n_pops, npairs = np_order ? P * P : P * (P + 1) / 2, ncols = P + (do_pairs ? P * (P - 1) : 0);
     if ((rc = c->res_f64.ensure((size_t)n_win * npairs)) != PG_OK) return rc;
     if ((rc = c->res_i64.ensure((size_t)n_win * npairs)) != PG_OK) return rc;
     if ((rc = c->stats.ensure((size_t)n_win * ncols + 1)) != PG_OK) return rc;
@@ -999,10 +1158,16 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
         hipEvent_t e0, e1;
         int r = pg_time_begin(c, PG_K_POPDIST_FIN, &e0, &e1);
         if (r != PG_OK) return r;
+        if (np_order) {
+            pg_launch_popdist_np(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, P, c->ref_row.p,
+                                 c->pop_rank.p, c->np_task_tree.p, c->np_trees.p, c->np_max_leaves, c->np_max_side, min_pair_sites, min_data, do_pairs,
+                                 c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, c->stats.p + (size_t)w0 * ncols);
+        } else {
         pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, P, min_pair_sites,
                               c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, c->all_diploid && c->pops_on_individuals ? 1 : 0);
         pg_launch_popstats(c->stream, c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, nb, c->pop_start.p, P,
                            min_data, do_pairs, c->stats.p + (size_t)w0 * ncols);
+        }
         if ((r = pg_time_end(c, PG_K_POPDIST_FIN, e0, e1, 1)) != PG_OK) return r;
         HIPCHK(hipGetLastError());
         return PG_OK;

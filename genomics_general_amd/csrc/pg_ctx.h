@@ -138,6 +138,11 @@ struct pg_ctx {
     DevBuf<int32_t> hap_order;     // k_hapstats: each population's slots in the reference's row order
     DevBuf<int32_t> site_tmp;      // pg_site_counts staging
     DevBuf<uint32_t> site_flags;   // pg_popfreq: one bit per site (k_popfreq_ordered)
+    // pi / dxy / Fst in NumPy's summation order (k_popdist_np): the reference's row order within the populations and the rank of
+    // the population names (pg_set_reference_order; identity until set), the pairwise-summation trees of the block lengths
+    DevBuf<int32_t> ref_row, pop_rank, np_trees, np_task_tree;
+    int np_state = 0;              // 0: not built for the current samples; 1: usable; -1: a block has too many runs (old finisher)
+    int np_max_leaves = 0, np_max_side = 0;
     // how the matrices of the last batch are laid out (set by pairwise_batches)
     int cN = 0, cshift = 0;
     // resident sites

@@ -44,6 +44,12 @@ void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *D
                            const int32_t *pop_start, int n_pops, int min_pair_sites, double *sum_out,
                            int64_t *cnt_out, int all_diploid);
 
+// pi / dxy / Fst with the sums in NumPy's pairwise order (k_popdist_np + k_popstats_np); sums / cnts: [n_win][n_pops^2] scratch
+void pg_launch_popdist_np(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
+                          const int32_t *pop_start, int n_pops, const int32_t *ref_row, const int32_t *pop_rank,
+                          const int32_t *task_tree, const int32_t *trees, int max_leaves, int max_side, int min_pair_sites,
+                          double min_data, int do_pairs, double *sums, int64_t *cnts, double *out);
+
 void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,
                            int64_t *cnt_out, int mean_mode);

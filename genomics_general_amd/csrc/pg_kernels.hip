@@ -594,6 +594,191 @@ void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts,
 }
 
 // ------------------------------------------------------------------------------------------------------
+// k_popdist_np / k_popstats_np: pi / dxy / Fst with the float64 SUMS formed in NumPy's order.
+// The reference takes np.nanmean over `distMat[np.ix_(rows, cols)]` (genomics.py:88-90, 976-992): the nan of the block become 0 and
+// the flattened (row-major) block is added up by NumPy's pairwise summation -- halves (the left one a multiple of 8 long) down to
+// runs of at most 128 values, a run as eight interleaved partial sums ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus its last n%8 values one
+// by one.  Any other order differs in the last bits, which shows where a value sits on a rounding tie of the printed digit (small
+// windows: quotients of small integers), where Fst is 1 - (pi_s / pi_t of a noise away from 1) = +-0.0, and it is what the goldens'
+// tie tolerance was for.  Three kinds of blocks per window: (x, x) for pi, (x, y) for dxy and (x+y, x+y) for the pi_t of Fst --
+// rows and columns in the reference's row order (haplotype names sorted, `ref_row`), the pair oriented by the sorted population
+// names (np.unique, genomics.py:965: `pop_rank`).  The tree of a block length n is laid out by the host (pg_abi.cpp np_tree):
+// leaf runs, and the inner nodes level by level.  One block of 256 threads per (task, window): 32 runs at a time are staged in LDS
+// as quotients (coalesced over the flattened index), eight lanes add up a run, the levels of the tree follow.
+// ------------------------------------------------------------------------------------------------------
+#define PG_NP_STAGE_LEAVES 32
+__global__ __launch_bounds__(256) void k_popdist_np(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat, int N, int cN,
+                                                    int cshift, const int32_t *__restrict__ pop_start, int n_pops,
+                                                    const int32_t *__restrict__ ref_row, const int32_t *__restrict__ pop_rank,
+                                                    const int32_t *__restrict__ task_tree, const int32_t *__restrict__ trees,
+                                                    int min_pair_sites, int max_leaves, double *__restrict__ sum_out,
+                                                    int64_t *__restrict__ cnt_out) {
+    extern __shared__ double np_lds[];
+    double *slots = np_lds;                                  // [2 * max_leaves]: run sums, then the inner nodes
+    double *q = np_lds + 2 * (size_t)max_leaves;             // [PG_NP_STAGE_LEAVES * 128]
+    __shared__ unsigned long long shc[4];
+    const int task = blockIdx.x, win = blockIdx.y, tid = threadIdx.x;
+    const int n_tasks = gridDim.x;
+    // task -> the two row segments A (then B for pi_t) and the column segments
+    int pa, pb, kind;                                        // kind 0: pi of pa; 1: dxy rows pa, columns pb; 2: pi_t of pa + pb
+    if (task < n_pops) { pa = pb = task; kind = 0; }
+    else {
+        const int u = task - n_pops, k = u >> 1;
+        int x = 0, rem = k;
+        while (rem >= n_pops - 1 - x) { rem -= n_pops - 1 - x; ++x; }
+        const int y = x + 1 + rem;
+        const bool xf = pop_rank[x] < pop_rank[y];
+        pa = xf ? x : y;
+        pb = xf ? y : x;
+        kind = 1 + (u & 1);
+    }
+    const int as = pop_start[pa], na = pop_start[pa + 1] - as, bs = pop_start[pb], nb_ = pop_start[pb + 1] - bs;
+    const int nr = kind == 2 ? na + nb_ : na, nc = kind == 0 ? na : kind == 1 ? nb_ : na + nb_;
+    const int n = nr * nc;
+    const int32_t *T = trees + task_tree[task];              // [L, n_inner, n_levels, leaf_off[L + 1], node_l[], node_r[], level_start[]]
+    const int L = T[0], n_inner = T[1], n_levels = T[2];
+    const int32_t *leaf_off = T + 3, *node_l = leaf_off + L + 1, *node_r = node_l + n_inner, *level_start = node_r + n_inner;
+    const int32_t *Cw = Cmat + (size_t)win * cN * cN, *Dw = Dmat + (size_t)win * N * N;
+    const int thr = min_pair_sites > 1 ? min_pair_sites : 1;
+    unsigned long long valid = 0ull;
+    // the slots of the block's rows and columns (the reference's row order inside a population)
+    int32_t *rowmap = reinterpret_cast<int32_t *>(q + PG_NP_STAGE_LEAVES * 128), *colmap = rowmap + nr;
+    for (int t = tid; t < nr; t += 256) rowmap[t] = ref_row[t < na ? as + t : bs + (t - na)];
+    for (int t = tid; t < nc; t += 256) colmap[t] = ref_row[kind == 1 ? bs + t : (t < na ? as + t : bs + (t - na))];
+    __syncthreads();
+    for (int l0 = 0; l0 < L; l0 += PG_NP_STAGE_LEAVES) {
+        const int l1 = l0 + PG_NP_STAGE_LEAVES < L ? l0 + PG_NP_STAGE_LEAVES : L;
+        const int k0 = leaf_off[l0], k1 = leaf_off[l1];
+        // quotients of the flattened elements [k0, k1): element k = (row k / nc, column k % nc); four per trip, their loads first
+        {
+            int k = k0 + tid;
+            int r = nc > 0 ? k / nc : 0, cc = nc > 0 ? k - r * nc : 0;
+            const int qi = 256 / (nc > 0 ? nc : 1), qj = 256 - qi * (nc > 0 ? nc : 1);
+            for (; k < k1; k += 1024) {
+                int cv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    cv[u] = 0;
+                    dv[u] = 0;
+                    if (k + 256 * u < k1) {
+                        const int i = rowmap[r], j = colmap[cc];
+                        if (i != j) {
+                            const int a = i < j ? i : j, b = i < j ? j : i;
+                            cv[u] = Cw[(size_t)(a >> cshift) * cN + (b >> cshift)];
+                            dv[u] = Dw[(size_t)a * N + b];
+                        }
+                    }
+                    r += qi;
+                    cc += qj;
+                    if (cc >= nc) { cc -= nc; ++r; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k + 256 * u < k1) {
+                        double v = 0.0;
+                        if (cv[u] >= thr) {
+                            const double cd = (double)cv[u];
+                            v = quot_counts((double)dv[u], cd, rcp_counts(cd));
+                            ++valid;
+                        }
+                        q[k + 256 * u - k0] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int leaf = l0 + (tid >> 3), j = tid & 7;
+            if (leaf < l1) {                                     // (the eight lanes of a run share the condition)
+                const int off = leaf_off[leaf] - k0, len = leaf_off[leaf + 1] - leaf_off[leaf];
+                double res;
+                if (len < 8) {                                   // a block of fewer than 8 values: one after the other from 0.
+                    res = 0.0;
+                    for (int i = 0; i < len; ++i) res = res + q[off + i];
+                } else {
+                    const int m8 = len - (len & 7);
+                    double rj = q[off + j];
+                    for (int i = 8; i < m8; i += 8) rj = rj + q[off + i + j];
+                    rj = rj + __shfl_xor(rj, 1, 64);
+                    rj = rj + __shfl_xor(rj, 2, 64);
+                    rj = rj + __shfl_xor(rj, 4, 64);
+                    res = rj;
+                    for (int i = m8; i < len; ++i) res = res + q[off + i];
+                }
+                if (j == 0) slots[leaf] = res;
+            }
+        }
+        __syncthreads();
+    }
+    for (int lv = 0; lv < n_levels; ++lv) {
+        for (int idx = level_start[lv] + tid; idx < level_start[lv + 1]; idx += 256) slots[L + idx] = slots[node_l[idx]] + slots[node_r[idx]];
+        __syncthreads();
+    }
+    // the valid elements of the block (an integer, any order)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) valid += __shfl_xor(valid, m, 64);
+    if ((tid & 63) == 0) shc[tid >> 6] = valid;
+    __syncthreads();
+    if (tid == 0) {
+        const double root = L > 0 ? slots[n_inner > 0 ? L + n_inner - 1 : 0] : 0.0;
+        sum_out[(size_t)win * n_tasks + task] = 0.0 + root;       // np.add.reduce starts from the identity
+        cnt_out[(size_t)win * n_tasks + task] = (int64_t)(shc[0] + shc[1] + shc[2] + shc[3]);
+    }
+    (void)n;
+}
+
+// pi / dxy / Fst from k_popdist_np's sums and counts (task order: pi of every population, then dxy and pi_t of every pair x < y,
+// x-major); the float64 operations of genomics.py:88-90 and 976-993 in the reference's order, the pair oriented by pop_rank
+__global__ __launch_bounds__(256) void k_popstats_np(const double *__restrict__ sums, const int64_t *__restrict__ cnts, int n_win,
+                                                     const int32_t *__restrict__ pop_start, const int32_t *__restrict__ pop_rank,
+                                                     int n_pops, double min_data, int do_pairs, double *__restrict__ out) {
+    const int npairs = n_pops * (n_pops + 1) / 2;
+    const int npo = n_pops * (n_pops - 1) / 2;
+    const int n_tasks = n_pops + 2 * npo;
+    const int ncols = n_pops + (do_pairs ? 2 * npo : 0);
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n_win * npairs) return;
+    const int win = (int)(idx / npairs), pidx = (int)(idx % npairs);
+    int x = 0, rem = pidx;
+    while (rem >= n_pops - x) { rem -= n_pops - x; ++x; }
+    const int y = x + rem;
+    const double *S = sums + (size_t)win * n_tasks;
+    const int64_t *Cn = cnts + (size_t)win * n_tasks;
+    auto size_of = [&](int p) { return (long long)(pop_start[p + 1] - pop_start[p]); };
+    auto pi_of = [&](int p) { return nanmean_min_dev(S[p], Cn[p], size_of(p) * size_of(p), min_data); };
+    double *O = out + (size_t)win * ncols;
+    if (x == y) {
+        O[x] = pi_of(x);
+        return;
+    }
+    if (!do_pairs) return;
+    const int k = x * n_pops - x * (x + 1) / 2 + (y - x - 1);
+    const bool xf = pop_rank[x] < pop_rank[y];
+    const int a = xf ? x : y, b = xf ? y : x;
+    const long long na = size_of(a), nb = size_of(b);
+    O[n_pops + k] = nanmean_min_dev(S[n_pops + 2 * k], Cn[n_pops + 2 * k], na * nb, min_data);
+    const double w = 1. * (double)na / (double)(na + nb);
+    const double pi_s = w * pi_of(a) + (1 - w) * pi_of(b);
+    const double pi_t = nanmean_min_dev(S[n_pops + 2 * k + 1], Cn[n_pops + 2 * k + 1], (na + nb) * (na + nb), min_data);
+    O[n_pops + npo + k] = 1 - pi_s / pi_t;
+}
+
+void pg_launch_popdist_np(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
+                          const int32_t *pop_start, int n_pops, const int32_t *ref_row, const int32_t *pop_rank,
+                          const int32_t *task_tree, const int32_t *trees, int max_leaves, int max_side, int min_pair_sites,
+                          double min_data, int do_pairs, double *sums, int64_t *cnts, double *out) {
+    if (n_win <= 0 || n_pops <= 0) return;
+    const int n_tasks = n_pops * n_pops;                     // P + 2 * P (P - 1) / 2
+    // run sums and inner nodes, the staged quotients, the row and column maps
+    const size_t lds = (2 * (size_t)max_leaves + PG_NP_STAGE_LEAVES * 128) * sizeof(double) + ((size_t)max_side + 8) * sizeof(int32_t);
+    hipLaunchKernelGGL(k_popdist_np, dim3(n_tasks, n_win), dim3(256), lds, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops, ref_row,
+                       pop_rank, task_tree, trees, min_pair_sites, max_leaves, sums, cnts);
+    const long long total = (long long)n_win * (n_pops * (n_pops + 1) / 2);
+    hipLaunchKernelGGL(k_popstats_np, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sums, cnts, n_win, pop_start, pop_rank,
+                       n_pops, min_data, do_pairs, out);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K_indpair: one thread per unordered individual pair (s<=t); haplotype slots of an individual are contiguous.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat,

@@ -128,6 +128,13 @@ class Engine:
     # ---- configuration / data ---------------------------------------------------------------
     def set_layout(self, layout):
         check(self._L.pg_set_samples(self._h, layout.n_hap, layout.hap_pop, layout.hap_sample, layout.n_pops))
+        if layout.n_pops > 0:
+            # the order the reference's sums run in: Alignment rows are the haplotypes sorted by name (genomics.py:1122), the
+            # populations np.unique's sorted labels (genomics.py:965)
+            names = np.array(layout.sampleData.popNames)
+            rank = np.empty(layout.n_pops, dtype=np.int32)
+            rank[np.argsort(names)] = np.arange(layout.n_pops, dtype=np.int32)
+            check(self._L.pg_set_reference_order(self._h, np.ascontiguousarray(pop_row_order(layout)), rank))
         self.layout = layout
         self.n_sites = 0
 
@@ -479,13 +486,7 @@ class WindowBatch:
         match matrix on the device, ties broken in the reference's row order (haplotype names sorted)."""
         lay = self.lay
         ms, diag_nan = self._cache_state()
-        order = lay.__dict__.get("_pop_row_order")
-        if order is None:
-            rank = np.empty(lay.n_hap, dtype=np.int64)
-            rank[lay.ref_order] = np.arange(lay.n_hap)
-            in_pop = np.where(lay.hap_pop >= 0)[0]
-            order = in_pop[np.lexsort((rank[in_pop], lay.hap_pop[in_pop]))].astype(np.int32)
-            lay._pop_row_order = order
+        order = pop_row_order(lay)
         tab = np.zeros((self.n, lay.n_pops, 3), dtype=np.float64)
         check(self.e._L.pg_hapstats(self.e._h, self.lo, self.hi, self.n, ms, 1 if diag_nan else 0, float(maxDist),
                                     np.ascontiguousarray(order), tab))
@@ -577,6 +578,19 @@ class WindowBatch:
                    "fdh2": f4c * 1. / sums[:, 10], "fh": f4c * 1. / sums[:, 11],
                    "ABBA": sums[:, 4], "BABA": sums[:, 5], "ABAA": sums[:, 12], "BAAA": sums[:, 13], "sitesUsed": used}
         return out                       # windows with sitesUsed == 0 carry 0.0 / nan; the drivers never print them
+
+
+def pop_row_order(lay):
+    """for each population the slots of its haplotypes in the reference's row order (haplotype names sorted, genomics.py:1122),
+    concatenated in population order: int32 [slots in populations]"""
+    order = lay.__dict__.get("_pop_row_order")
+    if order is None:
+        rank = np.empty(lay.n_hap, dtype=np.int64)
+        rank[lay.ref_order] = np.arange(lay.n_hap)
+        in_pop = np.where(lay.hap_pop >= 0)[0]
+        order = in_pop[np.lexsort((rank[in_pop], lay.hap_pop[in_pop]))].astype(np.int32)
+        lay._pop_row_order = order
+    return order
 
 
 def _tajima_d(n, S, theta_pi):

@@ -68,6 +68,14 @@ int pg_sync(pg_ctx *ctx);
  * [0,n_samples); slots of one individual must be contiguous. */
 int pg_set_samples(pg_ctx *ctx, int n_hap, const int32_t *hap_pop, const int32_t *hap_sample, int n_pops);
 
+/* The order the reference's float64 sums run in (optional; identity after pg_set_samples).  pop_row_order[slots in populations]:
+ * for each population the slots of its haplotypes in the order of the Alignment's rows (haplotype names sorted,
+ * genomics.py:1122), concatenated in population order; pop_name_rank[n_pops]: the position of each population among np.unique's
+ * sorted labels (genomics.py:965).  pg_popdist_stats then forms every np.nanmean of genomics.py:976-992 over the flattened block in
+ * NumPy's pairwise-summation order -- pi / dxy / Fst equal the reference's to the last bit (populations of up to a few hundred
+ * haplotypes; beyond, upper-triangle sums in a fixed tree: equal within 1e-15). */
+int pg_set_reference_order(pg_ctx *ctx, const int32_t *pop_row_order, const int32_t *pop_name_rank);
+
 /* ---- resident site buffer ------------------------------------------------------------------------ */
 int pg_reserve_sites(pg_ctx *ctx, int64_t n_sites);
 /* pg_reserve_sites for a large reservation (>= 4 GiB) with a choice of physical placement: up to max_trials (<= 8) allocations are

@@ -31,6 +31,12 @@ def make_engine(n_dip, n_pops, L, seed, var_thr=30000, miss_thr=5000, extra_nopo
     return e, lay, codes, names
 
 
+def same(a, b):
+    """bit for bit: equal values of equal sign (-0.0 is not 0.0), or both nan"""
+    a, b = np.float64(a), np.float64(b)
+    return bool((a == b and np.signbit(a) == np.signbit(b)) or (np.isnan(a) and np.isnan(b)))
+
+
 def close(a, b, tol=1e-9):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     both_nan = np.isnan(a) & np.isnan(b)

@@ -35,9 +35,9 @@ def oracle_window(e, lay, a, b):
     return aln
 
 
-def check_popdist(e, lay, lo, hi, sel, st, min_sites):
-    """D / C bit-exact and pi / dxy / Fst within 1e-9 of the oracle on the windows `sel` of a full-size batch whose statistics
-    `st` were computed over ALL windows of the batch"""
+def check_popdist(e, lay, lo, hi, sel, st, min_sites, same=False):
+    """D / C bit-exact and pi / dxy / Fst within 1e-9 of the oracle (same: to the last bit) on the windows `sel` of a full-size batch
+    whose statistics `st` were computed over ALL windows of the batch"""
     D, C = e.batch(lo[sel], hi[sel]).pairCounts(reference_order=True)
     for k, w in enumerate(sel):
         aln = oracle_window(e, lay, lo[w], hi[w])
@@ -48,7 +48,7 @@ def check_popdist(e, lay, lo, hi, sel, st, min_sites):
         assert Do.max() > 0 and Co.min() >= 0 and Co.max() > (hi[w] - lo[w]) // 2, "window %d holds no called data" % w
         for key, v in so.items():
             assert np.isfinite(v), (key, w)
-            assert G.close(st[key][w], v), (key, w, st[key][w], v)
+            assert G.same(st[key][w], v) if same else G.close(st[key][w], v), (key, w, st[key][w], v)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -72,6 +72,19 @@ def test_c2_popdist_windows_match_the_oracle(c2):
     for k, v in st.items():
         assert v.shape == (200,) and np.array_equal(v, again[k]) and np.all(np.isfinite(v)), k
         assert np.all(v <= 1) and (k.startswith("Fst_") or np.all(v >= 0)), k
+
+
+def test_c2_popdist_in_numpy_order_is_the_oracle_to_the_last_bit(c2, monkeypatch):
+    """windows of 50 kb take the fixed-tree finisher by default (pg_popdist_stats: NumPy's order up to 4096 sites a window); forced,
+    k_popdist_np reproduces np.nanmean over the 50 x 50, and 100 x 100 blocks (pieces of 8192 values, genomics.py:976-992) exactly"""
+    e, lay, lo, hi = c2
+    monkeypatch.setenv("PG_POPDIST_TREE", "1")
+    sel = np.array([0, 113, 199])
+    st = e.batch(lo[sel], hi[sel]).groupDistStats(True, 100, 0.01)
+    full = {k: np.full(200, np.nan) for k in st}
+    for k in st:
+        full[k][sel] = st[k]
+    check_popdist(e, lay, lo, hi, list(sel), full, 100, same=True)
 
 
 def test_c3_abbababa_windows_match_the_oracle(c2):

@@ -41,7 +41,7 @@ def _run(tool, argv, out):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PG_FUZZ_SEEDS", "8"))))      # PG_FUZZ_SEEDS=300: a longer sweep
 def test_random_command_lines_on_the_hip_engine_match_the_stand_in(seed, tmp_path, monkeypatch):
     rng = np.random.default_rng(77000 + seed)
     compared = 0

@@ -110,7 +110,44 @@ def test_group_dist_stats(min_sites, min_data, miss):
         Do, Co = orc.pair_counts_gemm(aln)
         so, _ = orc.group_dist_stats(aln, Do, Co, True, min_sites, min_data)
         for key, v in so.items():
-            assert G.close(st[key][k], v), (key, k, st[key][k], v)
+            assert G.same(st[key][k], v), (key, k, st[key][k], v)        # the sums in NumPy's order (k_popdist_np): to the last bit
+    e.close()
+
+
+@pytest.mark.parametrize("sizes,names,haploid,L", [
+    ((3, 7, 12), ("zeta", "alpha", "m"), (), 900),                     # np.unique's order is not the command line's; 6..24 haplotypes
+    ((1, 2, 5, 9), ("b", "a", "d", "c"), (0, 4, 9), 400),              # a population of one diploid; haploid samples: odd blocks
+    ((40, 33), ("x", "X"), (), 300),                                   # blocks of 6400 / 5280 / 21316 values: several levels of halves
+    ((2, 2), ("p1", "p0"), (1,), 37),                                  # blocks of fewer than 8 values / tiny windows: ties of the quotients
+])
+def test_group_dist_stats_to_the_last_bit_in_numpy_order(sizes, names, haploid, L):
+    """pi / dxy / Fst against the oracle (which calls np.nanmean on the blocks as the reference does) with ==: unequal populations,
+    population names whose sorted order differs from their order on the command line, haploid samples, windows of a few sites"""
+    from genomics_general_amd.engine import Engine
+    from genomics_general_amd.samples import HapLayout, SampleData
+    n_dip = sum(sizes)
+    inds = ["s%d" % d for d in range(n_dip)]
+    pop_inds, at = [], 0
+    for n in sizes:
+        pop_inds.append(inds[at:at + n])
+        at += n
+    ploidy = {nm: (1 if k in haploid else 2) for k, nm in enumerate(inds)}
+    lay = HapLayout(SampleData(indNames=list(inds), popNames=list(names), popInds=pop_inds, ploidyDict=ploidy), inds, "phased")
+    sid, pos = synth.dense_sites(L, 1)
+    sg = np.array([2 * inds.index(nm) + k for nm in lay.ind_order for k in range(len(lay.ind_slots[nm]))], dtype=np.int32)
+    codes = synth.gen_codes(99, sid, pos, n_dip, len(sizes), hap_index=sg, var_thr=30000, miss_thr=9000)
+    e = Engine(0)
+    e.set_layout(lay)
+    e.load_sites(codes)
+    wins = [(0, L), (0, L // 3), (L // 3, L // 3 + 11), (5, 6), (max(0, L - 40), L)]
+    for min_sites, min_data in ((1, 0.01), (8, 0.5)):
+        st = e.batch([w[0] for w in wins], [w[1] for w in wins]).groupDistStats(doPairs=True, minSites=min_sites, minData=min_data)
+        for k, (a, b) in enumerate(wins):
+            aln = oracle_aln(lay, codes, a, b)
+            Do, Co = orc.pair_counts_gemm(aln)
+            so, _ = orc.group_dist_stats(aln, Do, Co, True, min_sites, min_data)
+            for key, v in so.items():
+                assert G.same(st[key][k], v), (key, k, (a, b), min_sites, st[key][k], v)
     e.close()
 
 
@@ -305,7 +342,7 @@ def test_half_missing_genotypes_fall_back_to_haplotype_level_called_counts():
         assert np.array_equal(C[k], Co) and np.array_equal(D[k], Do)
         so, _ = orc.group_dist_stats(aln, Do, Co, True, 5, 0.01)
         for key, v in so.items():
-            assert G.close(st[key][k], v), (key, k)
+            assert G.same(st[key][k], v), (key, k)
     e.close()
 
 
