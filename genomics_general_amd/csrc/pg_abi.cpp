@@ -1080,7 +1080,6 @@ std::vector<int32_t> np_tree(int n) {
 }  // namespace
 
 #define PG_NP_MAX_LEAVES 1536      // 2 * 1536 + 32 * 128 doubles of LDS = 56 KB per block
-#define PG_NP_MAX_SITES 4096
 
 // the trees of this context's blocks: (x, x), and (x, y) / (x + y, x + y) for every pair: their lengths do not depend on the orientation
 static int np_prepare(pg_ctx *c) {
@@ -1343,10 +1342,27 @@ static int quartet_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_
         if ((rc = c->part_i64.ensure((size_t)nb * std::max(max_chunks, 1))) != PG_OK) return rc;
         if ((rc = c->res_f64.ensure((size_t)nb * nsum)) != PG_OK) return rc;
         if ((rc = c->res_i64.ensure((size_t)nb)) != PG_OK) return rc;
+        // the sums in NumPy's order where the last bit can show (windows of up to PG_NP_MAX_SITES sites; see pg_popdist_stats):
+        // k_abba_q raises a flag bit per used site, k_quartet_np adds the sites' terms up again
+        uint32_t *flags = nullptr;
+        int64_t base = 0;
+        const char *force = getenv("PG_QUARTET_TREE");
+        if (force ? atoi(force) != 0 : max_len <= PG_NP_MAX_SITES) {
+            int64_t top = 0;
+            base = INT64_MAX;
+            for (int w = w0; w < w1; ++w)
+                if (hi[w] > lo[w]) { base = std::min(base, lo[w]); top = std::max(top, hi[w]); }
+            if (base == INT64_MAX) base = top = 0;
+            base &= ~(int64_t)127;
+            const size_t words = (size_t)((top - base + 31) / 32) + 64;
+            if ((rc = c->site_flags.ensure(words)) != PG_OK) return rc;
+            HIPCHK(hipMemsetAsync(c->site_flags.p, 0, words * 4, c->stream));
+            flags = c->site_flags.p;
+        }
         hipEvent_t e0, e1;
         if ((rc = pg_time_begin(c, PG_K_SITESTATS, &e0, &e1)) != PG_OK) return rc;
         pg_launch_abba(c->stream, c->gt.p, c->S, c->win.p, c->win.p + nb, nb, max_chunks, c->pop_start.p, p1, p2, p3, p4,
-                       min_data, sel, nsum, c->part_f64.p, c->part_i64.p, c->res_f64.p, c->res_i64.p);
+                       min_data, sel, nsum, c->part_f64.p, c->part_i64.p, c->res_f64.p, c->res_i64.p, flags, base);
         if ((rc = pg_time_end(c, PG_K_SITESTATS, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
         if ((rc = c->out_pin.ensure((size_t)nb * (nsum + 1))) != PG_OK) return rc;

@@ -23,6 +23,9 @@
 // more; the host then repeats the call with PG_XV_CAP (and keeps that reservation for the rest of the context's life).
 #define PG_XV_CAP(grp) (3 * (grp))
 #define PG_XV_CAP_DEFAULT(grp) ((grp) + 1)
+// windows of up to this many sites get their float64 sums in NumPy's order (k_popdist_np, k_quartet_np): quotients and products of
+// small integers sit on rounding ties of the printed digit, differences of equal means are +-0.0
+#define PG_NP_MAX_SITES 4096
 #define PG_FLAG_MISMATCH 1      // some individual's two haplotypes differ in calledness: the diploid shortcut does not apply
 #define PG_FLAG_XV_OVERFLOW 2   // a window produced more XV words than reserved
 
@@ -58,7 +61,7 @@ void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *D
 void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                     int n_win, int max_chunks, const int32_t *pop_start, int p1, int p2, int p3, int p4,
                     double min_data, int sel, int nsum, double *part_sums, int64_t *part_used, double *sums_out,
-                    int64_t *used_out);
+                    int64_t *used_out, uint32_t *flags, int64_t base);
 
 void pg_launch_popfreq(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
                        const int64_t *win_hi, int n_win, int max_chunks, const int32_t *pop_start, int n_pops,

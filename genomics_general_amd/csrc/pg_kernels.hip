@@ -867,6 +867,12 @@ __device__ __forceinline__ void range_counts(const uint32_t *__restrict__ row, i
 // K_abba: grid (chunk, window).  Per-site terms follow genomics.py:1409-1475 and 1565-1569 operation for operation;
 // per-block partial sums are combined by k_abba_reduce in chunk order (deterministic).
 // ------------------------------------------------------------------------------------------------------
+// flag_site: one bit per site for the kernels that add a window's per-site values up in site order (k_popfreq_ordered: every slot
+// called and polymorphic within some population; k_quartet_np: the used sites of ABBABABA / fourPop)
+__device__ __forceinline__ void flag_site(uint32_t *__restrict__ flags, int64_t rel) {
+    atomicOr(&flags[rel >> 5], 1u << (rel & 31));
+}
+
 __device__ __forceinline__ double f4_term(double a, double b, double c, double d) {
     return (1 - a) * b * c * (1 - d) - a * (1 - b) * c * (1 - d);
 }
@@ -889,45 +895,52 @@ __device__ __forceinline__ double f4c_term(double a, double b, double c, double 
 }
 
 template <int NSUM>
-__device__ __forceinline__ void quartet_terms(const uint32_t e[8], QuartetAcc<NSUM> &A) {
+__device__ __forceinline__ void quartet_values(const uint32_t e[8], double (&t)[NSUM]) {
     const double p1 = (double)e[0] / (double)e[3];
     const double p2 = (double)e[1] / (double)e[4];
     const double p3 = (double)e[2] / (double)e[5];
     const double p4 = (double)e[7] / (double)e[6];
     const double abba = (1 - p1) * p2 * p3 * (1 - p4);
     const double baba = p1 * (1 - p2) * p3 * (1 - p4);
-    A.acc[0] += f4_term(p1, p2, p3, p4);
-    A.acc[1] += abba + baba;
+    t[0] = f4_term(p1, p2, p3, p4);
+    t[1] = abba + baba;
     const double pd = p2 * (double)(p2 > p3) + p3 * (double)(p3 >= p2);              // :1446
-    A.acc[2] += f4_term(p1, pd, pd, p4);
+    t[2] = f4_term(p1, pd, pd, p4);
     const bool a = p3 > p1, bb = p3 > p2, x = p1 > p2, y = !x;                       // :1460-1468
     const double xa = (double)(x && a), nxa = (double)(!(x && a));
     const double yb = (double)(y && bb), nyb = (double)(!(y && bb));
     const double pdm1 = p3 * xa + p1 * nxa;
     const double pdm2 = p3 * yb + p2 * nyb;
     const double pdm3 = -p3 * xa + p3 * yb - p1 * (double)(x && !a) + p2 * (double)(y && !bb);
-    A.acc[3] += f4_term(pdm1, pdm2, pdm3, p4);
-    A.acc[4] += abba;
-    A.acc[5] += baba;
+    t[3] = f4_term(pdm1, pdm2, pdm3, p4);
+    t[4] = abba;
+    t[5] = baba;
     if constexpr (NSUM > PG_ABBA_NSUM) {
-        const double num = f4c_term(p1, p2, p3, p4);
-        A.acc[6] += num;                                                              // fd', fdm', fdh, fdh2, fh numerators
-        A.acc[7] += f4c_term(p1, pd, pd, p4);                                         // :1455-1456
-        A.acc[8] += f4c_term(pdm1, pdm2, pdm3, p4);                                   // :1483-1486
+        t[6] = f4c_term(p1, p2, p3, p4);                                              // fd', fdm', fdh, fdh2, fh numerators
+        t[7] = f4c_term(p1, pd, pd, p4);                                              // :1455-1456
+        t[8] = f4c_term(pdm1, pdm2, pdm3, p4);                                        // :1483-1486
         const double t11 = f4c_term(p1, p3, p3, p4), t12 = f4c_term(p4, p2, p3, p4);
         const double t21 = f4c_term(p3, p2, p3, p4), t22 = f4c_term(p1, p4, p3, p4);
         double m = np_max(np_max(np_max(t11, t12), t21), t22);                        // np.amax: NaN propagates
-        A.acc[9] += m;                                                                // :1495-1502
+        t[9] = m;                                                                     // :1495-1502
         const double t31 = f4c_term(p1, p2, p2, p4), t32 = f4c_term(p1, p2, p3, p1);
         const double t41 = f4c_term(p1, p2, p1, p4), t42 = f4c_term(p1, p2, p3, p2);
         m = np_max(np_max(np_max(np_max(m, t31), t32), t41), t42);
-        A.acc[10] += m;                                                               // :1511-1523
+        t[10] = m;                                                                    // :1511-1523
         const double t1 = fabs(p1 - p2), t2 = fabs(p3 - p4);
         const double den = t1 * (double)(t1 > t2) + t2 * (double)(t2 >= t1);
-        A.acc[11] += den * den;                                                       // :1551-1554
-        A.acc[12] += (1 - p1) * p2 * (1 - p3) * (1 - p4);                             // ABAA :1557
-        A.acc[13] += p1 * (1 - p2) * (1 - p3) * (1 - p4);                             // BAAA :1560
+        t[11] = den * den;                                                            // :1551-1554
+        t[12] = (1 - p1) * p2 * (1 - p3) * (1 - p4);                                  // ABAA :1557
+        t[13] = p1 * (1 - p2) * (1 - p3) * (1 - p4);                                  // BAAA :1560
     }
+}
+
+template <int NSUM>
+__device__ __forceinline__ void quartet_terms(const uint32_t e[8], QuartetAcc<NSUM> &A) {
+    double t[NSUM];
+    quartet_values<NSUM>(e, t);
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) A.acc[k] += t[k];
     ++A.used;
 }
 
@@ -1042,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
                                                 const int64_t *__restrict__ win_hi, int max_chunks,
                                                 const int32_t *__restrict__ pop_start, int q1, int q2, int q3, int q4,
                                                 double min_data, int sel, double *__restrict__ part_sums,
-                                                int64_t *__restrict__ part_used) {
+                                                int64_t *__restrict__ part_used, uint32_t *__restrict__ flags, int64_t base) {
     __shared__ double shd[4 * (NSUM + 2)];
     __shared__ uint32_t ring[4][PG_ABBA_RING][8];
     __shared__ int64_t cand[4][PG_ABBA_CAND];
@@ -1128,6 +1141,7 @@ __global__ __launch_bounds__(256) void k_abba_q(const int8_t *__restrict__ gt, i
             const bool writer = good && q == 0;
             const unsigned long long bal = __ballot(writer);
             if (writer) {
+                if (flags) flag_site(flags, site - base);                 // a used site: k_quartet_np adds its terms up in site order
                 const int before = __popcll(bal & ((1ull << lane) - 1ull));
                 uint32_t *e = my_ring[(tail + before) & (PG_ABBA_RING - 1)];
                 e[0] = cder; e[1] = c_p2; e[2] = c_p3; e[3] = n; e[4] = n_p2; e[5] = n_p3; e[6] = n_o; e[7] = c_p4;
@@ -1278,16 +1292,211 @@ __global__ void k_abba_reduce(const double *__restrict__ part_sums, const int64_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_quartet_np: the sums of ABBABABA / fourPop in NumPy's order.  The reference takes `.sum()` of arrays over the window's used
+// sites (genomics.py:1431-1475, 1565-1569; 1420-1563): pairwise summation over pieces of 8192 values (see k_popdist_np).  One wave per
+// window walks the flag bits k_abba_q left (the used sites), a site per lane: the chosen allele's counts are taken again (the site
+// filters were applied when the flag was raised), the terms of up to 128 sites are staged in LDS and added up as a run -- eight lanes
+// per sum --, and the tree above the runs is followed with a small stack (its depth is at most 7 + the chain of pieces).
+// ------------------------------------------------------------------------------------------------------
+template <int NSUM>
+__global__ __launch_bounds__(64) void k_quartet_np(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
+                                                   const int64_t *__restrict__ win_hi, const int32_t *__restrict__ pop_start, int q1,
+                                                   int q2, int q3, int q4, int sel, const uint32_t *__restrict__ flags, int64_t base,
+                                                   double *__restrict__ sums_out) {
+    __shared__ uint16_t list[8192];
+    __shared__ double vals[NSUM][128];
+    __shared__ double runv[NSUM];
+    __shared__ double leftv[12][NSUM];
+    const int win = blockIdx.x, lane = threadIdx.x;
+    const int64_t lo = win_lo[win], hi = win_hi[win];
+    const int qs[4] = {q1, q2, q3, q4};
+    int ps[4], pe[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ps[k] = pop_start[qs[k]]; pe[k] = pop_start[qs[k] + 1]; }
+    const uint4 *f4 = reinterpret_cast<const uint4 *>(flags);
+    const int64_t q_first = hi > lo ? (lo - base) >> 7 : 0, q_last = hi > lo ? (hi - 1 - base) >> 7 : -1;
+    auto masked = [&](int64_t q, uint32_t (&bits)[4]) {                  // the flag words of sites [128 q, 128 q + 128) inside the window
+        bits[0] = bits[1] = bits[2] = bits[3] = 0u;
+        if (q > q_last) return;
+        const uint4 v = f4[q];
+        bits[0] = v.x; bits[1] = v.y; bits[2] = v.z; bits[3] = v.w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t s0 = base + (q << 7) + 32 * k;
+            if (s0 + 32 <= lo || s0 >= hi) bits[k] = 0u;
+            else {
+                if (s0 < lo) bits[k] &= ~0u << (int)(lo - s0);
+                if (hi - s0 < 32) bits[k] &= (1u << (int)(hi - s0)) - 1u;
+            }
+        }
+    };
+    // n = the used sites of the window
+    long long n = 0;
+    for (int64_t q0 = q_first; q0 <= q_last; q0 += 64) {
+        uint32_t bits[4];
+        masked(q0 + lane, bits);
+        n += __popc(bits[0]) + __popc(bits[1]) + __popc(bits[2]) + __popc(bits[3]);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m, 64);
+    // the stream of used sites: list[list_pos .. list_len) of the step that starts at flag group q_next - 64
+    int64_t q_next = q_first, step_site0 = 0;
+    int list_len = 0, list_pos = 0;
+    auto refill = [&]() {
+        while (list_pos == list_len && q_next <= q_last) {
+            uint32_t bits[4];
+            masked(q_next + lane, bits);
+            const int cnt = __popc(bits[0]) + __popc(bits[1]) + __popc(bits[2]) + __popc(bits[3]);
+            int pre = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(pre, d, 64);
+                if (lane >= d) pre += v;
+            }
+            const int total = __shfl(pre, 63, 64);
+            int k = pre - cnt;
+            __syncthreads();                                             // the previous step's list has been consumed
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                uint32_t b = bits[x];
+                while (b) {
+                    list[k++] = (uint16_t)(lane * 128 + 32 * x + (__ffs((int)b) - 1));
+                    b &= b - 1u;
+                }
+            }
+            __syncthreads();
+            step_site0 = base + (q_next << 7);
+            q_next += 64;
+            list_len = total;
+            list_pos = 0;
+        }
+    };
+    // the terms of the next `len` used sites -> vals[s][0 .. len)
+    auto fill_run = [&](int len) {
+        int filled = 0;
+        while (filled < len) {
+            refill();
+            int take = len - filled < list_len - list_pos ? len - filled : list_len - list_pos;
+            if (take > 64) take = 64;
+            if (lane < take) {
+                const int8_t *rowb = gt + (step_site0 + list[list_pos + lane]) * (int64_t)S;
+                uint32_t cnt[4][4], nk[4], tot[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    range_counts_x4(rowb, ps[k], pe[k], cnt[k]);
+                    nk[k] = cnt[k][0] + cnt[k][1] + cnt[k][2] + cnt[k][3];
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) tot[b] = cnt[0][b] + cnt[1][b] + cnt[2][b] + cnt[3][b];
+                int der = -1;                                            // the allele choice of k_abba_q (see there)
+                if (sel == PG_SEL_MINOR) {
+                    int lo_b = -1, hi_b = -1;
+#pragma unroll
+                    for (int b = 3; b >= 0; --b)
+                        if (tot[b] > 0) { if (hi_b < 0) hi_b = b; else lo_b = b; }
+                    uint32_t tl = 0u, th = 0u;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { if (b == lo_b) tl = tot[b]; if (b == hi_b) th = tot[b]; }
+                    if (tl < th) der = lo_b;
+                    else if (th < tl) der = hi_b;
+                    else der = (lo_b == 0 && hi_b == 1) ? 1 : lo_b;
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (tot[b] > 0 && cnt[3][b] == 0) der = b;
+                }
+                uint32_t e[8] = {0u, 0u, 0u, nk[0], nk[1], nk[2], nk[3], 0u};
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (b == der) { e[0] = cnt[0][b]; e[1] = cnt[1][b]; e[2] = cnt[2][b]; e[7] = cnt[3][b]; }
+                double t[NSUM];
+                quartet_values<NSUM>(e, t);
+#pragma unroll
+                for (int s = 0; s < NSUM; ++s) vals[s][filled + lane] = t[s];
+            }
+            filled += take;
+            list_pos += take;
+        }
+        __syncthreads();
+    };
+    // a run of len <= 128 values per sum, as NumPy adds it up -> runv[s]
+    auto run_sums = [&](int len) {
+        for (int s0 = 0; s0 < NSUM; s0 += 8) {
+            const int s = s0 + (lane >> 3), j = lane & 7;
+            if (s < NSUM) {
+                double res;
+                if (len < 8) {
+                    res = 0.0;
+                    for (int i = 0; i < len; ++i) res = res + vals[s][i];
+                } else {
+                    const int m8 = len - (len & 7);
+                    double rj = vals[s][j];
+                    for (int i = 8; i < m8; i += 8) rj = rj + vals[s][i + j];
+                    rj = rj + __shfl_xor(rj, 1, 64);
+                    rj = rj + __shfl_xor(rj, 2, 64);
+                    rj = rj + __shfl_xor(rj, 4, 64);
+                    res = rj;
+                    for (int i = m8; i < len; ++i) res = res + vals[s][i];
+                }
+                if (j == 0) runv[s] = res;
+            }
+        }
+        __syncthreads();
+    };
+    double total = 0.0;                                                  // lane s: sum s
+    for (long long done = 0; done < n; done += 8192) {
+        const int piece = n - done < 8192 ? (int)(n - done) : 8192;
+        // pairwise sum of `piece` values off the stream: the recursion with an explicit stack (wave-uniform control)
+        int size[12], stage[12], sp = 0;
+        size[0] = piece; stage[0] = 0; sp = 1;
+        double val = 0.0;
+        while (sp > 0) {
+            const int m = size[sp - 1];
+            bool have = false;
+            if (m <= 128) {
+                fill_run(m);
+                run_sums(m);
+                val = lane < NSUM ? runv[lane] : 0.0;
+                __syncthreads();
+                --sp;
+                have = true;
+            } else {
+                int n2 = m / 2;
+                n2 -= n2 % 8;
+                stage[sp - 1] = 1;
+                size[sp] = n2; stage[sp] = 0; ++sp;
+            }
+            while (have && sp > 0) {                                     // hand a finished value to its parent
+                const int pm = size[sp - 1];
+                int n2 = pm / 2;
+                n2 -= n2 % 8;
+                if (stage[sp - 1] == 1) {                                // the left half: keep it, go right
+                    if (lane < NSUM) leftv[sp - 1][lane] = val;
+                    stage[sp - 1] = 2;
+                    size[sp] = pm - n2; stage[sp] = 0; ++sp;
+                    have = false;
+                } else {                                                 // the right half: the parent is done
+                    if (lane < NSUM) val = leftv[sp - 1][lane] + val;
+                    --sp;
+                }
+            }
+        }
+        total = total + val;
+    }
+    if (lane < NSUM) sums_out[(size_t)win * NSUM + lane] = total;
+}
+
 void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                     int n_win, int max_chunks, const int32_t *pop_start, int p1, int p2, int p3, int p4,
                     double min_data, int sel, int nsum, double *part_sums, int64_t *part_used, double *sums_out,
-                    int64_t *used_out) {
+                    int64_t *used_out, uint32_t *flags, int64_t base) {
     if (n_win <= 0) return;
     if (max_chunks > 0) {
         const dim3 grid(max_chunks, n_win);
 #define PG_ABBA_LAUNCH(NS, NP)                                                                                          \
     hipLaunchKernelGGL((k_abba_q<NS, NP>), grid, dim3(256), 0, st, gt, S, win_lo, win_hi, max_chunks, pop_start, p1, p2, \
-                       p3, p4, min_data, sel, part_sums, part_used)
+                       p3, p4, min_data, sel, part_sums, part_used, flags, base)
         const int npass = (S + 255) / 256;
         if (nsum == PG_ABBA_NSUM) {
             if (npass == 1) PG_ABBA_LAUNCH(PG_ABBA_NSUM, 1);
@@ -1305,6 +1514,14 @@ void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_
     int total = n_win * (nsum + 1);
     hipLaunchKernelGGL(k_abba_reduce, dim3((total + 255) / 256), dim3(256), 0, st, part_sums, part_used, n_win,
                        max_chunks, nsum, win_lo, win_hi, sums_out, used_out);
+    if (flags) {                                                         // the sums again, in NumPy's order (the counts stay)
+        if (nsum == PG_ABBA_NSUM)
+            hipLaunchKernelGGL((k_quartet_np<PG_ABBA_NSUM>), dim3(n_win), dim3(64), 0, st, gt, S, win_lo, win_hi, pop_start, p1, p2, p3,
+                               p4, sel, flags, base, sums_out);
+        else
+            hipLaunchKernelGGL((k_quartet_np<PG_FOURPOP_NSUM>), dim3(n_win), dim3(64), 0, st, gt, S, win_lo, win_hi, pop_start, p1, p2,
+                               p3, p4, sel, flags, base, sums_out);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1313,11 +1530,6 @@ void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_
 struct FreqAcc {
     unsigned long long l, Sx[PG_MAX_POPS], Px[PG_MAX_POPS];
 };
-
-// flag_site: the site takes part in k_popfreq_ordered's sums (every slot called, polymorphic within some population)
-__device__ __forceinline__ void flag_site(uint32_t *__restrict__ flags, int64_t rel) {
-    atomicOr(&flags[rel >> 5], 1u << (rel & 31));
-}
 
 __device__ __forceinline__ void popfreq_site(const uint32_t *__restrict__ row, int n_hap, const int32_t *__restrict__ pop_start,
                                              int n_pops, FreqAcc &F, uint32_t *__restrict__ flags, int64_t rel) {

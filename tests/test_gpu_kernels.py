@@ -181,7 +181,7 @@ def test_ind_pair_dists_with_and_without_popdist_mask():
                                                  (600, 0.3, 9000)])     # 1200-byte rows: quad-layout screening
 def test_abbababa_sums(n_dip, min_data, miss):
     e, lay, codes, _ = G.make_engine(n_dip, 4, 6000, seed=44, var_thr=45000, miss_thr=miss)
-    wins = [(0, 3000), (3000, 3010), (3010, 6000), (10, 10)]
+    wins = [(0, 3000), (3000, 3010), (3010, 6000), (10, 10), (2, 4097), (100, 230)]
     wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
     got = wb.ABBABABA("p0", "p1", "p2", "p3", min_data)
     for k, (a, b) in enumerate(wins):
@@ -191,8 +191,8 @@ def test_abbababa_sums(n_dip, min_data, miss):
         want = orc.abbababa(oracle_aln(lay, codes, a, b), "p0", "p1", "p2", "p3", min_data)
         assert G.close(got["sitesUsed"][k], want["sitesUsed"])
         if want["sitesUsed"] > 0:
-            for key in ("D", "fd", "fdM", "ABBA", "BABA"):
-                assert G.close(got[key][k], want[key]), (key, k, got[key][k], want[key])
+            for key in ("D", "fd", "fdM", "ABBA", "BABA"):             # the sums in NumPy's order (k_quartet_np): to the last bit
+                assert G.same(got[key][k], want[key]), (key, k, got[key][k], want[key])
     e.close()
 
 
@@ -213,7 +213,7 @@ def test_fourpop_sums(mode, n_dip, min_data, miss):
         assert got["sitesUsed"][k] == want["sitesUsed"], (k, got["sitesUsed"][k], want["sitesUsed"])
         if want["sitesUsed"] > 0:
             for key in orc.FOURPOP_STATS:
-                assert G.close(got[key][k], want[key]), (key, k, got[key][k], want[key])
+                assert G.same(got[key][k], want[key]), (key, k, got[key][k], want[key])
     e.close()
 
 
