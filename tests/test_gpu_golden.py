@@ -30,10 +30,11 @@ def cells(text):
     return [ln.replace(",", " ").split() for ln in text.splitlines()]
 
 
-def compare_text(got, want, digits, inexact=None):
-    """Cells must be the same text, except that a floating-point cell may sit on the other side of a rounding tie: then the two
-    printed values differ by exactly ONE unit of the rounding digit (anything else is an error, however small).  Returns the number
-    of such cells; `inexact` collects (row, column, got, want) for the tie check of the caller."""
+def compare_text(got, want, digits, inexact=None, ties=False):
+    """Cells must be the same text.  ties=True (outputs with windows of more than 4096 sites, whose float64 sums are formed in a fixed
+    tree instead of NumPy's order: pg_popdist_stats): a floating-point cell may sit on the other side of a rounding tie -- then the
+    two printed values differ by exactly ONE unit of the rounding digit (anything else is an error, however small).  Returns the
+    number of such cells; `inexact` collects (row, column, got, want)."""
     g, w = cells(got), cells(want)
     assert len(g) == len(w), "row count %d != %d" % (len(g), len(w))
     unit = 10.0 ** (-digits)
@@ -47,6 +48,7 @@ def compare_text(got, want, digits, inexact=None):
                 gv, wv = float(gc), float(wc)
             except ValueError:
                 raise AssertionError("row %d: %r != %r" % (r, gc, wc))
+            assert ties, "row %d column %d: %r != %r" % (r, c, gc, wc)
             assert abs(abs(gv - wv) - unit) <= 1e-6 * unit, "row %d: %r vs %r is not one unit of the rounding digit" % (r, gc, wc)
             n_inexact += 1
             if inexact is not None:
@@ -64,27 +66,10 @@ def test_cli_reproduces_reference_output(case, tmp_path, geno=None):
         got = f.read()
     with open(os.path.join(GOLD, case["name"] + ".out")) as f:
         want = f.read()
-    inexact = []
-    n_inexact = compare_text(align_columns(got, want), want, round_digits(case), inexact)
-    # ties at the rounding digit are rare: the bulk must be textually identical
-    assert n_inexact <= max(2, len(want.split()) // 50), "%d cells differ in the last digit" % n_inexact
-    if inexact and case["tool"] in ("popgenWindows.py", "distMat.py"):
-        # ... and every such cell must BE a tie: printed with 12 digits, the value lies within 1e-9 of the midpoint between the
-        # two neighbours that were printed (a genuine error of 1e-5 at --roundTo 4 would pass the one-unit test, not this one)
-        argv12 = [a for a in argv]
-        if "--roundTo" in argv12:
-            argv12[argv12.index("--roundTo") + 1] = "12"
-        else:
-            argv12 = argv12[:-2] + ["--roundTo", "12"] + argv12[-2:]
-        out12 = out + ".r12"
-        argv12[argv12.index("-o") + 1] = out12
-        MAINS[case["tool"]](argv12)
-        with open(out12) as f:
-            hi = cells(align_columns(f.read(), want))
-        for r, c, gv, wv in inexact:
-            mid = 0.5 * (gv + wv)
-            assert abs(float(hi[r][c]) - mid) <= 1e-9 * max(1.0, abs(mid)), \
-                "row %d column %d: %r printed, reference %r, 12-digit value %s is not a rounding tie" % (r, c, gv, wv, hi[r][c])
+    # every window of the goldens is short enough for the float64 sums to be formed in NumPy's order (k_popdist_np, k_quartet_np,
+    # k_popfreq_ordered): the text is the reference's, cell for cell -- no rounding-tie allowance (compare_text words the difference)
+    n_inexact = compare_text(align_columns(got, want), want, round_digits(case))
+    assert n_inexact == 0, "%d cells differ in the last digit" % n_inexact
     side = os.path.join(GOLD, case["name"] + ".out.windows")
     if os.path.exists(side):
         with open(out + ".windows") as f, open(side) as g:
