@@ -188,6 +188,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->site_tmp.release();
     c->site_flags.release();
     c->ref_row.release();
+    c->samp_rank.release();
     c->pop_rank.release();
     c->np_trees.release();
     c->np_task_tree.release();
@@ -312,6 +313,7 @@ extern "C" int pg_set_samples(pg_ctx *c, int n_hap, const int32_t *hap_pop, cons
         int r2;
         if ((r2 = c->ref_row.upload(ident.data(), (size_t)n_hap, c->stream)) != PG_OK) return r2;
         if ((r2 = c->pop_rank.upload(ident.data(), (size_t)std::max(n_pops, 1), c->stream)) != PG_OK) return r2;
+        if ((r2 = c->samp_rank.upload(ident.data(), (size_t)n_hap, c->stream)) != PG_OK) return r2;        // (n_samp <= n_hap)
         HIPCHK(hipStreamSynchronize(c->stream));
         c->np_state = 0;
     }
@@ -1023,6 +1025,16 @@ extern "C" int pg_set_reference_order(pg_ctx *c, const int32_t *pop_row_order, c
     return PG_OK;
 }
 
+extern "C" int pg_set_sample_rank(pg_ctx *c, const int32_t *rank) {
+    if (!c || !rank) return pg_fail(PG_ERR_ARG, "pg_set_sample_rank: null argument");
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->samp_rank.upload(rank, (size_t)c->n_samp, c->stream)) != PG_OK) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
 // NumPy's pairwise summation of n values as a tree (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum): fewer than 8 values or at
 // most 128: a run (k_popdist_np adds it up as NumPy's unrolled loop does); more: the first n/2 rounded down to a multiple of 8, then
 // the rest.  blob = [L, n_inner, n_levels, leaf_off[L + 1], node_l[n_inner], node_r[n_inner], level_start[n_levels + 1]]; the inner
@@ -1203,7 +1215,7 @@ static int indpair_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_wi
         if (mean_mode == 0 && (r = c->res_i64.ensure((size_t)nb * npairs)) != PG_OK) return r;
         hipEvent_t e0, e1;
         if ((r = pg_time_begin(c, PG_K_INDPAIR_FIN, &e0, &e1)) != PG_OK) return r;
-        pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->samp_start.p, c->n_samp, min_pair_sites,
+        pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->samp_start.p, c->samp_rank.p, c->n_samp, min_pair_sites,
                               c->res_f64.p, c->res_i64.p, mean_mode);
         if ((r = pg_time_end(c, PG_K_INDPAIR_FIN, e0, e1, 1)) != PG_OK) return r;
         HIPCHK(hipGetLastError());
@@ -1249,7 +1261,7 @@ extern "C" int pg_indpairdist_mean_from_counts(pg_ctx *c, const int32_t *D, cons
         if ((rc = c->res_f64.ensure((size_t)nb * npairs)) != PG_OK) return rc;
         HIPCHK(hipMemcpyAsync(c->Dmat.p, D + (size_t)w0 * NN, (size_t)nb * NN * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->Cmat.p, C + (size_t)w0 * NN, (size_t)nb * NN * 4, hipMemcpyHostToDevice, c->stream));
-        pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->n_hap, 0, nb, c->samp_start.p, c->n_samp, min_pair_sites,
+        pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->n_hap, 0, nb, c->samp_start.p, c->samp_rank.p, c->n_samp, min_pair_sites,
                               c->res_f64.p, nullptr, diag_counts_zeros ? 2 : 1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(d_out + (size_t)w0 * npairs, c->res_f64.p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->stream));

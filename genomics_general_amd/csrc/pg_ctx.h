@@ -141,6 +141,7 @@ struct pg_ctx {
     // pi / dxy / Fst in NumPy's summation order (k_popdist_np): the reference's row order within the populations and the rank of
     // the population names (pg_set_reference_order; identity until set), the pairwise-summation trees of the block lengths
     DevBuf<int32_t> ref_row, pop_rank, np_trees, np_task_tree;
+    DevBuf<int32_t> samp_rank;     // k_indpair_fin: which individual of a pair supplies the rows of its haplotype block (pg_set_sample_rank)
     int np_state = 0;              // 0: not built for the current samples; 1: usable; -1: a block has too many runs (old finisher)
     int np_max_leaves = 0, np_max_side = 0;
     // how the matrices of the last batch are laid out (set by pairwise_batches)

@@ -54,7 +54,7 @@ void pg_launch_popdist_np(hipStream_t st, const int32_t *Cmat, const int32_t *Dm
                           double min_data, int do_pairs, double *sums, int64_t *cnts, double *out);
 
 void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
-                           const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,
+                           const int32_t *samp_start, const int32_t *samp_rank, int n_samp, int min_pair_sites, double *sum_out,
                            int64_t *cnt_out, int mean_mode);
 
 

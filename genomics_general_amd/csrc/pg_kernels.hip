@@ -782,7 +782,8 @@ void pg_launch_popdist_np(hipStream_t st, const int32_t *Cmat, const int32_t *Dm
 // K_indpair: one thread per unordered individual pair (s<=t); haplotype slots of an individual are contiguous.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat,
-                                                     int N, int cN, int cshift, const int32_t *__restrict__ samp_start, int n_samp,
+                                                     int N, int cN, int cshift, const int32_t *__restrict__ samp_start,
+                                                     const int32_t *__restrict__ samp_rank, int n_samp,
                                                      int min_pair_sites, double *__restrict__ sum_out,
                                                      int64_t *__restrict__ cnt_out, int mean_mode) {
     const int win = blockIdx.y;
@@ -803,12 +804,17 @@ __global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__
         const int t = s + (int)(pidx - ((long long)s * n_samp - (long long)s * (s - 1) / 2));
         double sum = 0.0;
         long long cnt = 0;
-        for (int a = samp_start[s]; a < samp_start[s + 1]; ++a)
-            for (int b = samp_start[t]; b < samp_start[t + 1]; ++b) {
-                if (s == t && a >= b) continue;
-                const int c = Cw[(size_t)(a >> cshift) * cN + (b >> cshift)];
-                if (c >= thr) { sum += (double)Dw[(size_t)a * N + b] / (double)c; ++cnt; }
-            }
+        // np.nanmean adds the haplotype block up row by row (fewer than 8 values: one after the other): the rows are the haplotypes of the
+        // individual the caller names first -- `pairDistDict[i][j]` with i before j in sorted names (popgenWindows.py:55-57) or in the
+        // order of the samples (distMat.py:44-45): samp_rank (pg_set_sample_rank; slot order until set)
+        const int as = samp_start[s], ns = samp_start[s + 1] - as, bs = samp_start[t], nt = samp_start[t + 1] - bs;
+        const bool s_rows = samp_rank[s] <= samp_rank[t];
+        for (int u = 0; u < ns * nt; ++u) {
+            const int a = as + (s_rows ? u / nt : u % ns), b = bs + (s_rows ? u % nt : u / ns);
+            if (s == t && a >= b) continue;
+            const int c = Cw[(size_t)(a >> cshift) * cN + (b >> cshift)];
+            if (c >= thr) { sum += (double)Dw[(size_t)a * N + b] / (double)c; ++cnt; }
+        }
         if (mean_mode == 0) {
             sum_out[(size_t)win * npairs + pidx] = sum;
             cnt_out[(size_t)win * npairs + pidx] = cnt;
@@ -826,13 +832,13 @@ __global__ __launch_bounds__(256) void k_indpair_fin(const int32_t *__restrict__
 }
 
 void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
-                           const int32_t *samp_start, int n_samp, int min_pair_sites, double *sum_out,
+                           const int32_t *samp_start, const int32_t *samp_rank, int n_samp, int min_pair_sites, double *sum_out,
                            int64_t *cnt_out, int mean_mode) {
     if (n_win <= 0 || n_samp <= 0) return;
     long long npairs = (long long)n_samp * (n_samp + 1) / 2;
     int bx = (int)((npairs + 255) / 256);
     if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(k_indpair_fin, dim3(bx, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, samp_start, n_samp,
+    hipLaunchKernelGGL(k_indpair_fin, dim3(bx, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, samp_start, samp_rank, n_samp,
                        min_pair_sites, sum_out, cnt_out, mean_mode);
 }
 

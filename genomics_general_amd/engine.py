@@ -137,6 +137,18 @@ class Engine:
             check(self._L.pg_set_reference_order(self._h, np.ascontiguousarray(pop_row_order(layout)), rank))
         self.layout = layout
         self.n_sites = 0
+        self._pair_first = "slot"
+
+    def set_pair_first(self, first):
+        """which individual of a pair supplies the rows of the haplotype block pg_indpairdist_mean averages: "slot" (the earlier one
+        in layout.ind_order) or "name" (the one whose name sorts first)"""
+        if self.__dict__.get("_pair_first", "slot") != first:
+            n = self.layout.n_samp
+            rank = np.arange(n, dtype=np.int32)
+            if first == "name":
+                rank[np.argsort(np.array(self.layout.ind_order))] = np.arange(n, dtype=np.int32)
+            check(self._L.pg_set_sample_rank(self._h, np.ascontiguousarray(rank)))
+            self._pair_first = first
 
     def reserve(self, n_sites):
         """room for n_sites resident rows (growing drops the rows).  Reservations of 4 GiB and more try up to PG_PLACE_TRIALS
@@ -344,6 +356,7 @@ class Engine:
         C = np.ascontiguousarray(C, dtype=np.int32)
         assert D.shape == C.shape == (D.shape[0], lay.n_hap, lay.n_hap)
         tab = np.zeros((D.shape[0], n * (n + 1) // 2), np.float64)
+        self.set_pair_first("slot")
         check(self._L.pg_indpairdist_mean_from_counts(self._h, D, C, D.shape[0], int(minSites) if minSites else 0,
                                                       1 if includeSameWithSame else 0, tab))
         return tab
@@ -507,7 +520,7 @@ class WindowBatch:
         return sums, cnts
 
     # -- indPairDist -------------------------------------------------------------------------------------
-    def indPairTable(self, includeSameWithSame=False, minSites=None):
+    def indPairTable(self, includeSameWithSame=False, minSites=None, first="slot"):
         """Alignment.indPairDists as one array [window][pair]: the nanmean of every individual pair's haplotype block, finished
         on the device (pg_indpairdist_mean).  Pair (s<=t) in slot order of the individuals sits at lay.sample_pair_index(s,t).
         As in the reference (which mutates its cached distance matrix), a preceding groupDistStats leaves its minSites mask
@@ -515,6 +528,10 @@ class WindowBatch:
         lay = self.lay
         n = lay.n_samp
         npairs = n * (n + 1) // 2
+        # which individual of a pair supplies the rows of the haplotype block (the order np.nanmean adds a 2 x 2 block up in):
+        # first="slot": the earlier one in lay.ind_order (distMat.py:44-45: the order of its samples); "name": the one whose name
+        # sorts first (popgenWindows.py:55-57)
+        self.e.set_pair_first(first)
         # fully overwritten by the copy back; large tables land in page-locked memory (direct DMA)
         tab = (self.e.pinned.empty if self.n * npairs * 8 >= (1 << 20) else np.zeros)((self.n, npairs), np.float64)
         ms = int(minSites) if minSites else 0
@@ -533,7 +550,7 @@ class WindowBatch:
         """{name: {name: array over windows}} like Alignment.indPairDists(asDict=True); views into indPairTable()."""
         lay = self.lay
         n = lay.n_samp
-        tab = self.indPairTable(includeSameWithSame, minSites)
+        tab = self.indPairTable(includeSameWithSame, minSites, first="name")       # out[a][b] for a before b in sorted names
         out = {a: {} for a in lay.ind_order}
         for s in range(n):
             for t in range(s, n):

@@ -76,6 +76,12 @@ int pg_set_samples(pg_ctx *ctx, int n_hap, const int32_t *hap_pop, const int32_t
  * haplotypes; beyond, upper-triangle sums in a fixed tree: equal within 1e-15). */
 int pg_set_reference_order(pg_ctx *ctx, const int32_t *pop_row_order, const int32_t *pop_name_rank);
 
+/* rank[n_samples]: of an individual pair, the one with the smaller rank supplies the ROWS of the haplotype block whose np.nanmean
+ * pg_indpairdist_mean forms (genomics.py:946-947: `out[s][t]`, rows = the haplotypes of s; a 2 x 2 block added up row by row).
+ * popgenWindows.py reads `pairDistDict[i][j]` with i before j in sorted names (popgenWindows.py:55-57), distMat.py in the order of
+ * its samples (distMat.py:44-45).  Slot order after pg_set_samples. */
+int pg_set_sample_rank(pg_ctx *ctx, const int32_t *rank);
+
 /* ---- resident site buffer ------------------------------------------------------------------------ */
 int pg_reserve_sites(pg_ctx *ctx, int64_t n_sites);
 /* pg_reserve_sites for a large reservation (>= 4 GiB) with a choice of physical placement: up to max_trials (<= 8) allocations are
