@@ -789,6 +789,8 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
         else pg_launch_pairD(c->stream, sl.XV.p, d_nw, d_goff, nb, c->tasks2.p, c->n_tasks2, NP, N, ga / nb, c->Dmat.p, capg);
         if ((rc = pg_time_end(c, PG_K_PAIRD, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
+        c->cur_win_lo = d_lo;
+        c->cur_win_hi = d_hi;
         if ((rc = consume(w0, nb)) != PG_OK) return rc;
         HIPCHK(hipEventRecord(sl.consumed, c->stream));
         sl.used = true;
@@ -1151,33 +1153,38 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
     // the sums in NumPy's order (k_popdist_np) wherever the blocks' trees fit a thread block's LDS: populations of up to a few
     // hundred haplotypes; PG_POPDIST_TREE=0: the older finisher (upper triangles, a fixed reduction tree: equal within 1e-15)
     if ((rc = np_prepare(c)) != PG_OK) return rc;
-    int64_t longest = 0;
-    for (int w = 0; w < n_win; ++w) longest = std::max(longest, hi[w] - lo[w]);
     // NumPy's order where the last bit can show: windows of up to PG_NP_MAX_SITES sites (quotients of small integers sit on rounding
     // ties of the printed digit; Fst of equal populations is +-0.0).  Longer windows: the older finisher (upper triangles, a fixed
-    // tree; 40 times less work: every quotient is formed once instead of 2 .. 6 times), equal within 1e-15 -- a printed difference
-    // would need a mean within 1e-16 of a tie.  PG_POPDIST_TREE=1 / 0 forces one or the other.
+    // tree; 20 times less work: every quotient is formed once instead of 2 .. 6 times), equal within 1e-15 -- a printed difference
+    // would need a mean within 1e-16 of a tie.  The choice is made window by window (a window's numbers do not depend on what it is
+    // batched with).  PG_POPDIST_TREE=1 / 0 forces one or the other.
     const char *force = getenv("PG_POPDIST_TREE");
-    const bool np_order = c->np_state == 1 && (force ? atoi(force) != 0 : longest <= PG_NP_MAX_SITES);
-    const int P = c->n_pops, npairs = np_order ? P * P : P * (P + 1) / 2, ncols = P + (do_pairs ? P * (P - 1) : 0);
-    if ((rc = c->res_f64.ensure((size_t)n_win * npairs)) != PG_OK) return rc;
-    if ((rc = c->res_i64.ensure((size_t)n_win * npairs)) != PG_OK) return rc;
+    const long long np_upto = c->np_state != 1 ? -1 : force ? (atoi(force) != 0 ? (long long)INT64_MAX : -1) : PG_NP_MAX_SITES;
+    const int P = c->n_pops, npairs = P * (P + 1) / 2, ncols = P + (do_pairs ? P * (P - 1) : 0);
+    if ((rc = c->res_f64.ensure((size_t)n_win * P * P)) != PG_OK) return rc;           // k_popdist_np: P^2 sums a window
+    if ((rc = c->res_i64.ensure((size_t)n_win * P * P)) != PG_OK) return rc;
+    if ((rc = c->part_f64.ensure((size_t)n_win * npairs)) != PG_OK) return rc;         // k_popdist_fin: P (P + 1) / 2
+    if ((rc = c->part_i64.ensure((size_t)n_win * npairs)) != PG_OK) return rc;
     if ((rc = c->stats.ensure((size_t)n_win * ncols + 1)) != PG_OK) return rc;
     if ((rc = flag_ready(c)) != PG_OK) return rc;
     if (c->events[PG_K_PACK].size() > 4096 && (rc = fold_events(c)) != PG_OK) return rc;
     auto consume = [&](int w0, int nb) -> int {
+        bool any_short = false, any_long = false;
+        for (int w = w0; w < w0 + nb; ++w) (hi[w] - lo[w] <= np_upto ? any_short : any_long) = true;
         hipEvent_t e0, e1;
         int r = pg_time_begin(c, PG_K_POPDIST_FIN, &e0, &e1);
         if (r != PG_OK) return r;
-        if (np_order) {
+        if (any_short)
             pg_launch_popdist_np(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, P, c->ref_row.p,
                                  c->pop_rank.p, c->np_task_tree.p, c->np_trees.p, c->np_max_leaves, c->np_max_side, min_pair_sites, min_data, do_pairs,
-                                 c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, c->stats.p + (size_t)w0 * ncols);
-        } else {
-        pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, P, min_pair_sites,
-                              c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, c->all_diploid && c->pops_on_individuals ? 1 : 0);
-        pg_launch_popstats(c->stream, c->res_f64.p + (size_t)w0 * npairs, c->res_i64.p + (size_t)w0 * npairs, nb, c->pop_start.p, P,
-                           min_data, do_pairs, c->stats.p + (size_t)w0 * ncols);
+                                 c->res_f64.p + (size_t)w0 * P * P, c->res_i64.p + (size_t)w0 * P * P, c->stats.p + (size_t)w0 * ncols,
+                                 c->cur_win_lo, c->cur_win_hi, np_upto);
+        if (any_long) {
+            pg_launch_popdist_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->pop_start.p, P, min_pair_sites,
+                                  c->part_f64.p + (size_t)w0 * npairs, c->part_i64.p + (size_t)w0 * npairs,
+                                  c->all_diploid && c->pops_on_individuals ? 1 : 0, c->cur_win_lo, c->cur_win_hi, np_upto);
+            pg_launch_popstats(c->stream, c->part_f64.p + (size_t)w0 * npairs, c->part_i64.p + (size_t)w0 * npairs, nb, c->pop_start.p, P,
+                               min_data, do_pairs, c->stats.p + (size_t)w0 * ncols, c->cur_win_lo, c->cur_win_hi, np_upto);
         }
         if ((r = pg_time_end(c, PG_K_POPDIST_FIN, e0, e1, 1)) != PG_OK) return r;
         HIPCHK(hipGetLastError());
@@ -1359,7 +1366,10 @@ static int quartet_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_
         uint32_t *flags = nullptr;
         int64_t base = 0;
         const char *force = getenv("PG_QUARTET_TREE");
-        if (force ? atoi(force) != 0 : max_len <= PG_NP_MAX_SITES) {
+        const long long np_upto = force ? (atoi(force) != 0 ? (long long)INT64_MAX : -1) : PG_NP_MAX_SITES;       // window by window
+        bool any_short = false;
+        for (int w = w0; w < w1; ++w) any_short = any_short || hi[w] - lo[w] <= np_upto;
+        if (any_short) {
             int64_t top = 0;
             base = INT64_MAX;
             for (int w = w0; w < w1; ++w)
@@ -1374,7 +1384,7 @@ static int quartet_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_
         hipEvent_t e0, e1;
         if ((rc = pg_time_begin(c, PG_K_SITESTATS, &e0, &e1)) != PG_OK) return rc;
         pg_launch_abba(c->stream, c->gt.p, c->S, c->win.p, c->win.p + nb, nb, max_chunks, c->pop_start.p, p1, p2, p3, p4,
-                       min_data, sel, nsum, c->part_f64.p, c->part_i64.p, c->res_f64.p, c->res_i64.p, flags, base);
+                       min_data, sel, nsum, c->part_f64.p, c->part_i64.p, c->res_f64.p, c->res_i64.p, flags, base, np_upto);
         if ((rc = pg_time_end(c, PG_K_SITESTATS, e0, e1, 1)) != PG_OK) return rc;
         HIPCHK(hipGetLastError());
         if ((rc = c->out_pin.ensure((size_t)nb * (nsum + 1))) != PG_OK) return rc;

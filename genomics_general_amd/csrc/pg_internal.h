@@ -45,13 +45,15 @@ void pg_launch_synth(hipStream_t st, int8_t *gt, int S, int n_hap, int64_t site0
 
 void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *pop_start, int n_pops, int min_pair_sites, double *sum_out,
-                           int64_t *cnt_out, int all_diploid);
+                           int64_t *cnt_out, int all_diploid, const int64_t *win_lo = nullptr, const int64_t *win_hi = nullptr,
+                           long long skip_upto = -1);          // windows of up to skip_upto sites are left to k_popdist_np
 
 // pi / dxy / Fst with the sums in NumPy's pairwise order (k_popdist_np + k_popstats_np); sums / cnts: [n_win][n_pops^2] scratch
 void pg_launch_popdist_np(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                           const int32_t *pop_start, int n_pops, const int32_t *ref_row, const int32_t *pop_rank,
                           const int32_t *task_tree, const int32_t *trees, int max_leaves, int max_side, int min_pair_sites,
-                          double min_data, int do_pairs, double *sums, int64_t *cnts, double *out);
+                          double min_data, int do_pairs, double *sums, int64_t *cnts, double *out, const int64_t *win_lo,
+                          const int64_t *win_hi, long long max_sites);
 
 void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *samp_start, const int32_t *samp_rank, int n_samp, int min_pair_sites, double *sum_out,
@@ -61,7 +63,7 @@ void pg_launch_indpair_fin(hipStream_t st, const int32_t *Cmat, const int32_t *D
 void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                     int n_win, int max_chunks, const int32_t *pop_start, int p1, int p2, int p3, int p4,
                     double min_data, int sel, int nsum, double *part_sums, int64_t *part_used, double *sums_out,
-                    int64_t *used_out, uint32_t *flags, int64_t base);
+                    int64_t *used_out, uint32_t *flags, int64_t base, long long max_sites);
 
 void pg_launch_popfreq(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
                        const int64_t *win_hi, int n_win, int max_chunks, const int32_t *pop_start, int n_pops,
@@ -112,4 +114,5 @@ void pg_launch_unpack(hipStream_t st, const uint8_t *cells, int n_cols, int64_t 
                       int8_t *gt, int S);
 void pg_launch_flag_export(hipStream_t st, int32_t *flag, double *dst);
 void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts, int n_win, const int32_t *pop_start,
-                        int n_pops, double min_data, int do_pairs, double *out);
+                        int n_pops, double min_data, int do_pairs, double *out, const int64_t *win_lo = nullptr,
+                        const int64_t *win_hi = nullptr, long long skip_upto = -1);

@@ -173,8 +173,10 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat,
                                                      int N, int cN, int cshift, const int32_t *__restrict__ pop_start, int n_pops,
                                                      int min_pair_sites, double *__restrict__ sum_out,
-                                                     int64_t *__restrict__ cnt_out) {
+                                                     int64_t *__restrict__ cnt_out, const int64_t *__restrict__ win_lo,
+                                                     const int64_t *__restrict__ win_hi, long long skip_upto) {
     __shared__ double shd[8];
+    if (win_lo && win_hi[blockIdx.y] - win_lo[blockIdx.y] <= skip_upto) return;      // k_popdist_np's window
     // decode pair index -> (x<=y)
     int pidx = blockIdx.x, x = 0;
     int rem = pidx;
@@ -290,18 +292,18 @@ __global__ __launch_bounds__(256) void k_popdist_fin(const int32_t *__restrict__
 
 void pg_launch_popdist_fin(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                            const int32_t *pop_start, int n_pops, int min_pair_sites, double *sum_out,
-                           int64_t *cnt_out, int all_diploid) {
+                           int64_t *cnt_out, int all_diploid, const int64_t *win_lo, const int64_t *win_hi, long long skip_upto) {
     if (n_win <= 0 || n_pops <= 0) return;
     int npairs = n_pops * (n_pops + 1) / 2;
     if (all_diploid && cshift == 1)
         hipLaunchKernelGGL(k_popdist_fin<1>, dim3(npairs, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops,
-                           min_pair_sites, sum_out, cnt_out);
+                           min_pair_sites, sum_out, cnt_out, win_lo, win_hi, skip_upto);
     else if (all_diploid && cshift == 0 && cN == N)
         hipLaunchKernelGGL(k_popdist_fin<2>, dim3(npairs, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops,
-                           min_pair_sites, sum_out, cnt_out);
+                           min_pair_sites, sum_out, cnt_out, win_lo, win_hi, skip_upto);
     else
         hipLaunchKernelGGL(k_popdist_fin<0>, dim3(npairs, n_win), dim3(256), 0, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops,
-                           min_pair_sites, sum_out, cnt_out);
+                           min_pair_sites, sum_out, cnt_out, win_lo, win_hi, skip_upto);
 #ifdef PG_DIV_PROBE
     {
         unsigned long long h[2];
@@ -331,13 +333,15 @@ __device__ __forceinline__ double nanmean_min_dev(double total, long long n_vali
 
 __global__ __launch_bounds__(256) void k_popstats(const double *__restrict__ sums, const int64_t *__restrict__ cnts, int n_win,
                                                   const int32_t *__restrict__ pop_start, int n_pops, double min_data, int do_pairs,
-                                                  double *__restrict__ out) {
+                                                  double *__restrict__ out, const int64_t *__restrict__ win_lo,
+                                                  const int64_t *__restrict__ win_hi, long long skip_upto) {
     const int npairs = n_pops * (n_pops + 1) / 2;
     const int npo = n_pops * (n_pops - 1) / 2;
     const int ncols = n_pops + (do_pairs ? 2 * npo : 0);
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n_win * npairs) return;
     const int win = (int)(idx / npairs), pidx = (int)(idx % npairs);
+    if (win_lo && win_hi[win] - win_lo[win] <= skip_upto) return;
     int x = 0, rem = pidx;
     while (rem >= n_pops - x) { rem -= n_pops - x; ++x; }
     const int y = x + rem;
@@ -586,11 +590,12 @@ void pg_launch_flag_export(hipStream_t st, int32_t *flag, double *dst) {
 }
 
 void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts, int n_win, const int32_t *pop_start,
-                        int n_pops, double min_data, int do_pairs, double *out) {
+                        int n_pops, double min_data, int do_pairs, double *out, const int64_t *win_lo, const int64_t *win_hi,
+                        long long skip_upto) {
     if (n_win <= 0 || n_pops <= 0) return;
     const long long total = (long long)n_win * (n_pops * (n_pops + 1) / 2);
     hipLaunchKernelGGL(k_popstats, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sums, cnts, n_win, pop_start, n_pops,
-                       min_data, do_pairs, out);
+                       min_data, do_pairs, out, win_lo, win_hi, skip_upto);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -612,8 +617,10 @@ __global__ __launch_bounds__(256) void k_popdist_np(const int32_t *__restrict__ 
                                                     const int32_t *__restrict__ ref_row, const int32_t *__restrict__ pop_rank,
                                                     const int32_t *__restrict__ task_tree, const int32_t *__restrict__ trees,
                                                     int min_pair_sites, int max_leaves, double *__restrict__ sum_out,
-                                                    int64_t *__restrict__ cnt_out) {
+                                                    int64_t *__restrict__ cnt_out, const int64_t *__restrict__ win_lo,
+                                                    const int64_t *__restrict__ win_hi, long long max_sites) {
     extern __shared__ double np_lds[];
+    if (win_hi[blockIdx.y] - win_lo[blockIdx.y] > max_sites) return;          // a long window: the fixed-tree finisher's
     double *slots = np_lds;                                  // [2 * max_leaves]: run sums, then the inner nodes
     double *q = np_lds + 2 * (size_t)max_leaves;             // [PG_NP_STAGE_LEAVES * 128]
     __shared__ unsigned long long shc[4];
@@ -731,7 +738,9 @@ __global__ __launch_bounds__(256) void k_popdist_np(const int32_t *__restrict__ 
 // x-major); the float64 operations of genomics.py:88-90 and 976-993 in the reference's order, the pair oriented by pop_rank
 __global__ __launch_bounds__(256) void k_popstats_np(const double *__restrict__ sums, const int64_t *__restrict__ cnts, int n_win,
                                                      const int32_t *__restrict__ pop_start, const int32_t *__restrict__ pop_rank,
-                                                     int n_pops, double min_data, int do_pairs, double *__restrict__ out) {
+                                                     int n_pops, double min_data, int do_pairs, double *__restrict__ out,
+                                                     const int64_t *__restrict__ win_lo, const int64_t *__restrict__ win_hi,
+                                                     long long max_sites) {
     const int npairs = n_pops * (n_pops + 1) / 2;
     const int npo = n_pops * (n_pops - 1) / 2;
     const int n_tasks = n_pops + 2 * npo;
@@ -739,6 +748,7 @@ __global__ __launch_bounds__(256) void k_popstats_np(const double *__restrict__ 
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n_win * npairs) return;
     const int win = (int)(idx / npairs), pidx = (int)(idx % npairs);
+    if (win_hi[win] - win_lo[win] > max_sites) return;
     int x = 0, rem = pidx;
     while (rem >= n_pops - x) { rem -= n_pops - x; ++x; }
     const int y = x + rem;
@@ -766,16 +776,17 @@ __global__ __launch_bounds__(256) void k_popstats_np(const double *__restrict__ 
 void pg_launch_popdist_np(hipStream_t st, const int32_t *Cmat, const int32_t *Dmat, int N, int cN, int cshift, int n_win,
                           const int32_t *pop_start, int n_pops, const int32_t *ref_row, const int32_t *pop_rank,
                           const int32_t *task_tree, const int32_t *trees, int max_leaves, int max_side, int min_pair_sites,
-                          double min_data, int do_pairs, double *sums, int64_t *cnts, double *out) {
+                          double min_data, int do_pairs, double *sums, int64_t *cnts, double *out, const int64_t *win_lo,
+                          const int64_t *win_hi, long long max_sites) {
     if (n_win <= 0 || n_pops <= 0) return;
     const int n_tasks = n_pops * n_pops;                     // P + 2 * P (P - 1) / 2
     // run sums and inner nodes, the staged quotients, the row and column maps
     const size_t lds = (2 * (size_t)max_leaves + PG_NP_STAGE_LEAVES * 128) * sizeof(double) + ((size_t)max_side + 8) * sizeof(int32_t);
     hipLaunchKernelGGL(k_popdist_np, dim3(n_tasks, n_win), dim3(256), lds, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops, ref_row,
-                       pop_rank, task_tree, trees, min_pair_sites, max_leaves, sums, cnts);
+                       pop_rank, task_tree, trees, min_pair_sites, max_leaves, sums, cnts, win_lo, win_hi, max_sites);
     const long long total = (long long)n_win * (n_pops * (n_pops + 1) / 2);
     hipLaunchKernelGGL(k_popstats_np, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sums, cnts, n_win, pop_start, pop_rank,
-                       n_pops, min_data, do_pairs, out);
+                       n_pops, min_data, do_pairs, out, win_lo, win_hi, max_sites);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1309,13 +1320,14 @@ template <int NSUM>
 __global__ __launch_bounds__(64) void k_quartet_np(const int8_t *__restrict__ gt, int S, const int64_t *__restrict__ win_lo,
                                                    const int64_t *__restrict__ win_hi, const int32_t *__restrict__ pop_start, int q1,
                                                    int q2, int q3, int q4, int sel, const uint32_t *__restrict__ flags, int64_t base,
-                                                   double *__restrict__ sums_out) {
+                                                   double *__restrict__ sums_out, long long max_sites) {
     __shared__ uint16_t list[8192];
     __shared__ double vals[NSUM][128];
     __shared__ double runv[NSUM];
     __shared__ double leftv[12][NSUM];
     const int win = blockIdx.x, lane = threadIdx.x;
     const int64_t lo = win_lo[win], hi = win_hi[win];
+    if (hi - lo > max_sites) return;                                     // a long window keeps k_abba_reduce's sums
     const int qs[4] = {q1, q2, q3, q4};
     int ps[4], pe[4];
 #pragma unroll
@@ -1496,7 +1508,7 @@ __global__ __launch_bounds__(64) void k_quartet_np(const int8_t *__restrict__ gt
 void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_lo, const int64_t *win_hi,
                     int n_win, int max_chunks, const int32_t *pop_start, int p1, int p2, int p3, int p4,
                     double min_data, int sel, int nsum, double *part_sums, int64_t *part_used, double *sums_out,
-                    int64_t *used_out, uint32_t *flags, int64_t base) {
+                    int64_t *used_out, uint32_t *flags, int64_t base, long long max_sites) {
     if (n_win <= 0) return;
     if (max_chunks > 0) {
         const dim3 grid(max_chunks, n_win);
@@ -1523,10 +1535,10 @@ void pg_launch_abba(hipStream_t st, const int8_t *gt, int S, const int64_t *win_
     if (flags) {                                                         // the sums again, in NumPy's order (the counts stay)
         if (nsum == PG_ABBA_NSUM)
             hipLaunchKernelGGL((k_quartet_np<PG_ABBA_NSUM>), dim3(n_win), dim3(64), 0, st, gt, S, win_lo, win_hi, pop_start, p1, p2, p3,
-                               p4, sel, flags, base, sums_out);
+                               p4, sel, flags, base, sums_out, max_sites);
         else
             hipLaunchKernelGGL((k_quartet_np<PG_FOURPOP_NSUM>), dim3(n_win), dim3(64), 0, st, gt, S, win_lo, win_hi, pop_start, p1, p2,
-                               p3, p4, sel, flags, base, sums_out);
+                               p3, p4, sel, flags, base, sums_out, max_sites);
     }
 }
 

@@ -151,6 +151,35 @@ def test_group_dist_stats_to_the_last_bit_in_numpy_order(sizes, names, haploid, 
     e.close()
 
 
+def test_summation_order_is_chosen_window_by_window():
+    """windows of up to 4096 sites: NumPy's order (== the oracle); longer ones: the fixed trees (1e-9); a window's numbers do not
+    depend on the batch it is in (pg_popdist_stats, quartet_stats: the kernels skip each other's windows)"""
+    e, lay, codes, _ = G.make_engine(12, 4, 9000, seed=71, var_thr=40000, miss_thr=9000)
+    wins = [(0, 9000), (0, 3000), (3000, 7097), (100, 4196), (4196, 4196), (8000, 9000), (10, 4107)]
+    lo, hi = [w[0] for w in wins], [w[1] for w in wins]
+    st = e.batch(lo, hi).groupDistStats(True, 5, 0.01)
+    ab = e.batch(lo, hi).ABBABABA("p0", "p1", "p2", "p3", 0.3)
+    for k, (a, b) in enumerate(wins):
+        one = e.batch([a], [b]).groupDistStats(True, 5, 0.01)
+        one_ab = e.batch([a], [b]).ABBABABA("p0", "p1", "p2", "p3", 0.3)
+        for key in st:
+            assert G.same(st[key][k], one[key][0]), (key, k)
+        for key in ab:
+            assert G.same(ab[key][k], one_ab[key][0]), (key, k)
+        if b == a:
+            continue
+        short = b - a <= 4096
+        aln = oracle_aln(lay, codes, a, b)
+        Do, Co = orc.pair_counts_gemm(aln)
+        so, _ = orc.group_dist_stats(aln, Do, Co, True, 5, 0.01)
+        for key, v in so.items():
+            assert (G.same if short else G.close)(st[key][k], v), (key, k, st[key][k], v)
+        want = orc.abbababa(aln, "p0", "p1", "p2", "p3", 0.3)
+        for key in ("D", "fd", "fdM", "ABBA", "BABA"):
+            assert (G.same if short else G.close)(ab[key][k], want[key]), (key, k, ab[key][k], want[key])
+    e.close()
+
+
 def test_ind_pair_dists_with_and_without_popdist_mask():
     e, lay, codes, names = G.make_engine(9, 3, 1500, seed=33, miss_thr=25000)
     wins = [(0, 700), (700, 1500)]
