@@ -49,6 +49,10 @@ WORKLOADS = {
     # the C2 data set in 5 kb windows (2000 windows of 157 words): per-window fixed costs of the pair kernels; not a BASELINE.json config
     "c2_w5k": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=5_000, min_sites=100, tool="popgen",
                    desc="popgenWindows pi/Fst/Dxy: 1e7 sites x 100 diploids (200 haplotypes), 4 pops, 5 kb windows"),
+    # the C2 data set in 2 kb windows (5000 windows): windows of up to 4096 sites get their float64 sums in NumPy's order (k_popdist_np),
+    # what that costs at tier T0 (PG_POPDIST_TREE=0 for the fixed-tree finisher on the same windows); not a BASELINE.json config
+    "c2_w2k": dict(n_sites=10_000_000, n_scaf=4, n_dip=100, n_pops=4, wind=2_000, min_sites=100, tool="popgen",
+                   desc="popgenWindows pi/Fst/Dxy: 1e7 sites x 100 diploids (200 haplotypes), 4 pops, 2 kb windows"),
     # BASELINE.json configs[4]: 3*10^9 sites x 200 diploids sharded over the ranks (n_sites is per rank, set in main)
     "c5": dict(n_sites=None, n_scaf=3, n_dip=200, n_pops=4, wind=50_000, min_sites=100, tool="popgen",
                desc="popgenWindows pi/Fst/Dxy: this rank's share of 3e9 sites x 200 diploids (400 haplotypes), 4 pops, 50 kb windows"),

@@ -1093,7 +1093,7 @@ std::vector<int32_t> np_tree(int n) {
 }
 }  // namespace
 
-#define PG_NP_MAX_LEAVES 1536      // 2 * 1536 + 32 * 128 doubles of LDS = 56 KB per block
+#define PG_NP_MAX_LEAVES 1024      // LDS of a block: 2 * 1024 + 32 * 128 doubles + the tree's tables (3 * 1024 ints) + row maps < 64 KB
 
 // the trees of this context's blocks: (x, x), and (x, y) / (x + y, x + y) for every pair: their lengths do not depend on the orientation
 static int np_prepare(pg_ctx *c) {

@@ -612,6 +612,32 @@ void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts,
 // as quotients (coalesced over the flattened index), eight lanes add up a run, the levels of the tree follow.
 // ------------------------------------------------------------------------------------------------------
 #define PG_NP_STAGE_LEAVES 32
+
+// The pair kernels store the upper triangles of C and D.  k_popdist_np walks whole rows of symmetric blocks: reading the lower half
+// through the upper one (element (j, i) for i > j) turns every wave's load into 64 cache lines.  k_mirror_lower copies the upper
+// triangle into the lower one once per window (32 x 32 tiles through LDS: coalesced rows in, coalesced rows out).
+__global__ __launch_bounds__(256) void k_mirror_lower(int32_t *__restrict__ M, int n, const int64_t *__restrict__ win_lo,
+                                                      const int64_t *__restrict__ win_hi, long long max_sites) {
+    __shared__ int32_t tile[32][33];
+    const int win = blockIdx.y;
+    if (win_hi[win] - win_lo[win] > max_sites) return;
+    const int nt = (n + 31) / 32;
+    // blockIdx.x -> tile (ti <= tj) of the upper triangle
+    int t = blockIdx.x, ti = 0;
+    while (t >= nt - ti) { t -= nt - ti; ++ti; }
+    const int tj = ti + t;
+    int32_t *Mw = M + (size_t)win * n * n;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int r = ly; r < 32; r += 8) {
+        const int i = ti * 32 + r, j = tj * 32 + lx;
+        tile[r][lx] = (i < n && j < n) ? Mw[(size_t)i * n + j] : 0;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int i = tj * 32 + r, j = ti * 32 + lx;           // the mirrored tile: rows of tj, columns of ti
+        if (i < n && j < n && i > j) Mw[(size_t)i * n + j] = tile[lx][r];
+    }
+}
 __global__ __launch_bounds__(256) void k_popdist_np(const int32_t *__restrict__ Cmat, const int32_t *__restrict__ Dmat, int N, int cN,
                                                     int cshift, const int32_t *__restrict__ pop_start, int n_pops,
                                                     const int32_t *__restrict__ ref_row, const int32_t *__restrict__ pop_rank,
@@ -644,12 +670,16 @@ __global__ __launch_bounds__(256) void k_popdist_np(const int32_t *__restrict__ 
     const int n = nr * nc;
     const int32_t *T = trees + task_tree[task];              // [L, n_inner, n_levels, leaf_off[L + 1], node_l[], node_r[], level_start[]]
     const int L = T[0], n_inner = T[1], n_levels = T[2];
-    const int32_t *leaf_off = T + 3, *node_l = leaf_off + L + 1, *node_r = node_l + n_inner, *level_start = node_r + n_inner;
+    // the tree's tables are walked run by run and level by level: from LDS, not with a global-memory latency per level
+    int32_t *tree_s = reinterpret_cast<int32_t *>(q + PG_NP_STAGE_LEAVES * 128);
+    const int tree_len = (L + 1) + 2 * n_inner + (n_levels + 1);
+    for (int t = tid; t < tree_len; t += 256) tree_s[t] = T[3 + t];
+    const int32_t *leaf_off = tree_s, *node_l = leaf_off + L + 1, *node_r = node_l + n_inner, *level_start = node_r + n_inner;
     const int32_t *Cw = Cmat + (size_t)win * cN * cN, *Dw = Dmat + (size_t)win * N * N;
     const int thr = min_pair_sites > 1 ? min_pair_sites : 1;
     unsigned long long valid = 0ull;
     // the slots of the block's rows and columns (the reference's row order inside a population)
-    int32_t *rowmap = reinterpret_cast<int32_t *>(q + PG_NP_STAGE_LEAVES * 128), *colmap = rowmap + nr;
+    int32_t *rowmap = tree_s + tree_len, *colmap = rowmap + nr;
     for (int t = tid; t < nr; t += 256) rowmap[t] = ref_row[t < na ? as + t : bs + (t - na)];
     for (int t = tid; t < nc; t += 256) colmap[t] = ref_row[kind == 1 ? bs + t : (t < na ? as + t : bs + (t - na))];
     __syncthreads();
@@ -669,10 +699,9 @@ __global__ __launch_bounds__(256) void k_popdist_np(const int32_t *__restrict__ 
                     dv[u] = 0;
                     if (k + 256 * u < k1) {
                         const int i = rowmap[r], j = colmap[cc];
-                        if (i != j) {
-                            const int a = i < j ? i : j, b = i < j ? j : i;
-                            cv[u] = Cw[(size_t)(a >> cshift) * cN + (b >> cshift)];
-                            dv[u] = Dw[(size_t)a * N + b];
+                        if (i != j) {                                    // (both triangles hold the counts: k_mirror_lower)
+                            cv[u] = Cw[(size_t)(i >> cshift) * cN + (j >> cshift)];
+                            dv[u] = Dw[(size_t)i * N + j];
                         }
                     }
                     r += qi;
@@ -781,7 +810,15 @@ void pg_launch_popdist_np(hipStream_t st, const int32_t *Cmat, const int32_t *Dm
     if (n_win <= 0 || n_pops <= 0) return;
     const int n_tasks = n_pops * n_pops;                     // P + 2 * P (P - 1) / 2
     // run sums and inner nodes, the staged quotients, the row and column maps
-    const size_t lds = (2 * (size_t)max_leaves + PG_NP_STAGE_LEAVES * 128) * sizeof(double) + ((size_t)max_side + 8) * sizeof(int32_t);
+    const size_t lds = (2 * (size_t)max_leaves + PG_NP_STAGE_LEAVES * 128) * sizeof(double) +
+                       (3 * (size_t)max_leaves + 64 + (size_t)max_side + 8) * sizeof(int32_t);
+    {
+        const int ntD = (N + 31) / 32, ntC = (cN + 31) / 32;
+        hipLaunchKernelGGL(k_mirror_lower, dim3(ntD * (ntD + 1) / 2, n_win), dim3(256), 0, st, const_cast<int32_t *>(Dmat), N, win_lo, win_hi,
+                           max_sites);
+        hipLaunchKernelGGL(k_mirror_lower, dim3(ntC * (ntC + 1) / 2, n_win), dim3(256), 0, st, const_cast<int32_t *>(Cmat), cN, win_lo, win_hi,
+                           max_sites);
+    }
     hipLaunchKernelGGL(k_popdist_np, dim3(n_tasks, n_win), dim3(256), lds, st, Cmat, Dmat, N, cN, cshift, pop_start, n_pops, ref_row,
                        pop_rank, task_tree, trees, min_pair_sites, max_leaves, sums, cnts, win_lo, win_hi, max_sites);
     const long long total = (long long)n_win * (n_pops * (n_pops + 1) / 2);

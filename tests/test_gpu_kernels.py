@@ -151,6 +151,20 @@ def test_group_dist_stats_to_the_last_bit_in_numpy_order(sizes, names, haploid, 
     e.close()
 
 
+def test_populations_too_large_for_the_numpy_order_tree_keep_the_fixed_tree():
+    """two populations of 500 haplotypes: the (x+y, x+y) block has 10^6 values, more runs than a thread block's LDS holds
+    (pg_abi.cpp np_prepare): every window takes the upper-triangle finisher -- within 1e-9 of the oracle"""
+    e, lay, codes, _ = G.make_engine(500, 2, 300, seed=72, var_thr=40000, miss_thr=9000)
+    st = e.batch([0, 100], [300, 140]).groupDistStats(True, 5, 0.01)
+    for k, (a, b) in enumerate([(0, 300), (100, 140)]):
+        aln = oracle_aln(lay, codes, a, b)
+        Do, Co = orc.pair_counts_gemm(aln)
+        so, _ = orc.group_dist_stats(aln, Do, Co, True, 5, 0.01)
+        for key, v in so.items():
+            assert G.close(st[key][k], v), (key, k, st[key][k], v)
+    e.close()
+
+
 def test_summation_order_is_chosen_window_by_window():
     """windows of up to 4096 sites: NumPy's order (== the oracle); longer ones: the fixed trees (1e-9); a window's numbers do not
     depend on the batch it is in (pg_popdist_stats, quartet_stats: the kernels skip each other's windows)"""
