@@ -314,6 +314,8 @@ def gather_table(comm, local_rows, n_total):
     [n_total][k] table in window order on every rank.  One all-gather of equal-size (padded) blocks."""
     local_rows = np.asarray(local_rows, dtype=np.float64)
     k = local_rows.shape[1] if local_rows.ndim == 2 else 1
+    if k == 0:                       # no statistic column at all (popgenWindows.py --analysis popPairDist with one population)
+        return np.zeros((n_total, 0))
     local_rows = local_rows.reshape(-1, k)
     counts = shard_counts(n_total, comm.size)
     assert local_rows.shape[0] == counts[comm.rank], "shard size mismatch"

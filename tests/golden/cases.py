@@ -57,6 +57,9 @@ CASES = [
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "100", "--roundTo", "12", "-T", "2"] + pops_args(8, 2)),
     dict(name="c1_popgen_allpop", tool="popgenWindows.py", fixture="c1",
          argv=["-g", "{geno}", "-f", "phased", "-w", "2500", "-m", "50"]),
+    # one population and only the pair statistics asked for: no statistic column at all (the header ends in a comma, the rows do not)
+    dict(name="c1_popgen_pairdist_one_pop", tool="popgenWindows.py", fixture="c1",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "2500", "-m", "50", "--analysis", "popPairDist", "--addWindowID"]),
     dict(name="sparse_overlap_failed_id", tool="popgenWindows.py", fixture="sparse",
          argv=["-g", "{geno}", "-f", "phased", "-w", "500", "-s", "250", "-m", "10", "--writeFailedWindows",
                "--addWindowID", "--roundTo", "6"] + pops_args(12, 3)),
