@@ -259,6 +259,7 @@ def make_case(tmp, case, rng, tools):
                 argv += ["--polarize", "--fixed"]
     else:
         argv += ["--outFormat", pick(rng, ["raw", "phylip", "nexus"])]
+        inp["named"] = False
         if rng.random() < 0.4:
             argv += ["--windowDataOutFile", "{out}.windows"]
         if rng.random() < 0.3:
@@ -271,15 +272,29 @@ def make_case(tmp, case, rng, tools):
         if rng.random() < 0.5:
             digits = int(pick(rng, [3, 6, 8]))
             argv += ["--roundTo", str(digits)]
+    # the input on stdin (plain text; the reference needs the sample names on the command line then)
+    named = ("-p" in argv or "-P1" in argv or "--samples" in argv or "--header" in argv or "--headers" in argv)
+    if named and not inp["geno"].endswith(".gz") and rng.random() < 0.15:
+        argv[argv.index("-g") + 1] = "<" + inp["geno"]
     return tool, argv, digits, inp
+
+
+def split_stdin(argv):
+    """`-g <path` (a marker of make_case) -> (argv without -g, path to pipe into stdin)"""
+    if "-g" in argv and argv[argv.index("-g") + 1].startswith("<"):
+        k = argv.index("-g")
+        return argv[:k] + argv[k + 2:], argv[k + 1][1:]
+    return argv, None
 
 
 def run_case(case, tool, argv, digits, tmp, sizes, blocks):
     ref_out = os.path.join(tmp, "ref%d.out" % case)
     env = dict(os.environ, PYTHONHASHSEED="0")
+    argv, piped = split_stdin(argv)
     # the reference in its own process group: a hang (a dead worker, a loop of the parent) is ended with all its workers
     pr = subprocess.Popen([sys.executable, "-c", WRAP, os.path.join(REF, tool)] + [a.format(out=ref_out) for a in argv] + ["-o", ref_out],
-                          cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, start_new_session=True)
+                          cwd=tmp, stdin=open(piped, "rb") if piped else subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          env=env, start_new_session=True)
     try:
         ref_err = pr.communicate(timeout=100)[1].decode()
         hung = False
@@ -301,7 +316,8 @@ def run_case(case, tool, argv, digits, tmp, sizes, blocks):
             env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT="29500",
                        PG_COMM="file", PG_RDZV_FILE=os.path.join(tmp, "rdzv_%d_%d" % (case, size)), PG_STREAM_BYTES=str(block))
             procs.append(subprocess.Popen([sys.executable, "-c", test_dist.CLI_WORKER, tool] + [a.format(out=out) for a in argv] + ["-o", out],
-                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+                                          env=env, stdin=open(piped, "rb") if piped else subprocess.DEVNULL, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE))
         errs = []
         for p in procs:
             try:
@@ -338,8 +354,9 @@ def run_case(case, tool, argv, digits, tmp, sizes, blocks):
         if v in ("ok",) and want_w is not None and open(out + ".windows").read() != want_w:
             v, bad = "DIFF(windows file)", bad + 1
         verdicts.append("%d:%s" % (size, v))
-    line = "case %3d  %-18s rows %4d  %-34s %s" % (case, tool, want.count("\n"), " ".join(verdicts),
-                                                   " ".join(os.path.basename(a) if a.startswith(tmp) else a for a in argv[2:]))
+    line = "case %3d  %-18s rows %4d  %-34s %s%s" % (case, tool, want.count("\n"), " ".join(verdicts),
+                                                     " ".join(os.path.basename(a) if a.startswith(tmp) else a for a in argv[2 if not piped else 0:]),
+                                                     "  < " + os.path.basename(piped) if piped else "")
     return bad, line, notes
 
 
