@@ -69,3 +69,42 @@ def test_random_command_lines_on_the_hip_engine_match_the_stand_in(seed, tmp_pat
         assert got_side == want_side, what
         compared += 1
     assert compared >= CASES_PER_SEED // 2, "only %d of %d random command lines ran" % (compared, CASES_PER_SEED)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PG_FUZZ_RANK_SEEDS", "2"))))
+def test_random_command_lines_on_several_ranks_of_the_hip_engine(seed, tmp_path, monkeypatch):
+    """the same generator, the drivers started as 2 or 3 ranks on the one device (PG_COMM=file: window ranges of the input per rank,
+    device tokenizer on every rank, one gather of the rows) against the single-rank run in this process: the same text"""
+    import subprocess
+    rng = np.random.default_rng(88000 + seed)
+    compared = 0
+    for case in range(6):
+        tool, argv, digits, inp = F.make_case(str(tmp_path), case, rng, TOOLS)
+        argv = [a[1:] if a.startswith("<") else a for a in argv]
+        size = int(F.pick(rng, [2, 3]))
+        block = int(F.pick(rng, [3000, 30000, 1 << 30]))
+        what = "%s %s (%d ranks, blocks of %d)" % (tool, " ".join(argv), size, block)
+        monkeypatch.setenv("PG_STREAM_BYTES", str(block))
+        err_one, want, want_side = _run(tool, argv, str(tmp_path / ("one%d.out" % case)))
+        out = str(tmp_path / ("ranks%d.out" % case))
+        procs = []
+        for rank in range(size):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(37000 + (os.getpid() + 11 * case + size) % 2000), PG_COMM="file", PG_COMM_TIMEOUT="90",
+                       PG_RDZV_FILE=str(tmp_path / ("rdzv%d" % case)), PG_STREAM_BYTES=str(block))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, tool)] +
+                                          [a.format(out=out) for a in argv] + ["-o", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+        errs = [p.communicate(timeout=600)[1].decode() for p in procs]
+        failed = any(p.returncode != 0 for p in procs)
+        if err_one is not None or failed:
+            assert err_one is not None and failed, "%s\n  one rank: %s\n  ranks: %s" % (what, err_one, [e[-300:] for e in errs if "Error" in e][:1])
+            continue
+        with open(out) as f:
+            got = f.read()
+        assert align_columns(got, want) == want, what
+        if want_side is not None:
+            with open(out + ".windows") as f:
+                assert f.read() == want_side, what
+        compared += 1
+    assert compared >= 3
