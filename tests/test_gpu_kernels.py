@@ -118,6 +118,7 @@ def test_group_dist_stats(min_sites, min_data, miss):
     ((3, 7, 12), ("zeta", "alpha", "m"), (), 900),                     # np.unique's order is not the command line's; 6..24 haplotypes
     ((1, 2, 5, 9), ("b", "a", "d", "c"), (0, 4, 9), 400),              # a population of one diploid; haploid samples: odd blocks
     ((40, 33), ("x", "X"), (), 300),                                   # blocks of 6400 / 5280 / 21316 values: several levels of halves
+    ((90, 85), ("b", "a"), (3, 100), 120),                             # 178 + 169 haplotypes: 120 409 values = 15 pieces of 8192, 960 runs
     ((2, 2), ("p1", "p0"), (1,), 37),                                  # blocks of fewer than 8 values / tiny windows: ties of the quotients
 ])
 def test_group_dist_stats_to_the_last_bit_in_numpy_order(sizes, names, haploid, L):
