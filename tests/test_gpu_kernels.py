@@ -242,6 +242,28 @@ def test_abbababa_sums(n_dip, min_data, miss):
     e.close()
 
 
+def test_quartet_sums_in_numpy_order_over_several_pieces_of_8192_used_sites(monkeypatch):
+    """a window of 40 000 mostly variable sites forced into NumPy's order: more than 8192 used sites, so the sum is a chain of
+    pieces (np.add.reduce's buffer) on top of the pairwise trees -- ABBABABA and fourPop against the oracle with =="""
+    monkeypatch.setenv("PG_QUARTET_TREE", "1")
+    e, lay, codes, _ = G.make_engine(12, 4, 40000, seed=91, var_thr=62000, miss_thr=2000)
+    wins = [(0, 40000), (5, 20005)]
+    wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
+    got = wb.ABBABABA("p0", "p1", "p2", "p3", 0.3)
+    got4 = wb.fourPop("p0", "p1", "p2", "p3", 0.3)
+    for k, (a, b) in enumerate(wins):
+        aln = oracle_aln(lay, codes, a, b)
+        want = orc.abbababa(aln, "p0", "p1", "p2", "p3", 0.3)
+        assert want["sitesUsed"] > 8192 and got["sitesUsed"][k] == want["sitesUsed"], want["sitesUsed"]
+        for key in ("D", "fd", "fdM", "ABBA", "BABA"):
+            assert G.same(got[key][k], want[key]), (key, k, got[key][k], want[key])
+        want4 = orc.four_pop(aln, "p0", "p1", "p2", "p3", 0.3, False, False)
+        assert got4["sitesUsed"][k] == want4["sitesUsed"]
+        for key in orc.FOURPOP_STATS:
+            assert G.same(got4[key][k], want4[key]), (key, k, got4[key][k], want4[key])
+    e.close()
+
+
 @pytest.mark.parametrize("mode", ["minor", "polarize", "fixed"])
 @pytest.mark.parametrize("n_dip,min_data,miss", [(16, 0.01, 5000), (16, 0.5, 20000), (8, 0.0, 50000), (40, 0.9, 3000)])
 def test_fourpop_sums(mode, n_dip, min_data, miss):
