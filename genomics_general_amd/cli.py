@@ -832,6 +832,53 @@ def _fmt_cell(v):
     return str(v)
 
 
+NP_MAX_SITES = 4096      # csrc/pg_internal.h PG_NP_MAX_SITES: windows of up to this many sites get their sums in NumPy's order anyway
+
+
+def _near_rounding_tie(v, digits, ratio=False):
+    """which values could print differently with other last bits of a float64 sum: within reach of a rounding tie of the printed
+    digit, of zero (its sign), or -- ratios of sums -- so large / infinite that a denominator is rounding noise.  The fixed-tree sums
+    of a long window differ from NumPy's by at most ~ n eps (1e-11 relative for 10^5 terms)."""
+    v = np.asarray(v, dtype=np.float64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        s = np.abs(v) * 10.0 ** digits
+        d = np.abs(s - np.floor(s) - 0.5)
+        near = np.isfinite(v) & ((d < np.maximum(1e-6, s * 1e-10)) | (np.abs(v) < 1e-12))
+        if ratio:
+            near |= np.isinf(v) | (np.isfinite(v) & (np.abs(v) > 100.0))
+    return near
+
+
+def _refine_long_windows(run, good, sites_local, sd, digits, again, ratio_keys=(), also=None):
+    """The statistics `sd` of this rank's windows `good` were formed with fixed reduction trees where a window has more than 4096
+    sites.  Where one of them is within reach of a rounding tie (so that the reference's summation order could print another
+    digit), that window is computed again in NumPy's order (`again(batch)`): the text is the reference's for every window length
+    without paying for that order everywhere."""
+    idx = np.flatnonzero(good)
+    long_w = sites_local[idx] > NP_MAX_SITES
+    if not np.any(long_w):
+        return
+    near = np.zeros(len(idx), dtype=bool) if also is None else np.asarray(also, dtype=bool).copy()
+    for key, v in sd.items():
+        if np.asarray(v).dtype.kind == "f":
+            near |= _near_rounding_tie(v, digits, ratio=key in ratio_keys)
+    flagged = long_w & near
+    if not np.any(flagged):
+        return
+    mask = np.zeros(len(good), dtype=bool)
+    mask[idx[flagged]] = True
+    run.engine.set_sum_order(1)
+    try:
+        sd2 = again(run.batch(mask))
+    finally:
+        run.engine.set_sum_order(0)
+    for key in sd:
+        a = np.array(sd[key], copy=True)
+        a[flagged] = sd2[key]
+        sd[key] = a
+    run.timing["windows_recomputed_in_numpy_order"] = run.timing.get("windows_recomputed_in_numpy_order", 0) + int(flagged.sum())
+
+
 # ==========================================================================================================
 # popgenWindows.py
 # ==========================================================================================================
@@ -933,7 +980,11 @@ def popgen_main(argv=None):
             if "popFreq" in args.analysis:
                 sd.update(wb.groupFreqStats())
             if "popDist" in args.analysis or "popPairDist" in args.analysis:
-                sd.update(wb.groupDistStats(doPairs="popPairDist" in args.analysis, minSites=minSites, minData=args.minData))
+                def dist_stats(b):
+                    return b.groupDistStats(doPairs="popPairDist" in args.analysis, minSites=minSites, minData=args.minData)
+                gd = dist_stats(wb)
+                _refine_long_windows(run, good, sites_local, gd, args.roundTo, dist_stats)
+                sd.update(gd)
             if "indPairDist" in args.analysis:
                 pdd = wb.indPairDists()
                 for i, j in itertools.combinations_with_replacement(sorted(pdd.keys()), 2):
@@ -1047,11 +1098,18 @@ def _quartet_main(argv, prog, stats, fourpop):
         good = sites_local >= minSites
         table = np.full((run.w1 - run.w0, 1 + len(stats)), np.nan)           # sitesUsed + the statistics
         if np.any(good):
-            if fourpop:
-                sd = run.batch(good).fourPop(popNames[0], popNames[1], popNames[2], popNames[3], minData,
-                                             polarize=args.polarize, fixed=args.fixed)
-            else:
-                sd = run.batch(good).ABBABABA(popNames[0], popNames[1], popNames[2], popNames[3], minData)
+            def quartet_stats(b):
+                if fourpop:
+                    return b.fourPop(popNames[0], popNames[1], popNames[2], popNames[3], minData, polarize=args.polarize, fixed=args.fixed)
+                return b.ABBABABA(popNames[0], popNames[1], popNames[2], popNames[3], minData)
+            sd = quartet_stats(run.batch(good))
+            # (ratios of sums: a nan beside used sites is a 0 / 0 of sums that cancel -- in another order they may not)
+            ratios = [s_ for s_ in stats if s_ not in ("ABBA", "BABA", "ABAA", "BAAA")]
+            with np.errstate(invalid="ignore"):
+                odd = np.zeros(int(good.sum()), dtype=bool)
+                for s_ in ratios:
+                    odd |= np.isnan(sd[s_]) & (np.nan_to_num(np.asarray(sd["sitesUsed"], dtype=np.float64)) > 0)
+            _refine_long_windows(run, good, sites_local, sd, 4, quartet_stats, ratio_keys=ratios, also=odd)
             table[good, 0] = sd["sitesUsed"]
             for c, s in enumerate(stats):
                 table[good, 1 + c] = sd[s]

@@ -1027,6 +1027,20 @@ extern "C" int pg_set_reference_order(pg_ctx *c, const int32_t *pop_row_order, c
     return PG_OK;
 }
 
+extern "C" int pg_set_sum_order(pg_ctx *c, int mode) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (mode < 0 || mode > 2) return pg_fail(PG_ERR_ARG, "pg_set_sum_order: mode %d (0 = by window length, 1 = NumPy's order, 2 = fixed trees)", mode);
+    c->sum_order = mode;
+    return PG_OK;
+}
+
+// windows of up to this many sites take NumPy's summation order (env: an A/B switch of the tests; else the context's mode)
+static long long np_sites_limit(pg_ctx *c, const char *env_name) {
+    const char *force = getenv(env_name);
+    const int mode = force ? (atoi(force) != 0 ? 1 : 2) : c->sum_order;
+    return mode == 1 ? (long long)INT64_MAX : mode == 2 ? -1 : PG_NP_MAX_SITES;
+}
+
 extern "C" int pg_set_sample_rank(pg_ctx *c, const int32_t *rank) {
     if (!c || !rank) return pg_fail(PG_ERR_ARG, "pg_set_sample_rank: null argument");
     if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
@@ -1158,8 +1172,7 @@ extern "C" int pg_popdist_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi,
     // tree; 20 times less work: every quotient is formed once instead of 2 .. 6 times), equal within 1e-15 -- a printed difference
     // would need a mean within 1e-16 of a tie.  The choice is made window by window (a window's numbers do not depend on what it is
     // batched with).  PG_POPDIST_TREE=1 / 0 forces one or the other.
-    const char *force = getenv("PG_POPDIST_TREE");
-    const long long np_upto = c->np_state != 1 ? -1 : force ? (atoi(force) != 0 ? (long long)INT64_MAX : -1) : PG_NP_MAX_SITES;
+    const long long np_upto = c->np_state != 1 ? -1 : np_sites_limit(c, "PG_POPDIST_TREE");
     const int P = c->n_pops, npairs = P * (P + 1) / 2, ncols = P + (do_pairs ? P * (P - 1) : 0);
     if ((rc = c->res_f64.ensure((size_t)n_win * P * P)) != PG_OK) return rc;           // k_popdist_np: P^2 sums a window
     if ((rc = c->res_i64.ensure((size_t)n_win * P * P)) != PG_OK) return rc;
@@ -1365,8 +1378,7 @@ static int quartet_stats(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_
         // k_abba_q raises a flag bit per used site, k_quartet_np adds the sites' terms up again
         uint32_t *flags = nullptr;
         int64_t base = 0;
-        const char *force = getenv("PG_QUARTET_TREE");
-        const long long np_upto = force ? (atoi(force) != 0 ? (long long)INT64_MAX : -1) : PG_NP_MAX_SITES;       // window by window
+        const long long np_upto = np_sites_limit(c, "PG_QUARTET_TREE");                                          // window by window
         bool any_short = false;
         for (int w = w0; w < w1; ++w) any_short = any_short || hi[w] - lo[w] <= np_upto;
         if (any_short) {

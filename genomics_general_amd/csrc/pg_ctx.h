@@ -144,6 +144,7 @@ struct pg_ctx {
     DevBuf<int32_t> samp_rank;     // k_indpair_fin: which individual of a pair supplies the rows of its haplotype block (pg_set_sample_rank)
     int np_state = 0;              // 0: not built for the current samples; 1: usable; -1: a block has too many runs (old finisher)
     int np_max_leaves = 0, np_max_side = 0;
+    int sum_order = 0;             // pg_set_sum_order: 0 = NumPy's order up to PG_NP_MAX_SITES sites a window, 1 = for every window, 2 = for none
     const int64_t *cur_win_lo = nullptr, *cur_win_hi = nullptr;   // pairwise_batches: the staged windows of the sub-batch being consumed
     // how the matrices of the last batch are laid out (set by pairwise_batches)
     int cN = 0, cshift = 0;

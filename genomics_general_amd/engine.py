@@ -139,6 +139,11 @@ class Engine:
         self.n_sites = 0
         self._pair_first = "slot"
 
+    def set_sum_order(self, mode):
+        """0: the float64 sums of pi / dxy / Fst and of the ABBA-BABA statistics in NumPy's order for windows of up to 4096 sites;
+        1: for every window; 2: for none (pg_set_sum_order)"""
+        check(self._L.pg_set_sum_order(self._h, int(mode)))
+
     def set_pair_first(self, first):
         """which individual of a pair supplies the rows of the haplotype block pg_indpairdist_mean averages: "slot" (the earlier one
         in layout.ind_order) or "name" (the one whose name sorts first)"""

@@ -82,6 +82,11 @@ int pg_set_reference_order(pg_ctx *ctx, const int32_t *pop_row_order, const int3
  * its samples (distMat.py:44-45).  Slot order after pg_set_samples. */
 int pg_set_sample_rank(pg_ctx *ctx, const int32_t *rank);
 
+/* Which windows get their float64 sums in NumPy's order (pg_popdist_stats, pg_abbababa, pg_fourpop): 0 = those of up to 4096 sites
+ * (default: where the last bit shows in the printed digits), 1 = all (a caller that found a value of a long window within reach of
+ * a rounding tie asks again for that window: cli.py), 2 = none (fixed reduction trees, within 1e-15). */
+int pg_set_sum_order(pg_ctx *ctx, int mode);
+
 /* ---- resident site buffer ------------------------------------------------------------------------ */
 int pg_reserve_sites(pg_ctx *ctx, int64_t n_sites);
 /* pg_reserve_sites for a large reservation (>= 4 GiB) with a choice of physical placement: up to max_trials (<= 8) allocations are

@@ -79,6 +79,35 @@ def test_drivers_match_the_oracle_on_a_random_mid_size_input(tool, mode, geno, w
     assert n_inexact <= max(2, len(w.split()) // 50), "%d cells differ in the last digit" % n_inexact
 
 
+@pytest.mark.parametrize("tool", ["popgenWindows.py", "ABBABABAwindows.py"])
+def test_long_windows_print_the_reference_digits(tool, geno, tmp_path, monkeypatch, capfd):
+    """windows of 7500 / 10 000 sites: their float64 sums are formed with fixed reduction trees, and a window whose value is within
+    reach of a rounding tie of the printed digit is computed again in NumPy's order (cli._refine_long_windows).  With --roundTo 12 every
+    value is within reach (the trees agree to ~1e-13 only), so every window takes that second pass and the text must be the oracle's,
+    cell for cell; ABBABABAwindows.py (4 digits) recomputes next to nothing and must be the oracle's as well"""
+    per = N_DIP // N_POPS
+    if tool == "popgenWindows.py":
+        argv = ["-g", geno, "-f", "phased", "-w", "7500", "-m", "40", "--roundTo", "12", "--analysis", "popDist", "popPairDist"]
+        for k in range(N_POPS):
+            argv += ["-p", "p%d" % k, ",".join(NAMES[k * per:(k + 1) * per])]
+    else:
+        argv = ["-g", geno, "-f", "phased", "-w", "10000", "-m", "100", "--minData", "0.5",
+                "-P1", "a", ",".join(NAMES[0:8]), "-P2", "b", ",".join(NAMES[8:16]), "-P3", "c", ",".join(NAMES[16:24]),
+                "-O", "o", ",".join(NAMES[24:32])]
+    want = oracle_cli.run(tool, argv)
+    monkeypatch.setenv("PG_TIMING", "1")
+    out = str(tmp_path / "out.csv")
+    G.MAINS[tool](argv + ["-o", out])
+    with open(out) as f:
+        got = f.read()
+    assert len(want.splitlines()) >= 10
+    assert got == want
+    timing = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("PG_TIMING ")]
+    if tool == "popgenWindows.py":
+        import json
+        assert json.loads(timing[-1][len("PG_TIMING "):]).get("windows_recomputed_in_numpy_order", 0) >= 10
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher: two ranks (both on device 0 here, so the exchange goes through files: RCCL
     refuses duplicate devices), rank 0's JSON line on stdout, the result all-gather inside the reported time"""

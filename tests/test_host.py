@@ -536,3 +536,15 @@ def test_text_seek_pos_and_skip_rows_walk_data_lines_only():
     assert skip(text, 2) == (text.index(b"chr1\t9\tC/C"), 2)
     assert skip(text, 6) == (len(text), 6) and skip(text, 99) == (len(text), 6)
     assert 1 <= _lib.usable_cpus() <= (os.cpu_count() or 1)
+
+
+def test_values_within_reach_of_a_rounding_tie_are_recognised():
+    """cli._near_rounding_tie: which statistics of a long window (fixed-tree sums) are computed again in NumPy's order"""
+    import numpy as np
+    from genomics_general_amd import cli
+    v = np.array([0.12345, 0.1234, 0.0, -1e-17, 0.5, 0.30000000000000004, np.nan, 0.99995, 0.123449999])
+    assert cli._near_rounding_tie(v, 4).tolist() == [True, False, True, True, False, False, False, True, False]
+    assert cli._near_rounding_tie(np.array([0.125]), 2).tolist() == [True] and cli._near_rounding_tie(np.array([0.125]), 3).tolist() == [False]
+    r = np.array([1e15, np.inf, -np.inf, 3.0, np.nan])
+    assert cli._near_rounding_tie(r, 4, ratio=True).tolist() == [True, True, True, False, False]
+    assert cli._near_rounding_tie(np.array([0.3141592653589]), 12).tolist() == [True]          # 12 digits: beyond what the trees agree on
