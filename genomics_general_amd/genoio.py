@@ -15,10 +15,47 @@ from ._lib import check
 from .engine import encode_text
 
 
+class _Stdin:
+    """sys.stdin.buffer with a push-back: --inferPloidy looks at the first data row of a piped input before the run reads it"""
+
+    def __init__(self):
+        self.head = b""
+
+    def unread(self, data):
+        self.head = data + self.head
+
+    def read(self, n=-1):
+        if not self.head:
+            return sys.stdin.buffer.read(n)
+        if n is None or n < 0:
+            out, self.head = self.head + sys.stdin.buffer.read(), b""
+            return out
+        out, self.head = self.head[:n], self.head[n:]
+        if len(out) < n:
+            out += sys.stdin.buffer.read(n - len(out))
+        return out
+
+    def readline(self):
+        if not self.head:
+            return sys.stdin.buffer.readline()
+        nl = self.head.find(b"\n")
+        if nl < 0:
+            out, self.head = self.head + sys.stdin.buffer.readline(), b""
+            return out
+        out, self.head = self.head[:nl + 1], self.head[nl + 1:]
+        return out
+
+    def tell(self):
+        raise OSError("stdin is not seekable")
+
+
+STDIN = _Stdin()
+
+
 def read_all(path):
     """Whole input as bytes (gunzipped when the name ends in .gz; stdin when path is None)."""
     if path is None:
-        return sys.stdin.buffer.read()
+        return STDIN.read()
     if str(path).endswith(".gz"):
         with gzip.open(path, "rb") as f:
             return f.read()
@@ -218,7 +255,7 @@ class BlockReader:
         self.stop = None                  # byte offset at which this reader ends (restrict()); None = end of file
         self.mm = None                    # plain files are memory-mapped: blocks are views of the page cache, not copies
         if path is None:
-            self.f = sys.stdin.buffer
+            self.f = STDIN
         elif str(path).endswith(".gz"):
             self.f = BgzfFile(path) if BgzfFile.is_bgzf(path) else gzip.open(path, "rb")
         else:
@@ -482,7 +519,7 @@ class BlockReader:
                 self.mm.close()
             except BufferError:            # a block is still referenced somewhere: the mapping goes with its last view
                 pass
-        if self.f is not sys.stdin.buffer:
+        if self.f is not STDIN:
             self.f.close()
 
 
@@ -991,9 +1028,27 @@ def read_header_names(path):
 
 
 def first_row_ploidy(path, fmt, header_line=None):
-    """{sample name: ploidy its cell in the first data row implies} (for --inferPloidy); needs a file, not a pipe"""
+    """{sample name: ploidy its cell in the first data row implies} (for --inferPloidy); of a piped input the lines up to the first
+    data row are read and pushed back"""
+    def from_widths(names, line):
+        w = [len(c) for c in line.split()[2:]]
+        # splitSeq (genomics.py:390-396): phased cells hold their alleles at every other character, pairs one per character
+        return {nm: ((x + 1) // 2 if fmt == "phased" else x if fmt == "pairs" else 1 if fmt == "haplo" else 2) for nm, x in zip(names, w)}
     if path is None:
-        raise SystemExit("--inferPloidy needs -g FILE: the first data row is read ahead of the run")
+        seen, names = b"", (header_line.split()[2:] if header_line else None)
+        try:
+            while True:
+                raw = STDIN.readline()
+                seen += raw
+                if not raw:
+                    return {nm: (1 if fmt == "haplo" else 2) for nm in (names or [])}
+                line = raw.decode("utf-8", "replace")
+                if names is None:
+                    names = line.split()[2:]
+                elif line.strip() and not line.startswith("#"):
+                    return from_widths(names, line)
+        finally:
+            STDIN.unread(seen)
     if str(path).endswith(".pgeno"):
         rd = PackedReader(path)
         rd.close()
@@ -1003,10 +1058,7 @@ def first_row_ploidy(path, fmt, header_line=None):
         names = header_line.split()[2:] if header_line else f.readline().split()[2:]
         for line in f:
             if line.strip() and not line.startswith("#"):
-                w = [len(c) for c in line.split()[2:]]
-                # splitSeq (genomics.py:390-396): phased cells hold their alleles at every other character, pairs one per character
-                return {nm: ((x + 1) // 2 if fmt == "phased" else x if fmt == "pairs" else 1 if fmt == "haplo" else 2)
-                        for nm, x in zip(names, w)}
+                return from_widths(names, line)
     return {nm: (1 if fmt == "haplo" else 2) for nm in names}
 
 

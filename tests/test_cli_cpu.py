@@ -124,3 +124,23 @@ def test_infer_ploidy_refuses_a_file_whose_cell_widths_change(host_tokenizer, tm
         run_case(case, tmp_path, monkeypatch, geno=odd)
     assert "--inferPloidy" in str(err.value) and "--ploidyFile" in str(err.value)
     run_case(case, tmp_path, monkeypatch)                            # the regular file: the golden of the reference
+
+
+def test_infer_ploidy_of_a_piped_input(tmp_path):
+    """--inferPloidy with the genotypes on stdin: the first data row is looked at and pushed back (genoio.STDIN) -- the golden of the
+    same command line with -g FILE"""
+    import gzip
+    import subprocess
+    import sys
+    import test_dist
+    case = [c for c in CASES if c["name"] == "mixed_inferploidy"][0]
+    out = str(tmp_path / "piped.out")
+    argv = [a.format(geno="", dir=GOLD, out=out) for a in case["argv"]]
+    k = argv.index("-g")
+    argv = argv[:k] + argv[k + 2:] + ["-o", out]
+    text = gzip.open(os.path.join(GOLD, case["fixture"] + ".geno.gz"), "rb").read()
+    r = subprocess.run([sys.executable, "-c", test_dist.CLI_WORKER, case["tool"]] + argv, input=text, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    with open(out) as f, open(os.path.join(GOLD, case["name"] + ".out")) as g:
+        got, want = f.read(), g.read()
+    assert align_columns(got, want) == want
