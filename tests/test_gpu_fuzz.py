@@ -108,3 +108,34 @@ def test_random_command_lines_on_several_ranks_of_the_hip_engine(seed, tmp_path,
                 assert f.read() == want_side, what
         compared += 1
     assert compared >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PG_FUZZ_LONG_SEEDS", "3"))))
+def test_random_command_lines_with_windows_of_more_than_4096_sites(seed, tmp_path, monkeypatch):
+    """the generator with scaffolds of 6000 - 14 000 sites and windows of 4200 - 9000 sites: the float64 sums of such windows are
+    formed with fixed reduction trees and a window is computed again in NumPy's order only where a value is within reach of a
+    rounding tie (cli._refine_long_windows) -- the text must still be the stand-in's (the oracle's, NumPy's own sums), cell for cell"""
+    monkeypatch.setitem(F.LONG, "on", True)
+    rng = np.random.default_rng(99000 + seed)
+    compared = 0
+    for case in range(5):
+        tool, argv, digits, inp = F.make_case(str(tmp_path), case, rng, ["popgenWindows.py", "popgenWindows.py", "ABBABABAwindows.py",
+                                                                          "fourPopWindows.py", "distMat.py"])
+        argv = [a[1:] if a.startswith("<") else a for a in argv]
+        what = "%s %s" % (tool, " ".join(argv))
+        err_hip, got, got_side = _run(tool, argv, str(tmp_path / ("hip%d.out" % case)))
+        with monkeypatch.context() as m:
+            m.setattr(cli, "Engine", CpuEngine)
+            err_cpu, want, want_side = _run(tool, argv, str(tmp_path / ("cpu%d.out" % case)))
+        if err_cpu is not None or err_hip is not None:
+            assert err_hip is not None or "ZeroDivisionError" in err_cpu, "%s\n  HIP engine ran, the stand-in stopped: %s" % (what, err_cpu)
+            assert err_cpu is not None, "%s\n  the stand-in ran, the HIP engine stopped: %s" % (what, err_hip)
+            continue
+        try:
+            G.compare_text(align_columns(got, want), want, digits)
+        except AssertionError as e:
+            raise AssertionError("%s\n  %s" % (what, e))
+        assert got_side == want_side, what
+        compared += 1
+    assert compared >= 2

@@ -37,12 +37,19 @@ def pick(rng, seq):
     return seq[int(rng.integers(0, len(seq)))]
 
 
+LONG = {"on": False}      # long_windows(): scaffolds of 6000 - 14 000 sites and windows of more than 4096 sites (fixed-tree sums + refinement)
+
+
 def make_input(tmp, case, rng, tool):
     """-> dict(geno, fmt, names (columns), n_dip, scafs, lens, ploidy_argv)"""
     n_scaf = int(pick(rng, [1, 1, 2, 3, 4]))
     n_dip = int(pick(rng, [4, 5, 6, 8, 12]))
     lens = [int(rng.integers(300, 3000)) for _ in range(n_scaf)]
     density = float(pick(rng, [1.0, 0.6, 0.2, 0.05]))
+    if LONG["on"]:
+        n_scaf = int(pick(rng, [1, 2]))
+        lens = [int(rng.integers(6000, 14000)) for _ in range(n_scaf)]
+        density = float(pick(rng, [1.0, 1.0, 0.7]))
     sid, pos = [], []
     for k, ln in enumerate(lens):
         p = np.arange(1, ln + 1)
@@ -118,14 +125,14 @@ def window_argv(tmp, case, rng, tool, inp):
     kind = pick(rng, kinds)
     argv = []
     if kind == "coordinate":
-        w = int(rng.integers(30, 1200))
+        w = int(rng.integers(30, 1200)) if not LONG["on"] else int(rng.integers(4300, 9000))
         argv += ["-w", str(w)]
         if rng.random() < 0.5:
             argv += ["-s", str(int(rng.integers(10, 2 * w)))]
         if rng.random() < 0.2:
             argv = ["--windType", "coordinate"] + argv
     elif kind == "sites":
-        w = int(rng.integers(10, 300))
+        w = int(rng.integers(10, 300)) if not LONG["on"] else int(rng.integers(4200, 5500))
         argv += ["--windType", "sites", "-w", str(w)]
         if rng.random() < 0.5:
             argv += [overlap_flag, str(int(rng.integers(1, w)))]
@@ -138,7 +145,7 @@ def window_argv(tmp, case, rng, tool, inp):
         for k in range(int(rng.integers(1, 12))):
             s = int(rng.integers(0, len(inp["scafs"])))
             a = int(rng.integers(1, inp["lens"][s] + 200))
-            b = a + int(rng.integers(0, 900))
+            b = a + (int(rng.integers(0, 900)) if not LONG["on"] else int(rng.integers(4200, 9000)))
             name = inp["scafs"][s] if rng.random() > 0.1 else "absent"
             rows.append((name, a, b, "w%d" % k))
         if rng.random() < 0.5:
