@@ -87,9 +87,13 @@ def make_input(tmp, case, rng, tool):
         with op(geno, "rt") as f:
             lines = f.read().splitlines()
         # (freq.py reads a comment line as a site: scaffold `#`, garbage counts; the drop-in skips it like the window drivers)
-        how = pick(rng, ["blanks", "comments", "noheader"] if tool != "freq.py" else ["blanks"])
+        how = pick(rng, ["blanks", "comments", "noheader", "crlf", "trailing"] if tool != "freq.py" else ["blanks", "crlf", "trailing"])
         if how == "blanks":
             lines = [ln.replace("\t", " ") for ln in lines]
+        elif how == "crlf":
+            lines = [ln + "\r" for ln in lines]
+        elif how == "trailing":
+            lines = [ln + pick(rng, [" ", "\t", "  "]) for ln in lines]
         elif how == "comments":
             for _ in range(int(rng.integers(1, 4))):
                 lines.insert(int(rng.integers(1, len(lines) + 1)), "# a comment line")
