@@ -152,6 +152,25 @@ def test_group_dist_stats_to_the_last_bit_in_numpy_order(sizes, names, haploid, 
     e.close()
 
 
+def test_sum_order_can_be_set_through_the_api():
+    """pg_set_sum_order: 1 = NumPy's order for every window (a window of 6000 sites == the oracle), 2 = for none (a window of 500
+    sites within 1e-9), 0 = by window length again"""
+    e, lay, codes, _ = G.make_engine(10, 2, 6500, seed=73, var_thr=40000, miss_thr=9000)
+
+    def stats(a, b):
+        aln = oracle_aln(lay, codes, a, b)
+        Do, Co = orc.pair_counts_gemm(aln)
+        return orc.group_dist_stats(aln, Do, Co, True, 5, 0.01)[0]
+    long_w, short_w = stats(0, 6000), stats(6000, 6500)
+    for mode, same_long, same_short in ((1, True, True), (2, False, False), (0, False, True)):
+        e.set_sum_order(mode)
+        st = e.batch([0, 6000], [6000, 6500]).groupDistStats(True, 5, 0.01)
+        for key in long_w:
+            assert (G.same if same_long else G.close)(st[key][0], long_w[key]), (mode, key, st[key][0], long_w[key])
+            assert (G.same if same_short else G.close)(st[key][1], short_w[key]), (mode, key, st[key][1], short_w[key])
+    e.close()
+
+
 def test_populations_too_large_for_the_numpy_order_tree_keep_the_fixed_tree():
     """two populations of 500 haplotypes: the (x+y, x+y) block has 10^6 values, more runs than a thread block's LDS holds
     (pg_abi.cpp np_prepare): every window takes the upper-triangle finisher -- within 1e-9 of the oracle"""
