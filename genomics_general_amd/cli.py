@@ -835,7 +835,7 @@ def _fmt_cell(v):
 NP_MAX_SITES = 4096      # csrc/pg_internal.h PG_NP_MAX_SITES: windows of up to this many sites get their sums in NumPy's order anyway
 
 
-def _near_rounding_tie(v, digits, ratio=False):
+def _near_rounding_tie(v, digits, ratio=False, difference=False):
     """which values could print differently with other last bits of a float64 sum: within reach of a rounding tie of the printed
     digit, of zero (its sign), or -- ratios of sums -- so large / infinite that a denominator is rounding noise.  The fixed-tree sums
     of a long window differ from NumPy's by at most ~ n eps (1e-11 relative for 10^5 terms)."""
@@ -844,6 +844,8 @@ def _near_rounding_tie(v, digits, ratio=False):
         s = np.abs(v) * 10.0 ** digits
         d = np.abs(s - np.floor(s) - 0.5)
         near = np.isfinite(v) & ((d < np.maximum(1e-6, s * 1e-10)) | (np.abs(v) < 1e-12))
+        if difference:               # 1 - pi_s / pi_t: the error of the quotient is absolute (1e-11 bounds it), whatever is left of it
+            near |= np.isfinite(v) & (d < 10.0 ** digits * 1e-11)
         if ratio:
             near |= np.isinf(v) | (np.isfinite(v) & (np.abs(v) > 100.0))
     return near
@@ -861,7 +863,7 @@ def _refine_long_windows(run, good, sites_local, sd, digits, again, ratio_keys=(
     near = np.zeros(len(idx), dtype=bool) if also is None else np.asarray(also, dtype=bool).copy()
     for key, v in sd.items():
         if np.asarray(v).dtype.kind == "f":
-            near |= _near_rounding_tie(v, digits, ratio=key in ratio_keys)
+            near |= _near_rounding_tie(v, digits, ratio=key in ratio_keys, difference=key.startswith("Fst_"))
     flagged = long_w & near
     if not np.any(flagged):
         return

@@ -548,3 +548,7 @@ def test_values_within_reach_of_a_rounding_tie_are_recognised():
     r = np.array([1e15, np.inf, -np.inf, 3.0, np.nan])
     assert cli._near_rounding_tie(r, 4, ratio=True).tolist() == [True, True, True, False, False]
     assert cli._near_rounding_tie(np.array([0.3141592653589]), 12).tolist() == [True]          # 12 digits: beyond what the trees agree on
+    # Fst = 1 - pi_s / pi_t: an absolute error bound (1e-11) on a value that may be small
+    f = np.array([0.000123454996])
+    assert cli._near_rounding_tie(f, 8).tolist() == [False] and cli._near_rounding_tie(f, 8, difference=True).tolist() == [True]
+    assert cli._near_rounding_tie(np.array([0.0123]), 4, difference=True).tolist() == [False]
