@@ -48,6 +48,7 @@ SIGNATURES = {
     "pg_set_reference_order": (C.c_int, [_P, _i32p, _i32p]),
     "pg_set_sample_rank": (C.c_int, [_P, _i32p]),
     "pg_set_sum_order": (C.c_int, [_P, C.c_int]),
+    "pg_np_tree": (C.c_int, [C.c_int, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
     "pg_reserve_sites": (C.c_int, [_P, C.c_int64]),
     "pg_reserve_sites_tuned": (C.c_int, [_P, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pg_upload_sites": (C.c_int, [_P, C.c_int64, _i8p, C.c_int64]),

@@ -1107,6 +1107,15 @@ std::vector<int32_t> np_tree(int n) {
 }
 }  // namespace
 
+// the tree as k_popdist_np walks it, for callers without a GPU (tests/test_host.py adds values up along it and compares with NumPy)
+extern "C" int pg_np_tree(int n, int32_t *out, int64_t cap, int64_t *len) {
+    if (n < 0 || !len) return pg_fail(PG_ERR_ARG, "pg_np_tree: bad argument");
+    const std::vector<int32_t> b = np_tree(n);
+    *len = (int64_t)b.size();
+    if (out && cap >= (int64_t)b.size()) memcpy(out, b.data(), b.size() * sizeof(int32_t));
+    return PG_OK;
+}
+
 #define PG_NP_MAX_LEAVES 1024      // LDS of a block: 2 * 1024 + 32 * 128 doubles + the tree's tables (3 * 1024 ints) + row maps < 64 KB
 
 // the trees of this context's blocks: (x, x), and (x, y) / (x + y, x + y) for every pair: their lengths do not depend on the orientation

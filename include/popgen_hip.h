@@ -87,6 +87,12 @@ int pg_set_sample_rank(pg_ctx *ctx, const int32_t *rank);
  * a rounding tie asks again for that window: cli.py), 2 = none (fixed reduction trees, within 1e-15). */
 int pg_set_sum_order(pg_ctx *ctx, int mode);
 
+/* The pairwise-summation tree of n values as the NumPy-order kernels walk it (no device needed): out[0 .. *len) =
+ * { L, n_inner, n_levels, run_offset[L + 1], node_left[n_inner], node_right[n_inner], level_start[n_levels + 1] }; runs of at most
+ * 128 values (slots 0 .. L - 1), inner node k (slot L + k) = slot node_left[k] + slot node_right[k], the inner nodes ordered by
+ * height, the root last.  *len is set even when cap is too small. */
+int pg_np_tree(int n, int32_t *out, int64_t cap, int64_t *len);
+
 /* ---- resident site buffer ------------------------------------------------------------------------ */
 int pg_reserve_sites(pg_ctx *ctx, int64_t n_sites);
 /* pg_reserve_sites for a large reservation (>= 4 GiB) with a choice of physical placement: up to max_trials (<= 8) allocations are

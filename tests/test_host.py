@@ -552,3 +552,46 @@ def test_values_within_reach_of_a_rounding_tie_are_recognised():
     f = np.array([0.000123454996])
     assert cli._near_rounding_tie(f, 8).tolist() == [False] and cli._near_rounding_tie(f, 8, difference=True).tolist() == [True]
     assert cli._near_rounding_tie(np.array([0.0123]), 4, difference=True).tolist() == [False]
+
+
+def test_the_pairwise_summation_tree_adds_up_like_numpy():
+    """pg_np_tree (pg_abi.cpp np_tree: what k_popdist_np walks): values added up along it -- a run as eight interleaved partial sums
+    ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus its tail, the inner nodes in table order -- equal np.sum() to the last bit for lengths
+    around every boundary of NumPy's algorithm (8, 128, the halving rule, the 8192-value pieces of the ufunc buffer)"""
+    import ctypes as C
+    import numpy as np
+    from genomics_general_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+
+    def run_sum(a):
+        n = len(a)
+        if n < 8:
+            res = 0.0
+            for x in a:
+                res = res + x
+            return res
+        r = [a[j] for j in range(8)]
+        m8 = n - n % 8
+        for i in range(8, m8, 8):
+            for j in range(8):
+                r[j] = r[j] + a[i + j]
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for i in range(m8, n):
+            res = res + a[i]
+        return res
+
+    for n in (1, 2, 7, 8, 9, 15, 16, 127, 128, 129, 255, 256, 257, 1000, 4097, 8191, 8192, 8193, 8200, 10000, 16384, 16385, 21316, 40000, 131072):
+        blob = np.zeros(4 * n // 64 + 64, dtype=np.int32)
+        ln = C.c_int64(0)
+        _lib.check(L.pg_np_tree(n, blob, len(blob), C.byref(ln)))
+        assert ln.value <= len(blob)
+        nl, ni, nlev = int(blob[0]), int(blob[1]), int(blob[2])
+        off = blob[3:3 + nl + 1]
+        left, right = blob[4 + nl:4 + nl + ni], blob[4 + nl + ni:4 + nl + 2 * ni]
+        assert off[0] == 0 and off[nl] == n and np.all(np.diff(off) <= 128) and np.all(np.diff(off) >= 1)
+        a = (rng.random(n) * 0.1).tolist()
+        slots = [run_sum(a[off[k]:off[k + 1]]) for k in range(nl)] + [None] * ni
+        for k in range(ni):
+            slots[nl + k] = slots[left[k]] + slots[right[k]]
+        assert 0.0 + slots[-1] == float(np.sum(np.array(a))), n
