@@ -611,7 +611,7 @@ void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts,
 // leaf runs, and the inner nodes level by level.  One block of 256 threads per (task, window): 32 runs at a time are staged in LDS
 // as quotients (coalesced over the flattened index), eight lanes add up a run, the levels of the tree follow.
 // ------------------------------------------------------------------------------------------------------
-#define PG_NP_STAGE_LEAVES 32
+#define PG_NP_STAGE_LEAVES 8
 
 // The pair kernels store the upper triangles of C and D.  k_popdist_np walks whole rows of symmetric blocks: reading the lower half
 // through the upper one (element (j, i) for i > j) turns every wave's load into 64 cache lines.  k_mirror_lower copies the upper
@@ -691,34 +691,35 @@ __global__ __launch_bounds__(256) void k_popdist_np(const int32_t *__restrict__ 
             int k = k0 + tid;
             int r = nc > 0 ? k / nc : 0, cc = nc > 0 ? k - r * nc : 0;
             const int qi = 256 / (nc > 0 ? nc : 1), qj = 256 - qi * (nc > 0 ? nc : 1);
-            for (; k < k1; k += 1024) {
-                int cv[4], dv[4];
+            // every load of the round first (at most PG_NP_STAGE_LEAVES * 128 / 256 = 16 values a thread): the maps and the staged
+            // quotients share LDS, so a store between two trips kept the next trip's loads from being issued early
+            constexpr int U = PG_NP_STAGE_LEAVES * 128 / 256;
+            int cv[U], dv[U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    cv[u] = 0;
-                    dv[u] = 0;
-                    if (k + 256 * u < k1) {
-                        const int i = rowmap[r], j = colmap[cc];
-                        if (i != j) {                                    // (both triangles hold the counts: k_mirror_lower)
-                            cv[u] = Cw[(size_t)(i >> cshift) * cN + (j >> cshift)];
-                            dv[u] = Dw[(size_t)i * N + j];
-                        }
+            for (int u = 0; u < U; ++u) {
+                cv[u] = 0;
+                dv[u] = 0;
+                if (k + 256 * u < k1) {
+                    const int i = rowmap[r], j = colmap[cc];
+                    if (i != j) {                                    // (both triangles hold the counts: k_mirror_lower)
+                        cv[u] = Cw[(i >> cshift) * cN + (j >> cshift)];
+                        dv[u] = Dw[i * N + j];
                     }
-                    r += qi;
-                    cc += qj;
-                    if (cc >= nc) { cc -= nc; ++r; }
                 }
+                r += qi;
+                cc += qj;
+                if (cc >= nc) { cc -= nc; ++r; }
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (k + 256 * u < k1) {
-                        double v = 0.0;
-                        if (cv[u] >= thr) {
-                            const double cd = (double)cv[u];
-                            v = quot_counts((double)dv[u], cd, rcp_counts(cd));
-                            ++valid;
-                        }
-                        q[k + 256 * u - k0] = v;
+            for (int u = 0; u < U; ++u) {
+                if (k + 256 * u < k1) {
+                    double v = 0.0;
+                    if (cv[u] >= thr) {
+                        const double cd = (double)cv[u];
+                        v = quot_counts((double)dv[u], cd, rcp_counts(cd));
+                        ++valid;
                     }
+                    q[k + 256 * u - k0] = v;
                 }
             }
         }
