@@ -608,7 +608,7 @@ void pg_launch_popstats(hipStream_t st, const double *sums, const int64_t *cnts,
 // tie tolerance was for.  Three kinds of blocks per window: (x, x) for pi, (x, y) for dxy and (x+y, x+y) for the pi_t of Fst --
 // rows and columns in the reference's row order (haplotype names sorted, `ref_row`), the pair oriented by the sorted population
 // names (np.unique, genomics.py:965: `pop_rank`).  The tree of a block length n is laid out by the host (pg_abi.cpp np_tree):
-// leaf runs, and the inner nodes level by level.  One block of 256 threads per (task, window): 32 runs at a time are staged in LDS
+// leaf runs, and the inner nodes level by level.  One block of 256 threads per (task, window): 8 runs at a time are staged in LDS
 // as quotients (coalesced over the flattened index), eight lanes add up a run, the levels of the tree follow.
 // ------------------------------------------------------------------------------------------------------
 #define PG_NP_STAGE_LEAVES 8
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void k_popdist_np(const int32_t *__restrict__ 
             int k = k0 + tid;
             int r = nc > 0 ? k / nc : 0, cc = nc > 0 ? k - r * nc : 0;
             const int qi = 256 / (nc > 0 ? nc : 1), qj = 256 - qi * (nc > 0 ? nc : 1);
-            // every load of the round first (at most PG_NP_STAGE_LEAVES * 128 / 256 = 16 values a thread): the maps and the staged
+            // every load of the round first (PG_NP_STAGE_LEAVES * 128 / 256 = 4 values a thread): the maps and the staged
             // quotients share LDS, so a store between two trips kept the next trip's loads from being issued early
             constexpr int U = PG_NP_STAGE_LEAVES * 128 / 256;
             int cv[U], dv[U];
