@@ -1116,7 +1116,7 @@ extern "C" int pg_np_tree(int n, int32_t *out, int64_t cap, int64_t *len) {
     return PG_OK;
 }
 
-#define PG_NP_MAX_LEAVES 1024      // LDS of a block: 2 * 1024 + 32 * 128 doubles + the tree's tables (3 * 1024 ints) + row maps < 64 KB
+#define PG_NP_MAX_LEAVES 1024      // LDS of a block: 2 * 1024 + 8 * 128 doubles + the tree's tables (3 * 1024 ints) + row maps: 40 KB
 
 // the trees of this context's blocks: (x, x), and (x, y) / (x + y, x + y) for every pair: their lengths do not depend on the orientation
 static int np_prepare(pg_ctx *c) {
