@@ -87,6 +87,16 @@ SIGNATURES = {
     "pg_format_freq_rows": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_void_p, _i32p, _i32p, C.c_char_p, _i64p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_inflate_chunks": (C.c_int, [C.c_void_p, _i64p, _i64p, _i64p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
+    "pg_bgzf_walk": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pg_inflate_members": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i64p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    "pg_bgzf_compress": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
+    "pg_inflate_device": (C.c_int, [_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.POINTER(C.c_double)]),
+    "pg_tokenize_submit_bgzf": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_char_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p,
+                                          C.POINTER(C.c_int)]),
+    "pg_tokenize_run_names": (C.c_int, [_P, C.c_int, _i64p, _i32p, C.c_int64, C.c_void_p, C.c_int64]),
     "pg_decode_packed": (C.c_int, [_u8p, C.c_int64, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i8p, C.c_int]),
     "pg_pairwise": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i32p, _i32p]),
     "pg_popdist": (C.c_int, [_P, _i64p, _i64p, C.c_int, C.c_int, _f64p, _i64p]),

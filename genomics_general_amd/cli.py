@@ -487,6 +487,7 @@ class Run:
         The host keeps positions and scaffold runs only; no row ever exists in host memory.  The number of rows a block needs is
         bounded from its first line (every line of the regular layout is at least that long), the device counts the lines itself.
         The halves grow at quiet points (when this thread has finished everything handed over so far)."""
+        import os
         import queue
         import threading
         import time
@@ -543,6 +544,8 @@ class Run:
             eng.reserve(2 * st["half"])
             return saved
 
+        if hasattr(eng, "tokenize_submit_bgzf") and hasattr(self._reader, "spans") and os.environ.get("PG_BGZF_DEVICE", "1") != "0":
+            self._reader.spans = True                 # bgzip-compressed text arrives as blocks of deflated members
         # a block of a memory-mapped file is a view, a block of raw `.pgeno` cells a list of file offsets: nothing to read ahead
         mapped = getattr(self._reader, "mm", None) is not None or bool(getattr(self._reader, "packed", False))
         done_reading = []
@@ -578,6 +581,11 @@ class Run:
                 return True
             if not len(body) or not hasattr(eng, "tokenize_submit"):
                 return False
+            if isinstance(body, genoio.BgzfSpan):     # members of a bgzip file, still deflated: inflated on the device
+                ok = eng.tokenize_submit_bgzf(body, slot)
+                self.timing["bgzf_blocks_inflated_on_device"] = self.timing.get("bgzf_blocks_inflated_on_device", 0) + int(ok)
+                self.timing["bgzf_compressed_bytes"] = self.timing.get("bgzf_compressed_bytes", 0) + (len(body.comp) if ok else 0)
+                return ok
             return eng.tokenize_submit(body, slot, file=self._reader.file_range(body) if hasattr(self._reader, "file_range") else None)
 
         def parse(slot, row_offset, cap):
@@ -623,6 +631,8 @@ class Run:
                     else:
                         bound = row_bound(body) if len(body) else 0
                     if bound is None:
+                        if isinstance(body, genoio.BgzfSpan):
+                            body = bytes(body)
                         bound, sub = count(body), False       # (not a regular first line: the host tokenizer will take the block)
                     saved = None
                     if c_n + bound > st["half"]:

@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/popgen_hip.h"
 #include "pg_internal.h"
+#include "pg_inflate.h"
 
 #include <utility>
 #include <vector>
@@ -105,9 +106,25 @@ struct pg_ctx {
     hipEvent_t up_ev = nullptr;
     bool up_pending = false;
     DevBuf<uint8_t> cells_stage;     // packed cells of the upload in flight
+    // BGZF members inflated on the device (pg_inflate.hip): compressed bytes, member table, status [error bits, first bad member]
+    struct Inflate {
+        DevBuf<uint32_t> comp, crc_tab;
+        DevBuf<uint8_t> text;              // pg_inflate_device only (the tokenizer inflates into its text slots)
+        DevBuf<uint8_t> sink;              // 64 bytes per member: where the lanes of a copy step that have no byte store
+        DevBuf<PgiMember> members;
+        HostPin<PgiMember> h_members;
+        DevBuf<int32_t> status;
+        HostPin<int32_t> h_status;
+    } inf;
     // device-side tokenizer (pg_tokenize_*): two blocks in flight, each with its text, line feeds, per-line outputs
     struct TokSlot {
         DevBuf<uint8_t> text;
+        uint8_t *tp = nullptr;             // the block's first byte: text.p, or a 16-byte aligned place inside it (BGZF: head + inflated members)
+        Inflate inf;                       // the block arrived deflated (pg_tokenize_submit_bgzf)
+        bool deflated = false;
+        HostPin<uint8_t> h_head;
+        DevBuf<uint8_t> names;             // pg_tokenize_run_names: the scaffold names of the block's runs, gathered
+        DevBuf<int64_t> names_idx;
         DevBuf<int32_t> i32, dcols, pos;
         DevBuf<int64_t> i64, nl, off;
         HostPin<int64_t> h_total;          // page-locked landing: [0] lines, [1] status | runs

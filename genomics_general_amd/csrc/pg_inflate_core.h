@@ -1,0 +1,457 @@
+// DEFLATE (RFC 1951) decoder of ONE gzip member by ONE wavefront -- the core of k_inflate (pg_inflate.hip).
+//
+// `-g input.geno.gz` is the reference's normal input (popgenWindows.py:313, genomics.py:1917 gzip.open; the producer is
+// `parseVCF.py ... | bgzip > out.geno.gz`, VCF_processing/README.md:33): bgzip writes BGZF, a gzip file made of independent members of
+// at most 64 KiB of text each.  The members of a block of the input are copied to the device as they are and inflated there, a
+// wavefront per member, straight into the text slot of the device tokenizer (pg_tokenize.hip) -- the text never exists on the host.
+//
+// How a wavefront decodes a serial bit stream:
+//   * control flow is uniform: bit buffer, symbol, length, distance live in SGPRs (values come out of readlane / readfirstlane);
+//   * the compressed bytes sit in two VGPRs (lane i holds dword i of the current / next 256-byte piece): a refill is a v_readlane,
+//     a new piece one coalesced load, issued a whole piece ahead of its first use;
+//   * Huffman codes are decoded canonically WITHOUT tables: lane L holds the left-aligned limit of code length L, the next 15
+//     stream bits are bit-reversed (s_brev) and compared against all limits at once (v_cmp + ballot), the lowest set bit is the code
+//     length, one LDS read of the symbol list sorted by (length, symbol) gives the symbol.  Building that for a dynamic block is a
+//     histogram, a 15-step scan and a ranking by ballots -- no 2^k-entry tables to fill per block;
+//   * length / distance bases and extra-bit counts are lane constants (readlane);
+//   * a match is copied by the whole wavefront (64 bytes per load / store pair); a distance shorter than the wavefront becomes a
+//     pattern fill.  The output window is the output itself (global memory): a wavefront's vector memory operations execute in
+//     order, so a load sees the bytes an earlier store instruction of the same wavefront wrote.
+//
+// The same source is compiled twice: for the device (pg_inflate.hip), and -- with PG_INFLATE_EMULATE -- as a lockstep emulation of
+// the 64 lanes on the host, which tests/inflate_emul.cpp holds against zlib in the CPU suite (the per-lane statements are written
+// one memory operation per LANES block so that the emulation runs them in the order the hardware does).  The emulation is test
+// infrastructure; no product path runs it.
+#pragma once
+#include <stdint.h>
+
+#include "pg_inflate.h"
+
+#ifdef PG_INFLATE_EMULATE
+#define PGI_DEV static inline
+#define PL(type, name) type name[64]
+#define PLREF(type, name) type *name
+#define V(name) name[lane]
+#define LANES for (int lane = 0; lane < 64; ++lane)
+#define READLANE(name, l) (name[(l)])
+#define WRITELANE(name, l, val) (name[(l)] = (val))
+#define BALLOT(mask, expr)                                    \
+    do {                                                      \
+        mask = 0;                                             \
+        for (int lane = 0; lane < 64; ++lane)                 \
+            if (expr) mask |= 1ull << lane;                   \
+    } while (0)
+#define UNI(x) (x)
+#define UNI64(x) (x)
+#define PGI_SYNC
+#define PGI_ATOMIC_INC(p) (++*(p))
+#define PGI_LANE_PARAM
+#define PGI_LANE_ARG
+static inline uint32_t pgi_brev32(uint32_t x) {
+    x = (x >> 16) | (x << 16);
+    x = ((x & 0xFF00FF00u) >> 8) | ((x & 0x00FF00FFu) << 8);
+    x = ((x & 0xF0F0F0F0u) >> 4) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x & 0xCCCCCCCCu) >> 2) | ((x & 0x33333333u) << 2);
+    x = ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
+    return x;
+}
+#define PGI_CTZ64(x) __builtin_ctzll(x)
+#define PGI_POPC64(x) __builtin_popcountll(x)
+#else
+#define PGI_DEV __device__ __forceinline__ static
+#define PL(type, name) type name
+#define PLREF(type, name) type &name
+#define V(name) name
+#define LANES
+#define READLANE(name, l) __builtin_amdgcn_readlane((int)(name), (int)(l))
+// (a select, not a branch: a divergent branch around it would make every value the compiler sinks into its arms look divergent)
+template <class T, class U>
+__device__ __forceinline__ void pgi_setlane(T &name, int lane, int l, U val) {
+    name = lane == l ? (T)val : name;
+}
+#define WRITELANE(name, l, val) pgi_setlane(name, lane, (int)(l), (val))
+#define BALLOT(mask, expr) mask = __ballot(expr)
+#define UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
+#define UNI64(x) (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((x) >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x)))
+#define PGI_SYNC __syncthreads()
+#define PGI_ATOMIC_INC(p) atomicAdd((p), 1u)
+#define PGI_LANE_PARAM , const int lane
+#define PGI_LANE_ARG , lane
+#define pgi_brev32(x) __builtin_bitreverse32(x)
+#define PGI_CTZ64(x) __builtin_ctzll(x)
+#define PGI_POPC64(x) __popcll(x)
+#endif
+
+// LDS of one wavefront
+// Every per-lane statement below is written WITHOUT a branch on the lane (a lane that has nothing to store stores into a dump
+// area behind the array, a lane that has nothing to load loads a valid address and drops the value): the compiler threads jumps
+// through divergent branches, and every uniform value it then merges behind them (bit buffer, bit count, ...) turns "divergent",
+// i.e. moves from the scalar unit into vector registers -- the decode loop then runs at a fraction of its speed.
+struct PgiShared {
+    uint32_t hist[64];            // [0] collects the lanes without a symbol
+    uint16_t sorted_ll[288 + 64]; // literal / length symbols sorted by (code length, symbol) | dump
+    uint16_t sorted_d[32 + 64];   // distance symbols (and, while a dynamic header is read, the 19 symbols of the code-length code) | dump
+    uint8_t lens[320 + 64];       // code lengths: literal / length symbols, then the distance symbols | dump
+};
+
+// The canonical code of `n` symbols with lengths lens[] (0 = unused): lane L of lim holds (first code of length L + their number),
+// left-aligned to 15 bits; lane L of bas the index of the first symbol of length L in sorted[] minus its first code.
+// kind 0: code-length code, 1: literal / length, 2: distance (what zlib's inflate_table accepts: an incomplete set only when it is
+// a single code of one bit -- never for the code-length code --, no code at all: every decode then fails).
+PGI_DEV int pgi_build(const uint8_t *lens, int n, uint16_t *sorted, uint32_t *hist, PLREF(uint32_t, lim), PLREF(int32_t, bas),
+                      int dump, int kind PGI_LANE_PARAM) {
+    LANES { hist[lane] = 0; }
+    PGI_SYNC;
+    for (int g = 0; g < n; g += 64) {
+        LANES {
+            const int s = g + lane;                      // (< 320 + 64: inside lens[] whatever n is)
+            const int l = lens[s];
+            PGI_ATOMIC_INC(&hist[s < n ? l : 0]);
+        }
+    }
+    PGI_SYNC;
+    PL(uint32_t, cnt);
+    PL(uint32_t, nextpos);
+    LANES {
+        V(cnt) = lane < 16 ? hist[lane] : 0u;
+        V(lim) = 0u;
+        V(bas) = 0;
+        V(nextpos) = 0u;
+    }
+    uint32_t code = 0, off = 0;
+    int over = 0, maxlen = 0;
+    for (int L = 1; L <= 15; ++L) {
+        const uint32_t c = (uint32_t)READLANE(cnt, L);
+        const uint32_t first = code;
+        code += c;
+        if (code > (1u << L)) over = 1;
+        if (c) maxlen = L;
+        WRITELANE(lim, L, code << (15 - L));
+        WRITELANE(bas, L, (int32_t)off - (int32_t)first);
+        WRITELANE(nextpos, L, off);
+        off += c;
+        code <<= 1;
+    }
+    if (over) return PGI_ERR_CODE;
+    if (code != (1u << 16) && (kind == 0 || maxlen > 1)) return PGI_ERR_CODE;          // incomplete
+    for (int g = 0; g < n; g += 64) {
+        PL(int, l);
+        LANES {
+            const int s = g + lane;
+            const int x = (int)lens[s];
+            V(l) = s < n ? x : 0;
+        }
+        uint64_t any;
+        BALLOT(any, V(l) != 0);
+        if (!any) continue;
+        for (int L = 1; L <= maxlen; ++L) {
+            uint64_t m;
+            BALLOT(m, V(l) == L);
+            if (!m) continue;
+            const uint32_t p0 = (uint32_t)READLANE(nextpos, L);
+            LANES {
+                const uint32_t at = V(l) == L ? p0 + (uint32_t)PGI_POPC64(m & ((1ull << lane) - 1ull)) : (uint32_t)(dump + lane);
+                sorted[at] = (uint16_t)(g + lane);
+            }
+            WRITELANE(nextpos, L, p0 + (uint32_t)PGI_POPC64(m));
+        }
+    }
+    PGI_SYNC;
+    return 0;
+}
+
+// the bit reader (see the header comment); `comp` as dwords, n_dw of them may be read.  A piece that reaches past them repeats the
+// last dword (no select on the loaded value: the load must stay in flight until the piece is needed); those bits are never consumed by
+// a valid stream, and a damaged one is stopped by the check against the member's last bit.
+#define PGI_FILL1()                                                                  \
+    do {                                                                             \
+        const uint32_t w_ = (uint32_t)READLANE(cur, widx & 63u);                     \
+        buf |= (uint64_t)w_ << cnt;                                                  \
+        cnt += 32;                                                                   \
+        ++widx;                                                                      \
+        if ((widx & 63u) == 0u) {                                                    \
+            LANES { V(cur) = V(nxt); }                                               \
+            LANES {                                                                  \
+                const uint32_t a_ = widx + 64u + (uint32_t)lane;                     \
+                V(nxt) = comp[a_ < n_dw ? a_ : n_dw - 1u];                           \
+            }                                                                        \
+        }                                                                            \
+    } while (0)
+#define PGI_NEED(n)                     \
+    do {                                \
+        while (cnt < (n)) PGI_FILL1();  \
+    } while (0)
+#define PGI_DROP(n)        \
+    do {                   \
+        buf >>= (n);       \
+        cnt -= (int)(n);   \
+    } while (0)
+#define PGI_SEEK(byte_off)                                                  \
+    do {                                                                    \
+        const uint32_t d_ = (uint32_t)((byte_off) >> 2);                    \
+        const uint32_t c0_ = d_ & ~63u;                                     \
+        LANES {                                                             \
+            const uint32_t a_ = c0_ + (uint32_t)lane;                       \
+            V(cur) = comp[a_ < n_dw ? a_ : n_dw - 1u];                      \
+        }                                                                   \
+        LANES {                                                             \
+            const uint32_t a_ = c0_ + 64u + (uint32_t)lane;                 \
+            V(nxt) = comp[a_ < n_dw ? a_ : n_dw - 1u];                      \
+        }                                                                   \
+        widx = d_;                                                          \
+        buf = 0;                                                            \
+        cnt = 0;                                                            \
+        const int drop_ = (int)((byte_off) & 3u) * 8;                       \
+        if (drop_) {                                                        \
+            PGI_FILL1();                                                    \
+            PGI_DROP(drop_);                                                \
+        }                                                                   \
+    } while (0)
+// the next symbol of the code (lim, bas, sorted): its length in L_, the symbol in sym_
+#define PGI_DECODE(sym_, L_, lim, bas, sorted)                                                   \
+    do {                                                                                         \
+        const uint32_t c15_ = pgi_brev32((uint32_t)buf) >> 17;                                   \
+        uint64_t mm_;                                                                            \
+        BALLOT(mm_, c15_ < V(lim));                                                              \
+        if (!mm_) return PGI_ERR_CODE;                                                           \
+        L_ = (int)PGI_CTZ64(mm_);                                                                \
+        sym_ = (int)UNI(sorted[(int)(c15_ >> (15 - L_)) + (int)READLANE(bas, L_)]);              \
+        PGI_DROP(L_);                                                                            \
+    } while (0)
+
+// One member: in_len bytes of deflate stream at byte in_off of comp -> out_len bytes at dst.  0, or PGI_ERR_* bits.
+PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_t in_off, uint32_t in_len, uint8_t *dst,
+                       uint32_t out_len, uint8_t *sink, PgiShared *sh PGI_LANE_PARAM) {
+    // length / distance bases and extra bits (RFC 1951 3.2.5) as lane constants: base | extra << 16
+    PL(uint32_t, lconst);
+    PL(uint32_t, dconst);
+    LANES {
+        const uint32_t i = (uint32_t)lane;
+        uint32_t lb, le, db, de;
+        if (i < 8u) {
+            lb = 3u + i;
+            le = 0u;
+        } else if (i < 28u) {
+            le = (i >> 2) - 1u;
+            lb = 3u + ((4u + (i & 3u)) << le);
+        } else {
+            lb = 258u;
+            le = 0u;
+        }
+        if (i < 4u) {
+            db = 1u + i;
+            de = 0u;
+        } else {
+            de = ((i >> 1) - 1u) & 15u;
+            db = 1u + ((2u + (i & 1u)) << de);
+        }
+        V(lconst) = lb | (le << 16);
+        V(dconst) = (db & 0xFFFFu) | (de << 16);     // (bases up to 24577 fit 16 bits)
+    }
+    if (n_dw == 0u) return PGI_ERR_IN;
+    PL(uint32_t, cur);
+    PL(uint32_t, nxt);
+    uint32_t widx;
+    uint64_t buf;
+    int cnt;
+    PGI_SEEK(in_off);
+    const uint64_t end_bits = ((uint64_t)in_off + in_len) * 8u;
+    PL(uint32_t, lim_ll);
+    PL(int32_t, bas_ll);
+    PL(uint32_t, lim_d);
+    PL(int32_t, bas_d);
+    uint32_t pos = 0;
+    int fixed_built = 0;
+    for (;;) {
+        if ((uint64_t)widx * 32u - (uint64_t)cnt > end_bits) return PGI_ERR_IN;
+        PGI_NEED(3);
+        const int bfinal = (int)(buf & 1u), btype = (int)((buf >> 1) & 3u);
+        PGI_DROP(3);
+        if (btype == 3) return PGI_ERR_BTYPE;
+        if (btype == 0) {
+            PGI_DROP(cnt & 7);
+            PGI_NEED(32);
+            const uint32_t len = (uint32_t)(buf & 0xFFFFu), nlen = (uint32_t)((buf >> 16) & 0xFFFFu);
+            PGI_DROP(32);
+            if ((len ^ 0xFFFFu) != nlen) return PGI_ERR_STORED;
+            const uint64_t bp = ((uint64_t)widx * 32u - (uint64_t)cnt) >> 3;
+            if (bp + len > (uint64_t)in_off + in_len) return PGI_ERR_IN;
+            if ((uint64_t)pos + len > out_len) return PGI_ERR_OUT;
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(comp) + bp;
+            for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+                PL(uint8_t, v);
+                LANES {
+                    const uint32_t i = i0 + (uint32_t)lane;
+                    V(v) = src[i < len ? i : 0u];
+                }
+                LANES {
+                    const uint32_t i = i0 + (uint32_t)lane;
+                    uint8_t *q = i < len ? dst + pos + i : sink + lane;
+                    *q = V(v);
+                }
+            }
+            pos += len;
+            const uint64_t np = bp + len;
+            PGI_SEEK(np);
+            fixed_built = 0;            // (nothing lost, but keep the flag honest: the tables below are per block)
+        } else {
+            if (btype == 1) {
+                if (!fixed_built) {
+                    for (int g = 0; g < 320; g += 64) {
+                        LANES {
+                            const int s = g + lane;
+                            sh->lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+                        }
+                    }
+                    PGI_SYNC;
+                    int rc = pgi_build(sh->lens, 288, sh->sorted_ll, sh->hist, lim_ll, bas_ll, 288, 1 PGI_LANE_ARG);
+                    if (rc) return rc;
+                    rc = pgi_build(sh->lens + 288, 32, sh->sorted_d, sh->hist, lim_d, bas_d, 32, 2 PGI_LANE_ARG);
+                    if (rc) return rc;
+                    fixed_built = 1;
+                }
+            } else {
+                fixed_built = 0;
+                PGI_NEED(14);
+                const int hlit = (int)(buf & 31u) + 257, hdist = (int)((buf >> 5) & 31u) + 1, hclen = (int)((buf >> 10) & 15u) + 4;
+                PGI_DROP(14);
+                if (hlit > 286 || hdist > 30) return PGI_ERR_CODE;
+                // the code-length code: 3 bits each, in the order of RFC 1951 3.2.7
+                LANES { sh->lens[lane] = 0; }
+                PGI_SYNC;
+                for (int i = 0; i < hclen; ++i) {
+                    PGI_NEED(3);
+                    const int v = (int)(buf & 7u);
+                    PGI_DROP(3);
+                    // order: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+                    int sym;
+                    if (i < 3) sym = 16 + i;
+                    else if (i == 3) sym = 0;
+                    else if ((i & 1) == 0) sym = 8 + ((i - 4) >> 1);        // i = 4, 6, 8 ... 18 -> 8, 9, 10 ... 15
+                    else sym = 7 - ((i - 5) >> 1);                           // i = 5, 7, 9 ... 17 -> 7, 6, 5 ... 1
+                    LANES { sh->lens[sym] = (uint8_t)v; }                  // (every lane the same byte)
+                }
+                PGI_SYNC;
+                PL(uint32_t, lim_p);
+                PL(int32_t, bas_p);
+                int rc = pgi_build(sh->lens, 19, sh->sorted_d, sh->hist, lim_p, bas_p, 32, 0 PGI_LANE_ARG);
+                if (rc) return rc;
+                // the code lengths of the literal / length and distance codes, run-length coded (3.2.7)
+                const int total = hlit + hdist;
+                int i = 0, prev = 0;
+                while (i < total) {
+                    PGI_NEED(22);
+                    int sym, L;
+                    PGI_DECODE(sym, L, lim_p, bas_p, sh->sorted_d);
+                    if (sym < 16) {
+                        LANES { sh->lens[i] = (uint8_t)sym; }
+                        prev = sym;
+                        ++i;
+                        continue;
+                    }
+                    int rep, val;
+                    if (sym == 16) {
+                        if (i == 0) return PGI_ERR_CODE;
+                        val = prev;
+                        rep = 3 + (int)(buf & 3u);
+                        PGI_DROP(2);
+                    } else if (sym == 17) {
+                        val = 0;
+                        rep = 3 + (int)(buf & 7u);
+                        PGI_DROP(3);
+                    } else {
+                        val = 0;
+                        rep = 11 + (int)(buf & 127u);
+                        PGI_DROP(7);
+                    }
+                    if (i + rep > total) return PGI_ERR_CODE;
+                    for (int r0 = 0; r0 < rep; r0 += 64) {
+                        LANES { sh->lens[r0 + lane < rep ? i + r0 + lane : 320 + lane] = (uint8_t)val; }
+                    }
+                    prev = val;
+                    i += rep;
+                }
+                PGI_SYNC;
+                if ((int)UNI(sh->lens[256]) == 0) return PGI_ERR_CODE;               // no end-of-block code
+                // the distance lengths follow the hlit literal / length lengths: move them where pgi_build of the fixed code has them
+                PL(uint8_t, dl);
+                LANES {
+                    const uint8_t x = sh->lens[hlit + lane];               // (hlit + 63 < 320 + 64)
+                    V(dl) = lane < hdist ? x : (uint8_t)0;
+                }
+                PGI_SYNC;
+                LANES { sh->lens[lane < 32 ? 288 + lane : 320 + lane] = V(dl); }
+                PGI_SYNC;
+                rc = pgi_build(sh->lens, hlit, sh->sorted_ll, sh->hist, lim_ll, bas_ll, 288, 1 PGI_LANE_ARG);
+                if (rc) return rc;
+                rc = pgi_build(sh->lens + 288, hdist, sh->sorted_d, sh->hist, lim_d, bas_d, 32, 2 PGI_LANE_ARG);
+                if (rc) return rc;
+            }
+            // ---- the symbols of the block ----
+            for (;;) {
+                PGI_NEED(32);
+                int sym, L;
+                PGI_DECODE(sym, L, lim_ll, bas_ll, sh->sorted_ll);
+                if (sym < 256) {
+                    if (pos >= out_len) return PGI_ERR_OUT;
+                    LANES { dst[pos] = (uint8_t)sym; }                     // (every lane the same byte: one request)
+                    ++pos;
+                    continue;
+                }
+                if (sym == 256) break;
+                sym -= 257;
+                if (sym >= 29) return PGI_ERR_CODE;
+                const uint32_t lc = (uint32_t)READLANE(lconst, sym);
+                const uint32_t le = lc >> 16;
+                const uint32_t len = (lc & 0xFFFFu) + (uint32_t)(buf & ((1u << le) - 1u));
+                PGI_DROP(le);
+                PGI_NEED(32);
+                int dsym;
+                PGI_DECODE(dsym, L, lim_d, bas_d, sh->sorted_d);
+                if (dsym >= 30) return PGI_ERR_CODE;
+                const uint32_t dc = (uint32_t)READLANE(dconst, dsym);
+                const uint32_t de = dc >> 16;
+                const uint32_t dist = (dc & 0xFFFFu) + (uint32_t)(buf & ((1u << de) - 1u));
+                PGI_DROP(de);
+                if (dist > pos) return PGI_ERR_DIST;
+                if ((uint64_t)pos + len > out_len) return PGI_ERR_OUT;
+                uint8_t *d = dst + pos;
+                if (dist >= 64u || dist >= len) {
+                    // forward copy, 64 bytes per step: with dist >= 64 a later step may read what an earlier one wrote (in order)
+                    for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+                        PL(uint8_t, v);
+                        LANES {
+                            const uint32_t i = i0 + (uint32_t)lane;
+                            V(v) = d[(int64_t)(i < len ? i : 0u) - (int64_t)dist];
+                        }
+                        LANES {
+                            const uint32_t i = i0 + (uint32_t)lane;
+                            uint8_t *q = i < len ? d + i : sink + lane;
+                            *q = V(v);
+                        }
+                    }
+                } else {
+                    // the match overlaps itself: a pattern of `dist` bytes, repeated.  The lanes hold as many whole periods as fit.
+                    const uint32_t step = (64u / dist) * dist;
+                    PL(uint8_t, v);
+                    LANES {
+                        const uint32_t lm = (uint32_t)lane % dist;
+                        V(v) = d[(int64_t)lm - (int64_t)dist];
+                    }
+                    for (uint32_t i0 = 0; i0 < len; i0 += step) {
+                        LANES {
+                            const uint32_t i = i0 + (uint32_t)lane;
+                            uint8_t *q = ((uint32_t)lane < step && i < len) ? d + i : sink + lane;
+                            *q = V(v);
+                        }
+                    }
+                }
+                pos += len;
+            }
+        }
+        if (bfinal) break;
+    }
+    if ((uint64_t)widx * 32u - (uint64_t)cnt > end_bits) return PGI_ERR_IN;
+    if (pos != out_len) return PGI_ERR_OUT;
+    return 0;
+}

@@ -345,33 +345,105 @@ static int stage_bytes(pg_ctx *c, const TokSource &src, int64_t len, uint8_t *ds
     return PG_OK;
 }
 
-static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, int fmt, int n_cols, int max_ploidy,
-                      const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out) {
-    if (!c || !col_slot || !col_ploidy || !ok_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit: null argument");
-    if (slot < 0 || slot > 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit: slot %d", slot);
-    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
-    if (fmt < PG_FMT_PHASED || fmt > PG_FMT_DIPLO || n_cols < 1 || max_ploidy < 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: bad format description");
-    pg_ctx::TokSlot &T = c->tok[slot];
-    T.state = 0;
-    T.len = len;
-    T.n_lines = 0;
+// the checks of a submit that do not need the text: 1 = go on, 0 = the fast path does not take this layout (*ok_out stays 0), < 0: error
+static int tok_check(pg_ctx *c, int slot, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out) {
+    if (!c || !col_slot || !col_ploidy || !ok_out) return -pg_fail(PG_ERR_ARG, "pg_tokenize_submit: null argument");
+    if (slot < 0 || slot > 1) return -pg_fail(PG_ERR_ARG, "pg_tokenize_submit: slot %d", slot);
+    if (c->n_hap <= 0) return -pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    if (fmt < PG_FMT_PHASED || fmt > PG_FMT_DIPLO || n_cols < 1 || max_ploidy < 1) return -pg_fail(PG_ERR_ARG, "pg_tokenize_text: bad format description");
     *ok_out = 0;
-    if (len == 0) { T.state = 1; *ok_out = 1; return PG_OK; }
     bool any = false;
     for (int k = 0; k < n_cols; ++k) {
         if (col_ploidy[k] <= 0) continue;
         any = true;
-        if (col_ploidy[k] > max_ploidy) return pg_fail(PG_ERR_ARG, "col_ploidy[%d]=%d exceeds max_ploidy", k, col_ploidy[k]);
-        if (fmt == PG_FMT_DIPLO && col_ploidy[k] != 2) return PG_OK;
-        if (fmt == PG_FMT_HAPLO && col_ploidy[k] != 1) return PG_OK;
+        if (col_ploidy[k] > max_ploidy) return -pg_fail(PG_ERR_ARG, "col_ploidy[%d]=%d exceeds max_ploidy", k, col_ploidy[k]);
+        if (fmt == PG_FMT_DIPLO && col_ploidy[k] != 2) return 0;
+        if (fmt == PG_FMT_HAPLO && col_ploidy[k] != 1) return 0;
         for (int a = 0; a < col_ploidy[k]; ++a) {
             const int s = col_slot[(size_t)k * max_ploidy + a];
-            if (s < 0 || s >= c->n_hap) return pg_fail(PG_ERR_ARG, "col_slot[%d][%d]=%d out of range", k, a, s);
+            if (s < 0 || s >= c->n_hap) return -pg_fail(PG_ERR_ARG, "col_slot[%d][%d]=%d out of range", k, a, s);
         }
     }
+    return any ? 1 : 0;
+}
+
+// The cell widths of the block, read off its first line [text, e) (scaffold, position, then n_cols cells with one blank between
+// them): a wanted column's cell must be as wide as its ploidy says (phased: 2 p - 1 characters, pairs: p, haplo / diplo: 1); a file
+// of mixed ploidy has narrower cells for its haploid samples.  Every other line is held against these widths on the device.
+static bool tok_layout(pg_ctx::TokSlot &T, const char *text, const char *e, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
+                       const int32_t *col_ploidy) {
+    T.cols.assign((size_t)n_cols * (max_ploidy + 3), 0);         // col_slot | col_ploidy | cell offsets | cell widths
+    memcpy(T.cols.data(), col_slot, (size_t)n_cols * max_ploidy * 4);
+    memcpy(T.cols.data() + (size_t)n_cols * max_ploidy, col_ploidy, (size_t)n_cols * 4);
+    int32_t *col_off = T.cols.data() + (size_t)n_cols * (max_ploidy + 1), *col_w = col_off + n_cols;
+    auto blank_h = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f'; };
+    const char *p = text;
+    for (int tok = 0; tok < 2; ++tok) {                                    // scaffold, position
+        while (p < e && blank_h(*p)) ++p;
+        if (p == e) return false;
+        while (p < e && !blank_h(*p)) ++p;
+    }
+    while (p < e && blank_h(*p)) ++p;
+    const char *cells0 = p;
+    for (int k = 0; k < n_cols; ++k) {
+        const char *b = p;
+        while (p < e && !blank_h(*p)) ++p;
+        const int w = (int)(p - b);
+        if (w < 1) return false;
+        if (col_ploidy[k] > 0) {
+            const int want = fmt == PG_FMT_PHASED ? 2 * col_ploidy[k] - 1 : (fmt == PG_FMT_PAIRS ? col_ploidy[k] : 1);
+            if (w != want) return false;
+        }
+        col_off[k] = (int32_t)(b - cells0);
+        col_w[k] = w;
+        if (k + 1 < n_cols) {
+            if (p == e || !blank_h(*p)) return false;
+            ++p;                                                            // exactly one separator
+        }
+    }
+    if (p != e) return false;
+    T.cells_w = (int)(p - cells0);
+    T.fmt = fmt;
+    T.n_cols = n_cols;
+    T.max_ploidy = max_ploidy;
+    return true;
+}
+
+// line feeds of the slot's text (T.tp, len bytes): counted on the copy stream, the total on its way to the host
+static int tok_count(pg_ctx *c, pg_ctx::TokSlot &T, int64_t len) {
+    int rc;
+    hipStream_t st = c->stream_up;
+    const int64_t n_tiles = (len + NL_TILE - 1) / NL_TILE;
+    T.n_tiles = n_tiles;
+    if ((rc = T.i32.ensure((size_t)n_tiles + 4)) != PG_OK) return rc;
+    if ((rc = T.i64.ensure((size_t)n_tiles + 2)) != PG_OK) return rc;
+    if ((rc = T.h_total.ensure(8)) != PG_OK) return rc;           // [0] lines, page-locked landing of small results: [1] status | runs, [2] inflate status
+    int32_t *d_status = T.i32.p + n_tiles;                          // [0] status bits, [1] number of runs
+    int64_t *d_total = T.i64.p + n_tiles;
+    HIPCHK(hipMemsetAsync(d_status, 0, 8, st));
+    hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_tiles), dim3(256), 0, st, T.tp, len, T.i32.p);
+    hipLaunchKernelGGL(k_nl_scan, dim3(1), dim3(256), 0, st, T.i32.p, n_tiles, T.i64.p, d_total);
+    HIPCHK(hipMemcpyAsync(T.h_total.p, d_total, 8, hipMemcpyDeviceToHost, st));
+    if (!T.counted) HIPCHK(hipEventCreateWithFlags(&T.counted, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(T.counted, st));
+    T.state = 2;                                                    // text on the device, lines being counted
+    return PG_OK;
+}
+
+static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, int fmt, int n_cols, int max_ploidy,
+                      const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out) {
+    const int chk = tok_check(c, slot, fmt, n_cols, max_ploidy, col_slot, col_ploidy, ok_out);
+    if (chk < 0) return -chk;
+    pg_ctx::TokSlot &T = c->tok[slot];
+    T.state = 0;
+    T.len = len;
+    T.n_lines = 0;
+    T.deflated = false;
+    if (len == 0) { T.state = 1; *ok_out = 1; return PG_OK; }
+    if (chk == 0) return PG_OK;
     char last = 0;
     if (!src.read(len - 1, &last, 1)) return pg_fail(PG_ERR_ARG, "pg_tokenize_file: cannot read %lld bytes at offset %lld", (long long)len, (long long)src.off);
-    if (!any || last != '\n') return PG_OK;
+    if (last != '\n') return PG_OK;
     // the block's first line (in memory: where it is; from a file: read ahead, 64 KiB and more until its line feed shows)
     std::vector<char> head;
     const char *text = src.text;
@@ -385,69 +457,80 @@ static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, in
         }
         text = head.data();
     }
-    // The cell widths of the block, read off its first line (scaffold, position, then n_cols cells with one blank between them):
-    // a wanted column's cell must be as wide as its ploidy says (phased: 2 p - 1 characters, pairs: p, haplo / diplo: 1); a file of
-    // mixed ploidy has narrower cells for its haploid samples.  Every other line is held against these widths on the device.
-    T.cols.assign((size_t)n_cols * (max_ploidy + 3), 0);         // col_slot | col_ploidy | cell offsets | cell widths
-    memcpy(T.cols.data(), col_slot, (size_t)n_cols * max_ploidy * 4);
-    memcpy(T.cols.data() + (size_t)n_cols * max_ploidy, col_ploidy, (size_t)n_cols * 4);
-    int32_t *col_off = T.cols.data() + (size_t)n_cols * (max_ploidy + 1), *col_w = col_off + n_cols;
-    {
-        auto blank_h = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f'; };
-        const char *p = text, *e = static_cast<const char *>(memchr(text, '\n', head.empty() ? (size_t)len : head.size()));
-        for (int tok = 0; tok < 2; ++tok) {                                    // scaffold, position
-            while (p < e && blank_h(*p)) ++p;
-            if (p == e) return PG_OK;
-            while (p < e && !blank_h(*p)) ++p;
-        }
-        while (p < e && blank_h(*p)) ++p;
-        const char *cells0 = p;
-        for (int k = 0; k < n_cols; ++k) {
-            const char *b = p;
-            while (p < e && !blank_h(*p)) ++p;
-            const int w = (int)(p - b);
-            if (w < 1) return PG_OK;
-            if (col_ploidy[k] > 0) {
-                const int want = fmt == PG_FMT_PHASED ? 2 * col_ploidy[k] - 1 : (fmt == PG_FMT_PAIRS ? col_ploidy[k] : 1);
-                if (w != want) return PG_OK;
-            }
-            col_off[k] = (int32_t)(b - cells0);
-            col_w[k] = w;
-            if (k + 1 < n_cols) {
-                if (p == e || !blank_h(*p)) return PG_OK;
-                ++p;                                                            // exactly one separator
-            }
-        }
-        if (p != e) return PG_OK;
-        T.cells_w = (int)(p - cells0);
+    const char *e = static_cast<const char *>(memchr(text, '\n', head.empty() ? (size_t)len : head.size()));
+    if (!tok_layout(T, text, e, fmt, n_cols, max_ploidy, col_slot, col_ploidy)) return PG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t_stage0 = now();
+    if ((rc = T.text.ensure((size_t)len + 32)) != PG_OK) return rc;
+    T.tp = T.text.p;
+    if ((rc = stage_bytes(c, src, len, T.text.p)) != PG_OK) return rc;
+    c->tok_stage_s += std::chrono::duration<double>(now() - t_stage0).count();
+    c->tok_bytes += len;
+    if ((rc = tok_count(c, T, len)) != PG_OK) return rc;
+    *ok_out = 1;
+    return PG_OK;
+}
+
+int pg_inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const uint32_t *comp_d, uint32_t n_dw, const uint32_t *in_off,
+                     const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d);
+int pg_inflate_error(const int32_t *status);
+void pg_launch_gather_bytes(hipStream_t st, const uint8_t *text, const int64_t *off, const int32_t *len, const int64_t *dst, int n,
+                            uint8_t *out);
+
+// The submit step for a block of bgzip-compressed text: comp[0 .. comp_len) holds n_members whole BGZF members (table: pg_bgzf_walk),
+// which cross PCIe as they are and are inflated on the device (k_inflate, a wavefront per member; CRC-32 checked) into the slot's
+// text buffer behind `head` (head_len bytes of text the caller already has: the unfinished line the previous block ended with).
+// The block's text is  head + the members' text  cut to text_len bytes (the caller keeps what follows the last line feed for the
+// next block); first_line: the block's first line without its line feed (the cell widths are read off it).
+static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
+                           const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head, int64_t head_len,
+                           int64_t text_len, const char *first_line, int64_t first_line_len, int fmt, int n_cols, int max_ploidy,
+                           const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out) {
+    const int chk = tok_check(c, slot, fmt, n_cols, max_ploidy, col_slot, col_ploidy, ok_out);
+    if (chk < 0) return -chk;
+    if (comp_len < 0 || comp_len >= (1ll << 32) || n_members < 0 || head_len < 0 || text_len < 0 || first_line_len < 0 ||
+        (n_members > 0 && (!comp || !in_off || !in_len || !out_len)) || (head_len > 0 && !head) || (first_line_len > 0 && !first_line))
+        return pg_fail(PG_ERR_ARG, "pg_tokenize_submit_bgzf: bad argument");
+    int64_t total = head_len;
+    for (int64_t k = 0; k < n_members; ++k) {
+        if ((int64_t)in_off[k] + in_len[k] > comp_len) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit_bgzf: member %lld lies outside the compressed bytes", (long long)k);
+        total += out_len[k];
     }
-    T.fmt = fmt;
-    T.n_cols = n_cols;
-    T.max_ploidy = max_ploidy;
+    if (text_len > total) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit_bgzf: text_len %lld exceeds the %lld bytes of the block", (long long)text_len, (long long)total);
+    pg_ctx::TokSlot &T = c->tok[slot];
+    T.state = 0;
+    T.len = text_len;
+    T.n_lines = 0;
+    T.deflated = true;
+    if (text_len == 0) { T.state = 1; *ok_out = 1; return PG_OK; }
+    if (chk == 0) return PG_OK;
+    if (!tok_layout(T, first_line, first_line + first_line_len, fmt, n_cols, max_ploidy, col_slot, col_ploidy)) return PG_OK;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream_up;
     int rc;
     auto now = [] { return std::chrono::steady_clock::now(); };
     const auto t_stage0 = now();
-    if ((rc = T.text.ensure((size_t)len + 32)) != PG_OK) return rc;
-    if ((rc = stage_bytes(c, src, len, T.text.p)) != PG_OK) return rc;
+    if ((rc = T.text.ensure((size_t)total + 64)) != PG_OK) return rc;
+    T.tp = T.text.p;                                                 // (hipMalloc aligns to 256 bytes; the members' text starts at any byte)
+    // (the slot's buffers are free: the block that used them last has been collected.  Bytes behind comp_len in the last dword are
+    // never consumed by a valid stream, and a damaged one is stopped by the bounds of its member)
+    const size_t n_dw = ((size_t)comp_len + 3) / 4;
+    if ((rc = T.inf.comp.ensure(n_dw + 1)) != PG_OK) return rc;
+    if ((rc = T.h_total.ensure(8)) != PG_OK) return rc;
+    const TokSource src{reinterpret_cast<const char *>(comp), -1, 0};
+    if ((rc = stage_bytes(c, src, comp_len, reinterpret_cast<uint8_t *>(T.inf.comp.p))) != PG_OK) return rc;
     c->tok_stage_s += std::chrono::duration<double>(now() - t_stage0).count();
-    c->tok_bytes += len;
-    // ---- line feeds: counted behind the copies, the total on its way to the host ----
-    const int64_t n_tiles = (len + NL_TILE - 1) / NL_TILE;
-    T.n_tiles = n_tiles;
-    if ((rc = T.i32.ensure((size_t)n_tiles + 4)) != PG_OK) return rc;
-    if ((rc = T.i64.ensure((size_t)n_tiles + 2)) != PG_OK) return rc;
-    if ((rc = T.h_total.ensure(8)) != PG_OK) return rc;           // [0] lines, page-locked landing of small results: [2..3] status, runs
-    int32_t *d_status = T.i32.p + n_tiles;                          // [0] status bits, [1] number of runs
-    int64_t *d_total = T.i64.p + n_tiles;
-    HIPCHK(hipMemsetAsync(d_status, 0, 8, st));
-    hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_tiles), dim3(256), 0, st, T.text.p, len, T.i32.p);
-    hipLaunchKernelGGL(k_nl_scan, dim3(1), dim3(256), 0, st, T.i32.p, n_tiles, T.i64.p, d_total);
-    HIPCHK(hipMemcpyAsync(T.h_total.p, d_total, 8, hipMemcpyDeviceToHost, st));
-    if (!T.counted) HIPCHK(hipEventCreateWithFlags(&T.counted, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(T.counted, st));
-    T.state = 2;                                                    // text on the device, lines being counted
+    c->tok_bytes += comp_len;
+    if (head_len) {
+        if ((rc = T.h_head.ensure((size_t)head_len)) != PG_OK) return rc;
+        memcpy(T.h_head.p, head, (size_t)head_len);
+        HIPCHK(hipMemcpyAsync(T.tp, T.h_head.p, (size_t)head_len, hipMemcpyHostToDevice, st));
+    }
+    if ((rc = pg_inflate_queue(c, st, T.inf, T.inf.comp.p, (uint32_t)n_dw, in_off, in_len, out_len, crc, n_members, T.tp + head_len)) != PG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(T.h_total.p + 2, T.inf.status.p, 8, hipMemcpyDeviceToHost, st));     // [error bits, first bad member]: read by parse
+    if ((rc = tok_count(c, T, text_len)) != PG_OK) return rc;
     *ok_out = 1;
     return PG_OK;
 }
@@ -464,6 +547,11 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream_up;
     HIPCHK(hipEventSynchronize(T.counted));
+    if (T.deflated) {
+        int32_t ist[2];
+        memcpy(ist, T.h_total.p + 2, 8);
+        if (ist[0]) { T.state = 0; return pg_inflate_error(ist); }
+    }
     const int64_t n_lines = T.h_total.p[0];
     T.n_lines = n_lines;
     *n_rows_out = n_lines;
@@ -476,7 +564,7 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
     const int64_t n_tiles = T.n_tiles;
     int32_t *d_status = T.i32.p + n_tiles;
     if ((rc = T.nl.ensure((size_t)n_lines)) != PG_OK) return rc;
-    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(256), 0, st, T.text.p, T.len, T.i64.p, T.nl.p);
+    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(256), 0, st, T.tp, T.len, T.i64.p, T.nl.p);
     if ((rc = T.dcols.ensure(T.cols.size())) != PG_OK) return rc;
     if ((rc = T.h_cols.ensure(T.cols.size())) != PG_OK) return rc;
     memcpy(T.h_cols.p, T.cols.data(), T.cols.size() * 4);
@@ -495,7 +583,7 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
         auto code = [](char ch) { return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 4 : ch == 'T' ? 8 : 0; };
         for (int k = 0; d[k]; ++k) dip.v[(int)d[k]] = (uint8_t)(code(pr[k][0]) | (code(pr[k][1]) << 4));
     }
-    hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, T.text.p, T.nl.p, n_lines, T.fmt, n_cols,
+    hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, T.tp, T.nl.p, n_lines, T.fmt, n_cols,
                        T.cells_w, max_ploidy, T.dcols.p, T.dcols.p + (size_t)n_cols * max_ploidy,
                        T.dcols.p + (size_t)n_cols * (max_ploidy + 1), T.dcols.p + (size_t)n_cols * (max_ploidy + 2),
                        c->gt.p + row_offset * c->S, c->S,
@@ -603,6 +691,50 @@ extern "C" int pg_tokenize_submit(pg_ctx *c, int slot, const char *text, int fd,
     if ((!text && fd < 0 && len) || file_offset < 0 || len < 0) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit: no text");
     const TokSource src{text ? text : (fd < 0 ? "" : nullptr), fd, file_offset};
     return tok_submit(c, slot, src, len, fmt, n_cols, max_ploidy, col_slot, col_ploidy, ok_out);
+}
+
+extern "C" int pg_tokenize_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off,
+                                       const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members,
+                                       const char *head, int64_t head_len, int64_t text_len, const char *first_line,
+                                       int64_t first_line_len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
+                                       const int32_t *col_ploidy, int *ok_out) {
+    return tok_submit_bgzf(c, slot, comp, comp_len, in_off, in_len, out_len, crc, n_members, head, head_len, text_len, first_line,
+                           first_line_len, fmt, n_cols, max_ploidy, col_slot, col_ploidy, ok_out);
+}
+
+// The scaffold names of the runs pg_tokenize_collect reported for `slot` (their offsets and lengths in the block's text), read back
+// from the text on the device: out receives the names one after the other.  For blocks whose text the host never had (BGZF).
+extern "C" int pg_tokenize_run_names(pg_ctx *c, int slot, const int64_t *run_off, const int32_t *run_len, int64_t n_runs, char *out,
+                                     int64_t out_capacity) {
+    if (!c || slot < 0 || slot > 1 || n_runs < 0 || (n_runs > 0 && (!run_off || !run_len || !out)))
+        return pg_fail(PG_ERR_ARG, "pg_tokenize_run_names: bad argument");
+    if (n_runs == 0) return PG_OK;
+    pg_ctx::TokSlot &T = c->tok[slot];
+    if (!T.tp) return pg_fail(PG_ERR_STATE, "pg_tokenize_run_names: no text in slot %d", slot);
+    std::vector<int64_t> idx((size_t)n_runs * 2);                   // source offsets | destination offsets
+    int64_t total = 0;
+    for (int64_t k = 0; k < n_runs; ++k) {
+        if (run_off[k] < 0 || run_len[k] < 0 || run_off[k] + run_len[k] > T.len) return pg_fail(PG_ERR_ARG, "pg_tokenize_run_names: run %lld lies outside the block", (long long)k);
+        idx[(size_t)k] = run_off[k];
+        idx[(size_t)(n_runs + k)] = total;
+        total += run_len[k];
+    }
+    if (total > out_capacity) return pg_fail(PG_ERR_ARG, "pg_tokenize_run_names: %lld bytes of names, room for %lld", (long long)total, (long long)out_capacity);
+    if (total == 0) return PG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream_up;
+    int rc;
+    const size_t len_words = ((size_t)n_runs * 4 + 7) / 8;           // the int32 lengths ride behind the offsets
+    if ((rc = T.names_idx.ensure((size_t)n_runs * 2 + len_words)) != PG_OK) return rc;
+    if ((rc = T.names.ensure((size_t)total)) != PG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(T.names_idx.p, idx.data(), (size_t)n_runs * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(T.names_idx.p + n_runs * 2, run_len, (size_t)n_runs * 4, hipMemcpyHostToDevice, st));
+    pg_launch_gather_bytes(st, T.tp, T.names_idx.p, reinterpret_cast<const int32_t *>(T.names_idx.p + n_runs * 2), T.names_idx.p + n_runs,
+                           (int)n_runs, T.names.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, T.names.p, (size_t)total, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return PG_OK;
 }
 
 extern "C" int pg_tokenize_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capacity, int64_t run_capacity,

@@ -253,6 +253,19 @@ class Engine:
                                          lay.max_ploidy, np.ascontiguousarray(lay.col_slot), lay.col_ploidy, C.byref(ok)))
         return bool(ok.value)
 
+    def tokenize_submit_bgzf(self, span, slot):
+        """a block of bgzip-compressed text (genoio.BgzfSpan) -> device buffer of `slot`: the members cross PCIe deflated and are
+        inflated on the device (pg_tokenize_submit_bgzf); False: not the regular layout"""
+        lay = self.layout
+        in_off, in_len, out_len, crc = span.tab
+        ok = C.c_int(0)
+        vp = lambda a: C.c_void_p(a.ctypes.data)                            # noqa: E731
+        check(self._L.pg_tokenize_submit_bgzf(self._h, int(slot), vp(span.comp), len(span.comp), vp(in_off), vp(in_len), vp(out_len), vp(crc),
+                                              len(in_off), span.head, len(span.head), len(span), span.first_line, len(span.first_line),
+                                              _lib.FMT[lay.genoFormat], len(lay.col_ploidy), lay.max_ploidy,
+                                              np.ascontiguousarray(lay.col_slot), lay.col_ploidy, C.byref(ok)))
+        return bool(ok.value)
+
     def tokenize_parse(self, slot, row_offset, row_capacity, max_runs=1 << 16):
         """queue the parse of the block in `slot` into resident rows row_offset .. (at most row_capacity of them); returns the number of
         its lines, or None when they do not fit"""
@@ -269,7 +282,13 @@ class Engine:
         if not ok.value:
             return None
         k, r = int(got.value), int(nr.value)
-        names = [bytes(buf[int(roff[i]):int(roff[i]) + int(rlen[i])]).decode("utf-8", "replace") for i in range(r)]
+        if hasattr(buf, "tab"):                      # a BgzfSpan: the host never had this text, the names come back from the device
+            out = np.empty(max(int(rlen[:r].sum()), 1), dtype=np.uint8)
+            check(self._L.pg_tokenize_run_names(self._h, int(slot), roff, rlen, r, C.c_void_p(out.ctypes.data), len(out)))
+            ends = np.cumsum(rlen[:r])
+            names = [bytes(out[int(e) - int(n):int(e)]).decode("utf-8", "replace") for e, n in zip(ends, rlen[:r])]
+        else:
+            names = [bytes(buf[int(roff[i]):int(roff[i]) + int(rlen[i])]).decode("utf-8", "replace") for i in range(r)]
         return k, pos[:k], rrow[:r].copy(), names
 
     # packed cells (`.pgeno`, codec none) straight from the file: the staging threads of the tokenizer read them, k_unpack expands them

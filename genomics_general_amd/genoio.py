@@ -63,19 +63,88 @@ def read_all(path):
         return f.read()
 
 
+def bgzf_walk(buf, limit=None, max_text=0):
+    """member table of the BGZF bytes buf[:limit] (pg_bgzf_walk): (in_off, in_len, out_len, crc) as uint32 arrays -- where each
+    member's deflate stream lies in buf, its inflated size and checksum --, the bytes the walked members occupy, their text bytes.
+    Stops in front of an incomplete member, or once the members hold max_text bytes of text (0: no limit)."""
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    n = len(arr) if limit is None else max(min(int(limit), len(arr)), 0)
+    cap = n // 28 + 1
+    tab = np.empty((4, cap), dtype=np.uint32)
+    k, used, text = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    ptr = [C.c_void_p(tab[i].ctypes.data) for i in range(4)]
+    rc = _lib.lib().pg_bgzf_walk(C.c_void_p(arr.ctypes.data if n else 0), n, cap, int(max_text), ptr[0], ptr[1], ptr[2], ptr[3],
+                                 C.byref(k), C.byref(used), C.byref(text))
+    if rc == _lib.PG_ERR_PARSE:
+        raise ValueError("input stops being BGZF in the middle (bad member header)")
+    check(rc)
+    m = int(k.value)
+    return (tab[0, :m], tab[1, :m], tab[2, :m], tab[3, :m]), int(used.value), int(text.value)
+
+
+def bgzf_inflate(buf, tab, n_threads=0):
+    """the text of the members `tab` (bgzf_walk) of buf as a uint8 array, inflated by the library's host threads (zlib; the
+    checksums are verified)"""
+    in_off, in_len, out_len, crc = tab
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    out_off = np.zeros(len(out_len) + 1, dtype=np.int64)
+    np.cumsum(out_len, out=out_off[1:])
+    dst = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+    rc = _lib.lib().pg_inflate_members(C.c_void_p(arr.ctypes.data if len(arr) else 0), C.c_void_p(in_off.ctypes.data),
+                                       C.c_void_p(in_len.ctypes.data), out_off, C.c_void_p(out_len.ctypes.data),
+                                       C.c_void_p(crc.ctypes.data), len(out_len), C.c_void_p(dst.ctypes.data), int(n_threads))
+    if rc == _lib.PG_ERR_PARSE:
+        raise ValueError(_lib.lib().pg_last_error().decode("utf-8", "replace"))
+    check(rc)
+    return dst[:int(out_off[-1])]
+
+
+def bgzf_compress(text, level=6, block=65280, eof_marker=True, n_threads=0):
+    """text (bytes-like) as BGZF bytes, the way bgzip writes them (pg_bgzf_compress: a pool of host threads)"""
+    arr = np.frombuffer(text, dtype=np.uint8)
+    cap = len(arr) + len(arr) // 1000 + (len(arr) // block + 2) * 64 + 65536
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_int64(0)
+    check(_lib.lib().pg_bgzf_compress(C.c_void_p(arr.ctypes.data if len(arr) else 0), len(arr), int(level), int(block), int(bool(eof_marker)),
+                                      C.c_void_p(out.ctypes.data), cap, C.byref(n), int(n_threads)))
+    return out[:int(n.value)]
+
+
+class BgzfSpan:
+    """A block of a BGZF input that is still deflated: `head` (text the reader already holds: what the previous block left behind
+    its last line feed) followed by the text of whole members, cut behind the block's last line feed (len() = that many bytes of
+    text).  Engine.tokenize_submit_bgzf sends the members to the device as they are and inflates them there; bytes(span) inflates
+    them on the host (a block the device tokenizer does not take)."""
+
+    def __init__(self, head, comp, tab, text_len, first_line):
+        self.head, self.comp, self.tab, self.text_len, self.first_line = head, comp, tab, text_len, first_line
+
+    def __len__(self):
+        return self.text_len
+
+    def __bytes__(self):
+        return (self.head + bgzf_inflate(self.comp, self.tab).tobytes())[:self.text_len]
+
+    def __getitem__(self, key):                 # (the first bytes of the block: what the ingestion loop looks at to bound its rows)
+        if isinstance(key, slice) and key.start in (None, 0) and key.step is None:
+            line = self.first_line + b"\n"
+            return line[:key.stop] if key.stop is not None else line
+        raise TypeError("a BgzfSpan offers its first line only")
+
+
 class BgzfFile:
     """Read-only file object over a BGZF file (bgzip / htslib: a gzip file made of independent members of at most 64 KiB,
     each announcing its compressed size in a 'BC' extra field).  A plain gzip stream has to be inflated serially, which caps
-    `.geno.gz` ingestion at a few hundred MB/s of text; BGZF members are inflated here by a pool of threads (zlib releases
-    the GIL).  Offers read(n), readline() and close(), which is all BlockReader needs."""
+    `.geno.gz` ingestion at a few hundred MB/s of text; BGZF members are independent: read_span() hands out whole blocks of them
+    still deflated (they are inflated on the device), read(n) / readline() inflate them with the library's host threads
+    (pg_inflate_members).  Offers read(n), readline() and close(), which is all BlockReader needs."""
 
-    CHUNK = 32 << 20                    # compressed bytes fetched per refill
+    CHUNK = 32 << 20                    # compressed bytes fetched per refill at most (the first refills are small: header line, cuts)
 
     def __init__(self, path, n_threads=0):
         import os
-        from concurrent.futures import ThreadPoolExecutor
         self.raw = open(path, "rb")
-        self.pool = ThreadPoolExecutor(max_workers=n_threads or min(16, _lib.usable_cpus()))
+        self.n_threads = n_threads
         self.pending = b""               # compressed bytes not yet split into whole members
         self.buf = bytearray()           # inflated bytes not yet handed out
         self.eof = False
@@ -85,6 +154,8 @@ class BgzfFile:
         self.keep_track = False          # ... of every member since seek_member (a scan that needs virtual positions)
         self.stop = None                 # (member file offset, bytes of that member to keep): where a rank's share ends
         self.size = os.path.getsize(path)
+        self._next_read = 1 << 16
+        self._ratio = 8.0                # text bytes per compressed byte, as seen so far (read_span sizes its reads with it)
 
     @staticmethod
     def is_bgzf(path):
@@ -99,52 +170,161 @@ class BgzfFile:
     @staticmethod
     def _inflate(member):
         import zlib
-        return zlib.decompress(member[18:-8], wbits=-15)
+        (in_off, in_len, out_len, crc), used, _ = bgzf_walk(member)
+        if used != len(member) or len(in_off) != 1:
+            raise ValueError("damaged BGZF member")
+        out = zlib.decompress(bytes(member[int(in_off[0]):int(in_off[0]) + int(in_len[0])]), wbits=-15)
+        if len(out) != int(out_len[0]) or (zlib.crc32(out) & 0xffffffff) != int(crc[0]):
+            raise ValueError("damaged BGZF member (size or checksum)")
+        return out
 
-    def _refill(self):
-        new = self.raw.read(self.CHUNK)
-        data = self.pending + new
+    def _stop_member(self, data, off):
+        """the share ends inside the member at data[off:] (self.stop): its first stop[1] bytes; reads on until the member is whole"""
+        while True:
+            if off + 18 <= len(data):
+                size = int.from_bytes(data[off + 16:off + 18], "little") + 1
+                if off + size <= len(data):
+                    return self._inflate(data[off:off + size])[:self.stop[1]]
+            more = self.raw.read(1 << 16)
+            if not more:
+                raise ValueError("truncated BGZF input")
+            data = data + more
+
+    def _refill(self, need=0):
+        """inflate more members into buf: as many as hold `need` bytes of text (0: all that are at hand)"""
+        new, exhausted = b"", False
+        if len(self.pending) < (1 << 17):
+            new = self.raw.read(self._next_read)
+            self._next_read = min(self._next_read * 4, self.CHUNK)
+            exhausted = not new
+        data = self.pending + new if new else self.pending
         if not data:
             self.eof = True
             return
-        members, starts, off, n = [], [], 0, len(data)
-        last_keep = None
-        while off + 18 <= n:
-            if data[off:off + 4] != b"\x1f\x8b\x08\x04" or data[off + 12:off + 14] != b"BC":
-                raise ValueError("input stops being BGZF in the middle (bad member header)")
-            size = int.from_bytes(data[off + 16:off + 18], "little") + 1
-            if off + size > n:
-                break
-            if self.stop is not None and self.cpos + off >= self.stop[0]:
-                # the share ends inside this member (or right before it): keep its first stop[1] bytes and finish
-                if self.cpos + off == self.stop[0] and self.stop[1] > 0:
-                    members.append(data[off:off + size])
-                    starts.append(self.cpos + off)
-                    last_keep = self.stop[1]
-                self.eof = True
-                break
-            members.append(data[off:off + size])
-            starts.append(self.cpos + off)
-            off += size
-        self.pending = data[off:]
-        self.cpos += off
-        if not new and not self.eof:
-            if self.pending:
-                raise ValueError("truncated BGZF input")
+        limit, at_stop, last = len(data), False, None
+        if self.stop is not None and self.cpos + limit > self.stop[0]:
+            limit, at_stop = max(self.stop[0] - self.cpos, 0), True      # the share ends inside (or right before) the member there
+        tab, used, _ = bgzf_walk(data, limit, need)
+        in_off, in_len, out_len, _crc = tab
+        if at_stop and used == limit:
             self.eof = True
-        parts = list(self.pool.map(self._inflate, members))
-        if last_keep is not None:
-            parts[-1] = parts[-1][:last_keep]
-        for st, part in zip(starts, parts):
-            self.track.append((self.produced, st))
-            self.produced += len(part)
-            self.buf += part
+            if self.stop[1] > 0:
+                last = self._stop_member(data, limit)
+        elif exhausted and used == len(data):
+            self.eof = True
+        elif len(in_off) == 0 and (exhausted or at_stop):
+            raise ValueError("truncated BGZF input")
+        self.pending = b"" if self.eof else data[used:]
+        if len(in_off):
+            text = bgzf_inflate(data, tab, self.n_threads)
+            # where every member starts in the file: the first at cpos, each of the others behind its predecessor's trailer
+            starts = np.empty(len(in_off), dtype=np.int64)
+            starts[0] = self.cpos
+            starts[1:] = self.cpos + in_off[:-1].astype(np.int64) + in_len[:-1] + 8
+            at = self.produced + np.concatenate([[0], np.cumsum(out_len[:-1], dtype=np.int64)])
+            self.track.extend(zip(at.tolist(), starts.tolist()))
+            self.produced += len(text)
+            self.buf += memoryview(text)
+        self.cpos += used
+        if last is not None:
+            self.track.append((self.produced, self.cpos))
+            self.produced += len(last)
+            self.buf += last
         if not self.keep_track and len(self.track) > 4096:
             consumed = self.produced - len(self.buf)
             k = 0
             while k + 1 < len(self.track) and self.track[k + 1][0] <= consumed:
                 k += 1
             del self.track[:k]
+
+    def read_span(self, nbytes):
+        """The next block of about nbytes of text as a BgzfSpan (its members still deflated), cut behind its last line feed; bytes
+        when nothing compressed is left (the end of the input or of this reader's share: possibly without a final line feed), b""
+        at the end.  What follows the block's last line feed stays buffered as the head of the next block; finding it costs one
+        member inflated on the host (the last), the block's first line another."""
+        head = bytes(self.buf)
+        self.buf = bytearray()
+        if self.eof:
+            return head
+        want = max(int(nbytes) - len(head), 1 << 16)
+        data = self.pending
+        self.pending = b""
+        file_done = False
+        while True:
+            limit, stop_here = len(data), False
+            if self.stop is not None and self.cpos + limit > self.stop[0]:
+                limit, stop_here = max(self.stop[0] - self.cpos, 0), True
+            tab, used, text = bgzf_walk(data, limit, want)
+            if text >= want or stop_here or file_done:
+                break
+            more = self.raw.read(max(int((want - text) / self._ratio * 1.1), 1 << 20))
+            if not more:
+                file_done = True
+            else:
+                data = data + more if len(data) else more
+        in_off, in_len, out_len, crc = tab
+        n = len(in_off)
+        reached_stop = stop_here and used == limit
+        if (file_done and used != len(data)) or (stop_here and text < want and used != limit):
+            raise ValueError("truncated BGZF input")
+        if n:
+            self._ratio = max(text / max(used, 1), 1.0)
+        tail_extra = b""
+        if reached_stop:
+            self.eof = True
+            if self.stop[1] > 0:
+                tail_extra = self._stop_member(data, limit)
+        elif file_done and used == len(data):
+            self.eof = True
+        if not self.eof:
+            self.pending = bytes(data[used:]) if used < len(data) else b""
+        self.cpos += used
+
+        def member_text(k):
+            a = int(in_off[k])
+            import zlib
+            return zlib.decompress(bytes(data[a:a + int(in_len[k])]), wbits=-15)
+
+        if n == 0:                                       # nothing compressed left (the end of the input / of the share)
+            return head + tail_extra
+        # the block ends behind the last line feed of its members' text: walk back from the last member
+        tail, k, found = [], n - 1, False
+        while k >= 0 and n - k <= 64:
+            t = member_text(k)
+            cut = t.rfind(b"\n")
+            if cut >= 0:
+                tail.append(t[cut + 1:])
+                found = True
+                break
+            tail.append(t)
+            k -= 1
+        if not found:
+            # no line ends in the last members (lines of megabytes): this block is inflated on the host and handed on as text
+            body = head + bgzf_inflate(data, tab, self.n_threads).tobytes() + tail_extra
+            if self.eof:
+                return body
+            cut = body.rfind(b"\n") + 1
+            self.buf = bytearray(body[cut:])
+            return body[:cut] if cut else self.read_span(len(body) + int(nbytes))
+        tail = b"".join(reversed(tail))
+        text_len = len(head) + text - len(tail)
+        self.buf = bytearray(tail + tail_extra)
+        # the block's first line: in head, or head + the start of the first members' text
+        nl = head.find(b"\n")
+        if nl >= 0:
+            first = head[:nl]
+        else:
+            first, k = head, 0
+            while True:
+                t = member_text(k)
+                nl = t.find(b"\n")
+                if nl >= 0:
+                    first += t[:nl]
+                    break
+                first += t
+                k += 1
+        comp = np.frombuffer(data, dtype=np.uint8)[:used]
+        return BgzfSpan(head, comp, (in_off, in_len, out_len, crc), text_len, first)
 
     def set_stop(self, coffset, uoffset):
         """end this reader's share at byte `uoffset` of the member at file offset `coffset` (which may already be buffered)"""
@@ -222,7 +402,7 @@ class BgzfFile:
             self.buf = bytearray()
             return out
         while len(self.buf) < n and not self.eof:
-            self._refill()
+            self._refill(n - len(self.buf))
         out = bytes(self.buf[:n])
         del self.buf[:n]
         return out
@@ -238,11 +418,10 @@ class BgzfFile:
                 out = bytes(self.buf)
                 self.buf = bytearray()
                 return out
-            self._refill()
+            self._refill(1)
 
     def close(self):
         self.raw.close()
-        self.pool.shutdown(wait=False)
 
 
 class BlockReader:
@@ -267,6 +446,7 @@ class BlockReader:
                 self._mm_addr = int(probe.ctypes.data)       # where the mapping begins: file_range() turns a block into (fd, offset)
                 del probe
         self.bytes_read = 0
+        self.spans = False                # BGZF input: read_block() may hand out BgzfSpan blocks (members still deflated: the device inflates them)
 
     def read_header(self):
         line = self.mm.readline() if self.mm is not None else self.f.readline()
@@ -302,6 +482,10 @@ class BlockReader:
             mm.seek(end)
             self.bytes_read += end - pos
             return memoryview(mm)[pos:end]
+        if self.spans and nbytes is not None and isinstance(self.f, BgzfFile):
+            data = self.f.read_span(nbytes)
+            self.bytes_read += len(data)
+            return data
         if self.stop is not None:
             left = max(self.stop - self.f.tell(), 0)
             if nbytes is None or nbytes >= left:
@@ -511,6 +695,8 @@ class BlockReader:
             bz.set_stop(*end)
 
     def to_geno(self, body, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, keep_packed=False):
+        if isinstance(body, BgzfSpan):
+            body = bytes(body)
         return encode(body, layout, n_threads, head_rows, pitch, alloc)
 
     def close(self):

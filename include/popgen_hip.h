@@ -269,6 +269,43 @@ int pg_format_freq_rows(int mode, int64_t n_rows, int n_pops, const void *values
 int pg_inflate_chunks(const uint8_t *src, const int64_t *src_off, const int64_t *src_len, const int64_t *raw_len, int n_chunks,
                       uint8_t *dst_a, int64_t len_a, uint8_t *dst_b, int64_t len_b, int n_threads);
 
+/* ---- `.geno.gz` written by bgzip (BGZF: independent gzip members of at most 64 KiB of text) ----------------------------------------
+ * Replaces gzip.open() in GenoFileReader.__init__ (genomics.py:1917-1919; popgenWindows.py:313 "-g input.geno.gz" is the
+ * reference's normal input, its producer `parseVCF.py ... | bgzip`, VCF_processing/README.md:33).
+ *
+ * pg_bgzf_walk: the member table of buf[0 .. len) (RFC 1952 headers parsed; each member must carry the 'B' 'C' size subfield).  It
+ * stops in front of a member that is not complete in buf, after max_members members, or once the walked members hold >= max_text
+ * bytes of text (max_text <= 0: no limit).  Per member k: its deflate stream buf[in_off[k] .. + in_len[k]), ISIZE out_len[k] and
+ * CRC-32 crc[k] of its trailer.  *consumed_out = bytes of buf the walked members occupy, *text_out = sum of their ISIZE. */
+int pg_bgzf_walk(const uint8_t *buf, int64_t len, int64_t max_members, int64_t max_text, uint32_t *in_off, uint32_t *in_len,
+                 uint32_t *out_len, uint32_t *crc, int64_t *n_members_out, int64_t *consumed_out, int64_t *text_out);
+/* the members inflated by a pool of host threads (zlib): member k -> dst[out_off[k] .. + out_len[k]); crc (may be NULL) is checked.
+ * The route of blocks the device tokenizer refuses and of the readers' own small reads (header line, shard cuts). */
+int pg_inflate_members(const uint8_t *comp, const uint32_t *in_off, const uint32_t *in_len, const int64_t *out_off,
+                       const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *dst, int n_threads);
+/* text -> BGZF, what `bgzip` writes (tools/bgzip.py; bench.py's compressed samples; tests): members of `block` bytes of text (bgzip:
+ * 65280) deflated at `level` by a pool of host threads, + the empty EOF member when eof_marker != 0. */
+int pg_bgzf_compress(const uint8_t *text, int64_t len, int level, int block, int eof_marker, uint8_t *out, int64_t out_cap,
+                     int64_t *out_len_out, int n_threads);
+/* the members inflated ON THE DEVICE (k_inflate: one wavefront per member, canonical Huffman decoding by ballot, matches copied 64
+ * bytes at a time; k_crc32 checks the trailers when crc != NULL): comp[0 .. comp_len) -> dst[0 .. sum out_len).  kernel_ms_out (may
+ * be NULL): device time of the kernels.  PG_ERR_PARSE names the first damaged member. */
+int pg_inflate_device(pg_ctx *ctx, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
+                      const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *dst, double *kernel_ms_out);
+/* The submit step of the device tokenizer (pg_tokenize_submit) for a block that is still deflated: the members cross PCIe as they
+ * are (10 - 26 x fewer bytes than their text) and are inflated into the slot's text buffer behind `head` (head_len bytes of text the
+ * caller already holds: the unfinished line the previous block ended with).  The block's text = head + the members' text, cut to
+ * text_len bytes (it must end with a line feed; the caller keeps what follows for the next block).  first_line: the block's first
+ * line without its line feed (the cell widths are read off it).  parse / collect as for plain text; a damaged member makes
+ * pg_tokenize_parse fail with PG_ERR_PARSE.  pg_tokenize_run_names reads the scaffold names of the runs pg_tokenize_collect reported
+ * (offsets / lengths in the block's text) back from the device, one after the other into out: the host never had that text. */
+int pg_tokenize_submit_bgzf(pg_ctx *ctx, int slot, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
+                            const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head, int64_t head_len,
+                            int64_t text_len, const char *first_line, int64_t first_line_len, int fmt, int n_cols, int max_ploidy,
+                            const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out);
+int pg_tokenize_run_names(pg_ctx *ctx, int slot, const int64_t *run_off, const int32_t *run_len, int64_t n_runs, char *out,
+                          int64_t out_capacity);
+
 /* Packed `.pgeno` input (genomics_general_amd/genoio.py: a tokenised `.geno` file kept on disk, one byte per genotype cell =
  * first allele code | second allele code << 4, in file column order): block of cells -> one-hot codes in slot order, same
  * col_slot / col_ploidy tables as pg_encode_text. */

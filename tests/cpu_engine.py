@@ -83,6 +83,31 @@ class CpuEngine:
         self._slots[slot] = [body, None]
         return True
 
+    bgzf_spans = 0                       # blocks that arrived as genoio.BgzfSpan (members still deflated)
+
+    def tokenize_submit_bgzf(self, span, slot):
+        """pg_tokenize_submit_bgzf: the members are inflated HERE with Python's zlib (not with the library's host pool the
+        span itself would use), checked against their trailers, put behind the head and cut to the span's length"""
+        import zlib
+        from genomics_general_amd import genoio
+        assert isinstance(span, genoio.BgzfSpan)
+        in_off, in_len, out_len, crc = span.tab
+        raw = span.comp.tobytes()
+        parts = [span.head]
+        for k in range(len(in_off)):
+            t = zlib.decompress(raw[int(in_off[k]):int(in_off[k]) + int(in_len[k])], wbits=-15)
+            assert len(t) == int(out_len[k]) and (zlib.crc32(t) & 0xffffffff) == int(crc[k])
+            parts.append(t)
+        body = b"".join(parts)
+        assert len(span) <= len(body) and body[len(span) - 1:len(span)] == b"\n" and b"\n" not in body[len(span):]
+        body = body[:len(span)]
+        assert body.split(b"\n", 1)[0] == span.first_line and bytes(span) == body
+        CpuEngine.bgzf_spans += 1
+        ok = self.tokenize_submit(body, slot)
+        if ok:
+            self._slots[slot].append(span)
+        return ok
+
     def tokenize_parse(self, slot, row_offset, row_capacity, max_runs=1 << 16):
         from genomics_general_amd import genoio
         body = self._slots[slot][0]
@@ -94,8 +119,9 @@ class CpuEngine:
         return d.n_sites
 
     def tokenize_collect(self, slot, buf, n_rows, max_runs=1 << 16):
-        body, d = self._slots.pop(slot)
-        assert bytes(buf) == body and d is not None
+        item = self._slots.pop(slot)
+        body, d = item[0], item[1]
+        assert (buf is item[2] if len(item) > 2 else bytes(buf) == body) and d is not None
         return d.n_sites, d.pos.copy(), d.run_starts.astype(np.int64), list(d.run_names)
 
     # packed cells from the file (pg_stage_file / pg_unpack_staged / pg_stage_sync)
