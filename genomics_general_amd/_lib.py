@@ -93,7 +93,7 @@ SIGNATURES = {
     "pg_bgzf_compress": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_inflate_device": (C.c_int, [_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.POINTER(C.c_double)]),
-    "pg_tokenize_submit_bgzf": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+    "pg_tokenize_submit_bgzf": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_char_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p,
                                           C.POINTER(C.c_int)]),
     "pg_tokenize_run_names": (C.c_int, [_P, C.c_int, _i64p, _i32p, C.c_int64, C.c_void_p, C.c_int64]),

@@ -479,19 +479,21 @@ int pg_inflate_error(const int32_t *status);
 void pg_launch_gather_bytes(hipStream_t st, const uint8_t *text, const int64_t *off, const int32_t *len, const int64_t *dst, int n,
                             uint8_t *out);
 
-// The submit step for a block of bgzip-compressed text: comp[0 .. comp_len) holds n_members whole BGZF members (table: pg_bgzf_walk),
+// The submit step for a block of bgzip-compressed text: comp[0 .. comp_len) -- or, with comp == NULL, comp_len bytes at file_offset of
+// fd -- holds n_members whole BGZF members (table: pg_bgzf_walk),
 // which cross PCIe as they are and are inflated on the device (k_inflate, a wavefront per member; CRC-32 checked) into the slot's
 // text buffer behind `head` (head_len bytes of text the caller already has: the unfinished line the previous block ended with).
 // The block's text is  head + the members' text  cut to text_len bytes (the caller keeps what follows the last line feed for the
 // next block); first_line: the block's first line without its line feed (the cell widths are read off it).
-static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
+static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int64_t file_offset, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
                            const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head, int64_t head_len,
                            int64_t text_len, const char *first_line, int64_t first_line_len, int fmt, int n_cols, int max_ploidy,
                            const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out) {
     const int chk = tok_check(c, slot, fmt, n_cols, max_ploidy, col_slot, col_ploidy, ok_out);
     if (chk < 0) return -chk;
     if (comp_len < 0 || comp_len >= (1ll << 32) || n_members < 0 || head_len < 0 || text_len < 0 || first_line_len < 0 ||
-        (n_members > 0 && (!comp || !in_off || !in_len || !out_len)) || (head_len > 0 && !head) || (first_line_len > 0 && !first_line))
+        (n_members > 0 && ((!comp && fd < 0) || file_offset < 0 || !in_off || !in_len || !out_len)) || (head_len > 0 && !head) ||
+        (first_line_len > 0 && !first_line))
         return pg_fail(PG_ERR_ARG, "pg_tokenize_submit_bgzf: bad argument");
     int64_t total = head_len;
     for (int64_t k = 0; k < n_members; ++k) {
@@ -519,7 +521,8 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int64_t com
     const size_t n_dw = ((size_t)comp_len + 3) / 4;
     if ((rc = T.inf.comp.ensure(n_dw + 1)) != PG_OK) return rc;
     if ((rc = T.h_total.ensure(8)) != PG_OK) return rc;
-    const TokSource src{reinterpret_cast<const char *>(comp), -1, 0};
+    // (from a file: the staging threads pread() the members from the page cache straight into their page-locked buffers)
+    const TokSource src{comp ? reinterpret_cast<const char *>(comp) : nullptr, comp ? -1 : fd, comp ? 0 : file_offset};
     if ((rc = stage_bytes(c, src, comp_len, reinterpret_cast<uint8_t *>(T.inf.comp.p))) != PG_OK) return rc;
     c->tok_stage_s += std::chrono::duration<double>(now() - t_stage0).count();
     c->tok_bytes += comp_len;
@@ -693,12 +696,12 @@ extern "C" int pg_tokenize_submit(pg_ctx *c, int slot, const char *text, int fd,
     return tok_submit(c, slot, src, len, fmt, n_cols, max_ploidy, col_slot, col_ploidy, ok_out);
 }
 
-extern "C" int pg_tokenize_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off,
+extern "C" int pg_tokenize_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int64_t file_offset, int64_t comp_len, const uint32_t *in_off,
                                        const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members,
                                        const char *head, int64_t head_len, int64_t text_len, const char *first_line,
                                        int64_t first_line_len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
                                        const int32_t *col_ploidy, int *ok_out) {
-    return tok_submit_bgzf(c, slot, comp, comp_len, in_off, in_len, out_len, crc, n_members, head, head_len, text_len, first_line,
+    return tok_submit_bgzf(c, slot, comp, fd, file_offset, comp_len, in_off, in_len, out_len, crc, n_members, head, head_len, text_len, first_line,
                            first_line_len, fmt, n_cols, max_ploidy, col_slot, col_ploidy, ok_out);
 }
 

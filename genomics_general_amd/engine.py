@@ -260,7 +260,8 @@ class Engine:
         in_off, in_len, out_len, crc = span.tab
         ok = C.c_int(0)
         vp = lambda a: C.c_void_p(a.ctypes.data)                            # noqa: E731
-        check(self._L.pg_tokenize_submit_bgzf(self._h, int(slot), vp(span.comp), len(span.comp), vp(in_off), vp(in_len), vp(out_len), vp(crc),
+        src = (None, int(span.file[0]), int(span.file[1])) if span.file is not None else (vp(span.comp), -1, 0)
+        check(self._L.pg_tokenize_submit_bgzf(self._h, int(slot), src[0], src[1], src[2], len(span.comp), vp(in_off), vp(in_len), vp(out_len), vp(crc),
                                               len(in_off), span.head, len(span.head), len(span), span.first_line, len(span.first_line),
                                               _lib.FMT[lay.genoFormat], len(lay.col_ploidy), lay.max_ploidy,
                                               np.ascontiguousarray(lay.col_slot), lay.col_ploidy, C.byref(ok)))

@@ -116,8 +116,9 @@ class BgzfSpan:
     text).  Engine.tokenize_submit_bgzf sends the members to the device as they are and inflates them there; bytes(span) inflates
     them on the host (a block the device tokenizer does not take)."""
 
-    def __init__(self, head, comp, tab, text_len, first_line):
+    def __init__(self, head, comp, tab, text_len, first_line, file=None):
         self.head, self.comp, self.tab, self.text_len, self.first_line = head, comp, tab, text_len, first_line
+        self.file = file                  # (file descriptor, offset of comp in the file) when comp is a view of the memory-mapped file
 
     def __len__(self):
         return self.text_len
@@ -155,7 +156,8 @@ class BgzfFile:
         self.stop = None                 # (member file offset, bytes of that member to keep): where a rank's share ends
         self.size = os.path.getsize(path)
         self._next_read = 1 << 16
-        self._ratio = 8.0                # text bytes per compressed byte, as seen so far (read_span sizes its reads with it)
+        self._ratio = 8.0                # text bytes per compressed byte, as seen so far (read_span sizes its looks with it)
+        self.mm = self.mv = None         # read_span: the file memory-mapped
 
     @staticmethod
     def is_bgzf(path):
@@ -241,52 +243,55 @@ class BgzfFile:
         """The next block of about nbytes of text as a BgzfSpan (its members still deflated), cut behind its last line feed; bytes
         when nothing compressed is left (the end of the input or of this reader's share: possibly without a final line feed), b""
         at the end.  What follows the block's last line feed stays buffered as the head of the next block; finding it costs one
-        member inflated on the host (the last), the block's first line another."""
+        member inflated on the host (the last), the block's first line another.  The members are looked at where they lie in the
+        page cache (a memory map of the file: the walk reads their headers and trailers, nothing is copied); the engine's staging
+        threads read them from the file themselves."""
+        import zlib
         head = bytes(self.buf)
         self.buf = bytearray()
         if self.eof:
             return head
+        if self.mm is None:
+            import mmap
+            self.mm = mmap.mmap(self.raw.fileno(), 0, access=mmap.ACCESS_READ)
+            self.mv = memoryview(self.mm)
+        self.pending = b""                               # (compressed bytes an earlier read() fetched but did not inflate: still in the map)
         want = max(int(nbytes) - len(head), 1 << 16)
-        data = self.pending
-        self.pending = b""
-        file_done = False
+        end = self.size if self.stop is None else min(self.stop[0], self.size)
+        span = max(int(want / self._ratio * 1.05), 1 << 20)
         while True:
-            limit, stop_here = len(data), False
-            if self.stop is not None and self.cpos + limit > self.stop[0]:
-                limit, stop_here = max(self.stop[0] - self.cpos, 0), True
-            tab, used, text = bgzf_walk(data, limit, want)
-            if text >= want or stop_here or file_done:
+            limit = min(self.cpos + span, end)
+            try:                                         # MADV_POPULATE_READ: one call maps the pages the walk is about to touch
+                lo = self.cpos & ~4095
+                self.mm.madvise(22, lo, limit - lo)
+            except (OSError, ValueError, AttributeError):
+                pass
+            data = self.mv[self.cpos:limit]
+            tab, used, text = bgzf_walk(data, None, want)
+            if text >= want or limit == end:
                 break
-            more = self.raw.read(max(int((want - text) / self._ratio * 1.1), 1 << 20))
-            if not more:
-                file_done = True
-            else:
-                data = data + more if len(data) else more
+            span = max(int(span * max(want / max(text, 1), 1.0) * 1.05), span + (1 << 20))
         in_off, in_len, out_len, crc = tab
         n = len(in_off)
-        reached_stop = stop_here and used == limit
-        if (file_done and used != len(data)) or (stop_here and text < want and used != limit):
+        if text < want and self.cpos + used != end:
             raise ValueError("truncated BGZF input")
         if n:
             self._ratio = max(text / max(used, 1), 1.0)
-        tail_extra = b""
-        if reached_stop:
-            self.eof = True
-            if self.stop[1] > 0:
-                tail_extra = self._stop_member(data, limit)
-        elif file_done and used == len(data):
-            self.eof = True
-        if not self.eof:
-            self.pending = bytes(data[used:]) if used < len(data) else b""
+        file_off = self.cpos
         self.cpos += used
+        tail_extra = b""
+        if self.cpos == end:
+            self.eof = True
+            if self.stop is not None and self.stop[0] < self.size and self.stop[1] > 0:
+                tail_extra = self._stop_member(bytes(self.mv[end:min(end + (1 << 16), self.size)]), 0)
+        self.raw.seek(self.cpos)
+        if n == 0:                                       # nothing compressed left (the end of the input / of the share)
+            return head + tail_extra
 
         def member_text(k):
             a = int(in_off[k])
-            import zlib
-            return zlib.decompress(bytes(data[a:a + int(in_len[k])]), wbits=-15)
+            return zlib.decompress(data[a:a + int(in_len[k])], wbits=-15)
 
-        if n == 0:                                       # nothing compressed left (the end of the input / of the share)
-            return head + tail_extra
         # the block ends behind the last line feed of its members' text: walk back from the last member
         tail, k, found = [], n - 1, False
         while k >= 0 and n - k <= 64:
@@ -300,7 +305,7 @@ class BgzfFile:
             k -= 1
         if not found:
             # no line ends in the last members (lines of megabytes): this block is inflated on the host and handed on as text
-            body = head + bgzf_inflate(data, tab, self.n_threads).tobytes() + tail_extra
+            body = head + bgzf_inflate(data[:used], tab, self.n_threads).tobytes() + tail_extra
             if self.eof:
                 return body
             cut = body.rfind(b"\n") + 1
@@ -324,7 +329,7 @@ class BgzfFile:
                 first += t
                 k += 1
         comp = np.frombuffer(data, dtype=np.uint8)[:used]
-        return BgzfSpan(head, comp, (in_off, in_len, out_len, crc), text_len, first)
+        return BgzfSpan(head, comp, (in_off, in_len, out_len, crc), text_len, first, file=(self.raw.fileno(), file_off))
 
     def set_stop(self, coffset, uoffset):
         """end this reader's share at byte `uoffset` of the member at file offset `coffset` (which may already be buffered)"""
@@ -421,6 +426,12 @@ class BgzfFile:
             self._refill(1)
 
     def close(self):
+        if self.mm is not None:
+            try:
+                self.mv.release()
+                self.mm.close()
+            except BufferError:            # a span is still referenced somewhere: the mapping goes with its last view
+                pass
         self.raw.close()
 
 

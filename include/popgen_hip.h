@@ -292,14 +292,16 @@ int pg_bgzf_compress(const uint8_t *text, int64_t len, int level, int block, int
  * be NULL): device time of the kernels.  PG_ERR_PARSE names the first damaged member. */
 int pg_inflate_device(pg_ctx *ctx, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
                       const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *dst, double *kernel_ms_out);
-/* The submit step of the device tokenizer (pg_tokenize_submit) for a block that is still deflated: the members cross PCIe as they
+/* The submit step of the device tokenizer (pg_tokenize_submit) for a block that is still deflated -- comp[0 .. comp_len), or with
+ * comp == NULL the comp_len bytes at file_offset of fd (read by the staging threads with pread) --: the members cross PCIe as they
  * are (10 - 26 x fewer bytes than their text) and are inflated into the slot's text buffer behind `head` (head_len bytes of text the
  * caller already holds: the unfinished line the previous block ended with).  The block's text = head + the members' text, cut to
  * text_len bytes (it must end with a line feed; the caller keeps what follows for the next block).  first_line: the block's first
  * line without its line feed (the cell widths are read off it).  parse / collect as for plain text; a damaged member makes
  * pg_tokenize_parse fail with PG_ERR_PARSE.  pg_tokenize_run_names reads the scaffold names of the runs pg_tokenize_collect reported
  * (offsets / lengths in the block's text) back from the device, one after the other into out: the host never had that text. */
-int pg_tokenize_submit_bgzf(pg_ctx *ctx, int slot, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
+int pg_tokenize_submit_bgzf(pg_ctx *ctx, int slot, const uint8_t *comp, int fd, int64_t file_offset, int64_t comp_len,
+                            const uint32_t *in_off, const uint32_t *in_len,
                             const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head, int64_t head_len,
                             int64_t text_len, const char *first_line, int64_t first_line_len, int fmt, int n_cols, int max_ploidy,
                             const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out);
