@@ -363,8 +363,8 @@ class Run:
             except BaseException as exc:
                 put(prepared, exc)
 
-        threading.Thread(target=produce, daemon=True).start()
-        threading.Thread(target=prepare, daemon=True).start()
+        threading.Thread(target=produce, daemon=True, name="reader").start()
+        threading.Thread(target=prepare, daemon=True, name="prepare").start()
 
         def take(block=True):
             try:
@@ -546,6 +546,8 @@ class Run:
 
         if hasattr(eng, "tokenize_submit_bgzf") and hasattr(self._reader, "spans") and os.environ.get("PG_BGZF_DEVICE", "1") != "0":
             self._reader.spans = True                 # bgzip-compressed text arrives as blocks of deflated members
+            if isinstance(self._reader.f, genoio.BgzfFile) and hasattr(eng, "pinned"):
+                self._reader.f.alloc = eng.pinned.empty   # ... read straight into page-locked buffers: one DMA each
         # a block of a memory-mapped file is a view, a block of raw `.pgeno` cells a list of file offsets: nothing to read ahead
         mapped = getattr(self._reader, "mm", None) is not None or bool(getattr(self._reader, "packed", False))
         done_reading = []
@@ -687,8 +689,8 @@ class Run:
                 put(ready, exc)
 
         if not mapped:
-            threading.Thread(target=produce, daemon=True).start()
-        threading.Thread(target=ingest, daemon=True).start()
+            threading.Thread(target=produce, daemon=True, name="reader").start()
+        threading.Thread(target=ingest, daemon=True, name="ingest").start()
         self.timing["device_tokenizer"] = 1
         self.timing["packed_cells_from_file"] = int(packed)
         self.timing["host_tokenized_blocks"] = 0
@@ -763,6 +765,10 @@ class Run:
             if t.get("device_tokenizer") and hasattr(self.engine, "tokenize_stats"):
                 ts = self.engine.tokenize_stats()            # inside tokenize_s: the copies of the text (PCIe) and the kernels behind them
                 t["tokenizer_h2d_s"], t["tokenizer_kernels_s"], t["tokenizer_bytes"] = ts["h2d_s"], ts["kernels_s"], ts["bytes"]
+            calls = getattr(getattr(self.engine, "_L", None), "calls", None)
+            if calls:                                        # C-ABI calls per thread: [calls, seconds], the dozen largest
+                top = sorted(calls.items(), key=lambda kv: -kv[1][1])[:14]
+                t["lib_calls"] = {"%s:%s" % k: [v[0], round(v[1], 4)] for k, v in top}
             # (the stages overlap when tokenize_s + windows_s + compute_and_write_s > total_s - context_s)
             sys.stderr.write("PG_TIMING " + json.dumps(t) + "\n")
 
@@ -981,11 +987,15 @@ def popgen_main(argv=None):
     sink = run.open_sink(args.outFile, ("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites," + ",".join(stats) + "\n",
                          id_column=args.addWindowID)
     last_row = None                      # (ok, text) of the previously emitted window: a dup row repeats it verbatim
+    import time
+    tm = run.timing
+    tm.update(main_stats_s=0.0, main_refine_s=0.0, main_format_s=0.0)    # where the main thread's time goes inside a chunk (PG_TIMING)
     for _ in run.chunks():
         T = run.T
         sites_local = T.sites[run.w0:run.w1]
         good = sites_local >= minSites
         table = np.full((run.w1 - run.w0, len(stats)), np.nan)
+        t_c = time.perf_counter()
         if np.any(good) and stats:
             wb = run.batch(good)
             sd = {}
@@ -995,7 +1005,9 @@ def popgen_main(argv=None):
                 def dist_stats(b):
                     return b.groupDistStats(doPairs="popPairDist" in args.analysis, minSites=minSites, minData=args.minData)
                 gd = dist_stats(wb)
+                t_r = time.perf_counter()
                 _refine_long_windows(run, good, sites_local, gd, args.roundTo, dist_stats)
+                tm["main_refine_s"] += time.perf_counter() - t_r
                 sd.update(gd)
             if "indPairDist" in args.analysis:
                 pdd = wb.indPairDists()
@@ -1008,9 +1020,11 @@ def popgen_main(argv=None):
                 sd.update(wb.H12stats(maxDist=args.hapDist))
             for c, s in enumerate(stats):
                 table[good, c] = sd[s]
+        tm["main_stats_s"] += time.perf_counter() - t_c
         full = run.gather(table)
         if not sink.local:
             continue
+        t_c = time.perf_counter()
         for k in range(T.n):
             if T.dup[k]:
                 ok, text = last_row
@@ -1029,6 +1043,7 @@ def popgen_main(argv=None):
             if not (ok or args.writeFailedWindows):
                 continue
             sink.write(text)
+        tm["main_format_s"] += time.perf_counter() - t_c
     tested, written = sink.close()
     if run.world.rank == 0:
         sys.stderr.write(str(tested) + " windows were tested.\n")
@@ -1424,7 +1439,7 @@ def freq_main(argv=None):
             except BaseException as exc:
                 ready.put(exc)
 
-        threading.Thread(target=prepare, daemon=True).start()
+        threading.Thread(target=prepare, daemon=True, name="prepare").start()
         while True:
             data = ready.get()
             if data is None:

@@ -172,6 +172,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
         drop(T.inf);
         if (k == 0) drop(c->inf);
         if (T.counted) (void)hipEventDestroy(T.counted);
+        if (T.staged) (void)hipEventDestroy(T.staged);
     }
     c->tok_pin.release();
     drop_events(c);

@@ -130,7 +130,7 @@ struct pg_ctx {
         HostPin<int64_t> h_total;          // page-locked landing: [0] lines, [1] status | runs
         HostPin<int32_t> h_pos, h_cols;
         std::vector<int32_t> cols;         // col_slot | col_ploidy | cell offsets | cell widths of the submitted block
-        hipEvent_t counted = nullptr;
+        hipEvent_t counted = nullptr, staged = nullptr;   // line feeds counted / deflated bytes on the device
         int state = 0;                     // 0 idle, 1 empty block, 2 submitted, 3 parse queued, 4 empty result
         int fmt = 0, n_cols = 0, max_ploidy = 0, cells_w = 0;
         int64_t len = 0, n_lines = 0, n_tiles = 0, run_cap = 0;

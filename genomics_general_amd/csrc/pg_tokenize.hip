@@ -521,9 +521,25 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
     const size_t n_dw = ((size_t)comp_len + 3) / 4;
     if ((rc = T.inf.comp.ensure(n_dw + 1)) != PG_OK) return rc;
     if ((rc = T.h_total.ensure(8)) != PG_OK) return rc;
-    // (from a file: the staging threads pread() the members from the page cache straight into their page-locked buffers)
-    const TokSource src{comp ? reinterpret_cast<const char *>(comp) : nullptr, comp ? -1 : fd, comp ? 0 : file_offset};
-    if ((rc = stage_bytes(c, src, comp_len, reinterpret_cast<uint8_t *>(T.inf.comp.p))) != PG_OK) return rc;
+    bool pinned = false;
+    if (comp) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, comp) == hipSuccess) pinned = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();                                // (pageable memory: not an error)
+    }
+    if (pinned) {
+        // page-locked bytes (the reader thread filled a buffer of the engine's pool): ONE asynchronous DMA on a copy stream of its own,
+        // beside the kernels of the previous block; the caller keeps the buffer alive until it has collected this block
+        if (!c->tok_st[0]) HIPCHK(hipStreamCreateWithFlags(&c->tok_st[0], hipStreamNonBlocking));
+        if (!T.staged) HIPCHK(hipEventCreateWithFlags(&T.staged, hipEventDisableTiming));
+        HIPCHK(hipMemcpyAsync(T.inf.comp.p, comp, (size_t)comp_len, hipMemcpyHostToDevice, c->tok_st[0]));
+        HIPCHK(hipEventRecord(T.staged, c->tok_st[0]));
+        HIPCHK(hipStreamWaitEvent(st, T.staged, 0));
+    } else {
+        // (from a file: the staging threads pread() the members from the page cache straight into their page-locked buffers)
+        const TokSource src{comp ? reinterpret_cast<const char *>(comp) : nullptr, comp ? -1 : fd, comp ? 0 : file_offset};
+        if ((rc = stage_bytes(c, src, comp_len, reinterpret_cast<uint8_t *>(T.inf.comp.p))) != PG_OK) return rc;
+    }
     c->tok_stage_s += std::chrono::duration<double>(now() - t_stage0).count();
     c->tok_bytes += comp_len;
     if (head_len) {

@@ -100,11 +100,37 @@ class PinnedPool:
         return arr
 
 
+class _TimedLib:
+    """PG_TIMING=1: the library behind a proxy that adds up calls and wall seconds per entry point and thread (cli.Run.report_timing
+    prints them as "lib_calls": where a driver's time goes between Python and the C-ABI)"""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self.calls = {}                  # (thread name, function) -> [calls, seconds]
+
+    def __getattr__(self, name):
+        import threading
+        import time
+        fn = getattr(self._lib, name)
+
+        def timed(*args):
+            t0 = time.perf_counter()
+            try:
+                return fn(*args)
+            finally:
+                slot = self.calls.setdefault((threading.current_thread().name, name), [0, 0.0])
+                slot[0] += 1
+                slot[1] += time.perf_counter() - t0
+        setattr(self, name, timed)
+        return timed
+
+
 class Engine:
     """One device context (pg_ctx).  Not thread-safe; one per GPU."""
 
     def __init__(self, device=0):
-        self._L = _lib.lib()
+        import os
+        self._L = _TimedLib(_lib.lib()) if os.environ.get("PG_TIMING") else _lib.lib()
         h = C.c_void_p()
         check(self._L.pg_ctx_create(C.byref(h), device))
         self._h = h

@@ -118,7 +118,7 @@ class BgzfSpan:
 
     def __init__(self, head, comp, tab, text_len, first_line, file=None):
         self.head, self.comp, self.tab, self.text_len, self.first_line = head, comp, tab, text_len, first_line
-        self.file = file                  # (file descriptor, offset of comp in the file) when comp is a view of the memory-mapped file
+        self.file = file                  # (file descriptor, offset of comp in the file): the engine's staging threads then read the members themselves
 
     def __len__(self):
         return self.text_len
@@ -156,8 +156,8 @@ class BgzfFile:
         self.stop = None                 # (member file offset, bytes of that member to keep): where a rank's share ends
         self.size = os.path.getsize(path)
         self._next_read = 1 << 16
-        self._ratio = 8.0                # text bytes per compressed byte, as seen so far (read_span sizes its looks with it)
-        self.mm = self.mv = None         # read_span: the file memory-mapped
+        self._ratio = 12.0               # text bytes per compressed byte, as seen so far (read_span sizes its reads with it)
+        self.alloc = np.empty            # read_span: allocator of the buffers the members are read into (the engine's page-locked pool)
 
     @staticmethod
     def is_bgzf(path):
@@ -243,30 +243,29 @@ class BgzfFile:
         """The next block of about nbytes of text as a BgzfSpan (its members still deflated), cut behind its last line feed; bytes
         when nothing compressed is left (the end of the input or of this reader's share: possibly without a final line feed), b""
         at the end.  What follows the block's last line feed stays buffered as the head of the next block; finding it costs one
-        member inflated on the host (the last), the block's first line another.  The members are looked at where they lie in the
-        page cache (a memory map of the file: the walk reads their headers and trailers, nothing is copied); the engine's staging
-        threads read them from the file themselves."""
+        member inflated on the host (the last), the block's first line another."""
         import zlib
         head = bytes(self.buf)
         self.buf = bytearray()
         if self.eof:
             return head
-        if self.mm is None:
-            import mmap
-            self.mm = mmap.mmap(self.raw.fileno(), 0, access=mmap.ACCESS_READ)
-            self.mv = memoryview(self.mm)
-        self.pending = b""                               # (compressed bytes an earlier read() fetched but did not inflate: still in the map)
+        self.pending = b""                               # (compressed bytes an earlier read() fetched but did not inflate are read again)
         want = max(int(nbytes) - len(head), 1 << 16)
         end = self.size if self.stop is None else min(self.stop[0], self.size)
         span = max(int(want / self._ratio * 1.05), 1 << 20)
+        fd = self.raw.fileno()
         while True:
             limit = min(self.cpos + span, end)
-            try:                                         # MADV_POPULATE_READ: one call maps the pages the walk is about to touch
-                lo = self.cpos & ~4095
-                self.mm.madvise(22, lo, limit - lo)
-            except (OSError, ValueError, AttributeError):
-                pass
-            data = self.mv[self.cpos:limit]
+            # the members go into a buffer of the engine's page-locked pool when there is one (self.alloc): the copy to the device is
+            # then one asynchronous DMA out of this very buffer, queued by the ingestion thread while this thread reads the next block
+            buf = self.alloc((max(limit - self.cpos, 1),), np.uint8)
+            view, got = memoryview(buf).cast("B"), 0
+            while got < limit - self.cpos:
+                k = os.preadv(fd, [view[got:min(got + (1 << 30), limit - self.cpos)]], self.cpos + got)
+                if k <= 0:
+                    raise ValueError("truncated BGZF input")
+                got += k
+            data = view[:got]
             tab, used, text = bgzf_walk(data, None, want)
             if text >= want or limit == end:
                 break
@@ -277,14 +276,13 @@ class BgzfFile:
             raise ValueError("truncated BGZF input")
         if n:
             self._ratio = max(text / max(used, 1), 1.0)
-        file_off = self.cpos
         self.cpos += used
         tail_extra = b""
+        self.raw.seek(self.cpos)
         if self.cpos == end:
             self.eof = True
             if self.stop is not None and self.stop[0] < self.size and self.stop[1] > 0:
-                tail_extra = self._stop_member(bytes(self.mv[end:min(end + (1 << 16), self.size)]), 0)
-        self.raw.seek(self.cpos)
+                tail_extra = self._stop_member(self.raw.read(1 << 16), 0)
         if n == 0:                                       # nothing compressed left (the end of the input / of the share)
             return head + tail_extra
 
@@ -328,8 +326,7 @@ class BgzfFile:
                     break
                 first += t
                 k += 1
-        comp = np.frombuffer(data, dtype=np.uint8)[:used]
-        return BgzfSpan(head, comp, (in_off, in_len, out_len, crc), text_len, first, file=(self.raw.fileno(), file_off))
+        return BgzfSpan(head, buf[:used], (in_off, in_len, out_len, crc), text_len, first)
 
     def set_stop(self, coffset, uoffset):
         """end this reader's share at byte `uoffset` of the member at file offset `coffset` (which may already be buffered)"""
@@ -426,12 +423,6 @@ class BgzfFile:
             self._refill(1)
 
     def close(self):
-        if self.mm is not None:
-            try:
-                self.mv.release()
-                self.mm.close()
-            except BufferError:            # a span is still referenced somewhere: the mapping goes with its last view
-                pass
         self.raw.close()
 
 
