@@ -655,7 +655,7 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
     return t2
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, script=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, the environment a launcher would
     set), pass rank 0's JSON line through and wait for all of them.  No torch anywhere."""
     import socket
@@ -667,11 +667,28 @@ def spawn_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    PG_RDZV_FILE="/tmp/pg_rdzv_bench_%d_%d" % (os.getpid(), port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    # all children are watched: the first one that ends with an error ends the launch (the others would wait for it at the next
+    # exchange; the drivers stop by themselves when a peer leaves a failure marker, bench.py's ranks are stopped here)
+    rc, live = 0, dict(enumerate(procs))
+    while live and rc == 0:
+        for r, p in list(live.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del live[r]
+            if code != 0:
+                rc = abs(code)
+                sys.stderr.write("bench.py: rank %d ended with exit code %d; stopping the other %d ranks\n" % (r, code, len(live)))
+        time.sleep(0.05)
+    for p in live.values():
+        p.terminate()
+    for p in live.values():
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
     return rc
 
 

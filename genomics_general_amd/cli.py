@@ -897,9 +897,34 @@ def _refine_long_windows(run, good, sites_local, sd, digits, again, ratio_keys=(
     run.timing["windows_recomputed_in_numpy_order"] = run.timing.get("windows_recomputed_in_numpy_order", 0) + int(flagged.sum())
 
 
+def guarded_main(fn):
+    """A driver's entry point under a multi-rank launch: whatever ends this rank -- a parse error in its share of the input, an
+    assertion, a failed library call -- is left as a marker next to the launch's rendezvous file (dist.mark_failed) before it
+    propagates, and every wait of the other ranks (the exchange of the shard plan, the gather of the rows, the final barrier) looks
+    for such markers: they stop within a fraction of a second with one line naming the failed rank, instead of hanging the way the
+    reference does when a worker dies (popgenWindows.py:456-460) or sitting out PG_COMM_TIMEOUT."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(argv=None):
+        try:
+            return fn(argv)
+        except BaseException as exc:
+            world = dist.world_from_env()
+            if world.size > 1 and not (isinstance(exc, SystemExit) and exc.code in (0, None)):
+                dist.mark_failed(world, exc)
+                if isinstance(exc, dist.PeerFailed):
+                    sys.stderr.write("rank %d stops: %s\n" % (world.rank, exc))
+                    sys.stderr.flush()
+                    os._exit(3)                     # (helper threads of the ingestion may still be inside the library)
+            raise
+    return wrapper
+
+
 # ==========================================================================================================
 # popgenWindows.py
 # ==========================================================================================================
+@guarded_main
 def popgen_main(argv=None):
     ap = argparse.ArgumentParser(prog="popgenWindows.py", epilog=ENGINE_EPILOG)
     _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined"))})
@@ -1060,10 +1085,12 @@ def popgen_main(argv=None):
 FOURPOP_STATS = ["ABBA", "BABA", "ABAA", "BAAA", "D", "fd", "fd'", "fdm", "fdm'", "fdh", "fdh2", "fh"]   # fourPopWindows.py:241
 
 
+@guarded_main
 def abbababa_main(argv=None):
     return _quartet_main(argv, "ABBABABAwindows.py", ["ABBA", "BABA", "D", "fd", "fdM"], fourpop=False)
 
 
+@guarded_main
 def fourpop_main(argv=None):
     """fourPopWindows.py:105-150 flag table; statistics genomics.py:1585-1643."""
     return _quartet_main(argv, "fourPopWindows.py", FOURPOP_STATS, fourpop=True)
@@ -1184,6 +1211,7 @@ def _matrix_text(M, names, fmt, roundTo):
     return s + ";\nEND; [Distances]\n"
 
 
+@guarded_main
 def distmat_main(argv=None):
     ap = argparse.ArgumentParser(prog="distMat.py", epilog=ENGINE_EPILOG)
     _add(ap, WINDOW_FLAGS, **{"--windType": dict(choices=("sites", "coordinate", "predefined", "cat"))})      # -m: default 1 (distMat.py:123)
@@ -1312,6 +1340,7 @@ def distmat_main(argv=None):
 # ==========================================================================================================
 # freq.py  (SURVEY.md 8f "next" row 1: the raw output of the per-site population count kernel as a TSV)
 # ==========================================================================================================
+@guarded_main
 def freq_main(argv=None):
     """Drop-in for the reference's freq.py (freq.py:30-113, 192-300): per-site per-population base counts, or the
     frequency / count of a target allele (`--target derived|minor`).  Counts come from k_site_counts (pg_site_counts).

@@ -514,6 +514,9 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
     int rc;
     auto now = [] { return std::chrono::steady_clock::now(); };
     const auto t_stage0 = now();
+    static const bool trace = getenv("PG_TOK_TRACE") != nullptr;
+    double tr[6] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&](int k) { if (trace) tr[k] = std::chrono::duration<double>(now() - t_stage0).count() * 1e3; };
     if ((rc = T.text.ensure((size_t)total + 64)) != PG_OK) return rc;
     T.tp = T.text.p;                                                 // (hipMalloc aligns to 256 bytes; the members' text starts at any byte)
     // (the slot's buffers are free: the block that used them last has been collected.  Bytes behind comp_len in the last dword are
@@ -521,6 +524,7 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
     const size_t n_dw = ((size_t)comp_len + 3) / 4;
     if ((rc = T.inf.comp.ensure(n_dw + 1)) != PG_OK) return rc;
     if ((rc = T.h_total.ensure(8)) != PG_OK) return rc;
+    lap(0);
     bool pinned = false;
     if (comp) {
         hipPointerAttribute_t attr;
@@ -540,6 +544,7 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
         const TokSource src{comp ? reinterpret_cast<const char *>(comp) : nullptr, comp ? -1 : fd, comp ? 0 : file_offset};
         if ((rc = stage_bytes(c, src, comp_len, reinterpret_cast<uint8_t *>(T.inf.comp.p))) != PG_OK) return rc;
     }
+    lap(1);
     c->tok_stage_s += std::chrono::duration<double>(now() - t_stage0).count();
     c->tok_bytes += comp_len;
     if (head_len) {
@@ -547,9 +552,13 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
         memcpy(T.h_head.p, head, (size_t)head_len);
         HIPCHK(hipMemcpyAsync(T.tp, T.h_head.p, (size_t)head_len, hipMemcpyHostToDevice, st));
     }
+    lap(2);
     if ((rc = pg_inflate_queue(c, st, T.inf, T.inf.comp.p, (uint32_t)n_dw, in_off, in_len, out_len, crc, n_members, T.tp + head_len)) != PG_OK) return rc;
+    lap(3);
     HIPCHK(hipMemcpyAsync(T.h_total.p + 2, T.inf.status.p, 8, hipMemcpyDeviceToHost, st));     // [error bits, first bad member]: read by parse
     if ((rc = tok_count(c, T, text_len)) != PG_OK) return rc;
+    lap(4);
+    if (trace) fprintf(stderr, "PG_TOK_TRACE submit_bgzf slot %d pinned %d: alloc %.2f copy %.2f head %.2f inflate_queue %.2f count_queue %.2f ms\n", slot, (int)pinned, tr[0], tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3]);
     *ok_out = 1;
     return PG_OK;
 }

@@ -87,13 +87,74 @@ def exchange_unique_id(world, make_id, timeout_s=180.0):
                 uid = f.read()
             if len(uid) == 128:
                 return uid, path
-            if uid.startswith(b"RCCL-FAILED"):           # rank 0 could not create the id: nobody waits for it (make_comm)
+            if uid.startswith(b"RCCL-FAILED") and os.path.getmtime(path) >= _T_START - 120.0:
+                # rank 0 could not create the id: nobody waits for it (make_comm).  (An older marker is the leftover of a launch
+                # that failed under the same rendezvous name: this launch's rank 0 is about to replace it.)
                 raise RuntimeError("rank 0 reported: " + uid.decode("utf-8", "replace")[:200])
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout_s:
             raise TimeoutError("rank %d: no RCCL unique id at %s after %.0f s" % (world.rank, path, timeout_s))
+        check_peers(world)
         time.sleep(0.01)
+
+
+# ---- a rank that fails tells the others (the reference's worst habit is to hang on a worker's error, popgenWindows.py:456-460) ----
+_T_START = time.time()
+
+
+class PeerFailed(RuntimeError):
+    """another rank of this launch has failed: this one stops at once instead of waiting for it at the next exchange"""
+
+
+def _failure_glob():
+    return _rdzv_path() + ".failed_r"
+
+
+def mark_failed(world, exc):
+    """leave `<rendezvous>.failed_r<rank>` with the reason (drivers: cli.guarded_main); PeerFailed is not marked again"""
+    if world.size <= 1 or isinstance(exc, PeerFailed):
+        return
+    try:
+        path = _failure_glob() + str(world.rank)
+        with open(path + ".tmp", "w") as f:
+            f.write("%s: %s" % (type(exc).__name__, str(exc)[:300]))
+        os.replace(path + ".tmp", path)
+    except OSError:
+        pass
+
+
+def clear_failures(world):
+    """rank 0, before it opens the launch's rendezvous: markers a dead launch left under the same name"""
+    import glob
+    for path in glob.glob(_failure_glob() + "*"):
+        try:
+            if os.path.getmtime(path) < _T_START - 1.0:
+                os.remove(path)
+        except OSError:
+            pass
+
+
+def peer_failure(world):
+    """"rank R failed: reason" of the first marker another rank of THIS launch has left, else None.  A marker older than two minutes
+    before this process started belongs to an earlier launch under the same rendezvous name and is ignored."""
+    import glob
+    for path in sorted(glob.glob(_failure_glob() + "[0-9]*")):
+        try:
+            r = int(path[len(_failure_glob()):])
+            if r == world.rank or os.path.getmtime(path) < _T_START - 120.0:
+                continue
+            with open(path) as f:
+                return "rank %d failed: %s" % (r, f.read()[:300])
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def check_peers(world):
+    msg = peer_failure(world)
+    if msg:
+        raise PeerFailed(msg)
 
 
 # ---- communicators (same small interface) ------------------------------------------------------------------
@@ -115,7 +176,10 @@ class RcclComm:
 
     def __init__(self, engine, world):
         from .engine import Engine
-        self.e, self.size, self.rank = engine, world.size, world.rank
+        self.e, self.size, self.rank, self.world = engine, world.size, world.rank, world
+        self.timeout_s = float(os.environ.get("PG_COMM_TIMEOUT", "300"))
+        if world.rank == 0:
+            clear_failures(world)
         # RCCL prints a version banner on file descriptor 1 while it initialises; the drivers' stdout carries data (CSV, the
         # benchmark's JSON line), so fd 1 is pointed at stderr for the duration of the initialisation
         import sys
@@ -124,8 +188,8 @@ class RcclComm:
         os.dup2(2, 1)
         try:
             uid, path = exchange_unique_id(world, Engine.comm_unique_id)
-            engine.comm_setup(world.size, world.rank, uid)
-            engine.comm_barrier()
+            self._guarded(engine.comm_setup, world.size, world.rank, uid)
+            self._guarded(engine.comm_barrier)
         finally:
             os.dup2(saved, 1)
             os.close(saved)
@@ -135,11 +199,42 @@ class RcclComm:
             except OSError:
                 pass
 
+    def _guarded(self, fn, *args):
+        """A collective whose peer has died never returns (ncclAllGather blocks in hipStreamSynchronize for good): it runs on a helper
+        thread while this one watches for a failed peer and for PG_COMM_TIMEOUT; then the rank says why and leaves -- the
+        communicator cannot be used again, and a thread stuck in the runtime cannot be joined."""
+        import sys
+        import threading
+        box = {}
+
+        def run():
+            try:
+                box["v"] = fn(*args)
+            except BaseException as exc:
+                box["e"] = exc
+        th = threading.Thread(target=run, daemon=True, name="collective")
+        th.start()
+        t0 = time.time()
+        while True:
+            th.join(0.05)
+            if not th.is_alive():
+                break
+            why = peer_failure(self.world)
+            if why is None and time.time() - t0 > self.timeout_s:
+                why = "no answer from the other ranks within PG_COMM_TIMEOUT = %.0f s" % self.timeout_s
+            if why is not None:
+                sys.stderr.write("rank %d: leaving the collective: %s\n" % (self.rank, why))
+                sys.stderr.flush()
+                os._exit(3)
+        if "e" in box:
+            raise box["e"]
+        return box["v"]
+
     def allgather(self, arr):
-        return self.e.comm_allgather(arr)
+        return self._guarded(self.e.comm_allgather, arr)
 
     def barrier(self):
-        self.e.comm_barrier()
+        self._guarded(self.e.comm_barrier)
 
     def close(self):
         pass
@@ -161,7 +256,10 @@ class FileComm:
         import uuid
         if timeout_s is None:
             timeout_s = float(os.environ.get("PG_COMM_TIMEOUT", "300"))        # how long a rank waits for the others at an exchange
-        self.size, self.rank, self.timeout_s = world.size, world.rank, timeout_s
+        self.size, self.rank, self.timeout_s, self.world = world.size, world.rank, timeout_s, world
+        self._last_check = 0.0
+        if world.rank == 0:
+            clear_failures(world)
         base = _rdzv_path()
         self.pointer = base + ".dir"
         self.seq = 0
@@ -180,8 +278,19 @@ class FileComm:
                             pass
                 if time.time() - t0 > timeout_s:
                     raise TimeoutError("rank 0: only %d of %d ranks arrived at %s" % (1 + len(tokens), self.size, self.dir))
+                self._watch()
                 time.sleep(0.0005)
             self._put(os.path.join(self.dir, "go"), json.dumps({str(r): t for r, t in tokens.items()}).encode())
+            # every rank is here, so every rank has read the "RCCL-FAILED" note this rank may have left in the hand-over file of the
+            # unique id (exchange_unique_id): it must not outlive the launch (the next launch under the same
+            # MASTER_ADDR / MASTER_PORT would read it before its own rank 0 has replaced it)
+            try:
+                with open(base, "rb") as f:
+                    stale = f.read(11) == b"RCCL-FAILED"
+                if stale:
+                    os.remove(base)
+            except OSError:
+                pass
             return
         token, said = uuid.uuid4().hex, set()
         while True:
@@ -200,7 +309,16 @@ class FileComm:
                 pass
             if time.time() - t0 > timeout_s:
                 raise TimeoutError("rank %d: rank 0 never opened an exchange directory through %s" % (self.rank, self.pointer))
+            self._watch()
             time.sleep(0.0005)
+
+    def _watch(self):
+        """inside every wait loop: a rank that has failed (cli.guarded_main leaves a marker) ends the wait at once; looked for 20
+        times a second"""
+        now = time.time()
+        if now - self._last_check >= 0.05:
+            self._last_check = now
+            check_peers(self.world)
 
     @staticmethod
     def _put(path, data):
@@ -224,6 +342,7 @@ class FileComm:
             while not os.path.exists(path):
                 if time.time() - t0 > self.timeout_s:
                     raise TimeoutError("rank %d: rank %d never arrived at exchange %d (%s)" % (self.rank, r, self.seq, path))
+                self._watch()
                 time.sleep(0.0005)
             rows.append(a if r == self.rank else np.load(path))
         # everybody has passed exchange seq-1 once its files of exchange seq exist: the own file of seq-1 can go
@@ -243,6 +362,10 @@ class FileComm:
         rank leaves a marker, rank 0 waits for all markers and removes the directory and the pointer to it."""
         self.barrier()
         with open(os.path.join(self.dir, "done_r%d" % self.rank), "w"):
+            pass
+        try:
+            os.remove(_failure_glob() + str(self.rank))            # (a marker of this rank from an earlier, failed launch)
+        except OSError:
             pass
         if self.rank != 0:
             return

@@ -628,3 +628,99 @@ def test_window_ranges_shard_one_and_four_scaffolds_over_2_3_and_8_ranks(name, s
         assert sum(t["sites"] > 0 for t in timing) >= min(size, n_windows // 2), [t["sites"] for t in timing]
         for t in timing:
             assert t["text_bytes"] <= 1.3 / size * size_b + span_lines * size_b / n_lines + 64, (size, [x["text_bytes"] for x in timing], size_b)
+
+
+def _corrupt_one_share(geno, size, bad_rank, tmp_path):
+    """a copy of the text file `geno` with a position that is not a number on a line in the middle of rank bad_rank's equal share of the
+    bytes (the shard plan cuts near the equal split, so that line is tokenised by that rank alone)"""
+    with open(geno, "rb") as f:
+        text = f.read()
+    at = text.index(b"\n", int(len(text) * (bad_rank + 0.5) / size)) + 1
+    line_end = text.index(b"\n", at)
+    fields = text[at:line_end].split(b"\t")
+    fields[1] = b"12x4"
+    bad = str(tmp_path / "bad.geno")
+    with open(bad, "wb") as f:
+        f.write(text[:at] + b"\t".join(fields) + text[line_end:])
+    return bad
+
+
+@pytest.mark.parametrize("comm", ["file", "gloo"])
+def test_a_failing_rank_ends_the_whole_launch_within_seconds(comm, tmp_path):
+    """with 8 ranks and an input that makes ONE rank's tokenizer raise, every process must be gone within seconds,
+    with a non-zero exit code, the error named once by the rank that met it and one line by each of the others -- not one rank sitting
+    in the exchange until PG_COMM_TIMEOUT (300 s).  The failing rank leaves a marker next to the rendezvous file
+    (cli.guarded_main, dist.mark_failed); every wait loop of the file communicator, and the helper-thread watch around a collective
+    of the RCCL communicator (here its gloo stand-in is wrapped the same way), looks for it."""
+    import gzip
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from cases import CASES
+    gold = os.path.join(ROOT, "tests", "golden")
+    case = [c for c in CASES if c["name"] == "one_popgen_overlap_failed_id"][0]
+    geno = str(tmp_path / "one.geno")
+    with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f, open(geno, "wb") as g:
+        g.write(f.read())
+    size, bad_rank = (8, 5) if comm == "file" else (3, 1)
+    bad = _corrupt_one_share(geno, size, bad_rank, tmp_path)
+    out = str(tmp_path / "never.out")
+    argv = [a.format(geno=bad, dir=gold, out=out) for a in case["argv"]] + ["-o", out]
+    worker = CLI_WORKER.replace("dist.RcclComm = lambda engine, world: dist.GlooComm(world)", GUARDED_GLOO) if comm == "gloo" else CLI_WORKER
+    procs, t0 = [], time.time()
+    for rank in range(size):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(43000 + (os.getpid() * 3 + size) % 2000), PG_STREAM_BYTES="20000", PG_COMM_TIMEOUT="120",
+                   PG_RDZV_FILE=str(tmp_path / "rdzv"))
+        if comm == "file":
+            env["PG_COMM"] = "file"
+        procs.append(subprocess.Popen([sys.executable, "-c", worker, case["tool"]] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    errs = []
+    for p in procs:
+        try:
+            _, e = p.communicate(timeout=60)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            _, e = p.communicate()
+            e += b"\n[killed by the test after 60 s]"
+        errs.append(e.decode())
+    took = time.time() - t0
+    assert all(p.returncode not in (0, None) for p in procs), [p.returncode for p in procs]
+    assert not any("killed by the test" in e for e in errs), "a rank hung: " + " | ".join(e[-200:] for e in errs)
+    assert took < 30, "the launch took %.0f s to end" % took
+    assert "12x4" in errs[bad_rank] or "position" in errs[bad_rank], errs[bad_rank][-600:]
+    named = [r for r, e in enumerate(errs) if "rank %d failed" % bad_rank in e]
+    assert len(named) >= size - 2 and bad_rank not in named, (named, [e[-300:] for e in errs])
+    assert sum("Traceback" in e for e in errs) == 1, "the error must be spelled out once, by the rank that met it"
+
+
+GUARDED_GLOO = """
+class _Guarded(dist.RcclComm):
+    def __init__(self, engine, world):
+        import os
+        self.size, self.rank, self.world = world.size, world.rank, world
+        self.timeout_s = float(os.environ.get("PG_COMM_TIMEOUT", "300"))
+        if world.rank == 0:
+            dist.clear_failures(world)
+        self.g = self._guarded(dist.GlooComm, world)
+    def allgather(self, arr):
+        return self._guarded(self.g.allgather, arr)
+    def barrier(self):
+        self._guarded(self.g.barrier)
+    def close(self):
+        pass
+dist.RcclComm = _Guarded
+"""
+
+
+def test_bench_spawn_ranks_stops_everybody_when_one_rank_fails(tmp_path):
+    """bench.py --gpus N without a launcher: a rank that dies must not leave the parent waiting for rank 0 (which waits for the dead one)"""
+    import time
+    script = str(tmp_path / "fake_bench.py")
+    with open(script, "w") as f:
+        f.write("import os, sys, time\nsys.path.insert(0, %r)\nimport bench\n"
+                "if 'RANK' not in os.environ:\n    sys.exit(bench.spawn_ranks(4, script=os.path.abspath(__file__)))\n"
+                "if os.environ['RANK'] == '2':\n    sys.exit(7)\ntime.sleep(120)\n" % ROOT)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, script], capture_output=True, timeout=90)
+    assert p.returncode == 7 and time.time() - t0 < 30, (p.returncode, time.time() - t0, p.stderr.decode()[-500:])
+    assert b"rank 2 ended with exit code 7" in p.stderr

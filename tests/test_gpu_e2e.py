@@ -211,3 +211,47 @@ def test_infer_ploidy_refuses_a_file_whose_cell_widths_change_on_the_device(tmp_
     with pytest.raises(SystemExit) as err:
         G.MAINS[case["tool"]]([a.format(geno=odd, dir=gold, out=out) for a in case["argv"]] + ["-o", out])
     assert "--inferPloidy" in str(err.value)
+
+
+def test_a_failing_rank_ends_the_whole_launch_on_the_device(tmp_path):
+    """8 ranks on device 0 (PG_COMM=file), the HIP engine: a position that is not a number in rank 5's share of the text makes that
+    rank's tokenizer raise; every process is gone within seconds with a non-zero exit code, the error spelled out once (VERDICT
+    round 4: one rank used to sit in the exchange until PG_COMM_TIMEOUT)"""
+    import gzip
+    import subprocess
+    import sys
+    import time
+    from test_dist import _corrupt_one_share
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    sys.path.insert(0, gold)
+    from cases import CASES
+    case = [c for c in CASES if c["name"] == "one_popgen_overlap_failed_id"][0]
+    geno = str(tmp_path / "one.geno")
+    with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f, open(geno, "wb") as g:
+        g.write(f.read())
+    size, bad_rank = 8, 5
+    bad = _corrupt_one_share(geno, size, bad_rank, tmp_path)
+    out = str(tmp_path / "never.out")
+    argv = [a.format(geno=bad, dir=gold, out=out) for a in case["argv"]] + ["-o", out]
+    procs, t0 = [], time.time()
+    for rank in range(size):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(39000 + os.getpid() % 1500), PG_COMM="file", PG_COMM_TIMEOUT="120", PG_RDZV_FILE=str(tmp_path / "rdzv"))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "popgenWindows.py")] + argv, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE))
+    errs = []
+    for p in procs:
+        try:
+            _, e = p.communicate(timeout=90)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            _, e = p.communicate()
+            e += b"\n[killed by the test after 90 s]"
+        errs.append(e.decode())
+    took = time.time() - t0
+    assert all(p.returncode not in (0, None) for p in procs), [p.returncode for p in procs]
+    assert not any("killed by the test" in e for e in errs), "a rank hung: " + " | ".join(e[-200:] for e in errs)
+    assert took < 45, "the launch took %.0f s to end" % took                      # (eight device contexts on one GPU start one after the other)
+    assert "Traceback" in errs[bad_rank] and sum("Traceback" in e for e in errs) == 1, [e[-300:] for e in errs]
+    assert sum("rank %d failed" % bad_rank in e for e in errs) >= size - 2
