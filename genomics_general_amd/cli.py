@@ -1007,6 +1007,8 @@ def popgen_main(argv=None):
     # H12stats answers a population that is ONE cluster with the integer `H2 = 0` (genomics.py:1092-1093): printed "0", not "0.0"
     # (H2 of two or more clusters is a sum of positive squares, never exactly zero)
     h2_stat = [s.startswith("H2_") and "hapStats" in args.analysis for s in stats]
+    int_cols = [c for c, f in enumerate(int_stat) if f]
+    h2_cols = [c for c, f in enumerate(h2_stat) if f]
 
     run = Run(args, sampleData, wp, minSites, header_line=args.header, coords_keep=3, stream=True, shardable=True)
     sink = run.open_sink(args.outFile, ("windowID," if args.addWindowID else "") + "scaffold,start,end,mid,sites," + ",".join(stats) + "\n",
@@ -1050,20 +1052,25 @@ def popgen_main(argv=None):
         if not sink.local:
             continue
         t_c = time.perf_counter()
+        # the rows as text: one rounding pass over the table (np.round is what round(np.float64) calls), then Python numbers, whose
+        # str() is numpy's for float64 (shortest repr, "nan", "inf", "-0.0") -- no numpy scalar per cell (popgenWindows.py:66-75)
+        R = np.round(full, args.roundTo).tolist()
+        ids, start, end, mid = T.ID, T.start, T.end, T.mid
+        sites, dup = np.asarray(T.sites).tolist(), np.asarray(T.dup).tolist()
         for k in range(T.n):
-            if T.dup[k]:
+            if dup[k]:
                 ok, text = last_row
             else:
-                ok = T.sites[k] >= minSites
-                vals = []
-                for c in range(len(stats)):
-                    v = full[k, c]
-                    if (int_stat[c] and v == v) or (h2_stat[c] and v == 0):
-                        vals.append(int(v))
-                    else:
-                        vals.append(round(np.float64(v), args.roundTo))
-                row = ([T.ID[k]] if args.addWindowID else []) + [T.scaffold[k], T.start[k], T.end[k], T.mid[k], int(T.sites[k])] + vals
-                text = ",".join(_fmt_cell(x) for x in row) + "\n"
+                ok = sites[k] >= minSites
+                vals = R[k]
+                for c in int_cols:
+                    if vals[c] == vals[c]:
+                        vals[c] = int(vals[c])
+                for c in h2_cols:
+                    if vals[c] == 0:
+                        vals[c] = 0
+                row = ([ids[k]] if args.addWindowID else []) + [T.scaffold[k], start[k], end[k], mid[k], int(sites[k])] + vals
+                text = ",".join(map(str, row)) + "\n"
                 last_row = (ok, text)
             if not (ok or args.writeFailedWindows):
                 continue

@@ -41,6 +41,9 @@ struct DevBuf {
         return PG_OK;
     }
     int ensure(size_t n) { return n <= cap ? PG_OK : alloc(n); }
+    // for buffers whose size follows the blocks of a streamed input (each a little different from the last): an eighth of headroom, so
+    // that a block slightly larger than every block before it does not cost a hipFree (which waits for the device) + hipMalloc
+    int ensure_roomy(size_t n) { return n <= cap ? PG_OK : alloc(n + n / 8 + 4096); }
     int upload(const T *h, size_t n, hipStream_t st) {
         int rc = ensure(n);
         if (rc != PG_OK) return rc;
@@ -72,6 +75,7 @@ struct HostPin {
         cap = n;
         return PG_OK;
     }
+    int ensure_roomy(size_t n) { return n <= cap ? PG_OK : ensure(n + n / 8 + 4096); }      // (see DevBuf::ensure_roomy)
     void release() {
         if (p) (void)hipHostFree(p);
         p = nullptr;

@@ -20,7 +20,10 @@
 
 namespace {
 
-__global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ comp, uint32_t n_dw, const PgiMember *__restrict__ mem,
+#ifndef PGI_WAVES
+#define PGI_WAVES 6
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PGI_WAVES, PGI_WAVES))) void k_inflate(const uint32_t *__restrict__ comp, uint32_t n_dw, const PgiMember *__restrict__ mem,
                                                 int n_members, uint8_t *__restrict__ out, uint8_t *__restrict__ sink,
                                                 int32_t *__restrict__ status) {
     __shared__ PgiShared sh;
@@ -295,10 +298,10 @@ extern "C" int pg_bgzf_compress(const uint8_t *text, int64_t len, int level, int
 static int inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const uint32_t *comp_d, uint32_t n_dw, const uint32_t *in_off,
                          const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d) {
     int rc;
-    if ((rc = I.h_members.ensure((size_t)n_members + 1)) != PG_OK) return rc;
-    if ((rc = I.members.ensure((size_t)n_members + 1)) != PG_OK) return rc;
+    if ((rc = I.h_members.ensure_roomy((size_t)n_members + 1)) != PG_OK) return rc;
+    if ((rc = I.members.ensure_roomy((size_t)n_members + 1)) != PG_OK) return rc;
     if ((rc = I.status.ensure(2)) != PG_OK) return rc;
-    if ((rc = I.sink.ensure((size_t)(n_members + 1) * 64)) != PG_OK) return rc;
+    if ((rc = I.sink.ensure_roomy((size_t)(n_members + 1) * 64)) != PG_OK) return rc;
     if ((rc = I.h_status.ensure(2)) != PG_OK) return rc;
     uint64_t at = 0;
     for (int64_t k = 0; k < n_members; ++k) {

@@ -47,6 +47,7 @@
 #define PGI_ATOMIC_INC(p) (++*(p))
 #define PGI_LANE_PARAM
 #define PGI_LANE_ARG
+#define PGI_NOUNROLL
 static inline uint32_t pgi_brev32(uint32_t x) {
     x = (x >> 16) | (x << 16);
     x = ((x & 0xFF00FF00u) >> 8) | ((x & 0x00FF00FFu) << 8);
@@ -77,6 +78,7 @@ __device__ __forceinline__ void pgi_setlane(T &name, int lane, int l, U val) {
 #define PGI_ATOMIC_INC(p) atomicAdd((p), 1u)
 #define PGI_LANE_PARAM , const int lane
 #define PGI_LANE_ARG , lane
+#define PGI_NOUNROLL _Pragma("nounroll")
 #define pgi_brev32(x) __builtin_bitreverse32(x)
 #define PGI_CTZ64(x) __builtin_ctzll(x)
 #define PGI_POPC64(x) __popcll(x)
@@ -120,6 +122,7 @@ PGI_DEV int pgi_build(const uint8_t *lens, int n, uint16_t *sorted, uint32_t *hi
     }
     uint32_t code = 0, off = 0;
     int over = 0, maxlen = 0;
+    PGI_NOUNROLL
     for (int L = 1; L <= 15; ++L) {
         const uint32_t c = (uint32_t)READLANE(cnt, L);
         const uint32_t first = code;
@@ -295,6 +298,8 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
             PGI_SEEK(np);
             fixed_built = 0;            // (nothing lost, but keep the flag honest: the tables below are per block)
         } else {
+            int hlit = 288, hdist = 32;                      // the fixed code (3.2.6)
+            const int build = btype == 2 || !fixed_built;
             if (btype == 1) {
                 if (!fixed_built) {
                     for (int g = 0; g < 320; g += 64) {
@@ -304,16 +309,12 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                         }
                     }
                     PGI_SYNC;
-                    int rc = pgi_build(sh->lens, 288, sh->sorted_ll, sh->hist, lim_ll, bas_ll, 288, 1 PGI_LANE_ARG);
-                    if (rc) return rc;
-                    rc = pgi_build(sh->lens + 288, 32, sh->sorted_d, sh->hist, lim_d, bas_d, 32, 2 PGI_LANE_ARG);
-                    if (rc) return rc;
-                    fixed_built = 1;
                 }
             } else {
-                fixed_built = 0;
                 PGI_NEED(14);
-                const int hlit = (int)(buf & 31u) + 257, hdist = (int)((buf >> 5) & 31u) + 1, hclen = (int)((buf >> 10) & 15u) + 4;
+                hlit = (int)(buf & 31u) + 257;
+                hdist = (int)((buf >> 5) & 31u) + 1;
+                const int hclen = (int)((buf >> 10) & 15u) + 4;
                 PGI_DROP(14);
                 if (hlit > 286 || hdist > 30) return PGI_ERR_CODE;
                 // the code-length code: 3 bits each, in the order of RFC 1951 3.2.7
@@ -382,10 +383,25 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 PGI_SYNC;
                 LANES { sh->lens[lane < 32 ? 288 + lane : 320 + lane] = V(dl); }
                 PGI_SYNC;
-                rc = pgi_build(sh->lens, hlit, sh->sorted_ll, sh->hist, lim_ll, bas_ll, 288, 1 PGI_LANE_ARG);
-                if (rc) return rc;
-                rc = pgi_build(sh->lens + 288, hdist, sh->sorted_d, sh->hist, lim_d, bas_d, 32, 2 PGI_LANE_ARG);
-                if (rc) return rc;
+            }
+            if (build) {
+                // one copy of the table builder in the code for both codes of a block, fixed or dynamic: first the distance code, then
+                // the literal / length code
+                for (int t = 2; t >= 1; --t) {
+                    PL(uint32_t, lim_t);
+                    PL(int32_t, bas_t);
+                    const int rc = pgi_build(t == 2 ? sh->lens + 288 : sh->lens, t == 2 ? hdist : hlit, t == 2 ? sh->sorted_d : sh->sorted_ll,
+                                             sh->hist, lim_t, bas_t, t == 2 ? 32 : 288, t PGI_LANE_ARG);
+                    if (rc) return rc;
+                    if (t == 2) {
+                        LANES { V(lim_d) = V(lim_t); }
+                        LANES { V(bas_d) = V(bas_t); }
+                    } else {
+                        LANES { V(lim_ll) = V(lim_t); }
+                        LANES { V(bas_ll) = V(bas_t); }
+                    }
+                }
+                fixed_built = btype == 1;
             }
             // ---- the symbols of the block ----
             for (;;) {
@@ -416,8 +432,28 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 if (dist > pos) return PGI_ERR_DIST;
                 if ((uint64_t)pos + len > out_len) return PGI_ERR_OUT;
                 uint8_t *d = dst + pos;
-                if (dist >= 64u || dist >= len) {
-                    // forward copy, 64 bytes per step: with dist >= 64 a later step may read what an earlier one wrote (in order)
+                if (dist >= len) {
+                    // source and destination do not overlap (the usual case: the match is in a line further up): all its bytes are
+                    // loaded -- up to five loads of 64 bytes in flight at once -- before any is stored, so a match costs one trip
+                    // to the cache instead of one per 64 bytes
+                    PL(uint8_t, v0);
+                    PL(uint8_t, v1);
+                    PL(uint8_t, v2);
+                    PL(uint8_t, v3);
+                    PL(uint8_t, v4);
+                    const uint8_t *sp = d - dist;
+                    LANES { V(v0) = sp[(uint32_t)lane < len ? (uint32_t)lane : 0u]; }
+                    if (len > 64u) LANES { V(v1) = sp[64u + (uint32_t)lane < len ? 64u + (uint32_t)lane : 0u]; }
+                    if (len > 128u) LANES { V(v2) = sp[128u + (uint32_t)lane < len ? 128u + (uint32_t)lane : 0u]; }
+                    if (len > 192u) LANES { V(v3) = sp[192u + (uint32_t)lane < len ? 192u + (uint32_t)lane : 0u]; }
+                    if (len > 256u) LANES { V(v4) = sp[256u + (uint32_t)lane < len ? 256u + (uint32_t)lane : 0u]; }
+                    LANES { *((uint32_t)lane < len ? d + lane : sink + lane) = V(v0); }
+                    if (len > 64u) LANES { *(64u + (uint32_t)lane < len ? d + 64 + lane : sink + lane) = V(v1); }
+                    if (len > 128u) LANES { *(128u + (uint32_t)lane < len ? d + 128 + lane : sink + lane) = V(v2); }
+                    if (len > 192u) LANES { *(192u + (uint32_t)lane < len ? d + 192 + lane : sink + lane) = V(v3); }
+                    if (len > 256u) LANES { *(256u + (uint32_t)lane < len ? d + 256 + lane : sink + lane) = V(v4); }
+                } else if (dist >= 64u) {
+                    // forward copy, 64 bytes per step: a later step may read what an earlier one wrote (in order)
                     for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
                         PL(uint8_t, v);
                         LANES {

@@ -415,8 +415,8 @@ static int tok_count(pg_ctx *c, pg_ctx::TokSlot &T, int64_t len) {
     hipStream_t st = c->stream_up;
     const int64_t n_tiles = (len + NL_TILE - 1) / NL_TILE;
     T.n_tiles = n_tiles;
-    if ((rc = T.i32.ensure((size_t)n_tiles + 4)) != PG_OK) return rc;
-    if ((rc = T.i64.ensure((size_t)n_tiles + 2)) != PG_OK) return rc;
+    if ((rc = T.i32.ensure_roomy((size_t)n_tiles + 4)) != PG_OK) return rc;
+    if ((rc = T.i64.ensure_roomy((size_t)n_tiles + 2)) != PG_OK) return rc;
     if ((rc = T.h_total.ensure(8)) != PG_OK) return rc;           // [0] lines, page-locked landing of small results: [1] status | runs, [2] inflate status
     int32_t *d_status = T.i32.p + n_tiles;                          // [0] status bits, [1] number of runs
     int64_t *d_total = T.i64.p + n_tiles;
@@ -463,7 +463,7 @@ static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, in
     int rc;
     auto now = [] { return std::chrono::steady_clock::now(); };
     const auto t_stage0 = now();
-    if ((rc = T.text.ensure((size_t)len + 32)) != PG_OK) return rc;
+    if ((rc = T.text.ensure_roomy((size_t)len + 32)) != PG_OK) return rc;
     T.tp = T.text.p;
     if ((rc = stage_bytes(c, src, len, T.text.p)) != PG_OK) return rc;
     c->tok_stage_s += std::chrono::duration<double>(now() - t_stage0).count();
@@ -517,12 +517,12 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
     static const bool trace = getenv("PG_TOK_TRACE") != nullptr;
     double tr[6] = {0, 0, 0, 0, 0, 0};
     auto lap = [&](int k) { if (trace) tr[k] = std::chrono::duration<double>(now() - t_stage0).count() * 1e3; };
-    if ((rc = T.text.ensure((size_t)total + 64)) != PG_OK) return rc;
+    if ((rc = T.text.ensure_roomy((size_t)total + 64)) != PG_OK) return rc;
     T.tp = T.text.p;                                                 // (hipMalloc aligns to 256 bytes; the members' text starts at any byte)
     // (the slot's buffers are free: the block that used them last has been collected.  Bytes behind comp_len in the last dword are
     // never consumed by a valid stream, and a damaged one is stopped by the bounds of its member)
     const size_t n_dw = ((size_t)comp_len + 3) / 4;
-    if ((rc = T.inf.comp.ensure(n_dw + 1)) != PG_OK) return rc;
+    if ((rc = T.inf.comp.ensure_roomy(n_dw + 1)) != PG_OK) return rc;
     if ((rc = T.h_total.ensure(8)) != PG_OK) return rc;
     lap(0);
     bool pinned = false;
@@ -591,7 +591,7 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
     const int n_cols = T.n_cols, max_ploidy = T.max_ploidy;
     const int64_t n_tiles = T.n_tiles;
     int32_t *d_status = T.i32.p + n_tiles;
-    if ((rc = T.nl.ensure((size_t)n_lines)) != PG_OK) return rc;
+    if ((rc = T.nl.ensure_roomy((size_t)n_lines)) != PG_OK) return rc;
     hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(256), 0, st, T.tp, T.len, T.i64.p, T.nl.p);
     if ((rc = T.dcols.ensure(T.cols.size())) != PG_OK) return rc;
     if ((rc = T.h_cols.ensure(T.cols.size())) != PG_OK) return rc;
@@ -599,9 +599,9 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
     HIPCHK(hipMemcpyAsync(T.dcols.p, T.h_cols.p, T.cols.size() * 4, hipMemcpyHostToDevice, st));
     const int64_t run_cap = std::min<int64_t>(run_capacity, n_lines);
     T.run_cap = run_cap;
-    if ((rc = T.pos.ensure((size_t)n_lines + (size_t)run_cap + 8)) != PG_OK) return rc;      // pos [n_lines] + run_len [run_cap] (int32 each)
+    if ((rc = T.pos.ensure_roomy((size_t)n_lines + (size_t)run_cap + 8)) != PG_OK) return rc;      // pos [n_lines] + run_len [run_cap] (int32 each)
     if ((rc = T.off.ensure((size_t)run_cap * 2)) != PG_OK) return rc;                         // run_row, run_off
-    if ((rc = T.h_pos.ensure((size_t)n_lines)) != PG_OK) return rc;
+    if ((rc = T.h_pos.ensure_roomy((size_t)n_lines)) != PG_OK) return rc;
     HIPCHK(hipMemsetAsync(c->gt.p + row_offset * c->S, 0, (size_t)n_lines * c->S, st));
     DipTable dip;
     memset(dip.v, 0, sizeof(dip.v));
@@ -800,7 +800,7 @@ extern "C" int pg_stage_file(pg_ctx *c, int slot, int fd, int64_t file_offset, i
     if ((size_t)capacity + 32 > T.text.cap) {
         if (dst_offset != 0) return pg_fail(PG_ERR_STATE, "pg_stage_file: the staging buffer can only grow at dst_offset 0");
         HIPCHK(hipStreamSynchronize(c->stream_up));              // (an earlier expansion may still read the old buffer)
-        if ((rc = T.text.ensure((size_t)capacity + 32)) != PG_OK) return rc;
+        if ((rc = T.text.ensure_roomy((size_t)capacity + 32)) != PG_OK) return rc;
     }
     const auto t0 = std::chrono::steady_clock::now();
     const TokSource src{nullptr, fd, file_offset};

@@ -28,7 +28,15 @@ t0 = time.perf_counter()
 n_in, n_out = bgzip.bgzip_file(geno, geno + ".gz")
 print("bgzip: %.2f GB -> %.3f GB (%.1f : 1) in %.1f s" % (n_in / 1e9, n_out / 1e9, n_in / n_out, time.perf_counter() - t0), flush=True)
 res = {}
-for label, path, env in (("text", geno, {}), ("bgzf_device", geno + ".gz", {}), ("bgzf_host_pool", geno + ".gz", {"PG_BGZF_DEVICE": "0"})):
+runs = [("text", geno, {}), ("bgzf_device", geno + ".gz", {})]
+if os.environ.get("T2_HOST_POOL", "1") != "0":
+    runs.append(("bgzf_host_pool", geno + ".gz", {"PG_BGZF_DEVICE": "0"}))
+# what a rank gets at N = 8 under the GPU boxes' 16-CPU quota: two host threads (four at N = 4)
+for nt in (os.environ.get("T2_HOST_THREADS") or "").split(","):
+    if nt:
+        runs += [("text_%s_host_threads" % nt, geno, {"PG_HOST_THREADS": nt}), ("bgzf_device_%s_host_threads" % nt, geno + ".gz", {"PG_HOST_THREADS": nt})]
+summary = {}
+for label, path, env in runs:
     c = [path if x == geno else (path + ".csv") if x == geno + ".csv" else x for x in cmd]
     for rep in range(2):
         r = subprocess.run(c, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1", **env), stderr=subprocess.PIPE, stdout=subprocess.PIPE)
@@ -36,10 +44,19 @@ for label, path, env in (("text", geno, {}), ("bgzf_device", geno + ".gz", {}), 
         if not line:
             print(label, "FAILED", r.stderr.decode()[-2000:])
             break
+        for ln in r.stderr.decode().splitlines():
+            if ln.startswith("PG_TOK_TRACE"):
+                print("   ", ln)
         tm = json.loads(line[-1][len("PG_TIMING "):])
         res[label] = tm
         print(label, rep, json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm.items()}), flush=True)
         print("   -> %.2f GB/s of text, %.2f without the context" % (n_in / tm["total_s"] / 1e9, n_in / (tm["total_s"] - tm.get("context_s", 0)) / 1e9))
+        summary.setdefault(label, []).append({"total_s": round(tm["total_s"], 4), "context_s": round(tm.get("context_s", 0), 4),
+                                              "text_GBps": round(n_in / tm["total_s"] / 1e9, 2),
+                                              "text_GBps_without_context": round(n_in / (tm["total_s"] - tm.get("context_s", 0)) / 1e9, 2),
+                                              "tokenize_s": round(tm.get("tokenize_s", 0), 4), "read_s": round(tm.get("read_s", 0), 4),
+                                              "compute_and_write_s": round(tm.get("compute_and_write_s", 0), 4)})
+print("SUMMARY " + json.dumps({"sites": n_sites, "diploids": n_dip, "text_bytes": n_in, "bgzf_bytes": n_out, "usable_cpus": _lib.usable_cpus(), "runs": summary}))
 csvs = [open(p + ".csv").read() for p in (geno, geno + ".gz")]
 print("csv equal:", csvs[0] == csvs[1], len(csvs[0]))
 # the kernels alone
