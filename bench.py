@@ -623,6 +623,71 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
                                       "popgenWindows.py" % (n_txt, psize / 1e9, pwrite_s)}
         except Exception as exc:
             t2["packed"] = {"error": repr(exc)[:300]}
+        # the same text the way the reference's users keep it -- `.geno.gz` (popgenWindows.py:313; parseVCF.py ... | bgzip): as BGZF
+        # the members cross PCIe deflated and are inflated on the device (k_inflate, a wavefront per member); as a single gzip stream
+        # (what `gzip` writes: one serial stream, nothing to parallelise) a hundredth of the sample through the gzip module
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bgzip
+            gz, csv4 = os.path.join(tmp, "sample.geno.gz"), os.path.join(tmp, "out4.csv")
+            w0 = time.perf_counter()
+            n_in, n_gz = bgzip.bgzip_file(geno, gz)
+            zip_s = time.perf_counter() - w0
+            cmd4 = [gz if c == geno else csv4 if c == csv else c for c in cmd]
+            r4 = subprocess.run(cmd4, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE,
+                                timeout=900)
+            line4 = [ln for ln in r4.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")]
+            if not line4:
+                raise RuntimeError("popgenWindows.py: " + r4.stderr.decode()[-300:])
+            tb = json.loads(line4[-1][len("PG_TIMING "):])
+            with open(csv) as f, open(csv4) as g:
+                same4 = f.read() == g.read()
+            work4 = tb["total_s"] - tb.get("context_s", 0.0)
+            t2["bgzf"] = {"text_GBps": round(size / tb["total_s"] / 1e9, 2), "sites_per_sec": round(n_txt / tb["total_s"], 1),
+                          "windows_per_sec": round(len(rows) / tb["total_s"], 3), "file_bytes": n_gz, "deflate_ratio": round(size / n_gz, 1),
+                          "csv_equals_text_run": bool(same4),
+                          "inflate": "device (k_inflate + k_crc32)" if tb.get("bgzf_blocks_inflated_on_device") else "host threads (zlib)",
+                          "blocks_inflated_on_device": tb.get("bgzf_blocks_inflated_on_device", 0),
+                          "without_context_creation": {"seconds": round(work4, 4), "text_GBps": round(size / work4 / 1e9, 2),
+                                                       "sites_per_sec": round(n_txt / work4, 1)},
+                          "seconds": {k: round(tb[k], 4) for k in ("total_s", "context_s", "read_s", "first_block_prefetch_s", "tokenize_s",
+                                                                    "tokenizer_h2d_s", "tokenizer_kernels_s", "windows_s", "prep_wait_s",
+                                                                    "compute_and_write_s") if k in tb},
+                          "sample": "the same %d sites bgzipped (level 6, members of 65280 bytes: %.2f GB, written in %.1f s before the clock "
+                                    "starts) through popgenWindows.py" % (n_txt, n_gz / 1e9, zip_s)}
+            # one serial gzip stream: a hundredth of the sample (the rate does not depend on the size; the whole sample would take minutes)
+            import gzip as _gzip
+            n_ser = max(n_txt // 100 // wind, 2) * wind
+            sgz, csv5 = os.path.join(tmp, "serial.geno.gz"), os.path.join(tmp, "out5.csv")
+            w0 = time.perf_counter()
+            with open(geno, "rb") as f, _gzip.open(sgz, "wb", compresslevel=6) as g:
+                got = 0
+                for ln in f:                                            # header + n_ser data lines
+                    g.write(ln)
+                    got += 1
+                    if got > n_ser:
+                        break
+            ser_zip_s = time.perf_counter() - w0
+            cmd5 = [sgz if c == geno else csv5 if c == csv else c for c in cmd]
+            r5 = subprocess.run(cmd5, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE,
+                                timeout=900)
+            line5 = [ln for ln in r5.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")]
+            if not line5:
+                raise RuntimeError("popgenWindows.py: " + r5.stderr.decode()[-300:])
+            ts = json.loads(line5[-1][len("PG_TIMING "):])
+            with open(csv) as f, open(csv5) as g:
+                head_rows = f.readlines()[:1 + n_ser // wind]
+                same5 = head_rows == g.readlines()
+            works = ts["total_s"] - ts.get("context_s", 0.0)
+            t2["gz"] = {"text_GBps": round(ts["text_bytes"] / ts["total_s"] / 1e9, 3), "sites": n_ser, "text_bytes": ts["text_bytes"],
+                        "file_bytes": os.path.getsize(sgz), "csv_equals_text_run": bool(same5),
+                        "without_context_creation": {"seconds": round(works, 4), "text_GBps": round(ts["text_bytes"] / works / 1e9, 3)},
+                        "inflate": "one serial stream: Python's gzip module on the reader thread (a single-member gzip file has no "
+                                   "independent pieces; `bgzip` the file to get the BGZF route)",
+                        "sample": "the first %d sites as ONE gzip stream (written in %.1f s before the clock starts)" % (n_ser, ser_zip_s)}
+        except Exception as exc:
+            t2.setdefault("bgzf", {"error": repr(exc)[:300]})
+            t2.setdefault("gz", {"error": repr(exc)[:300]})
         # the same file on TWO ranks (both on this GPU, so the rows travel through files and the ranks share one PCIe link: not a
         # scaling number): the drivers' multi-GPU plan at the size of real data -- every rank reads, tokenises and computes its
         # window range of the ONE scaffold, the gathered CSV is the single-rank one

@@ -207,6 +207,25 @@ class Run:
                 self._streamer = windows.SitesWindowStream(wparams["windSize"], wparams["overlap"], wparams["maxDist"],
                                                            minSites, inc, exc)
             self._block_bytes = int(os.environ.get("PG_STREAM_BYTES", 1 << 30))
+        # bgzip-compressed text on one rank: the first block (its members read, walked, its first and last line found) is fetched
+        # while the device context is still being created
+        self._first_block = None
+        if (self.world.size == 1 and self._block_bytes is not None and isinstance(getattr(self._reader, "f", None), genoio.BgzfFile)
+                and hasattr(Engine, "tokenize_submit_bgzf") and device_tokenizer_takes(self.layout)
+                and os.environ.get("PG_GPU_TOKENIZER", "1") != "0" and os.environ.get("PG_BGZF_DEVICE", "1") != "0"):
+            self._reader.spans = True
+            box = {}
+
+            def first_block():
+                try:
+                    t_f = time.perf_counter()
+                    box["block"] = self._reader.read_block(self._block_bytes)
+                    box["seconds"] = time.perf_counter() - t_f
+                except BaseException as exc:
+                    box["error"] = exc
+            th = threading.Thread(target=first_block, name="first-block")
+            th.start()
+            self._first_block = (th, box)
         t0 = time.perf_counter()
         engine_thread.join()
         if "error" in made:
@@ -323,6 +342,9 @@ class Run:
 
         def produce():
             try:
+                first = self._take_first_block()
+                if first is not None and (not put(blocks, first) or len(first) == 0):
+                    return
                 while True:
                     b = self._reader.read_block(self._block_bytes)
                     if not put(blocks, b) or self._block_bytes is None or len(b) == 0:
@@ -452,6 +474,18 @@ class Run:
                 eng.upload_wait()
         self._reader.close()
 
+    def _take_first_block(self):
+        """the block the constructor's helper thread has fetched (bgzip-compressed input on one rank), or None"""
+        if self._first_block is None:
+            return None
+        th, box = self._first_block
+        self._first_block = None
+        th.join()
+        if "error" in box:
+            raise box["error"]
+        self.timing["first_block_prefetch_s"] = box["seconds"]
+        return box["block"]
+
     def _explain_ploidy_error(self, exc):
         """--inferPloidy: the reference infers the ploidy of every sample WINDOW BY WINDOW from the shortest cell the window holds
         (genoToAlignment with ploidy None, genomics.py:1110; splitSeq zips the cells, genomics.py:390-396), so a file whose cell
@@ -509,6 +543,9 @@ class Run:
 
         def produce():
             try:
+                first = self._take_first_block()              # (fetched beside the creation of the device context)
+                if first is not None and (not put(blocks, first) or len(first) == 0):
+                    return
                 while True:
                     b = self._reader.read_block(self._block_bytes)
                     if not put(blocks, b) or self._block_bytes is None or len(b) == 0:

@@ -94,6 +94,26 @@ struct PgiShared {
     uint16_t sorted_ll[288 + 64]; // literal / length symbols sorted by (code length, symbol) | dump
     uint16_t sorted_d[32 + 64];   // distance symbols (and, while a dynamic header is read, the 19 symbols of the code-length code) | dump
     uint8_t lens[320 + 64];       // code lengths: literal / length symbols, then the distance symbols | dump
+    alignas(16) uint8_t ring[4096];   // the last PGI_RING bytes of the output
+};
+
+// The output window.  The text a member inflates to is written into a ring in LDS and leaves for global memory in pieces of 1 KiB
+// (64 lanes x 16 bytes, aligned stores), so
+//   * a match whose source lies in the ring -- nearly all of them: the line above, or the one above that -- is an LDS read and an LDS
+//     write: no trip to the L2, and no wait for the acknowledgement of earlier stores (gfx9 counts loads and stores in ONE counter:
+//     with byte stores per symbol every load of a match waited for every store before it -- 3700 cycles per symbol, measured);
+//   * a match from further back reads global memory, which by then holds those bytes (everything older than the ring minus the
+//     longest match has been flushed), and finds at most two flush stores in flight;
+//   * the stores are few and wide (~70 per member instead of ~1500 byte-wide ones).
+// The ring index of output byte p is (p + A) mod PGI_RING with A = the misalignment of the member's first byte in global memory, so
+// that 16-byte aligned pieces of the destination are 16-byte aligned in the ring.  Lanes past the end of a match write into ring
+// slots ahead of the output (no select): those are rewritten before they are read, and what they overwrite lies further back than
+// any source the ring is asked for (PGI_NEAR).
+#define PGI_RING 4096u
+#define PGI_NEAR (PGI_RING - 320u)          // sources up to this distance are read from the ring
+#define PGI_FLUSH_AT 2048u                  // bytes not yet in global memory that start a flush
+struct alignas(16) PgiU4 {
+    uint32_t x, y, z, w;
 };
 
 // The canonical code of `n` symbols with lengths lens[] (0 = unused): lane L of lim holds (first code of length L + their number),
@@ -263,7 +283,37 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
     PL(int32_t, bas_ll);
     PL(uint32_t, lim_d);
     PL(int32_t, bas_d);
-    uint32_t pos = 0;
+    uint32_t pos = 0, fl = 0;                        // output bytes produced / of them in global memory already
+    const uint32_t A = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+    uint8_t *const ring = sh->ring;
+#define PGI_RIX(p) (((uint32_t)(p) + A) & (PGI_RING - 1u))
+// n < 64 bytes from the ring to global memory, a byte per lane (the head in front of the first aligned piece, the tail)
+#define PGI_FLUSH_BYTES(n)                                                        \
+    do {                                                                          \
+        PL(uint8_t, fb_);                                                         \
+        LANES { V(fb_) = ring[PGI_RIX(fl + (uint32_t)lane)]; }                    \
+        LANES { *((uint32_t)lane < (n) ? dst + fl + lane : sink + lane) = V(fb_); } \
+        fl += (n);                                                                \
+    } while (0)
+#define PGI_FLUSH(final)                                                                         \
+    do {                                                                                         \
+        if (((fl + A) & 15u) != 0u) {                                                            \
+            const uint32_t h_ = 16u - ((fl + A) & 15u), n_ = h_ < pos - fl ? h_ : pos - fl;      \
+            PGI_FLUSH_BYTES(n_);                                                                 \
+        }                                                                                        \
+        while (pos - fl >= 1024u) {                                                              \
+            PL(PgiU4, fq_);                                                                      \
+            LANES { V(fq_) = *reinterpret_cast<const PgiU4 *>(ring + PGI_RIX(fl + 16u * (uint32_t)lane)); } \
+            LANES { *reinterpret_cast<PgiU4 *>(dst + fl + 16u * (uint32_t)lane) = V(fq_); }      \
+            fl += 1024u;                                                                         \
+        }                                                                                        \
+        if (final) {                                                                             \
+            while (fl < pos) {                                                                   \
+                const uint32_t n_ = pos - fl < 64u ? pos - fl : 64u;                             \
+                PGI_FLUSH_BYTES(n_);                                                             \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
     int fixed_built = 0;
     for (;;) {
         if ((uint64_t)widx * 32u - (uint64_t)cnt > end_bits) return PGI_ERR_IN;
@@ -287,13 +337,10 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                     const uint32_t i = i0 + (uint32_t)lane;
                     V(v) = src[i < len ? i : 0u];
                 }
-                LANES {
-                    const uint32_t i = i0 + (uint32_t)lane;
-                    uint8_t *q = i < len ? dst + pos + i : sink + lane;
-                    *q = V(v);
-                }
+                LANES { ring[PGI_RIX(pos + (uint32_t)lane)] = V(v); }
+                pos += len - i0 < 64u ? len - i0 : 64u;
+                if (pos - fl >= PGI_FLUSH_AT) PGI_FLUSH(0);
             }
-            pos += len;
             const uint64_t np = bp + len;
             PGI_SEEK(np);
             fixed_built = 0;            // (nothing lost, but keep the flag honest: the tables below are per block)
@@ -405,12 +452,13 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
             }
             // ---- the symbols of the block ----
             for (;;) {
+                if (pos - fl >= PGI_FLUSH_AT) PGI_FLUSH(0);
                 PGI_NEED(32);
                 int sym, L;
                 PGI_DECODE(sym, L, lim_ll, bas_ll, sh->sorted_ll);
                 if (sym < 256) {
                     if (pos >= out_len) return PGI_ERR_OUT;
-                    LANES { dst[pos] = (uint8_t)sym; }                     // (every lane the same byte: one request)
+                    LANES { ring[PGI_RIX(pos)] = (uint8_t)sym; }           // (every lane the same byte)
                     ++pos;
                     continue;
                 }
@@ -431,55 +479,50 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 PGI_DROP(de);
                 if (dist > pos) return PGI_ERR_DIST;
                 if ((uint64_t)pos + len > out_len) return PGI_ERR_OUT;
-                uint8_t *d = dst + pos;
+                PL(uint8_t, v0);
+                PL(uint8_t, v1);
+                PL(uint8_t, v2);
+                PL(uint8_t, v3);
+                PL(uint8_t, v4);
                 if (dist >= len) {
-                    // source and destination do not overlap (the usual case: the match is in a line further up): all its bytes are
-                    // loaded -- up to five loads of 64 bytes in flight at once -- before any is stored, so a match costs one trip
-                    // to the cache instead of one per 64 bytes
-                    PL(uint8_t, v0);
-                    PL(uint8_t, v1);
-                    PL(uint8_t, v2);
-                    PL(uint8_t, v3);
-                    PL(uint8_t, v4);
-                    const uint8_t *sp = d - dist;
-                    LANES { V(v0) = sp[(uint32_t)lane < len ? (uint32_t)lane : 0u]; }
-                    if (len > 64u) LANES { V(v1) = sp[64u + (uint32_t)lane < len ? 64u + (uint32_t)lane : 0u]; }
-                    if (len > 128u) LANES { V(v2) = sp[128u + (uint32_t)lane < len ? 128u + (uint32_t)lane : 0u]; }
-                    if (len > 192u) LANES { V(v3) = sp[192u + (uint32_t)lane < len ? 192u + (uint32_t)lane : 0u]; }
-                    if (len > 256u) LANES { V(v4) = sp[256u + (uint32_t)lane < len ? 256u + (uint32_t)lane : 0u]; }
-                    LANES { *((uint32_t)lane < len ? d + lane : sink + lane) = V(v0); }
-                    if (len > 64u) LANES { *(64u + (uint32_t)lane < len ? d + 64 + lane : sink + lane) = V(v1); }
-                    if (len > 128u) LANES { *(128u + (uint32_t)lane < len ? d + 128 + lane : sink + lane) = V(v2); }
-                    if (len > 192u) LANES { *(192u + (uint32_t)lane < len ? d + 192 + lane : sink + lane) = V(v3); }
-                    if (len > 256u) LANES { *(256u + (uint32_t)lane < len ? d + 256 + lane : sink + lane) = V(v4); }
+                    // source and destination do not overlap (the usual case: the match is in a line further up): all its bytes are read
+                    // -- up to five reads of 64 bytes in flight at once -- before any is written
+                    if (dist <= PGI_NEAR) {
+                        const uint32_t sp = pos - dist + (uint32_t)0;
+                        LANES { V(v0) = ring[PGI_RIX(sp + (uint32_t)lane)]; }
+                        if (len > 64u) LANES { V(v1) = ring[PGI_RIX(sp + 64u + (uint32_t)lane)]; }
+                        if (len > 128u) LANES { V(v2) = ring[PGI_RIX(sp + 128u + (uint32_t)lane)]; }
+                        if (len > 192u) LANES { V(v3) = ring[PGI_RIX(sp + 192u + (uint32_t)lane)]; }
+                        if (len > 256u) LANES { V(v4) = ring[PGI_RIX(sp + 256u + (uint32_t)lane)]; }
+                    } else {
+                        // further back than the ring reaches: those bytes are in global memory (flushed: see the note at the ring)
+                        const uint8_t *sp = dst + (pos - dist);
+                        LANES { V(v0) = sp[(uint32_t)lane < len ? (uint32_t)lane : 0u]; }
+                        if (len > 64u) LANES { V(v1) = sp[64u + (uint32_t)lane < len ? 64u + (uint32_t)lane : 0u]; }
+                        if (len > 128u) LANES { V(v2) = sp[128u + (uint32_t)lane < len ? 128u + (uint32_t)lane : 0u]; }
+                        if (len > 192u) LANES { V(v3) = sp[192u + (uint32_t)lane < len ? 192u + (uint32_t)lane : 0u]; }
+                        if (len > 256u) LANES { V(v4) = sp[256u + (uint32_t)lane < len ? 256u + (uint32_t)lane : 0u]; }
+                    }
+                    LANES { ring[PGI_RIX(pos + (uint32_t)lane)] = V(v0); }
+                    if (len > 64u) LANES { ring[PGI_RIX(pos + 64u + (uint32_t)lane)] = V(v1); }
+                    if (len > 128u) LANES { ring[PGI_RIX(pos + 128u + (uint32_t)lane)] = V(v2); }
+                    if (len > 192u) LANES { ring[PGI_RIX(pos + 192u + (uint32_t)lane)] = V(v3); }
+                    if (len > 256u) LANES { ring[PGI_RIX(pos + 256u + (uint32_t)lane)] = V(v4); }
                 } else if (dist >= 64u) {
-                    // forward copy, 64 bytes per step: a later step may read what an earlier one wrote (in order)
+                    // the match overlaps itself with a period of 64 bytes or more: 64 bytes per step, a later step reads what an
+                    // earlier one wrote (LDS operations of a wavefront execute in order)
                     for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
-                        PL(uint8_t, v);
-                        LANES {
-                            const uint32_t i = i0 + (uint32_t)lane;
-                            V(v) = d[(int64_t)(i < len ? i : 0u) - (int64_t)dist];
-                        }
-                        LANES {
-                            const uint32_t i = i0 + (uint32_t)lane;
-                            uint8_t *q = i < len ? d + i : sink + lane;
-                            *q = V(v);
-                        }
+                        LANES { V(v0) = ring[PGI_RIX(pos - dist + i0 + (uint32_t)lane)]; }
+                        LANES { ring[PGI_RIX(pos + i0 + (uint32_t)lane)] = V(v0); }
                     }
                 } else {
-                    // the match overlaps itself: a pattern of `dist` bytes, repeated.  The lanes hold as many whole periods as fit.
+                    // ... with a short period: a pattern of `dist` bytes, repeated.  Every lane holds the byte of its place in the
+                    // pattern; a step writes as many whole periods as fit into 64 lanes (and the start of one more: the same bytes
+                    // the next step writes there)
                     const uint32_t step = (64u / dist) * dist;
-                    PL(uint8_t, v);
-                    LANES {
-                        const uint32_t lm = (uint32_t)lane % dist;
-                        V(v) = d[(int64_t)lm - (int64_t)dist];
-                    }
+                    LANES { V(v0) = ring[PGI_RIX(pos - dist + (uint32_t)lane % dist)]; }
                     for (uint32_t i0 = 0; i0 < len; i0 += step) {
-                        LANES {
-                            const uint32_t i = i0 + (uint32_t)lane;
-                            uint8_t *q = ((uint32_t)lane < step && i < len) ? d + i : sink + lane;
-                            *q = V(v);
-                        }
+                        LANES { ring[PGI_RIX(pos + i0 + (uint32_t)lane)] = V(v0); }
                     }
                 }
                 pos += len;
@@ -489,5 +532,6 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
     }
     if ((uint64_t)widx * 32u - (uint64_t)cnt > end_bits) return PGI_ERR_IN;
     if (pos != out_len) return PGI_ERR_OUT;
+    PGI_FLUSH(1);
     return 0;
 }

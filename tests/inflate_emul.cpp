@@ -7,12 +7,29 @@
 #include <cstring>
 #include <vector>
 
-// comp: n_comp bytes (any alignment); the deflate stream is comp[in_off : in_off + in_len]; dst: out_len bytes.
-extern "C" int pgi_emul_inflate(const uint8_t *comp, uint32_t n_comp, uint32_t in_off, uint32_t in_len, uint8_t *dst, uint32_t out_len) {
+// comp: n_comp bytes (any alignment); the deflate stream is comp[in_off : in_off + in_len]; dst: out_len bytes.  The member is
+// inflated to an address that is `misalign` bytes behind a 16-byte boundary (the kernel flushes its ring in aligned 16-byte pieces;
+// a member's text starts at any byte of the block's text) and copied to dst.
+extern "C" int pgi_emul_inflate_at(const uint8_t *comp, uint32_t n_comp, uint32_t in_off, uint32_t in_len, uint8_t *dst, uint32_t out_len,
+                                   int misalign) {
     std::vector<uint32_t> words((n_comp + 3) / 4 + 1, 0u);
     if (n_comp) std::memcpy(words.data(), comp, n_comp);
     PgiShared sh;
     std::memset(&sh, 0xAB, sizeof(sh));
     uint8_t sink[64];
-    return pgi_member(words.data(), (uint32_t)((n_comp + 3) / 4), in_off, in_len, dst, out_len, sink, &sh);
+    std::vector<PgiU4> out((size_t)out_len / 16 + 4);
+    uint8_t *at = reinterpret_cast<uint8_t *>(out.data()) + (misalign & 15);
+    std::memset(out.data(), 0xCD, out.size() * 16);
+    const int rc = pgi_member(words.data(), (uint32_t)((n_comp + 3) / 4), in_off, in_len, at, out_len, sink, &sh);
+    // nothing in front of the member's first byte or behind its last may have been touched (its neighbours' text lives there)
+    for (int k = 0; k < (misalign & 15); ++k)
+        if (reinterpret_cast<uint8_t *>(out.data())[k] != 0xCD) return 1 << 20;
+    for (size_t k = (size_t)(misalign & 15) + out_len; k < out.size() * 16; ++k)
+        if (reinterpret_cast<uint8_t *>(out.data())[k] != 0xCD) return 1 << 21;
+    if (out_len) std::memcpy(dst, at, out_len);
+    return rc;
+}
+
+extern "C" int pgi_emul_inflate(const uint8_t *comp, uint32_t n_comp, uint32_t in_off, uint32_t in_len, uint8_t *dst, uint32_t out_len) {
+    return pgi_emul_inflate_at(comp, n_comp, in_off, in_len, dst, out_len, (int)((in_off * 7u + out_len) & 15u));
 }
