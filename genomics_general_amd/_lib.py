@@ -57,14 +57,14 @@ SIGNATURES = {
     "pg_upload_sites_async": (C.c_int, [_P, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]),
     "pg_upload_packed_async": (C.c_int, [_P, C.c_int64, C.c_void_p, C.c_int64, C.c_int, _i32p]),
     "pg_upload_wait": (C.c_int, [_P]),
-    "pg_tokenize_text": (C.c_int, [_P, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int64, _i32p, C.c_int64,
+    "pg_tokenize_text": (C.c_int, [_P, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int64, _i64p, C.c_int64,
                                    _i64p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
-    "pg_tokenize_file": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int64, _i32p, C.c_int64,
+    "pg_tokenize_file": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int64, _i64p, C.c_int64,
                                    _i64p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "pg_tokenize_submit": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p,
                                      C.POINTER(C.c_int)]),
     "pg_tokenize_parse": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
-    "pg_tokenize_collect": (C.c_int, [_P, C.c_int, _i32p, C.c_int64, _i64p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64),
+    "pg_tokenize_collect": (C.c_int, [_P, C.c_int, _i64p, C.c_int64, _i64p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "pg_stage_file": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "pg_unpack_staged": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int, _i32p, C.c_int64]),
@@ -73,7 +73,7 @@ SIGNATURES = {
     "pg_move_rows": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64]),
     "pg_synth_fill": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32,
                                 _i32p, C.c_int32, C.c_int32]),
-    "pg_encode_text": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i8p, _i32p,
+    "pg_encode_text": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i8p, _i64p,
                                  _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_scaffold_runs": (C.c_int, [C.c_void_p, _i64p, _i32p, C.c_int64, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
     "pg_count_lines": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
@@ -84,7 +84,7 @@ SIGNATURES = {
     "pg_text_skip_rows": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     # (struct array + many pointers: genomics_general_amd/vcf.py passes explicit ctypes objects)
     "pg_encode_vcf": (C.c_int, None),
-    "pg_format_freq_rows": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_void_p, _i32p, _i32p, C.c_char_p, _i64p, C.c_void_p, C.c_void_p,
+    "pg_format_freq_rows": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_void_p, _i64p, _i32p, C.c_char_p, _i64p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_inflate_chunks": (C.c_int, [C.c_void_p, _i64p, _i64p, _i64p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
     "pg_bgzf_walk": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -165,6 +165,7 @@ class Run:
             # N ranks on one node: the native helpers (line count, tokenizers, staging copies of the device tokenizer) share the cores
             os.environ["PG_HOST_THREADS"] = str(max(1, _lib.usable_cpus() // self.world.size))
         self._t_start = time.perf_counter()
+        self._timeline = [] if os.environ.get("PG_TIMELINE") else None
         self.timing = {"read_s": 0.0, "text_bytes": 0, "tokenize_s": 0.0, "windows_s": 0.0, "sites": 0, "windows": 0,
                        "engine_and_upload_s": 0.0, "upload_s": 0.0, "prep_wait_s": 0.0, "chunks": 0}   # printed as JSON on stderr when PG_TIMING=1
         # the device context (HIP runtime start-up, streams: 0.1 - 0.2 s) is created by a helper thread while this one opens the input,
@@ -474,6 +475,14 @@ class Run:
                 eng.upload_wait()
         self._reader.close()
 
+    def _ev(self, label, t0):
+        """PG_TIMELINE=1: (thread, label, start, end) of a step, seconds since the run began; report_timing prints the list"""
+        if self._timeline is not None:
+            import threading
+            import time
+            self._timeline.append((threading.current_thread().name, label, round(t0 - self._t_start, 5),
+                                   round(time.perf_counter() - self._t_start, 5)))
+
     def _take_first_block(self):
         """the block the constructor's helper thread has fetched (bgzip-compressed input on one rank), or None"""
         if self._first_block is None:
@@ -547,7 +556,9 @@ class Run:
                 if first is not None and (not put(blocks, first) or len(first) == 0):
                     return
                 while True:
+                    t_e = time.perf_counter()
                     b = self._reader.read_block(self._block_bytes)
+                    self._ev("read_block", t_e)
                     if not put(blocks, b) or self._block_bytes is None or len(b) == 0:
                         return
             except BaseException as exc:
@@ -616,7 +627,7 @@ class Run:
                     eng.stage_file(slot, b.fd, b.cells_off, b.n * nc, at, total)
                     parts.append((at, b.n))
                     at += b.n * nc
-                staged[slot] = (parts, np.concatenate([b.positions() for b in body]).astype(np.int32, copy=False))
+                staged[slot] = (parts, np.concatenate([b.positions() for b in body]).astype(np.int64, copy=False))
                 return True
             if not len(body) or not hasattr(eng, "tokenize_submit"):
                 return False
@@ -653,8 +664,12 @@ class Run:
         def ingest():
             carry, carry_row0, k = None, 0, 0
             try:
+                t_e = time.perf_counter()
                 body, read_s = fetch()
+                self._ev("fetch", t_e)
+                t_e = time.perf_counter()
                 sub = submit(body, 0)
+                self._ev("submit", t_e)
                 while True:
                     final = self._streamer is None or len(body) == 0
                     tm = {"read_s": read_s, "host_tokenized": 0}
@@ -663,6 +678,7 @@ class Run:
                         if stop.is_set():
                             return
                     tm["half_wait_s"] = time.perf_counter() - t0
+                    self._ev("half_wait", t0)
                     t0 = time.perf_counter()
                     c_n = carry.n_sites if carry is not None else 0
                     if packed:
@@ -682,12 +698,20 @@ class Run:
                     elif c_n:
                         eng.move_rows(carry_row0, base, c_n)
                     # parse(k) is queued, then the text of block k+1 crosses PCIe while those kernels run, then the results of k
+                    t_e = time.perf_counter()
                     n_lines = parse(k % 2, base + c_n, bound) if sub else None
+                    self._ev("parse", t_e)
                     nxt, nxt_sub, read_s = None, False, 0.0
                     if not final:
+                        t_e = time.perf_counter()
                         nxt, read_s = fetch()
+                        self._ev("fetch", t_e)
+                        t_e = time.perf_counter()
                         nxt_sub = submit(nxt, (k + 1) % 2)
+                        self._ev("submit", t_e)
+                    t_e = time.perf_counter()
                     got = collect(k % 2, body, n_lines) if n_lines is not None else None
+                    self._ev("collect", t_e)
                     if got is not None:
                         n, pos, starts, names = got
                         block = genoio.GenoData(None, pos, starts, names)
@@ -705,7 +729,7 @@ class Run:
                     del body
                     data = genoio.concat_meta(carry, block)
                     if data is None:
-                        data = genoio.GenoData(None, np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int64), [])
+                        data = genoio.GenoData(None, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), [])
                     tm["tokenize_s"] = time.perf_counter() - t0 - read_s
                     t0 = time.perf_counter()
                     if self._streamer is not None:
@@ -716,6 +740,7 @@ class Run:
                         T.dup = np.zeros(T.n, dtype=bool)
                         keep_from = data.n_sites
                     tm["windows_s"] = time.perf_counter() - t0
+                    self._ev("windows", t0)
                     carry = None if final else genoio.tail_meta(data, keep_from)
                     carry_row0 = base + keep_from
                     if not put(ready, (data, T, base, final, int(block.n_sites), tm)) or final:
@@ -752,6 +777,7 @@ class Run:
                 if isinstance(item, BaseException):
                     raise item
                 self.timing["prep_wait_s"] += time.perf_counter() - t0      # time this thread waited for the ingestion thread
+                self._ev("wait_ready", t0)
                 data, T, base, final, n_new, tm = item
                 for key in ("read_s", "tokenize_s", "windows_s"):
                     self.timing[key] += tm[key]
@@ -773,6 +799,7 @@ class Run:
                     if T.n:
                         yield self
                 finally:
+                    self._ev("chunk", t_y)
                     ready.task_done()                         # the rows of this block are no longer needed: its half may be rewritten
                     halves.release()
                 if T.n:                                       # (what the caller did with the chunk: kernels, statistics, rows)
@@ -808,6 +835,8 @@ class Run:
                 t["lib_calls"] = {"%s:%s" % k: [v[0], round(v[1], 4)] for k, v in top}
             # (the stages overlap when tokenize_s + windows_s + compute_and_write_s > total_s - context_s)
             sys.stderr.write("PG_TIMING " + json.dumps(t) + "\n")
+            if self._timeline is not None:
+                sys.stderr.write("PG_TIMELINE " + json.dumps(self._timeline) + "\n")
 
     def finish(self):
         """the end of a driver: nobody leaves before everybody's rows are written; the communicator is closed (the file communicator
@@ -1606,7 +1635,7 @@ def freq_main(argv=None):
         if len(text_buf) < cap:
             text_buf = np.empty(cap, dtype=np.uint8)
         got = C.c_int64(0)
-        check(L.pg_format_freq_rows(mode, b - a, P, C.c_void_p(values.ctypes.data), np.ascontiguousarray(data.pos[a:b]),
+        check(L.pg_format_freq_rows(mode, b - a, P, C.c_void_p(values.ctypes.data), np.ascontiguousarray(data.pos[a:b], dtype=np.int64),
                                     np.ascontiguousarray(run_of_row[a:b], dtype=np.int32) - run0, names_blob, name_off,
                                     C.c_void_p(keep.ctypes.data) if keep is not None else None,
                                     C.c_void_p(text_buf.ctypes.data), cap, C.byref(got), 0))

@@ -130,9 +130,10 @@ struct pg_ctx {
         DevBuf<uint8_t> names;             // pg_tokenize_run_names: the scaffold names of the block's runs, gathered
         DevBuf<int64_t> names_idx;
         DevBuf<int32_t> i32, dcols, pos;
-        DevBuf<int64_t> i64, nl, off;
+        DevBuf<int64_t> i64, nl, off, pos64;
         HostPin<int64_t> h_total;          // page-locked landing: [0] lines, [1] status | runs
-        HostPin<int32_t> h_pos, h_cols;
+        HostPin<int64_t> h_pos;
+        HostPin<int32_t> h_cols;
         std::vector<int32_t> cols;         // col_slot | col_ploidy | cell offsets | cell widths of the submitted block
         hipEvent_t counted = nullptr, staged = nullptr;   // line feeds counted / deflated bytes on the device
         int state = 0;                     // 0 idle, 1 empty block, 2 submitted, 3 parse queued, 4 empty result

@@ -41,7 +41,7 @@ struct Shared {
     int fmt, n_cols, max_ploidy, n_hap;
     const int32_t *col_slot, *col_ploidy;
     int8_t *gt;
-    int32_t *pos;
+    int64_t *pos;
     int64_t *scaf_off;
     int32_t *scaf_len;
     int64_t cap;
@@ -92,10 +92,13 @@ void parse_range(Shared &sh, const char *b, const char *e, int64_t row) {
             bool neg = false;
             if (p < le && (*p == '+' || *p == '-')) { neg = (*p == '-'); ++p; }
             if (p >= le || *p < '0' || *p > '9') { set_err(sh, "position is not an integer", row, -1); return; }
+            // (the reference parses Python integers, genomics.py:1884-1904: positions beyond 2^31 -- chromosomes of more than
+            // 2.1 Gb exist -- are carried as int64; eighteen digits is where this parser stops)
             int64_t v = 0;
-            while (p < le && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); if (v > 0x7FFFFFFFll) break; ++p; }
-            if (v > 0x7FFFFFFFll || (p < le && !is_ws(*p))) { set_err(sh, "position is not a 32-bit integer", row, -1); return; }
-            sh.pos[row] = (int32_t)(neg ? -v : v);
+            int nd = 0;
+            while (p < le && *p >= '0' && *p <= '9' && nd < 19) { v = v * 10 + (*p - '0'); ++p; ++nd; }
+            if (nd > 18 || (p < le && !is_ws(*p))) { set_err(sh, "position is not an integer of at most 18 digits", row, -1); return; }
+            sh.pos[row] = neg ? -v : v;
             int8_t *out = sh.gt + (size_t)row * H;
             memset(out, 0, H);
             for (int c = 0; c < sh.n_cols; ++c) {
@@ -255,7 +258,7 @@ extern "C" int pg_text_skip_rows(const char *buf, size_t len, int64_t n_rows, in
 }
 
 extern "C" int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
-                              const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int32_t *pos_out, int64_t *scaf_off,
+                              const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int64_t *pos_out, int64_t *scaf_off,
                               int32_t *scaf_len, int64_t cap_sites, int64_t *n_sites_out, int n_threads) {
     if ((!buf && len) || !col_slot || !col_ploidy || !n_sites_out) return pg_fail(PG_ERR_ARG, "pg_encode_text: null argument");
     if (cap_sites > 0 && (!gt_out || !pos_out || !scaf_off || !scaf_len)) return pg_fail(PG_ERR_ARG, "pg_encode_text: null output");
@@ -455,7 +458,7 @@ inline void put_round4(std::string &o, double v) {
 }
 }  // namespace
 
-extern "C" int pg_format_freq_rows(int mode, int64_t n_rows, int n_pops, const void *values, const int32_t *pos,
+extern "C" int pg_format_freq_rows(int mode, int64_t n_rows, int n_pops, const void *values, const int64_t *pos,
                                    const int32_t *run_of_row, const char *names, const int64_t *name_off, const uint8_t *keep,
                                    char *out, int64_t out_cap, int64_t *out_len, int n_threads) {
     if (mode < 0 || mode > 2 || n_rows < 0 || n_pops < 1 || !out_len) return pg_fail(PG_ERR_ARG, "pg_format_freq_rows: bad argument");

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
                                                    int fmt, int n_cols, int cells_w, int max_ploidy,
                                                    const int32_t *__restrict__ col_slot, const int32_t *__restrict__ col_ploidy,
                                                    const int32_t *__restrict__ col_off, const int32_t *__restrict__ col_w,
-                                                   int8_t *__restrict__ rows, int S, int32_t *__restrict__ pos_out,
+                                                   int8_t *__restrict__ rows, int S, int64_t *__restrict__ pos_out,
                                                    int64_t *__restrict__ run_row, int64_t *__restrict__ run_off, int32_t *__restrict__ run_len,
                                                    int32_t *__restrict__ n_runs, int64_t run_cap, int32_t *__restrict__ status, DipTable dip) {
     const int lane = threadIdx.x & 63;
@@ -177,14 +177,13 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
                     const uint64_t dg = __ballot(ch >= '0' && ch <= '9');
                     const uint64_t range = ((1ull << p2) - 1ull) & ~((1ull << d0) - 1ull);
                     long long v = 0;
-                    if (p2 <= d0 || (dg & range) != range) bad |= TOK_BAD_POS;
+                    if (p2 <= d0 || p2 - d0 > 18 || (dg & range) != range) bad |= TOK_BAD_POS;      // (up to 18 digits: int64, as the host tokenizer)
                     else
-                        for (int k = d0; k < p2 && v <= 0x7FFFFFFFll; ++k) v = v * 10 + (rl(ch, k) - '0');
-                    if (v > 0x7FFFFFFFll) bad |= TOK_BAD_POS;
+                        for (int k = d0; k < p2; ++k) v = v * 10 + (rl(ch, k) - '0');
                     cells_at = ls + __builtin_ctzll(r2);
                     if (le - cells_at != (int64_t)cells_w) bad |= TOK_IRREGULAR;
                     if (lane == 0) {
-                        pos_out[row] = (int32_t)(neg ? -v : v);
+                        pos_out[row] = neg ? -v : v;
                         if (differs) {
                             const int k = atomicAdd(n_runs, 1);
                             if (k < run_cap) { run_row[k] = row; run_off[k] = ls; run_len[k] = p1; }
@@ -220,9 +219,9 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
         if (p < le && (text[p] == '+' || text[p] == '-')) { neg = text[p] == '-'; ++p; }
         long long v = 0;
         const int64_t d0 = p;
-        while (p < le && text[p] >= '0' && text[p] <= '9' && v <= 0x7FFFFFFFll) { v = v * 10 + (text[p] - '0'); ++p; }
-        if (p == d0 || v > 0x7FFFFFFFll || (p < le && !blank(text[p]))) bad |= TOK_BAD_POS;
-        pos_out[row] = (int32_t)(neg ? -v : v);
+        while (p < le && text[p] >= '0' && text[p] <= '9' && p - d0 < 19) { v = v * 10 + (text[p] - '0'); ++p; }
+        if (p == d0 || p - d0 > 18 || (p < le && !blank(text[p]))) bad |= TOK_BAD_POS;
+        pos_out[row] = neg ? -v : v;
         while (p < le && blank(text[p])) ++p;
         cells_at = p;
         // the regular layout: n_cols cells of their columns' widths, one separator between them, the last cell ends the line
@@ -599,7 +598,8 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
     HIPCHK(hipMemcpyAsync(T.dcols.p, T.h_cols.p, T.cols.size() * 4, hipMemcpyHostToDevice, st));
     const int64_t run_cap = std::min<int64_t>(run_capacity, n_lines);
     T.run_cap = run_cap;
-    if ((rc = T.pos.ensure_roomy((size_t)n_lines + (size_t)run_cap + 8)) != PG_OK) return rc;      // pos [n_lines] + run_len [run_cap] (int32 each)
+    if ((rc = T.pos.ensure_roomy((size_t)run_cap + 8)) != PG_OK) return rc;                          // run_len [run_cap] (int32)
+    if ((rc = T.pos64.ensure_roomy((size_t)n_lines + 8)) != PG_OK) return rc;                       // positions (int64)
     if ((rc = T.off.ensure((size_t)run_cap * 2)) != PG_OK) return rc;                         // run_row, run_off
     if ((rc = T.h_pos.ensure_roomy((size_t)n_lines)) != PG_OK) return rc;
     HIPCHK(hipMemsetAsync(c->gt.p + row_offset * c->S, 0, (size_t)n_lines * c->S, st));
@@ -615,17 +615,17 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
                        T.cells_w, max_ploidy, T.dcols.p, T.dcols.p + (size_t)n_cols * max_ploidy,
                        T.dcols.p + (size_t)n_cols * (max_ploidy + 1), T.dcols.p + (size_t)n_cols * (max_ploidy + 2),
                        c->gt.p + row_offset * c->S, c->S,
-                       T.pos.p, T.off.p, T.off.p + run_cap, T.pos.p + n_lines, d_status + 1, run_cap, d_status, dip);
+                       T.pos64.p, T.off.p, T.off.p + run_cap, T.pos.p, d_status + 1, run_cap, d_status, dip);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(T.h_total.p + 1, d_status, 8, hipMemcpyDeviceToHost, st));            // status | runs, as two int32
-    HIPCHK(hipMemcpyAsync(T.h_pos.p, T.pos.p, (size_t)n_lines * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(T.h_pos.p, T.pos64.p, (size_t)n_lines * 8, hipMemcpyDeviceToHost, st));
     T.state = 3;
     *ok_out = 1;
     c->tok_kernel_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return PG_OK;
 }
 
-static int tok_collect(pg_ctx *c, int slot, int32_t *pos_out, int64_t pos_capacity, int64_t *run_row_out, int64_t *run_off_out,
+static int tok_collect(pg_ctx *c, int slot, int64_t *pos_out, int64_t pos_capacity, int64_t *run_row_out, int64_t *run_off_out,
                        int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out) {
     if (!c || !n_rows_out || !n_runs_out || !ok_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_collect: null argument");
     if (slot < 0 || slot > 1) return pg_fail(PG_ERR_ARG, "pg_tokenize_collect: slot %d", slot);
@@ -651,7 +651,7 @@ static int tok_collect(pg_ctx *c, int slot, int32_t *pos_out, int64_t pos_capaci
     int32_t status[2];
     memcpy(status, T.h_total.p + 1, 8);
     if (status[0] != 0) return PG_OK;
-    memcpy(pos_out, T.h_pos.p, (size_t)n_lines * 4);
+    memcpy(pos_out, T.h_pos.p, (size_t)n_lines * 8);
     const int64_t nr = status[1], run_cap = T.run_cap;
     *n_runs_out = nr;
     if (nr > run_cap || nr > run_capacity) return PG_OK;                                     // more runs than the caller has room for
@@ -660,7 +660,7 @@ static int tok_collect(pg_ctx *c, int slot, int32_t *pos_out, int64_t pos_capaci
     if (nr) {
         HIPCHK(hipMemcpyAsync(rr.data(), T.off.p, (size_t)nr * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(ro.data(), T.off.p + run_cap, (size_t)nr * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(rlen.data(), T.pos.p + n_lines, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(rlen.data(), T.pos.p, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     std::vector<int64_t> order((size_t)nr);
@@ -677,7 +677,7 @@ static int tok_collect(pg_ctx *c, int slot, int32_t *pos_out, int64_t pos_capaci
 }
 
 static int tokenize_block(pg_ctx *c, const TokSource &src, int64_t len, int fmt, int n_cols, int max_ploidy,
-                          const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out,
+                          const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int64_t *pos_out,
                           int64_t row_capacity, int64_t *run_row_out, int64_t *run_off_out, int32_t *run_len_out,
                           int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out) {
     if (!n_rows_out || !n_runs_out || !ok_out) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null argument");
@@ -695,7 +695,7 @@ static int tokenize_block(pg_ctx *c, const TokSource &src, int64_t len, int fmt,
 }
 
 extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fmt, int n_cols, int max_ploidy,
-                                const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out,
+                                const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int64_t *pos_out,
                                 int64_t row_capacity, int64_t *run_row_out, int64_t *run_off_out, int32_t *run_len_out,
                                 int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out) {
     if (!text && len) return pg_fail(PG_ERR_ARG, "pg_tokenize_text: null argument");
@@ -705,7 +705,7 @@ extern "C" int pg_tokenize_text(pg_ctx *c, const char *text, int64_t len, int fm
 }
 
 extern "C" int pg_tokenize_file(pg_ctx *c, int fd, int64_t file_offset, int64_t len, int fmt, int n_cols, int max_ploidy,
-                                const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out,
+                                const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int64_t *pos_out,
                                 int64_t row_capacity, int64_t *run_row_out, int64_t *run_off_out, int32_t *run_len_out,
                                 int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out) {
     if (fd < 0 || file_offset < 0 || len < 0) return pg_fail(PG_ERR_ARG, "pg_tokenize_file: bad file range");
@@ -770,7 +770,7 @@ extern "C" int pg_tokenize_parse(pg_ctx *c, int slot, int64_t row_offset, int64_
     return tok_parse(c, slot, row_offset, row_capacity, run_capacity, n_rows_out, ok_out);
 }
 
-extern "C" int pg_tokenize_collect(pg_ctx *c, int slot, int32_t *pos_out, int64_t pos_capacity, int64_t *run_row_out,
+extern "C" int pg_tokenize_collect(pg_ctx *c, int slot, int64_t *pos_out, int64_t pos_capacity, int64_t *run_row_out,
                                    int64_t *run_off_out, int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out,
                                    int64_t *n_runs_out, int *ok_out) {
     return tok_collect(c, slot, pos_out, pos_capacity, run_row_out, run_off_out, run_len_out, run_capacity, n_rows_out, n_runs_out, ok_out);

@@ -95,7 +95,7 @@ struct Shared {
     char missing;
     uint8_t *chars, *phase, *row_flag;
     int8_t *idx;
-    int32_t *pos;
+    int64_t *pos;
     int64_t *chrom_off, *ref_off, *alt_off;
     int32_t *chrom_len, *ref_len, *alt_len;
     int64_t cap;
@@ -187,12 +187,12 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
                     if (p < pe && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
                     long long v = 0;
                     if (p >= pe) { set_err(sh, "POS is not an integer", &t[0], &t[1]); return kept; }
+                    if (pe - p > 18) { set_err(sh, "POS has more than 18 digits", &t[0], &t[1]); return kept; }
                     for (; p < pe; ++p) {
                         if (*p < '0' || *p > '9') { set_err(sh, "POS is not an integer", &t[0], &t[1]); return kept; }
                         v = v * 10 + (*p - '0');
-                        if (v > 0x7FFFFFFFll) { set_err(sh, "POS does not fit 32 bits", &t[0], &t[1]); return kept; }
                     }
-                    sh.pos[row] = (int32_t)(neg ? -v : v);
+                    sh.pos[row] = (int64_t)(neg ? -v : v);
                 }
                 sh.chrom_off[row] = t[0].p - sh.buf;
                 sh.chrom_len[row] = t[0].n;
@@ -357,7 +357,7 @@ extern "C" int pg_encode_vcf(const char *buf, size_t len, int n_vcf_samples, int
                              const int32_t *sel_ploidy, int flags, double min_qual, int max_ref_len, const pg_vcf_filter *filters,
                              int n_filters, const char *contigs, int n_contig_bytes, int contig_mode, char missing,
                              const char *prev_chrom, int prev_chrom_len, const char *prev_pos, int prev_pos_len, uint8_t *chars_out,
-                             int8_t *idx_out, uint8_t *phase_out, uint8_t *row_flag_out, int32_t *pos_out, int64_t *chrom_off,
+                             int8_t *idx_out, uint8_t *phase_out, uint8_t *row_flag_out, int64_t *pos_out, int64_t *chrom_off,
                              int32_t *chrom_len, int64_t *ref_off, int32_t *ref_len, int64_t *alt_off, int32_t *alt_len,
                              int64_t cap_sites, int64_t *n_sites_out, int64_t *n_multibase_out, int n_threads) {
     if ((!buf && len) || !n_sites_out) return pg_fail(PG_ERR_ARG, "pg_encode_vcf: null argument");

@@ -21,7 +21,7 @@ from ._lib import check
 
 def encode_text(buf, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, full_out=None):
     """K0 host tokenizer.  buf: bytes of complete `.geno` data lines (no header).
-    Returns (gt int8 [L][pitch or n_hap] in slot order, pos int32 [L], scaf_off int64 [L], scaf_len int32 [L]).
+    Returns (gt int8 [L][pitch or n_hap] in slot order, pos int64 [L], scaf_off int64 [L], scaf_len int32 [L]).
     head_rows > 0: gt and pos are views into arrays with that many spare rows in front (gt.base / pos.base), so that a
     caller can put carried-over rows before the new ones without copying the new ones.
     pitch: bytes per output row (the engine's row pitch: columns past n_hap stay zero, and the rows can be uploaded with one
@@ -35,7 +35,7 @@ def encode_text(buf, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, f
     width = int(pitch) if pitch else layout.n_hap
     assert width >= layout.n_hap
     alloc = alloc or np.zeros                   # (the tokenizer clears every row it writes, pad columns included)
-    gt_full, pos_full = alloc((head_rows + cap, width), np.int8), alloc((head_rows + cap,), np.int32)
+    gt_full, pos_full = alloc((head_rows + cap, width), np.int8), alloc((head_rows + cap,), np.int64)
     if full_out is not None:
         full_out.append((gt_full, pos_full))
     gt, pos = gt_full[head_rows:], pos_full[head_rows:]
@@ -235,7 +235,7 @@ class Engine:
 
     def tokenize_text(self, buf, row_offset=0, n_rows=None, max_runs=1 << 16, at_most=False, file=None):
         """K0 on the device: complete `.geno` data lines (bytes-like: bytes, memoryview, mmap) -> resident rows row_offset ..;
-        returns (n, pos int32 [n], run_starts int64 [r], run_names) or None when the block is not of the regular layout the device
+        returns (n, pos int64 [n], run_starts int64 [r], run_names) or None when the block is not of the regular layout the device
         tokenizer handles (the caller then takes the host tokenizer).  The rows must be reserved: n_rows = number of data lines
         (pg_count_lines) if known; with at_most an upper bound of it (the device counts the lines itself: no pass of the host
         over the text).  file = (file descriptor, offset of buf in the file) of a plain-text block: the staging threads then read
@@ -247,7 +247,7 @@ class Engine:
             check(self._L.pg_count_lines(ptr, nbytes, C.byref(n)))
             n_rows = int(n.value)
         cap = max(int(n_rows), 1)
-        pos = np.empty(cap, dtype=np.int32)
+        pos = np.empty(cap, dtype=np.int64)
         while True:
             rrow, roff, rlen = np.empty(max_runs, dtype=np.int64), np.empty(max_runs, dtype=np.int64), np.empty(max_runs, dtype=np.int32)
             got, nr, ok = C.c_int64(0), C.c_int64(0), C.c_int(0)
@@ -302,7 +302,7 @@ class Engine:
 
     def tokenize_collect(self, slot, buf, n_rows, max_runs=1 << 16):
         """wait for the parse of `slot`; (n, pos, run_starts, run_names) or None (irregular text met on the device, too many runs)"""
-        pos = np.empty(max(int(n_rows), 1), dtype=np.int32)
+        pos = np.empty(max(int(n_rows), 1), dtype=np.int64)
         rrow, roff, rlen = np.empty(max_runs, dtype=np.int64), np.empty(max_runs, dtype=np.int64), np.empty(max_runs, dtype=np.int32)
         got, nr, ok = C.c_int64(0), C.c_int64(0), C.c_int(0)
         check(self._L.pg_tokenize_collect(self._h, int(slot), pos, len(pos), rrow, roff, rlen, max_runs, C.byref(got), C.byref(nr), C.byref(ok)))

@@ -809,7 +809,7 @@ def find_run_boundary_bgzf(path, guess, wanted):
 # ---- packed `.pgeno` files: a tokenised `.geno` kept on disk ---------------------------------------------------------------
 # SURVEY.md 8f row 4.  Layout (little endian): magic, u32 length + JSON header {"names": [...], "ploidy": [...], "codec": ...}
 # (file column order), then blocks { u64 n_rows, u32 n_runs, n_runs x (u64 first_row, u16 len, scaffold name),
-# payload }, terminated by a block with n_rows = 0; payload = pos || u8 cells[n_rows][n_cols], stored raw (codec "none") or as
+# payload }, terminated by a block with n_rows = 0; payload = pos (i64 when the header says "pos_bytes": 8, else i32) || u8 cells[n_rows][n_cols], stored raw (codec "none") or as
 # independently deflated 4 MiB chunks (codec "zlib", the default: u32 n_chunks, n_chunks x (u32 stored, u32 raw), data; both sides
 # work on the chunks with a thread pool).  A cell byte = first allele code | second << 4 (one-hot
 # codes A=1 C=2 G=4 T=8, 0 = missing), independent of the text format it came from and of any population layout, so one packed
@@ -827,13 +827,21 @@ def _pool():
 
 
 class PackedWriter:
-    def __init__(self, path, names, ploidy, codec="zlib"):
+    """pos_bytes: width of the stored positions: 8 (int64: what the text tokenizers carry -- the reference parses Python integers,
+    genomics.py:1884-1904, and chromosomes of more than 2^31 bases exist) or 4 (files written before round 5; the header then has
+    no "pos_bytes" key)"""
+
+    def __init__(self, path, names, ploidy, codec="zlib", pos_bytes=8):
         import json
-        assert codec in ("none", "zlib")
+        assert codec in ("none", "zlib") and pos_bytes in (4, 8)
         self.f = open(path, "wb")
         self.n_cols = len(names)
         self.codec = codec
-        head = json.dumps({"names": list(names), "ploidy": [int(p) for p in ploidy], "codec": codec}).encode()
+        self.pos_bytes = pos_bytes
+        head = {"names": list(names), "ploidy": [int(p) for p in ploidy], "codec": codec}
+        if pos_bytes != 4:
+            head["pos_bytes"] = pos_bytes
+        head = json.dumps(head).encode()
         self.f.write(PGENO_MAGIC + len(head).to_bytes(4, "little") + head)
 
     def write_block(self, data, cells):
@@ -847,7 +855,10 @@ class PackedWriter:
             b = nm.encode()
             out += [int(st).to_bytes(8, "little"), len(b).to_bytes(2, "little"), b]
         self.f.write(b"".join(out))
-        payload = np.ascontiguousarray(data.pos, dtype="<i4").tobytes() + np.ascontiguousarray(cells, dtype=np.uint8).tobytes()
+        pos = np.asarray(data.pos)
+        if self.pos_bytes == 4 and len(pos) and (int(pos.max()) > 0x7FFFFFFF or int(pos.min()) < -0x80000000):
+            raise ValueError("a position beyond 32 bits in a .pgeno file with 4-byte positions")
+        payload = np.ascontiguousarray(pos, dtype="<i%d" % self.pos_bytes).tobytes() + np.ascontiguousarray(cells, dtype=np.uint8).tobytes()
         if self.codec == "none":
             self.f.write(payload)
             return
@@ -869,8 +880,9 @@ class _PackedBlock:
     """One block of a `.pgeno` file as read from disk: scaffold runs + either the materialised arrays (pos, cells) or the still
     deflated chunks (comp, table), which PackedReader.to_geno inflates straight into their destination (pg_inflate_chunks)."""
 
-    def __init__(self, starts, names, n, n_cols, pos=None, cells=None, comp=None, table=None, fd=None, pos_off=0, cells_off=0):
+    def __init__(self, starts, names, n, n_cols, pos=None, cells=None, comp=None, table=None, fd=None, pos_off=0, cells_off=0, pos_bytes=4):
         self.starts, self.names, self.n, self.n_cols = starts, names, n, n_cols
+        self.pos_bytes = pos_bytes        # width of the positions in the file (4 or 8); in memory they are int64
         self.pos, self.cells, self.comp, self.table = pos, cells, comp, table
         # codec "none": the payload stays in the file until somebody wants it -- the device route reads the cells with the staging
         # threads of the tokenizer (pg_stage_file), the host route straight into its destination
@@ -881,7 +893,7 @@ class _PackedBlock:
 
     def positions(self):
         if self.in_file():
-            return np.frombuffer(os.pread(self.fd, 4 * self.n, self.pos_off), dtype="<i4")
+            return np.frombuffer(os.pread(self.fd, self.pos_bytes * self.n, self.pos_off), dtype="<i%d" % self.pos_bytes).astype(np.int64)
         self.materialise()
         return self.pos
 
@@ -896,7 +908,15 @@ class _PackedBlock:
             got += k
 
     def inflate_into(self, pos_dst, cells_dst, n_threads=0):
-        """positions -> pos_dst[n] (int32), cells -> cells_dst[n][n_cols] (uint8, C-contiguous rows)"""
+        """positions -> pos_dst[n] (int64), cells -> cells_dst[n][n_cols] (uint8, C-contiguous rows)"""
+        if self.pos_bytes != 8 and (self.in_file() or self.comp is not None):      # 4-byte positions: through a buffer of their own
+            tmp = np.empty(self.n, dtype=np.int32)
+            self._inflate_raw(tmp, cells_dst, n_threads)
+            pos_dst[...] = tmp
+            return
+        self._inflate_raw(pos_dst, cells_dst, n_threads)
+
+    def _inflate_raw(self, pos_dst, cells_dst, n_threads=0):
         if self.in_file():
             assert pos_dst.flags.c_contiguous and cells_dst.flags.c_contiguous
             self._read_into(self.fd, pos_dst, self.pos_off)
@@ -912,16 +932,16 @@ class _PackedBlock:
         src = np.frombuffer(self.comp, dtype=np.uint8)
         check(_lib.lib().pg_inflate_chunks(C.c_void_p(src.ctypes.data), off, np.ascontiguousarray(stored),
                                            np.ascontiguousarray(self.table[:, 1].astype(np.int64)), len(stored),
-                                           C.c_void_p(pos_dst.ctypes.data), 4 * self.n, C.c_void_p(cells_dst.ctypes.data),
+                                           C.c_void_p(pos_dst.ctypes.data), self.pos_bytes * self.n, C.c_void_p(cells_dst.ctypes.data),
                                            self.n * self.n_cols, n_threads))
 
     def materialise(self):
         if self.in_file():
-            pos, cells = np.empty(self.n, dtype=np.int32), np.empty((self.n, self.n_cols), dtype=np.uint8)
+            pos, cells = np.empty(self.n, dtype=np.int64), np.empty((self.n, self.n_cols), dtype=np.uint8)
             self.inflate_into(pos, cells)
             self.pos, self.cells = pos, cells
         if self.comp is not None:
-            pos, cells = np.empty(self.n, dtype=np.int32), np.empty((self.n, self.n_cols), dtype=np.uint8)
+            pos, cells = np.empty(self.n, dtype=np.int64), np.empty((self.n, self.n_cols), dtype=np.uint8)
             self.inflate_into(pos, cells)
             self.pos, self.cells, self.comp, self.table = pos, cells, None, None
         return self
@@ -932,10 +952,10 @@ class _PackedBlock:
         names = [self.names[k] for k in keep]
         starts = np.maximum(self.starts[keep] - a, 0)
         if self.in_file():
-            return _PackedBlock(starts, names, b - a, self.n_cols, fd=self.fd, pos_off=self.pos_off + 4 * a,
-                                cells_off=self.cells_off + a * self.n_cols)
+            return _PackedBlock(starts, names, b - a, self.n_cols, fd=self.fd, pos_off=self.pos_off + self.pos_bytes * a,
+                                cells_off=self.cells_off + a * self.n_cols, pos_bytes=self.pos_bytes)
         self.materialise()
-        return _PackedBlock(starts, names, b - a, self.n_cols, self.pos[a:b], self.cells[a:b])
+        return _PackedBlock(starts, names, b - a, self.n_cols, self.pos[a:b], self.cells[a:b], pos_bytes=self.pos_bytes)
 
 
 class PackedReader:
@@ -952,6 +972,9 @@ class PackedReader:
         hl = int.from_bytes(self.f.read(4), "little")
         self.head = json.loads(self.f.read(hl).decode())
         self.names, self.ploidy = self.head["names"], np.asarray(self.head["ploidy"], dtype=np.int32)
+        self.pos_bytes = int(self.head.get("pos_bytes", 4))           # (files written before round 5: 4-byte positions, no key)
+        if self.pos_bytes not in (4, 8):
+            raise ValueError("%s: positions of %d bytes" % (path, self.pos_bytes))
         self.codec = self.head.get("codec", "none")
         if self.codec not in ("none", "zlib"):
             raise ValueError("%s: unknown codec %r" % (path, self.codec))
@@ -985,7 +1008,7 @@ class PackedReader:
                 ln = int.from_bytes(f.read(2), "little")
                 names.append(f.read(ln).decode())
             if self.codec == "none":
-                f.seek(4 * n + n * self.n_cols, 1)
+                f.seek(self.pos_bytes * n + n * self.n_cols, 1)
             else:
                 n_chunks = int.from_bytes(f.read(4), "little")
                 table = np.frombuffer(f.read(8 * n_chunks), dtype="<u4").reshape(-1, 2)
@@ -1041,7 +1064,7 @@ class PackedReader:
             self.done = True
 
     def positions(self, blocks, a, b):
-        """positions of the global rows [a, b): the position arrays are the first 4 * n_rows bytes of the payloads of the blocks that
+        """positions of the global rows [a, b): the position arrays are the first pos_bytes * n_rows bytes of the payloads of the blocks that
         overlap the range (the deflated chunks that hold them are inflated, nothing else is read); the file position is restored"""
         import zlib
         f, here, out = self.f, self.f.tell(), []
@@ -1054,19 +1077,19 @@ class PackedReader:
                 continue
             f.seek(off + 12 + sum(10 + len(nm.encode()) for nm in names))
             if self.codec == "none":
-                pos = np.frombuffer(f.read(4 * n), dtype="<i4")
+                pos = np.frombuffer(f.read(self.pos_bytes * n), dtype="<i%d" % self.pos_bytes).astype(np.int64)
             else:
                 n_chunks = int.from_bytes(f.read(4), "little")
                 table = np.frombuffer(f.read(8 * n_chunks), dtype="<u4").reshape(-1, 2)
                 raw, k = b"", 0
-                while len(raw) < 4 * n:
+                while len(raw) < self.pos_bytes * n:
                     raw += zlib.decompress(f.read(int(table[k, 0])))
                     k += 1
-                pos = np.frombuffer(raw[:4 * n], dtype="<i4")
+                pos = np.frombuffer(raw[:self.pos_bytes * n], dtype="<i%d" % self.pos_bytes).astype(np.int64)
             cache[off] = pos
             out.append(pos[max(a - g, 0):min(b - g, n)])
         f.seek(here)
-        return np.concatenate(out) if out else np.zeros(0, dtype=np.int32)
+        return np.concatenate(out) if out else np.zeros(0, dtype=np.int64)
 
     def _one(self):
         raw = self.f.read(8)
@@ -1080,7 +1103,7 @@ class PackedReader:
             starts.append(int.from_bytes(self.f.read(8), "little"))
             ln = int.from_bytes(self.f.read(2), "little")
             names.append(self.f.read(ln).decode())
-        want = 4 * n + n * self.n_cols
+        want = self.pos_bytes * n + n * self.n_cols
         starts = np.asarray(starts, dtype=np.int64)
         if self.codec == "none":
             at = self.f.tell()
@@ -1088,7 +1111,8 @@ class PackedReader:
                 raise ValueError("truncated .pgeno file")
             self.f.seek(want, 1)                              # the payload stays where it is: whoever needs it reads it from there
             self.bytes_read += 12 + want
-            blk = _PackedBlock(starts, names, n, self.n_cols, fd=self.f.fileno(), pos_off=at, cells_off=at + 4 * n)
+            blk = _PackedBlock(starts, names, n, self.n_cols, fd=self.f.fileno(), pos_off=at, cells_off=at + self.pos_bytes * n,
+                               pos_bytes=self.pos_bytes)
         else:
             n_chunks = int.from_bytes(self.f.read(4), "little")
             table = np.frombuffer(self.f.read(8 * n_chunks), dtype="<u4").reshape(-1, 2)
@@ -1098,7 +1122,7 @@ class PackedReader:
             if len(comp) != int(table[:, 0].sum()):
                 raise ValueError("truncated .pgeno file")
             self.bytes_read += 16 + 8 * n_chunks + len(comp)
-            blk = _PackedBlock(starts, names, n, self.n_cols, comp=comp, table=table)
+            blk = _PackedBlock(starts, names, n, self.n_cols, comp=comp, table=table, pos_bytes=self.pos_bytes)
         g0, self._g = self._g, self._g + n
         if self._rows is not None:                       # trim the block to this reader's rows
             a, b = max(self._rows[0] - g0, 0), min(self._rows[1] - g0, n)
@@ -1136,7 +1160,7 @@ class PackedReader:
         alloc = alloc or np.zeros
         width = self.n_cols if keep_packed else (int(pitch) if pitch else layout.n_hap)
         gt_full = alloc((head_rows + max(n, 1), width), np.uint8 if keep_packed else np.int8)
-        pos_full = alloc((head_rows + max(n, 1),), np.int32)
+        pos_full = alloc((head_rows + max(n, 1),), np.int64)
         gt, pos = gt_full[head_rows:head_rows + n], pos_full[head_rows:head_rows + n]
         starts, names, row = [], [], 0
         L = _lib.lib()

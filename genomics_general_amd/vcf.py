@@ -452,7 +452,7 @@ def parse_vcf_main(argv=None):
         aidx = np.zeros((cap, 2 * n_sel), dtype=np.int8)
         phase = np.zeros((cap, n_sel), dtype=np.uint8)
         rflag = np.zeros(cap, dtype=np.uint8)
-        pos = np.zeros(cap, dtype=np.int32)
+        pos = np.zeros(cap, dtype=np.int64)
         coff, roff, aoff = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64)
         clen, rlen, alen = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
         n, nmb = C.c_int64(0), C.c_int64(0)

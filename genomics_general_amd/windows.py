@@ -1,7 +1,7 @@
 """Window index computation: which sites land in which window, and which (possibly empty) windows exist.
 
 The reference does this one text line at a time inside Python generators (genomics.py:1971-2223).  Here the
-positions of the whole input are already an int32 array (K0), so windows are computed as index ranges
+positions of the whole input are already an int64 array (K0), so windows are computed as index ranges
 [lo,hi) into it with searchsorted, reproducing the generators' observable behaviour:
 
   slidingCoordWindows   genomics.py:1971-2027  -> coord_windows

@@ -134,14 +134,14 @@ int pg_upload_wait(pg_ctx *ctx);
  * token in text), sorted by row, run_capacity entries each (*ok_out = 0 when there are more).  Call pg_count_lines first to
  * reserve the rows.  Blocks on the copy stream. */
 int pg_tokenize_text(pg_ctx *ctx, const char *text, int64_t len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
-                     const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out, int64_t row_capacity, int64_t *run_row_out,
+                     const int32_t *col_ploidy, int64_t row_offset, int64_t *pos_out, int64_t row_capacity, int64_t *run_row_out,
                      int64_t *run_off_out, int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out,
                      int *ok_out);
 /* The same for `len` bytes at offset file_offset of an open file (plain text on disk): the staging threads pread() the text from
  * the page cache straight into their page-locked buffers, so the block never has to be mapped, faulted in or walked by the host.
  * Offsets in run_off_out are relative to file_offset. */
 int pg_tokenize_file(pg_ctx *ctx, int fd, int64_t file_offset, int64_t len, int fmt, int n_cols, int max_ploidy,
-                     const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int32_t *pos_out, int64_t row_capacity,
+                     const int32_t *col_slot, const int32_t *col_ploidy, int64_t row_offset, int64_t *pos_out, int64_t row_capacity,
                      int64_t *run_row_out, int64_t *run_off_out, int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out,
                      int64_t *n_runs_out, int *ok_out);
 /* The device tokenizer in three steps, two blocks in flight (slot 0 / 1), for a caller that overlaps the kernels of one block with
@@ -155,7 +155,7 @@ int pg_tokenize_submit(pg_ctx *ctx, int slot, const char *text, int fd, int64_t 
                        int max_ploidy, const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out);
 int pg_tokenize_parse(pg_ctx *ctx, int slot, int64_t row_offset, int64_t row_capacity, int64_t run_capacity, int64_t *n_rows_out,
                       int *ok_out);
-int pg_tokenize_collect(pg_ctx *ctx, int slot, int32_t *pos_out, int64_t pos_capacity, int64_t *run_row_out, int64_t *run_off_out,
+int pg_tokenize_collect(pg_ctx *ctx, int slot, int64_t *pos_out, int64_t pos_capacity, int64_t *run_row_out, int64_t *run_off_out,
                         int32_t *run_len_out, int64_t run_capacity, int64_t *n_rows_out, int64_t *n_runs_out, int *ok_out);
 /* Packed cells (`.pgeno` with codec none: one byte per genotype) straight from the file, by the staging
  * threads of the device tokenizer: pg_stage_file brings `len` bytes at file_offset of fd to byte dst_offset of staging slot 0 / 1
@@ -194,7 +194,7 @@ int pg_synth_fill(pg_ctx *ctx, int64_t site_offset, int64_t n_sites, int64_t fir
  * Error PG_ERR_PARSE when a wanted cell does not have the width its ploidy/format implies (the
  * reference asserts "Sample ploidy doesn't match number of sequences", genomics.py:1111). */
 int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
-                   const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int32_t *pos_out, int64_t *scaf_off,
+                   const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int64_t *pos_out, int64_t *scaf_off,
                    int32_t *scaf_len, int64_t cap_sites, int64_t *n_sites_out, int n_threads);
 /* Row indices at which the scaffold token changes (contiguous scaffold runs, the unit slidingCoordWindows
  * restarts its window on, genomics.py:2013-2017).  n_runs_out is always the true count. */
@@ -250,7 +250,7 @@ typedef struct pg_vcf_filter {      /* --gtf flag=X min=X max=X siteTypes=.. gtT
 int pg_encode_vcf(const char *buf, size_t len, int n_vcf_samples, int n_sel, const int32_t *sel_col, const int32_t *sel_ploidy,
                   int flags, double min_qual, int max_ref_len, const pg_vcf_filter *filters, int n_filters, const char *contigs,
                   int n_contig_bytes, int contig_mode, char missing, const char *prev_chrom, int prev_chrom_len, const char *prev_pos,
-                  int prev_pos_len, uint8_t *chars_out, int8_t *idx_out, uint8_t *phase_out, uint8_t *row_flag_out, int32_t *pos_out,
+                  int prev_pos_len, uint8_t *chars_out, int8_t *idx_out, uint8_t *phase_out, uint8_t *row_flag_out, int64_t *pos_out,
                   int64_t *chrom_off, int32_t *chrom_len, int64_t *ref_off, int32_t *ref_len, int64_t *alt_off, int32_t *alt_len,
                   int64_t cap_sites, int64_t *n_sites_out, int64_t *n_multibase_out, int n_threads);
 
@@ -259,7 +259,7 @@ int pg_encode_vcf(const char *buf, size_t len, int n_vcf_samples, int n_sel, con
  * printed as NumPy prints a double rounded to four decimals (nan, 0.0, 0.3333).  run_of_row[i] indexes the scaffold names
  * (names[name_off[r] .. name_off[r+1])); keep[i] == 0 drops row i (NULL keeps all).  *out_len = bytes needed; PG_ERR_ARG when that
  * exceeds out_cap. */
-int pg_format_freq_rows(int mode, int64_t n_rows, int n_pops, const void *values, const int32_t *pos, const int32_t *run_of_row,
+int pg_format_freq_rows(int mode, int64_t n_rows, int n_pops, const void *values, const int64_t *pos, const int32_t *run_of_row,
                         const char *names, const int64_t *name_off, const uint8_t *keep, char *out, int64_t out_cap, int64_t *out_len,
                         int n_threads);
 

@@ -30,6 +30,10 @@ FIXTURES = {
     "four": dict(seed=20261003, n_dip=8, n_pops=4, scaf_len=[3000, 3000, 3000, 3000], density=0.5, var_thr=40000, miss_thr=5000,
                  fmt="phased", sep="/"),
     "haplo": dict(seed=20260929, n_dip=5, n_pops=2, scaf_len=[4000], density=0.5, var_thr=30000, miss_thr=4000, fmt="haplo", sep=""),
+    # positions beyond 32 bits (the reference parses Python integers, genomics.py:1884-1904; chromosomes of more than 2^31 bases
+    # exist): the first scaffold's positions straddle 2^31, the second starts at 3 * 10^9
+    "bigpos": dict(seed=20261004, n_dip=8, n_pops=4, scaf_len=[4000, 2000], density=0.5, var_thr=30000, miss_thr=5000, fmt="phased", sep="/",
+                   pos_offset=[2 ** 31 - 2000, 3000000000]),
 }
 
 
@@ -239,3 +243,17 @@ AUX_FILES = {
     "abba_exclude.txt": "chr2\n",
     "mixed_ploidy.txt": "".join("s%d %d\n" % (d, 1 if d in (1, 6, 9) else 2) for d in range(10)),
 }
+
+
+CASES += [
+    # ---- positions beyond 2^31 (int64 from the tokenizers to the CSV) ----
+    dict(name="bigpos_popgen_sites", tool="popgenWindows.py", fixture="bigpos",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "300", "-O", "100", "-m", "100", "--roundTo", "8",
+               "--addWindowID"] + pops_args(8, 4)),
+    dict(name="bigpos_popgen_coordinate", tool="popgenWindows.py", fixture="bigpos",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000000000", "-s", "500000000", "-m", "100", "--writeFailedWindows", "--addWindowID"] + pops_args(8, 4)),
+    dict(name="bigpos_abba_sites", tool="ABBABABAwindows.py", fixture="bigpos",
+         argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "400", "--overlap", "100", "-m", "50"] + abba_args(8)),
+    dict(name="bigpos_freq", tool="freq.py", fixture="bigpos",
+         argv=["-g", "{geno}", "-f", "phased"] + pops_args(8, 4)),
+]

@@ -37,6 +37,8 @@ def fixture_sites(p):
             pos = pos[keep]
         if k == 0 and "gap" in p:
             pos = pos[(pos < p["gap"][0]) | (pos > p["gap"][1])]
+        if "pos_offset" in p:
+            pos = pos + int(p["pos_offset"][k])
         scaf_ids.append(np.full(len(pos), k, dtype=np.int64))
         poss.append(pos)
     return np.concatenate(scaf_ids), np.concatenate(poss)

@@ -585,7 +585,7 @@ def _launch(tool, argv, size, port, env_extra=None):
 
 @pytest.mark.parametrize("name,sizes", [("one_popgen_overlap_failed_id", (2, 3, 8)), ("one_popgen_stepgap", (8,)), ("one_popgen_sites", (3, 8)),
                                         ("one_distmat_windows_id", (8,)), ("four_popgen_id", (2, 3, 8)), ("four_abba_overlap", (8,)),
-                                        ("four_fourpop", (3,))])
+                                        ("four_fourpop", (3,)), ("bigpos_popgen_sites", (3,))])
 def test_window_ranges_shard_one_and_four_scaffolds_over_2_3_and_8_ranks(name, sizes, tmp_path):
     """SURVEY 8e "else split a scaffold's window range": a ONE-scaffold file and a FOUR-scaffold file (the layout of the north-star
     data set) on 2, 3 and 8 ranks.  Every rank reads, tokenises and computes only its window range (genomics_general_amd.shardplan:

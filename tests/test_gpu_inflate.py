@@ -168,7 +168,8 @@ def test_goldens_as_plain_gzip_still_take_the_serial_reader(tmp_path, monkeypatc
 
 
 @pytest.mark.parametrize("name,tool,size", [("one_popgen_overlap_failed_id", "popgenWindows.py", 8), ("four_popgen_id", "popgenWindows.py", 3),
-                                            ("four_abba_overlap", "ABBABABAwindows.py", 2), ("holes_distmat_cat_nexus", "distMat.py", 3)])
+                                            ("four_abba_overlap", "ABBABABAwindows.py", 2), ("holes_distmat_cat_nexus", "distMat.py", 3),
+                                            ("bigpos_popgen_coordinate", "popgenWindows.py", 3)])
 def test_bgzf_on_several_ranks_cut_inside_members(name, tool, size, tmp_path):
     import gzip
     import subprocess

@@ -47,6 +47,9 @@ for label, path, env in runs:
         for ln in r.stderr.decode().splitlines():
             if ln.startswith("PG_TOK_TRACE"):
                 print("   ", ln)
+            if ln.startswith("PG_TIMELINE ") and rep == 1:
+                for th, lab, a, b in json.loads(ln[len("PG_TIMELINE "):]):
+                    print("    TL %-12s %-11s %8.1f -> %8.1f ms  (%6.1f)" % (th, lab, a * 1e3, b * 1e3, (b - a) * 1e3))
         tm = json.loads(line[-1][len("PG_TIMING "):])
         res[label] = tm
         print(label, rep, json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm.items()}), flush=True)
