@@ -926,7 +926,10 @@ def _near_rounding_tie(v, digits, ratio=False, difference=False):
         s = np.abs(v) * 10.0 ** digits
         d = np.abs(s - np.floor(s) - 0.5)
         near = np.isfinite(v) & ((d < np.maximum(1e-6, s * 1e-10)) | (np.abs(v) < 1e-12))
-        if difference:               # 1 - pi_s / pi_t: the error of the quotient is absolute (1e-11 bounds it), whatever is left of it
+        if difference or ratio:
+            # 1 - pi_s / pi_t, (ABBA - BABA) / (ABBA + BABA), ...: what is printed is what is LEFT of sums that cancel, so the error of
+            # the value is absolute (n eps of the sums' magnitude: 1e-11 bounds it relative to a denominator of the value's own
+            # scale), not relative to the small value
             near |= np.isfinite(v) & (d < 10.0 ** digits * 1e-11)
         if ratio:
             near |= np.isinf(v) | (np.isfinite(v) & (np.abs(v) > 100.0))

@@ -1,9 +1,9 @@
 """-m gpu: the drop-in command lines, end to end (.geno text -> K0 -> HIP kernels -> CSV), against the committed
 outputs of the unmodified reference (tests/golden/, made by tests/golden/make_golden.py).
 
-Cells must be textually identical except floating-point cells that sit on a rounding tie (a 1-ulp difference can flip one;
-SURVEY.md section 7 'float formatting parity'): those differ by exactly one unit of the rounding digit, and -- checked by
-printing them again with 12 digits -- their value lies within 1e-9 of the midpoint."""
+Every cell must be the reference's TEXT: the float64 sums of the goldens' windows run in NumPy's own order on the device, so there is
+no rounding-tie allowance (compare_text asserts on any difference; its `ties=True` mode, one unit of the last digit, is only for
+outputs whose windows exceed 4096 sites and is not used by the golden tests)."""
 import os
 
 import pytest

@@ -52,7 +52,7 @@ def on_ranks(n, fn):
     return out
 
 
-def random_input(rng, max_runs=5, max_rows=120, pool=("c0", "c1", "c2", "c3"), dense=False):
+def random_input(rng, max_runs=5, max_rows=120, pool=("c0", "c1", "c2", "c3"), dense=False, span=600):
     names, starts, pos, prev = [], [], [], None
     for _ in range(int(rng.integers(1, max_runs + 1))):
         nm = str(rng.choice([x for x in pool if x != prev]))
@@ -64,7 +64,7 @@ def random_input(rng, max_runs=5, max_rows=120, pool=("c0", "c1", "c2", "c3"), d
             p0 = int(rng.integers(1, 40))
             pos += list(range(p0, p0 + n))
         else:
-            pos += list(np.sort(rng.integers(1, 600, size=n)))       # duplicates of a position included
+            pos += list(np.sort(rng.integers(1, span, size=n)))      # duplicates of a position included
     return np.array(starts), names, np.array(pos, dtype=np.int32)
 
 
@@ -186,10 +186,31 @@ def test_sites_windows_of_window_range_shards_are_the_windows_of_the_whole_input
         write_geno(path, starts, names, pos, rng, comments=trial % 5 == 2)
         w = int(rng.integers(2, 40))
         ov = int(rng.integers(0, w))
-        ms = max(int(rng.integers(1, w + 1)), ov + 1)
+        ms = int(rng.integers(1, w + 1))                     # (-m may lie below -O: ADVICE round 4)
         exc = [str(v) for v in rng.choice(["c0", "c1", "c2", "c3"], size=1)] if trial % 4 == 3 else None
         for n_ranks in (2, 3, 8):
             check_plan(path, starts, names, pos, "sites", w, ov, n_ranks, rng, None, exc, min_sites=ms)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_shards_with_sixteen_ranks_sparse_positions_and_scaffold_names_that_prefix_each_other(seed, tmp_path):
+    """minSites anywhere in 1..w (also below the overlap), 2 / 5 / 16 ranks, positions spread over 10^6 (most
+    coordinate windows empty), scaffold names c, c1, c10, c100 (a run boundary must not be found by a prefix match)"""
+    rng = np.random.default_rng(7300 + seed)
+    path = str(tmp_path / "x.geno")
+    pool = ("c", "c1", "c10", "c100")
+    for trial in range(40):
+        starts, names, pos = random_input(rng, max_runs=1 if trial % 3 == 0 else 6, pool=pool, span=1000000 if trial % 2 else 600)
+        write_geno(path, starts, names, pos, rng, comments=trial % 5 == 2)
+        w = int(rng.integers(2, 40))
+        ov = int(rng.integers(0, w))
+        ms = int(rng.integers(1, w + 1))
+        exc = [str(rng.choice(pool))] if trial % 4 == 3 else None
+        cw = int(rng.integers(3, 150)) * (2000 if trial % 2 else 1)
+        cstep = int(rng.integers(1, 2 * cw))
+        for n_ranks in (2, 5, 16):
+            check_plan(path, starts, names, pos, "sites", w, ov, n_ranks, rng, None, exc, min_sites=ms)
+            check_plan(path, starts, names, pos, "coordinate", cw, cstep, n_ranks, rng, None, exc)
 
 
 @pytest.mark.parametrize("seed", range(3))
@@ -214,7 +235,7 @@ def test_window_range_shards_of_bgzf_and_packed_input(seed, tmp_path):
                          codec="zlib" if trial % 2 else "none")
         ws = int(rng.integers(2, 40))
         ov = int(rng.integers(0, ws))
-        ms = max(int(rng.integers(1, ws + 1)), ov + 1)
+        ms = int(rng.integers(1, ws + 1))
         for n_ranks in (2, 3, 8):
             check_plan(path[:-5] + ".pgeno", starts, names, pos, "coordinate", w, step, n_ranks, rng, None, exc)
             check_plan(path[:-5] + ".pgeno", starts, names, pos, "sites", ws, ov, n_ranks, rng, None, exc, min_sites=ms)

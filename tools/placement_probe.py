@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Does the pack kernel's time on an EMPTY (zeroed) resident buffer predict its time on the same physical allocation once the
-data is there?  The kernel's time moves by +-6 % with the physical pages behind the 40 GB of rows (tools/pack_variance.py); if a
+data is there?  The kernel's time moves by +-6 % with the physical pages behind the 40 GB of rows (tools/attic/pack_variance.py); if a
 probe on the fresh allocation tells the two apart, reserve() could try a few allocations and keep a fast one.
 
     python tools/placement_probe.py [n_trials]"""
