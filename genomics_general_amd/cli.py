@@ -914,7 +914,7 @@ def _fmt_cell(v):
     return str(v)
 
 
-NP_MAX_SITES = 4096      # csrc/pg_internal.h PG_NP_MAX_SITES: windows of up to this many sites get their sums in NumPy's order anyway
+NP_MAX_SITES = 256       # csrc/pg_internal.h PG_NP_MAX_SITES: windows of up to this many sites get their sums in NumPy's order anyway
 
 
 def _near_rounding_tie(v, digits, ratio=False, difference=False):

@@ -25,7 +25,7 @@
 #define PG_XV_CAP_DEFAULT(grp) ((grp) + 1)
 // windows of up to this many sites get their float64 sums in NumPy's order (k_popdist_np, k_quartet_np): quotients and products of
 // small integers sit on rounding ties of the printed digit, differences of equal means are +-0.0
-#define PG_NP_MAX_SITES 4096
+#define PG_NP_MAX_SITES 256
 #define PG_FLAG_MISMATCH 1      // some individual's two haplotypes differ in calledness: the diploid shortcut does not apply
 #define PG_FLAG_XV_OVERFLOW 2   // a window produced more XV words than reserved
 

@@ -183,7 +183,7 @@ def test_infer_ploidy_of_a_piped_input(tmp_path):
 
 @pytest.mark.parametrize("tool", ["popgenWindows.py", "ABBABABAwindows.py"])
 def test_long_windows_take_the_refinement_pass_on_the_cpu_engine(tool, tmp_path, monkeypatch, capfd):
-    """windows of more than 4096 sites: cli._refine_long_windows looks for values within reach of a rounding tie and computes those
+    """windows of more than cli.NP_MAX_SITES (256) sites: cli._refine_long_windows looks for values within reach of a rounding tie and computes those
     windows again (on the stand-in engine: the same numbers) -- the bookkeeping of that second pass (masks, replaced rows, timing
     field) without a GPU; text == the oracle's command line"""
     import json
@@ -210,4 +210,4 @@ def test_long_windows_take_the_refinement_pass_on_the_cpu_engine(tool, tmp_path,
         assert f.read() == want
     if tool == "popgenWindows.py":
         t = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("PG_TIMING ")]
-        assert json.loads(t[-1][len("PG_TIMING "):]).get("windows_recomputed_in_numpy_order", 0) == 2       # the two windows of 5000 sites
+        assert json.loads(t[-1][len("PG_TIMING "):]).get("windows_recomputed_in_numpy_order", 0) == 3       # 5000 + 5000 + 1000 sites: all beyond 256

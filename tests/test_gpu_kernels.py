@@ -102,6 +102,7 @@ def test_pairwise_matches_reference_pair_loop_small():
 @pytest.mark.parametrize("min_sites,min_data,miss", [(1, 0.01, 5000), (40, 0.5, 30000), (300, 0.01, 20000)])
 def test_group_dist_stats(min_sites, min_data, miss):
     e, lay, codes, _ = G.make_engine(20, 4, 2400, seed=21, miss_thr=miss)
+    e.set_sum_order(1)          # NumPy's order for every window: these tests hold the NumPy-order kernels against the oracle with ==
     wins = [(0, 800), (800, 1100), (1100, 2400)]
     wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
     st = wb.groupDistStats(doPairs=True, minSites=min_sites, minData=min_data)
@@ -140,6 +141,7 @@ def test_group_dist_stats_to_the_last_bit_in_numpy_order(sizes, names, haploid, 
     e = Engine(0)
     e.set_layout(lay)
     e.load_sites(codes)
+    e.set_sum_order(1)          # NumPy's order for every window: these tests hold the NumPy-order kernels against the oracle with ==
     wins = [(0, L), (0, L // 3), (L // 3, L // 3 + 11), (5, 6), (max(0, L - 40), L)]
     for min_sites, min_data in ((1, 0.01), (8, 0.5)):
         st = e.batch([w[0] for w in wins], [w[1] for w in wins]).groupDistStats(doPairs=True, minSites=min_sites, minData=min_data)
@@ -153,18 +155,18 @@ def test_group_dist_stats_to_the_last_bit_in_numpy_order(sizes, names, haploid, 
 
 
 def test_sum_order_can_be_set_through_the_api():
-    """pg_set_sum_order: 1 = NumPy's order for every window (a window of 6000 sites == the oracle), 2 = for none (a window of 500
-    sites within 1e-9), 0 = by window length again"""
+    """pg_set_sum_order: 1 = NumPy's order for every window (a window of 6000 sites == the oracle), 2 = for none (a window of 200
+    sites within 1e-9), 0 = by window length again (cli.NP_MAX_SITES = PG_NP_MAX_SITES = 256 sites)"""
     e, lay, codes, _ = G.make_engine(10, 2, 6500, seed=73, var_thr=40000, miss_thr=9000)
 
     def stats(a, b):
         aln = oracle_aln(lay, codes, a, b)
         Do, Co = orc.pair_counts_gemm(aln)
         return orc.group_dist_stats(aln, Do, Co, True, 5, 0.01)[0]
-    long_w, short_w = stats(0, 6000), stats(6000, 6500)
+    long_w, short_w = stats(0, 6000), stats(6000, 6200)
     for mode, same_long, same_short in ((1, True, True), (2, False, False), (0, False, True)):
         e.set_sum_order(mode)
-        st = e.batch([0, 6000], [6000, 6500]).groupDistStats(True, 5, 0.01)
+        st = e.batch([0, 6000], [6000, 6200]).groupDistStats(True, 5, 0.01)
         for key in long_w:
             assert (G.same if same_long else G.close)(st[key][0], long_w[key]), (mode, key, st[key][0], long_w[key])
             assert (G.same if same_short else G.close)(st[key][1], short_w[key]), (mode, key, st[key][1], short_w[key])
@@ -186,10 +188,12 @@ def test_populations_too_large_for_the_numpy_order_tree_keep_the_fixed_tree():
 
 
 def test_summation_order_is_chosen_window_by_window():
-    """windows of up to 4096 sites: NumPy's order (== the oracle); longer ones: the fixed trees (1e-9); a window's numbers do not
-    depend on the batch it is in (pg_popdist_stats, quartet_stats: the kernels skip each other's windows)"""
+    """windows of up to cli.NP_MAX_SITES (256) sites: NumPy's order (== the oracle); longer ones: the fixed trees (1e-9; the drivers
+    compute a window again in NumPy's order where a printed digit could differ); a window's numbers do not depend on the batch it is
+    in (pg_popdist_stats, quartet_stats: the kernels skip each other's windows)"""
+    from genomics_general_amd.cli import NP_MAX_SITES as T
     e, lay, codes, _ = G.make_engine(12, 4, 9000, seed=71, var_thr=40000, miss_thr=9000)
-    wins = [(0, 9000), (0, 3000), (3000, 7097), (100, 4196), (4196, 4196), (8000, 9000), (10, 4107)]
+    wins = [(0, 9000), (0, T - 56), (3000, 3000 + T + 1), (100, 100 + T), (4196, 4196), (8000, 8000 + T // 2), (10, 10 + T + 1), (500, 4596)]
     lo, hi = [w[0] for w in wins], [w[1] for w in wins]
     st = e.batch(lo, hi).groupDistStats(True, 5, 0.01)
     ab = e.batch(lo, hi).ABBABABA("p0", "p1", "p2", "p3", 0.3)
@@ -202,7 +206,7 @@ def test_summation_order_is_chosen_window_by_window():
             assert G.same(ab[key][k], one_ab[key][0]), (key, k)
         if b == a:
             continue
-        short = b - a <= 4096
+        short = b - a <= T
         aln = oracle_aln(lay, codes, a, b)
         Do, Co = orc.pair_counts_gemm(aln)
         so, _ = orc.group_dist_stats(aln, Do, Co, True, 5, 0.01)
@@ -246,6 +250,7 @@ def test_ind_pair_dists_with_and_without_popdist_mask():
                                                  (600, 0.3, 9000)])     # 1200-byte rows: quad-layout screening
 def test_abbababa_sums(n_dip, min_data, miss):
     e, lay, codes, _ = G.make_engine(n_dip, 4, 6000, seed=44, var_thr=45000, miss_thr=miss)
+    e.set_sum_order(1)          # NumPy's order for every window: these tests hold the NumPy-order kernels against the oracle with ==
     wins = [(0, 3000), (3000, 3010), (3010, 6000), (10, 10), (2, 4097), (100, 230)]
     wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
     got = wb.ABBABABA("p0", "p1", "p2", "p3", min_data)
@@ -289,6 +294,7 @@ def test_fourpop_sums(mode, n_dip, min_data, miss):
     """genomics.fourPop: all 12 statistics + sitesUsed in the three allele-choice modes, incl. the argsort tie rule (8 or 16
     diploids give many 50:50 sites) and 0/0 frequencies under --minData 0"""
     e, lay, codes, _ = G.make_engine(n_dip, 4, 6000, seed=45 + n_dip, var_thr=45000, miss_thr=miss)
+    e.set_sum_order(1)          # NumPy's order for every window: these tests hold the NumPy-order kernels against the oracle with ==
     wins = [(0, 3000), (3000, 3010), (3010, 6000), (10, 10), (1, 2100)]
     wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
     got = wb.fourPop("p0", "p1", "p2", "p3", min_data, polarize=mode == "polarize", fixed=mode == "fixed")
@@ -419,6 +425,7 @@ def test_half_missing_genotypes_fall_back_to_haplotype_level_called_counts():
     e = Engine(0)
     e.set_layout(lay)
     e.load_sites(codes)
+    e.set_sum_order(1)          # NumPy's order for every window: these tests hold the NumPy-order kernels against the oracle with ==
     wins = [(0, 1500), (1500, 3000)]
     wb = e.batch([w[0] for w in wins], [w[1] for w in wins])
     D, C = wb.pairCounts(reference_order=True)
