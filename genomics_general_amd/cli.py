@@ -189,6 +189,12 @@ class Run:
         else:
             names = self._reader.read_header().decode("utf-8", "replace").split()[2:]
         self.timing["read_s"] += time.perf_counter() - t0
+        f = getattr(self._reader, "f", None)
+        if (args.genoFile and str(args.genoFile).endswith(".gz") and not isinstance(f, genoio.BgzfFile) and self.world.rank == 0
+                and os.path.getsize(args.genoFile) > int(os.environ.get("PG_GZIP_HINT_BYTES", 64 << 20))):
+            # one gzip stream has no independent pieces: it is inflated serially (~ 0.4 GB/s of text), whatever the GPU does
+            sys.stderr.write("note: %s is a single gzip stream and is inflated serially; written by `bgzip` (or tools/bgzip.py) the same "
+                             "text is inflated on the GPU, about a hundred times faster\n" % args.genoFile)
         self.layout = HapLayout(sampleData, names, args.genoFormat)
         self._infer_ploidy = bool(getattr(args, "inferPloidy", False))
         self._wparams = dict(wparams, include=args.include, exclude=args.exclude)

@@ -211,3 +211,12 @@ def test_long_windows_take_the_refinement_pass_on_the_cpu_engine(tool, tmp_path,
     if tool == "popgenWindows.py":
         t = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("PG_TIMING ")]
         assert json.loads(t[-1][len("PG_TIMING "):]).get("windows_recomputed_in_numpy_order", 0) == 3       # 5000 + 5000 + 1000 sites: all beyond 256
+
+
+def test_a_large_single_stream_gzip_input_gets_the_bgzip_hint(tmp_path, monkeypatch, capfd):
+    """a plain gzip file is inflated serially; beyond PG_GZIP_HINT_BYTES the driver says so once and names bgzip"""
+    case = [c for c in CASES if c["name"] == "c1_popgen"][0]
+    monkeypatch.setenv("PG_GZIP_HINT_BYTES", "1000")
+    run_case(case, tmp_path, monkeypatch)
+    err = capfd.readouterr().err
+    assert err.count("single gzip stream") == 1 and "bgzip" in err

@@ -1,0 +1,190 @@
+"""The DEFLATE decoder the GPU runs (genomics_general_amd/csrc/pg_inflate_core.h: one wavefront per BGZF member) held against zlib
+WITHOUT a GPU: tests/inflate_emul.cpp compiles the very same source as a lockstep emulation of its 64 lanes (every per-lane statement
+of the kernel is one memory operation, executed for lane 0 .. 63 in turn -- the order the hardware gives them).  So an error in the
+bit reader, the canonical Huffman decoding by limits, the table builder, the LDS ring, the flush in aligned pieces or the copy of
+overlapping matches shows up on every machine; what the GPU adds (tests/test_gpu_inflate.py) is the real thing at scale.
+
+Also here: the host side of the BGZF route -- pg_bgzf_walk, pg_inflate_members, pg_bgzf_compress, genoio.BgzfFile.read_span."""
+import ctypes as C
+import gzip
+import os
+import random
+import struct
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+from genomics_general_amd import genoio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emul(tmp_path_factory):
+    d = tmp_path_factory.mktemp("emul")
+    so = str(d / "libinflate_emul.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", os.path.join(ROOT, "tests", "inflate_emul.cpp"), "-o", so])
+    L = C.CDLL(so)
+    L.pgi_emul_inflate_at.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int]
+
+    def run(stream, out_len, pre=0, post=0, misalign=0, rng=random):
+        comp = bytes(rng.randrange(256) for _ in range(pre)) + stream + bytes(rng.randrange(256) for _ in range(post))
+        dst = C.create_string_buffer(max(out_len, 1) + 8)
+        rc = L.pgi_emul_inflate_at(comp, len(comp), pre, len(stream), dst, out_len, misalign)
+        return rc, dst.raw[:out_len]
+    return run
+
+
+def deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, memlevel=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, memlevel, strategy)
+    return c.compress(data) + c.flush()
+
+
+def geno_text(rng, n, ns):
+    return ("\n".join("scaf%d\t%d\t" % (i // 1000, i * 37 + 1) + "\t".join(rng.choice(["A/A", "A/T", "T/T", "N/N", "A/A", "A/A"]) for _ in range(ns))
+                      for i in range(n)) + "\n").encode()
+
+
+def test_the_kernel_source_inflates_what_zlib_deflates(emul):
+    """every block type (stored, fixed, dynamic), levels 0 - 9, five strategies, two memory levels (memLevel 1: dozens of blocks per
+    member), outputs of 0 .. 70 000 bytes, matches of every distance from 1 to 69 (the pattern fill below the wavefront's width, the
+    stepwise copy above it), output addresses at every misalignment of the 16-byte flush"""
+    rng = random.Random(1)
+    cases = [b"", b"a", b"abcabcabcabcabcabcabcabc" * 50, b"\0" * 70000, bytes(rng.randrange(256) for _ in range(65280)),
+             bytes(rng.randrange(4) for _ in range(65280)), geno_text(rng, 300, 50)[:65280], geno_text(rng, 80, 200)[:65280]]
+    for n in (1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 128, 129, 257, 258, 259, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097):
+        cases += [b"x" * n, bytes(rng.randrange(256) for _ in range(n)), (b"ab" * n)[:n]]
+    for p in range(1, 70):
+        pat = bytes(rng.randrange(256) for _ in range(p))
+        cases.append((pat * 400)[:3000 + p])
+    n = 0
+    for data in cases:
+        for level in (0, 1, 4, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+                ml = 8 if n % 3 else 1
+                rc, out = emul(deflate(data, level, strat, ml), len(data), pre=n % 9, post=n % 5, misalign=n % 16, rng=rng)
+                n += 1
+                assert rc == 0 and out == data, (len(data), level, strat, ml, rc)
+    assert n > 3500
+
+
+def test_matches_that_reach_behind_the_lds_ring_read_global_memory(emul):
+    """distances beyond the 4 KiB ring (zlib looks back up to 32 KiB): the source is text the wavefront has already flushed"""
+    rng = random.Random(2)
+    block = bytes(rng.randrange(256) for _ in range(300))
+    for gap in (3700, 3776, 3777, 4000, 4096, 4097, 5000, 9000, 20000, 32000):
+        data = block + bytes(rng.randrange(256) for _ in range(gap - 300)) + block + b"tail" + block[:100]
+        for mis in (0, 5, 15):
+            rc, out = emul(deflate(data, 9), len(data), misalign=mis, rng=rng)
+            assert rc == 0 and out == data, (gap, mis, rc)
+
+
+def test_damaged_streams_end_in_an_error_and_touch_nothing_outside_their_output(emul):
+    """flipped bits and truncations: whenever zlib accepts the stream with the same output size the emulation gives zlib's bytes, otherwise
+    it reports an error; the bytes in front of and behind the member's output stay untouched (inflate_emul.cpp checks canaries)"""
+    rng = random.Random(7)
+    base = [geno_text(rng, 40, 50), bytes(rng.randrange(256) for _ in range(3000)), b"abc" * 1000, bytes(rng.randrange(3) for _ in range(5000))]
+    agree = err = 0
+    for it in range(2500):
+        data = rng.choice(base)
+        raw = bytearray(deflate(data, rng.choice([1, 6, 9]), rng.choice([0, 0, zlib.Z_FIXED, zlib.Z_RLE])))
+        for _ in range(rng.choice([1, 1, 2, 5])):
+            raw[rng.randrange(len(raw))] ^= 1 << rng.randrange(8)
+        if rng.random() < 0.1:
+            raw = raw[:rng.randrange(len(raw))]
+        raw = bytes(raw)
+        try:
+            d = zlib.decompressobj(-15)
+            ref = d.decompress(raw)
+            ok = d.eof and len(d.unused_data) == 0 and len(ref) == len(data)
+        except zlib.error:
+            ref, ok = None, False
+        rc, out = emul(raw, len(data), misalign=it % 16, rng=rng)
+        assert rc < (1 << 20), "the decoder wrote outside its output"
+        if ok:
+            assert rc == 0 and out == ref
+            agree += 1
+        else:
+            assert rc != 0
+            err += 1
+    assert agree > 500 and err > 500
+
+
+# ---- host side --------------------------------------------------------------------------------------------------------------------
+def test_bgzf_compress_walk_and_host_inflate_round_trip(tmp_path):
+    rng = random.Random(3)
+    text = geno_text(rng, 3000, 60)
+    bz = genoio.bgzf_compress(text, block=7000)
+    assert gzip.decompress(bz.tobytes()) == text                          # a valid multi-member gzip file for everybody else
+    tab, used, n_text = genoio.bgzf_walk(bz)
+    assert used == len(bz) and n_text == len(text) and int(tab[2][-1]) == 0          # the EOF member
+    assert genoio.bgzf_inflate(bz, tab).tobytes() == text
+    # the walk stops in front of an incomplete member, and at the text it was asked for
+    tab2, used2, _ = genoio.bgzf_walk(bz[:len(bz) - 40])
+    assert len(tab2[0]) == len(tab[0]) - 2 and used2 < len(bz) - 40
+    tab3, _, text3 = genoio.bgzf_walk(bz, None, 20000)
+    assert 20000 <= text3 < 20000 + 7000 and len(tab3[0]) == 3
+    # other extra subfields in front of BC, a file name: legal gzip
+    comp = deflate(b"hello\n")
+    m = (b"\x1f\x8b\x08\x0c\0\0\0\0\0\xff" + struct.pack("<H", 13) + b"XY\x03\x00abc" + b"BC\x02\x00" + struct.pack("<H", 12 + 13 + 2 + len(comp) + 8 - 1) +
+         b"a\0" + comp + struct.pack("<II", zlib.crc32(b"hello\n"), 6))
+    tab4, used4, _ = genoio.bgzf_walk(m)
+    assert used4 == len(m) and genoio.bgzf_inflate(m, tab4).tobytes() == b"hello\n"
+    # damage: the host pool names it
+    bad = bytearray(bz.tobytes())
+    bad[int(tab[0][2]) + 30] ^= 0x20
+    with pytest.raises(ValueError, match="damaged BGZF member"):
+        genoio.bgzf_inflate(bytes(bad), tab)
+    with pytest.raises(ValueError, match="stops being BGZF"):
+        genoio.bgzf_walk(b"\x1f\x8b\x08\x00" + bytes(30))
+
+
+@pytest.mark.parametrize("blk,want", [(900, 4000), (5000, 30000), (65280, 100000)])
+def test_read_span_cuts_blocks_behind_their_last_line_feed(blk, want, tmp_path):
+    """BgzfFile.read_span: blocks of deflated members whose text = head + members' text, cut behind the last line feed; what follows
+    is the head of the next block; every byte of the input exactly once; first_line is the block's first line"""
+    rng = random.Random(blk)
+    text = b"#CHROM\tPOS\t" + b"\t".join(b"s%d" % i for i in range(30)) + b"\n" + geno_text(rng, 1500, 30)
+    path = str(tmp_path / "x.geno.gz")
+    with open(path, "wb") as f:
+        f.write(genoio.bgzf_compress(text, block=blk).tobytes())
+    rd = genoio.BlockReader(path)
+    rd.spans = True
+    parts = [rd.read_header()]
+    n_spans = 0
+    while True:
+        b = rd.read_block(want)
+        if not len(b):
+            break
+        if isinstance(b, genoio.BgzfSpan):
+            n_spans += 1
+            body = bytes(b)
+            assert body.endswith(b"\n") and body.split(b"\n", 1)[0] == b.first_line and len(body) == len(b)
+            assert bytes(b[:1 << 16]).startswith(b.first_line + b"\n"[:1])
+            parts.append(body)
+        else:
+            parts.append(bytes(b))
+    rd.close()
+    assert b"".join(parts) == text and n_spans >= 2
+
+
+def test_a_line_longer_than_the_members_of_a_block_is_handed_on_as_text(tmp_path):
+    """lines of 300 kB in members of 20 kB: no member of a block ends a line -- the reader inflates on the host and still delivers whole lines"""
+    line = b"chr1\t1\t" + b"\t".join([b"A/T"] * 75000) + b"\n"
+    text = b"#h\n" + line + line.replace(b"\t1\t", b"\t2\t") + b"chr1\t3\tA/A\n"
+    path = str(tmp_path / "long.geno.gz")
+    with open(path, "wb") as f:
+        f.write(genoio.bgzf_compress(text, block=20000).tobytes())
+    rd = genoio.BlockReader(path)
+    rd.spans = True
+    got = [rd.read_header()]
+    while True:
+        b = rd.read_block(100000)
+        if not len(b):
+            break
+        got.append(bytes(b))
+        assert got[-1].endswith(b"\n")
+    assert b"".join(got) == text
