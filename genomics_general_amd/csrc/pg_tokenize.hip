@@ -62,30 +62,30 @@ __global__ __launch_bounds__(256) void k_nl_count(const uint8_t *__restrict__ te
     if (threadIdx.x == 0) tile_count[blockIdx.x] = sh[0];
 }
 
-// exclusive prefix of the tile counts (one block; a 1 GiB block of text has 65 536 tiles)
+// exclusive prefix of the tile counts (one block; a 1 GiB block of text has 65 536 tiles): every thread adds up a contiguous share
+// of the tiles, the 256 shares are scanned in LDS, every thread writes the prefixes of its share (the first version scanned 256
+// tiles per trip with sixteen barriers each: 0.30 ms per block of text, a tenth of what the tokenizer's kernels took)
 __global__ __launch_bounds__(256) void k_nl_scan(const int32_t *__restrict__ tile_count, int64_t n_tiles, int64_t *__restrict__ tile_base,
                                                  int64_t *__restrict__ total) {
     __shared__ long long sh[256];
-    __shared__ long long carry;
-    if (threadIdx.x == 0) carry = 0;
+    const int64_t per = (n_tiles + 255) / 256;
+    const int64_t t0 = (int64_t)threadIdx.x * per, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+    long long mine = 0;
+    for (int64_t t = t0; t < t1; ++t) mine += tile_count[t];
+    sh[threadIdx.x] = mine;
     __syncthreads();
-    for (int64_t t0 = 0; t0 < n_tiles; t0 += 256) {
-        const int64_t t = t0 + threadIdx.x;
-        const long long v = t < n_tiles ? tile_count[t] : 0;
-        sh[threadIdx.x] = v;
+    for (int d = 1; d < 256; d <<= 1) {
+        const long long x = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
         __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            const long long x = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += x;
-            __syncthreads();
-        }
-        if (t < n_tiles) tile_base[t] = carry + sh[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry += sh[255];
+        sh[threadIdx.x] += x;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    long long run = sh[threadIdx.x] - mine;
+    for (int64_t t = t0; t < t1; ++t) {
+        tile_base[t] = run;
+        run += tile_count[t];
+    }
+    if (threadIdx.x == 255) *total = sh[255];
 }
 
 __global__ __launch_bounds__(256) void k_nl_write(const uint8_t *__restrict__ text, int64_t len, const int64_t *__restrict__ tile_base,
@@ -252,6 +252,212 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
                 for (int k = 0; k < pl; ++k) out[slots[k]] = base_code(cell[step * k]);
             }
         }
+    }
+    if (bad) atomicOr(status, bad);
+}
+
+
+// k_tok_parse, second form: a wavefront takes LPW consecutive lines instead of one.  What that buys: the column tables (slots,
+// ploidies, cell offsets and widths: the block copies them into LDS once) are no longer four dependent global loads per cell; the
+// line-feed positions of the wavefront's lines are one load; the first 64 bytes of line r + 1 are on their way while line r's
+// cells are taken apart, and double as "the previous line" of the run test (no second load); a cell of up to three characters and
+// its separator is ONE (unaligned) dword load instead of four byte loads; the row is put together in LDS (a byte per slot, scattered
+// by the lanes) and leaves as ONE coalesced store of dwords -- the first form's two byte stores per cell touched every cache line of
+// the row eight times with byte masks -- and is written whole (zeros where no column lands), so the caller need not clear the rows.
+// Same outputs, same status bits as k_tok_parse, which stays for layouts whose tables do not fit LDS and as PG_TOK_PARSE=1 (A/B, tests).
+constexpr int TOK_LPW = 16;
+__global__ __launch_bounds__(256) void k_tok_parse2(const uint8_t *__restrict__ text, const int64_t *__restrict__ nl_pos, int64_t n_lines,
+                                                    int fmt, int n_cols, int cells_w, int max_ploidy, const int32_t *__restrict__ dcols,
+                                                    int8_t *__restrict__ rows, int S, int64_t *__restrict__ pos_out,
+                                                    int64_t *__restrict__ run_row, int64_t *__restrict__ run_off, int32_t *__restrict__ run_len,
+                                                    int32_t *__restrict__ n_runs, int64_t run_cap, int32_t *__restrict__ status, DipTable dip) {
+    extern __shared__ int32_t tab[];                      // col_slot [n_cols][max_ploidy] | col_ploidy | col_off | col_w
+    const int n_tab = n_cols * (max_ploidy + 3);
+    for (int k = (int)threadIdx.x; k < n_tab; k += 256) tab[k] = dcols[k];
+    __syncthreads();
+    const int32_t *col_slot = tab, *col_ploidy = tab + (size_t)n_cols * max_ploidy, *col_off = col_ploidy + n_cols, *col_w = col_off + n_cols;
+    const int lane = threadIdx.x & 63;
+    int8_t *const lrow = reinterpret_cast<int8_t *>(tab + n_tab) + (size_t)(threadIdx.x >> 6) * S;      // this wavefront's row (S bytes, S % 16 == 0)
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TOK_LPW;
+    if (row0 >= n_lines) return;
+    const int n_here = (int)(n_lines - row0 < TOK_LPW ? n_lines - row0 : TOK_LPW);
+    // line feeds of the lines row0 - 2 .. row0 + n_here - 1: lane i holds nl_pos[row0 - 2 + i] (-1 in front of the text)
+    long long nlv = -1;
+    {
+        const int64_t r = row0 - 2 + lane;
+        if (r >= 0 && lane < n_here + 2) nlv = nl_pos[r];
+    }
+    const int nl_lo = (int)(uint32_t)nlv, nl_hi = (int)(nlv >> 32);
+    auto nl_at = [&](int i) -> int64_t {                  // line feed of line row0 - 2 + i (uniform i)
+        return ((int64_t)__builtin_amdgcn_readlane(nl_hi, i) << 32) | (uint32_t)__builtin_amdgcn_readlane(nl_lo, i);
+    };
+    auto head = [&](int64_t ls, int64_t le) -> int {      // the first 64 bytes of a line, a byte per lane (10 behind its end)
+        const int nv = (int)(le - ls < 64 ? le - ls : 64);
+        return lane < nv ? (int)text[ls + lane] : 10;
+    };
+    int bad = 0;
+    // the line in front of the first one (its head is the "previous line" of the run test)
+    int64_t pls = 0, ple = 0;
+    int pch = 10;
+    if (row0 > 0) {
+        pls = nl_at(0) + 1;
+        ple = nl_at(1);
+        pch = head(pls, ple);
+    }
+    int64_t ls = nl_at(1) + 1, le = nl_at(2);
+    int ch = head(ls, le);
+    for (int r = 0; r < n_here; ++r) {
+        const int64_t row = row0 + r;
+        // the next line's head is requested before this line is taken apart
+        int64_t nls = 0, nle = 0;
+        int nch = 10;
+        if (r + 1 < n_here) {
+            nls = le + 1;
+            nle = nl_at(r + 3);
+            nch = head(nls, nle);
+        }
+        int64_t cells_at = -1;
+        int lbad = 0;
+        const int nv = (int)(le - ls < 64 ? le - ls : 64);
+        const uint64_t valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+        const uint64_t bl = __ballot(blank((uint8_t)ch)) & valid, nb = ~bl & valid;
+        bool fast = false;
+        if (nv > 0 && (nb & 1ull) && bl) {
+            const int p1 = __builtin_ctzll(bl);                                       // end of the scaffold token
+            const uint64_t r1 = nb & ~((1ull << p1) - 1ull);
+            if (r1) {
+                int d0 = __builtin_ctzll(r1);                                         // start of the position
+                const uint64_t b2 = bl & ~((1ull << d0) - 1ull);
+                if (b2) {
+                    const int p2 = __builtin_ctzll(b2);                               // its end
+                    const uint64_t r2 = nb & ~((1ull << p2) - 1ull);
+                    bool differs = row == 0, prev_ok = true;
+                    if (row > 0) {
+                        const int pnv = (int)(ple - pls < 64 ? ple - pls : 64);
+                        const int p0 = rl(pch, 0);
+                        prev_ok = pnv > 0 && !blank((uint8_t)p0);
+                        const uint64_t neq = __ballot(ch != pch) & ((1ull << p1) - 1ull);
+                        const bool ends = p1 >= pnv ? (p1 == pnv && ple - pls == p1) : blank((uint8_t)rl(pch, p1));
+                        differs = neq != 0ull || !ends;
+                    }
+                    if (r2 && prev_ok) {
+                        fast = true;
+                        if (rl(ch, 0) == '#') lbad |= TOK_COMMENT;
+                        const int c0 = rl(ch, d0);
+                        const bool neg = c0 == '-';
+                        if (c0 == '+' || c0 == '-') ++d0;
+                        const uint64_t dg = __ballot(ch >= '0' && ch <= '9');
+                        const uint64_t range = ((1ull << p2) - 1ull) & ~((1ull << d0) - 1ull);
+                        long long v = 0;
+                        if (p2 <= d0 || p2 - d0 > 18 || (dg & range) != range) lbad |= TOK_BAD_POS;
+                        else
+                            for (int k = d0; k < p2; ++k) v = v * 10 + (rl(ch, k) - '0');
+                        cells_at = ls + __builtin_ctzll(r2);
+                        if (le - cells_at != (int64_t)cells_w) lbad |= TOK_IRREGULAR;
+                        if (lane == 0) {
+                            pos_out[row] = neg ? -v : v;
+                            if (differs) {
+                                const int k = atomicAdd(n_runs, 1);
+                                if (k < run_cap) { run_row[k] = row; run_off[k] = ls; run_len[k] = p1; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!fast && lane == 0) {                          // a head that does not fit 64 bytes, leading blanks: the byte-by-byte walk
+            int64_t p = ls;
+            if (p >= le || text[p] == '#') lbad |= TOK_COMMENT;
+            while (p < le && blank(text[p])) ++p;
+            const int64_t s0 = p;
+            while (p < le && !blank(text[p])) ++p;
+            if (p == s0) lbad |= TOK_COMMENT;                                       // blank line
+            bool differs = row == 0;
+            if (row > 0) {
+                int64_t q = pls;
+                const int64_t qe = ple;
+                while (q < qe && blank(text[q])) ++q;
+                int64_t a = s0;
+                while (a < p && q < qe && text[a] == text[q]) { ++a; ++q; }
+                differs = !(a == p && (q == qe || blank(text[q])));
+            }
+            if (differs) {
+                const int k = atomicAdd(n_runs, 1);
+                if (k < run_cap) { run_row[k] = row; run_off[k] = s0; run_len[k] = (int32_t)(p - s0); }
+            }
+            while (p < le && blank(text[p])) ++p;
+            bool neg = false;
+            if (p < le && (text[p] == '+' || text[p] == '-')) { neg = text[p] == '-'; ++p; }
+            long long v = 0;
+            const int64_t d0 = p;
+            while (p < le && text[p] >= '0' && text[p] <= '9' && p - d0 < 19) { v = v * 10 + (text[p] - '0'); ++p; }
+            if (p == d0 || p - d0 > 18 || (p < le && !blank(text[p]))) lbad |= TOK_BAD_POS;
+            pos_out[row] = neg ? -v : v;
+            while (p < le && blank(text[p])) ++p;
+            cells_at = p;
+            if (le - p != (int64_t)cells_w) lbad |= TOK_IRREGULAR;
+        }
+        cells_at = ((int64_t)__builtin_amdgcn_readfirstlane((int)(cells_at >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cells_at);
+        lbad = __builtin_amdgcn_readfirstlane(lbad);
+        for (int k = lane; k < S / 4; k += 64) reinterpret_cast<uint32_t *>(lrow)[k] = 0u;
+        if (!lbad) {
+            int8_t *out = lrow;
+            const uint8_t *cells = text + cells_at;
+            for (int c = lane; c < n_cols; c += 64) {
+                const int cellw = col_w[c];
+                const uint8_t *cell = cells + col_off[c];
+                const int pl = col_ploidy[c];
+                const int32_t *slots = col_slot + (size_t)c * max_ploidy;
+                if (cellw <= 3) {
+                    // the cell and its separator in one load (the text buffer has room behind its last byte; any alignment)
+                    uint32_t w4;
+                    __builtin_memcpy(&w4, cell, 4);
+                    const uint8_t b0 = (uint8_t)w4, b1 = (uint8_t)(w4 >> 8), b2 = (uint8_t)(w4 >> 16), b3 = (uint8_t)(w4 >> 24);
+                    const uint8_t sep = cellw == 1 ? b1 : cellw == 2 ? b2 : b3;
+                    if (c + 1 < n_cols && !blank(sep)) lbad |= TOK_IRREGULAR;
+                    if (blank(b0) || (cellw > 1 && blank(b1)) || (cellw > 2 && blank(b2))) lbad |= TOK_IRREGULAR;     // a shorter cell
+                    if (pl <= 0) continue;
+                    if (fmt == PG_FMT_DIPLO) {
+                        const uint8_t d = dip.v[b0];
+                        out[slots[0]] = (int8_t)(d & 15);
+                        out[slots[1]] = (int8_t)(d >> 4);
+                    } else if (fmt == PG_FMT_PHASED) {
+                        out[slots[0]] = base_code(b0);
+                        if (pl > 1) out[slots[1]] = base_code(b2);
+                    } else {
+                        out[slots[0]] = base_code(b0);
+                        if (pl > 1) out[slots[1]] = base_code(b1);
+                        if (pl > 2) out[slots[2]] = base_code(b2);
+                    }
+                } else {
+                    if (c + 1 < n_cols && !blank(cell[cellw])) lbad |= TOK_IRREGULAR;
+                    for (int k = 0; k < cellw; ++k)
+                        if (blank(cell[k])) lbad |= TOK_IRREGULAR;
+                    if (pl <= 0) continue;
+                    if (fmt == PG_FMT_DIPLO) {
+                        const uint8_t d = dip.v[cell[0]];
+                        out[slots[0]] = (int8_t)(d & 15);
+                        out[slots[1]] = (int8_t)(d >> 4);
+                    } else {
+                        const int step = fmt == PG_FMT_PHASED ? 2 : 1;
+                        for (int k = 0; k < pl; ++k) out[slots[k]] = base_code(cell[step * k]);
+                    }
+                }
+            }
+        }
+        {
+            // (LDS operations of a wavefront execute in order: the reads below see the bytes scattered above)
+            uint32_t *grow = reinterpret_cast<uint32_t *>(rows + row * (int64_t)S);
+            for (int k = lane; k < S / 4; k += 64) grow[k] = reinterpret_cast<const uint32_t *>(lrow)[k];
+        }
+        bad |= lbad;
+        pls = ls;
+        ple = le;
+        pch = ch;
+        ls = nls;
+        le = nle;
+        ch = nch;
     }
     if (bad) atomicOr(status, bad);
 }
@@ -602,7 +808,13 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
     if ((rc = T.pos64.ensure_roomy((size_t)n_lines + 8)) != PG_OK) return rc;                       // positions (int64)
     if ((rc = T.off.ensure((size_t)run_cap * 2)) != PG_OK) return rc;                         // run_row, run_off
     if ((rc = T.h_pos.ensure_roomy((size_t)n_lines)) != PG_OK) return rc;
-    HIPCHK(hipMemsetAsync(c->gt.p + row_offset * c->S, 0, (size_t)n_lines * c->S, st));
+    // the form with several lines per wavefront, the column tables and the row being put together in LDS (k_tok_parse2) whenever they
+    // fit; PG_TOK_PARSE=1: the first form (one line per wavefront, tables in global memory, rows cleared first), which is also the
+    // route of wider layouts
+    const size_t tab_bytes = (size_t)n_cols * (max_ploidy + 3) * 4, lds_bytes = tab_bytes + 4 * (size_t)c->S;
+    static const bool first_form = getenv("PG_TOK_PARSE") && atoi(getenv("PG_TOK_PARSE")) == 1;
+    const bool second_form = lds_bytes <= 60 * 1024 && !first_form;
+    if (!second_form) HIPCHK(hipMemsetAsync(c->gt.p + row_offset * c->S, 0, (size_t)n_lines * c->S, st));
     DipTable dip;
     memset(dip.v, 0, sizeof(dip.v));
     {
@@ -611,11 +823,18 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
         auto code = [](char ch) { return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 4 : ch == 'T' ? 8 : 0; };
         for (int k = 0; d[k]; ++k) dip.v[(int)d[k]] = (uint8_t)(code(pr[k][0]) | (code(pr[k][1]) << 4));
     }
-    hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, T.tp, T.nl.p, n_lines, T.fmt, n_cols,
-                       T.cells_w, max_ploidy, T.dcols.p, T.dcols.p + (size_t)n_cols * max_ploidy,
-                       T.dcols.p + (size_t)n_cols * (max_ploidy + 1), T.dcols.p + (size_t)n_cols * (max_ploidy + 2),
-                       c->gt.p + row_offset * c->S, c->S,
-                       T.pos64.p, T.off.p, T.off.p + run_cap, T.pos.p, d_status + 1, run_cap, d_status, dip);
+    if (second_form) {
+        const int64_t per_block = 4 * TOK_LPW;
+        hipLaunchKernelGGL(k_tok_parse2, dim3((unsigned)((n_lines + per_block - 1) / per_block)), dim3(256), lds_bytes, st, T.tp, T.nl.p, n_lines,
+                           T.fmt, n_cols, T.cells_w, max_ploidy, T.dcols.p, c->gt.p + row_offset * c->S, c->S,
+                           T.pos64.p, T.off.p, T.off.p + run_cap, T.pos.p, d_status + 1, run_cap, d_status, dip);
+    } else {
+        hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, T.tp, T.nl.p, n_lines, T.fmt, n_cols,
+                           T.cells_w, max_ploidy, T.dcols.p, T.dcols.p + (size_t)n_cols * max_ploidy,
+                           T.dcols.p + (size_t)n_cols * (max_ploidy + 1), T.dcols.p + (size_t)n_cols * (max_ploidy + 2),
+                           c->gt.p + row_offset * c->S, c->S,
+                           T.pos64.p, T.off.p, T.off.p + run_cap, T.pos.p, d_status + 1, run_cap, d_status, dip);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(T.h_total.p + 1, d_status, 8, hipMemcpyDeviceToHost, st));            // status | runs, as two int32
     HIPCHK(hipMemcpyAsync(T.h_pos.p, T.pos64.p, (size_t)n_lines * 8, hipMemcpyDeviceToHost, st));
