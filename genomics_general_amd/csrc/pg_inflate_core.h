@@ -242,6 +242,21 @@ PGI_DEV int pgi_build(const uint8_t *lens, int n, uint16_t *sorted, uint32_t *hi
         PGI_DROP(L_);                                                                            \
     } while (0)
 
+// The same inside the symbol loop, where nothing branches out: a bit pattern that is no code of an (incomplete) code yields the
+// symbol `invalid_` (which the loop's one accumulated check turns into PGI_ERR_CODE) and takes 15 bits.  Every early exit of the loop
+// costs the compiler a copy of the loop's live registers on each path; with none the loop is a fifth shorter.
+#define PGI_DECODE_NOEXIT(sym_, L_, lim, bas, sorted, n_sorted_, invalid_)                       \
+    do {                                                                                         \
+        const uint32_t c15_ = pgi_brev32((uint32_t)buf) >> 17;                                   \
+        uint64_t mm_;                                                                            \
+        BALLOT(mm_, c15_ < V(lim));                                                              \
+        L_ = (int)PGI_CTZ64(mm_ | (1ull << 15));                                                 \
+        const uint32_t ix_ = (uint32_t)((int)(c15_ >> (15 - L_)) + (int)READLANE(bas, L_));     \
+        const int s_ = (int)UNI(sorted[ix_ < (uint32_t)(n_sorted_) ? ix_ : 0u]);                 \
+        sym_ = mm_ ? s_ : (invalid_);                                                            \
+        PGI_DROP(L_);                                                                            \
+    } while (0)
+
 // One member: in_len bytes of deflate stream at byte in_off of comp -> out_len bytes at dst.  0, or PGI_ERR_* bits.
 PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_t in_off, uint32_t in_len, uint8_t *dst,
                        uint32_t out_len, uint8_t *sink, PgiShared *sh PGI_LANE_PARAM) {
@@ -451,34 +466,42 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 fixed_built = btype == 1;
             }
             // ---- the symbols of the block ----
+            // No check of a symbol leaves the loop: `acc` collects, in its sign bit, a length symbol beyond 28 and a distance symbol
+            // beyond 29 (both also what an invalid bit pattern decodes to), `accd` a distance that reaches in front of the member; they
+            // are looked at where the loop is left anyway -- at the end of the block, and in the flush branch every 2 KiB of output,
+            // together with the output running past its recorded size.  Until then a damaged stream decodes garbage into the LDS
+            // ring, which is harmless: the global memory is only touched by the flush and by matches from beyond the ring, and
+            // those are taken only when their source lies inside the member.
+            int32_t acc = 0, accd = 0;
             for (;;) {
-                if (pos - fl >= PGI_FLUSH_AT) PGI_FLUSH(0);
+                if (pos - fl >= PGI_FLUSH_AT) {
+                    if ((acc | accd) < 0 || pos > out_len) break;
+                    PGI_FLUSH(0);
+                }
                 PGI_NEED(32);
                 int sym, L;
-                PGI_DECODE(sym, L, lim_ll, bas_ll, sh->sorted_ll);
+                PGI_DECODE_NOEXIT(sym, L, lim_ll, bas_ll, sh->sorted_ll, 288, 257 + 63);
                 if (sym < 256) {
-                    if (pos >= out_len) return PGI_ERR_OUT;
                     LANES { ring[PGI_RIX(pos)] = (uint8_t)sym; }           // (every lane the same byte)
                     ++pos;
                     continue;
                 }
                 if (sym == 256) break;
                 sym -= 257;
-                if (sym >= 29) return PGI_ERR_CODE;
-                const uint32_t lc = (uint32_t)READLANE(lconst, sym);
+                acc |= 28 - sym;
+                const uint32_t lc = (uint32_t)READLANE(lconst, sym);               // (sym <= 63 whatever was decoded)
                 const uint32_t le = lc >> 16;
                 const uint32_t len = (lc & 0xFFFFu) + (uint32_t)(buf & ((1u << le) - 1u));
                 PGI_DROP(le);
                 PGI_NEED(32);
                 int dsym;
-                PGI_DECODE(dsym, L, lim_d, bas_d, sh->sorted_d);
-                if (dsym >= 30) return PGI_ERR_CODE;
+                PGI_DECODE_NOEXIT(dsym, L, lim_d, bas_d, sh->sorted_d, 32, 63);
+                acc |= 29 - dsym;
                 const uint32_t dc = (uint32_t)READLANE(dconst, dsym);
                 const uint32_t de = dc >> 16;
                 const uint32_t dist = (dc & 0xFFFFu) + (uint32_t)(buf & ((1u << de) - 1u));
                 PGI_DROP(de);
-                if (dist > pos) return PGI_ERR_DIST;
-                if ((uint64_t)pos + len > out_len) return PGI_ERR_OUT;
+                accd |= (int32_t)(pos - dist);                           // negative: the distance reaches in front of the member
                 PL(uint8_t, v0);
                 PL(uint8_t, v1);
                 PL(uint8_t, v2);
@@ -487,7 +510,7 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 if (dist >= len) {
                     // source and destination do not overlap (the usual case: the match is in a line further up): all its bytes are read
                     // -- up to five reads of 64 bytes in flight at once -- before any is written
-                    if (dist <= PGI_NEAR) {
+                    if (dist <= PGI_NEAR || dist > pos) {
                         const uint32_t sp = pos - dist + (uint32_t)0;
                         LANES { V(v0) = ring[PGI_RIX(sp + (uint32_t)lane)]; }
                         if (len > 64u) LANES { V(v1) = ring[PGI_RIX(sp + 64u + (uint32_t)lane)]; }
@@ -527,6 +550,9 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 }
                 pos += len;
             }
+            if (acc < 0) return PGI_ERR_CODE;
+            if (accd < 0) return PGI_ERR_DIST;
+            if (pos > out_len) return PGI_ERR_OUT;
         }
         if (bfinal) break;
     }
