@@ -587,9 +587,11 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
               "stages_overlap": bool(stages > work_s * 1.02),
               "seconds": {k: round(tm[k], 4) for k in ("total_s", "context_s", "context_create_s", "read_s", "tokenize_s", "tokenizer_h2d_s",
                                                         "tokenizer_kernels_s", "windows_s", "prep_wait_s", "engine_and_upload_s",
-                                                        "compute_and_write_s") if k in tm},
-              "seconds_note": "tokenize_s / windows_s: the ingestion thread; compute_and_write_s: the driver's main thread (kernels, "
-                              "statistics, CSV); prep_wait_s: what the main thread waited for the ingestion thread; they run beside each "
+                                                        "compute_and_write_s", "compute_first_chunk_s", "compute_other_chunks_s",
+                                                        "main_stats_s", "main_format_s") if k in tm},
+              "seconds_note": "tokenize_s / windows_s: the ingestion thread; compute_first_chunk_s + compute_other_chunks_s: what the main thread "
+                              "spends on the chunks (kernels, statistics, rows; main_stats_s / main_format_s inside); compute_and_write_s: the rest "
+                              "of the main thread's time outside its waits, start-up of the library and the runtime included; prep_wait_s: what the main thread waited for the ingestion thread; they run beside each "
                               "other, so their sum exceeds total_s - context_s when the stages overlap",
               "sample": "the first %d sites of the workload as %.1f GB of `.geno` text (%d windows; written in %.1f s before the clock starts) "
                         "through popgenWindows.py, timed inside the driver (total_s: from opening the input to the last row; the device "
@@ -652,7 +654,8 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
                                                        "sites_per_sec": round(n_txt / work4, 1)},
                           "seconds": {k: round(tb[k], 4) for k in ("total_s", "context_s", "read_s", "first_block_prefetch_s", "tokenize_s",
                                                                     "tokenizer_h2d_s", "tokenizer_kernels_s", "windows_s", "prep_wait_s",
-                                                                    "compute_and_write_s") if k in tb},
+                                                                    "compute_and_write_s", "compute_first_chunk_s", "compute_other_chunks_s",
+                                                                    "main_stats_s", "main_format_s") if k in tb},
                           "sample": "the same %d sites bgzipped (level 6, members of 65280 bytes: %.2f GB, written in %.1f s before the clock "
                                     "starts) through popgenWindows.py" % (n_txt, n_gz / 1e9, zip_s)}
             # one serial gzip stream: a hundredth of the sample (the rate does not depend on the size; the whole sample would take minutes)
