@@ -110,6 +110,42 @@ def bgzf_compress(text, level=6, block=65280, eof_marker=True, n_threads=0):
     return out[:int(n.value)]
 
 
+class BgzfWriter:
+    """Write-only file object that produces BGZF (what `... | bgzip > out.geno.gz` gives, VCF_processing/README.md:33): the bytes are
+    collected and deflated 16 MiB at a time by the library's host threads (pg_bgzf_compress).  A valid gzip file for every other
+    reader; the drivers inflate it on the GPU."""
+
+    PIECE = 255 * 65280 + 65280 * 2                   # a multiple of the member size: only the file's last member is short
+
+    def __init__(self, path, level=6, n_threads=0):
+        self.f = open(path, "wb")
+        self.level, self.n_threads = level, n_threads
+        self.buf = bytearray()
+
+    def write(self, data):
+        self.buf += data
+        while len(self.buf) >= self.PIECE:
+            self.f.write(memoryview(bgzf_compress(memoryview(self.buf)[:self.PIECE], self.level, eof_marker=False, n_threads=self.n_threads)))
+            del self.buf[:self.PIECE]
+        return len(data)
+
+    def flush(self):
+        pass
+
+    def close(self):
+        if self.f is None:
+            return
+        self.f.write(memoryview(bgzf_compress(bytes(self.buf), self.level, eof_marker=True, n_threads=self.n_threads)))
+        self.f.close()
+        self.f = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class BgzfSpan:
     """A block of a BGZF input that is still deflated: `head` (text the reader already holds: what the previous block left behind
     its last line feed) followed by the text of whole members, cut behind the block's last line feed (len() = that many bytes of

@@ -60,7 +60,10 @@ def _parse_gtf(tokens):
 def _open_out(path):
     if not path:
         return sys.stdout.buffer
-    return gzip.open(path, "wb") if path.endswith(".gz") else open(path, "wb")
+    # `-o out.geno.gz`: BGZF, deflated by the library's host threads -- what the reference's recipe `parseVCF.py ... | bgzip > out.geno.gz`
+    # (VCF_processing/README.md:33) produces, a valid gzip file for its readers (gzip.open there), and the form the drivers inflate on
+    # the GPU.  (parseVCF.py:358 itself would write one serial gzip stream.)
+    return genoio.BgzfWriter(path) if path.endswith(".gz") else open(path, "wb")
 
 
 def _last_key(body):

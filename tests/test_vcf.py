@@ -79,3 +79,19 @@ def test_expanded_rows_are_what_the_engine_tokenises():
     d = genoio.encode(body, lay)
     assert d.n_sites == body.count(b"\n") and d.gt.shape[1] == 2 * len(names)
     assert set(np.unique(d.gt)) <= {0, 1, 2, 4, 8} and (d.gt != 0).mean() > 0.5
+
+
+def test_gz_output_is_bgzf_and_holds_the_same_text(tmp_path):
+    """-o out.geno.gz: BGZF (what `parseVCF.py | bgzip` gives): a valid gzip file whose text is the plain output's"""
+    import gzip
+    from genomics_general_amd import genoio
+    plain, gz = str(tmp_path / "x.geno"), str(tmp_path / "x.geno.gz")
+    for out in (plain, gz):
+        assert vcf.parse_vcf_main(["-i", os.path.join(GOLD, "main.vcf.gz"), "-o", out]) in (0, None)
+    with open(plain, "rb") as f, gzip.open(gz, "rb") as g:
+        text = f.read()
+        assert g.read() == text and len(text) > 1000
+    assert genoio.BgzfFile.is_bgzf(gz)
+    rd = genoio.BlockReader(gz)
+    assert rd.read_header() + rd.read_block(None) == text
+    rd.close()
