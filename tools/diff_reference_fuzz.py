@@ -102,6 +102,15 @@ def make_input(tmp, case, rng, tool):
             lines = lines[1:]
         with op(geno, "wt") as f:
             f.write("\n".join(lines) + "\n")
+    if geno.endswith(".gz") and rng.random() < 0.6:
+        # the way bgzip writes it (BGZF: members of a few hundred to a few thousand bytes of text here, so that lines straddle them):
+        # gzip.open reads it like any gzip file, the drivers take the members apart and inflate them member-wise (on the device)
+        import gzip
+        from genomics_general_amd import genoio
+        with gzip.open(geno, "rb") as f:
+            text = f.read()
+        with open(geno, "wb") as f:
+            f.write(genoio.bgzf_compress(text, level=int(rng.integers(1, 10)), block=int(rng.integers(300, 20000))).tobytes())
     ploidy_argv = []
     if haploid:
         # a --ploidy LIST is dealt to the samples in the hash order of a set once populations are named (popgenWindows.py:277-296)
