@@ -200,35 +200,30 @@ class RcclComm:
                 pass
 
     def _guarded(self, fn, *args):
-        """A collective whose peer has died never returns (ncclAllGather blocks in hipStreamSynchronize for good): it runs on a helper
-        thread while this one watches for a failed peer and for PG_COMM_TIMEOUT; then the rank says why and leaves -- the
-        communicator cannot be used again, and a thread stuck in the runtime cannot be joined."""
+        """A collective whose peer has died never returns (ncclAllGather blocks in hipStreamSynchronize for good).  The call itself
+        stays on this thread (the communicator and the device context are never touched from another one); a watchdog thread looks
+        for a failed peer and for PG_COMM_TIMEOUT while the call is out, says why and ends the process -- the communicator cannot
+        be used again, and a thread stuck in the runtime cannot be interrupted."""
         import sys
         import threading
-        box = {}
-
-        def run():
-            try:
-                box["v"] = fn(*args)
-            except BaseException as exc:
-                box["e"] = exc
-        th = threading.Thread(target=run, daemon=True, name="collective")
-        th.start()
+        done = threading.Event()
         t0 = time.time()
-        while True:
-            th.join(0.05)
-            if not th.is_alive():
-                break
-            why = peer_failure(self.world)
-            if why is None and time.time() - t0 > self.timeout_s:
-                why = "no answer from the other ranks within PG_COMM_TIMEOUT = %.0f s" % self.timeout_s
-            if why is not None:
-                sys.stderr.write("rank %d: leaving the collective: %s\n" % (self.rank, why))
-                sys.stderr.flush()
-                os._exit(3)
-        if "e" in box:
-            raise box["e"]
-        return box["v"]
+
+        def watch():
+            while not done.wait(0.05):
+                why = peer_failure(self.world)
+                if why is None and time.time() - t0 > self.timeout_s:
+                    why = "no answer from the other ranks within PG_COMM_TIMEOUT = %.0f s" % self.timeout_s
+                if why is not None and not done.is_set():
+                    sys.stderr.write("rank %d: leaving the collective: %s\n" % (self.rank, why))
+                    sys.stderr.flush()
+                    os._exit(3)
+        th = threading.Thread(target=watch, daemon=True, name="collective-watchdog")
+        th.start()
+        try:
+            return fn(*args)
+        finally:
+            done.set()
 
     def allgather(self, arr):
         return self._guarded(self.e.comm_allgather, arr)
