@@ -165,7 +165,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->slot_src.release();
     for (int k = 0; k < 2; ++k) {
         pg_ctx::TokSlot &T = c->tok[k];
-        T.text.release(); T.i32.release(); T.dcols.release(); T.pos.release(); T.pos64.release(); T.i64.release(); T.nl.release(); T.off.release();
+        T.text.release(); T.i32.release(); T.dcols.release(); T.pos.release(); T.pos64.release(); T.cells_at.release(); T.i64.release(); T.nl.release(); T.off.release();
         T.h_total.release(); T.h_pos.release(); T.h_cols.release();
         T.h_head.release(); T.names.release(); T.names_idx.release();
         auto drop = [](pg_ctx::Inflate &I) { I.comp.release(); I.crc_tab.release(); I.text.release(); I.sink.release(); I.members.release(); I.h_members.release(); I.status.release(); I.h_status.release(); };

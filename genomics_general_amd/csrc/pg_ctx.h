@@ -130,7 +130,7 @@ struct pg_ctx {
         DevBuf<uint8_t> names;             // pg_tokenize_run_names: the scaffold names of the block's runs, gathered
         DevBuf<int64_t> names_idx;
         DevBuf<int32_t> i32, dcols, pos;
-        DevBuf<int64_t> i64, nl, off, pos64;
+        DevBuf<int64_t> i64, nl, off, pos64, cells_at;
         HostPin<int64_t> h_total;          // page-locked landing: [0] lines, [1] status | runs
         HostPin<int64_t> h_pos;
         HostPin<int32_t> h_cols;

@@ -257,151 +257,119 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
 }
 
 
-// k_tok_parse, second form: a wavefront takes LPW consecutive lines instead of one.  What that buys: the column tables (slots,
-// ploidies, cell offsets and widths: the block copies them into LDS once) are no longer four dependent global loads per cell; the
-// line-feed positions of the wavefront's lines are one load; the first 64 bytes of line r + 1 are on their way while line r's
-// cells are taken apart, and double as "the previous line" of the run test (no second load); a cell of up to three characters and
-// its separator is ONE (unaligned) dword load instead of four byte loads; the row is put together in LDS (a byte per slot, scattered
-// by the lanes) and leaves as ONE coalesced store of dwords -- the first form's two byte stores per cell touched every cache line of
-// the row eight times with byte masks -- and is written whole (zeros where no column lands), so the caller need not clear the rows.
+// k_tok_parse, second form: two kernels.
+//   k_tok_heads   a THREAD per line: the line's first 64 bytes go into LDS (four unaligned 16-byte loads), the thread walks them --
+//                 scaffold token, position, start of the cells -- the way the host tokenizer does, compares its scaffold token with
+//                 the line before (the neighbour's bytes are in LDS too) and leaves position, start of the cells (-1: a line the fast
+//                 path does not take) and, where a run starts, the run.  Vector instructions on 64 lines at once: the first
+//                 form spent 860 SCALAR instructions per line on this (ballots, mask arithmetic, a 64-bit multiply per digit,
+//                 execution masks: it was bound by the scalar unit, 2.1 - 2.6 ms per GiB of text).
+//   k_tok_cells   a wavefront per line, 16 lines one after the other: column tables (slots, ploidies, cell offsets and widths) in
+//                 LDS, a cell and its separator as ONE (unaligned) dword load, the row put together in LDS (a byte per slot) and
+//                 stored whole with coalesced dwords (zeros where no column lands: the caller need not clear the rows).
 // Same outputs, same status bits as k_tok_parse, which stays for layouts whose tables do not fit LDS and as PG_TOK_PARSE=1 (A/B, tests).
 constexpr int TOK_LPW = 16;
-__global__ __launch_bounds__(256) void k_tok_parse2(const uint8_t *__restrict__ text, const int64_t *__restrict__ nl_pos, int64_t n_lines,
-                                                    int fmt, int n_cols, int cells_w, int max_ploidy, const int32_t *__restrict__ dcols,
-                                                    int8_t *__restrict__ rows, int S, int64_t *__restrict__ pos_out,
-                                                    int64_t *__restrict__ run_row, int64_t *__restrict__ run_off, int32_t *__restrict__ run_len,
-                                                    int32_t *__restrict__ n_runs, int64_t run_cap, int32_t *__restrict__ status, DipTable dip) {
-    extern __shared__ int32_t tab[];                      // col_slot [n_cols][max_ploidy] | col_ploidy | col_off | col_w
+constexpr int HEAD_BYTES = 64, HEAD_PITCH = 68;
+
+__global__ __launch_bounds__(256) void k_tok_heads(const uint8_t *__restrict__ text, const int64_t *__restrict__ nl_pos, int64_t n_lines, int cells_w,
+                                                   int64_t *__restrict__ pos_out, int64_t *__restrict__ cells_at_out,
+                                                   int64_t *__restrict__ run_row, int64_t *__restrict__ run_off, int32_t *__restrict__ run_len,
+                                                   int32_t *__restrict__ n_runs, int64_t run_cap, int32_t *__restrict__ status) {
+    __shared__ uint32_t hb[257][HEAD_PITCH / 4];           // [0]: the line in front of the block's first line
+    const int t = (int)threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.x * 256 + t;
+    int64_t ls = 0, le = 0;
+    if (row < n_lines) {
+        ls = row ? nl_pos[row - 1] + 1 : 0;
+        le = nl_pos[row];
+        // (the text buffer has 96 bytes of room behind its last byte: a head may be read past the end of a short last line)
+        uint4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __builtin_memcpy(&q[k], text + ls + 16 * k, 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hb[t + 1][4 * k] = q[k].x;
+            hb[t + 1][4 * k + 1] = q[k].y;
+            hb[t + 1][4 * k + 2] = q[k].z;
+            hb[t + 1][4 * k + 3] = q[k].w;
+        }
+    }
+    int64_t pls = 0, ple = 0;
+    if (row > 0 && row < n_lines) {
+        pls = row > 1 ? nl_pos[row - 2] + 1 : 0;
+        ple = ls - 1;
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                uint32_t w;
+                __builtin_memcpy(&w, text + pls + 4 * k, 4);
+                hb[0][k] = w;
+            }
+        }
+    }
+    __syncthreads();
+    if (row >= n_lines) return;
+    const uint8_t *mine = reinterpret_cast<const uint8_t *>(hb[t + 1]), *prev = reinterpret_cast<const uint8_t *>(hb[t]);
+    const int64_t n = le - ls, pn = ple - pls;
+    auto B = [&](int64_t k) -> uint8_t { return k < HEAD_BYTES ? mine[k] : text[ls + k]; };       // k < n
+    auto PB = [&](int64_t k) -> uint8_t { return k < HEAD_BYTES ? prev[k] : text[pls + k]; };    // k < pn
+    int bad = 0;
+    int64_t p = 0;
+    if (n <= 0 || B(0) == '#') bad |= TOK_COMMENT;
+    while (p < n && blank(B(p))) ++p;
+    const int64_t s0 = p;
+    while (p < n && !blank(B(p))) ++p;
+    if (p == s0) bad |= TOK_COMMENT;                                             // blank line
+    // a new scaffold run starts where the token differs from the previous line's
+    bool differs = row == 0;
+    if (row > 0) {
+        int64_t q = 0;
+        while (q < pn && blank(PB(q))) ++q;
+        int64_t a = s0;
+        while (a < p && q < pn && B(a) == PB(q)) { ++a; ++q; }
+        differs = !(a == p && (q == pn || blank(PB(q))));
+    }
+    if (differs) {
+        const int k = atomicAdd(n_runs, 1);
+        if (k < run_cap) { run_row[k] = row; run_off[k] = ls + s0; run_len[k] = (int32_t)(p - s0); }
+    }
+    while (p < n && blank(B(p))) ++p;
+    bool neg = false;
+    if (p < n && (B(p) == '+' || B(p) == '-')) { neg = B(p) == '-'; ++p; }
+    long long v = 0;
+    const int64_t d0 = p;
+    while (p < n && B(p) >= '0' && B(p) <= '9' && p - d0 < 19) { v = v * 10 + (B(p) - '0'); ++p; }
+    if (p == d0 || p - d0 > 18 || (p < n && !blank(B(p)))) bad |= TOK_BAD_POS;
+    pos_out[row] = neg ? -v : v;
+    while (p < n && blank(B(p))) ++p;
+    // the regular layout: n_cols cells of their columns' widths, one separator between them, the last cell ends the line
+    if (n - p != (int64_t)cells_w) bad |= TOK_IRREGULAR;
+    cells_at_out[row] = bad ? -1 : ls + p;
+    if (bad) atomicOr(status, bad);
+}
+
+__global__ __launch_bounds__(256) void k_tok_cells(const uint8_t *__restrict__ text, const int64_t *__restrict__ cells_at_in, int64_t n_lines,
+                                                   int fmt, int n_cols, int max_ploidy, const int32_t *__restrict__ dcols,
+                                                   int8_t *__restrict__ rows, int S, int32_t *__restrict__ status, DipTable dip) {
+    extern __shared__ int32_t tab[];                      // col_slot [n_cols][max_ploidy] | col_ploidy | col_off | col_w | 4 rows of S bytes
     const int n_tab = n_cols * (max_ploidy + 3);
     for (int k = (int)threadIdx.x; k < n_tab; k += 256) tab[k] = dcols[k];
     __syncthreads();
     const int32_t *col_slot = tab, *col_ploidy = tab + (size_t)n_cols * max_ploidy, *col_off = col_ploidy + n_cols, *col_w = col_off + n_cols;
     const int lane = threadIdx.x & 63;
-    int8_t *const lrow = reinterpret_cast<int8_t *>(tab + n_tab) + (size_t)(threadIdx.x >> 6) * S;      // this wavefront's row (S bytes, S % 16 == 0)
+    int8_t *const lrow = reinterpret_cast<int8_t *>(tab + n_tab) + (size_t)(threadIdx.x >> 6) * S;      // this wavefront's row (S % 16 == 0)
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TOK_LPW;
     if (row0 >= n_lines) return;
     const int n_here = (int)(n_lines - row0 < TOK_LPW ? n_lines - row0 : TOK_LPW);
-    // line feeds of the lines row0 - 2 .. row0 + n_here - 1: lane i holds nl_pos[row0 - 2 + i] (-1 in front of the text)
-    long long nlv = -1;
-    {
-        const int64_t r = row0 - 2 + lane;
-        if (r >= 0 && lane < n_here + 2) nlv = nl_pos[r];
-    }
-    const int nl_lo = (int)(uint32_t)nlv, nl_hi = (int)(nlv >> 32);
-    auto nl_at = [&](int i) -> int64_t {                  // line feed of line row0 - 2 + i (uniform i)
-        return ((int64_t)__builtin_amdgcn_readlane(nl_hi, i) << 32) | (uint32_t)__builtin_amdgcn_readlane(nl_lo, i);
-    };
-    auto head = [&](int64_t ls, int64_t le) -> int {      // the first 64 bytes of a line, a byte per lane (10 behind its end)
-        const int nv = (int)(le - ls < 64 ? le - ls : 64);
-        return lane < nv ? (int)text[ls + lane] : 10;
-    };
+    long long cav = -1;                                   // lane i: where the cells of line row0 + i begin (-1: not a regular line)
+    if (lane < n_here) cav = cells_at_in[row0 + lane];
+    const int ca_lo = (int)(uint32_t)cav, ca_hi = (int)(cav >> 32);
     int bad = 0;
-    // the line in front of the first one (its head is the "previous line" of the run test)
-    int64_t pls = 0, ple = 0;
-    int pch = 10;
-    if (row0 > 0) {
-        pls = nl_at(0) + 1;
-        ple = nl_at(1);
-        pch = head(pls, ple);
-    }
-    int64_t ls = nl_at(1) + 1, le = nl_at(2);
-    int ch = head(ls, le);
     for (int r = 0; r < n_here; ++r) {
         const int64_t row = row0 + r;
-        // the next line's head is requested before this line is taken apart
-        int64_t nls = 0, nle = 0;
-        int nch = 10;
-        if (r + 1 < n_here) {
-            nls = le + 1;
-            nle = nl_at(r + 3);
-            nch = head(nls, nle);
-        }
-        int64_t cells_at = -1;
-        int lbad = 0;
-        const int nv = (int)(le - ls < 64 ? le - ls : 64);
-        const uint64_t valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
-        const uint64_t bl = __ballot(blank((uint8_t)ch)) & valid, nb = ~bl & valid;
-        bool fast = false;
-        if (nv > 0 && (nb & 1ull) && bl) {
-            const int p1 = __builtin_ctzll(bl);                                       // end of the scaffold token
-            const uint64_t r1 = nb & ~((1ull << p1) - 1ull);
-            if (r1) {
-                int d0 = __builtin_ctzll(r1);                                         // start of the position
-                const uint64_t b2 = bl & ~((1ull << d0) - 1ull);
-                if (b2) {
-                    const int p2 = __builtin_ctzll(b2);                               // its end
-                    const uint64_t r2 = nb & ~((1ull << p2) - 1ull);
-                    bool differs = row == 0, prev_ok = true;
-                    if (row > 0) {
-                        const int pnv = (int)(ple - pls < 64 ? ple - pls : 64);
-                        const int p0 = rl(pch, 0);
-                        prev_ok = pnv > 0 && !blank((uint8_t)p0);
-                        const uint64_t neq = __ballot(ch != pch) & ((1ull << p1) - 1ull);
-                        const bool ends = p1 >= pnv ? (p1 == pnv && ple - pls == p1) : blank((uint8_t)rl(pch, p1));
-                        differs = neq != 0ull || !ends;
-                    }
-                    if (r2 && prev_ok) {
-                        fast = true;
-                        if (rl(ch, 0) == '#') lbad |= TOK_COMMENT;
-                        const int c0 = rl(ch, d0);
-                        const bool neg = c0 == '-';
-                        if (c0 == '+' || c0 == '-') ++d0;
-                        const uint64_t dg = __ballot(ch >= '0' && ch <= '9');
-                        const uint64_t range = ((1ull << p2) - 1ull) & ~((1ull << d0) - 1ull);
-                        long long v = 0;
-                        if (p2 <= d0 || p2 - d0 > 18 || (dg & range) != range) lbad |= TOK_BAD_POS;
-                        else
-                            for (int k = d0; k < p2; ++k) v = v * 10 + (rl(ch, k) - '0');
-                        cells_at = ls + __builtin_ctzll(r2);
-                        if (le - cells_at != (int64_t)cells_w) lbad |= TOK_IRREGULAR;
-                        if (lane == 0) {
-                            pos_out[row] = neg ? -v : v;
-                            if (differs) {
-                                const int k = atomicAdd(n_runs, 1);
-                                if (k < run_cap) { run_row[k] = row; run_off[k] = ls; run_len[k] = p1; }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (!fast && lane == 0) {                          // a head that does not fit 64 bytes, leading blanks: the byte-by-byte walk
-            int64_t p = ls;
-            if (p >= le || text[p] == '#') lbad |= TOK_COMMENT;
-            while (p < le && blank(text[p])) ++p;
-            const int64_t s0 = p;
-            while (p < le && !blank(text[p])) ++p;
-            if (p == s0) lbad |= TOK_COMMENT;                                       // blank line
-            bool differs = row == 0;
-            if (row > 0) {
-                int64_t q = pls;
-                const int64_t qe = ple;
-                while (q < qe && blank(text[q])) ++q;
-                int64_t a = s0;
-                while (a < p && q < qe && text[a] == text[q]) { ++a; ++q; }
-                differs = !(a == p && (q == qe || blank(text[q])));
-            }
-            if (differs) {
-                const int k = atomicAdd(n_runs, 1);
-                if (k < run_cap) { run_row[k] = row; run_off[k] = s0; run_len[k] = (int32_t)(p - s0); }
-            }
-            while (p < le && blank(text[p])) ++p;
-            bool neg = false;
-            if (p < le && (text[p] == '+' || text[p] == '-')) { neg = text[p] == '-'; ++p; }
-            long long v = 0;
-            const int64_t d0 = p;
-            while (p < le && text[p] >= '0' && text[p] <= '9' && p - d0 < 19) { v = v * 10 + (text[p] - '0'); ++p; }
-            if (p == d0 || p - d0 > 18 || (p < le && !blank(text[p]))) lbad |= TOK_BAD_POS;
-            pos_out[row] = neg ? -v : v;
-            while (p < le && blank(text[p])) ++p;
-            cells_at = p;
-            if (le - p != (int64_t)cells_w) lbad |= TOK_IRREGULAR;
-        }
-        cells_at = ((int64_t)__builtin_amdgcn_readfirstlane((int)(cells_at >> 32)) << 32) |
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cells_at);
-        lbad = __builtin_amdgcn_readfirstlane(lbad);
+        const int64_t cells_at = ((int64_t)__builtin_amdgcn_readlane(ca_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane(ca_lo, r);
         for (int k = lane; k < S / 4; k += 64) reinterpret_cast<uint32_t *>(lrow)[k] = 0u;
-        if (!lbad) {
+        if (cells_at >= 0) {
             int8_t *out = lrow;
             const uint8_t *cells = text + cells_at;
             for (int c = lane; c < n_cols; c += 64) {
@@ -415,8 +383,9 @@ __global__ __launch_bounds__(256) void k_tok_parse2(const uint8_t *__restrict__ 
                     __builtin_memcpy(&w4, cell, 4);
                     const uint8_t b0 = (uint8_t)w4, b1 = (uint8_t)(w4 >> 8), b2 = (uint8_t)(w4 >> 16), b3 = (uint8_t)(w4 >> 24);
                     const uint8_t sep = cellw == 1 ? b1 : cellw == 2 ? b2 : b3;
-                    if (c + 1 < n_cols && !blank(sep)) lbad |= TOK_IRREGULAR;
-                    if (blank(b0) || (cellw > 1 && blank(b1)) || (cellw > 2 && blank(b2))) lbad |= TOK_IRREGULAR;     // a shorter cell
+                    int cb = (int)(c + 1 < n_cols) & (int)!blank(sep);
+                    cb |= (int)blank(b0) | ((int)(cellw > 1) & (int)blank(b1)) | ((int)(cellw > 2) & (int)blank(b2));      // a shorter cell
+                    if (cb) bad |= TOK_IRREGULAR;
                     if (pl <= 0) continue;
                     if (fmt == PG_FMT_DIPLO) {
                         const uint8_t d = dip.v[b0];
@@ -431,9 +400,9 @@ __global__ __launch_bounds__(256) void k_tok_parse2(const uint8_t *__restrict__ 
                         if (pl > 2) out[slots[2]] = base_code(b2);
                     }
                 } else {
-                    if (c + 1 < n_cols && !blank(cell[cellw])) lbad |= TOK_IRREGULAR;
+                    if (c + 1 < n_cols && !blank(cell[cellw])) bad |= TOK_IRREGULAR;
                     for (int k = 0; k < cellw; ++k)
-                        if (blank(cell[k])) lbad |= TOK_IRREGULAR;
+                        if (blank(cell[k])) bad |= TOK_IRREGULAR;
                     if (pl <= 0) continue;
                     if (fmt == PG_FMT_DIPLO) {
                         const uint8_t d = dip.v[cell[0]];
@@ -446,20 +415,105 @@ __global__ __launch_bounds__(256) void k_tok_parse2(const uint8_t *__restrict__ 
                 }
             }
         }
-        {
-            // (LDS operations of a wavefront execute in order: the reads below see the bytes scattered above)
-            uint32_t *grow = reinterpret_cast<uint32_t *>(rows + row * (int64_t)S);
-            for (int k = lane; k < S / 4; k += 64) grow[k] = reinterpret_cast<const uint32_t *>(lrow)[k];
-        }
-        bad |= lbad;
-        pls = ls;
-        ple = le;
-        pch = ch;
-        ls = nls;
-        le = nle;
-        ch = nch;
+        // (LDS operations of a wavefront execute in order: the reads below see the bytes scattered above)
+        uint32_t *grow = reinterpret_cast<uint32_t *>(rows + row * (int64_t)S);
+        for (int k = lane; k < S / 4; k += 64) grow[k] = reinterpret_cast<const uint32_t *>(lrow)[k];
     }
     if (bad) atomicOr(status, bad);
+}
+
+// k_tok_cells for the usual layouts (every cell of at most three characters: phased / pairs of ploidy <= 2 / 3, haplo, diplo): no branch
+// on a lane's column anywhere -- a lane past the last column takes the last column again (the same bytes to the same places), a
+// column that is not wanted or an allele a sample does not have writes into a dump byte behind the row, blanks and base codes are
+// bit arithmetic, the diplo table sits in LDS -- so the compiler keeps the line loop's state in scalar registers and the loop is a
+// few dozen vector instructions per 64 cells.
+__device__ __forceinline__ uint32_t blank32(uint32_t ch) {          // ' ' \t \r \v \f  (9, 11, 12, 13, 32)
+    const uint32_t t = ch - 9u;
+    return (t < 24u ? (0x80001Du >> t) : 0u) & 1u;
+}
+__device__ __forceinline__ uint32_t code32(uint32_t ch) {           // A 1, C 2, G 4, T 8, anything else 0
+    const uint32_t i = (ch >> 1) & 3u;                               // A 0, C 1, T 2, G 3
+    return ch == ((0x47544341u >> (8u * i)) & 255u) ? (0x04080201u >> (8u * i)) & 255u : 0u;
+}
+template <int FMT>
+__global__ __launch_bounds__(256) void k_tok_cells3(const uint8_t *__restrict__ text, const int64_t *__restrict__ cells_at_in, int64_t n_lines,
+                                                    int n_cols, int max_ploidy, const int32_t *__restrict__ dcols, int8_t *__restrict__ rows, int S,
+                                                    int32_t *__restrict__ status, DipTable dip) {
+    extern __shared__ int32_t lds[];                      // packed column table [n_cols] x 4 | diplo table 64 words | 4 x (row S + dump 64)
+    int4 *ctab = reinterpret_cast<int4 *>(lds);
+    uint32_t *dtab = reinterpret_cast<uint32_t *>(lds + 4 * n_cols);
+    {
+        const int32_t *col_slot = dcols, *col_ploidy = dcols + (size_t)n_cols * max_ploidy, *col_off = col_ploidy + n_cols, *col_w = col_off + n_cols;
+        for (int c = (int)threadIdx.x; c < n_cols; c += 256) {
+            const int pl = col_ploidy[c];
+            const int s0 = pl > 0 ? col_slot[(size_t)c * max_ploidy] : 0, s1 = pl > 1 ? col_slot[(size_t)c * max_ploidy + 1] : 0,
+                      s2 = pl > 2 ? col_slot[(size_t)c * max_ploidy + 2] : 0;
+            ctab[c] = make_int4(col_off[c], col_w[c] | ((pl < 0 ? 0 : pl) << 8), s0 | (s1 << 16), s2);
+        }
+        if (threadIdx.x < 64) {
+            const int k = 4 * (int)threadIdx.x;
+            dtab[threadIdx.x] = dip.v[k] | (dip.v[k + 1] << 8) | (dip.v[k + 2] << 16) | ((uint32_t)dip.v[k + 3] << 24);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int RS = S + 64;                                // a wavefront's row + 64 dump bytes
+    uint8_t *const lrow = reinterpret_cast<uint8_t *>(lds + 4 * n_cols + 64) + (size_t)(threadIdx.x >> 6) * RS;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TOK_LPW;
+    if (row0 >= n_lines) return;
+    const int n_here = (int)(n_lines - row0 < TOK_LPW ? n_lines - row0 : TOK_LPW);
+    long long cav = -1;
+    if (lane < n_here) cav = cells_at_in[row0 + lane];
+    const int ca_lo = (int)(uint32_t)cav, ca_hi = (int)(cav >> 32);
+    const int n_it = (n_cols + 63) >> 6, n_dw = S >> 2, n_dwit = (n_dw + 63) >> 6;
+    const int dump = S + lane;
+    uint32_t badv = 0u;
+    for (int r = 0; r < n_here; ++r) {
+        const int64_t row = row0 + r;
+        const int64_t cells_at = ((int64_t)__builtin_amdgcn_readlane(ca_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane(ca_lo, r);
+        for (int j = 0; j < n_dwit; ++j) {
+            const int k = lane + 64 * j;
+            reinterpret_cast<uint32_t *>(lrow)[k < n_dw ? k : n_dw - 1] = 0u;
+        }
+        if (cells_at >= 0) {                              // (uniform)
+            const uint8_t *cells = text + cells_at;
+            for (int j = 0; j < n_it; ++j) {
+                const int c0 = lane + 64 * j, c = c0 < n_cols ? c0 : n_cols - 1;
+                const int4 e = ctab[c];
+                const uint32_t cellw = (uint32_t)e.y & 255u, pl = (uint32_t)e.y >> 8;
+                uint32_t w4;
+                __builtin_memcpy(&w4, cells + e.x, 4);
+                const uint32_t b0 = w4 & 255u, b1 = (w4 >> 8) & 255u, b2 = (w4 >> 16) & 255u, b3 = w4 >> 24;
+                const uint32_t sep = cellw == 1u ? b1 : cellw == 2u ? b2 : b3;
+                badv |= ((uint32_t)(c + 1 < n_cols) & (blank32(sep) ^ 1u)) | blank32(b0) | ((uint32_t)(cellw > 1u) & blank32(b1)) |
+                        ((uint32_t)(cellw > 2u) & blank32(b2));
+                uint32_t x0, x1, x2 = 0u;
+                if (FMT == PG_FMT_DIPLO) {
+                    const uint32_t d = (dtab[b0 >> 2] >> (8u * (b0 & 3u))) & 255u;
+                    x0 = d & 15u;
+                    x1 = d >> 4;
+                } else if (FMT == PG_FMT_PHASED) {
+                    x0 = code32(b0);
+                    x1 = code32(b2);
+                } else {
+                    x0 = code32(b0);
+                    x1 = code32(b1);
+                    x2 = code32(b2);
+                }
+                const int s0 = e.z & 0xFFFF, s1 = (int)((uint32_t)e.z >> 16);
+                lrow[pl > 0u ? s0 : dump] = (uint8_t)x0;
+                lrow[pl > 1u ? s1 : dump] = (uint8_t)x1;
+                if (FMT == PG_FMT_PAIRS) lrow[pl > 2u ? e.w : dump] = (uint8_t)x2;
+            }
+        }
+        // (LDS operations of a wavefront execute in order: the reads below see the bytes scattered above)
+        uint32_t *grow = reinterpret_cast<uint32_t *>(rows + row * (int64_t)S);
+        for (int j = 0; j < n_dwit; ++j) {
+            const int k0 = lane + 64 * j, k = k0 < n_dw ? k0 : n_dw - 1;
+            grow[k] = reinterpret_cast<const uint32_t *>(lrow)[k];
+        }
+    }
+    if (__ballot(badv != 0u) && lane == 0) atomicOr(status, TOK_IRREGULAR);
 }
 
 }  // namespace
@@ -668,7 +722,7 @@ static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, in
     int rc;
     auto now = [] { return std::chrono::steady_clock::now(); };
     const auto t_stage0 = now();
-    if ((rc = T.text.ensure_roomy((size_t)len + 32)) != PG_OK) return rc;
+    if ((rc = T.text.ensure_roomy((size_t)len + 96)) != PG_OK) return rc;
     T.tp = T.text.p;
     if ((rc = stage_bytes(c, src, len, T.text.p)) != PG_OK) return rc;
     c->tok_stage_s += std::chrono::duration<double>(now() - t_stage0).count();
@@ -722,7 +776,7 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
     static const bool trace = getenv("PG_TOK_TRACE") != nullptr;
     double tr[6] = {0, 0, 0, 0, 0, 0};
     auto lap = [&](int k) { if (trace) tr[k] = std::chrono::duration<double>(now() - t_stage0).count() * 1e3; };
-    if ((rc = T.text.ensure_roomy((size_t)total + 64)) != PG_OK) return rc;
+    if ((rc = T.text.ensure_roomy((size_t)total + 96)) != PG_OK) return rc;
     T.tp = T.text.p;                                                 // (hipMalloc aligns to 256 bytes; the members' text starts at any byte)
     // (the slot's buffers are free: the block that used them last has been collected.  Bytes behind comp_len in the last dword are
     // never consumed by a valid stream, and a damaged one is stopped by the bounds of its member)
@@ -824,10 +878,26 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
         for (int k = 0; d[k]; ++k) dip.v[(int)d[k]] = (uint8_t)(code(pr[k][0]) | (code(pr[k][1]) << 4));
     }
     if (second_form) {
+        if ((rc = T.cells_at.ensure_roomy((size_t)n_lines + 8)) != PG_OK) return rc;
+        hipLaunchKernelGGL(k_tok_heads, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, T.tp, T.nl.p, n_lines, T.cells_w,
+                           T.pos64.p, T.cells_at.p, T.off.p, T.off.p + run_cap, T.pos.p, d_status + 1, run_cap, d_status);
         const int64_t per_block = 4 * TOK_LPW;
-        hipLaunchKernelGGL(k_tok_parse2, dim3((unsigned)((n_lines + per_block - 1) / per_block)), dim3(256), lds_bytes, st, T.tp, T.nl.p, n_lines,
-                           T.fmt, n_cols, T.cells_w, max_ploidy, T.dcols.p, c->gt.p + row_offset * c->S, c->S,
-                           T.pos64.p, T.off.p, T.off.p + run_cap, T.pos.p, d_status + 1, run_cap, d_status, dip);
+        const dim3 grid((unsigned)((n_lines + per_block - 1) / per_block));
+        int widest = 0;
+        for (int k = 0; k < n_cols; ++k) widest = std::max(widest, (int)T.cols[(size_t)n_cols * (max_ploidy + 2) + k]);
+        const size_t lds3 = (size_t)n_cols * 16 + 256 + 4 * ((size_t)c->S + 64);
+        static const bool general_cells = getenv("PG_TOK_PARSE") && atoi(getenv("PG_TOK_PARSE")) == 2;      // (A/B, tests)
+        if (widest <= 3 && lds3 <= 60 * 1024 && !general_cells) {
+#define PG_CELLS3(F) hipLaunchKernelGGL((k_tok_cells3<F>), grid, dim3(256), lds3, st, T.tp, T.cells_at.p, n_lines, n_cols, max_ploidy, T.dcols.p, \
+                                        c->gt.p + row_offset * c->S, c->S, d_status, dip)
+            if (T.fmt == PG_FMT_DIPLO) PG_CELLS3(PG_FMT_DIPLO);
+            else if (T.fmt == PG_FMT_PHASED) PG_CELLS3(PG_FMT_PHASED);
+            else PG_CELLS3(PG_FMT_PAIRS);                 // pairs and haplo: an allele per character
+#undef PG_CELLS3
+        } else {
+            hipLaunchKernelGGL(k_tok_cells, grid, dim3(256), lds_bytes, st, T.tp, T.cells_at.p,
+                               n_lines, T.fmt, n_cols, max_ploidy, T.dcols.p, c->gt.p + row_offset * c->S, c->S, d_status, dip);
+        }
     } else {
         hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, T.tp, T.nl.p, n_lines, T.fmt, n_cols,
                            T.cells_w, max_ploidy, T.dcols.p, T.dcols.p + (size_t)n_cols * max_ploidy,
