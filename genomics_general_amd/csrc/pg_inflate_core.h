@@ -43,6 +43,7 @@
     } while (0)
 #define UNI(x) (x)
 #define UNI64(x) (x)
+#define PGI_IN_VGPR(x) (x)
 #define PGI_SYNC
 #define PGI_ATOMIC_INC(p) (++*(p))
 #define PGI_LANE_PARAM
@@ -74,6 +75,16 @@ __device__ __forceinline__ void pgi_setlane(T &name, int lane, int l, U val) {
 #define BALLOT(mask, expr) mask = __ballot(expr)
 #define UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
 #define UNI64(x) (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((x) >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x)))
+// the bit buffer lives in VECTOR registers (every lane the same value): the scalar unit issues one instruction per SIMD every four cycles and is
+// what bounds the kernel, the vector unit has room -- so the shifts and masks of the bit buffer run there, and only what steers the
+// control flow (a code length, a symbol, extra bits) comes back through v_readfirstlane.  The empty asm makes the value "not known to be
+// uniform" to the compiler.
+__device__ __forceinline__ uint64_t pgi_in_vgpr(uint64_t x) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return ((uint64_t)hi << 32) | lo;
+}
+#define PGI_IN_VGPR(x) pgi_in_vgpr(x)
 #define PGI_SYNC __syncthreads()
 #define PGI_ATOMIC_INC(p) atomicAdd((p), 1u)
 #define PGI_LANE_PARAM , const int lane
@@ -189,7 +200,7 @@ PGI_DEV int pgi_build(const uint8_t *lens, int n, uint16_t *sorted, uint32_t *hi
 #define PGI_FILL1()                                                                  \
     do {                                                                             \
         const uint32_t w_ = (uint32_t)READLANE(cur, widx & 63u);                     \
-        buf |= (uint64_t)w_ << cnt;                                                  \
+        buf = PGI_IN_VGPR(buf | ((uint64_t)w_ << cnt));                              \
         cnt += 32;                                                                   \
         ++widx;                                                                      \
         if ((widx & 63u) == 0u) {                                                    \
@@ -222,7 +233,7 @@ PGI_DEV int pgi_build(const uint8_t *lens, int n, uint16_t *sorted, uint32_t *hi
             V(nxt) = comp[a_ < n_dw ? a_ : n_dw - 1u];                      \
         }                                                                   \
         widx = d_;                                                          \
-        buf = 0;                                                            \
+        buf = PGI_IN_VGPR(0);                                               \
         cnt = 0;                                                            \
         const int drop_ = (int)((byte_off) & 3u) * 8;                       \
         if (drop_) {                                                        \
@@ -333,13 +344,15 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
     for (;;) {
         if ((uint64_t)widx * 32u - (uint64_t)cnt > end_bits) return PGI_ERR_IN;
         PGI_NEED(3);
-        const int bfinal = (int)(buf & 1u), btype = (int)((buf >> 1) & 3u);
+        const uint32_t hdr = (uint32_t)UNI((uint32_t)buf & 7u);
+        const int bfinal = (int)(hdr & 1u), btype = (int)(hdr >> 1);
         PGI_DROP(3);
         if (btype == 3) return PGI_ERR_BTYPE;
         if (btype == 0) {
             PGI_DROP(cnt & 7);
             PGI_NEED(32);
-            const uint32_t len = (uint32_t)(buf & 0xFFFFu), nlen = (uint32_t)((buf >> 16) & 0xFFFFu);
+            const uint32_t lw = (uint32_t)UNI((uint32_t)buf);
+            const uint32_t len = lw & 0xFFFFu, nlen = lw >> 16;
             PGI_DROP(32);
             if ((len ^ 0xFFFFu) != nlen) return PGI_ERR_STORED;
             const uint64_t bp = ((uint64_t)widx * 32u - (uint64_t)cnt) >> 3;
@@ -374,9 +387,10 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 }
             } else {
                 PGI_NEED(14);
-                hlit = (int)(buf & 31u) + 257;
-                hdist = (int)((buf >> 5) & 31u) + 1;
-                const int hclen = (int)((buf >> 10) & 15u) + 4;
+                const uint32_t hw = (uint32_t)UNI((uint32_t)buf & 0x3FFFu);
+                hlit = (int)(hw & 31u) + 257;
+                hdist = (int)((hw >> 5) & 31u) + 1;
+                const int hclen = (int)((hw >> 10) & 15u) + 4;
                 PGI_DROP(14);
                 if (hlit > 286 || hdist > 30) return PGI_ERR_CODE;
                 // the code-length code: 3 bits each, in the order of RFC 1951 3.2.7
@@ -384,7 +398,7 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 PGI_SYNC;
                 for (int i = 0; i < hclen; ++i) {
                     PGI_NEED(3);
-                    const int v = (int)(buf & 7u);
+                    const int v = (int)UNI((uint32_t)buf & 7u);
                     PGI_DROP(3);
                     // order: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
                     int sym;
@@ -416,15 +430,15 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                     if (sym == 16) {
                         if (i == 0) return PGI_ERR_CODE;
                         val = prev;
-                        rep = 3 + (int)(buf & 3u);
+                        rep = 3 + (int)UNI((uint32_t)buf & 3u);
                         PGI_DROP(2);
                     } else if (sym == 17) {
                         val = 0;
-                        rep = 3 + (int)(buf & 7u);
+                        rep = 3 + (int)UNI((uint32_t)buf & 7u);
                         PGI_DROP(3);
                     } else {
                         val = 0;
-                        rep = 11 + (int)(buf & 127u);
+                        rep = 11 + (int)UNI((uint32_t)buf & 127u);
                         PGI_DROP(7);
                     }
                     if (i + rep > total) return PGI_ERR_CODE;
@@ -491,7 +505,7 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 acc |= 28 - sym;
                 const uint32_t lc = (uint32_t)READLANE(lconst, sym);               // (sym <= 63 whatever was decoded)
                 const uint32_t le = lc >> 16;
-                const uint32_t len = (lc & 0xFFFFu) + (uint32_t)(buf & ((1u << le) - 1u));
+                const uint32_t len = (lc & 0xFFFFu) + (uint32_t)UNI((uint32_t)buf & ((1u << le) - 1u));
                 PGI_DROP(le);
                 PGI_NEED(32);
                 int dsym;
@@ -499,7 +513,7 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 acc |= 29 - dsym;
                 const uint32_t dc = (uint32_t)READLANE(dconst, dsym);
                 const uint32_t de = dc >> 16;
-                const uint32_t dist = (dc & 0xFFFFu) + (uint32_t)(buf & ((1u << de) - 1u));
+                const uint32_t dist = (dc & 0xFFFFu) + (uint32_t)UNI((uint32_t)buf & ((1u << de) - 1u));
                 PGI_DROP(de);
                 accd |= (int32_t)(pos - dist);                           // negative: the distance reaches in front of the member
                 PL(uint8_t, v0);
