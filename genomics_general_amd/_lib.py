@@ -84,6 +84,9 @@ SIGNATURES = {
     "pg_text_skip_rows": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     # (struct array + many pointers: genomics_general_amd/vcf.py passes explicit ctypes objects)
     "pg_encode_vcf": (C.c_int, None),
+    "pg_vcf_render_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char, C.c_char, C.c_int,
+                                     C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_format_freq_rows": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_void_p, _i64p, _i32p, C.c_char_p, _i64p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_inflate_chunks": (C.c_int, [C.c_void_p, _i64p, _i64p, _i64p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),

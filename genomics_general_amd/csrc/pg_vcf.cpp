@@ -21,7 +21,12 @@ namespace {
 
 struct Tok { const char *p; int n; };
 
-inline bool ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+struct WsTable {
+    bool is[256];
+    WsTable() { memset(is, 0, sizeof(is)); is[(int)' '] = is[(int)'\t'] = is[(int)'\r'] = is[(int)'\v'] = is[(int)'\f'] = true; }
+};
+const WsTable WS;
+inline bool ws(char c) { return WS.is[(unsigned char)c]; }
 
 // str.split(): tokens separated by runs of whitespace
 int split_ws(const char *b, const char *e, Tok *out, int cap) {
@@ -72,6 +77,23 @@ int format_index(const Tok &fmt, const char *name, int nlen) {
 // Python float(): the whole (stripped) token must be a number
 bool py_float(const char *p, int n, double *v) {
     if (n <= 0) return false;
+    // the common spellings -- digits with at most one '.', at most 15 digits in all -- without strtod: the digits as an integer below
+    // 2^53 divided by an exact power of ten is the correctly rounded value (one IEEE division of two exact operands)
+    if (n <= 16) {
+        static const double P10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+        uint64_t m = 0;
+        int digits = 0, frac = -1, k = 0;
+        for (; k < n; ++k) {
+            const char c = p[k];
+            if (c >= '0' && c <= '9') { m = m * 10 + (uint64_t)(c - '0'); ++digits; if (frac >= 0) ++frac; }
+            else if (c == '.' && frac < 0) frac = 0;
+            else break;
+        }
+        if (k == n && digits >= 1 && digits <= 15) {
+            *v = frac > 0 ? (double)m / P10[frac] : (double)m;
+            return true;
+        }
+    }
     std::string tmp(p, (size_t)n);          // (any length: Python takes a long run of digits too)
     // strtod accepts hexadecimal floats ("0x1p3"), Python's float() does not
     size_t k = (tmp[0] == '+' || tmp[0] == '-') ? 1 : 0;
@@ -155,6 +177,8 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
     const int need = 9 + sh.n_vcf_samples;
     std::vector<Tok> tk((size_t)need + 1);
     std::vector<Tok> alt;
+    std::vector<int> fidx((size_t)sh.n_filters + 1), flag_len((size_t)sh.n_filters + 1);
+    for (int f = 0; f < sh.n_filters; ++f) flag_len[f] = (int)strlen(sh.filters[f].flag);
     long long kept = 0;
     while (b < e && !sh.err.load(std::memory_order_relaxed)) {
         const char *nl = static_cast<const char *>(memchr(b, '\n', (size_t)(e - b)));
@@ -219,6 +243,7 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
                 for (int i = 0; i < n_all; ++i) all_match = all_match && alt[i].n == t[3].n;
                 const int site_type = n_all == 1 ? 1 : (all_match ? 2 : 4);            // MONO / SNP / INDEL
                 const int gt_idx = format_index(t[8], "GT", 2);
+                for (int f = 0; f < sh.n_filters; ++f) fidx[f] = format_index(t[8], sh.filters[f].flag, flag_len[f]);
                 uint8_t *oc = sh.chars + (size_t)row * 2 * sh.n_sel;
                 int8_t *oi = sh.idx + (size_t)row * 2 * sh.n_sel;
                 uint8_t *op = sh.phase + (size_t)row * sh.n_sel;
@@ -264,7 +289,7 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
                         if (F.site_types && !(F.site_types & site_type)) continue;
                         if (F.gt_types && !(F.gt_types & gt_type)) continue;
                         if (F.samples && !F.samples[s]) continue;
-                        const int fi = format_index(t[8], F.flag, (int)strlen(F.flag));
+                        const int fi = fidx[f];
                         Tok v;
                         if (fi < 0 || !colon_piece(cell, fi, &v)) { passed = false; break; }
                         // np.array(value.split(","), dtype=float): every piece must parse and lie in [min, max]
@@ -421,5 +446,177 @@ extern "C" int pg_encode_vcf(const char *buf, size_t len, int n_vcf_samples, int
     }
     if (sh.err.load()) return pg_fail(PG_ERR_PARSE, "%s", sh.msg);
     if (n_multibase_out) *n_multibase_out = sh.multibase.load();
+    return PG_OK;
+}
+
+
+// ---- the `.geno` text of the rows pg_encode_vcf produced ---------------------------------------------------------------------------
+// What the reference prints per kept site (VCF_processing/parseVCF.py:151-169 getGenotype's printed form, 380-383 the output line):
+// CHROM, POS[, REF] and one cell per selected sample, joined by the separator.  A cell is the sample's allele characters joined by its
+// phase character; in a row whose row_flag is set (some printed allele longer than one base) the cells are put together from the
+// REF / ALT strings through the allele indices.
+namespace {
+
+struct RenderArgs {
+    const char *buf;
+    int n_sel;
+    const int32_t *ploidy;
+    const uint8_t *chars;
+    const int8_t *idx;
+    const uint8_t *phase;
+    const uint8_t *row_flag;
+    const int64_t *pos;
+    const int64_t *chrom_off;
+    const int32_t *chrom_len;
+    const int64_t *ref_off;
+    const int32_t *ref_len;
+    const int64_t *alt_off;
+    const int32_t *alt_len;
+    char sep, missing;
+    int add_ref;
+    int64_t plain_cells;                // bytes of the cells + separators + line feed of a row without long alleles
+};
+
+inline int dec_len(int64_t v) {
+    int n = v < 0 ? 1 : 0;
+    uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+    do { ++n; u /= 10; } while (u);
+    return n;
+}
+
+inline char *put_dec(char *o, int64_t v) {
+    char tmp[24];
+    int n = 0;
+    uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *o++ = '-';
+    while (n) *o++ = tmp[--n];
+    return o;
+}
+
+// the alleles of a flagged row: REF, then the pieces of ALT (none when ALT is ".")
+int row_alleles(const RenderArgs &A, int64_t r, Tok *al, int cap) {
+    int n = 0;
+    al[n].p = A.buf + A.ref_off[r]; al[n].n = A.ref_len[r]; ++n;
+    const char *p = A.buf + A.alt_off[r], *pe = p + A.alt_len[r];
+    if (!(A.alt_len[r] == 1 && p[0] == '.')) {
+        for (;;) {
+            const char *q = static_cast<const char *>(memchr(p, ',', (size_t)(pe - p)));
+            if (n < cap) { al[n].p = p; al[n].n = (int)((q ? q : pe) - p); }
+            ++n;
+            if (!q) break;
+            p = q + 1;
+        }
+    }
+    return n;
+}
+
+// bytes of row r; -1 when an allele index of a flagged row names no allele
+int64_t row_bytes(const RenderArgs &A, int64_t r) {
+    int64_t n = A.chrom_len[r] + 1 + dec_len(A.pos[r]) + 1 + (A.add_ref ? A.ref_len[r] + 1 : 0);
+    if (!A.row_flag[r]) return n + A.plain_cells;
+    Tok al[130];
+    const int na = row_alleles(A, r, al, 130);
+    const int8_t *ix = A.idx + (size_t)r * 2 * A.n_sel;
+    for (int s = 0; s < A.n_sel; ++s) {
+        for (int i = 0; i < A.ploidy[s]; ++i) {
+            const int a = ix[2 * s + i];
+            if (a >= na || a >= 130) return -1;
+            n += a >= 0 ? al[a].n : 1;
+        }
+        n += A.ploidy[s];                                   // (ploidy - 1) phase characters + the separator / line feed
+    }
+    if (A.n_sel == 0) n += 1;
+    return n;
+}
+
+char *row_put(const RenderArgs &A, int64_t r, char *o) {
+    memcpy(o, A.buf + A.chrom_off[r], (size_t)A.chrom_len[r]); o += A.chrom_len[r];
+    *o++ = A.sep;
+    o = put_dec(o, A.pos[r]);
+    *o++ = A.sep;
+    if (A.add_ref) { memcpy(o, A.buf + A.ref_off[r], (size_t)A.ref_len[r]); o += A.ref_len[r]; *o++ = A.sep; }
+    if (A.n_sel == 0) { *o++ = '\n'; return o; }
+    const uint8_t *c = A.chars + (size_t)r * 2 * A.n_sel;
+    const uint8_t *ph = A.phase + (size_t)r * A.n_sel;
+    if (!A.row_flag[r]) {
+        for (int s = 0; s < A.n_sel; ++s) {
+            *o++ = (char)c[2 * s];
+            if (A.ploidy[s] == 2) { *o++ = (char)ph[s]; *o++ = (char)c[2 * s + 1]; }
+            *o++ = s + 1 < A.n_sel ? A.sep : '\n';
+        }
+        return o;
+    }
+    Tok al[130];
+    row_alleles(A, r, al, 130);
+    const int8_t *ix = A.idx + (size_t)r * 2 * A.n_sel;
+    for (int s = 0; s < A.n_sel; ++s) {
+        for (int i = 0; i < A.ploidy[s]; ++i) {
+            if (i) *o++ = (char)ph[s];
+            const int a = ix[2 * s + i];
+            if (a >= 0) { memcpy(o, al[a].p, (size_t)al[a].n); o += al[a].n; }
+            else *o++ = A.missing;
+        }
+        *o++ = s + 1 < A.n_sel ? A.sep : '\n';
+    }
+    return o;
+}
+
+}  // namespace
+
+extern "C" int pg_vcf_render_rows(const char *buf, int64_t n_rows, int n_sel, const int32_t *sel_ploidy, const uint8_t *chars,
+                                  const int8_t *idx, const uint8_t *phase, const uint8_t *row_flag, const int64_t *pos,
+                                  const int64_t *chrom_off, const int32_t *chrom_len, const int64_t *ref_off, const int32_t *ref_len,
+                                  const int64_t *alt_off, const int32_t *alt_len, char sep, char missing, int add_ref, uint8_t *out,
+                                  int64_t out_cap, int64_t *out_len_out, int n_threads) {
+    if (n_rows < 0 || n_sel < 0 || !out_len_out) return pg_fail(PG_ERR_ARG, "pg_vcf_render_rows: bad argument");
+    *out_len_out = 0;
+    if (n_rows == 0) return PG_OK;
+    if (!buf || !row_flag || !pos || !chrom_off || !chrom_len || !ref_off || !ref_len || !alt_off || !alt_len ||
+        (n_sel > 0 && (!sel_ploidy || !chars || !idx || !phase)))
+        return pg_fail(PG_ERR_ARG, "pg_vcf_render_rows: null argument");
+    RenderArgs A;
+    A.buf = buf; A.n_sel = n_sel; A.ploidy = sel_ploidy; A.chars = chars; A.idx = idx; A.phase = phase; A.row_flag = row_flag;
+    A.pos = pos; A.chrom_off = chrom_off; A.chrom_len = chrom_len; A.ref_off = ref_off; A.ref_len = ref_len; A.alt_off = alt_off;
+    A.alt_len = alt_len; A.sep = sep; A.missing = missing ? missing : 'N'; A.add_ref = add_ref;
+    A.plain_cells = n_sel == 0 ? 1 : 0;
+    for (int s = 0; s < n_sel; ++s) {
+        if (sel_ploidy[s] < 1 || sel_ploidy[s] > 2) return pg_fail(PG_ERR_ARG, "ploidy of selected sample %d must be 1 or 2", s);
+        A.plain_cells += sel_ploidy[s] == 2 ? 4 : 2;
+    }
+    int nt = n_threads > 0 ? n_threads : pg_host_threads();
+    if (nt < 1) nt = 1;
+    if ((int64_t)nt > n_rows / 256 + 1) nt = (int)(n_rows / 256 + 1);
+    std::vector<int64_t> first((size_t)nt + 1), bytes((size_t)nt + 1, 0);
+    for (int t = 0; t <= nt; ++t) first[t] = n_rows * t / nt;
+    std::atomic<long long> bad(-1);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&, t]() {
+                int64_t n = 0;
+                for (int64_t r = first[t]; r < first[t + 1]; ++r) {
+                    const int64_t b = row_bytes(A, r);
+                    if (b < 0) { bad.store((long long)r); return; }
+                    n += b;
+                }
+                bytes[t + 1] = n;
+            });
+        for (auto &x : th) x.join();
+    }
+    if (bad.load() >= 0) return pg_fail(PG_ERR_ARG, "row %lld: an allele index names no allele of the site", bad.load());
+    for (int t = 0; t < nt; ++t) bytes[t + 1] += bytes[t];
+    *out_len_out = bytes[nt];
+    if (!out) return PG_OK;                                  // sizing call
+    if (bytes[nt] > out_cap) return pg_fail(PG_ERR_ARG, "the rows take %lld bytes, the output holds %lld", (long long)bytes[nt], (long long)out_cap);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&, t]() {
+                char *o = reinterpret_cast<char *>(out) + bytes[t];
+                for (int64_t r = first[t]; r < first[t + 1]; ++r) o = row_put(A, r, o);
+            });
+        for (auto &x : th) x.join();
+    }
     return PG_OK;
 }

@@ -293,6 +293,20 @@ class Engine:
                                               np.ascontiguousarray(lay.col_slot), lay.col_ploidy, C.byref(ok)))
         return bool(ok.value)
 
+    def inflate_members(self, comp, tab, dst):
+        """BGZF members (genoio.bgzf_walk's table over the bytes comp) inflated on the device into the host array dst
+        (pg_inflate_device: k_inflate + k_crc32, then one copy back -- page-locked dst: at the link's rate); returns the kernels' ms.
+        For text whose parser lives on the host (the VCF drop-in)."""
+        in_off, in_len, out_len, crc = tab
+        arr = np.frombuffer(comp, dtype=np.uint8)
+        total = int(out_len.sum(dtype=np.int64))
+        if dst.dtype != np.uint8 or not dst.flags.c_contiguous or dst.size < total:
+            raise ValueError("inflate_members: dst must be a contiguous uint8 array of at least %d bytes" % total)
+        vp = lambda a: C.c_void_p(a.ctypes.data if a.size else 0)           # noqa: E731
+        ms = C.c_double(0)
+        check(self._L.pg_inflate_device(self._h, vp(arr), arr.size, vp(in_off), vp(in_len), vp(out_len), vp(crc), len(in_off), vp(dst), C.byref(ms)))
+        return ms.value
+
     def tokenize_parse(self, slot, row_offset, row_capacity, max_runs=1 << 16):
         """queue the parse of the block in `slot` into resident rows row_offset .. (at most row_capacity of them); returns the number of
         its lines, or None when they do not fit"""

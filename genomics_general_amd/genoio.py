@@ -82,14 +82,17 @@ def bgzf_walk(buf, limit=None, max_text=0):
     return (tab[0, :m], tab[1, :m], tab[2, :m], tab[3, :m]), int(used.value), int(text.value)
 
 
-def bgzf_inflate(buf, tab, n_threads=0):
-    """the text of the members `tab` (bgzf_walk) of buf as a uint8 array, inflated by the library's host threads (zlib; the
-    checksums are verified)"""
+def bgzf_inflate(buf, tab, n_threads=0, dst=None):
+    """the text of the members `tab` (bgzf_walk) of buf as a uint8 array (dst when given: a uint8 array that holds it), inflated
+    by the library's host threads (zlib; the checksums are verified)"""
     in_off, in_len, out_len, crc = tab
     arr = np.frombuffer(buf, dtype=np.uint8)
     out_off = np.zeros(len(out_len) + 1, dtype=np.int64)
     np.cumsum(out_len, out=out_off[1:])
-    dst = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+    if dst is None:
+        dst = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+    elif dst.dtype != np.uint8 or not dst.flags.c_contiguous or dst.size < int(out_off[-1]):
+        raise ValueError("bgzf_inflate: dst must be a contiguous uint8 array of at least %d bytes" % int(out_off[-1]))
     rc = _lib.lib().pg_inflate_members(C.c_void_p(arr.ctypes.data if len(arr) else 0), C.c_void_p(in_off.ctypes.data),
                                        C.c_void_p(in_len.ctypes.data), out_off, C.c_void_p(out_len.ctypes.data),
                                        C.c_void_p(crc.ctypes.data), len(out_len), C.c_void_p(dst.ctypes.data), int(n_threads))
@@ -161,6 +164,24 @@ class BgzfSpan:
 
     def __bytes__(self):
         return (self.head + bgzf_inflate(self.comp, self.tab).tobytes())[:self.text_len]
+
+    def members_text_len(self):
+        return int(self.tab[2].sum(dtype=np.int64))
+
+    def inflate_into(self, dst, engine=None, n_threads=0):
+        """the block's text in dst (a uint8 array of at least len(head) + members_text_len() bytes; page-locked when it comes from
+        the engine's pool): the head, then the members inflated behind it -- by the device when an engine is given (k_inflate +
+        k_crc32, the text copied back), else by the library's host threads.  Returns dst[:len(self)]."""
+        h, total = len(self.head), self.members_text_len()
+        if dst.size < h + total:
+            raise ValueError("BgzfSpan.inflate_into: %d bytes needed, dst holds %d" % (h + total, dst.size))
+        if h:
+            dst[:h] = np.frombuffer(self.head, dtype=np.uint8)
+        if engine is not None:
+            engine.inflate_members(self.comp, self.tab, dst[h:h + total])
+        else:
+            bgzf_inflate(self.comp, self.tab, n_threads, dst=dst[h:h + total])
+        return dst[:self.text_len]
 
     def __getitem__(self, key):                 # (the first bytes of the block: what the ingestion loop looks at to bound its rows)
         if isinstance(key, slice) and key.start in (None, 0) and key.step is None:

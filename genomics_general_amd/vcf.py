@@ -18,8 +18,12 @@ reference prints them; the packed route stores such calls as missing (use --maxR
 import argparse
 import ctypes as C
 import gzip
+import json
 import os
+import queue
 import sys
+import threading
+import time
 
 import numpy as np
 
@@ -64,6 +68,118 @@ def _open_out(path):
     # (VCF_processing/README.md:33) produces, a valid gzip file for its readers (gzip.open there), and the form the drivers inflate on
     # the GPU.  (parseVCF.py:358 itself would write one serial gzip stream.)
     return genoio.BgzfWriter(path) if path.endswith(".gz") else open(path, "wb")
+
+
+class _AsyncOut:
+    """writes of the output file on a thread of their own (for `.gz`: genoio.BgzfWriter's deflate pool + the file), two blocks deep"""
+
+    def __init__(self, out):
+        self.out = out
+        self.q = queue.Queue(2)
+        self.err = None
+        self.th = threading.Thread(target=self._run, name="pg-vcf-write", daemon=True)
+        self.th.start()
+
+    def _run(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if self.err is None:
+                try:
+                    self.out.write(memoryview(item))
+                except BaseException as exc:                  # kept for the caller; the queue is still drained
+                    self.err = exc
+
+    def write(self, data):
+        if self.err is not None:
+            raise self.err
+        self.q.put(data)
+
+    def close(self):
+        self.q.put(None)
+        self.th.join()
+        if self.err is not None:
+            raise self.err
+
+
+def _text_blocks(reader, block_bytes, n_threads=0):
+    """the input's text in blocks of whole lines.  A bgzip-compressed VCF (what `bgzip` / GATK / bcftools write) is read as spans of
+    deflated members (genoio.BgzfFile.read_span) and inflated into a ring of buffers: ON THE DEVICE when there is one (the members
+    cross PCIe deflated, k_inflate takes a wavefront per member, the text comes back into page-locked memory; PG_BGZF_DEVICE=0:
+    never), else by the library's host threads.  Everything else: the reader's own blocks."""
+    eng = None
+    bg = isinstance(getattr(reader, "f", None), genoio.BgzfFile)
+    if bg and os.environ.get("PG_BGZF_DEVICE", "1") != "0" and _lib.device_count() > 0:
+        from .engine import Engine
+        eng = Engine(int(os.environ.get("PG_DEVICE", "0")))
+        reader.f.alloc = eng.pinned.empty
+    if bg:
+        reader.spans = True
+    empty = eng.pinned.empty if eng is not None else np.empty
+    ring, turn = [None] * 4, 0                  # one block with the parser, two queued, one being filled
+    info = {"bgzf": bg, "device_inflate": eng is not None, "inflate_kernel_ms": 0.0, "inflate_s": 0.0, "blocks": 0}
+    try:
+        while True:
+            blk = reader.read_block(block_bytes)
+            if len(blk) == 0:
+                break
+            info["blocks"] += 1
+            if isinstance(blk, genoio.BgzfSpan):
+                need = len(blk.head) + blk.members_text_len()
+                buf = ring[turn % 4]
+                if buf is None or buf.size < need:
+                    buf = ring[turn % 4] = empty((need + need // 16 + (1 << 16),), np.uint8)
+                turn += 1
+                t0 = time.perf_counter()
+                if eng is not None:
+                    h = len(blk.head)
+                    if h:
+                        buf[:h] = np.frombuffer(blk.head, dtype=np.uint8)
+                    info["inflate_kernel_ms"] += eng.inflate_members(blk.comp, blk.tab, buf[h:need])
+                    blk = buf[:len(blk)]
+                else:
+                    blk = blk.inflate_into(buf, None, n_threads)
+                info["inflate_s"] += time.perf_counter() - t0
+            yield blk
+    finally:
+        _text_blocks.last_info = info             # (the engine lives on: the parser may still be reading the last block in its memory)
+
+
+def _read_ahead(blocks, depth=2):
+    """the blocks of an iterator, produced by a thread `depth` blocks ahead of the consumer"""
+    q = queue.Queue(depth)
+    stop = threading.Event()
+    done = object()
+
+    def run():
+        try:
+            for body in blocks:
+                q.put(body)
+                if stop.is_set():
+                    break
+            q.put(done)
+        except BaseException as exc:
+            q.put(exc)
+
+    th = threading.Thread(target=run, name="pg-vcf-read", daemon=True)
+    th.start()
+    try:
+        while True:
+            body = q.get()
+            if isinstance(body, BaseException):
+                raise body
+            if body is done:
+                return
+            yield body
+    finally:
+        stop.set()
+        while th.is_alive():                                  # a reader blocked on a full queue
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(0.05)
 
 
 def _last_key(body):
@@ -438,85 +554,89 @@ def parse_vcf_main(argv=None):
     lut = np.zeros(256, dtype=np.uint8)
     for ch, code in zip(b"ACGT", (1, 2, 4, 8)):
         lut[ch] = code
-    # byte layout of a row's genotype part: per sample [c0, phase, c1] (diploid) or [c0] (haploid), then separator / newline
-    widths = np.where(pl == 2, 3, 1) + 1
-    col_at = np.concatenate([[0], np.cumsum(widths)[:-1]]).astype(np.int64)
-    W = int(widths.sum())
-    block_bytes = int(os.environ.get("PG_STREAM_BYTES", 256 << 20))
+    block_bytes = int(os.environ.get("PG_STREAM_BYTES", 128 << 20))
+    timing = {} if os.environ.get("PG_TIMING") else None
+    t_start = time.perf_counter()
+
+    def lap(name, t0):
+        t1 = time.perf_counter()
+        if timing is not None:
+            timing[name] = timing.get(name, 0.0) + t1 - t0
+        return t1
+
+    # three steps side by side: a reader thread (the next blocks: file pages, or BGZF members inflated by the library's host threads),
+    # this thread (pg_encode_vcf + pg_vcf_render_rows, both on host threads) and a writer thread (BGZF deflate + write)
+    sink = _AsyncOut(out) if out is not None else None
     prev_chrom = prev_pos = None
     n_multibase_total = 0
-    while True:
-        body = reader.read_block(block_bytes)
-        if len(body) == 0:
-            break
+    bufs = {}
+
+    def arr(name, shape, dtype):
+        """arrays of the parser's outputs, kept from block to block (pg_encode_vcf writes every field of a kept row)"""
+        a = bufs.get(name)
+        if a is None or a.shape[0] < shape[0]:
+            a = bufs[name] = np.empty(shape, dtype=dtype)
+        return a
+
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    t0 = time.perf_counter()
+    for body in _read_ahead(_text_blocks(reader, block_bytes, int(args.threads))):
+        t0 = lap("wait_for_block_s", t0)
         ptr, nbytes, keep = _lib.text_ptr(body)
-        cap = int(np.count_nonzero(keep == 10)) + 1
-        chars = np.zeros((cap, 2 * n_sel), dtype=np.uint8)
-        aidx = np.zeros((cap, 2 * n_sel), dtype=np.int8)
-        phase = np.zeros((cap, n_sel), dtype=np.uint8)
-        rflag = np.zeros(cap, dtype=np.uint8)
-        pos = np.zeros(cap, dtype=np.int64)
-        coff, roff, aoff = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64)
-        clen, rlen, alen = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
+        nl = C.c_int64(0)
+        check(L.pg_count_lines(ptr, nbytes, C.byref(nl)))
+        cap = int(nl.value) + 1
+        chars = arr("chars", (cap, 2 * n_sel), np.uint8)
+        aidx = arr("aidx", (cap, 2 * n_sel), np.int8)
+        phase = arr("phase", (cap, n_sel), np.uint8)
+        rflag = arr("rflag", (cap,), np.uint8)
+        pos = arr("pos", (cap,), np.int64)
+        coff, roff, aoff = arr("coff", (cap,), np.int64), arr("roff", (cap,), np.int64), arr("aoff", (cap,), np.int64)
+        clen, rlen, alen = arr("clen", (cap,), np.int32), arr("rlen", (cap,), np.int32), arr("alen", (cap,), np.int32)
         n, nmb = C.c_int64(0), C.c_int64(0)
-        check(fn(ptr, C.c_size_t(nbytes), len(vcf_samples), n_sel, sel_col.ctypes.data_as(C.c_void_p), pl.ctypes.data_as(C.c_void_p),
+        check(fn(ptr, C.c_size_t(nbytes), len(vcf_samples), n_sel, vp(sel_col), vp(pl),
                  flags, C.c_double(float(args.minQual or 0)), int(args.maxREFlen or 0), Farr, len(gtf),
                  C.c_char_p(contigs), len(contigs), contig_mode, C.c_char(missing.encode()),
                  C.c_char_p(prev_chrom), len(prev_chrom or b""), C.c_char_p(prev_pos), len(prev_pos or b""),
-                 chars.ctypes.data_as(C.c_void_p), aidx.ctypes.data_as(C.c_void_p), phase.ctypes.data_as(C.c_void_p),
-                 rflag.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
-                 coff.ctypes.data_as(C.c_void_p), clen.ctypes.data_as(C.c_void_p), roff.ctypes.data_as(C.c_void_p),
-                 rlen.ctypes.data_as(C.c_void_p), aoff.ctypes.data_as(C.c_void_p), alen.ctypes.data_as(C.c_void_p),
+                 vp(chars), vp(aidx), vp(phase), vp(rflag), vp(pos), vp(coff), vp(clen), vp(roff), vp(rlen), vp(aoff), vp(alen),
                  C.c_int64(cap), C.byref(n), C.byref(nmb), int(args.threads)))
+        t0 = lap("parse_s", t0)
         k = int(n.value)
         n_multibase_total += int(nmb.value)
         pc, pp = _last_key(body)
         if pc is not None:
             prev_chrom, prev_pos = pc, pp
         if k == 0:
+            del keep, body
+            t0 = time.perf_counter()
             continue
-        # scaffold runs of the kept rows (names are read once per run)
-        starts = np.zeros(k, dtype=np.int64)
-        nr = C.c_int64(0)
-        check(L.pg_scaffold_runs(ptr, coff, clen, k, starts, k, C.byref(nr)))
-        starts = starts[:nr.value]
-        run_names = [bytes(body[int(coff[i]):int(coff[i]) + int(clen[i])]) for i in starts]
-        if out is not None:
-            mat = np.empty((k, W), dtype=np.uint8)
-            for s in range(n_sel):
-                a = int(col_at[s])
-                mat[:, a] = chars[:k, 2 * s]
-                if pl[s] == 2:
-                    mat[:, a + 1] = phase[:k, s]
-                    mat[:, a + 2] = chars[:k, 2 * s + 1]
-                mat[:, a + int(widths[s]) - 1] = sep[0] if s + 1 < n_sel else 10
-            bounds = list(starts) + [k]
-            pieces = []
-            for r, nm in enumerate(run_names):
-                for i in range(int(bounds[r]), int(bounds[r + 1])):
-                    pre = nm + sep + str(int(pos[i])).encode() + sep
-                    if args.addRefTrack:
-                        pre += bytes(body[int(roff[i]):int(roff[i]) + int(rlen[i])]) + sep
-                    pieces.append(pre)
-                    if rflag[i]:
-                        # a printed allele of this row is longer than one base (e.g. `GG/GG` at a deletion site): the row is
-                        # rendered from the allele strings, as the reference does (parseVCF.py:151-169)
-                        alleles = [bytes(body[int(roff[i]):int(roff[i]) + int(rlen[i])])]
-                        alt = bytes(body[int(aoff[i]):int(aoff[i]) + int(alen[i])])
-                        if alt != b".":
-                            alleles += alt.split(b",")
-                        cells = []
-                        for s in range(n_sel):
-                            calls = [alleles[a] if a >= 0 else missing.encode() for a in aidx[i, 2 * s:2 * s + int(pl[s])]]
-                            cells.append(bytes([phase[i, s]]).join(calls))
-                        pieces.append(sep.join(cells) + b"\n")
-                    else:
-                        pieces.append(mat[i].tobytes() if n_sel else b"\n")
-            out.write(b"".join(pieces))
+        if sink is not None:
+            # the rows as text (pg_vcf_render_rows: a sizing call, then the bytes)
+            size = C.c_int64(0)
+            rargs = (ptr, k, n_sel, vp(pl), vp(chars), vp(aidx), vp(phase), vp(rflag), vp(pos), vp(coff), vp(clen), vp(roff), vp(rlen),
+                     vp(aoff), vp(alen), C.c_char(sep), C.c_char(missing.encode()), 1 if args.addRefTrack else 0)
+            check(L.pg_vcf_render_rows(*rargs, None, 0, C.byref(size), int(args.threads)))
+            text = np.empty(size.value, dtype=np.uint8)
+            check(L.pg_vcf_render_rows(*rargs, vp(text), size.value, C.byref(size), int(args.threads)))
+            t0 = lap("render_s", t0)
+            sink.write(text)
+            t0 = lap("wait_for_writer_s", t0)
         if packer is not None:
+            # scaffold runs of the kept rows (names are read once per run)
+            starts = np.zeros(k, dtype=np.int64)
+            nr = C.c_int64(0)
+            check(L.pg_scaffold_runs(ptr, coff, clen, k, starts, k, C.byref(nr)))
+            starts = starts[:nr.value]
+            run_names = [bytes(body[int(coff[i]):int(coff[i]) + int(clen[i])]) for i in starts]
             cells = lut[chars[:k, 0::2]] | (lut[chars[:k, 1::2]] << 4)
             packer.write_block(genoio.GenoData(None, pos[:k].copy(), starts.copy(), [nm.decode("utf-8", "replace") for nm in run_names]), cells)
+            t0 = lap("pack_s", t0)
         del keep, body
+        t0 = time.perf_counter()
+    if sink is not None:
+        t0 = time.perf_counter()
+        sink.close()
+        lap("wait_for_writer_s", t0)
     if out is not None and out is not sys.stdout.buffer:
         out.close()
     elif out is not None:
@@ -526,4 +646,8 @@ def parse_vcf_main(argv=None):
         if n_multibase_total:
             sys.stderr.write("%d allele calls longer than one base were stored as missing\n" % n_multibase_total)
     reader.close()
+    if timing is not None:
+        timing["total_s"] = time.perf_counter() - t_start
+        timing.update(getattr(_text_blocks, "last_info", {}))
+        sys.stderr.write("PG_TIMING " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in timing.items()}) + "\n")
     return 0

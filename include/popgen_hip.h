@@ -253,6 +253,15 @@ int pg_encode_vcf(const char *buf, size_t len, int n_vcf_samples, int n_sel, con
                   int prev_pos_len, uint8_t *chars_out, int8_t *idx_out, uint8_t *phase_out, uint8_t *row_flag_out, int64_t *pos_out,
                   int64_t *chrom_off, int32_t *chrom_len, int64_t *ref_off, int32_t *ref_len, int64_t *alt_off, int32_t *alt_len,
                   int64_t cap_sites, int64_t *n_sites_out, int64_t *n_multibase_out, int n_threads);
+/* The `.geno` text of rows [0, n_rows) of pg_encode_vcf's outputs, as the reference prints them (VCF_processing/parseVCF.py:151-169
+ * the cells, 380-383 the line: CHROM, POS[, REF when add_ref], one cell per selected sample, joined by sep): a cell = the sample's
+ * allele characters joined by its phase character; in a row whose row_flag is set the cells are put together from the REF / ALT
+ * strings in buf through idx.  out == NULL: only *out_len_out (the bytes the rows take) is computed. */
+int pg_vcf_render_rows(const char *buf, int64_t n_rows, int n_sel, const int32_t *sel_ploidy, const uint8_t *chars, const int8_t *idx,
+                       const uint8_t *phase, const uint8_t *row_flag, const int64_t *pos, const int64_t *chrom_off,
+                       const int32_t *chrom_len, const int64_t *ref_off, const int32_t *ref_len, const int64_t *alt_off,
+                       const int32_t *alt_len, char sep, char missing, int add_ref, uint8_t *out, int64_t out_cap,
+                       int64_t *out_len_out, int n_threads);
 
 /* freq.py's output rows (freq.py:98-113) formatted on all host threads: "scaffold\tposition\tcell\tcell...\n" per kept site.
  * mode 0: values = int32 [n][n_pops][4], cells "a,c,g,t"; mode 1: values = int64 [n][n_pops]; mode 2: values = double [n][n_pops]

@@ -195,3 +195,52 @@ def test_bgzf_on_several_ranks_cut_inside_members(name, tool, size, tmp_path):
     with open(out) as f, open(os.path.join(G.GOLD, case["name"] + ".out")) as g:
         got, want = f.read(), g.read()
     G.compare_text(align_columns(got, want), want, G.round_digits(case))
+
+
+# ---- the VCF drop-in on a bgzipped VCF: members inflated on the device, the text copied back for the host parser -------------------
+def _vcf_cases():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden_vcf import VCF_CASES
+    return [c for c in VCF_CASES if not any(a in ("--simplifyALT", "--expandMulti", "--field", "--missing") for a in c[2])]
+
+
+@pytest.mark.parametrize("name,src,argv", _vcf_cases(), ids=[c[0] for c in _vcf_cases()])
+@pytest.mark.parametrize("member,block", [(700, 3000), (65280, None)])
+def test_bgzipped_vcf_inflated_on_the_device(name, src, argv, member, block, tmp_path, monkeypatch):
+    import gzip
+    from genomics_general_amd import vcf
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vcf")
+    if block:
+        monkeypatch.setenv("PG_STREAM_BYTES", str(block))
+    bg = str(tmp_path / "in.vcf.gz")
+    with gzip.open(os.path.join(gold, src + ".vcf.gz"), "rb") as f:
+        text = f.read()
+    with open(bg, "wb") as f:
+        f.write(genoio.bgzf_compress(text, 6, member).tobytes())
+    out = str(tmp_path / "out.geno")
+    assert vcf.parse_vcf_main(["-i", bg, "-o", out] + [a.format(dir=gold) for a in argv]) in (0, None)
+    info = vcf._text_blocks.last_info
+    assert info["bgzf"] and info["device_inflate"] and info["blocks"] >= 1 and info["inflate_kernel_ms"] > 0
+    with open(out, "rb") as f, open(os.path.join(gold, name + ".geno"), "rb") as g:
+        assert f.read() == g.read()
+
+
+def test_engine_inflate_members_into_a_pinned_array_and_a_damaged_member():
+    rng = np.random.default_rng(3)
+    text = bytes(rng.choice(list(b"ACGT\t\n0123/|."), size=700000, p=None).astype(np.uint8))
+    comp = genoio.bgzf_compress(text, 6, 30000)
+    tab, used, n_text = genoio.bgzf_walk(comp, None, 1 << 30)
+    assert n_text == len(text)
+    e = Engine(0)
+    dst = e.pinned.empty((len(text) + 100,), np.uint8)
+    dst[:] = 0xEE
+    ms = e.inflate_members(memoryview(comp)[:used], tab, dst)
+    assert ms > 0 and dst[:len(text)].tobytes() == text and (dst[len(text):] == 0xEE).all()
+    bad = np.array(comp, copy=True)
+    bad[int(tab[0][5]) + 40] ^= 0x10                                            # a byte inside member 5's deflate stream
+    with pytest.raises(_lib.PopgenError):
+        e.inflate_members(memoryview(bad)[:used], tab, dst)
+    with pytest.raises(ValueError):
+        e.inflate_members(memoryview(comp)[:used], tab, dst[:1000])
+    e.close()

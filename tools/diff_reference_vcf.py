@@ -14,6 +14,7 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import make_golden_vcf as MV                                                    # noqa: E402
 
@@ -42,6 +43,13 @@ def make_case(tmp, case, rng):
         with gzip.open(vcf, "rb") as f, open(plain, "wb") as g:
             g.write(f.read())
         vcf = plain
+    elif rng.random() < 0.6:                                                     # what bgzip writes: members of a few hundred bytes to 64 KiB of text
+        import gzip
+        from genomics_general_amd import genoio
+        with gzip.open(vcf, "rb") as f:
+            text = f.read()
+        with open(vcf, "wb") as g:
+            g.write(genoio.bgzf_compress(text, 6, int(pick(rng, [300, 2000, 20000, 65280]))).tobytes())
     names = ["s%d" % k for k in range(n)]
     argv = []
     if rng.random() < 0.35:
