@@ -108,17 +108,22 @@ def _text_blocks(reader, block_bytes, n_threads=0):
     deflated members (genoio.BgzfFile.read_span) and inflated into a ring of buffers: ON THE DEVICE when there is one (the members
     cross PCIe deflated, k_inflate takes a wavefront per member, the text comes back into page-locked memory; PG_BGZF_DEVICE=0:
     never), else by the library's host threads.  Everything else: the reader's own blocks."""
-    eng = None
     bg = isinstance(getattr(reader, "f", None), genoio.BgzfFile)
+    made = {}
+    maker = None
     if bg and os.environ.get("PG_BGZF_DEVICE", "1") != "0" and _lib.device_count() > 0:
-        from .engine import Engine
-        eng = Engine(int(os.environ.get("PG_DEVICE", "0")))
-        reader.f.alloc = eng.pinned.empty
+        def make():                               # the device context takes 0.1 - 0.3 s: the first blocks do not wait for it
+            try:
+                from .engine import Engine
+                made["engine"] = Engine(int(os.environ.get("PG_DEVICE", "0")))
+            except BaseException as exc:
+                made["error"] = exc
+        maker = threading.Thread(target=make, name="pg-vcf-context", daemon=True)
+        maker.start()
     if bg:
         reader.spans = True
-    empty = eng.pinned.empty if eng is not None else np.empty
     ring, turn = [None] * 4, 0                  # one block with the parser, two queued, one being filled
-    info = {"bgzf": bg, "device_inflate": eng is not None, "inflate_kernel_ms": 0.0, "inflate_s": 0.0, "blocks": 0}
+    info = {"bgzf": bg, "device_inflate": False, "inflate_kernel_ms": 0.0, "inflate_s": 0.0, "blocks": 0, "blocks_inflated_on_device": 0}
     try:
         while True:
             blk = reader.read_block(block_bytes)
@@ -126,10 +131,18 @@ def _text_blocks(reader, block_bytes, n_threads=0):
                 break
             info["blocks"] += 1
             if isinstance(blk, genoio.BgzfSpan):
+                if maker is not None and (not maker.is_alive() or os.environ.get("PG_VCF_WAIT_FOR_DEVICE")):
+                    maker.join()
+                    maker = None
+                    if "error" in made:
+                        raise made["error"]
+                    reader.f.alloc = made["engine"].pinned.empty          # (the next spans arrive in page-locked memory)
+                    ring = [None] * 4
+                eng = made.get("engine") if maker is None else None
                 need = len(blk.head) + blk.members_text_len()
                 buf = ring[turn % 4]
                 if buf is None or buf.size < need:
-                    buf = ring[turn % 4] = empty((need + need // 16 + (1 << 16),), np.uint8)
+                    buf = ring[turn % 4] = (eng.pinned.empty if eng is not None else np.empty)((need + need // 16 + (1 << 16),), np.uint8)
                 turn += 1
                 t0 = time.perf_counter()
                 if eng is not None:
@@ -137,13 +150,18 @@ def _text_blocks(reader, block_bytes, n_threads=0):
                     if h:
                         buf[:h] = np.frombuffer(blk.head, dtype=np.uint8)
                     info["inflate_kernel_ms"] += eng.inflate_members(blk.comp, blk.tab, buf[h:need])
+                    info["blocks_inflated_on_device"] += 1
+                    info["device_inflate"] = True
                     blk = buf[:len(blk)]
                 else:
                     blk = blk.inflate_into(buf, None, n_threads)
                 info["inflate_s"] += time.perf_counter() - t0
             yield blk
     finally:
+        if maker is not None:
+            maker.join()
         _text_blocks.last_info = info             # (the engine lives on: the parser may still be reading the last block in its memory)
+        _text_blocks.engine = made.get("engine")
 
 
 def _read_ahead(blocks, depth=2):

@@ -117,9 +117,10 @@ def main():
             ("vcf.gz -> geno.gz, members inflated by the host threads (PG_BGZF_DEVICE=0)", bgz, os.path.join(tmp, "o1h.geno.gz"), [], {"PG_BGZF_DEVICE": "0"}),
             ("vcf -> geno", vcf, os.path.join(tmp, "o2.geno"), [], {}),
             ("vcf.gz -> pgeno (raw cells)", bgz, None, ["--packed", os.path.join(tmp, "o3.pgeno"), "--packedCodec", "none"], {})]
-    for name, src, dst, extra, env in legs:
+    only = [int(x) for x in os.environ.get("VCF_LEGS", "0,1,2,3").split(",")]
+    for name, src, dst, extra, env in [legs[k] for k in only]:
         best, binfo = None, {}
-        for _ in range(3):
+        for _ in range(int(os.environ.get("VCF_REPS", "3"))):
             info = {}
             dt = timed([sys.executable, shim, "-i", src] + (["-o", dst] if dst else []) + opts + extra, env=env, info=info)
             if best is None or dt < best:
@@ -127,10 +128,12 @@ def main():
         res["legs"][name] = {"seconds": round(best, 3), "sites_per_sec": round(n_sites / best), "vcf_text_MBps": round(size / best / 1e6, 1),
                              "timing": binfo}
     import gzip as _gz
-    with _gz.open(os.path.join(tmp, "o1.geno.gz"), "rb") as f1, _gz.open(os.path.join(tmp, "o1h.geno.gz"), "rb") as f2, open(os.path.join(tmp, "o2.geno"), "rb") as f3:
-        t1 = f1.read()
-        res["outputs_of_the_legs_identical"] = bool(t1 == f2.read() and t1 == f3.read())
-        res["geno_text_bytes"] = len(t1)
+    if only == [0, 1, 2, 3]:
+        with _gz.open(os.path.join(tmp, "o1.geno.gz"), "rb") as f1, _gz.open(os.path.join(tmp, "o1h.geno.gz"), "rb") as f2, \
+                open(os.path.join(tmp, "o2.geno"), "rb") as f3:
+            t1 = f1.read()
+            res["outputs_of_the_legs_identical"] = bool(t1 == f2.read() and t1 == f3.read())
+            res["geno_text_bytes"] = len(t1)
     if os.path.exists(REF) and ref_sites:
         head = os.path.join(tmp, "head.vcf")
         with open(vcf, "rb") as f, open(head, "wb") as g:
