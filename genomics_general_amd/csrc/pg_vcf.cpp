@@ -28,6 +28,25 @@ struct WsTable {
 const WsTable WS;
 inline bool ws(char c) { return WS.is[(unsigned char)c]; }
 
+// the end of the token that starts at p: eight bytes at a time (a byte below 0x21 raises its top bit in `m`; the lowest raised bit
+// is exact, borrows only travel upwards), the table decides whether that byte is one of str.split()'s separators
+inline const char *token_end(const char *p, const char *e) {
+    while (p + 8 <= e) {
+        uint64_t x;
+        memcpy(&x, p, 8);
+        const uint64_t m = (x - 0x2121212121212121ull) & ~x & 0x8080808080808080ull;
+        if (m) {
+            p += __builtin_ctzll(m) >> 3;
+            if (ws(*p)) return p;
+            ++p;
+            continue;
+        }
+        p += 8;
+    }
+    while (p < e && !ws(*p)) ++p;
+    return p;
+}
+
 // str.split(): tokens separated by runs of whitespace
 int split_ws(const char *b, const char *e, Tok *out, int cap) {
     int n = 0;
@@ -36,9 +55,10 @@ int split_ws(const char *b, const char *e, Tok *out, int cap) {
         while (p < e && ws(*p)) ++p;
         if (p >= e) break;
         const char *s = p;
-        while (p < e && !ws(*p)) ++p;
+        p = token_end(p, e);
         if (n < cap) { out[n].p = s; out[n].n = (int)(p - s); }
         ++n;
+        if (n >= cap && cap <= 6) break;                    // (the counting pass wants the first columns only)
     }
     return n;
 }
@@ -56,6 +76,34 @@ bool colon_piece(const Tok &t, int k, Tok *out) {
     const char *q = static_cast<const char *>(memchr(p, ':', (size_t)(e - p)));
     out->p = p;
     out->n = (int)((q ? q : e) - p);
+    return true;
+}
+
+// the offsets of a sample column's first 16 ':' (one pass, eight bytes at a time), and its k-th piece from them
+struct CellCols { int n; int at[16]; };
+inline void cell_cols(const Tok &c, CellCols *cc) {
+    int n = 0, i = 0;
+    for (; i + 8 <= c.n && n < 16; i += 8) {
+        uint64_t x;
+        memcpy(&x, c.p + i, 8);
+        const uint64_t y = x ^ 0x3a3a3a3a3a3a3a3aull;                                       // ':' -> 0
+        uint64_t m = ~(((y & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | y | 0x7f7f7f7f7f7f7f7full);   // 0x80 in every zero byte, exactly
+        while (m && n < 16) {
+            cc->at[n++] = i + (__builtin_ctzll(m) >> 3);
+            m &= m - 1;
+        }
+    }
+    for (; i < c.n && n < 16; ++i)
+        if (c.p[i] == ':') cc->at[n++] = i;
+    cc->n = n;
+}
+inline bool cell_piece(const Tok &c, const CellCols &cc, int k, Tok *out) {
+    if (k >= 16) return colon_piece(c, k, out);                 // (beyond what cc holds)
+    if (k > cc.n) return false;
+    const int a = k ? cc.at[k - 1] + 1 : 0;
+    const int b = k < cc.n ? cc.at[k] : c.n;
+    out->p = c.p + a;
+    out->n = b - a;
     return true;
 }
 
@@ -179,6 +227,8 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
     std::vector<Tok> alt;
     std::vector<int> fidx((size_t)sh.n_filters + 1), flag_len((size_t)sh.n_filters + 1);
     for (int f = 0; f < sh.n_filters; ++f) flag_len[f] = (int)strlen(sh.filters[f].flag);
+    bool any_gt_types = false;
+    for (int f = 0; f < sh.n_filters; ++f) any_gt_types = any_gt_types || sh.filters[f].gt_types != 0;
     long long kept = 0;
     while (b < e && !sh.err.load(std::memory_order_relaxed)) {
         const char *nl = static_cast<const char *>(memchr(b, '\n', (size_t)(e - b)));
@@ -195,12 +245,13 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
                 b = le + 1;
                 continue;
             }
-            nt = split_ws(b, le, tk.data(), need + 1);
+            nt = split_ws(b, le, tk.data(), 6);
             if (nt < 6) { set_err(sh, "VCF line with fewer than 6 columns", nullptr, nullptr); return kept; }
             const bool keep = site_kept(sh, tk.data(), nt, &prev_chrom, &prev_pos);
             prev_chrom = tk[0];
             prev_pos = tk[1];
             if (keep) {
+                nt = split_ws(b, le, tk.data(), need + 1);
                 const Tok *t = tk.data();
                 if (nt < need) { set_err(sh, "VCF line has fewer columns than the #CHROM header", &t[0], &t[1]); return kept; }
                 if (row >= sh.cap) { set_err(sh, "more sites than output capacity", nullptr, nullptr); return kept; }
@@ -251,7 +302,19 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
                     const Tok &cell = t[9 + sh.sel_col[s]];
                     const int ploidy = sh.sel_ploidy[s];
                     Tok gt = {nullptr, 0};
-                    if (gt_idx < 0 || !colon_piece(cell, gt_idx, &gt)) {
+                    CellCols cc;
+                    bool has_gt;
+                    if (gt_idx == 0 && sh.n_filters == 0) {              // only the first piece is looked at
+                        const char *q = static_cast<const char *>(memchr(cell.p, ':', (size_t)cell.n));
+                        gt.p = cell.p;
+                        gt.n = q ? (int)(q - cell.p) : cell.n;
+                        has_gt = true;
+                        cc.n = 0;
+                    } else {
+                        cell_cols(cell, &cc);
+                        has_gt = gt_idx >= 0 && cell_piece(cell, cc, gt_idx, &gt);
+                    }
+                    if (!has_gt) {
                         set_err(sh, "genotype without a GT field (the reference raises KeyError here)", &t[0], &t[1]);
                         return kept;
                     }
@@ -259,7 +322,12 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
                     Tok al[4];
                     int na = 0;
                     bool phased = false;
-                    {
+                    if (gt.n == 3 && (gt.p[1] == '/' || gt.p[1] == '|') && gt.p[0] != '/' && gt.p[0] != '|' && gt.p[2] != '/' && gt.p[2] != '|') {
+                        al[0].p = gt.p; al[0].n = 1;                     // the usual spelling: two one-character alleles
+                        al[1].p = gt.p + 2; al[1].n = 1;
+                        na = 2;
+                        phased = gt.p[1] == '|';
+                    } else {
                         const char *p = gt.p, *pe = p + gt.n, *s0 = p;
                         for (;; ++p) {
                             if (p == pe || *p == '/' || *p == '|') {
@@ -273,8 +341,8 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
                     }
                     op[s] = phased ? '|' : '/';
                     // GTtype (parseVCF.py:13-18) for the gtTypes selector of the genotype filters
-                    int gt_type;
-                    {
+                    int gt_type = 0;
+                    if (any_gt_types) {
                         bool distinct = false, has0 = false, hasdot = false;
                         for (int i = 0; i < na && i < 4; ++i) {
                             if (i && !(al[i].n == al[0].n && memcmp(al[i].p, al[0].p, (size_t)al[0].n) == 0)) distinct = true;
@@ -291,7 +359,7 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
                         if (F.samples && !F.samples[s]) continue;
                         const int fi = fidx[f];
                         Tok v;
-                        if (fi < 0 || !colon_piece(cell, fi, &v)) { passed = false; break; }
+                        if (fi < 0 || !cell_piece(cell, cc, fi, &v)) { passed = false; break; }
                         // np.array(value.split(","), dtype=float): every piece must parse and lie in [min, max]
                         const char *p = v.p, *pe = p + v.n;
                         for (;;) {

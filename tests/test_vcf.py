@@ -197,3 +197,32 @@ def test_render_rows_equals_the_line_by_line_rendering(seed):
         bad[int(np.flatnonzero(rflag)[0]), 0] = 100                             # an index that names no allele
         assert L.pg_vcf_render_rows(buf, k, n_sel, vp(pl), vp(chars), vp(bad), vp(phase), vp(rflag), vp(pos), vp(coff), vp(clen), vp(roff),
                                     vp(rlen), vp(aoff), vp(alen), C.c_char(b"\t"), C.c_char(b"N"), 0, None, 0, C.byref(size), 1) < 0
+
+
+def test_filter_on_a_format_field_beyond_the_sixteenth_colon(tmp_path):
+    """the parser keeps the offsets of a cell's first 16 ':'; a --gtf flag further back takes the general route: the same rows as with
+    the field moved to the front of FORMAT"""
+    rng = np.random.default_rng(12)
+    pad = ["F%02d" % k for k in range(17)]
+    lines_far, lines_near = [], []
+    head = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\tb\tc\n"
+    for i in range(300):
+        far, near = [], []
+        for s in range(3):
+            gt = ["0/0", "0/1", "1|1", "./.", "1/0"][int(rng.integers(0, 5))]
+            dp = str(int(rng.integers(0, 30)))
+            junk = [str(int(rng.integers(0, 9))) for _ in pad]
+            far.append(":".join([gt] + junk + [dp]))
+            near.append(":".join([gt, dp] + junk))
+        pre = "chr1\t%d\t.\tA\tC\t50\tPASS\t.\t" % (i + 1)
+        lines_far.append(pre + ":".join(["GT"] + pad + ["DP"]) + "\t" + "\t".join(far))
+        lines_near.append(pre + ":".join(["GT", "DP"] + pad) + "\t" + "\t".join(near))
+    outs = []
+    for tag, lines in (("far", lines_far), ("near", lines_near)):
+        src, out = str(tmp_path / (tag + ".vcf")), str(tmp_path / (tag + ".geno"))
+        with open(src, "w") as f:
+            f.write(head + "\n".join(lines) + "\n")
+        assert vcf.parse_vcf_main(["-i", src, "-o", out, "--gtf", "flag=DP", "min=10"]) in (0, None)
+        with open(out, "rb") as f:
+            outs.append(f.read())
+    assert outs[0] == outs[1] and outs[0].count(b"N/N") > 100 and outs[0].count(b"\n") == 301
