@@ -158,6 +158,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     if (c->up_ev) (void)hipEventDestroy(c->up_ev);
     for (int t = 0; t < PG_TOK_WORKERS; ++t) {
         if (c->tok_st[t]) (void)hipStreamDestroy(c->tok_st[t]);
+        if (t == 0 && c->tok_small) (void)hipStreamDestroy(c->tok_small);
         for (int k = 0; k < 2; ++k)
             if (c->tok_wev[t][k]) (void)hipEventDestroy(c->tok_wev[t][k]);
     }
@@ -173,6 +174,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
         if (k == 0) drop(c->inf);
         if (T.counted) (void)hipEventDestroy(T.counted);
         if (T.staged) (void)hipEventDestroy(T.staged);
+        if (T.parsed) (void)hipEventDestroy(T.parsed);
     }
     c->tok_pin.release();
     drop_events(c);

@@ -135,13 +135,14 @@ struct pg_ctx {
         HostPin<int64_t> h_pos;
         HostPin<int32_t> h_cols;
         std::vector<int32_t> cols;         // col_slot | col_ploidy | cell offsets | cell widths of the submitted block
-        hipEvent_t counted = nullptr, staged = nullptr;   // line feeds counted / deflated bytes on the device
+        hipEvent_t counted = nullptr, staged = nullptr, parsed = nullptr;   // line feeds counted / deflated bytes on the device / rows, positions, status there
         int state = 0;                     // 0 idle, 1 empty block, 2 submitted, 3 parse queued, 4 empty result
         int fmt = 0, n_cols = 0, max_ploidy = 0, cells_w = 0;
         int64_t len = 0, n_lines = 0, n_tiles = 0, run_cap = 0;
     } tok[2];
     HostPin<uint8_t> tok_pin;                              // two 4 MiB page-locked buffers per staging thread
     hipStream_t tok_st[PG_TOK_WORKERS] = {};               // one copy stream per staging thread
+    hipStream_t tok_small = nullptr;                       // the collect step's few kilobytes (beside the next block's inflate on stream_up)
     hipEvent_t tok_wev[PG_TOK_WORKERS][2] = {};
     double tok_stage_s = 0, tok_kernel_s = 0;              // pg_tokenize_stats: wall seconds of the copies / of everything behind them
     int64_t tok_bytes = 0;

@@ -908,6 +908,8 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(T.h_total.p + 1, d_status, 8, hipMemcpyDeviceToHost, st));            // status | runs, as two int32
     HIPCHK(hipMemcpyAsync(T.h_pos.p, T.pos64.p, (size_t)n_lines * 8, hipMemcpyDeviceToHost, st));
+    if (!T.parsed) HIPCHK(hipEventCreateWithFlags(&T.parsed, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(T.parsed, st));                            // (collect waits for THIS, not for what the next block has queued behind it)
     T.state = 3;
     *ok_out = 1;
     c->tok_kernel_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -932,8 +934,12 @@ static int tok_collect(pg_ctx *c, int slot, int64_t *pos_out, int64_t pos_capaci
         ~Clock() { c->tok_kernel_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
     } clock{c, t0};
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t st = c->stream_up;
-    HIPCHK(hipStreamSynchronize(st));
+    // the block's own work only: the next block's copy, inflate and line count are already queued behind it on the same stream and
+    // go on while the host turns this block into windows
+    if (T.parsed) HIPCHK(hipEventSynchronize(T.parsed));
+    else HIPCHK(hipStreamSynchronize(c->stream_up));
+    if (!c->tok_small) HIPCHK(hipStreamCreateWithFlags(&c->tok_small, hipStreamNonBlocking));
+    hipStream_t st = c->tok_small;
     const int64_t n_lines = T.n_lines;
     if (!pos_out || !run_row_out || !run_off_out || !run_len_out || pos_capacity < n_lines)
         return pg_fail(PG_ERR_ARG, "pg_tokenize_collect: outputs too small for %lld rows", (long long)n_lines);
@@ -1039,7 +1045,9 @@ extern "C" int pg_tokenize_run_names(pg_ctx *c, int slot, const int64_t *run_off
     if (total > out_capacity) return pg_fail(PG_ERR_ARG, "pg_tokenize_run_names: %lld bytes of names, room for %lld", (long long)total, (long long)out_capacity);
     if (total == 0) return PG_OK;
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t st = c->stream_up;
+    // (the block has been collected: its text is complete; the small stream, so that this does not wait for the next block's inflate)
+    if (!c->tok_small) HIPCHK(hipStreamCreateWithFlags(&c->tok_small, hipStreamNonBlocking));
+    hipStream_t st = c->tok_small;
     int rc;
     const size_t len_words = ((size_t)n_runs * 4 + 7) / 8;           // the int32 lengths ride behind the offsets
     if ((rc = T.names_idx.ensure((size_t)n_runs * 2 + len_words)) != PG_OK) return rc;
