@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""Tier T2 at the size of the north star, in the reference's default input format: ALL 1e8 sites x 200 diploids of the workload as ONE
+bgzipped `.geno.gz` (81 GB of text, ~3.2 GB on disk; 4 scaffolds of 2.5e7 sites) through the drop-in popgenWindows.py -- members
+inflated on the device, text tokenised where it lies, 2000 windows of 50 kb -- and every cell of its CSV compared with the statistics
+computed from the device-resident rows the file was written from (tier T0).
+
+    python tools/t2_northstar_bgzf.py [n_sites] [reps]        -> one JSON line
+
+The text itself is never on disk: pieces of 250 000 rows are rendered from the resident rows and deflated (pg_bgzf_compress, members of
+65 280 bytes of text like bgzip's) one after the other.  bench.py's `t2.bgzf` leg is the same run on the first 2.5e7 sites."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                                                   # noqa: E402
+from genomics_general_amd import genoio, synth                                 # noqa: E402
+from genomics_general_amd.engine import Engine                                 # noqa: E402
+from genomics_general_amd.samples import HapLayout, SampleData                 # noqa: E402
+
+
+def write_bgzf_resident(path, eng, lay, names, n_rows, scaf_len):
+    """rows 0 .. n_rows of the engine as bgzipped `.geno` text: scaffold chr<k+1> holds rows k * scaf_len ..., positions 1 .."""
+    n = len(names)
+    s0 = np.array([lay.ind_slots[nm][0] for nm in names])
+    tasks, a = [], 0
+    while a < n_rows:
+        k, r = divmod(a, scaf_len)
+        nd = len(str(r + 1))
+        b = min(n_rows, a + 250_000, (k + 1) * scaf_len, k * scaf_len + 10 ** nd - 1)
+        tasks.append((a, b, k, r, nd))
+        a = b
+    lock = threading.Lock()
+
+    def render(task):
+        a, b, k, r, nd = task
+        head = ("chr%d\t" % (k + 1)).encode()
+        with lock:
+            rows = eng.download(a, b - a)
+        letters = synth.codes_to_letters(rows)
+        line = np.empty((b - a, len(head) + nd + 1 + 4 * n), dtype=np.uint8)
+        line[:, :len(head)] = np.frombuffer(head, dtype=np.uint8)
+        pos = np.arange(r + 1, r + 1 + (b - a), dtype=np.int64)
+        for d in range(nd):
+            line[:, len(head) + nd - 1 - d] = (pos // 10 ** d % 10 + ord("0")).astype(np.uint8)
+        line[:, len(head) + nd] = ord("\t")
+        cell = line[:, len(head) + nd + 1:].reshape(b - a, n, 4)
+        cell[:, :, 0] = letters[:, s0]
+        cell[:, :, 1] = ord("/")
+        cell[:, :, 2] = letters[:, s0 + 1]
+        cell[:, :, 3] = ord("\t")
+        cell[:, -1, 3] = ord("\n")
+        return line.reshape(-1)
+
+    text_bytes = 0
+    with open(path, "wb") as f, ThreadPoolExecutor(6) as ex:
+        hdr = ("#CHROM\tPOS\t" + "\t".join(names) + "\n").encode()
+        f.write(memoryview(genoio.bgzf_compress(hdr, 6, eof_marker=False)))
+        text_bytes += len(hdr)
+        ahead, it = [], iter(tasks)
+        for t in it:
+            ahead.append(ex.submit(render, t))
+            if len(ahead) >= 6:
+                break
+        while ahead:
+            piece = ahead.pop(0).result()
+            nxt = next(it, None)
+            if nxt is not None:
+                ahead.append(ex.submit(render, nxt))
+            text_bytes += piece.size
+            f.write(memoryview(genoio.bgzf_compress(piece, 6, eof_marker=False)))
+            del piece
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return text_bytes, os.path.getsize(path)
+
+
+def main():
+    wl = bench.WORKLOADS["northstar"]
+    n_sites = int(sys.argv[1]) if len(sys.argv) > 1 else wl["n_sites"]
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    n_dip, wind = wl["n_dip"], wl["wind"]
+    scaf_len = int(os.environ.get("PG_NS_SCAF_LEN", wl["n_sites"] // wl["n_scaf"]))       # (a small value: a quick check of the tool itself)
+    n_sites = n_sites // wind * wind
+    names = ["s%d" % d for d in range(n_dip)]
+    per = n_dip // wl["n_pops"]
+    sd = SampleData(popNames=["pop%d" % k for k in range(wl["n_pops"])], popInds=[names[k * per:(k + 1) * per] for k in range(wl["n_pops"])])
+    lay = HapLayout(sd, names, "phased")
+    slot_gen = np.array([2 * names.index(nm) + k for nm in lay.ind_order for k in range(2)], dtype=np.int32)
+    e = Engine(0)
+    e.set_layout(lay)
+    e.reserve(n_sites)
+    e.synth_fill(0, n_sites, 0, synth.SEED_DEFAULT, wl["n_sites"], n_dip, wl["n_pops"], slot_gen, synth.VAR_THR, synth.MISS_THR)
+    lo = np.arange(0, n_sites, wind, dtype=np.int64)
+    t0 = time.perf_counter()
+    table, cols = e.batch(lo, lo + wind).groupDistTable(True, wl["min_sites"], 0.01)
+    e.sync()
+    t0_s = time.perf_counter() - t0
+    table = np.array(table, copy=True)
+    tmp = tempfile.mkdtemp(prefix="pg_northstar_", dir=os.environ.get("PG_BENCH_TMP", "/tmp"))
+    gz, csv = os.path.join(tmp, "northstar.geno.gz"), os.path.join(tmp, "out.csv")
+    w0 = time.perf_counter()
+    text_bytes, file_bytes = write_bgzf_resident(gz, e, lay, names, n_sites, scaf_len)
+    write_s = time.perf_counter() - w0
+    e.close()
+    cmd = [sys.executable, os.path.join(ROOT, "popgenWindows.py"), "-g", gz, "-o", csv, "-f", "phased", "-w", str(wind), "-m", str(wl["min_sites"]),
+           "--roundTo", "12"]
+    for k, p in enumerate(sd.popNames):
+        cmd += ["-p", p, ",".join(names[k * per:(k + 1) * per])]
+    runs = []
+    for _ in range(reps):
+        w0 = time.perf_counter()
+        r = subprocess.run(cmd, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE, timeout=1200)
+        wall = time.perf_counter() - w0
+        line = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")]
+        if r.returncode != 0 or not line:
+            raise SystemExit("popgenWindows.py failed:\n" + r.stderr.decode()[-2000:])
+        tm = json.loads(line[-1][len("PG_TIMING "):])
+        runs.append({"total_s": round(tm["total_s"], 4), "context_s": round(tm.get("context_s", 0.0), 4), "process_wall_s": round(wall, 3),
+                     "tokenize_s": round(tm.get("tokenize_s", 0.0), 4), "tokenizer_kernels_s": round(tm.get("tokenizer_kernels_s", 0.0), 4),
+                     "prep_wait_s": round(tm.get("prep_wait_s", 0.0), 4), "main_stats_s": round(tm.get("main_stats_s", 0.0), 4),
+                     "main_format_s": round(tm.get("main_format_s", 0.0), 4), "chunks": tm.get("chunks"),
+                     "bgzf_blocks_inflated_on_device": tm.get("bgzf_blocks_inflated_on_device"), "host_tokenized_blocks": tm.get("host_tokenized_blocks")})
+    with open(csv) as f:
+        rows = [ln.strip().split(",") for ln in f.readlines()]
+    head, rows = rows[0], rows[1:]
+    same = len(rows) == len(lo)
+    worst = 0.0
+    for w, row in enumerate(rows):
+        k, r = divmod(w * wind, scaf_len)
+        same = same and row[0] == "chr%d" % (k + 1) and int(row[1]) == r + 1 and int(row[2]) == r + wind and int(row[4]) == wind
+        for name, v in zip(head[5:], row[5:]):
+            g = table[w, cols.index(name)]
+            v = float(v)
+            if g != g or v != v:
+                same = same and (g != g and v != v)
+            else:
+                err = abs(v - g) / max(1.0, abs(g))
+                worst = max(worst, err)
+                same = same and err <= 1e-9
+    best = min(runs, key=lambda x: x["total_s"])
+    out = {"workload": "north star, whole: %d sites x %d diploids, %d scaffolds, %d windows of %d sites" % (n_sites, n_dip, -(-n_sites // scaf_len), len(lo), wind),
+           "input": "one `.geno.gz` written as BGZF (members of 65 280 bytes of text, level 6)", "text_bytes": text_bytes, "file_bytes": file_bytes,
+           "deflate_ratio": round(text_bytes / file_bytes, 1), "written_in_s": round(write_s, 1),
+           "runs": runs, "best": {"total_s": best["total_s"], "windows_per_sec": round(len(lo) / best["total_s"], 1),
+                                  "sites_per_sec": round(n_sites / best["total_s"], 1), "text_GBps": round(text_bytes / best["total_s"] / 1e9, 2),
+                                  "text_GBps_without_context": round(text_bytes / (best["total_s"] - best["context_s"]) / 1e9, 2)},
+           "csv_matches_t0": bool(same), "largest_relative_difference": worst, "compared_cells": len(rows) * (len(head) - 5),
+           "t0_pass_over_the_resident_rows_s": round(t0_s, 4),
+           "note": "total_s: inside the driver, from opening the input to the last row written (PG_TIMING); every float cell of the CSV (--roundTo 12) "
+                   "against the statistics of the resident rows (1e-9 relative); scaffold, start, end and sites of every row exact"}
+    print(json.dumps(out))
+    for fn in os.listdir(tmp):
+        os.remove(os.path.join(tmp, fn))
+    os.rmdir(tmp)
+
+
+if __name__ == "__main__":
+    main()
