@@ -102,6 +102,11 @@ class _AsyncOut:
         if self.err is not None:
             raise self.err
 
+    def abort(self):
+        self.err = self.err or RuntimeError("aborted")        # (what is still queued is not written)
+        self.q.put(None)
+        self.th.join()
+
 
 def _text_blocks(reader, block_bytes, n_threads=0):
     """the input's text in blocks of whole lines.  A bgzip-compressed VCF (what `bgzip` / GATK / bcftools write) is read as spans of
@@ -598,59 +603,69 @@ def parse_vcf_main(argv=None):
 
     vp = lambda a: C.c_void_p(a.ctypes.data)
     t0 = time.perf_counter()
-    for body in _read_ahead(_text_blocks(reader, block_bytes, int(args.threads))):
-        t0 = lap("wait_for_block_s", t0)
-        ptr, nbytes, keep = _lib.text_ptr(body)
-        nl = C.c_int64(0)
-        check(L.pg_count_lines(ptr, nbytes, C.byref(nl)))
-        cap = int(nl.value) + 1
-        chars = arr("chars", (cap, 2 * n_sel), np.uint8)
-        aidx = arr("aidx", (cap, 2 * n_sel), np.int8)
-        phase = arr("phase", (cap, n_sel), np.uint8)
-        rflag = arr("rflag", (cap,), np.uint8)
-        pos = arr("pos", (cap,), np.int64)
-        coff, roff, aoff = arr("coff", (cap,), np.int64), arr("roff", (cap,), np.int64), arr("aoff", (cap,), np.int64)
-        clen, rlen, alen = arr("clen", (cap,), np.int32), arr("rlen", (cap,), np.int32), arr("alen", (cap,), np.int32)
-        n, nmb = C.c_int64(0), C.c_int64(0)
-        check(fn(ptr, C.c_size_t(nbytes), len(vcf_samples), n_sel, vp(sel_col), vp(pl),
-                 flags, C.c_double(float(args.minQual or 0)), int(args.maxREFlen or 0), Farr, len(gtf),
-                 C.c_char_p(contigs), len(contigs), contig_mode, C.c_char(missing.encode()),
-                 C.c_char_p(prev_chrom), len(prev_chrom or b""), C.c_char_p(prev_pos), len(prev_pos or b""),
-                 vp(chars), vp(aidx), vp(phase), vp(rflag), vp(pos), vp(coff), vp(clen), vp(roff), vp(rlen), vp(aoff), vp(alen),
-                 C.c_int64(cap), C.byref(n), C.byref(nmb), int(args.threads)))
-        t0 = lap("parse_s", t0)
-        k = int(n.value)
-        n_multibase_total += int(nmb.value)
-        pc, pp = _last_key(body)
-        if pc is not None:
-            prev_chrom, prev_pos = pc, pp
-        if k == 0:
+    try:
+        for body in _read_ahead(_text_blocks(reader, block_bytes, int(args.threads))):
+            t0 = lap("wait_for_block_s", t0)
+            ptr, nbytes, keep = _lib.text_ptr(body)
+            nl = C.c_int64(0)
+            check(L.pg_count_lines(ptr, nbytes, C.byref(nl)))
+            cap = int(nl.value) + 1
+            chars = arr("chars", (cap, 2 * n_sel), np.uint8)
+            aidx = arr("aidx", (cap, 2 * n_sel), np.int8)
+            phase = arr("phase", (cap, n_sel), np.uint8)
+            rflag = arr("rflag", (cap,), np.uint8)
+            pos = arr("pos", (cap,), np.int64)
+            coff, roff, aoff = arr("coff", (cap,), np.int64), arr("roff", (cap,), np.int64), arr("aoff", (cap,), np.int64)
+            clen, rlen, alen = arr("clen", (cap,), np.int32), arr("rlen", (cap,), np.int32), arr("alen", (cap,), np.int32)
+            n, nmb = C.c_int64(0), C.c_int64(0)
+            check(fn(ptr, C.c_size_t(nbytes), len(vcf_samples), n_sel, vp(sel_col), vp(pl),
+                     flags, C.c_double(float(args.minQual or 0)), int(args.maxREFlen or 0), Farr, len(gtf),
+                     C.c_char_p(contigs), len(contigs), contig_mode, C.c_char(missing.encode()),
+                     C.c_char_p(prev_chrom), len(prev_chrom or b""), C.c_char_p(prev_pos), len(prev_pos or b""),
+                     vp(chars), vp(aidx), vp(phase), vp(rflag), vp(pos), vp(coff), vp(clen), vp(roff), vp(rlen), vp(aoff), vp(alen),
+                     C.c_int64(cap), C.byref(n), C.byref(nmb), int(args.threads)))
+            t0 = lap("parse_s", t0)
+            k = int(n.value)
+            n_multibase_total += int(nmb.value)
+            pc, pp = _last_key(body)
+            if pc is not None:
+                prev_chrom, prev_pos = pc, pp
+            if k == 0:
+                del keep, body
+                t0 = time.perf_counter()
+                continue
+            if sink is not None:
+                # the rows as text (pg_vcf_render_rows: a sizing call, then the bytes)
+                size = C.c_int64(0)
+                rargs = (ptr, k, n_sel, vp(pl), vp(chars), vp(aidx), vp(phase), vp(rflag), vp(pos), vp(coff), vp(clen), vp(roff), vp(rlen),
+                         vp(aoff), vp(alen), C.c_char(sep), C.c_char(missing.encode()), 1 if args.addRefTrack else 0)
+                check(L.pg_vcf_render_rows(*rargs, None, 0, C.byref(size), int(args.threads)))
+                text = np.empty(size.value, dtype=np.uint8)
+                check(L.pg_vcf_render_rows(*rargs, vp(text), size.value, C.byref(size), int(args.threads)))
+                t0 = lap("render_s", t0)
+                sink.write(text)
+                t0 = lap("wait_for_writer_s", t0)
+            if packer is not None:
+                # scaffold runs of the kept rows (names are read once per run)
+                starts = np.zeros(k, dtype=np.int64)
+                nr = C.c_int64(0)
+                check(L.pg_scaffold_runs(ptr, coff, clen, k, starts, k, C.byref(nr)))
+                starts = starts[:nr.value]
+                run_names = [bytes(body[int(coff[i]):int(coff[i]) + int(clen[i])]) for i in starts]
+                cells = lut[chars[:k, 0::2]] | (lut[chars[:k, 1::2]] << 4)
+                packer.write_block(genoio.GenoData(None, pos[:k].copy(), starts.copy(), [nm.decode("utf-8", "replace") for nm in run_names]), cells)
+                t0 = lap("pack_s", t0)
             del keep, body
             t0 = time.perf_counter()
-            continue
-        if sink is not None:
-            # the rows as text (pg_vcf_render_rows: a sizing call, then the bytes)
-            size = C.c_int64(0)
-            rargs = (ptr, k, n_sel, vp(pl), vp(chars), vp(aidx), vp(phase), vp(rflag), vp(pos), vp(coff), vp(clen), vp(roff), vp(rlen),
-                     vp(aoff), vp(alen), C.c_char(sep), C.c_char(missing.encode()), 1 if args.addRefTrack else 0)
-            check(L.pg_vcf_render_rows(*rargs, None, 0, C.byref(size), int(args.threads)))
-            text = np.empty(size.value, dtype=np.uint8)
-            check(L.pg_vcf_render_rows(*rargs, vp(text), size.value, C.byref(size), int(args.threads)))
-            t0 = lap("render_s", t0)
-            sink.write(text)
-            t0 = lap("wait_for_writer_s", t0)
-        if packer is not None:
-            # scaffold runs of the kept rows (names are read once per run)
-            starts = np.zeros(k, dtype=np.int64)
-            nr = C.c_int64(0)
-            check(L.pg_scaffold_runs(ptr, coff, clen, k, starts, k, C.byref(nr)))
-            starts = starts[:nr.value]
-            run_names = [bytes(body[int(coff[i]):int(coff[i]) + int(clen[i])]) for i in starts]
-            cells = lut[chars[:k, 0::2]] | (lut[chars[:k, 1::2]] << 4)
-            packer.write_block(genoio.GenoData(None, pos[:k].copy(), starts.copy(), [nm.decode("utf-8", "replace") for nm in run_names]), cells)
-            t0 = lap("pack_s", t0)
-        del keep, body
-        t0 = time.perf_counter()
+    except BaseException:
+        if sink is not None:                    # (the writer thread ends, whatever it had queued is dropped with the failed run)
+            sink.abort()
+        if out is not None and out is not sys.stdout.buffer:
+            try:
+                out.close()
+            except Exception:
+                pass
+        raise
     if sink is not None:
         t0 = time.perf_counter()
         sink.close()
