@@ -691,6 +691,55 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
         except Exception as exc:
             t2.setdefault("bgzf", {"error": repr(exc)[:300]})
             t2.setdefault("gz", {"error": repr(exc)[:300]})
+        # the WHOLE workload in that format: every resident site as one bgzipped `.geno.gz` (the text itself is never on disk: pieces
+        # of 250 000 rows are rendered from the resident rows and deflated one after the other, before the clock starts) through
+        # popgenWindows.py, every cell of its CSV against the T0 table.  north star: 81 GB of text, 3.2 GB on disk, 2000 windows
+        try:
+            n_all = int(t0_table.shape[0]) * wind
+            need = n_all * (4 * len(names) + 16) // 20
+            if (os.environ.get("PG_BENCH_T2_WHOLE", "1") != "0" and n_all > n_txt and n_all % scaf_len == 0
+                    and shutil.disk_usage(tmp).free > 2 * need):
+                if os.path.join(ROOT, "tools") not in sys.path:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import t2_northstar_bgzf as whole
+                wgz, csv6 = os.path.join(tmp, "whole.geno.gz"), os.path.join(tmp, "out6.csv")
+                w0 = time.perf_counter()
+                wtext, wfile = whole.write_bgzf_resident(wgz, eng, lay, names, n_all, scaf_len)
+                wwrite_s = time.perf_counter() - w0
+                cmd6 = [wgz if c == geno else csv6 if c == csv else c for c in cmd]
+                runs6 = []
+                for _ in range(2):
+                    r6 = subprocess.run(cmd6, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1"), stderr=subprocess.PIPE,
+                                        stdout=subprocess.PIPE, timeout=600)
+                    line6 = [ln for ln in r6.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")]
+                    if not line6:
+                        raise RuntimeError("popgenWindows.py: " + r6.stderr.decode()[-300:])
+                    runs6.append(json.loads(line6[-1][len("PG_TIMING "):]))
+                tw = min(runs6, key=lambda x: x["total_s"])
+                with open(csv6) as f:
+                    rows6 = [ln.strip().split(",") for ln in f.readlines()]
+                head6, rows6 = rows6[0], rows6[1:]
+                same6 = len(rows6) == t0_table.shape[0]
+                for w, row in enumerate(rows6):
+                    k6, r6_ = divmod(w * wind, scaf_len)
+                    same6 = same6 and int(row[1]) == r6_ + 1 and int(row[2]) == r6_ + wind and int(row[4]) == wind
+                    for name, v in zip(head6[5:], row[5:]):
+                        g = t0_table[w, cols.index(name)]
+                        same6 = same6 and (abs(float(v) - g) <= 1e-9 * max(1.0, abs(g)) or (g != g and float(v) != float(v)))
+                workw = tw["total_s"] - tw.get("context_s", 0.0)
+                t2["bgzf_whole_workload"] = {
+                    "windows_per_sec": round(len(rows6) / tw["total_s"], 1), "sites_per_sec": round(n_all / tw["total_s"], 1),
+                    "text_GBps": round(wtext / tw["total_s"] / 1e9, 2), "seconds": [round(x["total_s"], 4) for x in runs6],
+                    "sites": n_all, "windows": len(rows6), "scaffolds": n_all // scaf_len, "text_bytes": wtext, "file_bytes": wfile,
+                    "matches_t0": bool(same6), "blocks_inflated_on_device": tw.get("bgzf_blocks_inflated_on_device", 0),
+                    "without_context_creation": {"seconds": round(workw, 4), "windows_per_sec": round(len(rows6) / workw, 1),
+                                                 "text_GBps": round(wtext / workw / 1e9, 2)},
+                    "sample": "ALL %d sites of the workload as one bgzipped `.geno.gz` (%.1f GB of text, %.2f GB on disk, written from the "
+                              "resident rows in %.0f s before the clock starts) through popgenWindows.py, timed inside the driver; every "
+                              "cell of the CSV against the T0 table (1e-9 relative)" % (n_all, wtext / 1e9, wfile / 1e9, wwrite_s)}
+                os.remove(wgz)
+        except Exception as exc:
+            t2["bgzf_whole_workload"] = {"error": repr(exc)[:300]}
         # the same file on TWO ranks (both on this GPU, so the rows travel through files and the ranks share one PCIe link: not a
         # scaling number): the drivers' multi-GPU plan at the size of real data -- every rank reads, tokenises and computes its
         # window range of the ONE scaffold, the gathered CSV is the single-rank one
@@ -1166,6 +1215,12 @@ def main():
                               "ratio_to_reference_equivalent": (round(t2["windows_per_sec"] / cpu["reference_calibration"]["reference_equivalent_windows_per_sec"], 1)
                                                                 if "reference_calibration" in cpu else None),
                               "note": "tier T2 (text in, CSV out, one GPU + its host threads) against the CPU baseline's whole path on every host core"}
+        whole = t2.get("bgzf_whole_workload") or {}
+        if whole.get("windows_per_sec"):                      # the whole workload as the reference's default input (`.geno.gz`)
+            extra["t2_vs_cpu"]["bgzf_whole_workload"] = {
+                "ratio": round(whole["windows_per_sec"] / cpu["value"], 1), "gpu_windows_per_sec": whole["windows_per_sec"],
+                "ratio_to_reference_equivalent": (round(whole["windows_per_sec"] / cpu["reference_calibration"]["reference_equivalent_windows_per_sec"], 1)
+                                                  if "reference_calibration" in cpu else None)}
     if world.rank == 0:
         total_windows = total_win * args.steps
         total_sites = total_sites_step * args.steps
