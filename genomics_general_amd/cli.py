@@ -1279,17 +1279,19 @@ def _quartet_main(argv, prog, stats, fourpop):
 # ==========================================================================================================
 def _matrix_text(M, names, fmt, roundTo):
     """genomics.py:2288-2306 makeDistMatString / PhylipString / NexusString."""
-    txt = M.round(roundTo).astype(str)
+    # (`.round(r).astype(str)` there: the shortest repr of every float64 -- what repr() of the Python float gives, an order of
+    # magnitude faster than NumPy's string cast)
+    txt = [" ".join(map(repr, row)) for row in M.round(roundTo).tolist()]
     n = len(names)
     if fmt == "raw":
-        return "\n".join(" ".join(r) for r in txt) + "\n"
+        return "\n".join(txt) + "\n"
     if fmt == "phylip":
-        return str(M.shape[0]) + "\n" + "".join(str(names[i]) + "  " + " ".join(txt[i]) + "\n" for i in range(n))
+        return str(M.shape[0]) + "\n" + "".join(str(names[i]) + "  " + txt[i] + "\n" for i in range(n))
     s = "\nBEGIN Taxa;\nDIMENSIONS ntax={};\nTAXLABELS\n".format(n)
     s += "".join("[{}] '{}'\n".format(i + 1, names[i]) for i in range(n))
     s += ";\nEND; [Taxa]\n"
     s += "\nBEGIN Distances;\nDIMENSIONS ntax={};\nFORMAT labels=left diagonal triangle=both;\nMATRIX\n".format(n)
-    s += "".join("[{}] '{}'    ".format(i + 1, names[i]) + " ".join(txt[i]) + "\n" for i in range(n))
+    s += "".join("[{}] '{}'    ".format(i + 1, names[i]) + txt[i] + "\n" for i in range(n))
     return s + ";\nEND; [Distances]\n"
 
 
@@ -1424,6 +1426,8 @@ def distmat_main(argv=None):
 # ==========================================================================================================
 @guarded_main
 def freq_main(argv=None):
+    import time as _time
+    t_begin = _time.perf_counter()                          # (PG_TIMING total_s: from here, the device context included)
     """Drop-in for the reference's freq.py (freq.py:30-113, 192-300): per-site per-population base counts, or the
     frequency / count of a target allele (`--target derived|minor`).  Counts come from k_site_counts (pg_site_counts).
     Divergence: for `--target minor` the reference breaks count ties with np.random.choice (genomics.py:664-669); here the
@@ -1525,7 +1529,21 @@ def freq_main(argv=None):
     # K0 on the device (default for text in a layout pg_tokenize_text takes; PG_GPU_TOKENIZER=0 keeps the host tokenizer)
     on_device = (os.environ.get("PG_GPU_TOKENIZER", "1") != "0" and hasattr(eng, "tokenize_text")
                  and not getattr(reader, "packed", False) and device_tokenizer_takes(layout))
-    stats = {"device_tokenizer": int(on_device), "host_tokenized_blocks": 0, "blocks": 0}
+    # bgzipped text: blocks arrive as spans of deflated members (in page-locked memory) and are inflated on the device
+    spans = (on_device and hasattr(eng, "tokenize_submit_bgzf") and hasattr(reader, "spans") and isinstance(getattr(reader, "f", None), genoio.BgzfFile)
+             and os.environ.get("PG_BGZF_DEVICE", "1") != "0" and not sharded)
+    if spans:
+        reader.spans = True
+        reader.f.alloc = eng.pinned.empty
+    stats = {"device_tokenizer": int(on_device), "bgzf_blocks_inflated_on_device": 0, "host_tokenized_blocks": 0, "blocks": 0, "sites": 0, "wait_for_block_s": 0.0, "tokenize_s": 0.0,
+             "counts_s": 0.0, "format_s": 0.0, "write_s": 0.0}
+    stats["context_s"] = round(_time.perf_counter() - t_begin, 4)      # (argument parsing, the input's header, the device context)
+    t_start = t_begin
+
+    def lap(key, t0):
+        t1 = _time.perf_counter()
+        stats[key] += t1 - t0
+        return t1
 
     def site_blocks():
         """(GenoData of an input block, run index of each of its rows, a, b) for sub-blocks [a,b) of at most CH sites.  The next
@@ -1552,7 +1570,9 @@ def freq_main(argv=None):
 
         threading.Thread(target=prepare, daemon=True, name="prepare").start()
         while True:
+            t0 = _time.perf_counter()
             data = ready.get()
+            t0 = lap("wait_for_block_s", t0)
             if data is None:
                 return
             if isinstance(data, BaseException):
@@ -1561,17 +1581,36 @@ def freq_main(argv=None):
             if on_device:
                 # K0 on the device: the rows are written where k_site_counts reads them, only positions and runs come back
                 body = data
-                ptr, nbytes, _keep = _lib.text_ptr(body)
-                cnt = C.c_int64(0)
-                _lib.check(L.pg_count_lines(ptr, nbytes, C.byref(cnt)))
-                eng.reserve(int(cnt.value))
-                got = eng.tokenize_text(body, row_offset=0, n_rows=int(cnt.value)) if cnt.value else None
+                got = None
+                if isinstance(body, genoio.BgzfSpan):
+                    # (a line of the regular layout: its cells + scaffold, position, two blanks; a bound of the rows, as in Run)
+                    f3 = body.first_line.split(None, 2)
+                    if len(f3) == 3 and not body.first_line.startswith(b"#"):
+                        bound = len(body) // (len(f3[2]) + 1 + 4) + 1
+                        eng.reserve(bound)
+                        if eng.tokenize_submit_bgzf(body, 0):
+                            n_lines = eng.tokenize_parse(0, 0, bound)
+                            got = eng.tokenize_collect(0, body, n_lines) if n_lines is not None else None
+                    if got is not None:
+                        stats["bgzf_blocks_inflated_on_device"] += 1
+                    else:
+                        body = bytes(body)                  # not the regular layout: inflated on the host, the routes below
+                if got is None:
+                    ptr, nbytes, _keep = _lib.text_ptr(body)
+                    cnt = C.c_int64(0)
+                    _lib.check(L.pg_count_lines(ptr, nbytes, C.byref(cnt)))
+                    eng.reserve(int(cnt.value))
+                    got = eng.tokenize_text(body, row_offset=0, n_rows=int(cnt.value)) if cnt.value else None
+                else:
+                    _keep = None
                 if got is not None:
                     data = genoio.GenoData(None, got[1], got[2], got[3])
                 else:                                       # a block the device tokenizer refuses: host tokenizer, one upload
                     data = reader.to_geno(body, layout, pitch=pitch, alloc=alloc)
                     stats["host_tokenized_blocks"] += 1
                 del body, _keep
+                lap("tokenize_s", t0)
+            stats["sites"] += data.n_sites
             run_of_row = np.repeat(np.arange(len(data.run_starts)), np.diff(np.append(data.run_starts, data.n_sites)))
             for a in range(0, data.n_sites, CH):
                 yield data, run_of_row, a, min(data.n_sites, a + CH)
@@ -1597,48 +1636,20 @@ def freq_main(argv=None):
             names_blob = b"".join(enc)
             name_off = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.int64)
             name_max, run0 = max([len(e) for e in enc] + [1]), 0
-        if data.gt is None:                                 # tokenised on the device: the block's rows are resident
-            cnt32 = eng.batch([0], [0]).siteCounts(a, b)                        # int32 [n][P][4]
-        else:
+        t0 = _time.perf_counter()
+        lo_, hi_ = (a, b) if data.gt is None else (0, b - a)  # tokenised on the device: the block's rows are resident
+        if data.gt is not None:
             load(data.gt[a:b])
-            cnt32 = eng.batch([0], [0]).siteCounts(0, b - a)
-        cnt = cnt32.astype(np.int64)
-        n = cnt.sum(axis=2)
         keep = None                                                           # uint8 mask of the rows that are written
         if not args.target:
-            mode, values = 0, np.ascontiguousarray(cnt32)
+            mode, values = 0, np.ascontiguousarray(eng.batch([0], [0]).siteCounts(lo_, hi_))           # int32 [n][P][4]
         else:
-            if args.target == "derived":                                        # derivedAllele, genomics.py:636-662
-                outc = cnt[:, P - 1, :] > 0
-                inc = cnt[:, :P - 1, :].sum(axis=1) > 0
-                ok = (outc.sum(axis=1) == 1) & (inc.sum(axis=1) == 2) & np.any(outc & inc, axis=1)
-                base = np.argmax(inc & ~outc, axis=1)
-            else:                                                               # minorAllele, genomics.py:664-669
-                tot = cnt.sum(axis=1)
-                ok = (tot > 0).sum(axis=1) == 2
-                masked = np.where(tot > 0, tot, np.iinfo(np.int64).max)
-                base = np.argmin(masked, axis=1)
-            cols = []
-            for q in range(P):
-                good = ok & (n[:, q] >= minData)                                # freq.py:80: the COUNT is compared
-                tf = np.zeros(b - a, dtype=int) if asCounts else np.full(b - a, np.nan)
-                idx = np.where(good)[0]
-                if len(idx):
-                    c = cnt[idx, q, base[idx]]
-                    if asCounts:
-                        tf[idx] = c
-                    else:
-                        with np.errstate(divide="ignore", invalid="ignore"):
-                            tf[idx] = 1. * c / n[idx, q]
-                cols.append(np.around(tf, 4))
-            allf = np.column_stack(cols)
-            if args.threshold and not asCounts:
-                hi_, lo_ = allf >= args.threshold, allf < args.threshold
-                allf[hi_] = 1
-                allf[lo_] = 0
-            if not keepNan:
-                keep = (~np.all(np.isnan(allf), axis=1) if not asCounts else ~np.all(allf == 0, axis=1)).astype(np.uint8)
-            mode, values = (1, np.ascontiguousarray(allf, dtype=np.int64)) if asCounts else (2, np.ascontiguousarray(allf, dtype=np.float64))
+            # target allele, counts / rounded frequencies, --threshold and the rows' keep flags on the device (pg_site_target)
+            values, keep = eng.batch([0], [0]).siteTarget(lo_, hi_, args.target, minData, asCounts, args.threshold)
+            mode = 1 if asCounts else 2
+            if keepNan:
+                keep = None
+        t0 = lap("counts_s", t0)
         # the rows as text, formatted natively on all host threads (pg_format_freq_rows)
         cap = (b - a) * (name_max + 13 + P * (45 if mode == 0 else 22)) + 64
         if len(text_buf) < cap:
@@ -1648,10 +1659,12 @@ def freq_main(argv=None):
                                     np.ascontiguousarray(run_of_row[a:b], dtype=np.int32) - run0, names_blob, name_off,
                                     C.c_void_p(keep.ctypes.data) if keep is not None else None,
                                     C.c_void_p(text_buf.ctypes.data), cap, C.byref(got), 0))
+        t0 = lap("format_s", t0)
         if out is not None:
             sink.write(memoryview(text_buf)[:got.value])
         else:
             kept.append(bytes(memoryview(text_buf)[:got.value]))
+        lap("write_s", t0)
     reader.close()
     if world.size > 1:
         parts = dist.gather_bytes(comm, b"".join(kept))
@@ -1664,7 +1677,8 @@ def freq_main(argv=None):
             out.close()
     if os.environ.get("PG_TIMING"):
         import json
-        sys.stderr.write("PG_TIMING " + json.dumps(dict(stats, rank=world.rank)) + "\n")
+        stats["total_s"] = _time.perf_counter() - t_start
+        sys.stderr.write("PG_TIMING " + json.dumps(dict({k: (round(v, 4) if isinstance(v, float) else v) for k, v in stats.items()}, rank=world.rank)) + "\n")
     if world.rank == 0:
         sys.stderr.write("\nDone\n")
     if world.size > 1:

@@ -193,6 +193,8 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->hapbits.release();
     c->hap_order.release();
     c->site_tmp.release();
+    c->site_val.release();
+    c->site_keep.release();
     c->site_flags.release();
     c->ref_row.release();
     c->samp_rank.release();
@@ -1520,6 +1522,40 @@ extern "C" int pg_site_counts(pg_ctx *c, int64_t site_lo, int64_t site_hi, int32
             err = hipMemcpyAsync(cnt_out + (size_t)(s - site_lo) * c->n_pops * 4, tmp.p, (size_t)(e - s) * c->n_pops * 16, hipMemcpyDeviceToHost, c->stream);
         if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
         if (err != hipSuccess) return pg_fail(PG_ERR_HIP, "pg_site_counts: %s", hipGetErrorString(err));
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_site_target(pg_ctx *c, int64_t site_lo, int64_t site_hi, int target, double min_data, int as_counts, int has_threshold,
+                              double threshold, void *values_out, uint8_t *keep_out) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    if (site_lo < 0 || site_hi < site_lo || site_hi > c->cap_sites) return pg_fail(PG_ERR_ARG, "site range out of bounds");
+    if (c->n_pops < 1) return pg_fail(PG_ERR_STATE, "no populations set");
+    if (target != 1 && target != 2) return pg_fail(PG_ERR_ARG, "pg_site_target: target must be 1 (derived) or 2 (minor)");
+    if (target == 1 && c->n_pops < 2) return pg_fail(PG_ERR_ARG, "pg_site_target: the derived allele needs an outgroup population");
+    const int64_t n = site_hi - site_lo;
+    if (n == 0) return PG_OK;
+    if (!values_out || !keep_out) return pg_fail(PG_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t chunk = 1 << 22;
+    const int P = c->n_pops;
+    int rc;
+    if ((rc = c->site_tmp.ensure((size_t)std::min(n, chunk) * P * 4)) != PG_OK) return rc;
+    if ((rc = c->site_val.ensure((size_t)std::min(n, chunk) * P)) != PG_OK) return rc;
+    if ((rc = c->site_keep.ensure((size_t)std::min(n, chunk))) != PG_OK) return rc;
+    for (int64_t s = site_lo; s < site_hi; s += chunk) {
+        const int64_t e = std::min(site_hi, s + chunk);
+        pg_launch_site_counts(c->stream, c->gt.p, c->S, s, e, c->pop_start.p, P, c->site_tmp.p);
+        pg_launch_site_target(c->stream, c->site_tmp.p, e - s, P, target, min_data, as_counts ? 1 : 0, has_threshold ? 1 : 0, threshold,
+                              c->site_val.p, reinterpret_cast<long long *>(c->site_val.p), c->site_keep.p);
+        hipError_t err = hipGetLastError();
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(static_cast<char *>(values_out) + (size_t)(s - site_lo) * P * 8, c->site_val.p, (size_t)(e - s) * P * 8,
+                                 hipMemcpyDeviceToHost, c->stream);
+        if (err == hipSuccess) err = hipMemcpyAsync(keep_out + (s - site_lo), c->site_keep.p, (size_t)(e - s), hipMemcpyDeviceToHost, c->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+        if (err != hipSuccess) return pg_fail(PG_ERR_HIP, "pg_site_target: %s", hipGetErrorString(err));
     }
     return PG_OK;
 }

@@ -160,6 +160,8 @@ struct pg_ctx {
     DevBuf<uint32_t> hapbits;      // k_hapstats: match matrices as bit rows
     DevBuf<int32_t> hap_order;     // k_hapstats: each population's slots in the reference's row order
     DevBuf<int32_t> site_tmp;      // pg_site_counts staging
+    DevBuf<double> site_val;       // pg_site_target: the finished columns (float64 or int64, 8 bytes either way)
+    DevBuf<uint8_t> site_keep;     //                 and the rows' keep flags
     DevBuf<uint32_t> site_flags;   // pg_popfreq: one bit per site (k_popfreq_ordered)
     // pi / dxy / Fst in NumPy's summation order (k_popdist_np): the reference's row order within the populations and the rank of
     // the population names (pg_set_reference_order; identity until set), the pairwise-summation trees of the block lengths

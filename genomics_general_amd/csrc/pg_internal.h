@@ -74,6 +74,8 @@ void pg_launch_popfreq_ordered(hipStream_t st, const int8_t *gt, int S, const in
 
 void pg_launch_site_counts(hipStream_t st, const int8_t *gt, int S, int64_t site_lo, int64_t site_hi,
                            const int32_t *pop_start, int n_pops, int32_t *cnt_out);
+void pg_launch_site_target(hipStream_t st, const int32_t *cnt, int64_t n_sites, int n_pops, int target, double min_data, int as_counts,
+                           int has_threshold, double threshold, double *f_out, long long *i_out, uint8_t *keep_out);
 
 void pg_launch_hap_called(hipStream_t st, const int8_t *gt, int S, int n_hap, const int64_t *win_lo,
                           const int64_t *win_hi, int n_win, int max_chunks, unsigned long long *out);

@@ -1908,6 +1908,82 @@ void pg_launch_site_counts(hipStream_t st, const int8_t *gt, int S, int64_t site
 }
 
 // ------------------------------------------------------------------------------------------------------
+// K_target: freq.py's per-site finaliser over cnt[site][pop][4] (freq.py:60-105; derivedAllele / minorAllele genomics.py:636-669):
+// the target allele of the site (derived: the one ingroup allele the last population does not carry, when exactly one allele is
+// seen there, two among the others, one shared; minor: the rarer of exactly two), then per population its count or frequency
+// np.around(., 4) = rint(x * 1e4) / 1e4, the --threshold rule, and the row's keep flag.  A thread per site; float64 throughout.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_site_target(const int32_t *__restrict__ cnt, int64_t n_sites, int n_pops, int target,
+                                                     double min_data, int as_counts, int has_threshold, double threshold,
+                                                     double *__restrict__ f_out, long long *__restrict__ i_out,
+                                                     uint8_t *__restrict__ keep_out) {
+    const int64_t site = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (site >= n_sites) return;
+    const int4 *c4 = reinterpret_cast<const int4 *>(cnt + (size_t)site * n_pops * 4);
+    bool ok;
+    int base = 0;
+    if (target == 1) {
+        const int4 o = c4[n_pops - 1];
+        long long in[4] = {0, 0, 0, 0};
+        for (int q = 0; q < n_pops - 1; ++q) {
+            const int4 v = c4[q];
+            in[0] += v.x; in[1] += v.y; in[2] += v.z; in[3] += v.w;
+        }
+        const bool outc[4] = {o.x > 0, o.y > 0, o.z > 0, o.w > 0};
+        int n_out = 0, n_in = 0;
+        bool shared = false, found = false;
+        for (int b = 0; b < 4; ++b) {
+            const bool inc = in[b] > 0;
+            n_out += outc[b];
+            n_in += inc;
+            shared = shared || (outc[b] && inc);
+            if (!found && inc && !outc[b]) { base = b; found = true; }       // np.argmax of booleans: the first True (0 without one)
+        }
+        ok = n_out == 1 && n_in == 2 && shared;
+    } else {
+        long long tot[4] = {0, 0, 0, 0};
+        for (int q = 0; q < n_pops; ++q) {
+            const int4 v = c4[q];
+            tot[0] += v.x; tot[1] += v.y; tot[2] += v.z; tot[3] += v.w;
+        }
+        int seen = 0;
+        long long best = 0x7fffffffffffffffll;
+        for (int b = 0; b < 4; ++b) {
+            seen += tot[b] > 0;
+            const long long m = tot[b] > 0 ? tot[b] : 0x7fffffffffffffffll;
+            if (m < best) { best = m; base = b; }                              // np.argmin: the first minimum
+        }
+        ok = seen == 2;
+    }
+    bool all_nan = true, all_zero = true;
+    for (int q = 0; q < n_pops; ++q) {
+        const int4 v = c4[q];
+        const long long nq = (long long)v.x + v.y + v.z + v.w;
+        const long long cb = base == 0 ? v.x : base == 1 ? v.y : base == 2 ? v.z : v.w;
+        const bool good = ok && (double)nq >= min_data;                      // freq.py:80: the COUNT is compared with --minData
+        if (as_counts) {
+            const long long t = good ? cb : 0;
+            i_out[(size_t)site * n_pops + q] = t;
+            all_zero = all_zero && t == 0;
+        } else {
+            double t = __longlong_as_double(0x7ff8000000000000ll);
+            if (good) t = rint((1.0 * (double)cb / (double)nq) * 10000.0) / 10000.0;
+            if (has_threshold && t == t) t = t >= threshold ? 1.0 : 0.0;
+            f_out[(size_t)site * n_pops + q] = t;
+            all_nan = all_nan && t != t;
+        }
+    }
+    keep_out[site] = as_counts ? !all_zero : !all_nan;
+}
+
+void pg_launch_site_target(hipStream_t st, const int32_t *cnt, int64_t n_sites, int n_pops, int target, double min_data, int as_counts,
+                           int has_threshold, double threshold, double *f_out, long long *i_out, uint8_t *keep_out) {
+    if (n_sites <= 0 || n_pops <= 0) return;
+    hipLaunchKernelGGL(k_site_target, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, st, cnt, n_sites, n_pops, target, min_data,
+                       as_counts, has_threshold, threshold, f_out, i_out, keep_out);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K_called: per-window, per-haplotype number of called sites (Alignment.seqNonNan, genomics.py:1038-1040).
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hap_called(const int8_t *__restrict__ gt, int S, int n_hap,

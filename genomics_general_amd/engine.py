@@ -464,6 +464,18 @@ class WindowBatch:
         check(self.e._L.pg_site_counts(self.e._h, int(site_lo), int(site_hi), out))
         return out
 
+    def siteTarget(self, site_lo, site_hi, target, minData=0.0, asCounts=False, threshold=None):
+        """freq.py's columns for the sites [site_lo, site_hi) (pg_site_target: k_site_counts + k_site_target): (values [n][n_pops] --
+        int64 counts of the target allele when asCounts, else float64 frequencies rounded to 4 places --, keep [n] uint8: 0 for a row
+        that is all NaN / all zero).  target: "derived" (the last population is the outgroup) or "minor"."""
+        n, P = int(site_hi - site_lo), self.lay.n_pops
+        vals = np.empty((n, P), dtype=np.int64 if asCounts else np.float64)
+        keep = np.empty(n, dtype=np.uint8)
+        check(self.e._L.pg_site_target(self.e._h, int(site_lo), int(site_hi), {"derived": 1, "minor": 2}[target], float(minData),
+                                       1 if asCounts else 0, 1 if (threshold and not asCounts) else 0, float(threshold or 0.0),
+                                       C.c_void_p(vals.ctypes.data), C.c_void_p(keep.ctypes.data)))
+        return vals, keep
+
     # -- popDist / popPairDist ----------------------------------------------------------------------
     def groupDistTable(self, doPairs=True, minSites=None, minData=0.01):
         """pi / dxy / Fst of every window as one float64 table [window][column], finished on the device (k_popstats: the float64

@@ -416,6 +416,14 @@ int pg_popfreq(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_
 /* Replaces Alignment.siteFreqs(asCounts=True) / binBaseFreqs (genomics.py:1049-1052, 592-599) for every
  * population at once: cnt_out[n_sites][n_pops][4] (A,C,G,T) for sites [site_lo, site_hi). */
 int pg_site_counts(pg_ctx *ctx, int64_t site_lo, int64_t site_hi, int32_t *cnt_out);
+/* freq.py's per-site finaliser on those counts (freq.py:60-105 with derivedAllele / minorAllele, genomics.py:636-669), for sites
+ * [site_lo, site_hi): target 1 = derived (the last population is the outgroup), 2 = minor.  Per site and population the count of the
+ * target allele (as_counts: values_out is int64[n][n_pops], 0 where the site or the population's data fail) or its frequency
+ * np.around(c / n, 4) (values_out is float64[n][n_pops], NaN there; has_threshold: frequencies >= threshold become 1, the others 0);
+ * a population counts when its called alleles number >= min_data (freq.py:80 compares the COUNT).  keep_out[n]: 0 for a row that
+ * is all NaN / all zero (what freq.py drops without --keepNanLines). */
+int pg_site_target(pg_ctx *ctx, int64_t site_lo, int64_t site_hi, int target, double min_data, int as_counts, int has_threshold,
+                   double threshold, void *values_out, uint8_t *keep_out);
 
 /* ---- per-haplotype called-site counts ------------------------------------------------------------ */
 /* Replaces Alignment.seqNonNan (genomics.py:1038-1040) as used by distMat.py:40 (--minPerInd):

@@ -290,3 +290,40 @@ class CpuBatch:
             for k, code in enumerate((1, 2, 4, 8)):
                 out[:, p, k] = (gt[:, cols] == code).sum(axis=1)
         return out
+
+    def siteTarget(self, a, b, target, minData=0.0, asCounts=False, threshold=None):
+        """freq.py:60-105 with derivedAllele / minorAllele (genomics.py:636-669) in NumPy, the way the reference forms the columns:
+        the stand-in of pg_site_target"""
+        cnt = self.siteCounts(a, b).astype(np.int64)
+        P = self.lay.n_pops
+        n = cnt.sum(axis=2)
+        if target == "derived":                                             # derivedAllele, genomics.py:636-662
+            outc = cnt[:, P - 1, :] > 0
+            inc = cnt[:, :P - 1, :].sum(axis=1) > 0
+            ok = (outc.sum(axis=1) == 1) & (inc.sum(axis=1) == 2) & np.any(outc & inc, axis=1)
+            base = np.argmax(inc & ~outc, axis=1)
+        else:                                                               # minorAllele, genomics.py:664-669
+            tot = cnt.sum(axis=1)
+            ok = (tot > 0).sum(axis=1) == 2
+            masked = np.where(tot > 0, tot, np.iinfo(np.int64).max)
+            base = np.argmin(masked, axis=1)
+        cols = []
+        for q in range(P):
+            good = ok & (n[:, q] >= minData)                                # freq.py:80: the COUNT is compared
+            tf = np.zeros(b - a, dtype=int) if asCounts else np.full(b - a, np.nan)
+            idx = np.where(good)[0]
+            if len(idx):
+                c = cnt[idx, q, base[idx]]
+                if asCounts:
+                    tf[idx] = c
+                else:
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        tf[idx] = 1. * c / n[idx, q]
+            cols.append(np.around(tf, 4))
+        allf = np.column_stack(cols)
+        if threshold and not asCounts:
+            hi_, lo_ = allf >= threshold, allf < threshold
+            allf[hi_] = 1
+            allf[lo_] = 0
+        keep = (~np.all(np.isnan(allf), axis=1) if not asCounts else ~np.all(allf == 0, axis=1)).astype(np.uint8)
+        return (np.ascontiguousarray(allf, dtype=np.int64) if asCounts else np.ascontiguousarray(allf, dtype=np.float64)), keep

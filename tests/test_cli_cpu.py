@@ -92,7 +92,7 @@ def write_bgzf(path, text, blk, empty_member_at=None):
 
 
 @pytest.mark.parametrize("blk,block", [(700, "4000"), (5000, "4000"), (3000, "70000"), (65280, "30000")])
-@pytest.mark.parametrize("case", [c for c in G.STREAMABLE if c["fixture"] != "mixed" and c["tool"] != "freq.py"], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in G.STREAMABLE if c["fixture"] != "mixed"], ids=lambda c: c["name"])
 def test_drivers_on_bgzf_input_as_deflated_blocks(case, blk, block, tmp_path, monkeypatch):
     """`.geno.gz` written by bgzip: the blocks reach the engine as genoio.BgzfSpan (members still deflated, inflated by
     tokenize_submit_bgzf -- on the device in the real engine), cut behind their last line feed whatever the members' ends; members

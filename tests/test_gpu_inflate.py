@@ -140,7 +140,7 @@ def test_a_damaged_member_is_named_not_inflated(engine, damage):
     assert zlib.crc32(got) == zlib.crc32(b"".join(zlib.decompress(g[18:-8], wbits=-15) for g in good))
 
 
-BGZF_CASES = [c for c in G.STREAMABLE if c["fixture"] != "mixed" and c["tool"] != "freq.py"]
+BGZF_CASES = [c for c in G.STREAMABLE if c["fixture"] != "mixed"]
 
 
 @pytest.mark.parametrize("blk,block", [(700, 3000), (5000, 3000), (3000, 50000), (65280, 30000)])

@@ -797,3 +797,32 @@ def test_populations_that_split_an_individual_take_the_general_finaliser():
                         n += 1
                 assert cnts[w, k] == n and abs(sums[w, k] - tot) < 1e-9, (w, x, y, sums[w, k], tot, cnts[w, k], n)
                 k += 1
+
+
+@pytest.mark.parametrize("n_pops,seed,var_thr,miss_thr", [(4, 5, 30000, 5000), (2, 6, 50000, 20000), (3, 7, 12000, 40000), (5, 8, 60000, 0)])
+def test_site_target_equals_the_numpy_form_of_freq_py(n_pops, seed, var_thr, miss_thr):
+    """pg_site_target (k_site_counts + k_site_target: freq.py's target allele, counts / frequencies rounded to 4 places, --threshold,
+    keep flags) against the NumPy statements of freq.py:60-105 / genomics.py:636-669 (tests/cpu_engine.py: siteTarget): bit for bit"""
+    import cpu_engine
+    e, lay, codes, _ = G.make_engine(4 * n_pops + 1, n_pops, 20000, seed=seed, var_thr=var_thr, miss_thr=miss_thr, extra_nopop=1)
+    ce = cpu_engine.CpuEngine()
+    ce.set_layout(lay)
+    ce.reserve(len(codes))
+    ce.gt[:len(codes)] = codes
+    for target in ("derived", "minor"):
+        for as_counts, thr, min_data in ((False, None, 0.0), (True, None, 0.0), (False, 0.3, 2.0), (False, None, 5.5), (True, None, 3.0),
+                                         (False, 1.0, 0.0)):
+            for a, b in ((0, 20000), (17, 4113), (19999, 20000)):
+                vals, keep = e.batch([0], [0]).siteTarget(a, b, target, min_data, as_counts, thr)
+                want, wkeep = ce.batch([0], [0]).siteTarget(a, b, target, min_data, as_counts, thr)
+                assert vals.dtype == want.dtype and np.array_equal(keep, wkeep), (target, as_counts, thr, min_data)
+                if as_counts:
+                    assert np.array_equal(vals, want)
+                else:                                       # the same float64 values (0.0 against -0.0 cannot occur: frequencies), NaN where NaN
+                    assert np.array_equal(np.isnan(vals), np.isnan(want))
+                    assert np.array_equal(np.nan_to_num(vals, nan=-1.0), np.nan_to_num(want, nan=-1.0))
+                assert 0 < keep.sum() <= len(keep) or (b - a) == 1
+    from genomics_general_amd._lib import PopgenError
+    with pytest.raises(PopgenError):
+        e.batch([0], [0]).siteTarget(0, 30000, "minor")
+    e.close()
