@@ -33,6 +33,14 @@ def driver_commands(geno, out, names, n_pops, wind):
           "-O", "pop3", ",".join(names[3 * per:4 * per])]
     return {
         "popgenWindows.py": ["-g", geno, "-o", out + ".popgen.csv", "-f", "phased", "-w", str(wind), "-m", "100"] + pops,
+        "popgenWindows.py --analysis popFreq": ["-g", geno, "-o", out + ".popfreq.csv", "-f", "phased", "-w", str(wind), "-m", "100",
+                                                "--analysis", "popFreq"] + pops,
+        "popgenWindows.py --analysis indHet": ["-g", geno, "-o", out + ".indhet.csv", "-f", "phased", "-w", str(wind), "-m", "100",
+                                               "--analysis", "indHet"] + pops,
+        "popgenWindows.py --analysis hapStats": ["-g", geno, "-o", out + ".hapstats.csv", "-f", "phased", "-w", str(wind), "-m", "100",
+                                                 "--analysis", "hapStats"] + pops,
+        "popgenWindows.py --analysis indPairDist": ["-g", geno, "-o", out + ".indpair.csv", "-f", "phased", "-w", str(wind), "-m", "100",
+                                                    "--analysis", "indPairDist"] + pops,
         "ABBABABAwindows.py": ["-g", geno, "-o", out + ".abba.csv", "-f", "phased", "-w", str(wind), "-m", "100", "--minData", "0.5"] + p4,
         "fourPopWindows.py": ["-g", geno, "-o", out + ".fourpop.csv", "-f", "phased", "-w", str(wind), "-m", "100", "--minData", "0.5",
                               "--polarize"] + p4,
@@ -65,7 +73,7 @@ def gpu_mode(n_sites, n_dip):
     for tool, argv in driver_commands(geno + ".gz", os.path.join(tmp, "out"), names, 4, 50000).items():
         best = None
         for _ in range(2):
-            rc, wall, tm, err = run_timed(os.path.join(ROOT, tool), argv)
+            rc, wall, tm, err = run_timed(os.path.join(ROOT, tool.split()[0]), argv)
             if rc != 0 or tm is None:
                 best = {"error": err[-400:]}
                 break
@@ -116,8 +124,10 @@ def reference_mode(n_sites, n_dip):
     for tool in cmds_ref:
         ncpu = str(len(os.sched_getaffinity(0)))                     # the reference's own parallelism: worker processes per window / slice
         extra = ["-t", ncpu] if tool == "freq.py" else ["-T", ncpu]
+        if os.environ.get("DRV_ONLY") and os.environ["DRV_ONLY"] not in tool:
+            continue
         t = time.perf_counter()
-        r = subprocess.run([sys.executable, shim, os.path.join(REF, tool)] + cmds_ref[tool] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r = subprocess.run([sys.executable, shim, os.path.join(REF, tool.split()[0])] + cmds_ref[tool] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         dt = time.perf_counter() - t
         entry = {"reference_seconds": round(dt, 2), "reference_sites_per_sec": round(n_sites / dt, 1), "reference_rc": r.returncode,
                  "reference_workers": int(ncpu)}
