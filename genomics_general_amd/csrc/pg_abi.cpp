@@ -192,6 +192,12 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     c->Dfull.release();
     c->hapbits.release();
     c->hap_order.release();
+    if (c->res_stream) { (void)hipStreamSynchronize(c->res_stream); (void)hipStreamDestroy(c->res_stream); }
+    for (int f = 0; f < 2; ++f) {
+        c->res_alt[f].release();
+        if (c->res_fin[f]) (void)hipEventDestroy(c->res_fin[f]);
+        if (c->res_copied[f]) (void)hipEventDestroy(c->res_copied[f]);
+    }
     c->site_tmp.release();
     c->site_val.release();
     c->site_keep.release();
@@ -221,6 +227,22 @@ extern "C" int pg_sync(pg_ctx *c) {
     if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->res_stream) HIPCHK(hipStreamSynchronize(c->res_stream));
+    return PG_OK;
+}
+
+extern "C" int pg_set_deferred_results(pg_ctx *c, int on) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->res_stream) HIPCHK(hipStreamSynchronize(c->res_stream));
+    c->defer_results = on != 0;
+    return PG_OK;
+}
+
+extern "C" int pg_results_wait(pg_ctx *c) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->res_stream) HIPCHK(hipStreamSynchronize(c->res_stream));
     return PG_OK;
 }
 
@@ -544,6 +566,7 @@ static int fold_events(pg_ctx *c);
 static int fold_events(pg_ctx *c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->stream2));
+    if (c->res_stream) HIPCHK(hipStreamSynchronize(c->res_stream));
     for (int k = 0; k < PG_K_COUNT_; ++k) {
         for (auto &pr : c->events[k]) {
             float ms = 0.f;
@@ -1247,8 +1270,52 @@ static int indpair_run(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_wi
     HIPCHK(hipSetDevice(c->device));
     const size_t npairs = (size_t)c->n_samp * (c->n_samp + 1) / 2;
     // results are copied back per batch (they can be large for distMat-sized inputs)
+    // deferred: the table's copy into the caller's page-locked memory runs on a stream of its own while the NEXT call's kernels
+    // run; the caller reads the table after pg_results_wait / pg_sync
+    bool defer = false;
+    if (c->defer_results && mean_mode != 0 && n_win > 0) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, sum_out) == hipSuccess) defer = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
     rc = pairwise_run(c, lo, hi, n_win, [&](int w0, int nb) -> int {
         int r;
+        if (defer) {
+            const int f = c->res_flip;
+            c->res_flip ^= 1;
+            if (!c->res_stream) HIPCHK(hipStreamCreateWithFlags(&c->res_stream, hipStreamNonBlocking));
+            if (!c->res_fin[f]) HIPCHK(hipEventCreateWithFlags(&c->res_fin[f], hipEventDisableTiming));
+            const bool had_copy = c->res_copied[f] != nullptr;
+            if (!had_copy) HIPCHK(hipEventCreateWithFlags(&c->res_copied[f], hipEventDisableTiming));
+            if (c->res_alt[f].cap < (size_t)nb * npairs) {
+                if (had_copy) HIPCHK(hipEventSynchronize(c->res_copied[f]));       // (the buffer is replaced: its last copy must be out)
+                if ((r = c->res_alt[f].ensure((size_t)nb * npairs)) != PG_OK) return r;
+            } else if (had_copy) {
+                HIPCHK(hipStreamWaitEvent(c->stream, c->res_copied[f], 0));      // the finaliser overwrites what that copy reads
+            }
+            hipEvent_t e0, e1;
+            if ((r = pg_time_begin(c, PG_K_INDPAIR_FIN, &e0, &e1)) != PG_OK) return r;
+            pg_launch_indpair_fin(c->stream, c->Cmat.p, c->Dmat.p, c->n_hap, c->cN, c->cshift, nb, c->samp_start.p, c->samp_rank.p, c->n_samp,
+                                  min_pair_sites, c->res_alt[f].p, nullptr, mean_mode);
+            if ((r = pg_time_end(c, PG_K_INDPAIR_FIN, e0, e1, 1)) != PG_OK) return r;
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->res_fin[f], c->stream));
+            HIPCHK(hipStreamWaitEvent(c->res_stream, c->res_fin[f], 0));
+            hipEvent_t t0 = nullptr, t1 = nullptr;
+            if ((c->time_mask >> PG_K_RESULT_D2H) & 1u) {
+                if ((r = event_get(c, &t0)) != PG_OK || (r = event_get(c, &t1)) != PG_OK) return r;
+                HIPCHK(hipEventRecord(t0, c->res_stream));
+            }
+            HIPCHK(hipMemcpyAsync(sum_out + (size_t)w0 * npairs, c->res_alt[f].p, (size_t)nb * npairs * 8, hipMemcpyDeviceToHost, c->res_stream));
+            if (t0) {
+                HIPCHK(hipEventRecord(t1, c->res_stream));
+                c->events[PG_K_RESULT_D2H].push_back(std::make_pair(t0, t1));
+                c->acc_launches[PG_K_RESULT_D2H] += 1;
+            }
+            HIPCHK(hipEventRecord(c->res_copied[f], c->res_stream));
+            HIPCHK(hipStreamSynchronize(c->stream));                             // the kernels are done (the staging buffers are free); the copy goes on
+            return PG_OK;
+        }
         if ((r = c->res_f64.ensure((size_t)nb * npairs)) != PG_OK) return r;
         if (mean_mode == 0 && (r = c->res_i64.ensure((size_t)nb * npairs)) != PG_OK) return r;
         hipEvent_t e0, e1;

@@ -181,6 +181,13 @@ struct pg_ctx {
     DevBuf<int32_t> Cmat, Dmat;
     DevBuf<int64_t> win;        // [lo | hi | woff]
     DevBuf<double> res_f64, part_f64, stats;
+    // deferred result tables (pg_set_deferred_results): the finaliser writes into one of two device buffers, the copy to the caller's
+    // page-locked table runs on res_stream beside the kernels of the next call
+    hipStream_t res_stream = nullptr;
+    DevBuf<double> res_alt[2];
+    hipEvent_t res_fin[2] = {nullptr, nullptr}, res_copied[2] = {nullptr, nullptr};
+    int res_flip = 0;
+    bool defer_results = false;
     std::vector<hipEvent_t> event_pool;
     DevBuf<int64_t> res_i64, part_i64;
     HostPin<double> out_pin;     // pinned landing zone of small result tables

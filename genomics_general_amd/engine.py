@@ -293,6 +293,14 @@ class Engine:
                                               np.ascontiguousarray(lay.col_slot), lay.col_ploidy, C.byref(ok)))
         return bool(ok.value)
 
+    def set_deferred_results(self, on=True):
+        """large result tables (WindowBatch.indPairTable into page-locked memory) are copied back on a stream of their own while the
+        next call's kernels run; a table is complete after results_wait() / sync() (pg_set_deferred_results)"""
+        check(self._L.pg_set_deferred_results(self._h, 1 if on else 0))
+
+    def results_wait(self):
+        check(self._L.pg_results_wait(self._h))
+
     def inflate_members(self, comp, tab, dst):
         """BGZF members (genoio.bgzf_walk's table over the bytes comp) inflated on the device into the host array dst
         (pg_inflate_device: k_inflate + k_crc32, then one copy back -- page-locked dst: at the link's rate); returns the kernels' ms.

@@ -358,6 +358,12 @@ int pg_indpairdist(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, in
  * diag_counts_zeros != 0 (includeSameWithSame, genomics.py:940) one zero per haplotype counts as data. */
 int pg_indpairdist_mean(pg_ctx *ctx, const int64_t *win_lo, const int64_t *win_hi, int n_win, int min_pair_sites,
                         int diag_counts_zeros, double *d_out);
+/* Deferred result tables, for loops that compute large tables back to back (bench.py's distMat shape: 40 MB per pass): with on != 0,
+ * pg_indpairdist_mean returns when its kernels are done and lets the copy of the table into d_out -- which must then be page-locked
+ * (pg_host_alloc), else the call behaves as before -- run on a stream of its own, beside the kernels of the following calls (two
+ * device-side buffers alternate).  d_out is complete after pg_results_wait or pg_sync. */
+int pg_set_deferred_results(pg_ctx *ctx, int on);
+int pg_results_wait(pg_ctx *ctx);
 
 /* The same means from pair counts the CALLER supplies: D, C as pg_pairwise writes them ([n_win][n_hap][n_hap] int32, device slot
  * order).  Pair counts are sums over sites, so the counts of disjoint parts of a window add: this is how `distMat.py --windType cat`

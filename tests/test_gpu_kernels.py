@@ -826,3 +826,25 @@ def test_site_target_equals_the_numpy_form_of_freq_py(n_pops, seed, var_thr, mis
     with pytest.raises(PopgenError):
         e.batch([0], [0]).siteTarget(0, 30000, "minor")
     e.close()
+
+
+def test_deferred_result_tables_equal_the_immediate_ones():
+    """pg_set_deferred_results: the table of call k is copied into its page-locked array while call k + 1 computes (two device-side
+    buffers alternate); after results_wait() every table equals the one the immediate route returns -- also when a pageable array is
+    passed (then the call behaves as before) and when the table grows"""
+    e, lay, codes, _ = G.make_engine(400, 1, 6000, seed=9, var_thr=30000, miss_thr=8000)
+    wins = [([0, 3000], [3000, 6000]), ([0, 100, 5000], [6000, 2100, 6000]), ([17], [5999]), ([0, 2000, 4000], [2000, 4000, 6000])]
+    want = [e.batch(lo, hi).indPairTable().copy() for lo, hi in wins]
+    assert want[0].nbytes >= (1 << 20)                     # (large enough to land in page-locked memory)
+    e.set_deferred_results(True)
+    for rep in range(3):
+        got = [e.batch(lo, hi).indPairTable() for lo, hi in wins * 2]
+        e.results_wait()
+        for k, g in enumerate(got):
+            w = want[k % len(wins)]
+            assert g.shape == w.shape and np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(np.nan_to_num(g), np.nan_to_num(w)), (rep, k)
+    small = e.batch([0], [50]).indPairTable()              # below the page-locked threshold? (n_samp = 400: 80 200 pairs = 0.6 MB: pageable)
+    e.sync()
+    e.set_deferred_results(False)
+    assert np.array_equal(np.nan_to_num(small), np.nan_to_num(e.batch([0], [50]).indPairTable()))
+    e.close()
