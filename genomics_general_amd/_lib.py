@@ -115,6 +115,8 @@ SIGNATURES = {
     "pg_popfreq": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p, _i64p, _i64p, _f64p]),
     "pg_hap_called": (C.c_int, [_P, _i64p, _i64p, C.c_int, _i64p]),
     "pg_site_counts": (C.c_int, [_P, C.c_int64, C.c_int64, _i32p]),
+    "pg_format_float_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_char, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.POINTER(C.c_int64), C.c_int]),
     "pg_set_deferred_results": (C.c_int, [_P, C.c_int]),
     "pg_results_wait": (C.c_int, [_P]),
     "pg_site_target": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]),

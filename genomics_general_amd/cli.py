@@ -1277,21 +1277,38 @@ def _quartet_main(argv, prog, stats, fourpop):
 # ==========================================================================================================
 # distMat.py
 # ==========================================================================================================
+def _float_rows(M, roundTo, prefixes=None):
+    """the rows of a float64 matrix as text: `M.round(roundTo).astype(str)` joined by blanks, a line feed behind every row, an
+    optional prefix in front of each (pg_format_float_rows: repr(float) natively, on the host threads)"""
+    import ctypes as C
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    n, m = M.shape
+    blob, off = None, None
+    if prefixes is not None:
+        enc = [p.encode() for p in prefixes]
+        blob = b"".join(enc)
+        off = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.int64)
+    cap = n * (m * 26 + 1) + (len(blob) if blob else 0) + 16
+    out = np.empty(cap, dtype=np.uint8)
+    got = C.c_int64(0)
+    _lib.check(_lib.lib().pg_format_float_rows(C.c_void_p(M.ctypes.data), n, m, int(roundTo), C.c_char(b" "), blob,
+                                               C.c_void_p(off.ctypes.data) if off is not None else None, C.c_void_p(out.ctypes.data), cap,
+                                               C.byref(got), 0))
+    return out[:got.value].tobytes().decode()
+
+
 def _matrix_text(M, names, fmt, roundTo):
     """genomics.py:2288-2306 makeDistMatString / PhylipString / NexusString."""
-    # (`.round(r).astype(str)` there: the shortest repr of every float64 -- what repr() of the Python float gives, an order of
-    # magnitude faster than NumPy's string cast)
-    txt = [" ".join(map(repr, row)) for row in M.round(roundTo).tolist()]
     n = len(names)
     if fmt == "raw":
-        return "\n".join(txt) + "\n"
+        return _float_rows(M, roundTo)
     if fmt == "phylip":
-        return str(M.shape[0]) + "\n" + "".join(str(names[i]) + "  " + txt[i] + "\n" for i in range(n))
+        return str(M.shape[0]) + "\n" + _float_rows(M, roundTo, [str(names[i]) + "  " for i in range(n)])
     s = "\nBEGIN Taxa;\nDIMENSIONS ntax={};\nTAXLABELS\n".format(n)
     s += "".join("[{}] '{}'\n".format(i + 1, names[i]) for i in range(n))
     s += ";\nEND; [Taxa]\n"
     s += "\nBEGIN Distances;\nDIMENSIONS ntax={};\nFORMAT labels=left diagonal triangle=both;\nMATRIX\n".format(n)
-    s += "".join("[{}] '{}'    ".format(i + 1, names[i]) + txt[i] + "\n" for i in range(n))
+    s += _float_rows(M, roundTo, ["[{}] '{}'    ".format(i + 1, names[i]) for i in range(n)])
     return s + ";\nEND; [Distances]\n"
 
 

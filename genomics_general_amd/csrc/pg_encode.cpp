@@ -8,6 +8,8 @@
 
 #include <atomic>
 #include <cmath>
+#include <charconv>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -506,6 +508,122 @@ extern "C" int pg_format_freq_rows(int mode, int64_t n_rows, int n_pops, const v
     for (auto &x : part) total += (int64_t)x.size();
     *out_len = total;
     if (total > out_cap) return pg_fail(PG_ERR_ARG, "pg_format_freq_rows: %lld bytes of rows, capacity %lld", (long long)total, (long long)out_cap);
+    int64_t at = 0;
+    for (auto &x : part) {
+        memcpy(out + at, x.data(), x.size());
+        at += (int64_t)x.size();
+    }
+    return PG_OK;
+}
+
+
+// ---- rows of float64 values the way Python prints them ------------------------------------------------------------------------------
+// repr(float) (what `np.round(M, r).astype(str)` / `str(x)` give for a float64, genomics.py:2288-2306 makeDistMatString & co.): the
+// shortest digits that read back as the same double (std::to_chars, the same digits as David Gay's mode 0 in CPython), fixed
+// notation while the decimal point lies within (-4, 16] of the first digit -- ".0" behind an integer --, else d[.ddd]e+XX with at
+// least two exponent digits; "nan", "inf", "-inf"; "-0.0".
+namespace {
+
+void put_py_repr(std::string &o, double v) {
+    if (v != v) { o += "nan"; return; }
+    if (v == HUGE_VAL) { o += "inf"; return; }
+    if (v == -HUGE_VAL) { o += "-inf"; return; }
+    char b[40];
+    const auto r = std::to_chars(b, b + sizeof(b), v, std::chars_format::scientific);      // [-]d[.ddd]e[+-]XX[X]
+    const char *p = b, *e = r.ptr;
+    if (*p == '-') { o.push_back('-'); ++p; }
+    const char *ex = p;
+    while (ex < e && *ex != 'e') ++ex;
+    char dig[24];
+    int nd = 0;
+    for (const char *q = p; q < ex; ++q)
+        if (*q != '.') dig[nd++] = *q;
+    int e10 = 0;
+    {
+        const char *q = ex + 1;
+        const bool neg = *q == '-';
+        if (*q == '-' || *q == '+') ++q;
+        for (; q < e; ++q) e10 = e10 * 10 + (*q - '0');
+        if (neg) e10 = -e10;
+    }
+    if (nd == 1 && dig[0] == '0') { o += "0.0"; return; }
+    const int decpt = e10 + 1;                                // the value is 0.d1d2... x 10^decpt
+    if (decpt > -4 && decpt <= 16) {
+        if (decpt <= 0) {
+            o += "0.";
+            o.append((size_t)(-decpt), '0');
+            o.append(dig, (size_t)nd);
+        } else if (decpt >= nd) {
+            o.append(dig, (size_t)nd);
+            o.append((size_t)(decpt - nd), '0');
+            o += ".0";
+        } else {
+            o.append(dig, (size_t)decpt);
+            o.push_back('.');
+            o.append(dig + decpt, (size_t)(nd - decpt));
+        }
+        return;
+    }
+    o.push_back(dig[0]);
+    if (nd > 1) {
+        o.push_back('.');
+        o.append(dig + 1, (size_t)(nd - 1));
+    }
+    o.push_back('e');
+    int x = e10;
+    if (x < 0) { o.push_back('-'); x = -x; } else o.push_back('+');
+    char t[8];
+    int k = 0;
+    do { t[k++] = (char)('0' + x % 10); x /= 10; } while (x);
+    if (k < 2) t[k++] = '0';
+    while (k) o.push_back(t[--k]);
+}
+
+}  // namespace
+
+// n_rows rows of row_len values: value j of row i is v[i * row_len + j], rounded as np.round(x, round_to) rounds when round_to >= 0
+// (rint(x * 10^r) / 10^r; round_to < 0: as it is), printed as repr(float) does, the values of a row separated by `sep`, the row
+// ended by a line feed; prefix (may be NULL): bytes put in front of row i, prefix[prefix_off[i] .. prefix_off[i + 1]).
+extern "C" int pg_format_float_rows(const double *v, int64_t n_rows, int64_t row_len, int round_to, char sep, const char *prefix,
+                                    const int64_t *prefix_off, char *out, int64_t out_cap, int64_t *out_len, int n_threads) {
+    if (n_rows < 0 || row_len < 0 || !out_len || round_to > 22) return pg_fail(PG_ERR_ARG, "pg_format_float_rows: bad argument");
+    *out_len = 0;
+    if (n_rows == 0) return PG_OK;
+    if ((!v && row_len) || (prefix && !prefix_off)) return pg_fail(PG_ERR_ARG, "pg_format_float_rows: null argument");
+    double f = 1.0;
+    for (int k = 0; k < round_to; ++k) f *= 10.0;             // exact up to 10^22
+    int nt = n_threads > 0 ? n_threads : pg_host_threads();
+    if (nt < 1) nt = 1;
+    if ((int64_t)nt > n_rows * row_len / 2048 + 1) nt = (int)(n_rows * row_len / 2048 + 1);
+    if ((int64_t)nt > n_rows) nt = (int)n_rows;
+    std::vector<std::string> part(nt);
+    auto work = [&](int t) {
+        std::string &o = part[t];
+        const int64_t a = n_rows * t / nt, b = n_rows * (t + 1) / nt;
+        o.reserve((size_t)(b - a) * (size_t)(row_len * 8 + 16));
+        for (int64_t i = a; i < b; ++i) {
+            if (prefix) o.append(prefix + prefix_off[i], (size_t)(prefix_off[i + 1] - prefix_off[i]));
+            const double *row = v + (size_t)i * (size_t)row_len;
+            for (int64_t j = 0; j < row_len; ++j) {
+                if (j) o.push_back(sep);
+                double x = row[j];
+                if (round_to >= 0 && x == x && x != HUGE_VAL && x != -HUGE_VAL) x = std::nearbyint(x * f) / f;
+                put_py_repr(o, x);
+            }
+            o.push_back('\n');
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    int64_t total = 0;
+    for (auto &x : part) total += (int64_t)x.size();
+    *out_len = total;
+    if (!out) return PG_OK;                                  // sizing call
+    if (total > out_cap) return pg_fail(PG_ERR_ARG, "pg_format_float_rows: %lld bytes of rows, capacity %lld", (long long)total, (long long)out_cap);
     int64_t at = 0;
     for (auto &x : part) {
         memcpy(out + at, x.data(), x.size());

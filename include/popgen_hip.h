@@ -271,6 +271,14 @@ int pg_vcf_render_rows(const char *buf, int64_t n_rows, int n_sel, const int32_t
 int pg_format_freq_rows(int mode, int64_t n_rows, int n_pops, const void *values, const int64_t *pos, const int32_t *run_of_row,
                         const char *names, const int64_t *name_off, const uint8_t *keep, char *out, int64_t out_cap, int64_t *out_len,
                         int n_threads);
+/* Rows of float64 values as Python prints them: what makeDistMatString / PhylipString / NexusString (genomics.py:2288-2306) get from
+ * `distArray.round(roundTo).astype(str)`.  Value j of row i = v[i * row_len + j], rounded like np.round(x, round_to) when
+ * round_to >= 0 (rint(x * 10^r) / 10^r), printed as repr(float) (shortest digits that read back; fixed notation for
+ * 1e-4 <= |x| < 1e16 with ".0" behind integers, else d.ddde-XX; nan / inf / -0.0), separated by sep, a line feed behind the row;
+ * prefix (may be NULL): the bytes prefix[prefix_off[i] .. prefix_off[i+1]) in front of row i (taxon labels).  out == NULL: only
+ * *out_len. */
+int pg_format_float_rows(const double *v, int64_t n_rows, int64_t row_len, int round_to, char sep, const char *prefix,
+                         const int64_t *prefix_off, char *out, int64_t out_cap, int64_t *out_len, int n_threads);
 
 /* Inflate the independently deflated chunks of a `.pgeno` block (zlib streams; genoio.PackedWriter) on all host threads: the
  * concatenated output goes to dst_a (first len_a bytes: the block's int32 positions) and dst_b (the rest: its cells, e.g. rows of

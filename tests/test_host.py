@@ -595,3 +595,25 @@ def test_the_pairwise_summation_tree_adds_up_like_numpy():
         for k in range(ni):
             slots[nl + k] = slots[left[k]] + slots[right[k]]
         assert 0.0 + slots[-1] == float(np.sum(np.array(a))), n
+
+
+@pytest.mark.parametrize("round_to", [4, 10, 0, -1, 15])
+def test_format_float_rows_prints_what_numpy_prints(round_to):
+    """pg_format_float_rows (the matrix text of distMat.py) against `M.round(r).astype(str)` -- genomics.py:2288-2306 -- on special
+    values and on random doubles of every exponent: the same characters"""
+    from genomics_general_amd import cli
+    rng = np.random.default_rng(round_to + 7)
+    special = [0.0, -0.0, float("nan"), float("inf"), -float("inf"), 1e-5, 9.999e-5, 1e-4, 0.00012345, 1e15, 1e16, 9999999999999998.0,
+               123456789012345678.0, 1e22, 1e23, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 0.1, 0.5, 1.5, 2.5, 1.0, 100.0,
+               1e-7, 123.456, 0.30000000000000004]
+    special += [-x for x in special if x == x]
+    for vals in (special + [0.0] * (-len(special) % 6), rng.integers(0, 2 ** 64 - 1, size=60000, dtype=np.uint64).view(np.float64),
+                 rng.random(60000) * rng.choice([1e-9, 1e-4, 1e-2, 1, 1e3, 1e8, 1e15, 1e17], size=60000), np.round(rng.random(6000), 4)):
+        M = np.asarray(vals, dtype=np.float64).reshape(-1, 6)
+        with np.errstate(all="ignore"):
+            want = "".join(" ".join(row) + "\n" for row in (M.round(round_to) if round_to >= 0 else M).astype(str))
+        assert cli._float_rows(M, round_to) == want
+    M = rng.random((5, 3))
+    pre = ["a  ", "[2] 'bb'    ", "", "x", "yy "]
+    want = "".join(p + " ".join(row) + "\n" for p, row in zip(pre, M.round(4).astype(str)))
+    assert cli._float_rows(M, 4, pre) == want
