@@ -920,7 +920,8 @@ def _fmt_cell(v):
     return str(v)
 
 
-NP_MAX_SITES = 256       # csrc/pg_internal.h PG_NP_MAX_SITES: windows of up to this many sites get their sums in NumPy's order anyway
+WIDE_ROW_COLS = 256              # popgenWindows.py: rows of at least this many float columns (and no other kind) are formatted natively
+NP_MAX_SITES = 256               # csrc/pg_internal.h PG_NP_MAX_SITES: windows of up to this many sites get their sums in NumPy's order anyway
 
 
 def _near_rounding_tie(v, digits, ratio=False, difference=False):
@@ -1129,7 +1130,9 @@ def popgen_main(argv=None):
         t_c = time.perf_counter()
         # the rows as text: one rounding pass over the table (np.round is what round(np.float64) calls), then Python numbers, whose
         # str() is numpy's for float64 (shortest repr, "nan", "inf", "-0.0") -- no numpy scalar per cell (popgenWindows.py:66-75)
-        R = np.round(full, args.roundTo).tolist()
+        # (rows of hundreds of float columns -- indPairDist of many individuals -- and nothing but floats: formatted natively, all at once)
+        wide = full.shape[1] >= WIDE_ROW_COLS and not int_cols and not h2_cols and T.n > 0
+        R = _float_rows(full, args.roundTo, sep=",").split("\n") if wide else np.round(full, args.roundTo).tolist()
         ids, start, end, mid = T.ID, T.start, T.end, T.mid
         sites, dup = np.asarray(T.sites).tolist(), np.asarray(T.dup).tolist()
         for k in range(T.n):
@@ -1137,15 +1140,18 @@ def popgen_main(argv=None):
                 ok, text = last_row
             else:
                 ok = sites[k] >= minSites
-                vals = R[k]
-                for c in int_cols:
-                    if vals[c] == vals[c]:
-                        vals[c] = int(vals[c])
-                for c in h2_cols:
-                    if vals[c] == 0:
-                        vals[c] = 0
-                row = ([ids[k]] if args.addWindowID else []) + [T.scaffold[k], start[k], end[k], mid[k], int(sites[k])] + vals
-                text = ",".join(map(str, row)) + "\n"
+                head = ([ids[k]] if args.addWindowID else []) + [T.scaffold[k], start[k], end[k], mid[k], int(sites[k])]
+                if wide:
+                    text = ",".join(map(str, head)) + "," + R[k] + "\n"
+                else:
+                    vals = R[k]
+                    for c in int_cols:
+                        if vals[c] == vals[c]:
+                            vals[c] = int(vals[c])
+                    for c in h2_cols:
+                        if vals[c] == 0:
+                            vals[c] = 0
+                    text = ",".join(map(str, head + vals)) + "\n"
                 last_row = (ok, text)
             if not (ok or args.writeFailedWindows):
                 continue
@@ -1277,7 +1283,7 @@ def _quartet_main(argv, prog, stats, fourpop):
 # ==========================================================================================================
 # distMat.py
 # ==========================================================================================================
-def _float_rows(M, roundTo, prefixes=None):
+def _float_rows(M, roundTo, prefixes=None, sep=" "):
     """the rows of a float64 matrix as text: `M.round(roundTo).astype(str)` joined by blanks, a line feed behind every row, an
     optional prefix in front of each (pg_format_float_rows: repr(float) natively, on the host threads)"""
     import ctypes as C
@@ -1291,7 +1297,7 @@ def _float_rows(M, roundTo, prefixes=None):
     cap = n * (m * 26 + 1) + (len(blob) if blob else 0) + 16
     out = np.empty(cap, dtype=np.uint8)
     got = C.c_int64(0)
-    _lib.check(_lib.lib().pg_format_float_rows(C.c_void_p(M.ctypes.data), n, m, int(roundTo), C.c_char(b" "), blob,
+    _lib.check(_lib.lib().pg_format_float_rows(C.c_void_p(M.ctypes.data), n, m, int(roundTo), C.c_char(sep.encode()), blob,
                                                C.c_void_p(off.ctypes.data) if off is not None else None, C.c_void_p(out.ctypes.data), cap,
                                                C.byref(got), 0))
     return out[:got.value].tobytes().decode()

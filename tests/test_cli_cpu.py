@@ -220,3 +220,22 @@ def test_a_large_single_stream_gzip_input_gets_the_bgzip_hint(tmp_path, monkeypa
     run_case(case, tmp_path, monkeypatch)
     err = capfd.readouterr().err
     assert err.count("single gzip stream") == 1 and "bgzip" in err
+
+
+def test_rows_of_float_columns_only_formatted_natively(tmp_path, monkeypatch):
+    """popgenWindows.py --analysis indPairDist / popDist: rows of nothing but float columns take pg_format_float_rows when they are wide
+    (cli.WIDE_ROW_COLS); forced here on the goldens' narrow tables: the reference's text, nan and tiny values included"""
+    used = []
+    real = cli._float_rows
+    monkeypatch.setattr(cli, "WIDE_ROW_COLS", 1)
+    monkeypatch.setattr(cli, "_float_rows", lambda *a, **k: (used.append(1), real(*a, **k))[1])
+    n = 0
+    for case in CASES:
+        an = case["argv"][case["argv"].index("--analysis") + 1:] if "--analysis" in case["argv"] else ["popDist", "popPairDist"]
+        an = [a for a in an if not a.startswith("-") and a in ("popDist", "popPairDist", "indPairDist", "popFreq", "indHet", "hapStats")]
+        if case["tool"] != "popgenWindows.py" or not set(an) <= {"popDist", "popPairDist", "indPairDist"}:
+            continue
+        before = len(used)
+        run_case(case, tmp_path, monkeypatch)
+        n += len(used) > before
+    assert n >= 10, n
