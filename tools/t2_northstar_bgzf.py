@@ -157,6 +157,10 @@ def main():
            "note": "total_s: inside the driver, from opening the input to the last row written (PG_TIMING); every float cell of the CSV (--roundTo 12) "
                    "against the statistics of the resident rows (1e-9 relative); scaffold, start, end and sites of every row exact"}
     print(json.dumps(out))
+    if os.environ.get("PG_NS_KEEP"):                          # (for a profiler run of the same command: the file stays, the command is written next to it)
+        with open(os.environ["PG_NS_KEEP"], "w") as f:
+            f.write(" ".join(cmd) + "\n")
+        return
     for fn in os.listdir(tmp):
         os.remove(os.path.join(tmp, fn))
     os.rmdir(tmp)
