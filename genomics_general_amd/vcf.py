@@ -116,7 +116,9 @@ def _text_blocks(reader, block_bytes, n_threads=0):
     bg = isinstance(getattr(reader, "f", None), genoio.BgzfFile)
     made = {}
     maker = None
-    if bg and os.environ.get("PG_BGZF_DEVICE", "1") != "0" and _lib.device_count() > 0:
+    # (a small file is over before a device context exists -- 0.1 - 0.3 s --: the host threads inflate it; PG_VCF_WAIT_FOR_DEVICE: always)
+    worth = bg and (getattr(reader.f, "size", 0) >= (32 << 20) or os.environ.get("PG_VCF_WAIT_FOR_DEVICE"))
+    if worth and os.environ.get("PG_BGZF_DEVICE", "1") != "0" and _lib.device_count() > 0:
         def make():                               # the device context takes 0.1 - 0.3 s: the first blocks do not wait for it
             try:
                 from .engine import Engine
