@@ -96,10 +96,13 @@ void parse_range(Shared &sh, const char *b, const char *e, int64_t row) {
             if (p >= le || *p < '0' || *p > '9') { set_err(sh, "position is not an integer", row, -1); return; }
             // (the reference parses Python integers, genomics.py:1884-1904: positions beyond 2^31 -- chromosomes of more than
             // 2.1 Gb exist -- are carried as int64; eighteen digits is where this parser stops)
+            // (leading zeros do not count -- int("0000000000000000000012") is 12 there --, and the nineteenth significant digit is
+            // refused before it is multiplied in: ADVICE round 5)
             int64_t v = 0;
             int nd = 0;
-            while (p < le && *p >= '0' && *p <= '9' && nd < 19) { v = v * 10 + (*p - '0'); ++p; ++nd; }
-            if (nd > 18 || (p < le && !is_ws(*p))) { set_err(sh, "position is not an integer of at most 18 digits", row, -1); return; }
+            while (p < le && *p == '0') ++p;
+            while (p < le && *p >= '0' && *p <= '9' && nd < 18) { v = v * 10 + (*p - '0'); ++p; ++nd; }
+            if (p < le && !is_ws(*p)) { set_err(sh, "position is not an integer of at most 18 digits", row, -1); return; }
             sh.pos[row] = neg ? -v : v;
             int8_t *out = sh.gt + (size_t)row * H;
             memset(out, 0, H);

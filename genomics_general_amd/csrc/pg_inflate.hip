@@ -258,8 +258,18 @@ extern "C" int pg_bgzf_compress(const uint8_t *text, int64_t len, int level, int
             zs.next_out = o.data() + 18;
             zs.avail_out = (uInt)(o.size() - 26);
             if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { bad.store(1); break; }
-            const size_t cl = o.size() - 26 - zs.avail_out, total = 18 + cl + 8;
-            if (total > 65536) { bad.store(2); break; }                   // (incompressible text in a block near 64 KiB: use a smaller block)
+            size_t cl = o.size() - 26 - zs.avail_out, total = 18 + cl + 8;
+            if (total > 65536) {
+                // text that does not deflate (binary or already compressed input, high-entropy INFO strings) in a block near 64 KiB:
+                // one stored block (5 + m bytes; 65280 + 5 + 26 <= 65536 is why bgzip's block is 65280) -- ADVICE round 5
+                uint8_t *d = o.data() + 18;
+                d[0] = 1;
+                d[1] = (uint8_t)(m & 255); d[2] = (uint8_t)(m >> 8);
+                d[3] = (uint8_t)(~m & 255); d[4] = (uint8_t)((~m >> 8) & 255);
+                memcpy(d + 5, text + a, m);
+                cl = 5 + (size_t)m;
+                total = 18 + cl + 8;
+            }
             static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
             memcpy(o.data(), head, 16);
             o[16] = (uint8_t)((total - 1) & 255);
@@ -275,7 +285,7 @@ extern "C" int pg_bgzf_compress(const uint8_t *text, int64_t len, int level, int
     for (int t = 1; t < nt; ++t) th.emplace_back(work);
     work();
     for (auto &x : th) x.join();
-    if (bad.load()) return pg_fail(PG_ERR_ARG, bad.load() == 2 ? "pg_bgzf_compress: a member exceeds 64 KiB (incompressible text: use a smaller block)" : "pg_bgzf_compress: deflate failed");
+    if (bad.load()) return pg_fail(PG_ERR_ARG, "pg_bgzf_compress: deflate failed");
     int64_t at = 0;
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (auto &o : parts) {

@@ -219,8 +219,8 @@ __global__ __launch_bounds__(256) void k_tok_parse(const uint8_t *__restrict__ t
         if (p < le && (text[p] == '+' || text[p] == '-')) { neg = text[p] == '-'; ++p; }
         long long v = 0;
         const int64_t d0 = p;
-        while (p < le && text[p] >= '0' && text[p] <= '9' && p - d0 < 19) { v = v * 10 + (text[p] - '0'); ++p; }
-        if (p == d0 || p - d0 > 18 || (p < le && !blank(text[p]))) bad |= TOK_BAD_POS;
+        while (p < le && text[p] >= '0' && text[p] <= '9' && p - d0 < 18) { v = v * 10 + (text[p] - '0'); ++p; }
+        if (p == d0 || (p < le && !blank(text[p]))) bad |= TOK_BAD_POS;      // (a longer or zero-padded number: the host tokenizer's case)
         pos_out[row] = neg ? -v : v;
         while (p < le && blank(text[p])) ++p;
         cells_at = p;
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(256) void k_tok_heads(const uint8_t *__restrict__ t
     if (p < n && (B(p) == '+' || B(p) == '-')) { neg = B(p) == '-'; ++p; }
     long long v = 0;
     const int64_t d0 = p;
-    while (p < n && B(p) >= '0' && B(p) <= '9' && p - d0 < 19) { v = v * 10 + (B(p) - '0'); ++p; }
-    if (p == d0 || p - d0 > 18 || (p < n && !blank(B(p)))) bad |= TOK_BAD_POS;
+    while (p < n && B(p) >= '0' && B(p) <= '9' && p - d0 < 18) { v = v * 10 + (B(p) - '0'); ++p; }
+    if (p == d0 || (p < n && !blank(B(p)))) bad |= TOK_BAD_POS;                  // (a longer or zero-padded number: the host tokenizer's case)
     pos_out[row] = neg ? -v : v;
     while (p < n && blank(B(p))) ++p;
     // the regular layout: n_cols cells of their columns' widths, one separator between them, the last cell ends the line

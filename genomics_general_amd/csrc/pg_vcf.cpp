@@ -262,6 +262,7 @@ long long walk(Shared &sh, const char *b, const char *e, Tok prev_chrom, Tok pre
                     if (p < pe && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
                     long long v = 0;
                     if (p >= pe) { set_err(sh, "POS is not an integer", &t[0], &t[1]); return kept; }
+                    while (pe - p > 1 && *p == '0') ++p;                                  // int("007") == 7
                     if (pe - p > 18) { set_err(sh, "POS has more than 18 digits", &t[0], &t[1]); return kept; }
                     for (; p < pe; ++p) {
                         if (*p < '0' || *p > '9') { set_err(sh, "POS is not an integer", &t[0], &t[1]); return kept; }

@@ -101,6 +101,12 @@ def exchange_unique_id(world, make_id, timeout_s=180.0):
 
 # ---- a rank that fails tells the others (the reference's worst habit is to hang on a worker's error, popgenWindows.py:456-460) ----
 _T_START = time.time()
+# The launch this process belongs to, once it is known: rank 0 makes it up (the exchange directory of the file communicator, a
+# digest of the RCCL unique id), the others learn it in the rendezvous.  A failure marker quotes it, and a marker that quotes
+# another launch's token is never believed (under a stable rendezvous name -- MASTER_ADDR / MASTER_PORT,
+# PG_RDZV_FILE -- the marker of a launch that failed seconds ago used to end a healthy one).
+_LAUNCH = {"token": None}
+_UNTOKENED_SLACK_S = 2.0
 
 
 class PeerFailed(RuntimeError):
@@ -111,13 +117,32 @@ def _failure_glob():
     return _rdzv_path() + ".failed_r"
 
 
+def set_launch_token(token):
+    _LAUNCH["token"] = None if token is None else str(token)
+
+
+def forget_own_marker(world):
+    """every rank, when it starts: the marker an earlier launch's rank of the same number left under this rendezvous name"""
+    try:
+        path = _failure_glob() + str(world.rank)
+        if os.path.getmtime(path) < _T_START:
+            os.remove(path)
+    except OSError:
+        pass
+
+
 def mark_failed(world, exc):
-    """leave `<rendezvous>.failed_r<rank>` with the reason (drivers: cli.guarded_main); PeerFailed is not marked again"""
-    if world.size <= 1 or isinstance(exc, PeerFailed):
+    """leave `<rendezvous>.failed_r<rank>` with the launch's token and the reason (drivers: cli.guarded_main).  A rank that leaves
+    because a peer failed leaves a marker too (the reason quotes the peer's), so that ranks which cannot see the first marker --
+    it was written before they started -- do not sit out PG_COMM_TIMEOUT; the first marker of a rank stays."""
+    if world.size <= 1:
         return
     try:
         path = _failure_glob() + str(world.rank)
+        if isinstance(exc, PeerFailed) and os.path.exists(path) and os.path.getmtime(path) >= _T_START:
+            return
         with open(path + ".tmp", "w") as f:
+            f.write("pg-failure token=%s start=%.3f\n" % (_LAUNCH["token"] or "-", _T_START))
             f.write("%s: %s" % (type(exc).__name__, str(exc)[:300]))
         os.replace(path + ".tmp", path)
     except OSError:
@@ -135,17 +160,40 @@ def clear_failures(world):
             pass
 
 
+def _read_marker(path):
+    """(token or None, reason) of a marker file"""
+    with open(path) as f:
+        text = f.read(600)
+    token = None
+    if text.startswith("pg-failure "):
+        head, _, text = text.partition("\n")
+        for field in head.split()[1:]:
+            if field.startswith("token=") and field != "token=-":
+                token = field[6:]
+    return token, text[:300]
+
+
 def peer_failure(world):
-    """"rank R failed: reason" of the first marker another rank of THIS launch has left, else None.  A marker older than two minutes
-    before this process started belongs to an earlier launch under the same rendezvous name and is ignored."""
+    """"rank R failed: reason" of the first marker another rank of THIS launch has left, else None.  A marker that quotes a launch
+    token counts only when it is this process's token (a rank that does not know its launch yet does not believe it: it is about
+    to learn the token, or rank 0 -- which has removed every older marker and therefore believes what it finds -- is about to leave
+    one of its own).  A marker without a token (a rank that failed before the rendezvous) counts when it is not older than this
+    process, give or take the seconds ranks of one launch start apart."""
     import glob
+    mine = _LAUNCH["token"]
     for path in sorted(glob.glob(_failure_glob() + "[0-9]*")):
         try:
             r = int(path[len(_failure_glob()):])
-            if r == world.rank or os.path.getmtime(path) < _T_START - 120.0:
+            if r == world.rank:
                 continue
-            with open(path) as f:
-                return "rank %d failed: %s" % (r, f.read()[:300])
+            mtime = os.path.getmtime(path)
+            token, reason = _read_marker(path)
+            if token is not None:
+                if token != mine and not (mine is None and world.rank == 0 and mtime >= _T_START - 1.0):
+                    continue
+            elif mtime < _T_START - (1.0 if world.rank == 0 else _UNTOKENED_SLACK_S):
+                continue
+            return "rank %d failed: %s" % (r, reason)
         except (OSError, ValueError):
             continue
     return None
@@ -178,6 +226,7 @@ class RcclComm:
         from .engine import Engine
         self.e, self.size, self.rank, self.world = engine, world.size, world.rank, world
         self.timeout_s = float(os.environ.get("PG_COMM_TIMEOUT", "300"))
+        forget_own_marker(world)
         if world.rank == 0:
             clear_failures(world)
         # RCCL prints a version banner on file descriptor 1 while it initialises; the drivers' stdout carries data (CSV, the
@@ -188,6 +237,8 @@ class RcclComm:
         os.dup2(2, 1)
         try:
             uid, path = exchange_unique_id(world, Engine.comm_unique_id)
+            import hashlib
+            set_launch_token("rccl-" + hashlib.sha1(bytes(uid)).hexdigest()[:20])
             self._guarded(engine.comm_setup, world.size, world.rank, uid)
             self._guarded(engine.comm_barrier)
         finally:
@@ -217,6 +268,7 @@ class RcclComm:
                 if why is not None and not done.is_set():
                     sys.stderr.write("rank %d: leaving the collective: %s\n" % (self.rank, why))
                     sys.stderr.flush()
+                    mark_failed(self.world, PeerFailed(why))
                     os._exit(3)
         th = threading.Thread(target=watch, daemon=True, name="collective-watchdog")
         th.start()
@@ -253,6 +305,7 @@ class FileComm:
             timeout_s = float(os.environ.get("PG_COMM_TIMEOUT", "300"))        # how long a rank waits for the others at an exchange
         self.size, self.rank, self.timeout_s, self.world = world.size, world.rank, timeout_s, world
         self._last_check = 0.0
+        forget_own_marker(world)
         if world.rank == 0:
             clear_failures(world)
         base = _rdzv_path()
@@ -261,6 +314,7 @@ class FileComm:
         t0 = time.time()
         if self.rank == 0:
             self.dir = tempfile.mkdtemp(prefix=os.path.basename(base) + ".d.", dir=os.path.dirname(base) or ".")
+            set_launch_token("dir-" + os.path.basename(self.dir))
             self._put(self.pointer, self.dir.encode())
             tokens = {}
             while len(tokens) < self.size - 1:
@@ -299,6 +353,7 @@ class FileComm:
                     with open(os.path.join(d, "go")) as f:
                         if json.load(f).get(str(self.rank)) == token:
                             self.dir = d
+                            set_launch_token("dir-" + os.path.basename(d))
                             return
             except (OSError, ValueError):
                 pass

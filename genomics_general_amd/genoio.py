@@ -142,11 +142,22 @@ class BgzfWriter:
         self.f.close()
         self.f = None
 
+    def abort(self):
+        """a failed run: the file is closed as it is -- what is still buffered is dropped and NO end-of-file member is written, so
+        that the truncated output does not pass for a finished BGZF file (htslib: "no EOF marker")"""
+        if self.f is not None:
+            self.f.close()
+            self.f = None
+        self.buf = bytearray()
+
     def __enter__(self):
         return self
 
-    def __exit__(self, *exc):
-        self.close()
+    def __exit__(self, exc_type, *exc):
+        if exc_type is not None:
+            self.abort()
+        else:
+            self.close()
 
 
 class BgzfSpan:

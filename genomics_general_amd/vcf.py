@@ -664,7 +664,7 @@ def parse_vcf_main(argv=None):
             sink.abort()
         if out is not None and out is not sys.stdout.buffer:
             try:
-                out.close()
+                (out.abort if hasattr(out, "abort") else out.close)()       # (BGZF: no end-of-file member behind a truncated output)
             except Exception:
                 pass
         raise

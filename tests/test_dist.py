@@ -693,6 +693,55 @@ def test_a_failing_rank_ends_the_whole_launch_within_seconds(comm, tmp_path):
     assert sum("Traceback" in e for e in errs) == 1, "the error must be spelled out once, by the rank that met it"
 
 
+def test_the_marker_of_an_earlier_failed_launch_does_not_end_a_healthy_one(tmp_path):
+    """under a stable rendezvous name a marker of a launch that failed ten seconds ago -- rank 1's, with that
+    launch's token or without any -- was believed by a rank of the next, healthy launch that started before this launch's rank 0
+    had cleared it.  Markers quote their launch's token now; one without a token must be as young as the process that reads it."""
+    import time
+    rdzv = str(tmp_path / "rdzv")
+    for name, body in (("1", "pg-failure token=dir-rdzv.d.old start=1.0\nValueError: the old error"), ("2", "ValueError: older format")):
+        with open(rdzv + ".failed_r" + name, "w") as f:
+            f.write(body)
+        os.utime(rdzv + ".failed_r" + name, (time.time() - 10, time.time() - 10))
+    procs = []
+    for rank in (1, 2, 0):                                   # rank 0 comes last, late
+        if rank == 0:
+            time.sleep(1.0)
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="3", PG_COMM="file", PG_RDZV_FILE=rdzv, PG_COMM_TIMEOUT="60")
+        procs.append((rank, subprocess.Popen([sys.executable, "-c", FILE_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for rank, p in procs:
+        try:
+            o, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        assert p.returncode == 0 and ("rank %d ok" % rank) in o.decode(), (rank, o.decode()[-2000:])
+    assert os.listdir(str(tmp_path)) == []
+
+
+def test_failure_markers_are_tied_to_the_launch(tmp_path, monkeypatch):
+    from genomics_general_amd import dist
+    monkeypatch.setenv("PG_RDZV_FILE", str(tmp_path / "rdzv"))
+    w0, w1, w2 = (dist.World(r, 3, r) for r in range(3))
+    dist.set_launch_token("dir-A")
+    dist.mark_failed(w1, ValueError("boom"))
+    assert dist.peer_failure(w2) == "rank 1 failed: ValueError: boom" and dist.peer_failure(w1) is None
+    dist.set_launch_token("dir-B")                          # another launch: not believed
+    assert dist.peer_failure(w2) is None
+    dist.set_launch_token(None)                             # before the rendezvous: rank 0 (it has cleared older markers) believes it
+    assert dist.peer_failure(w2) is None and dist.peer_failure(w0) == "rank 1 failed: ValueError: boom"
+    # a rank that leaves because of a peer leaves a marker too, but does not overwrite its own first one
+    dist.mark_failed(w2, dist.PeerFailed("rank 1 failed: ValueError: boom"))
+    assert "rank 1 failed" in dist.peer_failure(dist.World(1, 3, 1))
+    dist.mark_failed(w1, dist.PeerFailed("rank 2 failed: x"))
+    assert dist._read_marker(str(tmp_path / "rdzv") + ".failed_r1")[1] == "ValueError: boom"
+    # start-up: a rank removes its own marker when that is older than the process
+    old = str(tmp_path / "rdzv") + ".failed_r2"
+    os.utime(old, (dist._T_START - 5, dist._T_START - 5))
+    dist.forget_own_marker(w2)
+    assert not os.path.exists(old)
+
+
 GUARDED_GLOO = """
 class _Guarded(dist.RcclComm):
     def __init__(self, engine, world):

@@ -188,6 +188,17 @@ def test_tokenizer_errors(text, fmt, msg):
     assert ei.value.code == _lib.PG_ERR_PARSE and msg in str(ei.value)
 
 
+def test_positions_with_leading_zeros_and_nineteen_digits():
+    """int() of the reference (genomics.py:1884-1904) takes a zero-padded position; nineteen significant digits are
+    refused before the multiplication that would leave int64"""
+    lay = HapLayout(SampleData(indNames=["a", "b"]), ["a", "b"], "phased")
+    data = genoio.encode(b"chr1 0000000000000000000012 A/C G/T\nchr1 000 A/C G/T\nchr1 -0999999999999999999 A/A T/T\nchr1 +007 A/A T/T\n", lay)
+    assert list(data.pos) == [12, 0, -999999999999999999, 7]
+    for bad in (b"chr1 9999999999999999999 A/C G/T\n", b"chr1 01234567890123456789 A/C G/T\n"):
+        with pytest.raises(_lib.PopgenError, match="at most 18 digits"):
+            encode_text(bad, lay)
+
+
 def test_sampledata_mirror():
     sd = SampleData(indNames=["q"], popNames=["A", "B"], popInds=[["x", "y"], ["y", "z"]], ploidyDict={"q": 1, "x": 2, "y": 2, "z": 2})
     assert sd.indNames == ["q", "x", "y", "z"]

@@ -142,6 +142,36 @@ def test_bgzf_compress_walk_and_host_inflate_round_trip(tmp_path):
         genoio.bgzf_walk(b"\x1f\x8b\x08\x00" + bytes(30))
 
 
+def test_text_that_does_not_deflate_is_stored_and_a_failed_writer_leaves_no_eof_member(tmp_path):
+    """(i) a 65280-byte block of random bytes deflates to more than 64 KiB - 26: pg_bgzf_compress stores it (what
+    bgzip's block size is made for) instead of failing the call; (ii) BgzfWriter.abort(): a truncated output must not end in the
+    end-of-file member"""
+    rng = random.Random(11)
+    noise = bytes(rng.getrandbits(8) for _ in range(65280 * 2 + 1000)) + b"A/A\tA/T\n" * 20000
+    bz = genoio.bgzf_compress(noise)
+    assert gzip.decompress(bz.tobytes()) == noise
+    tab, used, n_text = genoio.bgzf_walk(bz)
+    assert used == len(bz) and n_text == len(noise) and int(tab[1].max()) <= 65536 - 26 and int(tab[1][0]) in (65285, 65300)      # (zlib itself falls back to stored blocks: four of them here)
+    assert genoio.bgzf_inflate(bz, tab).tobytes() == noise
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    path = str(tmp_path / "x.gz")
+    w = genoio.BgzfWriter(path)
+    w.write(b"chr1\t1\tA/A\n" * 10)
+    w.close()
+    assert open(path, "rb").read().endswith(eof)
+    w = genoio.BgzfWriter(path)
+    w.write(noise[:genoio.BgzfWriter.PIECE + 5])
+    w.abort()
+    w.close()                                                                 # (idempotent after abort)
+    raw = open(path, "rb").read()
+    assert len(raw) > 0 and not raw.endswith(eof)
+    with pytest.raises(RuntimeError):
+        with genoio.BgzfWriter(path) as w:
+            w.write(b"chr1\t1\tA/A\n")
+            raise RuntimeError("the run failed")
+    assert open(path, "rb").read() == b""
+
+
 @pytest.mark.parametrize("blk,want", [(900, 4000), (5000, 30000), (65280, 100000)])
 def test_read_span_cuts_blocks_behind_their_last_line_feed(blk, want, tmp_path):
     """BgzfFile.read_span: blocks of deflated members whose text = head + members' text, cut behind the last line feed; what follows
