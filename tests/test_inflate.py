@@ -160,7 +160,7 @@ def test_text_that_does_not_deflate_is_stored_and_a_failed_writer_leaves_no_eof_
     w.close()
     assert open(path, "rb").read().endswith(eof)
     w = genoio.BgzfWriter(path)
-    w.write(noise[:genoio.BgzfWriter.PIECE + 5])
+    w.write((noise * 60)[:genoio.BgzfWriter.PIECE + 5])
     w.abort()
     w.close()                                                                 # (idempotent after abort)
     raw = open(path, "rb").read()
