@@ -22,6 +22,7 @@ class PopgenError(RuntimeError):
 
 PG_ERR_ARG, PG_ERR_HIP, PG_ERR_NODEV, PG_ERR_PARSE, PG_ERR_RCCL, PG_ERR_STATE = -1, -2, -3, -4, -5, -6
 FMT = {"phased": 0, "pairs": 1, "haplo": 2, "diplo": 3}
+FMT_NARROW_OK = 0x100        # OR'ed into pg_encode_text's fmt: cells may hold fewer alleles than their column's slots
 K_PACK, K_PAIRWISE, K_POPDIST_FIN, K_SITESTATS, K_SYNTH, K_PAIRD, K_INDPAIR_FIN, K_RESULT_D2H, K_ORDERED = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KERNEL_NAMES = {K_PACK: "k_pack", K_PAIRWISE: "k_pairC", K_POPDIST_FIN: "k_popdist_fin",
                 K_SITESTATS: "k_sitestats", K_SYNTH: "k_synth", K_PAIRD: "k_pairD", K_INDPAIR_FIN: "k_indpair_fin",
@@ -75,6 +76,8 @@ SIGNATURES = {
                                 _i32p, C.c_int32, C.c_int32]),
     "pg_encode_text": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i8p, _i64p,
                                  _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
+    "pg_text_cell_widths": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, _i32p, _i32p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64)]),
     "pg_scaffold_runs": (C.c_int, [C.c_void_p, _i64p, _i32p, C.c_int64, _i64p, C.c_int64, C.POINTER(C.c_int64)]),
     "pg_count_lines": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "pg_usable_cpus": (C.c_int, []),
@@ -127,6 +130,7 @@ SIGNATURES = {
     "pg_kernel_time_reset": (C.c_int, [_P]),
     "pg_debug_address": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pg_debug_place": (C.c_int, [_P, C.c_int, C.c_uint64]),
+    "pg_debug_cu_split": (C.c_int, [_P, C.c_int]),
     "pg_set_scratch_limit": (C.c_int, [_P, C.c_int64]),
     "pg_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pg_comm_init": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p]),

@@ -42,8 +42,8 @@ IO_FLAGS = [
 PLOIDY_FLAGS = [
     (("--ploidy",), dict(type=int, nargs="+", help="Ploidy for each sample")),
     (("--ploidyFile",), dict(help="File with samples names and ploidy as columns")),
-    (("--inferPloidy",), dict(action="store_true", help="Ploidy is inferred from the cells of the first data row (the reference infers it "
-                                                         "window by window, NOT RECOMMENDED there)")),
+    (("--inferPloidy",), dict(action="store_true", help="Ploidy will be inferred in each window (NOT RECOMMENDED): one extra pass over the "
+                                                         "input looks at the cell widths; where they never change, they decide once")),
 ]
 
 
@@ -111,10 +111,18 @@ def _ploidy_dict(args, inds, haploid_list):
             return dict([[s[0], int(s[1])] for s in [ln.split() for ln in pf]])
     if args.inferPloidy:
         # The reference leaves the ploidy open and genoToAlignment takes the number of sequences splitSeq returns for the window
-        # (genomics.py:1110, 390-396), i.e. what the cell width says.  Here the widths of the first data row decide once for the
-        # whole file; a later cell of another width is a tokenizer error (the reference would zip-truncate the window to its
-        # shortest cell).
+        # (genomics.py:1108-1111, 390-396): per window and sample, what the window's shortest cell holds.  In the phased / pairs
+        # formats that is a matter of the cell widths of the whole input: one pass over the text (pg_text_cell_widths) finds the
+        # rows at which they change.  No change (the usual case): the widths decide once, every fast path stays.  Otherwise the
+        # run tokenises under the widest ploidies and computes every window under its own (Run, MultiLayoutBatch).
         header = getattr(args, "header", None) or (" ".join(args.headers) if getattr(args, "headers", None) else None)
+        if args.genoFormat in ("phased", "pairs") and not (args.genoFile and str(args.genoFile).endswith(".pgeno")):
+            if args.genoFile is None:
+                args.genoFile = _spool_stdin()                   # (the pass over the widths, then the run itself, read it)
+            seg = genoio.scan_ploidy_segments(args.genoFile, args.genoFormat, list(inds), header)
+            if len(seg.starts) > 1:
+                args._ploidy_segments = seg
+            return seg.max_ploidy()
         inferred = genoio.first_row_ploidy(args.genoFile, args.genoFormat, header)
         for s in inds:
             assert s in inferred, "sample %s is not in the genotype file header" % s
@@ -123,6 +131,23 @@ def _ploidy_dict(args, inds, haploid_list):
     for s in haploid_list or []:
         d[s] = 1
     return d
+
+
+def _spool_stdin():
+    """--inferPloidy on a piped input: the text is needed twice (the cell widths of the whole input, then the run), so it goes into
+    a temporary file first, removed when the process ends"""
+    import atexit
+    import os
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="pg_stdin_", suffix=".geno")
+    atexit.register(lambda: os.path.exists(path) and os.remove(path))
+    with os.fdopen(fd, "wb") as f:
+        while True:
+            piece = genoio.STDIN.read(64 << 20)
+            if not piece:
+                break
+            f.write(piece)
+    return path
 
 
 def _make_windows(p, data, minSites, coords_keep=4):
@@ -197,6 +222,14 @@ class Run:
                              "text is inflated on the GPU, about a hundred times faster\n" % args.genoFile)
         self.layout = HapLayout(sampleData, names, args.genoFormat)
         self._infer_ploidy = bool(getattr(args, "inferPloidy", False))
+        # --inferPloidy on a file whose cell widths change (genoio.PloidySegments): self.layout holds the widest ploidies, the rows
+        # are tokenised under it by the host tokenizer (narrower cells leave their other slots missing) and stay on the host;
+        # batch() computes every window under the layout of its own ploidies (MultiLayoutBatch).  Every rank reads the whole
+        # input, the windows of a block are split over the ranks.
+        self._segments = getattr(args, "_ploidy_segments", None)
+        self._file_names = names
+        if self._segments is not None:
+            shardable = False
         self._wparams = dict(wparams, include=args.include, exclude=args.exclude)
         self._minSites, self._coords_keep, self._windows_fn = minSites, coords_keep, windows_fn
         self._streamer = None
@@ -218,7 +251,7 @@ class Run:
         # while the device context is still being created
         self._first_block = None
         if (self.world.size == 1 and self._block_bytes is not None and isinstance(getattr(self._reader, "f", None), genoio.BgzfFile)
-                and hasattr(Engine, "tokenize_submit_bgzf") and device_tokenizer_takes(self.layout)
+                and self._segments is None and hasattr(Engine, "tokenize_submit_bgzf") and device_tokenizer_takes(self.layout)
                 and os.environ.get("PG_GPU_TOKENIZER", "1") != "0" and os.environ.get("PG_BGZF_DEVICE", "1") != "0"):
             self._reader.spans = True
             box = {}
@@ -329,7 +362,8 @@ class Run:
                 self._explain_ploidy_error(exc)
                 raise
             return
-        piped = hasattr(eng, "upload_async")
+        seg = self._segments
+        piped = hasattr(eng, "upload_async") and seg is None
         pitch = eng.row_pitch if piped else None
         alloc = eng.pinned.empty if piped else None
         keep_packed = bool(piped and getattr(self._reader, "packed", False) and not os.environ.get("PG_HOST_UNPACK"))
@@ -362,6 +396,7 @@ class Run:
         def prepare():
             """tokenise block after block behind the rows carried over from the previous one; find the windows that are certain"""
             carry = None
+            rows_done = 0                     # data rows of the input in front of the current block
             try:
                 while True:
                     t0 = time.perf_counter()
@@ -371,11 +406,15 @@ class Run:
                     final = self._streamer is None or len(body) == 0
                     tm = {"read_s": time.perf_counter() - t0}             # time this stage waited for the reader
                     t0 = time.perf_counter()
+                    kw = dict(narrow_ok=True) if seg is not None else {}
                     block = self._reader.to_geno(body, self.layout, n_threads=self._tok_threads,
                                                  head_rows=carry.n_sites if carry is not None else 0, pitch=pitch, alloc=alloc,
-                                                 keep_packed=keep_packed)
+                                                 keep_packed=keep_packed, **kw)
                     del body
+                    row0 = rows_done - (carry.n_sites if carry is not None else 0)    # index, among the input's data rows, of row 0 of `data`
+                    rows_done += int(block.n_sites)
                     data = genoio.concat(carry, block)
+                    data.row0 = row0
                     tm["tokenize_s"] = time.perf_counter() - t0
                     t0 = time.perf_counter()
                     if self._streamer is not None:
@@ -450,7 +489,7 @@ class Run:
                 t0 = time.perf_counter()
                 if piped:
                     eng.upload_wait()
-                else:
+                elif seg is None:
                     eng.load_sites(cur["data"].gt[cur["s0"]:cur["s1"]])
                 self.timing["upload_s"] += time.perf_counter() - t0 + cur["t_stage"]
                 self.timing["engine_and_upload_s"] += time.perf_counter() - t0 + cur["t_stage"]
@@ -502,14 +541,14 @@ class Run:
         return box["block"]
 
     def _explain_ploidy_error(self, exc):
-        """--inferPloidy: the reference infers the ploidy of every sample WINDOW BY WINDOW from the shortest cell the window holds
-        (genoToAlignment with ploidy None, genomics.py:1110; splitSeq zips the cells, genomics.py:390-396), so a file whose cell
-        widths change gives windows of different haplotype counts there.  Here the first data row decides for the whole file: a
-        later cell of another width must not pass silently."""
+        """--inferPloidy in the haplo / diplo formats (one character per cell whatever the ploidy, genomics.py:390-396) and on `.pgeno`
+        input: nothing to infer from, the format decides; a cell of another width is an error here as it is a KeyError there.  (In
+        the phased / pairs formats the cell widths of the whole input are read first -- genoio.scan_ploidy_segments -- and windows
+        are computed under their own ploidies, so no such error arises.)"""
         if self._infer_ploidy and exc.code == _lib.PG_ERR_PARSE and "ploidy" in str(exc):
-            raise SystemExit("--inferPloidy: %s.\nThis engine infers the ploidy once, from the cell widths of the first data row; the "
-                             "reference infers it window by window (NOT RECOMMENDED there, popgenWindows.py:190).  A file whose cell "
-                             "widths change needs explicit ploidies: --ploidy / --ploidyFile / --haploid." % str(exc))
+            raise SystemExit("--inferPloidy: %s.\nIn the %s format a cell is one character per genotype; a cell of another width "
+                             "cannot be read.  Give explicit ploidies (--ploidy / --ploidyFile / --haploid) if the file mixes formats."
+                             % (str(exc), self.layout.genoFormat))
 
     def _device_tokenizer(self):
         """K0 on the device (Engine.tokenize_text; PG_GPU_TOKENIZER=0 keeps the host tokenizer): plain or gzipped text in one of the
@@ -517,6 +556,8 @@ class Run:
         of blanks, carriage returns, a cell of another width) is found by the kernels block by block, and such a block goes
         through the host tokenizer."""
         import os
+        if self._segments is not None:
+            return False
         if getattr(self._reader, "packed", False):
             # `.pgeno` with raw cells (codec none): the cells go from the file to the device through the same staging threads and
             # are expanded there (pg_stage_file / pg_unpack_staged); deflated cells are inflated by host threads (chunks())
@@ -852,7 +893,26 @@ class Run:
 
     def batch(self, mask):
         """WindowBatch over this rank's windows selected by boolean `mask`."""
+        if self._segments is not None:
+            return MultiLayoutBatch(self, mask)
         return self.engine.batch(self.lo[mask], self.hi[mask])
+
+    def layout_for(self, ploidy):
+        """(HapLayout, columns of self.layout's rows it takes) for the ploidies `ploidy[i]` of self._segments.inds[i]: an individual's
+        slots under fewer alleles are the first ones of its slots under self.layout (splitSeq zips the cells, genomics.py:390-396:
+        what a shorter cell in the window leaves of the others is their first characters)"""
+        key = bytes(np.asarray(ploidy, dtype=np.int32).data)
+        cache = self.__dict__.setdefault("_layouts", {})
+        if key not in cache:
+            sd0 = self.layout.sampleData
+            pl = dict(sd0.ploidy)
+            pl.update({nm: int(v) for nm, v in zip(self._segments.inds, ploidy)})
+            sd = SampleData(indNames=list(sd0.indNames), popNames=list(sd0.popNames), popInds=[list(sd0.popInds[p]) for p in sd0.popNames],
+                            popNumbers=list(sd0.popNumbers), ploidyDict=pl)
+            lay = HapLayout(sd, self._file_names, self.layout.genoFormat)
+            cols = np.array([self.layout.ind_slots[nm][k] for nm in lay.ind_order for k in range(len(lay.ind_slots[nm]))], dtype=np.int64)
+            cache[key] = (lay, cols)
+        return cache[key]
 
     def gather(self, table):
         """the statistics of ALL windows of the current chunk on every rank (replicated ingestion: one all-gather per chunk);
@@ -922,6 +982,72 @@ def _fmt_cell(v):
 
 WIDE_ROW_COLS = 256              # popgenWindows.py: rows of at least this many float columns (and no other kind) are formatted natively
 NP_MAX_SITES = 256               # csrc/pg_internal.h PG_NP_MAX_SITES: windows of up to this many sites get their sums in NumPy's order anyway
+
+
+class MultiLayoutBatch:
+    """--inferPloidy on an input whose cell widths change: the selected windows of the current chunk, grouped by the ploidies the
+    reference would infer for them (per window and sample: the fewest alleles a cell of the sample holds in the window,
+    genomics.py:1108-1111, 390-396).  Any WindowBatch method called on it runs group by group -- the engine gets the group's layout
+    (pg_set_samples: other haplotype counts, names and sort order), the group's rows with the columns that layout keeps, and the
+    group's windows -- and the results are put back in window order.  Results: arrays over the windows, dictionaries / tuples of
+    such (the keys are population and individual names, the same under every layout)."""
+
+    def __init__(self, run, mask):
+        self.run = run
+        self.lo, self.hi = run.lo[mask], run.hi[mask]            # rows of run.data, counted from run.site0
+        g = int(run.data.row0) + int(run.site0)
+        pl = run._segments.window_ploidy(g + self.lo, g + self.hi)
+        groups = {}
+        for w in range(len(self.lo)):
+            groups.setdefault(pl[w].tobytes(), []).append(w)
+        self.groups = [(np.frombuffer(k, dtype=np.int32), np.array(v, dtype=np.int64)) for k, v in groups.items()]
+        self.n = len(self.lo)
+
+    def _each(self):
+        run, eng = self.run, self.run.engine
+        for ploidy, sel in self.groups:
+            lay, cols = run.layout_for(ploidy)
+            lo, hi = self.lo[sel], self.hi[sel]
+            r0, r1 = int(lo.min()), int(hi.max())
+            rows = np.ascontiguousarray(run.data.gt[run.site0 + r0:run.site0 + r1][:, cols])
+            first = eng.__dict__.get("_pair_first", "slot")
+            eng.set_layout(lay)
+            if first != "slot" and hasattr(eng, "set_pair_first"):
+                eng.set_pair_first(first)
+            eng.load_sites(rows)
+            yield sel, eng.batch(lo - r0, hi - r0)
+
+    def _merge(self, parts, pad=None):
+        first = parts[0][1]
+        if isinstance(first, dict):
+            return {k: self._merge([(sel, r[k]) for sel, r in parts], pad) for k in first}
+        if isinstance(first, tuple):
+            return tuple(self._merge([(sel, r[i]) for sel, r in parts], pad) for i in range(len(first)))
+        if isinstance(first, list) and all(isinstance(x, str) for x in first):
+            return first                                          # column names
+        arrs = [(sel, np.asarray(r)) for sel, r in parts]
+        for sel, a in arrs:
+            if a.ndim < 1 or a.shape[0] != len(sel):
+                raise NotImplementedError("a result that is not an array over the windows, under --inferPloidy with changing ploidy")
+        trail = tuple(max(a.shape[d] for _, a in arrs) for d in range(1, arrs[0][1].ndim))
+        if pad is None and any(a.shape[1:] != trail for _, a in arrs):
+            raise NotImplementedError("a per-haplotype result under --inferPloidy with changing ploidy")
+        out = np.full((self.n,) + trail, 0 if pad is None else pad, dtype=np.result_type(*[a.dtype for _, a in arrs]))
+        for sel, a in arrs:
+            out[(sel,) + tuple(slice(0, d) for d in a.shape[1:])] = a
+        return out
+
+    def hapCalled(self):
+        """called sites per haplotype; the windows' haplotype counts differ: padded with the largest integer (distMat.py:40 takes the minimum)"""
+        return self._merge([(sel, b.hapCalled()) for sel, b in self._each()], pad=np.iinfo(np.int64).max)
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+
+        def call(*args, **kwargs):
+            return self._merge([(sel, getattr(b, name)(*args, **kwargs)) for sel, b in self._each()])
+        return call
 
 
 def _near_rounding_tie(v, digits, ratio=False, difference=False):

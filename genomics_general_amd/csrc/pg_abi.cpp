@@ -530,6 +530,32 @@ extern "C" int pg_debug_place(pg_ctx *c, int which, uint64_t lead_bytes) {
     return PG_OK;
 }
 
+// CU partition experiment (tools/cu_split_sweep.py; VERDICT round 5 #4a): ctx->stream (pair kernels, finalisers) is recreated on
+// `pair_cus_per_xcd` compute units of every XCD, ctx->stream2 (the pack kernel of the two-stream pipeline, PG_OVERLAP=1) on the
+// others; 0 = plain streams again.  (A queue's CU mask is dealt out to the XCDs bit by bit: bit i = CU i / 8 of XCD i % 8.)
+extern "C" int pg_debug_cu_split(pg_ctx *c, int pair_cus_per_xcd) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (pair_cus_per_xcd < 0 || pair_cus_per_xcd > 31) return pg_fail(PG_ERR_ARG, "pg_debug_cu_split: 0 ... 31 compute units per XCD");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    hipStream_t a = nullptr, b = nullptr;
+    if (pair_cus_per_xcd == 0) {
+        HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+    } else {
+        uint32_t ma[8], mb[8];
+        for (int w = 0; w < 8; ++w) { ma[w] = 0u; mb[w] = 0u; }
+        for (int i = 0; i < 256; ++i) ((i / 8 < pair_cus_per_xcd) ? ma : mb)[i >> 5] |= 1u << (i & 31);
+        HIPCHK(hipExtStreamCreateWithCUMask(&a, 8, ma));
+        HIPCHK(hipExtStreamCreateWithCUMask(&b, 8, mb));
+    }
+    (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->stream2);
+    c->stream = a;
+    c->stream2 = b;
+    return PG_OK;
+}
+
 // ---- kernel timing ----------------------------------------------------------------------------------
 // timing events are pooled: creating a pair per launch costs more host time than a small kernel
 static int event_get(pg_ctx *c, hipEvent_t *e) {
@@ -716,8 +742,9 @@ static int pairwise_batches(pg_ctx *c, const int64_t *lo, const int64_t *hi, int
     // (one batch uses one slot: it may take the whole scratch budget; sub-batches alternate between the two slots)
     const bool multi = total_words_all * word_bytes + (int64_t)n_win * mat_bytes > c->scratch_limit;
     const bool two_streams = getenv("PG_OVERLAP") != nullptr;
+    const int n_sub = two_streams && atoi(getenv("PG_OVERLAP")) >= 2 ? atoi(getenv("PG_OVERLAP")) : 8;      // (PG_OVERLAP=n: n sub-batches)
     const bool split = multi || two_streams;
-    int64_t target_words = two_streams ? std::max<int64_t>(total_words_all / 8, 32768) : total_words_all;
+    int64_t target_words = two_streams ? std::max<int64_t>(total_words_all / n_sub, 32768) : total_words_all;
     for (int k = 0; k < 2; ++k) {
         if (!c->slot[k].packed) HIPCHK(hipEventCreateWithFlags(&c->slot[k].packed, hipEventDisableTiming));
         if (!c->slot[k].consumed) HIPCHK(hipEventCreateWithFlags(&c->slot[k].consumed, hipEventDisableTiming));

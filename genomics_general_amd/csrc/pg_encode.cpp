@@ -41,6 +41,7 @@ struct Shared {
     const char *buf;
     size_t len;
     int fmt, n_cols, max_ploidy, n_hap;
+    bool narrow_ok;              // PG_FMT_NARROW_OK: a cell may hold fewer alleles than its column's slots (the rest stay missing)
     const int32_t *col_slot, *col_ploidy;
     int8_t *gt;
     int64_t *pos;
@@ -116,14 +117,16 @@ void parse_range(Shared &sh, const char *b, const char *e, int64_t row) {
                 if (pl <= 0) continue;
                 const int32_t *slots = sh.col_slot + (size_t)c * sh.max_ploidy;
                 switch (sh.fmt) {
-                    case PG_FMT_PHASED:
-                        if (w != 2 * pl - 1) { set_err(sh, "Sample ploidy doesn't match number of sequences (cell width)", row, c); return; }
-                        for (int k = 0; k < pl; ++k) out[slots[k]] = (int8_t)T.base[(uint8_t)c0[2 * k]];
+                    case PG_FMT_PHASED: {
+                        const int have = (w + 1) / 2;                        // splitSeq: every other character (genomics.py:390-396)
+                        if (w != 2 * pl - 1 && !(sh.narrow_ok && have < pl)) { set_err(sh, "Sample ploidy doesn't match number of sequences (cell width)", row, c); return; }
+                        for (int k = 0; k < (have < pl ? have : pl); ++k) out[slots[k]] = (int8_t)T.base[(uint8_t)c0[2 * k]];
                         break;
+                    }
                     case PG_FMT_PAIRS:
                     case PG_FMT_HAPLO:
-                        if (w != pl) { set_err(sh, "Sample ploidy doesn't match number of sequences (cell width)", row, c); return; }
-                        for (int k = 0; k < pl; ++k) out[slots[k]] = (int8_t)T.base[(uint8_t)c0[k]];
+                        if (w != pl && !(sh.narrow_ok && w < pl)) { set_err(sh, "Sample ploidy doesn't match number of sequences (cell width)", row, c); return; }
+                        for (int k = 0; k < (w < pl ? w : pl); ++k) out[slots[k]] = (int8_t)T.base[(uint8_t)c0[k]];
                         break;
                     default:  // PG_FMT_DIPLO
                         if (w != 1 || pl != 2) { set_err(sh, "Sample ploidy doesn't match number of sequences (diplo cell)", row, c); return; }
@@ -267,6 +270,8 @@ extern "C" int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, 
                               int32_t *scaf_len, int64_t cap_sites, int64_t *n_sites_out, int n_threads) {
     if ((!buf && len) || !col_slot || !col_ploidy || !n_sites_out) return pg_fail(PG_ERR_ARG, "pg_encode_text: null argument");
     if (cap_sites > 0 && (!gt_out || !pos_out || !scaf_off || !scaf_len)) return pg_fail(PG_ERR_ARG, "pg_encode_text: null output");
+    const bool narrow_ok = (fmt & PG_FMT_NARROW_OK) != 0;
+    fmt &= ~PG_FMT_NARROW_OK;
     if (fmt < PG_FMT_PHASED || fmt > PG_FMT_DIPLO) return pg_fail(PG_ERR_ARG, "unknown genotype format %d", fmt);
     if (n_cols < 0 || max_ploidy < 1 || n_hap < 1) return pg_fail(PG_ERR_ARG, "bad column description");
     for (int c = 0; c < n_cols; ++c) {
@@ -302,6 +307,7 @@ extern "C" int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, 
     for (int t = 0; t < nt; ++t) base[t + 1] = base[t] + cnt[t];
     if (base[nt] > cap_sites) return pg_fail(PG_ERR_ARG, "text holds %lld rows but output capacity is %lld", (long long)base[nt], (long long)cap_sites);
     Shared sh;
+    sh.narrow_ok = narrow_ok;
     sh.buf = buf; sh.len = len; sh.fmt = fmt; sh.n_cols = n_cols; sh.max_ploidy = max_ploidy; sh.n_hap = n_hap;
     sh.col_slot = col_slot; sh.col_ploidy = col_ploidy; sh.gt = gt_out; sh.pos = pos_out; sh.scaf_off = scaf_off;
     sh.scaf_len = scaf_len; sh.cap = cap_sites; sh.err = 0; sh.msg[0] = 0;
@@ -312,6 +318,92 @@ extern "C" int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, 
     }
     if (sh.err.load()) return pg_fail(PG_ERR_PARSE, "%s", sh.msg);
     *n_sites_out = base[nt];
+    return PG_OK;
+}
+
+// --inferPloidy (genomics.py:1108-1111: the reference takes a sample's ploidy in a window from the cells the window holds): the
+// widths of the watched columns' cells, row by row, reported as the rows at which they change.  state[n_cols] carries the widths
+// of the last data row from one buffer of whole lines to the next (-1 in every watched column: no row yet); the first data row
+// after such a state is always reported.  A row with fewer cells than columns keeps the missing columns' widths (the tokenizer
+// names that row).  change_width_out[k][n_cols] holds the widths from row change_row_out[k] (index among the buffer's data rows)
+// on; unwatched columns 0.  *n_changes_out is the true count also when it exceeds cap (call again with more room and the same
+// state as before: state is only advanced when everything fitted).
+extern "C" int pg_text_cell_widths(const char *buf, size_t len, int n_cols, const int32_t *col_watch, int32_t *state,
+                                   int64_t *change_row_out, int32_t *change_width_out, int64_t cap, int64_t *n_changes_out,
+                                   int64_t *n_rows_out) {
+    if ((!buf && len) || !col_watch || !state || !n_changes_out || !n_rows_out || n_cols < 0 || (cap > 0 && (!change_row_out || !change_width_out)))
+        return pg_fail(PG_ERR_ARG, "pg_text_cell_widths: bad argument");
+    int nt = pg_host_threads();
+    if (nt < 1) nt = 1;
+    if ((size_t)nt > len / (1 << 20) + 1) nt = (int)(len / (1 << 20) + 1);
+    const std::vector<size_t> cut = line_cuts(buf, len, nt);
+    struct Part { int64_t rows = 0; std::vector<int64_t> at; std::vector<int32_t> w; std::vector<int32_t> last; };
+    std::vector<Part> part((size_t)nt);
+    auto work = [&](int t) {
+        Part &P = part[(size_t)t];
+        std::vector<int32_t> cur((size_t)n_cols, -1), line((size_t)n_cols);
+        const char *b = buf + cut[(size_t)t], *e = buf + cut[(size_t)t + 1];
+        while (b < e) {
+            const char *nl = static_cast<const char *>(memchr(b, '\n', (size_t)(e - b)));
+            const char *le = nl ? nl : e;
+            if (data_line(b, le)) {
+                const char *p = b;
+                for (int f = 0; f < 2; ++f) {                       // scaffold, position
+                    while (p < le && is_ws(*p)) ++p;
+                    while (p < le && !is_ws(*p)) ++p;
+                }
+                bool differs = false;
+                for (int c = 0; c < n_cols; ++c) {
+                    while (p < le && is_ws(*p)) ++p;
+                    const char *c0 = p;
+                    while (p < le && !is_ws(*p)) ++p;
+                    const int32_t w = col_watch[c] ? (p > c0 ? (int32_t)(p - c0) : cur[(size_t)c]) : 0;
+                    line[(size_t)c] = w;
+                    differs |= w != cur[(size_t)c];
+                }
+                if (differs) {
+                    P.at.push_back(P.rows);
+                    P.w.insert(P.w.end(), line.begin(), line.end());
+                    cur = line;
+                }
+                ++P.rows;
+            }
+            b = le + 1;
+        }
+        P.last = cur;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    // the parts one after the other: a part's first report is dropped when its widths are those of the row in front of it
+    std::vector<int32_t> cur(state, state + n_cols);
+    for (int c = 0; c < n_cols; ++c)
+        if (!col_watch[c]) cur[(size_t)c] = 0;
+    int64_t n = 0, rows = 0;
+    for (int t = 0; t < nt; ++t) {
+        const Part &P = part[(size_t)t];
+        for (size_t k = 0; k < P.at.size(); ++k) {
+            const int32_t *w = P.w.data() + k * (size_t)n_cols;
+            // (a part starts from "unknown": a column it never saw a cell of still reads -1 there -- keep what is known)
+            std::vector<int32_t> full(w, w + n_cols);
+            for (int c = 0; c < n_cols; ++c)
+                if (full[(size_t)c] < 0) full[(size_t)c] = cur[(size_t)c];
+            if (full == cur) continue;
+            if (n < cap) {
+                change_row_out[n] = rows + P.at[k];
+                memcpy(change_width_out + (size_t)n * n_cols, full.data(), (size_t)n_cols * sizeof(int32_t));
+            }
+            ++n;
+            cur = full;
+        }
+        rows += P.rows;
+    }
+    *n_changes_out = n;
+    *n_rows_out = rows;
+    if (n <= cap) memcpy(state, cur.data(), (size_t)n_cols * sizeof(int32_t));
     return PG_OK;
 }
 

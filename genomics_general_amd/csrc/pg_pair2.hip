@@ -474,7 +474,7 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
                                                const int64_t *__restrict__ win_hi, const int64_t *__restrict__ goff,
                                                const int64_t *__restrict__ vgoff, uint32_t *__restrict__ Vp, int NPv,
                                                uint32_t *__restrict__ XV, int NP, int32_t *__restrict__ nw,
-                                               int32_t *__restrict__ mismatch, int capg, int grp, int fq) {
+                                               int32_t *__restrict__ mismatch, int capg, int grp, int fq, int perm) {
     constexpr int NWAVE = TPB / 64;
     constexpr int VN = DIP ? 2 : 4;                      // uint4 of called plane per thread and word quadruple
     const int FQ = fq, xc = (PACK_CELLS - fq * VN) / 2;  // quadruples per burst of the called plane; virtual-site words per burst  // quadruples per burst of the called plane; virtual-site words per burst
@@ -483,7 +483,10 @@ __global__ __launch_bounds__(TPB) void k_pack3(const int8_t *__restrict__ gt, in
     __shared__ uint4 stage[BURST ? PACK_CELLS * TPB : 1];
     uint4 *const stage_v = stage, *const stage_x = stage + FQ * VN * TPB;
     int nq = 0, nxs = 0, wq_first = 0;                   // staged quadruples / virtual-site words (block-uniform), first staged quadruple
-    const int b = blockIdx.y, g = blockIdx.x;
+    // perm (coprime with the number of windows, 1 = the windows in order): blocks that run at the same time -- consecutive
+    // blockIdx.y -- work on windows `perm` apart, i.e. on rows and planes spread over the whole batch instead of one moving
+    // stretch of it
+    const int b = (int)(((unsigned long long)blockIdx.y * (unsigned)perm) % gridDim.y), g = blockIdx.x;
     const int64_t lo = win_lo[b], hi = win_hi[b];
     const int W = (int)((hi - lo + 31) >> 5);
     const int w_begin = g * grp;
@@ -720,10 +723,20 @@ static void launch_pack2(hipStream_t st, int threads, dim3 grid, const int8_t *g
     // PG_PACK2=1 forces k_pack2 (A/B runs and tests).
     const bool force2 = getenv("PG_PACK2") != nullptr;
     if (threads <= 1024 && !force2) {
-#define PG_PACK3B(T, B) hipLaunchKernelGGL((k_pack3<T, DIP, B>), grid, dim3(T), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp, fq)
+#define PG_PACK3B(T, B) hipLaunchKernelGGL((k_pack3<T, DIP, B>), grid, dim3(T), 0, st, gt, S, win_lo, win_hi, goff, vgoff, Vp, NPv, XV, NP, nw, mismatch, capg, grp, fq, perm)
 #define PG_PACK3(T) PG_PACK3B(T, 0)
         // quadruples of the called plane per burst (the rest of the 24 LDS cells per thread holds virtual-site words)
         const int fq = DIP ? 8 : 4;
+        // PG_PACK_PERM=k (experiment): windows in the order 0, P, 2P, ... (mod n), P the number coprime with n next to n / k
+        int perm = 1;
+        if (const char *pe = getenv("PG_PACK_PERM")) {
+            const int k = atoi(pe), n = (int)grid.y;
+            if (k > 1 && n > 2 * k) {
+                auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+                perm = n / k;
+                while (gcd(perm, n) != 1) ++perm;
+            }
+        }
         const bool burst = getenv("PG_PACK_BURST") == nullptr || atoi(getenv("PG_PACK_BURST")) != 0;       // (0: A/B runs, tests)
         if (threads <= 64 && burst) PG_PACK3B(64, 1);
         else if (threads <= 128 && burst) PG_PACK3B(128, 1);

@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import check
 
 
-def encode_text(buf, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, full_out=None):
+def encode_text(buf, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, full_out=None, narrow_ok=False):
     """K0 host tokenizer.  buf: bytes of complete `.geno` data lines (no header).
     Returns (gt int8 [L][pitch or n_hap] in slot order, pos int64 [L], scaf_off int64 [L], scaf_len int32 [L]).
     head_rows > 0: gt and pos are views into arrays with that many spare rows in front (gt.base / pos.base), so that a
@@ -42,7 +42,9 @@ def encode_text(buf, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, f
     soff = np.zeros(cap, dtype=np.int64)
     slen = np.zeros(cap, dtype=np.int32)
     got = C.c_int64(0)
-    check(L.pg_encode_text(ptr, nbytes, _lib.FMT[layout.genoFormat], len(layout.col_ploidy), layout.max_ploidy,
+    # narrow_ok: a cell may hold fewer alleles than its column's ploidy (rows tokenised under the widest layout of a file whose
+    # ploidy changes along it: --inferPloidy)
+    check(L.pg_encode_text(ptr, nbytes, _lib.FMT[layout.genoFormat] | (_lib.FMT_NARROW_OK if narrow_ok else 0), len(layout.col_ploidy), layout.max_ploidy,
                            np.ascontiguousarray(layout.col_slot), layout.col_ploidy, width, gt, pos, soff, slen,
                            cap, C.byref(got), n_threads))
     k = int(got.value)

@@ -764,10 +764,10 @@ class BlockReader:
         elif end[0] < bz.size:
             bz.set_stop(*end)
 
-    def to_geno(self, body, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, keep_packed=False):
+    def to_geno(self, body, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, keep_packed=False, narrow_ok=False):
         if isinstance(body, BgzfSpan):
             body = bytes(body)
-        return encode(body, layout, n_threads, head_rows, pitch, alloc)
+        return encode(body, layout, n_threads, head_rows, pitch, alloc, narrow_ok)
 
     def close(self):
         if self.mm is not None:
@@ -1342,6 +1342,76 @@ def first_row_ploidy(path, fmt, header_line=None):
     return {nm: (1 if fmt == "haplo" else 2) for nm in names}
 
 
+class PloidySegments:
+    """--inferPloidy on a file whose cell widths change: `starts[k]` = index (among the file's data rows) of the first row of
+    segment k, `ploidy[k][i]` = what the cells of individual `inds[i]` hold there.  The reference infers the ploidy of a sample
+    per window, from the shortest cell the window holds (genoToAlignment with ploidy None, genomics.py:1108-1111; splitSeq zips
+    the cells, 390-396): `window_ploidy(a, b)` = the minimum over the segments that rows [a, b) touch."""
+
+    def __init__(self, inds, starts, ploidy):
+        self.inds, self.starts, self.ploidy = list(inds), np.asarray(starts, dtype=np.int64), np.asarray(ploidy, dtype=np.int32)
+
+    def max_ploidy(self):
+        return {nm: int(v) for nm, v in zip(self.inds, self.ploidy.max(axis=0))}
+
+    def window_ploidy(self, a, b):
+        """int32 [n_windows][n_inds] for the global data-row ranges [a[w], b[w]) (an empty range: the segment row a[w] would be in)"""
+        a, b = np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64)
+        s0 = np.maximum(np.searchsorted(self.starts, a, side="right") - 1, 0)
+        s1 = np.maximum(np.searchsorted(self.starts, np.maximum(b - 1, a), side="right") - 1, 0)
+        out = self.ploidy[s0].copy()
+        for w in np.flatnonzero(s1 > s0):
+            out[w] = self.ploidy[s0[w]:s1[w] + 1].min(axis=0)
+        return out
+
+
+def scan_ploidy_segments(path, fmt, inds, header_line=None, block_bytes=256 << 20):
+    """PloidySegments of a text input (plain, gzip or BGZF) in the phased / pairs formats: one pass of pg_text_cell_widths over the
+    whole file (host threads; the widths of the other columns are not looked at)."""
+    rd = BlockReader(path)
+    try:
+        names = header_line.split()[2:] if header_line else rd.read_header().decode("utf-8", "replace").split()[2:]
+        col = {}
+        for k, nm in enumerate(names):
+            col.setdefault(nm, k)
+        for nm in inds:
+            if nm not in col:
+                raise AssertionError("sample %s is not in the genotype file header" % nm)
+        n_cols = len(names)
+        watch = np.zeros(n_cols, dtype=np.int32)
+        watch[[col[nm] for nm in inds]] = 1
+        state = np.full(n_cols, -1, dtype=np.int32)
+        L = _lib.lib()
+        starts, widths, rows = [], [], 0
+        while True:
+            body = rd.read_block(block_bytes)
+            if len(body) == 0:
+                break
+            ptr, nbytes, _keep = _lib.text_ptr(body)
+            cap = 64
+            while True:
+                at, w = np.zeros(cap, dtype=np.int64), np.zeros((cap, max(n_cols, 1)), dtype=np.int32)
+                n, nr = C.c_int64(0), C.c_int64(0)
+                check(L.pg_text_cell_widths(ptr, nbytes, n_cols, watch, state, at, w, cap, C.byref(n), C.byref(nr)))
+                if n.value <= cap:
+                    break
+                cap = int(n.value)
+            for k in range(int(n.value)):
+                starts.append(rows + int(at[k]))
+                widths.append(w[k, [col[nm] for nm in inds]].copy())
+            rows += int(nr.value)
+            del body
+    finally:
+        rd.close()
+    if not starts:                                           # no data row at all
+        return PloidySegments(inds, [0], [[1 if fmt == "haplo" else 2] * len(inds)])
+    widths = np.array(widths, dtype=np.int32)
+    # splitSeq (genomics.py:390-396): phased cells hold their alleles at every other character, pairs one per character
+    ploidy = (widths + 1) // 2 if fmt == "phased" else widths
+    keep = [0] + [k for k in range(1, len(starts)) if not np.array_equal(ploidy[k], ploidy[k - 1])]
+    return PloidySegments(inds, [starts[k] for k in keep], ploidy[keep])
+
+
 def split_header(data, header_line=None):
     """(sample names, data bytes after the header).  With --header the file has no header line
     (GenoFileReader.__init__, genomics.py:1917-1919)."""
@@ -1414,9 +1484,9 @@ def tail_meta(d, keep_from):
     return GenoData(None, d.pos[keep_from:].copy(), starts, list(d.run_names[r:]))
 
 
-def encode(data, layout, n_threads=0, head_rows=0, pitch=None, alloc=None):
+def encode(data, layout, n_threads=0, head_rows=0, pitch=None, alloc=None, narrow_ok=False):
     full = []
-    gt, pos, soff, slen = encode_text(data, layout, n_threads, head_rows, pitch, alloc, full)
+    gt, pos, soff, slen = encode_text(data, layout, n_threads, head_rows, pitch, alloc, full, narrow_ok)
     n = len(pos)
     L = _lib.lib()
     ptr, _, _keep = _lib.text_ptr(data)

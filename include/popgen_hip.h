@@ -44,6 +44,9 @@ enum pg_status {
 
 /* genotype text formats, reference `-f/--genoFormat` (popgenWindows.py:205, genomics.py:390-396) */
 enum pg_geno_format { PG_FMT_PHASED = 0, PG_FMT_PAIRS = 1, PG_FMT_HAPLO = 2, PG_FMT_DIPLO = 3 };
+/* OR'ed into pg_encode_text's fmt: a cell may hold FEWER alleles than its column's ploidy (the remaining slots stay missing) --
+ * rows tokenised once under the widest layout of a file whose ploidy changes along it (--inferPloidy, genomics.py:1108-1111). */
+#define PG_FMT_NARROW_OK 0x100
 
 /* kernels whose HIP-event timings pg_kernel_time reports */
 enum pg_kernel_id { PG_K_PACK = 0, PG_K_PAIRWISE = 1 /* the called-count kernel (k_pairC*) */, PG_K_POPDIST_FIN = 2,
@@ -196,6 +199,15 @@ int pg_synth_fill(pg_ctx *ctx, int64_t site_offset, int64_t n_sites, int64_t fir
 int pg_encode_text(const char *buf, size_t len, int fmt, int n_cols, int max_ploidy, const int32_t *col_slot,
                    const int32_t *col_ploidy, int n_hap, int8_t *gt_out, int64_t *pos_out, int64_t *scaf_off,
                    int32_t *scaf_len, int64_t cap_sites, int64_t *n_sites_out, int n_threads);
+/* --inferPloidy: the reference takes the ploidy of a sample in a window from the cells the window holds (genoToAlignment with
+ * ploidy None, genomics.py:1108-1111; splitSeq zips them, 390-396), so the cell widths of the whole input decide.  This walks a
+ * buffer of whole lines and reports the data rows at which the width of a watched column's cell changes: change_row_out[k] (index
+ * among the buffer's data rows), change_width_out[k][n_cols] (the widths from that row on; unwatched columns 0).  state[n_cols]
+ * carries the last row's widths from buffer to buffer (start with -1 everywhere).  *n_changes_out is the true count; when it
+ * exceeds cap nothing is lost -- call again with more room (state is advanced only when all changes fitted). */
+int pg_text_cell_widths(const char *buf, size_t len, int n_cols, const int32_t *col_watch, int32_t *state,
+                        int64_t *change_row_out, int32_t *change_width_out, int64_t cap, int64_t *n_changes_out,
+                        int64_t *n_rows_out);
 /* Row indices at which the scaffold token changes (contiguous scaffold runs, the unit slidingCoordWindows
  * restarts its window on, genomics.py:2013-2017).  n_runs_out is always the true count. */
 int pg_scaffold_runs(const char *buf, const int64_t *scaf_off, const int32_t *scaf_len, int64_t n_sites,
@@ -455,6 +467,9 @@ int pg_kernel_time_reset(pg_ctx *ctx);
  * rows, 1 called plane, 2 XV planes), and a way to make its next allocation start lead_bytes behind what hipMalloc returns. */
 int pg_debug_address(pg_ctx *ctx, int which, uint64_t *addr_out, uint64_t *bytes_out);
 int pg_debug_place(pg_ctx *ctx, int which, uint64_t lead_bytes);
+/* CU partition experiment (tools/cu_split_sweep.py; not used by the drivers): the context's compute stream on pair_cus_per_xcd
+ * compute units of every XCD, the pack stream of the two-stream pipeline (PG_OVERLAP=1) on the others; 0 = plain streams. */
+int pg_debug_cu_split(pg_ctx *ctx, int pair_cus_per_xcd);
 /* scratch budget (bytes) for per-batch bit-planes + matrices; default 48 GiB (a job that fits runs as one batch; a larger one is
  * cut into at least eight sub-batches that alternate between two slots of half the budget each) */
 int pg_set_scratch_limit(pg_ctx *ctx, int64_t bytes);

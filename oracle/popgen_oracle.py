@@ -677,7 +677,7 @@ def popgen_windows_csv(geno_path, fmt, pops, wind_size, step=None, min_sites=1, 
     return "\n".join(lines) + "\n"
 
 
-def abbababa_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=1, min_data=0.01,
+def abbababa_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=1, min_data=0.01, ploidy=None,
                          wind_type="coordinate", overlap=0, max_dist=float("inf"), coords=None,
                          add_id=False, write_failed=False, include=None, exclude=None):
     """ABBABABAwindows.py:27-52 (wrapper) + 244-245 (header).  pops4: [(name,[samples])]*4 = P1,P2,P3,O."""
@@ -692,6 +692,9 @@ def abbababa_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=
                 ind_names.append(m)
     pop_of = {nm: [p for p, mem in pops4 if nm in mem][0] for nm in ind_names}
     ploidy_of = {nm: (1 if fmt == "haplo" else 2) for nm in ind_names}
+    if ploidy == "infer":                                          # --inferPloidy (ABBABABAwindows.py:224, fourPopWindows.py:228, distMat.py:214)
+        ploidy_of = {nm: None for nm in ind_names}
+        ploidy = None
     names4 = [p[0] for p in pops4]
     lines = [("windowID," if add_id else "") + "scaffold,start,end,mid,sites,sitesUsed,ABBA,BABA,D,fd,fdM"]
     wins = make_windows(sites, wind_type, wind_size, step, overlap, max_dist, min_sites, coords, include, exclude)
@@ -713,7 +716,7 @@ def abbababa_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=
     return "\n".join(lines) + "\n"
 
 
-def fourpop_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=1, min_data=0.01,
+def fourpop_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=1, min_data=0.01, ploidy=None,
                         wind_type="coordinate", overlap=0, max_dist=float("inf"), coords=None,
                         add_id=False, write_failed=False, include=None, exclude=None, polarize=False, fixed=False):
     """fourPopWindows.py:28-55 (wrapper) + 238-243 (header).  pops4: [(name,[samples])]*4 = P1,P2,P3,O."""
@@ -728,6 +731,9 @@ def fourpop_windows_csv(geno_path, fmt, pops4, wind_size, step=None, min_sites=1
                 ind_names.append(m)
     pop_of = {nm: [p for p, mem in pops4 if nm in mem][0] for nm in ind_names}
     ploidy_of = {nm: (1 if fmt == "haplo" else 2) for nm in ind_names}
+    if ploidy == "infer":                                          # --inferPloidy (ABBABABAwindows.py:224, fourPopWindows.py:228, distMat.py:214)
+        ploidy_of = {nm: None for nm in ind_names}
+        ploidy = None
     names4 = [p[0] for p in pops4]
     lines = [("windowID," if add_id else "") + "scaffold,start,end,mid,sites,sitesUsed," + ",".join(FOURPOP_STATS)]
     wins = make_windows(sites, wind_type, wind_size, step, overlap, max_dist, min_sites, coords, include, exclude)
@@ -760,6 +766,9 @@ def distmat_text(geno_path, fmt, wind_size=None, step=None, min_sites=1, wind_ty
         file_names, sites = read_sites(fh)
     ind_names = list(samples) if samples else list(file_names)
     ploidy_of = {nm: (1 if fmt == "haplo" else 2) for nm in ind_names}
+    if ploidy == "infer":                                          # --inferPloidy (ABBABABAwindows.py:224, fourPopWindows.py:228, distMat.py:214)
+        ploidy_of = {nm: None for nm in ind_names}
+        ploidy = None
     if ploidy:
         ploidy_of.update(ploidy)
     pop_of = {}

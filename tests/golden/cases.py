@@ -34,6 +34,14 @@ FIXTURES = {
     # exist): the first scaffold's positions straddle 2^31, the second starts at 3 * 10^9
     "bigpos": dict(seed=20261004, n_dip=8, n_pops=4, scaf_len=[4000, 2000], density=0.5, var_thr=30000, miss_thr=5000, fmt="phased", sep="/",
                    pos_offset=[2 ** 31 - 2000, 3000000000]),
+    # ploidy that changes along the file (--inferPloidy: per window and sample, genomics.py:1108-1111): four populations of
+    # three.  haploid_where = (samples, scaffold index, first position, last position): their cells are one character there.
+    # chr1: s2 and s8 from position 1001 on (a window boundary of -w 1000); chr2: the "males" s1, s4, s7, s10 everywhere (a sex
+    # chromosome behind an autosome), s5 for positions 1500 .. 1800 (inside a window)
+    "ploidyshift": dict(seed=20261005, n_dip=12, n_pops=4, scaf_len=[2400, 2600], density=0.8, var_thr=40000, miss_thr=4000, fmt="phased",
+                        sep="/", haploid_where=[((2, 8), 0, 1001, 10 ** 9), ((1, 4, 7, 10), 1, 1, 10 ** 9), ((5,), 1, 1500, 1800)]),
+    "ploidyshift_pairs": dict(seed=20261005, n_dip=12, n_pops=4, scaf_len=[2400, 2600], density=0.8, var_thr=40000, miss_thr=4000, fmt="pairs",
+                              sep="", haploid_where=[((2, 8), 0, 1001, 10 ** 9), ((1, 4, 7, 10), 1, 1, 10 ** 9), ((5,), 1, 1500, 1800)]),
 }
 
 
@@ -141,6 +149,24 @@ CASES = [
          argv=["-g", "{geno}", "-f", "phased", "--windType", "sites", "-w", "300", "-O", "50", "-m", "100", "--outFormat", "nexus"]),
     dict(name="abba_freq_indfreqs", tool="freq.py", fixture="abba",
          argv=["-g", "{geno}", "-f", "phased", "--indFreqs", "--target", "derived"]),
+    # ---- --inferPloidy on a file whose cell widths change (missing #1) ----
+    dict(name="ploidyshift_popgen", tool="popgenWindows.py", fixture="ploidyshift",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--inferPloidy", "--roundTo", "6",
+               "--analysis", "popFreq", "popDist", "popPairDist"] + pops_args(12, 4)),
+    dict(name="ploidyshift_popgen_sliding_ind", tool="popgenWindows.py", fixture="ploidyshift",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-s", "250", "-m", "20", "--inferPloidy", "--addWindowID", "--writeFailedWindows",
+               "--analysis", "popDist", "popPairDist", "indPairDist", "hapStats"] + pops_args(12, 2)),
+    dict(name="ploidyshift_popgen_sites_pairs", tool="popgenWindows.py", fixture="ploidyshift_pairs",
+         argv=["-g", "{geno}", "-f", "pairs", "--windType", "sites", "-w", "300", "--overlap", "100", "-m", "50", "--inferPloidy",
+               "--roundTo", "5"] + pops_args(12, 3)),
+    dict(name="ploidyshift_abba", tool="ABBABABAwindows.py", fixture="ploidyshift",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "800", "-m", "20", "--minData", "0.5", "--inferPloidy"] + abba_args(12)),
+    dict(name="ploidyshift_fourpop", tool="fourPopWindows.py", fixture="ploidyshift_pairs",
+         argv=["-g", "{geno}", "-f", "pairs", "-w", "800", "-m", "20", "--minData", "0.5", "--inferPloidy"] + abba_args(12)),
+    dict(name="ploidyshift_distmat", tool="distMat.py", fixture="ploidyshift",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "700", "-m", "20", "--inferPloidy", "--includeSameWithSame"]),
+    dict(name="ploidyshift_distmat_cat", tool="distMat.py", fixture="ploidyshift_pairs",
+         argv=["-g", "{geno}", "-f", "pairs", "--windType", "cat", "--inferPloidy", "--outFormat", "raw"]),
     # ---- fourPopWindows.py (the reference needs np.NaN injected by the harness under NumPy 2) ----
     dict(name="fourpop_minor", tool="fourPopWindows.py", fixture="abba",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-m", "20", "--minData", "0.5"] + abba_args(16)),

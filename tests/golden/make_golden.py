@@ -63,7 +63,21 @@ def make_fixture(name):
     with gzip.GzipFile(path, "wb", mtime=0) as raw:
         import io
         txt = io.TextIOWrapper(raw, newline="\n")
-        synth.write_geno(txt, scaf_names, sid, pos, codes, names, sep=p["sep"], fmt=p["fmt"], haploid=tuple(p.get("haploid", ())))
+        if p.get("haploid_where"):
+            # ploidy that changes along the file: the cells of some samples lose their second allele over ranges of positions
+            mem = io.StringIO()
+            synth.write_geno(mem, scaf_names, sid, pos, codes, names, sep=p["sep"], fmt=p["fmt"])
+            lines = mem.getvalue().split("\n")
+            for i in range(len(pos)):
+                f = lines[1 + i].split("\t")
+                for samples, k, a, b in p["haploid_where"]:
+                    if int(sid[i]) == k and a <= int(pos[i]) <= b:
+                        for d in samples:
+                            f[2 + d] = f[2 + d][0]
+                lines[1 + i] = "\t".join(f)
+            txt.write("\n".join(lines))
+        else:
+            synth.write_geno(txt, scaf_names, sid, pos, codes, names, sep=p["sep"], fmt=p["fmt"], haploid=tuple(p.get("haploid", ())))
         txt.flush()
     return path
 

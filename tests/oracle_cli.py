@@ -118,7 +118,7 @@ def run(tool, argv):
         kw = _common(argv)
         if kw["wind_type"] == "predefined":
             kw["coords"] = [c[:3] for c in kw["coords"]]        # popgenWindows.py:240 keeps 3 columns
-        o = _take(argv, "-O")
+        o = _take(argv, "-O") or _take(argv, "--overlap")
         kw["overlap"] = int(o) if o else 0
         pops = (_pops_with_file(argv, ("-p",)) if "--popsFile" in argv else _pops(argv, ("-p",))) or None
         samples = _take(argv, "--samples")
@@ -143,13 +143,13 @@ def run(tool, argv):
         kw["overlap"] = int(o) if o else 0
         pops4 = (_pops_with_file(argv, ("-P1", "-P2", "-P3", "-O")) if "--popsFile" in argv
                  else _pops(argv, ("-P1", "-P2", "-P3", "-O")))
-        return orc.abbababa_windows_csv(geno, fmt, pops4, **kw)
+        return orc.abbababa_windows_csv(geno, fmt, pops4, ploidy=_ploidy(argv, False), **kw)
     if tool == "fourPopWindows.py":
         kw = _common(argv)
         o = _take(argv, "--overlap")
         kw["overlap"] = int(o) if o else 0
         pops4 = _pops(argv, ("-P1", "-P2", "-P3", "-O"))
-        return orc.fourpop_windows_csv(geno, fmt, pops4, polarize="--polarize" in argv, fixed="--fixed" in argv, **kw)
+        return orc.fourpop_windows_csv(geno, fmt, pops4, polarize="--polarize" in argv, fixed="--fixed" in argv, ploidy=_ploidy(argv, False), **kw)
     if tool == "distMat.py":
         w, s, m = _take(argv, "-w"), _take(argv, "-s"), _take(argv, "-m")
         r = _take(argv, "--roundTo")

@@ -155,7 +155,9 @@ def test_drivers_with_two_ranks_write_the_single_rank_output(tmp_path):
     from golden_util import align_columns
     import test_gpu_golden as G
     gold = os.path.join(ROOT, "tests", "golden")
-    for k, name in enumerate(("sparse_overlap_failed_id", "abba_windows_sites", "multi_distmat", "sparse_predefined")):
+    # (ploidyshift_*: --inferPloidy on a file whose ploidy changes -- every rank reads the whole input, the windows are split)
+    for k, name in enumerate(("sparse_overlap_failed_id", "abba_windows_sites", "multi_distmat", "sparse_predefined",
+                              "ploidyshift_popgen_sliding_ind", "ploidyshift_fourpop")):
         case = [c for c in CASES if c["name"] == name][0]
         out = str(tmp_path / (name + ".out"))
         geno = os.path.join(gold, case["fixture"] + ".geno.gz")
@@ -566,7 +568,8 @@ def _launch(tool, argv, size, port, env_extra=None):
     procs = []
     for rank in range(size):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   PG_TIMING="1", PG_STREAM_BYTES="20000", **(env_extra or {}))
+                   PG_TIMING="1", PG_STREAM_BYTES="20000")
+        env.update(env_extra or {})
         if size >= 4:
             env["PG_COMM"] = "file"
         procs.append(subprocess.Popen([sys.executable, "-c", CLI_WORKER, tool] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
@@ -628,6 +631,38 @@ def test_window_ranges_shard_one_and_four_scaffolds_over_2_3_and_8_ranks(name, s
         assert sum(t["sites"] > 0 for t in timing) >= min(size, n_windows // 2), [t["sites"] for t in timing]
         for t in timing:
             assert t["text_bytes"] <= 1.3 / size * size_b + span_lines * size_b / n_lines + 64, (size, [x["text_bytes"] for x in timing], size_b)
+
+
+@pytest.mark.parametrize("name,size,bgzf", [("ploidyshift_popgen", 3, False), ("ploidyshift_popgen_sites_pairs", 2, True),
+                                             ("ploidyshift_abba", 3, True), ("ploidyshift_distmat", 2, False)])
+def test_infer_ploidy_with_changing_ploidy_on_2_and_3_ranks(name, size, bgzf, tmp_path):
+    """--inferPloidy on a file whose cell widths change (missing #1): every rank scans the widths and reads the
+    whole input (no window-range shards: the host tokenizer under the widest ploidies), the windows of every block are split over the
+    ranks and computed under their own ploidies, the rows are gathered per block; plain text and BGZF, 9 kB blocks"""
+    import gzip
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from cases import CASES
+    from golden_util import align_columns
+    import test_gpu_golden as G
+    import test_cli_cpu
+    gold = os.path.join(ROOT, "tests", "golden")
+    case = [c for c in CASES if c["name"] == name][0]
+    with gzip.open(os.path.join(gold, case["fixture"] + ".geno.gz"), "rb") as f:
+        text = f.read()
+    geno = str(tmp_path / (case["fixture"] + (".geno.gz" if bgzf else ".geno")))
+    if bgzf:
+        test_cli_cpu.write_bgzf(geno, text, 4000, empty_member_at=3)
+    else:
+        with open(geno, "wb") as g:
+            g.write(text)
+    out = str(tmp_path / (name + ".out"))
+    argv = [a.format(geno=geno, dir=gold, out=out) for a in case["argv"]] + ["-o", out]
+    timing = _launch(case["tool"], argv, size, 47000 + (os.getpid() * 5 + len(name)) % 2000,
+                     {"PG_RDZV_FILE": str(tmp_path / "rdzv"), "PG_COMM": "file", "PG_STREAM_BYTES": "9000"})
+    with open(out) as f, open(os.path.join(gold, name + ".out")) as g:
+        got, want = f.read(), g.read()
+    G.compare_text(align_columns(got, want), want, G.round_digits(case))
+    assert timing and not any(t["sharded_input"] for t in timing), timing
 
 
 def _corrupt_one_share(geno, size, bad_rank, tmp_path):

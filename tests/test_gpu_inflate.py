@@ -156,7 +156,7 @@ def test_goldens_as_bgzf_inflated_on_the_device(case, blk, block, tmp_path, monk
     monkeypatch.setenv("PG_TIMING", "1")
     G.test_cli_reproduces_reference_output(case, tmp_path, geno=geno)
     timing = [json.loads(ln[len("PG_TIMING "):]) for ln in capfd.readouterr().err.splitlines() if ln.startswith("PG_TIMING ")]
-    if len(text) > 2 * blk + 65536:
+    if len(text) > 2 * blk + 65536 and not case["fixture"].startswith("ploidyshift"):       # (changing ploidy: host tokenizer, host inflate)
         assert timing and timing[-1].get("bgzf_blocks_inflated_on_device", 0) > 0
 
 
