@@ -131,6 +131,7 @@ SIGNATURES = {
     "pg_debug_address": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pg_debug_place": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "pg_debug_cu_split": (C.c_int, [_P, C.c_int]),
+    "pg_ctx_create_times": (C.c_int, [C.POINTER(C.c_double)]),
     "pg_set_scratch_limit": (C.c_int, [_P, C.c_int64]),
     "pg_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pg_comm_init": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p]),

@@ -73,10 +73,14 @@ extern "C" int pg_usable_cpus(void) {
 extern "C" const char *pg_last_error(void) { return g_err; }
 extern "C" int pg_abi_version(void) { return PG_ABI_VERSION; }
 
+static double g_ctx_times[3] = {0.0, 0.0, 0.0};
+
 extern "C" int pg_device_count(int *n_out) {
     if (!n_out) return pg_fail(PG_ERR_ARG, "pg_device_count: null output");
     int n = 0;
+    const auto t_a = std::chrono::steady_clock::now();
     hipError_t e = hipGetDeviceCount(&n);
+    if (g_ctx_times[0] == 0.0) g_ctx_times[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
     if (e != hipSuccess) {
         *n_out = 0;
         (void)hipGetLastError();
@@ -94,11 +98,13 @@ extern "C" int pg_ctx_create(pg_ctx **out, int device) {
     if (rc != PG_OK) return rc;
     if (n <= 0) return pg_fail(PG_ERR_NODEV, "no HIP device visible: the popgen engine needs an AMD GPU (gfx950)");
     if (device < 0 || device >= n) return pg_fail(PG_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    const auto t_a = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(device));
     pg_ctx *c = new pg_ctx();
     c->device = device;
     if (getenv("PG_SCRATCH_GIB")) c->scratch_limit = (int64_t)atol(getenv("PG_SCRATCH_GIB")) << 30;    // default 48 GiB
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    g_ctx_times[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();   // hipSetDevice + the first stream
     if (e != hipSuccess) {
         delete c;
         return pg_fail(PG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -118,7 +124,16 @@ extern "C" int pg_ctx_create(pg_ctx **out, int device) {
         delete c;
         return pg_fail(PG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    g_ctx_times[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count() - g_ctx_times[1];   // the other two streams + an event
     *out = c;
+    return PG_OK;
+}
+
+// where the creation of the first context went (seconds): [0] hipGetDeviceCount (the runtime's start-up: hipInit), [1] hipSetDevice +
+// the first stream, [2] two more streams and an event (tools/ctx_time.py)
+extern "C" int pg_ctx_create_times(double *out3) {
+    if (!out3) return pg_fail(PG_ERR_ARG, "pg_ctx_create_times: null output");
+    for (int k = 0; k < 3; ++k) out3[k] = g_ctx_times[k];
     return PG_OK;
 }
 

@@ -114,7 +114,11 @@ struct pg_ctx {
     struct Inflate {
         DevBuf<uint32_t> comp, crc_tab;
         DevBuf<uint8_t> text;              // pg_inflate_device only (the tokenizer inflates into its text slots)
-        DevBuf<uint8_t> sink;              // 64 bytes per member: where the lanes of a copy step that have no byte store
+        DevBuf<uint8_t> sink;              // 128 bytes per member: where the lanes of a copy step that have no byte store
+        DevBuf<uint16_t> nl_list;          // the members' line feeds as k_inflate lists them (nl_cap offsets per member)
+        DevBuf<int32_t> nl_cnt;            //   their number per member
+        DevBuf<int64_t> mem_base;          //   line feeds in front of each member (k_member_scan)
+        uint32_t nl_cap = 0;               //   0: the block's line feeds are found by passes over its text
         DevBuf<PgiMember> members;
         HostPin<PgiMember> h_members;
         DevBuf<int32_t> status;
@@ -139,7 +143,9 @@ struct pg_ctx {
         int state = 0;                     // 0 idle, 1 empty block, 2 submitted, 3 parse queued, 4 empty result
         int fmt = 0, n_cols = 0, max_ploidy = 0, cells_w = 0;
         int64_t len = 0, n_lines = 0, n_tiles = 0, run_cap = 0;
+        int64_t n_members = 0, head_len = 0;   // (a block that arrived deflated)
     } tok[2];
+    int64_t tok_nl_fallbacks = 0;                          // deflated blocks whose line feeds were found by passes over the text after all
     HostPin<uint8_t> tok_pin;                              // two 4 MiB page-locked buffers per staging thread
     hipStream_t tok_st[PG_TOK_WORKERS] = {};               // one copy stream per staging thread
     hipStream_t tok_small = nullptr;                       // the collect step's few kilobytes (beside the next block's inflate on stream_up)

@@ -23,9 +23,13 @@ namespace {
 #ifndef PGI_WAVES
 #define PGI_WAVES 6
 #endif
+// nl_list (may be null): nl_cap offsets per member -- the member's line feeds in front of byte text_limit of the output, found in
+// the registers of the flush (pg_inflate_core.h); nl_cnt[m] = how many there are (more than nl_cap: the caller takes the passes over
+// the text instead, k_nl_count / k_nl_write)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PGI_WAVES, PGI_WAVES))) void k_inflate(const uint32_t *__restrict__ comp, uint32_t n_dw, const PgiMember *__restrict__ mem,
                                                 int n_members, uint8_t *__restrict__ out, uint8_t *__restrict__ sink,
-                                                int32_t *__restrict__ status) {
+                                                int32_t *__restrict__ status, uint16_t *__restrict__ nl_list, uint32_t nl_cap,
+                                                int32_t *__restrict__ nl_cnt, uint64_t text_limit) {
     __shared__ PgiShared sh;
     const int lane = (int)threadIdx.x;
     const int m = (int)blockIdx.x;
@@ -34,11 +38,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PGI_WAVES, P
     const uint32_t in_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)mem[m].in_len);
     const uint32_t out_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)mem[m].out_len);
     const uint64_t out_off = mem[m].out_off;
-    const int rc = pgi_member(comp, n_dw, in_off, in_len, out + out_off, out_len, sink + (size_t)m * 64, &sh, lane);   // sink: where lanes without a byte store
+    const uint64_t lim64 = text_limit > out_off ? text_limit - out_off : 0ull;
+    const uint32_t nl_lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lim64 > 0x10000ull ? 0x10000u : (uint32_t)lim64));
+    uint32_t nl_n = 0;
+    const int rc = pgi_member(comp, n_dw, in_off, in_len, out + out_off, out_len, sink + (size_t)m * 128, &sh,   // sink: where lanes without a byte store
+                              nl_list ? nl_list + (size_t)m * nl_cap : nullptr, nl_cap, nl_lim, &nl_n, lane);
+    if (nl_cnt && lane == 0) nl_cnt[m] = rc ? 0 : (int32_t)nl_n;
     if (rc && lane == 0) {
         atomicOr(status, rc);
         atomicMin(status + 1, m);
     }
+}
+
+// the members' line-feed lists -> the block's list: one block scans the counts (mem_base[m] = line feeds in front of member m, the
+// total, and whether a member had more than its list holds), then a wavefront per member moves its entries
+__global__ __launch_bounds__(256) void k_member_scan(const int32_t *__restrict__ nl_cnt, int n_members, uint32_t nl_cap, int64_t *__restrict__ mem_base,
+                                                     int64_t *__restrict__ total, int32_t *__restrict__ overflow) {
+    __shared__ long long sh[256];
+    __shared__ int over;
+    if (threadIdx.x == 0) over = 0;
+    __syncthreads();
+    const int per = (n_members + 255) / 256;
+    const int t0 = (int)threadIdx.x * per, t1 = t0 + per < n_members ? t0 + per : n_members;
+    long long mine = 0;
+    for (int t = t0; t < t1; ++t) {
+        mine += nl_cnt[t];
+        if ((uint32_t)nl_cnt[t] > nl_cap) over = 1;
+    }
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const long long x = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += x;
+        __syncthreads();
+    }
+    long long run = sh[threadIdx.x] - mine;
+    for (int t = t0; t < t1; ++t) {
+        mem_base[t] = run;
+        run += nl_cnt[t];
+    }
+    if (threadIdx.x == 255) {
+        *total = sh[255];
+        *overflow = over;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_nl_gather(const uint16_t *__restrict__ nl_list, uint32_t nl_cap, const int32_t *__restrict__ nl_cnt,
+                                                  const int64_t *__restrict__ mem_base, const PgiMember *__restrict__ mem, int64_t text_base,
+                                                  int64_t *__restrict__ nl_pos) {
+    const int m = (int)blockIdx.x;
+    const int n = nl_cnt[m];
+    const int64_t at = text_base + (int64_t)mem[m].out_off, base = mem_base[m];
+    const uint16_t *list = nl_list + (size_t)m * nl_cap;
+    for (int i = (int)threadIdx.x; i < n; i += 64) nl_pos[base + i] = at + list[i];
 }
 
 // ---- CRC-32 of the inflated members (gzip trailer, RFC 1952 2.3.1): four members per block, a wavefront each ----
@@ -305,13 +358,21 @@ extern "C" int pg_bgzf_compress(const uint8_t *text, int64_t len, int level, int
 // ---- device ------------------------------------------------------------------------------------------------------------------------
 // the member table of a block -> page-locked array -> device; queues k_inflate (+ k_crc32) on `st`.  comp_d: the compressed bytes on
 // the device (padded: n_dw dwords may be read); text_d: where byte 0 of the first member's text goes.
+// nl_cap > 0: the members' line feeds in front of byte text_limit of text_d are listed as they are inflated (I.nl_list, I.nl_cnt),
+// scanned (I.mem_base; total -> *d_total, a list that was too short -> *d_over)
 static int inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const uint32_t *comp_d, uint32_t n_dw, const uint32_t *in_off,
-                         const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d) {
+                         const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d,
+                         uint32_t nl_cap = 0, uint64_t text_limit = 0, int64_t *d_total = nullptr, int32_t *d_over = nullptr) {
     int rc;
+    if (nl_cap) {
+        if ((rc = I.nl_list.ensure_roomy((size_t)(n_members + 1) * nl_cap)) != PG_OK) return rc;
+        if ((rc = I.nl_cnt.ensure_roomy((size_t)n_members + 1)) != PG_OK) return rc;
+        if ((rc = I.mem_base.ensure_roomy((size_t)n_members + 1)) != PG_OK) return rc;
+    }
     if ((rc = I.h_members.ensure_roomy((size_t)n_members + 1)) != PG_OK) return rc;
     if ((rc = I.members.ensure_roomy((size_t)n_members + 1)) != PG_OK) return rc;
     if ((rc = I.status.ensure(2)) != PG_OK) return rc;
-    if ((rc = I.sink.ensure_roomy((size_t)(n_members + 1) * 64)) != PG_OK) return rc;
+    if ((rc = I.sink.ensure_roomy((size_t)(n_members + 1) * 128)) != PG_OK) return rc;
     if ((rc = I.h_status.ensure(2)) != PG_OK) return rc;
     uint64_t at = 0;
     for (int64_t k = 0; k < n_members; ++k) {
@@ -328,8 +389,13 @@ static int inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const ui
     HIPCHK(hipMemcpyAsync(I.status.p, I.h_status.p, 8, hipMemcpyHostToDevice, st));
     if (n_members == 0) return PG_OK;
     HIPCHK(hipMemcpyAsync(I.members.p, I.h_members.p, (size_t)n_members * sizeof(PgiMember), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_inflate, dim3((unsigned)n_members), dim3(64), 0, st, comp_d, n_dw, I.members.p, (int)n_members, text_d, I.sink.p, I.status.p);
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)n_members), dim3(64), 0, st, comp_d, n_dw, I.members.p, (int)n_members, text_d, I.sink.p, I.status.p,
+                       nl_cap ? I.nl_list.p : nullptr, nl_cap, nl_cap ? I.nl_cnt.p : nullptr, text_limit);
     HIPCHK(hipGetLastError());
+    if (nl_cap) {
+        hipLaunchKernelGGL(k_member_scan, dim3(1), dim3(256), 0, st, I.nl_cnt.p, (int)n_members, nl_cap, I.mem_base.p, d_total, d_over);
+        HIPCHK(hipGetLastError());
+    }
     if (crc && !getenv("PG_BGZF_NO_CRC")) {
         hipLaunchKernelGGL(k_crc32, dim3((unsigned)((n_members + 3) / 4)), dim3(256), 0, st, text_d, I.members.p, (int)n_members,
                            I.crc_tab.p, I.status.p);
@@ -390,8 +456,14 @@ extern "C" int pg_inflate_device(pg_ctx *c, const uint8_t *comp, int64_t comp_le
 
 // used by pg_tokenize.hip ------------------------------------------------------------------------------------------------------------
 int pg_inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const uint32_t *comp_d, uint32_t n_dw, const uint32_t *in_off,
-                     const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d) {
-    return inflate_queue(c, st, I, comp_d, n_dw, in_off, in_len, out_len, crc, n_members, text_d);
+                     const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d,
+                     uint32_t nl_cap, uint64_t text_limit, int64_t *d_total, int32_t *d_over) {
+    return inflate_queue(c, st, I, comp_d, n_dw, in_off, in_len, out_len, crc, n_members, text_d, nl_cap, text_limit, d_total, d_over);
+}
+// the block's list of line feeds from the members' lists (pg_tokenize_parse, a block that arrived deflated)
+void pg_launch_nl_gather(hipStream_t st, pg_ctx::Inflate &I, uint32_t nl_cap, int64_t n_members, int64_t text_base, int64_t *nl_pos) {
+    if (n_members > 0)
+        hipLaunchKernelGGL(k_nl_gather, dim3((unsigned)n_members), dim3(64), 0, st, I.nl_list.p, nl_cap, I.nl_cnt.p, I.mem_base.p, I.members.p, text_base, nl_pos);
 }
 int pg_inflate_error(const int32_t *status) { return inflate_error(status); }
 void pg_launch_gather_bytes(hipStream_t st, const uint8_t *text, const int64_t *off, const int32_t *len, const int64_t *dst, int n,

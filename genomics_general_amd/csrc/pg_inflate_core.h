@@ -269,8 +269,25 @@ PGI_DEV int pgi_build(const uint8_t *lens, int n, uint16_t *sorted, uint32_t *hi
     } while (0)
 
 // One member: in_len bytes of deflate stream at byte in_off of comp -> out_len bytes at dst.  0, or PGI_ERR_* bits.
+// sink: 128 bytes of the member's own where lanes without a byte store.  nl_list (may be null): the offsets, in the member's text,
+// of its line feeds in front of offset nl_lim, in order -- found in the registers of the flush, so that the tokenizer needs no pass
+// over the text for them (k_nl_count / k_nl_write); at most nl_cap are stored, *nl_n_out counts them all.
 PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_t in_off, uint32_t in_len, uint8_t *dst,
-                       uint32_t out_len, uint8_t *sink, PgiShared *sh PGI_LANE_PARAM) {
+                       uint32_t out_len, uint8_t *sink, PgiShared *sh, uint16_t *nl_list, uint32_t nl_cap, uint32_t nl_lim,
+                       uint32_t *nl_n_out PGI_LANE_PARAM) {
+    uint32_t nl_n = 0;
+    uint16_t *const nl_dump = reinterpret_cast<uint16_t *>(sink);
+// a line feed at offset p_ of the member's text
+#define PGI_NL_PUT(p)                                                                                          \
+    do {                                                                                                       \
+        const uint32_t p_ = (p);                                                                               \
+        if (p_ < nl_lim) {                                                                                     \
+            LANES { *((lane == 0 && nl_n < nl_cap) ? nl_list + nl_n : nl_dump + lane) = (uint16_t)p_; }        \
+            ++nl_n;                                                                                            \
+        }                                                                                                      \
+    } while (0)
+// 0x80 in every byte of x that is a line feed (exact: no borrow between the bytes)
+#define PGI_NL_FLAGS(x) (~((((x) ^ 0x0A0A0A0Au) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu | ((x) ^ 0x0A0A0A0Au) | 0x7F7F7F7Fu))
     // length / distance bases and extra bits (RFC 1951 3.2.5) as lane constants: base | extra << 16
     PL(uint32_t, lconst);
     PL(uint32_t, dconst);
@@ -319,6 +336,15 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
         PL(uint8_t, fb_);                                                         \
         LANES { V(fb_) = ring[PGI_RIX(fl + (uint32_t)lane)]; }                    \
         LANES { *((uint32_t)lane < (n) ? dst + fl + lane : sink + lane) = V(fb_); } \
+        if (nl_list) {                                                            \
+            uint64_t nm_;                                                         \
+            BALLOT(nm_, V(fb_) == 10 && (uint32_t)lane < (n));                    \
+            while (nm_) {                                                         \
+                const uint32_t b_ = (uint32_t)PGI_CTZ64(nm_);                     \
+                nm_ &= nm_ - 1ull;                                                \
+                PGI_NL_PUT(fl + b_);                                              \
+            }                                                                     \
+        }                                                                         \
         fl += (n);                                                                \
     } while (0)
 #define PGI_FLUSH(final)                                                                         \
@@ -331,6 +357,32 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
             PL(PgiU4, fq_);                                                                      \
             LANES { V(fq_) = *reinterpret_cast<const PgiU4 *>(ring + PGI_RIX(fl + 16u * (uint32_t)lane)); } \
             LANES { *reinterpret_cast<PgiU4 *>(dst + fl + 16u * (uint32_t)lane) = V(fq_); }      \
+            if (nl_list) {                                                                       \
+                PL(uint32_t, z0_);                                                               \
+                PL(uint32_t, z1_);                                                               \
+                PL(uint32_t, z2_);                                                               \
+                PL(uint32_t, z3_);                                                               \
+                LANES {                                                                          \
+                    V(z0_) = PGI_NL_FLAGS(V(fq_).x);                                             \
+                    V(z1_) = PGI_NL_FLAGS(V(fq_).y);                                             \
+                    V(z2_) = PGI_NL_FLAGS(V(fq_).z);                                             \
+                    V(z3_) = PGI_NL_FLAGS(V(fq_).w);                                             \
+                }                                                                                \
+                uint64_t nm_;                                                                    \
+                BALLOT(nm_, (V(z0_) | V(z1_) | V(z2_) | V(z3_)) != 0u);                          \
+                while (nm_) {                                                                    \
+                    const uint32_t l_ = (uint32_t)PGI_CTZ64(nm_);                                \
+                    nm_ &= nm_ - 1ull;                                                           \
+                    for (uint32_t d_ = 0; d_ < 4u; ++d_) {                                       \
+                        uint32_t zz_ = (uint32_t)(d_ == 0u ? READLANE(z0_, l_) : d_ == 1u ? READLANE(z1_, l_) : d_ == 2u ? READLANE(z2_, l_) : READLANE(z3_, l_)); \
+                        while (zz_) {                                                            \
+                            const uint32_t b_ = (uint32_t)__builtin_ctz(zz_);                    \
+                            zz_ &= zz_ - 1u;                                                     \
+                            PGI_NL_PUT(fl + 16u * l_ + 4u * d_ + (b_ >> 3));                     \
+                        }                                                                        \
+                    }                                                                            \
+                }                                                                                \
+            }                                                                                    \
             fl += 1024u;                                                                         \
         }                                                                                        \
         if (final) {                                                                             \
@@ -573,5 +625,6 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
     if ((uint64_t)widx * 32u - (uint64_t)cnt > end_bits) return PGI_ERR_IN;
     if (pos != out_len) return PGI_ERR_OUT;
     PGI_FLUSH(1);
+    if (nl_n_out) *nl_n_out = nl_n;
     return 0;
 }

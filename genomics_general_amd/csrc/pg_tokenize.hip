@@ -733,7 +733,9 @@ static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, in
 }
 
 int pg_inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const uint32_t *comp_d, uint32_t n_dw, const uint32_t *in_off,
-                     const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d);
+                     const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d,
+                     uint32_t nl_cap, uint64_t text_limit, int64_t *d_total, int32_t *d_over);
+void pg_launch_nl_gather(hipStream_t st, pg_ctx::Inflate &I, uint32_t nl_cap, int64_t n_members, int64_t text_base, int64_t *nl_pos);
 int pg_inflate_error(const int32_t *status);
 void pg_launch_gather_bytes(hipStream_t st, const uint8_t *text, const int64_t *off, const int32_t *len, const int64_t *dst, int n,
                             uint8_t *out);
@@ -812,10 +814,37 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
         HIPCHK(hipMemcpyAsync(T.tp, T.h_head.p, (size_t)head_len, hipMemcpyHostToDevice, st));
     }
     lap(2);
-    if ((rc = pg_inflate_queue(c, st, T.inf, T.inf.comp.p, (uint32_t)n_dw, in_off, in_len, out_len, crc, n_members, T.tp + head_len)) != PG_OK) return rc;
+    // The block's line feeds: listed by k_inflate member by member as the text passes through its registers (no pass over the text:
+    // k_nl_count, k_nl_scan and k_nl_write took 0.7 ms per GiB, a line of the chain's 5.5), unless the carried head holds one or
+    // PG_BGZF_NL=0 asks for the passes.  A member's list holds four times the lines a member of such lines has; a member with more
+    // (the block's lines are much shorter than its first) sends the block through the passes after all (pg_tokenize_parse).
+    static const bool nl_in_inflate = !(getenv("PG_BGZF_NL") && atoi(getenv("PG_BGZF_NL")) == 0);
+    uint32_t nl_cap = 0;
+    if (nl_in_inflate && n_members > 0 && !(head_len && memchr(head, '\n', (size_t)head_len))) {
+        const int64_t per_member = 65536 / std::max<int64_t>(first_line_len + 1, 8) + 1;
+        nl_cap = (uint32_t)std::min<int64_t>(16384, std::max<int64_t>(64, 4 * per_member));
+        if (const char *cap = getenv("PG_BGZF_NL_CAP")) nl_cap = (uint32_t)std::max(1, atoi(cap));         // (tests: lists that are too short)
+    }
+    T.inf.nl_cap = nl_cap;
+    T.n_members = n_members;
+    T.head_len = head_len;
+    if (nl_cap) {
+        T.n_tiles = 0;
+        if ((rc = T.i32.ensure_roomy(8)) != PG_OK) return rc;
+        if ((rc = T.i64.ensure_roomy(4)) != PG_OK) return rc;
+        HIPCHK(hipMemsetAsync(T.i32.p, 0, 16, st));                 // [0] status bits, [1] number of runs, [2] a member's list was too short
+    }
+    if ((rc = pg_inflate_queue(c, st, T.inf, T.inf.comp.p, (uint32_t)n_dw, in_off, in_len, out_len, crc, n_members, T.tp + head_len,
+                               nl_cap, (uint64_t)(text_len - head_len), nl_cap ? T.i64.p : nullptr, nl_cap ? T.i32.p + 2 : nullptr)) != PG_OK) return rc;
     lap(3);
     HIPCHK(hipMemcpyAsync(T.h_total.p + 2, T.inf.status.p, 8, hipMemcpyDeviceToHost, st));     // [error bits, first bad member]: read by parse
-    if ((rc = tok_count(c, T, text_len)) != PG_OK) return rc;
+    if (nl_cap) {
+        HIPCHK(hipMemcpyAsync(T.h_total.p, T.i64.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(T.h_total.p + 3, T.i32.p + 2, 4, hipMemcpyDeviceToHost, st));
+        if (!T.counted) HIPCHK(hipEventCreateWithFlags(&T.counted, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(T.counted, st));
+        T.state = 2;
+    } else if ((rc = tok_count(c, T, text_len)) != PG_OK) return rc;
     lap(4);
     if (trace) fprintf(stderr, "PG_TOK_TRACE submit_bgzf slot %d pinned %d: alloc %.2f copy %.2f head %.2f inflate_queue %.2f count_queue %.2f ms\n", slot, (int)pinned, tr[0], tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3]);
     *ok_out = 1;
@@ -839,6 +868,20 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
         memcpy(ist, T.h_total.p + 2, 8);
         if (ist[0]) { T.state = 0; return pg_inflate_error(ist); }
     }
+    bool nl_lists = T.deflated && T.inf.nl_cap > 0;
+    if (nl_lists) {
+        int32_t over = 0;
+        memcpy(&over, T.h_total.p + 3, 4);
+        if (over) {
+            // a member held more line feeds than its list: the passes over the text after all
+            nl_lists = false;
+            T.inf.nl_cap = 0;
+            int rc0 = tok_count(c, T, T.len);
+            if (rc0 != PG_OK) return rc0;
+            HIPCHK(hipEventSynchronize(T.counted));
+            ++c->tok_nl_fallbacks;
+        }
+    }
     const int64_t n_lines = T.h_total.p[0];
     T.n_lines = n_lines;
     *n_rows_out = n_lines;
@@ -851,7 +894,8 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
     const int64_t n_tiles = T.n_tiles;
     int32_t *d_status = T.i32.p + n_tiles;
     if ((rc = T.nl.ensure_roomy((size_t)n_lines)) != PG_OK) return rc;
-    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(256), 0, st, T.tp, T.len, T.i64.p, T.nl.p);
+    if (nl_lists) pg_launch_nl_gather(st, T.inf, T.inf.nl_cap, T.n_members, T.head_len, T.nl.p);
+    else hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(256), 0, st, T.tp, T.len, T.i64.p, T.nl.p);
     if ((rc = T.dcols.ensure(T.cols.size())) != PG_OK) return rc;
     if ((rc = T.h_cols.ensure(T.cols.size())) != PG_OK) return rc;
     memcpy(T.h_cols.p, T.cols.data(), T.cols.size() * 4);

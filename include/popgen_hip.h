@@ -470,6 +470,9 @@ int pg_debug_place(pg_ctx *ctx, int which, uint64_t lead_bytes);
 /* CU partition experiment (tools/cu_split_sweep.py; not used by the drivers): the context's compute stream on pair_cus_per_xcd
  * compute units of every XCD, the pack stream of the two-stream pipeline (PG_OVERLAP=1) on the others; 0 = plain streams. */
 int pg_debug_cu_split(pg_ctx *ctx, int pair_cus_per_xcd);
+/* Where the creation of the process's first context went, in seconds: [0] hipGetDeviceCount (the runtime's start-up), [1]
+ * hipSetDevice + the first stream, [2] the other streams and events (tools/ctx_time.py). */
+int pg_ctx_create_times(double *out3);
 /* scratch budget (bytes) for per-batch bit-planes + matrices; default 48 GiB (a job that fits runs as one batch; a larger one is
  * cut into at least eight sub-batches that alternate between two slots of half the budget each) */
 int pg_set_scratch_limit(pg_ctx *ctx, int64_t bytes);

@@ -160,6 +160,24 @@ def test_goldens_as_bgzf_inflated_on_the_device(case, blk, block, tmp_path, monk
         assert timing and timing[-1].get("bgzf_blocks_inflated_on_device", 0) > 0
 
 
+@pytest.mark.parametrize("env", [{"PG_BGZF_NL": "0"}, {"PG_BGZF_NL_CAP": "3"}], ids=["passes_over_the_text", "lists_too_short"])
+@pytest.mark.parametrize("name", ["c1_popgen", "abba_windows_sites", "sparse_overlap_failed_id"])
+def test_line_feeds_by_passes_over_the_text_give_the_same_rows(name, env, tmp_path, monkeypatch, capfd):
+    """round 6: k_inflate lists a block's line feeds member by member (the default, what every other BGZF test runs); PG_BGZF_NL=0 keeps
+    k_nl_count / k_nl_scan / k_nl_write, and a member with more line feeds than its list holds (PG_BGZF_NL_CAP=3) sends its block
+    through those passes after all: the reference's output either way"""
+    import gzip
+    case = [c for c in G.CASES if c["name"] == name][0]
+    with gzip.open(os.path.join(G.GOLD, case["fixture"] + ".geno.gz"), "rb") as f:
+        text = f.read()
+    geno = str(tmp_path / (case["fixture"] + ".geno.gz"))
+    write_bgzf(geno, text, 5000, empty_member_at=2)
+    monkeypatch.setenv("PG_STREAM_BYTES", "30000")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    G.test_cli_reproduces_reference_output(case, tmp_path, geno=geno)
+
+
 def test_goldens_as_plain_gzip_still_take_the_serial_reader(tmp_path, monkeypatch):
     """a single-stream gzip file cannot be inflated in parallel: the gzip module reads it, the device tokenizer gets text"""
     case = [c for c in G.CASES if c["name"] == "c1_popgen"][0]

@@ -30,10 +30,20 @@ def emul(tmp_path_factory):
     L = C.CDLL(so)
     L.pgi_emul_inflate_at.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int]
 
-    def run(stream, out_len, pre=0, post=0, misalign=0, rng=random):
+    L.pgi_emul_nl_setup.argtypes = [C.c_uint32, C.c_uint32]
+    L.pgi_emul_nl_result.argtypes = [C.POINTER(C.c_uint16), C.c_uint32]
+    L.pgi_emul_nl_result.restype = C.c_uint32
+
+    def run(stream, out_len, pre=0, post=0, misalign=0, rng=random, nl=None):
+        """nl = (capacity, limit): also the list of line feeds the decoder keeps beside the text -> (rc, text, count, offsets)"""
         comp = bytes(rng.randrange(256) for _ in range(pre)) + stream + bytes(rng.randrange(256) for _ in range(post))
         dst = C.create_string_buffer(max(out_len, 1) + 8)
+        L.pgi_emul_nl_setup(*(nl if nl else (0, 0xFFFFFFFF)))
         rc = L.pgi_emul_inflate_at(comp, len(comp), pre, len(stream), dst, out_len, misalign)
+        if nl:
+            buf = (C.c_uint16 * max(nl[0], 1))()
+            cnt = L.pgi_emul_nl_result(buf, nl[0])
+            return rc, dst.raw[:out_len], cnt, list(buf[:min(cnt, nl[0])])
         return rc, dst.raw[:out_len]
     return run
 
@@ -69,6 +79,30 @@ def test_the_kernel_source_inflates_what_zlib_deflates(emul):
                 n += 1
                 assert rc == 0 and out == data, (len(data), level, strat, ml, rc)
     assert n > 3500
+
+
+def test_the_decoder_lists_the_line_feeds_of_the_text_it_writes(emul):
+    """round 6: k_inflate reports the offsets of a member's line feeds, found in the registers of its flushes (head bytes, aligned
+    1 KiB pieces, tail bytes), so that the tokenizer needs no pass over the text for them: every offset, in order, for every
+    misalignment of the output; a limit (the block's text ends inside the member); a list that is too short still counts them all"""
+    rng = random.Random(5)
+    texts = [geno_text(rng, 300, 50)[:65280], geno_text(rng, 70, 200)[:60001], b"\n" * 3000, b"a\n" * 2000 + b"tail without a line feed",
+             b"\n", b"", b"x" * 5000, bytes(rng.choice(b"\nab") for _ in range(20000))]
+    n = 0
+    for data in texts:
+        want = [i for i, ch in enumerate(data) if ch == 10]
+        for mis in range(16):
+            for level in (0, 1, 6):
+                rc, out, cnt, offs = emul(deflate(data, level), len(data), misalign=mis, rng=rng, nl=(70000, 0xFFFFFFFF))
+                assert rc == 0 and out == data and cnt == len(want) and offs == want, (len(data), mis, level)
+                n += 1
+        for lim in (0, 1, len(data) // 2, len(data) - 1, len(data), len(data) + 5):
+            lim = max(lim, 0)
+            rc, out, cnt, offs = emul(deflate(data), len(data), misalign=lim % 16, rng=rng, nl=(70000, lim))
+            assert rc == 0 and offs == [i for i in want if i < lim] and cnt == len(offs)
+        rc, out, cnt, offs = emul(deflate(data), len(data), misalign=3, rng=rng, nl=(5, 0xFFFFFFFF))
+        assert rc == 0 and out == data and cnt == len(want) and offs == want[:5]
+    assert n > 300
 
 
 def test_matches_that_reach_behind_the_lds_ring_read_global_memory(emul):
