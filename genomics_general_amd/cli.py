@@ -1070,7 +1070,7 @@ def _near_rounding_tie(v, digits, ratio=False, difference=False):
 
 
 def _refine_long_windows(run, good, sites_local, sd, digits, again, ratio_keys=(), also=None):
-    """The statistics `sd` of this rank's windows `good` were formed with fixed reduction trees where a window has more than 4096
+    """The statistics `sd` of this rank's windows `good` were formed with fixed reduction trees where a window has more than NP_MAX_SITES (256)
     sites.  Where one of them is within reach of a rounding tie (so that the reference's summation order could print another
     digit), that window is computed again in NumPy's order (`again(batch)`): the text is the reference's for every window length
     without paying for that order everywhere."""

@@ -174,6 +174,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     for (int t = 0; t < PG_TOK_WORKERS; ++t) {
         if (c->tok_st[t]) (void)hipStreamDestroy(c->tok_st[t]);
         if (t == 0 && c->tok_small) (void)hipStreamDestroy(c->tok_small);
+        if (t == 0 && c->tok_crc) (void)hipStreamDestroy(c->tok_crc);
         for (int k = 0; k < 2; ++k)
             if (c->tok_wev[t][k]) (void)hipEventDestroy(c->tok_wev[t][k]);
     }
@@ -184,7 +185,13 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
         T.text.release(); T.i32.release(); T.dcols.release(); T.pos.release(); T.pos64.release(); T.cells_at.release(); T.i64.release(); T.nl.release(); T.off.release();
         T.h_total.release(); T.h_pos.release(); T.h_cols.release();
         T.h_head.release(); T.names.release(); T.names_idx.release();
-        auto drop = [](pg_ctx::Inflate &I) { I.comp.release(); I.crc_tab.release(); I.text.release(); I.sink.release(); I.members.release(); I.h_members.release(); I.status.release(); I.h_status.release(); };
+        auto drop = [](pg_ctx::Inflate &I) {
+            I.comp.release(); I.crc_tab.release(); I.text.release(); I.sink.release(); I.members.release(); I.h_members.release(); I.status.release(); I.h_status.release();
+            I.nl_list.release(); I.nl_cnt.release(); I.mem_base.release();
+            if (I.ev_inflated) (void)hipEventDestroy(I.ev_inflated);
+            if (I.ev_crc) (void)hipEventDestroy(I.ev_crc);
+            I.ev_inflated = I.ev_crc = nullptr;
+        };
         drop(T.inf);
         if (k == 0) drop(c->inf);
         if (T.counted) (void)hipEventDestroy(T.counted);

@@ -119,6 +119,8 @@ struct pg_ctx {
         DevBuf<int32_t> nl_cnt;            //   their number per member
         DevBuf<int64_t> mem_base;          //   line feeds in front of each member (k_member_scan)
         uint32_t nl_cap = 0;               //   0: the block's line feeds are found by passes over its text
+        hipEvent_t ev_inflated = nullptr, ev_crc = nullptr;   // k_crc32 on a stream of its own (the tokenizer's blocks)
+        bool crc_pending = false;
         DevBuf<PgiMember> members;
         HostPin<PgiMember> h_members;
         DevBuf<int32_t> status;
@@ -148,6 +150,7 @@ struct pg_ctx {
     int64_t tok_nl_fallbacks = 0;                          // deflated blocks whose line feeds were found by passes over the text after all
     HostPin<uint8_t> tok_pin;                              // two 4 MiB page-locked buffers per staging thread
     hipStream_t tok_st[PG_TOK_WORKERS] = {};               // one copy stream per staging thread
+    hipStream_t tok_crc = nullptr;                         // k_crc32 of a deflated block, beside the tokenizer's kernels
     hipStream_t tok_small = nullptr;                       // the collect step's few kilobytes (beside the next block's inflate on stream_up)
     hipEvent_t tok_wev[PG_TOK_WORKERS][2] = {};
     double tok_stage_s = 0, tok_kernel_s = 0;              // pg_tokenize_stats: wall seconds of the copies / of everything behind them

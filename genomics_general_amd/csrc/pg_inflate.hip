@@ -16,6 +16,8 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 namespace {
@@ -280,6 +282,149 @@ extern "C" int pg_inflate_members(const uint8_t *comp, const uint32_t *in_off, c
     return PG_OK;
 }
 
+// ---- host: ONE gzip stream (what `gzip` writes: `.geno.gz`, README.md:106 of the reference, read there by gzip.open) ---------------
+// A single deflate stream has no independent pieces: it is inflated serially, here by zlib's inflate() straight into the caller's
+// block buffer from a thread of the reader (the gzip module of rounds 3 - 5 went through 128 KiB Python byte strings: 0.4 GB/s of
+// text; this: profiles/r06/gzip_stream_reader.txt).  Concatenated members (`cat a.gz b.gz`) are followed; BGZF files take the member-
+// parallel routes above.
+struct pg_gz {
+    int fd = -1;
+    z_stream zs;
+    bool zs_live = false, eof = false, member_done = false;
+    std::vector<uint8_t> in, pending;          // compressed bytes read ahead; inflated bytes behind the last line feed handed out
+    size_t pending_at = 0;
+    int64_t total_in = 0, total_out = 0;
+};
+
+extern "C" int pg_gzip_open(const char *path, pg_gz **out) {
+    if (!path || !out) return pg_fail(PG_ERR_ARG, "pg_gzip_open: null argument");
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return pg_fail(PG_ERR_ARG, "pg_gzip_open: cannot open %s", path);
+    pg_gz *g = new pg_gz();
+    g->fd = fd;
+    memset(&g->zs, 0, sizeof(g->zs));
+    if (inflateInit2(&g->zs, 15 + 32) != Z_OK) {             // gzip or zlib header, detected
+        close(fd);
+        delete g;
+        return pg_fail(PG_ERR_HIP, "pg_gzip_open: inflateInit2 failed");
+    }
+    g->zs_live = true;
+    g->in.resize(1 << 20);
+    g->zs.avail_in = 0;
+    *out = g;
+    return PG_OK;
+}
+
+extern "C" int pg_gzip_close(pg_gz *g) {
+    if (!g) return PG_OK;
+    if (g->zs_live) inflateEnd(&g->zs);
+    if (g->fd >= 0) close(g->fd);
+    delete g;
+    return PG_OK;
+}
+
+// inflate up to `room` bytes to dst; returns the number produced (0 at the end of the input), < 0 on a damaged stream
+static int64_t gz_fill(pg_gz *g, uint8_t *dst, int64_t room) {
+    int64_t got = 0;
+    while (got < room && !g->eof) {
+        if (g->zs.avail_in == 0) {
+            const ssize_t r = read(g->fd, g->in.data(), g->in.size());
+            if (r < 0) return -1;
+            if (r == 0) {
+                // the end of the file: fine between members, an error inside one
+                if (!g->member_done && g->total_in > 0) return -2;
+                g->eof = true;
+                break;
+            }
+            g->zs.next_in = g->in.data();
+            g->zs.avail_in = (uInt)r;
+            g->total_in += r;
+        }
+        if (g->member_done) {
+            // bytes behind a member: the next member of a concatenated file (trailing zero padding is skipped, as gzip does)
+            while (g->zs.avail_in && *g->zs.next_in == 0) { ++g->zs.next_in; --g->zs.avail_in; }
+            if (!g->zs.avail_in) continue;
+            if (inflateReset(&g->zs) != Z_OK) return -3;
+            g->member_done = false;
+        }
+        const int64_t piece = std::min<int64_t>(room - got, 1 << 30);
+        g->zs.next_out = dst + got;
+        g->zs.avail_out = (uInt)piece;
+        const int rc = inflate(&g->zs, Z_NO_FLUSH);
+        got += piece - (int64_t)g->zs.avail_out;
+        if (rc == Z_STREAM_END) g->member_done = true;
+        else if (rc != Z_OK && rc != Z_BUF_ERROR) return -4;
+    }
+    g->total_out += got;
+    return got;
+}
+
+// At least `want` bytes of text (fewer only at the end of the input), extended to the next line feed: dst[0 .. *got_out).  cap must
+// exceed want by the longest line the caller expects; a line that does not end inside cap comes back without its line feed
+// (*complete_out = 0: call again and append).  *eof_out = 1 when nothing is left.
+extern "C" int pg_gzip_read_lines(pg_gz *g, uint8_t *dst, int64_t cap, int64_t want, int64_t *got_out, int *complete_out, int *eof_out) {
+    if (!g || !dst || !got_out || !complete_out || !eof_out || cap < 1 || want < 1) return pg_fail(PG_ERR_ARG, "pg_gzip_read_lines: bad argument");
+    if (want > cap) want = cap;
+    int64_t n = 0;
+    // what the last call inflated behind the line feed it stopped at
+    if (g->pending_at < g->pending.size()) {
+        const int64_t take = std::min<int64_t>((int64_t)(g->pending.size() - g->pending_at), cap);
+        memcpy(dst, g->pending.data() + g->pending_at, (size_t)take);
+        g->pending_at += (size_t)take;
+        n = take;
+    }
+    if (g->pending_at >= g->pending.size()) { g->pending.clear(); g->pending_at = 0; }
+    auto bad = [&](int64_t r) {
+        return pg_fail(PG_ERR_PARSE, "damaged gzip stream (%s; %lld bytes of text were read before)", r == -2 ? "the file ends inside a member" : r == -1 ? "read error" : "invalid deflate data or a wrong checksum", (long long)g->total_out);
+    };
+    // the bulk: straight into dst
+    if (n < want) {
+        const int64_t r = gz_fill(g, dst + n, want - n);
+        if (r < 0) return bad(r);
+        n += r;
+    }
+    bool complete = false;
+    if (n >= want && n > 0) {
+        // the first line feed at or behind byte want - 1 ends the block; what is already here behind it waits for the next call
+        const void *nl = memchr(dst + want - 1, '\n', (size_t)(n - (want - 1)));
+        if (nl) {
+            const int64_t cut = (static_cast<const uint8_t *>(nl) - dst) + 1;
+            if (cut < n) {
+                std::vector<uint8_t> rest(dst + cut, dst + n);
+                rest.insert(rest.end(), g->pending.begin() + (long)g->pending_at, g->pending.end());
+                g->pending.swap(rest);
+                g->pending_at = 0;
+            }
+            n = cut;
+            complete = true;
+        }
+    }
+    // ... else on to the next line feed, a piece at a time
+    while (!complete && n < cap && g->pending_at >= g->pending.size()) {
+        uint8_t piece[4096];
+        const int64_t r = gz_fill(g, piece, (int64_t)sizeof(piece));
+        if (r < 0) return bad(r);
+        if (r == 0) break;
+        const void *nl = memchr(piece, '\n', (size_t)r);
+        int64_t take = nl ? (static_cast<const uint8_t *>(nl) - piece) + 1 : r;
+        if (take > cap - n) { take = cap - n; nl = nullptr; }
+        memcpy(dst + n, piece, (size_t)take);
+        n += take;
+        if (take < r) {
+            g->pending.assign(piece + take, piece + r);
+            g->pending_at = 0;
+        }
+        if (nl) complete = true;
+    }
+    const bool drained = g->eof && g->pending_at >= g->pending.size();
+    if (drained) complete = true;                                    // (the input's last line may lack its line feed)
+    *got_out = n;
+    *complete_out = complete ? 1 : 0;
+    *eof_out = (n == 0 && drained) ? 1 : 0;
+    return PG_OK;
+}
+
 // ---- host: text -> BGZF (what `bgzip` writes; tools/bgzip.py, bench.py's compressed samples, tests) ------------------------------------
 // text[0 .. len) as members of `block` bytes of text each (bgzip: 65280), deflated at `level` by a pool of threads, + the empty EOF
 // member when eof_marker != 0.  *out_len_out = bytes written; PG_ERR_ARG when out_cap is too small (len + len / 1000 + 64 KiB + 28
@@ -362,7 +507,8 @@ extern "C" int pg_bgzf_compress(const uint8_t *text, int64_t len, int level, int
 // scanned (I.mem_base; total -> *d_total, a list that was too short -> *d_over)
 static int inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const uint32_t *comp_d, uint32_t n_dw, const uint32_t *in_off,
                          const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d,
-                         uint32_t nl_cap = 0, uint64_t text_limit = 0, int64_t *d_total = nullptr, int32_t *d_over = nullptr) {
+                         uint32_t nl_cap = 0, uint64_t text_limit = 0, int64_t *d_total = nullptr, int32_t *d_over = nullptr,
+                         hipStream_t crc_st = nullptr) {
     int rc;
     if (nl_cap) {
         if ((rc = I.nl_list.ensure_roomy((size_t)(n_members + 1) * nl_cap)) != PG_OK) return rc;
@@ -371,9 +517,9 @@ static int inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const ui
     }
     if ((rc = I.h_members.ensure_roomy((size_t)n_members + 1)) != PG_OK) return rc;
     if ((rc = I.members.ensure_roomy((size_t)n_members + 1)) != PG_OK) return rc;
-    if ((rc = I.status.ensure(2)) != PG_OK) return rc;
+    if ((rc = I.status.ensure(4)) != PG_OK) return rc;              // [0, 1] the decoder's error bits | first bad member, [2, 3] the same of the CRC check on its own stream
     if ((rc = I.sink.ensure_roomy((size_t)(n_members + 1) * 128)) != PG_OK) return rc;
-    if ((rc = I.h_status.ensure(2)) != PG_OK) return rc;
+    if ((rc = I.h_status.ensure(4)) != PG_OK) return rc;
     uint64_t at = 0;
     for (int64_t k = 0; k < n_members; ++k) {
         I.h_members.p[k] = PgiMember{in_off[k], in_len[k], at, out_len[k], crc ? crc[k] : 0u};
@@ -384,9 +530,9 @@ static int inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const ui
         if ((rc = I.crc_tab.ensure(t.size())) != PG_OK) return rc;
         HIPCHK(hipMemcpy(I.crc_tab.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
     }
-    I.h_status.p[0] = 0;
-    I.h_status.p[1] = 0x7FFFFFFF;
-    HIPCHK(hipMemcpyAsync(I.status.p, I.h_status.p, 8, hipMemcpyHostToDevice, st));
+    I.h_status.p[0] = I.h_status.p[2] = 0;
+    I.h_status.p[1] = I.h_status.p[3] = 0x7FFFFFFF;
+    HIPCHK(hipMemcpyAsync(I.status.p, I.h_status.p, 16, hipMemcpyHostToDevice, st));
     if (n_members == 0) return PG_OK;
     HIPCHK(hipMemcpyAsync(I.members.p, I.h_members.p, (size_t)n_members * sizeof(PgiMember), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_inflate, dim3((unsigned)n_members), dim3(64), 0, st, comp_d, n_dw, I.members.p, (int)n_members, text_d, I.sink.p, I.status.p,
@@ -396,10 +542,23 @@ static int inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const ui
         hipLaunchKernelGGL(k_member_scan, dim3(1), dim3(256), 0, st, I.nl_cnt.p, (int)n_members, nl_cap, I.mem_base.p, d_total, d_over);
         HIPCHK(hipGetLastError());
     }
+    I.crc_pending = false;
     if (crc && !getenv("PG_BGZF_NO_CRC")) {
-        hipLaunchKernelGGL(k_crc32, dim3((unsigned)((n_members + 3) / 4)), dim3(256), 0, st, text_d, I.members.p, (int)n_members,
-                           I.crc_tab.p, I.status.p);
+        if (crc_st) {
+            // the check needs the text and nobody needs the check before the block's rows are handed out: on a stream of its own,
+            // beside the line-feed scan and the tokenizer's kernels (0.5 ms per GiB of text off the chain of the block)
+            if (!I.ev_inflated) HIPCHK(hipEventCreateWithFlags(&I.ev_inflated, hipEventDisableTiming));
+            if (!I.ev_crc) HIPCHK(hipEventCreateWithFlags(&I.ev_crc, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(I.ev_inflated, st));
+            HIPCHK(hipStreamWaitEvent(crc_st, I.ev_inflated, 0));
+        }
+        hipLaunchKernelGGL(k_crc32, dim3((unsigned)((n_members + 3) / 4)), dim3(256), 0, crc_st ? crc_st : st, text_d, I.members.p, (int)n_members,
+                           I.crc_tab.p, crc_st ? I.status.p + 2 : I.status.p);
         HIPCHK(hipGetLastError());
+        if (crc_st) {
+            HIPCHK(hipEventRecord(I.ev_crc, crc_st));
+            I.crc_pending = true;
+        }
     }
     return PG_OK;
 }
@@ -457,8 +616,8 @@ extern "C" int pg_inflate_device(pg_ctx *c, const uint8_t *comp, int64_t comp_le
 // used by pg_tokenize.hip ------------------------------------------------------------------------------------------------------------
 int pg_inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const uint32_t *comp_d, uint32_t n_dw, const uint32_t *in_off,
                      const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d,
-                     uint32_t nl_cap, uint64_t text_limit, int64_t *d_total, int32_t *d_over) {
-    return inflate_queue(c, st, I, comp_d, n_dw, in_off, in_len, out_len, crc, n_members, text_d, nl_cap, text_limit, d_total, d_over);
+                     uint32_t nl_cap, uint64_t text_limit, int64_t *d_total, int32_t *d_over, hipStream_t crc_st) {
+    return inflate_queue(c, st, I, comp_d, n_dw, in_off, in_len, out_len, crc, n_members, text_d, nl_cap, text_limit, d_total, d_over, crc_st);
 }
 // the block's list of line feeds from the members' lists (pg_tokenize_parse, a block that arrived deflated)
 void pg_launch_nl_gather(hipStream_t st, pg_ctx::Inflate &I, uint32_t nl_cap, int64_t n_members, int64_t text_base, int64_t *nl_pos) {

@@ -734,7 +734,7 @@ static int tok_submit(pg_ctx *c, int slot, const TokSource &src, int64_t len, in
 
 int pg_inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const uint32_t *comp_d, uint32_t n_dw, const uint32_t *in_off,
                      const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *text_d,
-                     uint32_t nl_cap, uint64_t text_limit, int64_t *d_total, int32_t *d_over);
+                     uint32_t nl_cap, uint64_t text_limit, int64_t *d_total, int32_t *d_over, hipStream_t crc_st);
 void pg_launch_nl_gather(hipStream_t st, pg_ctx::Inflate &I, uint32_t nl_cap, int64_t n_members, int64_t text_base, int64_t *nl_pos);
 int pg_inflate_error(const int32_t *status);
 void pg_launch_gather_bytes(hipStream_t st, const uint8_t *text, const int64_t *off, const int32_t *len, const int64_t *dst, int n,
@@ -834,8 +834,13 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
         if ((rc = T.i64.ensure_roomy(4)) != PG_OK) return rc;
         HIPCHK(hipMemsetAsync(T.i32.p, 0, 16, st));                 // [0] status bits, [1] number of runs, [2] a member's list was too short
     }
+    static const bool crc_aside = !(getenv("PG_BGZF_CRC_STREAM") && atoi(getenv("PG_BGZF_CRC_STREAM")) == 0);
+    if (crc_aside && !c->tok_crc) HIPCHK(hipStreamCreateWithFlags(&c->tok_crc, hipStreamNonBlocking));
+    // (the slot's text must not be written while the check of the block that used it last still reads it)
+    if (T.inf.crc_pending && T.inf.ev_crc) HIPCHK(hipStreamWaitEvent(st, T.inf.ev_crc, 0));
     if ((rc = pg_inflate_queue(c, st, T.inf, T.inf.comp.p, (uint32_t)n_dw, in_off, in_len, out_len, crc, n_members, T.tp + head_len,
-                               nl_cap, (uint64_t)(text_len - head_len), nl_cap ? T.i64.p : nullptr, nl_cap ? T.i32.p + 2 : nullptr)) != PG_OK) return rc;
+                               nl_cap, (uint64_t)(text_len - head_len), nl_cap ? T.i64.p : nullptr, nl_cap ? T.i32.p + 2 : nullptr,
+                               crc_aside ? c->tok_crc : nullptr)) != PG_OK) return rc;
     lap(3);
     HIPCHK(hipMemcpyAsync(T.h_total.p + 2, T.inf.status.p, 8, hipMemcpyDeviceToHost, st));     // [error bits, first bad member]: read by parse
     if (nl_cap) {
@@ -950,6 +955,10 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
                            T.pos64.p, T.off.p, T.off.p + run_cap, T.pos.p, d_status + 1, run_cap, d_status, dip);
     }
     HIPCHK(hipGetLastError());
+    if (T.deflated && T.inf.crc_pending) {
+        HIPCHK(hipStreamWaitEvent(st, T.inf.ev_crc, 0));             // (long done: it started behind the inflate)
+        HIPCHK(hipMemcpyAsync(T.h_total.p + 4, T.inf.status.p + 2, 8, hipMemcpyDeviceToHost, st));   // read by collect
+    }
     HIPCHK(hipMemcpyAsync(T.h_total.p + 1, d_status, 8, hipMemcpyDeviceToHost, st));            // status | runs, as two int32
     HIPCHK(hipMemcpyAsync(T.h_pos.p, T.pos64.p, (size_t)n_lines * 8, hipMemcpyDeviceToHost, st));
     if (!T.parsed) HIPCHK(hipEventCreateWithFlags(&T.parsed, hipEventDisableTiming));
@@ -987,6 +996,12 @@ static int tok_collect(pg_ctx *c, int slot, int64_t *pos_out, int64_t pos_capaci
     const int64_t n_lines = T.n_lines;
     if (!pos_out || !run_row_out || !run_off_out || !run_len_out || pos_capacity < n_lines)
         return pg_fail(PG_ERR_ARG, "pg_tokenize_collect: outputs too small for %lld rows", (long long)n_lines);
+    if (T.deflated && T.inf.crc_pending) {
+        T.inf.crc_pending = false;
+        int32_t cst[2];
+        memcpy(cst, T.h_total.p + 4, 8);
+        if (cst[0]) return pg_inflate_error(cst);                    // a member's text is not what its trailer says
+    }
     int32_t status[2];
     memcpy(status, T.h_total.p + 1, 8);
     if (status[0] != 0) return PG_OK;

@@ -168,7 +168,7 @@ class Engine:
         self._pair_first = "slot"
 
     def set_sum_order(self, mode):
-        """0: the float64 sums of pi / dxy / Fst and of the ABBA-BABA statistics in NumPy's order for windows of up to 4096 sites;
+        """0: the float64 sums of pi / dxy / Fst and of the ABBA-BABA statistics in NumPy's order for windows of up to 256 sites (PG_NP_MAX_SITES);
         1: for every window; 2: for none (pg_set_sum_order)"""
         check(self._L.pg_set_sum_order(self._h, int(mode)))
 

@@ -494,6 +494,61 @@ class BgzfFile:
         self.raw.close()
 
 
+class GzipStream:
+    """ONE gzip stream (what `gzip` writes; the reference reads it with gzip.open, genomics.py:1917): inflated serially by zlib in the
+    library (pg_gzip_read_lines), straight into the block's buffer -- no Python byte strings on the way.  BGZF files never come here
+    (BgzfFile: members in parallel, on the device)."""
+
+    MARGIN = 16 << 20
+
+    def __init__(self, path):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        check(self._L.pg_gzip_open(os.fsencode(str(path)), C.byref(h)))
+        self._h = h
+        self.eof = False
+
+    def read_lines(self, want):
+        """at least `want` bytes of text (fewer at the end of the input) up to a line feed, as a memoryview of a fresh array;
+        want None: everything that is left"""
+        if want is None:
+            parts = []
+            while True:
+                b = self.read_lines(256 << 20)
+                if len(b) == 0:
+                    break
+                parts.append(np.frombuffer(b, dtype=np.uint8))
+            return memoryview(np.concatenate(parts)) if len(parts) > 1 else memoryview(parts[0]) if parts else b""
+        if self.eof:
+            return b""
+        want = max(int(want), 1)
+        parts, total = [], 0
+        while True:
+            cap = want + self.MARGIN
+            buf = np.empty(cap, dtype=np.uint8)
+            got, complete, eof = C.c_int64(0), C.c_int(0), C.c_int(0)
+            check(self._L.pg_gzip_read_lines(self._h, C.c_void_p(buf.ctypes.data), cap, want, C.byref(got), C.byref(complete), C.byref(eof)))
+            if got.value:
+                parts.append(buf[:got.value])
+                total += got.value
+            if eof.value:
+                self.eof = True
+            if complete.value or eof.value:
+                break
+            want = 1                                   # (a line longer than the margin: the rest of it)
+        if not parts:
+            return b""
+        return memoryview(parts[0] if len(parts) == 1 else np.concatenate(parts))
+
+    def readline(self):
+        return bytes(self.read_lines(1))
+
+    def close(self):
+        if self._h is not None:
+            self._L.pg_gzip_close(self._h)
+            self._h = None
+
+
 class BlockReader:
     """The input as a sequence of byte blocks that end at line boundaries (gunzipped when the name ends in .gz -- in parallel
     when the file is BGZF, i.e. written by bgzip; stdin when path is None).  read_block(None) returns everything that is
@@ -506,7 +561,8 @@ class BlockReader:
         if path is None:
             self.f = STDIN
         elif str(path).endswith(".gz"):
-            self.f = BgzfFile(path) if BgzfFile.is_bgzf(path) else gzip.open(path, "rb")
+            # (PG_GZIP_NATIVE=0: Python's gzip module, the reader of rounds 3 - 5)
+            self.f = BgzfFile(path) if BgzfFile.is_bgzf(path) else (GzipStream(path) if os.environ.get("PG_GZIP_NATIVE", "1") != "0" else gzip.open(path, "rb"))
         else:
             import mmap
             self.f = open(path, "rb")
@@ -572,6 +628,8 @@ class BlockReader:
             return data
         if nbytes is None:
             data = self.f.read()
+        elif isinstance(self.f, GzipStream):
+            data = self.f.read_lines(nbytes)
         else:
             data = self.f.read(nbytes)
             if data and not data.endswith(b"\n"):

@@ -85,7 +85,7 @@ int pg_set_reference_order(pg_ctx *ctx, const int32_t *pop_row_order, const int3
  * its samples (distMat.py:44-45).  Slot order after pg_set_samples. */
 int pg_set_sample_rank(pg_ctx *ctx, const int32_t *rank);
 
-/* Which windows get their float64 sums in NumPy's order (pg_popdist_stats, pg_abbababa, pg_fourpop): 0 = those of up to 4096 sites
+/* Which windows get their float64 sums in NumPy's order (pg_popdist_stats, pg_abbababa, pg_fourpop): 0 = those of up to 256 sites (PG_NP_MAX_SITES)
  * (default: where the last bit shows in the printed digits), 1 = all (a caller that found a value of a long window within reach of
  * a rounding tie asks again for that window: cli.py), 2 = none (fixed reduction trees, within 1e-15). */
 int pg_set_sum_order(pg_ctx *ctx, int mode);
@@ -310,6 +310,15 @@ int pg_bgzf_walk(const uint8_t *buf, int64_t len, int64_t max_members, int64_t m
                  uint32_t *out_len, uint32_t *crc, int64_t *n_members_out, int64_t *consumed_out, int64_t *text_out);
 /* the members inflated by a pool of host threads (zlib): member k -> dst[out_off[k] .. + out_len[k]); crc (may be NULL) is checked.
  * The route of blocks the device tokenizer refuses and of the readers' own small reads (header line, shard cuts). */
+/* ONE gzip stream (`gzip file.geno`: the reference reads it with gzip.open, popgenWindows.py:313, genomics.py:1917): nothing to run in
+ * parallel, so zlib's inflate() on the reader's thread, straight into the caller's block buffer.  pg_gzip_read_lines: at least `want`
+ * bytes of text (fewer only at the end of the input) extended to the next line feed, in dst[0 .. *got_out); cap > want by the
+ * longest line expected; *complete_out = 0: the last line did not end inside cap (call again, append); *eof_out = 1: nothing left.
+ * Concatenated members are followed; a damaged stream is PG_ERR_PARSE. */
+typedef struct pg_gz pg_gz;
+int pg_gzip_open(const char *path, pg_gz **out);
+int pg_gzip_read_lines(pg_gz *g, uint8_t *dst, int64_t cap, int64_t want, int64_t *got_out, int *complete_out, int *eof_out);
+int pg_gzip_close(pg_gz *g);
 int pg_inflate_members(const uint8_t *comp, const uint32_t *in_off, const uint32_t *in_len, const int64_t *out_off,
                        const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *dst, int n_threads);
 /* text -> BGZF, what `bgzip` writes (tools/bgzip.py; bench.py's compressed samples; tests): members of `block` bytes of text (bgzip:

@@ -199,6 +199,22 @@ def test_positions_with_leading_zeros_and_nineteen_digits():
             encode_text(bad, lay)
 
 
+def test_the_documented_numpy_order_limit_is_the_compiled_one():
+    """PG_NP_MAX_SITES moved from 4096 to 256 and the header, engine.py and cli.py kept the old number.  The
+    header is the contract: whatever it, the Python mirror and the docstrings say must be the number the library was compiled with."""
+    import re
+    with open(os.path.join(ROOT, "genomics_general_amd", "csrc", "pg_internal.h")) as f:
+        compiled = int(re.search(r"#define PG_NP_MAX_SITES (\d+)", f.read()).group(1))
+    from genomics_general_amd import cli
+    assert cli.NP_MAX_SITES == compiled
+    for rel, pat in (("include/popgen_hip.h", r"up to (\d+) sites \(PG_NP_MAX_SITES\)"),
+                     ("genomics_general_amd/engine.py", r"up to (\d+) sites \(PG_NP_MAX_SITES\)"),
+                     ("genomics_general_amd/cli.py", r"more than NP_MAX_SITES \((\d+)\)")):
+        with open(os.path.join(ROOT, rel)) as f:
+            found = re.findall(pat, f.read())
+        assert found and all(int(x) == compiled for x in found), (rel, found, compiled)
+
+
 def test_sampledata_mirror():
     sd = SampleData(indNames=["q"], popNames=["A", "B"], popInds=[["x", "y"], ["y", "z"]], ploidyDict={"q": 1, "x": 2, "y": 2, "z": 2})
     assert sd.indNames == ["q", "x", "y", "z"]

@@ -252,3 +252,61 @@ def test_a_line_longer_than_the_members_of_a_block_is_handed_on_as_text(tmp_path
         got.append(bytes(b))
         assert got[-1].endswith(b"\n")
     assert b"".join(got) == text
+
+
+def test_one_gzip_stream_through_the_native_reader(tmp_path):
+    """`gzip file.geno` (README.md:106 of the reference; gzip.open there): ONE deflate stream, read by zlib inside the library
+    (pg_gzip_read_lines) straight into the block's buffer.  Blocks end at line feeds whatever size is asked for, concatenated members
+    (`cat a.gz b.gz`) and an empty member are followed, a last line without a line feed comes through, damage and truncation are
+    named."""
+    rng = random.Random(4)
+
+    def lines(n):
+        return b"".join(b"chr1\t%d\t" % i + b"\t".join(rng.choice([b"A/A", b"A/T", b"T/T"]) for _ in range(rng.randrange(1, 40))) + b"\n"
+                        for i in range(n))
+    cases = [b"", b"x", b"no newline at end", lines(5), lines(3000), lines(200) + b"tail", b"\n" * 1000, b"a" * 3000000 + b"\n" + lines(10)]
+    for k, data in enumerate(cases):
+        for multi in (False, True):
+            p = str(tmp_path / ("t%d.gz" % k))
+            with open(p, "wb") as f:
+                if multi and len(data) > 10:
+                    h = len(data) // 3
+                    f.write(gzip.compress(data[:h]) + gzip.compress(b"") + gzip.compress(data[h:]))
+                else:
+                    f.write(gzip.compress(data))
+            for want in (1, 7, 4096, 70000, None):
+                rd = genoio.GzipStream(p)
+                got = b""
+                while True:
+                    b = bytes(rd.read_lines(want))
+                    if not b:
+                        break
+                    assert b.endswith(b"\n") or got + b == data
+                    assert want is None or got + b == data or len(b) >= want
+                    got += b
+                assert got == data, (k, multi, want)
+                rd.close()
+    # the drivers' reader: header line, then blocks
+    p = str(tmp_path / "g.geno.gz")
+    text = b"#CHROM\tPOS\ta\tb\n" + lines(4000)
+    with open(p, "wb") as f:
+        f.write(gzip.compress(text))
+    rd = genoio.BlockReader(p)
+    assert isinstance(rd.f, genoio.GzipStream) and rd.read_header() == b"#CHROM\tPOS\ta\tb\n"
+    body = b""
+    while True:
+        b = rd.read_block(30000)
+        if len(b) == 0:
+            break
+        body += bytes(b)
+    assert body == text[len(b"#CHROM\tPOS\ta\tb\n"):]
+    rd.close()
+    raw = bytearray(gzip.compress(lines(3000)))
+    raw[len(raw) // 2] ^= 0x55
+    for blob, what in ((bytes(raw), "invalid deflate data"), (gzip.compress(lines(3000))[:-300], "ends inside a member")):
+        with open(p, "wb") as f:
+            f.write(blob)
+        with pytest.raises(Exception, match=what):
+            rd = genoio.GzipStream(p)
+            while bytes(rd.read_lines(1000)):
+                pass

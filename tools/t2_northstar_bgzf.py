@@ -110,42 +110,53 @@ def main():
     text_bytes, file_bytes = write_bgzf_resident(gz, e, lay, names, n_sites, scaf_len)
     write_s = time.perf_counter() - w0
     e.close()
-    cmd = [sys.executable, os.path.join(ROOT, "popgenWindows.py"), "-g", gz, "-o", csv, "-f", "phased", "-w", str(wind), "-m", str(wl["min_sites"]),
-           "--roundTo", os.environ.get("PG_NS_ROUND", "12")]
-    tol = 1e-9 if int(os.environ.get("PG_NS_ROUND", "12")) >= 10 else 0.51 * 10.0 ** -int(os.environ.get("PG_NS_ROUND", "12"))
+    cmd = [sys.executable, os.path.join(ROOT, "popgenWindows.py"), "-g", gz, "-o", csv, "-f", "phased", "-w", str(wind), "-m", str(wl["min_sites"])]
     for k, p in enumerate(sd.popNames):
         cmd += ["-p", p, ",".join(names[k * per:(k + 1) * per])]
-    runs = []
-    for _ in range(reps):
+
+    def run_once(argv):
         w0 = time.perf_counter()
-        r = subprocess.run(cmd, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE, timeout=1200)
+        r = subprocess.run(argv, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE, timeout=1200)
         wall = time.perf_counter() - w0
         line = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")]
         if r.returncode != 0 or not line:
             raise SystemExit("popgenWindows.py failed:\n" + r.stderr.decode()[-2000:])
         tm = json.loads(line[-1][len("PG_TIMING "):])
-        runs.append({"total_s": round(tm["total_s"], 4), "context_s": round(tm.get("context_s", 0.0), 4), "process_wall_s": round(wall, 3),
-                     "tokenize_s": round(tm.get("tokenize_s", 0.0), 4), "tokenizer_kernels_s": round(tm.get("tokenizer_kernels_s", 0.0), 4),
-                     "prep_wait_s": round(tm.get("prep_wait_s", 0.0), 4), "main_stats_s": round(tm.get("main_stats_s", 0.0), 4),
-                     "main_format_s": round(tm.get("main_format_s", 0.0), 4), "chunks": tm.get("chunks"),
-                     "bgzf_blocks_inflated_on_device": tm.get("bgzf_blocks_inflated_on_device"), "host_tokenized_blocks": tm.get("host_tokenized_blocks")})
-    with open(csv) as f:
-        rows = [ln.strip().split(",") for ln in f.readlines()]
-    head, rows = rows[0], rows[1:]
-    same = len(rows) == len(lo)
-    worst = 0.0
-    for w, row in enumerate(rows):
-        k, r = divmod(w * wind, scaf_len)
-        same = same and row[0] == "chr%d" % (k + 1) and int(row[1]) == r + 1 and int(row[2]) == r + wind and int(row[4]) == wind
-        for name, v in zip(head[5:], row[5:]):
-            g = table[w, cols.index(name)]
-            v = float(v)
-            if g != g or v != v:
-                same = same and (g != g and v != v)
-            else:
-                err = abs(v - g) / max(1.0, abs(g))
-                worst = max(worst, err)
-                same = same and err <= tol
+        return {"total_s": round(tm["total_s"], 4), "context_s": round(tm.get("context_s", 0.0), 4), "process_wall_s": round(wall, 3),
+                "tokenize_s": round(tm.get("tokenize_s", 0.0), 4), "tokenizer_kernels_s": round(tm.get("tokenizer_kernels_s", 0.0), 4),
+                "prep_wait_s": round(tm.get("prep_wait_s", 0.0), 4), "main_stats_s": round(tm.get("main_stats_s", 0.0), 4),
+                "main_format_s": round(tm.get("main_format_s", 0.0), 4), "chunks": tm.get("chunks"),
+                "windows_recomputed_in_numpy_order": tm.get("windows_recomputed_in_numpy_order", 0),
+                "bgzf_blocks_inflated_on_device": tm.get("bgzf_blocks_inflated_on_device"), "host_tokenized_blocks": tm.get("host_tokenized_blocks")}
+
+    def check_csv(tol):
+        with open(csv) as f:
+            rows = [ln.strip().split(",") for ln in f.readlines()]
+        head, rows = rows[0], rows[1:]
+        same = len(rows) == len(lo)
+        worst = 0.0
+        for w, row in enumerate(rows):
+            k, r = divmod(w * wind, scaf_len)
+            same = same and row[0] == "chr%d" % (k + 1) and int(row[1]) == r + 1 and int(row[2]) == r + wind and int(row[4]) == wind
+            for name, v in zip(head[5:], row[5:]):
+                g = table[w, cols.index(name)]
+                v = float(v)
+                if g != g or v != v:
+                    same = same and (g != g and v != v)
+                else:
+                    err = abs(v - g) / max(1.0, abs(g))
+                    worst = max(worst, err)
+                    same = same and err <= tol
+        return bool(same), worst, len(rows) * (len(head) - 5)
+
+    # The timed runs are the reference's own command line: its default --roundTo 4 (popgenWindows.py:198).  One more run prints twelve
+    # decimals, so that every cell can be held against the T0 statistics to 1e-9 -- at twelve digits every value is within reach of
+    # a rounding tie of its last digit, so the driver computes EVERY window a second time in NumPy's summation order
+    # (cli._refine_long_windows): that run does twice the statistics work and is reported beside the others, not as the rate.
+    runs = [run_once(cmd) for _ in range(reps)]
+    same4, worst4, n_cells = check_csv(0.51e-4)
+    deep = run_once(cmd + ["--roundTo", "12"])
+    same12, worst12, _ = check_csv(1e-9)
     best = min(runs, key=lambda x: x["total_s"])
     out = {"workload": "north star, whole: %d sites x %d diploids, %d scaffolds, %d windows of %d sites" % (n_sites, n_dip, -(-n_sites // scaf_len), len(lo), wind),
            "input": "one `.geno.gz` written as BGZF (members of 65 280 bytes of text, level 6)", "text_bytes": text_bytes, "file_bytes": file_bytes,
@@ -153,10 +164,15 @@ def main():
            "runs": runs, "best": {"total_s": best["total_s"], "windows_per_sec": round(len(lo) / best["total_s"], 1),
                                   "sites_per_sec": round(n_sites / best["total_s"], 1), "text_GBps": round(text_bytes / best["total_s"] / 1e9, 2),
                                   "text_GBps_without_context": round(text_bytes / (best["total_s"] - best["context_s"]) / 1e9, 2)},
-           "round_to": int(os.environ.get("PG_NS_ROUND", "12")), "csv_matches_t0": bool(same), "largest_relative_difference": worst, "compared_cells": len(rows) * (len(head) - 5),
+           "round_to": 4, "csv_matches_t0": bool(same4 and same12), "largest_relative_difference": worst12, "compared_cells": n_cells,
+           "run_at_roundTo_12": dict(deep, csv_matches_t0=same12, tolerance=1e-9, largest_relative_difference=worst12,
+                                     windows_per_sec=round(len(lo) / deep["total_s"], 1)),
+           "largest_difference_at_the_default_rounding": worst4,
            "t0_pass_over_the_resident_rows_s": round(t0_s, 4),
-           "note": "total_s: inside the driver, from opening the input to the last row written (PG_TIMING); every float cell of the CSV (--roundTo 12) "
-                   "against the statistics of the resident rows (1e-9 relative); scaffold, start, end and sites of every row exact"}
+           "note": "total_s: inside the driver, from opening the input to the last row written (PG_TIMING).  Timed runs: the reference's default "
+                   "rounding (4 decimals); run_at_roundTo_12: the same command printing 12 decimals, every float cell against the statistics of "
+                   "the resident rows (1e-9 relative) -- there every window is computed twice (fixed trees, then NumPy's order for the last "
+                   "digit); scaffold, start, end and sites of every row exact"}
     print(json.dumps(out))
     if os.environ.get("PG_NS_KEEP"):                          # (for a profiler run of the same command: the file stays, the command is written next to it)
         with open(os.environ["PG_NS_KEEP"], "w") as f:
