@@ -626,10 +626,10 @@ class BlockReader:
                 data = data[:len(data) - over]
             self.bytes_read += len(data)
             return data
-        if nbytes is None:
-            data = self.f.read()
-        elif isinstance(self.f, GzipStream):
+        if isinstance(self.f, GzipStream):
             data = self.f.read_lines(nbytes)
+        elif nbytes is None:
+            data = self.f.read()
         else:
             data = self.f.read(nbytes)
             if data and not data.endswith(b"\n"):
