@@ -8,15 +8,21 @@
 //   pg_tokenize_submit_bgzf  the submit step of the device tokenizer for a block that is still deflated
 #include "pg_ctx.h"
 #include "pg_inflate_core.h"
+#include "pg_fast_inflate.h"
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <mutex>
+#include <deque>
+#include <condition_variable>
 #include <thread>
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -294,7 +300,153 @@ struct pg_gz {
     std::vector<uint8_t> in, pending;          // compressed bytes read ahead; inflated bytes behind the last line feed handed out
     size_t pending_at = 0;
     int64_t total_in = 0, total_out = 0;
+    // the route of pg_fast_inflate.h: the file mapped, this library's own decoder (PG_GZIP_FAST=0: zlib's inflate(), above)
+    const uint8_t *map = nullptr;
+    size_t map_len = 0, map_at = 0;
+    pgfi::State *fi = nullptr;
+    bool in_member = false;
+    uint32_t crc = 0, isize = 0;
 };
+
+// CRC-32 beside the decoder: zlib's crc32 runs at about 1 GB/s a thread, the decoder at more than 2 -- so the pieces the decoder
+// finishes (8 MiB each, still in the cache) are checksummed by a few helper threads while it goes on, and the pieces' values are
+// combined in order (crc32_combine) where the member ends or the call returns.
+struct CrcPipe {
+    struct Job { const uint8_t *p; size_t n; uint32_t crc; };
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    size_t next = 0;
+    bool closing = false;
+    std::vector<std::thread> th;
+    void start(int n_threads) {
+        for (int t = 0; t < n_threads; ++t)
+            th.emplace_back([this]() {
+                for (;;) {
+                    Job *j = nullptr;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv.wait(lk, [&] { return next < jobs.size() || closing; });
+                        if (next >= jobs.size()) return;
+                        j = &jobs[next++];
+                    }
+                    j->crc = (uint32_t)crc32_z(0u, j->p, j->n);
+                }
+            });
+    }
+    void push(const uint8_t *p, size_t n) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            jobs.push_back(Job{p, n, 0u});
+        }
+        cv.notify_one();
+    }
+    // waits for the helpers and folds the pieces pushed so far into crc
+    uint32_t drain(uint32_t crc) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            closing = true;
+        }
+        cv.notify_all();
+        for (auto &x : th) x.join();
+        th.clear();
+        for (const Job &j : jobs) crc = (uint32_t)crc32_combine(crc, j.crc, (z_off_t)j.n);
+        jobs.clear();
+        next = 0;
+        closing = false;
+        return crc;
+    }
+};
+
+// the gzip member header at g->map[g->map_at ..] (RFC 1952); 0: parsed (map_at behind it), 1: the end of the file (only zero padding
+// left), < 0: not a gzip member
+static int gz_member_header(pg_gz *g) {
+    const uint8_t *p = g->map + g->map_at, *e = g->map + g->map_len;
+    while (p < e && *p == 0) ++p;                                       // (padding between / behind members, as gzip skips it)
+    if (p == e) { g->map_at = g->map_len; return 1; }
+    if (e - p < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return -1;
+    const int flg = p[3];
+    p += 10;
+    if (flg & 4) {
+        if (e - p < 2) return -1;
+        const size_t xlen = (size_t)p[0] | ((size_t)p[1] << 8);
+        p += 2;
+        if ((size_t)(e - p) < xlen) return -1;
+        p += xlen;
+    }
+    for (int f = 8; f <= 16; f <<= 1)                                   // FNAME, FCOMMENT: zero-terminated
+        if (flg & f) {
+            const void *z = memchr(p, 0, (size_t)(e - p));
+            if (!z) return -1;
+            p = static_cast<const uint8_t *>(z) + 1;
+        }
+    if (flg & 2) {
+        if (e - p < 2) return -1;
+        p += 2;
+    }
+    g->map_at = (size_t)(p - g->map);
+    return 0;
+}
+
+static int64_t gz_fill_fast(pg_gz *g, uint8_t *dst, int64_t room) {
+    int64_t got = 0;
+    static const bool skip_crc = getenv("PG_GZIP_NO_CRC") != nullptr;                        // (timing experiments only)
+    const bool piped = room >= (32 << 20) && !skip_crc;
+    CrcPipe pipe;
+    const int helpers = std::max(1, std::min(4, pg_host_threads() - 1));
+    auto fold = [&]() {                                                                      // the helpers' pieces into g->crc
+        if (!pipe.th.empty() || !pipe.jobs.empty()) {
+            g->crc = pipe.drain(g->crc);
+        }
+    };
+    int64_t rc_out = 0;
+    while (got < room && !g->eof) {
+        if (!g->in_member) {
+            const int h = gz_member_header(g);
+            if (h == 1) {
+                if (g->total_out == 0 && !g->member_done && g->map_len > 0) { rc_out = -4; break; }   // (nothing but zeros)
+                g->eof = true;
+                break;
+            }
+            if (h < 0) { rc_out = g->member_done ? -5 : -4; break; }
+            pgfi::State &st = *g->fi;
+            st.in = g->map + g->map_at;
+            st.in_end = g->map + g->map_len;
+            st.bitbuf = 0; st.bitcnt = 0; st.over = 0; st.phase = 0; st.last = false; st.pend_len = 0; st.win_len = 0; st.tables_fixed = false;
+            g->in_member = true;
+            g->member_done = false;
+            g->crc = 0;
+            g->isize = 0;
+        }
+        uint64_t n = 0;
+        const uint64_t piece = piped ? std::min<uint64_t>((uint64_t)(room - got), 8u << 20) : (uint64_t)(room - got);
+        const int rc = pgfi::inflate(*g->fi, dst + got, piece, &n);
+        if (n) {
+            if (piped) {
+                if (pipe.th.empty()) pipe.start(helpers);
+                pipe.push(dst + got, (size_t)n);
+            } else if (!skip_crc) g->crc = (uint32_t)crc32_z(g->crc, dst + got, (size_t)n);
+            g->isize += (uint32_t)n;
+            got += (int64_t)n;
+        }
+        if (rc == pgfi::NEED_OUTPUT) continue;                                               // (the piece is full; the loop ends when the room is)
+        if (rc == pgfi::ERR_INPUT) { rc_out = -2; break; }
+        if (rc != pgfi::STREAM_END) { rc_out = -4; break; }
+        const uint8_t *t = nullptr;
+        if (!pgfi::stream_tail(*g->fi, &t) || (g->map + g->map_len) - t < 8) { rc_out = -2; break; }
+        const uint32_t want_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t want_len = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        fold();
+        if ((want_crc != g->crc && !skip_crc) || want_len != g->isize) { rc_out = -4; break; }
+        g->map_at = (size_t)(t + 8 - g->map);
+        g->in_member = false;
+        g->member_done = true;
+    }
+    fold();
+    if (rc_out < 0) return rc_out;
+    g->total_out += got;
+    return got;
+}
 
 extern "C" int pg_gzip_open(const char *path, pg_gz **out) {
     if (!path || !out) return pg_fail(PG_ERR_ARG, "pg_gzip_open: null argument");
@@ -312,6 +464,20 @@ extern "C" int pg_gzip_open(const char *path, pg_gz **out) {
     g->zs_live = true;
     g->in.resize(1 << 20);
     g->zs.avail_in = 0;
+    if (!(getenv("PG_GZIP_FAST") && atoi(getenv("PG_GZIP_FAST")) == 0)) {
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+            g->map_len = (size_t)sb.st_size;
+            if (g->map_len) {
+                void *m = mmap(nullptr, g->map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    g->map = static_cast<const uint8_t *>(m);
+                    (void)madvise(m, g->map_len, MADV_SEQUENTIAL);
+                }
+            }
+            if (g->map || g->map_len == 0) g->fi = new pgfi::State();
+        }
+    }
     *out = g;
     return PG_OK;
 }
@@ -319,6 +485,8 @@ extern "C" int pg_gzip_open(const char *path, pg_gz **out) {
 extern "C" int pg_gzip_close(pg_gz *g) {
     if (!g) return PG_OK;
     if (g->zs_live) inflateEnd(&g->zs);
+    if (g->map) munmap(const_cast<uint8_t *>(g->map), g->map_len);
+    delete g->fi;
     if (g->fd >= 0) close(g->fd);
     delete g;
     return PG_OK;
@@ -326,6 +494,10 @@ extern "C" int pg_gzip_close(pg_gz *g) {
 
 // inflate up to `room` bytes to dst; returns the number produced (0 at the end of the input), < 0 on a damaged stream
 static int64_t gz_fill(pg_gz *g, uint8_t *dst, int64_t room) {
+    if (g->fi) {
+        if (g->map_len == 0) { g->eof = true; return 0; }
+        return gz_fill_fast(g, dst, room);
+    }
     int64_t got = 0;
     while (got < room && !g->eof) {
         if (g->zs.avail_in == 0) {
@@ -376,7 +548,7 @@ extern "C" int pg_gzip_read_lines(pg_gz *g, uint8_t *dst, int64_t cap, int64_t w
     }
     if (g->pending_at >= g->pending.size()) { g->pending.clear(); g->pending_at = 0; }
     auto bad = [&](int64_t r) {
-        return pg_fail(PG_ERR_PARSE, "damaged gzip stream (%s; %lld bytes of text were read before)", r == -2 ? "the file ends inside a member" : r == -1 ? "read error" : "invalid deflate data or a wrong checksum", (long long)g->total_out);
+        return pg_fail(PG_ERR_PARSE, "damaged gzip stream (%s; %lld bytes of text were read before)", r == -2 ? "the file ends inside a member" : r == -1 ? "read error" : r == -5 ? "bytes behind the last member that are no gzip member" : "invalid deflate data or a wrong checksum", (long long)g->total_out);
     };
     // the bulk: straight into dst
     if (n < want) {

@@ -834,7 +834,10 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
         if ((rc = T.i64.ensure_roomy(4)) != PG_OK) return rc;
         HIPCHK(hipMemsetAsync(T.i32.p, 0, 16, st));                 // [0] status bits, [1] number of runs, [2] a member's list was too short
     }
-    static const bool crc_aside = !(getenv("PG_BGZF_CRC_STREAM") && atoi(getenv("PG_BGZF_CRC_STREAM")) == 0);
+    // PG_BGZF_CRC_STREAM=1: k_crc32 on a stream of its own, beside the tokenizer's kernels.  Measured on the whole north star
+    // (profiles/r06/t2_whole_crc_stream_ab.txt): 0.81 - 0.84 s against 0.64 - 0.80 s with the check on the chain -- kernels of two streams
+    // share the compute units and every one of them, the statistics kernels of the main thread included, gets slower; not the default.
+    static const bool crc_aside = getenv("PG_BGZF_CRC_STREAM") && atoi(getenv("PG_BGZF_CRC_STREAM")) == 1;
     if (crc_aside && !c->tok_crc) HIPCHK(hipStreamCreateWithFlags(&c->tok_crc, hipStreamNonBlocking));
     // (the slot's text must not be written while the check of the block that used it last still reads it)
     if (T.inf.crc_pending && T.inf.ev_crc) HIPCHK(hipStreamWaitEvent(st, T.inf.ev_crc, 0));

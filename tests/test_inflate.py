@@ -310,3 +310,69 @@ def test_one_gzip_stream_through_the_native_reader(tmp_path):
             rd = genoio.GzipStream(p)
             while bytes(rd.read_lines(1000)):
                 pass
+
+
+def test_the_fast_host_decoder_against_zlib(tmp_path):
+    """genomics_general_amd/csrc/pg_fast_inflate.h (the decoder behind GzipStream: one long stream, 11-bit tables, eight-byte
+    refills and copies, resumable at any output byte): every block type, level, strategy and two memory levels (memLevel 1: many
+    short blocks), outputs that straddle the caller's buffers at odd sizes (the saved 32 KiB window, the rest of a match carried
+    over), patterns of every short period; then damaged and truncated streams: refused, or exactly zlib's bytes -- never a crash
+    (`make asan-test` runs this file under AddressSanitizer)."""
+    rng = random.Random(11)
+    cases = [b"", b"a", b"abc" * 1000, bytes(rng.randrange(256) for _ in range(60000)), bytes(rng.randrange(4) for _ in range(120000)),
+             geno_text(rng, 2000, 50), geno_text(rng, 300, 400), b"\0" * 200000]
+    for p in range(1, 24):
+        pat = bytes(rng.randrange(256) for _ in range(p))
+        cases.append((pat * 3000)[:40000 + p])
+    path = str(tmp_path / "f.gz")
+    n = 0
+    for data in cases:
+        for level in (0, 1, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                ml = 8 if n % 2 else 1
+                c = zlib.compressobj(level, zlib.DEFLATED, 31, ml, strat)
+                with open(path, "wb") as f:
+                    f.write(c.compress(data) + c.flush())
+                for want in (1 << 30, 1000, 33333):
+                    rd = genoio.GzipStream(path)
+                    assert rd._L.pg_gzip_open is not None
+                    got = b""
+                    while True:
+                        b = bytes(rd.read_lines(want))
+                        if not b:
+                            break
+                        got += b
+                    rd.close()
+                    assert got == data, (len(data), level, strat, ml, want)
+                    n += 1
+    assert n > 1400
+    base = geno_text(rng, 1500, 60)
+    blob0 = gzip.compress(base, 6)
+    refused = 0
+    for it in range(600):
+        raw = bytearray(blob0)
+        k = it % 3
+        if k == 0:
+            raw[rng.randrange(10, len(raw))] ^= 1 << rng.randrange(8)
+        elif k == 1:
+            raw = raw[:rng.randrange(len(raw))]
+        else:
+            a = rng.randrange(10, len(raw))
+            m = rng.randrange(1, 8)
+            raw[a:a + m] = bytes(rng.randrange(256) for _ in range(m))
+        with open(path, "wb") as f:
+            f.write(raw)
+        try:
+            rd = genoio.GzipStream(path)
+            got = b""
+            while True:
+                b = bytes(rd.read_lines(50000))
+                if not b:
+                    break
+                got += b
+            rd.close()
+        except Exception:
+            refused += 1
+            continue
+        assert got == gzip.decompress(bytes(raw)), it
+    assert refused > 500
