@@ -4,9 +4,6 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from genomics_general_amd import _early  # noqa: E402
-
-_early.start()        # the HIP runtime's start-up beside the imports (a bgzipped VCF is inflated on the device)
 from genomics_general_amd.vcf import parse_vcf_main  # noqa: E402
 
 if __name__ == "__main__":

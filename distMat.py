@@ -3,10 +3,7 @@
 pairwise distances computed on an MI355X by libpopgen_hip.so.  See genomics_general_amd/cli.py."""
 import sys
 
-from genomics_general_amd import _early
-
-_early.start()        # the HIP runtime's start-up (0.1 s) beside the imports and the argument parsing
-from genomics_general_amd.cli import distmat_main  # noqa: E402
+from genomics_general_amd.cli import distmat_main
 
 if __name__ == "__main__":
     sys.exit(distmat_main())

@@ -4,10 +4,7 @@ statistics (ABBA, BABA, ABAA, BAAA, D, fd, fd', fdm, fdm', fdh, fdh2, fh) per wi
 libpopgen_hip.so.  See genomics_general_amd/cli.py."""
 import sys
 
-from genomics_general_amd import _early
-
-_early.start()        # the HIP runtime's start-up (0.1 s) beside the imports and the argument parsing
-from genomics_general_amd.cli import fourpop_main  # noqa: E402
+from genomics_general_amd.cli import fourpop_main
 
 if __name__ == "__main__":
     sys.exit(fourpop_main())

@@ -3,10 +3,7 @@
 libpopgen_hip.so (k_site_counts).  See genomics_general_amd/cli.py."""
 import sys
 
-from genomics_general_amd import _early
-
-_early.start()        # the HIP runtime's start-up (0.1 s) beside the imports and the argument parsing
-from genomics_general_amd.cli import freq_main  # noqa: E402
+from genomics_general_amd.cli import freq_main
 
 if __name__ == "__main__":
     sys.exit(freq_main())

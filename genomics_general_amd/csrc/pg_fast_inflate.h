@@ -136,7 +136,14 @@ struct State {
     uint32_t win_len = 0;       // valid bytes (the newest is window[win_len - 1] once full: kept linear, newest at the end)
     uint64_t total_out = 0;
     int over = 0;               // zero bytes fed to the bit buffer behind the end of the input (a valid stream never consumes them)
+    // marker mode (pg_par_gunzip.h: a chunk decoded before the 32 KiB in front of it are known): bit positions, relative to `base`, of
+    // block starts at which the decoder is to stop (ascending); stopped_at = the one it stopped at
+    const uint8_t *base = nullptr;
+    const uint64_t *stops = nullptr;
+    int n_stops = 0;
+    uint64_t stopped_at = 0;
 };
+enum { STOPPED = 3 };
 
 static inline uint64_t load64(const uint8_t *p) {
     uint64_t v;
@@ -168,18 +175,20 @@ struct Reader {
     }
 };
 
-static inline void copy_match(uint8_t *out, uint32_t dist, uint32_t len) {
+template <typename T>
+static inline void copy_match(T *out, uint32_t dist, uint32_t len) {
     // out[k] = out[k - dist]; may write up to 7 bytes past len (the caller leaves room)
-    const uint8_t *src = out - dist;
-    if (dist >= 8) {
-        uint8_t *end = out + len;
+    const T *src = out - dist;
+    constexpr uint32_t PER = 8 / sizeof(T);                                            // elements per eight-byte copy
+    if (dist >= PER) {
+        T *end = out + len;
         do {
             memcpy(out, src, 8);
-            out += 8;
-            src += 8;
+            out += PER;
+            src += PER;
         } while (out < end);
-    } else if (dist == 1) {
-        memset(out, *src, len);
+    } else if (dist == 1 && sizeof(T) == 1) {
+        memset(out, (int)*src, len);
     } else {
         for (uint32_t k = 0; k < len; ++k) out[k] = src[k];
     }
@@ -203,15 +212,25 @@ static void save_window(State &s, const uint8_t *out_begin, const uint8_t *out) 
 
 // Inflate into out_begin[0 .. cap): returns NEED_OUTPUT (cap bytes written, more to come), STREAM_END (*n_out bytes written, the
 // deflate stream has ended; s.in / s.bitcnt tell where), or an error.
-static int inflate(State &s, uint8_t *out_begin, uint64_t cap, uint64_t *n_out) {
+// MARK (T = uint16_t): the 32 KiB in front of out_begin are not known yet -- a byte copied from there becomes the marker
+// 0x8000 | its index in that window (0 = the oldest byte, 32767 = the byte right in front of out_begin), to be replaced later;
+// out_begin is then the chunk's first element in every call, `at` the number of elements already written, and the decoder also
+// stops (STOPPED) in front of a block that starts at one of s.stops.
+template <typename T, bool MARK>
+static int inflate_t(State &s, T *out_begin, uint64_t cap, uint64_t *n_out, uint64_t at = 0) {
     Reader rd(s);
-    uint8_t *out = out_begin, *const out_end = out_begin + cap;
+    T *out = out_begin + at, *const out_end = out_begin + cap;
+    T *const first = out;
     *n_out = 0;
     auto done = [&](int rc) {
-        *n_out = (uint64_t)(out - out_begin);
+        *n_out = (uint64_t)(out - first);
         s.total_out += *n_out;
-        save_window(s, out_begin, out);
+        if (!MARK) save_window(s, reinterpret_cast<const uint8_t *>(out_begin), reinterpret_cast<const uint8_t *>(out));
         return rc;
+    };
+    auto window_at = [&](uint32_t k) -> T {                                             // element k in front of out_begin (k = 1: the newest)
+        if (MARK) return (T)(0x8000u | (32768u - k));
+        return (T)s.window[s.win_len - k];
     };
     // the rest of a match the last buffer could not take
     auto emit_match = [&](uint32_t len, uint32_t dist) -> bool {                        // false: the buffer is full (rest in pend_*)
@@ -220,7 +239,7 @@ static int inflate(State &s, uint8_t *out_begin, uint64_t cap, uint64_t *n_out) 
             // (part of) the source lies in earlier output: byte by byte through the saved window
             if ((uint64_t)dist - have > s.win_len) return true;                        // (checked by the caller; never here)
             while (len && out < out_end && (uint64_t)(out - out_begin) < dist) {
-                *out = window_byte(s, dist - (uint32_t)(out - out_begin));
+                *out = window_at(dist - (uint32_t)(out - out_begin));
                 ++out;
                 --len;
             }
@@ -246,6 +265,21 @@ static int inflate(State &s, uint8_t *out_begin, uint64_t cap, uint64_t *n_out) 
     for (;;) {
         if (s.phase == 3) return done(STREAM_END);
         if (s.phase == 0) {
+            if (MARK && s.n_stops && s.over == 0) {
+                const uint64_t at_bit = (uint64_t)(s.in - s.base) * 8u - (uint64_t)s.bitcnt;
+                if (at_bit >= s.stops[0]) {
+                    int lo = 0, hi = s.n_stops;                                        // the first stop >= at_bit
+                    while (lo < hi) {
+                        const int mid = (lo + hi) / 2;
+                        if (s.stops[mid] < at_bit) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    if (lo < s.n_stops && s.stops[lo] == at_bit) {
+                        s.stopped_at = at_bit;
+                        return done(STOPPED);
+                    }
+                }
+            }
             rd.refill();
             const uint32_t hdr = (uint32_t)s.bitbuf & 7u;
             s.bitbuf >>= 3;
@@ -342,7 +376,9 @@ static int inflate(State &s, uint8_t *out_begin, uint64_t cap, uint64_t *n_out) 
             if ((uint64_t)(s.in_end - s.in) < n) return done(ERR_INPUT);
             const uint64_t room = (uint64_t)(out_end - out);
             if (n > room) n = room;
-            memcpy(out, s.in, (size_t)n);
+            if (sizeof(T) == 1) memcpy(out, s.in, (size_t)n);
+            else
+                for (uint64_t k = 0; k < n; ++k) out[k] = (T)s.in[k];
             out += n;
             s.in += n;
             s.stored_left -= (uint32_t)n;
@@ -366,18 +402,18 @@ static int inflate(State &s, uint8_t *out_begin, uint64_t cap, uint64_t *n_out) 
             s.bitcnt -= (int)(e & 255u);
             uint32_t kind = (e >> 12) & 15u;
             if (kind == K_LIT) {
-                *out++ = (uint8_t)(e >> 16);
+                *out++ = (T)(e >> 16);
                 // a second and a third literal out of the same refill (45 bits at most)
                 e = ll[s.bitbuf & ((1u << LL_BITS) - 1u)];
                 if (((e >> 12) & 15u) != K_LIT) continue;
                 s.bitbuf >>= (e & 255u);
                 s.bitcnt -= (int)(e & 255u);
-                *out++ = (uint8_t)(e >> 16);
+                *out++ = (T)(e >> 16);
                 e = ll[s.bitbuf & ((1u << LL_BITS) - 1u)];
                 if (((e >> 12) & 15u) != K_LIT) continue;
                 s.bitbuf >>= (e & 255u);
                 s.bitcnt -= (int)(e & 255u);
-                *out++ = (uint8_t)(e >> 16);
+                *out++ = (T)(e >> 16);
                 continue;
             }
             if (kind != K_LEN) {
@@ -427,7 +463,7 @@ static int inflate(State &s, uint8_t *out_begin, uint64_t cap, uint64_t *n_out) 
             s.bitcnt -= (int)(e & 255u);
             const uint32_t kind = (e >> 12) & 15u;
             if (kind == K_LIT) {
-                *out++ = (uint8_t)(e >> 16);
+                *out++ = (T)(e >> 16);
                 continue;
             }
             if (kind == K_EOB) goto block_end;
@@ -459,6 +495,22 @@ static int inflate(State &s, uint8_t *out_begin, uint64_t cap, uint64_t *n_out) 
     block_end:
         if (s.over > 8) return done(ERR_INPUT);
         s.phase = s.last ? 3 : 0;
+    }
+}
+
+static inline int inflate(State &s, uint8_t *out_begin, uint64_t cap, uint64_t *n_out) { return inflate_t<uint8_t, false>(s, out_begin, cap, n_out); }
+
+// start decoding at bit `bit` of base[0 .. len) (a block header is expected there)
+static inline void start_at(State &s, const uint8_t *base, uint64_t len, uint64_t bit) {
+    s.base = base;
+    s.in = base + (bit >> 3);
+    s.in_end = base + len;
+    s.bitbuf = 0; s.bitcnt = 0; s.over = 0; s.phase = 0; s.last = false; s.pend_len = 0; s.stored_left = 0; s.tables_fixed = false;
+    if (bit & 7u) {
+        Reader rd(s);
+        rd.refill();
+        s.bitbuf >>= (bit & 7u);
+        s.bitcnt -= (int)(bit & 7u);
     }
 }
 

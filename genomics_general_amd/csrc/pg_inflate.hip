@@ -9,6 +9,7 @@
 #include "pg_ctx.h"
 #include "pg_inflate_core.h"
 #include "pg_fast_inflate.h"
+#include "pg_par_gunzip.h"
 
 #include <algorithm>
 #include <atomic>
@@ -306,7 +307,47 @@ struct pg_gz {
     pgfi::State *fi = nullptr;
     bool in_member = false;
     uint32_t crc = 0, isize = 0;
+    // ... and of pg_par_gunzip.h: the stream decoded in chunks side by side, a batch of text at a time
+    int par_threads = 0;                       // 0: serial
+    uint64_t par_chunk = 2u << 20;
+    pgpar::Batch *pb = nullptr;                // its spill buffer: text of the last batch that did not fit the caller's buffer
+    size_t ptext_at = 0;
+    uint64_t pbit = 0;
+    uint8_t pwin[32768];
+    uint32_t pwl = 0;
+    int64_t par_batches = 0, par_fallbacks = 0;
 };
+
+// n bytes from src to dst on a few threads (the batch's text into the caller's block buffer)
+static void copy_parallel(uint8_t *dst, const uint8_t *src, size_t n, int nt) {
+    if (n < (16u << 20) || nt < 2) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + (size_t)nt - 1) / (size_t)nt;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([=]() {
+            const size_t a = std::min(n, per * (size_t)t), b = std::min(n, a + per);
+            memcpy(dst + a, src + a, b - a);
+        });
+    for (auto &x : th) x.join();
+}
+
+static uint32_t crc32_threads(uint32_t crc, const uint8_t *p, size_t n, int nt) {
+    if (n < (8u << 20) || nt < 2) return pg_crc32(crc, p, n);
+    std::vector<uint32_t> part((size_t)nt);
+    std::vector<std::thread> th;
+    const size_t per = (n + (size_t)nt - 1) / (size_t)nt;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t]() {
+            const size_t a = std::min(n, per * (size_t)t), b = std::min(n, a + per);
+            part[(size_t)t] = pg_crc32(0u, p + a, b - a);
+        });
+    for (auto &x : th) x.join();
+    for (int t = 0; t < nt; ++t) {
+        const size_t a = std::min(n, per * (size_t)t), b = std::min(n, a + per);
+        crc = (uint32_t)crc32_combine(crc, part[(size_t)t], (z_off_t)(b - a));
+    }
+    return crc;
+}
 
 // CRC-32 beside the decoder: zlib's crc32 runs at about 1 GB/s a thread, the decoder at more than 2 -- so the pieces the decoder
 // finishes (8 MiB each, still in the cache) are checksummed by a few helper threads while it goes on, and the pieces' values are
@@ -330,7 +371,7 @@ struct CrcPipe {
                         if (next >= jobs.size()) return;
                         j = &jobs[next++];
                     }
-                    j->crc = (uint32_t)crc32_z(0u, j->p, j->n);
+                    j->crc = pg_crc32(0u, j->p, j->n);
                 }
             });
     }
@@ -391,7 +432,13 @@ static int gz_member_header(pg_gz *g) {
 static int64_t gz_fill_fast(pg_gz *g, uint8_t *dst, int64_t room) {
     int64_t got = 0;
     static const bool skip_crc = getenv("PG_GZIP_NO_CRC") != nullptr;                        // (timing experiments only)
-    const bool piped = room >= (32 << 20) && !skip_crc;
+    // (where the CPU multiplies carry-less, pg_crc32 keeps up with the decoder on this thread: pieces of 2 MiB, checksummed while they
+    // are in the cache; elsewhere zlib's crc32 on helper threads)
+    bool fast_crc = false;
+#if defined(__x86_64__)
+    fast_crc = pgcrc::have_clmul();
+#endif
+    const bool piped = room >= (32 << 20) && !skip_crc && !fast_crc;
     CrcPipe pipe;
     const int helpers = std::max(1, std::min(4, pg_host_threads() - 1));
     auto fold = [&]() {                                                                      // the helpers' pieces into g->crc
@@ -419,13 +466,13 @@ static int64_t gz_fill_fast(pg_gz *g, uint8_t *dst, int64_t room) {
             g->isize = 0;
         }
         uint64_t n = 0;
-        const uint64_t piece = piped ? std::min<uint64_t>((uint64_t)(room - got), 8u << 20) : (uint64_t)(room - got);
+        const uint64_t piece = piped ? std::min<uint64_t>((uint64_t)(room - got), 8u << 20) : fast_crc ? std::min<uint64_t>((uint64_t)(room - got), 2u << 20) : (uint64_t)(room - got);
         const int rc = pgfi::inflate(*g->fi, dst + got, piece, &n);
         if (n) {
             if (piped) {
                 if (pipe.th.empty()) pipe.start(helpers);
                 pipe.push(dst + got, (size_t)n);
-            } else if (!skip_crc) g->crc = (uint32_t)crc32_z(g->crc, dst + got, (size_t)n);
+            } else if (!skip_crc) g->crc = pg_crc32(g->crc, dst + got, (size_t)n);
             g->isize += (uint32_t)n;
             got += (int64_t)n;
         }
@@ -476,6 +523,14 @@ extern "C" int pg_gzip_open(const char *path, pg_gz **out) {
                 }
             }
             if (g->map || g->map_len == 0) g->fi = new pgfi::State();
+            // chunks side by side from 8 MiB of compressed bytes and three threads on (PG_GZIP_THREADS=1: the serial decoder)
+            int nt = std::min(16, pg_host_threads());
+            if (const char *e = getenv("PG_GZIP_THREADS")) nt = atoi(e);
+            if (const char *e = getenv("PG_GZIP_CHUNK")) g->par_chunk = (uint64_t)std::max(4096, atoi(e));
+            if (g->fi && nt >= 3 && g->map_len >= (getenv("PG_GZIP_CHUNK") ? 0u : (8u << 20))) {
+                g->par_threads = nt;
+                g->pb = new pgpar::Batch();
+            }
         }
     }
     *out = g;
@@ -487,15 +542,93 @@ extern "C" int pg_gzip_close(pg_gz *g) {
     if (g->zs_live) inflateEnd(&g->zs);
     if (g->map) munmap(const_cast<uint8_t *>(g->map), g->map_len);
     delete g->fi;
+    delete g->pb;
     if (g->fd >= 0) close(g->fd);
     delete g;
     return PG_OK;
 }
 
 // inflate up to `room` bytes to dst; returns the number produced (0 at the end of the input), < 0 on a damaged stream
+static int gz_member_header(pg_gz *g);
+static int64_t gz_fill_fast(pg_gz *g, uint8_t *dst, int64_t room);
+
+// the stream in chunks side by side (pg_par_gunzip.h): a batch of text at a time into g->ptext, handed out from there
+static int64_t gz_fill_par(pg_gz *g, uint8_t *dst, int64_t room) {
+    int64_t got = 0;
+    pgpar::Batch &B = *g->pb;
+    while (got < room && !g->eof) {
+        if (g->ptext_at < B.spill_len) {
+            const size_t take = std::min<size_t>((size_t)B.spill_len - g->ptext_at, (size_t)(room - got));
+            copy_parallel(dst + got, B.spill + g->ptext_at, take, g->par_threads);
+            g->ptext_at += take;
+            got += (int64_t)take;
+            continue;
+        }
+        B.spill_len = 0;
+        g->ptext_at = 0;
+        if (g->par_threads <= 0) break;                                              // (fell back: the serial decoder goes on)
+        if (!g->in_member) {
+            const int h = gz_member_header(g);
+            if (h == 1) {
+                if (g->total_out == 0 && !g->member_done && g->map_len > 0) return -4;
+                g->eof = true;
+                break;
+            }
+            if (h < 0) return g->member_done ? -5 : -4;
+            g->in_member = true;
+            g->member_done = false;
+            g->crc = 0;
+            g->isize = 0;
+            g->pbit = (uint64_t)g->map_at * 8;
+            g->pwl = 0;
+        }
+        const int rc = B.decode(g->map, g->map_len, g->pbit, g->pwin, g->pwl, g->par_threads, g->par_chunk);
+        if (rc < 0) {
+            // no chain of chunks (no dynamic block start found where one was needed, a piece that does not decode): this member goes on
+            // serially from the batch's first bit, with the window in front of it
+            ++g->par_fallbacks;
+            pgfi::State &st = *g->fi;
+            pgfi::start_at(st, g->map, g->map_len, g->pbit);
+            memcpy(st.window, g->pwin + (32768 - g->pwl), g->pwl);
+            st.win_len = g->pwl;
+            g->par_threads = 0;
+            break;
+        }
+        ++g->par_batches;
+        const uint64_t direct = B.emit(dst + got, (uint64_t)(room - got));
+        for (size_t i = 0; i < B.chain.size(); ++i) {
+            const pgpar::Chunk &c = B.ch[(size_t)B.chain[i]];
+            g->crc = (uint32_t)crc32_combine(g->crc, c.crc, (z_off_t)c.n);
+        }
+        g->isize += (uint32_t)B.total;
+        got += (int64_t)direct;
+        g->pbit = B.end_bit;
+        memcpy(g->pwin, B.window_out(), 32768);
+        g->pwl = B.w_len_out;
+        if (B.ended) {
+            const uint8_t *t = g->map + (B.end_bit >> 3);
+            if ((g->map + g->map_len) - t < 8) return -2;
+            const uint32_t want_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            const uint32_t want_len = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+            if (want_crc != g->crc || want_len != g->isize) return -4;
+            g->map_at = (size_t)(t + 8 - g->map);
+            g->in_member = false;
+            g->member_done = true;
+        }
+    }
+    g->total_out += got;
+    if (g->par_threads <= 0 && got < room && !g->eof) {
+        const int64_t r = gz_fill_fast(g, dst + got, room - got);                    // (counts its own bytes)
+        if (r < 0) return r;
+        got += r;
+    }
+    return got;
+}
+
 static int64_t gz_fill(pg_gz *g, uint8_t *dst, int64_t room) {
     if (g->fi) {
         if (g->map_len == 0) { g->eof = true; return 0; }
+        if (g->pb && (g->par_threads > 0 || g->ptext_at < g->pb->spill_len)) return gz_fill_par(g, dst, room);
         return gz_fill_fast(g, dst, room);
     }
     int64_t got = 0;

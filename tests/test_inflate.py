@@ -376,3 +376,95 @@ def test_the_fast_host_decoder_against_zlib(tmp_path):
             continue
         assert got == gzip.decompress(bytes(raw)), it
     assert refused > 500
+
+
+@pytest.mark.parametrize("chunk,threads", [("20000", "8"), ("4096", "3"), ("300000", "16")])
+def test_one_gzip_stream_in_chunks_side_by_side(chunk, threads, tmp_path, monkeypatch):
+    """genomics_general_amd/csrc/pg_par_gunzip.h: block starts found by trial (dynamic-block headers that parse and decode), every
+    chunk decoded without the 32 KiB in front of it (16-bit output with markers), chunks chained by their bit positions, windows
+    handed on, markers replaced, CRC-32 per chunk combined in order.  Tiny chunks here (PG_GZIP_CHUNK), so that a file of a few
+    megabytes runs through many batches: levels and strategies whose blocks are stored or fixed-code (no start to be found: the
+    serial decoder takes over), concatenated members, a stream that ends inside a batch, damaged streams."""
+    monkeypatch.setenv("PG_GZIP_CHUNK", chunk)
+    monkeypatch.setenv("PG_GZIP_THREADS", threads)
+    rng = random.Random(21)
+    big = geno_text(rng, 9000, 120)                                       # 4 MB of text
+    path = str(tmp_path / "p.gz")
+    n = 0
+    for data in (big, big[:700000], bytes(rng.randrange(4) for _ in range(600000)), b"ACGT" * 200000):
+        for level, strat in ((6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED),
+                             (0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_HUFFMAN_ONLY)):
+            for ml in (8, 2):
+                c = zlib.compressobj(level, zlib.DEFLATED, 31, ml, strat)
+                blob = c.compress(data) + c.flush()
+                with open(path, "wb") as f:
+                    f.write(blob if n % 3 else blob + gzip.compress(data[:1000]) + blob)
+                want_text = data if n % 3 else data + data[:1000] + data
+                for want in (1 << 30, 250000):
+                    rd = genoio.GzipStream(path)
+                    got = b""
+                    while True:
+                        b = bytes(rd.read_lines(want))
+                        if not b:
+                            break
+                        got += b
+                    rd.close()
+                    assert got == want_text, (len(data), level, strat, ml, want)
+                n += 1
+    blob0 = gzip.compress(big, 6)
+    refused = 0
+    for it in range(60):
+        raw = bytearray(blob0)
+        if it % 2:
+            raw[rng.randrange(10, len(raw))] ^= 1 << rng.randrange(8)
+        else:
+            raw = raw[:rng.randrange(len(raw))]
+        with open(path, "wb") as f:
+            f.write(raw)
+        try:
+            rd = genoio.GzipStream(path)
+            got = b""
+            while True:
+                b = bytes(rd.read_lines(1 << 30))
+                if not b:
+                    break
+                got += b
+            rd.close()
+        except Exception:
+            refused += 1
+            continue
+        assert got == gzip.decompress(bytes(raw)), it
+    assert refused >= 55
+
+
+def test_the_carry_less_crc32_equals_zlibs(tmp_path):
+    """csrc/pg_crc32_fast.h (PCLMULQDQ folding where the CPU has it) against zlib's crc32 on every length up to 700 bytes at 17
+    alignments and a few long buffers, through a small C++ program (the library itself uses it for gzip trailers)"""
+    header = os.path.join(ROOT, "genomics_general_amd", "csrc", "pg_crc32_fast.h")
+    prog = """
+#include "HEADER"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+int main() {
+    std::vector<uint8_t> b(1 << 20);
+    srand(3);
+    for (auto &x : b) x = (uint8_t)rand();
+    int bad = 0;
+    for (size_t off = 0; off < 17; ++off)
+        for (size_t len = 0; len < 700; ++len) {
+            uint32_t seed = (uint32_t)(len * 2654435761u);
+            if (pg_crc32(seed, b.data() + off, len) != (uint32_t)crc32_z(seed, b.data() + off, len)) ++bad;
+        }
+    for (size_t len : {1000u, 4096u, 65537u, 1000003u})
+        if (pg_crc32(0, b.data() + 1, len % (1 << 20)) != (uint32_t)crc32_z(0, b.data() + 1, len % (1 << 20))) ++bad;
+    printf("%d", bad);
+    return bad != 0;
+}
+""".replace("HEADER", header)
+    src = str(tmp_path / "t.cpp")
+    with open(src, "w") as f:
+        f.write(prog)
+    exe = str(tmp_path / "t")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-lz", "-o", exe])
+    assert subprocess.check_output([exe]).strip() == b"0"
