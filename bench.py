@@ -31,6 +31,7 @@ libpopgen_hip.so.
 import argparse
 import json
 import os
+import struct
 import sys
 import time
 
@@ -690,18 +691,51 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
                                                                     "main_stats_s", "main_format_s") if k in tb},
                           "sample": "the same %d sites bgzipped (level 6, members of 65280 bytes: %.2f GB, written in %.1f s before the clock "
                                     "starts) through popgenWindows.py" % (n_txt, n_gz / 1e9, zip_s)}
-            # one serial gzip stream: a hundredth of the sample (the rate does not depend on the size; the whole sample would take minutes)
-            import gzip as _gzip
-            n_ser = max(n_txt // 100 // wind, 2) * wind
+            # ONE gzip stream (what `gzip` / `pigz` write: a single member, nothing that names its pieces): a tenth of the sample.  Written
+            # the way pigz does it -- pieces deflated side by side, each primed with the 32 KiB in front of it (one continuous stream of
+            # back references), joined by sync flushes -- because one thread of the gzip module would need a minute for it
+            import zlib as _zlib
+            from concurrent.futures import ThreadPoolExecutor
+            n_ser = max(n_txt // 10 // wind, 2) * wind
             sgz, csv5 = os.path.join(tmp, "serial.geno.gz"), os.path.join(tmp, "out5.csv")
             w0 = time.perf_counter()
-            with open(geno, "rb") as f, _gzip.open(sgz, "wb", compresslevel=6) as g:
-                got = 0
-                for ln in f:                                            # header + n_ser data lines
-                    g.write(ln)
-                    got += 1
-                    if got > n_ser:
+            with open(geno, "rb") as f:
+                head_line = f.readline()
+                body_len = 0
+                lines_left = n_ser
+                pos0 = f.tell()
+                # the byte length of n_ser data lines: every line of the sample has its scaffold, position and cells, so count them
+                while lines_left > 0:
+                    chunk = f.read(64 << 20)
+                    if not chunk:
                         break
+                    k = chunk.count(b"\n")
+                    if k <= lines_left:
+                        body_len += len(chunk)
+                        lines_left -= k
+                    else:
+                        at = -1
+                        for _ in range(lines_left):
+                            at = chunk.index(b"\n", at + 1)
+                        body_len += at + 1
+                        lines_left = 0
+                f.seek(pos0)
+                text5 = head_line + f.read(body_len)
+            piece = 8 << 20
+
+            def deflate_piece(a):
+                zd = text5[max(a - 32768, 0):a]
+                c5 = _zlib.compressobj(6, _zlib.DEFLATED, -15, 8, _zlib.Z_DEFAULT_STRATEGY, zd) if zd else _zlib.compressobj(6, _zlib.DEFLATED, -15)
+                last = a + piece >= len(text5)
+                return c5.compress(text5[a:a + piece]) + c5.flush(_zlib.Z_FINISH if last else _zlib.Z_SYNC_FLUSH)
+            with ThreadPoolExecutor(max(2, min(16, _lib.usable_cpus()))) as pool5:
+                parts5 = list(pool5.map(deflate_piece, range(0, len(text5), piece)))
+            with open(sgz, "wb") as g:
+                g.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
+                for p5 in parts5:
+                    g.write(p5)
+                g.write(struct.pack("<II", _zlib.crc32(text5) & 0xFFFFFFFF, len(text5) & 0xFFFFFFFF))
+            del text5, parts5
             ser_zip_s = time.perf_counter() - w0
             cmd5 = [sgz if c == geno else csv5 if c == csv else c for c in cmd]
             r5 = subprocess.run(cmd5, env=dict(os.environ, PG_TIMING="1", PG_PLACE_TRIALS="1"), stderr=subprocess.PIPE, stdout=subprocess.PIPE,
@@ -717,9 +751,11 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
             t2["gz"] = {"text_GBps": round(ts["text_bytes"] / ts["total_s"] / 1e9, 3), "sites": n_ser, "text_bytes": ts["text_bytes"],
                         "file_bytes": os.path.getsize(sgz), "csv_equals_text_run": bool(same5),
                         "without_context_creation": {"seconds": round(works, 4), "text_GBps": round(ts["text_bytes"] / works / 1e9, 3)},
-                        "inflate": "one serial stream: Python's gzip module on the reader thread (a single-member gzip file has no "
-                                   "independent pieces; `bgzip` the file to get the BGZF route)",
-                        "sample": "the first %d sites as ONE gzip stream (written in %.1f s before the clock starts)" % (n_ser, ser_zip_s)}
+                        "gzip_reader": ts.get("gzip_reader"),
+                        "inflate": "host: the library's own deflate decoder, chunks of the ONE stream side by side (block starts found by trial, "
+                                   "16-bit output with markers for the unknown window, chained and resolved; csrc/pg_par_gunzip.h) -- the device "
+                                   "takes over at the tokenizer; `bgzip` the file to get the BGZF route, whose members the device inflates",
+                        "sample": "the first %d sites as ONE gzip stream (one member, written pigz-style in %.1f s before the clock starts)" % (n_ser, ser_zip_s)}
         except Exception as exc:
             t2.setdefault("bgzf", {"error": repr(exc)[:300]})
             t2.setdefault("gz", {"error": repr(exc)[:300]})
@@ -1278,14 +1314,17 @@ def main():
         # what the port's number means in units of the reference: both were timed on the same windows and the same cores where the
         # reference exists (bench.py --cpu-baseline-only in the build container; the committed line)
         try:
-            cal_path = os.path.join(ROOT, "profiles", "r04", "cpu_baseline_reference_%s_build_container.json" % args.workload)
+            cal_path = next(pth for pth in (os.path.join(ROOT, "profiles", rr, "cpu_baseline_reference_%s_build_container.json" % args.workload)
+                                            for rr in ("r06", "r04")) if os.path.exists(pth))
             with open(cal_path) as f:
                 cal = json.load(f)["cpu_baseline"]
             ratio = cal["port_same_windows"]["port_over_reference"]
             cpu["reference_calibration"] = {"port_over_reference": ratio, "reference_equivalent_windows_per_sec": round(cpu["value"] / ratio, 5),
                                             "source": os.path.relpath(cal_path, ROOT),
                                             "note": "the unmodified reference (-T 8) and this port on the same 8 windows and the same 8 vCPU of the "
-                                                    "build container: the port is that many times faster; an estimate, not a measurement on this host"}
+                                                    "build container: the port is that many times faster; an estimate, not a measurement on this host.  "
+                                                    "(The reference is Python: by the rules of this build it cannot travel to the GPU box in any form, "
+                                                    "so `kind` is \"port\" there and \"reference\" only where /root/reference exists.)"}
         except Exception:
             pass
     t2 = extra.get("t2") or {}

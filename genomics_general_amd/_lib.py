@@ -79,6 +79,7 @@ SIGNATURES = {
     "pg_gzip_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "pg_gzip_read_lines": (C.c_int, [_P, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pg_gzip_close": (C.c_int, [_P]),
+    "pg_gzip_stats": (C.c_int, [_P, _i64p]),
     "pg_text_cell_widths": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, _i32p, _i32p, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64)]),
     "pg_scaffold_runs": (C.c_int, [C.c_void_p, _i64p, _i32p, C.c_int64, _i64p, C.c_int64, C.POINTER(C.c_int64)]),

@@ -876,6 +876,9 @@ class Run:
             if t.get("device_tokenizer") and hasattr(self.engine, "tokenize_stats"):
                 ts = self.engine.tokenize_stats()            # inside tokenize_s: the copies of the text (PCIe) and the kernels behind them
                 t["tokenizer_h2d_s"], t["tokenizer_kernels_s"], t["tokenizer_bytes"] = ts["h2d_s"], ts["kernels_s"], ts["bytes"]
+            gz = getattr(getattr(self._reader, "f", None), "stats", None)
+            if gz is not None and not isinstance(getattr(self._reader, "f", None), genoio.BgzfFile):
+                t["gzip_reader"] = gz()                      # ONE gzip stream: which decoder read it
             calls = getattr(getattr(self.engine, "_L", None), "calls", None)
             if calls:                                        # C-ABI calls per thread: [calls, seconds], the dozen largest
                 top = sorted(calls.items(), key=lambda kv: -kv[1][1])[:14]

@@ -537,6 +537,16 @@ extern "C" int pg_gzip_open(const char *path, pg_gz **out) {
     return PG_OK;
 }
 
+// [0] threads of the chunk-parallel decoder (0: serial), [1] batches it decoded, [2] times a member went on serially, [3] bytes of text so far
+extern "C" int pg_gzip_stats(pg_gz *g, int64_t *out4) {
+    if (!g || !out4) return pg_fail(PG_ERR_ARG, "pg_gzip_stats: null argument");
+    out4[0] = g->fi ? (g->pb ? (g->par_threads > 0 ? g->par_threads : -1) : 0) : -2;      // -1: fell back to the serial decoder, -2: zlib
+    out4[1] = g->par_batches;
+    out4[2] = g->par_fallbacks;
+    out4[3] = g->total_out;
+    return PG_OK;
+}
+
 extern "C" int pg_gzip_close(pg_gz *g) {
     if (!g) return PG_OK;
     if (g->zs_live) inflateEnd(&g->zs);

@@ -543,8 +543,18 @@ class GzipStream:
     def readline(self):
         return bytes(self.read_lines(1))
 
+    def stats(self):
+        """which decoder read the stream: {"decoder", "threads", "batches", "serial_takeovers"}"""
+        if self._h is not None:
+            a = np.zeros(4, dtype=np.int64)
+            check(self._L.pg_gzip_stats(self._h, a))
+            self._stats = {"decoder": ("zlib" if a[0] == -2 else "serial (pg_fast_inflate.h)" if a[0] <= 0 else "chunks side by side (pg_par_gunzip.h)"),
+                           "threads": int(max(a[0], 1)), "batches": int(a[1]), "serial_takeovers": int(a[2])}
+        return getattr(self, "_stats", None)
+
     def close(self):
         if self._h is not None:
+            self.stats()
             self._L.pg_gzip_close(self._h)
             self._h = None
 

@@ -319,6 +319,9 @@ typedef struct pg_gz pg_gz;
 int pg_gzip_open(const char *path, pg_gz **out);
 int pg_gzip_read_lines(pg_gz *g, uint8_t *dst, int64_t cap, int64_t want, int64_t *got_out, int *complete_out, int *eof_out);
 int pg_gzip_close(pg_gz *g);
+/* out4: [0] threads of the chunk-parallel decoder (0: the serial decoder, -1: it took over after a batch found no chain of chunks,
+ * -2: zlib), [1] batches decoded side by side, [2] members that went on serially, [3] bytes of text handed out so far */
+int pg_gzip_stats(pg_gz *g, int64_t *out4);
 int pg_inflate_members(const uint8_t *comp, const uint32_t *in_off, const uint32_t *in_len, const int64_t *out_off,
                        const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *dst, int n_threads);
 /* text -> BGZF, what `bgzip` writes (tools/bgzip.py; bench.py's compressed samples; tests): members of `block` bytes of text (bgzip:
