@@ -1005,20 +1005,31 @@ class MultiLayoutBatch:
             groups.setdefault(pl[w].tobytes(), []).append(w)
         self.groups = [(np.frombuffer(k, dtype=np.int32), np.array(v, dtype=np.int64)) for k, v in groups.items()]
         self.n = len(self.lo)
+        self._batches = {}
+        run._ml_count = run.__dict__.get("_ml_count", 0) + 1
+        self._token = run._ml_count                   # (not id(self): a later object may get the address of a dead one)
 
     def _each(self):
+        """(windows of the group, its WindowBatch) group by group.  A group's batch object lives as long as this object -- the
+        reference's Alignment carries state from one statistic to the next (groupDistStats leaves its minSites mask and a nan
+        diagonal in the cached distance matrix, genomics.py:959-963, which indPairDists / sampleHet / H12stats then see) and so
+        does WindowBatch --; what is loaded again when the engine holds another group is the layout and the rows."""
         run, eng = self.run, self.run.engine
-        for ploidy, sel in self.groups:
-            lay, cols = run.layout_for(ploidy)
+        for g, (ploidy, sel) in enumerate(self.groups):
             lo, hi = self.lo[sel], self.hi[sel]
             r0, r1 = int(lo.min()), int(hi.max())
-            rows = np.ascontiguousarray(run.data.gt[run.site0 + r0:run.site0 + r1][:, cols])
-            first = eng.__dict__.get("_pair_first", "slot")
-            eng.set_layout(lay)
-            if first != "slot" and hasattr(eng, "set_pair_first"):
-                eng.set_pair_first(first)
-            eng.load_sites(rows)
-            yield sel, eng.batch(lo - r0, hi - r0)
+            if run.__dict__.get("_ml_loaded") != (self._token, g):
+                lay, cols = run.layout_for(ploidy)
+                rows = np.ascontiguousarray(run.data.gt[run.site0 + r0:run.site0 + r1][:, cols])
+                first = eng.__dict__.get("_pair_first", "slot")
+                eng.set_layout(lay)
+                if first != "slot" and hasattr(eng, "set_pair_first"):
+                    eng.set_pair_first(first)
+                eng.load_sites(rows)
+                run._ml_loaded = (self._token, g)
+            if g not in self._batches:
+                self._batches[g] = eng.batch(lo - r0, hi - r0)
+            yield sel, self._batches[g]
 
     def _merge(self, parts, pad=None):
         first = parts[0][1]

@@ -260,26 +260,48 @@ extern "C" int pg_inflate_members(const uint8_t *comp, const uint32_t *in_off, c
     int nt = n_threads > 0 ? n_threads : pg_host_threads();
     nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt, (n_members + 15) / 16));
     std::atomic<int64_t> next(0), bad(-1);
+    // (the library's own decoder and checksum, pg_fast_inflate.h / pg_crc32_fast.h: three times zlib's rate per thread; PG_GZIP_FAST=0
+    // keeps zlib's inflate)
+    static const bool use_zlib = getenv("PG_GZIP_FAST") && atoi(getenv("PG_GZIP_FAST")) == 0;
     auto work = [&]() {
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
-        if (inflateInit2(&zs, -15) != Z_OK) { bad.store(0); return; }
+        if (use_zlib && inflateInit2(&zs, -15) != Z_OK) { bad.store(0); return; }
+        pgfi::State *st = use_zlib ? nullptr : new pgfi::State();
         for (;;) {
             const int64_t k0 = next.fetch_add(16);
             if (k0 >= n_members || bad.load() >= 0) break;
             for (int64_t k = k0; k < std::min(n_members, k0 + 16); ++k) {
-                inflateReset(&zs);
-                zs.next_in = const_cast<Bytef *>(comp + in_off[k]);
-                zs.avail_in = in_len[k];
-                zs.next_out = dst + out_off[k];
-                zs.avail_out = out_len[k];
-                const int rc = out_len[k] || in_len[k] ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
-                const bool ok = rc == Z_STREAM_END && zs.avail_out == 0 &&
-                                (!crc || (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst + out_off[k], out_len[k]) == crc[k]);
+                bool ok;
+                if (use_zlib) {
+                    inflateReset(&zs);
+                    zs.next_in = const_cast<Bytef *>(comp + in_off[k]);
+                    zs.avail_in = in_len[k];
+                    zs.next_out = dst + out_off[k];
+                    zs.avail_out = out_len[k];
+                    const int rc = out_len[k] || in_len[k] ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+                    ok = rc == Z_STREAM_END && zs.avail_out == 0;
+                } else if (!out_len[k] && !in_len[k]) {
+                    ok = true;
+                } else {
+                    pgfi::start_at(*st, comp + in_off[k], in_len[k], 0);
+                    st->win_len = 0;
+                    uint64_t n = 0;
+                    // (one element of room behind the member's size: a stream that holds more must not pass as complete)
+                    const int rc = pgfi::inflate(*st, dst + out_off[k], out_len[k], &n);
+                    ok = (rc == pgfi::STREAM_END && n == out_len[k]) ||
+                         (rc == pgfi::NEED_OUTPUT && n == out_len[k] && st->pend_len == 0 && [&] {          // the end-of-block code may still be unread
+                              uint8_t extra;
+                              uint64_t m = 0;
+                              return pgfi::inflate(*st, &extra, 1, &m) == pgfi::STREAM_END && m == 0;
+                          }());
+                }
+                ok = ok && (!crc || pg_crc32(0u, dst + out_off[k], out_len[k]) == crc[k]);
                 if (!ok) { bad.store(k); break; }
             }
         }
-        inflateEnd(&zs);
+        if (use_zlib) inflateEnd(&zs);
+        delete st;
     };
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(work);

@@ -156,6 +156,12 @@ CASES = [
     dict(name="ploidyshift_popgen_sliding_ind", tool="popgenWindows.py", fixture="ploidyshift",
          argv=["-g", "{geno}", "-f", "phased", "-w", "1000", "-s", "250", "-m", "20", "--inferPloidy", "--addWindowID", "--writeFailedWindows",
                "--analysis", "popDist", "popPairDist", "indPairDist", "hapStats"] + pops_args(12, 2)),
+    # (-m 44 in windows of about 48 sites: pairs of haplotypes below the threshold, so what groupDistStats leaves in the cached distance
+    # matrix -- its mask and the nan diagonal, genomics.py:959-963 -- shows in indPairDist and hapStats; the differential fuzz of round 6
+    # found that state lost between the statistics of a window whose ploidies had been inferred)
+    dict(name="ploidyshift_popgen_mask_state", tool="popgenWindows.py", fixture="ploidyshift",
+         argv=["-g", "{geno}", "-f", "phased", "-w", "60", "-m", "44", "--inferPloidy", "--roundTo", "5",
+               "--analysis", "popDist", "popPairDist", "indPairDist", "hapStats"] + pops_args(12, 3)),
     dict(name="ploidyshift_popgen_sites_pairs", tool="popgenWindows.py", fixture="ploidyshift_pairs",
          argv=["-g", "{geno}", "-f", "pairs", "--windType", "sites", "-w", "300", "--overlap", "100", "-m", "50", "--inferPloidy",
                "--roundTo", "5"] + pops_args(12, 3)),

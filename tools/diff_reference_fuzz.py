@@ -80,6 +80,26 @@ def make_input(tmp, case, rng, tool):
     scafs = [pick(rng, ["chr%d", "scaffold_%d", "%d"]) % (k + 1) for k in range(n_scaf)]
     geno = os.path.join(tmp, "c%d.geno%s" % (case, ".gz" if rng.random() < 0.25 else ""))
     synth.write_geno(geno, scafs, sid, pos, codes, names, sep=pick(rng, ["/", "/", "|"]), fmt=fmt, haploid=haploid)
+    # --inferPloidy on a file whose ploidy changes along it (genomics.py:1108-1111: per window and sample): the cells of some samples
+    # lose their second allele over one to three stretches of rows (window boundaries fall anywhere in them)
+    shifting = fmt in ("phased", "pairs") and tool != "freq.py" and rng.random() < 0.25
+    if shifting:
+        import gzip
+        op = gzip.open if geno.endswith(".gz") else open
+        with op(geno, "rt") as f:
+            lines = f.read().splitlines()
+        n_rows = len(lines) - 1
+        for _ in range(int(rng.integers(1, 4))):
+            who = rng.choice(n_dip, size=int(rng.integers(1, max(2, n_dip // 2))), replace=False)
+            a = int(rng.integers(0, max(n_rows, 1)))
+            b = min(n_rows, a + int(rng.integers(1, max(2, n_rows))))
+            for r in range(a, b):
+                f_ = lines[1 + r].split("\t")
+                for d in who:
+                    f_[2 + int(d)] = f_[2 + int(d)][0]
+                lines[1 + r] = "\t".join(f_)
+        with op(geno, "wt") as f:
+            f.write("\n".join(lines) + "\n")
     header_argv = []
     if rng.random() < 0.3:                                       # irregular text: blanks as separators, comment lines, no header line
         import gzip
@@ -112,7 +132,9 @@ def make_input(tmp, case, rng, tool):
         with open(geno, "wb") as f:
             f.write(genoio.bgzf_compress(text, level=int(rng.integers(1, 10)), block=int(rng.integers(300, 20000))).tobytes())
     ploidy_argv = []
-    if haploid:
+    if shifting:
+        ploidy_argv = ["--inferPloidy"]
+    elif haploid:
         # a --ploidy LIST is dealt to the samples in the hash order of a set once populations are named (popgenWindows.py:277-296)
         how = pick(rng, ["haploid", "file"])
         if how == "haploid":
