@@ -728,7 +728,7 @@ def t2_sample(eng, lay, wl, names, scaf_len, t0_table):
                 c5 = _zlib.compressobj(6, _zlib.DEFLATED, -15, 8, _zlib.Z_DEFAULT_STRATEGY, zd) if zd else _zlib.compressobj(6, _zlib.DEFLATED, -15)
                 last = a + piece >= len(text5)
                 return c5.compress(text5[a:a + piece]) + c5.flush(_zlib.Z_FINISH if last else _zlib.Z_SYNC_FLUSH)
-            with ThreadPoolExecutor(max(2, min(16, _lib.usable_cpus()))) as pool5:
+            with ThreadPoolExecutor(max(2, min(16, effective_cpus()["usable"]))) as pool5:
                 parts5 = list(pool5.map(deflate_piece, range(0, len(text5), piece)))
             with open(sgz, "wb") as g:
                 g.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
