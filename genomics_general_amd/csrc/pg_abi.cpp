@@ -186,7 +186,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
         T.h_total.release(); T.h_pos.release(); T.h_cols.release();
         T.h_head.release(); T.names.release(); T.names_idx.release();
         auto drop = [](pg_ctx::Inflate &I) {
-            I.comp.release(); I.crc_tab.release(); I.text.release(); I.sink.release(); I.members.release(); I.h_members.release(); I.status.release(); I.h_status.release();
+            I.comp.release(); I.crc_tab.release(); I.crc_fold.release(); I.text.release(); I.sink.release(); I.members.release(); I.h_members.release(); I.status.release(); I.h_status.release();
             I.nl_list.release(); I.nl_cnt.release(); I.mem_base.release();
             if (I.ev_inflated) (void)hipEventDestroy(I.ev_inflated);
             if (I.ev_crc) (void)hipEventDestroy(I.ev_crc);

@@ -112,7 +112,7 @@ struct pg_ctx {
     DevBuf<uint8_t> cells_stage;     // packed cells of the upload in flight
     // BGZF members inflated on the device (pg_inflate.hip): compressed bytes, member table, status [error bits, first bad member]
     struct Inflate {
-        DevBuf<uint32_t> comp, crc_tab;
+        DevBuf<uint32_t> comp, crc_tab, crc_fold;   // crc_tab: k_crc32's tables; crc_fold: pgi_make_crc_tables (the check inside k_inflate)
         DevBuf<uint8_t> text;              // pg_inflate_device only (the tokenizer inflates into its text slots)
         DevBuf<uint8_t> sink;              // 128 bytes per member: where the lanes of a copy step that have no byte store
         DevBuf<uint16_t> nl_list;          // the members' line feeds as k_inflate lists them (nl_cap offsets per member)

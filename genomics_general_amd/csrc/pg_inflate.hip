@@ -38,7 +38,7 @@ namespace {
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PGI_WAVES, PGI_WAVES))) void k_inflate(const uint32_t *__restrict__ comp, uint32_t n_dw, const PgiMember *__restrict__ mem,
                                                 int n_members, uint8_t *__restrict__ out, uint8_t *__restrict__ sink,
                                                 int32_t *__restrict__ status, uint16_t *__restrict__ nl_list, uint32_t nl_cap,
-                                                int32_t *__restrict__ nl_cnt, uint64_t text_limit) {
+                                                int32_t *__restrict__ nl_cnt, uint64_t text_limit, const uint32_t *__restrict__ crc_fold) {
     __shared__ PgiShared sh;
     const int lane = (int)threadIdx.x;
     const int m = (int)blockIdx.x;
@@ -51,7 +51,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PGI_WAVES, P
     const uint32_t nl_lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lim64 > 0x10000ull ? 0x10000u : (uint32_t)lim64));
     uint32_t nl_n = 0;
     const int rc = pgi_member(comp, n_dw, in_off, in_len, out + out_off, out_len, sink + (size_t)m * 128, &sh,   // sink: where lanes without a byte store
-                              nl_list ? nl_list + (size_t)m * nl_cap : nullptr, nl_cap, nl_lim, &nl_n, lane);
+                              nl_list ? nl_list + (size_t)m * nl_cap : nullptr, nl_cap, nl_lim, &nl_n,
+                              crc_fold, (uint32_t)__builtin_amdgcn_readfirstlane((int)mem[m].crc), lane);    // crc_fold: the member's CRC-32 checked in the flush
     if (nl_cnt && lane == 0) nl_cnt[m] = rc ? 0 : (int32_t)nl_n;
     if (rc && lane == 0) {
         atomicOr(status, rc);
@@ -872,15 +873,25 @@ static int inflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Inflate &I, const ui
     HIPCHK(hipMemcpyAsync(I.status.p, I.h_status.p, 16, hipMemcpyHostToDevice, st));
     if (n_members == 0) return PG_OK;
     HIPCHK(hipMemcpyAsync(I.members.p, I.h_members.p, (size_t)n_members * sizeof(PgiMember), hipMemcpyHostToDevice, st));
+    // The members' CRC-32: in k_inflate's flush, where the text is in registers (round 6; PG_BGZF_CRC_FOLD=0: k_crc32, a kernel that
+    // reads the text again -- 0.5 ms per GiB of it)
+    static const bool fold = !(getenv("PG_BGZF_CRC_FOLD") && atoi(getenv("PG_BGZF_CRC_FOLD")) == 0);
+    const bool check = crc && !getenv("PG_BGZF_NO_CRC");
+    if (check && fold && !I.crc_fold.p) {
+        std::vector<uint32_t> t(PGI_CRC_TAB);
+        pgi_make_crc_tables(t.data());
+        if ((rc = I.crc_fold.ensure(t.size())) != PG_OK) return rc;
+        HIPCHK(hipMemcpy(I.crc_fold.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
     hipLaunchKernelGGL(k_inflate, dim3((unsigned)n_members), dim3(64), 0, st, comp_d, n_dw, I.members.p, (int)n_members, text_d, I.sink.p, I.status.p,
-                       nl_cap ? I.nl_list.p : nullptr, nl_cap, nl_cap ? I.nl_cnt.p : nullptr, text_limit);
+                       nl_cap ? I.nl_list.p : nullptr, nl_cap, nl_cap ? I.nl_cnt.p : nullptr, text_limit, check && fold ? I.crc_fold.p : nullptr);
     HIPCHK(hipGetLastError());
     if (nl_cap) {
         hipLaunchKernelGGL(k_member_scan, dim3(1), dim3(256), 0, st, I.nl_cnt.p, (int)n_members, nl_cap, I.mem_base.p, d_total, d_over);
         HIPCHK(hipGetLastError());
     }
     I.crc_pending = false;
-    if (crc && !getenv("PG_BGZF_NO_CRC")) {
+    if (check && !fold) {
         if (crc_st) {
             // the check needs the text and nobody needs the check before the block's rows are handed out: on a stream of its own,
             // beside the line-feed scan and the tokenizer's kernels (0.5 ms per GiB of text off the chain of the block)

@@ -268,14 +268,66 @@ PGI_DEV int pgi_build(const uint8_t *lens, int n, uint16_t *sorted, uint32_t *hi
         PGI_DROP(L_);                                                                            \
     } while (0)
 
+// ---- CRC-32 of the member's text, taken where the text leaves for global memory (the flush holds it in registers) -----------------
+// Lane i checksums bytes [16 i, 16 i + 16) of every aligned 1 KiB piece: four table steps for its sixteen bytes (multiplication by
+// x^32, sliced by the four bytes of the register) and, in front of every piece but the first, one more for the 1008 bytes of the other
+// lanes in between (multiplication by x^8064) -- CRCs are linear, so the lanes' registers can run apart and be XORed at the end, each
+// first moved to the end of the aligned text (x^(128 m), m = the 16-byte chunks still to go: one 32-step product per lane and member).
+// The bytes in front of the first aligned piece and behind the last whole chunk go through the byte table.  Tables (global memory,
+// 9.5 KB: they stay in the L1): [0, 256) the byte table, [256, 1280) x^32 sliced, [1280, 2304) x^8064 sliced, [2304, 2368) x^(128 m).
+#define PGI_CRC_POLY 0xEDB88320u
+#define PGI_CRC_TAB 2368
+static inline uint32_t pgi_crc_mul_host(uint32_t a, uint32_t b) {          // a * b mod P, reflected (zlib's multmodp)
+    uint32_t p = 0;
+    for (int k = 31; k >= 0; --k) {
+        if ((a >> k) & 1u) p ^= b;
+        b = (b >> 1) ^ ((b & 1u) ? PGI_CRC_POLY : 0u);
+    }
+    return p;
+}
+static inline void pgi_make_crc_tables(uint32_t *t) {
+    for (uint32_t b = 0; b < 256; ++b) {
+        uint32_t c = b;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? PGI_CRC_POLY : 0u);
+        t[b] = c;
+    }
+    uint32_t x8 = 0x80000000u;                                              // x^0 ...
+    for (int k = 0; k < 8; ++k) x8 = (x8 >> 1) ^ ((x8 & 1u) ? PGI_CRC_POLY : 0u);       // ... x^8
+    auto power = [&](uint32_t bytes) {                                      // x^(8 * bytes)
+        uint32_t r = 0x80000000u, sq = x8;
+        for (uint32_t e = bytes; e; e >>= 1) {
+            if (e & 1u) r = pgi_crc_mul_host(r, sq);
+            sq = pgi_crc_mul_host(sq, sq);
+        }
+        return r;
+    };
+    const uint32_t x32 = power(4), x8064 = power(1008), x128 = power(16);
+    for (int q = 0; q < 4; ++q)
+        for (uint32_t b = 0; b < 256; ++b) {
+            t[256 + 256 * q + b] = pgi_crc_mul_host(x32, b << (8 * q));
+            t[1280 + 256 * q + b] = pgi_crc_mul_host(x8064, b << (8 * q));
+        }
+    t[2304] = 0x80000000u;
+    for (int m = 1; m < 64; ++m) t[2304 + m] = pgi_crc_mul_host(t[2304 + m - 1], x128);
+}
+
 // One member: in_len bytes of deflate stream at byte in_off of comp -> out_len bytes at dst.  0, or PGI_ERR_* bits.
 // sink: 128 bytes of the member's own where lanes without a byte store.  nl_list (may be null): the offsets, in the member's text,
 // of its line feeds in front of offset nl_lim, in order -- found in the registers of the flush, so that the tokenizer needs no pass
 // over the text for them (k_nl_count / k_nl_write); at most nl_cap are stored, *nl_n_out counts them all.
 PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_t in_off, uint32_t in_len, uint8_t *dst,
                        uint32_t out_len, uint8_t *sink, PgiShared *sh, uint16_t *nl_list, uint32_t nl_cap, uint32_t nl_lim,
-                       uint32_t *nl_n_out PGI_LANE_PARAM) {
+                       uint32_t *nl_n_out, const uint32_t *__restrict__ crc_tab, uint32_t want_crc PGI_LANE_PARAM) {
     uint32_t nl_n = 0;
+    // crc_tab (may be null: no check): pgi_make_crc_tables; want_crc: the CRC-32 of the member's trailer
+    PL(uint32_t, cs);                                // the lanes' CRC registers
+    LANES { V(cs) = lane == 0 ? 0xFFFFFFFFu : 0u; }
+    uint32_t crc_pieces = 0;                         // aligned 1 KiB pieces checksummed so far
+// v * x^k mod P by the sliced table at off_ (x^32: 256, x^8064: 1280)
+#define PGI_CRC_SLICED(v, off_) (crc_tab[(off_) + ((v) & 255u)] ^ crc_tab[(off_) + 256u + (((v) >> 8) & 255u)] ^ \
+                                 crc_tab[(off_) + 512u + (((v) >> 16) & 255u)] ^ crc_tab[(off_) + 768u + ((v) >> 24)])
+// one byte into a register (the byte table)
+#define PGI_CRC_BYTE(s_, b_) (crc_tab[((s_) ^ (uint32_t)(b_)) & 255u] ^ ((s_) >> 8))
     uint16_t *const nl_dump = reinterpret_cast<uint16_t *>(sink);
 // a line feed at offset p_ of the member's text
 #define PGI_NL_PUT(p)                                                                                          \
@@ -330,8 +382,9 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
     const uint32_t A = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
     uint8_t *const ring = sh->ring;
 #define PGI_RIX(p) (((uint32_t)(p) + A) & (PGI_RING - 1u))
-// n < 64 bytes from the ring to global memory, a byte per lane (the head in front of the first aligned piece, the tail)
-#define PGI_FLUSH_BYTES(n)                                                        \
+// n < 64 bytes from the ring to global memory, a byte per lane (the head in front of the first aligned piece, the last bytes
+// behind the last whole 16-byte chunk); creg_: the CRC register these bytes go into (uniform)
+#define PGI_FLUSH_BYTES(n, creg_)                                                 \
     do {                                                                          \
         PL(uint8_t, fb_);                                                         \
         LANES { V(fb_) = ring[PGI_RIX(fl + (uint32_t)lane)]; }                    \
@@ -345,51 +398,103 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 PGI_NL_PUT(fl + b_);                                              \
             }                                                                     \
         }                                                                         \
+        if (crc_tab) {                                                            \
+            for (uint32_t k_ = 0; k_ < (n); ++k_) {                               \
+                const uint32_t by_ = (uint32_t)READLANE(fb_, k_) & 255u;          \
+                creg_ = (uint32_t)UNI(PGI_CRC_BYTE(creg_, by_));                  \
+            }                                                                     \
+        }                                                                         \
         fl += (n);                                                                \
+    } while (0)
+// nl_ (1 .. 64) lanes x 16 bytes from the ring (16-byte aligned there and in global memory): stored, searched for line feeds, checksummed
+#define PGI_PIECE(nl_)                                                                           \
+    do {                                                                                         \
+        PL(PgiU4, fq_);                                                                          \
+        LANES { V(fq_) = *reinterpret_cast<const PgiU4 *>(ring + PGI_RIX(fl + 16u * (uint32_t)lane)); } \
+        LANES { *reinterpret_cast<PgiU4 *>((uint32_t)lane < (nl_) ? dst + fl + 16u * (uint32_t)lane : sink) = V(fq_); } \
+        if (nl_list) {                                                                           \
+            PL(uint32_t, z0_);                                                                   \
+            PL(uint32_t, z1_);                                                                   \
+            PL(uint32_t, z2_);                                                                   \
+            PL(uint32_t, z3_);                                                                   \
+            LANES {                                                                              \
+                V(z0_) = PGI_NL_FLAGS(V(fq_).x);                                                 \
+                V(z1_) = PGI_NL_FLAGS(V(fq_).y);                                                 \
+                V(z2_) = PGI_NL_FLAGS(V(fq_).z);                                                 \
+                V(z3_) = PGI_NL_FLAGS(V(fq_).w);                                                 \
+            }                                                                                    \
+            uint64_t nm_;                                                                        \
+            BALLOT(nm_, (V(z0_) | V(z1_) | V(z2_) | V(z3_)) != 0u && (uint32_t)lane < (nl_));    \
+            while (nm_) {                                                                        \
+                const uint32_t l_ = (uint32_t)PGI_CTZ64(nm_);                                    \
+                nm_ &= nm_ - 1ull;                                                               \
+                for (uint32_t d_ = 0; d_ < 4u; ++d_) {                                           \
+                    uint32_t zz_ = (uint32_t)(d_ == 0u ? READLANE(z0_, l_) : d_ == 1u ? READLANE(z1_, l_) : d_ == 2u ? READLANE(z2_, l_) : READLANE(z3_, l_)); \
+                    while (zz_) {                                                                \
+                        const uint32_t b_ = (uint32_t)__builtin_ctz(zz_);                        \
+                        zz_ &= zz_ - 1u;                                                         \
+                        PGI_NL_PUT(fl + 16u * l_ + 4u * d_ + (b_ >> 3));                         \
+                    }                                                                            \
+                }                                                                                \
+            }                                                                                    \
+        }                                                                                        \
+        if (crc_tab) {                                                                           \
+            LANES {                                                                              \
+                uint32_t c_ = V(cs);                                                             \
+                if (crc_pieces) c_ = PGI_CRC_SLICED(c_, 1280u);          /* (uniform) the 1008 bytes of the other lanes */ \
+                c_ ^= V(fq_).x;                                                                  \
+                c_ = PGI_CRC_SLICED(c_, 256u);                                                   \
+                c_ ^= V(fq_).y;                                                                  \
+                c_ = PGI_CRC_SLICED(c_, 256u);                                                   \
+                c_ ^= V(fq_).z;                                                                  \
+                c_ = PGI_CRC_SLICED(c_, 256u);                                                   \
+                c_ ^= V(fq_).w;                                                                  \
+                c_ = PGI_CRC_SLICED(c_, 256u);                                                   \
+                V(cs) = (uint32_t)lane < (nl_) ? c_ : V(cs);                                     \
+            }                                                                                    \
+        }                                                                                        \
+        fl += 16u * (nl_);                                                                       \
     } while (0)
 #define PGI_FLUSH(final)                                                                         \
     do {                                                                                         \
         if (((fl + A) & 15u) != 0u) {                                                            \
             const uint32_t h_ = 16u - ((fl + A) & 15u), n_ = h_ < pos - fl ? h_ : pos - fl;      \
-            PGI_FLUSH_BYTES(n_);                                                                 \
+            uint32_t c0_ = (uint32_t)READLANE(cs, 0);                                            \
+            PGI_FLUSH_BYTES(n_, c0_);                                                            \
+            WRITELANE(cs, 0, c0_);                                                               \
         }                                                                                        \
         while (pos - fl >= 1024u) {                                                              \
-            PL(PgiU4, fq_);                                                                      \
-            LANES { V(fq_) = *reinterpret_cast<const PgiU4 *>(ring + PGI_RIX(fl + 16u * (uint32_t)lane)); } \
-            LANES { *reinterpret_cast<PgiU4 *>(dst + fl + 16u * (uint32_t)lane) = V(fq_); }      \
-            if (nl_list) {                                                                       \
-                PL(uint32_t, z0_);                                                               \
-                PL(uint32_t, z1_);                                                               \
-                PL(uint32_t, z2_);                                                               \
-                PL(uint32_t, z3_);                                                               \
-                LANES {                                                                          \
-                    V(z0_) = PGI_NL_FLAGS(V(fq_).x);                                             \
-                    V(z1_) = PGI_NL_FLAGS(V(fq_).y);                                             \
-                    V(z2_) = PGI_NL_FLAGS(V(fq_).z);                                             \
-                    V(z3_) = PGI_NL_FLAGS(V(fq_).w);                                             \
-                }                                                                                \
-                uint64_t nm_;                                                                    \
-                BALLOT(nm_, (V(z0_) | V(z1_) | V(z2_) | V(z3_)) != 0u);                          \
-                while (nm_) {                                                                    \
-                    const uint32_t l_ = (uint32_t)PGI_CTZ64(nm_);                                \
-                    nm_ &= nm_ - 1ull;                                                           \
-                    for (uint32_t d_ = 0; d_ < 4u; ++d_) {                                       \
-                        uint32_t zz_ = (uint32_t)(d_ == 0u ? READLANE(z0_, l_) : d_ == 1u ? READLANE(z1_, l_) : d_ == 2u ? READLANE(z2_, l_) : READLANE(z3_, l_)); \
-                        while (zz_) {                                                            \
-                            const uint32_t b_ = (uint32_t)__builtin_ctz(zz_);                    \
-                            zz_ &= zz_ - 1u;                                                     \
-                            PGI_NL_PUT(fl + 16u * l_ + 4u * d_ + (b_ >> 3));                     \
-                        }                                                                        \
-                    }                                                                            \
-                }                                                                                \
-            }                                                                                    \
-            fl += 1024u;                                                                         \
+            PGI_PIECE(64u);                                                                      \
+            ++crc_pieces;                                                                        \
         }                                                                                        \
         if (final) {                                                                             \
-            while (fl < pos) {                                                                   \
-                const uint32_t n_ = pos - fl < 64u ? pos - fl : 64u;                             \
-                PGI_FLUSH_BYTES(n_);                                                             \
+            const uint32_t q_ = (pos - fl) >> 4;                 /* whole 16-byte chunks of the rest: lanes 0 .. q_ - 1 */ \
+            if (q_) PGI_PIECE(q_);                                                               \
+            uint32_t total_ = 0u;                                                                \
+            if (crc_tab) {                                                                       \
+                /* every lane's register to the end of the aligned text, then all of them XORed */ \
+                PL(uint32_t, ca_);                                                               \
+                PL(uint32_t, cb_);                                                               \
+                PL(uint32_t, cp_);                                                               \
+                LANES {                                                                          \
+                    const uint32_t m_ = (uint32_t)lane < q_ ? q_ - (uint32_t)lane - 1u : (crc_pieces ? 63u + q_ - (uint32_t)lane : 0u); \
+                    V(ca_) = crc_tab[2304u + (m_ & 63u)];                                        \
+                    V(cb_) = V(cs);                                                              \
+                    V(cp_) = 0u;                                                                 \
+                }                                                                                \
+                for (int k_ = 31; k_ >= 0; --k_) {                                               \
+                    LANES {                                                                      \
+                        V(cp_) ^= ((V(ca_) >> k_) & 1u) ? V(cb_) : 0u;                           \
+                        V(cb_) = (V(cb_) >> 1) ^ ((V(cb_) & 1u) ? PGI_CRC_POLY : 0u);            \
+                    }                                                                            \
+                }                                                                                \
+                for (int l_ = 0; l_ < 64; ++l_) total_ ^= (uint32_t)READLANE(cp_, l_);           \
             }                                                                                    \
+            if (fl < pos) {                                                                      \
+                const uint32_t r_ = pos - fl;                                                    \
+                PGI_FLUSH_BYTES(r_, total_);                                                     \
+            }                                                                                    \
+            if (crc_tab && (total_ ^ 0xFFFFFFFFu) != want_crc) return PGI_ERR_CRC;               \
         }                                                                                        \
     } while (0)
     int fixed_built = 0;

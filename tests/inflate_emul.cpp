@@ -10,6 +10,10 @@
 // the line feeds the decoder reports beside the text (pgi_member's nl_list): set the capacity and the limit first, read the list after
 static uint32_t g_nl_cap = 0, g_nl_lim = 0xFFFFFFFFu, g_nl_n = 0;
 static std::vector<uint16_t> g_nl;
+static int g_crc_on = 0;
+static uint32_t g_want_crc = 0;
+// the CRC-32 the decoder is to hold the text against (on = 0: no check)
+extern "C" void pgi_emul_crc_setup(int on, uint32_t want) { g_crc_on = on; g_want_crc = want; }
 extern "C" void pgi_emul_nl_setup(uint32_t cap, uint32_t lim) { g_nl_cap = cap; g_nl_lim = lim; }
 extern "C" uint32_t pgi_emul_nl_result(uint16_t *out, uint32_t cap) {
     for (uint32_t k = 0; k < g_nl.size() && k < cap; ++k) out[k] = g_nl[k];
@@ -25,14 +29,17 @@ extern "C" int pgi_emul_inflate_at(const uint8_t *comp, uint32_t n_comp, uint32_
     if (n_comp) std::memcpy(words.data(), comp, n_comp);
     PgiShared sh;
     std::memset(&sh, 0xAB, sizeof(sh));
-    alignas(2) uint8_t sink[128];
+    alignas(16) uint8_t sink[128];
     std::vector<uint16_t> nl(g_nl_cap ? g_nl_cap : 1);
     uint32_t nl_n = 0;
     std::vector<PgiU4> out((size_t)out_len / 16 + 4);
     uint8_t *at = reinterpret_cast<uint8_t *>(out.data()) + (misalign & 15);
     std::memset(out.data(), 0xCD, out.size() * 16);
+    static uint32_t crc_tab[PGI_CRC_TAB];
+    static bool crc_made = false;
+    if (!crc_made) { pgi_make_crc_tables(crc_tab); crc_made = true; }
     const int rc = pgi_member(words.data(), (uint32_t)((n_comp + 3) / 4), in_off, in_len, at, out_len, sink, &sh, g_nl_cap ? nl.data() : nullptr,
-                              g_nl_cap, g_nl_lim, &nl_n);
+                              g_nl_cap, g_nl_lim, &nl_n, g_crc_on ? crc_tab : nullptr, g_want_crc);
     g_nl_n = rc ? 0u : nl_n;
     g_nl.assign(nl.begin(), nl.begin() + (rc ? 0u : (nl_n < g_nl_cap ? nl_n : g_nl_cap)));
     // nothing in front of the member's first byte or behind its last may have been touched (its neighbours' text lives there)

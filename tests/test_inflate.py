@@ -34,11 +34,15 @@ def emul(tmp_path_factory):
     L.pgi_emul_nl_result.argtypes = [C.POINTER(C.c_uint16), C.c_uint32]
     L.pgi_emul_nl_result.restype = C.c_uint32
 
-    def run(stream, out_len, pre=0, post=0, misalign=0, rng=random, nl=None):
-        """nl = (capacity, limit): also the list of line feeds the decoder keeps beside the text -> (rc, text, count, offsets)"""
+    L.pgi_emul_crc_setup.argtypes = [C.c_int, C.c_uint32]
+
+    def run(stream, out_len, pre=0, post=0, misalign=0, rng=random, nl=None, crc=None):
+        """nl = (capacity, limit): also the list of line feeds the decoder keeps beside the text -> (rc, text, count, offsets);
+        crc: the CRC-32 the decoder holds the text against while it flushes it (None: no check)"""
         comp = bytes(rng.randrange(256) for _ in range(pre)) + stream + bytes(rng.randrange(256) for _ in range(post))
         dst = C.create_string_buffer(max(out_len, 1) + 8)
         L.pgi_emul_nl_setup(*(nl if nl else (0, 0xFFFFFFFF)))
+        L.pgi_emul_crc_setup(0 if crc is None else 1, 0 if crc is None else crc & 0xFFFFFFFF)
         rc = L.pgi_emul_inflate_at(comp, len(comp), pre, len(stream), dst, out_len, misalign)
         if nl:
             buf = (C.c_uint16 * max(nl[0], 1))()
@@ -75,7 +79,8 @@ def test_the_kernel_source_inflates_what_zlib_deflates(emul):
         for level in (0, 1, 4, 6, 9):
             for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
                 ml = 8 if n % 3 else 1
-                rc, out = emul(deflate(data, level, strat, ml), len(data), pre=n % 9, post=n % 5, misalign=n % 16, rng=rng)
+                rc, out = emul(deflate(data, level, strat, ml), len(data), pre=n % 9, post=n % 5, misalign=n % 16, rng=rng,
+                               crc=zlib.crc32(data) if n % 4 else None)
                 n += 1
                 assert rc == 0 and out == data, (len(data), level, strat, ml, rc)
     assert n > 3500
@@ -103,6 +108,26 @@ def test_the_decoder_lists_the_line_feeds_of_the_text_it_writes(emul):
         rc, out, cnt, offs = emul(deflate(data), len(data), misalign=3, rng=rng, nl=(5, 0xFFFFFFFF))
         assert rc == 0 and out == data and cnt == len(want) and offs == want[:5]
     assert n > 300
+
+
+def test_the_decoder_checksums_the_text_it_writes(emul):
+    """round 6: the member's CRC-32 is taken in the flush (lane i checksums bytes 16 i .. 16 i + 15 of every aligned 1 KiB piece; head
+    and last bytes through the byte table; the lanes' registers moved to the end of the text and XORed) instead of by a kernel that
+    reads the text again: every size around the piece and chunk boundaries at every misalignment; a wrong CRC is PGI_ERR_CRC (64)"""
+    rng = random.Random(9)
+    n = 0
+    sizes = list(range(0, 70)) + [1023, 1024, 1025, 1039, 1040, 1041, 2047, 2048, 2049, 2063, 2064, 2065, 3071, 3072, 3073, 4095, 4096, 4111, 4112,
+                                  5000, 20000, 65279, 65280]
+    for size in sizes:
+        data = bytes(rng.choice(b"ACGT/\t\nN") for _ in range(size))
+        good = zlib.crc32(data)
+        for mis in range(16):
+            rc, out = emul(deflate(data, 6 if size % 2 else 0), len(data), misalign=mis, rng=rng, crc=good)
+            assert rc == 0 and out == data, (size, mis, rc)
+            rc, out = emul(deflate(data), len(data), misalign=mis, rng=rng, crc=good ^ (1 << (n % 32)))
+            assert rc == 64, (size, mis, rc)
+            n += 1
+    assert n > 1400
 
 
 def test_matches_that_reach_behind_the_lds_ring_read_global_memory(emul):
