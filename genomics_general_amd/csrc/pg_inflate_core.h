@@ -27,6 +27,10 @@
 
 #include "pg_inflate.h"
 
+#ifndef PGI_LUT
+#define PGI_LUT 1                 // a direct table for codes of up to eight bits beside the table-free canonical decode
+#endif
+
 #ifdef PG_INFLATE_EMULATE
 #define PGI_DEV static inline
 #define PL(type, name) type name[64]
@@ -105,8 +109,47 @@ struct PgiShared {
     uint16_t sorted_ll[288 + 64]; // literal / length symbols sorted by (code length, symbol) | dump
     uint16_t sorted_d[32 + 64];   // distance symbols (and, while a dynamic header is read, the 19 symbols of the code-length code) | dump
     uint8_t lens[320 + 64];       // code lengths: literal / length symbols, then the distance symbols | dump
+#if PGI_LUT
+    uint16_t lut_ll[256];         // codes of up to eight bits, by the next eight stream bits: symbol | length << 12 (0: a longer code)
+    uint16_t lut_d[256];
+#endif
     alignas(16) uint8_t ring[4096];   // the last PGI_RING bytes of the output
 };
+
+#if PGI_LUT
+// The direct table of a code pgi_build has just described (lim, bas, sorted): entry i = what the canonical decode gives for the
+// eight stream bits i when the code is at most eight bits long (those bits alone decide it then), else 0.
+PGI_DEV void pgi_build_lut(PLREF(uint32_t, lim), PLREF(int32_t, bas), const uint16_t *sorted, int n_sorted, uint16_t *lut PGI_LANE_PARAM) {
+    for (int g = 0; g < 256; g += 64) {
+        PL(uint32_t, c15);
+        PL(uint32_t, lsel);
+        PL(int32_t, bsel);
+        LANES {
+            V(c15) = pgi_brev32((uint32_t)(g + lane)) >> 17;
+            V(lsel) = 0u;
+            V(bsel) = 0;
+        }
+        PGI_NOUNROLL
+        for (int L = 1; L <= 8; ++L) {
+            const uint32_t limL = (uint32_t)READLANE(lim, L);
+            const int32_t basL = (int32_t)READLANE(bas, L);
+            LANES {
+                const bool hit = V(lsel) == 0u && V(c15) < limL;
+                V(lsel) = hit ? (uint32_t)L : V(lsel);
+                V(bsel) = hit ? basL : V(bsel);
+            }
+        }
+        LANES {
+            const uint32_t l = V(lsel) ? V(lsel) : 1u;
+            const uint32_t ix = (uint32_t)((int32_t)(V(c15) >> (15u - l)) + V(bsel));
+            const bool ok = V(lsel) != 0u && ix < (uint32_t)n_sorted;
+            const uint32_t sym = sorted[ok ? ix : 0u];
+            lut[g + lane] = (uint16_t)(ok ? (sym | (V(lsel) << 12)) : 0u);
+        }
+    }
+    PGI_SYNC;
+}
+#endif
 
 // The output window.  The text a member inflates to is written into a ring in LDS and leaves for global memory in pieces of 1 KiB
 // (64 lanes x 16 bytes, aligned stores), so
@@ -310,6 +353,23 @@ static inline void pgi_make_crc_tables(uint32_t *t) {
     t[2304] = 0x80000000u;
     for (int m = 1; m < 64; ++m) t[2304 + m] = pgi_crc_mul_host(t[2304 + m - 1], x128);
 }
+
+#if PGI_LUT
+// ... with the direct table in front: one LDS read gives symbol and length of a code of up to eight bits
+#define PGI_DECODE_LUT(sym_, L_, lut_, lim, bas, sorted, n_sorted_, invalid_)                     \
+    do {                                                                                         \
+        const uint32_t e_ = (uint32_t)UNI(lut_[(uint32_t)buf & 255u]);                           \
+        if (e_) {                                                                                \
+            sym_ = (int)(e_ & 0xFFFu);                                                           \
+            L_ = (int)(e_ >> 12);                                                                \
+            PGI_DROP(L_);                                                                        \
+        } else {                                                                                 \
+            PGI_DECODE_NOEXIT(sym_, L_, lim, bas, sorted, n_sorted_, invalid_);                  \
+        }                                                                                        \
+    } while (0)
+#else
+#define PGI_DECODE_LUT(sym_, L_, lut_, lim, bas, sorted, n_sorted_, invalid_) PGI_DECODE_NOEXIT(sym_, L_, lim, bas, sorted, n_sorted_, invalid_)
+#endif
 
 // One member: in_len bytes of deflate stream at byte in_off of comp -> out_len bytes at dst.  0, or PGI_ERR_* bits.
 // sink: 128 bytes of the member's own where lanes without a byte store.  nl_list (may be null): the offsets, in the member's text,
@@ -626,6 +686,9 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                     const int rc = pgi_build(t == 2 ? sh->lens + 288 : sh->lens, t == 2 ? hdist : hlit, t == 2 ? sh->sorted_d : sh->sorted_ll,
                                              sh->hist, lim_t, bas_t, t == 2 ? 32 : 288, t PGI_LANE_ARG);
                     if (rc) return rc;
+#if PGI_LUT
+                    pgi_build_lut(lim_t, bas_t, t == 2 ? sh->sorted_d : sh->sorted_ll, t == 2 ? 32 : 288, t == 2 ? sh->lut_d : sh->lut_ll PGI_LANE_ARG);
+#endif
                     if (t == 2) {
                         LANES { V(lim_d) = V(lim_t); }
                         LANES { V(bas_d) = V(bas_t); }
@@ -651,7 +714,7 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 }
                 PGI_NEED(32);
                 int sym, L;
-                PGI_DECODE_NOEXIT(sym, L, lim_ll, bas_ll, sh->sorted_ll, 288, 257 + 63);
+                PGI_DECODE_LUT(sym, L, sh->lut_ll, lim_ll, bas_ll, sh->sorted_ll, 288, 257 + 63);
                 if (sym < 256) {
                     LANES { ring[PGI_RIX(pos)] = (uint8_t)sym; }           // (every lane the same byte)
                     ++pos;
@@ -666,7 +729,7 @@ PGI_DEV int pgi_member(const uint32_t *__restrict__ comp, uint32_t n_dw, uint32_
                 PGI_DROP(le);
                 PGI_NEED(32);
                 int dsym;
-                PGI_DECODE_NOEXIT(dsym, L, lim_d, bas_d, sh->sorted_d, 32, 63);
+                PGI_DECODE_LUT(dsym, L, sh->lut_d, lim_d, bas_d, sh->sorted_d, 32, 63);
                 acc |= 29 - dsym;
                 const uint32_t dc = (uint32_t)READLANE(dconst, dsym);
                 const uint32_t de = dc >> 16;

@@ -305,7 +305,7 @@ class Engine:
 
     def inflate_members(self, comp, tab, dst):
         """BGZF members (genoio.bgzf_walk's table over the bytes comp) inflated on the device into the host array dst
-        (pg_inflate_device: k_inflate + k_crc32, then one copy back -- page-locked dst: at the link's rate); returns the kernels' ms.
+        (pg_inflate_device: k_inflate -- the CRC-32 taken on the way out --, then one copy back -- page-locked dst: at the link's rate); returns the kernels' ms.
         For text whose parser lives on the host (the VCF drop-in)."""
         in_off, in_len, out_len, crc = tab
         arr = np.frombuffer(comp, dtype=np.uint8)

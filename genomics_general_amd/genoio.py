@@ -182,7 +182,7 @@ class BgzfSpan:
     def inflate_into(self, dst, engine=None, n_threads=0):
         """the block's text in dst (a uint8 array of at least len(head) + members_text_len() bytes; page-locked when it comes from
         the engine's pool): the head, then the members inflated behind it -- by the device when an engine is given (k_inflate +
-        k_crc32, the text copied back), else by the library's host threads.  Returns dst[:len(self)]."""
+        the CRC-32 checked on the way out, the text copied back), else by the library's host threads.  Returns dst[:len(self)]."""
         h, total = len(self.head), self.members_text_len()
         if dst.size < h + total:
             raise ValueError("BgzfSpan.inflate_into: %d bytes needed, dst holds %d" % (h + total, dst.size))

@@ -329,7 +329,7 @@ int pg_inflate_members(const uint8_t *comp, const uint32_t *in_off, const uint32
 int pg_bgzf_compress(const uint8_t *text, int64_t len, int level, int block, int eof_marker, uint8_t *out, int64_t out_cap,
                      int64_t *out_len_out, int n_threads);
 /* the members inflated ON THE DEVICE (k_inflate: one wavefront per member, canonical Huffman decoding by ballot, matches copied 64
- * bytes at a time; k_crc32 checks the trailers when crc != NULL): comp[0 .. comp_len) -> dst[0 .. sum out_len).  kernel_ms_out (may
+ * bytes at a time; the trailers' CRC-32 are checked when crc != NULL -- inside k_inflate as the text leaves, or by k_crc32 with PG_BGZF_CRC_FOLD=0): comp[0 .. comp_len) -> dst[0 .. sum out_len).  kernel_ms_out (may
  * be NULL): device time of the kernels.  PG_ERR_PARSE names the first damaged member. */
 int pg_inflate_device(pg_ctx *ctx, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
                       const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *dst, double *kernel_ms_out);
