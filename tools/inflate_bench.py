@@ -7,6 +7,10 @@ import argparse
 import ctypes as C
 import json
 import os
+
+# the benchmark's bgzipped samples are what htslib's bgzip writes (zlib, level 6) -- the reference's default input --, not what this
+# library's own, faster compressor would write (csrc/pg_fast_deflate.h: shorter matches, i.e. more symbols for k_inflate to decode)
+os.environ.setdefault("PG_BGZF_ZLIB", "1")
 import subprocess
 import sys
 import tempfile

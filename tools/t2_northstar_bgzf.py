@@ -10,6 +10,10 @@ The text itself is never on disk: pieces of 250 000 rows are rendered from the r
 65 280 bytes of text like bgzip's) one after the other.  bench.py's `t2.bgzf` leg is the same run on the first 2.5e7 sites."""
 import json
 import os
+
+# the benchmark's bgzipped samples are what htslib's bgzip writes (zlib, level 6) -- the reference's default input --, not what this
+# library's own, faster compressor would write (csrc/pg_fast_deflate.h: shorter matches, i.e. more symbols for k_inflate to decode)
+os.environ.setdefault("PG_BGZF_ZLIB", "1")
 import subprocess
 import sys
 import tempfile

@@ -109,7 +109,8 @@ def main():
     vcf = os.path.join(tmp, "in.vcf")
     size = write_vcf(vcf, n_sites, n_samples)
     bgz = vcf + ".gz"
-    timed([sys.executable, os.path.join(HERE, "bgzip.py"), vcf, bgz])
+    # the input is what htslib's bgzip writes (zlib, level 6); the drop-in's own writer keeps its default (the library's compressor)
+    timed([sys.executable, os.path.join(HERE, "bgzip.py"), vcf, bgz], env={"PG_BGZF_ZLIB": "1"})
     shim = os.path.join(ROOT, "VCF_processing", "parseVCF.py")
     opts = ["--skipIndels", "--minQual", "30", "--gtf", "flag=DP", "min=8", "--gtf", "flag=GQ", "min=20"]
     res = {"sites": n_sites, "samples": n_samples, "vcf_bytes": size, "vcf_gz_bytes": os.path.getsize(bgz), "options": " ".join(opts), "legs": {}}
