@@ -94,6 +94,15 @@ SIGNATURES = {
     "pg_vcf_render_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char, C.c_char, C.c_int,
                                      C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
+    "pg_vcf_dev_config": (C.c_int, None),
+    "pg_vcf_dev_submit": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64]),
+    "pg_vcf_dev_submit_bgzf": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
+    "pg_vcf_dev_parse": (C.c_int, [_P, C.c_int]),
+    "pg_vcf_dev_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pg_vcf_dev_rows": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int64]),
+    "pg_vcf_dev_text": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int64]),
+    "pg_vcf_dev_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pg_format_freq_rows": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_void_p, _i64p, _i32p, C.c_char_p, _i64p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_inflate_chunks": (C.c_int, [C.c_void_p, _i64p, _i64p, _i64p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),

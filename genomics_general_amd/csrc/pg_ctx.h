@@ -3,6 +3,7 @@
 #include "../../include/popgen_hip.h"
 #include "pg_internal.h"
 #include "pg_inflate.h"
+#include "pg_vcf_core.h"
 
 #include <utility>
 #include <vector>
@@ -147,6 +148,28 @@ struct pg_ctx {
         int64_t len = 0, n_lines = 0, n_tiles = 0, run_cap = 0;
         int64_t n_members = 0, head_len = 0;   // (a block that arrived deflated)
     } tok[2];
+    // VCF lines parsed on the device (pg_vcf_dev.hip): the option set of the run and, per text slot of the tokenizer, the per-line
+    // records, the rows' sizes and places, the rows' text
+    struct VcfDev {
+        bool configured = false;
+        PgvConfig cfg;
+        int waves_per_block = 4;
+        DevBuf<uint8_t> contigs, ploidy, fsel;
+        DevBuf<int32_t> sel_col;
+        DevBuf<uint32_t> cell_off;
+        struct Slot {
+            DevBuf<uint8_t> lines, out;
+            DevBuf<uint32_t> rlen;
+            DevBuf<int64_t> roff, status;        // status: [0] bits (1 a line needs the host, 2 the rows exceed `out`), [1] first such line, [2] bytes of the rows, [3] rows
+            HostPin<int64_t> h_status;
+            hipEvent_t done = nullptr;
+            int state = 0;                       // 0 idle, 1 text on its way / there, 2 kernels queued, 3 empty block
+            int64_t text_len = 0, out_cap = 0;
+            bool no_final_newline = false;
+        } s[2];
+        double kernel_ms = 0;                    // pg_vcf_dev_stats
+        int64_t blocks = 0, host_blocks = 0;
+    } vcf;
     int64_t tok_nl_fallbacks = 0;                          // deflated blocks whose line feeds were found by passes over the text after all
     HostPin<uint8_t> tok_pin;                              // two 4 MiB page-locked buffers per staging thread
     hipStream_t tok_st[PG_TOK_WORKERS] = {};               // one copy stream per staging thread

@@ -740,36 +740,13 @@ int pg_inflate_error(const int32_t *status);
 void pg_launch_gather_bytes(hipStream_t st, const uint8_t *text, const int64_t *off, const int32_t *len, const int64_t *dst, int n,
                             uint8_t *out);
 
-// The submit step for a block of bgzip-compressed text: comp[0 .. comp_len) -- or, with comp == NULL, comp_len bytes at file_offset of
-// fd -- holds n_members whole BGZF members (table: pg_bgzf_walk),
-// which cross PCIe as they are and are inflated on the device (k_inflate, a wavefront per member; CRC-32 checked) into the slot's
-// text buffer behind `head` (head_len bytes of text the caller already has: the unfinished line the previous block ended with).
-// The block's text is  head + the members' text  cut to text_len bytes (the caller keeps what follows the last line feed for the
-// next block); first_line: the block's first line without its line feed (the cell widths are read off it).
-static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int64_t file_offset, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
-                           const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head, int64_t head_len,
-                           int64_t text_len, const char *first_line, int64_t first_line_len, int fmt, int n_cols, int max_ploidy,
-                           const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out) {
-    const int chk = tok_check(c, slot, fmt, n_cols, max_ploidy, col_slot, col_ploidy, ok_out);
-    if (chk < 0) return -chk;
-    if (comp_len < 0 || comp_len >= (1ll << 32) || n_members < 0 || head_len < 0 || text_len < 0 || first_line_len < 0 ||
-        (n_members > 0 && ((!comp && fd < 0) || file_offset < 0 || !in_off || !in_len || !out_len)) || (head_len > 0 && !head) ||
-        (first_line_len > 0 && !first_line))
-        return pg_fail(PG_ERR_ARG, "pg_tokenize_submit_bgzf: bad argument");
-    int64_t total = head_len;
-    for (int64_t k = 0; k < n_members; ++k) {
-        if ((int64_t)in_off[k] + in_len[k] > comp_len) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit_bgzf: member %lld lies outside the compressed bytes", (long long)k);
-        total += out_len[k];
-    }
-    if (text_len > total) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit_bgzf: text_len %lld exceeds the %lld bytes of the block", (long long)text_len, (long long)total);
+// the device half of a deflated block's submit: the members cross PCIe as they are, k_inflate writes their text behind `head` into
+// the slot's text buffer and lists its line feeds (first_line_len sizes the members' lists); shared by the `.geno` tokenizer and
+// the VCF kernels (pg_tok_bgzf_submit)
+static int tok_bgzf_core(pg_ctx *c, int slot, const uint8_t *comp, int fd, int64_t file_offset, int64_t comp_len, const uint32_t *in_off,
+                         const uint32_t *in_len, const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head,
+                         int64_t head_len, int64_t text_len, int64_t total, int64_t first_line_len, int *ok_out) {
     pg_ctx::TokSlot &T = c->tok[slot];
-    T.state = 0;
-    T.len = text_len;
-    T.n_lines = 0;
-    T.deflated = true;
-    if (text_len == 0) { T.state = 1; *ok_out = 1; return PG_OK; }
-    if (chk == 0) return PG_OK;
-    if (!tok_layout(T, first_line, first_line + first_line_len, fmt, n_cols, max_ploidy, col_slot, col_ploidy)) return PG_OK;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream_up;
     int rc;
@@ -857,6 +834,41 @@ static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int
     if (trace) fprintf(stderr, "PG_TOK_TRACE submit_bgzf slot %d pinned %d: alloc %.2f copy %.2f head %.2f inflate_queue %.2f count_queue %.2f ms\n", slot, (int)pinned, tr[0], tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3]);
     *ok_out = 1;
     return PG_OK;
+}
+
+
+// The submit step for a block of bgzip-compressed text: comp[0 .. comp_len) -- or, with comp == NULL, comp_len bytes at file_offset of
+// fd -- holds n_members whole BGZF members (table: pg_bgzf_walk),
+// which cross PCIe as they are and are inflated on the device (k_inflate, a wavefront per member; CRC-32 checked) into the slot's
+// text buffer behind `head` (head_len bytes of text the caller already has: the unfinished line the previous block ended with).
+// The block's text is  head + the members' text  cut to text_len bytes (the caller keeps what follows the last line feed for the
+// next block); first_line: the block's first line without its line feed (the cell widths are read off it).
+static int tok_submit_bgzf(pg_ctx *c, int slot, const uint8_t *comp, int fd, int64_t file_offset, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
+                           const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head, int64_t head_len,
+                           int64_t text_len, const char *first_line, int64_t first_line_len, int fmt, int n_cols, int max_ploidy,
+                           const int32_t *col_slot, const int32_t *col_ploidy, int *ok_out) {
+    const int chk = tok_check(c, slot, fmt, n_cols, max_ploidy, col_slot, col_ploidy, ok_out);
+    if (chk < 0) return -chk;
+    if (comp_len < 0 || comp_len >= (1ll << 32) || n_members < 0 || head_len < 0 || text_len < 0 || first_line_len < 0 ||
+        (n_members > 0 && ((!comp && fd < 0) || file_offset < 0 || !in_off || !in_len || !out_len)) || (head_len > 0 && !head) ||
+        (first_line_len > 0 && !first_line))
+        return pg_fail(PG_ERR_ARG, "pg_tokenize_submit_bgzf: bad argument");
+    int64_t total = head_len;
+    for (int64_t k = 0; k < n_members; ++k) {
+        if ((int64_t)in_off[k] + in_len[k] > comp_len) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit_bgzf: member %lld lies outside the compressed bytes", (long long)k);
+        total += out_len[k];
+    }
+    if (text_len > total) return pg_fail(PG_ERR_ARG, "pg_tokenize_submit_bgzf: text_len %lld exceeds the %lld bytes of the block", (long long)text_len, (long long)total);
+    pg_ctx::TokSlot &T = c->tok[slot];
+    T.state = 0;
+    T.len = text_len;
+    T.n_lines = 0;
+    T.deflated = true;
+    if (text_len == 0) { T.state = 1; *ok_out = 1; return PG_OK; }
+    if (chk == 0) return PG_OK;
+    if (!tok_layout(T, first_line, first_line + first_line_len, fmt, n_cols, max_ploidy, col_slot, col_ploidy)) return PG_OK;
+    return tok_bgzf_core(c, slot, comp, fd, file_offset, comp_len, in_off, in_len, out_len, crc, n_members, head, head_len, text_len, total,
+                         first_line_len, ok_out);
 }
 
 static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capacity, int64_t run_capacity, int64_t *n_rows_out, int *ok_out) {
@@ -1030,6 +1042,107 @@ static int tok_collect(pg_ctx *c, int slot, int64_t *pos_out, int64_t pos_capaci
         run_len_out[k] = rlen[j];
     }
     *ok_out = 1;
+    return PG_OK;
+}
+
+// ---- the same first steps for the VCF kernels (pg_vcf_dev.hip): a block's text into a slot, its line feeds listed -----------------
+// pg_tok_text_submit / pg_tok_bgzf_submit: the text (or the deflated members) to the device, line feeds counted behind it;
+// pg_tok_lines: waits for the count, leaves the line-feed positions in the slot's `nl` (queued on the copy stream) and returns their
+// number.  The slot's buffers are the tokenizer's: a process runs one of the two.
+int pg_tok_text_submit(pg_ctx *c, int slot, const char *text, int fd, int64_t file_offset, int64_t len) {
+    pg_ctx::TokSlot &T = c->tok[slot];
+    T.state = 0;
+    T.len = len;
+    T.n_lines = 0;
+    T.deflated = false;
+    if (len == 0) { T.state = 1; return PG_OK; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((rc = T.text.ensure_roomy((size_t)len + 96)) != PG_OK) return rc;
+    T.tp = T.text.p;
+    const TokSource src{text, text ? -1 : fd, text ? 0 : file_offset};
+    if ((rc = stage_bytes(c, src, len, T.text.p)) != PG_OK) return rc;
+    c->tok_stage_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    c->tok_bytes += len;
+    return tok_count(c, T, len);
+}
+
+int pg_tok_bgzf_submit(pg_ctx *c, int slot, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
+                       const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head, int64_t head_len,
+                       int64_t text_len, int64_t line_len_hint) {
+    if (comp_len < 0 || comp_len >= (1ll << 32) || n_members < 0 || head_len < 0 || text_len < 0 ||
+        (n_members > 0 && (!comp || !in_off || !in_len || !out_len)) || (head_len > 0 && !head))
+        return pg_fail(PG_ERR_ARG, "pg_vcf_dev_submit_bgzf: bad argument");
+    int64_t total = head_len;
+    for (int64_t k = 0; k < n_members; ++k) {
+        if ((int64_t)in_off[k] + in_len[k] > comp_len) return pg_fail(PG_ERR_ARG, "pg_vcf_dev_submit_bgzf: member %lld lies outside the compressed bytes", (long long)k);
+        total += out_len[k];
+    }
+    if (text_len > total) return pg_fail(PG_ERR_ARG, "pg_vcf_dev_submit_bgzf: text_len %lld exceeds the %lld bytes of the block", (long long)text_len, (long long)total);
+    pg_ctx::TokSlot &T = c->tok[slot];
+    T.state = 0;
+    T.len = text_len;
+    T.n_lines = 0;
+    T.deflated = true;
+    if (text_len == 0) { T.state = 1; return PG_OK; }
+    int ok = 0;
+    return tok_bgzf_core(c, slot, comp, -1, 0, comp_len, in_off, in_len, out_len, crc, n_members, head, head_len, text_len, total,
+                         line_len_hint, &ok);
+}
+
+int pg_tok_lines(pg_ctx *c, int slot, int64_t *n_lines_out) {
+    pg_ctx::TokSlot &T = c->tok[slot];
+    *n_lines_out = 0;
+    if (T.state == 1) return PG_OK;
+    if (T.state != 2) return pg_fail(PG_ERR_STATE, "nothing submitted to slot %d", slot);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream_up;
+    HIPCHK(hipEventSynchronize(T.counted));
+    if (T.deflated) {
+        int32_t ist[2];
+        memcpy(ist, T.h_total.p + 2, 8);
+        if (ist[0]) { T.state = 0; return pg_inflate_error(ist); }
+    }
+    bool nl_lists = T.deflated && T.inf.nl_cap > 0;
+    if (nl_lists) {
+        int32_t over = 0;
+        memcpy(&over, T.h_total.p + 3, 4);
+        if (over) {                                                  // a member held more line feeds than its list: the passes over the text
+            nl_lists = false;
+            T.inf.nl_cap = 0;
+            int rc0 = tok_count(c, T, T.len);
+            if (rc0 != PG_OK) return rc0;
+            HIPCHK(hipEventSynchronize(T.counted));
+            ++c->tok_nl_fallbacks;
+        }
+    }
+    const int64_t n_lines = T.h_total.p[0];
+    T.n_lines = n_lines;
+    *n_lines_out = n_lines;
+    T.state = 0;
+    if (n_lines == 0) return PG_OK;
+    int rc;
+    if ((rc = T.nl.ensure_roomy((size_t)n_lines)) != PG_OK) return rc;
+    if (nl_lists) pg_launch_nl_gather(st, T.inf, T.inf.nl_cap, T.n_members, T.head_len, T.nl.p);
+    else hipLaunchKernelGGL(k_nl_write, dim3((unsigned)T.n_tiles), dim3(256), 0, st, T.tp, T.len, T.i64.p, T.nl.p);
+    HIPCHK(hipGetLastError());
+    if (T.deflated && T.inf.crc_pending) {                           // (PG_BGZF_CRC_FOLD=0 / PG_BGZF_CRC_STREAM=1: the check by a kernel of its own)
+        HIPCHK(hipStreamWaitEvent(st, T.inf.ev_crc, 0));
+        HIPCHK(hipMemcpyAsync(T.h_total.p + 4, T.inf.status.p + 2, 8, hipMemcpyDeviceToHost, st));
+    }
+    return PG_OK;
+}
+
+// the members' checksums of a deflated block whose kernels have finished (0: all as their trailers say)
+int pg_tok_crc_result(pg_ctx *c, int slot) {
+    pg_ctx::TokSlot &T = c->tok[slot];
+    if (T.deflated && T.inf.crc_pending) {
+        T.inf.crc_pending = false;
+        int32_t cst[2];
+        memcpy(cst, T.h_total.p + 4, 8);
+        if (cst[0]) return pg_inflate_error(cst);
+    }
     return PG_OK;
 }
 

@@ -317,6 +317,55 @@ class Engine:
         check(self._L.pg_inflate_device(self._h, vp(arr), arr.size, vp(in_off), vp(in_len), vp(out_len), vp(crc), len(in_off), vp(dst), C.byref(ms)))
         return ms.value
 
+    # ---- VCF lines parsed on the device (pg_vcf_dev_*; genomics_general_amd/vcf.py) ----
+    def vcf_config(self, plan):
+        """the option set of a parseVCF run (vcf.Plan) -> the device; None when the device path takes it, else the reason it does not"""
+        taken, why = C.c_int(0), C.c_char_p()
+        fn = self._L.pg_vcf_dev_config
+        check(fn(self._h, *plan.site_args(), C.c_char(plan.sep.encode()), 1 if plan.args.addRefTrack else 0, C.byref(taken), C.byref(why)))
+        return None if taken.value else (why.value or b"").decode()
+
+    def vcf_submit(self, slot, block, file=None):
+        """a block of whole lines (bytes-like; file = (descriptor, offset) when it is a view of a memory-mapped file: the staging
+        threads then read it themselves) or a genoio.BgzfSpan (members still deflated) -> text slot `slot`"""
+        if hasattr(block, "tab"):
+            in_off, in_len, out_len, crc = block.tab
+            vp = lambda a: C.c_void_p(a.ctypes.data if a.size else 0)           # noqa: E731
+            comp = np.frombuffer(block.comp, dtype=np.uint8)
+            check(self._L.pg_vcf_dev_submit_bgzf(self._h, int(slot), vp(comp), comp.size, vp(in_off), vp(in_len), vp(out_len), vp(crc), len(in_off),
+                                                 block.head, len(block.head), len(block), len(block.first_line) + 1, 1))
+            return comp
+        if file is not None:
+            check(self._L.pg_vcf_dev_submit(self._h, int(slot), None, int(file[0]), int(file[1]), len(block)))
+            return None
+        ptr, n, keep = _lib.text_ptr(block)
+        check(self._L.pg_vcf_dev_submit(self._h, int(slot), ptr, -1, 0, n))
+        return keep
+
+    def vcf_parse(self, slot):
+        check(self._L.pg_vcf_dev_parse(self._h, int(slot)))
+
+    def vcf_collect(self, slot):
+        """(bytes of the block's rows, their number, -1) or (0, 0, the first line the device does not take: the block is the host parser's)"""
+        n, rows, line = C.c_int64(0), C.c_int64(0), C.c_int64(-1)
+        check(self._L.pg_vcf_dev_collect(self._h, int(slot), C.byref(n), C.byref(rows), C.byref(line)))
+        return n.value, rows.value, line.value
+
+    def vcf_rows(self, slot, nbytes):
+        out = self.pinned.empty((max(int(nbytes), 1),), np.uint8)[:int(nbytes)]
+        check(self._L.pg_vcf_dev_rows(self._h, int(slot), C.c_void_p(out.ctypes.data), int(nbytes)))
+        return out
+
+    def vcf_text(self, slot, nbytes):
+        out = self.pinned.empty((max(int(nbytes), 1),), np.uint8)[:int(nbytes)]
+        check(self._L.pg_vcf_dev_text(self._h, int(slot), C.c_void_p(out.ctypes.data), int(nbytes)))
+        return out
+
+    def vcf_stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(self._L.pg_vcf_dev_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def tokenize_parse(self, slot, row_offset, row_capacity, max_runs=1 << 16):
         """queue the parse of the block in `slot` into resident rows row_offset .. (at most row_capacity of them); returns the number of
         its lines, or None when they do not fit"""

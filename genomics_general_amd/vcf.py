@@ -108,21 +108,34 @@ class _AsyncOut:
         self.th.join()
 
 
-def _text_blocks(reader, block_bytes, n_threads=0):
-    """the input's text in blocks of whole lines.  A bgzip-compressed VCF (what `bgzip` / GATK / bcftools write) is read as spans of
-    deflated members (genoio.BgzfFile.read_span) and inflated into a ring of buffers: ON THE DEVICE when there is one (the members
-    cross PCIe deflated, k_inflate takes a wavefront per member, the text comes back into page-locked memory; PG_BGZF_DEVICE=0:
-    never), else by the library's host threads.  Everything else: the reader's own blocks."""
+def _text_blocks(reader, block_bytes, n_threads=0, plan=None):
+    """the input in blocks of whole lines, as pairs (text, None) for the host parser or (raw, where) for the device's.
+
+    A bgzip-compressed VCF (what `bgzip` / GATK / bcftools write) is read as spans of deflated members (genoio.BgzfFile.read_span).
+    With a device and an option set its parser takes (`plan`: text output, no --packed; Engine.vcf_config), a block is handed on as it
+    is -- a BgzfSpan, or a view of the memory-mapped plain file with its (descriptor, offset) -- and the caller submits it to the
+    device (pg_vcf_dev_*): the text of a bgzipped VCF then never exists on the host.  Otherwise a span is inflated into a ring of
+    buffers: ON THE DEVICE when there is one (the members cross PCIe deflated, k_inflate takes a wavefront per member, the text comes
+    back into page-locked memory; PG_BGZF_DEVICE=0: never), else by the library's host threads; everything else: the reader's own
+    blocks.  PG_VCF_DEVICE=0: the host parser always; =1: the device's even for a small file (tests)."""
     bg = isinstance(getattr(reader, "f", None), genoio.BgzfFile)
     made = {}
     maker = None
-    # (a small file is over before a device context exists -- 0.1 - 0.3 s --: the host threads inflate it; PG_VCF_WAIT_FOR_DEVICE: always)
-    worth = bg and (getattr(reader.f, "size", 0) >= (32 << 20) or os.environ.get("PG_VCF_WAIT_FOR_DEVICE"))
-    if worth and os.environ.get("PG_BGZF_DEVICE", "1") != "0" and _lib.device_count() > 0:
+    force = os.environ.get("PG_VCF_DEVICE", "")
+    want_dev = plan is not None and force != "0"
+    # (a small file is over before a device context exists -- 0.1 - 0.3 s --: the host threads take it; PG_VCF_WAIT_FOR_DEVICE: always)
+    wait = bool(os.environ.get("PG_VCF_WAIT_FOR_DEVICE")) or (want_dev and force == "1")
+    size = getattr(reader.f, "size", 0) if bg else (reader.input_size() if reader.mm is not None else 0)
+    worth = (bg or (want_dev and reader.mm is not None)) and (size >= (32 << 20) or wait)
+    if worth and (os.environ.get("PG_BGZF_DEVICE", "1") != "0" or want_dev) and _lib.device_count() > 0:
         def make():                               # the device context takes 0.1 - 0.3 s: the first blocks do not wait for it
             try:
                 from .engine import Engine
-                made["engine"] = Engine(int(os.environ.get("PG_DEVICE", "0")))
+                eng = Engine(int(os.environ.get("PG_DEVICE", "0")))
+                if want_dev:
+                    made["why_not"] = eng.vcf_config(plan)
+                    made["dev"] = made["why_not"] is None
+                made["engine"] = eng
             except BaseException as exc:
                 made["error"] = exc
         maker = threading.Thread(target=make, name="pg-vcf-context", daemon=True)
@@ -130,22 +143,33 @@ def _text_blocks(reader, block_bytes, n_threads=0):
     if bg:
         reader.spans = True
     ring, turn = [None] * 4, 0                  # one block with the parser, two queued, one being filled
-    info = {"bgzf": bg, "device_inflate": False, "inflate_kernel_ms": 0.0, "inflate_s": 0.0, "blocks": 0, "blocks_inflated_on_device": 0}
+    info = {"bgzf": bg, "device_inflate": False, "inflate_kernel_ms": 0.0, "inflate_s": 0.0, "blocks": 0, "blocks_inflated_on_device": 0,
+            "blocks_parsed_on_device": 0}
     try:
         while True:
             blk = reader.read_block(block_bytes)
             if len(blk) == 0:
                 break
             info["blocks"] += 1
-            if isinstance(blk, genoio.BgzfSpan):
-                if maker is not None and (not maker.is_alive() or os.environ.get("PG_VCF_WAIT_FOR_DEVICE")):
-                    maker.join()
-                    maker = None
-                    if "error" in made:
-                        raise made["error"]
+            if maker is not None and (not maker.is_alive() or wait):
+                maker.join()
+                maker = None
+                if "error" in made:
+                    raise made["error"]
+                if bg:
                     reader.f.alloc = made["engine"].pinned.empty          # (the next spans arrive in page-locked memory)
-                    ring = [None] * 4
-                eng = made.get("engine") if maker is None else None
+                ring = [None] * 4
+                _text_blocks.engine = made["engine"]
+                if made.get("why_not"):
+                    info["device_parser_not_taken"] = made["why_not"]
+            eng = made.get("engine") if maker is None else None
+            if eng is not None and made.get("dev") and os.environ.get("PG_BGZF_DEVICE", "1") != "0":
+                info["blocks_parsed_on_device"] += 1
+                yield blk, (reader.file_range(blk) if not isinstance(blk, genoio.BgzfSpan) else None) or ()
+                continue
+            if isinstance(blk, genoio.BgzfSpan):
+                if os.environ.get("PG_BGZF_DEVICE", "1") == "0":
+                    eng = None
                 need = len(blk.head) + blk.members_text_len()
                 buf = ring[turn % 4]
                 if buf is None or buf.size < need:
@@ -163,7 +187,7 @@ def _text_blocks(reader, block_bytes, n_threads=0):
                 else:
                     blk = blk.inflate_into(buf, None, n_threads)
                 info["inflate_s"] += time.perf_counter() - t0
-            yield blk
+            yield blk, None
     finally:
         if maker is not None:
             maker.join()
@@ -446,7 +470,137 @@ def _cigar_main(args):
     return 0
 
 
-def parse_vcf_main(argv=None):
+class Plan:
+    """The option set of one parseVCF run in the forms the native parsers take (pg_encode_vcf on the host, pg_vcf_dev_* on the device,
+    tests/vcf_emul.cpp): selected sample columns and ploidies, genotype filters, contig list, option bits."""
+
+    def __init__(self, args, vcf_samples):
+        self.args = args
+        include, exclude = [], []                                     # parseIncludeExcludeArgs, parseVCF.py:306-330
+        if args.include:
+            include += args.include.split(",")
+        if args.exclude:
+            exclude += args.exclude.split(",")
+        if args.includeFile:
+            with open(args.includeFile, "rt") as f:
+                include += [c.strip() for c in f.read().split("\n")]
+        if args.excludeFile:
+            with open(args.excludeFile, "rt") as f:
+                exclude += [c.strip() for c in f.read().split("\n")]
+        if include:
+            sys.stderr.write("{} contigs will be included.".format(len(set(include))))
+        if exclude:
+            sys.stderr.write("{} contigs will be excluded.".format(len(set(exclude))))
+        self.vcf_samples = list(vcf_samples)
+        samples = args.samples.split(",") if args.samples else None
+        if samples:
+            for s in samples:
+                assert s in vcf_samples, "Sample {} not in VCF header\n".format(s)
+        else:
+            samples = list(vcf_samples)
+        self.samples = samples
+        ploidy = {s: args.ploidy for s in samples}
+        if args.ploidyFile:
+            with open(args.ploidyFile, "rt") as pf:
+                for ln in pf:
+                    f = ln.split()
+                    if f and f[0] in ploidy:
+                        ploidy[f[0]] = int(f[1])
+        self.pl = np.array([ploidy[s] for s in samples], dtype=np.int32)
+        if np.any((self.pl < 1) | (self.pl > 2)):
+            raise SystemExit("parseVCF.py: this drop-in holds ploidy 1 or 2")
+        # dict(zip(headers, elements)) keeps the LAST of duplicated sample names
+        col_of = {nm: k for k, nm in enumerate(vcf_samples)}
+        self.sel_col = np.array([col_of[s] for s in samples], dtype=np.int32)
+        self.n_sel = len(samples)
+        # ---- genotype filters ----
+        gtf = [_parse_gtf(g) for g in args.gtf] if args.gtf else []
+        self.keep_alive = []
+        self.n_filters = len(gtf)
+        self.Farr = Farr = (_Filter * max(len(gtf), 1))()
+        for k, g in enumerate(gtf):
+            Farr[k].flag = g["flag"].encode()
+            Farr[k].min, Farr[k].max = g["min"], g["max"]
+            Farr[k].site_types = sum(SITE_TYPES.get(t, 0) for t in set(g.get("siteTypes", [])))     # a set: a repeated name is one bit
+            Farr[k].gt_types = sum(GT_TYPES.get(t, 0) for t in set(g.get("gtTypes", [])))
+            if "siteTypes" in g and Farr[k].site_types == 0:
+                Farr[k].site_types = 1 << 30                          # names that match no site type: the filter never applies
+            if "gtTypes" in g and Farr[k].gt_types == 0:
+                Farr[k].gt_types = 1 << 30
+            if "samples" in g:
+                m = np.array([1 if s in g["samples"] else 0 for s in samples], dtype=np.uint8)
+                self.keep_alive.append(m)
+                Farr[k].samples = m.ctypes.data
+        self.flags = ((1 if args.skipIndels else 0) | (2 if args.keepPartial else 0) | (4 if args.ploidyMismatchToMissing else 0) |
+                      (8 if args.excludeDuplicates else 0))
+        self.contig_mode, self.contigs = 0, b""
+        if include and exclude:                                       # the reference applies both: keep included minus excluded
+            self.contig_mode, self.contigs = 1, "\n".join(sorted(set(include) - set(exclude))).encode()
+        elif include:
+            self.contig_mode, self.contigs = 1, "\n".join(sorted(set(include))).encode()
+        elif exclude:
+            self.contig_mode, self.contigs = 2, "\n".join(sorted(set(exclude))).encode()
+        self.missing = args.missing if args.missing is not None else "N"
+        self.sep = args.outSep
+        self.bufs = {}
+
+    def header_line(self):
+        sep = self.sep.encode()
+        return sep.join([b"#CHROM", b"POS"] + ([b"REF"] if self.args.addRefTrack else []) + [s.encode() for s in self.samples]) + b"\n"
+
+    def site_args(self):
+        """the arguments every native parser starts with behind its text (pg_encode_vcf's order)"""
+        a = self.args
+        vp = lambda x: C.c_void_p(x.ctypes.data)                      # noqa: E731
+        return (len(self.vcf_samples), self.n_sel, vp(self.sel_col), vp(self.pl), self.flags, C.c_double(float(a.minQual or 0)),
+                int(a.maxREFlen or 0), self.Farr, self.n_filters, C.c_char_p(self.contigs), len(self.contigs), self.contig_mode,
+                C.c_char(self.missing.encode()))
+
+    def _arr(self, name, shape, dtype):
+        """arrays of the host parser's outputs, kept from block to block (pg_encode_vcf writes every field of a kept row)"""
+        a = self.bufs.get(name)
+        if a is None or a.shape[0] < shape[0]:
+            a = self.bufs[name] = np.empty(shape, dtype=dtype)
+        return a
+
+    def host_parse(self, ptr, nbytes, prev_chrom=None, prev_pos=None, n_threads=0):
+        """pg_encode_vcf over the block of whole lines at ptr: the number of kept sites, the calls longer than one base, and the
+        arrays of its rows (for host_render / the packed writer)"""
+        L = _lib.lib()
+        fn = L.pg_encode_vcf
+        fn.restype = C.c_int
+        n_sel = self.n_sel
+        nl = C.c_int64(0)
+        check(L.pg_count_lines(ptr, nbytes, C.byref(nl)))
+        cap = int(nl.value) + 1
+        A = {"chars": self._arr("chars", (cap, 2 * n_sel), np.uint8), "aidx": self._arr("aidx", (cap, 2 * n_sel), np.int8),
+             "phase": self._arr("phase", (cap, n_sel), np.uint8), "rflag": self._arr("rflag", (cap,), np.uint8),
+             "pos": self._arr("pos", (cap,), np.int64), "coff": self._arr("coff", (cap,), np.int64), "clen": self._arr("clen", (cap,), np.int32),
+             "roff": self._arr("roff", (cap,), np.int64), "rlen": self._arr("rlen", (cap,), np.int32),
+             "aoff": self._arr("aoff", (cap,), np.int64), "alen": self._arr("alen", (cap,), np.int32)}
+        vp = lambda a: C.c_void_p(a.ctypes.data)                      # noqa: E731
+        n, nmb = C.c_int64(0), C.c_int64(0)
+        check(fn(ptr, C.c_size_t(nbytes), *self.site_args(),
+                 C.c_char_p(prev_chrom), len(prev_chrom or b""), C.c_char_p(prev_pos), len(prev_pos or b""),
+                 vp(A["chars"]), vp(A["aidx"]), vp(A["phase"]), vp(A["rflag"]), vp(A["pos"]), vp(A["coff"]), vp(A["clen"]), vp(A["roff"]),
+                 vp(A["rlen"]), vp(A["aoff"]), vp(A["alen"]), C.c_int64(cap), C.byref(n), C.byref(nmb), int(n_threads)))
+        return int(n.value), int(nmb.value), A
+
+    def host_render(self, ptr, k, A, n_threads=0):
+        """the `.geno` text of the k rows host_parse left (pg_vcf_render_rows: a sizing call, then the bytes)"""
+        L = _lib.lib()
+        vp = lambda a: C.c_void_p(a.ctypes.data)                      # noqa: E731
+        size = C.c_int64(0)
+        rargs = (ptr, k, self.n_sel, vp(self.pl), vp(A["chars"]), vp(A["aidx"]), vp(A["phase"]), vp(A["rflag"]), vp(A["pos"]), vp(A["coff"]),
+                 vp(A["clen"]), vp(A["roff"]), vp(A["rlen"]), vp(A["aoff"]), vp(A["alen"]), C.c_char(self.sep.encode()),
+                 C.c_char(self.missing.encode()), 1 if self.args.addRefTrack else 0)
+        check(L.pg_vcf_render_rows(*rargs, None, 0, C.byref(size), int(n_threads)))
+        text = np.empty(size.value, dtype=np.uint8)
+        check(L.pg_vcf_render_rows(*rargs, vp(text), size.value, C.byref(size), int(n_threads)))
+        return text
+
+
+def make_parser():
     ap = argparse.ArgumentParser(prog="parseVCF.py")
     ap.add_argument("-o", "--outFile", help="Output .geno file")
     ap.add_argument("-s", "--samples", help="sample names (separated by commas)")
@@ -476,7 +630,11 @@ def parse_vcf_main(argv=None):
     ap.add_argument("--packedCodec", choices=("zlib", "none"), default="zlib",
                     help="cells of the --packed file: deflated chunks (smallest) or raw (1 byte per genotype: read by the drivers at PCIe speed)")
     ap.add_argument("--threads", type=int, default=0, help="host threads of the native parser (default: all)")
-    args = ap.parse_args(argv)
+    return ap
+
+
+def parse_vcf_main(argv=None):
+    args = make_parser().parse_args(argv)
     if args.field is not None:
         return _field_main(args)
     if args.simplifyALT or args.expandMulti:
@@ -492,22 +650,6 @@ def parse_vcf_main(argv=None):
     if args.packed and args.addRefTrack and not want_text:
         raise SystemExit("parseVCF.py: --addRefTrack has no meaning for --packed output")
 
-    include, exclude = [], []                                     # parseIncludeExcludeArgs, parseVCF.py:306-330
-    if args.include:
-        include += args.include.split(",")
-    if args.exclude:
-        exclude += args.exclude.split(",")
-    if args.includeFile:
-        with open(args.includeFile, "rt") as f:
-            include += [c.strip() for c in f.read().split("\n")]
-    if args.excludeFile:
-        with open(args.excludeFile, "rt") as f:
-            exclude += [c.strip() for c in f.read().split("\n")]
-    if include:
-        sys.stderr.write("{} contigs will be included.".format(len(set(include))))
-    if exclude:
-        sys.stderr.write("{} contigs will be excluded.".format(len(set(exclude))))
-
     # ---- header (parseHeaderLines, parseVCF.py:213-236) ----
     reader = genoio.BlockReader(args.inFile)
     head = None
@@ -519,62 +661,15 @@ def parse_vcf_main(argv=None):
             head = line.decode("utf-8", "replace").split()
             break
     assert head is not None and len(head) >= 9, "no #CHROM header line in the VCF"
-    vcf_samples = head[9:]
-    samples = args.samples.split(",") if args.samples else None
-    if samples:
-        for s in samples:
-            assert s in vcf_samples, "Sample {} not in VCF header\n".format(s)
-    else:
-        samples = list(vcf_samples)
-    ploidy = {s: args.ploidy for s in samples}
-    if args.ploidyFile:
-        with open(args.ploidyFile, "rt") as pf:
-            for ln in pf:
-                f = ln.split()
-                if f and f[0] in ploidy:
-                    ploidy[f[0]] = int(f[1])
-    pl = np.array([ploidy[s] for s in samples], dtype=np.int32)
-    if np.any((pl < 1) | (pl > 2)):
-        raise SystemExit("parseVCF.py: this drop-in holds ploidy 1 or 2")
-    # dict(zip(headers, elements)) keeps the LAST of duplicated sample names
-    col_of = {nm: k for k, nm in enumerate(vcf_samples)}
-    sel_col = np.array([col_of[s] for s in samples], dtype=np.int32)
-    n_sel = len(samples)
-
-    # ---- genotype filters ----
-    gtf = [_parse_gtf(g) for g in args.gtf] if args.gtf else []
-    keep_alive = []
-    Farr = (_Filter * max(len(gtf), 1))()
-    for k, g in enumerate(gtf):
-        Farr[k].flag = g["flag"].encode()
-        Farr[k].min, Farr[k].max = g["min"], g["max"]
-        Farr[k].site_types = sum(SITE_TYPES.get(t, 0) for t in set(g.get("siteTypes", [])))     # a set: a repeated name is one bit
-        Farr[k].gt_types = sum(GT_TYPES.get(t, 0) for t in set(g.get("gtTypes", [])))
-        if "siteTypes" in g and Farr[k].site_types == 0:
-            Farr[k].site_types = 1 << 30                          # names that match no site type: the filter never applies
-        if "gtTypes" in g and Farr[k].gt_types == 0:
-            Farr[k].gt_types = 1 << 30
-        if "samples" in g:
-            m = np.array([1 if s in g["samples"] else 0 for s in samples], dtype=np.uint8)
-            keep_alive.append(m)
-            Farr[k].samples = m.ctypes.data
-    flags = ((1 if args.skipIndels else 0) | (2 if args.keepPartial else 0) | (4 if args.ploidyMismatchToMissing else 0) |
-             (8 if args.excludeDuplicates else 0))
-    contig_mode, contigs = 0, b""
-    if include and exclude:                                       # the reference applies both: keep included minus excluded
-        contig_mode, contigs = 1, "\n".join(sorted(set(include) - set(exclude))).encode()
-    elif include:
-        contig_mode, contigs = 1, "\n".join(sorted(set(include))).encode()
-    elif exclude:
-        contig_mode, contigs = 2, "\n".join(sorted(set(exclude))).encode()
+    plan = Plan(args, head[9:])
+    samples, n_sel, pl, missing = plan.samples, plan.n_sel, plan.pl, plan.missing
+    vcf_samples = plan.vcf_samples
 
     L = _lib.lib()
-    fn = L.pg_encode_vcf
-    fn.restype = C.c_int
     out = _open_out(args.outFile) if want_text else None
     sep = args.outSep.encode()
     if out is not None and not args.noHeader:
-        out.write(sep.join([b"#CHROM", b"POS"] + ([b"REF"] if args.addRefTrack else []) + [s.encode() for s in samples]) + b"\n")
+        out.write(plan.header_line())
     packer = genoio.PackedWriter(args.packed, samples, [int(p) for p in pl], args.packedCodec) if args.packed else None
     lut = np.zeros(256, dtype=np.uint8)
     for ch, code in zip(b"ACGT", (1, 2, 4, 8)):
@@ -592,73 +687,88 @@ def parse_vcf_main(argv=None):
     # three steps side by side: a reader thread (the next blocks: file pages, or BGZF members inflated by the library's host threads),
     # this thread (pg_encode_vcf + pg_vcf_render_rows, both on host threads) and a writer thread (BGZF deflate + write)
     sink = _AsyncOut(out) if out is not None else None
-    prev_chrom = prev_pos = None
-    n_multibase_total = 0
-    bufs = {}
+    state = {"prev_chrom": None, "prev_pos": None, "n_multibase": 0}
 
-    def arr(name, shape, dtype):
-        """arrays of the parser's outputs, kept from block to block (pg_encode_vcf writes every field of a kept row)"""
-        a = bufs.get(name)
-        if a is None or a.shape[0] < shape[0]:
-            a = bufs[name] = np.empty(shape, dtype=dtype)
-        return a
-
-    vp = lambda a: C.c_void_p(a.ctypes.data)
-    t0 = time.perf_counter()
-    try:
-        for body in _read_ahead(_text_blocks(reader, block_bytes, int(args.threads))):
-            t0 = lap("wait_for_block_s", t0)
-            ptr, nbytes, keep = _lib.text_ptr(body)
-            nl = C.c_int64(0)
-            check(L.pg_count_lines(ptr, nbytes, C.byref(nl)))
-            cap = int(nl.value) + 1
-            chars = arr("chars", (cap, 2 * n_sel), np.uint8)
-            aidx = arr("aidx", (cap, 2 * n_sel), np.int8)
-            phase = arr("phase", (cap, n_sel), np.uint8)
-            rflag = arr("rflag", (cap,), np.uint8)
-            pos = arr("pos", (cap,), np.int64)
-            coff, roff, aoff = arr("coff", (cap,), np.int64), arr("roff", (cap,), np.int64), arr("aoff", (cap,), np.int64)
-            clen, rlen, alen = arr("clen", (cap,), np.int32), arr("rlen", (cap,), np.int32), arr("alen", (cap,), np.int32)
-            n, nmb = C.c_int64(0), C.c_int64(0)
-            check(fn(ptr, C.c_size_t(nbytes), len(vcf_samples), n_sel, vp(sel_col), vp(pl),
-                     flags, C.c_double(float(args.minQual or 0)), int(args.maxREFlen or 0), Farr, len(gtf),
-                     C.c_char_p(contigs), len(contigs), contig_mode, C.c_char(missing.encode()),
-                     C.c_char_p(prev_chrom), len(prev_chrom or b""), C.c_char_p(prev_pos), len(prev_pos or b""),
-                     vp(chars), vp(aidx), vp(phase), vp(rflag), vp(pos), vp(coff), vp(clen), vp(roff), vp(rlen), vp(aoff), vp(alen),
-                     C.c_int64(cap), C.byref(n), C.byref(nmb), int(args.threads)))
-            t0 = lap("parse_s", t0)
-            k = int(n.value)
-            n_multibase_total += int(nmb.value)
+    def host_block(body):
+        """a block of text through the host parser: pg_encode_vcf + pg_vcf_render_rows on the host threads (+ the packed writer)"""
+        t0 = time.perf_counter()
+        ptr, nbytes, keep = _lib.text_ptr(body)
+        k, nmb, A = plan.host_parse(ptr, nbytes, state["prev_chrom"], state["prev_pos"], int(args.threads))
+        t0 = lap("parse_s", t0)
+        state["n_multibase"] += nmb
+        if args.excludeDuplicates:
             pc, pp = _last_key(body)
             if pc is not None:
-                prev_chrom, prev_pos = pc, pp
-            if k == 0:
-                del keep, body
-                t0 = time.perf_counter()
-                continue
-            if sink is not None:
-                # the rows as text (pg_vcf_render_rows: a sizing call, then the bytes)
-                size = C.c_int64(0)
-                rargs = (ptr, k, n_sel, vp(pl), vp(chars), vp(aidx), vp(phase), vp(rflag), vp(pos), vp(coff), vp(clen), vp(roff), vp(rlen),
-                         vp(aoff), vp(alen), C.c_char(sep), C.c_char(missing.encode()), 1 if args.addRefTrack else 0)
-                check(L.pg_vcf_render_rows(*rargs, None, 0, C.byref(size), int(args.threads)))
-                text = np.empty(size.value, dtype=np.uint8)
-                check(L.pg_vcf_render_rows(*rargs, vp(text), size.value, C.byref(size), int(args.threads)))
-                t0 = lap("render_s", t0)
+                state["prev_chrom"], state["prev_pos"] = pc, pp
+        if k == 0:
+            return
+        if sink is not None:
+            text = plan.host_render(ptr, k, A, int(args.threads))
+            t0 = lap("render_s", t0)
+            sink.write(text)
+            t0 = lap("wait_for_writer_s", t0)
+        if packer is not None:
+            chars, pos, coff, clen = A["chars"], A["pos"], A["coff"], A["clen"]
+            # scaffold runs of the kept rows (names are read once per run)
+            starts = np.zeros(k, dtype=np.int64)
+            nr = C.c_int64(0)
+            check(L.pg_scaffold_runs(ptr, coff, clen, k, starts, k, C.byref(nr)))
+            starts = starts[:nr.value]
+            run_names = [bytes(body[int(coff[i]):int(coff[i]) + int(clen[i])]) for i in starts]
+            cells = lut[chars[:k, 0::2]] | (lut[chars[:k, 1::2]] << 4)
+            packer.write_block(genoio.GenoData(None, pos[:k].copy(), starts.copy(), [nm.decode("utf-8", "replace") for nm in run_names]), cells)
+            lap("pack_s", t0)
+
+    def finish(pending):
+        """the rows of a block the device parsed -> the writer; a block with a line the device does not take -> the host parser"""
+        slot, raw, _keep = pending
+        t0 = time.perf_counter()
+        eng = _text_blocks.engine
+        nbytes, _rows, line = eng.vcf_collect(slot)
+        t0 = lap("device_wait_s", t0)
+        if line < 0:
+            if nbytes:
+                text = eng.vcf_rows(slot, nbytes)
+                t0 = lap("device_rows_s", t0)
                 sink.write(text)
-                t0 = lap("wait_for_writer_s", t0)
-            if packer is not None:
-                # scaffold runs of the kept rows (names are read once per run)
-                starts = np.zeros(k, dtype=np.int64)
-                nr = C.c_int64(0)
-                check(L.pg_scaffold_runs(ptr, coff, clen, k, starts, k, C.byref(nr)))
-                starts = starts[:nr.value]
-                run_names = [bytes(body[int(coff[i]):int(coff[i]) + int(clen[i])]) for i in starts]
-                cells = lut[chars[:k, 0::2]] | (lut[chars[:k, 1::2]] << 4)
-                packer.write_block(genoio.GenoData(None, pos[:k].copy(), starts.copy(), [nm.decode("utf-8", "replace") for nm in run_names]), cells)
-                t0 = lap("pack_s", t0)
-            del keep, body
+                lap("wait_for_writer_s", t0)
+            return
+        if timing is not None:
+            timing["blocks_handed_to_the_host_parser"] = timing.get("blocks_handed_to_the_host_parser", 0) + 1
+            timing.setdefault("first_line_handed_over", int(line))
+        host_block(eng.vcf_text(slot, len(raw)) if isinstance(raw, genoio.BgzfSpan) else raw)
+
+    # the device's parser takes text output without --packed (rows as text are what it makes)
+    dev_plan = plan if (sink is not None and packer is None) else None
+    t0 = time.perf_counter()
+    pending, slot = None, 0
+    try:
+        for body, where in _read_ahead(_text_blocks(reader, block_bytes, int(args.threads), dev_plan)):
+            t0 = lap("wait_for_block_s", t0)
+            if where is None:
+                if pending is not None:
+                    finish(pending)
+                    pending = None
+                host_block(body)
+            else:
+                # parse(k) is queued behind submit(k): while this thread waits for block k - 1 and hands its rows on, block k is
+                # copied / inflated; the kernels of k are queued as soon as its line count is back
+                eng = _text_blocks.engine
+                keep = eng.vcf_submit(slot, body, where or None)
+                t0 = lap("device_submit_s", t0)
+                if pending is not None:
+                    finish(pending)
+                t0 = time.perf_counter()
+                eng.vcf_parse(slot)
+                lap("device_parse_queue_s", t0)
+                pending = (slot, body, keep)
+                slot ^= 1
+            del body
             t0 = time.perf_counter()
+        if pending is not None:
+            finish(pending)
+            pending = None
+        n_multibase_total = state["n_multibase"]
     except BaseException:
         if sink is not None:                    # (the writer thread ends, whatever it had queued is dropped with the failed run)
             sink.abort()

@@ -275,6 +275,35 @@ int pg_vcf_render_rows(const char *buf, int64_t n_rows, int n_sel, const int32_t
                        const int32_t *alt_len, char sep, char missing, int add_ref, uint8_t *out, int64_t out_cap,
                        int64_t *out_len_out, int n_threads);
 
+/* ---- VCF lines -> `.geno` rows on the device (csrc/pg_vcf_dev.hip): pg_encode_vcf + pg_vcf_render_rows in one, for the regular
+ * spelling of a VCF line (single tabs, POS as plain digits, QUAL and the filtered FORMAT values as plain decimals of up to 15 digits,
+ * at most 16 alleles).  Replaces the same reference lines (VCF_processing/parseVCF.py:49-191, 367-370, 380-383).  A bgzipped VCF never
+ * crosses PCIe as text: k_inflate writes it into the tokenizer's text slot, only the rows come back.
+ *   pg_vcf_dev_config        the option set: pg_encode_vcf's arguments + the rows' separator and --addRefTrack.  *taken_out = 0 (with
+ *                            *why_out, a static string): an option set the device does not take (--excludeDuplicates, > 4 genotype
+ *                            filters, ...) -- the caller stays on pg_encode_vcf.
+ *   pg_vcf_dev_submit        a block of whole lines -> text slot `slot` (0 / 1): from memory, or len bytes at file_offset of fd
+ *   pg_vcf_dev_submit_bgzf   the same for a block of BGZF members (table: pg_bgzf_walk; head = text the caller holds in front of them,
+ *                            text_len = head + members cut behind the block's last line feed; line_len_hint = bytes of a typical line)
+ *   pg_vcf_dev_parse         queues k_vcf_heads / k_vcf_cells / k_vcf_scan on the block of `slot`
+ *   pg_vcf_dev_collect       waits for them.  *host_line_out < 0: *out_len_out bytes of rows (*n_rows_out rows) are ready for
+ *                            pg_vcf_dev_rows; else line *host_line_out of the block is one the device does not take (or the host
+ *                            parser would answer with an error): the BLOCK goes to pg_encode_vcf (pg_vcf_dev_text brings its text back
+ *                            when the host never had it)
+ * The ingestion loop of VCF_processing/parseVCF.py's drop-in runs   parse(k) -> submit(k+1) -> collect(k) -> rows(k). */
+int pg_vcf_dev_config(pg_ctx *ctx, int n_vcf_samples, int n_sel, const int32_t *sel_col, const int32_t *sel_ploidy, int flags,
+                      double min_qual, int max_ref_len, const pg_vcf_filter *filters, int n_filters, const char *contigs,
+                      int n_contig_bytes, int contig_mode, char missing, char sep, int add_ref, int *taken_out, const char **why_out);
+int pg_vcf_dev_submit(pg_ctx *ctx, int slot, const char *text, int fd, int64_t file_offset, int64_t len);
+int pg_vcf_dev_submit_bgzf(pg_ctx *ctx, int slot, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
+                           const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head, int64_t head_len,
+                           int64_t text_len, int64_t line_len_hint, int last_is_newline);
+int pg_vcf_dev_parse(pg_ctx *ctx, int slot);
+int pg_vcf_dev_collect(pg_ctx *ctx, int slot, int64_t *out_len_out, int64_t *n_rows_out, int64_t *host_line_out);
+int pg_vcf_dev_rows(pg_ctx *ctx, int slot, uint8_t *dst, int64_t len);
+int pg_vcf_dev_text(pg_ctx *ctx, int slot, uint8_t *dst, int64_t len);
+int pg_vcf_dev_stats(pg_ctx *ctx, int64_t *blocks_out, int64_t *host_blocks_out);
+
 /* freq.py's output rows (freq.py:98-113) formatted on all host threads: "scaffold\tposition\tcell\tcell...\n" per kept site.
  * mode 0: values = int32 [n][n_pops][4], cells "a,c,g,t"; mode 1: values = int64 [n][n_pops]; mode 2: values = double [n][n_pops]
  * printed as NumPy prints a double rounded to four decimals (nan, 0.0, 0.3333).  run_of_row[i] indexes the scaffold names

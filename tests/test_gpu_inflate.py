@@ -238,6 +238,7 @@ def test_bgzipped_vcf_inflated_on_the_device(name, src, argv, member, block, tmp
         f.write(genoio.bgzf_compress(text, 6, member).tobytes())
     out = str(tmp_path / "out.geno")
     monkeypatch.setenv("PG_VCF_WAIT_FOR_DEVICE", "1")             # (small files are over before the context exists: wait for it here)
+    monkeypatch.setenv("PG_VCF_DEVICE", "0")                      # (the host parser on device-inflated text; the device's parser: tests/test_gpu_vcf.py)
     assert vcf.parse_vcf_main(["-i", bg, "-o", out] + [a.format(dir=gold) for a in argv]) in (0, None)
     info = vcf._text_blocks.last_info
     assert info["bgzf"] and info["blocks"] >= 1

@@ -1,0 +1,174 @@
+"""VCF lines parsed on the device (csrc/pg_vcf_dev.hip: k_vcf_heads / k_vcf_cells / k_vcf_scan behind pg_vcf_dev_*) against the outputs
+of the UNMODIFIED reference parseVCF.py (tests/golden/vcf) and against the host parser (pg_encode_vcf + pg_vcf_render_rows): byte for
+byte, plain and bgzipped input, blocks of a few lines and whole files, lines the device hands to the host, thousands of sample
+columns."""
+import gzip
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from make_golden_vcf import VCF_CASES  # noqa: E402
+
+from genomics_general_amd import genoio, vcf  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden", "vcf")
+
+DEVICE_CASES = [c for c in VCF_CASES if not any(a in c[2] for a in ("--field", "--simplifyALT", "--expandMulti", "--excludeDuplicates")) and
+                not any(len(c[2][i + 1]) != 1 for i, a in enumerate(c[2]) if a in ("--missing", "--outSep"))]
+
+
+def _run(src, out, argv, env, monkeypatch, device="1"):
+    monkeypatch.setenv("PG_VCF_DEVICE", device)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rc = vcf.parse_vcf_main(["-i", src, "-o", out] + argv)
+    assert rc in (0, None)
+    info = dict(vcf._text_blocks.last_info)
+    eng = vcf._text_blocks.engine
+    info["stats"] = eng.vcf_stats() if (eng is not None and device == "1") else (0, 0)
+    with open(out, "rb") as f:
+        return f.read(), info
+
+
+@pytest.mark.parametrize("name,src,argv", DEVICE_CASES, ids=[c[0] for c in DEVICE_CASES])
+@pytest.mark.parametrize("form", ["plain", "plain_3000", "bgzf_700_3000", "bgzf_65280"])
+def test_goldens_through_the_device_parser(name, src, argv, form, tmp_path, monkeypatch):
+    with gzip.open(os.path.join(GOLD, src + ".vcf.gz"), "rb") as f:
+        text = f.read()
+    env = {}
+    if form.startswith("plain"):
+        path = str(tmp_path / "in.vcf")
+        with open(path, "wb") as f:
+            f.write(text)
+    else:
+        path = str(tmp_path / "in.vcf.gz")
+        with open(path, "wb") as f:
+            f.write(genoio.bgzf_compress(text, 6, int(form.split("_")[1])).tobytes())
+    if form.endswith("_3000"):
+        env["PG_STREAM_BYTES"] = "3000"
+    got, info = _run(path, str(tmp_path / "out.geno"), [a.format(dir=GOLD) for a in argv], env, monkeypatch)
+    with open(os.path.join(GOLD, name + ".geno"), "rb") as g:
+        assert got == g.read()
+    blocks, host_blocks = info["stats"]
+    # the goldens' files hold nothing the device hands over: every block it was given came back as rows
+    assert info["blocks_parsed_on_device"] >= 1 and blocks == info["blocks_parsed_on_device"] and host_blocks == 0, info
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_files_device_parser_equals_host_parser(seed, tmp_path, monkeypatch):
+    from genomics_general_amd._lib import PopgenError
+    from test_vcf import _fuzz_vcf
+    rng = np.random.default_rng(31000 + seed)
+    names, body, argv = _fuzz_vcf(rng, str(tmp_path))
+    head = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names).encode() + b"\n"
+    bgz = seed % 2 == 1
+    path = str(tmp_path / ("in.vcf.gz" if bgz else "in.vcf"))
+    with open(path, "wb") as f:
+        f.write(genoio.bgzf_compress(head + body, 6, 5000).tobytes() if bgz else head + body)
+    env = {"PG_STREAM_BYTES": str([2000, 20000, 1 << 27][seed % 3])}
+    try:
+        want, _ = _run(path, str(tmp_path / "host.geno"), argv, env, monkeypatch, device="0")
+    except PopgenError:
+        with pytest.raises(PopgenError):
+            _run(path, str(tmp_path / "dev.geno"), argv, env, monkeypatch)
+        return
+    got, info = _run(path, str(tmp_path / "dev.geno"), argv, env, monkeypatch)
+    assert got == want
+    assert info["blocks_parsed_on_device"] >= 1 and info["stats"][1] == 0, info
+
+
+def _bench_vcf(path, n_sites, n_samples):
+    import vcf_bench
+    return vcf_bench.write_vcf(path, n_sites, n_samples)
+
+
+@pytest.mark.parametrize("n_samples,argv", [
+    (50, ["--skipIndels", "--minQual", "30", "--gtf", "flag=DP", "min=8", "--gtf", "flag=GQ", "min=20"]),
+    (50, ["--gtf", "flag=AD", "min=2", "gtTypes=Het", "--addRefTrack", "--keepPartial"]),
+    (3, []),
+    (4000, ["--skipIndels", "-s", "ind0003,ind3999,ind0000,ind2048"]),          # two lines per block of the cells kernel
+    (9000, ["--gtf", "flag=GQ", "min=30"]),                                       # one line per block
+])
+def test_gatk_style_file_device_equals_host(n_samples, argv, tmp_path, monkeypatch):
+    """tools/vcf_bench.py's generator (GT:AD:DP:GQ, indels, tri-allelic sites, missing calls): plain and bgzipped, several blocks"""
+    n_sites = 30000 if n_samples <= 50 else 300
+    path = str(tmp_path / "in.vcf")
+    _bench_vcf(path, n_sites, n_samples)
+    if n_samples >= 4000:
+        with open(path, "rb") as f:
+            text = f.read()
+        # (the generator names its samples ind%03d)
+        names = text[text.index(b"#CHROM"):].split(b"\n", 1)[0].split(b"\t")[9:]
+        argv = [a if not a.startswith("ind") else ",".join(names[int(x[3:])].decode() for x in a.split(",")) for a in argv]
+    bgz = path + ".gz"
+    with open(path, "rb") as f, open(bgz, "wb") as g:
+        g.write(genoio.bgzf_compress(f.read(), 6, 65280).tobytes())
+    env = {"PG_STREAM_BYTES": str(8 << 20)}
+    want, _ = _run(path, str(tmp_path / "host.geno"), argv, env, monkeypatch, device="0")
+    for src in (path, bgz):
+        got, info = _run(src, str(tmp_path / "dev.geno"), argv, env, monkeypatch)
+        assert got == want, src
+        assert info["blocks_parsed_on_device"] >= 1 and info["stats"][1] == 0, info
+
+
+@pytest.mark.parametrize("what", ["crlf", "space", "pos_leading_zero", "qual_exponent", "no_final_newline", "seventeen_alleles", "wrong_ploidy"])
+def test_lines_the_device_does_not_take_go_to_the_host_parser(what, tmp_path, monkeypatch):
+    """one irregular line in the middle of a file of several blocks: that block comes out of the host parser, the others out of the
+    device's, and the output is the host parser's output of the whole file (an error where the host parser raises one)"""
+    from genomics_general_amd._lib import PopgenError
+    with gzip.open(os.path.join(GOLD, "main.vcf.gz"), "rb") as f:
+        lines = f.read().split(b"\n")
+    first = next(i for i, ln in enumerate(lines) if ln and not ln.startswith(b"#"))
+    k = first + 150
+    f_ = lines[k].split(b"\t")
+    argv = ["--skipIndels", "--minQual", "10"]
+    if what == "crlf":
+        lines[k] += b"\r"
+    elif what == "space":
+        lines[k] = lines[k].replace(b"\t", b" ", 1)
+    elif what == "pos_leading_zero":
+        f_[1] = b"00" + f_[1]
+        lines[k] = b"\t".join(f_)
+    elif what == "qual_exponent":
+        f_[5] = b"1e2"
+        lines[k] = b"\t".join(f_)
+    elif what == "no_final_newline":
+        while lines and not lines[-1]:
+            lines.pop()
+    elif what == "seventeen_alleles":
+        f_[3], f_[4] = b"A", b",".join([b"C", b"G", b"T", b"AA"] * 4)
+        lines[k] = b"\t".join(f_)
+        argv = []
+    elif what == "wrong_ploidy":
+        f_[9] = b"0/1/1" + f_[9][3:]
+        lines[k] = b"\t".join(f_)
+    path = str(tmp_path / "in.vcf")
+    with open(path, "wb") as f:
+        f.write(b"\n".join(lines))
+    env = {"PG_STREAM_BYTES": "6000"}
+    if what == "wrong_ploidy":
+        for dev in ("0", "1"):
+            with pytest.raises(PopgenError, match="ploidy"):
+                _run(path, str(tmp_path / "x.geno"), argv, env, monkeypatch, device=dev)
+        return
+    want, _ = _run(path, str(tmp_path / "host.geno"), argv, env, monkeypatch, device="0")
+    got, info = _run(path, str(tmp_path / "dev.geno"), argv, env, monkeypatch)
+    assert got == want
+    blocks, host_blocks = info["stats"]
+    assert host_blocks == 1 and blocks >= 3, info
+
+
+def test_option_sets_the_device_does_not_take_stay_on_the_host(tmp_path, monkeypatch):
+    src = str(tmp_path / "in.vcf.gz")
+    with gzip.open(os.path.join(GOLD, "main.vcf.gz"), "rb") as f, open(src, "wb") as g:
+        g.write(genoio.bgzf_compress(f.read(), 6, 3000).tobytes())
+    got, info = _run(src, str(tmp_path / "o.geno"), ["--skipIndels", "--excludeDuplicates"], {"PG_VCF_WAIT_FOR_DEVICE": "1"}, monkeypatch)
+    want, _ = _run(src, str(tmp_path / "h.geno"), ["--skipIndels", "--excludeDuplicates"], {}, monkeypatch, device="0")
+    assert got == want and info["blocks_parsed_on_device"] == 0 and "excludeDuplicates" in info.get("device_parser_not_taken", "")
