@@ -99,7 +99,10 @@ SIGNATURES = {
     "pg_vcf_dev_submit_bgzf": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "pg_vcf_dev_parse": (C.c_int, [_P, C.c_int]),
-    "pg_vcf_dev_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pg_vcf_dev_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pg_vcf_dev_set_output": (C.c_int, [_P, C.c_int]),
+    "pg_vcf_dev_rows_bgzf": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int64]),
+    "pg_bgzf_compress_device": (C.c_int, [_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pg_vcf_dev_rows": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int64]),
     "pg_vcf_dev_text": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int64]),
     "pg_vcf_dev_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

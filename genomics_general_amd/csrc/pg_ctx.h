@@ -148,6 +148,15 @@ struct pg_ctx {
         int64_t len = 0, n_lines = 0, n_tiles = 0, run_cap = 0;
         int64_t n_members = 0, head_len = 0;   // (a block that arrived deflated)
     } tok[2];
+    // text deflated on the device (pg_deflate.hip): token buffers of the persistent waves, the members' streams, sizes and CRC-32s, the
+    // assembled BGZF members
+    struct Deflate {
+        DevBuf<uint32_t> tok, out_len, crc;
+        DevBuf<uint8_t> slots, comp, text;      // text: pg_bgzf_compress_device only
+        DevBuf<int64_t> totals;                 // [0] bytes of text, [1] bytes of the members
+        HostPin<int64_t> h_totals;
+        void release() { tok.release(); out_len.release(); crc.release(); slots.release(); comp.release(); text.release(); totals.release(); h_totals.release(); }
+    } deflate;
     // VCF lines parsed on the device (pg_vcf_dev.hip): the option set of the run and, per text slot of the tokenizer, the per-line
     // records, the rows' sizes and places, the rows' text
     struct VcfDev {
@@ -160,13 +169,15 @@ struct pg_ctx {
         struct Slot {
             DevBuf<uint8_t> lines, out;
             DevBuf<uint32_t> rlen;
-            DevBuf<int64_t> roff, status;        // status: [0] bits (1 a line needs the host, 2 the rows exceed `out`), [1] first such line, [2] bytes of the rows, [3] rows
+            DevBuf<int64_t> roff, status;        // status: [0] bits (1 a line needs the host, 2 the rows exceed `out`), [1] first such line, [2] bytes of the rows, [3] rows, [4] bytes of the rows as BGZF members
+            Deflate df;                          // the rows deflated where they lie (pg_vcf_dev_set_output)
             HostPin<int64_t> h_status;
             hipEvent_t done = nullptr;
             int state = 0;                       // 0 idle, 1 text on its way / there, 2 kernels queued, 3 empty block
             int64_t text_len = 0, out_cap = 0;
             bool no_final_newline = false;
         } s[2];
+        bool bgzf_rows = false;                  // pg_vcf_dev_set_output: the rows leave the device as BGZF members
         double kernel_ms = 0;                    // pg_vcf_dev_stats
         int64_t blocks = 0, host_blocks = 0;
     } vcf;

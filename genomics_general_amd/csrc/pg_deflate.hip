@@ -1,0 +1,588 @@
+// DEFLATE on the device: text that lies in HBM -> BGZF members (`-o out.geno.gz` of the VCF drop-in, whose rows are made on the device:
+// `parseVCF.py ... | bgzip`, VCF_processing/README.md:33; popgenWindows.py:316) -- the counterpart of k_inflate.  The host's
+// compressor (pg_fast_deflate.h) was what the drop-in waited for once the device parsed the VCF (1.5 of 2.2 s on 16 CPUs).
+//
+//   k_deflate        a wavefront per member of 65 280 bytes of text (persistent: a wave takes member after member).
+//     matches        64 positions at a time, a lane each: the four bytes at the position are hashed into one of 2048 buckets of the
+//                    EIGHT most recent places with that hash (LDS, 32 KB a wave) -- text written row by row repeats its cells so often
+//                    that a bucket's depth, not the number of buckets, decides the ratio (measured on `.geno` rows: depth 4 / 8 / 16
+//                    = 84 / 90 / 94 % of zlib level 6's ratio) -- plus the nearest earlier lane of the window with the same four bytes;
+//                    every candidate is compared over sixteen bytes (two 8-byte loads from the text in HBM / L2), the best one kept.
+//                    Then the window is walked from its first uncovered position: a literal run up to the next lane with a match goes
+//                    out in one step (all lanes), a match of the full sixteen bytes is first extended by the WHOLE wave (lane k
+//                    compares dword k of candidate and text: up to 256 bytes in one step).  The window's positions enter their buckets
+//                    in order without a serial loop: a lane's rank among the lanes of its bucket (64 readlanes) is its slot.
+//     codes          one dynamic Huffman block per member: the frequencies are counted in LDS while the tokens are made; lane 0
+//                    builds the length-limited codes and the block header as the host's compressor does (two-queue merge, miniz-style
+//                    bound, run-length coded code lengths); a member whose coded size would reach its text's is stored.
+//     bits           64 tokens at a time: code + extra bits of a token form one value of up to 48 bits, a wave scan of the bit counts
+//                    gives its place, the lanes OR their pieces into a window in LDS, whole dwords leave for HBM.
+//   k_crc32_pieces   (pg_inflate.hip) the members' CRC-32
+//   k_bgzf_assemble  gzip header + BC field, the deflated bytes, CRC-32 and size of every member, one behind the other
+// Its output is any inflater's input (tests: zlib, k_inflate); it does not try to be zlib's bytes.
+#include "pg_ctx.h"
+
+#include <algorithm>
+#include <vector>
+
+int pg_launch_crc32_pieces(pg_ctx *c, hipStream_t st, const uint8_t *text, const long long *total_d, uint32_t piece, int64_t max_pieces,
+                           uint32_t *crc_out);
+
+namespace {
+
+constexpr int DF_W = 8;                       // places per bucket
+constexpr int DF_HB = 11;                     // 2048 buckets
+constexpr uint32_t DF_PIECE = 65280;          // text per member (bgzip's)
+constexpr uint32_t DF_SLOT = 65536;           // bytes a member's deflate stream may take (stored: text + 5)
+constexpr uint32_t DF_MAXL = 256;             // longest match (the format's 258 would need a 65th dword in the wave's compare)
+
+struct DfShared {
+    uint32_t bucket[(1 << DF_HB) * DF_W / 2];
+    uint32_t freq_ll[288], freq_d[32];
+    uint16_t code_ll[288], code_d[32];
+    uint8_t len_ll[288], len_d[32];
+    uint32_t win[112];                        // the bits of a batch of tokens on their way out
+    uint32_t hdr[192];                        // the block header's bits
+    // lane 0's work space for the codes
+    uint32_t w[576];
+    uint16_t parent[576], sym[288];
+    uint8_t depth[576];
+    uint8_t seq[320], cl_sym[320], cl_extra[320];
+    uint32_t freq_cl[19];
+    uint8_t len_cl[19];
+    uint16_t code_cl[19];
+    int count[64];
+    uint32_t next[16];
+};
+
+__device__ inline uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ inline uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ inline uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ inline uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// length 3 .. 257 -> (index of its length symbol, number of extra bits, their value); distance likewise
+__device__ inline void len_code(uint32_t len, uint32_t *idx, uint32_t *eb, uint32_t *ev) {
+    const uint32_t l3 = len - 3;
+    if (l3 < 8) { *idx = l3; *eb = 0; *ev = 0; return; }
+    const uint32_t nb = 31u - (uint32_t)__clz((int)l3), e = nb - 2;
+    *idx = 8 + 4 * (e - 1) + ((l3 - (1u << nb)) >> e);
+    *eb = e;
+    *ev = l3 & ((1u << e) - 1u);
+}
+__device__ inline void dist_code(uint32_t dist, uint32_t *idx, uint32_t *eb, uint32_t *ev) {
+    const uint32_t d1 = dist - 1;
+    if (d1 < 4) { *idx = d1; *eb = 0; *ev = 0; return; }
+    const uint32_t nb = 31u - (uint32_t)__clz((int)d1), e = nb - 1;
+    *idx = 2 * nb + ((d1 >> e) & 1u);
+    *eb = e;
+    *ev = d1 & ((1u << e) - 1u);
+}
+__device__ inline uint32_t len_extra_of(int idx) { return idx < 8 || idx >= 28 ? 0u : (uint32_t)((idx - 4) >> 2); }
+__device__ inline uint32_t dist_extra_of(int idx) { return idx < 4 ? 0u : (uint32_t)((idx - 2) >> 1); }
+
+// ---- lane 0: the codes (pg_fast_deflate.h's code_lengths / make_codes, with their work arrays in LDS) ----
+__device__ void df_code_lengths(const uint32_t *freq, int n, int max_bits, uint8_t *lens, DfShared &sh) {
+    int m = 0;
+    for (int s = 0; s < n; ++s) {
+        lens[s] = 0;
+        if (freq[s]) {
+            // insertion into the leaves sorted by (frequency, symbol)
+            int k = m++;
+            const uint32_t f = freq[s];
+            while (k > 0 && sh.w[k - 1] > f) {
+                sh.w[k] = sh.w[k - 1];
+                sh.sym[k] = sh.sym[k - 1];
+                --k;
+            }
+            sh.w[k] = f;
+            sh.sym[k] = (uint16_t)s;
+        }
+    }
+    if (m == 0) return;
+    if (m == 1) { lens[sh.sym[0]] = 1; return; }
+    int a = 0, b = m, made = m;
+    while (made < 2 * m - 1) {
+        int x, y;
+        if (a < m && (b >= made || sh.w[a] <= sh.w[b])) x = a++; else x = b++;
+        if (a < m && (b >= made || sh.w[a] <= sh.w[b])) y = a++; else y = b++;
+        sh.w[made] = sh.w[x] + sh.w[y];
+        sh.parent[x] = sh.parent[y] = (uint16_t)made;
+        ++made;
+    }
+    for (int i = 0; i < 64; ++i) sh.count[i] = 0;
+    sh.depth[2 * m - 2] = 0;
+    for (int i = 2 * m - 3; i >= 0; --i) {
+        const int d = sh.depth[sh.parent[i]] + 1;
+        sh.depth[i] = (uint8_t)(d < 63 ? d : 63);
+        if (i < m) ++sh.count[sh.depth[i]];
+    }
+    for (int i = max_bits + 1; i < 64; ++i) {
+        sh.count[max_bits] += sh.count[i];
+        sh.count[i] = 0;
+    }
+    unsigned long long total = 0;
+    for (int i = max_bits; i >= 1; --i) total += (unsigned long long)sh.count[i] << (max_bits - i);
+    while (total != (1ull << max_bits)) {
+        --sh.count[max_bits];
+        for (int i = max_bits - 1; i >= 1; --i)
+            if (sh.count[i]) {
+                --sh.count[i];
+                sh.count[i + 1] += 2;
+                break;
+            }
+        --total;
+    }
+    int at = 0;
+    for (int l = max_bits; l >= 1; --l)
+        for (int k = 0; k < sh.count[l]; ++k) lens[sh.sym[at++]] = (uint8_t)l;
+}
+
+__device__ void df_make_codes(const uint8_t *lens, int n, uint16_t *codes, DfShared &sh) {
+    for (int l = 0; l < 16; ++l) sh.count[l] = 0;
+    for (int s = 0; s < n; ++s) ++sh.count[lens[s]];
+    sh.count[0] = 0;
+    uint32_t code = 0;
+    for (int l = 1; l <= 15; ++l) {
+        code = (code + (uint32_t)sh.count[l - 1]) << 1;
+        sh.next[l] = code;
+    }
+    for (int s = 0; s < n; ++s) {
+        const int l = lens[s];
+        if (!l) { codes[s] = 0; continue; }
+        const uint32_t c = sh.next[l]++;
+        codes[s] = (uint16_t)(__brev(c) >> (32 - l));
+    }
+}
+
+struct HdrBits {
+    uint32_t *p;
+    unsigned long long acc;
+    int n, words;
+    __device__ void put(uint32_t v, int bits) {
+        acc |= (unsigned long long)v << n;
+        n += bits;
+        if (n >= 32) {
+            p[words++] = (uint32_t)acc;
+            acc >>= 32;
+            n -= 32;
+        }
+    }
+};
+
+// lane 0: codes from the frequencies, the block header's bits into sh.hdr; returns the bits of the header, *total_bits the whole stream's
+__device__ uint32_t df_codes_and_header(DfShared &sh, unsigned long long *total_bits) {
+    sh.freq_ll[256] = 1;
+    df_code_lengths(sh.freq_ll, 286, 15, sh.len_ll, sh);
+    df_code_lengths(sh.freq_d, 30, 15, sh.len_d, sh);
+    {
+        int used = 0;
+        for (int s = 0; s < 286; ++s) used += sh.len_ll[s] != 0;
+        if (used < 2) sh.len_ll[sh.len_ll[0] ? 1 : 0] = 1;      // (a complete code needs two symbols)
+        used = 0;
+        for (int s = 0; s < 30; ++s) used += sh.len_d[s] != 0;
+        if (used == 0) sh.len_d[0] = 1;                          // (no match at all: one unused distance code of one bit)
+    }
+    sh.len_ll[286] = sh.len_ll[287] = 0;
+    df_make_codes(sh.len_ll, 286, sh.code_ll, sh);
+    df_make_codes(sh.len_d, 30, sh.code_d, sh);
+    int hlit = 286, hdist = 30;
+    while (hlit > 257 && !sh.len_ll[hlit - 1]) --hlit;
+    while (hdist > 1 && !sh.len_d[hdist - 1]) --hdist;
+    const int total = hlit + hdist;
+    for (int k = 0; k < hlit; ++k) sh.seq[k] = sh.len_ll[k];
+    for (int k = 0; k < hdist; ++k) sh.seq[hlit + k] = sh.len_d[k];
+    int ncl = 0;
+    for (int s = 0; s < 19; ++s) sh.freq_cl[s] = 0;
+    for (int k = 0; k < total;) {                               // the code lengths, run-length coded (RFC 1951, 3.2.7)
+        int run = 1;
+        while (k + run < total && sh.seq[k + run] == sh.seq[k]) ++run;
+        if (sh.seq[k] == 0 && run >= 3) {
+            const int r = run < 138 ? run : 138;
+            sh.cl_sym[ncl] = (uint8_t)(r <= 10 ? 17 : 18);
+            sh.cl_extra[ncl] = (uint8_t)(r <= 10 ? r - 3 : r - 11);
+            ++sh.freq_cl[sh.cl_sym[ncl++]];
+            k += r;
+        } else if (sh.seq[k] != 0 && run >= 4) {
+            sh.cl_sym[ncl] = sh.seq[k];
+            sh.cl_extra[ncl] = 0;
+            ++sh.freq_cl[sh.cl_sym[ncl++]];
+            const int r = run - 1 < 6 ? run - 1 : 6;
+            sh.cl_sym[ncl] = 16;
+            sh.cl_extra[ncl] = (uint8_t)(r - 3);
+            ++sh.freq_cl[16];
+            ++ncl;
+            k += 1 + r;
+        } else {
+            sh.cl_sym[ncl] = sh.seq[k];
+            sh.cl_extra[ncl] = 0;
+            ++sh.freq_cl[sh.cl_sym[ncl++]];
+            ++k;
+        }
+    }
+    df_code_lengths(sh.freq_cl, 19, 7, sh.len_cl, sh);
+    {
+        int used = 0;
+        for (int s = 0; s < 19; ++s) used += sh.len_cl[s] != 0;
+        if (used < 2) sh.len_cl[sh.len_cl[0] ? 1 : 0] = 1;
+    }
+    df_make_codes(sh.len_cl, 19, sh.code_cl, sh);
+    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int hclen = 19;
+    while (hclen > 4 && !sh.len_cl[order[hclen - 1]]) --hclen;
+    HdrBits hb{sh.hdr, 0ull, 0, 0};
+    hb.put(1u | (2u << 1), 3);                                   // BFINAL, dynamic
+    hb.put((uint32_t)(hlit - 257), 5);
+    hb.put((uint32_t)(hdist - 1), 5);
+    hb.put((uint32_t)(hclen - 4), 4);
+    for (int k = 0; k < hclen; ++k) hb.put(sh.len_cl[order[k]], 3);
+    for (int k = 0; k < ncl; ++k) {
+        const int s = sh.cl_sym[k];
+        hb.put(sh.code_cl[s], sh.len_cl[s]);
+        if (s == 16) hb.put(sh.cl_extra[k], 2);
+        else if (s == 17) hb.put(sh.cl_extra[k], 3);
+        else if (s == 18) hb.put(sh.cl_extra[k], 7);
+    }
+    const uint32_t hdr_bits = (uint32_t)hb.words * 32u + (uint32_t)hb.n;
+    sh.hdr[hb.words] = (uint32_t)hb.acc;                         // the unfinished dword
+    unsigned long long bits = hdr_bits;
+    for (int s = 0; s < 286; ++s) bits += (unsigned long long)sh.freq_ll[s] * (sh.len_ll[s] + (s >= 257 ? len_extra_of(s - 257) : 0u));
+    for (int s = 0; s < 30; ++s) bits += (unsigned long long)sh.freq_d[s] * (sh.len_d[s] + dist_extra_of(s));
+    *total_bits = bits;
+    return hdr_bits;
+}
+
+__device__ inline int wave_incl_scan_u(int x, int lane) {
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+// in[0 .. n) -> one raw deflate stream (final block) at out (DF_SLOT bytes); returns its length (every lane)
+__device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ out, uint32_t *__restrict__ tok, DfShared &sh, int lane) {
+    auto stored = [&]() -> uint32_t {
+        if (lane == 0) {
+            out[0] = 1;
+            out[1] = (uint8_t)(n & 255); out[2] = (uint8_t)(n >> 8);
+            out[3] = (uint8_t)(~n & 255); out[4] = (uint8_t)((~n >> 8) & 255);
+        }
+        for (uint32_t k = (uint32_t)lane; k < n; k += 64) out[5 + k] = in[k];
+        return n + 5;
+    };
+    if (n < 16) return stored();
+    for (int k = lane; k < (1 << DF_HB) * DF_W / 2; k += 64) sh.bucket[k] = 0;
+    for (int k = lane; k < 288; k += 64) sh.freq_ll[k] = 0;
+    if (lane < 32) sh.freq_d[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- matches ----
+    uint32_t nt = 0, pos = 0;
+    for (uint32_t w0 = 0; w0 < n; w0 += 64) {
+        const uint32_t p = w0 + (uint32_t)lane;
+        const bool inb = p + 4 <= n;
+        const uint32_t maxl = inb ? (n - p < DF_MAXL ? n - p : DF_MAXL) : 0u;
+        uint64_t a0 = 0, a1 = 0;
+        if (p < n) { a0 = ld64(in + p); a1 = ld64(in + p + 8); }          // (the text's buffer is readable 32 bytes past its end)
+        const uint32_t v = (uint32_t)a0;
+        const uint32_t h = inb ? (v * 2654435761u) >> (32 - DF_HB) : 0x80000000u | (uint32_t)lane;
+        uint4 bk = make_uint4(0, 0, 0, 0);
+        if (inb) bk = *reinterpret_cast<const uint4 *>(&sh.bucket[h * (DF_W / 2)]);
+        int rank = 0, gsize = 0, close = -1;
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t hj = rl(h, j), vj = rl(v, j);
+            const bool e = hj == h;
+            gsize += e ? 1 : 0;
+            rank += (e && j < lane) ? 1 : 0;
+            if (vj == v && j < lane) close = j;
+        }
+        const uint32_t wend = w0 + 64 < n ? w0 + 64 : n;
+        const bool need = pos < wend;                             // (a window inside a long match only enters its buckets)
+        uint32_t bestL = 0, bestD = 0, capmask = 0;
+        const uint32_t q1s[9] = {bk.x & 0xffffu, bk.x >> 16, bk.y & 0xffffu, bk.y >> 16, bk.z & 0xffffu, bk.z >> 16, bk.w & 0xffffu, bk.w >> 16,
+                                 close >= 0 ? w0 + (uint32_t)close + 1u : 0u};
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const uint32_t q1 = q1s[c];
+            const bool ok = need && inb && q1 != 0 && p - (q1 - 1) <= 32768u;
+            if (ok) {
+                const uint32_t q = q1 - 1, d = p - q;
+                const uint64_t m0 = ld64(in + q) ^ a0;
+                uint32_t L;
+                if (m0) L = (uint32_t)(__ffsll((long long)m0) - 1) >> 3;
+                else {
+                    const uint64_t m1 = ld64(in + q + 8) ^ a1;
+                    L = m1 ? 8u + ((uint32_t)(__ffsll((long long)m1) - 1) >> 3) : 16u;
+                }
+                if (L > maxl) L = maxl;
+                if (L >= 4 && (L > bestL || (L == bestL && d < bestD))) { bestL = L; bestD = d; }
+                if (L == 16 && maxl > 16) capmask |= 1u << c;
+            }
+        }
+        // ---- the window's tokens, from its first uncovered position ----
+        while (pos < wend) {
+            const int l = (int)(pos - w0);
+            const uint32_t L = rl(bestL, l);
+            if (L < 4) {
+                const unsigned long long mm = __builtin_amdgcn_ballot_w64(bestL >= 4) >> l;
+                uint32_t run = mm ? (uint32_t)(__ffsll((long long)mm) - 1) : 64u;
+                if (run > wend - pos) run = wend - pos;
+                if ((uint32_t)lane >= (uint32_t)l && (uint32_t)lane < (uint32_t)l + run) {
+                    const uint32_t byte = (uint32_t)(a0 & 0xffu);
+                    tok[nt + (uint32_t)(lane - l)] = byte;
+                    atomicAdd(&sh.freq_ll[byte], 1u);
+                }
+                nt += run;
+                pos += run;
+            } else {
+                uint32_t mL = L, mD = rl(bestD, l);
+                const uint32_t caps = rl(capmask, l);
+                if (caps) {
+                    // the candidates that matched all sixteen bytes: the whole wave compares 256 bytes of each
+                    const uint32_t lim = rl(maxl, l);
+                    const bool cmp = 4u * (uint32_t)lane < lim;    // (nothing is read behind the member's last dword)
+                    uint32_t mine = 0;
+                    if (cmp) mine = ld32(in + pos + 4u * (uint32_t)lane);
+                    mL = 0;
+                    for (uint32_t cm = caps; cm; cm &= cm - 1) {
+                        const int c = __ffs((int)cm) - 1;
+                        uint32_t q1 = 0;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k)
+                            if (k == c) q1 = rl(q1s[k], l);
+                        const uint32_t q = q1 - 1, d = pos - q;
+                        uint32_t x = 1;
+                        if (cmp) x = ld32(in + q + 4u * (uint32_t)lane) ^ mine;
+                        const unsigned long long ne = __builtin_amdgcn_ballot_w64(x != 0);
+                        uint32_t len = 256;
+                        if (ne) {
+                            const int k0 = __ffsll((long long)ne) - 1;
+                            len = 4u * (uint32_t)k0 + ((uint32_t)(__ffs((int)rl(x, k0)) - 1) >> 3);
+                        }
+                        if (len > lim) len = lim;
+                        if (len > mL || (len == mL && d < mD)) { mL = len; mD = d; }
+                    }
+                }
+                if (lane == 0) {
+                    tok[nt] = 0x80000000u | ((mL - 3) << 16) | (mD - 1);
+                    uint32_t idx, eb, ev;
+                    len_code(mL, &idx, &eb, &ev);
+                    atomicAdd(&sh.freq_ll[257 + idx], 1u);
+                    dist_code(mD, &idx, &eb, &ev);
+                    atomicAdd(&sh.freq_d[idx], 1u);
+                }
+                ++nt;
+                pos += mL;
+            }
+        }
+        // ---- the window's positions into their buckets, most recent first: a lane's rank among the lanes of its bucket is its slot ----
+        if (inb) {
+            uint16_t *b16 = reinterpret_cast<uint16_t *>(&sh.bucket[h * (DF_W / 2)]);
+            const int slot = gsize - 1 - rank;
+            if (slot < DF_W) b16[slot] = (uint16_t)(p + 1);
+            if (rank == gsize - 1 && gsize < DF_W) {                 // the group's last lane moves the old places back
+                const uint32_t old[8] = {bk.x & 0xffffu, bk.x >> 16, bk.y & 0xffffu, bk.y >> 16, bk.z & 0xffffu, bk.z >> 16, bk.w & 0xffffu, bk.w >> 16};
+#pragma unroll
+                for (int k = 0; k < DF_W; ++k)
+                    if (k + gsize < DF_W) b16[k + gsize] = (uint16_t)old[k];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane == 0) tok[nt] = 256;                                // end of block, a token like the others
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- codes ----
+    unsigned long long total_bits = 0;
+    uint32_t hdr_bits = 0;
+    if (lane == 0) hdr_bits = df_codes_and_header(sh, &total_bits);
+    hdr_bits = rfl(hdr_bits);
+    const uint32_t tb_lo = rfl((uint32_t)total_bits), tb_hi = rfl((uint32_t)(total_bits >> 32));
+    total_bits = ((unsigned long long)tb_hi << 32) | tb_lo;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if ((total_bits + 7) / 8 >= (unsigned long long)n + 5) return stored();
+    // ---- bits ----
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    uint32_t wbase = hdr_bits >> 5;                              // dwords of the stream that have left
+    for (uint32_t k = (uint32_t)lane; k < wbase; k += 64) out32[k] = sh.hdr[k];
+    for (int k = lane; k < 112; k += 64) sh.win[k] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) sh.win[0] = sh.hdr[wbase];
+    uint32_t obit = hdr_bits;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (uint32_t k0 = 0; k0 <= nt; k0 += 64) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        unsigned long long val = 0;
+        int nb = 0;
+        if (k <= nt) {
+            const uint32_t t = tok[k];
+            if (!(t & 0x80000000u)) {
+                val = sh.code_ll[t];
+                nb = sh.len_ll[t];
+            } else {
+                const uint32_t len = ((t >> 16) & 0x7fffu) + 3, dist = (t & 0xffffu) + 1;
+                uint32_t li, leb, lev, di, deb, dev;
+                len_code(len, &li, &leb, &lev);
+                dist_code(dist, &di, &deb, &dev);
+                val = sh.code_ll[257 + li];
+                nb = sh.len_ll[257 + li];
+                val |= (unsigned long long)lev << nb;
+                nb += (int)leb;
+                val |= (unsigned long long)sh.code_d[di] << nb;
+                nb += sh.len_d[di];
+                val |= (unsigned long long)dev << nb;
+                nb += (int)deb;
+            }
+        }
+        const int incl = wave_incl_scan_u(nb, lane);
+        const uint32_t total = (uint32_t)__shfl(incl, 63, 64);
+        if (nb) {
+            const uint32_t rel = obit + (uint32_t)(incl - nb) - wbase * 32u;
+            const uint32_t wi = rel >> 5, sft = rel & 31u;
+            atomicOr(&sh.win[wi], (uint32_t)(val << sft));
+            if (sft + (uint32_t)nb > 32) atomicOr(&sh.win[wi + 1], (uint32_t)(sft ? val >> (32 - sft) : val >> 32));
+            if (sft + (uint32_t)nb > 64) atomicOr(&sh.win[wi + 2], (uint32_t)(val >> (64 - sft)));
+        }
+        obit += total;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t full = (obit >> 5) - wbase;               // whole dwords of the window
+        uint32_t carry = 0, mine0 = 0, mine1 = 0;
+        if ((uint32_t)lane < full) mine0 = sh.win[lane];
+        if ((uint32_t)lane + 64 < full) mine1 = sh.win[lane + 64];
+        carry = sh.win[full];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if ((uint32_t)lane < full) out32[wbase + (uint32_t)lane] = mine0;
+        if ((uint32_t)lane + 64 < full) out32[wbase + (uint32_t)lane + 64] = mine1;
+        for (int j = lane; j < 112; j += 64) sh.win[j] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) sh.win[0] = carry;
+        wbase += full;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane == 0 && (obit & 31u)) out32[wbase] = sh.win[0];
+    return (obit + 7) >> 3;
+}
+
+// status_p (may be null): a nonzero word there cancels the work (the VCF kernels raised it: the block goes to the host).
+// tok_all: 65 536 + 64 dwords per block of the grid; out_all: DF_SLOT bytes per member; out_len[m]: its deflate stream's bytes
+__global__ __launch_bounds__(64) void k_deflate(const uint8_t *__restrict__ text, const long long *__restrict__ total_p, const long long *__restrict__ status_p,
+                                                uint32_t *__restrict__ tok_all, uint8_t *__restrict__ out_all, uint32_t *__restrict__ out_len) {
+    __shared__ DfShared sh;
+    const int lane = (int)threadIdx.x;
+    if (status_p && status_p[0] != 0) return;
+    const long long total = *total_p;
+    const long long n_members = (total + DF_PIECE - 1) / DF_PIECE;
+    uint32_t *tok = tok_all + (size_t)blockIdx.x * (65536 + 64);
+    for (long long m = blockIdx.x; m < n_members; m += gridDim.x) {
+        const long long left = total - m * DF_PIECE;
+        const uint32_t n = (uint32_t)(left < DF_PIECE ? left : DF_PIECE);
+        const uint32_t got = df_member(text + m * DF_PIECE, n, out_all + (size_t)m * DF_SLOT, tok, sh, lane);
+        if (lane == 0) out_len[m] = got;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// the members one behind the other at dst: gzip header with the BC field, the deflate stream, CRC-32, size; *comp_total = their bytes
+__global__ __launch_bounds__(64) void k_bgzf_assemble(const long long *__restrict__ total_p, const long long *__restrict__ status_p,
+                                                      const uint8_t *__restrict__ out_all, const uint32_t *__restrict__ out_len,
+                                                      const uint32_t *__restrict__ crc, uint8_t *__restrict__ dst, long long *__restrict__ comp_total) {
+    const int lane = (int)threadIdx.x;
+    if (status_p && status_p[0] != 0) {
+        if (blockIdx.x == 0 && lane == 0) *comp_total = 0;
+        return;
+    }
+    const long long total = *total_p;
+    const long long n_members = (total + DF_PIECE - 1) / DF_PIECE;
+    if (n_members == 0 && blockIdx.x == 0 && lane == 0) *comp_total = 0;
+    for (long long m = blockIdx.x; m < n_members; m += gridDim.x) {
+        long long at = 0;
+        for (long long k = lane; k < m; k += 64) at += (long long)out_len[k] + 26;
+        for (int d = 32; d >= 1; d >>= 1) at += __shfl_xor(at, d, 64);
+        const uint32_t n = out_len[m], size = n + 26;
+        const long long left = total - m * DF_PIECE;
+        const uint32_t isize = (uint32_t)(left < DF_PIECE ? left : DF_PIECE);
+        uint8_t *o = dst + at;
+        if (lane < 18) {
+            const uint8_t hd[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)((size - 1) & 255), (uint8_t)((size - 1) >> 8)};
+            o[lane] = hd[lane];
+        }
+        const uint8_t *src = out_all + (size_t)m * DF_SLOT;
+        for (uint32_t k = (uint32_t)lane; k < n; k += 64) o[18 + k] = src[k];
+        if (lane < 4) o[18 + n + lane] = (uint8_t)(crc[m] >> (8 * lane));
+        else if (lane < 8) o[18 + n + lane] = (uint8_t)(isize >> (8 * (lane - 4)));
+        if (m == n_members - 1 && lane == 0) *comp_total = at + size;
+    }
+}
+
+}  // namespace
+
+// bytes the members of `text_bytes` of text may take at most, and how many they are
+static inline int64_t df_members(int64_t text_bytes) { return (text_bytes + DF_PIECE - 1) / DF_PIECE; }
+
+// Queues the three kernels on `st`: the text at text_d (its length read on the device from *total_d, at most max_text bytes; readable
+// 32 bytes past its end) -> BGZF members at D.comp, their bytes in *comp_total_d.  status_d: see k_deflate.
+int pg_deflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Deflate &D, const uint8_t *text_d, const long long *total_d, int64_t max_text,
+                     const long long *status_d, long long *comp_total_d) {
+    const int64_t max_members = std::max<int64_t>(1, df_members(max_text));
+    int rc;
+    hipDeviceProp_t prop;
+    static int cus = 0;
+    if (!cus) {
+        HIPCHK(hipGetDeviceProperties(&prop, c->device));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int64_t waves = std::min<int64_t>(max_members, (int64_t)cus * 3);       // 45 KB of LDS a wave: three per compute unit
+    if ((rc = D.tok.ensure_roomy((size_t)waves * (65536 + 64))) != PG_OK) return rc;
+    if ((rc = D.slots.ensure_roomy((size_t)max_members * DF_SLOT + 64)) != PG_OK) return rc;
+    if ((rc = D.out_len.ensure_roomy((size_t)max_members)) != PG_OK) return rc;
+    if ((rc = D.crc.ensure_roomy((size_t)max_members)) != PG_OK) return rc;
+    if ((rc = D.comp.ensure_roomy((size_t)max_members * (DF_SLOT) + 64)) != PG_OK) return rc;
+    hipLaunchKernelGGL(k_deflate, dim3((unsigned)waves), dim3(64), 0, st, text_d, total_d, status_d, D.tok.p, D.slots.p, D.out_len.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = pg_launch_crc32_pieces(c, st, text_d, total_d, DF_PIECE, max_members, D.crc.p)) != PG_OK) return rc;
+    hipLaunchKernelGGL(k_bgzf_assemble, dim3((unsigned)std::min<int64_t>(max_members, 4096)), dim3(64), 0, st, total_d, status_d, D.slots.p,
+                       D.out_len.p, D.crc.p, D.comp.p, comp_total_d);
+    HIPCHK(hipGetLastError());
+    return PG_OK;
+}
+
+// text[0 .. len) (host) -> BGZF members at out (host; no end-of-file member), compressed on the device.  For tests and tools: the
+// text crosses PCIe twice; the drop-ins compress what already lies in HBM (pg_vcf_dev_rows_bgzf).  kernel_ms_out: the three kernels.
+extern "C" int pg_bgzf_compress_device(pg_ctx *c, const uint8_t *text, int64_t len, uint8_t *out, int64_t out_cap, int64_t *out_len_out,
+                                       double *kernel_ms_out) {
+    if (!c || len < 0 || (len && !text) || !out_len_out) return pg_fail(PG_ERR_ARG, "pg_bgzf_compress_device: bad argument");
+    *out_len_out = 0;
+    if (len == 0) return PG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream_up;
+    pg_ctx::Deflate &D = c->deflate;
+    int rc;
+    if ((rc = D.text.ensure_roomy((size_t)len + 64)) != PG_OK) return rc;
+    if ((rc = D.totals.ensure(4)) != PG_OK || (rc = D.h_totals.ensure(4)) != PG_OK) return rc;
+    D.h_totals.p[0] = len;
+    D.h_totals.p[1] = 0;
+    HIPCHK(hipMemcpyAsync(D.totals.p, D.h_totals.p, 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(D.text.p, text, (size_t)len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(D.text.p + len, 0, 64, st));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, st));
+    rc = pg_deflate_queue(c, st, D, D.text.p, reinterpret_cast<const long long *>(D.totals.p), len, nullptr,
+                          reinterpret_cast<long long *>(D.totals.p + 1));
+    if (rc == PG_OK) {
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipMemcpyAsync(D.h_totals.p + 1, D.totals.p + 1, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (kernel_ms_out) *kernel_ms_out = ms;
+        const int64_t got = D.h_totals.p[1];
+        *out_len_out = got;
+        if (out && got <= out_cap) {
+            HIPCHK(hipMemcpy(out, D.comp.p, (size_t)got, hipMemcpyDeviceToHost));
+        } else if (out)
+            rc = pg_fail(PG_ERR_ARG, "pg_bgzf_compress_device: the members take %lld bytes, the output holds %lld", (long long)got, (long long)out_cap);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}

@@ -122,16 +122,8 @@ __device__ __forceinline__ uint32_t crc_mul(uint32_t a, uint32_t b) {      // a 
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_crc32(const uint8_t *__restrict__ text, const PgiMember *__restrict__ mem, int n_members,
-                                               const uint32_t *__restrict__ tab_g, int32_t *__restrict__ status) {
-    __shared__ uint32_t tab[CRC_TAB];
-    for (int k = (int)threadIdx.x; k < CRC_TAB; k += 256) tab[k] = tab_g[k];
-    __syncthreads();
-    const int lane = (int)threadIdx.x & 63;
-    const int m = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    if (m >= n_members) return;
-    const uint8_t *p = text + mem[m].out_off;
-    const uint32_t n = mem[m].out_len;
+// the CRC-32 of p[0 .. n) by one wavefront (tab: crc_tables() in LDS); the result is lane 0's
+__device__ inline uint32_t crc_wave(const uint8_t *__restrict__ p, uint32_t n, const uint32_t *tab, int lane) {
     uint32_t head = (uint32_t)((4u - ((uint32_t)(uintptr_t)p & 3u)) & 3u);
     if (head > n) head = n;
     const uint32_t N = (n - head) >> 2, t = n - head - 4u * N;
@@ -154,10 +146,39 @@ __global__ __launch_bounds__(256) void k_crc32(const uint8_t *__restrict__ text,
     if (lane == 0) {
         const uint8_t *q = p + head + 4u * N;
         for (uint32_t k = 0; k < t; ++k) s = tab[(s ^ q[k]) & 255u] ^ (s >> 8);
-        if ((s ^ 0xFFFFFFFFu) != mem[m].crc) {
-            atomicOr(status, PGI_ERR_CRC);
-            atomicMin(status + 1, m);
-        }
+    }
+    return s ^ 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void k_crc32(const uint8_t *__restrict__ text, const PgiMember *__restrict__ mem, int n_members,
+                                               const uint32_t *__restrict__ tab_g, int32_t *__restrict__ status) {
+    __shared__ uint32_t tab[CRC_TAB];
+    for (int k = (int)threadIdx.x; k < CRC_TAB; k += 256) tab[k] = tab_g[k];
+    __syncthreads();
+    const int lane = (int)threadIdx.x & 63;
+    const int m = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (m >= n_members) return;
+    const uint32_t crc = crc_wave(text + mem[m].out_off, mem[m].out_len, tab, lane);
+    if (lane == 0 && crc != mem[m].crc) {
+        atomicOr(status, PGI_ERR_CRC);
+        atomicMin(status + 1, m);
+    }
+}
+
+// the CRC-32 of the pieces text[k * piece ..] (piece bytes each, the last one what is left of *total_p) -> crc_out[k]: the trailers of
+// members k_deflate (pg_deflate.hip) writes
+__global__ __launch_bounds__(256) void k_crc32_pieces(const uint8_t *__restrict__ text, const long long *__restrict__ total_p, uint32_t piece,
+                                                      const uint32_t *__restrict__ tab_g, uint32_t *__restrict__ crc_out) {
+    __shared__ uint32_t tab[CRC_TAB];
+    for (int k = (int)threadIdx.x; k < CRC_TAB; k += 256) tab[k] = tab_g[k];
+    __syncthreads();
+    const int lane = (int)threadIdx.x & 63;
+    const long long total = *total_p;
+    const long long n_pieces = (total + piece - 1) / piece;
+    for (long long m = (long long)blockIdx.x * 4 + ((int)threadIdx.x >> 6); m < n_pieces; m += (long long)gridDim.x * 4) {
+        const long long left = total - m * piece;
+        const uint32_t crc = crc_wave(text + m * piece, (uint32_t)(left < piece ? left : piece), tab, lane);
+        if (lane == 0) crc_out[m] = crc;
     }
 }
 
@@ -990,4 +1011,20 @@ int pg_inflate_error(const int32_t *status) { return inflate_error(status); }
 void pg_launch_gather_bytes(hipStream_t st, const uint8_t *text, const int64_t *off, const int32_t *len, const int64_t *dst, int n,
                             uint8_t *out) {
     if (n > 0) hipLaunchKernelGGL(k_gather_bytes, dim3((unsigned)n), dim3(64), 0, st, text, off, len, dst, out);
+}
+
+// used by pg_deflate.hip: the CRC-32 of every `piece` bytes of text[0 .. *total_d) -> crc_out (grid sized for at most max_pieces)
+int pg_launch_crc32_pieces(pg_ctx *c, hipStream_t st, const uint8_t *text, const long long *total_d, uint32_t piece, int64_t max_pieces,
+                           uint32_t *crc_out) {
+    pg_ctx::Inflate &I = c->inf;
+    int rc;
+    if (!I.crc_tab.p) {
+        const std::vector<uint32_t> &t = crc_tables();
+        if ((rc = I.crc_tab.ensure(t.size())) != PG_OK) return rc;
+        HIPCHK(hipMemcpy(I.crc_tab.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((max_pieces + 3) / 4, 2048));
+    hipLaunchKernelGGL(k_crc32_pieces, dim3((unsigned)blocks), dim3(256), 0, st, text, total_d, piece, I.crc_tab.p, crc_out);
+    HIPCHK(hipGetLastError());
+    return PG_OK;
 }

@@ -28,6 +28,8 @@ int pg_tok_bgzf_submit(pg_ctx *c, int slot, const uint8_t *comp, int64_t comp_le
                        int64_t text_len, int64_t line_len_hint);
 int pg_tok_lines(pg_ctx *c, int slot, int64_t *n_lines_out);
 int pg_tok_crc_result(pg_ctx *c, int slot);
+int pg_deflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Deflate &D, const uint8_t *text_d, const long long *total_d, int64_t max_text,
+                     const long long *status_d, long long *comp_total_d);
 
 namespace {
 
@@ -341,11 +343,11 @@ extern "C" int pg_vcf_dev_parse(pg_ctx *c, int slot) {
     pg_ctx::TokSlot &T = c->tok[slot];
     int64_t n_lines = 0;
     if ((rc = pg_tok_lines(c, slot, &n_lines)) != PG_OK) { V.state = 0; return rc; }
-    if ((rc = V.status.ensure(4)) != PG_OK || (rc = V.h_status.ensure(4)) != PG_OK) return rc;
+    if ((rc = V.status.ensure(8)) != PG_OK || (rc = V.h_status.ensure(8)) != PG_OK) return rc;
     if (!V.done) HIPCHK(hipEventCreateWithFlags(&V.done, hipEventDisableTiming));
     V.h_status.p[0] = V.no_final_newline || n_lines == 0 ? PGV_ST_HOST : 0;     // (no line feed at all: one unfinished line)
     V.h_status.p[1] = V.no_final_newline || n_lines == 0 ? 0 : 0x7fffffffffffffffll;
-    V.h_status.p[2] = V.h_status.p[3] = 0;
+    V.h_status.p[2] = V.h_status.p[3] = V.h_status.p[4] = 0;
     if (V.h_status.p[0]) {                                       // nothing to queue: collect reports the block as the host's
         V.state = 2;
         HIPCHK(hipEventRecord(V.done, st));
@@ -358,7 +360,7 @@ extern "C" int pg_vcf_dev_parse(pg_ctx *c, int slot) {
     // length again on top of the plain rows' bound, a total beyond it sends the block to the host
     V.out_cap = T.len + n_lines * (int64_t)(D.cfg.plain_cells + 64) + 4096;
     if ((rc = V.out.ensure_roomy((size_t)V.out_cap)) != PG_OK) return rc;
-    HIPCHK(hipMemcpyAsync(V.status.p, V.h_status.p, 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(V.status.p, V.h_status.p, 40, hipMemcpyHostToDevice, st));
     PgvLine *lines = reinterpret_cast<PgvLine *>(V.lines.p);
     long long *status = reinterpret_cast<long long *>(V.status.p);
     hipLaunchKernelGGL(k_vcf_heads, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, T.tp, T.nl.p, n_lines, D.cfg, D.contigs.p, lines,
@@ -372,7 +374,9 @@ extern "C" int pg_vcf_dev_parse(pg_ctx *c, int slot) {
     hipLaunchKernelGGL((k_vcf_cells<1>), grid, dim3(64 * wpb), lds, st, T.tp, T.nl.p, n_lines, D.cfg, D.sel_col.p, D.ploidy.p, D.fsel.p,
                        D.cell_off.p, lines, V.rlen.p, V.roff.p, V.out.p, status, wpb);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(V.h_status.p, V.status.p, 32, hipMemcpyDeviceToHost, st));
+    // the rows deflated where they lie (k_deflate reads their size on the device; a raised status cancels it)
+    if (D.bgzf_rows && (rc = pg_deflate_queue(c, st, V.df, V.out.p, status + 2, V.out_cap, status, status + 4)) != PG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(V.h_status.p, V.status.p, 40, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(V.done, st));
     V.state = 2;
     ++D.blocks;
@@ -381,13 +385,14 @@ extern "C" int pg_vcf_dev_parse(pg_ctx *c, int slot) {
 
 // Waits for the block's kernels.  *host_line_out < 0: the rows are ready (*out_len_out bytes, *n_rows_out rows: pg_vcf_dev_rows);
 // else the block goes to the host parser -- line *host_line_out is the first the device does not take (or the rows would not fit).
-extern "C" int pg_vcf_dev_collect(pg_ctx *c, int slot, int64_t *out_len_out, int64_t *n_rows_out, int64_t *host_line_out) {
+extern "C" int pg_vcf_dev_collect(pg_ctx *c, int slot, int64_t *out_len_out, int64_t *n_rows_out, int64_t *host_line_out, int64_t *bgzf_len_out) {
     int rc = check_slot(c, slot, "pg_vcf_dev_collect");
     if (rc != PG_OK) return rc;
     if (!out_len_out || !n_rows_out || !host_line_out) return pg_fail(PG_ERR_ARG, "pg_vcf_dev_collect: null argument");
     pg_ctx::VcfDev::Slot &V = c->vcf.s[slot];
     *out_len_out = *n_rows_out = 0;
     *host_line_out = -1;
+    if (bgzf_len_out) *bgzf_len_out = 0;
     if (V.state == 3) { V.state = 0; return PG_OK; }
     if (V.state != 2) return pg_fail(PG_ERR_STATE, "pg_vcf_dev_collect: nothing parsed in slot %d", slot);
     HIPCHK(hipSetDevice(c->device));
@@ -401,6 +406,28 @@ extern "C" int pg_vcf_dev_collect(pg_ctx *c, int slot, int64_t *out_len_out, int
     }
     *out_len_out = V.h_status.p[2];
     *n_rows_out = V.h_status.p[3];
+    if (bgzf_len_out && c->vcf.bgzf_rows) *bgzf_len_out = V.h_status.p[4];
+    return PG_OK;
+}
+
+// bgzf_members != 0: the rows of every block parsed from now on are also deflated on the device (k_deflate: BGZF members of 65 280 bytes
+// of rows, no end-of-file member); pg_vcf_dev_collect then reports their bytes and pg_vcf_dev_rows_bgzf fetches them
+extern "C" int pg_vcf_dev_set_output(pg_ctx *c, int bgzf_members) {
+    if (!c) return pg_fail(PG_ERR_ARG, "pg_vcf_dev_set_output: null context");
+    c->vcf.bgzf_rows = bgzf_members != 0;
+    return PG_OK;
+}
+
+extern "C" int pg_vcf_dev_rows_bgzf(pg_ctx *c, int slot, uint8_t *dst, int64_t len) {
+    int rc = check_slot(c, slot, "pg_vcf_dev_rows_bgzf");
+    if (rc != PG_OK) return rc;
+    pg_ctx::VcfDev::Slot &V = c->vcf.s[slot];
+    if (len < 0 || (len && !dst) || (size_t)len > V.df.comp.cap) return pg_fail(PG_ERR_ARG, "pg_vcf_dev_rows_bgzf: bad length");
+    if (len == 0) return PG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->tok_small) HIPCHK(hipStreamCreateWithFlags(&c->tok_small, hipStreamNonBlocking));
+    HIPCHK(hipMemcpyAsync(dst, V.df.comp.p, (size_t)len, hipMemcpyDeviceToHost, c->tok_small));
+    HIPCHK(hipStreamSynchronize(c->tok_small));
     return PG_OK;
 }
 

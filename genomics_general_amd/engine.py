@@ -347,9 +347,30 @@ class Engine:
 
     def vcf_collect(self, slot):
         """(bytes of the block's rows, their number, -1) or (0, 0, the first line the device does not take: the block is the host parser's)"""
-        n, rows, line = C.c_int64(0), C.c_int64(0), C.c_int64(-1)
-        check(self._L.pg_vcf_dev_collect(self._h, int(slot), C.byref(n), C.byref(rows), C.byref(line)))
+        n, rows, line, gz = C.c_int64(0), C.c_int64(0), C.c_int64(-1), C.c_int64(0)
+        check(self._L.pg_vcf_dev_collect(self._h, int(slot), C.byref(n), C.byref(rows), C.byref(line), C.byref(gz)))
+        self.vcf_bgzf_bytes = gz.value              # (after vcf_set_output(True): the rows as BGZF members, for vcf_rows_bgzf)
         return n.value, rows.value, line.value
+
+    def vcf_set_output(self, bgzf_members):
+        """the rows of the blocks parsed from now on are also deflated on the device (k_deflate) into BGZF members"""
+        check(self._L.pg_vcf_dev_set_output(self._h, 1 if bgzf_members else 0))
+
+    def vcf_rows_bgzf(self, slot, nbytes):
+        out = self.pinned.empty((max(int(nbytes), 1),), np.uint8)[:int(nbytes)]
+        check(self._L.pg_vcf_dev_rows_bgzf(self._h, int(slot), C.c_void_p(out.ctypes.data), int(nbytes)))
+        return out
+
+    def bgzf_compress(self, text):
+        """text (bytes-like) -> (BGZF members without the end-of-file member as a uint8 array, the kernels' ms): k_deflate
+        (pg_bgzf_compress_device; tests, tools/bgzip.py --device)"""
+        arr = np.frombuffer(text, dtype=np.uint8)
+        cap = len(arr) + (len(arr) // 65280 + 2) * 64 + 65536
+        out = self.pinned.empty((cap,), np.uint8)
+        n, ms = C.c_int64(0), C.c_double(0)
+        check(self._L.pg_bgzf_compress_device(self._h, C.c_void_p(arr.ctypes.data if len(arr) else 0), len(arr), C.c_void_p(out.ctypes.data), cap,
+                                              C.byref(n), C.byref(ms)))
+        return out[:n.value], ms.value
 
     def vcf_rows(self, slot, nbytes):
         out = self.pinned.empty((max(int(nbytes), 1),), np.uint8)[:int(nbytes)]

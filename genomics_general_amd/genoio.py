@@ -132,6 +132,14 @@ class BgzfWriter:
             del self.buf[:self.PIECE]
         return len(data)
 
+    def write_members(self, members):
+        """whole BGZF members made elsewhere (the device's k_deflate): what is still buffered as text goes out first, as members of
+        its own -- a BGZF file is any sequence of members"""
+        if len(self.buf):
+            self.f.write(memoryview(bgzf_compress(bytes(self.buf), self.level, eof_marker=False, n_threads=self.n_threads)))
+            self.buf = bytearray()
+        self.f.write(memoryview(members))
+
     def flush(self):
         pass
 

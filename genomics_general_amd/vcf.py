@@ -87,7 +87,10 @@ class _AsyncOut:
                 return
             if self.err is None:
                 try:
-                    self.out.write(memoryview(item))
+                    if isinstance(item, tuple):               # ("members", bytes): BGZF members the device deflated
+                        self.out.write_members(item[1])
+                    else:
+                        self.out.write(memoryview(item))
                 except BaseException as exc:                  # kept for the caller; the queue is still drained
                     self.err = exc
 
@@ -108,7 +111,7 @@ class _AsyncOut:
         self.th.join()
 
 
-def _text_blocks(reader, block_bytes, n_threads=0, plan=None):
+def _text_blocks(reader, block_bytes, n_threads=0, plan=None, gz_rows=False):
     """the input in blocks of whole lines, as pairs (text, None) for the host parser or (raw, where) for the device's.
 
     A bgzip-compressed VCF (what `bgzip` / GATK / bcftools write) is read as spans of deflated members (genoio.BgzfFile.read_span).
@@ -117,7 +120,7 @@ def _text_blocks(reader, block_bytes, n_threads=0, plan=None):
     device (pg_vcf_dev_*): the text of a bgzipped VCF then never exists on the host.  Otherwise a span is inflated into a ring of
     buffers: ON THE DEVICE when there is one (the members cross PCIe deflated, k_inflate takes a wavefront per member, the text comes
     back into page-locked memory; PG_BGZF_DEVICE=0: never), else by the library's host threads; everything else: the reader's own
-    blocks.  PG_VCF_DEVICE=0: the host parser always; =1: the device's even for a small file (tests)."""
+    blocks.  gz_rows: the device also deflates the rows it makes (`-o out.geno.gz`: k_deflate, BGZF members).  PG_VCF_DEVICE=0: the host parser always; =1: the device's even for a small file (tests)."""
     bg = isinstance(getattr(reader, "f", None), genoio.BgzfFile)
     made = {}
     maker = None
@@ -135,6 +138,7 @@ def _text_blocks(reader, block_bytes, n_threads=0, plan=None):
                 if want_dev:
                     made["why_not"] = eng.vcf_config(plan)
                     made["dev"] = made["why_not"] is None
+                    eng.vcf_set_output(bool(gz_rows))
                 made["engine"] = eng
             except BaseException as exc:
                 made["error"] = exc
@@ -727,7 +731,12 @@ def parse_vcf_main(argv=None):
         nbytes, _rows, line = eng.vcf_collect(slot)
         t0 = lap("device_wait_s", t0)
         if line < 0:
-            if nbytes:
+            if nbytes and gz_rows:
+                members = eng.vcf_rows_bgzf(slot, eng.vcf_bgzf_bytes)
+                t0 = lap("device_rows_s", t0)
+                sink.write(("members", members))
+                lap("wait_for_writer_s", t0)
+            elif nbytes:
                 text = eng.vcf_rows(slot, nbytes)
                 t0 = lap("device_rows_s", t0)
                 sink.write(text)
@@ -740,10 +749,12 @@ def parse_vcf_main(argv=None):
 
     # the device's parser takes text output without --packed (rows as text are what it makes)
     dev_plan = plan if (sink is not None and packer is None) else None
+    # `-o out.geno.gz`: the rows are deflated where they are made (PG_DEFLATE_DEVICE=0: by the host threads of genoio.BgzfWriter)
+    gz_rows = dev_plan is not None and isinstance(out, genoio.BgzfWriter) and os.environ.get("PG_DEFLATE_DEVICE", "1") != "0"
     t0 = time.perf_counter()
     pending, slot = None, 0
     try:
-        for body, where in _read_ahead(_text_blocks(reader, block_bytes, int(args.threads), dev_plan)):
+        for body, where in _read_ahead(_text_blocks(reader, block_bytes, int(args.threads), dev_plan, gz_rows)):
             t0 = lap("wait_for_block_s", t0)
             if where is None:
                 if pending is not None:

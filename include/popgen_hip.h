@@ -299,8 +299,13 @@ int pg_vcf_dev_submit_bgzf(pg_ctx *ctx, int slot, const uint8_t *comp, int64_t c
                            const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head, int64_t head_len,
                            int64_t text_len, int64_t line_len_hint, int last_is_newline);
 int pg_vcf_dev_parse(pg_ctx *ctx, int slot);
-int pg_vcf_dev_collect(pg_ctx *ctx, int slot, int64_t *out_len_out, int64_t *n_rows_out, int64_t *host_line_out);
+int pg_vcf_dev_collect(pg_ctx *ctx, int slot, int64_t *out_len_out, int64_t *n_rows_out, int64_t *host_line_out, int64_t *bgzf_len_out);
 int pg_vcf_dev_rows(pg_ctx *ctx, int slot, uint8_t *dst, int64_t len);
+/* `-o out.geno.gz` (`parseVCF.py ... | bgzip`, VCF_processing/README.md:33): with pg_vcf_dev_set_output(ctx, 1) the rows of a block are
+ * also deflated where they lie (csrc/pg_deflate.hip: k_deflate, a wavefront per member of 65 280 bytes of rows; no end-of-file member);
+ * pg_vcf_dev_collect reports the members' bytes in *bgzf_len_out (may be NULL), pg_vcf_dev_rows_bgzf copies them to dst. */
+int pg_vcf_dev_set_output(pg_ctx *ctx, int bgzf_members);
+int pg_vcf_dev_rows_bgzf(pg_ctx *ctx, int slot, uint8_t *dst, int64_t len);
 int pg_vcf_dev_text(pg_ctx *ctx, int slot, uint8_t *dst, int64_t len);
 int pg_vcf_dev_stats(pg_ctx *ctx, int64_t *blocks_out, int64_t *host_blocks_out);
 
@@ -360,6 +365,12 @@ int pg_bgzf_compress(const uint8_t *text, int64_t len, int level, int block, int
 /* the members inflated ON THE DEVICE (k_inflate: one wavefront per member, canonical Huffman decoding by ballot, matches copied 64
  * bytes at a time; the trailers' CRC-32 are checked when crc != NULL -- inside k_inflate as the text leaves, or by k_crc32 with PG_BGZF_CRC_FOLD=0): comp[0 .. comp_len) -> dst[0 .. sum out_len).  kernel_ms_out (may
  * be NULL): device time of the kernels.  PG_ERR_PARSE names the first damaged member. */
+/* text[0 .. len) -> BGZF members (no end-of-file member) at out, deflated on the device by k_deflate -- the text crosses PCIe, so
+ * this is the entry point of tests and tools (tools/bgzip.py --device); a drop-in whose text is made on the device uses
+ * pg_vcf_dev_rows_bgzf.  *out_len_out: the members' bytes; kernel_ms_out (may be NULL): device time of the three kernels.
+ * Replaces bgzip in `parseVCF.py ... | bgzip` (VCF_processing/README.md:33). */
+int pg_bgzf_compress_device(pg_ctx *ctx, const uint8_t *text, int64_t len, uint8_t *out, int64_t out_cap, int64_t *out_len_out,
+                            double *kernel_ms_out);
 int pg_inflate_device(pg_ctx *ctx, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
                       const uint32_t *out_len, const uint32_t *crc, int64_t n_members, uint8_t *dst, double *kernel_ms_out);
 /* The submit step of the device tokenizer (pg_tokenize_submit) for a block that is still deflated -- comp[0 .. comp_len), or with
