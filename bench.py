@@ -437,6 +437,36 @@ def tier_samples(eng, lay, wl, names, slot_gen, scaf_len, n_sites, t1_block, t0_
     del host
     # ---- T2 ----
     out["t2"] = t2_sample(eng, lay, wl, names, scaf_len, t0_table)
+    out["vcf"] = vcf_sample()
+    return out
+
+
+def vcf_sample(n_sites=400000, n_samples=200):
+    """The upstream producer of the engine's input: VCF_processing/parseVCF.py's drop-in on a synthetic GATK-style
+    VCF (tools/vcf_bench.py: GT:AD:DP:GQ, indels, tri-allelic sites, missing calls; bgzipped by zlib at level 6 as htslib does) --
+    lines parsed on the device (k_vcf_heads / k_vcf_cells), `.geno.gz` rows deflated on the device (k_deflate) --, beside the same
+    command with the host parser and the host's deflate (PG_VCF_DEVICE=0).  Seconds are process wall-clock, device context included."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "vcf_bench.py")
+    out = {}
+    try:
+        for key, env in (("device_parser", {"VCF_LEGS": "0,2", "VCF_REPS": "2"}),
+                         ("host_parser", {"VCF_LEGS": "0", "VCF_REPS": "1", "PG_VCF_DEVICE": "0"})):
+            r = subprocess.run([sys.executable, tool, str(n_sites), str(n_samples), "--ref-sites", "0"], env=dict(os.environ, **env),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if r.returncode != 0:
+                out[key] = {"error": r.stderr.decode()[-300:]}
+                continue
+            res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            out.setdefault("sample", {k: res[k] for k in ("sites", "samples", "vcf_bytes", "vcf_gz_bytes", "options")})
+            out[key] = {name: {"seconds": leg["seconds"], "sites_per_sec": leg["sites_per_sec"], "vcf_text_MBps": leg["vcf_text_MBps"],
+                               "blocks_parsed_on_device": leg["timing"].get("blocks_parsed_on_device"),
+                               "blocks": leg["timing"].get("blocks")} for name, leg in res["legs"].items()}
+        a = out.get("device_parser", {}).get("vcf.gz -> geno.gz"), out.get("host_parser", {}).get("vcf.gz -> geno.gz")
+        if a[0] and a[1]:
+            out["device_over_host_parser"] = round(a[1]["seconds"] / a[0]["seconds"], 2)
+    except Exception as exc:                                    # side information: never lose the main line
+        out["error"] = repr(exc)[:300]
     return out
 
 

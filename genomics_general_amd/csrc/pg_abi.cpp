@@ -204,6 +204,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
         pg_ctx::VcfDev::Slot &V = c->vcf.s[k];
         V.lines.release(); V.out.release(); V.rlen.release(); V.roff.release(); V.status.release(); V.h_status.release(); V.df.release();
         if (V.done) (void)hipEventDestroy(V.done);
+        if (V.rows_ready) (void)hipEventDestroy(V.rows_ready);
     }
     c->tok_pin.release();
     drop_events(c);

@@ -172,7 +172,7 @@ struct pg_ctx {
             DevBuf<int64_t> roff, status;        // status: [0] bits (1 a line needs the host, 2 the rows exceed `out`), [1] first such line, [2] bytes of the rows, [3] rows, [4] bytes of the rows as BGZF members
             Deflate df;                          // the rows deflated where they lie (pg_vcf_dev_set_output)
             HostPin<int64_t> h_status;
-            hipEvent_t done = nullptr;
+            hipEvent_t done = nullptr, rows_ready = nullptr;
             int state = 0;                       // 0 idle, 1 text on its way / there, 2 kernels queued, 3 empty block
             int64_t text_len = 0, out_cap = 0;
             bool no_final_newline = false;

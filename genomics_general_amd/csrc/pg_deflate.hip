@@ -3,8 +3,8 @@
 // compressor (pg_fast_deflate.h) was what the drop-in waited for once the device parsed the VCF (1.5 of 2.2 s on 16 CPUs).
 //
 //   k_deflate        a wavefront per member of 65 280 bytes of text (persistent: a wave takes member after member).
-//     matches        64 positions at a time, a lane each: the four bytes at the position are hashed into one of 2048 buckets of the
-//                    EIGHT most recent places with that hash (LDS, 32 KB a wave) -- text written row by row repeats its cells so often
+//     matches        64 positions at a time, a lane each: the four bytes at the position are hashed into one of 512 buckets of the
+//                    EIGHT most recent places with that hash (LDS, 8 KB a wave) -- text written row by row repeats its cells so often
 //                    that a bucket's depth, not the number of buckets, decides the ratio (measured on `.geno` rows: depth 4 / 8 / 16
 //                    = 84 / 90 / 94 % of zlib level 6's ratio) -- plus the nearest earlier lane of the window with the same four bytes;
 //                    every candidate is compared over sixteen bytes (two 8-byte loads from the text in HBM / L2), the best one kept.
@@ -31,19 +31,22 @@ int pg_launch_crc32_pieces(pg_ctx *c, hipStream_t st, const uint8_t *text, const
 namespace {
 
 constexpr int DF_W = 8;                       // places per bucket
-constexpr int DF_HB = 11;                     // 2048 buckets
+#ifndef PGD_HB
+#define PGD_HB 9
+#endif
+#ifndef PGD_WAVES
+#define PGD_WAVES 3
+#endif
+constexpr int DF_HB = PGD_HB;                     // 512 buckets: 8 KB of LDS a wave (on `.geno` rows 512 ... 2048 buckets give the same ratio; 1024 buckets at two waves per SIMD: 27 against 20 ms per 326 MB, profiles/r06/deflate_bench_*.json)
 constexpr uint32_t DF_PIECE = 65280;          // text per member (bgzip's)
 constexpr uint32_t DF_SLOT = 65536;           // bytes a member's deflate stream may take (stored: text + 5)
 constexpr uint32_t DF_MAXL = 256;             // longest match (the format's 258 would need a 65th dword in the wave's compare)
 
-struct DfShared {
-    uint32_t bucket[(1 << DF_HB) * DF_W / 2];
-    uint32_t freq_ll[288], freq_d[32];
-    uint16_t code_ll[288], code_d[32];
-    uint8_t len_ll[288], len_d[32];
+// lane 0's work space for the codes, the header's bits and the window of bits on their way out: all of it after the matches, in the
+// memory the buckets leave behind
+struct DfWork {
     uint32_t win[112];                        // the bits of a batch of tokens on their way out
     uint32_t hdr[192];                        // the block header's bits
-    // lane 0's work space for the codes
     uint32_t w[576];
     uint16_t parent[576], sym[288];
     uint8_t depth[576];
@@ -54,6 +57,17 @@ struct DfShared {
     int count[64];
     uint32_t next[16];
 };
+
+struct DfShared {
+    union {
+        uint32_t bucket[(1 << DF_HB) * DF_W / 2];
+        DfWork k;
+    } u;
+    uint32_t freq_ll[288], freq_d[32];
+    uint16_t code_ll[288], code_d[32];
+    uint8_t len_ll[288], len_d[32];
+};
+static_assert(sizeof(DfWork) <= sizeof(uint32_t) * (1 << DF_HB) * DF_W / 2, "the work space must fit the buckets' memory");
 
 __device__ inline uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ inline uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -89,67 +103,67 @@ __device__ void df_code_lengths(const uint32_t *freq, int n, int max_bits, uint8
             // insertion into the leaves sorted by (frequency, symbol)
             int k = m++;
             const uint32_t f = freq[s];
-            while (k > 0 && sh.w[k - 1] > f) {
-                sh.w[k] = sh.w[k - 1];
-                sh.sym[k] = sh.sym[k - 1];
+            while (k > 0 && sh.u.k.w[k - 1] > f) {
+                sh.u.k.w[k] = sh.u.k.w[k - 1];
+                sh.u.k.sym[k] = sh.u.k.sym[k - 1];
                 --k;
             }
-            sh.w[k] = f;
-            sh.sym[k] = (uint16_t)s;
+            sh.u.k.w[k] = f;
+            sh.u.k.sym[k] = (uint16_t)s;
         }
     }
     if (m == 0) return;
-    if (m == 1) { lens[sh.sym[0]] = 1; return; }
+    if (m == 1) { lens[sh.u.k.sym[0]] = 1; return; }
     int a = 0, b = m, made = m;
     while (made < 2 * m - 1) {
         int x, y;
-        if (a < m && (b >= made || sh.w[a] <= sh.w[b])) x = a++; else x = b++;
-        if (a < m && (b >= made || sh.w[a] <= sh.w[b])) y = a++; else y = b++;
-        sh.w[made] = sh.w[x] + sh.w[y];
-        sh.parent[x] = sh.parent[y] = (uint16_t)made;
+        if (a < m && (b >= made || sh.u.k.w[a] <= sh.u.k.w[b])) x = a++; else x = b++;
+        if (a < m && (b >= made || sh.u.k.w[a] <= sh.u.k.w[b])) y = a++; else y = b++;
+        sh.u.k.w[made] = sh.u.k.w[x] + sh.u.k.w[y];
+        sh.u.k.parent[x] = sh.u.k.parent[y] = (uint16_t)made;
         ++made;
     }
-    for (int i = 0; i < 64; ++i) sh.count[i] = 0;
-    sh.depth[2 * m - 2] = 0;
+    for (int i = 0; i < 64; ++i) sh.u.k.count[i] = 0;
+    sh.u.k.depth[2 * m - 2] = 0;
     for (int i = 2 * m - 3; i >= 0; --i) {
-        const int d = sh.depth[sh.parent[i]] + 1;
-        sh.depth[i] = (uint8_t)(d < 63 ? d : 63);
-        if (i < m) ++sh.count[sh.depth[i]];
+        const int d = sh.u.k.depth[sh.u.k.parent[i]] + 1;
+        sh.u.k.depth[i] = (uint8_t)(d < 63 ? d : 63);
+        if (i < m) ++sh.u.k.count[sh.u.k.depth[i]];
     }
     for (int i = max_bits + 1; i < 64; ++i) {
-        sh.count[max_bits] += sh.count[i];
-        sh.count[i] = 0;
+        sh.u.k.count[max_bits] += sh.u.k.count[i];
+        sh.u.k.count[i] = 0;
     }
     unsigned long long total = 0;
-    for (int i = max_bits; i >= 1; --i) total += (unsigned long long)sh.count[i] << (max_bits - i);
+    for (int i = max_bits; i >= 1; --i) total += (unsigned long long)sh.u.k.count[i] << (max_bits - i);
     while (total != (1ull << max_bits)) {
-        --sh.count[max_bits];
+        --sh.u.k.count[max_bits];
         for (int i = max_bits - 1; i >= 1; --i)
-            if (sh.count[i]) {
-                --sh.count[i];
-                sh.count[i + 1] += 2;
+            if (sh.u.k.count[i]) {
+                --sh.u.k.count[i];
+                sh.u.k.count[i + 1] += 2;
                 break;
             }
         --total;
     }
     int at = 0;
     for (int l = max_bits; l >= 1; --l)
-        for (int k = 0; k < sh.count[l]; ++k) lens[sh.sym[at++]] = (uint8_t)l;
+        for (int k = 0; k < sh.u.k.count[l]; ++k) lens[sh.u.k.sym[at++]] = (uint8_t)l;
 }
 
 __device__ void df_make_codes(const uint8_t *lens, int n, uint16_t *codes, DfShared &sh) {
-    for (int l = 0; l < 16; ++l) sh.count[l] = 0;
-    for (int s = 0; s < n; ++s) ++sh.count[lens[s]];
-    sh.count[0] = 0;
+    for (int l = 0; l < 16; ++l) sh.u.k.count[l] = 0;
+    for (int s = 0; s < n; ++s) ++sh.u.k.count[lens[s]];
+    sh.u.k.count[0] = 0;
     uint32_t code = 0;
     for (int l = 1; l <= 15; ++l) {
-        code = (code + (uint32_t)sh.count[l - 1]) << 1;
-        sh.next[l] = code;
+        code = (code + (uint32_t)sh.u.k.count[l - 1]) << 1;
+        sh.u.k.next[l] = code;
     }
     for (int s = 0; s < n; ++s) {
         const int l = lens[s];
         if (!l) { codes[s] = 0; continue; }
-        const uint32_t c = sh.next[l]++;
+        const uint32_t c = sh.u.k.next[l]++;
         codes[s] = (uint16_t)(__brev(c) >> (32 - l));
     }
 }
@@ -169,7 +183,7 @@ struct HdrBits {
     }
 };
 
-// lane 0: codes from the frequencies, the block header's bits into sh.hdr; returns the bits of the header, *total_bits the whole stream's
+// lane 0: codes from the frequencies, the block header's bits into sh.u.k.hdr; returns the bits of the header, *total_bits the whole stream's
 __device__ uint32_t df_codes_and_header(DfShared &sh, unsigned long long *total_bits) {
     sh.freq_ll[256] = 1;
     df_code_lengths(sh.freq_ll, 286, 15, sh.len_ll, sh);
@@ -189,61 +203,61 @@ __device__ uint32_t df_codes_and_header(DfShared &sh, unsigned long long *total_
     while (hlit > 257 && !sh.len_ll[hlit - 1]) --hlit;
     while (hdist > 1 && !sh.len_d[hdist - 1]) --hdist;
     const int total = hlit + hdist;
-    for (int k = 0; k < hlit; ++k) sh.seq[k] = sh.len_ll[k];
-    for (int k = 0; k < hdist; ++k) sh.seq[hlit + k] = sh.len_d[k];
+    for (int k = 0; k < hlit; ++k) sh.u.k.seq[k] = sh.len_ll[k];
+    for (int k = 0; k < hdist; ++k) sh.u.k.seq[hlit + k] = sh.len_d[k];
     int ncl = 0;
-    for (int s = 0; s < 19; ++s) sh.freq_cl[s] = 0;
+    for (int s = 0; s < 19; ++s) sh.u.k.freq_cl[s] = 0;
     for (int k = 0; k < total;) {                               // the code lengths, run-length coded (RFC 1951, 3.2.7)
         int run = 1;
-        while (k + run < total && sh.seq[k + run] == sh.seq[k]) ++run;
-        if (sh.seq[k] == 0 && run >= 3) {
+        while (k + run < total && sh.u.k.seq[k + run] == sh.u.k.seq[k]) ++run;
+        if (sh.u.k.seq[k] == 0 && run >= 3) {
             const int r = run < 138 ? run : 138;
-            sh.cl_sym[ncl] = (uint8_t)(r <= 10 ? 17 : 18);
-            sh.cl_extra[ncl] = (uint8_t)(r <= 10 ? r - 3 : r - 11);
-            ++sh.freq_cl[sh.cl_sym[ncl++]];
+            sh.u.k.cl_sym[ncl] = (uint8_t)(r <= 10 ? 17 : 18);
+            sh.u.k.cl_extra[ncl] = (uint8_t)(r <= 10 ? r - 3 : r - 11);
+            ++sh.u.k.freq_cl[sh.u.k.cl_sym[ncl++]];
             k += r;
-        } else if (sh.seq[k] != 0 && run >= 4) {
-            sh.cl_sym[ncl] = sh.seq[k];
-            sh.cl_extra[ncl] = 0;
-            ++sh.freq_cl[sh.cl_sym[ncl++]];
+        } else if (sh.u.k.seq[k] != 0 && run >= 4) {
+            sh.u.k.cl_sym[ncl] = sh.u.k.seq[k];
+            sh.u.k.cl_extra[ncl] = 0;
+            ++sh.u.k.freq_cl[sh.u.k.cl_sym[ncl++]];
             const int r = run - 1 < 6 ? run - 1 : 6;
-            sh.cl_sym[ncl] = 16;
-            sh.cl_extra[ncl] = (uint8_t)(r - 3);
-            ++sh.freq_cl[16];
+            sh.u.k.cl_sym[ncl] = 16;
+            sh.u.k.cl_extra[ncl] = (uint8_t)(r - 3);
+            ++sh.u.k.freq_cl[16];
             ++ncl;
             k += 1 + r;
         } else {
-            sh.cl_sym[ncl] = sh.seq[k];
-            sh.cl_extra[ncl] = 0;
-            ++sh.freq_cl[sh.cl_sym[ncl++]];
+            sh.u.k.cl_sym[ncl] = sh.u.k.seq[k];
+            sh.u.k.cl_extra[ncl] = 0;
+            ++sh.u.k.freq_cl[sh.u.k.cl_sym[ncl++]];
             ++k;
         }
     }
-    df_code_lengths(sh.freq_cl, 19, 7, sh.len_cl, sh);
+    df_code_lengths(sh.u.k.freq_cl, 19, 7, sh.u.k.len_cl, sh);
     {
         int used = 0;
-        for (int s = 0; s < 19; ++s) used += sh.len_cl[s] != 0;
-        if (used < 2) sh.len_cl[sh.len_cl[0] ? 1 : 0] = 1;
+        for (int s = 0; s < 19; ++s) used += sh.u.k.len_cl[s] != 0;
+        if (used < 2) sh.u.k.len_cl[sh.u.k.len_cl[0] ? 1 : 0] = 1;
     }
-    df_make_codes(sh.len_cl, 19, sh.code_cl, sh);
+    df_make_codes(sh.u.k.len_cl, 19, sh.u.k.code_cl, sh);
     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     int hclen = 19;
-    while (hclen > 4 && !sh.len_cl[order[hclen - 1]]) --hclen;
-    HdrBits hb{sh.hdr, 0ull, 0, 0};
+    while (hclen > 4 && !sh.u.k.len_cl[order[hclen - 1]]) --hclen;
+    HdrBits hb{sh.u.k.hdr, 0ull, 0, 0};
     hb.put(1u | (2u << 1), 3);                                   // BFINAL, dynamic
     hb.put((uint32_t)(hlit - 257), 5);
     hb.put((uint32_t)(hdist - 1), 5);
     hb.put((uint32_t)(hclen - 4), 4);
-    for (int k = 0; k < hclen; ++k) hb.put(sh.len_cl[order[k]], 3);
+    for (int k = 0; k < hclen; ++k) hb.put(sh.u.k.len_cl[order[k]], 3);
     for (int k = 0; k < ncl; ++k) {
-        const int s = sh.cl_sym[k];
-        hb.put(sh.code_cl[s], sh.len_cl[s]);
-        if (s == 16) hb.put(sh.cl_extra[k], 2);
-        else if (s == 17) hb.put(sh.cl_extra[k], 3);
-        else if (s == 18) hb.put(sh.cl_extra[k], 7);
+        const int s = sh.u.k.cl_sym[k];
+        hb.put(sh.u.k.code_cl[s], sh.u.k.len_cl[s]);
+        if (s == 16) hb.put(sh.u.k.cl_extra[k], 2);
+        else if (s == 17) hb.put(sh.u.k.cl_extra[k], 3);
+        else if (s == 18) hb.put(sh.u.k.cl_extra[k], 7);
     }
     const uint32_t hdr_bits = (uint32_t)hb.words * 32u + (uint32_t)hb.n;
-    sh.hdr[hb.words] = (uint32_t)hb.acc;                         // the unfinished dword
+    sh.u.k.hdr[hb.words] = (uint32_t)hb.acc;                         // the unfinished dword
     unsigned long long bits = hdr_bits;
     for (int s = 0; s < 286; ++s) bits += (unsigned long long)sh.freq_ll[s] * (sh.len_ll[s] + (s >= 257 ? len_extra_of(s - 257) : 0u));
     for (int s = 0; s < 30; ++s) bits += (unsigned long long)sh.freq_d[s] * (sh.len_d[s] + dist_extra_of(s));
@@ -271,7 +285,7 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         return n + 5;
     };
     if (n < 16) return stored();
-    for (int k = lane; k < (1 << DF_HB) * DF_W / 2; k += 64) sh.bucket[k] = 0;
+    for (int k = lane; k < (1 << DF_HB) * DF_W / 2; k += 64) sh.u.bucket[k] = 0;
     for (int k = lane; k < 288; k += 64) sh.freq_ll[k] = 0;
     if (lane < 32) sh.freq_d[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -286,7 +300,7 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         const uint32_t v = (uint32_t)a0;
         const uint32_t h = inb ? (v * 2654435761u) >> (32 - DF_HB) : 0x80000000u | (uint32_t)lane;
         uint4 bk = make_uint4(0, 0, 0, 0);
-        if (inb) bk = *reinterpret_cast<const uint4 *>(&sh.bucket[h * (DF_W / 2)]);
+        if (inb) bk = *reinterpret_cast<const uint4 *>(&sh.u.bucket[h * (DF_W / 2)]);
         int rank = 0, gsize = 0, close = -1;
         for (int j = 0; j < 64; ++j) {
             const uint32_t hj = rl(h, j), vj = rl(v, j);
@@ -300,19 +314,37 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         uint32_t bestL = 0, bestD = 0, capmask = 0;
         const uint32_t q1s[9] = {bk.x & 0xffffu, bk.x >> 16, bk.y & 0xffffu, bk.y >> 16, bk.z & 0xffffu, bk.z >> 16, bk.w & 0xffffu, bk.w >> 16,
                                  close >= 0 ? w0 + (uint32_t)close + 1u : 0u};
+        // two rounds of loads, the nine candidates' side by side (one after the other they cost a member 8.7 ms: eighteen trips to
+        // L2 / HBM per window in a row; profiles/r06/vcf_gz_to_gz_kernel_stats_first.csv)
+        bool ok[9];
+        uint32_t qq[9];
+        uint64_t m0[9], m1[9];
+        const uint32_t safe = p < n ? p : 0u;                        // (a lane without a candidate reads its own place: no branch around a load)
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-            const uint32_t q1 = q1s[c];
-            const bool ok = need && inb && q1 != 0 && p - (q1 - 1) <= 32768u;
-            if (ok) {
-                const uint32_t q = q1 - 1, d = p - q;
-                const uint64_t m0 = ld64(in + q) ^ a0;
+            ok[c] = need && inb && q1s[c] != 0 && p - (q1s[c] - 1) <= 32768u;
+            qq[c] = ok[c] ? q1s[c] - 1 : safe;
+        }
+        if (need) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) m0[c] = ld64(in + qq[c]);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) m0[c] ^= a0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) m1[c] = ld64(in + qq[c] + 8);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) m1[c] ^= a1;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) m0[c] = m1[c] = ~0ull;
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            if (ok[c]) {
+                const uint32_t d = p - (q1s[c] - 1);
                 uint32_t L;
-                if (m0) L = (uint32_t)(__ffsll((long long)m0) - 1) >> 3;
-                else {
-                    const uint64_t m1 = ld64(in + q + 8) ^ a1;
-                    L = m1 ? 8u + ((uint32_t)(__ffsll((long long)m1) - 1) >> 3) : 16u;
-                }
+                if (m0[c]) L = (uint32_t)(__ffsll((long long)m0[c]) - 1) >> 3;
+                else L = m1[c] ? 8u + ((uint32_t)(__ffsll((long long)m1[c]) - 1) >> 3) : 16u;
                 if (L > maxl) L = maxl;
                 if (L >= 4 && (L > bestL || (L == bestL && d < bestD))) { bestL = L; bestD = d; }
                 if (L == 16 && maxl > 16) capmask |= 1u << c;
@@ -376,7 +408,7 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         }
         // ---- the window's positions into their buckets, most recent first: a lane's rank among the lanes of its bucket is its slot ----
         if (inb) {
-            uint16_t *b16 = reinterpret_cast<uint16_t *>(&sh.bucket[h * (DF_W / 2)]);
+            uint16_t *b16 = reinterpret_cast<uint16_t *>(&sh.u.bucket[h * (DF_W / 2)]);
             const int slot = gsize - 1 - rank;
             if (slot < DF_W) b16[slot] = (uint16_t)(p + 1);
             if (rank == gsize - 1 && gsize < DF_W) {                 // the group's last lane moves the old places back
@@ -402,10 +434,10 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
     // ---- bits ----
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
     uint32_t wbase = hdr_bits >> 5;                              // dwords of the stream that have left
-    for (uint32_t k = (uint32_t)lane; k < wbase; k += 64) out32[k] = sh.hdr[k];
-    for (int k = lane; k < 112; k += 64) sh.win[k] = 0;
+    for (uint32_t k = (uint32_t)lane; k < wbase; k += 64) out32[k] = sh.u.k.hdr[k];
+    for (int k = lane; k < 112; k += 64) sh.u.k.win[k] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane == 0) sh.win[0] = sh.hdr[wbase];
+    if (lane == 0) sh.u.k.win[0] = sh.u.k.hdr[wbase];
     uint32_t obit = hdr_bits;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (uint32_t k0 = 0; k0 <= nt; k0 += 64) {
@@ -437,33 +469,33 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         if (nb) {
             const uint32_t rel = obit + (uint32_t)(incl - nb) - wbase * 32u;
             const uint32_t wi = rel >> 5, sft = rel & 31u;
-            atomicOr(&sh.win[wi], (uint32_t)(val << sft));
-            if (sft + (uint32_t)nb > 32) atomicOr(&sh.win[wi + 1], (uint32_t)(sft ? val >> (32 - sft) : val >> 32));
-            if (sft + (uint32_t)nb > 64) atomicOr(&sh.win[wi + 2], (uint32_t)(val >> (64 - sft)));
+            atomicOr(&sh.u.k.win[wi], (uint32_t)(val << sft));
+            if (sft + (uint32_t)nb > 32) atomicOr(&sh.u.k.win[wi + 1], (uint32_t)(sft ? val >> (32 - sft) : val >> 32));
+            if (sft + (uint32_t)nb > 64) atomicOr(&sh.u.k.win[wi + 2], (uint32_t)(val >> (64 - sft)));
         }
         obit += total;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint32_t full = (obit >> 5) - wbase;               // whole dwords of the window
         uint32_t carry = 0, mine0 = 0, mine1 = 0;
-        if ((uint32_t)lane < full) mine0 = sh.win[lane];
-        if ((uint32_t)lane + 64 < full) mine1 = sh.win[lane + 64];
-        carry = sh.win[full];
+        if ((uint32_t)lane < full) mine0 = sh.u.k.win[lane];
+        if ((uint32_t)lane + 64 < full) mine1 = sh.u.k.win[lane + 64];
+        carry = sh.u.k.win[full];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if ((uint32_t)lane < full) out32[wbase + (uint32_t)lane] = mine0;
         if ((uint32_t)lane + 64 < full) out32[wbase + (uint32_t)lane + 64] = mine1;
-        for (int j = lane; j < 112; j += 64) sh.win[j] = 0;
+        for (int j = lane; j < 112; j += 64) sh.u.k.win[j] = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane == 0) sh.win[0] = carry;
+        if (lane == 0) sh.u.k.win[0] = carry;
         wbase += full;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (lane == 0 && (obit & 31u)) out32[wbase] = sh.win[0];
+    if (lane == 0 && (obit & 31u)) out32[wbase] = sh.u.k.win[0];
     return (obit + 7) >> 3;
 }
 
 // status_p (may be null): a nonzero word there cancels the work (the VCF kernels raised it: the block goes to the host).
 // tok_all: 65 536 + 64 dwords per block of the grid; out_all: DF_SLOT bytes per member; out_len[m]: its deflate stream's bytes
-__global__ __launch_bounds__(64) void k_deflate(const uint8_t *__restrict__ text, const long long *__restrict__ total_p, const long long *__restrict__ status_p,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PGD_WAVES, PGD_WAVES))) void k_deflate(const uint8_t *__restrict__ text, const long long *__restrict__ total_p, const long long *__restrict__ status_p,
                                                 uint32_t *__restrict__ tok_all, uint8_t *__restrict__ out_all, uint32_t *__restrict__ out_len) {
     __shared__ DfShared sh;
     const int lane = (int)threadIdx.x;
@@ -529,7 +561,7 @@ int pg_deflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Deflate &D, const uint8_
         HIPCHK(hipGetDeviceProperties(&prop, c->device));
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int64_t waves = std::min<int64_t>(max_members, (int64_t)cus * 3);       // 45 KB of LDS a wave: three per compute unit
+    const int64_t waves = std::min<int64_t>(max_members, (int64_t)cus * 4 * PGD_WAVES);       // 11 KB of LDS and 168 registers a wave: three per SIMD
     if ((rc = D.tok.ensure_roomy((size_t)waves * (65536 + 64))) != PG_OK) return rc;
     if ((rc = D.slots.ensure_roomy((size_t)max_members * DF_SLOT + 64)) != PG_OK) return rc;
     if ((rc = D.out_len.ensure_roomy((size_t)max_members)) != PG_OK) return rc;

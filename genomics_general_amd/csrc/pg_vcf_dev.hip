@@ -374,10 +374,22 @@ extern "C" int pg_vcf_dev_parse(pg_ctx *c, int slot) {
     hipLaunchKernelGGL((k_vcf_cells<1>), grid, dim3(64 * wpb), lds, st, T.tp, T.nl.p, n_lines, D.cfg, D.sel_col.p, D.ploidy.p, D.fsel.p,
                        D.cell_off.p, lines, V.rlen.p, V.roff.p, V.out.p, status, wpb);
     HIPCHK(hipGetLastError());
-    // the rows deflated where they lie (k_deflate reads their size on the device; a raised status cancels it)
-    if (D.bgzf_rows && (rc = pg_deflate_queue(c, st, V.df, V.out.p, status + 2, V.out_cap, status, status + 4)) != PG_OK) return rc;
-    HIPCHK(hipMemcpyAsync(V.h_status.p, V.status.p, 40, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(V.done, st));
+    // the rows deflated where they lie (k_deflate reads their size on the device; a raised status cancels it) -- on the context's second
+    // stream, beside the next block's k_inflate and parse kernels on the copy stream: a member costs k_deflate's wavefront 7.6 ms
+    // whatever else runs, and a block's rows seldom fill the chip's wave slots
+    hipStream_t fin = st;
+    if (D.bgzf_rows) {
+        static const bool aside = !(getenv("PG_DEFLATE_STREAM") && atoi(getenv("PG_DEFLATE_STREAM")) == 0);
+        if (aside && c->stream2) {
+            if (!V.rows_ready) HIPCHK(hipEventCreateWithFlags(&V.rows_ready, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(V.rows_ready, st));
+            HIPCHK(hipStreamWaitEvent(c->stream2, V.rows_ready, 0));
+            fin = c->stream2;
+        }
+        if ((rc = pg_deflate_queue(c, fin, V.df, V.out.p, status + 2, V.out_cap, status, status + 4)) != PG_OK) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(V.h_status.p, V.status.p, 40, hipMemcpyDeviceToHost, fin));
+    HIPCHK(hipEventRecord(V.done, fin));
     V.state = 2;
     ++D.blocks;
     return PG_OK;

@@ -146,12 +146,20 @@ def _text_blocks(reader, block_bytes, n_threads=0, plan=None, gz_rows=False):
         maker.start()
     if bg:
         reader.spans = True
+    dev_bytes = int(os.environ.get("PG_VCF_DEVICE_BYTES", 256 << 20))       # (128 MB / 256 / 512 / 1 GB: 0.68 / 0.54 / 0.60 / 0.68 s for 6 GB of bgzipped VCF, profiles/r06)
     ring, turn = [None] * 4, 0                  # one block with the parser, two queued, one being filled
     info = {"bgzf": bg, "device_inflate": False, "inflate_kernel_ms": 0.0, "inflate_s": 0.0, "blocks": 0, "blocks_inflated_on_device": 0,
             "blocks_parsed_on_device": 0}
     try:
         while True:
-            blk = reader.read_block(block_bytes)
+            # blocks of 32 MB for the host parser while the device context is being made (the switch comes as soon as it exists), then
+            # -- PG_VCF_DEVICE_BYTES -- blocks large enough to fill the chip: k_deflate takes a wavefront per 64 KiB of rows, a member
+            # costs it 7.6 ms whatever else runs, and the rows of 128 MB of VCF text are 570 members on 3072 wave slots
+            # (profiles/r06/vcf_gz_to_gz_kernel_stats*.csv)
+            size = block_bytes
+            if "PG_STREAM_BYTES" not in os.environ and worth and want_dev:
+                size = dev_bytes if (maker is None and made.get("dev")) else (32 << 20)
+            blk = reader.read_block(size)
             if len(blk) == 0:
                 break
             info["blocks"] += 1

@@ -167,3 +167,16 @@ def test_vcf_drop_in_writes_geno_gz_deflated_on_the_device(bgz_in, tmp_path, mon
     assert vcf.parse_vcf_main(["-i", src, "-o", got2] + argv) in (0, None)
     with open(got2, "rb") as f:
         assert gzip.decompress(f.read()) == gzip.decompress(raw)
+
+
+def test_bgzip_tool_on_the_device(tmp_path):
+    """tools/bgzip.py --device: a BGZF file (EOF member included) whose members k_deflate wrote"""
+    import subprocess
+    text = _geno_rows() * 3
+    src = str(tmp_path / "a.geno")
+    with open(src, "wb") as f:
+        f.write(text)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "bgzip.py"), "--device", src])
+    assert genoio.BgzfFile.is_bgzf(src + ".gz")
+    with gzip.open(src + ".gz", "rb") as f:
+        assert f.read() == text
