@@ -7,4 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from genomics_general_amd.vcf import parse_vcf_main  # noqa: E402
 
 if __name__ == "__main__":
-    sys.exit(parse_vcf_main())
+    rc = parse_vcf_main()
+    # the outputs are closed; what is left is releasing gigabytes of page-locked and device memory one buffer at a time (0.1 - 0.2 s
+    # of a run of under a second): the process ends here and the driver takes it all back at once
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(rc or 0)

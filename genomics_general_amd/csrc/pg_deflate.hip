@@ -3,15 +3,15 @@
 // compressor (pg_fast_deflate.h) was what the drop-in waited for once the device parsed the VCF (1.5 of 2.2 s on 16 CPUs).
 //
 //   k_deflate        a wavefront per member of 65 280 bytes of text (persistent: a wave takes member after member).
-//     matches        64 positions at a time, a lane each: the four bytes at the position are hashed into one of 512 buckets of the
-//                    EIGHT most recent places with that hash (LDS, 8 KB a wave) -- text written row by row repeats its cells so often
+//     matches        64 positions at a time, a lane each: the four bytes at the position are hashed into one of 256 buckets of the
+//                    EIGHT most recent places with that hash (LDS, 4 KB a wave) -- text written row by row repeats its cells so often
 //                    that a bucket's depth, not the number of buckets, decides the ratio (measured on `.geno` rows: depth 4 / 8 / 16
 //                    = 84 / 90 / 94 % of zlib level 6's ratio) -- plus the nearest earlier lane of the window with the same four bytes;
 //                    every candidate is compared over sixteen bytes (two 8-byte loads from the text in HBM / L2), the best one kept.
 //                    Then the window is walked from its first uncovered position: a literal run up to the next lane with a match goes
 //                    out in one step (all lanes), a match of the full sixteen bytes is first extended by the WHOLE wave (lane k
 //                    compares dword k of candidate and text: up to 256 bytes in one step).  The window's positions enter their buckets
-//                    in order without a serial loop: a lane's rank among the lanes of its bucket (64 readlanes) is its slot.
+//                    in order without a serial loop: a lane's rank among the lanes of its bucket (a bit mask per bucket in LDS) is its slot.
 //     codes          one dynamic Huffman block per member: the frequencies are counted in LDS while the tokens are made; lane 0
 //                    builds the length-limited codes and the block header as the host's compressor does (two-queue merge, miniz-style
 //                    bound, run-length coded code lengths); a member whose coded size would reach its text's is stored.
@@ -32,12 +32,12 @@ namespace {
 
 constexpr int DF_W = 8;                       // places per bucket
 #ifndef PGD_HB
-#define PGD_HB 9
+#define PGD_HB 8
 #endif
 #ifndef PGD_WAVES
 #define PGD_WAVES 3
 #endif
-constexpr int DF_HB = PGD_HB;                     // 512 buckets: 8 KB of LDS a wave (on `.geno` rows 512 ... 2048 buckets give the same ratio; 1024 buckets at two waves per SIMD: 27 against 20 ms per 326 MB, profiles/r06/deflate_bench_*.json)
+constexpr int DF_HB = PGD_HB;                     // 256 buckets: 4 KB of LDS a wave + 2 KB for the lanes' group masks (on `.geno` rows 256 ... 2048 buckets give the same ratio within 0.3 %; 2048 at one wave per SIMD 61 ms, 1024 at two 27, 512 at three 20 ms per 326 MB: profiles/r06/deflate_bench_*.json)
 constexpr uint32_t DF_PIECE = 65280;          // text per member (bgzip's)
 constexpr uint32_t DF_SLOT = 65536;           // bytes a member's deflate stream may take (stored: text + 5)
 constexpr uint32_t DF_MAXL = 256;             // longest match (the format's 258 would need a 65th dword in the wave's compare)
@@ -56,18 +56,22 @@ struct DfWork {
     uint16_t code_cl[19];
     int count[64];
     uint32_t next[16];
+    uint16_t code_ll[288], code_d[32];        // the block's codes (bit-reversed) and their lengths
+    uint8_t len_ll[288], len_d[32];
+};
+
+struct DfMatch {
+    uint32_t bucket[(1 << DF_HB) * DF_W / 2]; // the DF_W most recent places (+ 1, 16 bits each) of every hash
+    uint32_t grp[(1 << DF_HB) * 2];           // which lanes of the window at hand hash into a bucket (a bit per lane)
 };
 
 struct DfShared {
     union {
-        uint32_t bucket[(1 << DF_HB) * DF_W / 2];
+        DfMatch m;
         DfWork k;
     } u;
     uint32_t freq_ll[288], freq_d[32];
-    uint16_t code_ll[288], code_d[32];
-    uint8_t len_ll[288], len_d[32];
 };
-static_assert(sizeof(DfWork) <= sizeof(uint32_t) * (1 << DF_HB) * DF_W / 2, "the work space must fit the buckets' memory");
 
 __device__ inline uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ inline uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -186,25 +190,25 @@ struct HdrBits {
 // lane 0: codes from the frequencies, the block header's bits into sh.u.k.hdr; returns the bits of the header, *total_bits the whole stream's
 __device__ uint32_t df_codes_and_header(DfShared &sh, unsigned long long *total_bits) {
     sh.freq_ll[256] = 1;
-    df_code_lengths(sh.freq_ll, 286, 15, sh.len_ll, sh);
-    df_code_lengths(sh.freq_d, 30, 15, sh.len_d, sh);
+    df_code_lengths(sh.freq_ll, 286, 15, sh.u.k.len_ll, sh);
+    df_code_lengths(sh.freq_d, 30, 15, sh.u.k.len_d, sh);
     {
         int used = 0;
-        for (int s = 0; s < 286; ++s) used += sh.len_ll[s] != 0;
-        if (used < 2) sh.len_ll[sh.len_ll[0] ? 1 : 0] = 1;      // (a complete code needs two symbols)
+        for (int s = 0; s < 286; ++s) used += sh.u.k.len_ll[s] != 0;
+        if (used < 2) sh.u.k.len_ll[sh.u.k.len_ll[0] ? 1 : 0] = 1;      // (a complete code needs two symbols)
         used = 0;
-        for (int s = 0; s < 30; ++s) used += sh.len_d[s] != 0;
-        if (used == 0) sh.len_d[0] = 1;                          // (no match at all: one unused distance code of one bit)
+        for (int s = 0; s < 30; ++s) used += sh.u.k.len_d[s] != 0;
+        if (used == 0) sh.u.k.len_d[0] = 1;                          // (no match at all: one unused distance code of one bit)
     }
-    sh.len_ll[286] = sh.len_ll[287] = 0;
-    df_make_codes(sh.len_ll, 286, sh.code_ll, sh);
-    df_make_codes(sh.len_d, 30, sh.code_d, sh);
+    sh.u.k.len_ll[286] = sh.u.k.len_ll[287] = 0;
+    df_make_codes(sh.u.k.len_ll, 286, sh.u.k.code_ll, sh);
+    df_make_codes(sh.u.k.len_d, 30, sh.u.k.code_d, sh);
     int hlit = 286, hdist = 30;
-    while (hlit > 257 && !sh.len_ll[hlit - 1]) --hlit;
-    while (hdist > 1 && !sh.len_d[hdist - 1]) --hdist;
+    while (hlit > 257 && !sh.u.k.len_ll[hlit - 1]) --hlit;
+    while (hdist > 1 && !sh.u.k.len_d[hdist - 1]) --hdist;
     const int total = hlit + hdist;
-    for (int k = 0; k < hlit; ++k) sh.u.k.seq[k] = sh.len_ll[k];
-    for (int k = 0; k < hdist; ++k) sh.u.k.seq[hlit + k] = sh.len_d[k];
+    for (int k = 0; k < hlit; ++k) sh.u.k.seq[k] = sh.u.k.len_ll[k];
+    for (int k = 0; k < hdist; ++k) sh.u.k.seq[hlit + k] = sh.u.k.len_d[k];
     int ncl = 0;
     for (int s = 0; s < 19; ++s) sh.u.k.freq_cl[s] = 0;
     for (int k = 0; k < total;) {                               // the code lengths, run-length coded (RFC 1951, 3.2.7)
@@ -259,8 +263,8 @@ __device__ uint32_t df_codes_and_header(DfShared &sh, unsigned long long *total_
     const uint32_t hdr_bits = (uint32_t)hb.words * 32u + (uint32_t)hb.n;
     sh.u.k.hdr[hb.words] = (uint32_t)hb.acc;                         // the unfinished dword
     unsigned long long bits = hdr_bits;
-    for (int s = 0; s < 286; ++s) bits += (unsigned long long)sh.freq_ll[s] * (sh.len_ll[s] + (s >= 257 ? len_extra_of(s - 257) : 0u));
-    for (int s = 0; s < 30; ++s) bits += (unsigned long long)sh.freq_d[s] * (sh.len_d[s] + dist_extra_of(s));
+    for (int s = 0; s < 286; ++s) bits += (unsigned long long)sh.freq_ll[s] * (sh.u.k.len_ll[s] + (s >= 257 ? len_extra_of(s - 257) : 0u));
+    for (int s = 0; s < 30; ++s) bits += (unsigned long long)sh.freq_d[s] * (sh.u.k.len_d[s] + dist_extra_of(s));
     *total_bits = bits;
     return hdr_bits;
 }
@@ -285,7 +289,8 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         return n + 5;
     };
     if (n < 16) return stored();
-    for (int k = lane; k < (1 << DF_HB) * DF_W / 2; k += 64) sh.u.bucket[k] = 0;
+    for (int k = lane; k < (1 << DF_HB) * DF_W / 2; k += 64) sh.u.m.bucket[k] = 0;
+    for (int k = lane; k < (1 << DF_HB) * 2; k += 64) sh.u.m.grp[k] = 0;
     for (int k = lane; k < 288; k += 64) sh.freq_ll[k] = 0;
     if (lane < 32) sh.freq_d[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -300,15 +305,20 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         const uint32_t v = (uint32_t)a0;
         const uint32_t h = inb ? (v * 2654435761u) >> (32 - DF_HB) : 0x80000000u | (uint32_t)lane;
         uint4 bk = make_uint4(0, 0, 0, 0);
-        if (inb) bk = *reinterpret_cast<const uint4 *>(&sh.u.bucket[h * (DF_W / 2)]);
-        int rank = 0, gsize = 0, close = -1;
-        for (int j = 0; j < 64; ++j) {
-            const uint32_t hj = rl(h, j), vj = rl(v, j);
-            const bool e = hj == h;
-            gsize += e ? 1 : 0;
-            rank += (e && j < lane) ? 1 : 0;
-            if (vj == v && j < lane) close = j;
-        }
+        if (inb) bk = *reinterpret_cast<const uint4 *>(&sh.u.m.bucket[h * (DF_W / 2)]);
+        // the lanes of the window that share this lane's bucket, as a bit per lane: every lane sets its bit in the bucket's mask (LDS),
+        // reads the mask back and clears it again -- a lane's rank in its group, the group's size and the nearest earlier lane of it
+        // (a candidate like the bucket's: its bytes are compared) are three bit counts (the first version asked all 64 lanes for their
+        // hash, one v_readlane pair after the other: a third of the kernel's instructions)
+        unsigned long long gm = 0;
+        if (inb) atomicOr(&sh.u.m.grp[2 * h + ((uint32_t)lane >> 5)], 1u << ((uint32_t)lane & 31u));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (inb) gm = (unsigned long long)sh.u.m.grp[2 * h] | ((unsigned long long)sh.u.m.grp[2 * h + 1] << 32);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (inb) sh.u.m.grp[2 * h + ((uint32_t)lane >> 5)] = 0;
+        const unsigned long long lower = gm & ((1ull << lane) - 1ull);
+        const int rank = __popcll(lower), gsize = __popcll(gm);
+        const int close = lower ? 63 - __clzll((long long)lower) : -1;
         const uint32_t wend = w0 + 64 < n ? w0 + 64 : n;
         const bool need = pos < wend;                             // (a window inside a long match only enters its buckets)
         uint32_t bestL = 0, bestD = 0, capmask = 0;
@@ -350,6 +360,14 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
                 if (L == 16 && maxl > 16) capmask |= 1u << c;
             }
         }
+        // every lane's match as the token it would be, and the symbols it would count (the walk below only picks)
+        uint32_t tokw = 0, lsym = 0, dsym = 0;
+        if (bestL >= 4) {
+            uint32_t eb, ev;
+            tokw = 0x80000000u | ((bestL - 3) << 16) | (bestD - 1);
+            len_code(bestL, &lsym, &eb, &ev);
+            dist_code(bestD, &dsym, &eb, &ev);
+        }
         // ---- the window's tokens, from its first uncovered position ----
         while (pos < wend) {
             const int l = (int)(pos - w0);
@@ -366,10 +384,17 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
                 nt += run;
                 pos += run;
             } else {
-                uint32_t mL = L, mD = rl(bestD, l);
+                uint32_t mL = L;
                 const uint32_t caps = rl(capmask, l);
-                if (caps) {
+                if (!caps) {
+                    if (lane == 0) {
+                        tok[nt] = rl(tokw, l);
+                        atomicAdd(&sh.freq_ll[257 + rl(lsym, l)], 1u);
+                        atomicAdd(&sh.freq_d[rl(dsym, l)], 1u);
+                    }
+                } else {
                     // the candidates that matched all sixteen bytes: the whole wave compares 256 bytes of each
+                    uint32_t mD = rl(bestD, l);
                     const uint32_t lim = rl(maxl, l);
                     const bool cmp = 4u * (uint32_t)lane < lim;    // (nothing is read behind the member's last dword)
                     uint32_t mine = 0;
@@ -393,14 +418,14 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
                         if (len > lim) len = lim;
                         if (len > mL || (len == mL && d < mD)) { mL = len; mD = d; }
                     }
-                }
-                if (lane == 0) {
-                    tok[nt] = 0x80000000u | ((mL - 3) << 16) | (mD - 1);
-                    uint32_t idx, eb, ev;
-                    len_code(mL, &idx, &eb, &ev);
-                    atomicAdd(&sh.freq_ll[257 + idx], 1u);
-                    dist_code(mD, &idx, &eb, &ev);
-                    atomicAdd(&sh.freq_d[idx], 1u);
+                    if (lane == 0) {
+                        tok[nt] = 0x80000000u | ((mL - 3) << 16) | (mD - 1);
+                        uint32_t idx, eb, ev;
+                        len_code(mL, &idx, &eb, &ev);
+                        atomicAdd(&sh.freq_ll[257 + idx], 1u);
+                        dist_code(mD, &idx, &eb, &ev);
+                        atomicAdd(&sh.freq_d[idx], 1u);
+                    }
                 }
                 ++nt;
                 pos += mL;
@@ -408,7 +433,7 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         }
         // ---- the window's positions into their buckets, most recent first: a lane's rank among the lanes of its bucket is its slot ----
         if (inb) {
-            uint16_t *b16 = reinterpret_cast<uint16_t *>(&sh.u.bucket[h * (DF_W / 2)]);
+            uint16_t *b16 = reinterpret_cast<uint16_t *>(&sh.u.m.bucket[h * (DF_W / 2)]);
             const int slot = gsize - 1 - rank;
             if (slot < DF_W) b16[slot] = (uint16_t)(p + 1);
             if (rank == gsize - 1 && gsize < DF_W) {                 // the group's last lane moves the old places back
@@ -447,19 +472,19 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         if (k <= nt) {
             const uint32_t t = tok[k];
             if (!(t & 0x80000000u)) {
-                val = sh.code_ll[t];
-                nb = sh.len_ll[t];
+                val = sh.u.k.code_ll[t];
+                nb = sh.u.k.len_ll[t];
             } else {
                 const uint32_t len = ((t >> 16) & 0x7fffu) + 3, dist = (t & 0xffffu) + 1;
                 uint32_t li, leb, lev, di, deb, dev;
                 len_code(len, &li, &leb, &lev);
                 dist_code(dist, &di, &deb, &dev);
-                val = sh.code_ll[257 + li];
-                nb = sh.len_ll[257 + li];
+                val = sh.u.k.code_ll[257 + li];
+                nb = sh.u.k.len_ll[257 + li];
                 val |= (unsigned long long)lev << nb;
                 nb += (int)leb;
-                val |= (unsigned long long)sh.code_d[di] << nb;
-                nb += sh.len_d[di];
+                val |= (unsigned long long)sh.u.k.code_d[di] << nb;
+                nb += sh.u.k.len_d[di];
                 val |= (unsigned long long)dev << nb;
                 nb += (int)deb;
             }

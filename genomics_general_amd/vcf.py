@@ -158,7 +158,7 @@ def _text_blocks(reader, block_bytes, n_threads=0, plan=None, gz_rows=False):
             # (profiles/r06/vcf_gz_to_gz_kernel_stats*.csv)
             size = block_bytes
             if "PG_STREAM_BYTES" not in os.environ and worth and want_dev:
-                size = dev_bytes if (maker is None and made.get("dev")) else (32 << 20)
+                size = dev_bytes if (maker is None and made.get("dev")) else ((32 << 20) if maker is not None else block_bytes)
             blk = reader.read_block(size)
             if len(blk) == 0:
                 break
@@ -812,6 +812,13 @@ def parse_vcf_main(argv=None):
     reader.close()
     if timing is not None:
         timing["total_s"] = time.perf_counter() - t_start
+        try:                                                     # seconds since the process was started (interpreter, imports, header read, the run)
+            with open("/proc/self/stat") as f:
+                ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+            with open("/proc/uptime") as f:
+                timing["since_process_start_s"] = float(f.read().split()[0]) - ticks / os.sysconf("SC_CLK_TCK")
+        except Exception:
+            pass
         timing.update(getattr(_text_blocks, "last_info", {}))
         sys.stderr.write("PG_TIMING " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in timing.items()}) + "\n")
     return 0

@@ -86,7 +86,7 @@ def test_members_inflate_to_the_text(eng, what):
         assert len(comp) < len(text) // 100
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PG_DEFLATE_FUZZ_SEEDS", "60"))))
 def test_random_texts(eng, seed):
     rng = np.random.default_rng(77000 + seed)
     n = int(rng.choice([20, 300, 5000, 65280, 70000, 200000, 1000000]))

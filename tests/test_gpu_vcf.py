@@ -61,7 +61,7 @@ def test_goldens_through_the_device_parser(name, src, argv, form, tmp_path, monk
     assert info["blocks_parsed_on_device"] >= 1 and blocks == info["blocks_parsed_on_device"] and host_blocks == 0, info
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PG_VCF_FUZZ_SEEDS", "24"))))
 def test_random_files_device_parser_equals_host_parser(seed, tmp_path, monkeypatch):
     from genomics_general_amd._lib import PopgenError
     from test_vcf import _fuzz_vcf
@@ -95,10 +95,11 @@ def _bench_vcf(path, n_sites, n_samples):
     (3, []),
     (4000, ["--skipIndels", "-s", "ind0003,ind3999,ind0000,ind2048"]),          # two lines per block of the cells kernel
     (9000, ["--gtf", "flag=GQ", "min=30"]),                                       # one line per block
+    (14000, ["--skipIndels", "--gtf", "flag=DP", "min=8"]),                       # the most sample columns the device keeps tab positions for
 ])
 def test_gatk_style_file_device_equals_host(n_samples, argv, tmp_path, monkeypatch):
     """tools/vcf_bench.py's generator (GT:AD:DP:GQ, indels, tri-allelic sites, missing calls): plain and bgzipped, several blocks"""
-    n_sites = 30000 if n_samples <= 50 else 300
+    n_sites = 30000 if n_samples <= 50 else (300 if n_samples < 14000 else 120)
     path = str(tmp_path / "in.vcf")
     _bench_vcf(path, n_sites, n_samples)
     if n_samples >= 4000:
@@ -172,3 +173,20 @@ def test_option_sets_the_device_does_not_take_stay_on_the_host(tmp_path, monkeyp
     got, info = _run(src, str(tmp_path / "o.geno"), ["--skipIndels", "--excludeDuplicates"], {"PG_VCF_WAIT_FOR_DEVICE": "1"}, monkeypatch)
     want, _ = _run(src, str(tmp_path / "h.geno"), ["--skipIndels", "--excludeDuplicates"], {}, monkeypatch, device="0")
     assert got == want and info["blocks_parsed_on_device"] == 0 and "excludeDuplicates" in info.get("device_parser_not_taken", "")
+
+
+def test_a_damaged_member_of_a_bgzipped_vcf_is_named(tmp_path, monkeypatch):
+    """the device route inflates the members itself: a member whose bytes were changed fails the run with its number (CRC-32 / Huffman
+    code), it does not come out as rows"""
+    from genomics_general_amd._lib import PopgenError
+    with gzip.open(os.path.join(GOLD, "main.vcf.gz"), "rb") as f:
+        text = f.read()
+    comp = bytearray(genoio.bgzf_compress(text, 6, 4000).tobytes())
+    tab, used, _ = genoio.bgzf_walk(bytes(comp), None, 1 << 40)
+    k = len(tab[0]) // 2
+    comp[int(tab[0][k]) + int(tab[1][k]) // 2] ^= 0x5a
+    path = str(tmp_path / "in.vcf.gz")
+    with open(path, "wb") as f:
+        f.write(comp)
+    with pytest.raises((PopgenError, ValueError), match="member"):
+        _run(path, str(tmp_path / "o.geno"), ["--skipIndels"], {"PG_STREAM_BYTES": "20000"}, monkeypatch)

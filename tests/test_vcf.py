@@ -237,7 +237,10 @@ import subprocess  # noqa: E402
 @pytest.fixture(scope="module")
 def emul(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("vcf_emul") / "libvcf_emul.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", os.path.join(ROOT, "tests", "vcf_emul.cpp"), "-o", so])
+    # PG_EMUL_SANITIZE=1 (run under LD_PRELOAD of libasan, see `make asan-test`): the device's per-line / per-cell functions under
+    # AddressSanitizer + UBSan -- every read of the line's bytes checked against the exact end of the test's buffer
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-g"] if os.environ.get("PG_EMUL_SANITIZE") else []
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC"] + san + [os.path.join(ROOT, "tests", "vcf_emul.cpp"), "-o", so])
     return C.CDLL(so)
 
 
@@ -254,6 +257,7 @@ def _split_header(text):
 def _emul_rows(emul, plan, body):
     """(status, text, rows, line) of the emulated device path over a block of whole lines"""
     out = np.empty(4 * len(body) + 4096 + 64 * plan.n_sel * (body.count(b"\n") + 1), dtype=np.uint8)
+    body = bytes(body)                                            # (an exact-size object: a sanitizer build sees every read behind its end)
     n, rows, line, taken = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
     fn = emul.pgv_emul_block
     fn.restype = C.c_int
