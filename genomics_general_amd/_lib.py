@@ -95,6 +95,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char, C.c_char, C.c_int,
                                      C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "pg_vcf_dev_config": (C.c_int, None),
+    "pg_vcf_dev_set_prev": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_char_p, C.c_int]),
+    "pg_vcf_dev_prev": (C.c_int, [_P, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.POINTER(C.c_int)]),
     "pg_vcf_dev_submit": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64]),
     "pg_vcf_dev_submit_bgzf": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int]),

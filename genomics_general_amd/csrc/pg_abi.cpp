@@ -199,10 +199,10 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
         if (T.parsed) (void)hipEventDestroy(T.parsed);
     }
     c->deflate.release();
-    c->vcf.contigs.release(); c->vcf.ploidy.release(); c->vcf.fsel.release(); c->vcf.sel_col.release(); c->vcf.cell_off.release();
+    c->vcf.prevkey.release(); c->vcf.contigs.release(); c->vcf.ploidy.release(); c->vcf.fsel.release(); c->vcf.sel_col.release(); c->vcf.cell_off.release();
     for (int k = 0; k < 2; ++k) {
         pg_ctx::VcfDev::Slot &V = c->vcf.s[k];
-        V.lines.release(); V.out.release(); V.rlen.release(); V.roff.release(); V.status.release(); V.h_status.release(); V.df.release();
+        V.lines.release(); V.out.release(); V.rlen.release(); V.roff.release(); V.status.release(); V.h_status.release(); V.h_prev.release(); V.df.release();
         if (V.done) (void)hipEventDestroy(V.done);
         if (V.rows_ready) (void)hipEventDestroy(V.rows_ready);
     }

@@ -163,7 +163,7 @@ struct pg_ctx {
         bool configured = false;
         PgvConfig cfg;
         int waves_per_block = 4;
-        DevBuf<uint8_t> contigs, ploidy, fsel;
+        DevBuf<uint8_t> contigs, ploidy, fsel, prevkey;      // prevkey: the PgvKey of the last data line seen (--excludeDuplicates)
         DevBuf<int32_t> sel_col;
         DevBuf<uint32_t> cell_off;
         struct Slot {
@@ -172,6 +172,7 @@ struct pg_ctx {
             DevBuf<int64_t> roff, status;        // status: [0] bits (1 a line needs the host, 2 the rows exceed `out`), [1] first such line, [2] bytes of the rows, [3] rows, [4] bytes of the rows as BGZF members
             Deflate df;                          // the rows deflated where they lie (pg_vcf_dev_set_output)
             HostPin<int64_t> h_status;
+            HostPin<uint8_t> h_prev;             // the key the block started from
             hipEvent_t done = nullptr, rows_ready = nullptr;
             int state = 0;                       // 0 idle, 1 text on its way / there, 2 kernels queued, 3 empty block
             int64_t text_len = 0, out_cap = 0;

@@ -25,7 +25,6 @@ inline int pgv_make_config(int n_vcf_samples, int n_sel, const int32_t *sel_col,
     if (why) *why = none;
     if (n_sel < 0 || n_vcf_samples < 0 || (n_sel > 0 && (!sel_col || !sel_ploidy)) || n_filters < 0 || (n_filters > 0 && !filters)) return -1;
     auto no = [&](const char *w) { if (why) *why = w; return 0; };
-    if (flags & PG_VCF_EXCLUDE_DUPLICATES) return no("--excludeDuplicates compares a line with the data line before it");
     if (n_filters > PGV_MAX_FILTERS) return no("more than four genotype filters");
     if (n_vcf_samples < 1 || n_vcf_samples > PGV_MAX_VCF_SAMPLES) return no("no sample columns, or more than the device keeps tab positions for");
     if (n_sel < 1) return no("no selected sample");
@@ -33,7 +32,7 @@ inline int pgv_make_config(int n_vcf_samples, int n_sel, const int32_t *sel_col,
     memset(cfg, 0, sizeof(*cfg));
     cfg->n_vcf_samples = n_vcf_samples;
     cfg->n_sel = n_sel;
-    cfg->flags = flags & (PG_VCF_SKIP_INDELS | PG_VCF_KEEP_PARTIAL | PG_VCF_MISMATCH_TO_MISSING);
+    cfg->flags = flags & (PG_VCF_SKIP_INDELS | PG_VCF_KEEP_PARTIAL | PG_VCF_MISMATCH_TO_MISSING | PG_VCF_EXCLUDE_DUPLICATES);
     cfg->n_filters = n_filters;
     cfg->max_ref_len = max_ref_len;
     cfg->contig_mode = contig_mode;

@@ -31,6 +31,16 @@
 #define PGV_SKIP_INDELS 1
 #define PGV_KEEP_PARTIAL 2
 #define PGV_MISMATCH_TO_MISSING 4
+#define PGV_EXCLUDE_DUPLICATES 8
+
+#define PGV_KEY_MAX 120
+#define PGV_KEY_NONE 0xffffffffu         // no data line yet
+#define PGV_KEY_UNKNOWN 0xfffffffeu      // a data line whose tokens the key does not hold: the host decides
+// the CHROM and POS tokens of a data line (--excludeDuplicates compares a line with the data line before it, parseVCF.py:367)
+struct PgvKey {
+    uint32_t chrom_len, pos_len;
+    uint8_t chrom[PGV_KEY_MAX], pos[PGV_KEY_MAX];
+};
 
 #define PGV_LINE_KEPT 1u
 #define PGV_LINE_COMPLEX 2u      // some allele is not one base long: the row's cells are put together from the allele strings
@@ -105,6 +115,53 @@ PGV_HD bool pgv_eq(const uint8_t *a, const char *b, uint32_t n) {
     for (uint32_t k = 0; k < n; ++k)
         if (a[k] != (uint8_t)b[k]) return false;
     return true;
+}
+
+// the first two tokens of the line [t, t + n): 0 and their places (CHROM starts the line), 1 = not a data line (empty, or a '#' line:
+// the reference skips those), 2 = a spelling the host reads
+PGV_HD int pgv_line_key(const uint8_t *t, uint32_t n, uint32_t *chrom_len, uint32_t *pos_off, uint32_t *pos_len) {
+    if (n == 0 || t[0] == '#') return 1;
+    if (t[0] < 0x21) return 2;
+    uint32_t p = 0;
+    while (p < n && t[p] >= 0x21) ++p;
+    if (p >= n || t[p] != '\t') return 2;
+    *chrom_len = p;
+    const uint32_t a = ++p;
+    while (p < n && t[p] >= 0x21) ++p;
+    if (p >= n || t[p] != '\t' || p == a) return 2;
+    *pos_off = a;
+    *pos_len = p - a;
+    return 0;
+}
+
+// Is the kept line `t` (tokens from its PgvLine) a duplicate of the data line before it?  `before` walks back: before(j, &bt, &bn) gives
+// line i - 1 - j (false: no more lines in this block -- then `key` decides, the last data line of the blocks before).
+// 0 no, 1 yes, 2 the host decides.
+template <class Before>
+PGV_HD int pgv_is_duplicate(const uint8_t *t, const PgvLine &L, const PgvKey &key, Before before) {
+    for (uint32_t j = 0;; ++j) {
+        const uint8_t *bt;
+        uint32_t bn;
+        if (!before(j, &bt, &bn)) break;
+        uint32_t cl, po, pl;
+        const int r = pgv_line_key(bt, bn, &cl, &po, &pl);
+        if (r == 1) continue;
+        if (r == 2) return 2;
+        if (cl != L.chrom_len || pl != L.pos_len) return 0;
+        for (uint32_t k = 0; k < cl; ++k)
+            if (bt[k] != t[k]) return 0;
+        for (uint32_t k = 0; k < pl; ++k)
+            if (bt[po + k] != t[L.pos_off + k]) return 0;
+        return 1;
+    }
+    if (key.chrom_len == PGV_KEY_NONE) return 0;
+    if (key.chrom_len == PGV_KEY_UNKNOWN) return 2;
+    if (key.chrom_len != L.chrom_len || key.pos_len != L.pos_len) return 0;
+    for (uint32_t k = 0; k < L.chrom_len; ++k)
+        if (key.chrom[k] != t[k]) return 0;
+    for (uint32_t k = 0; k < L.pos_len; ++k)
+        if (key.pos[k] != t[L.pos_off + k]) return 0;
+    return 1;
 }
 
 // One line [t, t + n) (no line feed).  PGV_OK: L->flags says whether the site is kept and whether its row is a complex one;

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 
 #include <unistd.h>
 
@@ -43,7 +44,7 @@ __device__ inline void raise_host(long long *status, long long line) {
 
 __global__ __launch_bounds__(256) void k_vcf_heads(const uint8_t *__restrict__ text, const int64_t *__restrict__ nl, int64_t n_lines,
                                                    PgvConfig cfg, const uint8_t *__restrict__ contigs, PgvLine *__restrict__ lines,
-                                                   uint32_t *__restrict__ rlen, long long *__restrict__ status) {
+                                                   uint32_t *__restrict__ rlen, long long *__restrict__ status, const PgvKey *__restrict__ prev) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_lines) return;
     const int64_t ls = i ? nl[i - 1] + 1 : 0, le = nl[i];
@@ -57,9 +58,45 @@ __global__ __launch_bounds__(256) void k_vcf_heads(const uint8_t *__restrict__ t
             L->flags = 0;
             raise_host(status, i);
         }
+        if ((L->flags & PGV_LINE_KEPT) && (cfg.flags & PGV_EXCLUDE_DUPLICATES)) {
+            // --excludeDuplicates: against the data line before this one -- the lines above it in the block, then the key the blocks
+            // before left (k_vcf_lastkey)
+            const int dup = pgv_is_duplicate(text + ls, *L, *prev, [&](uint32_t j, const uint8_t **bt, uint32_t *bn) {
+                if ((int64_t)j >= i) return false;
+                const int64_t b = i - 1 - (int64_t)j;
+                const int64_t bs = b ? nl[b - 1] + 1 : 0;
+                *bt = text + bs;
+                *bn = (uint32_t)(nl[b] - bs);                    // (a line of 4 GB raises the flag on its own thread)
+                return true;
+            });
+            if (dup) L->flags = 0;
+            if (dup == 2) raise_host(status, i);
+        }
         if ((L->flags & PGV_LINE_KEPT) && !(L->flags & PGV_LINE_COMPLEX)) bytes = L->fixed_len + (uint32_t)cfg.plain_cells;
     }
     rlen[i] = bytes;
+}
+
+// the CHROM and POS tokens of the block's last data line -> *key (what the next block's first lines are held against); a block
+// without a data line leaves the key as it is
+__global__ void k_vcf_lastkey(const uint8_t *__restrict__ text, const int64_t *__restrict__ nl, int64_t n_lines, PgvKey *__restrict__ key) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int64_t i = n_lines - 1; i >= 0; --i) {
+        const int64_t ls = i ? nl[i - 1] + 1 : 0;
+        const uint64_t n = (uint64_t)(nl[i] - ls);
+        uint32_t cl = 0, po = 0, pl = 0;
+        const int r = n > 0xfffffff0ull ? 2 : pgv_line_key(text + ls, (uint32_t)n, &cl, &po, &pl);
+        if (r == 1) continue;
+        if (r == 2 || cl > PGV_KEY_MAX || pl > PGV_KEY_MAX) {
+            key->chrom_len = PGV_KEY_UNKNOWN;
+            return;
+        }
+        key->chrom_len = cl;
+        key->pos_len = pl;
+        for (uint32_t k = 0; k < cl; ++k) key->chrom[k] = text[ls + k];
+        for (uint32_t k = 0; k < pl; ++k) key->pos[k] = text[ls + po + k];
+        return;
+    }
 }
 
 __device__ inline int wave_incl_scan(int x, int lane) {
@@ -289,8 +326,53 @@ extern "C" int pg_vcf_dev_config(pg_ctx *c, int n_vcf_samples, int n_sel, const 
     // four lines per block while their tab positions fit 60 KB of LDS, else fewer
     const size_t per_wave = (size_t)n_vcf_samples * 4;
     c->vcf.waves_per_block = per_wave * 4 <= 60 * 1024 ? 4 : (per_wave * 2 <= 60 * 1024 ? 2 : 1);
+    if ((rc = c->vcf.prevkey.ensure(sizeof(PgvKey))) != PG_OK) return rc;
+    {
+        PgvKey none;
+        memset(&none, 0, sizeof(none));
+        none.chrom_len = PGV_KEY_NONE;
+        HIPCHK(hipMemcpy(c->vcf.prevkey.p, &none, sizeof(none), hipMemcpyHostToDevice));
+    }
     c->vcf.configured = true;
     *taken_out = 1;
+    return PG_OK;
+}
+
+// --excludeDuplicates: the CHROM and POS tokens of the data line before the next block submitted (a block the HOST parsed: the device
+// carries the key on from the blocks it sees itself); chrom == NULL: none
+extern "C" int pg_vcf_dev_set_prev(pg_ctx *c, const char *chrom, int chrom_len, const char *pos, int pos_len) {
+    if (!c || !c->vcf.configured) return pg_fail(PG_ERR_STATE, "pg_vcf_dev_set_prev: pg_vcf_dev_config must be called first");
+    if (chrom_len < 0 || pos_len < 0 || (chrom && !pos)) return pg_fail(PG_ERR_ARG, "pg_vcf_dev_set_prev: bad argument");
+    PgvKey key;
+    memset(&key, 0, sizeof(key));
+    if (!chrom) key.chrom_len = PGV_KEY_NONE;
+    else if (chrom_len > PGV_KEY_MAX || pos_len > PGV_KEY_MAX) key.chrom_len = PGV_KEY_UNKNOWN;
+    else {
+        key.chrom_len = (uint32_t)chrom_len;
+        key.pos_len = (uint32_t)pos_len;
+        memcpy(key.chrom, chrom, (size_t)chrom_len);
+        memcpy(key.pos, pos, (size_t)pos_len);
+    }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream_up));                  // (behind every block already queued)
+    HIPCHK(hipMemcpy(c->vcf.prevkey.p, &key, sizeof(key), hipMemcpyHostToDevice));
+    return PG_OK;
+}
+
+// the key the block collected from `slot` started from (for a block that goes to the host parser under --excludeDuplicates):
+// *chrom_len_out < 0: none.  chrom_out / pos_out: PGV_KEY_MAX (120) bytes each
+extern "C" int pg_vcf_dev_prev(pg_ctx *c, int slot, char *chrom_out, int *chrom_len_out, char *pos_out, int *pos_len_out) {
+    int rc = check_slot(c, slot, "pg_vcf_dev_prev");
+    if (rc != PG_OK) return rc;
+    if (!chrom_out || !chrom_len_out || !pos_out || !pos_len_out) return pg_fail(PG_ERR_ARG, "pg_vcf_dev_prev: null argument");
+    const PgvKey *key = reinterpret_cast<const PgvKey *>(c->vcf.s[slot].h_prev.p);
+    *chrom_len_out = *pos_len_out = -1;
+    if (!key || key->chrom_len == PGV_KEY_NONE) return PG_OK;
+    if (key->chrom_len == PGV_KEY_UNKNOWN) return pg_fail(PG_ERR_STATE, "pg_vcf_dev_prev: the data line before the block has tokens of more than 120 characters");
+    *chrom_len_out = (int)key->chrom_len;
+    *pos_len_out = (int)key->pos_len;
+    memcpy(chrom_out, key->chrom, key->chrom_len);
+    memcpy(pos_out, key->pos, key->pos_len);
     return PG_OK;
 }
 
@@ -363,8 +445,15 @@ extern "C" int pg_vcf_dev_parse(pg_ctx *c, int slot) {
     HIPCHK(hipMemcpyAsync(V.status.p, V.h_status.p, 40, hipMemcpyHostToDevice, st));
     PgvLine *lines = reinterpret_cast<PgvLine *>(V.lines.p);
     long long *status = reinterpret_cast<long long *>(V.status.p);
+    const PgvKey *prev = reinterpret_cast<const PgvKey *>(D.prevkey.p);
+    if (D.cfg.flags & PGV_EXCLUDE_DUPLICATES) {                  // (the key this block starts from, for a block that goes to the host after all)
+        if ((rc = V.h_prev.ensure(sizeof(PgvKey))) != PG_OK) return rc;
+        HIPCHK(hipMemcpyAsync(V.h_prev.p, D.prevkey.p, sizeof(PgvKey), hipMemcpyDeviceToHost, st));
+    }
     hipLaunchKernelGGL(k_vcf_heads, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, T.tp, T.nl.p, n_lines, D.cfg, D.contigs.p, lines,
-                       V.rlen.p, status);
+                       V.rlen.p, status, prev);
+    if (D.cfg.flags & PGV_EXCLUDE_DUPLICATES)
+        hipLaunchKernelGGL(k_vcf_lastkey, dim3(1), dim3(64), 0, st, T.tp, T.nl.p, n_lines, reinterpret_cast<PgvKey *>(D.prevkey.p));
     const int wpb = D.waves_per_block;
     const dim3 grid((unsigned)((n_lines + wpb - 1) / wpb));
     const size_t lds = (size_t)wpb * (size_t)D.cfg.n_vcf_samples * 4;

@@ -342,6 +342,17 @@ class Engine:
         check(self._L.pg_vcf_dev_submit(self._h, int(slot), ptr, -1, 0, n))
         return keep
 
+    def vcf_set_prev(self, chrom, pos):
+        """--excludeDuplicates: the CHROM / POS tokens (bytes; None: none) of the last data line of blocks the host parsed"""
+        check(self._L.pg_vcf_dev_set_prev(self._h, chrom, len(chrom or b""), pos, len(pos or b"")))
+
+    def vcf_prev(self, slot):
+        """(CHROM, POS) tokens of the data line before the block collected from `slot`, or (None, None)"""
+        a, b = C.create_string_buffer(128), C.create_string_buffer(128)
+        na, nb = C.c_int(-1), C.c_int(-1)
+        check(self._L.pg_vcf_dev_prev(self._h, int(slot), a, C.byref(na), b, C.byref(nb)))
+        return (None, None) if na.value < 0 else (a.raw[:na.value], b.raw[:nb.value])
+
     def vcf_parse(self, slot):
         check(self._L.pg_vcf_dev_parse(self._h, int(slot)))
 

@@ -753,6 +753,8 @@ def parse_vcf_main(argv=None):
         if timing is not None:
             timing["blocks_handed_to_the_host_parser"] = timing.get("blocks_handed_to_the_host_parser", 0) + 1
             timing.setdefault("first_line_handed_over", int(line))
+        if args.excludeDuplicates:                               # (the data line before this block: the device carried it)
+            state["prev_chrom"], state["prev_pos"] = eng.vcf_prev(slot)
         host_block(eng.vcf_text(slot, len(raw)) if isinstance(raw, genoio.BgzfSpan) else raw)
 
     # the device's parser takes text output without --packed (rows as text are what it makes)
@@ -769,10 +771,14 @@ def parse_vcf_main(argv=None):
                     finish(pending)
                     pending = None
                 host_block(body)
+                state["prev_on_device"] = False
             else:
                 # parse(k) is queued behind submit(k): while this thread waits for block k - 1 and hands its rows on, block k is
                 # copied / inflated; the kernels of k are queued as soon as its line count is back
                 eng = _text_blocks.engine
+                if args.excludeDuplicates and not state.get("prev_on_device"):
+                    eng.vcf_set_prev(state["prev_chrom"], state["prev_pos"])        # (of the blocks the host parsed so far)
+                    state["prev_on_device"] = True
                 keep = eng.vcf_submit(slot, body, where or None)
                 t0 = lap("device_submit_s", t0)
                 if pending is not None:

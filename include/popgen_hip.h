@@ -280,8 +280,8 @@ int pg_vcf_render_rows(const char *buf, int64_t n_rows, int n_sel, const int32_t
  * at most 16 alleles).  Replaces the same reference lines (VCF_processing/parseVCF.py:49-191, 367-370, 380-383).  A bgzipped VCF never
  * crosses PCIe as text: k_inflate writes it into the tokenizer's text slot, only the rows come back.
  *   pg_vcf_dev_config        the option set: pg_encode_vcf's arguments + the rows' separator and --addRefTrack.  *taken_out = 0 (with
- *                            *why_out, a static string): an option set the device does not take (--excludeDuplicates, > 4 genotype
- *                            filters, ...) -- the caller stays on pg_encode_vcf.
+ *                            *why_out, a static string): an option set the device does not take (> 4 genotype filters, > 14 000 sample
+ *                            columns, ...) -- the caller stays on pg_encode_vcf.
  *   pg_vcf_dev_submit        a block of whole lines -> text slot `slot` (0 / 1): from memory, or len bytes at file_offset of fd
  *   pg_vcf_dev_submit_bgzf   the same for a block of BGZF members (table: pg_bgzf_walk; head = text the caller holds in front of them,
  *                            text_len = head + members cut behind the block's last line feed; line_len_hint = bytes of a typical line)
@@ -294,6 +294,12 @@ int pg_vcf_render_rows(const char *buf, int64_t n_rows, int n_sel, const int32_t
 int pg_vcf_dev_config(pg_ctx *ctx, int n_vcf_samples, int n_sel, const int32_t *sel_col, const int32_t *sel_ploidy, int flags,
                       double min_qual, int max_ref_len, const pg_vcf_filter *filters, int n_filters, const char *contigs,
                       int n_contig_bytes, int contig_mode, char missing, char sep, int add_ref, int *taken_out, const char **why_out);
+/* --excludeDuplicates (parseVCF.py:367: a line against the DATA line before it): the device carries the CHROM / POS tokens of the last
+ * data line from block to block itself (k_vcf_lastkey); pg_vcf_dev_set_prev hands it the key of blocks the HOST parsed before the next
+ * submit (chrom == NULL: none), pg_vcf_dev_prev returns the key the block collected from `slot` started from (120 bytes each; a
+ * length < 0: none) -- what pg_encode_vcf needs as prev_chrom / prev_pos when that block goes to it. */
+int pg_vcf_dev_set_prev(pg_ctx *ctx, const char *chrom, int chrom_len, const char *pos, int pos_len);
+int pg_vcf_dev_prev(pg_ctx *ctx, int slot, char *chrom_out, int *chrom_len_out, char *pos_out, int *pos_len_out);
 int pg_vcf_dev_submit(pg_ctx *ctx, int slot, const char *text, int fd, int64_t file_offset, int64_t len);
 int pg_vcf_dev_submit_bgzf(pg_ctx *ctx, int slot, const uint8_t *comp, int64_t comp_len, const uint32_t *in_off, const uint32_t *in_len,
                            const uint32_t *out_len, const uint32_t *crc, int64_t n_members, const char *head, int64_t head_len,

@@ -20,7 +20,7 @@ from genomics_general_amd import genoio, vcf  # noqa: E402
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(ROOT, "tests", "golden", "vcf")
 
-DEVICE_CASES = [c for c in VCF_CASES if not any(a in c[2] for a in ("--field", "--simplifyALT", "--expandMulti", "--excludeDuplicates")) and
+DEVICE_CASES = [c for c in VCF_CASES if not any(a in c[2] for a in ("--field", "--simplifyALT", "--expandMulti")) and
                 not any(len(c[2][i + 1]) != 1 for i, a in enumerate(c[2]) if a in ("--missing", "--outSep"))]
 
 
@@ -170,9 +170,36 @@ def test_option_sets_the_device_does_not_take_stay_on_the_host(tmp_path, monkeyp
     src = str(tmp_path / "in.vcf.gz")
     with gzip.open(os.path.join(GOLD, "main.vcf.gz"), "rb") as f, open(src, "wb") as g:
         g.write(genoio.bgzf_compress(f.read(), 6, 3000).tobytes())
-    got, info = _run(src, str(tmp_path / "o.geno"), ["--skipIndels", "--excludeDuplicates"], {"PG_VCF_WAIT_FOR_DEVICE": "1"}, monkeypatch)
-    want, _ = _run(src, str(tmp_path / "h.geno"), ["--skipIndels", "--excludeDuplicates"], {}, monkeypatch, device="0")
-    assert got == want and info["blocks_parsed_on_device"] == 0 and "excludeDuplicates" in info.get("device_parser_not_taken", "")
+    argv = ["--skipIndels"] + [x for k in range(5) for x in ("--gtf", "flag=DP", "min=%d" % k)]         # five genotype filters
+    got, info = _run(src, str(tmp_path / "o.geno"), argv, {"PG_VCF_WAIT_FOR_DEVICE": "1"}, monkeypatch)
+    want, _ = _run(src, str(tmp_path / "h.geno"), argv, {}, monkeypatch, device="0")
+    assert got == want and info["blocks_parsed_on_device"] == 0 and "four genotype filters" in info.get("device_parser_not_taken", "")
+
+
+def test_exclude_duplicates_over_block_seams_and_host_blocks(tmp_path, monkeypatch):
+    """--excludeDuplicates on the device: runs of equal (CHROM, POS) cut by block seams (the device carries the key), with comment
+    lines in between, and with a block that goes to the host parser in the middle (the key crosses over both ways)"""
+    rng = np.random.default_rng(5)
+    lines, pos = [], 0
+    for k in range(3000):
+        if rng.random() < 0.6:
+            pos += int(rng.integers(1, 4))
+        if rng.random() < 0.02:
+            lines.append(b"# note %d" % k)
+        g = [b"0/0", b"0/1", b"1/1", b"./."][int(rng.integers(0, 4))]
+        lines.append(b"chr%d\t%d\t.\tA\tC\t50\tPASS\t.\tGT:DP\t%s:7\t0/1:9" % (1 + k // 1500, pos, g))
+    lines[1700] = lines[1700].replace(b"\tPASS", b" PASS")                    # a line only the host reads
+    head = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\tb\n"
+    path = str(tmp_path / "in.vcf")
+    with open(path, "wb") as f:
+        f.write(head + b"\n".join(lines) + b"\n")
+    for block in ("700", "5000", "100000000"):
+        env = {"PG_STREAM_BYTES": block}
+        want, _ = _run(path, str(tmp_path / "host.geno"), ["--excludeDuplicates"], env, monkeypatch, device="0")
+        got, info = _run(path, str(tmp_path / "dev.geno"), ["--excludeDuplicates"], env, monkeypatch)
+        assert got == want, block
+        assert info["blocks_parsed_on_device"] >= 1 and info["stats"][1] == 1, info
+    assert want.count(b"\n") < 2500                              # (duplicates were there to drop)
 
 
 def test_a_damaged_member_of_a_bgzipped_vcf_is_named(tmp_path, monkeypatch):

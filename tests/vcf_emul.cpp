@@ -6,6 +6,7 @@
 #include "../genomics_general_amd/csrc/pg_vcf_cfg.h"
 
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -35,8 +36,8 @@ bool line_tabs(const uint8_t *t, const PgvLine &L, int n_cols, std::vector<uint3
 extern "C" int pgv_emul_block(const uint8_t *text, int64_t len, int n_vcf_samples, int n_sel, const int32_t *sel_col,
                               const int32_t *sel_ploidy, int flags, double min_qual, int max_ref_len, const pg_vcf_filter *filters,
                               int n_filters, const char *contigs, int n_contig_bytes, int contig_mode, char missing, char sep,
-                              int add_ref, uint8_t *out, int64_t cap, int64_t *out_len, int64_t *n_rows, int64_t *host_line,
-                              int *taken) {
+                              int add_ref, const char *prev_chrom, int prev_chrom_len, const char *prev_pos, int prev_pos_len,
+                              uint8_t *out, int64_t cap, int64_t *out_len, int64_t *n_rows, int64_t *host_line, int *taken) {
     PgvConfig cfg;
     PgvTables tab;
     const char *why = nullptr;
@@ -56,6 +57,18 @@ extern "C" int pgv_emul_block(const uint8_t *text, int64_t len, int n_vcf_sample
     }
     start.push_back(len);
     const int64_t n_lines = (int64_t)start.size() - 1;
+    PgvKey key;                                                  // (what k_vcf_lastkey / pg_vcf_dev_set_prev leave on the device)
+    memset(&key, 0, sizeof(key));
+    key.chrom_len = PGV_KEY_NONE;
+    if (prev_chrom && prev_pos) {
+        if (prev_chrom_len > PGV_KEY_MAX || prev_pos_len > PGV_KEY_MAX) key.chrom_len = PGV_KEY_UNKNOWN;
+        else {
+            key.chrom_len = (uint32_t)prev_chrom_len;
+            key.pos_len = (uint32_t)prev_pos_len;
+            memcpy(key.chrom, prev_chrom, (size_t)prev_chrom_len);
+            memcpy(key.pos, prev_pos, (size_t)prev_pos_len);
+        }
+    }
     std::vector<PgvLine> lines((size_t)n_lines);
     std::vector<uint32_t> tabs;
     int64_t at = 0, rows = 0;
@@ -66,6 +79,17 @@ extern "C" int pgv_emul_block(const uint8_t *text, int64_t len, int n_vcf_sample
         PgvLine &L = lines[(size_t)i];
         if (pgv_head(t, (uint32_t)n64, cfg, reinterpret_cast<const uint8_t *>(contigs), &L) != PGV_OK) { *host_line = i; return 1; }
         if (!(L.flags & PGV_LINE_KEPT)) continue;
+        if (cfg.flags & PGV_EXCLUDE_DUPLICATES) {
+            const int dup = pgv_is_duplicate(t, L, key, [&](uint32_t j, const uint8_t **bt, uint32_t *bn) {
+                if ((int64_t)j >= i) return false;
+                const int64_t b = i - 1 - (int64_t)j;
+                *bt = text + start[(size_t)b];
+                *bn = (uint32_t)(start[(size_t)b + 1] - start[(size_t)b] - 1);
+                return true;
+            });
+            if (dup == 2) { *host_line = i; return 1; }
+            if (dup == 1) continue;
+        }
         if (!line_tabs(t, L, n_vcf_samples, tabs)) { *host_line = i; return 1; }
         const bool cx = (L.flags & PGV_LINE_COMPLEX) != 0;
         // sizes first (the kernels know a row's place before they write it)
