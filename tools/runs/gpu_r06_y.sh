@@ -4,7 +4,7 @@
 # VCF chain, the drivers end to end
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-O=gpurun_out/r06t; mkdir -p $O
+O=gpurun_out/r06y; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; grep -E "passed|failed|Error|^E " $O/pytest.log | tail -5
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -1 | tee $O/smoke.txt
 timeout 600 python tools/deflate_bench.py 400000 200 > $O/deflate_bench.json 2> $O/deflate_bench.err; cat $O/deflate_bench.json
