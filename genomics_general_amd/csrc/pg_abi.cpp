@@ -174,6 +174,7 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     for (int t = 0; t < PG_TOK_WORKERS; ++t) {
         if (c->tok_st[t]) (void)hipStreamDestroy(c->tok_st[t]);
         if (t == 0 && c->tok_small) (void)hipStreamDestroy(c->tok_small);
+        if (t == 0 && c->tok_parse) (void)hipStreamDestroy(c->tok_parse);
         if (t == 0 && c->tok_crc) (void)hipStreamDestroy(c->tok_crc);
         for (int k = 0; k < 2; ++k)
             if (c->tok_wev[t][k]) (void)hipEventDestroy(c->tok_wev[t][k]);

@@ -186,6 +186,7 @@ struct pg_ctx {
     HostPin<uint8_t> tok_pin;                              // two 4 MiB page-locked buffers per staging thread
     hipStream_t tok_st[PG_TOK_WORKERS] = {};               // one copy stream per staging thread
     hipStream_t tok_crc = nullptr;                         // k_crc32 of a deflated block, beside the tokenizer's kernels
+    hipStream_t tok_parse = nullptr;                       // PG_TOK_PARSE_STREAM=1: a block's parse kernels beside the next block's k_inflate
     hipStream_t tok_small = nullptr;                       // the collect step's few kilobytes (beside the next block's inflate on stream_up)
     hipEvent_t tok_wev[PG_TOK_WORKERS][2] = {};
     double tok_stage_s = 0, tok_kernel_s = 0;              // pg_tokenize_stats: wall seconds of the copies / of everything behind them

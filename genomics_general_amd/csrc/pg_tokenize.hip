@@ -881,7 +881,12 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
     if (T.state != 2) return pg_fail(PG_ERR_STATE, "pg_tokenize_parse: nothing submitted to slot %d", slot);
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t st = c->stream_up;
+    // PG_TOK_PARSE_STREAM=1: the block's parse kernels on a stream of their own, beside the NEXT block's k_inflate on the copy stream
+    // (submit(k + 1) queues it right behind this call) -- the block's text and line count are complete (the wait below), its rows are
+    // read only after collect
+    static const bool parse_aside = getenv("PG_TOK_PARSE_STREAM") && atoi(getenv("PG_TOK_PARSE_STREAM")) == 1;
+    if (parse_aside && !c->tok_parse) HIPCHK(hipStreamCreateWithFlags(&c->tok_parse, hipStreamNonBlocking));
+    hipStream_t st = parse_aside ? c->tok_parse : c->stream_up;
     HIPCHK(hipEventSynchronize(T.counted));
     if (T.deflated) {
         int32_t ist[2];
