@@ -69,10 +69,32 @@ def _lines(path):
         return [ln.rstrip() for ln in f.readlines()]
 
 
+class _BgzfTextOut:
+    """`-o out.csv.gz` (popgenWindows.py:316, freq.py: "If you add `.gz` it will be gzipped"): the reference's gzip.open(path, "wt") is
+    Python's gzip module at level 9 on the calling thread -- about 10 MB/s, seconds for the per-site table of freq.py behind a run of
+    a third of a second.  Here: BGZF (a valid gzip file for every reader) deflated 16 MiB at a time by the library's host threads
+    (genoio.BgzfWriter: pg_bgzf_compress).  A run that fails leaves the file without its end-of-file member."""
+
+    def __init__(self, path):
+        self.buffer = genoio.BgzfWriter(path)
+
+    def write(self, text):
+        self.buffer.write(text.encode() if isinstance(text, str) else text)
+        return len(text)
+
+    def flush(self):
+        pass
+
+    def close(self):
+        self.buffer.close()
+
+
 def _open_out(path):
     if not path:
         return sys.stdout
-    return gzip.open(path, "wt") if path.endswith(".gz") else open(path, "wt")
+    if path.endswith(".gz"):
+        return gzip.open(path, "wt") if os.environ.get("PG_OUT_GZIP_MODULE") else _BgzfTextOut(path)
+    return open(path, "wt")
 
 
 def _window_setup(args, overlap):

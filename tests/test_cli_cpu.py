@@ -272,3 +272,22 @@ def test_rows_of_float_columns_only_formatted_natively(tmp_path, monkeypatch):
         run_case(case, tmp_path, monkeypatch)
         n += len(used) > before
     assert n >= 10, n
+
+
+@pytest.mark.parametrize("name", ["c1_popgen", "abba_windows", "multi_distmat", "abba_freq_derived"])
+def test_gz_outputs_are_bgzf_holding_the_plain_output(name, tmp_path, monkeypatch):
+    """`-o out.gz` ("If you add `.gz` it will be gzipped", the reference's README on freq.py; popgenWindows.py:316): a gzip file any
+    reader takes -- here BGZF, deflated by the library's host threads instead of the gzip module at level 9 on the calling thread --
+    whose text is the plain output's"""
+    import gzip
+    case = next(c for c in CASES if c["name"] == name)
+    monkeypatch.setattr(cli, "Engine", CpuEngine)
+    geno = os.path.join(GOLD, case["fixture"] + ".geno.gz")
+    plain, gz = str(tmp_path / "o.out"), str(tmp_path / "o.out.gz")
+    for out in (plain, gz):
+        G.MAINS[case["tool"]]([a.format(geno=geno, dir=GOLD, out=out) for a in case["argv"]] + ["-o", out])
+    with open(plain, "rb") as f, gzip.open(gz, "rb") as g:
+        assert f.read() == g.read()
+    assert genoio.BgzfFile.is_bgzf(gz)
+    with open(gz, "rb") as f:
+        assert f.read().endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))

@@ -50,6 +50,11 @@ def driver_commands(geno, out, names, n_pops, wind):
                               "--polarize"] + p4,
         "distMat.py": ["-g", geno, "-f", "phased", "--windType", "coordinate", "-w", str(wind), "-o", out + ".dist", "--outFormat", "raw"],
         "freq.py": ["-g", geno, "-o", out + ".freq.tsv", "-f", "phased", "--target", "derived"] + pops,
+        # "If you add `.gz` it will be gzipped" (the reference's README): BGZF by the library's host threads here ...
+        "freq.py -o out.tsv.gz": ["-g", geno, "-o", out + ".freq.tsv.gz", "-f", "phased", "--target", "derived"] + pops,
+        # ... against what the reference does, gzip.open(path, "wt"): the gzip module at level 9 on the calling thread
+        "freq.py -o out.tsv.gz (PG_OUT_GZIP_MODULE=1: the gzip module, as the reference writes it)":
+            ["-g", geno, "-o", out + ".freq2.tsv.gz", "-f", "phased", "--target", "derived"] + pops,
     }
 
 
@@ -77,7 +82,7 @@ def gpu_mode(n_sites, n_dip):
     for tool, argv in driver_commands(geno + ".gz", os.path.join(tmp, "out"), names, 4, 50000).items():
         best = None
         for _ in range(2):
-            rc, wall, tm, err = run_timed(os.path.join(ROOT, tool.split()[0]), argv)
+            rc, wall, tm, err = run_timed(os.path.join(ROOT, tool.split()[0]), argv, {"PG_OUT_GZIP_MODULE": "1"} if "PG_OUT_GZIP_MODULE" in tool else None)
             if rc != 0 or tm is None:
                 best = {"error": err[-400:]}
                 break
@@ -128,7 +133,7 @@ def reference_mode(n_sites, n_dip):
     for tool in cmds_ref:
         ncpu = str(len(os.sched_getaffinity(0)))                     # the reference's own parallelism: worker processes per window / slice
         extra = ["-t", ncpu] if tool == "freq.py" else ["-T", ncpu]
-        if os.environ.get("DRV_ONLY") and os.environ["DRV_ONLY"] not in tool:
+        if (os.environ.get("DRV_ONLY") and os.environ["DRV_ONLY"] not in tool) or tool.startswith("freq.py -o"):
             continue
         t = time.perf_counter()
         r = subprocess.run([sys.executable, shim, os.path.join(REF, tool.split()[0])] + cmds_ref[tool] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
