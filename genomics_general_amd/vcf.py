@@ -128,22 +128,27 @@ def _text_blocks(reader, block_bytes, n_threads=0, plan=None, gz_rows=False):
     want_dev = plan is not None and force != "0"
     # (a small file is over before a device context exists -- 0.1 - 0.3 s --: the host threads take it; PG_VCF_WAIT_FOR_DEVICE: always)
     wait = bool(os.environ.get("PG_VCF_WAIT_FOR_DEVICE")) or (want_dev and force == "1")
-    size = getattr(reader.f, "size", 0) if bg else (reader.input_size() if reader.mm is not None else 0)
-    worth = (bg or (want_dev and reader.mm is not None)) and (size >= (32 << 20) or wait)
+    gzs = isinstance(getattr(reader, "f", None), genoio.GzipStream)           # ONE gzip stream (`gzip in.vcf`): the host inflates it, chunks side by side
+    size = getattr(reader.f, "size", 0) if bg else (reader.input_size() if reader.mm is not None else (4 * reader.input_size() if gzs else 0))
+    worth = (bg or (want_dev and (reader.mm is not None or gzs))) and (size >= (32 << 20) or wait)
+    def make():                                   # the device context takes 0.1 - 0.3 s: the first blocks do not wait for it
+        try:
+            from .engine import Engine
+            eng = Engine(int(os.environ.get("PG_DEVICE", "0")))
+            if want_dev:
+                made["why_not"] = eng.vcf_config(plan)
+                made["dev"] = made["why_not"] is None
+                eng.vcf_set_output(bool(gz_rows))
+            made["engine"] = eng
+        except BaseException as exc:
+            made["error"] = exc
+
     if worth and (os.environ.get("PG_BGZF_DEVICE", "1") != "0" or want_dev) and _lib.device_count() > 0:
-        def make():                               # the device context takes 0.1 - 0.3 s: the first blocks do not wait for it
-            try:
-                from .engine import Engine
-                eng = Engine(int(os.environ.get("PG_DEVICE", "0")))
-                if want_dev:
-                    made["why_not"] = eng.vcf_config(plan)
-                    made["dev"] = made["why_not"] is None
-                    eng.vcf_set_output(bool(gz_rows))
-                made["engine"] = eng
-            except BaseException as exc:
-                made["error"] = exc
         maker = threading.Thread(target=make, name="pg-vcf-context", daemon=True)
         maker.start()
+    # a pipe (`bcftools view ... | parseVCF.py`): its size shows only as it arrives -- the context is made once a first block of 32 MB
+    # has come in whole
+    piped_in = want_dev and not worth and getattr(reader, "path", None) is None and os.environ.get("PG_BGZF_DEVICE", "1") != "0"
     if bg:
         reader.spans = True
     dev_bytes = int(os.environ.get("PG_VCF_DEVICE_BYTES", 256 << 20))       # (128 MB / 256 / 512 / 1 GB: 0.68 / 0.54 / 0.60 / 0.68 s for 6 GB of bgzipped VCF, profiles/r06)
@@ -157,12 +162,16 @@ def _text_blocks(reader, block_bytes, n_threads=0, plan=None, gz_rows=False):
             # costs it 7.6 ms whatever else runs, and the rows of 128 MB of VCF text are 570 members on 3072 wave slots
             # (profiles/r06/vcf_gz_to_gz_kernel_stats*.csv)
             size = block_bytes
-            if "PG_STREAM_BYTES" not in os.environ and worth and want_dev:
-                size = dev_bytes if (maker is None and made.get("dev")) else ((32 << 20) if maker is not None else block_bytes)
+            if "PG_STREAM_BYTES" not in os.environ and (worth or piped_in) and want_dev:
+                size = dev_bytes if (maker is None and made.get("dev")) else ((32 << 20) if (maker is not None or piped_in) else block_bytes)
             blk = reader.read_block(size)
             if len(blk) == 0:
                 break
             info["blocks"] += 1
+            if piped_in and len(blk) >= (32 << 20) and _lib.device_count() > 0:
+                piped_in, worth = False, True
+                maker = threading.Thread(target=make, name="pg-vcf-context", daemon=True)
+                maker.start()
             if maker is not None and (not maker.is_alive() or wait):
                 maker.join()
                 maker = None

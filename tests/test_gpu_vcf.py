@@ -38,7 +38,7 @@ def _run(src, out, argv, env, monkeypatch, device="1"):
 
 
 @pytest.mark.parametrize("name,src,argv", DEVICE_CASES, ids=[c[0] for c in DEVICE_CASES])
-@pytest.mark.parametrize("form", ["plain", "plain_3000", "bgzf_700_3000", "bgzf_65280"])
+@pytest.mark.parametrize("form", ["plain", "plain_3000", "bgzf_700_3000", "bgzf_65280", "gzip_stream_3000"])
 def test_goldens_through_the_device_parser(name, src, argv, form, tmp_path, monkeypatch):
     with gzip.open(os.path.join(GOLD, src + ".vcf.gz"), "rb") as f:
         text = f.read()
@@ -46,6 +46,10 @@ def test_goldens_through_the_device_parser(name, src, argv, form, tmp_path, monk
     if form.startswith("plain"):
         path = str(tmp_path / "in.vcf")
         with open(path, "wb") as f:
+            f.write(text)
+    elif form.startswith("gzip_stream"):                          # `gzip in.vcf`: ONE stream, inflated on the host, parsed on the device
+        path = str(tmp_path / "in.vcf.gz")
+        with gzip.open(path, "wb") as f:
             f.write(text)
     else:
         path = str(tmp_path / "in.vcf.gz")
@@ -217,3 +221,32 @@ def test_a_damaged_member_of_a_bgzipped_vcf_is_named(tmp_path, monkeypatch):
         f.write(comp)
     with pytest.raises((PopgenError, ValueError), match="member"):
         _run(path, str(tmp_path / "o.geno"), ["--skipIndels"], {"PG_STREAM_BYTES": "20000"}, monkeypatch)
+
+
+def test_a_piped_vcf_reaches_the_device_once_it_proves_large(tmp_path):
+    """`bcftools view ... | parseVCF.py`: no size to look at -- the device context is made when a first block of 32 MB has arrived whole, the
+    blocks before it go through the host parser; the rows are the host parser's"""
+    import json
+    import subprocess
+    src = str(tmp_path / "in.vcf")
+    _bench_vcf(src, 60000, 100)
+    assert os.path.getsize(src) > (80 << 20)
+    shim = os.path.join(ROOT, "VCF_processing", "parseVCF.py")
+    outs = {}
+    for dev in ("0", "1"):
+        out = str(tmp_path / ("o%s.geno" % dev))
+        env = dict(os.environ, PG_TIMING="1")
+        env.pop("PG_STREAM_BYTES", None)
+        if dev == "0":
+            env["PG_VCF_DEVICE"] = "0"
+        else:
+            env.pop("PG_VCF_DEVICE", None)
+            env["PG_VCF_WAIT_FOR_DEVICE"] = "1"                   # (the host parser would finish these 90 MB before the context exists)
+        with open(src, "rb") as f:
+            r = subprocess.run([sys.executable, shim, "--skipIndels", "--minQual", "30", "-o", out], stdin=f, env=env, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-500:]
+        tm = [json.loads(ln[10:]) for ln in r.stderr.decode().splitlines() if ln.startswith("PG_TIMING ")][-1]
+        with open(out, "rb") as f:
+            outs[dev] = (f.read(), tm)
+    assert outs["0"][0] == outs["1"][0]
+    assert outs["0"][1]["blocks_parsed_on_device"] == 0 and outs["1"][1]["blocks_parsed_on_device"] >= 1, outs["1"][1]
