@@ -3,10 +3,9 @@
 // compressor (pg_fast_deflate.h) was what the drop-in waited for once the device parsed the VCF (1.5 of 2.2 s on 16 CPUs).
 //
 //   k_deflate        a wavefront per member of 65 280 bytes of text (persistent: a wave takes member after member).
-//     matches        64 positions at a time, a lane each: the four bytes at the position are hashed into one of 256 buckets of the
-//                    EIGHT most recent places with that hash (LDS, 4 KB a wave) -- text written row by row repeats its cells so often
-//                    that a bucket's depth, not the number of buckets, decides the ratio (measured on `.geno` rows: depth 4 / 8 / 16
-//                    = 84 / 90 / 94 % of zlib level 6's ratio) -- plus the nearest earlier lane of the window with the same four bytes;
+//     matches        64 positions at a time, a lane each: the four bytes at the position are hashed into one of 256 buckets of the TWO
+//                    most recent places with that hash, its twelve bytes into one of 512 buckets of the EIGHT most recent (LDS, 9 KB a
+//                    wave; why two tables: see DF_WA / DF_WB below) -- plus the nearest earlier lane of the window in its 4-byte bucket;
 //                    every candidate is compared over sixteen bytes (two 8-byte loads from the text in HBM / L2), the best one kept.
 //                    Then the window is walked from its first uncovered position: a literal run up to the next lane with a match goes
 //                    out in one step (all lanes), a match of the full sixteen bytes is first extended by the WHOLE wave (lane k
@@ -30,14 +29,24 @@ int pg_launch_crc32_pieces(pg_ctx *c, hipStream_t st, const uint8_t *text, const
 
 namespace {
 
-constexpr int DF_W = 8;                       // places per bucket
-#ifndef PGD_HB
-#define PGD_HB 8
+// Two tables of recent places.  Text written row by row repeats a four-byte context so often that the last places of its hash all lie in
+// the same row; a twelve-byte context recurs seldom enough for its last eight places to reach the rows above.  Measured on 326 MB of
+// `.geno` rows against zlib level 6's bytes (profiles/r06/deflate_bench_table_depths.txt; correlated rows in brackets): eight places
+// per 4-byte hash alone 1.115 x (1.155 x) in 13.6 ms; two per 4-byte + four per 12-byte hash 1.073 x (1.13 x) in 13.7 ms; two + eight
+// 1.048 x (1.10 x) in 20.9 ms -- the default; four + eight 1.042 x in 27.8 ms.  A CPU prototype of the wave's algorithm settled the
+// shape first (racy insertion: -15 %; a row-above or last-distance candidate, lazy evaluation: nothing).
+#ifndef PGD_WA
+#define PGD_WA 2
 #endif
+#ifndef PGD_WB
+#define PGD_WB 8
+#endif
+constexpr int DF_WA = PGD_WA, DF_HBA = 8;     // places per bucket (2 or 4) / log2 buckets of the 4-byte contexts
+constexpr int DF_WB = PGD_WB, DF_HBB = 9;     // ... (4 or 8) of the 12-byte contexts
+constexpr int DF_NC = DF_WA + DF_WB + 1;      // candidates of a position: the buckets' places + the nearest earlier lane of its 4-byte group
 #ifndef PGD_WAVES
 #define PGD_WAVES 3
 #endif
-constexpr int DF_HB = PGD_HB;                     // 256 buckets: 4 KB of LDS a wave + 2 KB for the lanes' group masks (on `.geno` rows 256 ... 2048 buckets give the same ratio within 0.3 %; 2048 at one wave per SIMD 61 ms, 1024 at two 27, 512 at three 20 ms per 326 MB: profiles/r06/deflate_bench_*.json)
 constexpr uint32_t DF_PIECE = 65280;          // text per member (bgzip's)
 constexpr uint32_t DF_SLOT = 65536;           // bytes a member's deflate stream may take (stored: text + 5)
 constexpr uint32_t DF_MAXL = 256;             // longest match (the format's 258 would need a 65th dword in the wave's compare)
@@ -61,8 +70,9 @@ struct DfWork {
 };
 
 struct DfMatch {
-    uint32_t bucket[(1 << DF_HB) * DF_W / 2]; // the DF_W most recent places (+ 1, 16 bits each) of every hash
-    uint32_t grp[(1 << DF_HB) * 2];           // which lanes of the window at hand hash into a bucket (a bit per lane)
+    uint32_t bucketA[(1 << DF_HBA) * DF_WA / 2];   // the most recent places (+ 1, 16 bits each) of every hash
+    uint32_t bucketB[(1 << DF_HBB) * DF_WB / 2];
+    uint32_t grp[(1 << DF_HBB) * 2];               // which lanes of the window at hand hash into a bucket (a bit per lane); table A's, then table B's
 };
 
 struct DfShared {
@@ -289,8 +299,7 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         return n + 5;
     };
     if (n < 16) return stored();
-    for (int k = lane; k < (1 << DF_HB) * DF_W / 2; k += 64) sh.u.m.bucket[k] = 0;
-    for (int k = lane; k < (1 << DF_HB) * 2; k += 64) sh.u.m.grp[k] = 0;
+    for (int k = lane; k < (int)(sizeof(DfMatch) / 4); k += 64) reinterpret_cast<uint32_t *>(&sh.u.m)[k] = 0;
     for (int k = lane; k < 288; k += 64) sh.freq_ll[k] = 0;
     if (lane < 32) sh.freq_d[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -298,58 +307,72 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
     uint32_t nt = 0, pos = 0;
     for (uint32_t w0 = 0; w0 < n; w0 += 64) {
         const uint32_t p = w0 + (uint32_t)lane;
-        const bool inb = p + 4 <= n;
+        const bool inb = p + 4 <= n, inbB = p + 12 <= n;
         const uint32_t maxl = inb ? (n - p < DF_MAXL ? n - p : DF_MAXL) : 0u;
         uint64_t a0 = 0, a1 = 0;
         if (p < n) { a0 = ld64(in + p); a1 = ld64(in + p + 8); }          // (the text's buffer is readable 32 bytes past its end)
         const uint32_t v = (uint32_t)a0;
-        const uint32_t h = inb ? (v * 2654435761u) >> (32 - DF_HB) : 0x80000000u | (uint32_t)lane;
-        uint4 bk = make_uint4(0, 0, 0, 0);
-        if (inb) bk = *reinterpret_cast<const uint4 *>(&sh.u.m.bucket[h * (DF_W / 2)]);
+        const uint32_t hA = (v * 2654435761u) >> (32 - DF_HBA);
+        const uint32_t hB = (uint32_t)(((a0 * 0x9E3779B97F4A7C15ull) ^ ((a1 & 0xffffffffull) * 0xC2B2AE3D27D4EB4Full)) >> (64 - DF_HBB));
+        uint32_t bkA[DF_WA / 2], bkB[DF_WB / 2];                   // (two places a word)
+#pragma unroll
+        for (int k = 0; k < DF_WA / 2; ++k) bkA[k] = inb ? sh.u.m.bucketA[hA * (DF_WA / 2) + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < DF_WB / 2; ++k) bkB[k] = inbB ? sh.u.m.bucketB[hB * (DF_WB / 2) + k] : 0u;
         // the lanes of the window that share this lane's bucket, as a bit per lane: every lane sets its bit in the bucket's mask (LDS),
         // reads the mask back and clears it again -- a lane's rank in its group, the group's size and the nearest earlier lane of it
         // (a candidate like the bucket's: its bytes are compared) are three bit counts (the first version asked all 64 lanes for their
-        // hash, one v_readlane pair after the other: a third of the kernel's instructions)
-        unsigned long long gm = 0;
-        if (inb) atomicOr(&sh.u.m.grp[2 * h + ((uint32_t)lane >> 5)], 1u << ((uint32_t)lane & 31u));
+        // hash, one v_readlane pair after the other: a third of the kernel's instructions).  Table A, then table B in the same words.
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        unsigned long long gmA = 0, gmB = 0;
+        if (inb) atomicOr(&sh.u.m.grp[2 * hA + ((uint32_t)lane >> 5)], 1u << ((uint32_t)lane & 31u));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (inb) gm = (unsigned long long)sh.u.m.grp[2 * h] | ((unsigned long long)sh.u.m.grp[2 * h + 1] << 32);
+        if (inb) gmA = (unsigned long long)sh.u.m.grp[2 * hA] | ((unsigned long long)sh.u.m.grp[2 * hA + 1] << 32);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (inb) sh.u.m.grp[2 * h + ((uint32_t)lane >> 5)] = 0;
-        const unsigned long long lower = gm & ((1ull << lane) - 1ull);
-        const int rank = __popcll(lower), gsize = __popcll(gm);
-        const int close = lower ? 63 - __clzll((long long)lower) : -1;
+        if (inb) sh.u.m.grp[2 * hA + ((uint32_t)lane >> 5)] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (inbB) atomicOr(&sh.u.m.grp[2 * hB + ((uint32_t)lane >> 5)], 1u << ((uint32_t)lane & 31u));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (inbB) gmB = (unsigned long long)sh.u.m.grp[2 * hB] | ((unsigned long long)sh.u.m.grp[2 * hB + 1] << 32);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (inbB) sh.u.m.grp[2 * hB + ((uint32_t)lane >> 5)] = 0;
+        const int rankA = __popcll(gmA & lt), gsizeA = __popcll(gmA), rankB = __popcll(gmB & lt), gsizeB = __popcll(gmB);
+        const int close = (gmA & lt) ? 63 - __clzll((long long)(gmA & lt)) : -1;
         const uint32_t wend = w0 + 64 < n ? w0 + 64 : n;
         const bool need = pos < wend;                             // (a window inside a long match only enters its buckets)
         uint32_t bestL = 0, bestD = 0, capmask = 0;
-        const uint32_t q1s[9] = {bk.x & 0xffffu, bk.x >> 16, bk.y & 0xffffu, bk.y >> 16, bk.z & 0xffffu, bk.z >> 16, bk.w & 0xffffu, bk.w >> 16,
-                                 close >= 0 ? w0 + (uint32_t)close + 1u : 0u};
-        // two rounds of loads, the nine candidates' side by side (one after the other they cost a member 8.7 ms: eighteen trips to
+        uint32_t q1s[DF_NC];
+#pragma unroll
+        for (int k = 0; k < DF_WA; ++k) q1s[k] = k & 1 ? bkA[k / 2] >> 16 : bkA[k / 2] & 0xffffu;
+#pragma unroll
+        for (int k = 0; k < DF_WB; ++k) q1s[DF_WA + k] = k & 1 ? bkB[k / 2] >> 16 : bkB[k / 2] & 0xffffu;
+        q1s[DF_NC - 1] = close >= 0 ? w0 + (uint32_t)close + 1u : 0u;
+        // two rounds of loads, the candidates' side by side (one after the other they cost a member 8.7 ms: eighteen trips to
         // L2 / HBM per window in a row; profiles/r06/vcf_gz_to_gz_kernel_stats_first.csv)
-        bool ok[9];
-        uint32_t qq[9];
-        uint64_t m0[9], m1[9];
+        bool ok[DF_NC];
+        uint32_t qq[DF_NC];
+        uint64_t m0[DF_NC], m1[DF_NC];
         const uint32_t safe = p < n ? p : 0u;                        // (a lane without a candidate reads its own place: no branch around a load)
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
+        for (int c = 0; c < DF_NC; ++c) {
             ok[c] = need && inb && q1s[c] != 0 && p - (q1s[c] - 1) <= 32768u;
             qq[c] = ok[c] ? q1s[c] - 1 : safe;
         }
         if (need) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c) m0[c] = ld64(in + qq[c]);
+            for (int c = 0; c < DF_NC; ++c) m0[c] = ld64(in + qq[c]);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) m0[c] ^= a0;
+            for (int c = 0; c < DF_NC; ++c) m0[c] ^= a0;
 #pragma unroll
-            for (int c = 0; c < 9; ++c) m1[c] = ld64(in + qq[c] + 8);
+            for (int c = 0; c < DF_NC; ++c) m1[c] = ld64(in + qq[c] + 8);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) m1[c] ^= a1;
+            for (int c = 0; c < DF_NC; ++c) m1[c] ^= a1;
         } else {
 #pragma unroll
-            for (int c = 0; c < 9; ++c) m0[c] = m1[c] = ~0ull;
+            for (int c = 0; c < DF_NC; ++c) m0[c] = m1[c] = ~0ull;
         }
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
+        for (int c = 0; c < DF_NC; ++c) {
             if (ok[c]) {
                 const uint32_t d = p - (q1s[c] - 1);
                 uint32_t L;
@@ -404,7 +427,7 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
                         const int c = __ffs((int)cm) - 1;
                         uint32_t q1 = 0;
 #pragma unroll
-                        for (int k = 0; k < 9; ++k)
+                        for (int k = 0; k < DF_NC; ++k)
                             if (k == c) q1 = rl(q1s[k], l);
                         const uint32_t q = q1 - 1, d = pos - q;
                         uint32_t x = 1;
@@ -433,14 +456,23 @@ __device__ uint32_t df_member(const uint8_t *__restrict__ in, uint32_t n, uint8_
         }
         // ---- the window's positions into their buckets, most recent first: a lane's rank among the lanes of its bucket is its slot ----
         if (inb) {
-            uint16_t *b16 = reinterpret_cast<uint16_t *>(&sh.u.m.bucket[h * (DF_W / 2)]);
-            const int slot = gsize - 1 - rank;
-            if (slot < DF_W) b16[slot] = (uint16_t)(p + 1);
-            if (rank == gsize - 1 && gsize < DF_W) {                 // the group's last lane moves the old places back
-                const uint32_t old[8] = {bk.x & 0xffffu, bk.x >> 16, bk.y & 0xffffu, bk.y >> 16, bk.z & 0xffffu, bk.z >> 16, bk.w & 0xffffu, bk.w >> 16};
+            uint16_t *b16 = reinterpret_cast<uint16_t *>(&sh.u.m.bucketA[hA * (DF_WA / 2)]);
+            const int slot = gsizeA - 1 - rankA;
+            if (slot < DF_WA) b16[slot] = (uint16_t)(p + 1);
+            if (rankA == gsizeA - 1 && gsizeA < DF_WA) {             // the group's last lane moves the old places back
 #pragma unroll
-                for (int k = 0; k < DF_W; ++k)
-                    if (k + gsize < DF_W) b16[k + gsize] = (uint16_t)old[k];
+                for (int k = 0; k < DF_WA; ++k)
+                    if (k + gsizeA < DF_WA) b16[k + gsizeA] = (uint16_t)q1s[k];
+            }
+        }
+        if (inbB) {
+            uint16_t *b16 = reinterpret_cast<uint16_t *>(&sh.u.m.bucketB[hB * (DF_WB / 2)]);
+            const int slot = gsizeB - 1 - rankB;
+            if (slot < DF_WB) b16[slot] = (uint16_t)(p + 1);
+            if (rankB == gsizeB - 1 && gsizeB < DF_WB) {
+#pragma unroll
+                for (int k = 0; k < DF_WB; ++k)
+                    if (k + gsizeB < DF_WB) b16[k + gsizeB] = (uint16_t)q1s[DF_WA + k];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -586,7 +618,7 @@ int pg_deflate_queue(pg_ctx *c, hipStream_t st, pg_ctx::Deflate &D, const uint8_
         HIPCHK(hipGetDeviceProperties(&prop, c->device));
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int64_t waves = std::min<int64_t>(max_members, (int64_t)cus * 4 * PGD_WAVES);       // 11 KB of LDS and 168 registers a wave: three per SIMD
+    const int64_t waves = std::min<int64_t>(max_members, (int64_t)cus * 4 * PGD_WAVES);       // 14.6 KB of LDS and 168 registers a wave: ten per compute unit
     if ((rc = D.tok.ensure_roomy((size_t)waves * (65536 + 64))) != PG_OK) return rc;
     if ((rc = D.slots.ensure_roomy((size_t)max_members * DF_SLOT + 64)) != PG_OK) return rc;
     if ((rc = D.out_len.ensure_roomy((size_t)max_members)) != PG_OK) return rc;
