@@ -25,7 +25,7 @@ inline int pgv_make_config(int n_vcf_samples, int n_sel, const int32_t *sel_col,
     if (why) *why = none;
     if (n_sel < 0 || n_vcf_samples < 0 || (n_sel > 0 && (!sel_col || !sel_ploidy)) || n_filters < 0 || (n_filters > 0 && !filters)) return -1;
     auto no = [&](const char *w) { if (why) *why = w; return 0; };
-    if (n_filters > PGV_MAX_FILTERS) return no("more than four genotype filters");
+    if (n_filters > PGV_MAX_FILTERS) return no("more than eight genotype filters");
     if (n_vcf_samples < 1 || n_vcf_samples > PGV_MAX_VCF_SAMPLES) return no("no sample columns, or more than the device keeps tab positions for");
     if (n_sel < 1) return no("no selected sample");
     if (n_contig_bytes > (1 << 16)) return no("a contig list of more than 64 KiB");

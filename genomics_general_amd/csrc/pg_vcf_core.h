@@ -20,7 +20,7 @@
 #define PGV_HD inline
 #endif
 
-#define PGV_MAX_FILTERS 4
+#define PGV_MAX_FILTERS 8
 #define PGV_MAX_ALLELES 16
 #define PGV_FLAG_LEN 16
 

@@ -293,7 +293,7 @@ int check_slot(pg_ctx *c, int slot, const char *who) {
 }  // namespace
 
 // The option set of the run (the arguments of pg_encode_vcf, + the output's separator and --addRefTrack).  *taken_out = 0: the device
-// path does not take it (--excludeDuplicates, more than four genotype filters, ...: why_out names the reason); the caller then stays
+// path does not take it (more than eight genotype filters, ...: why_out names the reason); the caller then stays
 // on pg_encode_vcf.
 extern "C" int pg_vcf_dev_config(pg_ctx *c, int n_vcf_samples, int n_sel, const int32_t *sel_col, const int32_t *sel_ploidy, int flags,
                                  double min_qual, int max_ref_len, const pg_vcf_filter *filters, int n_filters, const char *contigs,

@@ -280,7 +280,7 @@ int pg_vcf_render_rows(const char *buf, int64_t n_rows, int n_sel, const int32_t
  * at most 16 alleles).  Replaces the same reference lines (VCF_processing/parseVCF.py:49-191, 367-370, 380-383).  A bgzipped VCF never
  * crosses PCIe as text: k_inflate writes it into the tokenizer's text slot, only the rows come back.
  *   pg_vcf_dev_config        the option set: pg_encode_vcf's arguments + the rows' separator and --addRefTrack.  *taken_out = 0 (with
- *                            *why_out, a static string): an option set the device does not take (> 4 genotype filters, > 14 000 sample
+ *                            *why_out, a static string): an option set the device does not take (> 8 genotype filters, > 14 000 sample
  *                            columns, ...) -- the caller stays on pg_encode_vcf.
  *   pg_vcf_dev_submit        a block of whole lines -> text slot `slot` (0 / 1): from memory, or len bytes at file_offset of fd
  *   pg_vcf_dev_submit_bgzf   the same for a block of BGZF members (table: pg_bgzf_walk; head = text the caller holds in front of them,

@@ -174,10 +174,10 @@ def test_option_sets_the_device_does_not_take_stay_on_the_host(tmp_path, monkeyp
     src = str(tmp_path / "in.vcf.gz")
     with gzip.open(os.path.join(GOLD, "main.vcf.gz"), "rb") as f, open(src, "wb") as g:
         g.write(genoio.bgzf_compress(f.read(), 6, 3000).tobytes())
-    argv = ["--skipIndels"] + [x for k in range(5) for x in ("--gtf", "flag=DP", "min=%d" % k)]         # five genotype filters
+    argv = ["--skipIndels"] + [x for k in range(9) for x in ("--gtf", "flag=DP", "min=%d" % k)]         # nine genotype filters
     got, info = _run(src, str(tmp_path / "o.geno"), argv, {"PG_VCF_WAIT_FOR_DEVICE": "1"}, monkeypatch)
     want, _ = _run(src, str(tmp_path / "h.geno"), argv, {}, monkeypatch, device="0")
-    assert got == want and info["blocks_parsed_on_device"] == 0 and "four genotype filters" in info.get("device_parser_not_taken", "")
+    assert got == want and info["blocks_parsed_on_device"] == 0 and "eight genotype filters" in info.get("device_parser_not_taken", "")
 
 
 def test_exclude_duplicates_over_block_seams_and_host_blocks(tmp_path, monkeypatch):

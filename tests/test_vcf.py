@@ -327,7 +327,7 @@ def _fuzz_vcf(rng, tmp):
         argv += ["--exclude", ",".join(contigs)]
     if rng.random() < 0.4:
         argv += ["--minQual", str(int(D.pick(rng, [0, 10, 30, 80])))]
-    for _ in range(int(D.pick(rng, [0, 0, 1, 1, 2, 3, 4]))):
+    for _ in range(int(D.pick(rng, [0, 0, 1, 1, 2, 3, 4, 7]))):
         g = ["--gtf", "flag=" + D.pick(rng, ["DP", "GQ", "AD", "XX"])]
         if rng.random() < 0.8:
             g += ["min=" + str(D.pick(rng, [1, 5, 20, 50, 7.5]))]
