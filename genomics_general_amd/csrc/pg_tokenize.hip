@@ -435,7 +435,10 @@ __device__ __forceinline__ uint32_t code32(uint32_t ch) {           // A 1, C 2,
     const uint32_t i = (ch >> 1) & 3u;                               // A 0, C 1, T 2, G 3
     return ch == ((0x47544341u >> (8u * i)) & 255u) ? (0x04080201u >> (8u * i)) & 255u : 0u;
 }
-template <int FMT>
+// NIT > 0: the layout has 64 * (NIT - 1) + 1 ... 64 * NIT columns -- a lane's NIT column-table entries stay in registers for all of its
+// wave's lines and a line's NIT loads leave together (the table read from LDS in front of every load made a line four trips one after
+// the other: 0.70 ms per GiB of text at a quarter of what its bytes cost); NIT = 0: any number of columns, the table read per step
+template <int FMT, int NIT>
 __global__ __launch_bounds__(256) void k_tok_cells3(const uint8_t *__restrict__ text, const int64_t *__restrict__ cells_at_in, int64_t n_lines,
                                                     int n_cols, int max_ploidy, const int32_t *__restrict__ dcols, int8_t *__restrict__ rows, int S,
                                                     int32_t *__restrict__ status, DipTable dip) {
@@ -468,21 +471,42 @@ __global__ __launch_bounds__(256) void k_tok_cells3(const uint8_t *__restrict__ 
     const int n_it = (n_cols + 63) >> 6, n_dw = S >> 2, n_dwit = (n_dw + 63) >> 6;
     const int dump = S + lane;
     uint32_t badv = 0u;
+    int4 ev[NIT > 0 ? NIT : 1];
+    if (NIT > 0) {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int c0 = lane + 64 * j;
+            ev[j] = ctab[c0 < n_cols ? c0 : n_cols - 1];
+        }
+    }
+    // (NIT > 0) the NEXT line's bytes are asked for before this line's are worked on
+    uint32_t wn[NIT > 0 ? NIT : 1];
+    auto ask = [&](int r) {
+        const int64_t at = ((int64_t)__builtin_amdgcn_readlane(ca_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane(ca_lo, r);
+        if (at >= 0) {
+#pragma unroll
+            for (int j = 0; j < (NIT > 0 ? NIT : 1); ++j) __builtin_memcpy(&wn[j], text + at + ev[j].x, 4);
+        }
+    };
+    if (NIT > 0) ask(0);
     for (int r = 0; r < n_here; ++r) {
         const int64_t row = row0 + r;
         const int64_t cells_at = ((int64_t)__builtin_amdgcn_readlane(ca_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane(ca_lo, r);
+        uint32_t wv[NIT > 0 ? NIT : 1];
+        if (NIT > 0) {
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) wv[j] = wn[j];
+            if (r + 1 < n_here) ask(r + 1);
+        }
         for (int j = 0; j < n_dwit; ++j) {
             const int k = lane + 64 * j;
             reinterpret_cast<uint32_t *>(lrow)[k < n_dw ? k : n_dw - 1] = 0u;
         }
         if (cells_at >= 0) {                              // (uniform)
             const uint8_t *cells = text + cells_at;
-            for (int j = 0; j < n_it; ++j) {
-                const int c0 = lane + 64 * j, c = c0 < n_cols ? c0 : n_cols - 1;
-                const int4 e = ctab[c];
+            // one step: the cell of column c (table entry e, the four bytes w4 at its place) into the row
+            auto step = [&](int c, const int4 e, uint32_t w4) {
                 const uint32_t cellw = (uint32_t)e.y & 255u, pl = (uint32_t)e.y >> 8;
-                uint32_t w4;
-                __builtin_memcpy(&w4, cells + e.x, 4);
                 const uint32_t b0 = w4 & 255u, b1 = (w4 >> 8) & 255u, b2 = (w4 >> 16) & 255u, b3 = w4 >> 24;
                 const uint32_t sep = cellw == 1u ? b1 : cellw == 2u ? b2 : b3;
                 badv |= ((uint32_t)(c + 1 < n_cols) & (blank32(sep) ^ 1u)) | blank32(b0) | ((uint32_t)(cellw > 1u) & blank32(b1)) |
@@ -504,6 +528,21 @@ __global__ __launch_bounds__(256) void k_tok_cells3(const uint8_t *__restrict__ 
                 lrow[pl > 0u ? s0 : dump] = (uint8_t)x0;
                 lrow[pl > 1u ? s1 : dump] = (uint8_t)x1;
                 if (FMT == PG_FMT_PAIRS) lrow[pl > 2u ? e.w : dump] = (uint8_t)x2;
+            };
+            if (NIT > 0) {                                // (launched with NIT == n_it)
+#pragma unroll
+                for (int j = 0; j < NIT; ++j) {
+                    const int c0 = lane + 64 * j;
+                    step(c0 < n_cols ? c0 : n_cols - 1, ev[j], wv[j]);
+                }
+            } else {
+                for (int j = 0; j < n_it; ++j) {
+                    const int c0 = lane + 64 * j, c = c0 < n_cols ? c0 : n_cols - 1;
+                    const int4 e = ctab[c];
+                    uint32_t w4;
+                    __builtin_memcpy(&w4, cells + e.x, 4);
+                    step(c, e, w4);
+                }
             }
         }
         // (LDS operations of a wavefront execute in order: the reads below see the bytes scattered above)
@@ -957,12 +996,24 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
         const size_t lds3 = (size_t)n_cols * 16 + 256 + 4 * ((size_t)c->S + 64);
         static const bool general_cells = getenv("PG_TOK_PARSE") && atoi(getenv("PG_TOK_PARSE")) == 2;      // (A/B, tests)
         if (widest <= 3 && lds3 <= 60 * 1024 && !general_cells) {
-#define PG_CELLS3(F) hipLaunchKernelGGL((k_tok_cells3<F>), grid, dim3(256), lds3, st, T.tp, T.cells_at.p, n_lines, n_cols, max_ploidy, T.dcols.p, \
-                                        c->gt.p + row_offset * c->S, c->S, d_status, dip)
+#define PG_CELLS3N(F, N) hipLaunchKernelGGL((k_tok_cells3<F, N>), grid, dim3(256), lds3, st, T.tp, T.cells_at.p, n_lines, n_cols, max_ploidy, T.dcols.p, \
+                                            c->gt.p + row_offset * c->S, c->S, d_status, dip)
+            // (a lane's column-table entries in registers for layouts of up to 256 columns; PG_TOK_CELLS_REGS=0: the table read per step)
+            static const bool in_regs = !(getenv("PG_TOK_CELLS_REGS") && atoi(getenv("PG_TOK_CELLS_REGS")) == 0);
+            const int nit = (n_cols + 63) / 64;
+#define PG_CELLS3(F)                                         \
+    do {                                                     \
+        if (!in_regs || nit > 4) PG_CELLS3N(F, 0);           \
+        else if (nit == 1) PG_CELLS3N(F, 1);                 \
+        else if (nit == 2) PG_CELLS3N(F, 2);                 \
+        else if (nit == 3) PG_CELLS3N(F, 3);                 \
+        else PG_CELLS3N(F, 4);                               \
+    } while (0)
             if (T.fmt == PG_FMT_DIPLO) PG_CELLS3(PG_FMT_DIPLO);
             else if (T.fmt == PG_FMT_PHASED) PG_CELLS3(PG_FMT_PHASED);
             else PG_CELLS3(PG_FMT_PAIRS);                 // pairs and haplo: an allele per character
 #undef PG_CELLS3
+#undef PG_CELLS3N
         } else {
             hipLaunchKernelGGL(k_tok_cells, grid, dim3(256), lds_bytes, st, T.tp, T.cells_at.p,
                                n_lines, T.fmt, n_cols, max_ploidy, T.dcols.p, c->gt.p + row_offset * c->S, c->S, d_status, dip);
