@@ -198,6 +198,8 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
         if (T.counted) (void)hipEventDestroy(T.counted);
         if (T.staged) (void)hipEventDestroy(T.staged);
         if (T.parsed) (void)hipEventDestroy(T.parsed);
+        if (T.heads_done) (void)hipEventDestroy(T.heads_done);
+        if (T.pos_copied) (void)hipEventDestroy(T.pos_copied);
     }
     c->deflate.release();
     c->vcf.prevkey.release(); c->vcf.contigs.release(); c->vcf.ploidy.release(); c->vcf.fsel.release(); c->vcf.sel_col.release(); c->vcf.cell_off.release();

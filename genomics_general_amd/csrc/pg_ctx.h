@@ -143,6 +143,8 @@ struct pg_ctx {
         HostPin<int32_t> h_cols;
         std::vector<int32_t> cols;         // col_slot | col_ploidy | cell offsets | cell widths of the submitted block
         hipEvent_t counted = nullptr, staged = nullptr, parsed = nullptr;   // line feeds counted / deflated bytes on the device / rows, positions, status there
+        hipEvent_t heads_done = nullptr, pos_copied = nullptr;              // k_tok_heads finished / the positions are on the host (copied on the small stream)
+        bool pos_pending = false;
         int state = 0;                     // 0 idle, 1 empty block, 2 submitted, 3 parse queued, 4 empty result
         int fmt = 0, n_cols = 0, max_ploidy = 0, cells_w = 0;
         int64_t len = 0, n_lines = 0, n_tiles = 0, run_cap = 0;

@@ -985,10 +985,24 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
         auto code = [](char ch) { return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 4 : ch == 'T' ? 8 : 0; };
         for (int k = 0; d[k]; ++k) dip.v[(int)d[k]] = (uint8_t)(code(pr[k][0]) | (code(pr[k][1]) << 4));
     }
+    bool pos_on_small = false;
     if (second_form) {
         if ((rc = T.cells_at.ensure_roomy((size_t)n_lines + 8)) != PG_OK) return rc;
         hipLaunchKernelGGL(k_tok_heads, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, T.tp, T.nl.p, n_lines, T.cells_w,
                            T.pos64.p, T.cells_at.p, T.off.p, T.off.p + run_cap, T.pos.p, d_status + 1, run_cap, d_status);
+        // the positions (8 bytes a line: 10 MB per GiB of text, 0.45 ms of a blit kernel) leave on the small stream as soon as k_tok_heads
+        // has them, beside the cell kernel -- on the copy stream they stood between this block's cells and the next block's k_inflate
+        static const bool pos_aside = !(getenv("PG_TOK_POS_STREAM") && atoi(getenv("PG_TOK_POS_STREAM")) == 0);
+        if (pos_aside) {
+            if (!c->tok_small) HIPCHK(hipStreamCreateWithFlags(&c->tok_small, hipStreamNonBlocking));
+            if (!T.heads_done) HIPCHK(hipEventCreateWithFlags(&T.heads_done, hipEventDisableTiming));
+            if (!T.pos_copied) HIPCHK(hipEventCreateWithFlags(&T.pos_copied, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(T.heads_done, st));
+            HIPCHK(hipStreamWaitEvent(c->tok_small, T.heads_done, 0));
+            HIPCHK(hipMemcpyAsync(T.h_pos.p, T.pos64.p, (size_t)n_lines * 8, hipMemcpyDeviceToHost, c->tok_small));
+            HIPCHK(hipEventRecord(T.pos_copied, c->tok_small));
+            pos_on_small = true;
+        }
         const int64_t per_block = 4 * TOK_LPW;
         const dim3 grid((unsigned)((n_lines + per_block - 1) / per_block));
         int widest = 0;
@@ -1031,7 +1045,8 @@ static int tok_parse(pg_ctx *c, int slot, int64_t row_offset, int64_t row_capaci
         HIPCHK(hipMemcpyAsync(T.h_total.p + 4, T.inf.status.p + 2, 8, hipMemcpyDeviceToHost, st));   // read by collect
     }
     HIPCHK(hipMemcpyAsync(T.h_total.p + 1, d_status, 8, hipMemcpyDeviceToHost, st));            // status | runs, as two int32
-    HIPCHK(hipMemcpyAsync(T.h_pos.p, T.pos64.p, (size_t)n_lines * 8, hipMemcpyDeviceToHost, st));
+    if (!pos_on_small) HIPCHK(hipMemcpyAsync(T.h_pos.p, T.pos64.p, (size_t)n_lines * 8, hipMemcpyDeviceToHost, st));
+    T.pos_pending = pos_on_small;
     if (!T.parsed) HIPCHK(hipEventCreateWithFlags(&T.parsed, hipEventDisableTiming));
     HIPCHK(hipEventRecord(T.parsed, st));                            // (collect waits for THIS, not for what the next block has queued behind it)
     T.state = 3;
@@ -1062,6 +1077,10 @@ static int tok_collect(pg_ctx *c, int slot, int64_t *pos_out, int64_t pos_capaci
     // go on while the host turns this block into windows
     if (T.parsed) HIPCHK(hipEventSynchronize(T.parsed));
     else HIPCHK(hipStreamSynchronize(c->stream_up));
+    if (T.pos_pending) {
+        HIPCHK(hipEventSynchronize(T.pos_copied));
+        T.pos_pending = false;
+    }
     if (!c->tok_small) HIPCHK(hipStreamCreateWithFlags(&c->tok_small, hipStreamNonBlocking));
     hipStream_t st = c->tok_small;
     const int64_t n_lines = T.n_lines;
