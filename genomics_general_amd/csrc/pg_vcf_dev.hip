@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void k_vcf_heads(const uint8_t *__restrict__ t
 
 // the CHROM and POS tokens of the block's last data line -> *key (what the next block's first lines are held against); a block
 // without a data line leaves the key as it is
-__global__ void k_vcf_lastkey(const uint8_t *__restrict__ text, const int64_t *__restrict__ nl, int64_t n_lines, PgvKey *__restrict__ key) {
+// (a last data line the key cannot hold -- an irregular spelling, tokens of more than PGV_KEY_MAX characters -- sends ITS block to the
+// host parser too, so that the host holds the key the device lacks)
+__global__ void k_vcf_lastkey(const uint8_t *__restrict__ text, const int64_t *__restrict__ nl, int64_t n_lines, PgvKey *__restrict__ key,
+                              long long *__restrict__ status) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int64_t i = n_lines - 1; i >= 0; --i) {
         const int64_t ls = i ? nl[i - 1] + 1 : 0;
@@ -89,6 +92,7 @@ __global__ void k_vcf_lastkey(const uint8_t *__restrict__ text, const int64_t *_
         if (r == 1) continue;
         if (r == 2 || cl > PGV_KEY_MAX || pl > PGV_KEY_MAX) {
             key->chrom_len = PGV_KEY_UNKNOWN;
+            raise_host(status, i);
             return;
         }
         key->chrom_len = cl;
@@ -360,7 +364,8 @@ extern "C" int pg_vcf_dev_set_prev(pg_ctx *c, const char *chrom, int chrom_len, 
 }
 
 // the key the block collected from `slot` started from (for a block that goes to the host parser under --excludeDuplicates):
-// *chrom_len_out < 0: none.  chrom_out / pos_out: PGV_KEY_MAX (120) bytes each
+// *chrom_len_out == -1: none; -2: a line the key could not hold -- the block it ended went to the host parser for that reason, whose
+// last key the caller has.  chrom_out / pos_out: PGV_KEY_MAX (120) bytes each
 extern "C" int pg_vcf_dev_prev(pg_ctx *c, int slot, char *chrom_out, int *chrom_len_out, char *pos_out, int *pos_len_out) {
     int rc = check_slot(c, slot, "pg_vcf_dev_prev");
     if (rc != PG_OK) return rc;
@@ -368,7 +373,10 @@ extern "C" int pg_vcf_dev_prev(pg_ctx *c, int slot, char *chrom_out, int *chrom_
     const PgvKey *key = reinterpret_cast<const PgvKey *>(c->vcf.s[slot].h_prev.p);
     *chrom_len_out = *pos_len_out = -1;
     if (!key || key->chrom_len == PGV_KEY_NONE) return PG_OK;
-    if (key->chrom_len == PGV_KEY_UNKNOWN) return pg_fail(PG_ERR_STATE, "pg_vcf_dev_prev: the data line before the block has tokens of more than 120 characters");
+    if (key->chrom_len == PGV_KEY_UNKNOWN) {                     // the block before went to the host parser because of that very line: the caller holds its key
+        *chrom_len_out = *pos_len_out = -2;
+        return PG_OK;
+    }
     *chrom_len_out = (int)key->chrom_len;
     *pos_len_out = (int)key->pos_len;
     memcpy(chrom_out, key->chrom, key->chrom_len);
@@ -453,7 +461,7 @@ extern "C" int pg_vcf_dev_parse(pg_ctx *c, int slot) {
     hipLaunchKernelGGL(k_vcf_heads, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, T.tp, T.nl.p, n_lines, D.cfg, D.contigs.p, lines,
                        V.rlen.p, status, prev);
     if (D.cfg.flags & PGV_EXCLUDE_DUPLICATES)
-        hipLaunchKernelGGL(k_vcf_lastkey, dim3(1), dim3(64), 0, st, T.tp, T.nl.p, n_lines, reinterpret_cast<PgvKey *>(D.prevkey.p));
+        hipLaunchKernelGGL(k_vcf_lastkey, dim3(1), dim3(64), 0, st, T.tp, T.nl.p, n_lines, reinterpret_cast<PgvKey *>(D.prevkey.p), status);
     const int wpb = D.waves_per_block;
     const dim3 grid((unsigned)((n_lines + wpb - 1) / wpb));
     const size_t lds = (size_t)wpb * (size_t)D.cfg.n_vcf_samples * 4;

@@ -347,10 +347,13 @@ class Engine:
         check(self._L.pg_vcf_dev_set_prev(self._h, chrom, len(chrom or b""), pos, len(pos or b"")))
 
     def vcf_prev(self, slot):
-        """(CHROM, POS) tokens of the data line before the block collected from `slot`, or (None, None)"""
+        """(CHROM, POS) tokens of the data line before the block collected from `slot`, (None, None) when there is none, or None: the
+        block before ended in a line the device's key could not hold and went to the host parser for it -- the caller has its key"""
         a, b = C.create_string_buffer(128), C.create_string_buffer(128)
         na, nb = C.c_int(-1), C.c_int(-1)
         check(self._L.pg_vcf_dev_prev(self._h, int(slot), a, C.byref(na), b, C.byref(nb)))
+        if na.value == -2:
+            return None
         return (None, None) if na.value < 0 else (a.raw[:na.value], b.raw[:nb.value])
 
     def vcf_parse(self, slot):

@@ -763,7 +763,9 @@ def parse_vcf_main(argv=None):
             timing["blocks_handed_to_the_host_parser"] = timing.get("blocks_handed_to_the_host_parser", 0) + 1
             timing.setdefault("first_line_handed_over", int(line))
         if args.excludeDuplicates:                               # (the data line before this block: the device carried it)
-            state["prev_chrom"], state["prev_pos"] = eng.vcf_prev(slot)
+            key = eng.vcf_prev(slot)
+            if key is not None:                                  # (None: the block before was the host's for its last line -- its key is in `state`)
+                state["prev_chrom"], state["prev_pos"] = key
         host_block(eng.vcf_text(slot, len(raw)) if isinstance(raw, genoio.BgzfSpan) else raw)
 
     # the device's parser takes text output without --packed (rows as text are what it makes)

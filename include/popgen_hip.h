@@ -297,7 +297,7 @@ int pg_vcf_dev_config(pg_ctx *ctx, int n_vcf_samples, int n_sel, const int32_t *
 /* --excludeDuplicates (parseVCF.py:367: a line against the DATA line before it): the device carries the CHROM / POS tokens of the last
  * data line from block to block itself (k_vcf_lastkey); pg_vcf_dev_set_prev hands it the key of blocks the HOST parsed before the next
  * submit (chrom == NULL: none), pg_vcf_dev_prev returns the key the block collected from `slot` started from (120 bytes each; a
- * length < 0: none) -- what pg_encode_vcf needs as prev_chrom / prev_pos when that block goes to it. */
+ * length of -1: none; -2: the block before ended in a line the key could not hold and went to the host parser for it: the caller has that key) -- what pg_encode_vcf needs as prev_chrom / prev_pos when that block goes to it. */
 int pg_vcf_dev_set_prev(pg_ctx *ctx, const char *chrom, int chrom_len, const char *pos, int pos_len);
 int pg_vcf_dev_prev(pg_ctx *ctx, int slot, char *chrom_out, int *chrom_len_out, char *pos_out, int *pos_len_out);
 int pg_vcf_dev_submit(pg_ctx *ctx, int slot, const char *text, int fd, int64_t file_offset, int64_t len);

@@ -250,3 +250,25 @@ def test_a_piped_vcf_reaches_the_device_once_it_proves_large(tmp_path):
             outs[dev] = (f.read(), tm)
     assert outs["0"][0] == outs["1"][0]
     assert outs["0"][1]["blocks_parsed_on_device"] == 0 and outs["1"][1]["blocks_parsed_on_device"] >= 1, outs["1"][1]
+
+
+def test_exclude_duplicates_when_a_block_ends_in_a_line_only_the_host_reads(tmp_path, monkeypatch):
+    """--excludeDuplicates: the LAST data line of a block has a spelling the device does not take, or tokens its key cannot hold, and the
+    next block starts with its duplicate: the first block goes to the host parser for that line, and the second -- whose first line the
+    device cannot judge -- follows it with the host's key.  Blocks of one line each (PG_STREAM_BYTES=1)."""
+    def line(chrom, pos, sep=b"\t"):
+        return chrom + b"\t" + pos + sep + b".\tA\tC\t50\tPASS\t.\tGT\t0/1\t1/1"
+    for chrom, sep in ((b"chr1", b" "), (b"c" * 130, b"\t")):
+        lines = [line(b"chr1", b"%d" % (100 + k)) for k in range(30)]
+        lines[9] = line(chrom, b"109", sep)
+        lines[10] = line(chrom, b"109")                           # its duplicate, regular in every other way
+        lines[11] = line(chrom, b"109")                           # and another
+        head = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\tb\n"
+        path = str(tmp_path / "in.vcf")
+        with open(path, "wb") as f:
+            f.write(head + b"\n".join(lines) + b"\n")
+        env = {"PG_STREAM_BYTES": "1"}
+        want, _ = _run(path, str(tmp_path / "host.geno"), ["--excludeDuplicates"], env, monkeypatch, device="0")
+        got, info = _run(path, str(tmp_path / "dev.geno"), ["--excludeDuplicates"], env, monkeypatch)
+        assert got == want and want.count(b"\n") == 1 + 28, want.count(b"\n")     # (header + 30 lines - the two duplicates)
+        assert info["stats"][1] >= 2, info                         # the irregular block and the one behind it
