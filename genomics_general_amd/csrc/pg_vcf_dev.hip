@@ -438,6 +438,10 @@ extern "C" int pg_vcf_dev_parse(pg_ctx *c, int slot) {
     V.h_status.p[0] = V.no_final_newline || n_lines == 0 ? PGV_ST_HOST : 0;     // (no line feed at all: one unfinished line)
     V.h_status.p[1] = V.no_final_newline || n_lines == 0 ? 0 : 0x7fffffffffffffffll;
     V.h_status.p[2] = V.h_status.p[3] = V.h_status.p[4] = 0;
+    if (D.cfg.flags & PGV_EXCLUDE_DUPLICATES) {                  // (the key this block starts from, for a block that goes to the host after all)
+        if ((rc = V.h_prev.ensure(sizeof(PgvKey))) != PG_OK) return rc;
+        HIPCHK(hipMemcpyAsync(V.h_prev.p, D.prevkey.p, sizeof(PgvKey), hipMemcpyDeviceToHost, st));
+    }
     if (V.h_status.p[0]) {                                       // nothing to queue: collect reports the block as the host's
         V.state = 2;
         HIPCHK(hipEventRecord(V.done, st));
@@ -454,10 +458,6 @@ extern "C" int pg_vcf_dev_parse(pg_ctx *c, int slot) {
     PgvLine *lines = reinterpret_cast<PgvLine *>(V.lines.p);
     long long *status = reinterpret_cast<long long *>(V.status.p);
     const PgvKey *prev = reinterpret_cast<const PgvKey *>(D.prevkey.p);
-    if (D.cfg.flags & PGV_EXCLUDE_DUPLICATES) {                  // (the key this block starts from, for a block that goes to the host after all)
-        if ((rc = V.h_prev.ensure(sizeof(PgvKey))) != PG_OK) return rc;
-        HIPCHK(hipMemcpyAsync(V.h_prev.p, D.prevkey.p, sizeof(PgvKey), hipMemcpyDeviceToHost, st));
-    }
     hipLaunchKernelGGL(k_vcf_heads, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, T.tp, T.nl.p, n_lines, D.cfg, D.contigs.p, lines,
                        V.rlen.p, status, prev);
     if (D.cfg.flags & PGV_EXCLUDE_DUPLICATES)

@@ -272,3 +272,20 @@ def test_exclude_duplicates_when_a_block_ends_in_a_line_only_the_host_reads(tmp_
         got, info = _run(path, str(tmp_path / "dev.geno"), ["--excludeDuplicates"], env, monkeypatch)
         assert got == want and want.count(b"\n") == 1 + 28, want.count(b"\n")     # (header + 30 lines - the two duplicates)
         assert info["stats"][1] >= 2, info                         # the irregular block and the one behind it
+
+
+def test_exclude_duplicates_on_a_last_line_without_a_line_feed(tmp_path, monkeypatch):
+    """the file's last line has no line feed (that block is the host's) and repeats the line before it, which the device parsed in
+    another block: the host parser gets the device's key"""
+    def line(pos):
+        return b"chr1\t%d\t.\tA\tC\t50\tPASS\t.\tGT\t0/1\t1/1" % pos
+    lines = [line(100 + k) for k in range(12)] + [line(111)]
+    head = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\tb\n"
+    path = str(tmp_path / "in.vcf")
+    with open(path, "wb") as f:
+        f.write(head + b"\n".join(lines))                         # (no line feed behind the last line)
+    env = {"PG_STREAM_BYTES": "1"}
+    want, _ = _run(path, str(tmp_path / "host.geno"), ["--excludeDuplicates"], env, monkeypatch, device="0")
+    got, info = _run(path, str(tmp_path / "dev.geno"), ["--excludeDuplicates"], env, monkeypatch)
+    assert got == want and want.count(b"\n") == 1 + 12
+    assert info["stats"][1] == 1, info
