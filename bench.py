@@ -1043,6 +1043,11 @@ def main():
         eng.reserve(max(n_sites, 1) + extra_rows)
         if n_sites:
             eng.synth_fill(0, n_sites, first, synth.SEED_DEFAULT, scaf_len, n_dip, n_pops, slot_gen, synth.VAR_THR, synth.MISS_THR)
+            if eng.plane_placement is not None and wl["tool"] in ("popgen", "distmat"):
+                # a resident data set of 4 GiB and more (reserve() chose among placements of the rows and, on the empty rows, of the
+                # planes): the planes chosen once more on the rows as the passes will read them (PG_PLANE_TRIALS=1: no such choices)
+                d["planes_on_empty_rows"] = eng.plane_placement
+                eng.tune_planes(n_sites, min(8, 2 * int(os.environ.get("PG_PLANE_TRIALS", "4"))), wl["wind"])
         good = T.sites >= wl["min_sites"]
         d.update(n_sites=n_sites, lo=T.lo[good], hi=T.hi[good], n_win=int(good.sum()), sites_per_step=int((T.hi[good] - T.lo[good]).sum()))
         return d
@@ -1238,6 +1243,15 @@ def main():
         extra["placement_trials"] = {"probe_ms": eng.placement[0], "kept": eng.placement[1],
                                      "note": "reserve() tried these physical placements of the resident rows (empty) and kept the "
                                              "one the pack + pair path streams fastest from; PG_PLACE_TRIALS=1 takes the first"}
+        if getattr(eng, "plane_placement", None):
+            extra["placement_trials"]["planes_probe_ms"] = eng.plane_placement[0]
+            extra["placement_trials"]["planes_kept"] = eng.plane_placement[1]
+            if data.get("planes_on_empty_rows"):
+                extra["placement_trials"]["planes_probe_ms_on_empty_rows"] = data["planes_on_empty_rows"][0]
+            extra["placement_trials"]["planes_note"] = ("then, with the rows where they are, sets of the planes the pack kernel writes "
+                                                        "(pg_tune_planes): by reserve() on the empty rows, and once more on the filled rows "
+                                                        "(planes_probe_ms: ms per pass on each set; candidate 0 = the set chosen on the empty "
+                                                        "rows); all of it before the warm-up, PG_PLANE_TRIALS=1 keeps the first set")
     extra["kernel_ms_per_step"] = {rocprof_name.get(kid, k): round(kt[k][0] / n_warm, 4)
                                    for kid, k in _lib.KERNEL_NAMES.items() if kt[k][1] > 0}
     if deferred:

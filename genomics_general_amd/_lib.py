@@ -52,6 +52,7 @@ SIGNATURES = {
     "pg_np_tree": (C.c_int, [C.c_int, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
     "pg_reserve_sites": (C.c_int, [_P, C.c_int64]),
     "pg_reserve_sites_tuned": (C.c_int, [_P, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pg_tune_planes": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pg_upload_sites": (C.c_int, [_P, C.c_int64, _i8p, C.c_int64]),
     "pg_download_sites": (C.c_int, [_P, C.c_int64, _i8p, C.c_int64]),
     "pg_row_pitch": (C.c_int, [_P, C.POINTER(C.c_int)]),

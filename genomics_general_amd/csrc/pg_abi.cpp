@@ -1041,6 +1041,102 @@ extern "C" int pg_reserve_sites_tuned(pg_ctx *c, int64_t n_sites, int max_trials
     return PG_OK;
 }
 
+// ---- placement of the planes ------------------------------------------------------------------------------------------------------
+// The other half of the pair: with the rows where they are, the pack kernel's time still moves by up to 4 % with the pages behind the
+// planes it writes (tools/pack_placement2.py: 7.81 -> 7.54, 7.55 -> 7.87 ms when only the planes were allocated again).  Planes are
+// cheap to try -- a few GB, nothing to fill: up to max_trials (<= 8) sets of them are held together, the regular pack + pair path over
+// windows of window_sites (<= 0: 50 000) of the resident rows (empty or not: the rows are only read) is timed on each, the fastest set
+// stays in the slots.  The choice made on empty rows carries over to the filled ones only in part (tools/plane_placement.py: 1 % against
+// 1.5 - 3 % for a choice made on the rows as they are), so a caller with a long-lived data set calls this once the rows are loaded.  Candidate 0 = the planes the context holds when called.  Later passes of that shape or a smaller one keep the set (buffers only grow).
+extern "C" int pg_tune_planes(pg_ctx *c, int64_t n_sites, int64_t window_sites, int max_trials, double *probe_ms_out, int *n_trials_out,
+                              int *chosen_out) {
+    if (!c) return pg_fail(PG_ERR_ARG, "null ctx");
+    if (n_trials_out) *n_trials_out = 0;
+    if (chosen_out) *chosen_out = -1;
+    if (c->n_hap <= 0) return pg_fail(PG_ERR_STATE, "pg_set_samples must be called first");
+    if (n_sites < 1 || n_sites > c->cap_sites) return pg_fail(PG_ERR_ARG, "pg_tune_planes: n_sites must lie inside the reservation");
+    HIPCHK(hipSetDevice(c->device));
+    const int trials = std::min(max_trials, 8);
+    if (trials < 2) return PG_OK;
+    const int64_t wind = window_sites > 0 ? window_sites : 50000;
+    if ((n_sites + wind - 1) / wind > (1 << 24)) return pg_fail(PG_ERR_ARG, "pg_tune_planes: more than 2^24 windows");
+    const int n_win = (int)((n_sites + wind - 1) / wind);
+    std::vector<int64_t> lo((size_t)n_win), hi((size_t)n_win);
+    for (int w = 0; w < n_win; ++w) { lo[(size_t)w] = w * wind; hi[(size_t)w] = std::min<int64_t>(n_sites, (w + 1) * wind); }
+    struct Set { DevBuf<uint32_t> Vp[2], XV[2]; };
+    std::vector<Set> cand((size_t)trials);
+    auto take = [&](Set &s) {                                 // the slots' planes -> s (plain pointers; the slots are left without)
+        for (int k = 0; k < 2; ++k) {
+            s.Vp[k] = c->slot[k].Vp;
+            s.XV[k] = c->slot[k].XV;
+            c->slot[k].Vp = DevBuf<uint32_t>();
+            c->slot[k].XV = DevBuf<uint32_t>();
+        }
+    };
+    auto give = [&](Set &s) {
+        for (int k = 0; k < 2; ++k) {
+            c->slot[k].Vp = s.Vp[k];
+            c->slot[k].XV = s.XV[k];
+            s.Vp[k] = DevBuf<uint32_t>();
+            s.XV[k] = DevBuf<uint32_t>();
+        }
+    };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        return pg_fail(PG_ERR_HIP, "hipEventCreate");
+    }
+    const uint32_t saved_mask = c->time_mask;
+    c->time_mask = 0;                                         // the probe's launches are not the caller's statistics
+    int rc = PG_OK, best = -1, tried = 0;
+    double best_ms = 0.0;
+    size_t set_bytes = 0;
+    for (int t = 0; t < trials && rc == PG_OK; ++t) {
+        // (t > 0: the slots hold no planes, pairwise_run's ensure() allocates a fresh set beside the ones held in cand[])
+        if (t > 0) {                                          // room for one more set, twice over, and 8 GiB to spare -- or stop here
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * set_bytes + ((size_t)8 << 30)) break;
+        }
+        float ms = 0.0f, fastest = 0.0f;
+        for (int pass = 0; pass < 3 && rc == PG_OK; ++pass) {                 // the first pass allocates; the faster of the next two counts
+            if (hipEventRecord(e0, c->stream) != hipSuccess) { rc = pg_fail(PG_ERR_HIP, "hipEventRecord"); break; }
+            rc = pairwise_run(c, lo.data(), hi.data(), n_win, [](int, int) -> int { return PG_OK; });
+            if (rc != PG_OK) break;
+            if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = pg_fail(PG_ERR_HIP, "probe timing"); break; }
+            if (pass == 1 || (pass == 2 && ms < fastest)) fastest = ms;
+        }
+        if (rc != PG_OK) {
+            if (t > 0 && rc == PG_ERR_HIP) {               // out of memory: make do with the candidates so far
+                rc = PG_OK;
+                (void)hipGetLastError();
+                Set failed;
+                take(failed);
+                for (int k = 0; k < 2; ++k) { failed.Vp[k].release(); failed.XV[k].release(); }
+            }
+            break;
+        }
+        take(cand[(size_t)t]);
+        for (int k = 0; t == 0 && k < 2; ++k) set_bytes += (cand[0].Vp[k].cap + cand[0].XV[k].cap) * sizeof(uint32_t);
+        ++tried;
+        if (probe_ms_out) probe_ms_out[t] = fastest;
+        if (best < 0 || fastest < best_ms) { best = t; best_ms = fastest; }
+    }
+    c->time_mask = saved_mask;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream2);
+    if (best >= 0) give(cand[(size_t)best]);
+    for (int t = 0; t < trials; ++t)
+        for (int k = 0; k < 2; ++k) { cand[(size_t)t].Vp[k].release(); cand[(size_t)t].XV[k].release(); }
+    for (int k = 0; k < 2; ++k) c->slot[k].used = false;      // (everything was waited for above)
+    if (rc != PG_OK) return rc;
+    if (n_trials_out) *n_trials_out = tried;
+    if (chosen_out) *chosen_out = best;
+    return PG_OK;
+}
+
 extern "C" int pg_pairwise(pg_ctx *c, const int64_t *lo, const int64_t *hi, int n_win, int32_t *D_out, int32_t *C_out) {
     int rc = check_windows(c, lo, hi, n_win);
     if (rc != PG_OK) return rc;

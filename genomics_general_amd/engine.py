@@ -140,6 +140,7 @@ class Engine:
         self.layout = None
         self.n_sites = 0
         self.placement = None
+        self.plane_placement = None
         self.pinned = PinnedPool()
 
     def close(self):
@@ -189,15 +190,34 @@ class Engine:
         self.placement = (probe ms per candidate, index kept) of the last such reservation."""
         import os
         trials = int(os.environ.get("PG_PLACE_TRIALS", "4"))
+        if int(n_sites) > self.n_sites:
+            self.placement = self.plane_placement = None      # (a growing reservation: new rows, nothing chosen yet)
         if trials > 1:
             ms = (C.c_double * 8)()
             n, k = C.c_int(0), C.c_int(-1)
             check(self._L.pg_reserve_sites_tuned(self._h, int(n_sites), trials, ms, C.byref(n), C.byref(k)))
             if n.value:
                 self.placement = ([round(ms[i], 4) for i in range(n.value)], int(k.value))
+                # ... and, with the rows where they now are, the planes the pack kernel writes (PG_PLANE_TRIALS, default 4, 1 = off)
+                self.tune_planes(n_sites)
         else:
             check(self._L.pg_reserve_sites(self._h, int(n_sites)))
         self.n_sites = max(self.n_sites, int(n_sites))
+
+    def tune_planes(self, n_sites, trials=None, window_sites=50000):
+        """pg_tune_planes: up to `trials` (PG_PLANE_TRIALS, default 4; at most 8) sets of the planes the pack kernel writes, tried
+        on windows of window_sites of the resident rows [0, n_sites), the fastest kept; self.plane_placement = (probe ms per
+        candidate, index kept).  reserve() calls it on the empty rows; a choice made on the loaded rows is worth more
+        (tools/plane_placement.py).  Results do not depend on it."""
+        import os
+        trials = int(os.environ.get("PG_PLANE_TRIALS", "4")) if trials is None else int(trials)
+        if trials < 2:
+            return None
+        ms = (C.c_double * 8)()
+        n, k = C.c_int(0), C.c_int(-1)
+        check(self._L.pg_tune_planes(self._h, int(n_sites), int(window_sites), trials, ms, C.byref(n), C.byref(k)))
+        self.plane_placement = ([round(ms[i], 4) for i in range(n.value)], int(k.value))
+        return self.plane_placement
 
     def upload(self, gt, offset=0):
         gt = np.ascontiguousarray(gt, dtype=np.int8)

@@ -104,6 +104,14 @@ int pg_reserve_sites(pg_ctx *ctx, int64_t n_sites);
  * probe times, *n_trials_out the number of candidates, *chosen_out the index kept.  Smaller reservations, or when memory does not
  * hold two candidates beside the scratch budget: exactly pg_reserve_sites. */
 int pg_reserve_sites_tuned(pg_ctx *ctx, int64_t n_sites, int max_trials, double *probe_ms_out, int *n_trials_out, int *chosen_out);
+/* The same choice for the planes the pack kernel writes (with the rows where they are, its time still moves by up to 4 % with the
+ * pages behind the planes): up to max_trials (<= 8) sets of planes are held together, the regular pack + pair path over windows of
+ * window_sites (<= 0: 50 000) of rows [0, n_sites) of the reservation -- empty or filled, they are only read -- is timed on each, the
+ * fastest set is kept, the others released.  Candidate 0 = the planes the context holds when called.  Outputs as above
+ * (probe_ms_out[max_trials]).  A choice made on the rows as they will be read is worth more than one made on empty rows: call it
+ * once a long-lived data set is loaded.  Results do not depend on it; a later pass that needs larger planes allocates new ones. */
+int pg_tune_planes(pg_ctx *ctx, int64_t n_sites, int64_t window_sites, int max_trials, double *probe_ms_out, int *n_trials_out,
+                   int *chosen_out);
 /* Copy gt[n_sites][n_hap] (tightly packed rows) to sites [site_offset, site_offset+n_sites). */
 int pg_upload_sites(pg_ctx *ctx, int64_t site_offset, const int8_t *gt, int64_t n_sites);
 int pg_download_sites(pg_ctx *ctx, int64_t site_offset, int8_t *gt_out, int64_t n_sites);

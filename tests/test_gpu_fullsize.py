@@ -191,6 +191,9 @@ def test_northstar_shape_windows_match_the_oracle():
     # 40 GB of rows: Engine.reserve went through pg_reserve_sites_tuned (several placements probed while empty, one kept)
     assert e.placement is not None and len(e.placement[0]) >= 2 and 0 <= e.placement[1] < len(e.placement[0]), e.placement
     assert min(e.placement[0]) == e.placement[0][e.placement[1]] > 0
+    # ... and then several sets of the planes the pack kernel writes (pg_tune_planes)
+    pp = e.plane_placement
+    assert pp is not None and len(pp[0]) >= 2 and min(pp[0]) == pp[0][pp[1]] > 0, pp
     lo = np.arange(0, n_sites, WIND, dtype=np.int64)
     hi = lo + WIND
     st = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
@@ -198,6 +201,12 @@ def test_northstar_shape_windows_match_the_oracle():
     again = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
     for k, v in st.items():
         assert v.shape == (2000,) and np.array_equal(v, again[k]) and np.all(np.isfinite(v)), k
+    # the planes chosen once more, now on the filled rows: other memory behind them, the same table
+    pp = e.tune_planes(n_sites, 3)
+    assert len(pp[0]) == 3 and min(pp[0]) == pp[0][pp[1]] > 0, pp
+    again = e.batch(lo, hi).groupDistStats(True, 100, 0.01)
+    for k, v in st.items():
+        assert np.array_equal(v, again[k]), k
     e.close()
 
 
@@ -236,6 +245,7 @@ def test_reservation_without_placement_trials_and_regrowth(monkeypatch):
     e.set_layout(lay)
     e.reserve(300_000_000)
     assert e.placement is None
+    assert e.plane_placement is None
     e.close()
     monkeypatch.delenv("PG_PLACE_TRIALS")
     e = Engine(0)
@@ -243,6 +253,7 @@ def test_reservation_without_placement_trials_and_regrowth(monkeypatch):
     e.reserve(340_000_000)
     first = e.placement
     assert first is not None and len(first[0]) >= 2
+    assert e.plane_placement is not None
     e.reserve(400_000_000)
     assert e.placement is not None and e.placement is not first
     n = 400_000_000

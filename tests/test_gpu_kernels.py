@@ -90,6 +90,25 @@ def test_batch_of_empty_windows_after_a_real_batch_gives_zero_matrices():
     e.close()
 
 
+def test_other_planes_behind_the_pack_kernel_give_the_same_counts():
+    """pg_tune_planes (Engine.tune_planes): several sets of the planes the pack kernel writes are tried on the resident rows and one
+    is kept -- whichever it is, the counts are the ones of the oracle; the call is refused outside the reservation"""
+    e, lay, codes, _ = G.make_engine(12, 3, 130_000, seed=11, miss_thr=9000)
+    lo, hi = [0, 40_000, 90_001], [40_000, 90_001, 130_000]
+    before = e.batch(lo, hi).pairCounts(reference_order=True)
+    for trials in (2, 8, 50):
+        ms, kept = e.tune_planes(130_000, trials)
+        assert len(ms) == min(trials, 8) and 0 <= kept < len(ms) and min(ms) == ms[kept] > 0, (ms, kept)
+        after = e.batch(lo, hi).pairCounts(reference_order=True)
+        assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    assert e.tune_planes(130_000, 1) is None
+    with pytest.raises(Exception, match="inside the reservation"):
+        e.tune_planes(10**9, 2)
+    Do, Co = orc.pair_counts_gemm(oracle_aln(lay, codes, 40_000, 90_001))
+    assert np.array_equal(before[0][1], Do) and np.array_equal(before[1][1], Co)
+    e.close()
+
+
 def test_pairwise_matches_reference_pair_loop_small():
     """the faithful pair-by-pair loop of the reference (not the GEMM shortcut) on a small case"""
     e, lay, codes, _ = G.make_engine(6, 2, 700, seed=5, miss_thr=20000)
