@@ -1,10 +1,12 @@
 #!/usr/bin/env python
 """A rocprofv3 kernel trace of `python bench.py` holds more launches of the pack kernel than the timed steps: reserve()'s placement
-probes (two passes over each candidate allocation, on empty rows) and the warm-up passes come first.  The timed region is the `steps` launches of the dominant kernel that follow the `warmup` ones behind
-the fill of the rows (k_synth); this script
-writes the per-kernel statistics of exactly those passes, next to rocprofv3's own --stats table over all launches.
+probes (passes over each candidate allocation, on empty rows) come first, then k_synth fills the rows, then pg_tune_planes tries its
+sets of planes on the filled rows (three passes a set), then the warm-up passes.  The timed region is the `steps` launches of the
+dominant kernel that follow the `probes` + `warmup` ones behind the fill of the rows; this script writes the per-kernel statistics
+of exactly those passes, next to rocprofv3's own --stats table over all launches.  `probes` = 3 x the number of sets in the bench
+line's placement_trials.planes_probe_ms (0 under PG_PLANE_TRIALS=1): pass the bench line's file and it is read from there.
 
-    python tools/prof_timed_region.py <kernel_trace.csv> <steps> [warmup = 2] [dominant kernel prefix = k_pack3] > summary.csv"""
+    python tools/prof_timed_region.py <kernel_trace.csv> <steps> [warmup = 2] [dominant kernel prefix = k_pack3] [bench line .json | probes = 0] > summary.csv"""
 import csv
 import statistics
 import sys
@@ -18,13 +20,22 @@ def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     dom = sys.argv[4] if len(sys.argv) > 4 else "k_pack3"
+    probes = 0
+    if len(sys.argv) > 5:
+        if sys.argv[5].isdigit():
+            probes = int(sys.argv[5])
+        else:
+            import json
+            line = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])
+            probes = 3 * len((line.get("placement_trials") or {}).get("planes_probe_ms") or [])
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
-    # bench.py's T0 section: reserve() (its probe passes run on empty rows) -> k_synth fills the rows -> `warmup` passes -> `steps`
-    # timed passes -> the other tiers.  So: the dominant kernel's launches behind the first k_synth launch, the first `warmup` of
-    # them dropped, the next `steps` kept.
+    # bench.py's T0 section: reserve() (its probe passes run on empty rows) -> k_synth fills the rows -> `probes` passes of
+    # pg_tune_planes -> `warmup` passes -> `steps` timed passes -> the other tiers.  So: the dominant kernel's launches behind the
+    # first k_synth launch, the first `probes + warmup` of them dropped, the next `steps` kept.
+    warmup += probes
     synth = [i for i, r in enumerate(rows) if r[2].startswith("k_synth")]
     start = synth[0] if synth else 0
     idx = [i for i in range(start, len(rows)) if rows[i][2].startswith(dom)]
