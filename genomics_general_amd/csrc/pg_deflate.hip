@@ -651,13 +651,16 @@ extern "C" int pg_bgzf_compress_device(pg_ctx *c, const uint8_t *text, int64_t l
     HIPCHK(hipMemcpyAsync(D.totals.p, D.h_totals.p, 16, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(D.text.p, text, (size_t)len, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(D.text.p + len, 0, 64, st));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, st));
-    rc = pg_deflate_queue(c, st, D, D.text.p, reinterpret_cast<const long long *>(D.totals.p), len, nullptr,
-                          reinterpret_cast<long long *>(D.totals.p + 1));
-    if (rc == PG_OK) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        return pg_fail(PG_ERR_HIP, "hipEventCreate");
+    }
+    rc = [&]() -> int {                                       // (every early return of HIPCHK passes the events' release below)
+        HIPCHK(hipEventRecord(e0, st));
+        int r = pg_deflate_queue(c, st, D, D.text.p, reinterpret_cast<const long long *>(D.totals.p), len, nullptr,
+                                 reinterpret_cast<long long *>(D.totals.p + 1));
+        if (r != PG_OK) return r;
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipMemcpyAsync(D.h_totals.p + 1, D.totals.p + 1, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -669,8 +672,9 @@ extern "C" int pg_bgzf_compress_device(pg_ctx *c, const uint8_t *text, int64_t l
         if (out && got <= out_cap) {
             HIPCHK(hipMemcpy(out, D.comp.p, (size_t)got, hipMemcpyDeviceToHost));
         } else if (out)
-            rc = pg_fail(PG_ERR_ARG, "pg_bgzf_compress_device: the members take %lld bytes, the output holds %lld", (long long)got, (long long)out_cap);
-    }
+            return pg_fail(PG_ERR_ARG, "pg_bgzf_compress_device: the members take %lld bytes, the output holds %lld", (long long)got, (long long)out_cap);
+        return PG_OK;
+    }();
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
