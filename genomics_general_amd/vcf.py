@@ -291,7 +291,9 @@ def _contig_lists(args):
 def _field_main(args):
     """`--field NAME`: one row per site that passes the site filters (contigs, --minQual, --maxREFlen, --excludeDuplicates), the
     samples' values of FORMAT field NAME (parseVCF.py:371, getGenoField 185-191), `--missing` (default ".") where a sample has
-    none.  Genotype filters, ploidy and indel options play no part, as in the reference."""
+    none.  Genotype filters, ploidy and indel options play no part, as in the reference; --simplifyALT / --expandMulti do, the way
+    they do there: the records' INFO and CIGAR strings are read (and stop the run where they are not what that code expects), and
+    --expandMulti prints a record as one row per base of REF holding one CHARACTER of every value."""
     if args.packed:
         raise SystemExit("parseVCF.py: --field writes text only (no --packed)")
     include, exclude = _contig_lists(args)
@@ -312,6 +314,9 @@ def _field_main(args):
     where = [col_of[s] for s in samples]
     if not args.noHeader:
         out.write(args.outSep.join(["#CHROM", "POS"] + (["REF"] if args.addRefTrack else []) + samples) + "\n")
+    import re
+    split_gt = re.compile("[/|]")
+    simplify = args.simplifyALT or args.expandMulti
     last = None
     for line in inp:
         f = line.split()
@@ -321,7 +326,14 @@ def _field_main(args):
             if (f[0], f[1]) == last:
                 continue
             last = (f[0], f[1])
-        chrom, ref, qual = f[0], f[3], f[5]
+        chrom, pos, ref, qual = f[0], int(f[1]), f[3], f[5]
+        if simplify:
+            # (VcfSite.__init__ reads INFO and rewrites the ALT haplotypes whatever is printed: a record without CIGAR, an INFO flag
+            # without `=` or a malformed CIGAR string ends the run here as it does there)
+            info = dict(x.split("=") for x in f[7].split(";"))
+            cigars = info["CIGAR"].split(",")
+            for k, a in enumerate(f[4].split(",") if f[4] != "." else []):
+                _simplify_alt(a, cigars[k])
         if (exclude and chrom in exclude) or (include and chrom not in include):
             continue
         if args.minQual:
@@ -332,13 +344,32 @@ def _field_main(args):
                 pass
         if args.maxREFlen and len(ref) > args.maxREFlen:
             continue
+        # a sample's FORMAT data as the reference holds them: dict(zip(names, values)) -- of a name that occurs twice the last value
+        # the cell still has --, and next to a GT its "alleles" (a tuple) and "phase" under those names (VcfSite.__init__, 93-96)
         keys = f[8].split(":")
-        k = keys.index(args.field) if args.field in keys else -1
+        occ = [i for i, nm in enumerate(keys) if nm == args.field]
+        gt_occ = [i for i, nm in enumerate(keys) if nm == "GT"] if args.field in ("alleles", "phase") else []
         vals = []
         for c in where:
             parts = f[c].split(":")
-            vals.append(parts[k] if 0 <= k < len(parts) else absent)
-        out.write(args.outSep.join([chrom, str(int(f[1]))] + ([ref] if args.addRefTrack else []) + vals) + "\n")
+            n = min(len(parts), len(keys))
+            v = absent
+            for i in reversed(occ):
+                if i < n:
+                    v = parts[i]
+                    break
+            for i in reversed(gt_occ):
+                if i < n:
+                    v = tuple(split_gt.split(parts[i])) if args.field == "alleles" else "|" if "|" in parts[i] else "/"
+                    break
+            vals.append(v)
+        if args.expandMulti:
+            # (parseVCF.py:380-385 runs for --field as well: row x of a record holds CHARACTER x of every value, and a value shorter
+            # than REF ends the run with an IndexError, as there)
+            for x in range(len(ref)):
+                out.write(args.outSep.join([chrom, str(pos + x)] + ([ref[x]] if args.addRefTrack else []) + [v[x] for v in vals]) + "\n")
+            continue
+        out.write(args.outSep.join([chrom, str(pos)] + ([ref] if args.addRefTrack else []) + vals) + "\n")
     if out is not sys.stdout:
         out.close()
     return 0

@@ -44,6 +44,10 @@ VCF_CASES = [
     ("cigar_expand_filters_subset", "cigar", ["--expandMulti", "--skipIndels", "--keepPartial", "--gtf", "flag=DP", "min=8", "--gtf", "flag=GQ",
                                               "min=30", "siteTypes=SNP", "gtTypes=Het", "-s", "s3,s1,s4", "--exclude", "chr2", "--outSep", " "]),
     ("cigar_simplify_hap", "cigarhap", ["--simplifyALT", "--ploidyFile", "{dir}/hap.ploidy", "--ploidyMismatchToMissing", "--maxREFlen", "3"]),
+    # --field beside --simplifyALT / --expandMulti: the expansion loop (parseVCF.py:380-385) runs over the VALUES, one character a row
+    ("cigar_field_gq_expand", "cigar", ["--field", "GQ", "--expandMulti", "--maxREFlen", "1", "--addRefTrack"]),
+    ("cigar_field_phase_simplify", "cigar", ["--field", "phase", "--simplifyALT", "-s", "s3,s1"]),
+    ("cigar_field_alleles_expand", "cigar", ["--field", "alleles", "--expandMulti", "--maxREFlen", "2", "--outSep", ","]),
 ]
 
 

@@ -435,6 +435,76 @@ def test_irregular_numbers_and_positions_go_to_the_host_or_agree(emul):
             assert rc == 0 and text == want and rows == k, kw
 
 
+_ODD = {
+    "GT second in FORMAT": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tDP:GT\t12:0/1\t7:1/1\n",
+    "GT alone": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT\t0/1\t1/1\n",
+    "a cell shorter than FORMAT": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:AD:DP\t0/1\t1/1:3,4:12\n",
+    "a cell longer than FORMAT": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/1:12:99:x\t1/1:7\n",
+    "phased": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0|1:12\t1|0:17\n",
+    "haploid call": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t1:12\t0/1:17\n",
+    "triploid call": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/1/1:12\t0/1:17\n",
+    "missing calls": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t./.:12\t.|.:17\n",
+    "half missing": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t./1:12\t0/.:17\n",
+    "a lone dot": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t.:12\t.\n",
+    "allele index beyond ALT": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/2:12\t1/1:17\n",
+    "allele index with a leading zero": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/01:12\t1/1:17\n",
+    "twelve alleles": b"chr1\t100\t.\tA\tC,G,T,AA,AC,AG,AT,CA,CC,CG,CT\t50\tPASS\t.\tGT:DP\t10/11:12\t0/9:17\n",
+    "twenty alleles": b"chr1\t100\t.\tA\t" + b",".join(b"A" * k for k in range(2, 21)) + b"\t50\tPASS\t.\tGT:DP\t18/19:12\t0/1:17\n",
+    "no ALT": b"chr1\t100\t.\tA\t.\t50\tPASS\t.\tGT:DP\t0/0:12\t0/0:17\n",
+    "star allele": b"chr1\t100\t.\tA\tC,*\t50\tPASS\t.\tGT:DP\t0/2:12\t1/2:17\n",
+    "symbolic allele": b"chr1\t100\t.\tA\t<DEL>\t50\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\n",
+    "lower case bases": b"chr1\t100\t.\ta\tc\t50\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\n",
+    "an insertion": b"chr1\t100\t.\tA\tACG\t50\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\n",
+    "a deletion": b"chr1\t100\t.\tACG\tA\t50\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\n",
+    "an empty last cell": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/1:12\t\n",
+    "an empty cell": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t\t1/1:17\n",
+    "a column more than the header": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\t0/0:9\n",
+    "a column fewer than the header": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/1:12\n",
+    "no sample columns": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\n",
+    "eight columns": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\n",
+    "a tab at the end": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\t\n",
+    "a blank inside a cell": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/1:1 2\t1/1:17\n",
+    "a blank in INFO": b"chr1\t100\t.\tA\tC\t50\tPASS\tA=1 B=2\tGT:DP\t0/1:12\t1/1:17\n",
+    "an empty CHROM": b"\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\n",
+    "an empty POS": b"chr1\t\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\n",
+    "an empty QUAL": b"chr1\t100\t.\tA\tC\t\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\n",
+    "an empty FORMAT": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\t\t0/1:12\t1/1:17\n",
+    "an empty ALT": b"chr1\t100\t.\tA\t\t50\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\n",
+    "a comma at the end of ALT": b"chr1\t100\t.\tA\tC,\t50\tPASS\t.\tGT:DP\t0/1:12\t1/2:17\n",
+    "a colon at the end of FORMAT": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP:\t0/1:12:\t1/1:17\n",
+    "FORMAT names that start alike": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DPX:DP\t0/1:1:12\t1/1:99:3\n",
+    "a separator of its own in GT": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\t0-1:12\t1/1:17\n",
+    "a letter as allele index": b"chr1\t100\t.\tA\tC\t50\tPASS\t.\tGT:DP\tx/1:12\t1/1:17\n",
+    "a high byte": b"chr1\t100\t.\tA\tC\t50\tPASS\t\xc3\xa9\tGT:DP\t0/1:12\t1/1:17\n",
+    "a NUL byte": b"chr1\t100\t.\tA\tC\t50\tPASS\t\x00\tGT:DP\t0/1:12\t1/1:17\n",
+}
+_ODD_ARGV = [[], ["--skipIndels"], ["--ploidyMismatchToMissing", "--keepPartial"], ["--gtf", "flag=DP", "min=10", "--ploidyMismatchToMissing"],
+             ["--addRefTrack", "--excludeDuplicates", "--minQual", "30", "--ploidyMismatchToMissing"]]
+
+
+@pytest.mark.parametrize("what", sorted(_ODD))
+def test_odd_lines_agree_with_the_host_parser_or_go_to_it(emul, what):
+    """lines a real file may hold and the generators do not write: the emulated device path either gives the host parser's rows or
+    hands the block over -- and it must hand over whatever the host parser stops at"""
+    from genomics_general_amd._lib import PopgenError
+    names = ["a", "b"]
+    plain = b"chr1\t%d\t.\tG\tT\t50\tPASS\t.\tGT:DP\t0/1:12\t1/1:17\n"
+    body = plain % 90 + _ODD[what] + plain % 110
+    for argv in _ODD_ARGV:
+        plan = _plan(argv, names)
+        rc, text, rows, ln, taken = _emul_rows(emul, plan, body)
+        assert taken and rc in (0, 1), (what, argv)
+        try:
+            want, k = _host_rows(plan, body)
+        except (PopgenError, ValueError, AssertionError):
+            assert rc == 1 and ln == 1, (what, argv, rc, ln)
+            continue
+        if rc == 0:
+            assert text == want and rows == k, (what, argv, text, want)
+        else:
+            assert ln == 1, (what, argv, ln)
+
+
 def test_duplicates_across_blocks_and_comment_lines(emul):
     """--excludeDuplicates: a line is held against the DATA line before it -- over '#' lines and empty lines in between, and over the
     seam of two blocks (the key the device carries); block by block the emulated device path == the host parser"""
