@@ -69,6 +69,25 @@ def _lines(path):
         return [ln.rstrip() for ln in f.readlines()]
 
 
+def _no_line_is_read(args, header_given):
+    """True when no data line of the input lies on a scaffold the contig lists let through (genomics.py:2016) -- then the reference
+    never looks a sample name up.  Text files only (a pipe cannot be read twice); stops at the first line that passes."""
+    import gzip
+    path = getattr(args, "genoFile", None)
+    if not path or str(path).endswith(".pgeno"):
+        return False
+    inc = set(_lines(args.include)) if getattr(args, "include", None) else None
+    exc = set(_lines(args.exclude)) if getattr(args, "exclude", None) else None
+    with (gzip.open(path, "rt") if str(path).endswith(".gz") else open(path, "rt")) as f:
+        if not header_given:
+            f.readline()
+        for line in f:
+            tok = line.split(None, 1)
+            if tok and ((not inc and not exc) or (inc and tok[0] in inc) or (exc and tok[0] not in exc)):
+                return False
+    return True
+
+
 class _BgzfTextOut:
     """`-o out.csv.gz` (popgenWindows.py:316, freq.py: "If you add `.gz` it will be gzipped"): the reference's gzip.open(path, "wt") is
     Python's gzip module at level 9 on the calling thread -- about 10 MB/s, seconds for the per-site table of freq.py behind a run of
@@ -242,7 +261,17 @@ class Run:
             # one gzip stream has no independent pieces: it is inflated serially (~ 0.4 GB/s of text), whatever the GPU does
             sys.stderr.write("note: %s is a single gzip stream and is inflated serially; written by `bgzip` (or tools/bgzip.py) the same "
                              "text is inflated on the GPU, about a hundred times faster\n" % args.genoFile)
-        self.layout = HapLayout(sampleData, names, args.genoFormat)
+        try:
+            self.layout = HapLayout(sampleData, names, args.genoFormat)
+        except KeyError:
+            # Names that are not in the header.  The reference looks a name up in the lines it adds to a window and nowhere else
+            # (genomics.py:1993), so a run whose contig lists leave no line of the file ends there with the header row and nothing
+            # else; any other run stops at its first line.  Same here: no line will be read, under columns made up for the purpose.
+            if not _no_line_is_read(args, header_line is not None):
+                raise
+            wanted = list(dict.fromkeys(sampleData.indNames))
+            names = wanted + ["\0column %d" % k for k in range(len(names) - len(wanted))]
+            self.layout = HapLayout(sampleData, names, args.genoFormat)
         self._infer_ploidy = bool(getattr(args, "inferPloidy", False))
         # --inferPloidy on a file whose cell widths change (genoio.PloidySegments): self.layout holds the widest ploidies, the rows
         # are tokenised under it by the host tokenizer (narrower cells leave their other slots missing) and stay on the host;

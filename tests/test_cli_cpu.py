@@ -291,3 +291,32 @@ def test_gz_outputs_are_bgzf_holding_the_plain_output(name, tmp_path, monkeypatc
     assert genoio.BgzfFile.is_bgzf(gz)
     with open(gz, "rb") as f:
         assert f.read().endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+def test_names_missing_from_the_header_matter_only_where_a_line_is_read(tmp_path, monkeypatch):
+    """A headerless file read with --header and without -p / --samples: the reference takes the sample names from the file's FIRST
+    DATA LINE (popgenWindows.py:284-286) and looks them up in the lines it adds to a window (genomics.py:1993) -- a KeyError at the
+    first such line, and a header row and nothing else when the contig lists leave no line (its output for this file, run here:
+    the expected text below; tools/diff_reference_fuzz.py 300 808, case 69)"""
+    import random
+    monkeypatch.setattr(cli, "Engine", CpuEngine)
+    rnd = random.Random(1)
+    geno = tmp_path / "f.geno"
+    with open(geno, "w") as f:
+        for p in range(1, 400):
+            f.write("scaffold_1\t%d\t%s\n" % (p, "\t".join(rnd.choice(["A/A", "A/T", "T/T", "N/N", "G/G"]) for _ in range(3))))
+    (tmp_path / "other.scafs").write_text("other\n")
+    (tmp_path / "s1.scafs").write_text("scaffold_1\n")
+    argv = ["-g", str(geno), "-f", "phased", "-w", "100", "-m", "10", "--writeFailedWindows", "--header", "#CHROM\tPOS\ts0\ts1\ts2",
+            "--analysis", "popDist", "indPairDist", "indHet", "--roundTo", "2"]
+    out = str(tmp_path / "o.csv")
+    assert cli.popgen_main.__wrapped__(argv + ["--include", str(tmp_path / "other.scafs"), "-o", out]) in (0, None)
+    with open(out) as f:
+        got = f.read().rstrip("\n").split(",")
+    want = ("scaffold,start,end,mid,sites,pi_all,d_A/A_A/A,d_A/A_A/T,d_A/A_G/G,d_A/T_A/T,d_A/T_G/G,d_G/G_G/G,"
+            "het_A/T,het_G/G,het_A/A").split(",")
+    assert got[:12] == want[:12] and sorted(got[12:]) == sorted(want[12:])                  # (het_*: hash order in the reference)
+    with pytest.raises(KeyError, match="not in the genotype file header"):
+        cli.popgen_main.__wrapped__(argv + ["--include", str(tmp_path / "s1.scafs"), "-o", str(tmp_path / "o2.csv")])
+    with pytest.raises(KeyError, match="not in the genotype file header"):
+        cli.popgen_main.__wrapped__(argv + ["-o", str(tmp_path / "o3.csv")])
