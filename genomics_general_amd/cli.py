@@ -1249,9 +1249,9 @@ def popgen_main(argv=None):
         popInds.append(list(allInds))
     ploidyDict = _ploidy_dict(args, allInds, args.haploid.split(",") if args.haploid else None)
     sampleData = SampleData(indNames=list(allInds), popNames=popNames, popInds=popInds, ploidyDict=ploidyDict)
-    if pop_analysis:
-        nopop = [i for i in sampleData.indNames if sampleData.getPop(i) is None]
-        assert not nopop, "samples without a population cannot be mixed with population statistics: " + ",".join(nopop[:5])
+    # (the reference trips over such a sample -- a TypeError, or a hang -- in the first window it computes statistics for, not before:
+    # a run all of whose windows fail --minSites writes its rows of nan; the assertion waits for the first good window too)
+    nopop = [i for i in sampleData.indNames if sampleData.getPop(i) is None] if pop_analysis else []
 
     # statistics, in output order (popgenWindows.py:326-354)
     stats = []
@@ -1291,6 +1291,7 @@ def popgen_main(argv=None):
         table = np.full((run.w1 - run.w0, len(stats)), np.nan)
         t_c = time.perf_counter()
         if np.any(good) and stats:
+            assert not nopop, "samples without a population cannot be mixed with population statistics: " + ",".join(nopop[:5])
             wb = run.batch(good)
             sd = {}
             if "popFreq" in args.analysis:

@@ -320,3 +320,27 @@ def test_names_missing_from_the_header_matter_only_where_a_line_is_read(tmp_path
         cli.popgen_main.__wrapped__(argv + ["--include", str(tmp_path / "s1.scafs"), "-o", str(tmp_path / "o2.csv")])
     with pytest.raises(KeyError, match="not in the genotype file header"):
         cli.popgen_main.__wrapped__(argv + ["-o", str(tmp_path / "o3.csv")])
+
+
+def test_a_sample_without_a_population_matters_only_in_a_window_that_is_computed(tmp_path, monkeypatch):
+    """--samples naming an individual of no population beside population statistics: the reference fails in the first window it
+    computes statistics for (a TypeError or a hang, genomics.py) and not before -- a run all of whose windows fail --minSites writes
+    its rows of nan (tools/diff_reference_fuzz.py 300 909, cases 173 and 200: `-m 0` means the window size)"""
+    import random
+    monkeypatch.setattr(cli, "Engine", CpuEngine)
+    rnd = random.Random(2)
+    geno = tmp_path / "f.geno"
+    with open(geno, "w") as f:
+        f.write("#CHROM\tPOS\ts0\ts1\ts2\ts3\n")
+        for p in range(1, 300, 2):
+            f.write("chr1\t%d\t%s\n" % (p, "\t".join(rnd.choice(["A/A", "A/T", "T/T", "N/N"]) for _ in range(4))))
+    argv = ["-g", str(geno), "-f", "phased", "-w", "100", "--writeFailedWindows", "--analysis", "popDist", "popPairDist", "-p", "A", "s0", "-p", "B", "s1",
+            "--samples", "s0,s3,s1"]
+    out = str(tmp_path / "o.csv")
+    assert cli.popgen_main.__wrapped__(argv + ["-m", "0", "-o", out]) in (0, None)          # minSites = 100 > the 50 sites of a window
+    with open(out) as f:
+        rows = f.read().splitlines()
+    assert rows[0] == "scaffold,start,end,mid,sites,pi_A,pi_B,dxy_A_B,Fst_A_B" and rows[1:] == [
+        "chr1,1,100,50,50,nan,nan,nan,nan", "chr1,101,200,150,50,nan,nan,nan,nan", "chr1,201,300,250,50,nan,nan,nan,nan"], rows
+    with pytest.raises(AssertionError, match="without a population"):
+        cli.popgen_main.__wrapped__(argv + ["-m", "10", "-o", str(tmp_path / "o2.csv")])
