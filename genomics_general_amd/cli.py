@@ -1341,7 +1341,7 @@ def popgen_main(argv=None):
                         if vals[c] == vals[c]:
                             vals[c] = int(vals[c])
                     for c in h2_cols:
-                        if vals[c] == 0:
+                        if full[k, c] == 0:                         # (before rounding: a small H2 that ROUNDS to zero prints "0.0")
                             vals[c] = 0
                     text = ",".join(map(str, head + vals)) + "\n"
                 last_row = (ok, text)

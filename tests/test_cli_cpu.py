@@ -344,3 +344,28 @@ def test_a_sample_without_a_population_matters_only_in_a_window_that_is_computed
         "chr1,1,100,50,50,nan,nan,nan,nan", "chr1,101,200,150,50,nan,nan,nan,nan", "chr1,201,300,250,50,nan,nan,nan,nan"], rows
     with pytest.raises(AssertionError, match="without a population"):
         cli.popgen_main.__wrapped__(argv + ["-m", "10", "-o", str(tmp_path / "o2.csv")])
+
+
+def test_h2_that_rounds_to_zero_is_a_float_and_h2_of_one_cluster_an_integer(tmp_path, monkeypatch):
+    """H12stats answers the integer `H2 = 0` for a population that is one cluster (genomics.py:1092-1093: printed "0") and a sum of
+    squares otherwise -- which may ROUND to zero and is then printed "0.0" (clusters of 22, 1 and 1 haplotypes at --roundTo 2; the
+    expected text is the reference's output for this file; tools/diff_reference_fuzz.py 300 1010, cases 89 and 106)"""
+    monkeypatch.setattr(cli, "Engine", CpuEngine)
+    geno = tmp_path / "f.geno"
+    with open(geno, "w") as f:
+        f.write("#CHROM\tPOS\t" + "\t".join("h%d" % k for k in range(24)) + "\n")
+        for p in range(1, 41):
+            row = ["A"] * 24
+            if p == 5:
+                row[22] = "T"
+            if p == 9:
+                row[23] = "T"
+            f.write("chr1\t%d\t%s\n" % (p, "\t".join(row)))
+        for p in range(101, 141):
+            f.write("chr1\t%d\t%s\n" % (p, "\t".join(["C"] * 24)))
+    out = str(tmp_path / "o.csv")
+    cli.popgen_main.__wrapped__(["-g", str(geno), "-f", "haplo", "-w", "100", "-m", "10", "--analysis", "hapStats", "--roundTo", "2", "-o", out])
+    with open(out) as f:
+        assert f.read() == ("scaffold,start,end,mid,sites,H1_all,H12_all,H2_all\n"
+                            "chr1,1,100,20,40,0.84,0.92,0.0\n"
+                            "chr1,101,200,120,40,1.0,1.0,0\n")
